@@ -1,0 +1,132 @@
+/*
+ * psgd_hip.h -- C ABI of the MI355X (gfx950) PSGD preconditioner engine.
+ *
+ * This is the drop-in boundary for the hot path of the reference module
+ * preconditioned_stochastic_gradient_descent.py ("psgd.py" below).  The
+ * reference has no FFI of its own (it is pure Python on TensorFlow), so each
+ * entry point cites the reference *function* (file:line) whose arithmetic it
+ * replaces.  The Python module of the same name in this repository binds these
+ * symbols through ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Every data pointer is a DEVICE pointer (HBM) unless marked [host].
+ *   - Matrices are row-major fp32.  U, V are [N, r] contiguous (leading
+ *     dimension r), vectors are [N] (the reference's [N,1] columns).
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on
+ *     it and performs no host synchronisation and no allocation.
+ *   - Return value: PSGD_OK (0) or a negative PSGD_ERR_* code.  Nothing is
+ *     written when an argument check fails.
+ *   - `ws` is a caller-owned device workspace of at least
+ *     psgd_uvd_workspace_bytes(N, r) bytes, 256-byte aligned.  Its contents
+ *     carry the small reduced vectors between the stages of one call.
+ *
+ * Multi-GPU (row-sharded flat parameter vector, one process per GPU): call the
+ * *_sweepK stage functions on the local shard and all-reduce the region that
+ * psgd_uvd_ws_region() reports between stages (SUM on the fp64 sums, MAX on
+ * the fp32 max buffer); pass sums_reduced=1 to the following stage.
+ */
+#ifndef PSGD_HIP_H
+#define PSGD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSGD_ABI_VERSION 1
+
+#define PSGD_OK                 0
+#define PSGD_ERR_BAD_ARG       (-1)   /* null pointer, N <= 0, r <= 0 ...            */
+#define PSGD_ERR_RANK          (-2)   /* rank r outside [1, PSGD_UVD_MAX_RANK]       */
+#define PSGD_ERR_WORKSPACE     (-3)   /* workspace missing, too small or misaligned  */
+#define PSGD_ERR_ALIGN         (-4)   /* a matrix pointer is not 16-byte aligned     */
+#define PSGD_ERR_LAUNCH        (-5)   /* HIP reported a launch error                 */
+#define PSGD_ERR_SHAPE         (-6)   /* Kron: shapes inconsistent / unsupported     */
+
+#define PSGD_UVD_MAX_RANK 32
+
+/* workspace regions that the multi-GPU driver must all-reduce between stages */
+#define PSGD_WS_SUMS_F64   0   /* double[len]: SUM over ranks  */
+#define PSGD_WS_MAX_F32    1   /* float[len]:  MAX over ranks  */
+
+int         psgd_abi_version(void);
+const char *psgd_error_string(int code);
+
+/* ------------------------------------------------------------------ UVd ---
+ * Q = (I + U V') diag(d), preconditioner P = Q'Q  (psgd.py:527-627).        */
+
+/* Bytes of device workspace needed for a shard of N rows at rank r
+ * (includes the N-float temporary for nablaD, psgd.py:581). <0 on error.   */
+int64_t psgd_uvd_workspace_bytes(int64_t N, int r);
+
+/* Byte offset (into ws) and element count of a region to all-reduce.
+ * `which` = PSGD_WS_SUMS_F64 / PSGD_WS_MAX_F32; `stage` selects what the next
+ * stage consumes: apply: 1 (after sweep1: r sums), 2 (after sweep2: r sums);
+ * update: 10 (balance maxima: 2 floats), 11 (after sweep1: Gram sums),
+ * 12 (after sweep2: 1 float max).  Returns 0 or an error code.             */
+int psgd_uvd_ws_region(int which, int stage, int64_t N, int r,
+                       int64_t *offset_bytes, int64_t *count);
+
+/* precond_grad_UVd_math(U, V, d, g)   psgd.py:619-627 (IpUVtmatvec :540-544)
+ *   out = d .* (I + V U') (I + U V') (d .* g)
+ * Three streaming sweeps (the second reduction depends on the first):
+ *   sweep1: s1 = V'(d.*g)            reads V,d,g
+ *   sweep2: s2 = U'(d.*g + U s1)     reads U,d,g
+ *   sweep3: out = d.*(g1 + V s2), g1 = d.*g + U s1   reads U,V,d,g writes out
+ * `out` must not alias any input.                                          */
+int psgd_uvd_apply_f32(const float *U, const float *V, const float *d,
+                       const float *g, float *out, int64_t N, int r,
+                       void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_apply_sweep1_f32(const float *V, const float *d, const float *g,
+                              int64_t N, int r, void *ws, int64_t ws_bytes,
+                              void *stream);
+int psgd_uvd_apply_sweep2_f32(const float *U, const float *d, const float *g,
+                              int64_t N, int r, int sums_reduced,
+                              void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_apply_sweep3_f32(const float *U, const float *V, const float *d,
+                              const float *g, float *out, int64_t N, int r,
+                              int sums_reduced, void *ws, int64_t ws_bytes,
+                              void *stream);
+
+/* update_precond_UVd_math_(U, V, d, v, h, step, tiny)   psgd.py:554-617
+ * Mutates U or V (branch update_U, psgd.py:588) and d in place.
+ *   balance  : the branch of psgd.py:562-567 (rescale U/rho, rho*V)
+ *   update_U : 1 -> psgd.py:589-601, 0 -> psgd.py:603-615
+ * Stages: [balance_max, balance_scale]  sweep1 (Gram of [U V t w])
+ *         sweep2 (r x r solves, row-local update of U or V, nablaD, max)
+ *         sweep3 (d <- d - mu d nablaD).                                    */
+int psgd_uvd_update_f32(float *U, float *V, float *d, const float *v,
+                        const float *h, int64_t N, int r, float step,
+                        float tiny, int balance, int update_U,
+                        void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_balance_max_f32(const float *U, const float *V, int64_t N, int r,
+                             void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_balance_scale_f32(float *U, float *V, int64_t N, int r,
+                               void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_update_sweep1_f32(const float *U, const float *V, const float *d,
+                               const float *v, const float *h, int64_t N,
+                               int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_update_sweep2_f32(float *U, float *V, const float *d,
+                               const float *v, const float *h, int64_t N,
+                               int r, float step, float tiny, int update_U,
+                               void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_update_sweep3_f32(float *d, int64_t N, int r, float step,
+                               float tiny, void *ws, int64_t ws_bytes,
+                               void *stream);
+
+/* IpUVtmatvec(U, V, x)   psgd.py:540-544:  out = x + U (V' x), x is [N].   */
+int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,
+                              float *out, int64_t N, int r,
+                              void *ws, int64_t ws_bytes, void *stream);
+
+/* Tuning knobs for experiments (not part of the stable ABI).
+ * key 0: staging path (0 = register staging, 1 = LDS-DMA).
+ * key 1: cap on blocks per CU for the sweeps (0 = occupancy query).        */
+int psgd_set_tuning(int key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSGD_HIP_H */

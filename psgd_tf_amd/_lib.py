@@ -1,0 +1,110 @@
+"""ctypes binding of libpsgd_hip.so (the C ABI declared in include/psgd_hip.h).
+
+The library is built in-tree by ``build_extension()`` (hipcc, --offload-arch=gfx950)
+and loaded lazily.  There is no fallback: if the shared object is missing or a
+call returns an error code, a PsgdHipError is raised.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libpsgd_hip.so")
+
+PSGD_OK = 0
+PSGD_WS_SUMS_F64 = 0
+PSGD_WS_MAX_F32 = 1
+UVD_MAX_RANK = 32
+
+
+class PsgdHipError(RuntimeError):
+    pass
+
+
+_c_f32p = ctypes.c_void_p   # device pointers travel as integers
+_c_ws = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_flt = ctypes.c_float
+_strm = ctypes.c_void_p
+
+# name -> (restype, argtypes); kept in one table so that tests can check that every
+# symbol declared in include/psgd_hip.h is bound and exported.
+SIGNATURES = {
+    "psgd_abi_version": (_int, []),
+    "psgd_error_string": (ctypes.c_char_p, [_int]),
+    "psgd_set_tuning": (_int, [_int, _int]),
+    "psgd_uvd_workspace_bytes": (_i64, [_i64, _int]),
+    "psgd_uvd_ws_region": (_int, [_int, _int, _i64, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "psgd_uvd_apply_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_apply_sweep1_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_apply_sweep2_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_apply_sweep3_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _c_ws,
+                                         _i64, _strm]),
+    "psgd_uvd_update_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _flt, _flt, _int, _int,
+                                   _c_ws, _i64, _strm]),
+    "psgd_uvd_balance_max_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_balance_scale_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_update_sweep1_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64,
+                                          _strm]),
+    "psgd_uvd_update_sweep2_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _flt, _flt, _int,
+                                          _c_ws, _i64, _strm]),
+    "psgd_uvd_update_sweep3_f32": (_int, [_c_f32p, _i64, _int, _flt, _flt, _c_ws, _i64, _strm]),
+    "psgd_uvd_ipuvt_matvec_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build_extension(force=False, jobs=None, verbose=False):
+    """Compile libpsgd_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    cmd = ["make", "-C", _CSRC, "-j%d" % jobs]
+    if force:
+        subprocess.run(["make", "-C", _CSRC, "clean"], check=True, capture_output=not verbose)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise PsgdHipError("building libpsgd_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def load():
+    """Return the loaded ctypes library, loading (never building) it on first use."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PsgdHipError(
+                "HIP extension %s is missing; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C psgd_tf_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        # torch ships its own libamdhip64.so (same SONAME); import it first so that the
+        # extension binds to the HIP runtime that owns torch's device memory and streams.
+        import torch  # noqa: F401
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.psgd_abi_version() != 1:
+            raise PsgdHipError("libpsgd_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != PSGD_OK:
+        msg = load().psgd_error_string(int(code)).decode()
+        raise PsgdHipError("%s failed: %s (code %d)" % (what, msg, code))
+
+
+def ws_region(which, stage, N, r):
+    off, cnt = _i64(0), _i64(0)
+    check(load().psgd_uvd_ws_region(which, stage, N, r, ctypes.byref(off), ctypes.byref(cnt)), "psgd_uvd_ws_region")
+    return off.value, cnt.value

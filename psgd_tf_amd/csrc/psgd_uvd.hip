@@ -1,0 +1,646 @@
+// psgd_uvd.hip -- C ABI (include/psgd_hip.h) of the UVd preconditioner path
+// plus the rank-independent kernels: partial-row reductions, the r x r algebra
+// of update_precond_UVd_math_ (psgd.py:574-615) in fp64, the d update
+// (psgd.py:582-584) and the U/V balancing branch (psgd.py:562-567).
+#include "uvd_kernels.h"
+#include "psgd_hip.h"
+#include <math.h>
+
+namespace psgd {
+
+const UvdOps* uvd_ops_group0(int r);
+const UvdOps* uvd_ops_group1(int r);
+const UvdOps* uvd_ops_group2(int r);
+const UvdOps* uvd_ops_group3(int r);
+
+const UvdOps* uvd_ops_for_rank(int r) {
+  if (r < 1 || r > PSGD_UVD_MAX_RANK) return nullptr;
+  switch ((r - 1) / 8) {
+    case 0: return uvd_ops_group0(r);
+    case 1: return uvd_ops_group1(r);
+    case 2: return uvd_ops_group2(r);
+    default: return uvd_ops_group3(r);
+  }
+}
+
+// ------------------------------------------------------------ workspace ----
+constexpr int64_t kSumsCap = 4096;   // doubles (Gram of r = 32 needs 3840)
+constexpr int64_t kCoefCap = 256;    // floats
+constexpr int64_t kMaxCap = 64;      // floats
+
+struct WsLayout {
+  int64_t sums_off, coef_off, max_off, part_off, part_bytes, pmax_off, nabla_off, total;
+};
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
+
+static WsLayout ws_layout(int64_t N, int r) {
+  WsLayout L;
+  const int nc = 2 * r + 2, nb = (nc + 15) / 16, np = nb * (nb + 1) / 2;
+  int64_t off = 0;
+  L.sums_off = off; off = align256(off + kSumsCap * 8);
+  L.coef_off = off; off = align256(off + kCoefCap * 4);
+  L.max_off = off;  off = align256(off + kMaxCap * 4);
+  const int64_t part_f32 = (int64_t)kMaxGrid * PSGD_UVD_MAX_RANK * 4;
+  const int64_t part_f64 = (int64_t)kGramMaxGrid * np * 256 * 8;
+  L.part_bytes = part_f32 > part_f64 ? part_f32 : part_f64;
+  L.part_off = off; off = align256(off + L.part_bytes);
+  L.pmax_off = off; off = align256(off + 2 * (int64_t)kMaxGrid * 4);
+  L.nabla_off = off; off = align256(off + N * 4);
+  L.total = off;
+  return L;
+}
+
+struct Ws {
+  double* sums; float* coef; float* maxbuf; void* part; float* pmax; float* nabla;
+};
+
+static int ws_open(void* ws, int64_t ws_bytes, int64_t N, int r, Ws* out) {
+  if (N <= 0) return PSGD_ERR_BAD_ARG;
+  if (r < 1 || r > PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return PSGD_ERR_WORKSPACE;
+  const WsLayout L = ws_layout(N, r);
+  if (ws_bytes < L.total) return PSGD_ERR_WORKSPACE;
+  char* b = static_cast<char*>(ws);
+  out->sums = reinterpret_cast<double*>(b + L.sums_off);
+  out->coef = reinterpret_cast<float*>(b + L.coef_off);
+  out->maxbuf = reinterpret_cast<float*>(b + L.max_off);
+  out->part = b + L.part_off;
+  out->pmax = reinterpret_cast<float*>(b + L.pmax_off);
+  out->nabla = reinterpret_cast<float*>(b + L.nabla_off);
+  return PSGD_OK;
+}
+
+static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+// ------------------------------------------------------------ device info --
+static int g_tune_staging = 0;
+static int g_tune_blocks_per_cu = 0;
+
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
+
+static int sweep_grid(const UvdOps* ops, int r, int which, int64_t N, int hard_cap) {
+  static int occ_cache[PSGD_UVD_MAX_RANK + 1][8];
+  int occ = occ_cache[r][which];
+  if (occ == 0) {
+    occ = ops->occupancy(which);
+    if (occ <= 0) occ = 1;
+    occ_cache[r][which] = occ;
+  }
+  if (g_tune_blocks_per_cu > 0 && g_tune_blocks_per_cu < occ) occ = g_tune_blocks_per_cu;
+  const int64_t tiles = (N + ops->tile_rows - 1) / ops->tile_rows;
+  int64_t grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t cap = (int64_t)num_cus() * occ;
+  if (grid > cap) grid = cap;
+  if (grid > hard_cap) grid = hard_cap;
+  if (grid < 1) grid = 1;
+  return (int)grid;
+}
+
+// ---------------------------------------------------------- small kernels --
+// sums[id] = sum_b part[b][id] in fp64, fixed order.  One lane per element id,
+// the four waves of a block take interleaved slices of the G partial rows.
+template <class T>
+__global__ __launch_bounds__(kThreads) void k_reduce_sum(const T* __restrict__ part, int G, int L,
+                                                         double* __restrict__ sums, float* __restrict__ coef) {
+  __shared__ double red[kWavesPerBlock][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int id = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (id < L)
+    for (int b = w; b < G; b += kWavesPerBlock) s += (double)part[(long)b * L + id];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && id < L) {
+    const double t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    sums[id] = t;
+    if (coef) coef[id] = (float)t;
+  }
+}
+
+// out[set] = max_b part[set*stride + b]
+__global__ __launch_bounds__(kThreads) void k_reduce_max(const float* __restrict__ part, int G, int stride,
+                                                         float* __restrict__ out) {
+  __shared__ float red[kWavesPerBlock];
+  const float* p = part + (long)blockIdx.x * stride;
+  float v = 0.0f;
+  for (int b = threadIdx.x; b < G; b += kThreads) v = fmaxf(v, p[b]);
+  block_max_store(v, red, out + blockIdx.x);
+}
+
+__global__ void k_publish(const double* __restrict__ sums, float* __restrict__ coef, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) coef[i] = (float)sums[i];
+}
+
+// d <- d - (mu d) nablaD, mu = step / (max|nablaD| + tiny)      psgd.py:582-584
+__global__ __launch_bounds__(kThreads) void k_update_d(float* d, const float* __restrict__ nabla, long N,
+                                                       const float* __restrict__ maxbuf, float step, float tiny) {
+  const float mu = step / (maxbuf[0] + tiny);
+  const long n4 = N / 4;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nth = (long)gridDim.x * blockDim.x;
+  float4* d4 = reinterpret_cast<float4*>(d);
+  const float4* n4p = reinterpret_cast<const float4*>(nabla);
+  for (long i = tid; i < n4; i += nth) {
+    float4 a = d4[i];
+    const float4 b = n4p[i];
+    a.x = a.x - (mu * a.x) * b.x;
+    a.y = a.y - (mu * a.y) * b.y;
+    a.z = a.z - (mu * a.z) * b.z;
+    a.w = a.w - (mu * a.w) * b.w;
+    d4[i] = a;
+  }
+  for (long i = n4 * 4 + tid; i < N; i += nth) d[i] = d[i] - (mu * d[i]) * nabla[i];
+}
+
+// max|U|, max|V| over the flat [N*r] arrays                       psgd.py:563-564
+__global__ __launch_bounds__(kThreads) void k_maxabs2(const float* __restrict__ U, const float* __restrict__ V,
+                                                      long n, float* part, int G) {
+  __shared__ float red[2][kWavesPerBlock];
+  const long n4 = n / 4;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nth = (long)gridDim.x * blockDim.x;
+  float mu = 0.0f, mv = 0.0f;
+  const float4* U4 = reinterpret_cast<const float4*>(U);
+  const float4* V4 = reinterpret_cast<const float4*>(V);
+  for (long i = tid; i < n4; i += nth) {
+    const float4 a = U4[i], b = V4[i];
+    mu = fmaxf(mu, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    mv = fmaxf(mv, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+  }
+  for (long i = n4 * 4 + tid; i < n; i += nth) {
+    mu = fmaxf(mu, fabsf(U[i]));
+    mv = fmaxf(mv, fabsf(V[i]));
+  }
+  block_max_store(mu, red[0], part + blockIdx.x);
+  __syncthreads();
+  block_max_store(mv, red[1], part + G + blockIdx.x);
+}
+
+// U <- U / rho, V <- rho V, rho = sqrt(max|U| / max|V|)            psgd.py:565-567
+__global__ __launch_bounds__(kThreads) void k_scale2(float* U, float* V, long n, const float* __restrict__ maxbuf) {
+  const float rho = sqrtf(maxbuf[0] / maxbuf[1]);
+  const long n4 = n / 4;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nth = (long)gridDim.x * blockDim.x;
+  float4* U4 = reinterpret_cast<float4*>(U);
+  float4* V4 = reinterpret_cast<float4*>(V);
+  for (long i = tid; i < n4; i += nth) {
+    float4 a = U4[i], b = V4[i];
+    a.x /= rho; a.y /= rho; a.z /= rho; a.w /= rho;
+    b.x *= rho; b.y *= rho; b.z *= rho; b.w *= rho;
+    U4[i] = a;
+    V4[i] = b;
+  }
+  for (long i = n4 * 4 + tid; i < n; i += nth) {
+    U[i] = U[i] / rho;
+    V[i] = rho * V[i];
+  }
+}
+
+// ------------------------------------------------- r x r algebra (fp64) ----
+constexpr int MR = PSGD_UVD_MAX_RANK;
+
+// Gaussian elimination with partial pivoting on one wave (lane = row); the
+// first maximal |entry| is the pivot, like LAPACK's idamax behind tf.linalg.solve.
+__device__ void lu_solve(double (*M)[MR + 1], double* rhs, double* x, int r, int lane) {
+  for (int k = 0; k < r; ++k) {
+    double val = (lane >= k && lane < r) ? fabs(M[lane][k]) : -1.0;
+    int idx = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_down(val, off, 64);
+      const int oi = __shfl_down(idx, off, 64);
+      if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+    }
+    const int piv = __shfl(idx, 0, 64);
+    if (piv != k) {
+      if (lane < r) { const double t = M[k][lane]; M[k][lane] = M[piv][lane]; M[piv][lane] = t; }
+      if (lane == 0) { const double t = rhs[k]; rhs[k] = rhs[piv]; rhs[piv] = t; }
+    }
+    __syncthreads();
+    const double pv = M[k][k];
+    if (lane > k && lane < r) {
+      const double f = M[lane][k] / pv;
+      for (int j = k + 1; j < r; ++j) M[lane][j] -= f * M[k][j];
+      rhs[lane] -= f * rhs[k];
+    }
+    __syncthreads();
+  }
+  for (int i = r - 1; i >= 0; --i) {
+    const double xi = rhs[i] / M[i][i];
+    if (lane == 0) x[i] = xi;
+    if (lane < i) rhs[lane] -= M[lane][i] * xi;
+    __syncthreads();
+  }
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+
+// One wave.  Reads the reduced Gram of W = [U | V | t | w] (MFMA block layout
+// of k_update_gram) and produces the coefficient block of UpdCoef.
+__global__ __launch_bounds__(64) void k_update_coef(const double* __restrict__ gram, int r, float step, float tiny,
+                                                    int update_U, float* __restrict__ coef) {
+  __shared__ double A[MR][MR + 1];    // U'U
+  __shared__ double B[MR][MR + 1];    // V'V
+  __shared__ double Cm[MR][MR + 1];   // V'U  (psgd.py:574)
+  __shared__ double M[MR][MR + 1];    // elimination scratch
+  __shared__ double ut[MR], uw[MR], vt[MR], vw[MR], s1[MR], s2[MR], x1[MR], x2[MR], p2[MR], cs1[MR], rhs[MR];
+  __shared__ double e1[MR], e2[MR], f1[MR], f2[MR];
+  const int lane = threadIdx.x;
+  const int nb = (2 * r + 2 + 15) / 16;
+  auto G = [&](int a, int b) -> double {
+    if (a > b) { const int t = a; a = b; b = t; }
+    const int bi = a >> 4, bj = b >> 4, i = a & 15, j = b & 15;
+    const int p = bi * nb - (bi * (bi - 1)) / 2 + (bj - bi);
+    return gram[p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j)];
+  };
+  for (int idx = lane; idx < r * r; idx += 64) {
+    const int i = idx / r, j = idx % r;
+    A[i][j] = G(i, j);
+    B[i][j] = G(r + i, r + j);
+    Cm[i][j] = G(j, r + i);
+  }
+  if (lane < r) {
+    ut[lane] = G(lane, 2 * r);
+    uw[lane] = G(lane, 2 * r + 1);
+    vt[lane] = G(r + lane, 2 * r);
+    vw[lane] = G(r + lane, 2 * r + 1);
+  }
+  const double tt = G(2 * r, 2 * r), tw = G(2 * r, 2 * r + 1), ww = G(2 * r + 1, 2 * r + 1);
+  __syncthreads();
+
+  // s1 = V't ; s2 = U'Qh = U't + (U'U) s1 ; cs1 = (V'U) s1
+  if (lane < r) s1[lane] = vt[lane];
+  __syncthreads();
+  if (lane < r) {
+    double a = ut[lane], c = 0.0;
+    for (int k = 0; k < r; ++k) { a += A[lane][k] * s1[k]; c += Cm[lane][k] * s1[k]; }
+    s2[lane] = a;
+    cs1[lane] = c;
+  }
+  // x1 = solve(K', U'w), K = I + V'U            (psgd.py:575-577, adjoint=True)
+  for (int idx = lane; idx < r * r; idx += 64) {
+    const int i = idx / r, j = idx % r;
+    M[i][j] = Cm[j][i] + (i == j ? 1.0 : 0.0);
+  }
+  if (lane < r) rhs[lane] = uw[lane];
+  __syncthreads();
+  lu_solve(M, rhs, x1, r, lane);
+  __syncthreads();
+  // p2 = V' invQtv = V'w - (V'V) x1 ; x2 = solve(K, p2)          (psgd.py:578)
+  if (lane < r) {
+    double a = vw[lane];
+    for (int k = 0; k < r; ++k) a -= B[lane][k] * x1[k];
+    p2[lane] = a;
+    rhs[lane] = a;
+  }
+  for (int idx = lane; idx < r * r; idx += 64) {
+    const int i = idx / r, j = idx % r;
+    M[i][j] = Cm[i][j] + (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  lu_solve(M, rhs, x2, r, lane);
+  __syncthreads();
+
+  // a = Qh = t + U s1, b = invQtv = w - V x1                      (psgd.py:587)
+  const bool act = lane < r;
+  const double s1ut = wave_sum(act ? s1[lane] * ut[lane] : 0.0);
+  const double s1s2 = wave_sum(act ? s1[lane] * s2[lane] : 0.0);
+  const double x1vw = wave_sum(act ? x1[lane] * vw[lane] : 0.0);
+  const double x1p2 = wave_sum(act ? x1[lane] * p2[lane] : 0.0);
+  const double x1vt = wave_sum(act ? x1[lane] * vt[lane] : 0.0);
+  const double s1uw = wave_sum(act ? s1[lane] * uw[lane] : 0.0);
+  const double x1cs1 = wave_sum(act ? x1[lane] * cs1[lane] : 0.0);
+  const double aa = tt + s1ut + s1s2;          // a'a = t't + 2 s1'U't + s1'(U'U)s1
+  const double bb = ww - x1vw - x1p2;          // b'b = w'w - 2 x1'V'w + x1'(V'V)x1
+  const double ab = tw - x1vt + s1uw - x1cs1;  // a'b
+
+  // e1 = a'M, e2 = b'M with M = V (update U) or U (update V); the norm needs
+  // ||M e1'||^2 = e1 (M'M) e1' etc.                       (psgd.py:589-596 / :603-610)
+  if (act) {
+    if (update_U) {
+      e1[lane] = vt[lane] + cs1[lane];   // atV = V't + (V'U) s1
+      e2[lane] = p2[lane];               // btV = V'w - (V'V) x1
+    } else {
+      double c = uw[lane];
+      for (int k = 0; k < r; ++k) c -= Cm[k][lane] * x1[k];
+      e1[lane] = s2[lane];               // atU = U't + (U'U) s1
+      e2[lane] = c;                      // btU = U'w - (U'V) x1
+    }
+  }
+  __syncthreads();
+  double g1 = 0.0, g2 = 0.0;
+  if (act) {
+    for (int k = 0; k < r; ++k) {
+      const double m = update_U ? B[lane][k] : A[lane][k];
+      g1 += m * e1[k];
+      g2 += m * e2[k];
+    }
+  }
+  const double pp = wave_sum(act ? e1[lane] * g1 : 0.0);
+  const double qq = wave_sum(act ? e2[lane] * g2 : 0.0);
+  const double pq = wave_sum(act ? e1[lane] * g2 : 0.0);
+  const double nrm = sqrt(fabs(aa * pp + bb * qq - 2.0 * ab * pq));
+  const double mu = (double)step / (nrm + (double)tiny);
+  // c1, c2: update U -> (atV K), (btV K) (psgd.py:600-601); update V -> atU, btU (:614-615)
+  if (act) {
+    if (update_U) {
+      double c1 = e1[lane], c2 = e2[lane];   // identity part of K
+      for (int i = 0; i < r; ++i) { c1 += e1[i] * Cm[i][lane]; c2 += e2[i] * Cm[i][lane]; }
+      f1[lane] = c1;
+      f2[lane] = c2;
+    } else {
+      f1[lane] = e1[lane];
+      f2[lane] = e2[lane];
+    }
+    coef[0 * r + lane] = (float)s1[lane];
+    coef[1 * r + lane] = (float)s2[lane];
+    coef[2 * r + lane] = (float)x1[lane];
+    coef[3 * r + lane] = (float)x2[lane];
+    coef[4 * r + lane] = (float)f1[lane];
+    coef[5 * r + lane] = (float)f2[lane];
+  }
+  if (lane == 0) {
+    coef[6 * r] = (float)mu;
+    coef[6 * r + 1] = (float)nrm;
+  }
+}
+
+}  // namespace psgd
+
+// ================================================================== C ABI ===
+using namespace psgd;
+
+#define PSGD_CHECK_LAUNCH(expr)                 \
+  do {                                          \
+    const int _e = (expr);                      \
+    if (_e != 0) return PSGD_ERR_LAUNCH;        \
+  } while (0)
+
+static inline int last_launch() { return (int)hipGetLastError(); }
+
+extern "C" {
+
+int psgd_abi_version(void) { return PSGD_ABI_VERSION; }
+
+const char* psgd_error_string(int code) {
+  switch (code) {
+    case PSGD_OK: return "ok";
+    case PSGD_ERR_BAD_ARG: return "bad argument (null pointer or non-positive size)";
+    case PSGD_ERR_RANK: return "rank of modification outside [1, 32]";
+    case PSGD_ERR_WORKSPACE: return "workspace missing, too small or not 256-byte aligned";
+    case PSGD_ERR_ALIGN: return "matrix pointer not 16-byte aligned";
+    case PSGD_ERR_LAUNCH: return "HIP kernel launch failed";
+    case PSGD_ERR_SHAPE: return "inconsistent or unsupported matrix shapes";
+    default: return "unknown error";
+  }
+}
+
+int psgd_set_tuning(int key, int value) {
+  if (key == 0) { g_tune_staging = value; return PSGD_OK; }
+  if (key == 1) { g_tune_blocks_per_cu = value; return PSGD_OK; }
+  return PSGD_ERR_BAD_ARG;
+}
+
+int64_t psgd_uvd_workspace_bytes(int64_t N, int r) {
+  if (N <= 0) return PSGD_ERR_BAD_ARG;
+  if (r < 1 || r > PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  return ws_layout(N, r).total;
+}
+
+int psgd_uvd_ws_region(int which, int stage, int64_t N, int r, int64_t* offset_bytes, int64_t* count) {
+  if (!offset_bytes || !count || N <= 0) return PSGD_ERR_BAD_ARG;
+  if (r < 1 || r > PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  const WsLayout L = ws_layout(N, r);
+  const int nc = 2 * r + 2, nb = (nc + 15) / 16, np = nb * (nb + 1) / 2;
+  if (which == PSGD_WS_SUMS_F64) {
+    if (stage == 1) { *offset_bytes = L.sums_off; *count = r; return PSGD_OK; }
+    if (stage == 2) { *offset_bytes = L.sums_off + (int64_t)r * 8; *count = r; return PSGD_OK; }
+    if (stage == 11) { *offset_bytes = L.sums_off; *count = (int64_t)np * 256; return PSGD_OK; }
+  } else if (which == PSGD_WS_MAX_F32) {
+    if (stage == 10) { *offset_bytes = L.max_off; *count = 2; return PSGD_OK; }
+    if (stage == 12) { *offset_bytes = L.max_off + 8; *count = 1; return PSGD_OK; }
+  }
+  return PSGD_ERR_BAD_ARG;
+}
+
+// ---------------------------------------------------------------- apply ----
+int psgd_uvd_apply_sweep1_f32(const float* V, const float* d, const float* g, int64_t N, int r, void* ws,
+                              int64_t ws_bytes, void* stream) {
+  if (!V || !d || !g) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(V)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
+  float* part = static_cast<float*>(w.part);
+  PSGD_CHECK_LAUNCH(ops->colreduce(2, V, d, g, N, part, grid, st));
+  hipLaunchKernelGGL((k_reduce_sum<float>), dim3((r + 63) / 64), dim3(kThreads), 0, st, part, grid, r, w.sums,
+                     w.coef);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_uvd_apply_sweep2_f32(const float* U, const float* d, const float* g, int64_t N, int r, int sums_reduced,
+                              void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !d || !g) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (sums_reduced) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w.sums, w.coef, r);
+    PSGD_CHECK_LAUNCH(last_launch());
+  }
+  const int grid = sweep_grid(ops, r, kOccApplyS2, N, kMaxGrid);
+  float* part = static_cast<float*>(w.part);
+  PSGD_CHECK_LAUNCH(ops->apply_s2(U, d, g, N, w.coef, part, grid, st));
+  hipLaunchKernelGGL((k_reduce_sum<float>), dim3((r + 63) / 64), dim3(kThreads), 0, st, part, grid, r, w.sums + r,
+                     w.coef + r);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_uvd_apply_sweep3_f32(const float* U, const float* V, const float* d, const float* g, float* out,
+                              int64_t N, int r, int sums_reduced, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !g || !out) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (sums_reduced) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, w.sums + r, w.coef + r, r);
+    PSGD_CHECK_LAUNCH(last_launch());
+  }
+  const int grid = sweep_grid(ops, r, kOccApplyS3, N, kMaxGrid);
+  PSGD_CHECK_LAUNCH(ops->apply_s3(U, V, d, g, out, N, w.coef, grid, st));
+  return PSGD_OK;
+}
+
+int psgd_uvd_apply_f32(const float* U, const float* V, const float* d, const float* g, float* out, int64_t N, int r,
+                       void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !g || !out) return PSGD_ERR_BAD_ARG;
+  int rc = psgd_uvd_apply_sweep1_f32(V, d, g, N, r, ws, ws_bytes, stream);
+  if (rc) return rc;
+  rc = psgd_uvd_apply_sweep2_f32(U, d, g, N, r, 0, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return psgd_uvd_apply_sweep3_f32(U, V, d, g, out, N, r, 0, ws, ws_bytes, stream);
+}
+
+int psgd_uvd_ipuvt_matvec_f32(const float* U, const float* V, const float* x, float* out, int64_t N, int r,
+                              void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !x || !out) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(w.part);
+  int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
+  PSGD_CHECK_LAUNCH(ops->colreduce(1, V, x, nullptr, N, part, grid, st));
+  hipLaunchKernelGGL((k_reduce_sum<float>), dim3((r + 63) / 64), dim3(kThreads), 0, st, part, grid, r, w.sums,
+                     w.coef);
+  PSGD_CHECK_LAUNCH(last_launch());
+  grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
+  PSGD_CHECK_LAUNCH(ops->rowdot_axpy(U, x, out, N, w.coef, grid, st));
+  return PSGD_OK;
+}
+
+// --------------------------------------------------------------- update ----
+static int flat_grid(int64_t n) {
+  int64_t g = (n / 4 + kThreads - 1) / kThreads;
+  const int64_t cap = (int64_t)num_cus() * 8;
+  if (g > cap) g = cap;
+  if (g > kMaxGrid) g = kMaxGrid;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int psgd_uvd_balance_max_f32(const float* U, const float* V, int64_t N, int r, void* ws, int64_t ws_bytes,
+                             void* stream) {
+  if (!U || !V) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = N * r;
+  const int grid = flat_grid(n);
+  hipLaunchKernelGGL(k_maxabs2, dim3(grid), dim3(kThreads), 0, st, U, V, (long)n, w.pmax, grid);
+  PSGD_CHECK_LAUNCH(last_launch());
+  hipLaunchKernelGGL(k_reduce_max, dim3(2), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_uvd_balance_scale_f32(float* U, float* V, int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = N * r;
+  hipLaunchKernelGGL(k_scale2, dim3(flat_grid(n)), dim3(kThreads), 0, st, U, V, (long)n, w.maxbuf);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, const float* v, const float* h,
+                               int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = sweep_grid(ops, r, kOccGram, N, kGramMaxGrid);
+  double* part = static_cast<double*>(w.part);
+  PSGD_CHECK_LAUNCH(ops->update_gram(U, V, d, v, h, N, part, grid, st));
+  const int L = ops->gram_len;
+  hipLaunchKernelGGL((k_reduce_sum<double>), dim3((L + 63) / 64), dim3(kThreads), 0, st, part, grid, L, w.sums,
+                     static_cast<float*>(nullptr));
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_uvd_update_sweep2_f32(float* U, float* V, const float* d, const float* v, const float* h, int64_t N, int r,
+                               float step, float tiny, int update_U, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(64), 0, st, w.sums, r, step, tiny, update_U, w.coef);
+  PSGD_CHECK_LAUNCH(last_launch());
+  const int grid = sweep_grid(ops, r, update_U ? kOccUpdS2U : kOccUpdS2V, N, kMaxGrid);
+  PSGD_CHECK_LAUNCH(ops->update_s2(update_U, U, V, d, v, h, N, w.coef, w.nabla, w.pmax, grid, st));
+  hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf + 2);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_uvd_update_sweep3_f32(float* d, int64_t N, int r, float step, float tiny, void* ws, int64_t ws_bytes,
+                               void* stream) {
+  if (!d) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(d)) return PSGD_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_update_d, dim3(flat_grid(N)), dim3(kThreads), 0, st, d, w.nabla, (long)N, w.maxbuf + 2,
+                     step, tiny);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_uvd_update_f32(float* U, float* V, float* d, const float* v, const float* h, int64_t N, int r, float step,
+                        float tiny, int balance, int update_U, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
+  int rc;
+  if (balance) {
+    rc = psgd_uvd_balance_max_f32(U, V, N, r, ws, ws_bytes, stream);
+    if (rc) return rc;
+    rc = psgd_uvd_balance_scale_f32(U, V, N, r, ws, ws_bytes, stream);
+    if (rc) return rc;
+  }
+  rc = psgd_uvd_update_sweep1_f32(U, V, d, v, h, N, r, ws, ws_bytes, stream);
+  if (rc) return rc;
+  rc = psgd_uvd_update_sweep2_f32(U, V, d, v, h, N, r, step, tiny, update_U, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return psgd_uvd_update_sweep3_f32(d, N, r, step, tiny, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

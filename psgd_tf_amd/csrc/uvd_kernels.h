@@ -1,0 +1,578 @@
+// uvd_kernels.h -- CDNA4 (gfx950) streaming kernels for the UVd preconditioner
+//   Q = (I + U V') diag(d)      reference: psgd.py:527-627
+//
+// Data layout in HBM is the reference's own: U, V are [N, r] row-major fp32
+// (80-byte rows at r = 20), d/g/v/h/out are [N] fp32.
+//
+// Execution model (one scheme for every sweep):
+//   * A 64-lane wavefront owns a tile of kTileRows consecutive rows.  The tile
+//     of each [N, r] operand is one contiguous span of HBM, so it is fetched
+//     with fully coalesced 16-byte loads (1 KiB per wave instruction), staged
+//     in a wave-private LDS buffer, and then read back one row per lane
+//     (ds_read_b128 / b64 at a row stride of r dwords is bank-conflict free for
+//     every r because gcd(r, 64) distinct lanes map to distinct bank groups).
+//   * Waves never synchronise with each other inside the sweep loop (no
+//     s_barrier): each wave prefetches its next tile into registers while it
+//     computes on the current one, so ~10 KiB per wave is always in flight.
+//   * Column reductions (V't etc.) are accumulated per lane, reduced across
+//     the wave with shuffles and across the block through LDS in a fixed order;
+//     one partial row per block goes to the workspace and a second tiny kernel
+//     sums the partial rows in fp64.  No float atomics: results are bitwise
+//     reproducible for a given grid.
+//   * The small r-vectors a sweep consumes (s1, s2, ...) come from a uniform
+//     `const float*`, which hipcc turns into scalar loads (SGPR operands).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psgd {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWave * kWavesPerBlock;
+constexpr int kMaxGrid = 2048;      // sweeps never launch more blocks than this
+constexpr int kGramMaxGrid = 1024;  // Gram sweep (fp64 partials are large)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Tile geometry for rank R.  A tile is kTileRows = 64 * kRowsPerLane rows (one
+// contiguous span of an [N, R] matrix) and is fetched with kLoadVec-float vector
+// loads, 64 lanes wide.  Preference: 16-byte loads; fall back to 8- or 4-byte
+// loads when a 16-byte-loadable tile would exceed 2048 floats (8 KiB) of LDS.
+constexpr int kMaxTileFloats = 2048;
+constexpr int cfg_rows_per_lane(int R, int lv) {
+  // smallest rpl in {1,2,4} with 64*rpl*R divisible by 64*lv
+  return (R % lv == 0) ? 1 : ((2 * R) % lv == 0 ? 2 : 4);
+}
+constexpr int cfg_load_vec(int R) {
+  return (64 * cfg_rows_per_lane(R, 4) * R <= kMaxTileFloats) ? 4
+       : (64 * cfg_rows_per_lane(R, 2) * R <= kMaxTileFloats) ? 2 : 1;
+}
+template <int LV> struct VecT;
+template <> struct VecT<4> { typedef float4 type; };
+template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<1> { typedef float type; };
+
+template <int R>
+struct Cfg {
+  static constexpr int kVec = (R % 4 == 0) ? 4 : ((R % 2 == 0) ? 2 : 1);   // LDS row read width
+  static constexpr int kLoadVec = cfg_load_vec(R);                          // global load width (floats)
+  static constexpr int kRowsPerLane = cfg_rows_per_lane(R, kLoadVec);       // rows one lane owns per tile
+  static constexpr int kTileRows = 64 * kRowsPerLane;
+  static constexpr int kTileFloats = kTileRows * R;
+  static constexpr int kLoadsPerLane = kTileFloats / (64 * kLoadVec);       // vector loads per lane per tile
+  typedef typename VecT<kLoadVec>::type LoadT;
+  static_assert(kTileFloats % (64 * kLoadVec) == 0, "tile must be whole wave-wide vector loads");
+  static_assert(kTileFloats <= kMaxTileFloats, "tile exceeds LDS budget");
+};
+
+template <int R>
+struct GramCfg {
+  static constexpr int kCols = 2 * R + 2;                // [U | V | t | w]
+  static constexpr int kBlocks = (kCols + 15) / 16;      // 16-column MFMA blocks
+  static constexpr int kPairs = kBlocks * (kBlocks + 1) / 2;
+  static constexpr int kLen = kPairs * 256;              // fp64 sums per Gram
+};
+
+// ---------------------------------------------------------------- staging ---
+template <int R, int NMAT, int NVEC>
+struct Prefetch {
+  typename Cfg<R>::LoadT m[NMAT][Cfg<R>::kLoadsPerLane];
+  float s[NVEC > 0 ? NVEC : 1][Cfg<R>::kRowsPerLane];
+};
+
+template <int R, int NMAT, int NVEC>
+__device__ __forceinline__ void issue_tile(Prefetch<R, NMAT, NVEC>& pf,
+                                           const float* const (&mats)[NMAT],
+                                           const float* const (&vecs)[NVEC > 0 ? NVEC : 1],
+                                           long tile, int lane) {
+  using C = Cfg<R>;
+  const long row0 = tile * C::kTileRows;
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m) {
+    const typename C::LoadT* src = reinterpret_cast<const typename C::LoadT*>(mats[m] + row0 * R);
+#pragma unroll
+    for (int j = 0; j < C::kLoadsPerLane; ++j) pf.m[m][j] = src[lane + 64 * j];
+  }
+#pragma unroll
+  for (int k = 0; k < NVEC; ++k) {
+#pragma unroll
+    for (int i = 0; i < C::kRowsPerLane; ++i) pf.s[k][i] = vecs[k][row0 + lane + 64 * i];
+  }
+}
+
+template <int R, int NMAT, int NVEC>
+__device__ __forceinline__ void commit_tile(const Prefetch<R, NMAT, NVEC>& pf, float* lds, int lane) {
+  using C = Cfg<R>;
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m) {
+    typename C::LoadT* dst = reinterpret_cast<typename C::LoadT*>(lds + m * C::kTileFloats);
+#pragma unroll
+    for (int j = 0; j < C::kLoadsPerLane; ++j) dst[lane + 64 * j] = pf.m[m][j];
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void read_row(const float* tile, int row, float (&x)[R]) {
+  const float* p = tile + row * R;
+  if constexpr (R % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < R / 4; ++c) {
+      const float4 q = reinterpret_cast<const float4*>(p)[c];
+      x[4 * c + 0] = q.x; x[4 * c + 1] = q.y; x[4 * c + 2] = q.z; x[4 * c + 3] = q.w;
+    }
+  } else if constexpr (R % 2 == 0) {
+#pragma unroll
+    for (int c = 0; c < R / 2; ++c) {
+      const float2 q = reinterpret_cast<const float2*>(p)[c];
+      x[2 * c + 0] = q.x; x[2 * c + 1] = q.y;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < R; ++c) x[c] = p[c];
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void write_row(float* tile, int row, const float (&x)[R]) {
+  float* p = tile + row * R;
+  if constexpr (R % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < R / 4; ++c)
+      reinterpret_cast<float4*>(p)[c] = make_float4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+  } else if constexpr (R % 2 == 0) {
+#pragma unroll
+    for (int c = 0; c < R / 2; ++c) reinterpret_cast<float2*>(p)[c] = make_float2(x[2 * c], x[2 * c + 1]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < R; ++c) p[c] = x[c];
+  }
+}
+
+// Generic row sweep.  mats: NMAT [N,R] inputs; vecs: NVEC [N] inputs;
+// WB >= 0: operand WB is modified by the body and streamed back to `mat_out`.
+// body(row, valid, x[NMAT][R], s[NVEC]).  Rows past N (tail tile only) arrive
+// zero-filled with valid == false.
+template <int R, int NMAT, int NVEC, int WB, class Body>
+__device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
+                                           const float* const (&vecs)[NVEC > 0 ? NVEC : 1],
+                                           float* mat_out, long N, float* lds, Body&& body) {
+  using C = Cfg<R>;
+  const int lane = threadIdx.x & 63;
+  const long gw = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * kWavesPerBlock;
+  const long nfull = N / C::kTileRows;
+
+  Prefetch<R, NMAT, NVEC> pf;
+  long tile = gw;
+  if (tile < nfull) issue_tile<R, NMAT, NVEC>(pf, mats, vecs, tile, lane);
+  while (tile < nfull) {
+    commit_tile<R, NMAT, NVEC>(pf, lds, lane);
+    float s_cur[NVEC > 0 ? NVEC : 1][C::kRowsPerLane];
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k)
+#pragma unroll
+      for (int i = 0; i < C::kRowsPerLane; ++i) s_cur[k][i] = pf.s[k][i];
+    const long next = tile + nw;
+    if (next < nfull) issue_tile<R, NMAT, NVEC>(pf, mats, vecs, next, lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < C::kRowsPerLane; ++i) {
+      const int rit = lane + 64 * i;
+      float x[NMAT][R];
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) read_row<R>(lds + m * C::kTileFloats, rit, x[m]);
+      float s[NVEC > 0 ? NVEC : 1];
+#pragma unroll
+      for (int k = 0; k < NVEC; ++k) s[k] = s_cur[k][i];
+      body(tile * C::kTileRows + rit, true, x, s);
+      if constexpr (WB >= 0) write_row<R>(lds + WB * C::kTileFloats, rit, x[WB]);
+    }
+    if constexpr (WB >= 0) {
+      __builtin_amdgcn_wave_barrier();
+      const typename C::LoadT* src = reinterpret_cast<const typename C::LoadT*>(lds + WB * C::kTileFloats);
+      typename C::LoadT* dst = reinterpret_cast<typename C::LoadT*>(mat_out + tile * C::kTileRows * R);
+#pragma unroll
+      for (int j = 0; j < C::kLoadsPerLane; ++j) dst[lane + 64 * j] = src[lane + 64 * j];
+      __builtin_amdgcn_wave_barrier();
+    }
+    tile = next;
+  }
+
+  // tail tile (N % kTileRows rows): guarded scalar staging, owned by one wave
+  const long tail_rows = N - nfull * C::kTileRows;
+  if (tail_rows > 0 && (nfull % nw) == gw) {
+    const long row0 = nfull * C::kTileRows;
+    const long tail_floats = tail_rows * R;
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m) {
+      const float* src = mats[m] + row0 * R;
+      float* dst = lds + m * C::kTileFloats;
+      for (int idx = lane; idx < C::kTileFloats; idx += 64) dst[idx] = (idx < tail_floats) ? src[idx] : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < C::kRowsPerLane; ++i) {
+      const int rit = lane + 64 * i;
+      const bool valid = rit < tail_rows;
+      float x[NMAT][R];
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) read_row<R>(lds + m * C::kTileFloats, rit, x[m]);
+      float s[NVEC > 0 ? NVEC : 1];
+#pragma unroll
+      for (int k = 0; k < NVEC; ++k) s[k] = valid ? vecs[k][row0 + rit] : 0.0f;
+      body(row0 + rit, valid, x, s);
+      if constexpr (WB >= 0) write_row<R>(lds + WB * C::kTileFloats, rit, x[WB]);
+    }
+    if constexpr (WB >= 0) {
+      __builtin_amdgcn_wave_barrier();
+      const float* src = lds + WB * C::kTileFloats;
+      float* dst = mat_out + row0 * R;
+      for (int idx = lane; idx < tail_floats; idx += 64) dst[idx] = src[idx];
+    }
+  }
+}
+
+// ------------------------------------------------------ block reductions ---
+// Sum acc[L] over the block (fixed order) and store one partial row.
+template <int L>
+__device__ __forceinline__ void block_sum_store(float (&acc)[L], float* red /* [waves][L] */, float* part_row) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < L; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[w * L + c] = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < L; c += kThreads) {
+    float s = red[c];
+#pragma unroll
+    for (int k = 1; k < kWavesPerBlock; ++k) s += red[k * L + c];
+    part_row[c] = s;
+  }
+}
+
+__device__ __forceinline__ void block_max_store(float v, float* red /* [waves] */, float* out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = red[0];
+#pragma unroll
+    for (int k = 1; k < kWavesPerBlock; ++k) s = fmaxf(s, red[k]);
+    *out = s;
+  }
+}
+
+template <int R>
+__device__ __forceinline__ float dot_row(const float (&x)[R], const float* __restrict__ c) {
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < R; ++k) s = fmaf(x[k], c[k], s);
+  return s;
+}
+
+// ------------------------------------------------------------- kernels -----
+// s = M' (a .* b)  (NVEC == 2) or M' a (NVEC == 1): apply sweep 1 (psgd.py:544
+// inner matmul with x = d*g, :625) and the first half of IpUVtmatvec.
+template <int R, int NVEC>
+__global__ __launch_bounds__(kThreads) void k_colreduce(const float* M, const float* a, const float* b,
+                                                        long N, float* part) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][Cfg<R>::kTileFloats];
+  __shared__ float red[kWavesPerBlock * R];
+  float acc[R];
+#pragma unroll
+  for (int c = 0; c < R; ++c) acc[c] = 0.0f;
+  const float* const mats[1] = {M};
+  auto body = [&](long, bool, float (&x)[1][R], float (&s)[NVEC]) {
+    float t = s[0];
+    if constexpr (NVEC > 1) t *= s[1];
+#pragma unroll
+    for (int c = 0; c < R; ++c) acc[c] = fmaf(x[0][c], t, acc[c]);
+  };
+  if constexpr (NVEC == 2) {
+    const float* const vecs[2] = {a, b};
+    sweep_rows<R, 1, 2, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
+  } else {
+    const float* const vecs[1] = {a};
+    sweep_rows<R, 1, 1, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
+  }
+  block_sum_store<R>(acc, red, part + (long)blockIdx.x * R);
+}
+
+// apply sweep 2: s2 = U' (t + U s1), t = d .* g   (psgd.py:626 -> :544)
+template <int R>
+__global__ __launch_bounds__(kThreads) void k_apply_s2(const float* U, const float* d, const float* g, long N,
+                                                       const float* __restrict__ coef, float* part) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][Cfg<R>::kTileFloats];
+  __shared__ float red[kWavesPerBlock * R];
+  float acc[R];
+#pragma unroll
+  for (int c = 0; c < R; ++c) acc[c] = 0.0f;
+  const float* const mats[1] = {U};
+  const float* const vecs[2] = {d, g};
+  sweep_rows<R, 1, 2, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                          [&](long, bool, float (&x)[1][R], float (&s)[2]) {
+                            const float t = s[0] * s[1];
+                            const float g1 = t + dot_row<R>(x[0], coef);
+#pragma unroll
+                            for (int c = 0; c < R; ++c) acc[c] = fmaf(x[0][c], g1, acc[c]);
+                          });
+  block_sum_store<R>(acc, red, part + (long)blockIdx.x * R);
+}
+
+// apply sweep 3: out = d .* (g1 + V s2), g1 = d.*g + U s1   (psgd.py:625-626)
+template <int R>
+__global__ __launch_bounds__(kThreads) void k_apply_s3(const float* U, const float* V, const float* d,
+                                                       const float* g, float* out, long N,
+                                                       const float* __restrict__ coef) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][2 * Cfg<R>::kTileFloats];
+  const float* const mats[2] = {U, V};
+  const float* const vecs[2] = {d, g};
+  sweep_rows<R, 2, 2, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                          [&](long row, bool valid, float (&x)[2][R], float (&s)[2]) {
+                            const float t = s[0] * s[1];
+                            const float g1 = t + dot_row<R>(x[0], coef);
+                            const float o = s[0] * (g1 + dot_row<R>(x[1], coef + R));
+                            if (valid) out[row] = o;
+                          });
+}
+
+// out = x + M s   (second half of IpUVtmatvec, psgd.py:544)
+template <int R>
+__global__ __launch_bounds__(kThreads) void k_rowdot_axpy(const float* M, const float* xin, float* out, long N,
+                                                          const float* __restrict__ coef) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][Cfg<R>::kTileFloats];
+  const float* const mats[1] = {M};
+  const float* const vecs[1] = {xin};
+  sweep_rows<R, 1, 1, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                          [&](long row, bool valid, float (&x)[1][R], float (&s)[1]) {
+                            const float o = s[0] + dot_row<R>(x[0], coef);
+                            if (valid) out[row] = o;
+                          });
+}
+
+// update sweep 1: Gram of W = [U | V | t | w], t = d.*h, w = v./d, on the
+// fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains).  The Gram
+// holds every inner product psgd.py:569-615 needs: V'U (:574), U'U, V'V, V't,
+// U't, U'w, V'w, t't, w'w, t'w.  Only block pairs bi <= bj are computed.
+// Chains are 1 tile long; tile results are accumulated in fp64.
+template <int R>
+__global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const float* V, const float* d,
+                                                          const float* v, const float* h, long N, double* part) {
+  using C = Cfg<R>;
+  using GC = GramCfg<R>;
+  constexpr int kTw = 2 * C::kTileFloats;             // t,w interleaved [kTileRows][2]
+  constexpr int kZero = kTw + 2 * C::kTileRows;       // 4 zero floats
+  constexpr int kWaveFloats = kZero + 4;
+  constexpr int kTileBytes = kWavesPerBlock * kWaveFloats * 4;
+  constexpr int kScratchBytes = 2 * GC::kLen * 8;
+  constexpr int kLdsBytes = kTileBytes > kScratchBytes ? kTileBytes : kScratchBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* lds = reinterpret_cast<float*>(smem) + w * kWaveFloats;
+  if (lane < 4) lds[kZero + lane] = 0.0f;
+
+  int obase[GC::kBlocks], ostride[GC::kBlocks];
+#pragma unroll
+  for (int b = 0; b < GC::kBlocks; ++b) {
+    const int col = 16 * b + (lane & 15);
+    if (col < R) { obase[b] = col; ostride[b] = R; }
+    else if (col < 2 * R) { obase[b] = C::kTileFloats + (col - R); ostride[b] = R; }
+    else if (col < 2 * R + 2) { obase[b] = kTw + (col - 2 * R); ostride[b] = 2; }
+    else { obase[b] = kZero; ostride[b] = 0; }
+    obase[b] += (lane >> 4) * ostride[b];
+  }
+
+  double acc64[GC::kPairs][4];
+#pragma unroll
+  for (int p = 0; p < GC::kPairs; ++p)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc64[p][e] = 0.0;
+
+  const long gw = (long)blockIdx.x * kWavesPerBlock + w;
+  const long nw = (long)gridDim.x * kWavesPerBlock;
+  const long nfull = N / C::kTileRows;
+  const long tail_rows = N - nfull * C::kTileRows;
+  const float* const mats[2] = {U, V};
+  const float* const vecs[3] = {d, v, h};
+
+  auto gram_tile = [&]() {
+    f32x4 acc[GC::kPairs];
+#pragma unroll
+    for (int p = 0; p < GC::kPairs; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int m = 0; m < C::kTileRows / 4; ++m) {
+      float a[GC::kBlocks];
+#pragma unroll
+      for (int b = 0; b < GC::kBlocks; ++b) a[b] = lds[obase[b] + 4 * m * ostride[b]];
+      int p = 0;
+#pragma unroll
+      for (int bi = 0; bi < GC::kBlocks; ++bi)
+#pragma unroll
+        for (int bj = bi; bj < GC::kBlocks; ++bj) {
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[bi], a[bj], acc[p], 0, 0, 0);
+          ++p;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < GC::kPairs; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
+  };
+
+  Prefetch<R, 2, 3> pf;
+  long tile = gw;
+  if (tile < nfull) issue_tile<R, 2, 3>(pf, mats, vecs, tile, lane);
+  while (tile < nfull) {
+    commit_tile<R, 2, 3>(pf, lds, lane);
+#pragma unroll
+    for (int i = 0; i < C::kRowsPerLane; ++i) {
+      const float dd = pf.s[0][i];
+      const float t = dd * pf.s[2][i];
+      const float ww = pf.s[1][i] / dd;
+      reinterpret_cast<float2*>(lds + kTw)[lane + 64 * i] = make_float2(t, ww);
+    }
+    const long next = tile + nw;
+    if (next < nfull) issue_tile<R, 2, 3>(pf, mats, vecs, next, lane);
+    __builtin_amdgcn_wave_barrier();
+    gram_tile();
+    __builtin_amdgcn_wave_barrier();
+    tile = next;
+  }
+  if (tail_rows > 0 && (nfull % nw) == gw) {
+    const long row0 = nfull * C::kTileRows;
+    const long tail_floats = tail_rows * R;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float* src = mats[m] + row0 * R;
+      float* dst = lds + m * C::kTileFloats;
+      for (int idx = lane; idx < C::kTileFloats; idx += 64) dst[idx] = (idx < tail_floats) ? src[idx] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < C::kRowsPerLane; ++i) {
+      const int rit = lane + 64 * i;
+      float t = 0.0f, ww = 0.0f;
+      if (rit < tail_rows) {
+        const float dd = d[row0 + rit];
+        t = dd * h[row0 + rit];
+        ww = v[row0 + rit] / dd;
+      }
+      reinterpret_cast<float2*>(lds + kTw)[rit] = make_float2(t, ww);
+    }
+    __builtin_amdgcn_wave_barrier();
+    gram_tile();
+  }
+
+  // block reduction in fp64 through LDS (tile buffers are dead now), fixed order:
+  // (w2,w3) -> scratch ; w0 += s0, w1 += s1 ; w1 -> scratch ; w0 += s0 ; w0 stores
+  __syncthreads();
+  double* scratch = reinterpret_cast<double*>(smem);
+  if (w >= 2) {
+#pragma unroll
+    for (int p = 0; p < GC::kPairs; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) scratch[(w - 2) * GC::kLen + p * 256 + e * 64 + lane] = acc64[p][e];
+  }
+  __syncthreads();
+  if (w < 2) {
+#pragma unroll
+    for (int p = 0; p < GC::kPairs; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc64[p][e] += scratch[w * GC::kLen + p * 256 + e * 64 + lane];
+  }
+  __syncthreads();
+  if (w == 1) {
+#pragma unroll
+    for (int p = 0; p < GC::kPairs; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) scratch[p * 256 + e * 64 + lane] = acc64[p][e];
+  }
+  __syncthreads();
+  if (w == 0) {
+    double* dst = part + (long)blockIdx.x * GC::kLen;
+#pragma unroll
+    for (int p = 0; p < GC::kPairs; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[p * 256 + e * 64 + lane] = acc64[p][e] + scratch[p * 256 + e * 64 + lane];
+  }
+}
+
+// coefficient block consumed by update sweep 2 (written by k_update_coef)
+//   [0,R) s1 = V't      [R,2R) s2 = U'Qh      [2R,3R) x1      [3R,4R) x2
+//   [4R,5R) c1          [5R,6R) c2            [6R] mu  [6R+1] norm (debug)
+template <int R>
+struct UpdCoef {
+  static constexpr int kS1 = 0, kS2 = R, kX1 = 2 * R, kX2 = 3 * R, kC1 = 4 * R, kC2 = 5 * R, kMu = 6 * R;
+};
+
+// update sweep 2 (row-local; psgd.py:569-601 / :603-615 given the r-vectors):
+//   a = t + U s1 (Qh)            b = w - V x1 (invQtv)
+//   Ph = d (a + V s2)            invPv = (b - U x2) / d
+//   nablaD = Ph h - v invPv      (stored; its max|.| reduced)
+//   UPDATE_U: U <- U - mu (a c1 - b c2),  c1 = atV K, c2 = btV K
+//   else    : V <- V - mu ((a + V c1) c1 - (b + V c2) c2),  c1 = atU, c2 = btU
+template <int R, bool UPDATE_U>
+__global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, const float* d, const float* v,
+                                                        const float* h, long N, const float* __restrict__ coef,
+                                                        float* nabla, float* part_max) {
+  using K = UpdCoef<R>;
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][2 * Cfg<R>::kTileFloats];
+  __shared__ float red[kWavesPerBlock];
+  float vmax = 0.0f;
+  const float mu = coef[K::kMu];
+  const float* const mats[2] = {U, V};
+  const float* const vecs[3] = {d, v, h};
+  sweep_rows<R, 2, 3, (UPDATE_U ? 0 : 1)>(
+      mats, vecs, UPDATE_U ? U : V, N, lds[threadIdx.x >> 6],
+      [&](long row, bool valid, float (&x)[2][R], float (&s)[3]) {
+        const float dd = s[0], vv = s[1], hh = s[2];
+        const float t = dd * hh;
+        const float ww = valid ? vv / dd : 0.0f;
+        const float a = t + dot_row<R>(x[0], coef + K::kS1);
+        const float b = ww - dot_row<R>(x[1], coef + K::kX1);
+        const float Ph = dd * (a + dot_row<R>(x[1], coef + K::kS2));
+        const float invPv = valid ? (b - dot_row<R>(x[0], coef + K::kX2)) / dd : 0.0f;
+        const float nd = Ph * hh - vv * invPv;
+        if (valid) {
+          nabla[row] = nd;
+          vmax = fmaxf(vmax, fabsf(nd));
+        }
+        if constexpr (UPDATE_U) {
+#pragma unroll
+          for (int c = 0; c < R; ++c) x[0][c] = x[0][c] - mu * (a * coef[K::kC1 + c] - b * coef[K::kC2 + c]);
+        } else {
+          const float al = a + dot_row<R>(x[1], coef + K::kC1);
+          const float be = b + dot_row<R>(x[1], coef + K::kC2);
+#pragma unroll
+          for (int c = 0; c < R; ++c) x[1][c] = x[1][c] - mu * (al * coef[K::kC1 + c] - be * coef[K::kC2 + c]);
+        }
+      });
+  block_max_store(vmax, red, part_max + blockIdx.x);
+}
+
+// ------------------------------------------------------- launch table ------
+struct UvdOps {
+  int tile_rows;
+  int gram_len;
+  // all launchers: grid chosen by caller (<= kMaxGrid), return hipError_t as int
+  int (*colreduce)(int nvec, const float* M, const float* a, const float* b, long N, float* part, int grid, hipStream_t st);
+  int (*apply_s2)(const float* U, const float* d, const float* g, long N, const float* coef, float* part, int grid, hipStream_t st);
+  int (*apply_s3)(const float* U, const float* V, const float* d, const float* g, float* out, long N, const float* coef, int grid, hipStream_t st);
+  int (*rowdot_axpy)(const float* M, const float* x, float* out, long N, const float* coef, int grid, hipStream_t st);
+  int (*update_gram)(const float* U, const float* V, const float* d, const float* v, const float* h, long N, double* part, int grid, hipStream_t st);
+  int (*update_s2)(int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N, const float* coef, float* nabla, float* part_max, int grid, hipStream_t st);
+  // max resident blocks per CU for each sweep kernel (occupancy query)
+  int (*occupancy)(int which);
+};
+
+enum { kOccColreduce = 0, kOccApplyS2, kOccApplyS3, kOccRowdot, kOccGram, kOccUpdS2U, kOccUpdS2V };
+
+const UvdOps* uvd_ops_for_rank(int r);   // nullptr when r is not instantiated
+
+}  // namespace psgd

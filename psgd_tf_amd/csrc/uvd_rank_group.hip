@@ -1,0 +1,90 @@
+// uvd_rank_group.hip -- instantiates the rank-templated UVd kernels for the 8
+// ranks PSGD_RANK_LO .. PSGD_RANK_LO+7 and exposes them through a table of host
+// launchers.  Compiled four times (ranks 1-8, 9-16, 17-24, 25-32) so that the
+// groups build in parallel.
+#include "uvd_kernels.h"
+
+#ifndef PSGD_RANK_LO
+#error "compile with -DPSGD_RANK_LO=<first rank> -DPSGD_GROUP_FN=<symbol>"
+#endif
+
+namespace psgd {
+
+template <int R>
+struct Launch {
+  static int colreduce(int nvec, const float* M, const float* a, const float* b, long N, float* part, int grid,
+                       hipStream_t st) {
+    if (nvec == 2)
+      hipLaunchKernelGGL((k_colreduce<R, 2>), dim3(grid), dim3(kThreads), 0, st, M, a, b, N, part);
+    else
+      hipLaunchKernelGGL((k_colreduce<R, 1>), dim3(grid), dim3(kThreads), 0, st, M, a, b, N, part);
+    return (int)hipGetLastError();
+  }
+  static int apply_s2(const float* U, const float* d, const float* g, long N, const float* coef, float* part,
+                      int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_apply_s2<R>), dim3(grid), dim3(kThreads), 0, st, U, d, g, N, coef, part);
+    return (int)hipGetLastError();
+  }
+  static int apply_s3(const float* U, const float* V, const float* d, const float* g, float* out, long N,
+                      const float* coef, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_apply_s3<R>), dim3(grid), dim3(kThreads), 0, st, U, V, d, g, out, N, coef);
+    return (int)hipGetLastError();
+  }
+  static int rowdot_axpy(const float* M, const float* x, float* out, long N, const float* coef, int grid,
+                         hipStream_t st) {
+    hipLaunchKernelGGL((k_rowdot_axpy<R>), dim3(grid), dim3(kThreads), 0, st, M, x, out, N, coef);
+    return (int)hipGetLastError();
+  }
+  static int update_gram(const float* U, const float* V, const float* d, const float* v, const float* h, long N,
+                         double* part, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_update_gram<R>), dim3(grid), dim3(kThreads), 0, st, U, V, d, v, h, N, part);
+    return (int)hipGetLastError();
+  }
+  static int update_s2(int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N,
+                       const float* coef, float* nabla, float* part_max, int grid, hipStream_t st) {
+    if (update_U)
+      hipLaunchKernelGGL((k_update_s2<R, true>), dim3(grid), dim3(kThreads), 0, st, U, V, d, v, h, N, coef, nabla,
+                         part_max);
+    else
+      hipLaunchKernelGGL((k_update_s2<R, false>), dim3(grid), dim3(kThreads), 0, st, U, V, d, v, h, N, coef,
+                         nabla, part_max);
+    return (int)hipGetLastError();
+  }
+  static int occupancy(int which) {
+    const void* f = nullptr;
+    switch (which) {
+      case kOccColreduce: f = reinterpret_cast<const void*>(&k_colreduce<R, 2>); break;
+      case kOccApplyS2: f = reinterpret_cast<const void*>(&k_apply_s2<R>); break;
+      case kOccApplyS3: f = reinterpret_cast<const void*>(&k_apply_s3<R>); break;
+      case kOccRowdot: f = reinterpret_cast<const void*>(&k_rowdot_axpy<R>); break;
+      case kOccGram: f = reinterpret_cast<const void*>(&k_update_gram<R>); break;
+      case kOccUpdS2U: f = reinterpret_cast<const void*>(&k_update_s2<R, true>); break;
+      case kOccUpdS2V: f = reinterpret_cast<const void*>(&k_update_s2<R, false>); break;
+      default: return 0;
+    }
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, kThreads, 0) != hipSuccess) return 0;
+    return n;
+  }
+  static const UvdOps* ops() {
+    static const UvdOps o = {Cfg<R>::kTileRows, GramCfg<R>::kLen, &colreduce, &apply_s2, &apply_s3,
+                             &rowdot_axpy,      &update_gram,     &update_s2, &occupancy};
+    return &o;
+  }
+};
+
+const UvdOps* PSGD_GROUP_FN(int r) {
+  switch (r - PSGD_RANK_LO) {
+    case 0: return Launch<PSGD_RANK_LO + 0>::ops();
+    case 1: return Launch<PSGD_RANK_LO + 1>::ops();
+    case 2: return Launch<PSGD_RANK_LO + 2>::ops();
+    case 3: return Launch<PSGD_RANK_LO + 3>::ops();
+    case 4: return Launch<PSGD_RANK_LO + 4>::ops();
+    case 5: return Launch<PSGD_RANK_LO + 5>::ops();
+    case 6: return Launch<PSGD_RANK_LO + 6>::ops();
+    case 7: return Launch<PSGD_RANK_LO + 7>::ops();
+    default: return nullptr;
+  }
+}
+
+}  // namespace psgd

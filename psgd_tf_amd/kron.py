@@ -1,0 +1,233 @@
+"""Kronecker-product preconditioner: shape dispatch (psgd.py:72-152) and the seven formats.
+
+(dense, dense) -- the hot path, psgd.py:156-192 -- runs in the HIP kernels of
+csrc/psgd_kron.hip through the C ABI.  The sparse formats (normalization / scaling
+factors, psgd.py:198-391) are the "next" rows of SURVEY 8f-1: they are reachable through
+the same two public entry points and are computed here with device-side torch ops until
+their fused kernels land.
+"""
+import torch
+
+from . import _lib
+
+_tiny = torch.finfo(torch.float32).tiny
+
+KRON_FORMATS = ("dense_dense", "dense_norm", "dense_scale", "norm_dense",
+                "norm_scale", "scale_dense", "scale_norm", "unknown")
+
+
+def kron_format(shape_l, shape_r):
+    """The dispatch table of psgd.py:80-110 / :122-152.  Square is tested first, so a
+    [1,1] or [2,2] factor is dense (README.md:39)."""
+    m, n = int(shape_l[0]), int(shape_l[1])
+    p, q = int(shape_r[0]), int(shape_r[1])
+    if m == n:
+        return "dense_dense" if p == q else "dense_norm" if p == 2 else "dense_scale" if p == 1 else "unknown"
+    if m == 2:
+        return "norm_dense" if p == q else "norm_scale" if p == 1 else "unknown"
+    if m == 1:
+        return "scale_dense" if p == q else "scale_norm" if p == 2 else "unknown"
+    return "unknown"
+
+
+def _check_rank2_f32(name, *tensors):
+    # the reference pins its public Kron functions to rank-2 fp32 (psgd.py:67-71, 113-115)
+    for t in tensors:
+        if t.dim() != 2:
+            raise ValueError("%s: rank-2 tensors required, got shape %s" % (name, tuple(t.shape)))
+        if t.dtype != torch.float32:
+            raise TypeError("%s: fp32 tensors required, got %s" % (name, t.dtype))
+
+
+# --------------------------------------------------------------------------- dense (x) dense: HIP
+_kron_ws = {}
+
+
+def _kron_workspace(device, M, N):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), M, N)
+    ws = _kron_ws.get(key)
+    if ws is None:
+        nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes(M, N))
+        if nbytes < 0:
+            _lib.check(nbytes, "psgd_kron_dd_workspace_bytes")
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _kron_ws[key] = ws
+    return ws
+
+
+def _require_hip(name, *tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise _lib.PsgdHipError("%s runs on the HIP device only (tensor is on %s); no CPU fallback" % (name, t.device))
+
+
+def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
+    """psgd.py:156-179 on the GPU; pure (fresh outputs)."""
+    _require_hip("update_precond_kron", Ql, Qr, dX, dG)
+    M, N = dX.shape
+    Ql, Qr, dX, dG = (t.contiguous() for t in (Ql, Qr, dX, dG))
+    QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
+    ws = _kron_workspace(dX.device, M, N)
+    rc = _lib.load().psgd_kron_dd_update_f32(Ql.data_ptr(), Qr.data_ptr(), dX.data_ptr(), dG.data_ptr(),
+                                              QlO.data_ptr(), QrO.data_ptr(), M, N, float(step), float(_tiny),
+                                              ws.data_ptr(), ws.numel(),
+                                              torch.cuda.current_stream(dX.device).cuda_stream)
+    _lib.check(rc, "psgd_kron_dd_update_f32")
+    return QlO, QrO
+
+
+def _precond_grad_dense_dense(Ql, Qr, Grad):
+    """psgd.py:182-192 on the GPU."""
+    _require_hip("precond_grad_kron", Ql, Qr, Grad)
+    M, N = Grad.shape
+    Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
+    out = torch.empty_like(Grad)
+    ws = _kron_workspace(Grad.device, M, N)
+    rc = _lib.load().psgd_kron_dd_apply_f32(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
+                                             ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream(Grad.device).cuda_stream)
+    _lib.check(rc, "psgd_kron_dd_apply_f32")
+    return out
+
+
+# --------------------------------------------------------------------------- sparse formats: torch ops
+def _solve_ut_adjoint(Q, X):
+    """tf.linalg.triangular_solve(Q, X, lower=False, adjoint=True): Q^T Y = X."""
+    return torch.linalg.solve_triangular(Q.t(), X, upper=False)
+
+
+def _ql_times(ql, X):
+    return ql[0:1].t() * X + ql[1:].t() @ X[-1:]                                  # psgd.py:218-219
+
+
+def _ql_inv_t_times(ql, X):
+    Bt = (1.0 / ql[0:1]).t() * X                                                  # psgd.py:230
+    last = Bt[-1:] - (ql[1:] / (ql[0:1] * ql[0, -1])) @ X                         # :231-232
+    return torch.cat([Bt[:-1], last], 0)
+
+
+def _norm_grad1(A, Bt):
+    g_diag = torch.sum(A * A, 1) - torch.sum(Bt * Bt, 1)                          # psgd.py:235
+    g_bias = A[:-1] @ A[-1:].t() - Bt[:-1] @ Bt[-1:].t()                          # :236
+    g_bias = torch.cat([torch.reshape(g_bias, [-1]), torch.zeros(1, dtype=A.dtype, device=A.device)], 0)   # :237
+    return g_diag, g_bias
+
+
+def _update_precond_norm_dense(ql, Qr, dX, dG, step):
+    """psgd.py:198-246."""
+    rho = torch.sqrt(torch.max(ql[0]) / torch.max(torch.diagonal(Qr)))
+    ql = ql / rho
+    Qr = rho * Qr
+    A = _ql_times(ql, dG) @ Qr.t()
+    Bt = _solve_ut_adjoint(Qr, _ql_inv_t_times(ql, dX).t()).t()
+    g_diag, g_bias = _norm_grad1(A, Bt)
+    step1 = step / (torch.maximum(torch.max(torch.abs(g_diag)), torch.max(torch.abs(g_bias))) + _tiny)
+    new_ql0 = ql[0] - step1 * g_diag * ql[0]
+    new_ql1 = ql[1] - step1 * (g_diag * ql[1] + ql[0, -1] * g_bias)
+    grad2 = torch.triu(A.t() @ A - Bt.t() @ Bt)
+    step2 = step / (torch.max(torch.abs(grad2)) + _tiny)
+    return torch.stack((new_ql0, new_ql1)), Qr - (step2 * grad2) @ Qr
+
+
+def _norm_left_gram_apply(ql, preG):
+    add_last_row = ql[1:] @ preG                                                  # psgd.py:265
+    preG = ql[0:1].t() * preG
+    return torch.cat([preG[:-1], preG[-1:] + add_last_row], 0)
+
+
+def _precond_grad_norm_dense(ql, Qr, Grad):
+    """psgd.py:249-270."""
+    preG = _ql_times(ql, Grad)
+    if preG.shape[0] < preG.shape[1]:
+        preG = (preG @ Qr.t()) @ Qr
+    else:
+        preG = preG @ (Qr.t() @ Qr)
+    return _norm_left_gram_apply(ql, preG)
+
+
+def _update_precond_dense_scale(Ql, qr, dX, dG, step):
+    """psgd.py:276-307."""
+    rho = torch.sqrt(torch.max(torch.diagonal(Ql)) / torch.max(qr))
+    Ql = Ql / rho
+    qr = rho * qr
+    A = (Ql @ dG) * qr
+    Bt = _solve_ut_adjoint(Ql, dX) * (1.0 / qr)
+    grad1 = torch.triu(A @ A.t() - Bt @ Bt.t())
+    step1 = step / (torch.max(torch.abs(grad1)) + _tiny)
+    grad2 = torch.sum(A * A, 0, keepdim=True) - torch.sum(Bt * Bt, 0, keepdim=True)
+    step2 = step / (torch.max(torch.abs(grad2)) + _tiny)
+    return Ql - (step1 * grad1) @ Ql, qr - step2 * grad2 * qr
+
+
+def _precond_grad_dense_scale(Ql, qr, Grad):
+    """psgd.py:310-322."""
+    if Grad.shape[0] < Grad.shape[1]:
+        preG = (Ql.t() @ Ql) @ Grad
+    else:
+        preG = Ql.t() @ (Ql @ Grad)
+    return preG * (qr * qr)
+
+
+def _update_precond_norm_scale(ql, qr, dX, dG, step):
+    """psgd.py:328-369."""
+    rho = torch.sqrt(torch.max(ql[0]) / torch.max(qr))
+    ql = ql / rho
+    qr = rho * qr
+    A = _ql_times(ql, dG) * qr
+    Bt = _ql_inv_t_times(ql, dX) * (1.0 / qr)
+    g_diag, g_bias = _norm_grad1(A, Bt)
+    step1 = step / (torch.maximum(torch.max(torch.abs(g_diag)), torch.max(torch.abs(g_bias))) + _tiny)
+    new_ql0 = ql[0] - step1 * g_diag * ql[0]
+    new_ql1 = ql[1] - step1 * (g_diag * ql[1] + ql[0, -1] * g_bias)
+    grad2 = torch.sum(A * A, 0, keepdim=True) - torch.sum(Bt * Bt, 0, keepdim=True)
+    step2 = step / (torch.max(torch.abs(grad2)) + _tiny)
+    return torch.stack((new_ql0, new_ql1)), qr - step2 * grad2 * qr
+
+
+def _precond_grad_norm_scale(ql, qr, Grad):
+    """psgd.py:372-391."""
+    preG = _ql_times(ql, Grad) * (qr * qr)
+    return _norm_left_gram_apply(ql, preG)
+
+
+# --------------------------------------------------------------------------- public dispatchers
+def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
+    _check_rank2_f32("update_precond_kron", Ql, Qr, dX, dG)
+    fmt = kron_format(Ql.shape, Qr.shape)
+    if fmt == "dense_dense":
+        return _update_precond_dense_dense(Ql, Qr, dX, dG, step)                            # psgd.py:84
+    if fmt == "dense_norm":
+        return _update_precond_norm_dense(Qr, Ql, dX.t(), dG.t(), step)[::-1]               # :86
+    if fmt == "dense_scale":
+        return _update_precond_dense_scale(Ql, Qr, dX, dG, step)                            # :88
+    if fmt == "norm_dense":
+        return _update_precond_norm_dense(Ql, Qr, dX, dG, step)                             # :94
+    if fmt == "norm_scale":
+        return _update_precond_norm_scale(Ql, Qr, dX, dG, step)                             # :96
+    if fmt == "scale_dense":
+        return _update_precond_dense_scale(Qr, Ql, dX.t(), dG.t(), step)[::-1]              # :102
+    if fmt == "scale_norm":
+        return _update_precond_norm_scale(Qr, Ql, dX.t(), dG.t(), step)[::-1]               # :104
+    print("Unknown Kronecker product preconditioner, no update")                            # :90,98,106,109
+    return Ql, Qr
+
+
+def precond_grad_kron(Ql, Qr, Grad):
+    _check_rank2_f32("precond_grad_kron", Ql, Qr, Grad)
+    fmt = kron_format(Ql.shape, Qr.shape)
+    if fmt == "dense_dense":
+        return _precond_grad_dense_dense(Ql, Qr, Grad)                                      # psgd.py:126
+    if fmt == "dense_norm":
+        return _precond_grad_norm_dense(Qr, Ql, Grad.t()).t()                               # :128
+    if fmt == "dense_scale":
+        return _precond_grad_dense_scale(Ql, Qr, Grad)                                      # :130
+    if fmt == "norm_dense":
+        return _precond_grad_norm_dense(Ql, Qr, Grad)                                       # :136
+    if fmt == "norm_scale":
+        return _precond_grad_norm_scale(Ql, Qr, Grad)                                       # :138
+    if fmt == "scale_dense":
+        return _precond_grad_dense_scale(Qr, Ql, Grad.t()).t()                              # :144
+    if fmt == "scale_norm":
+        return _precond_grad_norm_scale(Qr, Ql, Grad.t()).t()                               # :146
+    print("Unknown Kronecker product preconditioner, no preconditioning")                   # :132,140,148,151
+    return Grad

@@ -1,0 +1,323 @@
+"""MI355X-native PSGD preconditioner engine -- host-side mirror of the reference module.
+
+Same module name, function names, positional order and defaults as the reference
+``preconditioned_stochastic_gradient_descent.py`` ("psgd.py" in the citations), so the
+demo drivers' call patterns (``import preconditioned_stochastic_gradient_descent as psgd``,
+hello_psgd.py:5) carry over with torch tensors in place of tf tensors:
+
+    update_precond_dense(Q, dxs, dgs, step=0.01) -> Q                  psgd.py:26
+    precond_grad_dense(Q, grads) -> list                               psgd.py:45
+    update_precond_kron(Ql, Qr, dX, dG, step=0.01) -> (Ql, Qr)         psgd.py:72
+    precond_grad_kron(Ql, Qr, Grad) -> Tensor                          psgd.py:116
+    IpUVtmatvec(U, V, x)                                               psgd.py:540
+    update_precond_UVd_math_(U, V, d, v, h, step, tiny) -> None        psgd.py:554  (in place)
+    precond_grad_UVd_math(U, V, d, g) -> Tensor                        psgd.py:619
+    class UVd(...).step(closure)                                       psgd.py:630
+
+The UVd and Kron dense(x)dense arithmetic runs in hand-written HIP kernels behind the
+C ABI of include/psgd_hip.h (bound in _lib.py).  Tensors must be fp32, contiguous and
+resident on a ROCm device; anything else raises -- there is no CPU fallback for the
+hot path.  The dense preconditioner (psgd.py:26-63) is host-side plumbing on torch ops
+(2x2 matrices, never a kernel target).
+
+The reference draws its two branch decisions (psgd.py:562, :588) from TensorFlow's
+global RNG; here they come from a torch.Generator (module default, or ``generator=``)
+or are fixed through the keyword-only ``balance=`` / ``update_U=`` arguments.
+"""
+import math
+
+import torch
+
+from . import _lib
+from . import kron as _kron
+
+dtype = torch.float32                                  # psgd.py:20
+_tiny = torch.finfo(torch.float32).tiny                # psgd.py:22 (smallest normal fp32)
+
+_branch_rng = torch.Generator(device="cpu")
+_branch_rng.manual_seed(0x50534744)
+
+
+def manual_seed(seed):
+    """Seed the generator behind the branch draws of update_precond_UVd_math_ and UVd.step."""
+    _branch_rng.manual_seed(int(seed))
+
+
+# --------------------------------------------------------------------------- helpers
+_ws_cache = {}
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_hip(name, *tensors):
+    for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s: expected torch tensors, got %r" % (name, type(t)))
+        if not t.is_cuda:
+            raise _lib.PsgdHipError("%s runs on the HIP device only (tensor is on %s); no CPU fallback" % (name, t.device))
+        if t.dtype != torch.float32:
+            raise TypeError("%s: fp32 tensors required, got %s" % (name, t.dtype))
+        if not t.is_contiguous():
+            raise ValueError("%s: contiguous tensors required" % name)
+    dev = tensors[0].device
+    for t in tensors:
+        if t.device != dev:
+            raise ValueError("%s: all tensors must be on one device" % name)
+    return dev
+
+
+def uvd_workspace(device, N, r):
+    """Cached device workspace for a shard of N rows at rank r (see psgd_uvd_workspace_bytes)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(N), int(r))
+    ws = _ws_cache.get(key)
+    if ws is None:
+        nbytes = _lib.load().psgd_uvd_workspace_bytes(N, r)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "psgd_uvd_workspace_bytes")
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _uvd_shapes(name, U, V, *cols):
+    if U.dim() != 2 or V.shape != U.shape:
+        raise ValueError("%s: U and V must both be [N, r]" % name)
+    N, r = U.shape
+    for c in cols:
+        if c.numel() != N or (c.dim() == 2 and c.shape[1] != 1) or c.dim() > 2:
+            raise ValueError("%s: column vectors must be [N] or [N, 1] with N = %d" % (name, N))
+    return N, r
+
+
+# --------------------------------------------------------------------------- dense (plumbing)
+def update_precond_dense(Q, dxs, dgs, step=0.01):
+    """psgd.py:26-42.  Host-side plumbing on torch ops (config 1, hello_psgd: 2x2 on CPU)."""
+    dx = torch.cat([torch.reshape(x, [-1, 1]) for x in dxs], 0)
+    dg = torch.cat([torch.reshape(g, [-1, 1]) for g in dgs], 0)
+    a = Q @ dg
+    b = torch.linalg.solve_triangular(Q.t(), dx, upper=False)      # Q^T b = dx  (:39, adjoint=True)
+    grad = torch.triu(a @ a.t() - b @ b.t())
+    step0 = step / (torch.max(torch.abs(grad)) + torch.finfo(Q.dtype).tiny)
+    return Q - (step0 * grad) @ Q
+
+
+def precond_grad_dense(Q, grads):
+    """psgd.py:45-63: list in, list out with the original shapes."""
+    cols = [torch.reshape(g, [-1, 1]) for g in grads]
+    lens = [c.shape[0] for c in cols]
+    grad = torch.cat(cols, 0)
+    pre_grad = Q.t() @ (Q @ grad)
+    pre_grads, idx = [], 0
+    for g, n in zip(grads, lens):
+        pre_grads.append(torch.reshape(pre_grad[idx:idx + n], g.shape))
+        idx = idx + n
+    return pre_grads
+
+
+# --------------------------------------------------------------------------- Kron
+def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
+    """psgd.py:72-110 (shape dispatch of SURVEY Appendix B); returns (Ql_new, Qr_new)."""
+    return _kron.update_precond_kron(Ql, Qr, dX, dG, step)
+
+
+def precond_grad_kron(Ql, Qr, Grad):
+    """psgd.py:116-152; returns the preconditioned gradient, same shape as Grad."""
+    return _kron.precond_grad_kron(Ql, Qr, Grad)
+
+
+# --------------------------------------------------------------------------- UVd math
+def IpUVtmatvec(U, V, x):
+    """psgd.py:540-544: (I + U V') x for a column vector x ([N] or [N,1]) or [N,k] matrix."""
+    dev = _require_hip("IpUVtmatvec", U, V, x)
+    if x.dim() == 2 and x.shape[1] > 1:
+        cols = [IpUVtmatvec(U, V, x[:, j].contiguous()) for j in range(x.shape[1])]
+        return torch.stack(cols, 1)
+    N, r = _uvd_shapes("IpUVtmatvec", U, V, x)
+    out = torch.empty_like(x)
+    ws = uvd_workspace(dev, N, r)
+    rc = _lib.load().psgd_uvd_ipuvt_matvec_f32(U.data_ptr(), V.data_ptr(), x.data_ptr(), out.data_ptr(), N, r,
+                                                ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "psgd_uvd_ipuvt_matvec_f32")
+    return out
+
+
+def precond_grad_UVd_math(U, V, d, g):
+    """psgd.py:619-627: d .* (I + V U')(I + U V')(d .* g); returns a new tensor shaped like g."""
+    dev = _require_hip("precond_grad_UVd_math", U, V, d, g)
+    N, r = _uvd_shapes("precond_grad_UVd_math", U, V, d, g)
+    out = torch.empty_like(g)
+    ws = uvd_workspace(dev, N, r)
+    rc = _lib.load().psgd_uvd_apply_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), g.data_ptr(), out.data_ptr(),
+                                         N, r, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "psgd_uvd_apply_f32")
+    return out
+
+
+def _draw_branch(p, generator):
+    gen = generator if generator is not None else _branch_rng
+    return bool(torch.rand((), generator=gen).item() < p)
+
+
+def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_U=None, generator=None):
+    """psgd.py:554-617.  Updates U or V, and d, IN PLACE; returns None.
+
+    balance / update_U fix the two random branches of the reference (:562 p=0.01, :588 p=0.5);
+    left at None they are drawn from `generator` (a CPU torch.Generator; module default otherwise),
+    in the reference's order."""
+    dev = _require_hip("update_precond_UVd_math_", U, V, d, v, h)
+    N, r = _uvd_shapes("update_precond_UVd_math_", U, V, d, v, h)
+    if balance is None:
+        balance = _draw_branch(0.01, generator)
+    if update_U is None:
+        update_U = _draw_branch(0.5, generator)
+    ws = uvd_workspace(dev, N, r)
+    rc = _lib.load().psgd_uvd_update_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), N, r,
+                                          float(step), float(tiny), int(bool(balance)), int(bool(update_U)),
+                                          ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "psgd_uvd_update_f32")
+    return None
+
+
+# --------------------------------------------------------------------------- UVd optimizer wrapper
+class _Hyper:
+    """Stand-in for the non-trainable tf.Variable hyper-parameters of psgd.py:673-680:
+    change them with .assign(value), read them with float()/bool()."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def assign(self, value):
+        self.value = value.value if isinstance(value, _Hyper) else value
+        return self
+
+    def numpy(self):
+        return self.value
+
+    def __float__(self):
+        return float(self.value)
+
+    def __bool__(self):
+        return bool(self.value)
+
+    def __repr__(self):
+        return "_Hyper(%r)" % (self.value,)
+
+
+def uvd_param_index(params):
+    """psgd.py:684-686: sizes and cumulative sizes of the parameters, in list order."""
+    sizes = [int(p.numel()) for p in params]
+    cumsizes, acc = [], 0
+    for s in sizes:
+        acc += s
+        cumsizes.append(acc)
+    return sizes, cumsizes
+
+
+def _flatten_params(params_with_grad):
+    """tf.nest.flatten order (psgd.py:668-669): depth-first through lists/tuples/dicts (dict keys sorted)."""
+    if isinstance(params_with_grad, torch.Tensor):
+        return [params_with_grad]
+    out = []
+    if isinstance(params_with_grad, dict):
+        for k in sorted(params_with_grad):
+            out.extend(_flatten_params(params_with_grad[k]))
+    else:
+        for p in params_with_grad:
+            out.extend(_flatten_params(p))
+    return out
+
+
+class UVd:
+    """Low-rank modification (UVd) preconditioner as an optimizer, psgd.py:630-764.
+
+    Same constructor arguments and defaults as the reference (psgd.py:663-666).  Parameters are
+    torch tensors with requires_grad=True on a ROCm device (the reference's `.trainable` filter,
+    :670, maps to requires_grad).  `step(closure)` returns whatever closure returns (:764)."""
+
+    def __init__(self, params_with_grad, rank_of_modification: int = 10, preconditioner_init_scale=1.0,
+                 lr_params=0.01, lr_preconditioner=0.01,
+                 grad_clip_max_norm=None, preconditioner_update_probability=1.0,
+                 exact_hessian_vector_product: bool = True, generator=None):
+        params = _flatten_params(params_with_grad)
+        self._params_with_grad = [p for p in params if p.requires_grad]                      # :670
+        p0 = self._params_with_grad[0]
+        self._dtype = p0.dtype                                                               # :671
+        if self._dtype != torch.float32:
+            raise TypeError("UVd: the HIP engine computes in fp32 only")
+        self._device = p0.device
+        self.lr_params = _Hyper(lr_params)                                                   # :673
+        self.lr_preconditioner = _Hyper(lr_preconditioner)                                   # :674
+        self.grad_clip_max_norm = _Hyper(math.inf if grad_clip_max_norm is None else grad_clip_max_norm)  # :675-678
+        self.preconditioner_update_probability = _Hyper(preconditioner_update_probability)  # :679
+        self.exact_hessian_vector_product = _Hyper(bool(exact_hessian_vector_product))       # :680
+        self._tiny = torch.finfo(self._dtype).tiny                                           # :682
+        self._delta_param_scale = torch.finfo(self._dtype).eps ** 0.5                        # :683
+        self._param_sizes, self._param_cumsizes = uvd_param_index(self._params_with_grad)    # :684-685
+        num_params = self._param_cumsizes[-1]                                                # :686
+        r = int(rank_of_modification)
+        uv_scale = (1.0 / (num_params * r)) ** 0.5                                           # :687
+        self._generator = generator
+        self._U = torch.randn(num_params, r, dtype=self._dtype, device=self._device) * uv_scale      # :688
+        self._V = torch.randn(num_params, r, dtype=self._dtype, device=self._device) * uv_scale      # :689
+        self._d = torch.ones(num_params, 1, dtype=self._dtype, device=self._device) * preconditioner_init_scale  # :690
+
+    def _loss_of(self, closure_returns):
+        return closure_returns if isinstance(closure_returns, torch.Tensor) else closure_returns[0]
+
+    def step(self, closure):
+        """psgd.py:692-764."""
+        params = self._params_with_grad
+        update_Q = _draw_branch(float(self.preconditioner_update_probability), self._generator)   # :703
+        exact = bool(self.exact_hessian_vector_product)
+        vs = None
+        if update_Q:
+            if exact:                                                                         # :706-714
+                with torch.enable_grad():
+                    closure_returns = closure()
+                    loss = self._loss_of(closure_returns)
+                    grads = torch.autograd.grad(loss, params, create_graph=True)
+                    vs = [torch.randn_like(p) for p in params]
+                    Hvs = torch.autograd.grad(grads, params, vs)
+                grads = [g.detach() for g in grads]
+            else:                                                                             # :715-727
+                with torch.enable_grad():
+                    closure_returns = closure()
+                    grads = torch.autograd.grad(self._loss_of(closure_returns), params)
+                vs = [torch.randn_like(p) * self._delta_param_scale for p in params]
+                with torch.no_grad():
+                    for p, v in zip(params, vs):
+                        p.add_(v)
+                with torch.enable_grad():
+                    perturbed_grads = torch.autograd.grad(self._loss_of(closure()), params)
+                Hvs = [pg - g for pg, g in zip(perturbed_grads, grads)]
+            v = torch.cat([torch.reshape(x, [-1]) for x in vs], 0)                            # :729
+            h = torch.cat([torch.reshape(x, [-1]) for x in Hvs], 0)                           # :730
+            if not exact:                                                                     # :734-736
+                v = v / self._delta_param_scale
+                h = h / self._delta_param_scale
+            update_precond_UVd_math_(self._U, self._V, self._d, v[:, None].contiguous(), h[:, None].contiguous(),
+                                     step=float(self.lr_preconditioner), tiny=self._tiny,
+                                     generator=self._generator)
+        else:                                                                                 # :737-744
+            with torch.enable_grad():
+                closure_returns = closure()
+                grads = torch.autograd.grad(self._loss_of(closure_returns), params)
+
+        grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0)                          # :747
+        pre_grad = precond_grad_UVd_math(self._U, self._V, self._d, grad[:, None].contiguous())   # :748
+        max_norm = float(self.grad_clip_max_norm)
+        if math.isinf(max_norm):                                                              # :750-751
+            lr = float(self.lr_params)
+        else:                                                                                 # :753-754
+            grad_norm = torch.sqrt(torch.sum(pre_grad * pre_grad)) + self._tiny
+            lr = float(self.lr_params) * torch.clamp(max_norm / grad_norm, max=1.0)
+        with torch.no_grad():                                                                 # :757-762
+            undo = (not exact) and update_Q
+            for k, (p, i, j) in enumerate(zip(params, self._param_sizes, self._param_cumsizes)):
+                delta = lr * torch.reshape(pre_grad[j - i:j], p.shape)
+                if undo:
+                    delta = delta + vs[k]
+                p.sub_(delta)
+        return closure_returns                                                                # :764

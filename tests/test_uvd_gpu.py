@@ -1,0 +1,164 @@
+"""GPU parity: HIP UVd path (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerance (BASELINE.json north_star): preconditioned gradient within 1e-5 relative (norm-wise)
+of the fp64 oracle; the updated state U, V, d within 1e-5 as well, and the *increment* of an
+update (a quantity ~step = 1e-2 of the state) within 2e-3 of the fp64 increment.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import psgd_oracle as orc
+from tests.uvd_cases import TINY32, make_uvd_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+
+APPLY_TOL = 1e-5
+STATE_TOL = 1e-5
+INCR_TOL = 2e-3
+
+# (N, r): tile edges (63/64/65 rows), ragged tails, every load-width class of the tile
+# config (r % 4 == 0, r % 2 == 0, odd), the extremes r = 1 and r = 32, N = 1.
+SHAPES = [(1, 4), (63, 20), (64, 20), (65, 20), (777, 3), (1000, 1), (1021, 10), (4096, 10), (5000, 20),
+          (2049, 32), (1537, 17), (3000, 18), (2500, 9), (4099, 7), (100003, 20), (300001, 10), (50000, 31)]
+
+
+def _to_dev(p):
+    return {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+
+
+def _f64(p):
+    return {k: v.astype(np.float64) for k, v in p.items()}
+
+
+@pytest.fixture(scope="module")
+def psgd(hip_lib):
+    import preconditioned_stochastic_gradient_descent as m
+    assert torch.cuda.is_available()
+    return m
+
+
+@pytest.mark.parametrize("N,r", SHAPES)
+@pytest.mark.parametrize("uv_gain,d_spread", [(1.0, 0.0), (3.0, 0.5)])
+def test_precond_grad_matches_oracle(psgd, N, r, uv_gain, d_spread):
+    p = make_uvd_problem(N, r, seed=N + r, uv_gain=uv_gain, d_spread=d_spread)
+    t = _to_dev(p)
+    out = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    assert out.shape == t["g"].shape and out.dtype == torch.float32
+    q = _f64(p)
+    ref = orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])
+    assert rel_err(out.cpu().numpy(), ref) < APPLY_TOL
+    # inputs untouched
+    for k in ("U", "V", "d", "g"):
+        assert np.array_equal(t[k].cpu().numpy(), p[k])
+
+
+@pytest.mark.parametrize("N,r", [(1021, 10), (5000, 20), (777, 3), (2049, 32)])
+def test_ipuvt_matvec(psgd, N, r):
+    p = make_uvd_problem(N, r, seed=7)
+    t = _to_dev(p)
+    out = psgd.IpUVtmatvec(t["U"], t["V"], t["g"])
+    q = _f64(p)
+    assert rel_err(out.cpu().numpy(), orc.IpUVtmatvec(q["U"], q["V"], q["g"])) < APPLY_TOL
+    x2 = torch.stack([t["g"][:, 0], t["v"][:, 0]], 1).contiguous()
+    out2 = psgd.IpUVtmatvec(t["U"], t["V"], x2)
+    ref2 = orc.IpUVtmatvec(q["U"], q["V"], np.concatenate([q["g"], q["v"]], 1))
+    assert rel_err(out2.cpu().numpy(), ref2) < APPLY_TOL
+
+
+@pytest.mark.parametrize("N,r", SHAPES)
+@pytest.mark.parametrize("update_U", [True, False])
+def test_update_matches_oracle(psgd, N, r, update_U):
+    if N < r:   # K = I + V'U stays well conditioned only with enough rows; N = 1 covered below
+        pytest.skip("degenerate")
+    p = make_uvd_problem(N, r, seed=3 * N + r, uv_gain=2.0, d_spread=0.3)
+    t = _to_dev(p)
+    ret = psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32,
+                                        balance=False, update_U=update_U)
+    assert ret is None
+    q = _f64(p)
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False,
+                                 update_U=update_U)
+    got = {k: t[k].cpu().numpy() for k in ("U", "V", "d")}
+    for k in ("U", "V", "d"):
+        assert rel_err(got[k], q[k]) < STATE_TOL, k
+    changed, frozen = ("U", "V") if update_U else ("V", "U")
+    assert np.array_equal(got[frozen], p[frozen])            # only one factor changes (psgd.py:586)
+    for k in (changed, "d"):
+        inc_ref = q[k] - p[k].astype(np.float64)
+        inc_got = got[k].astype(np.float64) - p[k].astype(np.float64)
+        assert rel_err(inc_got, inc_ref) < INCR_TOL, k
+    # v, h read-only
+    assert np.array_equal(t["v"].cpu().numpy(), p["v"]) and np.array_equal(t["h"].cpu().numpy(), p["h"])
+
+
+@pytest.mark.parametrize("N,r", [(5000, 20), (1021, 10), (4099, 7)])
+def test_update_balance_branch(psgd, N, r):
+    p = make_uvd_problem(N, r, seed=11, uv_gain=2.0)
+    p["U"] *= 7.0       # make rho != 1
+    t = _to_dev(p)
+    psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32, balance=True, update_U=True)
+    q = _f64(p)
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=True, update_U=True)
+    for k in ("U", "V", "d"):
+        assert rel_err(t[k].cpu().numpy(), q[k]) < STATE_TOL, k
+
+
+def test_update_then_apply_sequence(psgd):
+    """Ten alternating updates followed by an apply, against the fp64 oracle run on the same stream
+    of inputs (the UVd.step call pattern, psgd.py:732 -> :748)."""
+    N, r = 20000, 10
+    p = make_uvd_problem(N, r, seed=5)
+    t = _to_dev(p)
+    q = _f64(p)
+    rng = np.random.default_rng(99)
+    for it in range(10):
+        v = rng.standard_normal((N, 1)).astype(np.float32)
+        h = (np.exp(rng.uniform(np.log(1e-2), np.log(1e2), (N, 1))) * v).astype(np.float32)
+        upd = (it % 2 == 0)
+        psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], torch.from_numpy(v).cuda(),
+                                      torch.from_numpy(h).cuda(), 0.01, TINY32, balance=(it == 4), update_U=upd)
+        orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], v.astype(np.float64), h.astype(np.float64), 0.01,
+                                     TINY32, balance=(it == 4), update_U=upd)
+    for k in ("U", "V", "d"):
+        assert rel_err(t[k].cpu().numpy(), q[k]) < 5e-5, k
+    out = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    ref = orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])
+    assert rel_err(out.cpu().numpy(), ref) < 5e-5
+
+
+def test_run_to_run_bitwise_reproducible(psgd):
+    p = make_uvd_problem(100003, 20, seed=1)
+    t = _to_dev(p)
+    a = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    b = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    assert torch.equal(a, b)
+
+
+def test_fixed_point_leaves_state_unchanged(psgd):
+    """KAT-FP: with h = P^-1 v the update gradient vanishes (a = b, nablaD = 0)."""
+    N, r = 3000, 5
+    p = make_uvd_problem(N, r, seed=2, uv_gain=2.0, d_spread=0.2)
+    q = _f64(p)
+    Q = (np.eye(N) + q["U"] @ q["V"].T) * q["d"].T                   # Q = (I + U V') diag(d)
+    h = np.linalg.solve(Q.T @ Q, q["v"])                             # P h = v
+    t = _to_dev(p)
+    t["h"] = torch.from_numpy(h.astype(np.float32)).cuda()
+    psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32, balance=False,
+                                  update_U=True)
+    # nablaD is pure rounding noise, normalised to max |.| = step: d moves by at most step, U by ~noise
+    assert rel_err(t["d"].cpu().numpy(), p["d"]) < 0.011
+    assert np.isfinite(t["U"].cpu().numpy()).all()
+
+
+def test_rejects_bad_arguments(psgd):
+    from psgd_tf_amd._lib import PsgdHipError
+    p = make_uvd_problem(100, 4)
+    t = _to_dev(p)
+    with pytest.raises(PsgdHipError):
+        psgd.precond_grad_UVd_math(t["U"].cpu(), t["V"].cpu(), t["d"].cpu(), t["g"].cpu())
+    with pytest.raises(TypeError):
+        psgd.precond_grad_UVd_math(t["U"].double(), t["V"].double(), t["d"].double(), t["g"].double())
+    big = torch.zeros(100, 33, device="cuda")
+    with pytest.raises(PsgdHipError):
+        psgd.precond_grad_UVd_math(big, big.clone(), t["d"], t["g"])
