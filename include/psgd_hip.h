@@ -126,6 +126,26 @@ int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,
  * key 1: cap on blocks per CU for the sweeps (0 = occupancy query).        */
 int psgd_set_tuning(int key, int value);
 
+/* ----------------------------------------------------------------- Kron ---
+ * P = kron(Qr'Qr, Ql'Ql) with dense upper-triangular Ql [M,M], Qr [N,N]
+ * (psgd.py:156-192).  G, dX, dG are [M,N] row-major.                       */
+
+int64_t psgd_kron_dd_workspace_bytes(int M, int N);
+
+/* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.
+ * Association order follows the reference: M < N uses ((Ql'Ql) G) Qr' Qr,
+ * otherwise Ql' (Ql (G (Qr'Qr))).                                          */
+int psgd_kron_dd_apply_f32(const float *Ql, const float *Qr, const float *G,
+                           float *out, int M, int N, void *ws,
+                           int64_t ws_bytes, void *stream);
+
+/* _update_precond_dense_dense(Ql, Qr, dX, dG, step)  psgd.py:156-179.
+ * Pure: Ql, Qr are read, the new factors are written to QlOut, QrOut.      */
+int psgd_kron_dd_update_f32(const float *Ql, const float *Qr, const float *dX,
+                            const float *dG, float *QlOut, float *QrOut,
+                            int M, int N, float step, float tiny, void *ws,
+                            int64_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,10 @@ SIGNATURES = {
                                           _c_ws, _i64, _strm]),
     "psgd_uvd_update_sweep3_f32": (_int, [_c_f32p, _i64, _int, _flt, _flt, _c_ws, _i64, _strm]),
     "psgd_uvd_ipuvt_matvec_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_workspace_bytes": (_i64, [_int, _int]),
+    "psgd_kron_dd_apply_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_update_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _flt, _flt,
+                                       _c_ws, _i64, _strm]),
 }
 
 _lib = None

@@ -48,9 +48,12 @@ constexpr int cfg_load_vec(int R) {
   return (64 * cfg_rows_per_lane(R, 4) * R <= kMaxTileFloats) ? 4
        : (64 * cfg_rows_per_lane(R, 2) * R <= kMaxTileFloats) ? 2 : 1;
 }
+// native clang vector types (HIP's float4 is a struct-with-union that blocks SROA of
+// register arrays: the prefetch buffers ended up in scratch memory with it)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int LV> struct VecT;
-template <> struct VecT<4> { typedef float4 type; };
-template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<4> { typedef f32x4 type; };
+template <> struct VecT<2> { typedef f32x2 type; };
 template <> struct VecT<1> { typedef float type; };
 
 template <int R>
@@ -110,7 +113,18 @@ __device__ __forceinline__ void commit_tile(const Prefetch<R, NMAT, NVEC>& pf, f
 #pragma unroll
     for (int j = 0; j < C::kLoadsPerLane; ++j) dst[lane + 64 * j] = pf.m[m][j];
   }
+  // the per-row vectors go through LDS as well (each lane reads back its own values): every
+  // register a global load targets is then consumed here, at the top of the loop, so nothing
+  // loop-carried forces an early s_waitcnt on the next tile's loads.
+  float* sv = lds + NMAT * C::kTileFloats;
+#pragma unroll
+  for (int k = 0; k < NVEC; ++k)
+#pragma unroll
+    for (int i = 0; i < C::kRowsPerLane; ++i) sv[k * C::kTileRows + lane + 64 * i] = pf.s[k][i];
 }
+
+template <int R, int NMAT, int NVEC>
+constexpr int sweep_lds_floats() { return NMAT * Cfg<R>::kTileFloats + NVEC * Cfg<R>::kTileRows; }
 
 template <int R>
 __device__ __forceinline__ void read_row(const float* tile, int row, float (&x)[R]) {
@@ -118,14 +132,14 @@ __device__ __forceinline__ void read_row(const float* tile, int row, float (&x)[
   if constexpr (R % 4 == 0) {
 #pragma unroll
     for (int c = 0; c < R / 4; ++c) {
-      const float4 q = reinterpret_cast<const float4*>(p)[c];
-      x[4 * c + 0] = q.x; x[4 * c + 1] = q.y; x[4 * c + 2] = q.z; x[4 * c + 3] = q.w;
+      const f32x4 q = reinterpret_cast<const f32x4*>(p)[c];
+      x[4 * c + 0] = q[0]; x[4 * c + 1] = q[1]; x[4 * c + 2] = q[2]; x[4 * c + 3] = q[3];
     }
   } else if constexpr (R % 2 == 0) {
 #pragma unroll
     for (int c = 0; c < R / 2; ++c) {
-      const float2 q = reinterpret_cast<const float2*>(p)[c];
-      x[2 * c + 0] = q.x; x[2 * c + 1] = q.y;
+      const f32x2 q = reinterpret_cast<const f32x2*>(p)[c];
+      x[2 * c + 0] = q[0]; x[2 * c + 1] = q[1];
     }
   } else {
 #pragma unroll
@@ -139,10 +153,10 @@ __device__ __forceinline__ void write_row(float* tile, int row, const float (&x)
   if constexpr (R % 4 == 0) {
 #pragma unroll
     for (int c = 0; c < R / 4; ++c)
-      reinterpret_cast<float4*>(p)[c] = make_float4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+      reinterpret_cast<f32x4*>(p)[c] = f32x4{x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]};
   } else if constexpr (R % 2 == 0) {
 #pragma unroll
-    for (int c = 0; c < R / 2; ++c) reinterpret_cast<float2*>(p)[c] = make_float2(x[2 * c], x[2 * c + 1]);
+    for (int c = 0; c < R / 2; ++c) reinterpret_cast<f32x2*>(p)[c] = f32x2{x[2 * c], x[2 * c + 1]};
   } else {
 #pragma unroll
     for (int c = 0; c < R; ++c) p[c] = x[c];
@@ -165,16 +179,13 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
 
   Prefetch<R, NMAT, NVEC> pf;
   long tile = gw;
+  // The prefetch is unconditional (the last iteration re-reads its own tile) so that the
+  // buffers stay in registers and the loads stay in flight across the compute phase.
   if (tile < nfull) issue_tile<R, NMAT, NVEC>(pf, mats, vecs, tile, lane);
   while (tile < nfull) {
     commit_tile<R, NMAT, NVEC>(pf, lds, lane);
-    float s_cur[NVEC > 0 ? NVEC : 1][C::kRowsPerLane];
-#pragma unroll
-    for (int k = 0; k < NVEC; ++k)
-#pragma unroll
-      for (int i = 0; i < C::kRowsPerLane; ++i) s_cur[k][i] = pf.s[k][i];
     const long next = tile + nw;
-    if (next < nfull) issue_tile<R, NMAT, NVEC>(pf, mats, vecs, next, lane);
+    issue_tile<R, NMAT, NVEC>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < C::kRowsPerLane; ++i) {
@@ -184,7 +195,7 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
       for (int m = 0; m < NMAT; ++m) read_row<R>(lds + m * C::kTileFloats, rit, x[m]);
       float s[NVEC > 0 ? NVEC : 1];
 #pragma unroll
-      for (int k = 0; k < NVEC; ++k) s[k] = s_cur[k][i];
+      for (int k = 0; k < NVEC; ++k) s[k] = lds[NMAT * C::kTileFloats + k * C::kTileRows + rit];
       body(tile * C::kTileRows + rit, true, x, s);
       if constexpr (WB >= 0) write_row<R>(lds + WB * C::kTileFloats, rit, x[WB]);
     }
@@ -282,7 +293,7 @@ __device__ __forceinline__ float dot_row(const float (&x)[R], const float* __res
 template <int R, int NVEC>
 __global__ __launch_bounds__(kThreads) void k_colreduce(const float* M, const float* a, const float* b,
                                                         long N, float* part) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][Cfg<R>::kTileFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, NVEC>()];
   __shared__ float red[kWavesPerBlock * R];
   float acc[R];
 #pragma unroll
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(kThreads) void k_colreduce(const float* M, const fl
 template <int R>
 __global__ __launch_bounds__(kThreads) void k_apply_s2(const float* U, const float* d, const float* g, long N,
                                                        const float* __restrict__ coef, float* part) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][Cfg<R>::kTileFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 2>()];
   __shared__ float red[kWavesPerBlock * R];
   float acc[R];
 #pragma unroll
@@ -330,7 +341,7 @@ template <int R>
 __global__ __launch_bounds__(kThreads) void k_apply_s3(const float* U, const float* V, const float* d,
                                                        const float* g, float* out, long N,
                                                        const float* __restrict__ coef) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][2 * Cfg<R>::kTileFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 2, 2>()];
   const float* const mats[2] = {U, V};
   const float* const vecs[2] = {d, g};
   sweep_rows<R, 2, 2, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_s3(const float* U, const flo
 template <int R>
 __global__ __launch_bounds__(kThreads) void k_rowdot_axpy(const float* M, const float* xin, float* out, long N,
                                                           const float* __restrict__ coef) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][Cfg<R>::kTileFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 1>()];
   const float* const mats[1] = {M};
   const float* const vecs[1] = {xin};
   sweep_rows<R, 1, 1, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
@@ -366,7 +377,8 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
                                                           const float* v, const float* h, long N, double* part) {
   using C = Cfg<R>;
   using GC = GramCfg<R>;
-  constexpr int kTw = 2 * C::kTileFloats;             // t,w interleaved [kTileRows][2]
+  constexpr int kSv = 2 * C::kTileFloats;             // staged d, v, h (3 x kTileRows) from commit_tile
+  constexpr int kTw = kSv + 3 * C::kTileRows;         // t,w interleaved [kTileRows][2]
   constexpr int kZero = kTw + 2 * C::kTileRows;       // 4 zero floats
   constexpr int kWaveFloats = kZero + 4;
   constexpr int kTileBytes = kWavesPerBlock * kWaveFloats * 4;
@@ -433,13 +445,13 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
     commit_tile<R, 2, 3>(pf, lds, lane);
 #pragma unroll
     for (int i = 0; i < C::kRowsPerLane; ++i) {
-      const float dd = pf.s[0][i];
-      const float t = dd * pf.s[2][i];
-      const float ww = pf.s[1][i] / dd;
-      reinterpret_cast<float2*>(lds + kTw)[lane + 64 * i] = make_float2(t, ww);
+      const float dd = lds[kSv + 0 * C::kTileRows + lane + 64 * i];
+      const float vv = lds[kSv + 1 * C::kTileRows + lane + 64 * i];
+      const float hh = lds[kSv + 2 * C::kTileRows + lane + 64 * i];
+      reinterpret_cast<f32x2*>(lds + kTw)[lane + 64 * i] = f32x2{dd * hh, vv / dd};
     }
     const long next = tile + nw;
-    if (next < nfull) issue_tile<R, 2, 3>(pf, mats, vecs, next, lane);
+    issue_tile<R, 2, 3>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
     __builtin_amdgcn_wave_barrier();
     gram_tile();
     __builtin_amdgcn_wave_barrier();
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
         t = dd * h[row0 + rit];
         ww = v[row0 + rit] / dd;
       }
-      reinterpret_cast<float2*>(lds + kTw)[rit] = make_float2(t, ww);
+      reinterpret_cast<f32x2*>(lds + kTw)[rit] = f32x2{t, ww};
     }
     __builtin_amdgcn_wave_barrier();
     gram_tile();
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, cons
                                                         const float* h, long N, const float* __restrict__ coef,
                                                         float* nabla, float* part_max) {
   using K = UpdCoef<R>;
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][2 * Cfg<R>::kTileFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 2, 3>()];
   __shared__ float red[kWavesPerBlock];
   float vmax = 0.0f;
   const float mu = coef[K::kMu];

@@ -1,0 +1,141 @@
+"""GPU parity: Kronecker-product preconditioner (HIP dense(x)dense through the C ABI, the sparse
+formats through the same dispatcher) vs the CPU oracle on identical seeded inputs.
+
+Tolerance: 1e-5 relative (norm-wise) against the fp64 oracle for the preconditioned gradient
+and for the updated factors; the update increment (~step of the factor) within 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import psgd_oracle as orc
+from tests.uvd_cases import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+INCR_TOL = 2e-3
+
+# LeNet5 affine shapes (mnist_with_lenet5.py:12-16), LSTM shapes (lstm_with_xor_problem.py),
+# the 1x1 dense factor of the NMT demo (:124), tile edges of the 64x64 GEMM blocks and 32-wide
+# triangular-solve blocks, and one larger case.
+DD_SHAPES = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (1, 1), (1, 7), (3, 3),
+             (2, 2), (64, 64), (65, 33), (32, 97), (128, 200), (300, 500), (512, 384)]
+
+
+def _tri_factor(rng, n, off=0.05):
+    return np.triu(rng.standard_normal((n, n)) * off, 1) + np.diag(np.exp(0.3 * rng.standard_normal(n)))
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+@pytest.fixture(scope="module")
+def psgd(hip_lib):
+    import preconditioned_stochastic_gradient_descent as m
+    return m
+
+
+@pytest.mark.parametrize("M,N", DD_SHAPES)
+def test_dense_dense_apply(psgd, M, N):
+    rng = np.random.default_rng(M * 1000 + N)
+    Ql, Qr = _tri_factor(rng, M), _tri_factor(rng, N)
+    G = rng.standard_normal((M, N))
+    Ql32, Qr32, G32 = (a.astype(np.float32) for a in (Ql, Qr, G))
+    out = psgd.precond_grad_kron(_dev(Ql32), _dev(Qr32), _dev(G32))
+    ref = orc.precond_grad_kron(Ql32.astype(np.float64), Qr32.astype(np.float64), G32.astype(np.float64))
+    assert out.shape == (M, N)
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("M,N", DD_SHAPES)
+def test_dense_dense_update(psgd, M, N):
+    rng = np.random.default_rng(M * 77 + N)
+    Ql, Qr = _tri_factor(rng, M) * 3.0, _tri_factor(rng, N)      # rho != 1
+    dX = rng.standard_normal((M, N))
+    Hl = np.eye(M) + 0.1 * np.diag(rng.uniform(0, 5, M))
+    Hr = np.eye(N) + 0.1 * np.diag(rng.uniform(0, 5, N))
+    dG = Hl @ dX @ Hr
+    a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG)]
+    dQl, dQr = _dev(a32[0]), _dev(a32[1])
+    Ql_n, Qr_n = psgd.update_precond_kron(dQl, dQr, _dev(a32[2]), _dev(a32[3]), 0.01)
+    a64 = [a.astype(np.float64) for a in a32]
+    Ql_r, Qr_r = orc.update_precond_kron(*a64, 0.01)
+    assert rel_err(Ql_n.cpu().numpy(), Ql_r) < TOL
+    assert rel_err(Qr_n.cpu().numpy(), Qr_r) < TOL
+    # pure: inputs untouched (psgd.py:179 returns new tensors)
+    assert np.array_equal(dQl.cpu().numpy(), a32[0]) and np.array_equal(dQr.cpu().numpy(), a32[1])
+    # increments relative to the balanced factors (psgd.py:169-170)
+    rho = np.sqrt(np.max(np.diag(a64[0])) / np.max(np.diag(a64[1])))
+    for got, ref, base in ((Ql_n, Ql_r, a64[0] / rho), (Qr_n, Qr_r, a64[1] * rho)):
+        inc_ref = ref - base
+        if np.linalg.norm(inc_ref) > 0:
+            assert rel_err(got.cpu().numpy().astype(np.float64) - base, inc_ref) < INCR_TOL
+    # KAT-TRI: upper-triangular with positive diagonal
+    for Qn in (Ql_n, Qr_n):
+        q = Qn.cpu().numpy()
+        assert np.array_equal(q, np.triu(q)) and (np.diag(q) > 0).all()
+
+
+def test_dense_dense_sequence_lenet(psgd):
+    """Ten update steps from Ql = I, Qr = I on the LeNet5 W3 shape, then an apply (mnist_with_lenet5.py:51-53)."""
+    M, N = 257, 120
+    rng = np.random.default_rng(0)
+    Ql, Qr = np.eye(M), np.eye(N)
+    tQl, tQr = _dev(Ql), _dev(Qr)
+    Hl = np.diag(np.exp(rng.uniform(-1, 1, M)))
+    Hr = np.diag(np.exp(rng.uniform(-1, 1, N)))
+    for _ in range(10):
+        dX = rng.standard_normal((M, N)).astype(np.float32)
+        dG = (Hl @ dX @ Hr).astype(np.float32)
+        tQl, tQr = psgd.update_precond_kron(tQl, tQr, _dev(dX), _dev(dG), 0.01)
+        Ql, Qr = orc.update_precond_kron(Ql, Qr, dX.astype(np.float64), dG.astype(np.float64), 0.01)
+    assert rel_err(tQl.cpu().numpy(), Ql) < 5e-5 and rel_err(tQr.cpu().numpy(), Qr) < 5e-5
+    G = rng.standard_normal((M, N)).astype(np.float32)
+    out = psgd.precond_grad_kron(tQl, tQr, _dev(G))
+    assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(Ql, Qr, G.astype(np.float64))) < 5e-5
+
+
+# every dispatch format of psgd.py:80-110 with shapes from demo_usage_of_all_preconditioners.py:68-78
+FORMATS = {
+    "dense_norm": ((5, 5), (2, 10)), "dense_scale": ((5, 5), (1, 20)), "norm_dense": ((2, 5), (10, 10)),
+    "norm_scale": ((2, 5), (1, 50)), "scale_dense": ((1, 5), (20, 20)), "scale_norm": ((1, 5), (2, 50)),
+}
+
+
+def _factor_for(rng, shape, other_dim):
+    m, n = shape
+    if m == n:
+        return _tri_factor(rng, m)
+    if m == 2:
+        return np.stack([np.exp(0.2 * rng.standard_normal(n)), 0.1 * rng.standard_normal(n)])
+    return np.exp(0.2 * rng.standard_normal((1, n)))
+
+
+@pytest.mark.parametrize("fmt", sorted(FORMATS))
+def test_sparse_formats_through_dispatcher(psgd, fmt):
+    sl, sr = FORMATS[fmt]
+    assert orc.kron_format(sl, sr) == fmt
+    rng = np.random.default_rng(len(fmt))
+    M, N = sl[1], sr[1]
+    Ql, Qr = _factor_for(rng, sl, M), _factor_for(rng, sr, N)
+    dX, G = rng.standard_normal((M, N)), rng.standard_normal((M, N))
+    dG = dX * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))
+    a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG, G)]
+    a64 = [a.astype(np.float64) for a in a32]
+    Ql_n, Qr_n = psgd.update_precond_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[2]), _dev(a32[3]), 0.01)
+    Ql_r, Qr_r = orc.update_precond_kron(a64[0], a64[1], a64[2], a64[3], 0.01)
+    assert Ql_n.shape == sl and Qr_n.shape == sr
+    assert rel_err(Ql_n.cpu().numpy(), Ql_r) < TOL and rel_err(Qr_n.cpu().numpy(), Qr_r) < TOL
+    out = psgd.precond_grad_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[4]))
+    assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(a64[0], a64[1], a64[4])) < TOL
+
+
+def test_unknown_format_passthrough(psgd, capsys):
+    Ql, Qr = torch.ones(2, 5, device="cuda"), torch.ones(2, 7, device="cuda")      # (norm, norm): unknown
+    G = torch.randn(5, 7, device="cuda")
+    a, b = psgd.update_precond_kron(Ql, Qr, G, G, 0.01)
+    assert a is Ql and b is Qr                                                      # psgd.py:97-99
+    assert psgd.precond_grad_kron(Ql, Qr, G) is G                                   # psgd.py:139-141
+    assert "Unknown Kronecker product preconditioner" in capsys.readouterr().out
