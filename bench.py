@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the PSGD preconditioner hot path on MI355X.
+
+Metric (BASELINE.json): params/sec for the UVd update + apply at N = 100M rows, r = 20:
+one "step" = update_precond_UVd_math_(U,V,d,v,h,step,tiny) followed by
+precond_grad_UVd_math(U,V,d,g) (the UVd.step call pattern, psgd.py:732 -> :748) on synthetic
+(g, v, h) already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 row-shards the flat parameter vector: every rank holds --rows rows (weak scaling, global
+N = rows * world) and only the r-dimensional reduced buffers are all-reduced (RCCL).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel (update sweep 2), timed live with HIP events on the launch
+                  stream (psgd_prof_*), algorithmic bytes per launch / average duration vs 8 TB/s;
+                  `paths` adds the same for whole apply / update / step (SURVEY 8d byte counts).
+  cpu_baseline -- the torch-CPU restatement of the reference op sequence (oracle/, "port") timed
+                  on this host's cores on a bounded sample of the same workload (N = 1 run only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TINY = 1.1754943508222875e-38  # psgd.py:22
+STEP = 0.01                    # psgd.py:664 (lr_preconditioner default)
+
+
+def make_inputs(n_local, n_global, r, dev, seed):
+    """SURVEY 8d synthetic inputs: U,V ~ N(0,1)(N r)^-1/2 (psgd.py:687-689), d = 1 (:690),
+    g,v ~ N(0,1) (:713), h = c.*v with c ~ LogUniform[1e-2,1e2]."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    scale = (1.0 / (n_global * r)) ** 0.5
+    U = torch.randn(n_local, r, device=dev, generator=g) * scale
+    V = torch.randn(n_local, r, device=dev, generator=g) * scale
+    d = torch.ones(n_local, 1, device=dev)
+    g1 = torch.Generator(device=dev).manual_seed(seed + 1)
+    grad = torch.randn(n_local, 1, device=dev, generator=g1)
+    v = torch.randn(n_local, 1, device=dev, generator=g1)
+    c = torch.exp(torch.empty(n_local, 1, device=dev).uniform_(-4.605170186, 4.605170186, generator=g1))
+    h = c * v
+    return U, V, d, grad, v, h
+
+
+def cpu_baseline(r, sample_rows, budget_s):
+    """Reference op sequence on torch-CPU (oracle/psgd_oracle_torch.py), update+apply, bounded sample."""
+    from oracle import psgd_oracle_torch as ref
+    cores = torch.get_num_threads()
+    U, V, d, grad, v, h = make_inputs(sample_rows, sample_rows, r, torch.device("cpu"), 0)
+    ref.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=True)   # warm-up
+    ref.precond_grad_UVd_math(U, V, d, grad)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        ref.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(steps % 2 == 1))
+        ref.precond_grad_UVd_math(U, V, d, grad)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 20:
+            break
+    return {"value": sample_rows * steps / el, "unit": "params/s", "cores": cores, "kind": "port",
+            "sample": "torch-CPU restatement of psgd.py:554-627 (TensorFlow unavailable), update+apply, "
+                      "N=%d r=%d fp32, %d steps in %.1f s, %d threads" % (sample_rows, r, steps, el, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows of the flat parameter vector per GPU")
+    ap.add_argument("--rank-r", type=int, default=20, help="rank of modification r")
+    ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import preconditioned_stochastic_gradient_descent as psgd
+    from psgd_tf_amd import _lib, sharded
+    lib = _lib.load()            # fails loudly if the HIP extension is missing
+
+    n_local, r = args.rows, args.rank_r
+    n_global = n_local * world
+    U, V, d, grad, v, h = make_inputs(n_local, n_global, r, dev, seed=1000 * rank)
+
+    if world == 1:
+        def step(i):
+            psgd.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+            return psgd.precond_grad_UVd_math(U, V, d, grad)
+    else:
+        def step(i):
+            sharded.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+            return sharded.precond_grad_UVd_math(U, V, d, grad)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    lib.psgd_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    slot_ms = {}
+    for name, slot in (("apply_s1", 0), ("apply_s2", 1), ("apply_s3", 2), ("update_s1", 3), ("update_s2", 4),
+                       ("update_s3", 5)):
+        tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
+        lib.psgd_prof_collect(slot, ctypes.byref(tot), ctypes.byref(cnt))
+        slot_ms[name] = (tot.value / cnt.value) if cnt.value else None
+    lib.psgd_prof_enable(0)
+    assert torch.isfinite(out).all().item(), "non-finite preconditioned gradient"
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_global * args.steps / elapsed
+        # algorithmic bytes per row per launch (DESIGN.md section 4 / SURVEY 8d)
+        kbytes = {"apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 2), "apply_s3": 4 * (2 * r + 3),
+                  "update_s1": 4 * (2 * r + 3), "update_s2": 4 * (3 * r + 4), "update_s3": 12}
+        kern = {k: {"avg_ms": slot_ms[k], "achieved_GBs": kbytes[k] * n_local / (slot_ms[k] * 1e-3) / 1e9}
+                for k in kbytes if slot_ms[k]}
+        dom = "update_s2"
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                rec = json.load(open(tp)).get("k_update_s2")
+                if rec and rec.get("rows") == n_local and rec.get("r") == r:
+                    traffic = rec["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        ach = kern[dom]["achieved_GBs"]
+        apply_ms = sum(slot_ms[k] for k in ("apply_s1", "apply_s2", "apply_s3"))
+        update_ms = sum(slot_ms[k] for k in ("update_s1", "update_s2", "update_s3"))
+        paths = {
+            "apply": {"alg_bytes_per_param": 4 * (4 * r + 5), "kernel_ms": apply_ms,
+                      "frac": 4 * (4 * r + 5) * n_local / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "update": {"alg_bytes_per_param": 4 * (5 * r + 10), "kernel_ms": update_ms,
+                       "frac": 4 * (5 * r + 10) * n_local / (update_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "step": {"alg_bytes_per_param": 4 * (9 * r + 15), "wall_ms": ms_per_step,
+                     "frac": 4 * (9 * r + 15) * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        res = {
+            "metric": "uvd_update_apply_params_per_sec", "value": value, "unit": "params/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "UVd preconditioner update+apply (update_precond_UVd_math_ then "
+                                   "precond_grad_UVd_math), N=%d rows per GPU, r=%d" % (n_local, r),
+                       "rows_per_gpu": n_local, "rows_global": n_global, "rank_of_modification": r,
+                       "parallelism": "row-sharded x%d, all-reduce of r-dim sums only" % world,
+                       "step": STEP, "branches": "balance=0, update_U alternating"},
+            "roofline": {"bound": "hbm", "kernel": "k_update_s2 (update sweep 2, dominant kernel)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": traffic, "alg_bytes_per_launch": kbytes[dom] * n_local,
+                         "avg_launch_ms": slot_ms[dom], "kernels": kern, "paths": paths},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del U, V, d, grad, v, h, out
+            torch.cuda.empty_cache()
+            res["cpu_baseline"] = cpu_baseline(r, args.cpu_sample_rows, args.cpu_budget_s)
+        print(json.dumps(res), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,6 +126,20 @@ int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,
  * key 1: cap on blocks per CU for the sweeps (0 = occupancy query).        */
 int psgd_set_tuning(int key, int value);
 
+/* Live kernel timing for bench.py (measurement aid, not part of the reference's surface).
+ * While enabled, every sweep-kernel launch is bracketed by HIP events recorded on the launch
+ * stream.  psgd_prof_collect() waits for the recorded events of `slot`, returns the summed
+ * kernel time and the launch count since the last collect, and clears the slot.
+ * It is the only call here that synchronises with the device.                            */
+#define PSGD_PROF_APPLY_S1   0
+#define PSGD_PROF_APPLY_S2   1
+#define PSGD_PROF_APPLY_S3   2
+#define PSGD_PROF_UPDATE_S1  3
+#define PSGD_PROF_UPDATE_S2  4
+#define PSGD_PROF_UPDATE_S3  5
+int psgd_prof_enable(int on);
+int psgd_prof_collect(int slot, double *total_ms, int *count);
+
 /* ----------------------------------------------------------------- Kron ---
  * P = kron(Qr'Qr, Ql'Ql) with dense upper-triangular Ql [M,M], Qr [N,N]
  * (psgd.py:156-192).  G, dX, dG are [M,N] row-major.                       */

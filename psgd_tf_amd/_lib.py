@@ -35,6 +35,8 @@ SIGNATURES = {
     "psgd_abi_version": (_int, []),
     "psgd_error_string": (ctypes.c_char_p, [_int]),
     "psgd_set_tuning": (_int, [_int, _int]),
+    "psgd_prof_enable": (_int, [_int]),
+    "psgd_prof_collect": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_int)]),
     "psgd_uvd_workspace_bytes": (_i64, [_i64, _int]),
     "psgd_uvd_ws_region": (_int, [_int, _int, _i64, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "psgd_uvd_apply_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),

@@ -77,11 +77,42 @@ static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintpt
 static int g_tune_staging = 0;
 static int g_tune_blocks_per_cu = 0;
 
+// Optional live kernel timing (bench.py): when enabled, every sweep launch is bracketed by a pair
+// of HIP events recorded on the launch stream; psgd_prof_collect() resolves them afterwards.
+// Nothing here synchronises inside a hot-path call.
+constexpr int kProfSlots = 8;
+constexpr int kProfMaxPairs = 4096;
+struct ProfPair { hipEvent_t e0, e1; };
+static int g_prof_on = 0;
+static ProfPair g_prof_pairs[kProfSlots][kProfMaxPairs];
+static int g_prof_created[kProfSlots];
+static int g_prof_used[kProfSlots];
+
+struct ProfScope {
+  hipEvent_t e1 = nullptr;
+  hipStream_t st;
+  ProfScope(int slot, hipStream_t s) : st(s) {
+    if (!g_prof_on || slot < 0 || slot >= kProfSlots || g_prof_used[slot] >= kProfMaxPairs) return;
+    const int i = g_prof_used[slot];
+    if (i >= g_prof_created[slot]) {
+      if (hipEventCreate(&g_prof_pairs[slot][i].e0) != hipSuccess) return;
+      if (hipEventCreate(&g_prof_pairs[slot][i].e1) != hipSuccess) return;
+      g_prof_created[slot] = i + 1;
+    }
+    g_prof_used[slot] = i + 1;
+    (void)hipEventRecord(g_prof_pairs[slot][i].e0, st);
+    e1 = g_prof_pairs[slot][i].e1;
+  }
+  ~ProfScope() {
+    if (e1) (void)hipEventRecord(e1, st);
+  }
+};
+
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     n = v;
@@ -108,8 +139,9 @@ static int sweep_grid(const UvdOps* ops, int r, int which, int64_t N, int hard_c
 }
 
 // ---------------------------------------------------------- small kernels --
-// sums[id] = sum_b part[b][id] in fp64, fixed order.  One lane per element id,
-// the four waves of a block take interleaved slices of the G partial rows.
+// sums[id] = sum_b part[b][id] in fp64, fixed order, for the big fp64 Gram partials stored
+// [G][L].  One lane per element id; the four waves of a block take interleaved slices of the
+// G partial rows, eight independent loads in flight per lane.
 template <class T>
 __global__ __launch_bounds__(kThreads) void k_reduce_sum(const T* __restrict__ part, int G, int L,
                                                          double* __restrict__ sums, float* __restrict__ coef) {
@@ -117,14 +149,42 @@ __global__ __launch_bounds__(kThreads) void k_reduce_sum(const T* __restrict__ p
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int id = blockIdx.x * 64 + lane;
   double s = 0.0;
-  if (id < L)
-    for (int b = w; b < G; b += kWavesPerBlock) s += (double)part[(long)b * L + id];
+  if (id < L) {
+    int b = w;
+    for (; b + 7 * kWavesPerBlock < G; b += 8 * kWavesPerBlock) {
+      T x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = part[(long)(b + u * kWavesPerBlock) * L + id];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)x[u];
+    }
+    for (; b < G; b += kWavesPerBlock) s += (double)part[(long)b * L + id];
+  }
   red[w][lane] = s;
   __syncthreads();
   if (w == 0 && id < L) {
     const double t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
     sums[id] = t;
     if (coef) coef[id] = (float)t;
+  }
+}
+
+// sums[id] = sum_b part[id][b] for the transposed fp32 partials of the column-reduction sweeps
+// ([L][G], L <= 32): one wave per element, lanes stride over the G partials (coalesced), fp64
+// shuffle tree.  Single block; fixed order.
+__global__ __launch_bounds__(kThreads) void k_reduce_sum_t(const float* __restrict__ part, int G, int L,
+                                                           double* __restrict__ sums, float* __restrict__ coef) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int id = w; id < L; id += kWavesPerBlock) {
+    const float* p = part + (long)id * G;
+    double s = 0.0;
+    for (int b = lane; b < G; b += 64) s += (double)p[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+      sums[id] = s;
+      if (coef) coef[id] = (float)s;
+    }
   }
 }
 
@@ -418,6 +478,29 @@ int psgd_set_tuning(int key, int value) {
   return PSGD_ERR_BAD_ARG;
 }
 
+int psgd_prof_enable(int on) {
+  g_prof_on = on ? 1 : 0;
+  for (int s = 0; s < kProfSlots; ++s) g_prof_used[s] = 0;
+  return PSGD_OK;
+}
+
+int psgd_prof_collect(int slot, double* total_ms, int* count) {
+  if (slot < 0 || slot >= kProfSlots || !total_ms || !count) return PSGD_ERR_BAD_ARG;
+  double tot = 0.0;
+  int n = 0;
+  for (int i = 0; i < g_prof_used[slot]; ++i) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(g_prof_pairs[slot][i].e1) != hipSuccess) continue;
+    if (hipEventElapsedTime(&ms, g_prof_pairs[slot][i].e0, g_prof_pairs[slot][i].e1) != hipSuccess) continue;
+    tot += ms;
+    ++n;
+  }
+  g_prof_used[slot] = 0;
+  *total_ms = tot;
+  *count = n;
+  return PSGD_OK;
+}
+
 int64_t psgd_uvd_workspace_bytes(int64_t N, int r) {
   if (N <= 0) return PSGD_ERR_BAD_ARG;
   if (r < 1 || r > PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
@@ -453,9 +536,11 @@ int psgd_uvd_apply_sweep1_f32(const float* V, const float* d, const float* g, in
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
   float* part = static_cast<float*>(w.part);
-  PSGD_CHECK_LAUNCH(ops->colreduce(2, V, d, g, N, part, grid, st));
-  hipLaunchKernelGGL((k_reduce_sum<float>), dim3((r + 63) / 64), dim3(kThreads), 0, st, part, grid, r, w.sums,
-                     w.coef);
+  {
+    ProfScope ps(PSGD_PROF_APPLY_S1, st);
+    PSGD_CHECK_LAUNCH(ops->colreduce(2, V, d, g, N, part, grid, st));
+  }
+  hipLaunchKernelGGL(k_reduce_sum_t, dim3(1), dim3(kThreads), 0, st, part, grid, r, w.sums, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
@@ -476,9 +561,11 @@ int psgd_uvd_apply_sweep2_f32(const float* U, const float* d, const float* g, in
   }
   const int grid = sweep_grid(ops, r, kOccApplyS2, N, kMaxGrid);
   float* part = static_cast<float*>(w.part);
-  PSGD_CHECK_LAUNCH(ops->apply_s2(U, d, g, N, w.coef, part, grid, st));
-  hipLaunchKernelGGL((k_reduce_sum<float>), dim3((r + 63) / 64), dim3(kThreads), 0, st, part, grid, r, w.sums + r,
-                     w.coef + r);
+  {
+    ProfScope ps(PSGD_PROF_APPLY_S2, st);
+    PSGD_CHECK_LAUNCH(ops->apply_s2(U, d, g, N, w.coef, part, grid, st));
+  }
+  hipLaunchKernelGGL(k_reduce_sum_t, dim3(1), dim3(kThreads), 0, st, part, grid, r, w.sums + r, w.coef + r);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
@@ -498,7 +585,10 @@ int psgd_uvd_apply_sweep3_f32(const float* U, const float* V, const float* d, co
     PSGD_CHECK_LAUNCH(last_launch());
   }
   const int grid = sweep_grid(ops, r, kOccApplyS3, N, kMaxGrid);
-  PSGD_CHECK_LAUNCH(ops->apply_s3(U, V, d, g, out, N, w.coef, grid, st));
+  {
+    ProfScope ps(PSGD_PROF_APPLY_S3, st);
+    PSGD_CHECK_LAUNCH(ops->apply_s3(U, V, d, g, out, N, w.coef, grid, st));
+  }
   return PSGD_OK;
 }
 
@@ -525,8 +615,7 @@ int psgd_uvd_ipuvt_matvec_f32(const float* U, const float* V, const float* x, fl
   float* part = static_cast<float*>(w.part);
   int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
   PSGD_CHECK_LAUNCH(ops->colreduce(1, V, x, nullptr, N, part, grid, st));
-  hipLaunchKernelGGL((k_reduce_sum<float>), dim3((r + 63) / 64), dim3(kThreads), 0, st, part, grid, r, w.sums,
-                     w.coef);
+  hipLaunchKernelGGL(k_reduce_sum_t, dim3(1), dim3(kThreads), 0, st, part, grid, r, w.sums, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
   PSGD_CHECK_LAUNCH(ops->rowdot_axpy(U, x, out, N, w.coef, grid, st));
@@ -585,7 +674,10 @@ int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = sweep_grid(ops, r, kOccGram, N, kGramMaxGrid);
   double* part = static_cast<double*>(w.part);
-  PSGD_CHECK_LAUNCH(ops->update_gram(U, V, d, v, h, N, part, grid, st));
+  {
+    ProfScope ps(PSGD_PROF_UPDATE_S1, st);
+    PSGD_CHECK_LAUNCH(ops->update_gram(U, V, d, v, h, N, part, grid, st));
+  }
   const int L = ops->gram_len;
   hipLaunchKernelGGL((k_reduce_sum<double>), dim3((L + 63) / 64), dim3(kThreads), 0, st, part, grid, L, w.sums,
                      static_cast<float*>(nullptr));
@@ -606,7 +698,10 @@ int psgd_uvd_update_sweep2_f32(float* U, float* V, const float* d, const float* 
   hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(64), 0, st, w.sums, r, step, tiny, update_U, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   const int grid = sweep_grid(ops, r, update_U ? kOccUpdS2U : kOccUpdS2V, N, kMaxGrid);
-  PSGD_CHECK_LAUNCH(ops->update_s2(update_U, U, V, d, v, h, N, w.coef, w.nabla, w.pmax, grid, st));
+  {
+    ProfScope ps(PSGD_PROF_UPDATE_S2, st);
+    PSGD_CHECK_LAUNCH(ops->update_s2(update_U, U, V, d, v, h, N, w.coef, w.nabla, w.pmax, grid, st));
+  }
   hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf + 2);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
@@ -620,9 +715,12 @@ int psgd_uvd_update_sweep3_f32(float* d, int64_t N, int r, float step, float tin
   if (rc) return rc;
   if (misaligned16(d)) return PSGD_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_update_d, dim3(flat_grid(N)), dim3(kThreads), 0, st, d, w.nabla, (long)N, w.maxbuf + 2,
-                     step, tiny);
-  PSGD_CHECK_LAUNCH(last_launch());
+  {
+    ProfScope ps(PSGD_PROF_UPDATE_S3, st);
+    hipLaunchKernelGGL(k_update_d, dim3(flat_grid(N)), dim3(kThreads), 0, st, d, w.nabla, (long)N, w.maxbuf + 2,
+                       step, tiny);
+    PSGD_CHECK_LAUNCH(last_launch());
+  }
   return PSGD_OK;
 }
 

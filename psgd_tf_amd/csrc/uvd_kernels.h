@@ -245,9 +245,10 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
 }
 
 // ------------------------------------------------------ block reductions ---
-// Sum acc[L] over the block (fixed order) and store one partial row.
+// Sum acc[L] over the block (fixed order) and store the block's partials TRANSPOSED:
+// part[c * G + block], so that the reduce kernel reads each element's G partials coalesced.
 template <int L>
-__device__ __forceinline__ void block_sum_store(float (&acc)[L], float* red /* [waves][L] */, float* part_row) {
+__device__ __forceinline__ void block_sum_store(float (&acc)[L], float* red /* [waves][L] */, float* part) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < L; ++c) {
@@ -261,7 +262,7 @@ __device__ __forceinline__ void block_sum_store(float (&acc)[L], float* red /* [
     float s = red[c];
 #pragma unroll
     for (int k = 1; k < kWavesPerBlock; ++k) s += red[k * L + c];
-    part_row[c] = s;
+    part[(long)c * gridDim.x + blockIdx.x] = s;
   }
 }
 
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void k_colreduce(const float* M, const fl
     const float* const vecs[1] = {a};
     sweep_rows<R, 1, 1, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
   }
-  block_sum_store<R>(acc, red, part + (long)blockIdx.x * R);
+  block_sum_store<R>(acc, red, part);
 }
 
 // apply sweep 2: s2 = U' (t + U s1), t = d .* g   (psgd.py:626 -> :544)
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_s2(const float* U, const flo
 #pragma unroll
                             for (int c = 0; c < R; ++c) acc[c] = fmaf(x[0][c], g1, acc[c]);
                           });
-  block_sum_store<R>(acc, red, part + (long)blockIdx.x * R);
+  block_sum_store<R>(acc, red, part);
 }
 
 // apply sweep 3: out = d .* (g1 + V s2), g1 = d.*g + U s1   (psgd.py:625-626)

@@ -109,7 +109,9 @@ def _factor_for(rng, shape, other_dim):
     if m == n:
         return _tri_factor(rng, m)
     if m == 2:
-        return np.stack([np.exp(0.2 * rng.standard_normal(n)), 0.1 * rng.standard_normal(n)])
+        q = np.stack([np.exp(0.2 * rng.standard_normal(n)), 0.1 * rng.standard_normal(n)])
+        q[1, -1] = 0.0      # psgd.py:205: the last entry of the stored column is unused and stays 0
+        return q
     return np.exp(0.2 * rng.standard_normal((1, n)))
 
 
