@@ -170,21 +170,29 @@ __global__ __launch_bounds__(kThreads) void k_reduce_sum(const T* __restrict__ p
 }
 
 // sums[id] = sum_b part[id][b] for the transposed fp32 partials of the column-reduction sweeps
-// ([L][G], L <= 32): one wave per element, lanes stride over the G partials (coalesced), fp64
-// shuffle tree.  Single block; fixed order.
+// ([L][G], G <= kMaxGrid = 2048): one wave per element; every lane issues its (up to 32) loads of
+// the element's G partials before summing, so one memory latency is paid, not G/64 of them.
+// fp64 shuffle tree, fixed order.
 __global__ __launch_bounds__(kThreads) void k_reduce_sum_t(const float* __restrict__ part, int G, int L,
                                                            double* __restrict__ sums, float* __restrict__ coef) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int id = w; id < L; id += kWavesPerBlock) {
-    const float* p = part + (long)id * G;
-    double s = 0.0;
-    for (int b = lane; b < G; b += 64) s += (double)p[b];
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (id >= L) return;
+  const float* p = part + (long)id * G;
+  float x[kMaxGrid / 64];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) {
-      sums[id] = s;
-      if (coef) coef[id] = (float)s;
-    }
+  for (int u = 0; u < kMaxGrid / 64; ++u) {
+    const int b = lane + 64 * u;
+    x[u] = (b < G) ? p[b] : 0.0f;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < kMaxGrid / 64; ++u) s += (double)x[u];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) {
+    sums[id] = s;
+    if (coef) coef[id] = (float)s;
   }
 }
 
@@ -540,7 +548,7 @@ int psgd_uvd_apply_sweep1_f32(const float* V, const float* d, const float* g, in
     ProfScope ps(PSGD_PROF_APPLY_S1, st);
     PSGD_CHECK_LAUNCH(ops->colreduce(2, V, d, g, N, part, grid, st));
   }
-  hipLaunchKernelGGL(k_reduce_sum_t, dim3(1), dim3(kThreads), 0, st, part, grid, r, w.sums, w.coef);
+  hipLaunchKernelGGL(k_reduce_sum_t, dim3((r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part, grid, r, w.sums, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
@@ -565,7 +573,7 @@ int psgd_uvd_apply_sweep2_f32(const float* U, const float* d, const float* g, in
     ProfScope ps(PSGD_PROF_APPLY_S2, st);
     PSGD_CHECK_LAUNCH(ops->apply_s2(U, d, g, N, w.coef, part, grid, st));
   }
-  hipLaunchKernelGGL(k_reduce_sum_t, dim3(1), dim3(kThreads), 0, st, part, grid, r, w.sums + r, w.coef + r);
+  hipLaunchKernelGGL(k_reduce_sum_t, dim3((r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part, grid, r, w.sums + r, w.coef + r);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
@@ -615,7 +623,7 @@ int psgd_uvd_ipuvt_matvec_f32(const float* U, const float* V, const float* x, fl
   float* part = static_cast<float*>(w.part);
   int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
   PSGD_CHECK_LAUNCH(ops->colreduce(1, V, x, nullptr, N, part, grid, st));
-  hipLaunchKernelGGL(k_reduce_sum_t, dim3(1), dim3(kThreads), 0, st, part, grid, r, w.sums, w.coef);
+  hipLaunchKernelGGL(k_reduce_sum_t, dim3((r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part, grid, r, w.sums, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
   PSGD_CHECK_LAUNCH(ops->rowdot_axpy(U, x, out, N, w.coef, grid, st));

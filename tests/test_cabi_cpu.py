@@ -1,0 +1,74 @@
+"""The C-ABI library: builds for gfx950 without a GPU, loads, and exports exactly the symbols
+that include/psgd_hip.h declares (and _lib.py binds).  No compute calls here -- only entry points
+whose argument checks return before any HIP call."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from psgd_tf_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "psgd_hip.h")
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(psgd_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build_extension()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "declared in psgd_hip.h but not exported: " + name
+        assert name in _lib.SIGNATURES, "declared in psgd_hip.h but not bound in _lib.py: " + name
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_abi_version_and_error_strings(lib):
+    assert lib.psgd_abi_version() == 1
+    assert lib.psgd_error_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, -6):
+        assert len(lib.psgd_error_string(code)) > 3
+
+
+def test_workspace_queries_and_argument_checks(lib):
+    # psgd.py:690 keeps an N-vector temporary per call (nablaD, :581): workspace grows by 4 N bytes
+    a = lib.psgd_uvd_workspace_bytes(1_000_000, 10)
+    b = lib.psgd_uvd_workspace_bytes(2_000_000, 10)
+    assert a > 0 and b - a == 4_000_000 and a % 256 == 0
+    assert lib.psgd_uvd_workspace_bytes(100, 0) == -2 and lib.psgd_uvd_workspace_bytes(100, 33) == -2   # PSGD_ERR_RANK
+    assert lib.psgd_uvd_workspace_bytes(0, 4) == -1                                                       # PSGD_ERR_BAD_ARG
+    off, cnt = _lib.ws_region(_lib.PSGD_WS_SUMS_F64, 1, 1000, 20)
+    off2, cnt2 = _lib.ws_region(_lib.PSGD_WS_SUMS_F64, 2, 1000, 20)
+    assert cnt == cnt2 == 20 and off2 - off == 160
+    _, gram = _lib.ws_region(_lib.PSGD_WS_SUMS_F64, 11, 1000, 20)
+    assert gram == 6 * 256                      # [U V t w] = 42 columns -> 3 MFMA blocks -> 6 block pairs
+    _, gram10 = _lib.ws_region(_lib.PSGD_WS_SUMS_F64, 11, 1000, 10)
+    assert gram10 == 3 * 256
+    _, m = _lib.ws_region(_lib.PSGD_WS_MAX_F32, 10, 1000, 20)
+    assert m == 2
+    # null pointers are rejected before anything touches the device
+    assert lib.psgd_uvd_apply_f32(None, None, None, None, None, 100, 4, None, 0, None) == -1
+    assert lib.psgd_uvd_update_f32(None, None, None, None, None, 100, 4, 0.01, 1e-38, 0, 1, None, 0, None) == -1
+    assert lib.psgd_kron_dd_apply_f32(None, None, None, None, 4, 4, None, 0, None) == -1
+    assert lib.psgd_kron_dd_workspace_bytes(0, 4) == -1
+    assert lib.psgd_kron_dd_workspace_bytes(257, 120) > 4 * (2 * 257 * 257 + 2 * 120 * 120 + 4 * 257 * 120)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.PsgdHipError, match="no CPU fallback|missing"):
+        _lib.load()

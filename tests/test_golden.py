@@ -1,0 +1,77 @@
+"""Golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the fp64 oracle).
+CPU: the oracle still reproduces them (fp64, to 1e-13: BLAS summation order may differ between
+hosts) and within rounding in fp32.
+GPU: the HIP path matches them to the stated tolerances."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import psgd_oracle as orc
+from tests.uvd_cases import rel_err
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+UVD = sorted(glob.glob(os.path.join(HERE, "uvd_*.npz")))
+KRON = sorted(glob.glob(os.path.join(HERE, "kron_*.npz")))
+
+
+def test_fixtures_present():
+    assert len(UVD) == 4 and len(KRON) == 4
+
+
+@pytest.mark.parametrize("path", UVD, ids=os.path.basename)
+def test_oracle_reproduces_uvd_golden(path):
+    z = np.load(path)
+    q = {k: z[k].astype(np.float64) for k in ("U", "V", "d", "g", "v", "h")}
+    assert rel_err(orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"]), z["pre_grad_before"]) < 1e-13
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], float(z["step"]), float(z["tiny"]),
+                                 balance=bool(z["balance"]), update_U=bool(z["update_U"]))
+    for k in ("U", "V", "d"):
+        assert rel_err(q[k], z[k + "_new"]) < 1e-13, k
+    # the fp32 run of the same op sequence stays within fp32 rounding of the golden
+    p = {k: z[k].copy() for k in ("U", "V", "d", "g", "v", "h")}
+    orc.update_precond_UVd_math_(p["U"], p["V"], p["d"], p["v"], p["h"], float(z["step"]), float(z["tiny"]),
+                                 balance=bool(z["balance"]), update_U=bool(z["update_U"]))
+    for k in ("U", "V", "d"):
+        assert rel_err(p[k], z[k + "_new"]) < 1e-5
+    assert rel_err(orc.precond_grad_UVd_math(p["U"], p["V"], p["d"], p["g"]), z["pre_grad_after"]) < 1e-5
+
+
+@pytest.mark.parametrize("path", KRON, ids=os.path.basename)
+def test_oracle_reproduces_kron_golden(path):
+    z = np.load(path)
+    f = lambda k: z[k].astype(np.float64)
+    a, b = orc.update_precond_kron(f("Ql"), f("Qr"), f("dX"), f("dG"), float(z["step"]))
+    assert rel_err(a, z["Ql_new"]) < 1e-13 and rel_err(b, z["Qr_new"]) < 1e-13
+    assert rel_err(orc.precond_grad_kron(f("Ql"), f("Qr"), f("G")), z["pre_grad"]) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", UVD, ids=os.path.basename)
+def test_hip_matches_uvd_golden(path, hip_lib):
+    import torch
+    import preconditioned_stochastic_gradient_descent as psgd
+    z = np.load(path)
+    t = {k: torch.from_numpy(z[k]).cuda() for k in ("U", "V", "d", "g", "v", "h")}
+    out0 = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    assert rel_err(out0.cpu().numpy(), z["pre_grad_before"]) < 1e-5
+    psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], float(z["step"]), float(z["tiny"]),
+                                  balance=bool(z["balance"]), update_U=bool(z["update_U"]))
+    for k in ("U", "V", "d"):
+        assert rel_err(t[k].cpu().numpy(), z[k + "_new"]) < 1e-5, k
+    out1 = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    assert rel_err(out1.cpu().numpy(), z["pre_grad_after"]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", KRON, ids=os.path.basename)
+def test_hip_matches_kron_golden(path, hip_lib):
+    import torch
+    import preconditioned_stochastic_gradient_descent as psgd
+    z = np.load(path)
+    c = lambda k: torch.from_numpy(z[k]).cuda()
+    a, b = psgd.update_precond_kron(c("Ql"), c("Qr"), c("dX"), c("dG"), float(z["step"]))
+    assert rel_err(a.cpu().numpy(), z["Ql_new"]) < 1e-5 and rel_err(b.cpu().numpy(), z["Qr_new"]) < 1e-5
+    out = psgd.precond_grad_kron(c("Ql"), c("Qr"), c("G"))
+    assert rel_err(out.cpu().numpy(), z["pre_grad"]) < 1e-5

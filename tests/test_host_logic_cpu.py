@@ -1,0 +1,112 @@
+"""Host-side logic of the drop-in module on CPU: dispatch table, index logic, hyper-parameter
+holders, the dense plumbing path (config 1: hello_psgd) and the refusal to run the hot path
+without the HIP device."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import preconditioned_stochastic_gradient_descent as psgd
+from oracle import psgd_oracle as orc
+from psgd_tf_amd import _lib, kron
+from tests.test_oracle_kat import DISPATCH
+from tests.uvd_cases import rel_err
+
+
+def test_module_surface_matches_reference_names():
+    # names imported by the reference's drivers (hello_psgd.py:25-26, mnist_with_lenet5.py:51,53,
+    # rnn_xor_UVd_preconditioner.py:37, psgd.py:540,554,619)
+    for name in ("update_precond_dense", "precond_grad_dense", "update_precond_kron", "precond_grad_kron",
+                 "IpUVtmatvec", "update_precond_UVd_math_", "precond_grad_UVd_math", "UVd", "dtype", "_tiny"):
+        assert hasattr(psgd, name), name
+    assert psgd.dtype == torch.float32 and psgd._tiny == float(np.finfo(np.float32).tiny)
+    import inspect
+    sig = inspect.signature(psgd.UVd.__init__)
+    assert list(sig.parameters)[1:9] == ["params_with_grad", "rank_of_modification", "preconditioner_init_scale",
+                                         "lr_params", "lr_preconditioner", "grad_clip_max_norm",
+                                         "preconditioner_update_probability", "exact_hessian_vector_product"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["rank_of_modification"], d["preconditioner_init_scale"], d["lr_params"], d["lr_preconditioner"],
+            d["grad_clip_max_norm"], d["preconditioner_update_probability"], d["exact_hessian_vector_product"]) == \
+        (10, 1.0, 0.01, 0.01, None, 1.0, True)                                      # psgd.py:663-666
+    assert inspect.signature(psgd.update_precond_kron).parameters["step"].default == 0.01   # psgd.py:72
+    assert inspect.signature(psgd.update_precond_dense).parameters["step"].default == 0.01  # psgd.py:26
+
+
+@pytest.mark.parametrize("sl,sr,fmt", DISPATCH)
+def test_dispatch_table_is_bit_exact_with_oracle(sl, sr, fmt):
+    assert kron.kron_format(sl, sr) == fmt == orc.kron_format(sl, sr)
+
+
+def test_param_index_logic():
+    shapes = [(2, 30), (30, 30), (30,), (30, 1), (1,)]
+    params = [torch.zeros(s) for s in shapes]
+    sizes, cum = psgd.uvd_param_index(params)
+    osizes, ocum = orc.uvd_param_index(shapes)
+    assert sizes == osizes == [60, 900, 30, 30, 1] and cum == list(ocum) == [60, 960, 990, 1020, 1021]
+
+
+def test_flatten_order_is_nest_flatten():
+    from psgd_tf_amd.preconditioned_stochastic_gradient_descent import _flatten_params
+    a, b, c, d = (torch.full((1,), float(i)) for i in range(4))
+    flat = _flatten_params([a, [b, (c,)], {"z": d, "y": a}])
+    assert [float(t) for t in flat] == [0.0, 1.0, 2.0, 0.0, 3.0]      # dict keys sorted, depth first
+    assert _flatten_params(a) == [a]                                    # psgd.py:668
+
+
+def test_hyper_parameters_assign_like_tf_variables():
+    h = psgd.UVd.__init__.__globals__["_Hyper"](0.01)
+    assert float(h) == 0.01
+    h.assign(0.5)                                                      # psgd.py:660-661 (Note 4)
+    assert float(h) == 0.5 and h.numpy() == 0.5
+    flag = psgd.UVd.__init__.__globals__["_Hyper"](True)
+    flag.assign(False)                                                 # rnn_xor_UVd_preconditioner.py:69
+    assert not bool(flag)
+
+
+def test_dense_plumbing_matches_oracle_and_kat_r():
+    Q = 0.1 * torch.eye(2, dtype=torch.float64)
+    vs = [torch.tensor(1.0, dtype=torch.float64), torch.tensor(0.0, dtype=torch.float64)]
+    hvs = [torch.tensor(802.0, dtype=torch.float64), torch.tensor(400.0, dtype=torch.float64)]
+    Qn = psgd.update_precond_dense(Q, vs, hvs, step=0.2)
+    assert np.allclose(Qn.numpy(), [[0.08, -0.0101326], [0.0, 0.09494634]], rtol=2e-6, atol=1e-9)
+    pg = psgd.precond_grad_dense(Qn, [torch.tensor(-4.0, dtype=torch.float64), torch.tensor(0.0, dtype=torch.float64)])
+    assert pg[0].shape == () and np.allclose([float(pg[0]), float(pg[1])], [-0.0256, 0.00324243], rtol=2e-6)
+    rng = np.random.default_rng(0)
+    Qa = np.triu(rng.standard_normal((7, 7)) * 0.1, 1) + np.eye(7)
+    dxs = [rng.standard_normal((2, 2)), rng.standard_normal(3)]
+    dgs = [rng.standard_normal((2, 2)), rng.standard_normal(3)]
+    got = psgd.update_precond_dense(torch.from_numpy(Qa), [torch.from_numpy(x) for x in dxs],
+                                    [torch.from_numpy(x) for x in dgs], step=0.05)
+    assert rel_err(got.numpy(), orc.update_precond_dense(Qa, dxs, dgs, 0.05)) < 1e-12
+    pgs = psgd.precond_grad_dense(got, [torch.from_numpy(x) for x in dgs])
+    refs = orc.precond_grad_dense(got.numpy(), dgs)
+    assert all(a.shape == b.shape and rel_err(a.numpy(), b) < 1e-12 for a, b in zip(pgs, refs))
+
+
+def test_hello_psgd_converges():
+    """Harness row H of SURVEY 8a: f falls from f0 = 4 toward 0 over 500 iterations."""
+    from examples.hello_psgd import run
+    f, xs, Q = run(num_iter=500, seed=0)
+    assert f[0] == pytest.approx(4.0) and f[-1] < 1e-8 and abs(xs[0] - 1) < 1e-3 and abs(xs[1] - 1) < 1e-3
+    f1, _, Q1 = run(num_iter=1, first_v=(1.0, 0.0))
+    assert np.allclose(Q1.numpy(), [[0.08, -0.0101326], [0.0, 0.09494634]], rtol=1e-5, atol=1e-8)
+
+
+def test_hot_path_refuses_cpu_tensors():
+    U, V = torch.zeros(10, 2), torch.zeros(10, 2)
+    d, g = torch.ones(10, 1), torch.ones(10, 1)
+    with pytest.raises(_lib.PsgdHipError, match="no CPU fallback"):
+        psgd.precond_grad_UVd_math(U, V, d, g)
+    with pytest.raises(_lib.PsgdHipError, match="no CPU fallback"):
+        psgd.update_precond_UVd_math_(U, V, d, g, g, 0.01, 1e-38)
+    with pytest.raises(_lib.PsgdHipError, match="no CPU fallback"):
+        psgd.update_precond_kron(torch.eye(3), torch.eye(4), torch.ones(3, 4), torch.ones(3, 4))
+    with pytest.raises(ValueError):
+        psgd.update_precond_kron(torch.eye(3), torch.eye(4), torch.ones(12), torch.ones(12))   # rank-2 only (psgd.py:67-71)
+
+
+def test_uvd_constants():
+    assert torch.finfo(torch.float32).eps ** 0.5 == pytest.approx(2.0 ** -11.5)    # psgd.py:683
+    assert math.isinf(float(psgd.UVd.__init__.__globals__["_Hyper"](math.inf)))     # psgd.py:675-676
