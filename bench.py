@@ -148,7 +148,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global * args.steps / elapsed
         # algorithmic bytes per row per launch (DESIGN.md section 4 / SURVEY 8d)
-        kbytes = {"apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 2), "apply_s3": 4 * (2 * r + 3),
+        kbytes = {"apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 3), "apply_s3": 4 * (r + 3),
                   "update_s1": 4 * (2 * r + 3), "update_s2": 4 * (3 * r + 4), "update_s3": 12}
         kern = {k: {"avg_ms": slot_ms[k], "achieved_GBs": kbytes[k] * n_local / (slot_ms[k] * 1e-3) / 1e9}
                 for k in kbytes if slot_ms[k]}

@@ -71,11 +71,12 @@ int psgd_uvd_ws_region(int which, int stage, int64_t N, int r,
 
 /* precond_grad_UVd_math(U, V, d, g)   psgd.py:619-627 (IpUVtmatvec :540-544)
  *   out = d .* (I + V U') (I + U V') (d .* g)
- * Three streaming sweeps (the second reduction depends on the first):
- *   sweep1: s1 = V'(d.*g)            reads V,d,g
- *   sweep2: s2 = U'(d.*g + U s1)     reads U,d,g
- *   sweep3: out = d.*(g1 + V s2), g1 = d.*g + U s1   reads U,V,d,g writes out
- * `out` must not alias any input.                                          */
+ * Three streaming sweeps (the second reduction depends on the first); V is read twice and
+ * U once:
+ *   sweep1: s1 = V'(d.*g)                          reads V,d,g
+ *   sweep2: g1 = d.*g + U s1 -> out;  s2 = U'g1    reads U,d,g   writes out (= g1)
+ *   sweep3: out = d.*(g1 + V s2)  in place         reads V,d,out writes out
+ * `out` must not alias any input; between sweep2 and sweep3 it holds g1.          */
 int psgd_uvd_apply_f32(const float *U, const float *V, const float *d,
                        const float *g, float *out, int64_t N, int r,
                        void *ws, int64_t ws_bytes, void *stream);
@@ -83,12 +84,11 @@ int psgd_uvd_apply_sweep1_f32(const float *V, const float *d, const float *g,
                               int64_t N, int r, void *ws, int64_t ws_bytes,
                               void *stream);
 int psgd_uvd_apply_sweep2_f32(const float *U, const float *d, const float *g,
+                              float *out, int64_t N, int r, int sums_reduced,
+                              void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_apply_sweep3_f32(const float *V, const float *d, float *out,
                               int64_t N, int r, int sums_reduced,
                               void *ws, int64_t ws_bytes, void *stream);
-int psgd_uvd_apply_sweep3_f32(const float *U, const float *V, const float *d,
-                              const float *g, float *out, int64_t N, int r,
-                              int sums_reduced, void *ws, int64_t ws_bytes,
-                              void *stream);
 
 /* update_precond_UVd_math_(U, V, d, v, h, step, tiny)   psgd.py:554-617
  * Mutates U or V (branch update_U, psgd.py:588) and d in place.
@@ -122,7 +122,8 @@ int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,
                               void *ws, int64_t ws_bytes, void *stream);
 
 /* Tuning knobs for experiments (not part of the stable ABI).
- * key 0: staging path (0 = register staging, 1 = LDS-DMA).
+ * key 0: streaming policy (0 = automatic: non-temporal when U,V exceed the Infinity Cache,
+ *        1 = never non-temporal, 2 = always non-temporal).
  * key 1: cap on blocks per CU for the sweeps (0 = occupancy query).        */
 int psgd_set_tuning(int key, int value);
 

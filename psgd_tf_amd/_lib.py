@@ -10,7 +10,7 @@ import subprocess
 import threading
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libpsgd_hip.so")
+LIB_PATH = os.environ.get("PSGD_HIP_LIB", os.path.join(_CSRC, "libpsgd_hip.so"))   # override: build experiments only
 
 PSGD_OK = 0
 PSGD_WS_SUMS_F64 = 0
@@ -41,9 +41,8 @@ SIGNATURES = {
     "psgd_uvd_ws_region": (_int, [_int, _int, _i64, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "psgd_uvd_apply_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_apply_sweep1_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
-    "psgd_uvd_apply_sweep2_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _c_ws, _i64, _strm]),
-    "psgd_uvd_apply_sweep3_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _c_ws,
-                                         _i64, _strm]),
+    "psgd_uvd_apply_sweep2_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_apply_sweep3_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_update_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _flt, _flt, _int, _int,
                                    _c_ws, _i64, _strm]),
     "psgd_uvd_balance_max_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),

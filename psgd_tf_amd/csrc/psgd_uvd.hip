@@ -120,6 +120,13 @@ static int num_cus() {
   return n;
 }
 
+// non-temporal streams only when U and V together exceed the Infinity Cache (256 MiB)
+static inline int use_nt(int64_t N, int r) {
+  if (g_tune_staging == 1) return 0;
+  if (g_tune_staging == 2) return 1;
+  return (int64_t)N * r * 8 > (int64_t)192 * 1024 * 1024;
+}
+
 static int sweep_grid(const UvdOps* ops, int r, int which, int64_t N, int hard_cap) {
   static int occ_cache[PSGD_UVD_MAX_RANK + 1][8];
   int occ = occ_cache[r][which];
@@ -546,16 +553,16 @@ int psgd_uvd_apply_sweep1_f32(const float* V, const float* d, const float* g, in
   float* part = static_cast<float*>(w.part);
   {
     ProfScope ps(PSGD_PROF_APPLY_S1, st);
-    PSGD_CHECK_LAUNCH(ops->colreduce(2, V, d, g, N, part, grid, st));
+    PSGD_CHECK_LAUNCH(ops->colreduce(use_nt(N, r), 2, V, d, g, N, part, grid, st));
   }
   hipLaunchKernelGGL(k_reduce_sum_t, dim3((r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part, grid, r, w.sums, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
 
-int psgd_uvd_apply_sweep2_f32(const float* U, const float* d, const float* g, int64_t N, int r, int sums_reduced,
-                              void* ws, int64_t ws_bytes, void* stream) {
-  if (!U || !d || !g) return PSGD_ERR_BAD_ARG;
+int psgd_uvd_apply_sweep2_f32(const float* U, const float* d, const float* g, float* out, int64_t N, int r,
+                              int sums_reduced, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !d || !g || !out) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
   if (rc) return rc;
@@ -571,20 +578,20 @@ int psgd_uvd_apply_sweep2_f32(const float* U, const float* d, const float* g, in
   float* part = static_cast<float*>(w.part);
   {
     ProfScope ps(PSGD_PROF_APPLY_S2, st);
-    PSGD_CHECK_LAUNCH(ops->apply_s2(U, d, g, N, w.coef, part, grid, st));
+    PSGD_CHECK_LAUNCH(ops->apply_s2(use_nt(N, r), U, d, g, out, N, w.coef, part, grid, st));
   }
   hipLaunchKernelGGL(k_reduce_sum_t, dim3((r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part, grid, r, w.sums + r, w.coef + r);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
 
-int psgd_uvd_apply_sweep3_f32(const float* U, const float* V, const float* d, const float* g, float* out,
-                              int64_t N, int r, int sums_reduced, void* ws, int64_t ws_bytes, void* stream) {
-  if (!U || !V || !d || !g || !out) return PSGD_ERR_BAD_ARG;
+int psgd_uvd_apply_sweep3_f32(const float* V, const float* d, float* out, int64_t N, int r, int sums_reduced,
+                              void* ws, int64_t ws_bytes, void* stream) {
+  if (!V || !d || !out) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
   if (rc) return rc;
-  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  if (misaligned16(V)) return PSGD_ERR_ALIGN;
   const UvdOps* ops = uvd_ops_for_rank(r);
   if (!ops) return PSGD_ERR_RANK;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -595,7 +602,7 @@ int psgd_uvd_apply_sweep3_f32(const float* U, const float* V, const float* d, co
   const int grid = sweep_grid(ops, r, kOccApplyS3, N, kMaxGrid);
   {
     ProfScope ps(PSGD_PROF_APPLY_S3, st);
-    PSGD_CHECK_LAUNCH(ops->apply_s3(U, V, d, g, out, N, w.coef, grid, st));
+    PSGD_CHECK_LAUNCH(ops->apply_s3(use_nt(N, r), V, d, out, N, w.coef, grid, st));
   }
   return PSGD_OK;
 }
@@ -605,9 +612,9 @@ int psgd_uvd_apply_f32(const float* U, const float* V, const float* d, const flo
   if (!U || !V || !d || !g || !out) return PSGD_ERR_BAD_ARG;
   int rc = psgd_uvd_apply_sweep1_f32(V, d, g, N, r, ws, ws_bytes, stream);
   if (rc) return rc;
-  rc = psgd_uvd_apply_sweep2_f32(U, d, g, N, r, 0, ws, ws_bytes, stream);
+  rc = psgd_uvd_apply_sweep2_f32(U, d, g, out, N, r, 0, ws, ws_bytes, stream);
   if (rc) return rc;
-  return psgd_uvd_apply_sweep3_f32(U, V, d, g, out, N, r, 0, ws, ws_bytes, stream);
+  return psgd_uvd_apply_sweep3_f32(V, d, out, N, r, 0, ws, ws_bytes, stream);
 }
 
 int psgd_uvd_ipuvt_matvec_f32(const float* U, const float* V, const float* x, float* out, int64_t N, int r,
@@ -622,11 +629,11 @@ int psgd_uvd_ipuvt_matvec_f32(const float* U, const float* V, const float* x, fl
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(w.part);
   int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
-  PSGD_CHECK_LAUNCH(ops->colreduce(1, V, x, nullptr, N, part, grid, st));
+  PSGD_CHECK_LAUNCH(ops->colreduce(use_nt(N, r), 1, V, x, nullptr, N, part, grid, st));
   hipLaunchKernelGGL(k_reduce_sum_t, dim3((r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part, grid, r, w.sums, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
-  PSGD_CHECK_LAUNCH(ops->rowdot_axpy(U, x, out, N, w.coef, grid, st));
+  PSGD_CHECK_LAUNCH(ops->rowdot_axpy(use_nt(N, r), U, x, out, N, w.coef, grid, st));
   return PSGD_OK;
 }
 
@@ -684,7 +691,7 @@ int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, c
   double* part = static_cast<double*>(w.part);
   {
     ProfScope ps(PSGD_PROF_UPDATE_S1, st);
-    PSGD_CHECK_LAUNCH(ops->update_gram(U, V, d, v, h, N, part, grid, st));
+    PSGD_CHECK_LAUNCH(ops->update_gram(use_nt(N, r), U, V, d, v, h, N, part, grid, st));
   }
   const int L = ops->gram_len;
   hipLaunchKernelGGL((k_reduce_sum<double>), dim3((L + 63) / 64), dim3(kThreads), 0, st, part, grid, L, w.sums,
@@ -708,7 +715,7 @@ int psgd_uvd_update_sweep2_f32(float* U, float* V, const float* d, const float* 
   const int grid = sweep_grid(ops, r, update_U ? kOccUpdS2U : kOccUpdS2V, N, kMaxGrid);
   {
     ProfScope ps(PSGD_PROF_UPDATE_S2, st);
-    PSGD_CHECK_LAUNCH(ops->update_s2(update_U, U, V, d, v, h, N, w.coef, w.nabla, w.pmax, grid, st));
+    PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, N, w.coef, w.nabla, w.pmax, grid, st));
   }
   hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf + 2);
   PSGD_CHECK_LAUNCH(last_launch());

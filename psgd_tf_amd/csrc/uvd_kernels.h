@@ -35,6 +35,20 @@ constexpr int kGramMaxGrid = 1024;  // Gram sweep (fp64 partials are large)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Streaming-access policy.  NT = true marks the big once-per-sweep streams non-temporal
+// (global_load/store ... nt): measured +6 % on apply and +2 % on update at N = 100M, r = 20
+// (profiles/r01_nt_variants.txt).  It is only chosen when the operands exceed the 256 MiB
+// Infinity Cache; smaller problems keep the default policy so that the three sweeps of one call
+// can hit in L2 / Infinity Cache.
+template <bool NT, class T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NT, class T>
+__device__ __forceinline__ T stream_load(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+
 // Tile geometry for rank R.  A tile is kTileRows = 64 * kRowsPerLane rows (one
 // contiguous span of an [N, R] matrix) and is fetched with kLoadVec-float vector
 // loads, 64 lanes wide.  Preference: 16-byte loads; fall back to 8- or 4-byte
@@ -84,7 +98,7 @@ struct Prefetch {
   float s[NVEC > 0 ? NVEC : 1][Cfg<R>::kRowsPerLane];
 };
 
-template <int R, int NMAT, int NVEC>
+template <int R, int NMAT, int NVEC, bool NT>
 __device__ __forceinline__ void issue_tile(Prefetch<R, NMAT, NVEC>& pf,
                                            const float* const (&mats)[NMAT],
                                            const float* const (&vecs)[NVEC > 0 ? NVEC : 1],
@@ -95,12 +109,12 @@ __device__ __forceinline__ void issue_tile(Prefetch<R, NMAT, NVEC>& pf,
   for (int m = 0; m < NMAT; ++m) {
     const typename C::LoadT* src = reinterpret_cast<const typename C::LoadT*>(mats[m] + row0 * R);
 #pragma unroll
-    for (int j = 0; j < C::kLoadsPerLane; ++j) pf.m[m][j] = src[lane + 64 * j];
+    for (int j = 0; j < C::kLoadsPerLane; ++j) pf.m[m][j] = stream_load<NT>(src + lane + 64 * j);
   }
 #pragma unroll
   for (int k = 0; k < NVEC; ++k) {
 #pragma unroll
-    for (int i = 0; i < C::kRowsPerLane; ++i) pf.s[k][i] = vecs[k][row0 + lane + 64 * i];
+    for (int i = 0; i < C::kRowsPerLane; ++i) pf.s[k][i] = stream_load<NT>(vecs[k] + row0 + lane + 64 * i);
   }
 }
 
@@ -167,7 +181,7 @@ __device__ __forceinline__ void write_row(float* tile, int row, const float (&x)
 // WB >= 0: operand WB is modified by the body and streamed back to `mat_out`.
 // body(row, valid, x[NMAT][R], s[NVEC]).  Rows past N (tail tile only) arrive
 // zero-filled with valid == false.
-template <int R, int NMAT, int NVEC, int WB, class Body>
+template <int R, int NMAT, int NVEC, int WB, bool NT, class Body>
 __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
                                            const float* const (&vecs)[NVEC > 0 ? NVEC : 1],
                                            float* mat_out, long N, float* lds, Body&& body) {
@@ -181,11 +195,11 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
   long tile = gw;
   // The prefetch is unconditional (the last iteration re-reads its own tile) so that the
   // buffers stay in registers and the loads stay in flight across the compute phase.
-  if (tile < nfull) issue_tile<R, NMAT, NVEC>(pf, mats, vecs, tile, lane);
+  if (tile < nfull) issue_tile<R, NMAT, NVEC, NT>(pf, mats, vecs, tile, lane);
   while (tile < nfull) {
     commit_tile<R, NMAT, NVEC>(pf, lds, lane);
     const long next = tile + nw;
-    issue_tile<R, NMAT, NVEC>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
+    issue_tile<R, NMAT, NVEC, NT>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < C::kRowsPerLane; ++i) {
@@ -204,7 +218,7 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
       const typename C::LoadT* src = reinterpret_cast<const typename C::LoadT*>(lds + WB * C::kTileFloats);
       typename C::LoadT* dst = reinterpret_cast<typename C::LoadT*>(mat_out + tile * C::kTileRows * R);
 #pragma unroll
-      for (int j = 0; j < C::kLoadsPerLane; ++j) dst[lane + 64 * j] = src[lane + 64 * j];
+      for (int j = 0; j < C::kLoadsPerLane; ++j) stream_store<NT>(dst + lane + 64 * j, src[lane + 64 * j]);
       __builtin_amdgcn_wave_barrier();
     }
     tile = next;
@@ -291,7 +305,7 @@ __device__ __forceinline__ float dot_row(const float (&x)[R], const float* __res
 // ------------------------------------------------------------- kernels -----
 // s = M' (a .* b)  (NVEC == 2) or M' a (NVEC == 1): apply sweep 1 (psgd.py:544
 // inner matmul with x = d*g, :625) and the first half of IpUVtmatvec.
-template <int R, int NVEC>
+template <int R, int NVEC, bool NT>
 __global__ __launch_bounds__(kThreads) void k_colreduce(const float* M, const float* a, const float* b,
                                                         long N, float* part) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, NVEC>()];
@@ -308,18 +322,20 @@ __global__ __launch_bounds__(kThreads) void k_colreduce(const float* M, const fl
   };
   if constexpr (NVEC == 2) {
     const float* const vecs[2] = {a, b};
-    sweep_rows<R, 1, 2, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
+    sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
   } else {
     const float* const vecs[1] = {a};
-    sweep_rows<R, 1, 1, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
+    sweep_rows<R, 1, 1, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
   }
   block_sum_store<R>(acc, red, part);
 }
 
-// apply sweep 2: s2 = U' (t + U s1), t = d .* g   (psgd.py:626 -> :544)
-template <int R>
-__global__ __launch_bounds__(kThreads) void k_apply_s2(const float* U, const float* d, const float* g, long N,
-                                                       const float* __restrict__ coef, float* part) {
+// apply sweep 2: g1 = t + U s1 (stored), s2 = U' g1, t = d .* g   (psgd.py:625 -> :626 -> :544)
+// g1 is row-local, so the pass that reduces U'g1 also writes it out (4 B/row); sweep 3 then needs
+// V only: U is read once per apply, not twice.
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_apply_s2(const float* U, const float* d, const float* g, float* g1out,
+                                                       long N, const float* __restrict__ coef, float* part) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 2>()];
   __shared__ float red[kWavesPerBlock * R];
   float acc[R];
@@ -327,44 +343,42 @@ __global__ __launch_bounds__(kThreads) void k_apply_s2(const float* U, const flo
   for (int c = 0; c < R; ++c) acc[c] = 0.0f;
   const float* const mats[1] = {U};
   const float* const vecs[2] = {d, g};
-  sweep_rows<R, 1, 2, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
-                          [&](long, bool, float (&x)[1][R], float (&s)[2]) {
+  sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                          [&](long row, bool valid, float (&x)[1][R], float (&s)[2]) {
                             const float t = s[0] * s[1];
                             const float g1 = t + dot_row<R>(x[0], coef);
+                            if (valid) stream_store<NT>(g1out + row, g1);
 #pragma unroll
                             for (int c = 0; c < R; ++c) acc[c] = fmaf(x[0][c], g1, acc[c]);
                           });
   block_sum_store<R>(acc, red, part);
 }
 
-// apply sweep 3: out = d .* (g1 + V s2), g1 = d.*g + U s1   (psgd.py:625-626)
-template <int R>
-__global__ __launch_bounds__(kThreads) void k_apply_s3(const float* U, const float* V, const float* d,
-                                                       const float* g, float* out, long N,
+// apply sweep 3: out = d .* (g1 + V s2), in place on the buffer that holds g1   (psgd.py:626)
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_apply_s3(const float* V, const float* d, float* out, long N,
                                                        const float* __restrict__ coef) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 2, 2>()];
-  const float* const mats[2] = {U, V};
-  const float* const vecs[2] = {d, g};
-  sweep_rows<R, 2, 2, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
-                          [&](long row, bool valid, float (&x)[2][R], float (&s)[2]) {
-                            const float t = s[0] * s[1];
-                            const float g1 = t + dot_row<R>(x[0], coef);
-                            const float o = s[0] * (g1 + dot_row<R>(x[1], coef + R));
-                            if (valid) out[row] = o;
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 2>()];
+  const float* const mats[1] = {V};
+  const float* const vecs[2] = {d, out};
+  sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                          [&](long row, bool valid, float (&x)[1][R], float (&s)[2]) {
+                            const float o = s[0] * (s[1] + dot_row<R>(x[0], coef + R));
+                            if (valid) stream_store<NT>(out + row, o);
                           });
 }
 
 // out = x + M s   (second half of IpUVtmatvec, psgd.py:544)
-template <int R>
+template <int R, bool NT>
 __global__ __launch_bounds__(kThreads) void k_rowdot_axpy(const float* M, const float* xin, float* out, long N,
                                                           const float* __restrict__ coef) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 1>()];
   const float* const mats[1] = {M};
   const float* const vecs[1] = {xin};
-  sweep_rows<R, 1, 1, -1>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+  sweep_rows<R, 1, 1, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
                           [&](long row, bool valid, float (&x)[1][R], float (&s)[1]) {
                             const float o = s[0] + dot_row<R>(x[0], coef);
-                            if (valid) out[row] = o;
+                            if (valid) stream_store<NT>(out + row, o);
                           });
 }
 
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(kThreads) void k_rowdot_axpy(const float* M, const 
 // holds every inner product psgd.py:569-615 needs: V'U (:574), U'U, V'V, V't,
 // U't, U'w, V'w, t't, w'w, t'w.  Only block pairs bi <= bj are computed.
 // Chains are 1 tile long; tile results are accumulated in fp64.
-template <int R>
+template <int R, bool NT>
 __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const float* V, const float* d,
                                                           const float* v, const float* h, long N, double* part) {
   using C = Cfg<R>;
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
 
   Prefetch<R, 2, 3> pf;
   long tile = gw;
-  if (tile < nfull) issue_tile<R, 2, 3>(pf, mats, vecs, tile, lane);
+  if (tile < nfull) issue_tile<R, 2, 3, NT>(pf, mats, vecs, tile, lane);
   while (tile < nfull) {
     commit_tile<R, 2, 3>(pf, lds, lane);
 #pragma unroll
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
       reinterpret_cast<f32x2*>(lds + kTw)[lane + 64 * i] = f32x2{dd * hh, vv / dd};
     }
     const long next = tile + nw;
-    issue_tile<R, 2, 3>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
+    issue_tile<R, 2, 3, NT>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
     __builtin_amdgcn_wave_barrier();
     gram_tile();
     __builtin_amdgcn_wave_barrier();
@@ -530,7 +544,7 @@ struct UpdCoef {
 //   nablaD = Ph h - v invPv      (stored; its max|.| reduced)
 //   UPDATE_U: U <- U - mu (a c1 - b c2),  c1 = atV K, c2 = btV K
 //   else    : V <- V - mu ((a + V c1) c1 - (b + V c2) c2),  c1 = atU, c2 = btU
-template <int R, bool UPDATE_U>
+template <int R, bool UPDATE_U, bool NT>
 __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, const float* d, const float* v,
                                                         const float* h, long N, const float* __restrict__ coef,
                                                         float* nabla, float* part_max) {
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, cons
   const float mu = coef[K::kMu];
   const float* const mats[2] = {U, V};
   const float* const vecs[3] = {d, v, h};
-  sweep_rows<R, 2, 3, (UPDATE_U ? 0 : 1)>(
+  sweep_rows<R, 2, 3, (UPDATE_U ? 0 : 1), NT>(
       mats, vecs, UPDATE_U ? U : V, N, lds[threadIdx.x >> 6],
       [&](long row, bool valid, float (&x)[2][R], float (&s)[3]) {
         const float dd = s[0], vv = s[1], hh = s[2];
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, cons
         const float invPv = valid ? (b - dot_row<R>(x[0], coef + K::kX2)) / dd : 0.0f;
         const float nd = Ph * hh - vv * invPv;
         if (valid) {
-          nabla[row] = nd;
+          stream_store<NT>(nabla + row, nd);
           vmax = fmaxf(vmax, fabsf(nd));
         }
         if constexpr (UPDATE_U) {
@@ -574,12 +588,13 @@ struct UvdOps {
   int tile_rows;
   int gram_len;
   // all launchers: grid chosen by caller (<= kMaxGrid), return hipError_t as int
-  int (*colreduce)(int nvec, const float* M, const float* a, const float* b, long N, float* part, int grid, hipStream_t st);
-  int (*apply_s2)(const float* U, const float* d, const float* g, long N, const float* coef, float* part, int grid, hipStream_t st);
-  int (*apply_s3)(const float* U, const float* V, const float* d, const float* g, float* out, long N, const float* coef, int grid, hipStream_t st);
-  int (*rowdot_axpy)(const float* M, const float* x, float* out, long N, const float* coef, int grid, hipStream_t st);
-  int (*update_gram)(const float* U, const float* V, const float* d, const float* v, const float* h, long N, double* part, int grid, hipStream_t st);
-  int (*update_s2)(int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N, const float* coef, float* nabla, float* part_max, int grid, hipStream_t st);
+  // `nt`: non-temporal policy for the big streams (see stream_load)
+  int (*colreduce)(int nt, int nvec, const float* M, const float* a, const float* b, long N, float* part, int grid, hipStream_t st);
+  int (*apply_s2)(int nt, const float* U, const float* d, const float* g, float* g1out, long N, const float* coef, float* part, int grid, hipStream_t st);
+  int (*apply_s3)(int nt, const float* V, const float* d, float* out, long N, const float* coef, int grid, hipStream_t st);
+  int (*rowdot_axpy)(int nt, const float* M, const float* x, float* out, long N, const float* coef, int grid, hipStream_t st);
+  int (*update_gram)(int nt, const float* U, const float* V, const float* d, const float* v, const float* h, long N, double* part, int grid, hipStream_t st);
+  int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N, const float* coef, float* nabla, float* part_max, int grid, hipStream_t st);
   // max resident blocks per CU for each sweep kernel (occupancy query)
   int (*occupancy)(int which);
 };

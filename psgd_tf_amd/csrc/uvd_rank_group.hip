@@ -10,56 +10,55 @@
 
 namespace psgd {
 
+#define PSGD_LAUNCH(KERNEL_T, KERNEL_F, ...)                                              \
+  do {                                                                                    \
+    if (nt)                                                                               \
+      hipLaunchKernelGGL(KERNEL_T, dim3(grid), dim3(kThreads), 0, st, __VA_ARGS__);      \
+    else                                                                                  \
+      hipLaunchKernelGGL(KERNEL_F, dim3(grid), dim3(kThreads), 0, st, __VA_ARGS__);      \
+    return (int)hipGetLastError();                                                        \
+  } while (0)
+
 template <int R>
 struct Launch {
-  static int colreduce(int nvec, const float* M, const float* a, const float* b, long N, float* part, int grid,
-                       hipStream_t st) {
-    if (nvec == 2)
-      hipLaunchKernelGGL((k_colreduce<R, 2>), dim3(grid), dim3(kThreads), 0, st, M, a, b, N, part);
-    else
-      hipLaunchKernelGGL((k_colreduce<R, 1>), dim3(grid), dim3(kThreads), 0, st, M, a, b, N, part);
-    return (int)hipGetLastError();
+  static int colreduce(int nt, int nvec, const float* M, const float* a, const float* b, long N, float* part,
+                       int grid, hipStream_t st) {
+    if (nvec == 2) PSGD_LAUNCH((k_colreduce<R, 2, true>), (k_colreduce<R, 2, false>), M, a, b, N, part);
+    PSGD_LAUNCH((k_colreduce<R, 1, true>), (k_colreduce<R, 1, false>), M, a, b, N, part);
   }
-  static int apply_s2(const float* U, const float* d, const float* g, long N, const float* coef, float* part,
-                      int grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_apply_s2<R>), dim3(grid), dim3(kThreads), 0, st, U, d, g, N, coef, part);
-    return (int)hipGetLastError();
+  static int apply_s2(int nt, const float* U, const float* d, const float* g, float* g1out, long N,
+                      const float* coef, float* part, int grid, hipStream_t st) {
+    PSGD_LAUNCH((k_apply_s2<R, true>), (k_apply_s2<R, false>), U, d, g, g1out, N, coef, part);
   }
-  static int apply_s3(const float* U, const float* V, const float* d, const float* g, float* out, long N,
-                      const float* coef, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_apply_s3<R>), dim3(grid), dim3(kThreads), 0, st, U, V, d, g, out, N, coef);
-    return (int)hipGetLastError();
+  static int apply_s3(int nt, const float* V, const float* d, float* out, long N, const float* coef, int grid,
+                      hipStream_t st) {
+    PSGD_LAUNCH((k_apply_s3<R, true>), (k_apply_s3<R, false>), V, d, out, N, coef);
   }
-  static int rowdot_axpy(const float* M, const float* x, float* out, long N, const float* coef, int grid,
+  static int rowdot_axpy(int nt, const float* M, const float* x, float* out, long N, const float* coef, int grid,
                          hipStream_t st) {
-    hipLaunchKernelGGL((k_rowdot_axpy<R>), dim3(grid), dim3(kThreads), 0, st, M, x, out, N, coef);
-    return (int)hipGetLastError();
+    PSGD_LAUNCH((k_rowdot_axpy<R, true>), (k_rowdot_axpy<R, false>), M, x, out, N, coef);
   }
-  static int update_gram(const float* U, const float* V, const float* d, const float* v, const float* h, long N,
-                         double* part, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_update_gram<R>), dim3(grid), dim3(kThreads), 0, st, U, V, d, v, h, N, part);
-    return (int)hipGetLastError();
+  static int update_gram(int nt, const float* U, const float* V, const float* d, const float* v, const float* h,
+                         long N, double* part, int grid, hipStream_t st) {
+    PSGD_LAUNCH((k_update_gram<R, true>), (k_update_gram<R, false>), U, V, d, v, h, N, part);
   }
-  static int update_s2(int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N,
-                       const float* coef, float* nabla, float* part_max, int grid, hipStream_t st) {
+  static int update_s2(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h,
+                       long N, const float* coef, float* nabla, float* part_max, int grid, hipStream_t st) {
     if (update_U)
-      hipLaunchKernelGGL((k_update_s2<R, true>), dim3(grid), dim3(kThreads), 0, st, U, V, d, v, h, N, coef, nabla,
-                         part_max);
-    else
-      hipLaunchKernelGGL((k_update_s2<R, false>), dim3(grid), dim3(kThreads), 0, st, U, V, d, v, h, N, coef,
-                         nabla, part_max);
-    return (int)hipGetLastError();
+      PSGD_LAUNCH((k_update_s2<R, true, true>), (k_update_s2<R, true, false>), U, V, d, v, h, N, coef, nabla, part_max);
+    PSGD_LAUNCH((k_update_s2<R, false, true>), (k_update_s2<R, false, false>), U, V, d, v, h, N, coef, nabla,
+                part_max);
   }
   static int occupancy(int which) {
     const void* f = nullptr;
     switch (which) {
-      case kOccColreduce: f = reinterpret_cast<const void*>(&k_colreduce<R, 2>); break;
-      case kOccApplyS2: f = reinterpret_cast<const void*>(&k_apply_s2<R>); break;
-      case kOccApplyS3: f = reinterpret_cast<const void*>(&k_apply_s3<R>); break;
-      case kOccRowdot: f = reinterpret_cast<const void*>(&k_rowdot_axpy<R>); break;
-      case kOccGram: f = reinterpret_cast<const void*>(&k_update_gram<R>); break;
-      case kOccUpdS2U: f = reinterpret_cast<const void*>(&k_update_s2<R, true>); break;
-      case kOccUpdS2V: f = reinterpret_cast<const void*>(&k_update_s2<R, false>); break;
+      case kOccColreduce: f = reinterpret_cast<const void*>(&k_colreduce<R, 2, true>); break;
+      case kOccApplyS2: f = reinterpret_cast<const void*>(&k_apply_s2<R, true>); break;
+      case kOccApplyS3: f = reinterpret_cast<const void*>(&k_apply_s3<R, true>); break;
+      case kOccRowdot: f = reinterpret_cast<const void*>(&k_rowdot_axpy<R, true>); break;
+      case kOccGram: f = reinterpret_cast<const void*>(&k_update_gram<R, true>); break;
+      case kOccUpdS2U: f = reinterpret_cast<const void*>(&k_update_s2<R, true, true>); break;
+      case kOccUpdS2V: f = reinterpret_cast<const void*>(&k_update_s2<R, false, true>); break;
       default: return 0;
     }
     int n = 0;

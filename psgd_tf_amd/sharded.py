@@ -60,15 +60,16 @@ class HipStages:
                                                       *self._w()), "apply_sweep1")
 
     def apply_sweep2(self, U, d, g):
+        self._out = torch.empty_like(g)           # holds g1 = d.*g + U s1 until sweep 3
         wp, wn, st = self._w()
-        _lib.check(self.lib.psgd_uvd_apply_sweep2_f32(U.data_ptr(), d.data_ptr(), g.data_ptr(), self.N, self.r, 1,
-                                                      wp, wn, st), "apply_sweep2")
+        _lib.check(self.lib.psgd_uvd_apply_sweep2_f32(U.data_ptr(), d.data_ptr(), g.data_ptr(), self._out.data_ptr(),
+                                                      self.N, self.r, 1, wp, wn, st), "apply_sweep2")
 
     def apply_sweep3(self, U, V, d, g):
-        out = torch.empty_like(g)
+        out, self._out = self._out, None
         wp, wn, st = self._w()
-        _lib.check(self.lib.psgd_uvd_apply_sweep3_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), g.data_ptr(),
-                                                      out.data_ptr(), self.N, self.r, 1, wp, wn, st), "apply_sweep3")
+        _lib.check(self.lib.psgd_uvd_apply_sweep3_f32(V.data_ptr(), d.data_ptr(), out.data_ptr(), self.N, self.r, 1,
+                                                      wp, wn, st), "apply_sweep3")
         return out
 
     def balance_max(self, U, V):

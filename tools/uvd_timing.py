@@ -39,8 +39,8 @@ def main():
 
     stages = {
         "apply_s1": lambda: lib.psgd_uvd_apply_sweep1_f32(P(V), P(d), P(gr), N, r, P(ws), ws.numel(), st),
-        "apply_s2": lambda: lib.psgd_uvd_apply_sweep2_f32(P(U), P(d), P(gr), N, r, 0, P(ws), ws.numel(), st),
-        "apply_s3": lambda: lib.psgd_uvd_apply_sweep3_f32(P(U), P(V), P(d), P(gr), P(out), N, r, 0, P(ws), ws.numel(), st),
+        "apply_s2": lambda: lib.psgd_uvd_apply_sweep2_f32(P(U), P(d), P(gr), P(out), N, r, 0, P(ws), ws.numel(), st),
+        "apply_s3": lambda: lib.psgd_uvd_apply_sweep3_f32(P(V), P(d), P(out), N, r, 0, P(ws), ws.numel(), st),
         "apply": lambda: lib.psgd_uvd_apply_f32(P(U), P(V), P(d), P(gr), P(out), N, r, P(ws), ws.numel(), st),
         "upd_s1": lambda: lib.psgd_uvd_update_sweep1_f32(P(U), P(V), P(d), P(v), P(h), N, r, P(ws), ws.numel(), st),
         "upd_s2U": lambda: lib.psgd_uvd_update_sweep2_f32(P(U), P(V), P(d), P(v), P(h), N, r, 0.01, 1.1754944e-38, 1, P(ws), ws.numel(), st),
@@ -49,7 +49,7 @@ def main():
         "update": lambda: lib.psgd_uvd_update_f32(P(U), P(V), P(d), P(v), P(h), N, r, 0.01, 1.1754944e-38, 0, 1, P(ws), ws.numel(), st),
     }
     bytes_per_row = {
-        "apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 2), "apply_s3": 4 * (2 * r + 3), "apply": 4 * (4 * r + 5),
+        "apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 3), "apply_s3": 4 * (r + 3), "apply": 4 * (4 * r + 5),
         "upd_s1": 4 * (2 * r + 3), "upd_s2U": 4 * (3 * r + 4), "upd_s2V": 4 * (3 * r + 4), "upd_s3": 12,
         "update": 4 * (5 * r + 10),
     }
