@@ -149,7 +149,8 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.
  * Association order follows the reference: M < N uses ((Ql'Ql) G) Qr' Qr,
- * otherwise Ql' (Ql (G (Qr'Qr))).                                          */
+ * otherwise Ql' (Ql (G (Qr'Qr))).  Ql, Qr are upper-triangular by the reference's
+ * invariant (psgd.py:175-179); entries below the diagonal are not read.     */
 int psgd_kron_dd_apply_f32(const float *Ql, const float *Qr, const float *G,
                            float *out, int M, int N, void *ws,
                            int64_t ws_bytes, void *stream);
@@ -159,6 +160,17 @@ int psgd_kron_dd_apply_f32(const float *Ql, const float *Qr, const float *G,
 int psgd_kron_dd_update_f32(const float *Ql, const float *Qr, const float *dX,
                             const float *dG, float *QlOut, float *QrOut,
                             int M, int N, float step, float tiny, void *ws,
+                            int64_t ws_bytes, void *stream);
+
+/* bf16-operand variant of _precond_grad_dense_dense (psgd.py:182-192) for Transformer-scale
+ * matrices (BASELINE config 5).  Outside the reference's contract (its Kron API is pinned to
+ * fp32, psgd.py:113-115): Ql, Qr are the fp32 master factors (rounded to bf16 per call), G and
+ * out are bf16 [M,N]; every product runs on the bf16 matrix cores with fp32 accumulation and
+ * bf16 intermediates, in the reference's association order.  M and N must be multiples of 8.
+ * Upper-triangular Ql, Qr are assumed (entries below the diagonal are not read).            */
+int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
+int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
+                            void *out_bf16, int M, int N, void *ws,
                             int64_t ws_bytes, void *stream);
 
 #ifdef __cplusplus

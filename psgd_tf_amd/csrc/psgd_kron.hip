@@ -42,7 +42,14 @@ struct GemmArgs {
   const float* scale_max;               // if set: A operand scaled by step / (scale_max[0] + tiny)
   float step, tiny;
   float* maxout;                        // EPI_TRIU_MAX: max|C| (atomicMax on int bits; zeroed by caller)
+  // Triangular operands: products with an upper-triangular factor only need part of the K range.
+  // klo/khi (per pass) restrict k to [lo, hi) with lo = row/col offset of the tile (rounded to BK):
+  //   KLO_M: k >= m0 (A upper-triangular, A(m,k) = 0 for k < m)      KHI_M: k < m0 + BM (A = U', zero for k > m)
+  //   KLO_N: k >= n0 (B(k,n) = 0 for k < n, e.g. B = U')             KHI_N: k < n0 + BN (B upper-triangular)
+  int kmode, kmode2;
 };
+
+enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8 };
 
 __device__ __forceinline__ void stage_tiles(float (*As)[LD], float (*Bs)[LD], const float* A, long a_rs, long a_cs,
                                             const float* B, long b_rs, long b_cs, int M, int N, int K, int m0,
@@ -93,7 +100,14 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
       const long b_rs = pass ? g.b2_rs : g.b_rs, b_cs = pass ? g.b2_cs : g.b_cs;
       const int K = pass ? g.K2 : g.K;
       const float mul = pass ? -a_mul : a_mul;
-      for (int k0 = 0; k0 < K; k0 += BK) {
+      const int km = pass ? g.kmode2 : g.kmode;
+      int klo = 0, khi = K;
+      if (km & KLO_M) klo = max(klo, m0);
+      if (km & KLO_N) klo = max(klo, n0);
+      if (km & KHI_M) khi = min(khi, m0 + BM);
+      if (km & KHI_N) khi = min(khi, n0 + BN);
+      klo = (klo / BK) * BK;
+      for (int k0 = klo; k0 < khi; k0 += BK) {
         __syncthreads();
         stage_tiles(As, Bs, A, a_rs, a_cs, B, b_rs, b_cs, g.M, g.N, K, m0, n0, k0, mul);
         __syncthreads();
@@ -301,15 +315,27 @@ int psgd_kron_dd_apply_f32(const float* Ql, const float* Qr, const float* G, flo
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
   if (M < N) {                                                               // psgd.py:189-190
-    KRON_LAUNCH(launch_gemm(gemm_args(Ql, M, true, Ql, M, false, k.g1, M, M, M, M), st));     // Ql'Ql
+    GemmArgs g1 = gemm_args(Ql, M, true, Ql, M, false, k.g1, M, M, M, M);                    // Ql'Ql
+    g1.kmode = KHI_M | KHI_N;
+    KRON_LAUNCH(launch_gemm(g1, st));
     KRON_LAUNCH(launch_gemm(gemm_args(k.g1, M, false, G, N, false, k.T, N, M, N, M), st));    // (.) G
-    KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N), st));     // (.) Qr'
-    KRON_LAUNCH(launch_gemm(gemm_args(k.A, N, false, Qr, N, false, out, N, M, N, N), st));    // (.) Qr
+    GemmArgs g3 = gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N);                     // (.) Qr'
+    g3.kmode = KLO_N;
+    KRON_LAUNCH(launch_gemm(g3, st));
+    GemmArgs g4 = gemm_args(k.A, N, false, Qr, N, false, out, N, M, N, N);                    // (.) Qr
+    g4.kmode = KHI_N;
+    KRON_LAUNCH(launch_gemm(g4, st));
   } else {                                                                   // psgd.py:191-192
-    KRON_LAUNCH(launch_gemm(gemm_args(Qr, N, true, Qr, N, false, k.g2, N, N, N, N), st));     // Qr'Qr
+    GemmArgs g1 = gemm_args(Qr, N, true, Qr, N, false, k.g2, N, N, N, N);                    // Qr'Qr
+    g1.kmode = KHI_M | KHI_N;
+    KRON_LAUNCH(launch_gemm(g1, st));
     KRON_LAUNCH(launch_gemm(gemm_args(G, N, false, k.g2, N, false, k.T, N, M, N, N), st));    // G (.)
-    KRON_LAUNCH(launch_gemm(gemm_args(Ql, M, false, k.T, N, false, k.A, N, M, N, M), st));    // Ql (.)
-    KRON_LAUNCH(launch_gemm(gemm_args(Ql, M, true, k.A, N, false, out, N, M, N, M), st));     // Ql' (.)
+    GemmArgs g3 = gemm_args(Ql, M, false, k.T, N, false, k.A, N, M, N, M);                    // Ql (.)
+    g3.kmode = KLO_M;
+    KRON_LAUNCH(launch_gemm(g3, st));
+    GemmArgs g4 = gemm_args(Ql, M, true, k.A, N, false, out, N, M, N, M);                     // Ql' (.)
+    g4.kmode = KHI_M;
+    KRON_LAUNCH(launch_gemm(g4, st));
   }
   return PSGD_OK;
 }
@@ -333,8 +359,16 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     KRON_LAUNCH((int)hipGetLastError());
   }
   // K1: A = QlS (dG QrS')
-  KRON_LAUNCH(launch_gemm(gemm_args(dG, N, false, k.QrS, N, true, k.T, N, M, N, N), st));
-  KRON_LAUNCH(launch_gemm(gemm_args(k.QlS, M, false, k.T, N, false, k.A, N, M, N, M), st));
+  {
+    GemmArgs g = gemm_args(dG, N, false, k.QrS, N, true, k.T, N, M, N, N);
+    g.kmode = KLO_N;
+    KRON_LAUNCH(launch_gemm(g, st));
+  }
+  {
+    GemmArgs g = gemm_args(k.QlS, M, false, k.T, N, false, k.A, N, M, N, M);
+    g.kmode = KLO_M;
+    KRON_LAUNCH(launch_gemm(g, st));
+  }
   // K2: X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
   hipLaunchKernelGGL(k_trsm_ut, dim3((M + 63) / 64), dim3(kThreads), 0, st, k.QrS, N, dX, k.X1, M, (long)N, 1L);
   KRON_LAUNCH((int)hipGetLastError());
@@ -358,11 +392,13 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   {
     GemmArgs g = gemm_args(k.g1, M, false, k.QlS, M, false, QlOut, M, M, M, M);
     g.epi = EPI_D_MINUS; g.D = k.QlS; g.ldd = M; g.scale_max = k.scal + 0; g.step = step; g.tiny = tiny;
+    g.kmode = KLO_M | KHI_N;
     KRON_LAUNCH(launch_gemm(g, st));
   }
   {
     GemmArgs g = gemm_args(k.g2, N, false, k.QrS, N, false, QrOut, N, N, N, N);
     g.epi = EPI_D_MINUS; g.D = k.QrS; g.ldd = N; g.scale_max = k.scal + 1; g.step = step; g.tiny = tiny;
+    g.kmode = KLO_M | KHI_N;
     KRON_LAUNCH(launch_gemm(g, st));
   }
   return PSGD_OK;

@@ -30,12 +30,13 @@ def kron_format(shape_l, shape_r):
     return "unknown"
 
 
-def _check_rank2_f32(name, *tensors):
-    # the reference pins its public Kron functions to rank-2 fp32 (psgd.py:67-71, 113-115)
-    for t in tensors:
+def _check_rank2_f32(name, *tensors, allow_bf16_last=False):
+    # the reference pins its public Kron functions to rank-2 fp32 (psgd.py:67-71, 113-115);
+    # the one extension is a bf16 gradient for the (dense, dense) apply (BASELINE config 5)
+    for i, t in enumerate(tensors):
         if t.dim() != 2:
             raise ValueError("%s: rank-2 tensors required, got shape %s" % (name, tuple(t.shape)))
-        if t.dtype != torch.float32:
+        if t.dtype != torch.float32 and not (allow_bf16_last and i == len(tensors) - 1 and t.dtype == torch.bfloat16):
             raise TypeError("%s: fp32 tensors required, got %s" % (name, t.dtype))
 
 
@@ -76,9 +77,33 @@ def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
     return QlO, QrO
 
 
+_kron_ws_bf16 = {}
+
+
+def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
+    """psgd.py:182-192 with bf16 MFMA operands (Grad and result in bf16, fp32 master factors)."""
+    M, N = Grad.shape
+    if M % 8 or N % 8:
+        raise ValueError("precond_grad_kron: the bf16 path needs M and N to be multiples of 8, got %dx%d" % (M, N))
+    Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
+    out = torch.empty_like(Grad)
+    key = (Grad.device.index, M, N)
+    ws = _kron_ws_bf16.get(key)
+    if ws is None:
+        ws = torch.empty(int(_lib.load().psgd_kron_dd_workspace_bytes_bf16(M, N)), dtype=torch.uint8, device=Grad.device)
+        _kron_ws_bf16[key] = ws
+    rc = _lib.load().psgd_kron_dd_apply_bf16(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
+                                              ws.data_ptr(), ws.numel(),
+                                              torch.cuda.current_stream(Grad.device).cuda_stream)
+    _lib.check(rc, "psgd_kron_dd_apply_bf16")
+    return out
+
+
 def _precond_grad_dense_dense(Ql, Qr, Grad):
     """psgd.py:182-192 on the GPU."""
     _require_hip("precond_grad_kron", Ql, Qr, Grad)
+    if Grad.dtype == torch.bfloat16:
+        return _precond_grad_dense_dense_bf16(Ql, Qr, Grad)
     M, N = Grad.shape
     Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
     out = torch.empty_like(Grad)
@@ -213,8 +238,8 @@ def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
 
 
 def precond_grad_kron(Ql, Qr, Grad):
-    _check_rank2_f32("precond_grad_kron", Ql, Qr, Grad)
     fmt = kron_format(Ql.shape, Qr.shape)
+    _check_rank2_f32("precond_grad_kron", Ql, Qr, Grad, allow_bf16_last=(fmt == "dense_dense"))
     if fmt == "dense_dense":
         return _precond_grad_dense_dense(Ql, Qr, Grad)                                      # psgd.py:126
     if fmt == "dense_norm":

@@ -141,3 +141,27 @@ def test_unknown_format_passthrough(psgd, capsys):
     assert a is Ql and b is Qr                                                      # psgd.py:97-99
     assert psgd.precond_grad_kron(Ql, Qr, G) is G                                   # psgd.py:139-141
     assert "Unknown Kronecker product preconditioner" in capsys.readouterr().out
+
+
+# ----------------------------------------------------------------------------- bf16-operand apply (config 5)
+BF16_TOL = 2e-2      # 4 chained bf16-operand GEMMs with bf16 intermediates: ~2^-8 per rounding, see DESIGN.md 4.4
+
+
+@pytest.mark.parametrize("M,N", [(128, 128), (256, 512), (512, 256), (136, 264), (1024, 1024), (8, 8), (200, 72)])
+def test_dense_dense_apply_bf16(psgd, M, N):
+    rng = np.random.default_rng(M + 3 * N)
+    Ql, Qr = _tri_factor(rng, M).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16)
+    out = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), G)
+    assert out.dtype == torch.bfloat16 and out.shape == (M, N)
+    ref = orc.precond_grad_kron(Ql.astype(np.float64), Qr.astype(np.float64), G.float().cpu().numpy().astype(np.float64))
+    assert rel_err(out.float().cpu().numpy(), ref) < BF16_TOL
+    # and it agrees with the fp32 HIP path on the same (bf16-valued) gradient to the same tolerance
+    out32 = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), G.float())
+    assert rel_err(out.float().cpu().numpy(), out32.cpu().numpy()) < BF16_TOL
+
+
+def test_bf16_path_rejects_odd_shapes(psgd):
+    with pytest.raises(ValueError):
+        psgd.precond_grad_kron(torch.eye(5, device="cuda"), torch.eye(12, device="cuda"),
+                               torch.ones(5, 12, device="cuda", dtype=torch.bfloat16))
