@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the multi-GPU code path (process group + all-reduces) even at world size 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,9 +97,12 @@ def main():
     torch.cuda.set_device(dev)
 
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_sharded
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     import preconditioned_stochastic_gradient_descent as psgd
     from psgd_tf_amd import _lib, sharded
@@ -107,7 +112,7 @@ def main():
     n_global = n_local * world
     U, V, d, grad, v, h = make_inputs(n_local, n_global, r, dev, seed=1000 * rank)
 
-    if world == 1:
+    if not use_dist:
         def step(i):
             psgd.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
             return psgd.precond_grad_UVd_math(U, V, d, grad)
@@ -117,7 +122,7 @@ def main():
             return sharded.precond_grad_UVd_math(U, V, d, grad)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -139,7 +144,7 @@ def main():
     lib.psgd_prof_enable(0)
     assert torch.isfinite(out).all().item(), "non-finite preconditioned gradient"
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -193,7 +198,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(r, args.cpu_sample_rows, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -35,9 +35,9 @@ struct GemmArgs {
   const float* A2; long a2_rs, a2_cs;   // optional second pair, subtracted
   const float* B2; long b2_rs, b2_cs;
   int K2;
-  float* C; long ldc;
+  float* C; long ldc;                   // C(m,n) = C[m*ldc + n*c_cs]  (c_cs = 0 means 1)
   int M, N, K;
-  const float* D; long ldd;             // EPI_D_MINUS: C = D - acc
+  const float* D; long ldd;             // EPI_D_MINUS: C = D - acc, D(m,n) = D[m*ldd + n*c_cs]
   int epi;
   const float* scale_max;               // if set: A operand scaled by step / (scale_max[0] + tiny)
   float step, tiny;
@@ -47,6 +47,7 @@ struct GemmArgs {
   //   KLO_M: k >= m0 (A upper-triangular, A(m,k) = 0 for k < m)      KHI_M: k < m0 + BM (A = U', zero for k > m)
   //   KLO_N: k >= n0 (B(k,n) = 0 for k < n, e.g. B = U')             KHI_N: k < n0 + BN (B upper-triangular)
   int kmode, kmode2;
+  long c_cs;
 };
 
 enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8 };
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
   }
 
   float vmax = 0.0f;
+  const long ccs = g.c_cs ? g.c_cs : 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -143,9 +145,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
             v = (col >= row) ? v : 0.0f;
             vmax = fmaxf(vmax, fabsf(v));
           } else if (g.epi == EPI_D_MINUS) {
-            v = g.D[(long)row * g.ldd + col] - v;
+            v = g.D[(long)row * g.ldd + col * ccs] - v;
           }
-          g.C[(long)row * g.ldc + col] = v;
+          g.C[(long)row * g.ldc + col * ccs] = v;
         }
       }
   if (g.epi == EPI_TRIU_MAX) {
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
 // Element (i,j) of X / Y lives at  i*si + j*sj.  With (si,sj) = (ld,1) this is the right solve
 // Y Q = X on row-major [nvec,n]; with (si,sj) = (1,ld) it is Q'Y = X on row-major [n,nvec]
 // (tf.linalg.triangular_solve(Q, X, lower=False, adjoint=True), psgd.py:174).
-__global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ Q, int n, const float* __restrict__ X,
+// Q has leading dimension ldq (a diagonal block of a larger factor can be passed); X may alias Y.
+__global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ Q, int n, int ldq, const float* X,
                                                       float* Y, int nvec, long si, long sj) {
   __shared__ float red[4][64][33];
   __shared__ float Qd[32][32];
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int jj = j0 + j * 16 + (lane & 15);
-        b[j] = (jj < n) ? Q[(long)kk * n + jj] : 0.0f;
+        b[j] = (jj < n) ? Q[(long)kk * ldq + jj] : 0.0f;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ 
         for (int e = 0; e < 4; ++e) red[w][i * 16 + (lane >> 4) * 4 + e][j * 16 + (lane & 15)] = acc[i][j][e];
     for (int e = threadIdx.x; e < 1024; e += kThreads) {
       const int r = e >> 5, c = e & 31;
-      Qd[r][c] = (j0 + r < n && j0 + c < n) ? Q[(long)(j0 + r) * n + j0 + c] : (r == c ? 1.0f : 0.0f);
+      Qd[r][c] = (j0 + r < n && j0 + c < n) ? Q[(long)(j0 + r) * ldq + j0 + c] : (r == c ? 1.0f : 0.0f);
     }
     __syncthreads();
     if (w == 0) {
@@ -290,6 +293,40 @@ static GemmArgs gemm_args(const float* A, int lda, bool ta, const float* B, int 
   return g;
 }
 
+// Blocked solve of  y[i,:] Q = x[i,:]  (see k_trsm_ut) for large n: 256-wide column blocks;
+//   Y[:, jb] = X[:, jb] - Y[:, 0:j0] Q[0:j0, jb]      (one MFMA GEMM, K = j0)
+//   Y[:, jb] <- Y[:, jb] Q[jb, jb]^-1                 (substitution kernel on the diagonal block)
+constexpr int kTrsmBlock = 256;
+
+static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, hipStream_t st) {
+  const dim3 grid((nvec + 63) / 64);
+  if (n <= 2 * kTrsmBlock) {
+    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q, n, n, X, Y, nvec, si, sj);
+    return (int)hipGetLastError();
+  }
+  for (int j0 = 0; j0 < n; j0 += kTrsmBlock) {
+    const int jw = (n - j0 < kTrsmBlock) ? (n - j0) : kTrsmBlock;
+    const float* Xb = X + (long)j0 * sj;
+    float* Yb = Y + (long)j0 * sj;
+    if (j0 > 0) {
+      GemmArgs g = {};
+      g.A = Y; g.a_rs = si; g.a_cs = sj;                 // A(i,k) = Y[i,k]
+      g.B = Q + j0; g.b_rs = n; g.b_cs = 1;              // B(k,j) = Q[k, j0+j]
+      g.C = Yb; g.ldc = si; g.c_cs = sj;
+      g.D = Xb; g.ldd = si;
+      g.M = nvec; g.N = jw; g.K = j0;
+      g.epi = EPI_D_MINUS;
+      const int e = launch_gemm(g, st);
+      if (e) return e;
+    }
+    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q + (long)j0 * n + j0, jw, n, (j0 > 0 ? Yb : Xb), Yb, nvec,
+                       si, sj);
+    const int e = (int)hipGetLastError();
+    if (e) return e;
+  }
+  return 0;
+}
+
 }  // namespace psgdk
 
 using namespace psgdk;
@@ -370,10 +407,8 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     KRON_LAUNCH(launch_gemm(g, st));
   }
   // K2: X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
-  hipLaunchKernelGGL(k_trsm_ut, dim3((M + 63) / 64), dim3(kThreads), 0, st, k.QrS, N, dX, k.X1, M, (long)N, 1L);
-  KRON_LAUNCH((int)hipGetLastError());
-  hipLaunchKernelGGL(k_trsm_ut, dim3((N + 63) / 64), dim3(kThreads), 0, st, k.QlS, M, k.X1, k.Bt, N, 1L, (long)N);
-  KRON_LAUNCH((int)hipGetLastError());
+  KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, st));
+  KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, st));
   // K3/K5: grad1 = triu(A A' - Bt Bt'), max|grad1| -> scal[0]
   {
     GemmArgs g = gemm_args(k.A, N, false, k.A, N, true, k.g1, M, M, M, N);

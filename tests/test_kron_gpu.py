@@ -20,7 +20,7 @@ INCR_TOL = 2e-3
 # the 1x1 dense factor of the NMT demo (:124), tile edges of the 64x64 GEMM blocks and 32-wide
 # triangular-solve blocks, and one larger case.
 DD_SHAPES = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (1, 1), (1, 7), (3, 3),
-             (2, 2), (64, 64), (65, 33), (32, 97), (128, 200), (300, 500), (512, 384)]
+             (2, 2), (64, 64), (65, 33), (32, 97), (128, 200), (300, 500), (512, 384), (700, 600), (1100, 530)]
 
 
 def _tri_factor(rng, n, off=0.05):
