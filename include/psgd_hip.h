@@ -147,6 +147,9 @@ int psgd_prof_collect(int slot, double *total_ms, int *count);
 
 int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 
+/* Experiment knob (not stable ABI). key 0: fp32 GEMM kernel choice (0 auto, 1 64-tile, 2 128-tile). */
+int psgd_kron_set_tuning(int key, int value);
+
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.
  * Association order follows the reference: M < N uses ((Ql'Ql) G) Qr' Qr,
  * otherwise Ql' (Ql (G (Qr'Qr))).  Ql, Qr are upper-triangular by the reference's

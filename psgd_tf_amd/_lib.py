@@ -54,6 +54,7 @@ SIGNATURES = {
     "psgd_uvd_update_sweep3_f32": (_int, [_c_f32p, _i64, _int, _flt, _flt, _c_ws, _i64, _strm]),
     "psgd_uvd_ipuvt_matvec_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_kron_dd_workspace_bytes": (_i64, [_int, _int]),
+    "psgd_kron_set_tuning": (_int, [_int, _int]),
     "psgd_kron_dd_apply_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
     "psgd_kron_dd_workspace_bytes_bf16": (_i64, [_int, _int]),
     "psgd_kron_dd_apply_bf16": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),

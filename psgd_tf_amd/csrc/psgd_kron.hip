@@ -157,6 +157,184 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large-tile variant of k_gemm_f32 (same GemmArgs, same epilogues): 128 x 128 x 16 tile, wave tile
+// 64 x 64 = 4 x 4 MFMA tiles (16 MFMAs per 8 LDS operand reads), LDS double-buffered with the next
+// K tile prefetched into registers while the current one is multiplied (one barrier per K tile),
+// 16-byte global loads on interior tiles whenever the operand's contiguous dimension allows it.
+// LDS pitch 144 floats: the 4 k-rows of an MFMA operand read land 16 banks apart (conflict-free).
+constexpr int GM = 128, GN = 128, GK = 16, GP = 144;
+
+struct TileSrc {
+  const float* P; long rs, cs;   // element (x, k) at P[x*rs + k*cs], x = m (A) or n (B)
+  int X, K;                      // extents
+};
+
+// loads one 128 x 16 operand tile into 8 registers per thread
+__device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int khi, float mul, float (&r)[8]) {
+  const int tid = threadIdx.x;
+  const bool interior = (x0 + GM <= t.X) && (k0 + GK <= khi);
+  if (interior && t.cs == 1 && (t.rs & 3) == 0 && ((reinterpret_cast<uintptr_t>(t.P) & 15) == 0)) {
+    // K-contiguous: two float4 along k per thread
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f = tid + kThreads * u, row = f >> 2, k4 = f & 3;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(t.P + (long)(x0 + row) * t.rs + k0 + 4 * k4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e] * mul;
+    }
+  } else if (interior && t.rs == 1 && (t.cs & 3) == 0 && ((reinterpret_cast<uintptr_t>(t.P) & 15) == 0)) {
+    // X-contiguous: two float4 along x per thread
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f = tid + kThreads * u, k = f >> 5, x4 = f & 31;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(t.P + (long)(k0 + k) * t.cs + x0 + 4 * x4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e] * mul;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + kThreads * u;
+      int x, k;
+      if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % GM; k = e / GM; }
+      const int gx = x0 + x, gk = k0 + k;
+      r[u] = (gx < t.X && gk < khi) ? t.P[(long)gx * t.rs + (long)gk * t.cs] * mul : 0.0f;
+    }
+  }
+}
+
+// writes the registers of g2r_tile into an LDS tile T[k][x]; must take the same branch
+__device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int khi, const float (&r)[8], float (*T)[GP]) {
+  const int tid = threadIdx.x;
+  const bool interior = (x0 + GM <= t.X) && (k0 + GK <= khi);
+  if (interior && t.cs == 1 && (t.rs & 3) == 0 && ((reinterpret_cast<uintptr_t>(t.P) & 15) == 0)) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f = tid + kThreads * u, row = f >> 2, k4 = f & 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[4 * k4 + e][row] = r[4 * u + e];
+    }
+  } else if (interior && t.rs == 1 && (t.cs & 3) == 0 && ((reinterpret_cast<uintptr_t>(t.P) & 15) == 0)) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f = tid + kThreads * u, k = f >> 5, x4 = f & 31;
+      *reinterpret_cast<f32x4*>(&T[k][4 * x4]) = f32x4{r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]};
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + kThreads * u;
+      int x, k;
+      if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % GM; k = e / GM; }
+      T[k][x] = r[u];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_gemm_f32_big(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][GK][GP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GK][GP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+  const bool tri_skip = (g.epi == EPI_TRIU_MAX) && (m0 >= n0 + GN);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float a_mul = 1.0f;
+  if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
+
+  // K ranges of the (up to) two passes
+  int klo[2] = {0, 0}, khi[2] = {0, 0}, nk[2] = {0, 0};
+  if (!tri_skip) {
+    for (int p = 0; p < 2; ++p) {
+      if (p == 1 && !g.A2) break;
+      const int K = p ? g.K2 : g.K, km = p ? g.kmode2 : g.kmode;
+      int lo = 0, hi = K;
+      if (km & KLO_M) lo = max(lo, m0);
+      if (km & KLO_N) lo = max(lo, n0);
+      if (km & KHI_M) hi = min(hi, m0 + GM);
+      if (km & KHI_N) hi = min(hi, n0 + GN);
+      lo = (lo / GK) * GK;
+      klo[p] = lo; khi[p] = hi; nk[p] = hi > lo ? (hi - lo + GK - 1) / GK : 0;
+    }
+  }
+  const int ntile = nk[0] + nk[1];
+  const TileSrc ta[2] = {{g.A, g.a_rs, g.a_cs, g.M, g.K}, {g.A2, g.a2_rs, g.a2_cs, g.M, g.K2}};
+  const TileSrc tb[2] = {{g.B, g.b_cs, g.b_rs, g.N, g.K}, {g.B2, g.b2_cs, g.b2_rs, g.N, g.K2}};   // (n, k) view of B
+
+  float ra[8], rb[8];
+  auto fetch = [&](int t) {
+    const int p = t < nk[0] ? 0 : 1;
+    const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
+    g2r_tile(ta[p], m0, k0, khi[p], p ? -a_mul : a_mul, ra);
+    g2r_tile(tb[p], n0, k0, khi[p], 1.0f, rb);
+  };
+  auto commit = [&](int t, int buf) {
+    const int p = t < nk[0] ? 0 : 1;
+    const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
+    r2s_tile(ta[p], m0, k0, khi[p], ra, As[buf]);
+    r2s_tile(tb[p], n0, k0, khi[p], rb, Bs[buf]);
+  };
+
+  if (ntile > 0) {
+    fetch(0);
+    commit(0, 0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntile) fetch(t + 1);
+#pragma unroll
+    for (int kk = 0; kk < GK / 4; ++kk) {
+      const int kr = kk * 4 + (lane >> 4);
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[buf][kr][wm * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kr][wn * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < ntile) commit(t + 1, buf ^ 1);
+    __syncthreads();
+  }
+
+  float vmax = 0.0f;
+  const long ccs = g.c_cs ? g.c_cs : 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + e;
+        const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+        if (row < g.M && col < g.N) {
+          float v = acc[i][j][e];
+          if (g.epi == EPI_TRIU_MAX) {
+            v = (col >= row) ? v : 0.0f;
+            vmax = fmaxf(vmax, fabsf(v));
+          } else if (g.epi == EPI_D_MINUS) {
+            v = g.D[(long)row * g.ldd + col * ccs] - v;
+          }
+          g.C[(long)row * g.ldc + col * ccs] = v;
+        }
+      }
+  if (g.epi == EPI_TRIU_MAX) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0 && vmax > 0.0f) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+  }
+}
+
 // Solve  y[i,:] Q = x[i,:]  for nvec independent vectors i, Q upper-triangular [n,n] row-major:
 //   y[i,j] = (x[i,j] - sum_{k<j} y[i,k] Q[k,j]) / Q[j,j]
 // Element (i,j) of X / Y lives at  i*si + j*sj.  With (si,sj) = (ld,1) this is the right solve
@@ -276,9 +454,19 @@ static KronWs kron_layout(char* base, int M, int N) {
   return k;
 }
 
+static int g_force_gemm = 0;   // 0 auto, 1 always 64-tile kernel, 2 always 128-tile kernel (experiments)
+
 static int launch_gemm(const GemmArgs& g, hipStream_t st) {
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
-  hipLaunchKernelGGL(k_gemm_f32, grid, dim3(kThreads), 0, st, g);
+  // the 128-tile kernel needs enough tiles to fill the chip; small problems keep 64 x 64 tiles
+  const long big_tiles = (long)((g.N + GN - 1) / GN) * ((g.M + GM - 1) / GM);
+  const bool use_big = g_force_gemm == 2 || (g_force_gemm == 0 && big_tiles >= 64);
+  if (use_big) {
+    dim3 grid((g.N + GN - 1) / GN, (g.M + GM - 1) / GM);
+    hipLaunchKernelGGL(k_gemm_f32_big, grid, dim3(kThreads), 0, st, g);
+  } else {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(kThreads), 0, st, g);
+  }
   return (int)hipGetLastError();
 }
 
@@ -293,9 +481,12 @@ static GemmArgs gemm_args(const float* A, int lda, bool ta, const float* B, int 
   return g;
 }
 
-// Blocked solve of  y[i,:] Q = x[i,:]  (see k_trsm_ut) for large n: 256-wide column blocks;
-//   Y[:, jb] = X[:, jb] - Y[:, 0:j0] Q[0:j0, jb]      (one MFMA GEMM, K = j0)
-//   Y[:, jb] <- Y[:, jb] Q[jb, jb]^-1                 (substitution kernel on the diagonal block)
+// Blocked solve of  y[i,:] Q = x[i,:]  (see k_trsm_ut) for large n, right-looking so that the
+// MFMA GEMMs are wide (N = all remaining columns, K = block width):
+//   Y <- X
+//   for each 256-wide column block jb:   Y[:, jb] <- Y[:, jb] Q[jb, jb]^-1      (substitution kernel, in place)
+//                                        Y[:, >jb] -= Y[:, jb] Q[jb, >jb]      (one GEMM)
+// X and Y are dense nvec*n arrays (either orientation), so the initial copy is one memcpy.
 constexpr int kTrsmBlock = 256;
 
 static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, hipStream_t st) {
@@ -304,25 +495,26 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
     hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q, n, n, X, Y, nvec, si, sj);
     return (int)hipGetLastError();
   }
+  if (hipMemcpyAsync(Y, X, (size_t)nvec * n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
   for (int j0 = 0; j0 < n; j0 += kTrsmBlock) {
     const int jw = (n - j0 < kTrsmBlock) ? (n - j0) : kTrsmBlock;
-    const float* Xb = X + (long)j0 * sj;
     float* Yb = Y + (long)j0 * sj;
-    if (j0 > 0) {
+    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q + (long)j0 * n + j0, jw, n, Yb, Yb, nvec, si, sj);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    const int rest = n - j0 - jw;
+    if (rest > 0) {
       GemmArgs g = {};
-      g.A = Y; g.a_rs = si; g.a_cs = sj;                 // A(i,k) = Y[i,k]
-      g.B = Q + j0; g.b_rs = n; g.b_cs = 1;              // B(k,j) = Q[k, j0+j]
-      g.C = Yb; g.ldc = si; g.c_cs = sj;
-      g.D = Xb; g.ldd = si;
-      g.M = nvec; g.N = jw; g.K = j0;
+      g.A = Yb; g.a_rs = si; g.a_cs = sj;                              // A(i,k) = Y[i, j0+k]
+      g.B = Q + (long)j0 * n + j0 + jw; g.b_rs = n; g.b_cs = 1;        // B(k,j) = Q[j0+k, j0+jw+j]
+      float* Yr = Y + (long)(j0 + jw) * sj;
+      g.C = Yr; g.ldc = si; g.c_cs = sj;
+      g.D = Yr; g.ldd = si;                                            // in place: C = C - A B
+      g.M = nvec; g.N = rest; g.K = jw;
       g.epi = EPI_D_MINUS;
-      const int e = launch_gemm(g, st);
+      e = launch_gemm(g, st);
       if (e) return e;
     }
-    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q + (long)j0 * n + j0, jw, n, (j0 > 0 ? Yb : Xb), Yb, nvec,
-                       si, sj);
-    const int e = (int)hipGetLastError();
-    if (e) return e;
   }
   return 0;
 }
@@ -337,6 +529,11 @@ using namespace psgdk;
   } while (0)
 
 extern "C" {
+
+int psgd_kron_set_tuning(int key, int value) {
+  if (key == 0) { g_force_gemm = value; return PSGD_OK; }
+  return PSGD_ERR_BAD_ARG;
+}
 
 int64_t psgd_kron_dd_workspace_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return PSGD_ERR_BAD_ARG;

@@ -165,3 +165,24 @@ def test_bf16_path_rejects_odd_shapes(psgd):
     with pytest.raises(ValueError):
         psgd.precond_grad_kron(torch.eye(5, device="cuda"), torch.eye(12, device="cuda"),
                                torch.ones(5, 12, device="cuda", dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N", [(257, 120), (300, 500), (1100, 530), (128, 128), (640, 256)])
+def test_large_tile_gemm_kernel_forced(psgd, hip_lib, M, N):
+    """The 128-tile fp32 GEMM kernel is only auto-selected for >= 64 tiles; force it on small and
+    ragged shapes (edge tiles, unaligned leading dimensions) and compare with the oracle."""
+    rng = np.random.default_rng(M + N)
+    Ql, Qr = _tri_factor(rng, M) * 2.0, _tri_factor(rng, N)
+    dX, dG, G = (rng.standard_normal((M, N)) for _ in range(3))
+    a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG, G)]
+    a64 = [a.astype(np.float64) for a in a32]
+    hip_lib.psgd_kron_set_tuning(0, 2)
+    try:
+        out = psgd.precond_grad_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[4]))
+        Ql_n, Qr_n = psgd.update_precond_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[2]), _dev(a32[3]), 0.01)
+        torch.cuda.synchronize()
+    finally:
+        hip_lib.psgd_kron_set_tuning(0, 0)
+    assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(a64[0], a64[1], a64[4])) < TOL
+    Ql_r, Qr_r = orc.update_precond_kron(a64[0], a64[1], a64[2], a64[3], 0.01)
+    assert rel_err(Ql_n.cpu().numpy(), Ql_r) < TOL and rel_err(Qr_n.cpu().numpy(), Qr_r) < TOL
