@@ -73,6 +73,56 @@ def cpu_baseline(r, sample_rows, budget_s):
                       "N=%d r=%d fp32, %d steps in %.1f s, %d threads" % (sample_rows, r, steps, el, cores)}
 
 
+LENET5 = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10)]      # mnist_with_lenet5.py:12-16
+
+
+def kron_apply_flops(M, N):
+    """F_ref of SURVEY 8d: the dense flops of the reference's op sequence (psgd.py:189-192)."""
+    return 2 * M**3 + 2 * M * M * N + 4 * M * N * N if M < N else 2 * N**3 + 2 * M * N * N + 4 * M * M * N
+
+
+def kron_bench(dev, psgd, iters=20):
+    """Second half of the BASELINE metric: Kron dense(x)dense apply GFLOP/s (F_ref numerator).
+    4096 x 4096 with bf16 MFMA operands (config 5), the same in exact fp32, and the LeNet5 layer
+    set in fp32 (config 3; launch/latency-bound: reported as us per set)."""
+    def state(M, N):
+        g = torch.Generator(device=dev).manual_seed(M * 7 + N)
+        Ql = torch.triu(torch.randn(M, M, device=dev, generator=g) * 0.02, 1) + torch.eye(M, device=dev)
+        Qr = torch.triu(torch.randn(N, N, device=dev, generator=g) * 0.02, 1) + torch.eye(N, device=dev)
+        # ten warm-up updates' worth of structure is not needed for timing: factors are dense upper-triangular
+        return Ql, Qr, torch.randn(M, N, device=dev, generator=g)
+
+    def timeit(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+
+    M = N = 4096
+    Ql, Qr, G = state(M, N)
+    Gb = G.to(torch.bfloat16)
+    t_bf16 = timeit(lambda: psgd.precond_grad_kron(Ql, Qr, Gb), iters)
+    t_f32 = timeit(lambda: psgd.precond_grad_kron(Ql, Qr, G), iters)
+    sts = [state(m, n) for m, n in LENET5]
+    t_lenet = timeit(lambda: [psgd.precond_grad_kron(a, b, c) for a, b, c in sts], 50)
+    f_big = kron_apply_flops(M, N)
+    f_lenet = sum(kron_apply_flops(m, n) for m, n in LENET5)
+    return {
+        "metric": "kron_dense_dense_apply_gflops", "flop_count": "F_ref (dense flops of psgd.py:189-192)",
+        "4096x4096_bf16_operands": {"ms": t_bf16, "gflops": f_big / t_bf16 / 1e6, "mfma_peak_gflops": 2.5e6,
+                                    "frac_of_bf16_peak_Fref": f_big / t_bf16 / 1e6 / 2.5e6,
+                                    "note": "triangular K-ranges skipped: issued flops ~0.5 F_ref"},
+        "4096x4096_fp32": {"ms": t_f32, "gflops": f_big / t_f32 / 1e6, "mfma_peak_gflops": 157.3e3},
+        "lenet5_set_fp32": {"us": t_lenet * 1e3, "gflops": f_lenet / t_lenet / 1e6, "bound": "launch/latency"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +133,7 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kron", action="store_true", help="skip the Kron apply GFLOP/s leg")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU code path (process group + all-reduces) even at world size 1")
     args = ap.parse_args()
@@ -192,10 +243,13 @@ def main():
                          "traffic": traffic, "alg_bytes_per_launch": kbytes[dom] * n_local,
                          "avg_launch_ms": slot_ms[dom], "kernels": kern, "paths": paths},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1:
             del U, V, d, grad, v, h, out
             torch.cuda.empty_cache()
-            res["cpu_baseline"] = cpu_baseline(r, args.cpu_sample_rows, args.cpu_budget_s)
+            if not args.no_kron:
+                res["kron"] = kron_bench(dev, psgd)
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(r, args.cpu_sample_rows, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
 
     if use_dist:

@@ -147,7 +147,7 @@ int psgd_prof_collect(int slot, double *total_ms, int *count);
 
 int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 
-/* Experiment knob (not stable ABI). key 0: fp32 GEMM kernel choice (0 auto, 1 64-tile, 2 128-tile). */
+/* Experiment knob (not stable ABI). key 0: fp32 GEMM tile choice (0 auto, 1 = 64, 2 = 128, 3 = 32). */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.
@@ -164,6 +164,23 @@ int psgd_kron_dd_update_f32(const float *Ql, const float *Qr, const float *dX,
                             const float *dG, float *QlOut, float *QrOut,
                             int M, int N, float step, float tiny, void *ws,
                             int64_t ws_bytes, void *stream);
+
+/* Batched forms for networks of small layers (LeNet5: mnist_with_lenet5.py:12-16, where every
+ * GEMM is launch-bound): the same stage of every layer runs in ONE launch.  Arrays are HOST
+ * arrays of `count` device pointers / sizes; `ws` holds the per-layer workspaces back to back
+ * (psgd_kron_dd_workspace_bytes_batched).  Results are identical to the per-layer calls.
+ * The batched update requires M, N <= 512 for every layer (PSGD_ERR_SHAPE otherwise).       */
+int64_t psgd_kron_dd_workspace_bytes_batched(const int *M, const int *N, int count);
+int psgd_kron_dd_apply_batched_f32(const float *const *Ql, const float *const *Qr,
+                                   const float *const *G, float *const *out,
+                                   const int *M, const int *N, int count,
+                                   void *ws, int64_t ws_bytes, void *stream);
+int psgd_kron_dd_update_batched_f32(const float *const *Ql, const float *const *Qr,
+                                    const float *const *dX, const float *const *dG,
+                                    float *const *QlOut, float *const *QrOut,
+                                    const int *M, const int *N, int count,
+                                    float step, float tiny,
+                                    void *ws, int64_t ws_bytes, void *stream);
 
 /* bf16-operand variant of _precond_grad_dense_dense (psgd.py:182-192) for Transformer-scale
  * matrices (BASELINE config 5).  Outside the reference's contract (its Kron API is pinned to

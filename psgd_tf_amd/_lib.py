@@ -55,6 +55,11 @@ SIGNATURES = {
     "psgd_uvd_ipuvt_matvec_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_kron_dd_workspace_bytes": (_i64, [_int, _int]),
     "psgd_kron_set_tuning": (_int, [_int, _int]),
+    "psgd_kron_dd_workspace_bytes_batched": (_i64, [ctypes.POINTER(_int), ctypes.POINTER(_int), _int]),
+    "psgd_kron_dd_apply_batched_f32": (_int, [ctypes.POINTER(ctypes.c_void_p)] * 4 + [ctypes.POINTER(_int)] * 2 +
+                                       [_int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_update_batched_f32": (_int, [ctypes.POINTER(ctypes.c_void_p)] * 6 + [ctypes.POINTER(_int)] * 2 +
+                                        [_int, _flt, _flt, _c_ws, _i64, _strm]),
     "psgd_kron_dd_apply_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
     "psgd_kron_dd_workspace_bytes_bf16": (_i64, [_int, _int]),
     "psgd_kron_dd_apply_bf16": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),

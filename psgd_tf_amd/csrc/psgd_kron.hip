@@ -24,7 +24,6 @@ namespace psgdk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, BK = 16, LD = 80;   // LDS row pitch 80 floats: conflict-free MFMA reads
 constexpr int kThreads = 256;
 
 enum { EPI_STORE = 0, EPI_TRIU_MAX = 1, EPI_D_MINUS = 2 };
@@ -52,204 +51,116 @@ struct GemmArgs {
 
 enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8 };
 
-__device__ __forceinline__ void stage_tiles(float (*As)[LD], float (*Bs)[LD], const float* A, long a_rs, long a_cs,
-                                            const float* B, long b_rs, long b_cs, int M, int N, int K, int m0,
-                                            int n0, int k0, float a_mul) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int t = 0; t < (BM * BK) / kThreads; ++t) {
-    const int e = tid + kThreads * t;
-    int m, k;
-    if (a_cs == 1) { k = e % BK; m = e / BK; } else { m = e % BM; k = e / BM; }
-    const int gm = m0 + m, gk = k0 + k;
-    As[k][m] = (gm < M && gk < K) ? A[gm * a_rs + gk * a_cs] * a_mul : 0.0f;
-  }
-#pragma unroll
-  for (int t = 0; t < (BN * BK) / kThreads; ++t) {
-    const int e = tid + kThreads * t;
-    int n, k;
-    if (b_cs == 1) { n = e % BN; k = e / BN; } else { k = e % BK; n = e / BK; }
-    const int gn = n0 + n, gk = k0 + k;
-    Bs[k][n] = (gn < N && gk < K) ? B[gk * b_rs + gn * b_cs] : 0.0f;
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
-  __shared__ float As[BK][LD];
-  __shared__ float Bs[BK][LD];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wm = w >> 1, wn = w & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  // upper-triangular outputs: tiles strictly below the diagonal are all zero
-  const bool tri_skip = (g.epi == EPI_TRIU_MAX) && (m0 >= n0 + BN);
-
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  float a_mul = 1.0f;
-  if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
-
-  if (!tri_skip) {
-    for (int pass = 0; pass < 2; ++pass) {
-      const float* A = pass ? g.A2 : g.A;
-      const float* B = pass ? g.B2 : g.B;
-      if (!A) break;
-      const long a_rs = pass ? g.a2_rs : g.a_rs, a_cs = pass ? g.a2_cs : g.a_cs;
-      const long b_rs = pass ? g.b2_rs : g.b_rs, b_cs = pass ? g.b2_cs : g.b_cs;
-      const int K = pass ? g.K2 : g.K;
-      const float mul = pass ? -a_mul : a_mul;
-      const int km = pass ? g.kmode2 : g.kmode;
-      int klo = 0, khi = K;
-      if (km & KLO_M) klo = max(klo, m0);
-      if (km & KLO_N) klo = max(klo, n0);
-      if (km & KHI_M) khi = min(khi, m0 + BM);
-      if (km & KHI_N) khi = min(khi, n0 + BN);
-      klo = (klo / BK) * BK;
-      for (int k0 = klo; k0 < khi; k0 += BK) {
-        __syncthreads();
-        stage_tiles(As, Bs, A, a_rs, a_cs, B, b_rs, b_cs, g.M, g.N, K, m0, n0, k0, mul);
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-          const int kr = kk * 4 + (lane >> 4);
-          float a[2], b[2];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) a[i] = As[kr][wm * 32 + i * 16 + (lane & 15)];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) b[j] = Bs[kr][wn * 32 + j * 16 + (lane & 15)];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  float vmax = 0.0f;
-  const long ccs = g.c_cs ? g.c_cs : 1;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + e;
-        const int col = n0 + wn * 32 + j * 16 + (lane & 15);
-        if (row < g.M && col < g.N) {
-          float v = acc[i][j][e];
-          if (g.epi == EPI_TRIU_MAX) {
-            v = (col >= row) ? v : 0.0f;
-            vmax = fmaxf(vmax, fabsf(v));
-          } else if (g.epi == EPI_D_MINUS) {
-            v = g.D[(long)row * g.ldd + col * ccs] - v;
-          }
-          g.C[(long)row * g.ldc + col * ccs] = v;
-        }
-      }
-  if (g.epi == EPI_TRIU_MAX) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    if (lane == 0 && vmax > 0.0f) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Large-tile variant of k_gemm_f32 (same GemmArgs, same epilogues): 128 x 128 x 16 tile, wave tile
-// 64 x 64 = 4 x 4 MFMA tiles (16 MFMAs per 8 LDS operand reads), LDS double-buffered with the next
-// K tile prefetched into registers while the current one is multiplied (one barrier per K tile),
-// 16-byte global loads on interior tiles whenever the operand's contiguous dimension allows it.
-// LDS pitch 144 floats: the 4 k-rows of an MFMA operand read land 16 banks apart (conflict-free).
-constexpr int GM = 128, GN = 128, GK = 16, GP = 144;
+// fp32 GEMM on the matrix cores, one template for two square tile sizes T (64 for small problems
+// and the batched launches, 128 when there are enough tiles to fill the chip):
+//   T x T x 16 block tile, 4 waves (2 x 2), wave tile T/2 x T/2 = (T/32)^2 MFMA 16x16x4 tiles;
+//   LDS double-buffered, the next K tile is prefetched into registers while the current one is
+//   multiplied (one barrier per K tile); 16-byte global loads on interior tiles whenever the
+//   operand's contiguous dimension allows it, guarded scalar loads on edges / odd strides;
+//   LDS pitch T + 16 floats: the 4 k-rows of an MFMA operand read land 16 banks apart.
 
 struct TileSrc {
   const float* P; long rs, cs;   // element (x, k) at P[x*rs + k*cs], x = m (A) or n (B)
-  int X, K;                      // extents
+  int X;                         // extent along x
 };
 
-// loads one 128 x 16 operand tile into 8 registers per thread
-__device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int khi, float mul, float (&r)[8]) {
+template <int T, int GK>
+__device__ __forceinline__ int tile_mode(const TileSrc& t, int x0, int k0, int khi) {
+  const bool interior = (x0 + T <= t.X) && (k0 + GK <= khi);
+  const bool aligned = (reinterpret_cast<uintptr_t>(t.P) & 15) == 0;
+  if (interior && aligned && t.cs == 1 && (t.rs & 3) == 0) return 1;   // K-contiguous, float4 along k
+  if (interior && aligned && t.rs == 1 && (t.cs & 3) == 0) return 2;   // X-contiguous, float4 along x
+  return 0;
+}
+
+template <int T, int GK>
+__device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int khi, float mul,
+                                         float (&r)[T * GK / kThreads]) {
   const int tid = threadIdx.x;
-  const bool interior = (x0 + GM <= t.X) && (k0 + GK <= khi);
-  if (interior && t.cs == 1 && (t.rs & 3) == 0 && ((reinterpret_cast<uintptr_t>(t.P) & 15) == 0)) {
-    // K-contiguous: two float4 along k per thread
+  constexpr int NV = T * GK / (4 * kThreads);   // float4 per thread
+  const int mode = tile_mode<T, GK>(t, x0, k0, khi);
+  if (mode == 1) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f = tid + kThreads * u, row = f >> 2, k4 = f & 3;
+    for (int u = 0; u < NV; ++u) {
+      const int f = tid + kThreads * u, row = f / (GK / 4), k4 = f % (GK / 4);
       const f32x4 v = *reinterpret_cast<const f32x4*>(t.P + (long)(x0 + row) * t.rs + k0 + 4 * k4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e] * mul;
     }
-  } else if (interior && t.rs == 1 && (t.cs & 3) == 0 && ((reinterpret_cast<uintptr_t>(t.P) & 15) == 0)) {
-    // X-contiguous: two float4 along x per thread
+  } else if (mode == 2) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f = tid + kThreads * u, k = f >> 5, x4 = f & 31;
+    for (int u = 0; u < NV; ++u) {
+      const int f = tid + kThreads * u, k = f / (T / 4), x4 = f % (T / 4);
       const f32x4 v = *reinterpret_cast<const f32x4*>(t.P + (long)(k0 + k) * t.cs + x0 + 4 * x4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e] * mul;
     }
   } else {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < T * GK / kThreads; ++u) {
       const int e = tid + kThreads * u;
       int x, k;
-      if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % GM; k = e / GM; }
+      if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % T; k = e / T; }
       const int gx = x0 + x, gk = k0 + k;
       r[u] = (gx < t.X && gk < khi) ? t.P[(long)gx * t.rs + (long)gk * t.cs] * mul : 0.0f;
     }
   }
 }
 
-// writes the registers of g2r_tile into an LDS tile T[k][x]; must take the same branch
-__device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int khi, const float (&r)[8], float (*T)[GP]) {
+template <int T, int GK>
+__device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int khi,
+                                         const float (&r)[T * GK / kThreads], float (*S)[T + 16]) {
   const int tid = threadIdx.x;
-  const bool interior = (x0 + GM <= t.X) && (k0 + GK <= khi);
-  if (interior && t.cs == 1 && (t.rs & 3) == 0 && ((reinterpret_cast<uintptr_t>(t.P) & 15) == 0)) {
+  constexpr int NV = T * GK / (4 * kThreads);
+  const int mode = tile_mode<T, GK>(t, x0, k0, khi);
+  if (mode == 1) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f = tid + kThreads * u, row = f >> 2, k4 = f & 3;
+    for (int u = 0; u < NV; ++u) {
+      const int f = tid + kThreads * u, row = f / (GK / 4), k4 = f % (GK / 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) T[4 * k4 + e][row] = r[4 * u + e];
+      for (int e = 0; e < 4; ++e) S[4 * k4 + e][row] = r[4 * u + e];
     }
-  } else if (interior && t.rs == 1 && (t.cs & 3) == 0 && ((reinterpret_cast<uintptr_t>(t.P) & 15) == 0)) {
+  } else if (mode == 2) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f = tid + kThreads * u, k = f >> 5, x4 = f & 31;
-      *reinterpret_cast<f32x4*>(&T[k][4 * x4]) = f32x4{r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]};
+    for (int u = 0; u < NV; ++u) {
+      const int f = tid + kThreads * u, k = f / (T / 4), x4 = f % (T / 4);
+      *reinterpret_cast<f32x4*>(&S[k][4 * x4]) = f32x4{r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]};
     }
   } else {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < T * GK / kThreads; ++u) {
       const int e = tid + kThreads * u;
       int x, k;
-      if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % GM; k = e / GM; }
-      T[k][x] = r[u];
+      if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % T; k = e / T; }
+      S[k][x] = r[u];
     }
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_gemm_f32_big(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[2][GK][GP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][GK][GP];
+template <int T, int GK>
+struct GemmLds {
+  float A[2][GK][T + 16];
+  float B[2][GK][T + 16];
+};
+
+template <int T, int GK>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, GemmLds<T, GK>& L) {
+  constexpr int W = T / 2, NT = T / 32;   // wave tile edge, MFMA tiles per wave edge
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1;
-  const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
-  const bool tri_skip = (g.epi == EPI_TRIU_MAX) && (m0 >= n0 + GN);
+  // upper-triangular outputs: tiles strictly below the diagonal are all zero
+  const bool tri_skip = (g.epi == EPI_TRIU_MAX) && (m0 >= n0 + T);
 
-  f32x4 acc[4][4];
+  f32x4 acc[NT][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   float a_mul = 1.0f;
   if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
 
-  // K ranges of the (up to) two passes
   int klo[2] = {0, 0}, khi[2] = {0, 0}, nk[2] = {0, 0};
   if (!tri_skip) {
     for (int p = 0; p < 2; ++p) {
@@ -258,28 +169,28 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32_big(GemmArgs g) {
       int lo = 0, hi = K;
       if (km & KLO_M) lo = max(lo, m0);
       if (km & KLO_N) lo = max(lo, n0);
-      if (km & KHI_M) hi = min(hi, m0 + GM);
-      if (km & KHI_N) hi = min(hi, n0 + GN);
+      if (km & KHI_M) hi = min(hi, m0 + T);
+      if (km & KHI_N) hi = min(hi, n0 + T);
       lo = (lo / GK) * GK;
       klo[p] = lo; khi[p] = hi; nk[p] = hi > lo ? (hi - lo + GK - 1) / GK : 0;
     }
   }
   const int ntile = nk[0] + nk[1];
-  const TileSrc ta[2] = {{g.A, g.a_rs, g.a_cs, g.M, g.K}, {g.A2, g.a2_rs, g.a2_cs, g.M, g.K2}};
-  const TileSrc tb[2] = {{g.B, g.b_cs, g.b_rs, g.N, g.K}, {g.B2, g.b2_cs, g.b2_rs, g.N, g.K2}};   // (n, k) view of B
+  const TileSrc ta[2] = {{g.A, g.a_rs, g.a_cs, g.M}, {g.A2, g.a2_rs, g.a2_cs, g.M}};
+  const TileSrc tb[2] = {{g.B, g.b_cs, g.b_rs, g.N}, {g.B2, g.b2_cs, g.b2_rs, g.N}};   // (n, k) view of B
 
-  float ra[8], rb[8];
+  float ra[T * GK / kThreads], rb[T * GK / kThreads];
   auto fetch = [&](int t) {
     const int p = t < nk[0] ? 0 : 1;
     const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
-    g2r_tile(ta[p], m0, k0, khi[p], p ? -a_mul : a_mul, ra);
-    g2r_tile(tb[p], n0, k0, khi[p], 1.0f, rb);
+    g2r_tile<T, GK>(ta[p], m0, k0, khi[p], p ? -a_mul : a_mul, ra);
+    g2r_tile<T, GK>(tb[p], n0, k0, khi[p], 1.0f, rb);
   };
   auto commit = [&](int t, int buf) {
     const int p = t < nk[0] ? 0 : 1;
     const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
-    r2s_tile(ta[p], m0, k0, khi[p], ra, As[buf]);
-    r2s_tile(tb[p], n0, k0, khi[p], rb, Bs[buf]);
+    r2s_tile<T, GK>(ta[p], m0, k0, khi[p], ra, L.A[buf]);
+    r2s_tile<T, GK>(tb[p], n0, k0, khi[p], rb, L.B[buf]);
   };
 
   if (ntile > 0) {
@@ -293,15 +204,15 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32_big(GemmArgs g) {
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
       const int kr = kk * 4 + (lane >> 4);
-      float a[4], b[4];
+      float a[NT], b[NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[buf][kr][wm * 64 + i * 16 + (lane & 15)];
+      for (int i = 0; i < NT; ++i) a[i] = L.A[buf][kr][wm * W + i * 16 + (lane & 15)];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kr][wn * 64 + j * 16 + (lane & 15)];
+      for (int j = 0; j < NT; ++j) b[j] = L.B[buf][kr][wn * W + j * 16 + (lane & 15)];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < ntile) commit(t + 1, buf ^ 1);
     __syncthreads();
@@ -310,13 +221,13 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32_big(GemmArgs g) {
   float vmax = 0.0f;
   const long ccs = g.c_cs ? g.c_cs : 1;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + e;
-        const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+        const int row = m0 + wm * W + i * 16 + (lane >> 4) * 4 + e;
+        const int col = n0 + wn * W + j * 16 + (lane & 15);
         if (row < g.M && col < g.N) {
           float v = acc[i][j][e];
           if (g.epi == EPI_TRIU_MAX) {
@@ -335,18 +246,52 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32_big(GemmArgs g) {
   }
 }
 
+template <int T, int GK>
+__global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) GemmLds<T, GK> L;
+  gemm_body<T, GK>(g, blockIdx.y * T, blockIdx.x * T, L);
+}
+
+// tile configurations: 128 x 128 x 16 for large problems; 64 x 64 x 64 for small ones, where the
+// grid cannot fill the chip and every K step costs a full (unhidden) load latency
+constexpr int kSmallK = 64, kBigK = 16;
+
+// One launch for the same stage of several independent problems (the layers of a small network):
+// blockIdx.x -> (problem, tile) through the prefix sums of the tile counts.  64 x 64 tiles.
+constexpr int kMaxBatch = 8;
+struct GemmBatch {
+  int count;
+  int tile_end[kMaxBatch];     // inclusive prefix sums of tiles
+  GemmArgs g[kMaxBatch];
+};
+
+template <int T>
+__global__ __launch_bounds__(kThreads) void k_gemm_f32_batched(GemmBatch b) {
+  __shared__ __attribute__((aligned(16))) GemmLds<T, kSmallK> L;
+  int p = 0;
+  while (p + 1 < b.count && (int)blockIdx.x >= b.tile_end[p]) ++p;
+  const int t = blockIdx.x - (p ? b.tile_end[p - 1] : 0);
+  const GemmArgs& g = b.g[p];
+  const int tn = (g.N + T - 1) / T;
+  gemm_body<T, kSmallK>(g, (t / tn) * T, (t % tn) * T, L);
+}
+
 // Solve  y[i,:] Q = x[i,:]  for nvec independent vectors i, Q upper-triangular [n,n] row-major:
 //   y[i,j] = (x[i,j] - sum_{k<j} y[i,k] Q[k,j]) / Q[j,j]
 // Element (i,j) of X / Y lives at  i*si + j*sj.  With (si,sj) = (ld,1) this is the right solve
 // Y Q = X on row-major [nvec,n]; with (si,sj) = (1,ld) it is Q'Y = X on row-major [n,nvec]
 // (tf.linalg.triangular_solve(Q, X, lower=False, adjoint=True), psgd.py:174).
 // Q has leading dimension ldq (a diagonal block of a larger factor can be passed); X may alias Y.
-__global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ Q, int n, int ldq, const float* X,
-                                                      float* Y, int nvec, long si, long sj) {
-  __shared__ float red[4][64][33];
-  __shared__ float Qd[32][32];
+struct TrsmArgs {
+  const float* Q; int n, ldq;
+  const float* X; float* Y;
+  int nvec; long si, sj;
+};
+
+__device__ __forceinline__ void trsm_body(const float* __restrict__ Q, int n, int ldq, const float* X, float* Y,
+                                          int nvec, long si, long sj, int v0, float (*red)[64][33],
+                                          float (*Qd)[32]) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int v0 = blockIdx.x * 64;
   for (int j0 = 0; j0 < n; j0 += 32) {
     const int jw = (n - j0 < 32) ? (n - j0) : 32;
     f32x4 acc[4][2];
@@ -409,10 +354,39 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ 
   }
 }
 
+__global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ Q, int n, int ldq, const float* X,
+                                                      float* Y, int nvec, long si, long sj) {
+  __shared__ float red[4][64][33];
+  __shared__ float Qd[32][32];
+  trsm_body(Q, n, ldq, X, Y, nvec, si, sj, blockIdx.x * 64, red, Qd);
+}
+
+struct TrsmBatch {
+  int count;
+  int blk_end[kMaxBatch];
+  TrsmArgs t[kMaxBatch];
+};
+
+__global__ __launch_bounds__(kThreads) void k_trsm_ut_batched(TrsmBatch b) {
+  __shared__ float red[4][64][33];
+  __shared__ float Qd[32][32];
+  int p = 0;
+  while (p + 1 < b.count && (int)blockIdx.x >= b.blk_end[p]) ++p;
+  const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
+  const TrsmArgs& t = b.t[p];
+  trsm_body(t.Q, t.n, t.ldq, t.X, t.Y, t.nvec, t.si, t.sj, blk * 64, red, Qd);
+}
+
 // rho = sqrt(max diag Ql / max diag Qr); QlS = Ql / rho; QrS = rho Qr      (psgd.py:166-170)
-__global__ __launch_bounds__(kThreads) void k_kron_balance(const float* __restrict__ Ql, const float* __restrict__ Qr,
-                                                           int M, int N, float* QlS, float* QrS) {
-  __shared__ float red[2][4];
+struct BalanceBatch {
+  int count;
+  const float* Ql[kMaxBatch]; const float* Qr[kMaxBatch];
+  float* QlS[kMaxBatch]; float* QrS[kMaxBatch];
+  int M[kMaxBatch], N[kMaxBatch];
+};
+
+__device__ __forceinline__ void balance_body(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
+                                             float* QlS, float* QrS, float (*red)[4]) {
   float ml = -INFINITY, mr = -INFINITY;
   for (int i = threadIdx.x; i < M; i += kThreads) ml = fmaxf(ml, Ql[(long)i * M + i]);
   for (int i = threadIdx.x; i < N; i += kThreads) mr = fmaxf(mr, Qr[(long)i * N + i]);
@@ -431,6 +405,18 @@ __global__ __launch_bounds__(kThreads) void k_kron_balance(const float* __restri
   const long tid = (long)blockIdx.x * kThreads + threadIdx.x, nth = (long)gridDim.x * kThreads;
   for (long i = tid; i < nl; i += nth) QlS[i] = Ql[i] / rho;
   for (long i = tid; i < nr; i += nth) QrS[i] = rho * Qr[i];
+}
+
+__global__ __launch_bounds__(kThreads) void k_kron_balance(const float* __restrict__ Ql, const float* __restrict__ Qr,
+                                                           int M, int N, float* QlS, float* QrS) {
+  __shared__ float red[2][4];
+  balance_body(Ql, Qr, M, N, QlS, QrS, red);
+}
+
+__global__ __launch_bounds__(kThreads) void k_kron_balance_batched(BalanceBatch b) {
+  __shared__ float red[2][4];
+  const int p = blockIdx.y;
+  balance_body(b.Ql[p], b.Qr[p], b.M[p], b.N[p], b.QlS[p], b.QrS[p], red);
 }
 
 // ------------------------------------------------------------- host side ----
@@ -458,27 +444,63 @@ static int g_force_gemm = 0;   // 0 auto, 1 always 64-tile kernel, 2 always 128-
 
 static int launch_gemm(const GemmArgs& g, hipStream_t st) {
   // the 128-tile kernel needs enough tiles to fill the chip; small problems keep 64 x 64 tiles
-  const long big_tiles = (long)((g.N + GN - 1) / GN) * ((g.M + GM - 1) / GM);
-  const bool use_big = g_force_gemm == 2 || (g_force_gemm == 0 && big_tiles >= 64);
-  if (use_big) {
-    dim3 grid((g.N + GN - 1) / GN, (g.M + GM - 1) / GM);
-    hipLaunchKernelGGL(k_gemm_f32_big, grid, dim3(kThreads), 0, st, g);
-  } else {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
-    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(kThreads), 0, st, g);
-  }
+  const long t128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
+  const long t64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64);
+  int T = t128 >= 64 ? 128 : (t64 >= 48 ? 64 : 32);   // tiny problems: more, smaller tiles (latency-bound per block)
+  if (g_force_gemm == 1) T = 64;
+  if (g_force_gemm == 2) T = 128;
+  if (g_force_gemm == 3) T = 32;
+  dim3 grid((g.N + T - 1) / T, (g.M + T - 1) / T);
+  if (T == 128) hipLaunchKernelGGL((k_gemm_f32<128, kBigK>), grid, dim3(kThreads), 0, st, g);
+  else if (T == 64) hipLaunchKernelGGL((k_gemm_f32<64, kSmallK>), grid, dim3(kThreads), 0, st, g);
+  else hipLaunchKernelGGL((k_gemm_f32<32, kSmallK>), grid, dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
 }
 
 // C[M,N] = op(A) op(B); ta/tb: operand stored transposed (row-major [K,M] / [N,K])
 static GemmArgs gemm_args(const float* A, int lda, bool ta, const float* B, int ldb, bool tb, float* C, int ldc, int M,
-                          int N, int K) {
+                          int N, int K, int kmode = 0) {
   GemmArgs g = {};
   g.A = A; g.a_rs = ta ? 1 : lda; g.a_cs = ta ? lda : 1;
   g.B = B; g.b_rs = tb ? 1 : ldb; g.b_cs = tb ? ldb : 1;
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.epi = EPI_STORE;
+  g.kmode = kmode;
   return g;
+}
+
+// The four products of _precond_grad_dense_dense in the reference's association order
+// (psgd.py:189-192) with the K ranges implied by the upper-triangular factors.
+static void plan_apply(const float* Ql, const float* Qr, const float* G, float* out, int M, int N, const KronWs& k,
+                       GemmArgs (&s)[4]) {
+  if (M < N) {                                                                    // psgd.py:189-190
+    s[0] = gemm_args(Ql, M, true, Ql, M, false, k.g1, M, M, M, M, KHI_M | KHI_N);   // Ql'Ql
+    s[1] = gemm_args(k.g1, M, false, G, N, false, k.T, N, M, N, M);                 // (.) G
+    s[2] = gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N, KLO_N);           // (.) Qr'
+    s[3] = gemm_args(k.A, N, false, Qr, N, false, out, N, M, N, N, KHI_N);          // (.) Qr
+  } else {                                                                        // psgd.py:191-192
+    s[0] = gemm_args(Qr, N, true, Qr, N, false, k.g2, N, N, N, N, KHI_M | KHI_N);   // Qr'Qr
+    s[1] = gemm_args(G, N, false, k.g2, N, false, k.T, N, M, N, N);                 // G (.)
+    s[2] = gemm_args(Ql, M, false, k.T, N, false, k.A, N, M, N, M, KLO_M);          // Ql (.)
+    s[3] = gemm_args(Ql, M, true, k.A, N, false, out, N, M, N, M, KHI_M);           // Ql' (.)
+  }
+}
+
+// GEMM stages of _update_precond_dense_dense (psgd.py:173-179): 0,1 before the solves, 2..5 after.
+static void plan_update(const float* dG, float* QlOut, float* QrOut, int M, int N, float step, float tiny,
+                        const KronWs& k, GemmArgs (&s)[6]) {
+  s[0] = gemm_args(dG, N, false, k.QrS, N, true, k.T, N, M, N, N, KLO_N);           // T = dG QrS'       (:173)
+  s[1] = gemm_args(k.QlS, M, false, k.T, N, false, k.A, N, M, N, M, KLO_M);         // A = QlS T
+  s[2] = gemm_args(k.A, N, false, k.A, N, true, k.g1, M, M, M, N);                  // grad1 = triu(A A' - Bt Bt') (:175)
+  s[2].A2 = k.Bt; s[2].a2_rs = N; s[2].a2_cs = 1; s[2].B2 = k.Bt; s[2].b2_rs = 1; s[2].b2_cs = N; s[2].K2 = N;
+  s[2].epi = EPI_TRIU_MAX; s[2].maxout = k.scal + 0;
+  s[3] = gemm_args(k.A, N, true, k.A, N, false, k.g2, N, N, N, M);                  // grad2 = triu(A'A - Bt'Bt) (:176)
+  s[3].A2 = k.Bt; s[3].a2_rs = 1; s[3].a2_cs = N; s[3].B2 = k.Bt; s[3].b2_rs = N; s[3].b2_cs = 1; s[3].K2 = M;
+  s[3].epi = EPI_TRIU_MAX; s[3].maxout = k.scal + 1;
+  s[4] = gemm_args(k.g1, M, false, k.QlS, M, false, QlOut, M, M, M, M, KLO_M | KHI_N);   // QlS - (step1 grad1) QlS (:179)
+  s[4].epi = EPI_D_MINUS; s[4].D = k.QlS; s[4].ldd = M; s[4].scale_max = k.scal + 0; s[4].step = step; s[4].tiny = tiny;
+  s[5] = gemm_args(k.g2, N, false, k.QrS, N, false, QrOut, N, N, N, N, KLO_M | KHI_N);   // QrS - (step2 grad2) QrS
+  s[5].epi = EPI_D_MINUS; s[5].D = k.QrS; s[5].ldd = N; s[5].scale_max = k.scal + 1; s[5].step = step; s[5].tiny = tiny;
 }
 
 // Blocked solve of  y[i,:] Q = x[i,:]  (see k_trsm_ut) for large n, right-looking so that the
@@ -519,6 +541,23 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
   return 0;
 }
 
+static int launch_gemm_batch(const GemmArgs* g, int count, hipStream_t st) {
+  GemmBatch b;
+  b.count = count;
+  long t64 = 0;
+  for (int p = 0; p < count; ++p) t64 += (long)((g[p].N + 63) / 64) * ((g[p].M + 63) / 64);
+  const int T = t64 >= 96 ? 64 : 32;
+  int tiles = 0;
+  for (int p = 0; p < count; ++p) {
+    b.g[p] = g[p];
+    tiles += ((g[p].N + T - 1) / T) * ((g[p].M + T - 1) / T);
+    b.tile_end[p] = tiles;
+  }
+  if (T == 64) hipLaunchKernelGGL((k_gemm_f32_batched<64>), dim3(tiles), dim3(kThreads), 0, st, b);
+  else hipLaunchKernelGGL((k_gemm_f32_batched<32>), dim3(tiles), dim3(kThreads), 0, st, b);
+  return (int)hipGetLastError();
+}
+
 }  // namespace psgdk
 
 using namespace psgdk;
@@ -527,6 +566,11 @@ using namespace psgdk;
   do {                                        \
     if ((expr) != 0) return PSGD_ERR_LAUNCH;  \
   } while (0)
+
+static int kron_ws_check(void* ws, int64_t ws_bytes, int64_t need) {
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < need) return PSGD_ERR_WORKSPACE;
+  return PSGD_OK;
+}
 
 extern "C" {
 
@@ -544,33 +588,12 @@ int psgd_kron_dd_apply_f32(const float* Ql, const float* Qr, const float* G, flo
                            int64_t ws_bytes, void* stream) {
   if (!Ql || !Qr || !G || !out) return PSGD_ERR_BAD_ARG;
   if (M <= 0 || N <= 0) return PSGD_ERR_SHAPE;
-  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < kron_layout(nullptr, M, N).total)
-    return PSGD_ERR_WORKSPACE;
+  if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  if (M < N) {                                                               // psgd.py:189-190
-    GemmArgs g1 = gemm_args(Ql, M, true, Ql, M, false, k.g1, M, M, M, M);                    // Ql'Ql
-    g1.kmode = KHI_M | KHI_N;
-    KRON_LAUNCH(launch_gemm(g1, st));
-    KRON_LAUNCH(launch_gemm(gemm_args(k.g1, M, false, G, N, false, k.T, N, M, N, M), st));    // (.) G
-    GemmArgs g3 = gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N);                     // (.) Qr'
-    g3.kmode = KLO_N;
-    KRON_LAUNCH(launch_gemm(g3, st));
-    GemmArgs g4 = gemm_args(k.A, N, false, Qr, N, false, out, N, M, N, N);                    // (.) Qr
-    g4.kmode = KHI_N;
-    KRON_LAUNCH(launch_gemm(g4, st));
-  } else {                                                                   // psgd.py:191-192
-    GemmArgs g1 = gemm_args(Qr, N, true, Qr, N, false, k.g2, N, N, N, N);                    // Qr'Qr
-    g1.kmode = KHI_M | KHI_N;
-    KRON_LAUNCH(launch_gemm(g1, st));
-    KRON_LAUNCH(launch_gemm(gemm_args(G, N, false, k.g2, N, false, k.T, N, M, N, N), st));    // G (.)
-    GemmArgs g3 = gemm_args(Ql, M, false, k.T, N, false, k.A, N, M, N, M);                    // Ql (.)
-    g3.kmode = KLO_M;
-    KRON_LAUNCH(launch_gemm(g3, st));
-    GemmArgs g4 = gemm_args(Ql, M, true, k.A, N, false, out, N, M, N, M);                     // Ql' (.)
-    g4.kmode = KHI_M;
-    KRON_LAUNCH(launch_gemm(g4, st));
-  }
+  GemmArgs s[4];
+  plan_apply(Ql, Qr, G, out, M, N, k, s);
+  for (int i = 0; i < 4; ++i) KRON_LAUNCH(launch_gemm(s[i], st));
   return PSGD_OK;
 }
 
@@ -579,59 +602,117 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
                             void* stream) {
   if (!Ql || !Qr || !dX || !dG || !QlOut || !QrOut) return PSGD_ERR_BAD_ARG;
   if (M <= 0 || N <= 0) return PSGD_ERR_SHAPE;
-  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < kron_layout(nullptr, M, N).total)
-    return PSGD_ERR_WORKSPACE;
+  if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
   if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
-  // K0: balance
-  {
+  {                                                                               // K0: balance (:166-170)
     const long tot = (long)M * M + (long)N * N;
     int grid = (int)((tot + kThreads - 1) / kThreads);
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, k.QlS, k.QrS);
     KRON_LAUNCH((int)hipGetLastError());
   }
-  // K1: A = QlS (dG QrS')
-  {
-    GemmArgs g = gemm_args(dG, N, false, k.QrS, N, true, k.T, N, M, N, N);
-    g.kmode = KLO_N;
-    KRON_LAUNCH(launch_gemm(g, st));
-  }
-  {
-    GemmArgs g = gemm_args(k.QlS, M, false, k.T, N, false, k.A, N, M, N, M);
-    g.kmode = KLO_M;
-    KRON_LAUNCH(launch_gemm(g, st));
-  }
-  // K2: X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
+  GemmArgs s[6];
+  plan_update(dG, QlOut, QrOut, M, N, step, tiny, k, s);
+  KRON_LAUNCH(launch_gemm(s[0], st));
+  KRON_LAUNCH(launch_gemm(s[1], st));
+  // K2 (:174): X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
   KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, st));
   KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, st));
-  // K3/K5: grad1 = triu(A A' - Bt Bt'), max|grad1| -> scal[0]
-  {
-    GemmArgs g = gemm_args(k.A, N, false, k.A, N, true, k.g1, M, M, M, N);
-    g.A2 = k.Bt; g.a2_rs = N; g.a2_cs = 1; g.B2 = k.Bt; g.b2_rs = 1; g.b2_cs = N; g.K2 = N;
-    g.epi = EPI_TRIU_MAX; g.maxout = k.scal + 0;
-    KRON_LAUNCH(launch_gemm(g, st));
+  for (int i = 2; i < 6; ++i) KRON_LAUNCH(launch_gemm(s[i], st));
+  return PSGD_OK;
+}
+
+/* ---- batched forms: the same stage of every layer in one launch (LeNet5-size layers are
+ * launch-bound: 4 launches per apply of the whole set instead of 4 per layer). ------------- */
+
+int64_t psgd_kron_dd_workspace_bytes_batched(const int* M, const int* N, int count) {
+  if (!M || !N || count <= 0) return PSGD_ERR_BAD_ARG;
+  int64_t tot = 0;
+  for (int p = 0; p < count; ++p) {
+    if (M[p] <= 0 || N[p] <= 0) return PSGD_ERR_BAD_ARG;
+    tot += kron_layout(nullptr, M[p], N[p]).total;
   }
-  // K4/K5: grad2 = triu(A'A - Bt'Bt), max|grad2| -> scal[1]
-  {
-    GemmArgs g = gemm_args(k.A, N, true, k.A, N, false, k.g2, N, N, N, M);
-    g.A2 = k.Bt; g.a2_rs = 1; g.a2_cs = N; g.B2 = k.Bt; g.b2_rs = N; g.b2_cs = 1; g.K2 = M;
-    g.epi = EPI_TRIU_MAX; g.maxout = k.scal + 1;
-    KRON_LAUNCH(launch_gemm(g, st));
+  return tot;
+}
+
+int psgd_kron_dd_apply_batched_f32(const float* const* Ql, const float* const* Qr, const float* const* G,
+                                   float* const* out, const int* M, const int* N, int count, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+  if (!Ql || !Qr || !G || !out || !M || !N || count <= 0) return PSGD_ERR_BAD_ARG;
+  const int64_t need = psgd_kron_dd_workspace_bytes_batched(M, N, count);
+  if (need < 0) return (int)need;
+  if (kron_ws_check(ws, ws_bytes, need)) return PSGD_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = static_cast<char*>(ws);
+  for (int p0 = 0; p0 < count; p0 += kMaxBatch) {
+    const int nb = (count - p0 < kMaxBatch) ? count - p0 : kMaxBatch;
+    GemmArgs s[kMaxBatch][4];
+    for (int q = 0; q < nb; ++q) {
+      const int p = p0 + q;
+      if (!Ql[p] || !Qr[p] || !G[p] || !out[p]) return PSGD_ERR_BAD_ARG;
+      KronWs k = kron_layout(base, M[p], N[p]);
+      base += k.total;
+      plan_apply(Ql[p], Qr[p], G[p], out[p], M[p], N[p], k, s[q]);
+    }
+    for (int stage = 0; stage < 4; ++stage) {
+      GemmArgs g[kMaxBatch];
+      for (int q = 0; q < nb; ++q) g[q] = s[q][stage];
+      KRON_LAUNCH(launch_gemm_batch(g, nb, st));
+    }
   }
-  // K6: Q - (step_i grad_i) Q
-  {
-    GemmArgs g = gemm_args(k.g1, M, false, k.QlS, M, false, QlOut, M, M, M, M);
-    g.epi = EPI_D_MINUS; g.D = k.QlS; g.ldd = M; g.scale_max = k.scal + 0; g.step = step; g.tiny = tiny;
-    g.kmode = KLO_M | KHI_N;
-    KRON_LAUNCH(launch_gemm(g, st));
-  }
-  {
-    GemmArgs g = gemm_args(k.g2, N, false, k.QrS, N, false, QrOut, N, N, N, N);
-    g.epi = EPI_D_MINUS; g.D = k.QrS; g.ldd = N; g.scale_max = k.scal + 1; g.step = step; g.tiny = tiny;
-    g.kmode = KLO_M | KHI_N;
-    KRON_LAUNCH(launch_gemm(g, st));
+  return PSGD_OK;
+}
+
+int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* Qr, const float* const* dX,
+                                    const float* const* dG, float* const* QlOut, float* const* QrOut, const int* M,
+                                    const int* N, int count, float step, float tiny, void* ws, int64_t ws_bytes,
+                                    void* stream) {
+  if (!Ql || !Qr || !dX || !dG || !QlOut || !QrOut || !M || !N || count <= 0) return PSGD_ERR_BAD_ARG;
+  const int64_t need = psgd_kron_dd_workspace_bytes_batched(M, N, count);
+  if (need < 0) return (int)need;
+  if (kron_ws_check(ws, ws_bytes, need)) return PSGD_ERR_WORKSPACE;
+  for (int p = 0; p < count; ++p)
+    if (M[p] > 2 * kTrsmBlock || N[p] > 2 * kTrsmBlock) return PSGD_ERR_SHAPE;   // batched form is for small layers
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = static_cast<char*>(ws);
+  for (int p0 = 0; p0 < count; p0 += kMaxBatch) {
+    const int nb = (count - p0 < kMaxBatch) ? count - p0 : kMaxBatch;
+    GemmArgs s[kMaxBatch][6];
+    KronWs k[kMaxBatch];
+    BalanceBatch bb;
+    TrsmBatch t1, t2;
+    bb.count = t1.count = t2.count = nb;
+    int blk1 = 0, blk2 = 0;
+    for (int q = 0; q < nb; ++q) {
+      const int p = p0 + q;
+      if (!Ql[p] || !Qr[p] || !dX[p] || !dG[p] || !QlOut[p] || !QrOut[p]) return PSGD_ERR_BAD_ARG;
+      k[q] = kron_layout(base, M[p], N[p]);
+      base += k[q].total;
+      if (hipMemsetAsync(k[q].scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
+      plan_update(dG[p], QlOut[p], QrOut[p], M[p], N[p], step, tiny, k[q], s[q]);
+      bb.Ql[q] = Ql[p]; bb.Qr[q] = Qr[p]; bb.QlS[q] = k[q].QlS; bb.QrS[q] = k[q].QrS; bb.M[q] = M[p]; bb.N[q] = N[p];
+      t1.t[q] = {k[q].QrS, N[p], N[p], dX[p], k[q].X1, M[p], (long)N[p], 1L};
+      t2.t[q] = {k[q].QlS, M[p], M[p], k[q].X1, k[q].Bt, N[p], 1L, (long)N[p]};
+      blk1 += (M[p] + 63) / 64; t1.blk_end[q] = blk1;
+      blk2 += (N[p] + 63) / 64; t2.blk_end[q] = blk2;
+    }
+    hipLaunchKernelGGL(k_kron_balance_batched, dim3(64, nb), dim3(kThreads), 0, st, bb);
+    KRON_LAUNCH((int)hipGetLastError());
+    GemmArgs g[kMaxBatch];
+    for (int stage = 0; stage < 2; ++stage) {
+      for (int q = 0; q < nb; ++q) g[q] = s[q][stage];
+      KRON_LAUNCH(launch_gemm_batch(g, nb, st));
+    }
+    hipLaunchKernelGGL(k_trsm_ut_batched, dim3(blk1), dim3(kThreads), 0, st, t1);
+    KRON_LAUNCH((int)hipGetLastError());
+    hipLaunchKernelGGL(k_trsm_ut_batched, dim3(blk2), dim3(kThreads), 0, st, t2);
+    KRON_LAUNCH((int)hipGetLastError());
+    for (int stage = 2; stage < 6; ++stage) {
+      for (int q = 0; q < nb; ++q) g[q] = s[q][stage];
+      KRON_LAUNCH(launch_gemm_batch(g, nb, st));
+    }
   }
   return PSGD_OK;
 }

@@ -115,6 +115,75 @@ def _precond_grad_dense_dense(Ql, Qr, Grad):
     return out
 
 
+# --------------------------------------------------------------------------- batched (dense, dense): HIP
+_batch_ws = {}
+
+
+def _batched_ok(Qls, Qrs, mats):
+    return all(kron_format(a.shape, b.shape) == "dense_dense" and a.dtype == b.dtype == g.dtype == torch.float32
+               and g.is_cuda for a, b, g in zip(Qls, Qrs, mats))
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(vals):
+    import ctypes
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def _batch_workspace(device, Ms, Ns):
+    key = (device.index, tuple(Ms), tuple(Ns))
+    ws = _batch_ws.get(key)
+    if ws is None:
+        nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes_batched(_int_array(Ms), _int_array(Ns), len(Ms)))
+        if nbytes < 0:
+            _lib.check(nbytes, "psgd_kron_dd_workspace_bytes_batched")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _batch_ws[key] = ws
+    return ws
+
+
+def precond_grad_kron_batched(Qls, Qrs, Grads):
+    """[precond_grad_kron(Ql, Qr, G) for ...] (mnist_with_lenet5.py:53) with the same stage of every
+    (dense, dense) layer in one kernel launch.  Other formats fall back to the per-layer call."""
+    Qls, Qrs, Grads = list(Qls), list(Qrs), list(Grads)
+    if not _batched_ok(Qls, Qrs, Grads):
+        return [precond_grad_kron(a, b, g) for a, b, g in zip(Qls, Qrs, Grads)]
+    Qls, Qrs, Grads = ([t.contiguous() for t in ts] for ts in (Qls, Qrs, Grads))
+    outs = [torch.empty_like(g) for g in Grads]
+    Ms, Ns = [g.shape[0] for g in Grads], [g.shape[1] for g in Grads]
+    dev = Grads[0].device
+    ws = _batch_workspace(dev, Ms, Ns)
+    rc = _lib.load().psgd_kron_dd_apply_batched_f32(_ptr_array(Qls), _ptr_array(Qrs), _ptr_array(Grads),
+                                                     _ptr_array(outs), _int_array(Ms), _int_array(Ns), len(Ms),
+                                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psgd_kron_dd_apply_batched_f32")
+    return outs
+
+
+def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
+    """[update_precond_kron(Ql, Qr, dX, dG, step) for ...] (mnist_with_lenet5.py:51), batched as above.
+    Returns a list of (Ql_new, Qr_new)."""
+    Qls, Qrs, dXs, dGs = list(Qls), list(Qrs), list(dXs), list(dGs)
+    small = all(max(x.shape) <= 512 for x in dXs)
+    if not (small and _batched_ok(Qls, Qrs, dXs) and _batched_ok(Qls, Qrs, dGs)):
+        return [update_precond_kron(a, b, x, g, step) for a, b, x, g in zip(Qls, Qrs, dXs, dGs)]
+    Qls, Qrs, dXs, dGs = ([t.contiguous() for t in ts] for ts in (Qls, Qrs, dXs, dGs))
+    QlO, QrO = [torch.empty_like(t) for t in Qls], [torch.empty_like(t) for t in Qrs]
+    Ms, Ns = [x.shape[0] for x in dXs], [x.shape[1] for x in dXs]
+    dev = dXs[0].device
+    ws = _batch_workspace(dev, Ms, Ns)
+    rc = _lib.load().psgd_kron_dd_update_batched_f32(_ptr_array(Qls), _ptr_array(Qrs), _ptr_array(dXs), _ptr_array(dGs),
+                                                      _ptr_array(QlO), _ptr_array(QrO), _int_array(Ms), _int_array(Ns),
+                                                      len(Ms), float(step), float(_tiny), ws.data_ptr(), ws.numel(),
+                                                      torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "psgd_kron_dd_update_batched_f32")
+    return list(zip(QlO, QrO))
+
+
 # --------------------------------------------------------------------------- sparse formats: torch ops
 def _solve_ut_adjoint(Q, X):
     """tf.linalg.triangular_solve(Q, X, lower=False, adjoint=True): Q^T Y = X."""

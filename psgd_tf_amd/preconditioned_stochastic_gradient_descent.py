@@ -127,6 +127,16 @@ def precond_grad_kron(Ql, Qr, Grad):
     return _kron.precond_grad_kron(Ql, Qr, Grad)
 
 
+def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
+    """Extension: the list comprehension of mnist_with_lenet5.py:51 as one batched call."""
+    return _kron.update_precond_kron_batched(Qls, Qrs, dXs, dGs, step)
+
+
+def precond_grad_kron_batched(Qls, Qrs, Grads):
+    """Extension: the list comprehension of mnist_with_lenet5.py:53 as one batched call."""
+    return _kron.precond_grad_kron_batched(Qls, Qrs, Grads)
+
+
 # --------------------------------------------------------------------------- UVd math
 def IpUVtmatvec(U, V, x):
     """psgd.py:540-544: (I + U V') x for a column vector x ([N] or [N,1]) or [N,k] matrix."""

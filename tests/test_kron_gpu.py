@@ -167,16 +167,17 @@ def test_bf16_path_rejects_odd_shapes(psgd):
                                torch.ones(5, 12, device="cuda", dtype=torch.bfloat16))
 
 
+@pytest.mark.parametrize("tile_choice", [1, 2, 3])
 @pytest.mark.parametrize("M,N", [(257, 120), (300, 500), (1100, 530), (128, 128), (640, 256)])
-def test_large_tile_gemm_kernel_forced(psgd, hip_lib, M, N):
-    """The 128-tile fp32 GEMM kernel is only auto-selected for >= 64 tiles; force it on small and
-    ragged shapes (edge tiles, unaligned leading dimensions) and compare with the oracle."""
+def test_every_gemm_tile_size_forced(psgd, hip_lib, M, N, tile_choice):
+    """The fp32 GEMM picks its tile size (32 / 64 / 128) from the problem size; force each one on small
+    and ragged shapes (edge tiles, unaligned leading dimensions) and compare with the oracle."""
     rng = np.random.default_rng(M + N)
     Ql, Qr = _tri_factor(rng, M) * 2.0, _tri_factor(rng, N)
     dX, dG, G = (rng.standard_normal((M, N)) for _ in range(3))
     a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG, G)]
     a64 = [a.astype(np.float64) for a in a32]
-    hip_lib.psgd_kron_set_tuning(0, 2)
+    hip_lib.psgd_kron_set_tuning(0, tile_choice)
     try:
         out = psgd.precond_grad_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[4]))
         Ql_n, Qr_n = psgd.update_precond_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[2]), _dev(a32[3]), 0.01)
@@ -186,3 +187,20 @@ def test_large_tile_gemm_kernel_forced(psgd, hip_lib, M, N):
     assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(a64[0], a64[1], a64[4])) < TOL
     Ql_r, Qr_r = orc.update_precond_kron(a64[0], a64[1], a64[2], a64[3], 0.01)
     assert rel_err(Ql_n.cpu().numpy(), Ql_r) < TOL and rel_err(Qr_n.cpu().numpy(), Qr_r) < TOL
+
+
+def test_batched_lenet_set_equals_per_layer(psgd):
+    """The batched calls must give exactly the per-layer results (same kernels, same tiles)."""
+    shapes = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (1, 1), (3, 3)]   # > 8: two chunks
+    rng = np.random.default_rng(5)
+    Qls = [_dev(_tri_factor(rng, m) * 2.0) for m, n in shapes]
+    Qrs = [_dev(_tri_factor(rng, n)) for m, n in shapes]
+    dXs = [_dev(rng.standard_normal((m, n))) for m, n in shapes]
+    dGs = [_dev(rng.standard_normal((m, n))) for m, n in shapes]
+    Gs = [_dev(rng.standard_normal((m, n))) for m, n in shapes]
+    outs = psgd.precond_grad_kron_batched(Qls, Qrs, Gs)
+    news = psgd.update_precond_kron_batched(Qls, Qrs, dXs, dGs, 0.01)
+    for i, (m, n) in enumerate(shapes):
+        assert torch.equal(outs[i], psgd.precond_grad_kron(Qls[i], Qrs[i], Gs[i])), (m, n)
+        a, b = psgd.update_precond_kron(Qls[i], Qrs[i], dXs[i], dGs[i], 0.01)
+        assert torch.equal(news[i][0], a) and torch.equal(news[i][1], b), (m, n)

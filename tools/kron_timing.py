@@ -56,11 +56,17 @@ def main():
     def lenet_update():
         return [psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01) for (Ql, Qr, dX, dG, G) in sts]
 
+    Qls, Qrs = [x[0] for x in sts], [x[1] for x in sts]
+    dXs, dGs, Gs = [x[2] for x in sts], [x[3] for x in sts], [x[4] for x in sts]
+    tab = timeit(lambda: psgd.precond_grad_kron_batched(Qls, Qrs, Gs), 50)
+    tub = timeit(lambda: psgd.update_precond_kron_batched(Qls, Qrs, dXs, dGs, 0.01), 50)
     fa = sum(flops_apply(M, N) for M, N in LENET)
     fu = sum(flops_update(M, N) for M, N in LENET)
     ta, tu = timeit(lenet_apply, 50), timeit(lenet_update, 50)
     print("LeNet5 set  apply  %8.1f us  %7.2f GFLOP/s (F_ref)" % (ta * 1e3, fa / ta / 1e6))
     print("LeNet5 set  update %8.1f us  %7.2f GFLOP/s (F_ref)" % (tu * 1e3, fu / tu / 1e6))
+    print("LeNet5 set  apply  batched %8.1f us  %7.2f GFLOP/s" % (tab * 1e3, fa / tab / 1e6))
+    print("LeNet5 set  update batched %8.1f us  %7.2f GFLOP/s" % (tub * 1e3, fu / tub / 1e6))
     for (M, N) in [(257, 120), (1024, 1024), (args.big, args.big)]:
         Ql, Qr, dX, dG, G = state(M, N, dev)
         ta = timeit(lambda: psgd.precond_grad_kron(Ql, Qr, G), args.iters)
