@@ -1,0 +1,124 @@
+"""GPU: the UVd optimizer wrapper (psgd.py:630-764) -- state/index logic on the device, exact and
+finite-difference Hessian-vector products through torch.autograd, clipping, the FD perturbation
+undo -- on a small delayed-XOR-like RNN of the reference's size (rnn_xor_UVd_preconditioner.py:28-31:
+1021 parameters in 5 tensors)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import psgd_oracle as orc
+from tests.uvd_cases import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_params(dev, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    shapes = [(2, 30), (30, 30), (30,), (30, 1), (1,)]
+    return [(torch.randn(s, generator=g) * 0.3).to(dev).requires_grad_(True) for s in shapes]
+
+
+def _xor_batch(dev, seed, batch=64, seq=8):
+    rng = np.random.default_rng(seed)
+    x = np.zeros((batch, seq, 2), dtype=np.float32)
+    y = np.zeros((batch, 1), dtype=np.float32)
+    for i in range(batch):
+        x[i, :, 0] = rng.choice([-1.0, 1.0], seq)
+        i1, i2 = int(rng.integers(0, 2)), int(rng.integers(2, seq))
+        x[i, i1, 1] = x[i, i2, 1] = 1.0
+        y[i] = -1.0 if x[i, i1, 0] == x[i, i2, 0] else 1.0
+    return torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+
+
+def _loss(params, x, y):
+    Wx, Wh, bh, Wo, bo = params
+    h = torch.zeros(x.shape[0], 30, device=x.device)
+    for t in range(x.shape[1]):
+        h = torch.tanh(x[:, t] @ Wx + h @ Wh + bh)
+    return -torch.mean(torch.log(torch.sigmoid(y * (h @ Wo + bo))))     # rnn_xor_UVd_preconditioner.py:43-44
+
+
+def test_init_state_and_index_logic(hip_lib):
+    import preconditioned_stochastic_gradient_descent as psgd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    params = _make_params(dev)
+    opt = psgd.UVd(params, rank_of_modification=10, preconditioner_init_scale=0.5)
+    assert opt._param_sizes == [60, 900, 30, 30, 1] and opt._param_cumsizes == [60, 960, 990, 1020, 1021]   # psgd.py:684-685
+    assert opt._U.shape == (1021, 10) and opt._V.shape == (1021, 10) and opt._d.shape == (1021, 1)
+    assert torch.all(opt._d == 0.5)                                                                       # psgd.py:690
+    std = (1.0 / (1021 * 10)) ** 0.5                                                                     # psgd.py:687
+    assert abs(float(opt._U.std()) / std - 1) < 0.05 and abs(float(opt._V.std()) / std - 1) < 0.05
+    assert opt._tiny == float(np.finfo(np.float32).tiny) and opt._delta_param_scale == pytest.approx(2.0 ** -11.5)
+    assert math.isinf(float(opt.grad_clip_max_norm))                                                     # psgd.py:675-676
+
+
+def test_one_exact_step_matches_oracle(hip_lib):
+    """One step with update probability 1 and exact Hv: replay the same (v, h, g) through the fp64 oracle."""
+    import preconditioned_stochastic_gradient_descent as psgd
+    dev = torch.device("cuda:0")
+    params = _make_params(dev, seed=1)
+    x, y = _xor_batch(dev, 1)
+    gen = torch.Generator().manual_seed(5)
+    opt = psgd.UVd(params, rank_of_modification=10, lr_params=0.05, lr_preconditioner=0.02, grad_clip_max_norm=1.0,
+                   generator=gen)
+    U0, V0, d0 = (t.cpu().numpy().astype(np.float64) for t in (opt._U, opt._V, opt._d))
+    p0 = [p.detach().clone() for p in params]
+    # reproduce the probe vectors the step will draw (torch.randn_like on the device uses the global generator)
+    torch.manual_seed(123)
+    vs = [torch.randn_like(p) for p in params]
+    torch.manual_seed(123)
+    closure = lambda: _loss(params, x, y)
+    ret = opt.step(closure)
+    assert torch.is_tensor(ret) and ret.dim() == 0
+    # oracle replay
+    grads = torch.autograd.grad(_loss(p0_req := [p.clone().requires_grad_(True) for p in p0], x, y), p0_req, create_graph=True)
+    Hvs = torch.autograd.grad(grads, p0_req, vs)
+    flat = lambda ts: np.concatenate([t.detach().reshape(-1).cpu().numpy().astype(np.float64) for t in ts])[:, None]
+    v, h, g = flat(vs), flat(Hvs), flat(grads)
+    gen2 = torch.Generator().manual_seed(5)
+    assert torch.rand((), generator=gen2).item() < 1.0                      # the update_Q draw (psgd.py:703)
+    bal = bool(torch.rand((), generator=gen2).item() < 0.01)
+    upd = bool(torch.rand((), generator=gen2).item() < 0.5)
+    orc.update_precond_UVd_math_(U0, V0, d0, v, h, 0.02, opt._tiny, balance=bal, update_U=upd)
+    for got, ref in ((opt._U, U0), (opt._V, V0), (opt._d, d0)):
+        assert rel_err(got.cpu().numpy(), ref) < 2e-5
+    pre = orc.precond_grad_UVd_math(U0, V0, d0, g)
+    lr = float(orc.uvd_clip_lr(pre, 0.05, 1.0, opt._tiny))                  # psgd.py:750-754
+    new_flat = flat(p0) - lr * pre
+    assert rel_err(flat(params), new_flat) < 2e-5
+    # unflatten order: each tensor got its own slice (psgd.py:758-759)
+    for p, ref in zip(params, orc.uvd_unflatten(new_flat[:, 0], [tuple(q.shape) for q in p0])):
+        assert rel_err(p.detach().cpu().numpy(), ref) < 2e-5
+
+
+def test_training_reduces_loss_exact_then_finite_difference(hip_lib):
+    import preconditioned_stochastic_gradient_descent as psgd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    params = _make_params(dev, seed=2)
+    opt = psgd.UVd(params, rank_of_modification=10, lr_params=0.02, lr_preconditioner=0.02, grad_clip_max_norm=1.0,
+                   preconditioner_update_probability=1.0, exact_hessian_vector_product=True)
+    losses = []
+    for it in range(300):
+        x, y = _xor_batch(dev, 100 + it)
+        if it == 150:
+            opt.exact_hessian_vector_product.assign(False)                # rnn_xor_UVd_preconditioner.py:69
+            opt.preconditioner_update_probability.assign(0.5)
+        losses.append(float(opt.step(lambda: _loss(params, x, y)).detach()))
+    assert all(math.isfinite(l) for l in losses)
+    assert np.mean(losses[-20:]) < np.mean(losses[:20]) - 0.03        # learning, not diverging (XOR needs thousands of steps)
+    assert all(torch.isfinite(t).all() for t in (opt._U, opt._V, opt._d))
+
+
+def test_no_update_branch_leaves_preconditioner_alone(hip_lib):
+    import preconditioned_stochastic_gradient_descent as psgd
+    dev = torch.device("cuda:0")
+    params = _make_params(dev, seed=3)
+    x, y = _xor_batch(dev, 3)
+    opt = psgd.UVd(params, preconditioner_update_probability=0.0)         # psgd.py:737-744
+    U0, V0, d0 = opt._U.clone(), opt._V.clone(), opt._d.clone()
+    opt.step(lambda: [_loss(params, x, y), "aux"])                         # closure may return a list (psgd.py:711)
+    assert torch.equal(opt._U, U0) and torch.equal(opt._V, V0) and torch.equal(opt._d, d0)
