@@ -136,6 +136,7 @@ static int sweep_grid(const UvdOps* ops, int r, int which, int64_t N, int hard_c
     occ_cache[r][which] = occ;
   }
   if (g_tune_blocks_per_cu > 0 && g_tune_blocks_per_cu < occ) occ = g_tune_blocks_per_cu;
+  if (g_tune_blocks_per_cu < 0) occ = -g_tune_blocks_per_cu;   // experiments: force, even above the occupancy query
   const int64_t tiles = (N + ops->tile_rows - 1) / ops->tile_rows;
   int64_t grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t cap = (int64_t)num_cus() * occ;
@@ -287,36 +288,60 @@ __global__ __launch_bounds__(kThreads) void k_scale2(float* U, float* V, long n,
 // ------------------------------------------------- r x r algebra (fp64) ----
 constexpr int MR = PSGD_UVD_MAX_RANK;
 
-// Gaussian elimination with partial pivoting on one wave (lane = row); the
-// first maximal |entry| is the pivot, like LAPACK's idamax behind tf.linalg.solve.
-__device__ void lu_solve(double (*M)[MR + 1], double* rhs, double* x, int r, int lane) {
+// Solve M x = rhs (r <= 32) with Gaussian elimination and partial pivoting (first maximal |entry|, as
+// LAPACK's getrf behind tf.linalg.solve), cooperatively by a 256-thread block: the augmented matrix
+// Mx[i][0..r] (column r = rhs) lives in LDS; every elimination step updates its (r-k-1) x (r-k)
+// trailing entries in parallel, one barrier pair per step.  x is left in xs[0..r).
+// 1/d to full fp64 accuracy: hardware v_rcp_f64 estimate + two Newton steps (an IEEE fp64 division
+// costs ~500 cycles on the vector ALU and sat on the critical path of every elimination step)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = x * (2.0 - d * x);
+  x = x * (2.0 - d * x);
+  return x;
+}
+
+// max over lanes 0..31 of a wave with DPP row shifts (VALU speed; a __shfl_down tree on doubles costs
+// ~900 cycles of ds_bpermute latency per search).  Result valid in every lane (readlane 31).
+__device__ __forceinline__ unsigned wave32_umax(unsigned x) {
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));   // row_shr:1
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));   // row_shr:2
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));   // row_shr:4
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));   // row_shr:8
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 31);
+}
+
+__device__ void lu_solve_block(double (*Mx)[MR + 2], int r, double* xs, int* piv_s) {
+  const int tid = threadIdx.x;
+  (void)piv_s;
   for (int k = 0; k < r; ++k) {
-    double val = (lane >= k && lane < r) ? fabs(M[lane][k]) : -1.0;
-    int idx = lane;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ov = __shfl_down(val, off, 64);
-      const int oi = __shfl_down(idx, off, 64);
-      if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
-    }
-    const int piv = __shfl(idx, 0, 64);
-    if (piv != k) {
-      if (lane < r) { const double t = M[k][lane]; M[k][lane] = M[piv][lane]; M[piv][lane] = t; }
-      if (lane == 0) { const double t = rhs[k]; rhs[k] = rhs[piv]; rhs[piv] = t; }
+    // pivot = first row i >= k with the largest |Mx[i][k]| (compared as fp32 keys): every wave finds it
+    // redundantly (lane l looks at row k + l), so no broadcast and no extra barrier is needed
+    const int lane = tid & 63;
+    const unsigned key = (lane < r - k) ? __float_as_uint(fabsf((float)Mx[k + lane][k])) : 0u;
+    const unsigned kmax = wave32_umax(key);
+    const unsigned long long hit = __ballot(key == kmax && lane < r - k);
+    const int piv = hit ? k + (__ffsll((long long)hit) - 1) : k;
+    __syncthreads();                                   // all scans done before rows move
+    if (piv != k && tid <= r) {
+      const double t = Mx[k][tid];
+      Mx[k][tid] = Mx[piv][tid];
+      Mx[piv][tid] = t;
     }
     __syncthreads();
-    const double pv = M[k][k];
-    if (lane > k && lane < r) {
-      const double f = M[lane][k] / pv;
-      for (int j = k + 1; j < r; ++j) M[lane][j] -= f * M[k][j];
-      rhs[lane] -= f * rhs[k];
+    const double rpk = fast_rcp(Mx[k][k]);
+    const int nrow = r - k - 1, ncol = r - k;          // rows k+1..r-1, columns k+1..r (incl. rhs)
+    for (int e = tid; e < nrow * ncol; e += blockDim.x) {
+      const int i = k + 1 + e / ncol, j = k + 1 + e % ncol;
+      Mx[i][j] -= (Mx[i][k] * rpk) * Mx[k][j];
     }
     __syncthreads();
   }
-  for (int i = r - 1; i >= 0; --i) {
-    const double xi = rhs[i] / M[i][i];
-    if (lane == 0) x[i] = xi;
-    if (lane < i) rhs[lane] -= M[lane][i] * xi;
+  for (int k = r - 1; k >= 0; --k) {
+    const double xk = Mx[k][r] * fast_rcp(Mx[k][k]);      // row k is final: rows > k were folded in already
+    if (tid == 0) xs[k] = xk;
+    if (tid < k) Mx[tid][r] -= Mx[tid][k] * xk;
     __syncthreads();
   }
 }
@@ -327,17 +352,19 @@ __device__ inline double wave_sum(double v) {
   return __shfl(v, 0, 64);
 }
 
-// One wave.  Reads the reduced Gram of W = [U | V | t | w] (MFMA block layout
-// of k_update_gram) and produces the coefficient block of UpdCoef.
-__global__ __launch_bounds__(64) void k_update_coef(const double* __restrict__ gram, int r, float step, float tiny,
-                                                    int update_U, float* __restrict__ coef) {
+// One 256-thread block.  Reads the reduced Gram of W = [U | V | t | w] (MFMA block layout of
+// k_update_gram) and produces the coefficient block of UpdCoef.  fp64 throughout.
+__global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restrict__ gram, int r, float step, float tiny,
+                                                          int update_U, float* __restrict__ coef) {
   __shared__ double A[MR][MR + 1];    // U'U
   __shared__ double B[MR][MR + 1];    // V'V
   __shared__ double Cm[MR][MR + 1];   // V'U  (psgd.py:574)
-  __shared__ double M[MR][MR + 1];    // elimination scratch
-  __shared__ double ut[MR], uw[MR], vt[MR], vw[MR], s1[MR], s2[MR], x1[MR], x2[MR], p2[MR], cs1[MR], rhs[MR];
-  __shared__ double e1[MR], e2[MR], f1[MR], f2[MR];
-  const int lane = threadIdx.x;
+  __shared__ double Mx[MR][MR + 2];   // augmented elimination matrix
+  __shared__ double ut[MR], uw[MR], vt[MR], vw[MR], s1[MR], s2[MR], x1[MR], x2[MR], p2[MR], cs1[MR];
+  __shared__ double e1[MR], e2[MR];
+  __shared__ double sc[3];
+  __shared__ int piv_s;
+  const int tid = threadIdx.x;
   const int nb = (2 * r + 2 + 15) / 16;
   auto G = [&](int a, int b) -> double {
     if (a > b) { const int t = a; a = b; b = t; }
@@ -345,56 +372,58 @@ __global__ __launch_bounds__(64) void k_update_coef(const double* __restrict__ g
     const int p = bi * nb - (bi * (bi - 1)) / 2 + (bj - bi);
     return gram[p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j)];
   };
-  for (int idx = lane; idx < r * r; idx += 64) {
+  for (int idx = tid; idx < r * r; idx += kThreads) {
     const int i = idx / r, j = idx % r;
     A[i][j] = G(i, j);
     B[i][j] = G(r + i, r + j);
     Cm[i][j] = G(j, r + i);
   }
-  if (lane < r) {
-    ut[lane] = G(lane, 2 * r);
-    uw[lane] = G(lane, 2 * r + 1);
-    vt[lane] = G(r + lane, 2 * r);
-    vw[lane] = G(r + lane, 2 * r + 1);
+  if (tid < r) {
+    ut[tid] = G(tid, 2 * r);
+    uw[tid] = G(tid, 2 * r + 1);
+    vt[tid] = G(r + tid, 2 * r);
+    vw[tid] = G(r + tid, 2 * r + 1);
+    s1[tid] = vt[tid];                                   // s1 = V't
   }
-  const double tt = G(2 * r, 2 * r), tw = G(2 * r, 2 * r + 1), ww = G(2 * r + 1, 2 * r + 1);
+  if (tid == 0) { sc[0] = G(2 * r, 2 * r); sc[1] = G(2 * r, 2 * r + 1); sc[2] = G(2 * r + 1, 2 * r + 1); }
   __syncthreads();
 
-  // s1 = V't ; s2 = U'Qh = U't + (U'U) s1 ; cs1 = (V'U) s1
-  if (lane < r) s1[lane] = vt[lane];
-  __syncthreads();
-  if (lane < r) {
-    double a = ut[lane], c = 0.0;
-    for (int k = 0; k < r; ++k) { a += A[lane][k] * s1[k]; c += Cm[lane][k] * s1[k]; }
-    s2[lane] = a;
-    cs1[lane] = c;
+  // s2 = U'Qh = U't + (U'U) s1 ; cs1 = (V'U) s1
+  if (tid < r) {
+    double a = ut[tid], c = 0.0;
+    for (int k = 0; k < r; ++k) { a += A[tid][k] * s1[k]; c += Cm[tid][k] * s1[k]; }
+    s2[tid] = a;
+    cs1[tid] = c;
   }
   // x1 = solve(K', U'w), K = I + V'U            (psgd.py:575-577, adjoint=True)
-  for (int idx = lane; idx < r * r; idx += 64) {
+  for (int idx = tid; idx < r * r; idx += kThreads) {
     const int i = idx / r, j = idx % r;
-    M[i][j] = Cm[j][i] + (i == j ? 1.0 : 0.0);
+    Mx[i][j] = Cm[j][i] + (i == j ? 1.0 : 0.0);
   }
-  if (lane < r) rhs[lane] = uw[lane];
+  if (tid < r) Mx[tid][r] = uw[tid];
   __syncthreads();
-  lu_solve(M, rhs, x1, r, lane);
+  lu_solve_block(Mx, r, x1, &piv_s);
   __syncthreads();
   // p2 = V' invQtv = V'w - (V'V) x1 ; x2 = solve(K, p2)          (psgd.py:578)
-  if (lane < r) {
-    double a = vw[lane];
-    for (int k = 0; k < r; ++k) a -= B[lane][k] * x1[k];
-    p2[lane] = a;
-    rhs[lane] = a;
+  if (tid < r) {
+    double a = vw[tid];
+    for (int k = 0; k < r; ++k) a -= B[tid][k] * x1[k];
+    p2[tid] = a;
+    Mx[tid][r] = a;
   }
-  for (int idx = lane; idx < r * r; idx += 64) {
+  for (int idx = tid; idx < r * r; idx += kThreads) {
     const int i = idx / r, j = idx % r;
-    M[i][j] = Cm[i][j] + (i == j ? 1.0 : 0.0);
+    Mx[i][j] = Cm[i][j] + (i == j ? 1.0 : 0.0);
   }
   __syncthreads();
-  lu_solve(M, rhs, x2, r, lane);
+  lu_solve_block(Mx, r, x2, &piv_s);
   __syncthreads();
+  if (tid >= 64) return;                                  // the rest is one wave of r-vector algebra
 
-  // a = Qh = t + U s1, b = invQtv = w - V x1                      (psgd.py:587)
+  const int lane = tid;
   const bool act = lane < r;
+  const double tt = sc[0], tw = sc[1], ww = sc[2];
+  // a = Qh = t + U s1, b = invQtv = w - V x1                      (psgd.py:587)
   const double s1ut = wave_sum(act ? s1[lane] * ut[lane] : 0.0);
   const double s1s2 = wave_sum(act ? s1[lane] * s2[lane] : 0.0);
   const double x1vw = wave_sum(act ? x1[lane] * vw[lane] : 0.0);
@@ -408,18 +437,21 @@ __global__ __launch_bounds__(64) void k_update_coef(const double* __restrict__ g
 
   // e1 = a'M, e2 = b'M with M = V (update U) or U (update V); the norm needs
   // ||M e1'||^2 = e1 (M'M) e1' etc.                       (psgd.py:589-596 / :603-610)
+  double my_e1 = 0.0, my_e2 = 0.0;
   if (act) {
     if (update_U) {
-      e1[lane] = vt[lane] + cs1[lane];   // atV = V't + (V'U) s1
-      e2[lane] = p2[lane];               // btV = V'w - (V'V) x1
+      my_e1 = vt[lane] + cs1[lane];      // atV = V't + (V'U) s1
+      my_e2 = p2[lane];                  // btV = V'w - (V'V) x1
     } else {
       double c = uw[lane];
       for (int k = 0; k < r; ++k) c -= Cm[k][lane] * x1[k];
-      e1[lane] = s2[lane];               // atU = U't + (U'U) s1
-      e2[lane] = c;                      // btU = U'w - (U'V) x1
+      my_e1 = s2[lane];                  // atU = U't + (U'U) s1
+      my_e2 = c;                         // btU = U'w - (U'V) x1
     }
+    e1[lane] = my_e1;
+    e2[lane] = my_e2;
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   double g1 = 0.0, g2 = 0.0;
   if (act) {
     for (int k = 0; k < r; ++k) {
@@ -428,28 +460,23 @@ __global__ __launch_bounds__(64) void k_update_coef(const double* __restrict__ g
       g2 += m * e2[k];
     }
   }
-  const double pp = wave_sum(act ? e1[lane] * g1 : 0.0);
-  const double qq = wave_sum(act ? e2[lane] * g2 : 0.0);
-  const double pq = wave_sum(act ? e1[lane] * g2 : 0.0);
+  const double pp = wave_sum(act ? my_e1 * g1 : 0.0);
+  const double qq = wave_sum(act ? my_e2 * g2 : 0.0);
+  const double pq = wave_sum(act ? my_e1 * g2 : 0.0);
   const double nrm = sqrt(fabs(aa * pp + bb * qq - 2.0 * ab * pq));
   const double mu = (double)step / (nrm + (double)tiny);
   // c1, c2: update U -> (atV K), (btV K) (psgd.py:600-601); update V -> atU, btU (:614-615)
   if (act) {
-    if (update_U) {
-      double c1 = e1[lane], c2 = e2[lane];   // identity part of K
+    double c1 = my_e1, c2 = my_e2;
+    if (update_U) {                        // + e K's off-identity part
       for (int i = 0; i < r; ++i) { c1 += e1[i] * Cm[i][lane]; c2 += e2[i] * Cm[i][lane]; }
-      f1[lane] = c1;
-      f2[lane] = c2;
-    } else {
-      f1[lane] = e1[lane];
-      f2[lane] = e2[lane];
     }
     coef[0 * r + lane] = (float)s1[lane];
     coef[1 * r + lane] = (float)s2[lane];
     coef[2 * r + lane] = (float)x1[lane];
     coef[3 * r + lane] = (float)x2[lane];
-    coef[4 * r + lane] = (float)f1[lane];
-    coef[5 * r + lane] = (float)f2[lane];
+    coef[4 * r + lane] = (float)c1;
+    coef[5 * r + lane] = (float)c2;
   }
   if (lane == 0) {
     coef[6 * r] = (float)mu;
@@ -710,7 +737,7 @@ int psgd_uvd_update_sweep2_f32(float* U, float* V, const float* d, const float* 
   const UvdOps* ops = uvd_ops_for_rank(r);
   if (!ops) return PSGD_ERR_RANK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(64), 0, st, w.sums, r, step, tiny, update_U, w.coef);
+  hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(kThreads), 0, st, w.sums, r, step, tiny, update_U, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   const int grid = sweep_grid(ops, r, update_U ? kOccUpdS2U : kOccUpdS2V, N, kMaxGrid);
   {

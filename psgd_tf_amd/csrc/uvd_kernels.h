@@ -429,10 +429,22 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
   const float* const mats[2] = {U, V};
   const float* const vecs[3] = {d, v, h};
 
-  auto gram_tile = [&]() {
-    f32x4 acc[GC::kPairs];
+  // fp32 MFMA accumulators persist across kFlushTiles tiles (chains of <= 256 rows), then fold into fp64
+  constexpr int kFlushTiles = (256 / C::kTileRows) > 0 ? (256 / C::kTileRows) : 1;
+  f32x4 acc[GC::kPairs];
 #pragma unroll
-    for (int p = 0; p < GC::kPairs; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < GC::kPairs; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int since_flush = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int p = 0; p < GC::kPairs; ++p) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
+      acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    since_flush = 0;
+  };
+  auto gram_tile = [&]() {
 #pragma unroll 4
     for (int m = 0; m < C::kTileRows / 4; ++m) {
       float a[GC::kBlocks];
@@ -447,10 +459,7 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
           ++p;
         }
     }
-#pragma unroll
-    for (int p = 0; p < GC::kPairs; ++p)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
+    if (++since_flush == kFlushTiles) flush();
   };
 
   Prefetch<R, 2, 3> pf;
@@ -496,6 +505,7 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
     gram_tile();
   }
 
+  flush();
   // block reduction in fp64 through LDS (tile buffers are dead now), fixed order:
   // (w2,w3) -> scratch ; w0 += s0, w1 += s1 ; w1 -> scratch ; w0 += s0 ; w0 stores
   __syncthreads();

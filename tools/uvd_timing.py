@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--r", type=int, default=20)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bpc", type=int, default=0, help="cap on blocks per CU (tuning key 1)")
+    ap.add_argument("--alias-shift", type=int, default=-1,
+                    help="experiment: V = U's buffer shifted by this many rows (same DRAM region)")
     args = ap.parse_args()
     N, r = args.N, args.r
     dev = torch.device("cuda:0")
@@ -27,7 +29,11 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     scale = (1.0 / (N * r)) ** 0.5
     U = torch.randn(N, r, device=dev, generator=g) * scale
-    V = torch.randn(N, r, device=dev, generator=g) * scale
+    if args.alias_shift >= 0:
+        buf = torch.randn(N + args.alias_shift, r, device=dev, generator=g) * scale
+        U, V = buf[:N], buf[args.alias_shift:]
+    else:
+        V = torch.randn(N, r, device=dev, generator=g) * scale
     d = torch.ones(N, 1, device=dev)
     gr = torch.randn(N, 1, device=dev, generator=g)
     v = torch.randn(N, 1, device=dev, generator=g)
