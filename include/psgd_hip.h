@@ -182,6 +182,34 @@ int psgd_kron_dd_update_batched_f32(const float *const *Ql, const float *const *
                                     float step, float tiny,
                                     void *ws, int64_t ws_bytes, void *stream);
 
+/* Sparse Kronecker factors (psgd.py:198-391), canonical orientations; the dispatcher's mirrored
+ * formats (psgd.py:86,102,104 / :128,144,146) call these on transposed views.
+ *   fmt 0 "ds": (dense, scaling)          Ql [M,M], qr [N]          psgd.py:276-322
+ *   fmt 1 "nd": (normalization, dense)    ql [2,M], Qr [N,N]        psgd.py:198-270
+ *   fmt 2 "ns": (normalization, scaling)  ql [2,M], qr [N]          psgd.py:328-391
+ * dX, dG, G are strided views: element (m,n) at p[m*rs + n*cs] (dX and dG share strides).
+ * Factor outputs and `out` are contiguous ([M,M] / [2,M] / [N] / [N,N] / [M,N]).  Pure: inputs
+ * are never written.                                                                        */
+int64_t psgd_kron_sparse_workspace_bytes(int fmt, int M, int N);
+int psgd_kron_ds_update_f32(const float *Ql, const float *qr, const float *dX, const float *dG,
+                            int64_t xrs, int64_t xcs, float *QlOut, float *qrOut, int M, int N,
+                            float step, float tiny, void *ws, int64_t ws_bytes, void *stream);
+int psgd_kron_ds_apply_f32(const float *Ql, const float *qr, const float *G, int64_t grs,
+                           int64_t gcs, float *out, int M, int N, void *ws, int64_t ws_bytes,
+                           void *stream);
+int psgd_kron_nd_update_f32(const float *ql, const float *Qr, const float *dX, const float *dG,
+                            int64_t xrs, int64_t xcs, float *qlOut, float *QrOut, int M, int N,
+                            float step, float tiny, void *ws, int64_t ws_bytes, void *stream);
+int psgd_kron_nd_apply_f32(const float *ql, const float *Qr, const float *G, int64_t grs,
+                           int64_t gcs, float *out, int M, int N, void *ws, int64_t ws_bytes,
+                           void *stream);
+int psgd_kron_ns_update_f32(const float *ql, const float *qr, const float *dX, const float *dG,
+                            int64_t xrs, int64_t xcs, float *qlOut, float *qrOut, int M, int N,
+                            float step, float tiny, void *ws, int64_t ws_bytes, void *stream);
+int psgd_kron_ns_apply_f32(const float *ql, const float *qr, const float *G, int64_t grs,
+                           int64_t gcs, float *out, int M, int N, void *ws, int64_t ws_bytes,
+                           void *stream);
+
 /* bf16-operand variant of _precond_grad_dense_dense (psgd.py:182-192) for Transformer-scale
  * matrices (BASELINE config 5).  Outside the reference's contract (its Kron API is pinned to
  * fp32, psgd.py:113-115): Ql, Qr are the fp32 master factors (rounded to bf16 per call), G and

@@ -47,6 +47,7 @@ struct GemmArgs {
   //   KLO_N: k >= n0 (B(k,n) = 0 for k < n, e.g. B = U')             KHI_N: k < n0 + BN (B upper-triangular)
   int kmode, kmode2;
   long c_cs;
+  const float* colv; int colsq;         // EPI_STORE: C(m,n) *= colv[n] (colsq: *= colv[n]^2)
 };
 
 enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8 };
@@ -235,6 +236,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, Gem
             vmax = fmaxf(vmax, fabsf(v));
           } else if (g.epi == EPI_D_MINUS) {
             v = g.D[(long)row * g.ldd + col * ccs] - v;
+          } else if (g.colv) {
+            const float cv = g.colv[col];
+            v *= g.colsq ? cv * cv : cv;
           }
           g.C[(long)row * g.ldc + col * ccs] = v;
         }
@@ -285,12 +289,14 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32_batched(GemmBatch b) {
 struct TrsmArgs {
   const float* Q; int n, ldq;
   const float* X; float* Y;
-  int nvec; long si, sj;
+  int nvec; long si, sj;        // strides of Y (and of X unless xi/xj are set)
+  long xi, xj;                  // strides of X; 0,0 = same as Y
 };
 
 __device__ __forceinline__ void trsm_body(const float* __restrict__ Q, int n, int ldq, const float* X, float* Y,
-                                          int nvec, long si, long sj, int v0, float (*red)[64][33],
-                                          float (*Qd)[32]) {
+                                          int nvec, long si, long sj, long xi, long xj, int v0,
+                                          float (*red)[64][33], float (*Qd)[32]) {
+  if (xi == 0 && xj == 0) { xi = si; xj = sj; }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int j0 = 0; j0 < n; j0 += 32) {
     const int jw = (n - j0 < 32) ? (n - j0) : 32;
@@ -334,7 +340,7 @@ __device__ __forceinline__ void trsm_body(const float* __restrict__ Q, int n, in
       float rr[32];
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
-        const float x = (vok && j < jw) ? X[v * si + (long)(j0 + j) * sj] : 0.0f;
+        const float x = (vok && j < jw) ? X[v * xi + (long)(j0 + j) * xj] : 0.0f;
         rr[j] = x - (((red[0][lane][j] + red[1][lane][j]) + red[2][lane][j]) + red[3][lane][j]);
       }
 #pragma unroll
@@ -355,10 +361,10 @@ __device__ __forceinline__ void trsm_body(const float* __restrict__ Q, int n, in
 }
 
 __global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ Q, int n, int ldq, const float* X,
-                                                      float* Y, int nvec, long si, long sj) {
+                                                      float* Y, int nvec, long si, long sj, long xi, long xj) {
   __shared__ float red[4][64][33];
   __shared__ float Qd[32][32];
-  trsm_body(Q, n, ldq, X, Y, nvec, si, sj, blockIdx.x * 64, red, Qd);
+  trsm_body(Q, n, ldq, X, Y, nvec, si, sj, xi, xj, blockIdx.x * 64, red, Qd);
 }
 
 struct TrsmBatch {
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut_batched(TrsmBatch b) {
   while (p + 1 < b.count && (int)blockIdx.x >= b.blk_end[p]) ++p;
   const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
   const TrsmArgs& t = b.t[p];
-  trsm_body(t.Q, t.n, t.ldq, t.X, t.Y, t.nvec, t.si, t.sj, blk * 64, red, Qd);
+  trsm_body(t.Q, t.n, t.ldq, t.X, t.Y, t.nvec, t.si, t.sj, t.xi, t.xj, blk * 64, red, Qd);
 }
 
 // rho = sqrt(max diag Ql / max diag Qr); QlS = Ql / rho; QrS = rho Qr      (psgd.py:166-170)
@@ -417,6 +423,156 @@ __global__ __launch_bounds__(kThreads) void k_kron_balance_batched(BalanceBatch 
   __shared__ float red[2][4];
   const int p = blockIdx.y;
   balance_body(b.Ql[p], b.Qr[p], b.M[p], b.N[p], b.QlS[p], b.QrS[p], red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse Kronecker factors (psgd.py:198-391): a *normalization* factor ql [2,M] is the matrix
+// diag(ql[0]) with last column ql[1] (ql[1][M-1] unused, kept 0), a *scaling* factor qr [1,N] is
+// diag(qr).  Their halves of the update/apply are elementwise / reduction kernels; the dense half
+// of a mixed format reuses the MFMA GEMM and the triangular solve above.  Data matrices come as
+// strided views (element (m,n) at p[m*rs + n*cs]) so that the mirrored formats of the dispatcher
+// (psgd.py:86,102,104: transposed data) need no copies.
+struct MatView { const float* p; long rs, cs; };
+
+// Y[m,n] = (q0[m] X[m,n] + q1[m] X[M-1,n]) * c(n),  c = 1 | colv[n] | colv[n]^2     (Ql X, psgd.py:218-219)
+__global__ __launch_bounds__(kThreads) void k_norm_left(MatView X, const float* __restrict__ q0,
+                                                        const float* __restrict__ q1, int M, int N,
+                                                        const float* __restrict__ colv, int colsq, float* Y) {
+  const long tot = (long)M * N;
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < tot; e += (long)gridDim.x * kThreads) {
+    const int m = (int)(e / N), n = (int)(e % N);
+    float v = q0[m] * X.p[m * X.rs + n * X.cs] + q1[m] * X.p[(long)(M - 1) * X.rs + n * X.cs];
+    if (colv) { const float c = colv[n]; v *= colsq ? c * c : c; }
+    Y[e] = v;
+  }
+}
+
+// out[n] = sum_i w_i Z[i,n];  mode 0: w_i = q1[i] / (q0[i] q0[M-1]) (psgd.py:232);  mode 1: w_i = q1[i] (psgd.py:265);
+// mode 2: out[n] = sum_i Z[i,n]^2 - Z2[i,n]^2 (psgd.py:304).  64 columns per block, 4 waves split the rows.
+__global__ __launch_bounds__(kThreads) void k_col_reduce(MatView Z, MatView Z2, const float* __restrict__ q0,
+                                                         const float* __restrict__ q1, int M, int N, int mode,
+                                                         float* out) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  float acc = 0.0f;
+  if (n < N) {
+    const float qlast = (mode == 0) ? q0[M - 1] : 1.0f;
+    for (int i = ty; i < M; i += 4) {
+      const float z = Z.p[i * Z.rs + n * Z.cs];
+      if (mode == 0) acc += (q1[i] / (q0[i] * qlast)) * z;
+      else if (mode == 1) acc += q1[i] * z;
+      else { const float z2 = Z2.p[i * Z2.rs + n * Z2.cs]; acc += z * z - z2 * z2; }
+    }
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && n < N) out[n] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+}
+
+// Y[m,n] = (X[m,n] (1/q0[m]) - [m == M-1] s[n]) * (colv ? 1/colv[n] : 1)            (Ql^-T X, psgd.py:230-232,356)
+__global__ __launch_bounds__(kThreads) void k_norm_left_invT(MatView X, const float* __restrict__ q0,
+                                                             const float* __restrict__ sv, int M, int N,
+                                                             const float* __restrict__ colv, float* Y) {
+  const long tot = (long)M * N;
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < tot; e += (long)gridDim.x * kThreads) {
+    const int m = (int)(e / N), n = (int)(e % N);
+    float v = (1.0f / q0[m]) * X.p[m * X.rs + n * X.cs];
+    if (m == M - 1) v -= sv[n];
+    if (colv) v *= 1.0f / colv[n];
+    Y[e] = v;
+  }
+}
+
+// Y[m,n] = q0[m] Z[m,n] + [m == M-1] t[n]                                           (Ql^T Z, psgd.py:266-268)
+__global__ __launch_bounds__(kThreads) void k_norm_leftT(const float* __restrict__ Z, const float* __restrict__ q0,
+                                                         const float* __restrict__ tv, int M, int N, float* Y) {
+  const long tot = (long)M * N;
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < tot; e += (long)gridDim.x * kThreads) {
+    const int m = (int)(e / N), n = (int)(e % N);
+    float v = q0[m] * Z[e];
+    if (m == M - 1) v += tv[n];
+    Y[e] = v;
+  }
+}
+
+// Y[m,n] *= 1/colv[n]                                                               (psgd.py:299)
+__global__ __launch_bounds__(kThreads) void k_col_inv_scale(float* Y, const float* __restrict__ colv, int M, int N) {
+  const long tot = (long)M * N;
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < tot; e += (long)gridDim.x * kThreads)
+    Y[e] *= 1.0f / colv[(int)(e % N)];
+}
+
+// gd[m] = sum_n A[m,n]^2 - Bt[m,n]^2 ; gb[m] = sum_n A[m,n] A[M-1,n] - Bt[m,n] Bt[M-1,n] (0 for m = M-1)   (psgd.py:235-237)
+// one wave per row
+__global__ __launch_bounds__(kThreads) void k_row_stats(const float* __restrict__ A, const float* __restrict__ Bt, int M,
+                                                        int N, float* gd, float* gb) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float d = 0.0f, b = 0.0f;
+  for (int n = lane; n < N; n += 64) {
+    const float a = A[(long)m * N + n], t = Bt[(long)m * N + n];
+    d += a * a - t * t;
+    b += a * A[(long)(M - 1) * N + n] - t * Bt[(long)(M - 1) * N + n];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { d += __shfl_down(d, off, 64); b += __shfl_down(b, off, 64); }
+  if (lane == 0) { gd[m] = d; gb[m] = (m == M - 1) ? 0.0f : b; }
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return r;
+}
+
+// new_ql0 = ql0 - step1 gd ql0 ; new_ql1 = ql1 - step1 (gd ql1 + ql0[M-1] gb),
+// step1 = step / (max(max|gd|, max|gb|) + tiny)                                      (psgd.py:239-241); one block
+__global__ __launch_bounds__(kThreads) void k_norm_finalize(const float* __restrict__ ql, const float* __restrict__ gd,
+                                                            const float* __restrict__ gb, int M, float step, float tiny,
+                                                            float* qlOut) {
+  __shared__ float red[4];
+  float v = 0.0f;
+  for (int i = threadIdx.x; i < M; i += kThreads) v = fmaxf(v, fmaxf(fabsf(gd[i]), fabsf(gb[i])));
+  const float step1 = step / (block_max(v, red) + tiny);
+  const float qlast = ql[M - 1];
+  for (int i = threadIdx.x; i < M; i += kThreads) {
+    qlOut[i] = ql[i] - step1 * gd[i] * ql[i];
+    qlOut[M + i] = ql[M + i] - step1 * (gd[i] * ql[M + i] + qlast * gb[i]);
+  }
+}
+
+// new_qr = qr - step2 g2 qr, step2 = step / (max|g2| + tiny)                          (psgd.py:305-307); one block
+__global__ __launch_bounds__(kThreads) void k_scale_finalize(const float* __restrict__ qr, const float* __restrict__ g2,
+                                                             int N, float step, float tiny, float* qrOut) {
+  __shared__ float red[4];
+  float v = 0.0f;
+  for (int i = threadIdx.x; i < N; i += kThreads) v = fmaxf(v, fabsf(g2[i]));
+  const float step2 = step / (block_max(v, red) + tiny);
+  for (int i = threadIdx.x; i < N; i += kThreads) qrOut[i] = qr[i] - step2 * g2[i] * qr[i];
+}
+
+// rho = sqrt(max L / max R) over the "diagonals" of the two factors (a dense factor: stride n+1; a
+// normalization factor: its first row; a scaling factor: itself); Lout = L / rho, Rout = rho R.
+// (psgd.py:211-215, 288-292, 342-346)
+__global__ __launch_bounds__(kThreads) void k_balance_generic(const float* __restrict__ L, long l_stride, int l_cnt,
+                                                              long l_tot, const float* __restrict__ R, long r_stride,
+                                                              int r_cnt, long r_tot, float* Lout, float* Rout) {
+  __shared__ float red[4];
+  float ml = -INFINITY, mr = -INFINITY;
+  for (int i = threadIdx.x; i < l_cnt; i += kThreads) ml = fmaxf(ml, L[i * l_stride]);
+  for (int i = threadIdx.x; i < r_cnt; i += kThreads) mr = fmaxf(mr, R[i * r_stride]);
+  ml = block_max(ml, red);
+  mr = block_max(mr, red);
+  const float rho = sqrtf(ml / mr);
+  const long tid = (long)blockIdx.x * kThreads + threadIdx.x, nth = (long)gridDim.x * kThreads;
+  for (long i = tid; i < l_tot; i += nth) Lout[i] = L[i] / rho;
+  for (long i = tid; i < r_tot; i += nth) Rout[i] = rho * R[i];
 }
 
 // ------------------------------------------------------------- host side ----
@@ -511,17 +667,33 @@ static void plan_update(const float* dG, float* QlOut, float* QrOut, int M, int 
 // X and Y are dense nvec*n arrays (either orientation), so the initial copy is one memcpy.
 constexpr int kTrsmBlock = 256;
 
-static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, hipStream_t st) {
+__global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long xi, long xj, float* Y, long si, long sj,
+                                                           int nvec, int n) {
+  const long tot = (long)nvec * n;
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < tot; e += (long)gridDim.x * kThreads) {
+    const long i = (si < sj) ? e % nvec : e / n, j = (si < sj) ? e / nvec : e % n;
+    Y[i * si + j * sj] = X[i * xi + j * xj];
+  }
+}
+
+// xi/xj: strides of X when they differ from Y's (0,0 = same layout)
+static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, hipStream_t st,
+                   long xi = 0, long xj = 0) {
   const dim3 grid((nvec + 63) / 64);
   if (n <= 2 * kTrsmBlock) {
-    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q, n, n, X, Y, nvec, si, sj);
+    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q, n, n, X, Y, nvec, si, sj, xi, xj);
     return (int)hipGetLastError();
   }
-  if (hipMemcpyAsync(Y, X, (size_t)nvec * n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+  if (xi == 0 && xj == 0) {
+    if (hipMemcpyAsync(Y, X, (size_t)nvec * n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+  } else {
+    hipLaunchKernelGGL(k_copy_strided, dim3(1024), dim3(kThreads), 0, st, X, xi, xj, Y, si, sj, nvec, n);
+    if (hipGetLastError() != hipSuccess) return 1;
+  }
   for (int j0 = 0; j0 < n; j0 += kTrsmBlock) {
     const int jw = (n - j0 < kTrsmBlock) ? (n - j0) : kTrsmBlock;
     float* Yb = Y + (long)j0 * sj;
-    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q + (long)j0 * n + j0, jw, n, Yb, Yb, nvec, si, sj);
+    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q + (long)j0 * n + j0, jw, n, Yb, Yb, nvec, si, sj, 0L, 0L);
     int e = (int)hipGetLastError();
     if (e) return e;
     const int rest = n - j0 - jw;
@@ -693,8 +865,8 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
       if (hipMemsetAsync(k[q].scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
       plan_update(dG[p], QlOut[p], QrOut[p], M[p], N[p], step, tiny, k[q], s[q]);
       bb.Ql[q] = Ql[p]; bb.Qr[q] = Qr[p]; bb.QlS[q] = k[q].QlS; bb.QrS[q] = k[q].QrS; bb.M[q] = M[p]; bb.N[q] = N[p];
-      t1.t[q] = {k[q].QrS, N[p], N[p], dX[p], k[q].X1, M[p], (long)N[p], 1L};
-      t2.t[q] = {k[q].QlS, M[p], M[p], k[q].X1, k[q].Bt, N[p], 1L, (long)N[p]};
+      t1.t[q] = {k[q].QrS, N[p], N[p], dX[p], k[q].X1, M[p], (long)N[p], 1L, 0L, 0L};
+      t2.t[q] = {k[q].QlS, M[p], M[p], k[q].X1, k[q].Bt, N[p], 1L, (long)N[p], 0L, 0L};
       blk1 += (M[p] + 63) / 64; t1.blk_end[q] = blk1;
       blk2 += (N[p] + 63) / 64; t2.blk_end[q] = blk2;
     }
@@ -714,6 +886,223 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
       KRON_LAUNCH(launch_gemm_batch(g, nb, st));
     }
   }
+  return PSGD_OK;
+}
+
+/* ---- sparse Kronecker formats (psgd.py:198-391): canonical (left, right) orientations ----
+ * fmt 0: (dense, scaling)  Ql [M,M], qr [N]          psgd.py:276-322
+ * fmt 1: (normalization, dense)  ql [2,M], Qr [N,N]  psgd.py:198-270
+ * fmt 2: (normalization, scaling) ql [2,M], qr [N]   psgd.py:328-391
+ * Data matrices are strided views (element (m,n) at p[m*rs + n*cs]); results are contiguous. */
+
+struct SparseWs {
+  float *scal, *LS, *RS, *T, *A, *Bt, *gsq, *v0, *v1, *v2, *v3;
+  int64_t total;
+};
+
+static SparseWs sparse_layout(char* base, int fmt, int M, int N) {
+  SparseWs k;
+  const int64_t mn = (int64_t)M * N * 4;
+  const int64_t lbytes = (fmt == 0) ? (int64_t)M * M * 4 : (int64_t)2 * M * 4;
+  const int64_t rbytes = (fmt == 1) ? (int64_t)N * N * 4 : (int64_t)N * 4;
+  const int64_t gbytes = (fmt == 0) ? (int64_t)M * M * 4 : (fmt == 1 ? (int64_t)N * N * 4 : 256);
+  const int64_t vb = (int64_t)(M > N ? M : N) * 4;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { float* p = reinterpret_cast<float*>(base + off); off = align256(off + bytes); return p; };
+  k.scal = take(256);
+  k.LS = take(lbytes); k.RS = take(rbytes);
+  k.T = take(mn); k.A = take(mn); k.Bt = take(mn);
+  k.gsq = take(gbytes);
+  k.v0 = take(vb); k.v1 = take(vb); k.v2 = take(vb); k.v3 = take(vb);
+  k.total = off;
+  return k;
+}
+
+static inline int ew_grid(long tot) {
+  long g = (tot + kThreads - 1) / kThreads;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+#define SP_LAUNCH(kernel, grid, ...)                                            \
+  do {                                                                          \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, st, __VA_ARGS__); \
+    if (hipGetLastError() != hipSuccess) return PSGD_ERR_LAUNCH;                \
+  } while (0)
+
+int64_t psgd_kron_sparse_workspace_bytes(int fmt, int M, int N) {
+  if (fmt < 0 || fmt > 2 || M <= 0 || N <= 0) return PSGD_ERR_BAD_ARG;
+  return sparse_layout(nullptr, fmt, M, N).total;
+}
+
+static int sparse_open(int fmt, int M, int N, void* ws, int64_t ws_bytes, SparseWs* k) {
+  if (M <= 0 || N <= 0) return PSGD_ERR_SHAPE;
+  if (kron_ws_check(ws, ws_bytes, sparse_layout(nullptr, fmt, M, N).total)) return PSGD_ERR_WORKSPACE;
+  *k = sparse_layout(static_cast<char*>(ws), fmt, M, N);
+  return PSGD_OK;
+}
+
+// (dense, scaling) update, psgd.py:276-307
+int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, const float* dG, int64_t xrs, int64_t xcs,
+                            float* QlOut, float* qrOut, int M, int N, float step, float tiny, void* ws,
+                            int64_t ws_bytes, void* stream) {
+  if (!Ql || !qr || !dX || !dG || !QlOut || !qrOut) return PSGD_ERR_BAD_ARG;
+  SparseWs k;
+  const int rc = sparse_open(0, M, N, ws, ws_bytes, &k);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
+  SP_LAUNCH(k_balance_generic, ew_grid((long)M * M), Ql, (long)M + 1, M, (long)M * M, qr, 1L, N, (long)N, k.LS, k.RS);
+  {                                                          // A = (QlS dG) .* qrS          (:295-296)
+    GemmArgs g = gemm_args(k.LS, M, false, dG, 0, false, k.A, N, M, N, M, KLO_M);
+    g.b_rs = xrs; g.b_cs = xcs;
+    g.colv = k.RS;
+    KRON_LAUNCH(launch_gemm(g, st));
+  }
+  // Bt = (QlS^-T dX) .* (1/qrS)                             (:298-299); columns independent
+  KRON_LAUNCH(trsm_ut(k.LS, M, dX, k.Bt, N, 1L, (long)N, st, (long)xcs, (long)xrs));
+  SP_LAUNCH(k_col_inv_scale, ew_grid((long)M * N), k.Bt, k.RS, M, N);
+  {                                                          // grad1 = triu(A A' - Bt Bt')  (:301)
+    GemmArgs g = gemm_args(k.A, N, false, k.A, N, true, k.gsq, M, M, M, N);
+    g.A2 = k.Bt; g.a2_rs = N; g.a2_cs = 1; g.B2 = k.Bt; g.b2_rs = 1; g.b2_cs = N; g.K2 = N;
+    g.epi = EPI_TRIU_MAX; g.maxout = k.scal;
+    KRON_LAUNCH(launch_gemm(g, st));
+  }
+  {                                                          // grad2 = colsum(A^2) - colsum(Bt^2)   (:304)
+    MatView a = {k.A, N, 1}, b = {k.Bt, N, 1};
+    SP_LAUNCH(k_col_reduce, (N + 63) / 64, a, b, (const float*)nullptr, (const float*)nullptr, M, N, 2, k.v0);
+  }
+  {                                                          // Ql - (step1 grad1) Ql         (:307)
+    GemmArgs g = gemm_args(k.gsq, M, false, k.LS, M, false, QlOut, M, M, M, M, KLO_M | KHI_N);
+    g.epi = EPI_D_MINUS; g.D = k.LS; g.ldd = M; g.scale_max = k.scal; g.step = step; g.tiny = tiny;
+    KRON_LAUNCH(launch_gemm(g, st));
+  }
+  SP_LAUNCH(k_scale_finalize, 1, k.RS, k.v0, N, step, tiny, qrOut);
+  return PSGD_OK;
+}
+
+// (dense, scaling) apply, psgd.py:310-322; out contiguous [M,N]
+int psgd_kron_ds_apply_f32(const float* Ql, const float* qr, const float* G, int64_t grs, int64_t gcs, float* out, int M,
+                           int N, void* ws, int64_t ws_bytes, void* stream) {
+  if (!Ql || !qr || !G || !out) return PSGD_ERR_BAD_ARG;
+  SparseWs k;
+  const int rc = sparse_open(0, M, N, ws, ws_bytes, &k);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (M < N) {                                               // (Ql'Ql) G                     (:318-319)
+    KRON_LAUNCH(launch_gemm(gemm_args(Ql, M, true, Ql, M, false, k.gsq, M, M, M, M, KHI_M | KHI_N), st));
+    GemmArgs g = gemm_args(k.gsq, M, false, G, 0, false, out, N, M, N, M);
+    g.b_rs = grs; g.b_cs = gcs; g.colv = qr; g.colsq = 1;
+    KRON_LAUNCH(launch_gemm(g, st));
+  } else {                                                   // Ql' (Ql G)                    (:320-321)
+    GemmArgs g1 = gemm_args(Ql, M, false, G, 0, false, k.T, N, M, N, M, KLO_M);
+    g1.b_rs = grs; g1.b_cs = gcs;
+    KRON_LAUNCH(launch_gemm(g1, st));
+    GemmArgs g2 = gemm_args(Ql, M, true, k.T, N, false, out, N, M, N, M, KHI_M);
+    g2.colv = qr; g2.colsq = 1;                              // .* (qr qr)                     (:322)
+    KRON_LAUNCH(launch_gemm(g2, st));
+  }
+  return PSGD_OK;
+}
+
+// shared by the two normalization-left updates: A0 = Ql dG (opt. .* colv), Bt0 = Ql^-T dX (opt. .* 1/colv)
+static int norm_left_pair(const SparseWs& k, const float* dX, const float* dG, long xrs, long xcs, int M, int N,
+                          const float* colv, float* A0, float* Bt0, hipStream_t st) {
+  const float* q0 = k.LS;
+  const float* q1 = k.LS + M;
+  MatView vx = {dX, xrs, xcs}, vg = {dG, xrs, xcs};
+  SP_LAUNCH(k_norm_left, ew_grid((long)M * N), vg, q0, q1, M, N, colv, 0, A0);
+  SP_LAUNCH(k_col_reduce, (N + 63) / 64, vx, vx, q0, q1, M, N, 0, k.v0);
+  SP_LAUNCH(k_norm_left_invT, ew_grid((long)M * N), vx, q0, (const float*)k.v0, M, N, colv, Bt0);
+  return PSGD_OK;
+}
+
+// (normalization, dense) update, psgd.py:198-246
+int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, const float* dG, int64_t xrs, int64_t xcs,
+                            float* qlOut, float* QrOut, int M, int N, float step, float tiny, void* ws,
+                            int64_t ws_bytes, void* stream) {
+  if (!ql || !Qr || !dX || !dG || !qlOut || !QrOut) return PSGD_ERR_BAD_ARG;
+  SparseWs k;
+  const int rc = sparse_open(1, M, N, ws, ws_bytes, &k);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
+  SP_LAUNCH(k_balance_generic, ew_grid((long)N * N), ql, 1L, M, (long)2 * M, Qr, (long)N + 1, N, (long)N * N, k.LS, k.RS);
+  int e = norm_left_pair(k, dX, dG, xrs, xcs, M, N, nullptr, k.T, k.Bt, st);       // T = Ql dG ; Bt = Ql^-T dX
+  if (e) return e;
+  KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), st));   // A = T QrS'  (:220)
+  KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.T, M, (long)N, 1L, st));                    // Bt QrS^-1 -> T   (:233)
+  SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.T, M, N, k.v1, k.v2);    // (:235-237)
+  SP_LAUNCH(k_norm_finalize, 1, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
+  {                                                          // grad2 = triu(A'A - Bt'Bt)     (:243)
+    GemmArgs g = gemm_args(k.A, N, true, k.A, N, false, k.gsq, N, N, N, M);
+    g.A2 = k.T; g.a2_rs = 1; g.a2_cs = N; g.B2 = k.T; g.b2_rs = N; g.b2_cs = 1; g.K2 = M;
+    g.epi = EPI_TRIU_MAX; g.maxout = k.scal;
+    KRON_LAUNCH(launch_gemm(g, st));
+  }
+  {                                                          // Qr - (step2 grad2) Qr         (:246)
+    GemmArgs g = gemm_args(k.gsq, N, false, k.RS, N, false, QrOut, N, N, N, N, KLO_M | KHI_N);
+    g.epi = EPI_D_MINUS; g.D = k.RS; g.ldd = N; g.scale_max = k.scal; g.step = step; g.tiny = tiny;
+    KRON_LAUNCH(launch_gemm(g, st));
+  }
+  return PSGD_OK;
+}
+
+// (normalization, dense) apply, psgd.py:249-270
+int psgd_kron_nd_apply_f32(const float* ql, const float* Qr, const float* G, int64_t grs, int64_t gcs, float* out, int M,
+                           int N, void* ws, int64_t ws_bytes, void* stream) {
+  if (!ql || !Qr || !G || !out) return PSGD_ERR_BAD_ARG;
+  SparseWs k;
+  const int rc = sparse_open(1, M, N, ws, ws_bytes, &k);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MatView vg = {G, grs, gcs};
+  SP_LAUNCH(k_norm_left, ew_grid((long)M * N), vg, ql, ql + M, M, N, (const float*)nullptr, 0, k.T);   // Ql G (:258-259)
+  if (M < N) {                                               // (P Qr') Qr                    (:260-261)
+    KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N, KLO_N), st));
+    KRON_LAUNCH(launch_gemm(gemm_args(k.A, N, false, Qr, N, false, k.Bt, N, M, N, N, KHI_N), st));
+  } else {                                                   // P (Qr'Qr)                     (:263)
+    KRON_LAUNCH(launch_gemm(gemm_args(Qr, N, true, Qr, N, false, k.gsq, N, N, N, N, KHI_M | KHI_N), st));
+    KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.gsq, N, false, k.Bt, N, M, N, N), st));
+  }
+  MatView vz = {k.Bt, N, 1};
+  SP_LAUNCH(k_col_reduce, (N + 63) / 64, vz, vz, ql, ql + M, M, N, 1, k.v0);                             // (:265)
+  SP_LAUNCH(k_norm_leftT, ew_grid((long)M * N), (const float*)k.Bt, ql, (const float*)k.v0, M, N, out);  // (:266-268)
+  return PSGD_OK;
+}
+
+// (normalization, scaling) update, psgd.py:328-369
+int psgd_kron_ns_update_f32(const float* ql, const float* qr, const float* dX, const float* dG, int64_t xrs, int64_t xcs,
+                            float* qlOut, float* qrOut, int M, int N, float step, float tiny, void* ws,
+                            int64_t ws_bytes, void* stream) {
+  if (!ql || !qr || !dX || !dG || !qlOut || !qrOut) return PSGD_ERR_BAD_ARG;
+  SparseWs k;
+  const int rc = sparse_open(2, M, N, ws, ws_bytes, &k);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SP_LAUNCH(k_balance_generic, 1, ql, 1L, M, (long)2 * M, qr, 1L, N, (long)N, k.LS, k.RS);
+  int e = norm_left_pair(k, dX, dG, xrs, xcs, M, N, k.RS, k.A, k.Bt, st);          // (:349-356)
+  if (e) return e;
+  SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.Bt, M, N, k.v1, k.v2);   // (:358-360)
+  SP_LAUNCH(k_norm_finalize, 1, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
+  MatView a = {k.A, N, 1}, b = {k.Bt, N, 1};
+  SP_LAUNCH(k_col_reduce, (N + 63) / 64, a, b, (const float*)nullptr, (const float*)nullptr, M, N, 2, k.v3);   // (:366)
+  SP_LAUNCH(k_scale_finalize, 1, (const float*)k.RS, (const float*)k.v3, N, step, tiny, qrOut);
+  return PSGD_OK;
+}
+
+// (normalization, scaling) apply, psgd.py:372-391
+int psgd_kron_ns_apply_f32(const float* ql, const float* qr, const float* G, int64_t grs, int64_t gcs, float* out, int M,
+                           int N, void* ws, int64_t ws_bytes, void* stream) {
+  if (!ql || !qr || !G || !out) return PSGD_ERR_BAD_ARG;
+  SparseWs k;
+  const int rc = sparse_open(2, M, N, ws, ws_bytes, &k);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MatView vg = {G, grs, gcs};
+  SP_LAUNCH(k_norm_left, ew_grid((long)M * N), vg, ql, ql + M, M, N, qr, 1, k.T);                       // (:383-385)
+  MatView vz = {k.T, N, 1};
+  SP_LAUNCH(k_col_reduce, (N + 63) / 64, vz, vz, ql, ql + M, M, N, 1, k.v0);                             // (:386)
+  SP_LAUNCH(k_norm_leftT, ew_grid((long)M * N), (const float*)k.T, ql, (const float*)k.v0, M, N, out);   // (:387-389)
   return PSGD_OK;
 }
 

@@ -2,9 +2,9 @@
 
 (dense, dense) -- the hot path, psgd.py:156-192 -- runs in the HIP kernels of
 csrc/psgd_kron.hip through the C ABI.  The sparse formats (normalization / scaling
-factors, psgd.py:198-391) are the "next" rows of SURVEY 8f-1: they are reachable through
-the same two public entry points and are computed here with device-side torch ops until
-their fused kernels land.
+factors, psgd.py:198-391) are reachable through the same two public entry
+points and run in HIP as well: elementwise / reduction kernels for the sparse half, the same
+MFMA GEMM and triangular solve for the dense half of a mixed format.
 """
 import torch
 
@@ -184,104 +184,82 @@ def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
     return list(zip(QlO, QrO))
 
 
-# --------------------------------------------------------------------------- sparse formats: torch ops
-def _solve_ut_adjoint(Q, X):
-    """tf.linalg.triangular_solve(Q, X, lower=False, adjoint=True): Q^T Y = X."""
-    return torch.linalg.solve_triangular(Q.t(), X, upper=False)
+# --------------------------------------------------------------------------- sparse formats: HIP
+# Canonical orientations (psgd.py:198-391).  The data matrices may be transposed views (the mirrored
+# formats of the dispatcher pass dX.t(), dG.t(), Grad.t()): their strides go straight to the kernels.
+_SPARSE_FMT = {"ds": 0, "nd": 1, "ns": 2}
+_sparse_ws = {}
 
 
-def _ql_times(ql, X):
-    return ql[0:1].t() * X + ql[1:].t() @ X[-1:]                                  # psgd.py:218-219
+def _sparse_workspace(device, fmt, M, N):
+    key = (device.index, fmt, M, N)
+    ws = _sparse_ws.get(key)
+    if ws is None:
+        nbytes = int(_lib.load().psgd_kron_sparse_workspace_bytes(_SPARSE_FMT[fmt], M, N))
+        if nbytes < 0:
+            _lib.check(nbytes, "psgd_kron_sparse_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _sparse_ws[key] = ws
+    return ws
 
 
-def _ql_inv_t_times(ql, X):
-    Bt = (1.0 / ql[0:1]).t() * X                                                  # psgd.py:230
-    last = Bt[-1:] - (ql[1:] / (ql[0:1] * ql[0, -1])) @ X                         # :231-232
-    return torch.cat([Bt[:-1], last], 0)
+def _sparse_update(fmt, L, R, dX, dG, step):
+    _require_hip("update_precond_kron", L, R, dX, dG)
+    M, N = dX.shape
+    if dG.stride() != dX.stride():
+        dG = dG.contiguous() if dX.is_contiguous() else dG.t().contiguous().t()
+    L, R = L.contiguous(), R.contiguous()
+    Lo, Ro = torch.empty_like(L), torch.empty_like(R)
+    ws = _sparse_workspace(dX.device, fmt, M, N)
+    fn = getattr(_lib.load(), "psgd_kron_%s_update_f32" % fmt)
+    rc = fn(L.data_ptr(), R.data_ptr(), dX.data_ptr(), dG.data_ptr(), dX.stride(0), dX.stride(1), Lo.data_ptr(),
+            Ro.data_ptr(), M, N, float(step), float(_tiny), ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream(dX.device).cuda_stream)
+    _lib.check(rc, "psgd_kron_%s_update_f32" % fmt)
+    return Lo, Ro
 
 
-def _norm_grad1(A, Bt):
-    g_diag = torch.sum(A * A, 1) - torch.sum(Bt * Bt, 1)                          # psgd.py:235
-    g_bias = A[:-1] @ A[-1:].t() - Bt[:-1] @ Bt[-1:].t()                          # :236
-    g_bias = torch.cat([torch.reshape(g_bias, [-1]), torch.zeros(1, dtype=A.dtype, device=A.device)], 0)   # :237
-    return g_diag, g_bias
+def _sparse_apply(fmt, L, R, Grad):
+    _require_hip("precond_grad_kron", L, R, Grad)
+    M, N = Grad.shape
+    L, R = L.contiguous(), R.contiguous()
+    out = torch.empty(M, N, dtype=Grad.dtype, device=Grad.device)
+    ws = _sparse_workspace(Grad.device, fmt, M, N)
+    fn = getattr(_lib.load(), "psgd_kron_%s_apply_f32" % fmt)
+    rc = fn(L.data_ptr(), R.data_ptr(), Grad.data_ptr(), Grad.stride(0), Grad.stride(1), out.data_ptr(), M, N,
+            ws.data_ptr(), ws.numel(), torch.cuda.current_stream(Grad.device).cuda_stream)
+    _lib.check(rc, "psgd_kron_%s_apply_f32" % fmt)
+    return out
 
 
 def _update_precond_norm_dense(ql, Qr, dX, dG, step):
     """psgd.py:198-246."""
-    rho = torch.sqrt(torch.max(ql[0]) / torch.max(torch.diagonal(Qr)))
-    ql = ql / rho
-    Qr = rho * Qr
-    A = _ql_times(ql, dG) @ Qr.t()
-    Bt = _solve_ut_adjoint(Qr, _ql_inv_t_times(ql, dX).t()).t()
-    g_diag, g_bias = _norm_grad1(A, Bt)
-    step1 = step / (torch.maximum(torch.max(torch.abs(g_diag)), torch.max(torch.abs(g_bias))) + _tiny)
-    new_ql0 = ql[0] - step1 * g_diag * ql[0]
-    new_ql1 = ql[1] - step1 * (g_diag * ql[1] + ql[0, -1] * g_bias)
-    grad2 = torch.triu(A.t() @ A - Bt.t() @ Bt)
-    step2 = step / (torch.max(torch.abs(grad2)) + _tiny)
-    return torch.stack((new_ql0, new_ql1)), Qr - (step2 * grad2) @ Qr
-
-
-def _norm_left_gram_apply(ql, preG):
-    add_last_row = ql[1:] @ preG                                                  # psgd.py:265
-    preG = ql[0:1].t() * preG
-    return torch.cat([preG[:-1], preG[-1:] + add_last_row], 0)
+    return _sparse_update("nd", ql, Qr, dX, dG, step)
 
 
 def _precond_grad_norm_dense(ql, Qr, Grad):
     """psgd.py:249-270."""
-    preG = _ql_times(ql, Grad)
-    if preG.shape[0] < preG.shape[1]:
-        preG = (preG @ Qr.t()) @ Qr
-    else:
-        preG = preG @ (Qr.t() @ Qr)
-    return _norm_left_gram_apply(ql, preG)
+    return _sparse_apply("nd", ql, Qr, Grad)
 
 
 def _update_precond_dense_scale(Ql, qr, dX, dG, step):
     """psgd.py:276-307."""
-    rho = torch.sqrt(torch.max(torch.diagonal(Ql)) / torch.max(qr))
-    Ql = Ql / rho
-    qr = rho * qr
-    A = (Ql @ dG) * qr
-    Bt = _solve_ut_adjoint(Ql, dX) * (1.0 / qr)
-    grad1 = torch.triu(A @ A.t() - Bt @ Bt.t())
-    step1 = step / (torch.max(torch.abs(grad1)) + _tiny)
-    grad2 = torch.sum(A * A, 0, keepdim=True) - torch.sum(Bt * Bt, 0, keepdim=True)
-    step2 = step / (torch.max(torch.abs(grad2)) + _tiny)
-    return Ql - (step1 * grad1) @ Ql, qr - step2 * grad2 * qr
+    return _sparse_update("ds", Ql, qr, dX, dG, step)
 
 
 def _precond_grad_dense_scale(Ql, qr, Grad):
     """psgd.py:310-322."""
-    if Grad.shape[0] < Grad.shape[1]:
-        preG = (Ql.t() @ Ql) @ Grad
-    else:
-        preG = Ql.t() @ (Ql @ Grad)
-    return preG * (qr * qr)
+    return _sparse_apply("ds", Ql, qr, Grad)
 
 
 def _update_precond_norm_scale(ql, qr, dX, dG, step):
     """psgd.py:328-369."""
-    rho = torch.sqrt(torch.max(ql[0]) / torch.max(qr))
-    ql = ql / rho
-    qr = rho * qr
-    A = _ql_times(ql, dG) * qr
-    Bt = _ql_inv_t_times(ql, dX) * (1.0 / qr)
-    g_diag, g_bias = _norm_grad1(A, Bt)
-    step1 = step / (torch.maximum(torch.max(torch.abs(g_diag)), torch.max(torch.abs(g_bias))) + _tiny)
-    new_ql0 = ql[0] - step1 * g_diag * ql[0]
-    new_ql1 = ql[1] - step1 * (g_diag * ql[1] + ql[0, -1] * g_bias)
-    grad2 = torch.sum(A * A, 0, keepdim=True) - torch.sum(Bt * Bt, 0, keepdim=True)
-    step2 = step / (torch.max(torch.abs(grad2)) + _tiny)
-    return torch.stack((new_ql0, new_ql1)), qr - step2 * grad2 * qr
+    return _sparse_update("ns", ql, qr, dX, dG, step)
 
 
 def _precond_grad_norm_scale(ql, qr, Grad):
     """psgd.py:372-391."""
-    preG = _ql_times(ql, Grad) * (qr * qr)
-    return _norm_left_gram_apply(ql, preG)
+    return _sparse_apply("ns", ql, qr, Grad)
 
 
 # --------------------------------------------------------------------------- public dispatchers

@@ -204,3 +204,39 @@ def test_batched_lenet_set_equals_per_layer(psgd):
         assert torch.equal(outs[i], psgd.precond_grad_kron(Qls[i], Qrs[i], Gs[i])), (m, n)
         a, b = psgd.update_precond_kron(Qls[i], Qrs[i], dXs[i], dGs[i], 0.01)
         assert torch.equal(news[i][0], a) and torch.equal(news[i][1], b), (m, n)
+
+
+# larger sparse-format cases: embedding-like shapes (README.md:54 recommends these formats for large
+# embeddings), the blocked triangular solve (dense side > 512) and ragged edges
+BIG_FORMATS = [
+    ("norm_dense", (2, 1500), (64, 64)), ("dense_norm", (64, 64), (2, 1500)),
+    ("dense_scale", (600, 600), (1, 37)), ("scale_dense", (1, 37), (600, 600)),
+    ("norm_scale", (2, 1001), (1, 129)), ("scale_norm", (1, 129), (2, 1001)),
+    ("norm_dense", (2, 33), (530, 530)), ("dense_scale", (257, 257), (1, 120)),
+]
+
+
+@pytest.mark.parametrize("fmt,sl,sr", BIG_FORMATS)
+def test_sparse_formats_large(psgd, fmt, sl, sr):
+    assert orc.kron_format(sl, sr) == fmt
+    rng = np.random.default_rng(sl[1] * 3 + sr[1])
+    M, N = sl[1], sr[1]
+    Ql, Qr = _factor_for(rng, sl, M), _factor_for(rng, sr, N)
+    if sl[0] == sl[1]:
+        Ql = Ql * 3.0                                # rho != 1
+    dX, G = rng.standard_normal((M, N)), rng.standard_normal((M, N))
+    dG = dX * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))
+    a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG, G)]
+    a64 = [a.astype(np.float64) for a in a32]
+    tQl, tQr = _dev(a32[0]), _dev(a32[1])
+    Ql_r, Qr_r = a64[0], a64[1]
+    for it in range(3):                               # a short sequence: factors feed back
+        tQl, tQr = psgd.update_precond_kron(tQl, tQr, _dev(a32[2]), _dev(a32[3]), 0.02)
+        Ql_r, Qr_r = orc.update_precond_kron(Ql_r, Qr_r, a64[2], a64[3], 0.02)
+    assert tuple(tQl.shape) == sl and tuple(tQr.shape) == sr
+    assert rel_err(tQl.cpu().numpy(), Ql_r) < 3e-5 and rel_err(tQr.cpu().numpy(), Qr_r) < 3e-5
+    out = psgd.precond_grad_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[4]))
+    assert out.shape == (M, N)
+    assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(a64[0], a64[1], a64[4])) < TOL
+    # inputs are never written
+    assert np.array_equal(_dev(a32[0]).cpu().numpy(), a32[0])
