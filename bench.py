@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kron", action="store_true", help="skip the Kron apply GFLOP/s leg")
+    ap.add_argument("--unfused", action="store_true",
+                    help="time update_precond_UVd_math_ + precond_grad_UVd_math as two separate calls")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU code path (process group + all-reduces) even at world size 1")
     args = ap.parse_args()
@@ -163,14 +165,17 @@ def main():
     n_global = n_local * world
     U, V, d, grad, v, h = make_inputs(n_local, n_global, r, dev, seed=1000 * rank)
 
-    if not use_dist:
+    # one step = update then apply on the updated state (psgd.py:732 -> :748).  Default: the fused call
+    # (identical results, one pass over V less); --unfused times the two reference-named calls back to back.
+    mod = sharded if use_dist else psgd
+    if args.unfused:
         def step(i):
-            psgd.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
-            return psgd.precond_grad_UVd_math(U, V, d, grad)
+            mod.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+            return mod.precond_grad_UVd_math(U, V, d, grad)
     else:
         def step(i):
-            sharded.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
-            return sharded.precond_grad_UVd_math(U, V, d, grad)
+            return mod.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, STEP, TINY, balance=False,
+                                                                update_U=(i % 2 == 0))
 
     def fence():
         if use_dist:
@@ -219,13 +224,16 @@ def main():
             except Exception:
                 traffic = None
         ach = kern[dom]["achieved_GBs"]
-        apply_ms = sum(slot_ms[k] for k in ("apply_s1", "apply_s2", "apply_s3"))
-        update_ms = sum(slot_ms[k] for k in ("update_s1", "update_s2", "update_s3"))
+        apply_ms = sum(slot_ms[k] or 0.0 for k in ("apply_s1", "apply_s2", "apply_s3"))
+        update_ms = sum(slot_ms[k] or 0.0 for k in ("update_s1", "update_s2", "update_s3"))
+        if not args.unfused:
+            kbytes["update_s2"] = 4 * (3 * r + 5)      # + 4 B/row for g; produces the apply's s1
         paths = {
+            "fused": not args.unfused,
             "apply": {"alg_bytes_per_param": 4 * (4 * r + 5), "kernel_ms": apply_ms,
-                      "frac": 4 * (4 * r + 5) * n_local / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                      "frac": (4 * (4 * r + 5) * n_local / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.unfused else None},
             "update": {"alg_bytes_per_param": 4 * (5 * r + 10), "kernel_ms": update_ms,
-                       "frac": 4 * (5 * r + 10) * n_local / (update_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                       "frac": (4 * (5 * r + 10) * n_local / (update_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.unfused else None},
             "step": {"alg_bytes_per_param": 4 * (9 * r + 15), "wall_ms": ms_per_step,
                      "frac": 4 * (9 * r + 15) * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
@@ -234,7 +242,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "UVd preconditioner update+apply (update_precond_UVd_math_ then "
-                                   "precond_grad_UVd_math), N=%d rows per GPU, r=%d" % (n_local, r),
+                                   "precond_grad_UVd_math%s), N=%d rows per GPU, r=%d"
+                                   % ("" if args.unfused else ", fused call", n_local, r),
                        "rows_per_gpu": n_local, "rows_global": n_global, "rank_of_modification": r,
                        "parallelism": "row-sharded x%d, all-reduce of r-dim sums only" % world,
                        "step": STEP, "branches": "balance=0, update_U alternating"},

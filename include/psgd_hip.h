@@ -65,7 +65,8 @@ int64_t psgd_uvd_workspace_bytes(int64_t N, int r);
  * `which` = PSGD_WS_SUMS_F64 / PSGD_WS_MAX_F32; `stage` selects what the next
  * stage consumes: apply: 1 (after sweep1: r sums), 2 (after sweep2: r sums);
  * update: 10 (balance maxima: 2 floats), 11 (after sweep1: Gram sums),
- * 12 (after sweep2: 1 float max).  Returns 0 or an error code.             */
+ * 12 (after sweep2: 1 float max), 13 (after the fused sweep2: 2r sums p,q).
+ * Returns 0 or an error code.                                                */
 int psgd_uvd_ws_region(int which, int stage, int64_t N, int r,
                        int64_t *offset_bytes, int64_t *count);
 
@@ -115,6 +116,22 @@ int psgd_uvd_update_sweep2_f32(float *U, float *V, const float *d,
 int psgd_uvd_update_sweep3_f32(float *d, int64_t N, int r, float step,
                                float tiny, void *ws, int64_t ws_bytes,
                                void *stream);
+
+/* Fused update -> apply (the UVd.step call pattern, psgd.py:732 -> :748).
+ * Same results as psgd_uvd_update_f32 followed by psgd_uvd_apply_f32 on the updated state, with one
+ * pass over V removed: update sweep 2 also reduces p = Vnew'(d.*g) and q = Vnew'(d.*g.*nablaD), and the
+ * apply's first reduction is s1 = p - mu q (dnew = d - mu d.*nablaD, psgd.py:584).
+ * Multi-GPU stages: ... update_sweep1 -> SUM(11) -> update_sweep2_fused -> MAX(12), SUM(13: 2r sums) ->
+ * update_sweep3 -> fused_s1 -> apply_sweep2(sums_reduced = 0) -> SUM(2) -> apply_sweep3(sums_reduced = 1). */
+int psgd_uvd_update_apply_f32(float *U, float *V, float *d, const float *v, const float *h,
+                              const float *g, float *out, int64_t N, int r, float step, float tiny,
+                              int balance, int update_U, void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_update_sweep2_fused_f32(float *U, float *V, const float *d, const float *v,
+                                     const float *h, const float *g, int64_t N, int r, float step,
+                                     float tiny, int update_U, void *ws, int64_t ws_bytes,
+                                     void *stream);
+int psgd_uvd_fused_s1_f32(int64_t N, int r, float step, float tiny, void *ws, int64_t ws_bytes,
+                          void *stream);
 
 /* IpUVtmatvec(U, V, x)   psgd.py:540-544:  out = x + U (V' x), x is [N].   */
 int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,

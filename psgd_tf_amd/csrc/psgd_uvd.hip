@@ -25,6 +25,7 @@ const UvdOps* uvd_ops_for_rank(int r) {
 
 // ------------------------------------------------------------ workspace ----
 constexpr int64_t kSumsCap = 4096;   // doubles (Gram of r = 32 needs 3840)
+constexpr int kPqSumsOff = 3840;      // the fused p,q sums (2r <= 64 doubles) live above the largest Gram
 constexpr int64_t kCoefCap = 256;    // floats
 constexpr int64_t kMaxCap = 64;      // floats
 
@@ -41,7 +42,7 @@ static WsLayout ws_layout(int64_t N, int r) {
   L.sums_off = off; off = align256(off + kSumsCap * 8);
   L.coef_off = off; off = align256(off + kCoefCap * 4);
   L.max_off = off;  off = align256(off + kMaxCap * 4);
-  const int64_t part_f32 = (int64_t)kMaxGrid * PSGD_UVD_MAX_RANK * 4;
+  const int64_t part_f32 = (int64_t)kMaxGrid * 2 * PSGD_UVD_MAX_RANK * 4;
   const int64_t part_f64 = (int64_t)kGramMaxGrid * np * 256 * 8;
   L.part_bytes = part_f32 > part_f64 ? part_f32 : part_f64;
   L.part_off = off; off = align256(off + L.part_bytes);
@@ -217,6 +218,18 @@ __global__ __launch_bounds__(kThreads) void k_reduce_max(const float* __restrict
 __global__ void k_publish(const double* __restrict__ sums, float* __restrict__ coef, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) coef[i] = (float)sums[i];
+}
+
+// s1 = p - mu q with p = Vnew'(d.*g), q = Vnew'(d.*g.*nablaD), mu = step / (max|nablaD| + tiny): the first
+// reduction of the apply that follows an update (see k_update_s2 FUSE).  Writes the apply's s1 slots.
+__global__ void k_fused_s1(const double* __restrict__ pq, const float* __restrict__ maxbuf, float step, float tiny, int r,
+                           double* __restrict__ s1_sums, float* __restrict__ s1_coef) {
+  const int c = threadIdx.x;
+  if (c >= r) return;
+  const double mu = (double)(step / (maxbuf[0] + tiny));
+  const double s = pq[c] - mu * pq[r + c];
+  s1_sums[c] = s;
+  s1_coef[c] = (float)s;
 }
 
 // d <- d - (mu d) nablaD, mu = step / (max|nablaD| + tiny)      psgd.py:582-584
@@ -558,6 +571,7 @@ int psgd_uvd_ws_region(int which, int stage, int64_t N, int r, int64_t* offset_b
     if (stage == 1) { *offset_bytes = L.sums_off; *count = r; return PSGD_OK; }
     if (stage == 2) { *offset_bytes = L.sums_off + (int64_t)r * 8; *count = r; return PSGD_OK; }
     if (stage == 11) { *offset_bytes = L.sums_off; *count = (int64_t)np * 256; return PSGD_OK; }
+    if (stage == 13) { *offset_bytes = L.sums_off + (int64_t)kPqSumsOff * 8; *count = 2 * r; return PSGD_OK; }
   } else if (which == PSGD_WS_MAX_F32) {
     if (stage == 10) { *offset_bytes = L.max_off; *count = 2; return PSGD_OK; }
     if (stage == 12) { *offset_bytes = L.max_off + 8; *count = 1; return PSGD_OK; }
@@ -727,8 +741,9 @@ int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, c
   return PSGD_OK;
 }
 
-int psgd_uvd_update_sweep2_f32(float* U, float* V, const float* d, const float* v, const float* h, int64_t N, int r,
-                               float step, float tiny, int update_U, void* ws, int64_t ws_bytes, void* stream) {
+static int update_sweep2_impl(float* U, float* V, const float* d, const float* v, const float* h, const float* g,
+                              int64_t N, int r, float step, float tiny, int update_U, void* ws, int64_t ws_bytes,
+                              void* stream) {
   if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
@@ -739,12 +754,41 @@ int psgd_uvd_update_sweep2_f32(float* U, float* V, const float* d, const float* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(kThreads), 0, st, w.sums, r, step, tiny, update_U, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
-  const int grid = sweep_grid(ops, r, update_U ? kOccUpdS2U : kOccUpdS2V, N, kMaxGrid);
+  const int grid = sweep_grid(ops, r, g ? kOccUpdS2F : (update_U ? kOccUpdS2U : kOccUpdS2V), N, kMaxGrid);
+  float* part = static_cast<float*>(w.part);
   {
     ProfScope ps(PSGD_PROF_UPDATE_S2, st);
-    PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, N, w.coef, w.nabla, w.pmax, grid, st));
+    PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, g, N, w.coef, w.nabla, w.pmax, part, grid, st));
   }
   hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf + 2);
+  PSGD_CHECK_LAUNCH(last_launch());
+  if (g) {
+    hipLaunchKernelGGL(k_reduce_sum_t, dim3((2 * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
+                       grid, 2 * r, w.sums + kPqSumsOff, static_cast<float*>(nullptr));
+    PSGD_CHECK_LAUNCH(last_launch());
+  }
+  return PSGD_OK;
+}
+
+int psgd_uvd_update_sweep2_f32(float* U, float* V, const float* d, const float* v, const float* h, int64_t N, int r,
+                               float step, float tiny, int update_U, void* ws, int64_t ws_bytes, void* stream) {
+  return update_sweep2_impl(U, V, d, v, h, nullptr, N, r, step, tiny, update_U, ws, ws_bytes, stream);
+}
+
+int psgd_uvd_update_sweep2_fused_f32(float* U, float* V, const float* d, const float* v, const float* h,
+                                     const float* g, int64_t N, int r, float step, float tiny, int update_U, void* ws,
+                                     int64_t ws_bytes, void* stream) {
+  if (!g) return PSGD_ERR_BAD_ARG;
+  return update_sweep2_impl(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream);
+}
+
+int psgd_uvd_fused_s1_f32(int64_t N, int r, float step, float tiny, void* ws, int64_t ws_bytes, void* stream) {
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_fused_s1, dim3(1), dim3(64), 0, st, w.sums + kPqSumsOff, w.maxbuf + 2, step, tiny, r, w.sums,
+                     w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
@@ -781,6 +825,32 @@ int psgd_uvd_update_f32(float* U, float* V, float* d, const float* v, const floa
   rc = psgd_uvd_update_sweep2_f32(U, V, d, v, h, N, r, step, tiny, update_U, ws, ws_bytes, stream);
   if (rc) return rc;
   return psgd_uvd_update_sweep3_f32(d, N, r, step, tiny, ws, ws_bytes, stream);
+}
+
+/* update_precond_UVd_math_ followed by precond_grad_UVd_math on the updated state (the UVd.step
+ * pattern, psgd.py:732 -> :748), with the apply's first reduction folded into update sweep 2. */
+int psgd_uvd_update_apply_f32(float* U, float* V, float* d, const float* v, const float* h, const float* g, float* out,
+                              int64_t N, int r, float step, float tiny, int balance, int update_U, void* ws,
+                              int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !v || !h || !g || !out) return PSGD_ERR_BAD_ARG;
+  int rc;
+  if (balance) {
+    rc = psgd_uvd_balance_max_f32(U, V, N, r, ws, ws_bytes, stream);
+    if (rc) return rc;
+    rc = psgd_uvd_balance_scale_f32(U, V, N, r, ws, ws_bytes, stream);
+    if (rc) return rc;
+  }
+  rc = psgd_uvd_update_sweep1_f32(U, V, d, v, h, N, r, ws, ws_bytes, stream);
+  if (rc) return rc;
+  rc = psgd_uvd_update_sweep2_fused_f32(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream);
+  if (rc) return rc;
+  rc = psgd_uvd_update_sweep3_f32(d, N, r, step, tiny, ws, ws_bytes, stream);
+  if (rc) return rc;
+  rc = psgd_uvd_fused_s1_f32(N, r, step, tiny, ws, ws_bytes, stream);
+  if (rc) return rc;
+  rc = psgd_uvd_apply_sweep2_f32(U, d, g, out, N, r, 0, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return psgd_uvd_apply_sweep3_f32(V, d, out, N, r, 0, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -554,42 +554,65 @@ struct UpdCoef {
 //   nablaD = Ph h - v invPv      (stored; its max|.| reduced)
 //   UPDATE_U: U <- U - mu (a c1 - b c2),  c1 = atV K, c2 = btV K
 //   else    : V <- V - mu ((a + V c1) c1 - (b + V c2) c2),  c1 = atU, c2 = btU
-template <int R, bool UPDATE_U, bool NT>
+// FUSE: UVd.step applies the preconditioner right after updating it (psgd.py:732 -> :748).
+// The apply's first reduction is s1 = Vnew'(dnew .* g) with dnew = d - mu d .* nablaD (psgd.py:584), i.e.
+//   s1 = Vnew'(d.*g) - mu Vnew'(d.*nablaD.*g)
+// and both column reductions can ride on this sweep (the new V row is in registers): 2R extra per-lane
+// accumulators and 4 B/row for g replace a whole extra pass over V.
+template <int R, bool UPDATE_U, bool NT, bool FUSE>
 __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, const float* d, const float* v,
-                                                        const float* h, long N, const float* __restrict__ coef,
-                                                        float* nabla, float* part_max) {
+                                                        const float* h, const float* g, long N,
+                                                        const float* __restrict__ coef, float* nabla, float* part_max,
+                                                        float* part_pq) {
   using K = UpdCoef<R>;
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 2, 3>()];
-  __shared__ float red[kWavesPerBlock];
+  constexpr int NV = FUSE ? 4 : 3;
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 2, NV>()];
+  __shared__ float red[kWavesPerBlock * (FUSE ? 2 * R : 1)];
   float vmax = 0.0f;
+  float pq[FUSE ? 2 * R : 1];
+#pragma unroll
+  for (int c = 0; c < (FUSE ? 2 * R : 1); ++c) pq[c] = 0.0f;
   const float mu = coef[K::kMu];
   const float* const mats[2] = {U, V};
-  const float* const vecs[3] = {d, v, h};
-  sweep_rows<R, 2, 3, (UPDATE_U ? 0 : 1), NT>(
-      mats, vecs, UPDATE_U ? U : V, N, lds[threadIdx.x >> 6],
-      [&](long row, bool valid, float (&x)[2][R], float (&s)[3]) {
-        const float dd = s[0], vv = s[1], hh = s[2];
-        const float t = dd * hh;
-        const float ww = valid ? vv / dd : 0.0f;
-        const float a = t + dot_row<R>(x[0], coef + K::kS1);
-        const float b = ww - dot_row<R>(x[1], coef + K::kX1);
-        const float Ph = dd * (a + dot_row<R>(x[1], coef + K::kS2));
-        const float invPv = valid ? (b - dot_row<R>(x[0], coef + K::kX2)) / dd : 0.0f;
-        const float nd = Ph * hh - vv * invPv;
-        if (valid) {
-          stream_store<NT>(nabla + row, nd);
-          vmax = fmaxf(vmax, fabsf(nd));
-        }
-        if constexpr (UPDATE_U) {
+  const float* vecs_[4] = {d, v, h, g};
+  const float* const (&vecs)[NV] = reinterpret_cast<const float* const (&)[NV]>(vecs_);
+  auto body = [&](long row, bool valid, float (&x)[2][R], float (&s)[NV]) {
+    const float dd = s[0], vv = s[1], hh = s[2];
+    const float t = dd * hh;
+    const float ww = valid ? vv / dd : 0.0f;
+    const float a = t + dot_row<R>(x[0], coef + K::kS1);
+    const float b = ww - dot_row<R>(x[1], coef + K::kX1);
+    const float Ph = dd * (a + dot_row<R>(x[1], coef + K::kS2));
+    const float invPv = valid ? (b - dot_row<R>(x[0], coef + K::kX2)) / dd : 0.0f;
+    const float nd = Ph * hh - vv * invPv;
+    if (valid) {
+      stream_store<NT>(nabla + row, nd);
+      vmax = fmaxf(vmax, fabsf(nd));
+    }
+    if constexpr (UPDATE_U) {
 #pragma unroll
-          for (int c = 0; c < R; ++c) x[0][c] = x[0][c] - mu * (a * coef[K::kC1 + c] - b * coef[K::kC2 + c]);
-        } else {
-          const float al = a + dot_row<R>(x[1], coef + K::kC1);
-          const float be = b + dot_row<R>(x[1], coef + K::kC2);
+      for (int c = 0; c < R; ++c) x[0][c] = x[0][c] - mu * (a * coef[K::kC1 + c] - b * coef[K::kC2 + c]);
+    } else {
+      const float al = a + dot_row<R>(x[1], coef + K::kC1);
+      const float be = b + dot_row<R>(x[1], coef + K::kC2);
 #pragma unroll
-          for (int c = 0; c < R; ++c) x[1][c] = x[1][c] - mu * (al * coef[K::kC1 + c] - be * coef[K::kC2 + c]);
-        }
-      });
+      for (int c = 0; c < R; ++c) x[1][c] = x[1][c] - mu * (al * coef[K::kC1 + c] - be * coef[K::kC2 + c]);
+    }
+    if constexpr (FUSE) {
+      const float tg = dd * s[NV - 1];          // d .* g        (rows past N: zero-filled)
+      const float tn = tg * nd;                 // d .* g .* nablaD
+#pragma unroll
+      for (int c = 0; c < R; ++c) {
+        pq[c] = fmaf(x[1][c], tg, pq[c]);
+        pq[R + c] = fmaf(x[1][c], tn, pq[R + c]);
+      }
+    }
+  };
+  sweep_rows<R, 2, NV, (UPDATE_U ? 0 : 1), NT>(mats, vecs, UPDATE_U ? U : V, N, lds[threadIdx.x >> 6], body);
+  if constexpr (FUSE) {
+    block_sum_store<2 * R>(pq, red, part_pq);
+    __syncthreads();
+  }
   block_max_store(vmax, red, part_max + blockIdx.x);
 }
 
@@ -604,12 +627,13 @@ struct UvdOps {
   int (*apply_s3)(int nt, const float* V, const float* d, float* out, long N, const float* coef, int grid, hipStream_t st);
   int (*rowdot_axpy)(int nt, const float* M, const float* x, float* out, long N, const float* coef, int grid, hipStream_t st);
   int (*update_gram)(int nt, const float* U, const float* V, const float* d, const float* v, const float* h, long N, double* part, int grid, hipStream_t st);
-  int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N, const float* coef, float* nabla, float* part_max, int grid, hipStream_t st);
+  // g / part_pq non-null: fused form that also reduces V'(d.*g) and V'(d.*g.*nablaD) (see k_update_s2)
+  int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, const float* g, long N, const float* coef, float* nabla, float* part_max, float* part_pq, int grid, hipStream_t st);
   // max resident blocks per CU for each sweep kernel (occupancy query)
   int (*occupancy)(int which);
 };
 
-enum { kOccColreduce = 0, kOccApplyS2, kOccApplyS3, kOccRowdot, kOccGram, kOccUpdS2U, kOccUpdS2V };
+enum { kOccColreduce = 0, kOccApplyS2, kOccApplyS3, kOccRowdot, kOccGram, kOccUpdS2U, kOccUpdS2V, kOccUpdS2F };
 
 const UvdOps* uvd_ops_for_rank(int r);   // nullptr when r is not instantiated
 

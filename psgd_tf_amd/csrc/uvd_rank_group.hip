@@ -43,11 +43,20 @@ struct Launch {
     PSGD_LAUNCH((k_update_gram<R, true>), (k_update_gram<R, false>), U, V, d, v, h, N, part);
   }
   static int update_s2(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h,
-                       long N, const float* coef, float* nabla, float* part_max, int grid, hipStream_t st) {
+                       const float* g, long N, const float* coef, float* nabla, float* part_max, float* part_pq,
+                       int grid, hipStream_t st) {
+    if (g) {
+      if (update_U)
+        PSGD_LAUNCH((k_update_s2<R, true, true, true>), (k_update_s2<R, true, false, true>), U, V, d, v, h, g, N, coef,
+                    nabla, part_max, part_pq);
+      PSGD_LAUNCH((k_update_s2<R, false, true, true>), (k_update_s2<R, false, false, true>), U, V, d, v, h, g, N, coef,
+                  nabla, part_max, part_pq);
+    }
     if (update_U)
-      PSGD_LAUNCH((k_update_s2<R, true, true>), (k_update_s2<R, true, false>), U, V, d, v, h, N, coef, nabla, part_max);
-    PSGD_LAUNCH((k_update_s2<R, false, true>), (k_update_s2<R, false, false>), U, V, d, v, h, N, coef, nabla,
-                part_max);
+      PSGD_LAUNCH((k_update_s2<R, true, true, false>), (k_update_s2<R, true, false, false>), U, V, d, v, h, g, N, coef,
+                  nabla, part_max, part_pq);
+    PSGD_LAUNCH((k_update_s2<R, false, true, false>), (k_update_s2<R, false, false, false>), U, V, d, v, h, g, N, coef,
+                nabla, part_max, part_pq);
   }
   static int occupancy(int which) {
     const void* f = nullptr;
@@ -57,8 +66,9 @@ struct Launch {
       case kOccApplyS3: f = reinterpret_cast<const void*>(&k_apply_s3<R, true>); break;
       case kOccRowdot: f = reinterpret_cast<const void*>(&k_rowdot_axpy<R, true>); break;
       case kOccGram: f = reinterpret_cast<const void*>(&k_update_gram<R, true>); break;
-      case kOccUpdS2U: f = reinterpret_cast<const void*>(&k_update_s2<R, true, true>); break;
-      case kOccUpdS2V: f = reinterpret_cast<const void*>(&k_update_s2<R, false, true>); break;
+      case kOccUpdS2U: f = reinterpret_cast<const void*>(&k_update_s2<R, true, true, false>); break;
+      case kOccUpdS2V: f = reinterpret_cast<const void*>(&k_update_s2<R, false, true, false>); break;
+      case kOccUpdS2F: f = reinterpret_cast<const void*>(&k_update_s2<R, false, true, true>); break;
       default: return 0;
     }
     int n = 0;

@@ -190,6 +190,28 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
     return None
 
 
+def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, balance=None, update_U=None,
+                                             generator=None):
+    """Extension: update_precond_UVd_math_(U, V, d, v, h, step, tiny) followed by
+    precond_grad_UVd_math(U, V, d, g) on the updated state -- the UVd.step pattern (psgd.py:732 -> :748) --
+    as one fused call that saves a pass over V.  U or V, and d, are updated in place; returns the
+    preconditioned gradient."""
+    dev = _require_hip("update_precond_UVd_math_and_precond_grad", U, V, d, v, h, g)
+    N, r = _uvd_shapes("update_precond_UVd_math_and_precond_grad", U, V, d, v, h, g)
+    if balance is None:
+        balance = _draw_branch(0.01, generator)
+    if update_U is None:
+        update_U = _draw_branch(0.5, generator)
+    out = torch.empty_like(g)
+    ws = uvd_workspace(dev, N, r)
+    rc = _lib.load().psgd_uvd_update_apply_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(),
+                                                g.data_ptr(), out.data_ptr(), N, r, float(step), float(tiny),
+                                                int(bool(balance)), int(bool(update_U)), ws.data_ptr(), ws.numel(),
+                                                _stream_ptr(dev))
+    _lib.check(rc, "psgd_uvd_update_apply_f32")
+    return out
+
+
 # --------------------------------------------------------------------------- UVd optimizer wrapper
 class _Hyper:
     """Stand-in for the non-trainable tf.Variable hyper-parameters of psgd.py:673-680:
@@ -307,16 +329,18 @@ class UVd:
             if not exact:                                                                     # :734-736
                 v = v / self._delta_param_scale
                 h = h / self._delta_param_scale
-            update_precond_UVd_math_(self._U, self._V, self._d, v[:, None].contiguous(), h[:, None].contiguous(),
-                                     step=float(self.lr_preconditioner), tiny=self._tiny,
-                                     generator=self._generator)
+            grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0)                      # :747
+            # :732-733 then :748 as one fused call (same results, one pass over V less)
+            pre_grad = update_precond_UVd_math_and_precond_grad(
+                self._U, self._V, self._d, v[:, None].contiguous(), h[:, None].contiguous(),
+                grad[:, None].contiguous(), step=float(self.lr_preconditioner), tiny=self._tiny,
+                generator=self._generator)
         else:                                                                                 # :737-744
             with torch.enable_grad():
                 closure_returns = closure()
                 grads = torch.autograd.grad(self._loss_of(closure_returns), params)
-
-        grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0)                          # :747
-        pre_grad = precond_grad_UVd_math(self._U, self._V, self._d, grad[:, None].contiguous())   # :748
+            grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0)                      # :747
+            pre_grad = precond_grad_UVd_math(self._U, self._V, self._d, grad[:, None].contiguous())   # :748
         max_norm = float(self.grad_clip_max_norm)
         if math.isinf(max_norm):                                                              # :750-751
             lr = float(self.lr_params)

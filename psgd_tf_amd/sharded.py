@@ -90,6 +90,24 @@ class HipStages:
                                                        h.data_ptr(), self.N, self.r, float(step), float(tiny),
                                                        int(bool(update_U)), wp, wn, st), "update_sweep2")
 
+    def update_sweep2_fused(self, U, V, d, v, h, g, step, tiny, update_U):
+        wp, wn, st = self._w()
+        _lib.check(self.lib.psgd_uvd_update_sweep2_fused_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(),
+                                                             h.data_ptr(), g.data_ptr(), self.N, self.r, float(step),
+                                                             float(tiny), int(bool(update_U)), wp, wn, st),
+                   "update_sweep2_fused")
+
+    def fused_s1(self, step, tiny):
+        wp, wn, st = self._w()
+        _lib.check(self.lib.psgd_uvd_fused_s1_f32(self.N, self.r, float(step), float(tiny), wp, wn, st), "fused_s1")
+
+    def apply_sweep2_local_s1(self, U, d, g):
+        """apply sweep 2 when s1 is already in place on every rank (after fused_s1)."""
+        self._out = torch.empty_like(g)
+        wp, wn, st = self._w()
+        _lib.check(self.lib.psgd_uvd_apply_sweep2_f32(U.data_ptr(), d.data_ptr(), g.data_ptr(), self._out.data_ptr(),
+                                                      self.N, self.r, 0, wp, wn, st), "apply_sweep2")
+
     def update_sweep3(self, d, step, tiny):
         wp, wn, st = self._w()
         _lib.check(self.lib.psgd_uvd_update_sweep3_f32(d.data_ptr(), self.N, self.r, float(step), float(tiny),
@@ -156,3 +174,25 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
     dist.all_reduce(be.maxbuf(12), op=dist.ReduceOp.MAX, group=group)
     be.update_sweep3(d, step, tiny)
     return None
+
+
+def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, balance=None, update_U=None,
+                                             generator=None, group=None, backend=None):
+    """Sharded fused update -> apply; returns this rank's rows of the preconditioned gradient.
+    Exchanges: SUM Gram, MAX max|nablaD| + SUM 2r (p, q), SUM r (s2) -- one all-reduce fewer than update + apply."""
+    be = backend if backend is not None else hip_backend_for(U)
+    balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
+    if balance:
+        be.balance_max(U, V)
+        dist.all_reduce(be.maxbuf(10), op=dist.ReduceOp.MAX, group=group)
+        be.balance_scale(U, V)
+    be.update_sweep1(U, V, d, v, h)
+    dist.all_reduce(be.sums(11), op=dist.ReduceOp.SUM, group=group)
+    be.update_sweep2_fused(U, V, d, v, h, g, step, tiny, update_U)
+    dist.all_reduce(be.maxbuf(12), op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(be.sums(13), op=dist.ReduceOp.SUM, group=group)
+    be.update_sweep3(d, step, tiny)
+    be.fused_s1(step, tiny)
+    be.apply_sweep2_local_s1(U, d, g)
+    dist.all_reduce(be.sums(2), op=dist.ReduceOp.SUM, group=group)
+    return be.apply_sweep3(U, V, d, g)

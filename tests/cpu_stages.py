@@ -16,7 +16,7 @@ class NumpyStages:
         self.dtype = dtype
         nc = 2 * r + 2
         self._sums = {1: torch.zeros(r, dtype=torch.float64), 2: torch.zeros(r, dtype=torch.float64),
-                      11: torch.zeros(nc * nc, dtype=torch.float64)}
+                      11: torch.zeros(nc * nc, dtype=torch.float64), 13: torch.zeros(2 * r, dtype=torch.float64)}
         self._max = {10: torch.zeros(2, dtype=torch.float32), 12: torch.zeros(1, dtype=torch.float32)}
         self.nabla = None
 
@@ -100,6 +100,24 @@ class NumpyStages:
         else:
             al, be = a + Vn @ c(e1), b + Vn @ c(e2)
             Vn -= mu * (al @ c(e1).T - be @ c(e2).T)
+
+    def update_sweep2_fused(self, U, V, d, v, h, g, step, tiny, update_U):
+        """sweep 2 + the two extra column reductions of the fused update->apply."""
+        dn, gn = self._np(d), self._np(g)
+        d_old = dn.copy()
+        self.update_sweep2(U, V, d, v, h, step, tiny, update_U)
+        Vn = self._np(V)                                   # the NEW V in the V branch
+        p = Vn.T @ (d_old * gn)
+        q = Vn.T @ (d_old * gn * self.nabla)
+        self._sums[13][:] = torch.from_numpy(np.concatenate([p, q]).astype(np.float64).ravel())
+
+    def fused_s1(self, step, tiny):
+        mu = step / (float(self._max[12][0]) + tiny)
+        pq = self._sums[13].numpy()
+        self._sums[1][:] = torch.from_numpy(pq[:self.r] - mu * pq[self.r:])
+
+    def apply_sweep2_local_s1(self, U, d, g):
+        self.apply_sweep2(U, d, g)
 
     def update_sweep3(self, d, step, tiny):
         dn = self._np(d)

@@ -44,6 +44,13 @@ def _worker(rank, world, port, outdir):
         out = sharded.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"], backend=be)
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), U=t["U"].numpy(), V=t["V"].numpy(), d=t["d"].numpy(),
                  out=out.numpy(), lo=lo, hi=hi)
+        # fused update -> apply (one V pass less): both branches, continuing from that state
+        outs_f = []
+        for upd in (True, False):
+            outs_f.append(sharded.update_precond_UVd_math_and_precond_grad(
+                t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY, balance=False, update_U=upd, backend=be))
+        np.savez(os.path.join(outdir, "fused%d.npz" % rank), U=t["U"].numpy(), V=t["V"].numpy(), d=t["d"].numpy(),
+                 o0=outs_f[0].numpy(), o1=outs_f[1].numpy())
     finally:
         dist.destroy_process_group()
 
@@ -62,6 +69,7 @@ def test_sharded_update_and_apply_equal_unsharded_oracle():
     with tempfile.TemporaryDirectory() as outdir:
         mp.spawn(_worker, args=(WORLD, _free_port(), outdir), nprocs=WORLD, join=True)
         parts = [np.load(os.path.join(outdir, "rank%d.npz" % k)) for k in range(WORLD)]
+        fused = [np.load(os.path.join(outdir, "fused%d.npz" % k)) for k in range(WORLD)]
     assert parts[0]["lo"] == 0 and parts[0]["hi"] == parts[1]["lo"] and parts[1]["hi"] == N
     got = {k: np.concatenate([q[k] for q in parts], 0) for k in ("U", "V", "d", "out")}
 
@@ -80,6 +88,15 @@ def test_sharded_update_and_apply_equal_unsharded_oracle():
     for k in ("U", "V", "d"):
         assert rel_err(got[k], q[k]) < 1e-7, k
     assert rel_err(got["out"], ref_out) < 1e-7
+    # the fused calls continue from that state: update (U branch) + apply, then update (V branch) + apply
+    gotf = {k: np.concatenate([f[k] for f in fused], 0) for k in ("U", "V", "d", "o0", "o1")}
+    refs = []
+    for upd in (True, False):
+        orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY, balance=False, update_U=upd)
+        refs.append(orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"]))
+    assert rel_err(gotf["o0"], refs[0]) < 1e-7 and rel_err(gotf["o1"], refs[1]) < 1e-7
+    for k in ("U", "V", "d"):
+        assert rel_err(gotf[k], q[k]) < 1e-7, k
 
 
 def test_shard_rows_cover_and_align():

@@ -44,6 +44,12 @@ def test_sharded_world1_equals_unsharded(pg, hip_lib, N, r):
         assert rel_err(b[k].cpu().numpy(), q[k]) < 1e-5
     assert torch.equal(oa, ob)
     assert rel_err(ob.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < 1e-5
+    # fused update -> apply through the sharded driver == the unsharded fused call
+    of_a = psgd.update_precond_UVd_math_and_precond_grad(a["U"], a["V"], a["d"], a["v"], a["h"], a["g"], 0.01, TINY32,
+                                                         balance=False, update_U=True)
+    of_b = sharded.update_precond_UVd_math_and_precond_grad(b["U"], b["V"], b["d"], b["v"], b["h"], b["g"], 0.01,
+                                                            TINY32, balance=False, update_U=True)
+    assert torch.equal(of_a, of_b) and torch.equal(a["U"], b["U"]) and torch.equal(a["d"], b["d"])   # same kernels
     # branch agreement path (rank 0 draws, broadcast) runs on the device
     gen = torch.Generator().manual_seed(3)
     sharded.update_precond_UVd_math_(b["U"], b["V"], b["d"], b["v"], b["h"], 0.01, TINY32, generator=gen)

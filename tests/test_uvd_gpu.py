@@ -162,3 +162,21 @@ def test_rejects_bad_arguments(psgd):
     big = torch.zeros(100, 33, device="cuda")
     with pytest.raises(PsgdHipError):
         psgd.precond_grad_UVd_math(big, big.clone(), t["d"], t["g"])
+
+
+@pytest.mark.parametrize("N,r", [(1021, 10), (5000, 20), (4099, 7), (100003, 20), (2049, 32), (777, 3)])
+@pytest.mark.parametrize("update_U", [True, False])
+def test_fused_update_apply_matches_oracle_and_unfused(psgd, N, r, update_U):
+    """the fused call = update_precond_UVd_math_ then precond_grad_UVd_math (psgd.py:732 -> :748)."""
+    p = make_uvd_problem(N, r, seed=N + 7 * r, uv_gain=2.0, d_spread=0.3)
+    a, b = _to_dev(p), _to_dev(p)
+    out_f = psgd.update_precond_UVd_math_and_precond_grad(a["U"], a["V"], a["d"], a["v"], a["h"], a["g"], 0.01, TINY32,
+                                                          balance=False, update_U=update_U)
+    psgd.update_precond_UVd_math_(b["U"], b["V"], b["d"], b["v"], b["h"], 0.01, TINY32, balance=False, update_U=update_U)
+    out_u = psgd.precond_grad_UVd_math(b["U"], b["V"], b["d"], b["g"])
+    for k in ("U", "V", "d"):                                   # same arithmetic, separately compiled kernel variant
+        assert rel_err(a[k].cpu().numpy(), b[k].cpu().numpy()) < 1e-6, k
+    assert rel_err(out_f.cpu().numpy(), out_u.cpu().numpy()) < 2e-6
+    q = _f64(p)
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=update_U)
+    assert rel_err(out_f.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < APPLY_TOL
