@@ -110,7 +110,9 @@ def kron_bench(dev, psgd, iters=20):
     t_bf16 = timeit(lambda: psgd.precond_grad_kron(Ql, Qr, Gb), iters)
     t_f32 = timeit(lambda: psgd.precond_grad_kron(Ql, Qr, G), iters)
     sts = [state(m, n) for m, n in LENET5]
-    t_lenet = timeit(lambda: [psgd.precond_grad_kron(a, b, c) for a, b, c in sts], 50)
+    Qls, Qrs, Gs = [x[0] for x in sts], [x[1] for x in sts], [x[2] for x in sts]
+    t_lenet = timeit(lambda: psgd.precond_grad_kron_batched(Qls, Qrs, Gs), 50)        # one launch per stage for all layers
+    t_lenet_loop = timeit(lambda: [psgd.precond_grad_kron(a, b, c) for a, b, c in sts], 50)
     f_big = kron_apply_flops(M, N)
     f_lenet = sum(kron_apply_flops(m, n) for m, n in LENET5)
     return {
@@ -119,7 +121,8 @@ def kron_bench(dev, psgd, iters=20):
                                     "frac_of_bf16_peak_Fref": f_big / t_bf16 / 1e6 / 2.5e6,
                                     "note": "triangular K-ranges skipped: issued flops ~0.5 F_ref"},
         "4096x4096_fp32": {"ms": t_f32, "gflops": f_big / t_f32 / 1e6, "mfma_peak_gflops": 157.3e3},
-        "lenet5_set_fp32": {"us": t_lenet * 1e3, "gflops": f_lenet / t_lenet / 1e6, "bound": "launch/latency"},
+        "lenet5_set_fp32": {"us": t_lenet * 1e3, "gflops": f_lenet / t_lenet / 1e6, "bound": "launch/latency",
+                            "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop * 1e3},
     }
 
 
