@@ -234,6 +234,8 @@ int psgd_kron_ns_apply_f32(const float *ql, const float *qr, const float *G, int
  * bf16 intermediates, in the reference's association order.  M and N must be multiples of 8.
  * Upper-triangular Ql, Qr are assumed (entries below the diagonal are not read).            */
 int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
+/* Experiment knob (not stable ABI). key 0: bf16 GEMM variant (0/1 register-staged double buffer, 2 LDS-DMA ring). */
+int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,
                             int64_t ws_bytes, void *stream);

@@ -253,7 +253,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, Gem
 template <int T, int GK>
 __global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) GemmLds<T, GK> L;
-  gemm_body<T, GK>(g, blockIdx.y * T, blockIdx.x * T, L);
+  // longest-K tiles first (see the bf16 kernel): an upper K bound grows with the tile index
+  int by = blockIdx.y, bx = blockIdx.x;
+  if (g.kmode & (KHI_M | KHI_N)) { by = gridDim.y - 1 - by; bx = gridDim.x - 1 - bx; }
+  gemm_body<T, GK>(g, by * T, bx * T, L);
 }
 
 // tile configurations: 128 x 128 x 16 for large problems; 64 x 64 x 64 for small ones, where the

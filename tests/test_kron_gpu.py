@@ -147,7 +147,8 @@ def test_unknown_format_passthrough(psgd, capsys):
 BF16_TOL = 2e-2      # 4 chained bf16-operand GEMMs with bf16 intermediates: ~2^-8 per rounding, see DESIGN.md 4.4
 
 
-@pytest.mark.parametrize("M,N", [(128, 128), (256, 512), (512, 256), (136, 264), (1024, 1024), (8, 8), (200, 72)])
+@pytest.mark.parametrize("M,N", [(128, 128), (256, 512), (512, 256), (136, 264), (1024, 1024), (8, 8), (200, 72),
+                                 (4096, 2048), (2048, 4096)])      # the last two: 8x8 tile-patch scheduling path
 def test_dense_dense_apply_bf16(psgd, M, N):
     rng = np.random.default_rng(M + 3 * N)
     Ql, Qr = _tri_factor(rng, M).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
@@ -159,6 +160,15 @@ def test_dense_dense_apply_bf16(psgd, M, N):
     # and it agrees with the fp32 HIP path on the same (bf16-valued) gradient to the same tolerance
     out32 = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), G.float())
     assert rel_err(out.float().cpu().numpy(), out32.cpu().numpy()) < BF16_TOL
+    if M * N >= 4096 * 2048:                          # both GEMM variants on the big shapes
+        from psgd_tf_amd import _lib
+        for variant in (1, 2):
+            _lib.load().psgd_kron_bf16_set_tuning(0, variant)
+            try:
+                outv = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), G)
+            finally:
+                _lib.load().psgd_kron_bf16_set_tuning(0, 0)
+            assert rel_err(outv.float().cpu().numpy(), ref) < BF16_TOL, variant
 
 
 def test_bf16_path_rejects_odd_shapes(psgd):

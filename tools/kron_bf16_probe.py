@@ -1,0 +1,12 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import preconditioned_stochastic_gradient_descent as psgd
+from tools.kron_timing import state
+M = N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+from psgd_tf_amd import _lib
+_lib.load().psgd_kron_bf16_set_tuning(0, int(os.environ.get("HG_VARIANT", "0")))
+Ql, Qr, dX, dG, G = state(M, N, torch.device("cuda:0"))
+Gb = G.to(torch.bfloat16)
+for _ in range(4):
+    psgd.precond_grad_kron(Ql, Qr, Gb)
+torch.cuda.synchronize()
