@@ -370,11 +370,154 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut(const float* __restrict__ 
   trsm_body(Q, n, ldq, X, Y, nvec, si, sj, xi, xj, blockIdx.x * 64, red, Qd);
 }
 
+// Inverses of the 32 x 32 diagonal sub-blocks of an upper-triangular Q (identity-padded at the ragged end):
+// Dinv[b] = Q[32b:32b+32, 32b:32b+32]^-1, by substitution, lane = row of the inverse.  One wave per block; all
+// blocks of a factor in parallel (~5 us), after which no solve below contains a serial per-vector chain.
+__global__ __launch_bounds__(64) void k_tri_inv32(const float* __restrict__ Q, int n, int ldq, float* __restrict__ Dinv) {
+  __shared__ float Qd[32][33];
+  const int lane = threadIdx.x, b = blockIdx.x, j0 = b * 32;
+  for (int e = lane; e < 1024; e += 64) {
+    const int r = e >> 5, c = e & 31;
+    Qd[r][c] = (j0 + r < n && j0 + c < n) ? Q[(long)(j0 + r) * ldq + j0 + c] : (r == c ? 1.0f : 0.0f);
+  }
+  __syncthreads();
+  if (lane < 32) {
+    float rr[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) rr[j] = (j == lane) ? 1.0f : 0.0f;      // row `lane` of I; solve x Qd = e_lane
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float y = rr[j] / Qd[j][j];
+      rr[j] = y;
+#pragma unroll
+      for (int j2 = j + 1; j2 < 32; ++j2) rr[j2] = fmaf(-y, Qd[j][j2], rr[j2]);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) Dinv[(long)b * 1024 + lane * 32 + j] = rr[j];
+  }
+}
+
+// Solve y Q = x for n <= 512 with the workgroup's strip of 64 vectors resident in LDS and the diagonal
+// sub-blocks pre-inverted (k_tri_inv32): every 32-wide sub-step is  Y_s = R_s Dinv_s  followed by the
+// trailing update  S[:, later] -= Y_s Q[s-rows, later],  both on MFMA with the A operand read from LDS.
+// (Blocked TRSM via small triangular inverses + GEMM is the standard GPU formulation; the substitution
+// kernel above is kept for the batched small-layer path.)  Dynamic LDS: 64 x pitch + 32 x 33 floats.
+constexpr int kStripN = 512;
+
+__device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __restrict__ Dinv, int v0, float* S,
+                                              int pitch, float (*Dd)[33]) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long xi = (t.xi == 0 && t.xj == 0) ? t.si : t.xi, xj = (t.xi == 0 && t.xj == 0) ? t.sj : t.xj;
+  const int n = t.n;
+  const int npad = (n + 31) & ~31;
+  for (int e = tid; e < 64 * npad; e += kThreads) {
+    int v, j;
+    if (xj == 1) { j = e % npad; v = e / npad; } else { v = e & 63; j = e >> 6; }
+    S[v * pitch + j] = (v0 + v < t.nvec && j < n) ? t.X[(long)(v0 + v) * xi + (long)j * xj] : 0.0f;
+  }
+  for (int j0 = 0; j0 < n; j0 += 32) {
+    for (int e = tid; e < 1024; e += kThreads) Dd[e >> 5][e & 31] = Dinv[(long)(j0 >> 5) * 1024 + e];
+    __syncthreads();
+    {   // Y_s = R_s Dinv_s : wave w owns vector block w (rows 16w..16w+15), reads and rewrites only those rows
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = kk * 4 + (lane >> 4);
+        const float a = S[(w * 16 + (lane & 15)) * pitch + j0 + k];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Dd[k][c * 16 + (lane & 15)], acc[c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[(w * 16 + (lane >> 4) * 4 + e) * pitch + j0 + c * 16 + (lane & 15)] = acc[c][e];
+    }
+    __syncthreads();
+    const int c_begin = j0 + 32;
+    const int ncb = (n > c_begin) ? (n - c_begin + 15) / 16 : 0;
+    for (int cb = w; cb < ncb; cb += 4) {
+      const int col = c_begin + cb * 16 + (lane & 15);
+      const bool cok = col < n;
+      float bq[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) bq[kk] = cok ? t.Q[(long)(j0 + kk * 4 + (lane >> 4)) * t.ldq + col] : 0.0f;
+      f32x4 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = S[(i * 16 + (lane >> 4) * 4 + e) * pitch + col];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = j0 + kk * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(-S[(i * 16 + (lane & 15)) * pitch + k], bq[kk], acc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[(i * 16 + (lane >> 4) * 4 + e) * pitch + col] = acc[i][e];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < 64 * n; e += kThreads) {
+    int v, j;
+    if (t.sj == 1) { j = e % n; v = e / n; } else { v = e & 63; j = e >> 6; }
+    if (v0 + v < t.nvec) t.Y[(long)(v0 + v) * t.si + (long)j * t.sj] = S[v * pitch + j];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_trsm_ut_inv(TrsmArgs t, const float* __restrict__ Dinv) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  const int pitch = ((t.n + 31) & ~31) + 2;          // == 2 (mod 32): MFMA A-operand reads (v, k) hit distinct banks
+  trsm_inv_body(t, Dinv, blockIdx.x * 64, dyn_lds, pitch, reinterpret_cast<float (*)[33]>(dyn_lds + 64 * pitch));
+}
+
 struct TrsmBatch {
   int count;
-  int blk_end[kMaxBatch];
+  int blk_end[kMaxBatch];      // inclusive prefix sums of 64-vector strips (solve) / of 32-blocks (inversion)
   TrsmArgs t[kMaxBatch];
+  const float* dinv[kMaxBatch];
 };
+
+__global__ __launch_bounds__(64) void k_tri_inv32_batched(TrsmBatch b) {
+  int p = 0;
+  while (p + 1 < b.count && (int)blockIdx.x >= b.blk_end[p]) ++p;
+  const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
+  const TrsmArgs& t = b.t[p];
+  // same body as k_tri_inv32 for block `blk` of problem p
+  __shared__ float Qd[32][33];
+  const int lane = threadIdx.x, j0 = blk * 32;
+  for (int e = lane; e < 1024; e += 64) {
+    const int r = e >> 5, c = e & 31;
+    Qd[r][c] = (j0 + r < t.n && j0 + c < t.n) ? t.Q[(long)(j0 + r) * t.ldq + j0 + c] : (r == c ? 1.0f : 0.0f);
+  }
+  __syncthreads();
+  if (lane < 32) {
+    float rr[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) rr[j] = (j == lane) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float y = rr[j] / Qd[j][j];
+      rr[j] = y;
+#pragma unroll
+      for (int j2 = j + 1; j2 < 32; ++j2) rr[j2] = fmaf(-y, Qd[j][j2], rr[j2]);
+    }
+    float* out = const_cast<float*>(b.dinv[p]) + (long)blk * 1024 + lane * 32;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) out[j] = rr[j];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_trsm_ut_inv_batched(TrsmBatch b, int pitch_max) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  int p = 0;
+  while (p + 1 < b.count && (int)blockIdx.x >= b.blk_end[p]) ++p;
+  const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
+  const TrsmArgs& t = b.t[p];
+  const int pitch = ((t.n + 31) & ~31) + 2;
+  trsm_inv_body(t, b.dinv[p], blk * 64, dyn_lds, pitch, reinterpret_cast<float (*)[33]>(dyn_lds + 64 * pitch_max));
+}
 
 __global__ __launch_bounds__(kThreads) void k_trsm_ut_batched(TrsmBatch b) {
   __shared__ float red[4][64][33];
@@ -582,7 +725,7 @@ __global__ __launch_bounds__(kThreads) void k_balance_generic(const float* __res
 static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct KronWs {
-  float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2;
+  float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv;
   int64_t total;
 };
 
@@ -595,6 +738,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.QlS = take(mm); k.QrS = take(nn);
   k.T = take(mn); k.A = take(mn); k.X1 = take(mn); k.Bt = take(mn);
   k.g1 = take(mm); k.g2 = take(nn);
+  k.dinv = take((int64_t)((M + 31) / 32 + (N + 31) / 32) * 1024 * 4);
   k.total = off;
   return k;
 }
@@ -662,14 +806,6 @@ static void plan_update(const float* dG, float* QlOut, float* QrOut, int M, int 
   s[5].epi = EPI_D_MINUS; s[5].D = k.QrS; s[5].ldd = N; s[5].scale_max = k.scal + 1; s[5].step = step; s[5].tiny = tiny;
 }
 
-// Blocked solve of  y[i,:] Q = x[i,:]  (see k_trsm_ut) for large n, right-looking so that the
-// MFMA GEMMs are wide (N = all remaining columns, K = block width):
-//   Y <- X
-//   for each 256-wide column block jb:   Y[:, jb] <- Y[:, jb] Q[jb, jb]^-1      (substitution kernel, in place)
-//                                        Y[:, >jb] -= Y[:, jb] Q[jb, >jb]      (one GEMM)
-// X and Y are dense nvec*n arrays (either orientation), so the initial copy is one memcpy.
-constexpr int kTrsmBlock = 256;
-
 __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long xi, long xj, float* Y, long si, long sj,
                                                            int nvec, int n) {
   const long tot = (long)nvec * n;
@@ -679,13 +815,32 @@ __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long 
   }
 }
 
-// xi/xj: strides of X when they differ from Y's (0,0 = same layout)
-static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, hipStream_t st,
-                   long xi = 0, long xj = 0) {
-  const dim3 grid((nvec + 63) / 64);
-  if (n <= 2 * kTrsmBlock) {
-    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q, n, n, X, Y, nvec, si, sj, xi, xj);
-    return (int)hipGetLastError();
+// Solve  y[i,:] Q = x[i,:]  (see k_trsm_ut).  `dinv` is scratch for the inverted 32 x 32 diagonal sub-blocks
+// (ceil(n/32) * 1024 floats).  n <= 512: one strip kernel.  Larger n: right-looking over 512-wide column blocks,
+//   Y <- X;  for each block jb:  Y[:, jb] <- Y[:, jb] Q[jb, jb]^-1  (strip kernel, in place)
+//                                Y[:, >jb] -= Y[:, jb] Q[jb, >jb]   (one wide MFMA GEMM, K = 512)
+constexpr int kTrsmBlock = kStripN;
+
+static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
+  static bool attr_set = false;
+  const int pitch = ((t.n + 31) & ~31) + 2;
+  const size_t lds = (size_t)(64 * pitch + 32 * 33) * sizeof(float);
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trsm_ut_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((64 * (kStripN + 2) + 32 * 33) * sizeof(float))) != hipSuccess) return 1;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_trsm_ut_inv, dim3((t.nvec + 63) / 64), dim3(kThreads), lds, st, t, dinv);
+  return (int)hipGetLastError();
+}
+
+static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
+                   hipStream_t st, long xi = 0, long xj = 0) {
+  hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
+  if (hipGetLastError() != hipSuccess) return 1;
+  if (n <= kStripN) {
+    TrsmArgs t = {Q, n, n, X, Y, nvec, si, sj, xi, xj};
+    return launch_strip(t, dinv, st);
   }
   if (xi == 0 && xj == 0) {
     if (hipMemcpyAsync(Y, X, (size_t)nvec * n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
@@ -696,8 +851,8 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
   for (int j0 = 0; j0 < n; j0 += kTrsmBlock) {
     const int jw = (n - j0 < kTrsmBlock) ? (n - j0) : kTrsmBlock;
     float* Yb = Y + (long)j0 * sj;
-    hipLaunchKernelGGL(k_trsm_ut, grid, dim3(kThreads), 0, st, Q + (long)j0 * n + j0, jw, n, Yb, Yb, nvec, si, sj, 0L, 0L);
-    int e = (int)hipGetLastError();
+    TrsmArgs t = {Q + (long)j0 * n + j0, jw, n, Yb, Yb, nvec, si, sj, 0L, 0L};
+    int e = launch_strip(t, dinv + (long)(j0 / 32) * 1024, st);
     if (e) return e;
     const int rest = n - j0 - jw;
     if (rest > 0) {
@@ -793,8 +948,8 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   KRON_LAUNCH(launch_gemm(s[0], st));
   KRON_LAUNCH(launch_gemm(s[1], st));
   // K2 (:174): X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
-  KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, st));
-  KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, st));
+  KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st));
+  KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st));
   for (int i = 2; i < 6; ++i) KRON_LAUNCH(launch_gemm(s[i], st));
   return PSGD_OK;
 }
@@ -849,7 +1004,7 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
   if (need < 0) return (int)need;
   if (kron_ws_check(ws, ws_bytes, need)) return PSGD_ERR_WORKSPACE;
   for (int p = 0; p < count; ++p)
-    if (M[p] > 2 * kTrsmBlock || N[p] > 2 * kTrsmBlock) return PSGD_ERR_SHAPE;   // batched form is for small layers
+    if (M[p] > 512 || N[p] > 512) return PSGD_ERR_SHAPE;   // batched form is for small layers
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* base = static_cast<char*>(ws);
   for (int p0 = 0; p0 < count; p0 += kMaxBatch) {
@@ -869,6 +1024,7 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
       plan_update(dG[p], QlOut[p], QrOut[p], M[p], N[p], step, tiny, k[q], s[q]);
       bb.Ql[q] = Ql[p]; bb.Qr[q] = Qr[p]; bb.QlS[q] = k[q].QlS; bb.QrS[q] = k[q].QrS; bb.M[q] = M[p]; bb.N[q] = N[p];
       t1.t[q] = {k[q].QrS, N[p], N[p], dX[p], k[q].X1, M[p], (long)N[p], 1L, 0L, 0L};
+      t1.dinv[q] = k[q].dinv; t2.dinv[q] = k[q].dinv + (long)((N[p] + 31) / 32) * 1024;
       t2.t[q] = {k[q].QlS, M[p], M[p], k[q].X1, k[q].Bt, N[p], 1L, (long)N[p], 0L, 0L};
       blk1 += (M[p] + 63) / 64; t1.blk_end[q] = blk1;
       blk2 += (N[p] + 63) / 64; t2.blk_end[q] = blk2;
@@ -880,10 +1036,31 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
       for (int q = 0; q < nb; ++q) g[q] = s[q][stage];
       KRON_LAUNCH(launch_gemm_batch(g, nb, st));
     }
-    hipLaunchKernelGGL(k_trsm_ut_batched, dim3(blk1), dim3(kThreads), 0, st, t1);
-    KRON_LAUNCH((int)hipGetLastError());
-    hipLaunchKernelGGL(k_trsm_ut_batched, dim3(blk2), dim3(kThreads), 0, st, t2);
-    KRON_LAUNCH((int)hipGetLastError());
+    // K2 (:174) for every layer: invert the 32 x 32 diagonal blocks of all factors, then the two solves
+    for (int pass = 0; pass < 2; ++pass) {
+      TrsmBatch& tb = pass ? t2 : t1;
+      TrsmBatch ib = tb;
+      int nblk = 0, nmax = 0;
+      for (int q = 0; q < nb; ++q) {
+        nblk += (tb.t[q].n + 31) / 32;
+        ib.blk_end[q] = nblk;
+        if (tb.t[q].n > nmax) nmax = tb.t[q].n;
+      }
+      hipLaunchKernelGGL(k_tri_inv32_batched, dim3(nblk), dim3(64), 0, st, ib);
+      KRON_LAUNCH((int)hipGetLastError());
+      const int pitch_max = ((nmax + 31) & ~31) + 2;
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trsm_ut_inv_batched),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((64 * (kStripN + 2) + 32 * 33) * sizeof(float))) != hipSuccess)
+          return PSGD_ERR_LAUNCH;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k_trsm_ut_inv_batched, dim3(pass ? blk2 : blk1), dim3(kThreads),
+                         (size_t)(64 * pitch_max + 32 * 33) * sizeof(float), st, tb, pitch_max);
+      KRON_LAUNCH((int)hipGetLastError());
+    }
     for (int stage = 2; stage < 6; ++stage) {
       for (int q = 0; q < nb; ++q) g[q] = s[q][stage];
       KRON_LAUNCH(launch_gemm_batch(g, nb, st));
@@ -899,7 +1076,7 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
  * Data matrices are strided views (element (m,n) at p[m*rs + n*cs]); results are contiguous. */
 
 struct SparseWs {
-  float *scal, *LS, *RS, *T, *A, *Bt, *gsq, *v0, *v1, *v2, *v3;
+  float *scal, *LS, *RS, *T, *A, *Bt, *gsq, *v0, *v1, *v2, *v3, *dinv;
   int64_t total;
 };
 
@@ -917,6 +1094,7 @@ static SparseWs sparse_layout(char* base, int fmt, int M, int N) {
   k.T = take(mn); k.A = take(mn); k.Bt = take(mn);
   k.gsq = take(gbytes);
   k.v0 = take(vb); k.v1 = take(vb); k.v2 = take(vb); k.v3 = take(vb);
+  k.dinv = take((int64_t)(((M > N ? M : N) + 31) / 32) * 1024 * 4);
   k.total = off;
   return k;
 }
@@ -962,7 +1140,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
     KRON_LAUNCH(launch_gemm(g, st));
   }
   // Bt = (QlS^-T dX) .* (1/qrS)                             (:298-299); columns independent
-  KRON_LAUNCH(trsm_ut(k.LS, M, dX, k.Bt, N, 1L, (long)N, st, (long)xcs, (long)xrs));
+  KRON_LAUNCH(trsm_ut(k.LS, M, dX, k.Bt, N, 1L, (long)N, k.dinv, st, (long)xcs, (long)xrs));
   SP_LAUNCH(k_col_inv_scale, ew_grid((long)M * N), k.Bt, k.RS, M, N);
   {                                                          // grad1 = triu(A A' - Bt Bt')  (:301)
     GemmArgs g = gemm_args(k.A, N, false, k.A, N, true, k.gsq, M, M, M, N);
@@ -1033,7 +1211,7 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
   int e = norm_left_pair(k, dX, dG, xrs, xcs, M, N, nullptr, k.T, k.Bt, st);       // T = Ql dG ; Bt = Ql^-T dX
   if (e) return e;
   KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), st));   // A = T QrS'  (:220)
-  KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.T, M, (long)N, 1L, st));                    // Bt QrS^-1 -> T   (:233)
+  KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.T, M, (long)N, 1L, k.dinv, st));                    // Bt QrS^-1 -> T   (:233)
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.T, M, N, k.v1, k.v2);    // (:235-237)
   SP_LAUNCH(k_norm_finalize, 1, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
   {                                                          // grad2 = triu(A'A - Bt'Bt)     (:243)

@@ -200,7 +200,8 @@ def test_every_gemm_tile_size_forced(psgd, hip_lib, M, N, tile_choice):
 
 
 def test_batched_lenet_set_equals_per_layer(psgd):
-    """The batched calls must give exactly the per-layer results (same kernels, same tiles)."""
+    """The batched calls must agree with the per-layer results (bitwise for the GEMM-only apply; the update's
+    triangular solves may take a different blocking per path, so those agree to rounding)."""
     shapes = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (1, 1), (3, 3)]   # > 8: two chunks
     rng = np.random.default_rng(5)
     Qls = [_dev(_tri_factor(rng, m) * 2.0) for m, n in shapes]
@@ -213,7 +214,8 @@ def test_batched_lenet_set_equals_per_layer(psgd):
     for i, (m, n) in enumerate(shapes):
         assert torch.equal(outs[i], psgd.precond_grad_kron(Qls[i], Qrs[i], Gs[i])), (m, n)
         a, b = psgd.update_precond_kron(Qls[i], Qrs[i], dXs[i], dGs[i], 0.01)
-        assert torch.equal(news[i][0], a) and torch.equal(news[i][1], b), (m, n)
+        assert rel_err(news[i][0].cpu().numpy(), a.cpu().numpy()) < 2e-6, (m, n)
+        assert rel_err(news[i][1].cpu().numpy(), b.cpu().numpy()) < 2e-6, (m, n)
 
 
 # larger sparse-format cases: embedding-like shapes (README.md:54 recommends these formats for large
