@@ -161,7 +161,15 @@ def test_rejects_bad_arguments(psgd):
         psgd.precond_grad_UVd_math(t["U"].double(), t["V"].double(), t["d"].double(), t["g"].double())
     big = torch.zeros(100, 33, device="cuda")
     with pytest.raises(PsgdHipError):
-        psgd.precond_grad_UVd_math(big, big.clone(), t["d"], t["g"])
+        psgd.precond_grad_UVd_math(big, big.clone(), t["d"], t["g"])                  # rank > 32
+    with pytest.raises(ValueError):
+        psgd.precond_grad_UVd_math(t["U"].t().contiguous().t(), t["V"], t["d"], t["g"])   # non-contiguous
+    # a row-slice that starts at an odd row of an r = 3 matrix is not 16-byte aligned: refused, not mis-read
+    p3 = _to_dev(make_uvd_problem(101, 3))
+    with pytest.raises(PsgdHipError, match="16-byte"):
+        psgd.precond_grad_UVd_math(p3["U"][1:], p3["V"][1:], p3["d"][1:], p3["g"][1:])
+    with pytest.raises(ValueError):
+        psgd.precond_grad_UVd_math(t["U"], t["V"][:50], t["d"], t["g"])               # shape mismatch
 
 
 @pytest.mark.parametrize("N,r", [(1021, 10), (5000, 20), (4099, 7), (100003, 20), (2049, 32), (777, 3)])
