@@ -382,6 +382,26 @@ __global__ __launch_bounds__(kThreads) void k_rowdot_axpy(const float* M, const 
                           });
 }
 
+// 3-way bf16 split of 8 fp32 values: x = h + m + l to ~2^-24 (bf16 keeps fp32's exponent range), so that
+// x*y ~ h*h' + h*m' + m*h' + h*l' + l*h' + m*m' can run on the bf16 matrix cores (16x the fp32 MFMA rate).
+#ifndef PSGD_GRAM_BF16X3
+#define PSGD_GRAM_BF16X3 1
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 a = static_cast<__bf16>(x[j]);
+    const float r1 = x[j] - static_cast<float>(a);
+    const __bf16 b = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(b);
+    h[j] = a;
+    m[j] = b;
+    l[j] = static_cast<__bf16>(r2);
+  }
+}
+
 // update sweep 1: Gram of W = [U | V | t | w], t = d.*h, w = v./d, on the
 // fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains).  The Gram
 // holds every inner product psgd.py:569-615 needs: V'U (:574), U'U, V'V, V't,
@@ -405,7 +425,7 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
   float* lds = reinterpret_cast<float*>(smem) + w * kWaveFloats;
   if (lane < 4) lds[kZero + lane] = 0.0f;
 
-  int obase[GC::kBlocks], ostride[GC::kBlocks];
+  int obase[GC::kBlocks], obase8[GC::kBlocks], ostride[GC::kBlocks];
 #pragma unroll
   for (int b = 0; b < GC::kBlocks; ++b) {
     const int col = 16 * b + (lane & 15);
@@ -413,7 +433,8 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
     else if (col < 2 * R) { obase[b] = C::kTileFloats + (col - R); ostride[b] = R; }
     else if (col < 2 * R + 2) { obase[b] = kTw + (col - 2 * R); ostride[b] = 2; }
     else { obase[b] = kZero; ostride[b] = 0; }
-    obase[b] += (lane >> 4) * ostride[b];
+    obase8[b] = obase[b] + 8 * (lane >> 4) * ostride[b];    // bf16 fragments: rows 8(l>>4) + j
+    obase[b] += (lane >> 4) * ostride[b];                    // fp32 MFMA: row (l>>4) of each group of 4
   }
 
   double acc64[GC::kPairs][4];
@@ -445,6 +466,37 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
     since_flush = 0;
   };
   auto gram_tile = [&]() {
+#if PSGD_GRAM_BF16X3
+    // 32-row chunks on v_mfma_f32_16x16x32_bf16: lane l holds, for each 16-column block, the 8 rows
+    // 32c + 8(l>>4) + j of column (l & 15) -- the same fragment serves as A (W' block bi) and as B (block bj).
+    // The fp32 formulation below needs 96 fp32 MFMAs (3072 SIMD cycles) per 64-row tile and pinned this
+    // sweep at the MFMA rate; this one needs 72 bf16 MFMAs (1152 cycles) and is HBM-bound.
+#pragma unroll 1
+    for (int c = 0; c < C::kTileRows / 32; ++c) {
+      bf16x8 fh[GC::kBlocks], fm[GC::kBlocks], fl[GC::kBlocks];
+#pragma unroll
+      for (int b = 0; b < GC::kBlocks; ++b) {
+        float x[8];
+        const int base = obase8[b] + 32 * c * ostride[b];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = lds[base + j * ostride[b]];
+        split3_bf16(x, fh[b], fm[b], fl[b]);
+      }
+      int p = 0;
+#pragma unroll
+      for (int bi = 0; bi < GC::kBlocks; ++bi)
+#pragma unroll
+        for (int bj = bi; bj < GC::kBlocks; ++bj) {
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[bi], fm[bj], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[bi], fl[bj], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[bi], fh[bj], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[bi], fm[bj], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm[bi], fh[bj], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[bi], fh[bj], acc[p], 0, 0, 0);
+          ++p;
+        }
+    }
+#else
 #pragma unroll 4
     for (int m = 0; m < C::kTileRows / 4; ++m) {
       float a[GC::kBlocks];
@@ -459,6 +511,7 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
           ++p;
         }
     }
+#endif
     if (++since_flush == kFlushTiles) flush();
   };
 
