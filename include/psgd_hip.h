@@ -158,6 +158,25 @@ int psgd_set_tuning(int key, int value);
 int psgd_prof_enable(int on);
 int psgd_prof_collect(int slot, double *total_ms, int *count);
 
+/* ------------------------------------------------------------ sparse LU ---
+ * P = Q'Q, Q = L U, L = [L1 0; L2 diag(l3)], U = [U1 U2; 0 diag(u3)]  (psgd.py:396-404).
+ * Layout is the reference's: L12 = [L1; L2] is [N, r] row-major (L1 lower triangular), U12 = [U1, U2]
+ * is [r, N] row-major (U1 upper triangular), l3 and u3 are [N - r].  1 <= r <= PSGD_UVD_MAX_RANK,
+ * N >= r.  L12 (and L12_new) must be 16-byte aligned; vectors need 4-byte alignment only.
+ *
+ * psgd_splu_apply_f32  replaces precond_grad_splu(L12, l3, U12, u3, grads)   psgd.py:483-524
+ *   g, out: the concatenated gradient / preconditioned gradient, [N] (the list <-> flat vector plumbing of
+ *   :495-497,:518-522 stays on the host side).  out must not alias g.
+ * psgd_splu_update_f32 replaces update_precond_splu(L12, l3, U12, u3, dxs, dgs, step)   psgd.py:396-480
+ *   dx, dg: the concatenated perturbations [N].  Pure like the reference: the new factors go to the *_new
+ *   buffers (which may alias the inputs for an in-place update).  tiny = psgd.py:22 `_tiny`.          */
+int64_t psgd_splu_workspace_bytes(int64_t N, int r);
+int psgd_splu_apply_f32(const float *L12, const float *l3, const float *U12, const float *u3, const float *g,
+                        float *out, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_splu_update_f32(const float *L12, const float *l3, const float *U12, const float *u3, const float *dx,
+                         const float *dg, float *L12_new, float *l3_new, float *U12_new, float *u3_new, int64_t N,
+                         int r, float step, float tiny, void *ws, int64_t ws_bytes, void *stream);
+
 /* ----------------------------------------------------------------- Kron ---
  * P = kron(Qr'Qr, Ql'Ql) with dense upper-triangular Ql [M,M], Qr [N,N]
  * (psgd.py:156-192).  G, dX, dG are [M,N] row-major.                       */

@@ -294,6 +294,99 @@ def precond_grad_kron(Ql, Qr, Grad):
     return Grad
 
 
+# --------------------------------------------------------------------------- sparse LU (splu)
+def _splu_blocks(L12, U12):
+    """psgd.py:420-424 / :499-503."""
+    r = U12.shape[0]
+    return r, L12[:r], L12[r:], U12[:, :r], U12[:, r:]
+
+
+def _tri_solve(A, b, lower, adjoint=False):
+    """tf.linalg.triangular_solve(A, b, lower=..., adjoint=...) (psgd.py:436,440,448,452)."""
+    return sla.solve_triangular(A, b, lower=lower, trans='T' if adjoint else 'N',
+                                check_finite=False).astype(A.dtype)
+
+
+def update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01):
+    """psgd.py:396-480.  Q = L U, L = [L1 0; L2 diag(l3)], U = [U1 U2; 0 diag(u3)].  Pure."""
+    dt = L12.dtype.type
+    step = dt(step)
+    tiny = tiny_of(L12.dtype)
+    r0 = U12.shape[0]
+    # signed max, as written; tf.reduce_max of an empty tensor (N == r) is -inf
+    max_l = max(np.max(np.diag(L12[:r0])), np.max(l3, initial=-np.inf))            # :411
+    max_u = max(np.max(np.diag(U12[:, :r0])), np.max(u3, initial=-np.inf))         # :412
+    rho = np.sqrt(max_l / max_u)                                                   # :413
+    L12 = L12 / rho                                                                # :414-417
+    l3 = l3 / rho
+    U12 = rho * U12
+    u3 = rho * u3
+
+    r, L1, L2, U1, U2 = _splu_blocks(L12, U12)                                     # :420-424
+    dx = np.concatenate([np.reshape(x, (-1, 1)) for x in dxs], 0).astype(L12.dtype)   # :426
+    dg = np.concatenate([np.reshape(g, (-1, 1)) for g in dgs], 0).astype(L12.dtype)   # :427
+
+    Ug1 = U1 @ dg[:r] + U2 @ dg[r:]                                                # :430
+    Ug2 = u3 * dg[r:]                                                              # :431
+    Qg1 = L1 @ Ug1                                                                 # :433
+    Qg2 = L2 @ Ug1 + l3 * Ug2                                                      # :434
+    iUtx1 = _tri_solve(U1, dx[:r], lower=False, adjoint=True)                      # :436
+    iUtx2 = (dx[r:] - U2.T @ iUtx1) / u3                                           # :437
+    iQtx2 = iUtx2 / l3                                                             # :439
+    iQtx1 = _tri_solve(L1, iUtx1 - L2.T @ iQtx2, lower=True, adjoint=True)         # :440
+    LtQg1 = L1.T @ Qg1 + L2.T @ Qg2                                                # :442
+    LtQg2 = l3 * Qg2                                                               # :443
+    Pg1 = U1.T @ LtQg1                                                             # :445
+    Pg2 = U2.T @ LtQg1 + u3 * LtQg2                                                # :446
+    iLiQtx1 = _tri_solve(L1, iQtx1, lower=True)                                    # :448
+    iLiQtx2 = (iQtx2 - L2 @ iLiQtx1) / l3                                          # :449
+    iPx2 = iLiQtx2 / u3                                                            # :451
+    iPx1 = _tri_solve(U1, iLiQtx1 - U2 @ iPx2, lower=False)                        # :452
+
+    grad1 = np.tril(Qg1 @ Qg1.T - iQtx1 @ iQtx1.T)                                 # :455-456
+    grad2 = Qg2 @ Qg1.T - iQtx2 @ iQtx1.T                                          # :457
+    grad3 = Qg2 * Qg2 - iQtx2 * iQtx2                                              # :458
+    max_abs_grad = max(np.max(np.abs(grad1)), _max0(np.abs(grad2)), _max0(np.abs(grad3)))   # :459-461
+    step0 = step / (max_abs_grad + tiny)                                           # :462
+    newL1 = L1 - (step0 * grad1) @ L1                                              # :463
+    newL2 = L2 - (step0 * grad2) @ L1 - step0 * grad3 * L2                         # :464
+    newl3 = l3 - step0 * grad3 * l3                                                # :465
+
+    grad1 = np.triu(Pg1 @ dg[:r].T - dx[:r] @ iPx1.T)                              # :468-469
+    grad2 = Pg1 @ dg[r:].T - dx[:r] @ iPx2.T                                       # :470
+    grad3 = Pg2 * dg[r:] - dx[r:] * iPx2                                           # :471
+    max_abs_grad = max(np.max(np.abs(grad1)), _max0(np.abs(grad2)), _max0(np.abs(grad3)))   # :472-474
+    step0 = step / (max_abs_grad + tiny)                                           # :475
+    newU1 = U1 - U1 @ (step0 * grad1)                                              # :476
+    newU2 = U2 - U1 @ (step0 * grad2) - step0 * grad3.T * U2                       # :477
+    newu3 = u3 - step0 * grad3 * u3                                                # :478
+    return (np.concatenate([newL1, newL2], 0), newl3, np.concatenate([newU1, newU2], 1), newu3)   # :480
+
+
+def _max0(x):
+    return np.max(x) if x.size else x.dtype.type(0)
+
+
+def precond_grad_splu(L12, l3, U12, u3, grads):
+    """psgd.py:483-524."""
+    grad = [np.reshape(g, (-1, 1)) for g in grads]                                 # :495
+    lens = [g.shape[0] for g in grad]                                              # :496
+    grad = np.concatenate(grad, 0).astype(L12.dtype)                               # :497
+    r, L1, L2, U1, U2 = _splu_blocks(L12, U12)                                     # :499-503
+    Ug1 = U1 @ grad[:r] + U2 @ grad[r:]                                            # :506
+    Ug2 = u3 * grad[r:]                                                            # :507
+    Qg1 = L1 @ Ug1                                                                 # :509
+    Qg2 = L2 @ Ug1 + l3 * Ug2                                                      # :510
+    LtQg1 = L1.T @ Qg1 + L2.T @ Qg2                                                # :512
+    LtQg2 = l3 * Qg2                                                               # :513
+    pre_grad = np.concatenate([U1.T @ LtQg1, U2.T @ LtQg1 + u3 * LtQg2], 0)        # :515-516
+    pre_grads, idx = [], 0                                                         # :518-522
+    for i in range(len(grads)):
+        pre_grads.append(np.reshape(pre_grad[idx:idx + lens[i]], np.shape(grads[i])))
+        idx += lens[i]
+    return pre_grads
+
+
 # --------------------------------------------------------------------------- UVd
 def IpUVtmatvec(U, V, x):
     """psgd.py:540-544: (I + U V') x."""

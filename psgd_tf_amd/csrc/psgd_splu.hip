@@ -1,0 +1,483 @@
+// psgd_splu.hip -- C ABI (include/psgd_hip.h) of the sparse-LU preconditioner path
+// (update_precond_splu / precond_grad_splu, psgd.py:396-524): the r x r "corner" algebra in fp64
+// (L1, U1, four triangular solves, corner gradients, step sizes, the rho balance of :411-417),
+// partial reductions, and the host sequencing of the sweeps in splu_kernels.h.
+#include "splu_kernels.h"
+#include "psgd_hip.h"
+#include <math.h>
+
+namespace psgd {
+
+const SpluOps* splu_ops_group0(int r);
+const SpluOps* splu_ops_group1(int r);
+const SpluOps* splu_ops_group2(int r);
+const SpluOps* splu_ops_group3(int r);
+
+const SpluOps* splu_ops_for_rank(int r) {
+  if (r < 1 || r > PSGD_UVD_MAX_RANK) return nullptr;
+  switch ((r - 1) / 8) {
+    case 0: return splu_ops_group0(r);
+    case 1: return splu_ops_group1(r);
+    case 2: return splu_ops_group2(r);
+    default: return splu_ops_group3(r);
+  }
+}
+
+constexpr int MR = PSGD_UVD_MAX_RANK;
+
+// ------------------------------------------------------------ workspace ----
+// doubles: sums A [MR] | sums B [2 MR] | sums C [MR] | state vectors (7 x MR)
+enum { kSumA = 0, kSumB = MR, kSumC = 3 * MR, kStUg1 = 4 * MR, kStQg1 = 5 * MR, kStIUtx1 = 6 * MR, kStIQtx1 = 7 * MR,
+       kStLtQg1 = 8 * MR, kStPg1 = 9 * MR, kStILiQtx1 = 10 * MR, kDoubles = 11 * MR };
+constexpr int64_t kCoefFloats = 8 * MR;
+constexpr int64_t kMaxFloats = 8;
+
+struct SpluWs {
+  double* dbl; float* coef; float* maxbuf; float* part; float* pmax; float* qg2; float* iq2;
+};
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
+
+static int64_t splu_layout(int64_t N, int r, char* base, SpluWs* w) {
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { const int64_t o = off; off = align256(off + bytes); return o; };
+  const int64_t o_dbl = take(kDoubles * 8), o_coef = take(kCoefFloats * 4), o_max = take(kMaxFloats * 4);
+  const int64_t o_part = take((int64_t)kMaxGrid * 2 * MR * 4), o_pmax = take((int64_t)kMaxGrid * 4 * 4);
+  const int64_t n2 = N > r ? N - r : 0;
+  const int64_t o_q = take(n2 * 4), o_i = take(n2 * 4);
+  if (w) {
+    w->dbl = reinterpret_cast<double*>(base + o_dbl);
+    w->coef = reinterpret_cast<float*>(base + o_coef);
+    w->maxbuf = reinterpret_cast<float*>(base + o_max);
+    w->part = reinterpret_cast<float*>(base + o_part);
+    w->pmax = reinterpret_cast<float*>(base + o_pmax);
+    w->qg2 = reinterpret_cast<float*>(base + o_q);
+    w->iq2 = reinterpret_cast<float*>(base + o_i);
+  }
+  return off;
+}
+
+// --------------------------------------------------------- small kernels ---
+// sums[id] = sum_b part[id][b]: one wave per element, fp64 tree, fixed order (cf. k_reduce_sum_t in psgd_uvd.hip)
+__global__ __launch_bounds__(kThreads) void k_splu_reduce_sum(const float* __restrict__ part, int G, int L,
+                                                              double* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (id >= L) return;
+  const float* p = part + (long)id * G;
+  float x[kMaxGrid / 64];
+#pragma unroll
+  for (int u = 0; u < kMaxGrid / 64; ++u) {
+    const int b = lane + 64 * u;
+    x[u] = (b < G) ? p[b] : 0.0f;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < kMaxGrid / 64; ++u) s += (double)x[u];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) sums[id] = s;
+}
+
+// out[set] = max_b part[set*G + b]   (signed: the balance of psgd.py:411-412 takes max, not max|.|)
+__global__ __launch_bounds__(kThreads) void k_splu_reduce_max(const float* __restrict__ part, int G,
+                                                              float* __restrict__ out) {
+  __shared__ float red[kWavesPerBlock];
+  const float* p = part + (long)blockIdx.x * G;
+  float v = -INFINITY;
+  for (int b = threadIdx.x; b < G; b += kThreads) v = fmaxf(v, p[b]);
+  block_max_store(v, red, out + blockIdx.x);
+}
+
+// ----------------------------------------------------- r x r corner (fp64) -
+// One 256-thread block; L1 and U1 live in LDS as doubles.  Helpers are block-cooperative.
+struct Corner {
+  double L1[MR][MR + 1];
+  double U1[MR][MR + 1];
+  double v[8][MR];   // scratch vectors
+};
+
+__device__ __forceinline__ void corner_load(Corner& c, const float* L12, const float* U12, long ldu, int r) {
+  for (int e = threadIdx.x; e < r * r; e += blockDim.x) {
+    const int i = e / r, j = e % r;
+    c.L1[i][j] = (double)L12[(long)i * r + j];
+    c.U1[i][j] = (double)U12[(long)i * ldu + j];
+  }
+  __syncthreads();
+}
+
+// y = M x (trans = false) or M' x (trans = true); y must not alias x
+__device__ __forceinline__ void corner_matvec(const double (*M)[MR + 1], bool trans, const double* x, double* y, int r) {
+  const int i = threadIdx.x;
+  if (i < r) {
+    double s = 0.0;
+    for (int j = 0; j < r; ++j) s += (trans ? M[j][i] : M[i][j]) * x[j];
+    y[i] = s;
+  }
+  __syncthreads();
+}
+
+// in place: b <- T^-1 b with T = M (trans = false) or M' (trans = true); `lower` says which triangle of M is used
+// (tf.linalg.triangular_solve ignores the other one)
+__device__ __forceinline__ void corner_trisolve(const double (*M)[MR + 1], bool lower, bool trans, double* b, int r) {
+  const bool fwd = (lower != trans);
+  const int j = threadIdx.x;
+  for (int step = 0; step < r; ++step) {
+    const int p = fwd ? step : r - 1 - step;
+    if (j == p) b[p] = b[p] / M[p][p];
+    __syncthreads();
+    const bool rem = fwd ? (j > p && j < r) : (j < p);
+    if (rem) b[j] -= (trans ? M[p][j] : M[j][p]) * b[p];
+    __syncthreads();
+  }
+}
+
+// after sweep 1 of either path: Ug1 = U1 g1 + U2 g2 (:430/:506), Qg1 = L1 Ug1 (:433/:509);
+// update only: iUtx1 = U1^-T dx1 (:436).  coef <- [Ug1 | iUtx1]
+__global__ __launch_bounds__(kThreads) void k_splu_corner1(const float* L12, const float* U12, long ldu, int r,
+                                                           const float* g1, const float* x1 /* null for apply */,
+                                                           double* dbl, float* coef) {
+  __shared__ Corner c;
+  corner_load(c, L12, U12, ldu, r);
+  const int t = threadIdx.x;
+  if (t < r) c.v[0][t] = (double)g1[t];
+  __syncthreads();
+  corner_matvec(c.U1, false, c.v[0], c.v[1], r);
+  if (t < r) {
+    c.v[1][t] += dbl[kSumA + t];
+    dbl[kStUg1 + t] = c.v[1][t];
+    coef[t] = (float)c.v[1][t];
+  }
+  __syncthreads();
+  corner_matvec(c.L1, false, c.v[1], c.v[2], r);
+  if (t < r) dbl[kStQg1 + t] = c.v[2][t];
+  if (x1) {
+    if (t < r) c.v[3][t] = (double)x1[t];
+    __syncthreads();
+    corner_trisolve(c.U1, /*lower=*/false, /*trans=*/true, c.v[3], r);
+    if (t < r) {
+      dbl[kStIUtx1 + t] = c.v[3][t];
+      coef[r + t] = (float)c.v[3][t];
+    }
+  }
+}
+
+// apply, after sweep 2: LtQg1 = L1' Qg1 + L2' Qg2 (:512); out1 = U1' LtQg1 (:515).  coef <- LtQg1
+__global__ __launch_bounds__(kThreads) void k_splu_corner_apply2(const float* L12, const float* U12, long ldu, int r,
+                                                                 double* dbl, float* coef, float* out1) {
+  __shared__ Corner c;
+  corner_load(c, L12, U12, ldu, r);
+  const int t = threadIdx.x;
+  if (t < r) c.v[0][t] = dbl[kStQg1 + t];
+  __syncthreads();
+  corner_matvec(c.L1, true, c.v[0], c.v[1], r);
+  if (t < r) {
+    c.v[1][t] += dbl[kSumB + t];
+    coef[t] = (float)c.v[1][t];
+  }
+  __syncthreads();
+  corner_matvec(c.U1, true, c.v[1], c.v[2], r);
+  if (t < r) out1[t] = (float)c.v[2][t];
+}
+
+// update, after sweep 2: iQtx1 (:440), LtQg1 (:442), Pg1 (:445), iLiQtx1 (:448).
+// coef <- [LtQg1 | iLiQtx1 | Qg1 | iQtx1 | Pg1 | dx1]
+__global__ __launch_bounds__(kThreads) void k_splu_corner_upd2(const float* L12, const float* U12, long ldu, int r,
+                                                               const float* x1, double* dbl, float* coef) {
+  __shared__ Corner c;
+  corner_load(c, L12, U12, ldu, r);
+  const int t = threadIdx.x;
+  if (t < r) {
+    c.v[0][t] = dbl[kStIUtx1 + t] - dbl[kSumB + r + t];   // iUtx1 - L2' iQtx2
+    c.v[1][t] = dbl[kStQg1 + t];
+  }
+  __syncthreads();
+  corner_trisolve(c.L1, /*lower=*/true, /*trans=*/true, c.v[0], r);   // iQtx1
+  corner_matvec(c.L1, true, c.v[1], c.v[2], r);                      // L1' Qg1
+  if (t < r) c.v[2][t] += dbl[kSumB + t];                             // LtQg1
+  __syncthreads();
+  corner_matvec(c.U1, true, c.v[2], c.v[3], r);                      // Pg1
+  if (t < r) c.v[4][t] = c.v[0][t];
+  __syncthreads();
+  corner_trisolve(c.L1, /*lower=*/true, /*trans=*/false, c.v[4], r);  // iLiQtx1
+  if (t < r) {
+    dbl[kStIQtx1 + t] = c.v[0][t];
+    dbl[kStLtQg1 + t] = c.v[2][t];
+    dbl[kStPg1 + t] = c.v[3][t];
+    dbl[kStILiQtx1 + t] = c.v[4][t];
+    coef[t] = (float)c.v[2][t];
+    coef[r + t] = (float)c.v[4][t];
+    coef[2 * r + t] = (float)c.v[1][t];
+    coef[3 * r + t] = (float)c.v[0][t];
+    coef[4 * r + t] = (float)c.v[3][t];
+    coef[5 * r + t] = x1[t];
+  }
+}
+
+__device__ __forceinline__ double block_max_f64(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double m = red[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmax(m, red[k]);
+  return m;
+}
+
+// update, after sweep 3: iPx1 (:452); rho (:411-413); corner gradients, both step sizes, new L1 (:455-463) and new
+// U1 (:468-476) written out; coef <- [LtQg1 | iLiQtx1 | a | b | c | e | sL sU rho 1/rho] for sweep 4.
+__global__ __launch_bounds__(kThreads) void k_splu_corner_upd3(const float* L12, const float* U12, long ldu, int r,
+                                                               const float* x1, const float* g1, int has_tail,
+                                                               float step, float tiny, double* dbl,
+                                                               const float* maxbuf, float* coef, float* L12o,
+                                                               float* U12o) {
+  __shared__ Corner c;
+  __shared__ double red[kWavesPerBlock];
+  __shared__ double G[MR][MR + 1];
+  corner_load(c, L12, U12, ldu, r);
+  const int t = threadIdx.x;
+  // v0 = iPx1, v1 = Qg1, v2 = iQtx1, v3 = Pg1, v4 = dx1, v5 = dg1
+  if (t < r) {
+    c.v[0][t] = dbl[kStILiQtx1 + t] - dbl[kSumC + t];
+    c.v[1][t] = dbl[kStQg1 + t];
+    c.v[2][t] = dbl[kStIQtx1 + t];
+    c.v[3][t] = dbl[kStPg1 + t];
+    c.v[4][t] = (double)x1[t];
+    c.v[5][t] = (double)g1[t];
+  }
+  __syncthreads();
+  corner_trisolve(c.U1, /*lower=*/false, /*trans=*/false, c.v[0], r);
+
+  // dynamic-range balance (:411-417): signed maxima, as written
+  double dl = -INFINITY, du = -INFINITY;
+  if (t < r) { dl = c.L1[t][t]; du = c.U1[t][t]; }
+  double max_l = block_max_f64(dl, red);
+  double max_u = block_max_f64(du, red);
+  if (has_tail) { max_l = fmax(max_l, (double)maxbuf[2]); max_u = fmax(max_u, (double)maxbuf[3]); }
+  const float rho_f = sqrtf((float)max_l / (float)max_u);
+  const double rho = (double)rho_f, irho = 1.0 / rho;
+
+  // ---- L: grad1 = tril(Qg1 Qg1' - iQtx1 iQtx1'), step0, newL1 = L1s - step0 grad1 L1s, L1s = L1 / rho
+  double m = 0.0;
+  for (int e = t; e < r * r; e += blockDim.x) {
+    const int i = e / r, j = e % r;
+    const double g = (j <= i) ? c.v[1][i] * c.v[1][j] - c.v[2][i] * c.v[2][j] : 0.0;
+    G[i][j] = g;
+    m = fmax(m, fabs(g));
+  }
+  m = block_max_f64(m, red);
+  if (has_tail) m = fmax(m, (double)maxbuf[0]);
+  const double sL = (double)(step / ((float)m + tiny));
+  for (int e = t; e < r * r; e += blockDim.x) {
+    const int i = e / r, j = e % r;
+    double s = 0.0;
+    for (int k = 0; k < r; ++k) s += G[i][k] * (c.L1[k][j] * irho);
+    L12o[(long)i * r + j] = (float)(c.L1[i][j] * irho - sL * s);
+  }
+  if (t < r) {   // a = L1s' Qg1, b = L1s' iQtx1
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < r; ++k) {
+      a += c.L1[k][t] * irho * c.v[1][k];
+      b += c.L1[k][t] * irho * c.v[2][k];
+    }
+    coef[2 * r + t] = (float)a;
+    coef[3 * r + t] = (float)b;
+  }
+  __syncthreads();
+
+  // ---- U: grad1 = triu(Pg1 dg1' - dx1 iPx1'), step0, newU1 = U1s - U1s (step0 grad1), U1s = rho U1
+  m = 0.0;
+  for (int e = t; e < r * r; e += blockDim.x) {
+    const int i = e / r, j = e % r;
+    const double g = (j >= i) ? c.v[3][i] * c.v[5][j] - c.v[4][i] * c.v[0][j] : 0.0;
+    G[i][j] = g;
+    m = fmax(m, fabs(g));
+  }
+  m = block_max_f64(m, red);
+  if (has_tail) m = fmax(m, (double)maxbuf[1]);
+  const double sU = (double)(step / ((float)m + tiny));
+  for (int e = t; e < r * r; e += blockDim.x) {
+    const int i = e / r, j = e % r;
+    double s = 0.0;
+    for (int k = 0; k < r; ++k) s += (c.U1[i][k] * rho) * G[k][j];
+    U12o[(long)i * ldu + j] = (float)(c.U1[i][j] * rho - sU * s);
+  }
+  if (t < r) {   // c = U1s Pg1, e = U1s dx1
+    double cc = 0.0, ee = 0.0;
+    for (int k = 0; k < r; ++k) {
+      cc += c.U1[t][k] * rho * c.v[3][k];
+      ee += c.U1[t][k] * rho * c.v[4][k];
+    }
+    coef[4 * r + t] = (float)cc;
+    coef[5 * r + t] = (float)ee;
+    coef[t] = (float)dbl[kStLtQg1 + t];
+    coef[r + t] = (float)dbl[kStILiQtx1 + t];
+  }
+  if (t == 0) {
+    coef[6 * r + 0] = (float)sL;
+    coef[6 * r + 1] = (float)sU;
+    coef[6 * r + 2] = rho_f;
+    coef[6 * r + 3] = (float)irho;
+  }
+}
+
+// ------------------------------------------------------------- host side ---
+static int splu_grid(const SpluOps* ops, int r, int which, int64_t rows, bool tiled) {
+  static int occ_cache[PSGD_UVD_MAX_RANK + 1][6];
+  int occ = occ_cache[r][which];
+  if (occ == 0) {
+    occ = ops->occupancy(which);
+    if (occ <= 0) occ = 1;
+    occ_cache[r][which] = occ;
+  }
+  occ = policy_grid_blocks(occ);
+  int64_t grid;
+  if (tiled) {
+    const int64_t tiles = (rows + ops->tile_rows - 1) / ops->tile_rows;
+    grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  } else {
+    grid = (rows + kThreads - 1) / kThreads;
+  }
+  const int64_t cap = (int64_t)device_cus() * occ;
+  if (grid > cap) grid = cap;
+  if (grid > kMaxGrid) grid = kMaxGrid;
+  if (grid < 1) grid = 1;
+  return (int)grid;
+}
+
+struct SpluGeom {
+  int64_t n2, n2s;
+  int head;
+  long ldu;
+};
+
+static SpluGeom splu_geom(int64_t N, int r) {
+  SpluGeom g;
+  g.n2 = N - r;
+  int h = (r & 1) ? ((4 - (r & 3)) & 3) : 0;   // (r + h) * r floats = a multiple of 16 bytes
+  if (h > g.n2) h = (int)g.n2;
+  g.head = h;
+  g.n2s = g.n2 - h;
+  g.ldu = (long)N;
+  return g;
+}
+
+}  // namespace psgd
+
+using namespace psgd;
+
+#define PSGD_CHECK_LAUNCH(expr)                 \
+  do {                                          \
+    const int _e = (expr);                      \
+    if (_e != 0) return PSGD_ERR_LAUNCH;        \
+  } while (0)
+static inline int last_launch() { return (int)hipGetLastError(); }
+static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+static int splu_open(void* ws, int64_t ws_bytes, int64_t N, int r, SpluWs* w) {
+  if (r < 1 || r > PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  if (N < r) return PSGD_ERR_BAD_ARG;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return PSGD_ERR_WORKSPACE;
+  if (ws_bytes < splu_layout(N, r, nullptr, nullptr)) return PSGD_ERR_WORKSPACE;
+  splu_layout(N, r, static_cast<char*>(ws), w);
+  return PSGD_OK;
+}
+
+extern "C" {
+
+int64_t psgd_splu_workspace_bytes(int64_t N, int r) {
+  if (r < 1 || r > PSGD_UVD_MAX_RANK || N < r) return 0;
+  return splu_layout(N, r, nullptr, nullptr);
+}
+
+int psgd_splu_apply_f32(const float* L12, const float* l3, const float* U12, const float* u3, const float* g, float* out,
+                        int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L12 || !U12 || !g || !out) return PSGD_ERR_BAD_ARG;
+  SpluWs w;
+  const int rc = splu_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  const SpluGeom ge = splu_geom(N, r);
+  if (ge.n2 > 0 && (!l3 || !u3)) return PSGD_ERR_BAD_ARG;
+  if (misaligned16(L12)) return PSGD_ERR_ALIGN;
+  const SpluOps* ops = splu_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nt = policy_nt((int64_t)N * r * 8);
+  const float* U2 = U12 + r;
+  const float* L2s = L12 + (int64_t)(r + ge.head) * r;
+  float* out2 = out + r;
+  const int rblocks = (r + kWavesPerBlock - 1) / kWavesPerBlock;
+
+  int grid = splu_grid(ops, r, 0, ge.n2, false);
+  PSGD_CHECK_LAUNCH(ops->u2dot(nt, U2, ge.ldu, g + r, ge.n2, w.part, grid, st));
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumA);
+  hipLaunchKernelGGL(k_splu_corner1, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, g, (const float*)nullptr, w.dbl,
+                     w.coef);
+  PSGD_CHECK_LAUNCH(last_launch());
+  grid = splu_grid(ops, r, 1, ge.n2s, true);
+  PSGD_CHECK_LAUNCH(ops->apply_s2(nt, L2s, l3 + ge.head, u3 + ge.head, g + r + ge.head, out2 + ge.head, ge.n2s, ge.head,
+                                  w.coef, w.part, grid, st));
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumB);
+  hipLaunchKernelGGL(k_splu_corner_apply2, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, w.dbl, w.coef, out);
+  PSGD_CHECK_LAUNCH(last_launch());
+  if (ge.n2 > 0) {
+    grid = splu_grid(ops, r, 2, ge.n2, false);
+    PSGD_CHECK_LAUNCH(ops->apply_s3(nt, U2, ge.ldu, l3, u3, out2, ge.n2, w.coef, grid, st));
+  }
+  return PSGD_OK;
+}
+
+int psgd_splu_update_f32(const float* L12, const float* l3, const float* U12, const float* u3, const float* dx,
+                         const float* dg, float* L12_new, float* l3_new, float* U12_new, float* u3_new, int64_t N, int r,
+                         float step, float tiny, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L12 || !U12 || !dx || !dg || !L12_new || !U12_new) return PSGD_ERR_BAD_ARG;
+  SpluWs w;
+  const int rc = splu_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  const SpluGeom ge = splu_geom(N, r);
+  if (ge.n2 > 0 && (!l3 || !u3 || !l3_new || !u3_new)) return PSGD_ERR_BAD_ARG;
+  if (misaligned16(L12) || misaligned16(L12_new)) return PSGD_ERR_ALIGN;
+  const SpluOps* ops = splu_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nt = policy_nt((int64_t)N * r * 8);
+  const int h = ge.head;
+  const float* U2 = U12 + r;
+  const float* L2s = L12 + (int64_t)(r + h) * r;
+  const float *x2 = dx + r, *g2 = dg + r;
+  const int rblocks = (r + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int r2blocks = (2 * r + kWavesPerBlock - 1) / kWavesPerBlock;
+
+  int grid = splu_grid(ops, r, 0, ge.n2, false);
+  PSGD_CHECK_LAUNCH(ops->u2dot(nt, U2, ge.ldu, g2, ge.n2, w.part, grid, st));
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumA);
+  hipLaunchKernelGGL(k_splu_corner1, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dg, dx, w.dbl, w.coef);
+  PSGD_CHECK_LAUNCH(last_launch());
+
+  grid = splu_grid(ops, r, 3, ge.n2s, true);
+  PSGD_CHECK_LAUNCH(ops->upd_s2(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, x2 + h, g2 + h, w.qg2 + h, w.iq2 + h, ge.n2s, h,
+                                w.coef, w.part, grid, st));
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(r2blocks), dim3(kThreads), 0, st, w.part, grid, 2 * r, w.dbl + kSumB);
+  // sums B are stored [L2'Qg2 (r) | L2'iQtx2 (r)] contiguously: kSumB + r + t addresses the second half
+  hipLaunchKernelGGL(k_splu_corner_upd2, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dx, w.dbl, w.coef);
+  PSGD_CHECK_LAUNCH(last_launch());
+
+  grid = splu_grid(ops, r, 4, ge.n2s, true);
+  PSGD_CHECK_LAUNCH(ops->upd_s3(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, w.qg2 + h, w.iq2 + h, g2 + h, x2 + h, ge.n2s, h,
+                                w.coef, w.part, w.pmax, grid, st));
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumC);
+  hipLaunchKernelGGL(k_splu_reduce_max, dim3(4), dim3(kThreads), 0, st, w.pmax, grid, w.maxbuf);
+  hipLaunchKernelGGL(k_splu_corner_upd3, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dx, dg, ge.n2 > 0 ? 1 : 0,
+                     step, tiny, w.dbl, w.maxbuf, w.coef, L12_new, U12_new);
+  PSGD_CHECK_LAUNCH(last_launch());
+
+  if (ge.n2 > 0) {
+    grid = splu_grid(ops, r, 5, ge.n2s, true);
+    PSGD_CHECK_LAUNCH(ops->upd_s4(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, w.qg2 + h, w.iq2 + h, g2 + h, x2 + h,
+                                  L12_new + (int64_t)(r + h) * r, U12_new + r + h, l3_new + h, u3_new + h, ge.n2s, h,
+                                  w.coef, grid, st));
+  }
+  return PSGD_OK;
+}
+
+}  // extern "C"

@@ -128,6 +128,19 @@ static inline int use_nt(int64_t N, int r) {
   return (int64_t)N * r * 8 > (int64_t)192 * 1024 * 1024;
 }
 
+int policy_nt(int64_t stream_bytes) {
+  if (g_tune_staging == 1) return 0;
+  if (g_tune_staging == 2) return 1;
+  return stream_bytes > (int64_t)192 * 1024 * 1024;
+}
+int policy_grid_blocks(int occ) {
+  if (occ <= 0) occ = 1;
+  if (g_tune_blocks_per_cu > 0 && g_tune_blocks_per_cu < occ) occ = g_tune_blocks_per_cu;
+  if (g_tune_blocks_per_cu < 0) occ = -g_tune_blocks_per_cu;
+  return occ;
+}
+int device_cus() { return num_cus(); }
+
 static int sweep_grid(const UvdOps* ops, int r, int which, int64_t N, int hard_cap) {
   static int occ_cache[PSGD_UVD_MAX_RANK + 1][8];
   int occ = occ_cache[r][which];

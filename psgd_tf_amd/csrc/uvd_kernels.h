@@ -690,4 +690,9 @@ enum { kOccColreduce = 0, kOccApplyS2, kOccApplyS3, kOccRowdot, kOccGram, kOccUp
 
 const UvdOps* uvd_ops_for_rank(int r);   // nullptr when r is not instantiated
 
+// shared launch policy (psgd_uvd.hip; set through psgd_set_tuning)
+int policy_nt(int64_t stream_bytes);     // non-temporal streams when the operands exceed the Infinity Cache
+int policy_grid_blocks(int occupancy);   // blocks per CU after the tuning override
+int device_cus();
+
 }  // namespace psgd

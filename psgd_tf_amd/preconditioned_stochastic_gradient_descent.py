@@ -9,12 +9,14 @@ hello_psgd.py:5) carry over with torch tensors in place of tf tensors:
     precond_grad_dense(Q, grads) -> list                               psgd.py:45
     update_precond_kron(Ql, Qr, dX, dG, step=0.01) -> (Ql, Qr)         psgd.py:72
     precond_grad_kron(Ql, Qr, Grad) -> Tensor                          psgd.py:116
+    update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01) -> 4    psgd.py:396
+    precond_grad_splu(L12, l3, U12, u3, grads) -> list                 psgd.py:483
     IpUVtmatvec(U, V, x)                                               psgd.py:540
     update_precond_UVd_math_(U, V, d, v, h, step, tiny) -> None        psgd.py:554  (in place)
     precond_grad_UVd_math(U, V, d, g) -> Tensor                        psgd.py:619
     class UVd(...).step(closure)                                       psgd.py:630
 
-The UVd and Kron dense(x)dense arithmetic runs in hand-written HIP kernels behind the
+The UVd, sparse-LU and Kron arithmetic runs in hand-written HIP kernels behind the
 C ABI of include/psgd_hip.h (bound in _lib.py).  Tensors must be fp32, contiguous and
 resident on a ROCm device; anything else raises -- there is no CPU fallback for the
 hot path.  The dense preconditioner (psgd.py:26-63) is host-side plumbing on torch ops
@@ -135,6 +137,72 @@ def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
 def precond_grad_kron_batched(Qls, Qrs, Grads):
     """Extension: the list comprehension of mnist_with_lenet5.py:53 as one batched call."""
     return _kron.precond_grad_kron_batched(Qls, Qrs, Grads)
+
+
+# --------------------------------------------------------------------------- sparse LU
+def _splu_workspace(device, N, r):
+    key = ("splu", device.index if device.index is not None else torch.cuda.current_device(), int(N), int(r))
+    ws = _ws_cache.get(key)
+    if ws is None:
+        nbytes = int(_lib.load().psgd_splu_workspace_bytes(N, r))
+        if nbytes <= 0:
+            raise _lib.PsgdHipError("psgd_splu_workspace_bytes: unsupported shape N=%d r=%d (1 <= r <= 32, N >= r)" % (N, r))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _splu_shapes(name, L12, l3, U12, u3):
+    if L12.dim() != 2 or U12.dim() != 2 or U12.shape != (L12.shape[1], L12.shape[0]):
+        raise ValueError("%s: L12 must be [N, r] and U12 [r, N]" % name)
+    N, r = L12.shape
+    for c in (l3, u3):
+        if c.numel() != N - r or c.dim() > 2 or (c.dim() == 2 and c.shape[1] != 1):
+            raise ValueError("%s: l3 and u3 must be [N - r, 1] with N - r = %d" % (name, N - r))
+    return N, r
+
+
+def _tall(name, xs, N):
+    """psgd.py:426-427 / :495-497: the list as one tall column vector (device-side cat; plumbing)."""
+    flat = torch.cat([torch.reshape(x, [-1]) for x in xs], 0) if len(xs) != 1 else torch.reshape(xs[0], [-1])
+    if flat.numel() != N:
+        raise ValueError("%s: the list holds %d elements, the preconditioner is for %d" % (name, flat.numel(), N))
+    return flat.contiguous()
+
+
+def update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01):
+    """psgd.py:396-480: returns (L12_new, l3_new, U12_new, u3_new); inputs are not modified."""
+    dev = _require_hip("update_precond_splu", L12, l3, U12, u3)
+    N, r = _splu_shapes("update_precond_splu", L12, l3, U12, u3)
+    dx, dg = _tall("update_precond_splu", dxs, N), _tall("update_precond_splu", dgs, N)
+    _require_hip("update_precond_splu", dx, dg, L12)
+    out = [torch.empty_like(t) for t in (L12, l3, U12, u3)]
+    ws = _splu_workspace(dev, N, r)
+    rc = _lib.load().psgd_splu_update_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(), dx.data_ptr(),
+                                          dg.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                          out[3].data_ptr(), N, r, float(step), float(_tiny), ws.data_ptr(), ws.numel(),
+                                          _stream_ptr(dev))
+    _lib.check(rc, "psgd_splu_update_f32")
+    return tuple(out)
+
+
+def precond_grad_splu(L12, l3, U12, u3, grads):
+    """psgd.py:483-524: list of gradients in, list of preconditioned gradients (same shapes) out."""
+    dev = _require_hip("precond_grad_splu", L12, l3, U12, u3)
+    N, r = _splu_shapes("precond_grad_splu", L12, l3, U12, u3)
+    g = _tall("precond_grad_splu", grads, N)
+    _require_hip("precond_grad_splu", g, L12)
+    out = torch.empty_like(g)
+    ws = _splu_workspace(dev, N, r)
+    rc = _lib.load().psgd_splu_apply_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(), g.data_ptr(),
+                                         out.data_ptr(), N, r, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "psgd_splu_apply_f32")
+    pre_grads, idx = [], 0                                                       # :518-522
+    for x in grads:
+        n = x.numel()
+        pre_grads.append(torch.reshape(out[idx:idx + n], x.shape))
+        idx += n
+    return pre_grads
 
 
 # --------------------------------------------------------------------------- UVd math

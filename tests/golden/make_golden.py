@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import psgd_oracle as orc          # noqa: E402
 from tests.uvd_cases import make_uvd_problem   # noqa: E402
+from tests.splu_cases import make_splu_problem  # noqa: E402
 
 TINY32 = float(np.finfo(np.float32).tiny)
 
@@ -48,6 +49,15 @@ def kron_case(name, M, N, seed):
                         Ql_new=Ql_new, Qr_new=Qr_new, pre_grad=pre)
 
 
+def splu_case(name, N, r, seed, step, demo_init=False):
+    p = make_splu_problem(N, r, seed=seed, init_like_demo=demo_init)
+    q = {k: v.astype(np.float64) for k, v in p.items()}
+    pre = orc.precond_grad_splu(q["L12"], q["l3"], q["U12"], q["u3"], [q["g"]])[0]
+    new = orc.update_precond_splu(q["L12"], q["l3"], q["U12"], q["u3"], [q["dx"]], [q["dg"]], step)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **p, step=step, pre_grad=pre, L12_new=new[0], l3_new=new[1],
+                        U12_new=new[2], u3_new=new[3])
+
+
 if __name__ == "__main__":
     uvd_case("uvd_n1021_r10_updU", 1021, 10, 1, 2.0, 0.3, False, True)     # rnn_xor model size (KAT-IDX)
     uvd_case("uvd_n1021_r10_updV_bal", 1021, 10, 2, 2.0, 0.3, True, False)
@@ -57,4 +67,7 @@ if __name__ == "__main__":
     kron_case("kron_lenet_w5_85x10", 85, 10, 6)                             # mnist_with_lenet5.py:16
     kron_case("kron_wide_16x40", 16, 40, 7)                                 # M < N branch (psgd.py:189-190)
     kron_case("kron_1x1_3x3", 1, 3, 8)                                      # 1x1 dense factor (NMT demo :124)
+    splu_case("splu_n400_r10_demo_init", 400, 10, 9, 0.1, demo_init=True)   # demo_usage_of_all_preconditioners.py:45-51,61
+    splu_case("splu_n1021_r7", 1021, 7, 10, 0.01)                           # odd rank (alignment head path)
+    splu_case("splu_n2048_r20", 2048, 20, 11, 0.1)
     print(sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

@@ -14,10 +14,12 @@ from tests.uvd_cases import rel_err
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 UVD = sorted(glob.glob(os.path.join(HERE, "uvd_*.npz")))
 KRON = sorted(glob.glob(os.path.join(HERE, "kron_*.npz")))
+SPLU = sorted(glob.glob(os.path.join(HERE, "splu_*.npz")))
+SPLU_KEYS = ("L12", "l3", "U12", "u3")
 
 
 def test_fixtures_present():
-    assert len(UVD) == 4 and len(KRON) == 4
+    assert len(UVD) == 4 and len(KRON) == 4 and len(SPLU) == 3
 
 
 @pytest.mark.parametrize("path", UVD, ids=os.path.basename)
@@ -45,6 +47,33 @@ def test_oracle_reproduces_kron_golden(path):
     a, b = orc.update_precond_kron(f("Ql"), f("Qr"), f("dX"), f("dG"), float(z["step"]))
     assert rel_err(a, z["Ql_new"]) < 1e-13 and rel_err(b, z["Qr_new"]) < 1e-13
     assert rel_err(orc.precond_grad_kron(f("Ql"), f("Qr"), f("G")), z["pre_grad"]) < 1e-13
+
+
+@pytest.mark.parametrize("path", SPLU, ids=os.path.basename)
+def test_oracle_reproduces_splu_golden(path):
+    z = np.load(path)
+    f = lambda k: z[k].astype(np.float64)
+    new = orc.update_precond_splu(f("L12"), f("l3"), f("U12"), f("u3"), [f("dx")], [f("dg")], float(z["step"]))
+    for k, a in zip(SPLU_KEYS, new):
+        assert rel_err(a, z[k + "_new"]) < 1e-13, k
+    assert rel_err(orc.precond_grad_splu(f("L12"), f("l3"), f("U12"), f("u3"), [f("g")])[0], z["pre_grad"]) < 1e-13
+    new32 = orc.update_precond_splu(z["L12"], z["l3"], z["U12"], z["u3"], [z["dx"]], [z["dg"]], float(z["step"]))
+    for k, a in zip(SPLU_KEYS, new32):
+        assert rel_err(a, z[k + "_new"]) < 1e-5, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SPLU, ids=os.path.basename)
+def test_hip_matches_splu_golden(path, hip_lib):
+    import torch
+    import preconditioned_stochastic_gradient_descent as psgd
+    z = np.load(path)
+    c = lambda k: torch.from_numpy(z[k]).cuda()
+    new = psgd.update_precond_splu(c("L12"), c("l3"), c("U12"), c("u3"), [c("dx")], [c("dg")], float(z["step"]))
+    for k, a in zip(SPLU_KEYS, new):
+        assert rel_err(a.cpu().numpy(), z[k + "_new"]) < 1e-5, k
+    out = psgd.precond_grad_splu(c("L12"), c("l3"), c("U12"), c("u3"), [c("g")])[0]
+    assert rel_err(out.cpu().numpy(), z["pre_grad"]) < 1e-5
 
 
 @pytest.mark.gpu

@@ -300,3 +300,98 @@ def test_torch_port_matches_numpy_oracle():
     a = orc.update_precond_dense_dense(Ql, Qr, dX, dG, 0.01)
     b = ot.update_precond_dense_dense(*(torch.from_numpy(x) for x in (Ql, Qr, dX, dG)), 0.01, TINY64)
     assert rel_err(b[0].numpy(), a[0]) < 1e-12 and rel_err(b[1].numpy(), a[1]) < 1e-12
+
+
+# ----------------------------------------------------------------------------- sparse LU (psgd.py:396-524)
+from tests.splu_cases import make_splu_problem, splu_dense   # noqa: E402
+
+
+@pytest.mark.parametrize("N,r", [(40, 5), (23, 1), (12, 12), (64, 10)])
+def test_splu_apply_is_dense_QtQ(N, r):
+    """precond_grad_splu = (LU)'(LU) g with the N x N factors written out (psgd.py:399-403, :486-487)."""
+    p = {k: v.astype(np.float64) for k, v in make_splu_problem(N, r, seed=N + r).items()}
+    L, U = splu_dense(p["L12"], p["l3"], p["U12"], p["u3"])
+    Q = L @ U
+    want = Q.T @ (Q @ p["g"])
+    k = N // 3
+    got = orc.precond_grad_splu(p["L12"], p["l3"], p["U12"], p["u3"], [p["g"][:k].reshape(-1), p["g"][k:].reshape(1, -1)])
+    assert got[0].shape == (k,) and got[1].shape == (1, N - k)                 # shapes restored (:518-522)
+    assert rel_err(np.concatenate([x.reshape(-1) for x in got]), want[:, 0]) < 1e-13
+
+
+@pytest.mark.parametrize("N,r", [(40, 5), (23, 1), (64, 10)])
+def test_splu_update_is_masked_dense_update(N, r):
+    """The block formulas :455-478 are the dense rule  L <- L - mu tril_mask(Qg Qg' - Q^-T x (Q^-T x)') L,
+    U <- U - mu U triu_mask(Pg g' - x (P^-1 x)'), restricted to the sparsity pattern, with the dynamic-range
+    balance of :411-417 applied first.  Independent route: full N x N solves."""
+    p = {k: v.astype(np.float64) for k, v in make_splu_problem(N, r, seed=3 * N + r).items()}
+    step = 0.1
+    new = orc.update_precond_splu(p["L12"], p["l3"], p["U12"], p["u3"], [p["dx"]], [p["dg"]], step)
+    L, U = splu_dense(p["L12"], p["l3"], p["U12"], p["u3"])
+    rho = np.sqrt(np.max(np.diag(L)) / np.max(np.diag(U)))
+    L, U = L / rho, U * rho
+    Q = L @ U
+    Qg, iQtx = Q @ p["dg"], np.linalg.solve(Q.T, p["dx"])
+    mask = np.tril(np.ones((N, N), bool))
+    mask[:, r:] = False
+    mask |= np.eye(N, dtype=bool)
+    GL = (Qg @ Qg.T - iQtx @ iQtx.T) * mask
+    Lw = L - step / np.max(np.abs(GL)) * GL @ L
+    Pg, iPx = Q.T @ Qg, np.linalg.solve(Q, iQtx)
+    GU = (Pg @ p["dg"].T - p["dx"] @ iPx.T) * mask.T
+    Uw = U - step / np.max(np.abs(GU)) * U @ GU
+    Ln, Un = splu_dense(*new)
+    assert rel_err(Ln, Lw) < 1e-12 and rel_err(Un, Uw) < 1e-12
+    assert np.array_equal(np.triu(new[0][:r], 1), np.zeros((r, r))) and np.array_equal(np.tril(new[2][:, :r], -1), np.zeros((r, r)))
+    # pure: inputs untouched
+    q = make_splu_problem(N, r, seed=3 * N + r)
+    assert all(np.array_equal(p[k], q[k].astype(np.float64)) for k in ("L12", "l3", "U12", "u3"))
+
+
+def test_splu_gradient_vanishes_at_fixed_point():
+    """With dg = P^-1 dx both whitening residuals vanish: Q dg = Q^-T dx and P dg = dx, so the raw gradients
+    of :455-458 and :468-471 are rounding noise (they are then normalised to max = step, like UVd's)."""
+    N, r = 30, 4
+    p = {k: v.astype(np.float64) for k, v in make_splu_problem(N, r, seed=5).items()}
+    L, U = splu_dense(p["L12"], p["l3"], p["U12"], p["u3"])
+    Q = L @ U
+    dg = np.linalg.solve(Q.T @ Q, p["dx"])
+    assert rel_err(Q @ dg, np.linalg.solve(Q.T, p["dx"])) < 1e-12
+    # a tiny step from the fixed point keeps the state to O(step) even though the noise is normalised up
+    new = orc.update_precond_splu(p["L12"], p["l3"], p["U12"], p["u3"], [p["dx"]], [dg], 1e-6)
+    rho = np.sqrt(max(np.max(np.diag(p["L12"][:r])), np.max(p["l3"])) / max(np.max(np.diag(p["U12"][:, :r])), np.max(p["u3"])))
+    assert rel_err(new[0], p["L12"] / rho) < 1e-5 and rel_err(new[2], p["U12"] * rho) < 1e-5
+
+
+def test_splu_demo_initial_state_first_step():
+    """KAT from demo_usage_of_all_preconditioners.py:47-51: L = U = 0.1 I.  Then Q = 0.01 I, rho = 1,
+    Qg = 0.01 dg, Q^-T dx = 100 dx: every formula collapses to elementwise arithmetic."""
+    N, r, step = 12, 3, 0.1
+    p = {k: v.astype(np.float64) for k, v in make_splu_problem(N, r, seed=1, init_like_demo=True).items()}
+    dx, dg = p["dx"], p["dg"]
+    c = float(np.float32(0.1))                                                  # the fixtures are fp32 values
+    nL12, nl3, nU12, nu3 = orc.update_precond_splu(p["L12"], p["l3"], p["U12"], p["u3"], [dx], [dg], step)
+    a, b = c * c * dg, dx / (c * c)
+    GL1, GL2, GL3 = np.tril(a[:r] @ a[:r].T - b[:r] @ b[:r].T), a[r:] @ a[:r].T - b[r:] @ b[:r].T, a[r:] ** 2 - b[r:] ** 2
+    mu = step / max(np.abs(GL1).max(), np.abs(GL2).max(), np.abs(GL3).max())
+    assert rel_err(nL12, c * np.concatenate([np.eye(r) - mu * GL1, -mu * GL2], 0)) < 1e-12
+    assert rel_err(nl3, c * (1 - mu * GL3)) < 1e-12
+    Pg, iPx = c ** 4 * dg, dx / c ** 4
+    GU1, GU2, GU3 = np.triu(Pg[:r] @ dg[:r].T - dx[:r] @ iPx[:r].T), Pg[:r] @ dg[r:].T - dx[:r] @ iPx[r:].T, Pg[r:] * dg[r:] - dx[r:] * iPx[r:]
+    mu = step / max(np.abs(GU1).max(), np.abs(GU2).max(), np.abs(GU3).max())
+    assert rel_err(nU12, c * np.concatenate([np.eye(r) - mu * GU1, -mu * GU2], 1)) < 1e-12
+    assert rel_err(nu3, c * (1 - mu * GU3)) < 1e-12
+    out = orc.precond_grad_splu(p["L12"], p["l3"], p["U12"], p["u3"], [p["g"]])
+    assert rel_err(out[0], c ** 4 * p["g"]) < 1e-12
+
+
+def test_splu_fp32_oracle_tracks_fp64():
+    p = make_splu_problem(4096, 10, seed=2)
+    q = {k: v.astype(np.float64) for k, v in p.items()}
+    a = orc.update_precond_splu(p["L12"], p["l3"], p["U12"], p["u3"], [p["dx"]], [p["dg"]], 0.01)
+    b = orc.update_precond_splu(q["L12"], q["l3"], q["U12"], q["u3"], [q["dx"]], [q["dg"]], 0.01)
+    assert all(x.dtype == np.float32 for x in a)
+    for x, y in zip(a, b):
+        assert rel_err(x, y) < 1e-5
+    assert rel_err(orc.precond_grad_splu(p["L12"], p["l3"], p["U12"], p["u3"], [p["g"]])[0],
+                   orc.precond_grad_splu(q["L12"], q["l3"], q["U12"], q["u3"], [q["g"]])[0]) < 1e-5
