@@ -29,11 +29,11 @@ constexpr int MR = PSGD_UVD_MAX_RANK;
 // doubles: sums A [MR] | sums B [2 MR] | sums C [MR] | state vectors (7 x MR)
 enum { kSumA = 0, kSumB = MR, kSumC = 3 * MR, kStUg1 = 4 * MR, kStQg1 = 5 * MR, kStIUtx1 = 6 * MR, kStIQtx1 = 7 * MR,
        kStLtQg1 = 8 * MR, kStPg1 = 9 * MR, kStILiQtx1 = 10 * MR, kDoubles = 11 * MR };
-constexpr int64_t kCoefFloats = 8 * MR;
+constexpr int64_t kCoefFloats = 9 * MR;
 constexpr int64_t kMaxFloats = 8;
 
 struct SpluWs {
-  double* dbl; float* coef; float* maxbuf; float* part; float* pmax; float* qg2; float* iq2;
+  double* dbl; float* coef; float* maxbuf; float* part; float* pmax;
 };
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
@@ -43,16 +43,13 @@ static int64_t splu_layout(int64_t N, int r, char* base, SpluWs* w) {
   auto take = [&](int64_t bytes) { const int64_t o = off; off = align256(off + bytes); return o; };
   const int64_t o_dbl = take(kDoubles * 8), o_coef = take(kCoefFloats * 4), o_max = take(kMaxFloats * 4);
   const int64_t o_part = take((int64_t)kMaxGrid * 2 * MR * 4), o_pmax = take((int64_t)kMaxGrid * 4 * 4);
-  const int64_t n2 = N > r ? N - r : 0;
-  const int64_t o_q = take(n2 * 4), o_i = take(n2 * 4);
+  (void)N; (void)r;
   if (w) {
     w->dbl = reinterpret_cast<double*>(base + o_dbl);
     w->coef = reinterpret_cast<float*>(base + o_coef);
     w->maxbuf = reinterpret_cast<float*>(base + o_max);
     w->part = reinterpret_cast<float*>(base + o_part);
     w->pmax = reinterpret_cast<float*>(base + o_pmax);
-    w->qg2 = reinterpret_cast<float*>(base + o_q);
-    w->iq2 = reinterpret_cast<float*>(base + o_i);
   }
   return off;
 }
@@ -181,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void k_splu_corner_apply2(const float* L1
 }
 
 // update, after sweep 2: iQtx1 (:440), LtQg1 (:442), Pg1 (:445), iLiQtx1 (:448).
-// coef <- [LtQg1 | iLiQtx1 | Qg1 | iQtx1 | Pg1 | dx1]
+// coef <- [LtQg1 | iLiQtx1 | Qg1 | iQtx1 | Pg1 | dx1 | Ug1 | iUtx1]
 __global__ __launch_bounds__(kThreads) void k_splu_corner_upd2(const float* L12, const float* U12, long ldu, int r,
                                                                const float* x1, double* dbl, float* coef) {
   __shared__ Corner c;
@@ -211,6 +208,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_corner_upd2(const float* L12,
     coef[3 * r + t] = (float)c.v[0][t];
     coef[4 * r + t] = (float)c.v[3][t];
     coef[5 * r + t] = x1[t];
+    coef[6 * r + t] = (float)dbl[kStUg1 + t];
+    coef[7 * r + t] = (float)dbl[kStIUtx1 + t];
   }
 }
 
@@ -225,7 +224,7 @@ __device__ __forceinline__ double block_max_f64(double v, double* red) {
 }
 
 // update, after sweep 3: iPx1 (:452); rho (:411-413); corner gradients, both step sizes, new L1 (:455-463) and new
-// U1 (:468-476) written out; coef <- [LtQg1 | iLiQtx1 | a | b | c | e | sL sU rho 1/rho] for sweep 4.
+// U1 (:468-476) written out; coef <- [LtQg1 | iLiQtx1 | a | b | c | e | Ug1 | iUtx1 | sL sU rho 1/rho] for sweep 4.
 __global__ __launch_bounds__(kThreads) void k_splu_corner_upd3(const float* L12, const float* U12, long ldu, int r,
                                                                const float* x1, const float* g1, int has_tail,
                                                                float step, float tiny, double* dbl,
@@ -314,14 +313,16 @@ __global__ __launch_bounds__(kThreads) void k_splu_corner_upd3(const float* L12,
     coef[r + t] = (float)dbl[kStILiQtx1 + t];
   }
   if (t == 0) {
-    coef[6 * r + 0] = (float)sL;
-    coef[6 * r + 1] = (float)sU;
-    coef[6 * r + 2] = rho_f;
-    coef[6 * r + 3] = (float)irho;
+    coef[8 * r + 0] = (float)sL;
+    coef[8 * r + 1] = (float)sU;
+    coef[8 * r + 2] = rho_f;
+    coef[8 * r + 3] = (float)irho;
   }
 }
 
 // ------------------------------------------------------------- host side ---
+static inline int col_tile_rows(int nvec) { return 64 * ((nvec <= 12) ? 4 : ((nvec <= 24) ? 2 : 1)); }
+
 static int splu_grid(const SpluOps* ops, int r, int which, int64_t rows, bool tiled) {
   static int occ_cache[PSGD_UVD_MAX_RANK + 1][6];
   int occ = occ_cache[r][which];
@@ -335,8 +336,10 @@ static int splu_grid(const SpluOps* ops, int r, int which, int64_t rows, bool ti
   if (tiled) {
     const int64_t tiles = (rows + ops->tile_rows - 1) / ops->tile_rows;
     grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  } else {
-    grid = (rows + kThreads - 1) / kThreads;
+  } else {   // column sweeps (ColCfg in splu_kernels.h): which 0 = u2dot (r + 1 vectors), 2 = apply_s3 (r + 3)
+    const int tr = col_tile_rows(which == 0 ? r + 1 : r + 3);
+    const int64_t tiles = (rows + tr - 1) / tr;
+    grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
   }
   const int64_t cap = (int64_t)device_cus() * occ;
   if (grid > cap) grid = cap;
@@ -455,16 +458,16 @@ int psgd_splu_update_f32(const float* L12, const float* l3, const float* U12, co
   PSGD_CHECK_LAUNCH(last_launch());
 
   grid = splu_grid(ops, r, 3, ge.n2s, true);
-  PSGD_CHECK_LAUNCH(ops->upd_s2(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, x2 + h, g2 + h, w.qg2 + h, w.iq2 + h, ge.n2s, h,
-                                w.coef, w.part, grid, st));
+  PSGD_CHECK_LAUNCH(ops->upd_s2(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, x2 + h, g2 + h, ge.n2s, h, w.coef, w.part, grid,
+                                st));
   hipLaunchKernelGGL(k_splu_reduce_sum, dim3(r2blocks), dim3(kThreads), 0, st, w.part, grid, 2 * r, w.dbl + kSumB);
   // sums B are stored [L2'Qg2 (r) | L2'iQtx2 (r)] contiguously: kSumB + r + t addresses the second half
   hipLaunchKernelGGL(k_splu_corner_upd2, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dx, w.dbl, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
 
   grid = splu_grid(ops, r, 4, ge.n2s, true);
-  PSGD_CHECK_LAUNCH(ops->upd_s3(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, w.qg2 + h, w.iq2 + h, g2 + h, x2 + h, ge.n2s, h,
-                                w.coef, w.part, w.pmax, grid, st));
+  PSGD_CHECK_LAUNCH(ops->upd_s3(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, g2 + h, x2 + h, ge.n2s, h, w.coef, w.part, w.pmax,
+                                grid, st));
   hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumC);
   hipLaunchKernelGGL(k_splu_reduce_max, dim3(4), dim3(kThreads), 0, st, w.pmax, grid, w.maxbuf);
   hipLaunchKernelGGL(k_splu_corner_upd3, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dx, dg, ge.n2 > 0 ? 1 : 0,
@@ -473,7 +476,7 @@ int psgd_splu_update_f32(const float* L12, const float* l3, const float* U12, co
 
   if (ge.n2 > 0) {
     grid = splu_grid(ops, r, 5, ge.n2s, true);
-    PSGD_CHECK_LAUNCH(ops->upd_s4(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, w.qg2 + h, w.iq2 + h, g2 + h, x2 + h,
+    PSGD_CHECK_LAUNCH(ops->upd_s4(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, g2 + h, x2 + h,
                                   L12_new + (int64_t)(r + h) * r, U12_new + r + h, l3_new + h, u3_new + h, ge.n2s, h,
                                   w.coef, grid, st));
   }

@@ -34,8 +34,8 @@ template <int R>
 struct SpluLaunch {
   static constexpr int kLdsA2 = splu_lds_bytes<R, 3, R>();
   static constexpr int kLdsU2 = splu_lds_bytes<R, R + 4, 2 * R>();
-  static constexpr int kLdsU3 = splu_lds_bytes<R, R + 6, R>();
-  static constexpr int kLdsU4 = splu_lds_bytes<R, R + 6, 0>();
+  static constexpr int kLdsU3 = splu_lds_bytes<R, R + 4, R>();
+  static constexpr int kLdsU4 = splu_lds_bytes<R, R + 4, 0>();
 
   static int u2dot(int nt, const float* U2, long ldu, const float* x, long n2, float* part, int grid, hipStream_t st) {
     SPLU_LAUNCH((k_splu_u2dot<R, true>), (k_splu_u2dot<R, false>), 0, U2, ldu, x, n2, part);
@@ -50,22 +50,22 @@ struct SpluLaunch {
     SPLU_LAUNCH((k_splu_apply_s3<R, true>), (k_splu_apply_s3<R, false>), 0, U2, ldu, l3, u3, out2, n2, coef);
   }
   static int upd_s2(int nt, const float* L2s, const float* U2s, long ldu, const float* l3, const float* u3,
-                    const float* x2, const float* g2, float* qg2, float* iq2, long n2s, int head, const float* coef,
-                    float* part, int grid, hipStream_t st) {
-    SPLU_LAUNCH((k_splu_upd_s2<R, true>), (k_splu_upd_s2<R, false>), kLdsU2, L2s, U2s, ldu, l3, u3, x2, g2, qg2, iq2,
-                n2s, head, coef, part);
+                    const float* x2, const float* g2, long n2s, int head, const float* coef, float* part, int grid,
+                    hipStream_t st) {
+    SPLU_LAUNCH((k_splu_upd_s2<R, true>), (k_splu_upd_s2<R, false>), kLdsU2, L2s, U2s, ldu, l3, u3, x2, g2, n2s, head,
+                coef, part);
   }
   static int upd_s3(int nt, const float* L2s, const float* U2s, long ldu, const float* l3, const float* u3,
-                    const float* qg2, const float* iq2, const float* g2, const float* x2, long n2s, int head,
-                    const float* coef, float* part, float* pmax, int grid, hipStream_t st) {
-    SPLU_LAUNCH((k_splu_upd_s3<R, true>), (k_splu_upd_s3<R, false>), kLdsU3, L2s, U2s, ldu, l3, u3, qg2, iq2, g2, x2,
-                n2s, head, coef, part, pmax);
+                    const float* g2, const float* x2, long n2s, int head, const float* coef, float* part, float* pmax,
+                    int grid, hipStream_t st) {
+    SPLU_LAUNCH((k_splu_upd_s3<R, true>), (k_splu_upd_s3<R, false>), kLdsU3, L2s, U2s, ldu, l3, u3, g2, x2, n2s, head,
+                coef, part, pmax);
   }
   static int upd_s4(int nt, const float* L2s, const float* U2s, long ldu, const float* l3, const float* u3,
-                    const float* qg2, const float* iq2, const float* g2, const float* x2, float* L2o, float* U2o,
-                    float* l3o, float* u3o, long n2s, int head, const float* coef, int grid, hipStream_t st) {
-    SPLU_LAUNCH((k_splu_upd_s4<R, true>), (k_splu_upd_s4<R, false>), kLdsU4, L2s, U2s, ldu, l3, u3, qg2, iq2, g2, x2,
-                L2o, U2o, l3o, u3o, n2s, head, coef);
+                    const float* g2, const float* x2, float* L2o, float* U2o, float* l3o, float* u3o, long n2s,
+                    int head, const float* coef, int grid, hipStream_t st) {
+    SPLU_LAUNCH((k_splu_upd_s4<R, true>), (k_splu_upd_s4<R, false>), kLdsU4, L2s, U2s, ldu, l3, u3, g2, x2, L2o, U2o,
+                l3o, u3o, n2s, head, coef);
   }
   static int occupancy(int which) {
     const void* f = nullptr;

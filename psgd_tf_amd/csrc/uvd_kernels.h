@@ -32,6 +32,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWave * kWavesPerBlock;
 constexpr int kMaxGrid = 2048;      // sweeps never launch more blocks than this
 constexpr int kGramMaxGrid = 1024;  // Gram sweep (fp64 partials are large)
+#ifndef PSGD_TILE_CHUNK
+#define PSGD_TILE_CHUNK 1
+#endif
+constexpr int kTileChunk = PSGD_TILE_CHUNK;   // consecutive tiles a wave takes before striding (sweep_rows)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -192,13 +196,17 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
   const long nfull = N / C::kTileRows;
 
   Prefetch<R, NMAT, NVEC> pf;
-  long tile = gw;
+  // tile order of one wave: chunks of kTileChunk consecutive tiles, chunks dealt round-robin over the waves
+  constexpr int CH = kTileChunk;
+  long it = 0;
+  auto tile_at = [&](long j) { return (CH == 1) ? gw + j * nw : ((j / CH) * nw + gw) * CH + (j % CH); };
+  long tile = tile_at(0);
   // The prefetch is unconditional (the last iteration re-reads its own tile) so that the
   // buffers stay in registers and the loads stay in flight across the compute phase.
   if (tile < nfull) issue_tile<R, NMAT, NVEC, NT>(pf, mats, vecs, tile, lane);
   while (tile < nfull) {
     commit_tile<R, NMAT, NVEC>(pf, lds, lane);
-    const long next = tile + nw;
+    const long next = tile_at(++it);
     issue_tile<R, NMAT, NVEC, NT>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -226,7 +234,7 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
 
   // tail tile (N % kTileRows rows): guarded scalar staging, owned by one wave
   const long tail_rows = N - nfull * C::kTileRows;
-  if (tail_rows > 0 && (nfull % nw) == gw) {
+  if (tail_rows > 0 && ((nfull / CH) % nw) == gw) {
     const long row0 = nfull * C::kTileRows;
     const long tail_floats = tail_rows * R;
 #pragma unroll
