@@ -126,6 +126,42 @@ def kron_bench(dev, psgd, iters=20):
     }
 
 
+def splu_bench(dev, psgd, N=50_000_000, r=10, iters=10):
+    """Secondary leg: sparse-LU preconditioner update + apply (psgd.py:396-524) at the rank the
+    reference's demo uses (demo_usage_of_all_preconditioners.py:45).  Bytes are what the sweeps move."""
+    g = torch.Generator(device=dev).manual_seed(3)
+    n2, sc = N - r, 0.3 / r ** 0.5
+    L12 = torch.randn(N, r, device=dev, generator=g) * (sc * 3 * (r / N) ** 0.5)
+    U12 = torch.randn(r, N, device=dev, generator=g) * (sc * 3 * (r / N) ** 0.5)
+    L12[:r] = torch.tril(torch.randn(r, r, device=dev, generator=g) * sc, -1) + torch.eye(r, device=dev)
+    U12[:, :r] = torch.triu(torch.randn(r, r, device=dev, generator=g) * sc, 1) + torch.eye(r, device=dev)
+    l3 = torch.exp(torch.empty(n2, 1, device=dev).uniform_(-0.5, 0.5, generator=g))
+    u3 = torch.exp(torch.empty(n2, 1, device=dev).uniform_(-0.5, 0.5, generator=g)) * 0.7
+    dx = torch.randn(N, 1, device=dev, generator=g)
+    dg = dx * torch.exp(torch.empty(N, 1, device=dev).uniform_(-2.3, 2.3, generator=g))
+    gr = torch.randn(N, 1, device=dev, generator=g)
+    st = [L12, l3, U12, u3]
+
+    def step():
+        st[:] = psgd.update_precond_splu(*st, [dx], [dg], 0.01)
+        return psgd.precond_grad_splu(*st, [gr])
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    bytes_row = 4 * (9 * r + 15) + 4 * (3 * r + 9)     # update: 4 sweeps; apply: 3 sweeps
+    return {"metric": "splu_update_apply_params_per_sec", "value": N / ms * 1e3, "unit": "params/s", "N": N, "r": r,
+            "ms_per_step": ms, "bytes_per_param": bytes_row, "achieved_GBs": bytes_row * N / ms / 1e6,
+            "frac_of_hbm_peak": bytes_row * N / ms / 1e6 / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +296,7 @@ def main():
             torch.cuda.empty_cache()
             if not args.no_kron:
                 res["kron"] = kron_bench(dev, psgd)
+                res["splu"] = splu_bench(dev, psgd)
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(r, args.cpu_sample_rows, args.cpu_budget_s)
         print(json.dumps(res), flush=True)

@@ -37,7 +37,7 @@ def main():
     gr = torch.randn(N, 1, device=dev, generator=g)
     calls = {
         "apply": (lambda: psgd.precond_grad_splu(L12, l3, U12, u3, [gr]), 4 * (3 * r + 9)),
-        "update": (lambda: psgd.update_precond_splu(L12, l3, U12, u3, [dx], [dg], 0.01), 4 * (9 * r + 21)),
+        "update": (lambda: psgd.update_precond_splu(L12, l3, U12, u3, [dx], [dg], 0.01), 4 * (9 * r + 15)),
     }
     for name, (fn, bpr) in calls.items():
         for _ in range(2):
