@@ -39,6 +39,7 @@ struct HGemmArgs {
   void* C; long ldc;
   int c_bf16, c_trans;              // element type and orientation of the stored result
   int M, N, K, kmode;
+  int sym;                          // C is symmetric (A == B): tiles below the diagonal are skipped, the others stored twice
 };
 
 __device__ __forceinline__ uint16_t f2bf(float x) {
@@ -56,7 +57,20 @@ __device__ __forceinline__ void hgemm_tile_coords(const HGemmArgs& g, int& m0, i
   const int tiles_n = (g.N + TN - 1) / TN, tiles_m = (g.M + TM - 1) / TM;
   const int nt = tiles_m * tiles_n;
   int trow, tcol;
-  if (tiles_m % 8 == 0 && tiles_n % 8 == 0 && nt % 512 == 0) {
+  if (g.sym) {
+    // symmetric product (M == N, kmode = KHI_M | KHI_N): only the T (T + 1) / 2 tiles on or above the diagonal are
+    // launched.  L = those tiles sorted by K length (row index) descending.  The first 256 blocks (one per CU) take
+    // L[0..255]; the second 256 take the NEXT 256 entries in ascending order, so that the CU holding the longest
+    // tile gets the shortest companion (two blocks are resident per CU); the rest follow in order.
+    const int T = tiles_m, ntu = T * (T + 1) / 2, W = 256;
+    int idx = blockIdx.x;
+    if (idx >= W && idx < 2 * W) { const int hi = min(ntu, 2 * W); idx = hi - 1 - (idx - W); }
+    int sdiag = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+    while (sdiag * (sdiag + 1) / 2 > idx) --sdiag;
+    while ((sdiag + 1) * (sdiag + 2) / 2 <= idx) ++sdiag;
+    trow = T - 1 - sdiag;
+    tcol = trow + idx - sdiag * (sdiag + 1) / 2;
+  } else if (tiles_m % 8 == 0 && tiles_n % 8 == 0 && nt % 512 == 0) {
     const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;      // j-th block of this XCD
     const int pm = tiles_m / 8, pn = tiles_n / 8;            // patch grid
     const int npatch = pm * pn, ppx = npatch / 8;            // patches per XCD
@@ -189,6 +203,21 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
             if (g.c_bf16) static_cast<uint16_t*>(g.C)[(long)(row0 + e) * g.ldc + col] = f2bf(acc[i][j][e]);
             else static_cast<float*>(g.C)[(long)(row0 + e) * g.ldc + col] = acc[i][j][e];
           }
+        if (g.sym && n0 > m0) {       // mirror: C[col][row0 .. row0+3] (M == N, multiples of 8 by contract)
+          if (g.c_bf16) {
+            uint16_t* p = static_cast<uint16_t*>(g.C) + (long)col * g.ldc + row0;
+            if (row0 + 3 < g.M) {
+              *reinterpret_cast<ushort4*>(p) = make_ushort4(f2bf(acc[i][j][0]), f2bf(acc[i][j][1]), f2bf(acc[i][j][2]), f2bf(acc[i][j][3]));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) if (row0 + e < g.M) p[e] = f2bf(acc[i][j][e]);
+            }
+          } else {
+            float* p = static_cast<float*>(g.C) + (long)col * g.ldc + row0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (row0 + e < g.M) p[e] = acc[i][j][e];
+          }
+        }
       }
     }
 }
@@ -296,6 +325,212 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt_dma(HGemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4, wave tile 128 x 64), 128 KiB of LDS, for dense interior problems
+// (M, N multiples of 256, K ranges multiples of 64).  A 128 x 128 tile needs 34 TB/s of L2->CU traffic to keep
+// the matrix cores busy and tops out at ~0.75 PFLOP/s; this tile halves the traffic per flop and hides the rest
+// behind a finer-grained schedule (after the "8-phase" structure of cdna_hip_programming.md section 5):
+//
+//   * a K tile is staged as four HALF-TILES of 128 rows x 64 k (16 KiB): B-h0, A-h0, B-h1, A-h1, where A-h{q}
+//     holds the q-th 64-row half of BOTH wave rows and B-h{q} the q-th 32-column half of all four wave
+//     columns.  Every half-tile is therefore consumed (copied into fragment registers) in exactly one phase;
+//   * a K tile is computed in four phases, one 64 x 32 quadrant of the wave tile each (16 MFMAs):
+//       ph0 (m0,n0): reads B-h0, A-h0   ph1 (m0,n1): reads B-h1   ph2 (m1,n1): reads A-h1   ph3 (m1,n0): no reads
+//   * the LDS holds 8 half-tile slots (two K tiles).  Phase q issues the LDS-DMA of half-tile q + 7, i.e. the
+//     slot a half-tile occupied is refilled one (B-h0) or two phases after it was read, and the loads run
+//     a full K tile plus three half-tiles ahead of the math.  One counted wait per K tile (vmcnt(6) in ph3)
+//     retires the whole next K tile while the three youngest half-tiles stay in flight;
+//   * the two wave rows run staggered by one barrier: while one group issues its fragment reads and DMA, the
+//     other runs its 16 MFMAs, so the LDS pipe and the matrix cores of a SIMD (one wave of each group) overlap.
+//
+// Hazards (# = global barrier count; a wave of group g passes #(2q+1+g) and #(2q+2+g) around its MFMAs of phase q):
+//   RAW  DMA -> ds_read: the wait sits in ph3 before the first barrier of that phase, the reads of the next K
+//        tile start in the following phase, i.e. after every wave has waited and passed a barrier;
+//   WAR  ds_read -> DMA: B-h0 is refilled one phase after it is read, by a wave that may be one barrier ahead:
+//        the reader retires its four B reads (issued first) with lgkmcnt(8) BEFORE its first barrier of ph0.
+//        All other slots are refilled two phases after their read, when the reader has passed its MFMAs.
+constexpr int T2 = 256;
+constexpr int kThreads2 = 512;
+
+__device__ __forceinline__ void hgemm256_tile_coords(const HGemmArgs& g, int& m0, int& n0, int& klo, int& nk) {
+  const int tiles_m = g.M / T2, tiles_n = g.N / T2, nt = tiles_m * tiles_n;
+  int trow, tcol;
+  if (tiles_m % 4 == 0 && tiles_n % 8 == 0 && nt % 256 == 0) {
+    // 4 x 8 tile patches per XCD (32 CUs): one K step of a patch pulls 4 A panels and 8 B panels through its L2
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+    const int pn = tiles_n / 8;
+    const int pid = (j / 32) * 8 + xcd, e = j % 32;
+    trow = (pid / pn) * 4 + e / 8;
+    tcol = (pid % pn) * 8 + e % 8;
+  } else {
+    int id = blockIdx.x;
+    const int q = nt / 8, r = nt % 8, xcd = id % 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
+    trow = id / tiles_n; tcol = id % tiles_n;
+  }
+  m0 = trow * T2; n0 = tcol * T2;
+  klo = 0;
+  int khi = g.K;
+  if (g.kmode & KLO_M) klo = max(klo, m0);
+  if (g.kmode & KLO_N) klo = max(klo, n0);
+  if (g.kmode & KHI_M) khi = min(khi, m0 + T2);
+  if (g.kmode & KHI_N) khi = min(khi, n0 + T2);
+  klo = (klo / TK) * TK;
+  nk = (khi > klo) ? (khi - klo + TK - 1) / TK : 0;
+}
+
+#define HG_FENCE() asm volatile("" ::: "memory")
+
+template <int N> struct IntC { static constexpr int value = N; };
+
+__global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];   // 8 half-tile slots, the ONLY __shared__ object
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 2, wc = w & 3;
+  int m0, n0, klo, nk;
+  hgemm256_tile_coords(g, m0, n0, klo, nk);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA sources: half type j (0 B-h0, 1 A-h0, 2 B-h1, 3 A-h1), instruction t (0, 1).  The DMA writes linearly
+  // (wave base + 16 * lane), so the swizzle of the LDS image is applied to the per-lane SOURCE address.
+  const uint16_t* src[4][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int p = (t * 8 + w) * 64 + lane;            // 16-byte position within the half-tile
+    const int lr = p >> 3, chunk = (p & 7) ^ (lr & 7);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      src[2 * q + 1][t] = g.A + (long)(m0 + (lr >> 6) * 128 + q * 64 + (lr & 63)) * g.lda + chunk * 8 + klo;
+      src[2 * q][t] = g.B + (long)(n0 + (lr >> 5) * 64 + q * 32 + (lr & 31)) * g.ldb + chunk * 8 + klo;
+    }
+  }
+  auto issue = [&](int n) {                             // half-tile sequence number n = 4 kt + j
+    const int kt = n >> 2, j = n & 3;
+    const int slot = (kt & 1) * 4 + j;
+    const long k0 = (long)kt * TK;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint16_t* s0 = (j == 0) ? src[0][t] : (j == 1) ? src[1][t] : (j == 2) ? src[2][t] : src[3][t];
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(s0 + k0), (lds_ptr_t)&lds[slot * 1024 + (t * 8 + w) * 64], 16, 0, 0);
+    }
+  };
+
+  // fragment read positions (16-byte units inside a slot): row*8 + (chunk ^ (row & 7)), chunk = ks*4 + (lane>>4)
+  const int c0 = (lane >> 4) ^ (lane & 7);
+  const int rowA = (wr * 64 + (lane & 15)) * 8, rowB = (wc * 32 + (lane & 15)) * 8;
+  const int posA[2] = {rowA + c0, rowA + (c0 ^ 4)};
+  const int posB[2] = {rowB + c0, rowB + (c0 ^ 4)};
+
+  bf16x8 a[4][2], b0[2][2], b1[2][2];
+  const int total = 4 * nk;
+
+  // prologue: half-tiles 0..6 in flight, K tile 0 landed
+#pragma unroll
+  for (int n = 0; n < 7; ++n)
+    if (n < total) issue(n);
+  if (nk >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HG_FENCE();
+  __builtin_amdgcn_s_barrier();
+  HG_FENCE();
+  if (wr == 1) __builtin_amdgcn_s_barrier();            // stagger the second wave row by one barrier
+  HG_FENCE();
+
+  auto phase = [&](auto PHc, int kt) {
+    constexpr int PH = decltype(PHc)::value;
+    const u32x4* base = lds + (kt & 1) * 4096;
+    // ---- fragment reads of this phase
+    if constexpr (PH == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b0[j][ks] = __builtin_bit_cast(bf16x8, base[0 * 1024 + posB[ks] + j * 128]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a[i][ks] = __builtin_bit_cast(bf16x8, base[1 * 1024 + posA[ks] + i * 128]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (PH == 1) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b1[j][ks] = __builtin_bit_cast(bf16x8, base[2 * 1024 + posB[ks] + j * 128]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (PH == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a[i][ks] = __builtin_bit_cast(bf16x8, base[3 * 1024 + posA[ks] + i * 128]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- DMA of half-tile q + 7
+    const int n = 4 * kt + PH + 7;
+    if (n < total) issue(n);
+    if constexpr (PH == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four B-h0 reads are done
+    if constexpr (PH == 3) {
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    HG_FENCE();
+    __builtin_amdgcn_s_barrier();
+    HG_FENCE();
+    // ---- 16 MFMAs: one 64 x 32 quadrant x K = 64
+    constexpr int MQ = (PH >= 2) ? 1 : 0;
+    constexpr int NQ = (PH == 1 || PH == 2) ? 1 : 0;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 bv = NQ ? b1[j][ks] : b0[j][ks];
+          acc[4 * MQ + i][2 * NQ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bv, acc[4 * MQ + i][2 * NQ + j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    HG_FENCE();
+    __builtin_amdgcn_s_barrier();
+    HG_FENCE();
+  };
+
+  for (int kt = 0; kt < nk; ++kt) {
+    phase(IntC<0>{}, kt);
+    phase(IntC<1>{}, kt);
+    phase(IntC<2>{}, kt);
+    phase(IntC<3>{}, kt);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();            // matches the stagger barrier of the other wave row
+
+  // epilogue: acc[i][j][e] is C[m0 + wr*128 + i*16 + (lane>>4)*4 + e][n0 + wc*64 + j*16 + (lane&15)]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row0 = m0 + wr * 128 + i * 16 + (lane >> 4) * 4;
+      const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+      if (g.c_trans) {
+        if (g.c_bf16) {
+          uint16_t* p = static_cast<uint16_t*>(g.C) + (long)col * g.ldc + row0;
+          *reinterpret_cast<ushort4*>(p) = make_ushort4(f2bf(acc[i][j][0]), f2bf(acc[i][j][1]), f2bf(acc[i][j][2]), f2bf(acc[i][j][3]));
+        } else {
+          *reinterpret_cast<f32x4*>(static_cast<float*>(g.C) + (long)col * g.ldc + row0) = acc[i][j];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (g.c_bf16) static_cast<uint16_t*>(g.C)[(long)(row0 + e) * g.ldc + col] = f2bf(acc[i][j][e]);
+          else static_cast<float*>(g.C)[(long)(row0 + e) * g.ldc + col] = acc[i][j][e];
+        }
+      }
+    }
+}
+
 // dst (bf16) = src or src', 64 x 64 tiles through LDS.  SRC_BF16 selects the source element type.
 template <bool SRC_BF16>
 __global__ __launch_bounds__(kThreads) void k_to_bf16(const void* src, long lds_, uint16_t* dst, long ldd, int rows,
@@ -322,23 +557,52 @@ __global__ __launch_bounds__(kThreads) void k_to_bf16(const void* src, long lds_
   }
 }
 
-// dst = bf16(src) and dstT = bf16(src') in one pass over a square fp32 matrix (64 x 64 tiles through LDS)
-__global__ __launch_bounds__(kThreads) void k_to_bf16_both(const float* src, uint16_t* dst, uint16_t* dstT, int n) {
-  __shared__ uint16_t tile[64][66];
+// bf16 copies of an upper-triangular fp32 factor Q [n][n]: dst = bf16(Q) and/or dstT = bf16(Q').  64 x 64 tiles,
+// 16-byte global accesses on both sides.  Only the 256 x 256 blocks on or above the block diagonal are touched:
+// the GEMMs restrict their K ranges at tile granularity (<= 256), so they never read the rest of the copies.
+template <bool WRITE_N, bool WRITE_T>
+__global__ __launch_bounds__(kThreads) void k_factor_to_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                             uint16_t* __restrict__ dstT, int n) {
+  __shared__ uint16_t tile[64][72];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  for (int e = threadIdx.x; e < 64 * 64; e += kThreads) {
-    const int r = e >> 6, c = e & 63;
-    uint16_t v = 0;
-    if (r0 + r < n && c0 + c < n) {
-      v = f2bf(src[(long)(r0 + r) * n + c0 + c]);
-      dst[(long)(r0 + r) * n + c0 + c] = v;
-    }
-    tile[r][c] = v;
+  if ((r0 >> 8) > (c0 >> 8)) return;
+  const int t = threadIdx.x, row = t >> 2, cq = (t & 3) * 16;
+  uint16_t v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r0 + row < n && c0 + cq + 4 * q < n) x = *reinterpret_cast<const f32x4*>(src + (long)(r0 + row) * n + c0 + cq + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = f2bf(x[e]);
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 64 * 64; e += kThreads) {
-    const int a = e >> 6, b = e & 63;
-    if (c0 + a < n && r0 + b < n) dstT[(long)(c0 + a) * n + r0 + b] = tile[b][a];
+  if constexpr (WRITE_N) {
+    if (r0 + row < n) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (c0 + cq + 8 * h < n) {
+          u32x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = (unsigned)v[8 * h + 2 * e] | ((unsigned)v[8 * h + 2 * e + 1] << 16);
+          *reinterpret_cast<u32x4*>(dst + (long)(r0 + row) * n + c0 + cq + 8 * h) = pk;
+        }
+    }
+  }
+  if constexpr (WRITE_T) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tile[row][cq + e] = v[e];
+    __syncthreads();
+    const int a = t >> 2, bq = (t & 3) * 16;      // row a of the transposed tile, 16 consecutive columns
+    if (c0 + a < n) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (r0 + bq + 8 * h < n) {
+          u32x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            pk[e] = (unsigned)tile[bq + 8 * h + 2 * e][a] | ((unsigned)tile[bq + 8 * h + 2 * e + 1][a] << 16);
+          *reinterpret_cast<u32x4*>(dstT + (long)(c0 + a) * n + r0 + bq + 8 * h) = pk;
+        }
+    }
   }
 }
 
@@ -361,15 +625,24 @@ static HWs hws_layout(char* base, int M, int N) {
   return k;
 }
 
-static int g_hgemm_variant = 0;   // 0 / 1: register-staged double buffer (2 blocks/CU; measured faster), 2: LDS-DMA ring
+static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, else 128^2 register-staged);
+                                  // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
 
 static int launch_hgemm(const uint16_t* A, long lda, const uint16_t* B, long ldb, void* C, long ldc, int c_bf16,
-                        int c_trans, int M, int N, int K, int kmode, hipStream_t st) {
-  HGemmArgs g = {A, lda, B, ldb, C, ldc, c_bf16, c_trans, M, N, K, kmode};
-  const int nt = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+                        int c_trans, int M, int N, int K, int kmode, hipStream_t st, int sym = 0) {
+  HGemmArgs g = {A, lda, B, ldb, C, ldc, c_bf16, c_trans, M, N, K, kmode, sym};
+  const int tm_ = (M + TM - 1) / TM;
+  const int nt = sym ? tm_ * (tm_ + 1) / 2 : tm_ * ((N + TN - 1) / TN);
   const bool interior = (M % TM == 0) && (N % TN == 0) && (K % TM == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
-  if (g_hgemm_variant == 2 && interior) hipLaunchKernelGGL(k_hgemm_nt_dma, dim3(nt), dim3(kThreads), 0, st, g);
+  const bool big = interior && !sym && (M % T2 == 0) && (N % T2 == 0) && (K % T2 == 0);
+  // auto: dense products only (a triangular K range makes the single full-K tile per CU the critical path: measured
+  // equal to the 128^2 kernel), and only when the 256^2 tiles fill >= 80 % of the CU slots of their last wave
+  const int nt2 = (M / T2) * (N / T2);
+  const bool fills = nt2 * 5 >= ((nt2 + 255) / 256) * 256 * 4;
+  const bool use256 = big && ((g_hgemm_variant == 0 && kmode == 0 && fills) || g_hgemm_variant == 3);
+  if (use256) hipLaunchKernelGGL(k_hgemm_nt_256, dim3((M / T2) * (N / T2)), dim3(kThreads2), 0, st, g);
+  else if (g_hgemm_variant == 2 && interior && !sym) hipLaunchKernelGGL(k_hgemm_nt_dma, dim3(nt), dim3(kThreads), 0, st, g);
   else hipLaunchKernelGGL(k_hgemm_nt, dim3(nt), dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
 }
@@ -379,6 +652,14 @@ static int launch_cvt(const void* src, int src_bf16, long lds_, uint16_t* dst, l
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   if (src_bf16) hipLaunchKernelGGL((k_to_bf16<true>), grid, dim3(kThreads), 0, st, src, lds_, dst, ldd, rows, cols, transpose);
   else hipLaunchKernelGGL((k_to_bf16<false>), grid, dim3(kThreads), 0, st, src, lds_, dst, ldd, rows, cols, transpose);
+  return (int)hipGetLastError();
+}
+
+static int launch_factor_cvt(const float* Q, uint16_t* dst, uint16_t* dstT, int n, hipStream_t st) {
+  dim3 grid((n + 63) / 64, (n + 63) / 64);
+  if (dst && dstT) hipLaunchKernelGGL((k_factor_to_bf16<true, true>), grid, dim3(kThreads), 0, st, Q, dst, dstT, n);
+  else if (dstT) hipLaunchKernelGGL((k_factor_to_bf16<false, true>), grid, dim3(kThreads), 0, st, Q, dst, dstT, n);
+  else hipLaunchKernelGGL((k_factor_to_bf16<true, false>), grid, dim3(kThreads), 0, st, Q, dst, dstT, n);
   return (int)hipGetLastError();
 }
 
@@ -414,12 +695,11 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
   HWs k = hws_layout(static_cast<char*>(ws), M, N);
   const uint16_t* Gb = static_cast<const uint16_t*>(G);
   if (M < N) {                                                                     // psgd.py:189-190
-    HK(launch_cvt(Ql, 0, M, k.QlT, M, M, M, 1, st));
-    hipLaunchKernelGGL(k_to_bf16_both, dim3((N + 63) / 64, (N + 63) / 64), dim3(kThreads), 0, st, Qr, k.Qr, k.QrT, N);
-    HK((int)hipGetLastError());
+    HK(launch_factor_cvt(Ql, nullptr, k.QlT, M, st));
+    HK(launch_factor_cvt(Qr, k.Qr, k.QrT, N, st));
     HK(launch_cvt(G, 1, N, k.GT, M, M, N, 1, st));
-    // T1 = Ql'Ql              A = Ql' [M][K=M], Bt = Ql' ; k <= min(m, n)
-    HK(launch_hgemm(k.QlT, M, k.QlT, M, k.T1, M, 1, 0, M, M, M, KHI_M | KHI_N, st));
+    // T1 = Ql'Ql              A = Ql' [M][K=M], Bt = Ql' ; k <= min(m, n); symmetric: upper tiles computed, stored twice
+    HK(launch_hgemm(k.QlT, M, k.QlT, M, k.T1, M, 1, 0, M, M, M, KHI_M | KHI_N, st, 1));
     // T2 = T1 G               A = T1 [M][K=M], Bt = G' [N][M]
     HK(launch_hgemm(k.T1, M, k.GT, M, k.T2, N, 1, 0, M, N, M, 0, st));
     // T3 = T2 Qr'             A = T2 [M][K=N], Bt[n][k] = Qr'[k][n] = Qr[n][k] ; k >= n
@@ -427,11 +707,10 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
     // out = T3 Qr             Bt[n][k] = Qr[k][n] = Qr'[n][k] ; k <= n
     HK(launch_hgemm(k.T3, N, k.QrT, N, out, N, 1, 0, M, N, N, KHI_N, st));
   } else {                                                                         // psgd.py:191-192
-    HK(launch_cvt(Qr, 0, N, k.QrT, N, N, N, 1, st));
-    hipLaunchKernelGGL(k_to_bf16_both, dim3((M + 63) / 64, (M + 63) / 64), dim3(kThreads), 0, st, Ql, k.Ql, k.QlT, M);
-    HK((int)hipGetLastError());
-    // T1 = Qr'Qr  (symmetric, so it is its own Bt layout)
-    HK(launch_hgemm(k.QrT, N, k.QrT, N, k.T1, N, 1, 0, N, N, N, KHI_M | KHI_N, st));
+    HK(launch_factor_cvt(Qr, nullptr, k.QrT, N, st));
+    HK(launch_factor_cvt(Ql, k.Ql, k.QlT, M, st));
+    // T1 = Qr'Qr  (symmetric, so it is its own Bt layout; upper tiles computed, stored twice)
+    HK(launch_hgemm(k.QrT, N, k.QrT, N, k.T1, N, 1, 0, N, N, N, KHI_M | KHI_N, st, 1));
     // T2 = G T1               A = G [M][K=N], Bt = T1' = T1 ; stored transposed: T2' [N][M]
     HK(launch_hgemm(Gb, N, k.T1, N, k.T2, M, 1, 1, M, N, N, 0, st));
     // T3 = Ql T2              A = Ql [M][K=M] (k >= m), Bt = T2' ; stored transposed: T3' [N][M]

@@ -160,15 +160,44 @@ def test_dense_dense_apply_bf16(psgd, M, N):
     # and it agrees with the fp32 HIP path on the same (bf16-valued) gradient to the same tolerance
     out32 = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), G.float())
     assert rel_err(out.float().cpu().numpy(), out32.cpu().numpy()) < BF16_TOL
-    if M * N >= 4096 * 2048:                          # both GEMM variants on the big shapes
-        from psgd_tf_amd import _lib
-        for variant in (1, 2):
-            _lib.load().psgd_kron_bf16_set_tuning(0, variant)
-            try:
-                outv = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), G)
-            finally:
-                _lib.load().psgd_kron_bf16_set_tuning(0, 0)
-            assert rel_err(outv.float().cpu().numpy(), ref) < BF16_TOL, variant
+    from psgd_tf_amd import _lib
+    variants = [1]                                    # 128^2 register-staged everywhere
+    if M * N >= 4096 * 2048:
+        variants.append(2)                            # 128^2 LDS-DMA ring
+    if M % 256 == 0 and N % 256 == 0:
+        variants.append(3)                            # 256^2 8-phase kernel for every product it can take
+    outs = {}
+    for variant in variants:
+        _lib.load().psgd_kron_bf16_set_tuning(0, variant)
+        try:
+            outs[variant] = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), G)
+        finally:
+            _lib.load().psgd_kron_bf16_set_tuning(0, 0)
+        assert rel_err(outs[variant].float().cpu().numpy(), ref) < BF16_TOL, variant
+    # every variant multiplies the same bf16 operands in the same k order with fp32 accumulation: bitwise equal
+    for variant in variants[1:]:
+        assert torch.equal(outs[variant], outs[1]), variant
+    assert torch.equal(out, outs[1])
+
+
+@pytest.mark.parametrize("M,N", [(4096, 4096), (2048, 1024), (256, 256)])
+def test_bf16_gemm_variants_bitwise_stable(psgd, M, N):
+    """Race screen for the LDS-DMA kernels (counted vmcnt / raw barriers): repeated runs of the 256^2 kernel on
+    every product of the chain must reproduce the register-staged 128^2 kernel bit for bit."""
+    from psgd_tf_amd import _lib
+    rng = np.random.default_rng(M + N)
+    Ql, Qr = _dev(_tri_factor(rng, M).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
+    G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16)
+    lib = _lib.load()
+    lib.psgd_kron_bf16_set_tuning(0, 1)
+    try:
+        want = psgd.precond_grad_kron(Ql, Qr, G)
+        for variant in (3, 0):
+            lib.psgd_kron_bf16_set_tuning(0, variant)
+            for _ in range(6):
+                assert torch.equal(psgd.precond_grad_kron(Ql, Qr, G), want), variant
+    finally:
+        lib.psgd_kron_bf16_set_tuning(0, 0)
 
 
 def test_bf16_path_rejects_odd_shapes(psgd):
