@@ -1,7 +1,8 @@
 """Multi-threaded CPU restatement of the reference op sequence on torch-CPU.  TEST / BASELINE
 INFRASTRUCTURE ONLY (same rules as psgd_oracle.py: never imported by the product).
 
-Purpose: the `cpu_baseline` leg of bench.py.  The reference is TensorFlow-eager Python
+Purpose: the `cpu_baseline` leg of bench.py, and (device-agnostic torch ops, so it also runs in fp64 on the
+GPU through rocBLAS) the independent full-size cross-check of tests/test_full_size_gpu.py.  The reference is TensorFlow-eager Python
 (psgd.py); TensorFlow is not available, so the baseline is this restatement: one torch library
 call per TF op, same association order and same temporaries as psgd.py:540-627 (UVd) and
 psgd.py:156-192 (Kron dense(x)dense), run with torch's intra-op thread pool on the host cores.
@@ -31,7 +32,7 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, balance=False, update_U=
     Qh = IpUVtmatvec(U, V, d * h)
     Ph = d * IpUVtmatvec(V, U, Qh)
     VtU = torch.matmul(V.t(), U)
-    IpVtU = torch.eye(VtU.shape[0], dtype=VtU.dtype) + VtU
+    IpVtU = torch.eye(VtU.shape[0], dtype=VtU.dtype, device=VtU.device) + VtU
     invQtv = v / d
     invQtv = invQtv - torch.matmul(V, torch.linalg.solve(IpVtU.t(), torch.matmul(U.t(), invQtv)))
     invPv = invQtv - torch.matmul(U, torch.linalg.solve(IpVtU, torch.matmul(V.t(), invQtv)))
