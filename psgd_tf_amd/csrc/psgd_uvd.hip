@@ -245,6 +245,50 @@ __global__ void k_fused_s1(const double* __restrict__ pq, const float* __restric
   s1_coef[c] = (float)s;
 }
 
+// Single-GPU fused step: everything between update sweep 2 and the d update in ONE launch (k_reduce_max +
+// k_reduce_sum_t + k_fused_s1 of the staged path).  One wave per element c < r: it reduces the block maxima of
+// |nablaD| (every wave redundantly: G <= 2048 floats), the partial sums p_c, q_c in fp64, and publishes
+// s1_c = p_c - mu q_c; wave 0 also publishes the maximum for k_update_d.  Same arithmetic and order as the
+// staged kernels, so the two paths agree bit for bit.
+__global__ __launch_bounds__(kThreads) void k_post_s2_fused(const float* __restrict__ part, const float* __restrict__ pmax,
+                                                            int G, int r, float step, float tiny,
+                                                            double* __restrict__ pq_sums, float* __restrict__ maxout,
+                                                            double* __restrict__ s1_sums, float* __restrict__ s1_coef) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (c >= r) return;
+  float m = 0.0f;
+  for (int b = lane; b < G; b += 64) m = fmaxf(m, pmax[b]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  double pq[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float* p = part + (long)(k * r + c) * G;
+    float x[kMaxGrid / 64];
+#pragma unroll
+    for (int u = 0; u < kMaxGrid / 64; ++u) {
+      const int b = lane + 64 * u;
+      x[u] = (b < G) ? p[b] : 0.0f;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < kMaxGrid / 64; ++u) s += (double)x[u];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    pq[k] = s;
+  }
+  if (lane == 0) {
+    const double mu = (double)(step / (m + tiny));
+    const double s1 = pq[0] - mu * pq[1];
+    pq_sums[c] = pq[0];
+    pq_sums[r + c] = pq[1];
+    s1_sums[c] = s1;
+    s1_coef[c] = (float)s1;
+    if (c == 0) *maxout = m;
+  }
+}
+
 // d <- d - (mu d) nablaD, mu = step / (max|nablaD| + tiny)      psgd.py:582-584
 __global__ __launch_bounds__(kThreads) void k_update_d(float* d, const float* __restrict__ nabla, long N,
                                                        const float* __restrict__ maxbuf, float step, float tiny) {
@@ -756,7 +800,7 @@ int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, c
 
 static int update_sweep2_impl(float* U, float* V, const float* d, const float* v, const float* h, const float* g,
                               int64_t N, int r, float step, float tiny, int update_U, void* ws, int64_t ws_bytes,
-                              void* stream) {
+                              void* stream, bool one_launch_tail = false) {
   if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
@@ -772,6 +816,12 @@ static int update_sweep2_impl(float* U, float* V, const float* d, const float* v
   {
     ProfScope ps(PSGD_PROF_UPDATE_S2, st);
     PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, g, N, w.coef, w.nabla, w.pmax, part, grid, st));
+  }
+  if (one_launch_tail && g) {
+    hipLaunchKernelGGL(k_post_s2_fused, dim3((r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
+                       w.pmax, grid, r, step, tiny, w.sums + kPqSumsOff, w.maxbuf + 2, w.sums, w.coef);
+    PSGD_CHECK_LAUNCH(last_launch());
+    return PSGD_OK;
   }
   hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf + 2);
   PSGD_CHECK_LAUNCH(last_launch());
@@ -855,11 +905,9 @@ int psgd_uvd_update_apply_f32(float* U, float* V, float* d, const float* v, cons
   }
   rc = psgd_uvd_update_sweep1_f32(U, V, d, v, h, N, r, ws, ws_bytes, stream);
   if (rc) return rc;
-  rc = psgd_uvd_update_sweep2_fused_f32(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream);
+  rc = update_sweep2_impl(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream, /*one_launch_tail=*/true);
   if (rc) return rc;
   rc = psgd_uvd_update_sweep3_f32(d, N, r, step, tiny, ws, ws_bytes, stream);
-  if (rc) return rc;
-  rc = psgd_uvd_fused_s1_f32(N, r, step, tiny, ws, ws_bytes, stream);
   if (rc) return rc;
   rc = psgd_uvd_apply_sweep2_f32(U, d, g, out, N, r, 0, ws, ws_bytes, stream);
   if (rc) return rc;
