@@ -20,6 +20,10 @@ def main():
     ap.add_argument("--bpc", type=int, default=0, help="cap on blocks per CU (tuning key 1)")
     ap.add_argument("--alias-shift", type=int, default=-1,
                     help="experiment: V = U's buffer shifted by this many rows (same DRAM region)")
+    ap.add_argument("--swap-alloc", action="store_true", help="experiment: allocate V before U")
+    ap.add_argument("--pad-mb", type=int, default=0, help="experiment: dummy allocation between U and V (MiB)")
+    ap.add_argument("--pad-ws-kb", type=int, default=0, help="experiment: dummy allocation before the workspace (KiB)")
+    ap.add_argument("--only", default="", help="comma-separated stage names to time")
     args = ap.parse_args()
     N, r = args.N, args.r
     dev = torch.device("cuda:0")
@@ -28,8 +32,14 @@ def main():
         lib.psgd_set_tuning(1, args.bpc)
     g = torch.Generator(device=dev).manual_seed(0)
     scale = (1.0 / (N * r)) ** 0.5
+    if args.swap_alloc:
+        V0 = torch.randn(N, r, device=dev, generator=g) * scale
     U = torch.randn(N, r, device=dev, generator=g) * scale
-    if args.alias_shift >= 0:
+    if args.pad_mb:
+        pad = torch.empty(args.pad_mb * 2**20, dtype=torch.uint8, device=dev)
+    if args.swap_alloc:
+        V = V0
+    elif args.alias_shift >= 0:
         buf = torch.randn(N + args.alias_shift, r, device=dev, generator=g) * scale
         U, V = buf[:N], buf[args.alias_shift:]
     else:
@@ -38,6 +48,8 @@ def main():
     gr = torch.randn(N, 1, device=dev, generator=g)
     v = torch.randn(N, 1, device=dev, generator=g)
     h = v * torch.exp(torch.empty(N, 1, device=dev).uniform_(-4.6, 4.6, generator=g))
+    if args.pad_ws_kb:
+        pad2 = torch.empty(args.pad_ws_kb * 1024, dtype=torch.uint8, device=dev)
     ws = psgd.uvd_workspace(dev, N, r)
     out = torch.empty_like(gr)
     st = torch.cuda.current_stream().cuda_stream
@@ -59,7 +71,11 @@ def main():
         "upd_s1": 4 * (2 * r + 3), "upd_s2U": 4 * (3 * r + 4), "upd_s2V": 4 * (3 * r + 4), "upd_s3": 12,
         "update": 4 * (5 * r + 10),
     }
+    print("U %x V %x d %x ws %x" % (U.data_ptr(), V.data_ptr(), d.data_ptr(), ws.data_ptr()))
+    only = set(x for x in args.only.split(",") if x)
     for name, fn in stages.items():
+        if only and name not in only:
+            continue
         for _ in range(2):
             rc = fn()
             assert rc == 0, (name, rc)
