@@ -250,6 +250,8 @@ def main():
         # algorithmic bytes per row per launch (DESIGN.md section 4 / SURVEY 8d)
         kbytes = {"apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 3), "apply_s3": 4 * (r + 3),
                   "update_s1": 4 * (2 * r + 3), "update_s2": 4 * (3 * r + 4), "update_s3": 12}
+        if not args.unfused:
+            kbytes["update_s2"] = 4 * (3 * r + 5)      # + 4 B/row for g; produces the apply's s1
         kern = {k: {"avg_ms": slot_ms[k], "achieved_GBs": kbytes[k] * n_local / (slot_ms[k] * 1e-3) / 1e9}
                 for k in kbytes if slot_ms[k]}
         dom = "update_s2"
@@ -265,8 +267,6 @@ def main():
         ach = kern[dom]["achieved_GBs"]
         apply_ms = sum(slot_ms[k] or 0.0 for k in ("apply_s1", "apply_s2", "apply_s3"))
         update_ms = sum(slot_ms[k] or 0.0 for k in ("update_s1", "update_s2", "update_s3"))
-        if not args.unfused:
-            kbytes["update_s2"] = 4 * (3 * r + 5)      # + 4 B/row for g; produces the apply's s1
         paths = {
             "fused": not args.unfused,
             "apply": {"alg_bytes_per_param": 4 * (4 * r + 5), "kernel_ms": apply_ms,

@@ -1,0 +1,20 @@
+R=$PWD
+mkdir -p gpurun_out/kupd
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kupd/stats -- python3 $R/tools/kron_big_update.py > $R/gpurun_out/kupd/out.txt 2>&1
+python3 - <<PY
+import sqlite3,glob
+db=glob.glob('$R/gpurun_out/kupd/stats/**/*_results.db',recursive=True)[0]
+con=sqlite3.connect(db)
+cols=[r[1] for r in con.execute("pragma table_info(kernels)")]
+name="name" if "name" in cols else "kernel_name"
+rows=list(con.execute(f"select {name}, start, duration, 0 from kernels order by start"))
+# last update call: find last k_kron_balance
+idx=[i for i,r in enumerate(rows) if 'k_kron_balance' in r[0]]
+last=idx[-1]
+tot=0
+for n,s,d,gx in rows[last:]:
+    print("%-60s %9.1f us grid %d" % (n[:60], d/1e3, gx)); tot+=d
+print("sum", tot/1e3)
+PY
+rm -rf $R/gpurun_out/kupd/stats
