@@ -115,11 +115,21 @@ def kron_bench(dev, psgd, iters=20):
     t_lenet_loop = timeit(lambda: [psgd.precond_grad_kron(a, b, c) for a, b, c in sts], 50)
     f_big = kron_apply_flops(M, N)
     f_lenet = sum(kron_apply_flops(m, n) for m, n in LENET5)
+    pmc = None                          # matrix-core counters of the same call, collected with rocprofv3 --pmc
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "kron_mfma_pmc.json")))
+        pmc = {"source": "profiles/kron_mfma_pmc.json (rocprofv3 --pmc)", "issued_gflop_per_apply": pmc["issued_flops_per_apply"] / 1e9,
+               "issued_gflops": pmc["issued_flops_per_apply"] / t_bf16 / 1e6,
+               "frac_of_bf16_peak_issued": pmc["issued_flops_per_apply"] / t_bf16 / 1e6 / 2.5e6,
+               "MfmaUtil_percent": {"k_hgemm_nt_256 (dense product)": pmc["k_hgemm_nt_256"]["mfma_util_percent"],
+                                    "k_hgemm_nt (3 triangular / symmetric products)": pmc["k_hgemm_nt"]["mfma_util_percent"]}}
+    except Exception:
+        pmc = None
     return {
         "metric": "kron_dense_dense_apply_gflops", "flop_count": "F_ref (dense flops of psgd.py:189-192)",
         "4096x4096_bf16_operands": {"ms": t_bf16, "gflops": f_big / t_bf16 / 1e6, "mfma_peak_gflops": 2.5e6,
                                     "frac_of_bf16_peak_Fref": f_big / t_bf16 / 1e6 / 2.5e6,
-                                    "note": "triangular K-ranges skipped: issued flops ~0.5 F_ref"},
+                                    "note": "triangular K-ranges skipped: issued flops ~0.55 F_ref", "mfma_pmc": pmc},
         "4096x4096_fp32": {"ms": t_f32, "gflops": f_big / t_f32 / 1e6, "mfma_peak_gflops": 157.3e3},
         "lenet5_set_fp32": {"us": t_lenet * 1e3, "gflops": f_lenet / t_lenet / 1e6, "bound": "launch/latency",
                             "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop * 1e3},

@@ -1,0 +1,26 @@
+# MFMA utilisation of the Kron apply from hardware counters (rocprofv3 --pmc), 4096^2 bf16 operands.
+R=$PWD
+mkdir -p gpurun_out/mfma
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L 2>/dev/null | grep -i -E "mfma|MfmaUtil|SQ_BUSY_CU|GRBM_GUI_ACTIVE|SQ_BUSY_CYCLES" | head -40 > $R/gpurun_out/mfma/avail.txt
+for c in "MfmaUtil" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16"; do
+  tag=$(echo $c | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $c -d $R/gpurun_out/mfma/$tag -- python3 $R/tools/kron_bf16_probe.py 4096 > $R/gpurun_out/mfma/$tag.log 2>&1
+done
+cd $R
+python3 - <<'PY'
+import sqlite3, glob, collections
+for d in sorted(glob.glob('gpurun_out/mfma/*/')):
+    dbs = glob.glob(d + '**/*_results.db', recursive=True)
+    if not dbs: print(d, "no db"); continue
+    con = sqlite3.connect(dbs[0])
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for name, ctr, val, dur in con.execute("select kernel_name, counter_name, value, duration from counters_collection"):
+        if 'psgdh' in name: acc[name.split('(')[0]][ctr].append((val, dur))
+    for k, c in acc.items():
+        for ctr, vals in c.items():
+            n = len(vals)
+            print("%-46s %-34s launches %3d  mean %.4g  mean_dur_us %.1f" % (k[:46], ctr, n, sum(v for v, _ in vals) / n, sum(d for _, d in vals) / n / 1e3))
+PY
+cat gpurun_out/mfma/avail.txt | cut -c1-200 | head -30
+rm -rf gpurun_out/mfma/*/
