@@ -253,11 +253,16 @@ int psgd_kron_ns_apply_f32(const float *ql, const float *qr, const float *G, int
  * bf16 intermediates, in the reference's association order.  M and N must be multiples of 8.
  * Upper-triangular Ql, Qr are assumed (entries below the diagonal are not read).            */
 int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
-/* Experiment knob (not stable ABI). key 0: bf16 GEMM variant (0/1 register-staged double buffer, 2 LDS-DMA ring). */
+/* Experiment knob (not stable ABI). key 0: bf16 GEMM variant: 0 auto (256^2 8-phase kernel for large dense
+ * products, fused triangular pair when every 256^2 tile gets its own CU, 128^2 register-staged otherwise);
+ * 1 128^2 register-staged everywhere; 2 128^2 LDS-DMA ring; 3 256^2 for every product; 4 auto without the fused pair. */
 int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,
                             int64_t ws_bytes, void *stream);
+/* Debug aid (synchronises): 1 if a bounded spin of the fused triangular pair of the last bf16 apply on this
+ * workspace gave up (a block was not resident), else 0.  The apply's result is invalid in that case.          */
+int psgd_kron_bf16_handoff_timeouts(const void *ws, int M, int N);
 
 #ifdef __cplusplus
 }

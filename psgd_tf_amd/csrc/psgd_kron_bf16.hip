@@ -383,43 +383,20 @@ __device__ __forceinline__ void hgemm256_tile_coords(const HGemmArgs& g, int& m0
 
 template <int N> struct IntC { static constexpr int value = N; };
 
-__global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
-  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];   // 8 half-tile slots, the ONLY __shared__ object
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// The 8-phase main loop over `nk` K tiles.  src(n, t) = global address of the 16 bytes this lane moves with DMA
+// instruction t (0, 1) of half-tile n (n = 4 * sequence index of the K tile + {0 B-h0, 1 A-h0, 2 B-h1, 3 A-h1});
+// pre(n) runs (uniformly, all waves) right before half-tile n is issued inside the loop.  Self-contained: the
+// stagger barrier of the second wave row at entry is matched at exit.
+template <class Src, class Pre>
+__device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, int nk, int w, int lane, Src&& src,
+                                               Pre&& pre) {
   const int wr = w >> 2, wc = w & 3;
-  int m0, n0, klo, nk;
-  hgemm256_tile_coords(g, m0, n0, klo, nk);
-
-  f32x4 acc[8][4];
+  auto issue = [&](int n) {
+    const int slot = ((n >> 2) & 1) * 4 + (n & 3);
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // DMA sources: half type j (0 B-h0, 1 A-h0, 2 B-h1, 3 A-h1), instruction t (0, 1).  The DMA writes linearly
-  // (wave base + 16 * lane), so the swizzle of the LDS image is applied to the per-lane SOURCE address.
-  const uint16_t* src[4][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int p = (t * 8 + w) * 64 + lane;            // 16-byte position within the half-tile
-    const int lr = p >> 3, chunk = (p & 7) ^ (lr & 7);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      src[2 * q + 1][t] = g.A + (long)(m0 + (lr >> 6) * 128 + q * 64 + (lr & 63)) * g.lda + chunk * 8 + klo;
-      src[2 * q][t] = g.B + (long)(n0 + (lr >> 5) * 64 + q * 32 + (lr & 31)) * g.ldb + chunk * 8 + klo;
-    }
-  }
-  auto issue = [&](int n) {                             // half-tile sequence number n = 4 kt + j
-    const int kt = n >> 2, j = n & 3;
-    const int slot = (kt & 1) * 4 + j;
-    const long k0 = (long)kt * TK;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const uint16_t* s0 = (j == 0) ? src[0][t] : (j == 1) ? src[1][t] : (j == 2) ? src[2][t] : src[3][t];
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(s0 + k0), (lds_ptr_t)&lds[slot * 1024 + (t * 8 + w) * 64], 16, 0, 0);
-    }
+    for (int t = 0; t < 2; ++t)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src(n, t), (lds_ptr_t)&lds[slot * 1024 + (t * 8 + w) * 64], 16, 0, 0);
   };
-
   // fragment read positions (16-byte units inside a slot): row*8 + (chunk ^ (row & 7)), chunk = ks*4 + (lane>>4)
   const int c0 = (lane >> 4) ^ (lane & 7);
   const int rowA = (wr * 64 + (lane & 15)) * 8, rowB = (wc * 32 + (lane & 15)) * 8;
@@ -471,7 +448,10 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
     }
     // ---- DMA of half-tile q + 7
     const int n = 4 * kt + PH + 7;
-    if (n < total) issue(n);
+    if (n < total) {
+      pre(n);
+      issue(n);
+    }
     if constexpr (PH == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four B-h0 reads are done
     if constexpr (PH == 3) {
       if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -506,29 +486,192 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
     phase(IntC<3>{}, kt);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();            // matches the stagger barrier of the other wave row
+  HG_FENCE();
+}
 
-  // epilogue: acc[i][j][e] is C[m0 + wr*128 + i*16 + (lane>>4)*4 + e][n0 + wc*64 + j*16 + (lane&15)]
+// per-lane element offsets of the two DMA instructions of each half type inside an operand tile whose row 0 is
+// `row0` (A: tile rows, B: tile columns).  The DMA writes linearly (wave base + 16 * lane), so the XOR swizzle of the
+// LDS image is applied to the per-lane SOURCE address.
+__device__ __forceinline__ void hg256_offsets(int w, int lane, long lda, long ldb, long (&offA)[2][2], long (&offB)[2][2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int p = (t * 8 + w) * 64 + lane;            // 16-byte position within the half-tile
+    const int lr = p >> 3, chunk = (p & 7) ^ (lr & 7);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      offA[q][t] = (long)((lr >> 6) * 128 + q * 64 + (lr & 63)) * lda + chunk * 8;
+      offB[q][t] = (long)((lr >> 5) * 64 + q * 32 + (lr & 31)) * ldb + chunk * 8;
+    }
+  }
+}
+
+// acc[i][j][e] is C[m0 + wr*128 + i*16 + (lane>>4)*4 + e][n0 + wc*64 + j*16 + (lane&15)]
+template <bool PUBLISH>
+__device__ __forceinline__ void hg256_store(const f32x4 (&acc)[8][4], void* C, long ldc, int c_bf16, int c_trans, int m0,
+                                            int n0, int w, int lane) {
+  const int wr = w >> 2, wc = w & 3;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row0 = m0 + wr * 128 + i * 16 + (lane >> 4) * 4;
       const int col = n0 + wc * 64 + j * 16 + (lane & 15);
-      if (g.c_trans) {
-        if (g.c_bf16) {
-          uint16_t* p = static_cast<uint16_t*>(g.C) + (long)col * g.ldc + row0;
-          *reinterpret_cast<ushort4*>(p) = make_ushort4(f2bf(acc[i][j][0]), f2bf(acc[i][j][1]), f2bf(acc[i][j][2]), f2bf(acc[i][j][3]));
+      if (c_trans) {
+        if (c_bf16) {
+          uint16_t* p = static_cast<uint16_t*>(C) + (long)col * ldc + row0;
+          const unsigned long long pk = (unsigned long long)f2bf(acc[i][j][0]) | ((unsigned long long)f2bf(acc[i][j][1]) << 16) |
+                                        ((unsigned long long)f2bf(acc[i][j][2]) << 32) | ((unsigned long long)f2bf(acc[i][j][3]) << 48);
+          if constexpr (PUBLISH)   // write-through (sc1) 8-byte store: visible to other XCDs once this wave's vmcnt drains
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            *reinterpret_cast<unsigned long long*>(p) = pk;
         } else {
-          *reinterpret_cast<f32x4*>(static_cast<float*>(g.C) + (long)col * g.ldc + row0) = acc[i][j];
+          *reinterpret_cast<f32x4*>(static_cast<float*>(C) + (long)col * ldc + row0) = acc[i][j];
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (g.c_bf16) static_cast<uint16_t*>(g.C)[(long)(row0 + e) * g.ldc + col] = f2bf(acc[i][j][e]);
-          else static_cast<float*>(g.C)[(long)(row0 + e) * g.ldc + col] = acc[i][j][e];
+          if (c_bf16) static_cast<uint16_t*>(C)[(long)(row0 + e) * ldc + col] = f2bf(acc[i][j][e]);
+          else static_cast<float*>(C)[(long)(row0 + e) * ldc + col] = acc[i][j][e];
         }
       }
     }
+}
+
+__global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];   // 8 half-tile slots, the ONLY __shared__ object
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int m0, n0, klo, nk;
+  hgemm256_tile_coords(g, m0, n0, klo, nk);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  long offA[2][2], offB[2][2];
+  hg256_offsets(w, lane, g.lda, g.ldb, offA, offB);
+  const uint16_t* Abase = g.A + (long)m0 * g.lda + klo;
+  const uint16_t* Bbase = g.B + (long)n0 * g.ldb + klo;
+  auto src = [&](int n, int t) -> const uint16_t* {
+    const int j = n & 3;
+    const long k0 = (long)(n >> 2) * TK;
+    const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
+    return ((j & 1) ? Abase : Bbase) + o + k0;
+  };
+  hg256_mainloop(acc, lds, nk, w, lane, src, [](int) {});
+  hg256_store<false>(acc, g.C, g.ldc, g.c_bf16, g.c_trans, m0, n0, w, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused pair of triangular products  T3 = Ql T2 (k >= m)  ->  out = Ql' T3 (k <= m)   (psgd.py:191-192, M >= N branch)
+// as ONE launch of one persistent block per 256 x 256 tile (r, c).  Alone, each product leaves the chip half idle at
+// this tile size: tile row r of the first has K length 16 - r (in 256-wide chunks), of the second r + 1, and with one
+// tile per CU the full-K tile is the critical path (2 x 16 chunks).  Fused, block (r, c) computes its T3 tile
+// (16 - r chunks), publishes it, and then accumulates its out tile over the T3 tiles (j, c), j = r, r-1, ..., 0 IN THAT
+// ORDER: tile j is finished by its producer at time 16 - j, exactly when this block gets to it -- 17 chunks for
+// every block instead of 32 on the critical path.
+// Hand-off (cdna_hip_programming.md, Guideline 16, R1): the T3 tile is stored write-through (8-byte agent-scope
+// atomic stores = sc1), every storing wave drains vmcnt, the block's barrier, one lane stores the flag with an
+// agent-scope atomic; the consumer polls that one word (one lane, relaxed, bounded), does ONE agent-scope acquire,
+// drains, and the whole block passes a barrier before any wave issues a load of the handed-off bytes.  Flags are
+// zeroed by a memset node before every launch.  All blocks must be resident (grid <= number of CUs, one block per CU:
+// checked by the launcher); every spin is bounded and reports through a timeout word.
+struct HPairArgs {
+  const uint16_t* A1; long lda1;   // Ql  [M][M]   (k >= m)
+  const uint16_t* B1; long ldb1;   // T2' [N][M]
+  uint16_t* T3; long ldt;          // T3' [N][M]   written by phase A, read as the B operand of phase B
+  const uint16_t* A2; long lda2;   // Ql' [M][M]   (k <= m)
+  void* out; long ldo; int out_bf16, out_trans;
+  int M, N;                        // M = the triangular factor's dimension (tile rows), N = the other one
+  unsigned* flags;                 // [M/256][N/256], zeroed before the launch
+  unsigned* timeout;               // set to 1 if a spin gave up
+};
+
+__global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tiles_m = p.M / T2, tiles_n = p.N / T2;
+  // blocks b, b + 8, ... share an XCD: give each XCD whole tile columns (the hand-offs of a column stay on one L2
+  // when the column count allows); rows ascend with the block index inside a column
+  int r, c;
+  if (tiles_n % 8 == 0) {
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8, cpx = tiles_n / 8;
+    c = xcd * cpx + j / tiles_m;
+    r = j % tiles_m;
+  } else {
+    c = blockIdx.x / tiles_m;
+    r = blockIdx.x % tiles_m;
+  }
+  (void)tiles_n;
+  const int m0 = r * T2, n0 = c * T2;
+
+  f32x4 acc[8][4];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero();
+
+  // ---- phase A: T3 tile (r, c) = sum over k >= m0 of Ql[m][k] T2'[n][k]
+  {
+    long offA[2][2], offB[2][2];
+    hg256_offsets(w, lane, p.lda1, p.ldb1, offA, offB);
+    const uint16_t* Abase = p.A1 + (long)m0 * p.lda1 + m0;
+    const uint16_t* Bbase = p.B1 + (long)n0 * p.ldb1 + m0;
+    auto src = [&](int n, int t) -> const uint16_t* {
+      const int j = n & 3;
+      const long k0 = (long)(n >> 2) * TK;
+      const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
+      return ((j & 1) ? Abase : Bbase) + o + k0;
+    };
+    hg256_mainloop(acc, lds, (p.M - m0) / TK, w, lane, src, [](int) {});
+  }
+  // publish: T3'[n0 + col][m0 + row] (transposed, bf16), write-through; drain; barrier; flag
+  hg256_store<true>(acc, p.T3, p.ldt, 1, 1, m0, n0, w, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(p.flags + r * tiles_n + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- phase B: out tile (r, c) = sum over chunks j = r .. 0 of Ql'[m][k in chunk j] T3'[n][k in chunk j]
+  zero();
+  {
+    long offA[2][2], offB[2][2];
+    hg256_offsets(w, lane, p.lda2, p.ldt, offA, offB);
+    const uint16_t* Abase = p.A2 + (long)m0 * p.lda2;
+    const uint16_t* Bbase = p.T3 + (long)n0 * p.ldt;
+    auto src = [&](int n, int t) -> const uint16_t* {
+      const int j = n & 3, i = n >> 2;                     // i-th K tile of the sequence
+      const long k0 = (long)((r - (i >> 2)) * 4 + (i & 3)) * TK;   // chunk r - i/4, K tile i%4 inside it
+      const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
+      return ((j & 1) ? Abase : Bbase) + o + k0;
+    };
+    auto pre = [&](int n) {
+      if ((n & 15) != 0) return;                           // first half-tile of a new chunk (n > 0 here)
+      const int jchunk = r - (n >> 4);
+      if (w == 0) {
+        if (lane == 0) {
+          const unsigned* f = p.flags + jchunk * tiles_n + c;
+          unsigned spins = 0;
+          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) { __hip_atomic_store(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      HG_FENCE();
+      __builtin_amdgcn_s_barrier();
+      HG_FENCE();
+    };
+    // the first chunk is this block's own tile: its stores were drained before the barrier above
+    hg256_mainloop(acc, lds, (r + 1) * 4, w, lane, src, pre);
+  }
+  hg256_store<false>(acc, p.out, p.ldo, p.out_bf16, p.out_trans, m0, n0, w, lane);
 }
 
 // dst (bf16) = src or src', 64 x 64 tiles through LDS.  SRC_BF16 selects the source element type.
@@ -610,6 +753,8 @@ static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct HWs {
   uint16_t *Ql, *QlT, *Qr, *QrT, *GT, *T1, *T2, *T3;
+  unsigned* flags;        // hand-off words of the fused triangular pair: [timeout, pad x 3, flags...]
+  int64_t flag_bytes;
   int64_t total;
 };
 
@@ -621,11 +766,14 @@ static HWs hws_layout(char* base, int M, int N) {
   auto take = [&](int64_t bytes) { uint16_t* p = reinterpret_cast<uint16_t*>(base + off); off = align256(off + bytes); return p; };
   k.Ql = take(mm); k.QlT = take(mm); k.Qr = take(nn); k.QrT = take(nn);
   k.GT = take(mn); k.T1 = take(sq); k.T2 = take(mn); k.T3 = take(mn);
+  k.flag_bytes = ((int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2) * 4 + 16 + 15) / 16 * 16;
+  k.flags = reinterpret_cast<unsigned*>(take(k.flag_bytes));
   k.total = off;
   return k;
 }
 
-static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, else 128^2 register-staged);
+static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, fused triangular pair when every
+                                  //    tile gets its own CU, else 128^2 register-staged); 4: auto without the fused pair;
                                   // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
 
 static int launch_hgemm(const uint16_t* A, long lda, const uint16_t* B, long ldb, void* C, long ldc, int c_bf16,
@@ -640,11 +788,53 @@ static int launch_hgemm(const uint16_t* A, long lda, const uint16_t* B, long ldb
   // equal to the 128^2 kernel), and only when the 256^2 tiles fill >= 80 % of the CU slots of their last wave
   const int nt2 = (M / T2) * (N / T2);
   const bool fills = nt2 * 5 >= ((nt2 + 255) / 256) * 256 * 4;
-  const bool use256 = big && ((g_hgemm_variant == 0 && kmode == 0 && fills) || g_hgemm_variant == 3);
+  const bool use256 = big && (((g_hgemm_variant == 0 || g_hgemm_variant == 4) && kmode == 0 && fills) || g_hgemm_variant == 3);
   if (use256) hipLaunchKernelGGL(k_hgemm_nt_256, dim3((M / T2) * (N / T2)), dim3(kThreads2), 0, st, g);
   else if (g_hgemm_variant == 2 && interior && !sym) hipLaunchKernelGGL(k_hgemm_nt_dma, dim3(nt), dim3(kThreads), 0, st, g);
   else hipLaunchKernelGGL(k_hgemm_nt, dim3(nt), dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
+}
+
+static int device_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 1;
+    n = v;
+  }
+  return n;
+}
+
+// T3' = (Ql T2)' and out = Ql' T3 in one launch (k_hgemm_tri_pair_256); false if the shape contract does not hold
+static bool pair_legal(int M, int N) {
+  if (g_hgemm_variant != 0) return false;
+  if ((M % T2) || (N % T2)) return false;
+  const int tiles = (M / T2) * (N / T2);
+  return tiles >= 128 && tiles <= device_cu_count();      // every block resident (one per CU); enough tiles to pay off
+}
+
+// Q, Qt: the triangular factor and its transpose (dimension Mk); B1: the other operand [Nk][Mk]; T3: [Nk][Mk] hand-off
+// buffer; the result tile (rows = factor dimension) is stored plain or transposed.
+// Returns 0 on success, 1 on a launch error, 2 if the grid cannot be co-resident (the caller then runs the two
+// products separately).  The kernel's hand-offs need every block resident: one 128-KiB-LDS block per CU, so the grid
+// must not exceed the CU count and the occupancy query must admit the block (checked once; a cooperative launch
+// would repeat that check on every call for +15-19 us of host time).
+static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, const uint16_t* B1, uint16_t* T3, void* out,
+                           long ldo, int out_trans, int Mk, int Nk, hipStream_t st) {
+  static int blocks_per_cu = -1;
+  if (blocks_per_cu < 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&k_hgemm_tri_pair_256), kThreads2, 0) !=
+        hipSuccess) n = 0;
+    blocks_per_cu = n;
+  }
+  const int grid = (Mk / T2) * (Nk / T2);
+  if (blocks_per_cu < 1 || grid > device_cu_count()) return 2;
+  if (hipMemsetAsync(k.flags, 0, k.flag_bytes, st) != hipSuccess) return 1;
+  HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, k.flags + 4, k.flags};
+  hipLaunchKernelGGL(k_hgemm_tri_pair_256, dim3(grid), dim3(kThreads2), 0, st, p);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 static int launch_cvt(const void* src, int src_bf16, long lds_, uint16_t* dst, long ldd, int rows, int cols,
@@ -679,6 +869,14 @@ int psgd_kron_bf16_set_tuning(int key, int value) {
   return PSGD_ERR_BAD_ARG;
 }
 
+int psgd_kron_bf16_handoff_timeouts(const void* ws, int M, int N) {
+  if (!ws || M <= 0 || N <= 0) return PSGD_ERR_BAD_ARG;
+  HWs k = hws_layout(static_cast<char*>(const_cast<void*>(ws)), M, N);
+  unsigned v = 0;
+  if (hipMemcpy(&v, k.flags, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return PSGD_ERR_LAUNCH;
+  return (int)v;
+}
+
 int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N) {
   if (M <= 0 || N <= 0) return PSGD_ERR_BAD_ARG;
   return hws_layout(nullptr, M, N).total;
@@ -702,10 +900,17 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
     HK(launch_hgemm(k.QlT, M, k.QlT, M, k.T1, M, 1, 0, M, M, M, KHI_M | KHI_N, st, 1));
     // T2 = T1 G               A = T1 [M][K=M], Bt = G' [N][M]
     HK(launch_hgemm(k.T1, M, k.GT, M, k.T2, N, 1, 0, M, N, M, 0, st));
-    // T3 = T2 Qr'             A = T2 [M][K=N], Bt[n][k] = Qr'[k][n] = Qr[n][k] ; k >= n
-    HK(launch_hgemm(k.T2, N, k.Qr, N, k.T3, N, 1, 0, M, N, N, KLO_N, st));
-    // out = T3 Qr             Bt[n][k] = Qr[k][n] = Qr'[n][k] ; k <= n
-    HK(launch_hgemm(k.T3, N, k.QrT, N, out, N, 1, 0, M, N, N, KHI_N, st));
+    // fused pair with the roles of the operands swapped: (T2 Qr')' = Qr T2' and (T3 Qr)' = Qr' T3', i.e. the
+    // triangular factor is the A operand again, T2 [M][N] and T3 [M][N] are the K-contiguous B operands, and the
+    // result tile is stored transposed
+    int fused = pair_legal(N, M) ? launch_tri_pair(k, k.Qr, k.QrT, k.T2, k.T3, out, N, 1, N, M, st) : 2;
+    if (fused == 1) return PSGD_ERR_LAUNCH;
+    if (fused == 2) {
+      // T3 = T2 Qr'             A = T2 [M][K=N], Bt[n][k] = Qr'[k][n] = Qr[n][k] ; k >= n
+      HK(launch_hgemm(k.T2, N, k.Qr, N, k.T3, N, 1, 0, M, N, N, KLO_N, st));
+      // out = T3 Qr             Bt[n][k] = Qr[k][n] = Qr'[n][k] ; k <= n
+      HK(launch_hgemm(k.T3, N, k.QrT, N, out, N, 1, 0, M, N, N, KHI_N, st));
+    }
   } else {                                                                         // psgd.py:191-192
     HK(launch_factor_cvt(Qr, nullptr, k.QrT, N, st));
     HK(launch_factor_cvt(Ql, k.Ql, k.QlT, M, st));
@@ -713,10 +918,14 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
     HK(launch_hgemm(k.QrT, N, k.QrT, N, k.T1, N, 1, 0, N, N, N, KHI_M | KHI_N, st, 1));
     // T2 = G T1               A = G [M][K=N], Bt = T1' = T1 ; stored transposed: T2' [N][M]
     HK(launch_hgemm(Gb, N, k.T1, N, k.T2, M, 1, 1, M, N, N, 0, st));
-    // T3 = Ql T2              A = Ql [M][K=M] (k >= m), Bt = T2' ; stored transposed: T3' [N][M]
-    HK(launch_hgemm(k.Ql, M, k.T2, M, k.T3, M, 1, 1, M, N, M, KLO_M, st));
-    // out = Ql' T3            A = Ql' [M][K=M] (k <= m), Bt = T3'
-    HK(launch_hgemm(k.QlT, M, k.T3, M, out, N, 1, 0, M, N, M, KHI_M, st));
+    int fused = pair_legal(M, N) ? launch_tri_pair(k, k.Ql, k.QlT, k.T2, k.T3, out, N, 0, M, N, st) : 2;
+    if (fused == 1) return PSGD_ERR_LAUNCH;
+    if (fused == 2) {                                      // not fused: the two products as separate launches
+      // T3 = Ql T2              A = Ql [M][K=M] (k >= m), Bt = T2' ; stored transposed: T3' [N][M]
+      HK(launch_hgemm(k.Ql, M, k.T2, M, k.T3, M, 1, 1, M, N, M, KLO_M, st));
+      // out = Ql' T3            A = Ql' [M][K=M] (k <= m), Bt = T3'
+      HK(launch_hgemm(k.QlT, M, k.T3, M, out, N, 1, 0, M, N, M, KHI_M, st));
+    }
   }
   return PSGD_OK;
 }

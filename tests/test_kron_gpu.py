@@ -166,6 +166,7 @@ def test_dense_dense_apply_bf16(psgd, M, N):
         variants.append(2)                            # 128^2 LDS-DMA ring
     if M % 256 == 0 and N % 256 == 0:
         variants.append(3)                            # 256^2 8-phase kernel for every product it can take
+        variants.append(4)                            # auto without the fused triangular pair
     outs = {}
     for variant in variants:
         _lib.load().psgd_kron_bf16_set_tuning(0, variant)
@@ -177,7 +178,9 @@ def test_dense_dense_apply_bf16(psgd, M, N):
     # every variant multiplies the same bf16 operands in the same k order with fp32 accumulation: bitwise equal
     for variant in variants[1:]:
         assert torch.equal(outs[variant], outs[1]), variant
-    assert torch.equal(out, outs[1])
+    # the default may take the fused triangular pair, which sums its K chunks in descending order: same products,
+    # other fp32 summation order, so single bf16 roundings may flip (<= 1 bf16 ulp per element)
+    assert rel_err(out.float().cpu().numpy(), outs[1].float().cpu().numpy()) < 2e-3
 
 
 @pytest.mark.parametrize("M,N", [(4096, 4096), (2048, 1024), (256, 256)])
@@ -192,10 +195,40 @@ def test_bf16_gemm_variants_bitwise_stable(psgd, M, N):
     lib.psgd_kron_bf16_set_tuning(0, 1)
     try:
         want = psgd.precond_grad_kron(Ql, Qr, G)
-        for variant in (3, 0):
+        for variant in (3, 4):
             lib.psgd_kron_bf16_set_tuning(0, variant)
             for _ in range(6):
                 assert torch.equal(psgd.precond_grad_kron(Ql, Qr, G), want), variant
+    finally:
+        lib.psgd_kron_bf16_set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("M,N", [(4096, 4096), (4096, 2048), (8192, 1024), (2048, 4096), (1024, 8192)])
+def test_bf16_fused_triangular_pair(psgd, M, N):
+    """The wavefront-scheduled fused launch of  T3 = Ql T2,  out = Ql' T3  (in-launch hand-offs between workgroups).
+    Checked against the two separate products on a stream of DIFFERENT gradients, so a hand-off that read a stale T3
+    tile (the workspace still holds the previous call's) cannot pass; repeated calls must agree bit for bit; no spin
+    may time out."""
+    from psgd_tf_amd import _lib, kron
+    rng = np.random.default_rng(M + N)
+    Ql, Qr = _dev(_tri_factor(rng, M, 0.01).astype(np.float32)), _dev(_tri_factor(rng, N, 0.01).astype(np.float32))
+    Gs = [torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16) for _ in range(3)]
+    lib = _lib.load()
+    try:
+        lib.psgd_kron_bf16_set_tuning(0, 1)
+        want = [psgd.precond_grad_kron(Ql, Qr, G) for G in Gs]
+        lib.psgd_kron_bf16_set_tuning(0, 0)
+        first = None
+        for rep in range(4):
+            for i in (0, 1, 2, 1, 0):
+                got = psgd.precond_grad_kron(Ql, Qr, Gs[i])
+                assert rel_err(got.float().cpu().numpy(), want[i].float().cpu().numpy()) < 2e-3, (rep, i)
+                if i == 2:
+                    if first is None:
+                        first = got
+                    assert torch.equal(got, first), rep
+        ws = kron._kron_ws_bf16[(Ql.device.index, M, N)]
+        assert lib.psgd_kron_bf16_handoff_timeouts(ws.data_ptr(), M, N) == 0
     finally:
         lib.psgd_kron_bf16_set_tuning(0, 0)
 
