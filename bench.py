@@ -121,8 +121,8 @@ def kron_bench(dev, psgd, iters=20):
         pmc = {"source": "profiles/kron_mfma_pmc.json (rocprofv3 --pmc)", "issued_gflop_per_apply": pmc["issued_flops_per_apply"] / 1e9,
                "issued_gflops": pmc["issued_flops_per_apply"] / t_bf16 / 1e6,
                "frac_of_bf16_peak_issued": pmc["issued_flops_per_apply"] / t_bf16 / 1e6 / 2.5e6,
-               "MfmaUtil_percent": {"k_hgemm_nt_256 (dense product)": pmc["k_hgemm_nt_256"]["mfma_util_percent"],
-                                    "k_hgemm_nt (3 triangular / symmetric products)": pmc["k_hgemm_nt"]["mfma_util_percent"]}}
+               "MfmaUtil_percent": {k: v["mfma_util_percent"] for k, v in pmc["kernels"].items()},
+               "MfmaUtil_percent_time_weighted": pmc["mfma_util_percent_time_weighted"]}
     except Exception:
         pmc = None
     return {
