@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
 // atomic stores = sc1), every storing wave drains vmcnt, the block's barrier, one lane stores the flag with an
 // agent-scope atomic; the consumer polls that one word (one lane, relaxed, bounded), does ONE agent-scope acquire,
 // drains, and the whole block passes a barrier before any wave issues a load of the handed-off bytes.  Flags are
-// zeroed by a memset node before every launch.  All blocks must be resident (grid <= number of CUs, one block per CU:
+// zeroed before every launch (by the factor-conversion kernel that opens the call).  All blocks must be resident (grid <= number of CUs, one block per CU:
 // checked by the launcher); every spin is bounded and reports through a timeout word.
 struct HPairArgs {
   const uint16_t* A1; long lda1;   // Ql  [M][M]   (k >= m)
@@ -703,12 +703,19 @@ __global__ __launch_bounds__(kThreads) void k_to_bf16(const void* src, long lds_
 // bf16 copies of an upper-triangular fp32 factor Q [n][n]: dst = bf16(Q) and/or dstT = bf16(Q').  64 x 64 tiles,
 // 16-byte global accesses on both sides.  Only the 256 x 256 blocks on or above the block diagonal are touched:
 // the GEMMs restrict their K ranges at tile granularity (<= 256), so they never read the rest of the copies.
-template <bool WRITE_N, bool WRITE_T>
-__global__ __launch_bounds__(kThreads) void k_factor_to_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst,
-                                                             uint16_t* __restrict__ dstT, int n) {
+// Both factors of a call in ONE launch (blockIdx.z selects the job); block (0,0,0) also zeroes the hand-off words of
+// the fused triangular pair, which runs later on the same stream.
+struct FactorJob { const float* src; uint16_t* dst; uint16_t* dstT; int n; };
+
+__global__ __launch_bounds__(kThreads) void k_factors_to_bf16(FactorJob j0, FactorJob j1, unsigned* zero_words, int nzero) {
   __shared__ uint16_t tile[64][72];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < nzero; i += kThreads) zero_words[i] = 0u;
+  const FactorJob j = blockIdx.z ? j1 : j0;
+  const float* __restrict__ src = j.src;
+  const int n = j.n;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  if ((r0 >> 8) > (c0 >> 8)) return;
+  if (r0 >= n || c0 >= n || (r0 >> 8) > (c0 >> 8)) return;
   const int t = threadIdx.x, row = t >> 2, cq = (t & 3) * 16;
   uint16_t v[16];
 #pragma unroll
@@ -718,7 +725,7 @@ __global__ __launch_bounds__(kThreads) void k_factor_to_bf16(const float* __rest
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[4 * q + e] = f2bf(x[e]);
   }
-  if constexpr (WRITE_N) {
+  if (j.dst) {
     if (r0 + row < n) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -726,11 +733,11 @@ __global__ __launch_bounds__(kThreads) void k_factor_to_bf16(const float* __rest
           u32x4 pk;
 #pragma unroll
           for (int e = 0; e < 4; ++e) pk[e] = (unsigned)v[8 * h + 2 * e] | ((unsigned)v[8 * h + 2 * e + 1] << 16);
-          *reinterpret_cast<u32x4*>(dst + (long)(r0 + row) * n + c0 + cq + 8 * h) = pk;
+          *reinterpret_cast<u32x4*>(j.dst + (long)(r0 + row) * n + c0 + cq + 8 * h) = pk;
         }
     }
   }
-  if constexpr (WRITE_T) {
+  if (j.dstT) {                                   // uniform per block
 #pragma unroll
     for (int e = 0; e < 16; ++e) tile[row][cq + e] = v[e];
     __syncthreads();
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(kThreads) void k_factor_to_bf16(const float* __rest
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             pk[e] = (unsigned)tile[bq + 8 * h + 2 * e][a] | ((unsigned)tile[bq + 8 * h + 2 * e + 1][a] << 16);
-          *reinterpret_cast<u32x4*>(dstT + (long)(c0 + a) * n + r0 + bq + 8 * h) = pk;
+          *reinterpret_cast<u32x4*>(j.dstT + (long)(c0 + a) * n + r0 + bq + 8 * h) = pk;
         }
     }
   }
@@ -831,7 +838,7 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
   }
   const int grid = (Mk / T2) * (Nk / T2);
   if (blocks_per_cu < 1 || grid > device_cu_count()) return 2;
-  if (hipMemsetAsync(k.flags, 0, k.flag_bytes, st) != hipSuccess) return 1;
+  // the hand-off words were zeroed by k_factors_to_bf16 earlier on this stream
   HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, k.flags + 4, k.flags};
   hipLaunchKernelGGL(k_hgemm_tri_pair_256, dim3(grid), dim3(kThreads2), 0, st, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
@@ -845,11 +852,10 @@ static int launch_cvt(const void* src, int src_bf16, long lds_, uint16_t* dst, l
   return (int)hipGetLastError();
 }
 
-static int launch_factor_cvt(const float* Q, uint16_t* dst, uint16_t* dstT, int n, hipStream_t st) {
-  dim3 grid((n + 63) / 64, (n + 63) / 64);
-  if (dst && dstT) hipLaunchKernelGGL((k_factor_to_bf16<true, true>), grid, dim3(kThreads), 0, st, Q, dst, dstT, n);
-  else if (dstT) hipLaunchKernelGGL((k_factor_to_bf16<false, true>), grid, dim3(kThreads), 0, st, Q, dst, dstT, n);
-  else hipLaunchKernelGGL((k_factor_to_bf16<true, false>), grid, dim3(kThreads), 0, st, Q, dst, dstT, n);
+static int launch_factors_cvt(const HWs& k, FactorJob j0, FactorJob j1, hipStream_t st) {
+  const int n = j0.n > j1.n ? j0.n : j1.n;
+  dim3 grid((n + 63) / 64, (n + 63) / 64, 2);
+  hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, j0, j1, k.flags, (int)(k.flag_bytes / 4));
   return (int)hipGetLastError();
 }
 
@@ -893,8 +899,7 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
   HWs k = hws_layout(static_cast<char*>(ws), M, N);
   const uint16_t* Gb = static_cast<const uint16_t*>(G);
   if (M < N) {                                                                     // psgd.py:189-190
-    HK(launch_factor_cvt(Ql, nullptr, k.QlT, M, st));
-    HK(launch_factor_cvt(Qr, k.Qr, k.QrT, N, st));
+    HK(launch_factors_cvt(k, FactorJob{Ql, nullptr, k.QlT, M}, FactorJob{Qr, k.Qr, k.QrT, N}, st));
     HK(launch_cvt(G, 1, N, k.GT, M, M, N, 1, st));
     // T1 = Ql'Ql              A = Ql' [M][K=M], Bt = Ql' ; k <= min(m, n); symmetric: upper tiles computed, stored twice
     HK(launch_hgemm(k.QlT, M, k.QlT, M, k.T1, M, 1, 0, M, M, M, KHI_M | KHI_N, st, 1));
@@ -912,8 +917,7 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
       HK(launch_hgemm(k.T3, N, k.QrT, N, out, N, 1, 0, M, N, N, KHI_N, st));
     }
   } else {                                                                         // psgd.py:191-192
-    HK(launch_factor_cvt(Qr, nullptr, k.QrT, N, st));
-    HK(launch_factor_cvt(Ql, k.Ql, k.QlT, M, st));
+    HK(launch_factors_cvt(k, FactorJob{Qr, nullptr, k.QrT, N}, FactorJob{Ql, k.Ql, k.QlT, M}, st));
     // T1 = Qr'Qr  (symmetric, so it is its own Bt layout; upper tiles computed, stored twice)
     HK(launch_hgemm(k.QrT, N, k.QrT, N, k.T1, N, 1, 0, N, N, N, KHI_M | KHI_N, st, 1));
     // T2 = G T1               A = G [M][K=N], Bt = T1' = T1 ; stored transposed: T2' [N][M]
