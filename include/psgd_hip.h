@@ -255,7 +255,8 @@ int psgd_kron_ns_apply_f32(const float *ql, const float *qr, const float *G, int
 int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
 /* Experiment knob (not stable ABI). key 0: bf16 GEMM variant: 0 auto (256^2 8-phase kernel for large dense
  * products, fused triangular pair when every 256^2 tile gets its own CU, 128^2 register-staged otherwise);
- * 1 128^2 register-staged everywhere; 2 128^2 LDS-DMA ring; 3 256^2 for every product; 4 auto without the fused pair. */
+ * 1 128^2 register-staged everywhere; 2 128^2 LDS-DMA ring; 3 256^2 for every product; 4 auto without the fused pair.
+ * key 1: 1 (default) two fused triangular pairs, (G Qr') Qr then Ql' (Ql .), where legal; 0 keep the Gram-first chain. */
 int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,

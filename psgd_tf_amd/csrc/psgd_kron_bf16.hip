@@ -760,7 +760,7 @@ static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct HWs {
   uint16_t *Ql, *QlT, *Qr, *QrT, *GT, *T1, *T2, *T3;
-  unsigned* flags;        // hand-off words of the fused triangular pair: [timeout, pad x 3, flags...]
+  unsigned* flags;        // hand-off words of the fused triangular pairs: [timeout, pad x 3, flag set 0, flag set 1]
   int64_t flag_bytes;
   int64_t total;
 };
@@ -773,12 +773,13 @@ static HWs hws_layout(char* base, int M, int N) {
   auto take = [&](int64_t bytes) { uint16_t* p = reinterpret_cast<uint16_t*>(base + off); off = align256(off + bytes); return p; };
   k.Ql = take(mm); k.QlT = take(mm); k.Qr = take(nn); k.QrT = take(nn);
   k.GT = take(mn); k.T1 = take(sq); k.T2 = take(mn); k.T3 = take(mn);
-  k.flag_bytes = ((int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2) * 4 + 16 + 15) / 16 * 16;
+  k.flag_bytes = ((int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2) * 8 + 16 + 15) / 16 * 16;   // two flag sets
   k.flags = reinterpret_cast<unsigned*>(take(k.flag_bytes));
   k.total = off;
   return k;
 }
 
+static int g_two_pairs = 1;       // tuning key 1: 0 = keep the Gram-first chain even where two fused pairs are possible
 static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, fused triangular pair when every
                                   //    tile gets its own CU, else 128^2 register-staged); 4: auto without the fused pair;
                                   // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
@@ -828,7 +829,7 @@ static bool pair_legal(int M, int N) {
 // must not exceed the CU count and the occupancy query must admit the block (checked once; a cooperative launch
 // would repeat that check on every call for +15-19 us of host time).
 static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, const uint16_t* B1, uint16_t* T3, void* out,
-                           long ldo, int out_trans, int Mk, int Nk, hipStream_t st) {
+                           long ldo, int out_trans, int Mk, int Nk, hipStream_t st, int flag_set = 0) {
   static int blocks_per_cu = -1;
   if (blocks_per_cu < 0) {
     int n = 0;
@@ -839,7 +840,7 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
   const int grid = (Mk / T2) * (Nk / T2);
   if (blocks_per_cu < 1 || grid > device_cu_count()) return 2;
   // the hand-off words were zeroed by k_factors_to_bf16 earlier on this stream
-  HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, k.flags + 4, k.flags};
+  HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, k.flags + 4 + flag_set * grid, k.flags};
   hipLaunchKernelGGL(k_hgemm_tri_pair_256, dim3(grid), dim3(kThreads2), 0, st, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -872,6 +873,7 @@ extern "C" {
 
 int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 0) { g_hgemm_variant = value; return PSGD_OK; }
+  if (key == 1) { g_two_pairs = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -898,6 +900,20 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
   hipStream_t st = static_cast<hipStream_t>(stream);
   HWs k = hws_layout(static_cast<char*>(ws), M, N);
   const uint16_t* Gb = static_cast<const uint16_t*>(G);
+  if (pair_legal(M, N) && g_two_pairs) {
+    // Two fused triangular pairs and no Gram:  out = Ql' (Ql ((G Qr') Qr)).  Same product as psgd.py:189-192 with the
+    // Gram Qr'Qr (resp. Ql'Ql) re-associated into the chain: (G Qr') Qr costs the flops of the dense G (Qr'Qr) alone,
+    // and both halves have the complementary-K structure the wavefront kernel balances.  bf16 path only (one bf16
+    // rounding moves from the Gram to G Qr'); the fp32 path keeps the reference's association order.
+    HK(launch_factors_cvt(k, FactorJob{Qr, k.Qr, k.QrT, N}, FactorJob{Ql, k.Ql, k.QlT, M}, st));
+    // right pair: Y' [N][M] = ((G Qr') Qr)'   -- triangular factor Qr as the A operand, G [M][N] the K-contiguous B operand
+    int rc1 = launch_tri_pair(k, k.Qr, k.QrT, Gb, k.T3, k.T2, M, 0, N, M, st, 0);
+    // left pair: out [M][N] = Ql' (Ql Y)      -- B operand Y' [N][M]
+    int rc2 = rc1 ? rc1 : launch_tri_pair(k, k.Ql, k.QlT, k.T2, k.T3, out, N, 0, M, N, st, 1);
+    if (rc1 == 0 && rc2 == 0) return PSGD_OK;
+    if (rc1 == 1 || rc2 == 1) return PSGD_ERR_LAUNCH;
+    // not resident-able (2): fall through to the staged chain below (nothing was launched besides the conversions)
+  }
   if (M < N) {                                                                     // psgd.py:189-190
     HK(launch_factors_cvt(k, FactorJob{Ql, nullptr, k.QlT, M}, FactorJob{Qr, k.Qr, k.QrT, N}, st));
     HK(launch_cvt(G, 1, N, k.GT, M, M, N, 1, st));

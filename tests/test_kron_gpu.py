@@ -178,9 +178,9 @@ def test_dense_dense_apply_bf16(psgd, M, N):
     # every variant multiplies the same bf16 operands in the same k order with fp32 accumulation: bitwise equal
     for variant in variants[1:]:
         assert torch.equal(outs[variant], outs[1]), variant
-    # the default may take the fused triangular pair, which sums its K chunks in descending order: same products,
-    # other fp32 summation order, so single bf16 roundings may flip (<= 1 bf16 ulp per element)
-    assert rel_err(out.float().cpu().numpy(), outs[1].float().cpu().numpy()) < 2e-3
+    # the default may take the fused triangular pairs: K chunks summed in descending order and the Gram re-associated
+    # into the chain ((G Qr') Qr), so single bf16 roundings fall elsewhere
+    assert rel_err(out.float().cpu().numpy(), outs[1].float().cpu().numpy()) < 1e-2
 
 
 @pytest.mark.parametrize("M,N", [(4096, 4096), (2048, 1024), (256, 256)])
@@ -218,19 +218,24 @@ def test_bf16_fused_triangular_pair(psgd, M, N):
         lib.psgd_kron_bf16_set_tuning(0, 1)
         want = [psgd.precond_grad_kron(Ql, Qr, G) for G in Gs]
         lib.psgd_kron_bf16_set_tuning(0, 0)
-        first = None
-        for rep in range(4):
-            for i in (0, 1, 2, 1, 0):
-                got = psgd.precond_grad_kron(Ql, Qr, Gs[i])
-                assert rel_err(got.float().cpu().numpy(), want[i].float().cpu().numpy()) < 2e-3, (rep, i)
-                if i == 2:
-                    if first is None:
-                        first = got
-                    assert torch.equal(got, first), rep
-        ws = kron._kron_ws_bf16[(Ql.device.index, M, N)]
-        assert lib.psgd_kron_bf16_handoff_timeouts(ws.data_ptr(), M, N) == 0
+        # two_pairs = 0: Gram first, then ONE fused pair (same association as the staged chain: <= 1 bf16 ulp apart);
+        # two_pairs = 1 (default): (G Qr') Qr then Ql' (Ql .): one bf16 rounding sits elsewhere
+        for two_pairs, tol in ((0, 2e-3), (1, 1e-2)):
+            lib.psgd_kron_bf16_set_tuning(1, two_pairs)
+            first = None
+            for rep in range(3):
+                for i in (0, 1, 2, 1, 0):
+                    got = psgd.precond_grad_kron(Ql, Qr, Gs[i])
+                    assert rel_err(got.float().cpu().numpy(), want[i].float().cpu().numpy()) < tol, (two_pairs, rep, i)
+                    if i == 2:
+                        if first is None:
+                            first = got
+                        assert torch.equal(got, first), (two_pairs, rep)
+            ws = kron._kron_ws_bf16[(Ql.device.index, M, N)]
+            assert lib.psgd_kron_bf16_handoff_timeouts(ws.data_ptr(), M, N) == 0
     finally:
         lib.psgd_kron_bf16_set_tuning(0, 0)
+        lib.psgd_kron_bf16_set_tuning(1, 1)
 
 
 def test_bf16_path_rejects_odd_shapes(psgd):
