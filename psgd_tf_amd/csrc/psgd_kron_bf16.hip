@@ -585,6 +585,7 @@ struct HPairArgs {
   const uint16_t* A2; long lda2;   // Ql' [M][M]   (k <= m)
   void* out; long ldo; int out_bf16, out_trans;
   int M, N;                        // M = the triangular factor's dimension (tile rows), N = the other one
+  int c_begin, c_count;            // tile columns of this launch (hand-offs stay inside a column)
   unsigned* flags;                 // [M/256][N/256], zeroed before the launch
   unsigned* timeout;               // set to 1 if a spin gave up
 };
@@ -596,15 +597,14 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
   // blocks b, b + 8, ... share an XCD: give each XCD whole tile columns (the hand-offs of a column stay on one L2
   // when the column count allows); rows ascend with the block index inside a column
   int r, c;
-  if (tiles_n % 8 == 0) {
-    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8, cpx = tiles_n / 8;
-    c = xcd * cpx + j / tiles_m;
+  if (p.c_count % 8 == 0) {
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8, cpx = p.c_count / 8;
+    c = p.c_begin + xcd * cpx + j / tiles_m;
     r = j % tiles_m;
   } else {
-    c = blockIdx.x / tiles_m;
+    c = p.c_begin + blockIdx.x / tiles_m;
     r = blockIdx.x % tiles_m;
   }
-  (void)tiles_n;
   const int m0 = r * T2, n0 = c * T2;
 
   f32x4 acc[8][4];
@@ -819,7 +819,9 @@ static bool pair_legal(int M, int N) {
   if (g_hgemm_variant != 0) return false;
   if ((M % T2) || (N % T2)) return false;
   const int tiles = (M / T2) * (N / T2);
-  return tiles >= 128 && tiles <= device_cu_count();      // every block resident (one per CU); enough tiles to pay off
+  // a launch takes whole tile columns (hand-offs stay inside a column) and must be fully resident, one block per CU;
+  // below ~128 tiles the 128^2 kernels have more parallelism
+  return tiles >= 128 && (M / T2) <= device_cu_count();
 }
 
 // Q, Qt: the triangular factor and its transpose (dimension Mk); B1: the other operand [Nk][Mk]; T3: [Nk][Mk] hand-off
@@ -837,12 +839,20 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
         hipSuccess) n = 0;
     blocks_per_cu = n;
   }
-  const int grid = (Mk / T2) * (Nk / T2);
-  if (blocks_per_cu < 1 || grid > device_cu_count()) return 2;
+  const int tiles_m = Mk / T2, tiles_n = Nk / T2;
+  if (blocks_per_cu < 1 || tiles_m > device_cu_count()) return 2;
+  int cpl = device_cu_count() / tiles_m;                 // tile columns per launch
+  if (cpl >= 8) cpl = cpl / 8 * 8;                       // whole columns per XCD
+  if (cpl > tiles_n) cpl = tiles_n;
   // the hand-off words were zeroed by k_factors_to_bf16 earlier on this stream
-  HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, k.flags + 4 + flag_set * grid, k.flags};
-  hipLaunchKernelGGL(k_hgemm_tri_pair_256, dim3(grid), dim3(kThreads2), 0, st, p);
-  return hipGetLastError() == hipSuccess ? 0 : 1;
+  for (int c0 = 0; c0 < tiles_n; c0 += cpl) {
+    const int cc = (tiles_n - c0 < cpl) ? tiles_n - c0 : cpl;
+    HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, c0, cc,
+                   k.flags + 4 + flag_set * tiles_m * tiles_n, k.flags};
+    hipLaunchKernelGGL(k_hgemm_tri_pair_256, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
+    if (hipGetLastError() != hipSuccess) return 1;
+  }
+  return 0;
 }
 
 static int launch_cvt(const void* src, int src_bf16, long lds_, uint16_t* dst, long ldd, int rows, int cols,

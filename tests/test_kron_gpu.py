@@ -203,7 +203,8 @@ def test_bf16_gemm_variants_bitwise_stable(psgd, M, N):
         lib.psgd_kron_bf16_set_tuning(0, 0)
 
 
-@pytest.mark.parametrize("M,N", [(4096, 4096), (4096, 2048), (8192, 1024), (2048, 4096), (1024, 8192)])
+@pytest.mark.parametrize("M,N", [(4096, 4096), (4096, 2048), (8192, 1024), (2048, 4096), (1024, 8192),
+                                 (8192, 4096), (6144, 6144)])      # the last two: several column-group launches
 def test_bf16_fused_triangular_pair(psgd, M, N):
     """The wavefront-scheduled fused launch of  T3 = Ql T2,  out = Ql' T3  (in-launch hand-offs between workgroups).
     Checked against the two separate products on a stream of DIFFERENT gradients, so a hand-off that read a stale T3
