@@ -357,7 +357,11 @@ struct SpluGeom {
 static SpluGeom splu_geom(int64_t N, int r) {
   SpluGeom g;
   g.n2 = N - r;
-  int h = (r & 1) ? ((4 - (r & 3)) & 3) : 0;   // (r + h) * r floats = a multiple of 16 bytes
+  // The streamed part starts `head` rows into the tail so that (r + head) is a multiple of 32 rows: the L2 tiles then
+  // start on a 16-byte boundary for every r ((r + head) r floats), and the r column streams of U2 (row k of U12 starts
+  // k N + r floats into the buffer) start on a 128-byte line whenever N is a multiple of 32 -- unaligned 256-byte
+  // wave accesses straddle an extra line that the neighbouring tile fetches again (+13 % fetched bytes measured).
+  int h = (32 - (r & 31)) & 31;
   if (h > g.n2) h = (int)g.n2;
   g.head = h;
   g.n2s = g.n2 - h;
@@ -411,8 +415,8 @@ int psgd_splu_apply_f32(const float* L12, const float* l3, const float* U12, con
   float* out2 = out + r;
   const int rblocks = (r + kWavesPerBlock - 1) / kWavesPerBlock;
 
-  int grid = splu_grid(ops, r, 0, ge.n2, false);
-  PSGD_CHECK_LAUNCH(ops->u2dot(nt, U2, ge.ldu, g + r, ge.n2, w.part, grid, st));
+  int grid = splu_grid(ops, r, 0, ge.n2s, false);
+  PSGD_CHECK_LAUNCH(ops->u2dot(nt, U2 + ge.head, ge.ldu, g + r + ge.head, ge.n2s, ge.head, w.part, grid, st));
   hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumA);
   hipLaunchKernelGGL(k_splu_corner1, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, g, (const float*)nullptr, w.dbl,
                      w.coef);
@@ -424,8 +428,9 @@ int psgd_splu_apply_f32(const float* L12, const float* l3, const float* U12, con
   hipLaunchKernelGGL(k_splu_corner_apply2, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, w.dbl, w.coef, out);
   PSGD_CHECK_LAUNCH(last_launch());
   if (ge.n2 > 0) {
-    grid = splu_grid(ops, r, 2, ge.n2, false);
-    PSGD_CHECK_LAUNCH(ops->apply_s3(nt, U2, ge.ldu, l3, u3, out2, ge.n2, w.coef, grid, st));
+    grid = splu_grid(ops, r, 2, ge.n2s, false);
+    PSGD_CHECK_LAUNCH(ops->apply_s3(nt, U2 + ge.head, ge.ldu, l3 + ge.head, u3 + ge.head, out2 + ge.head, ge.n2s, ge.head,
+                                    w.coef, grid, st));
   }
   return PSGD_OK;
 }
@@ -451,8 +456,8 @@ int psgd_splu_update_f32(const float* L12, const float* l3, const float* U12, co
   const int rblocks = (r + kWavesPerBlock - 1) / kWavesPerBlock;
   const int r2blocks = (2 * r + kWavesPerBlock - 1) / kWavesPerBlock;
 
-  int grid = splu_grid(ops, r, 0, ge.n2, false);
-  PSGD_CHECK_LAUNCH(ops->u2dot(nt, U2, ge.ldu, g2, ge.n2, w.part, grid, st));
+  int grid = splu_grid(ops, r, 0, ge.n2s, false);
+  PSGD_CHECK_LAUNCH(ops->u2dot(nt, U2 + h, ge.ldu, g2 + h, ge.n2s, h, w.part, grid, st));
   hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumA);
   hipLaunchKernelGGL(k_splu_corner1, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dg, dx, w.dbl, w.coef);
   PSGD_CHECK_LAUNCH(last_launch());

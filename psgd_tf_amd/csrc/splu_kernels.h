@@ -22,8 +22,9 @@
 //         rather than stored by s2: a thin output stream costs far more than its bytes on this memory
 //         system (profiles/r01_store_stream_microbench.txt), and the update sweeps stay read-only until s4.
 //
-// The first rows of the tail are handled by a scalar "head" path (block 0) so that the LDS-staged
-// tiles of L2 start on a 16-byte boundary for every r (L2 starts r*r floats into L12).
+// The first rows of the tail are handled by a scalar "head" path (block 0) so that the streamed part starts at a
+// row where r + head is a multiple of 32: 16-byte aligned L2 tiles for every r, 128-byte aligned U2 column streams
+// whenever N is a multiple of 32.
 #pragma once
 #include "uvd_kernels.h"
 
@@ -115,9 +116,21 @@ __device__ __forceinline__ void sweep_cols(const float* const (&vecs)[NVEC], lon
   }
 }
 
+// rows [-head, 0) relative to the (already shifted) pointers of a column sweep, one lane each, block 0 only
+template <int NVEC, class Body>
+__device__ __forceinline__ void cols_head(const float* const (&vecs)[NVEC], int head, Body&& body) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < head) {
+    const long row = (long)threadIdx.x - head;
+    float s[NVEC];
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k) s[k] = vecs[k][row];
+    body(row, true, s);
+  }
+}
+
 // part[k] = sum_i U2[k][i] x[i]      psgd.py:430 / :506 (second matmul)
 template <int R, bool NT>
-__global__ __launch_bounds__(kThreads) void k_splu_u2dot(const float* U2, long ldu, const float* x, long n2,
+__global__ __launch_bounds__(kThreads) void k_splu_u2dot(const float* U2, long ldu, const float* x, long n2, int head,
                                                          float* part) {
   constexpr int NV = R + 1;
   __shared__ float lds[kWavesPerBlock][ColCfg<NV>::kLdsFloats];
@@ -130,10 +143,12 @@ __global__ __launch_bounds__(kThreads) void k_splu_u2dot(const float* U2, long l
   for (int k = 0; k < R; ++k) vecs_[k] = U2 + k * ldu;
   vecs_[R] = x;
   const float* const (&vecs)[NV] = reinterpret_cast<const float* const (&)[NV]>(vecs_);
-  sweep_cols<NV, NT>(vecs, n2, lds[threadIdx.x >> 6], [&](long, bool, float (&s)[NV]) {
+  auto body = [&](long, bool, float (&s)[NV]) {
 #pragma unroll
     for (int k = 0; k < R; ++k) acc[k] = fmaf(s[k], s[R], acc[k]);
-  });
+  };
+  sweep_cols<NV, NT>(vecs, n2, lds[threadIdx.x >> 6], body);
+  cols_head<NV>(vecs, head, body);
   block_sum_store<R>(acc, red, part);
 }
 
@@ -164,7 +179,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_apply_s2(const float* L2s, co
 // apply sweep 3: out2 = U2' LtQg1 + u3 (l3 Qg2), in place on the buffer holding Qg2      psgd.py:513,516
 template <int R, bool NT>
 __global__ __launch_bounds__(kThreads) void k_splu_apply_s3(const float* U2, long ldu, const float* l3, const float* u3,
-                                                            float* out2, long n2, const float* __restrict__ coef) {
+                                                            float* out2, long n2, int head,
+                                                            const float* __restrict__ coef) {
   constexpr int NV = R + 3;
   __shared__ float lds[kWavesPerBlock][ColCfg<NV>::kLdsFloats];
   const float* vecs_[NV];
@@ -172,12 +188,14 @@ __global__ __launch_bounds__(kThreads) void k_splu_apply_s3(const float* U2, lon
   for (int k = 0; k < R; ++k) vecs_[k] = U2 + k * ldu;
   vecs_[R] = l3; vecs_[R + 1] = u3; vecs_[R + 2] = out2;
   const float* const (&vecs)[NV] = reinterpret_cast<const float* const (&)[NV]>(vecs_);
-  sweep_cols<NV, NT>(vecs, n2, lds[threadIdx.x >> 6], [&](long row, bool valid, float (&s)[NV]) {
+  auto body = [&](long row, bool valid, float (&s)[NV]) {
     float o = s[R + 1] * (s[R] * s[R + 2]);
 #pragma unroll
     for (int k = 0; k < R; ++k) o = fmaf(s[k], coef[k], o);
     if (valid) stream_store<NT>(out2 + row, o);
-  });
+  };
+  sweep_cols<NV, NT>(vecs, n2, lds[threadIdx.x >> 6], body);
+  cols_head<NV>(vecs, head, body);
 }
 
 // coefficient block of update sweeps 3 and 4 (floats)
@@ -359,10 +377,10 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s4(const float* L2s, cons
 struct SpluOps {
   int tile_rows;
   int lds_apply_s2, lds_upd_s2, lds_upd_s3, lds_upd_s4;   // dynamic LDS bytes per block
-  int (*u2dot)(int nt, const float* U2, long ldu, const float* x, long n2, float* part, int grid, hipStream_t st);
+  int (*u2dot)(int nt, const float* U2, long ldu, const float* x, long n2, int head, float* part, int grid, hipStream_t st);
   int (*apply_s2)(int nt, const float* L2s, const float* l3, const float* u3, const float* g2, float* qg2, long n2s,
                   int head, const float* coef, float* part, int grid, hipStream_t st);
-  int (*apply_s3)(int nt, const float* U2, long ldu, const float* l3, const float* u3, float* out2, long n2,
+  int (*apply_s3)(int nt, const float* U2, long ldu, const float* l3, const float* u3, float* out2, long n2, int head,
                   const float* coef, int grid, hipStream_t st);
   int (*upd_s2)(int nt, const float* L2s, const float* U2s, long ldu, const float* l3, const float* u3, const float* x2,
                 const float* g2, long n2s, int head, const float* coef, float* part, int grid, hipStream_t st);

@@ -37,17 +37,18 @@ struct SpluLaunch {
   static constexpr int kLdsU3 = splu_lds_bytes<R, R + 4, R>();
   static constexpr int kLdsU4 = splu_lds_bytes<R, R + 4, 0>();
 
-  static int u2dot(int nt, const float* U2, long ldu, const float* x, long n2, float* part, int grid, hipStream_t st) {
-    SPLU_LAUNCH((k_splu_u2dot<R, true>), (k_splu_u2dot<R, false>), 0, U2, ldu, x, n2, part);
+  static int u2dot(int nt, const float* U2, long ldu, const float* x, long n2, int head, float* part, int grid,
+                   hipStream_t st) {
+    SPLU_LAUNCH((k_splu_u2dot<R, true>), (k_splu_u2dot<R, false>), 0, U2, ldu, x, n2, head, part);
   }
   static int apply_s2(int nt, const float* L2s, const float* l3, const float* u3, const float* g2, float* qg2, long n2s,
                       int head, const float* coef, float* part, int grid, hipStream_t st) {
     SPLU_LAUNCH((k_splu_apply_s2<R, true>), (k_splu_apply_s2<R, false>), kLdsA2, L2s, l3, u3, g2, qg2, n2s, head, coef,
                 part);
   }
-  static int apply_s3(int nt, const float* U2, long ldu, const float* l3, const float* u3, float* out2, long n2,
+  static int apply_s3(int nt, const float* U2, long ldu, const float* l3, const float* u3, float* out2, long n2, int head,
                       const float* coef, int grid, hipStream_t st) {
-    SPLU_LAUNCH((k_splu_apply_s3<R, true>), (k_splu_apply_s3<R, false>), 0, U2, ldu, l3, u3, out2, n2, coef);
+    SPLU_LAUNCH((k_splu_apply_s3<R, true>), (k_splu_apply_s3<R, false>), 0, U2, ldu, l3, u3, out2, n2, head, coef);
   }
   static int upd_s2(int nt, const float* L2s, const float* U2s, long ldu, const float* l3, const float* u3,
                     const float* x2, const float* g2, long n2s, int head, const float* coef, float* part, int grid,

@@ -127,10 +127,11 @@ def hip_backend_for(U):
 
 
 def shard_rows(n_global, rank, world):
-    """Contiguous row block of rank `rank`: [lo, hi).  Block starts are multiples of 4 rows so that
-    every shard of a 16-byte aligned [N, r] array stays 16-byte aligned for any r."""
+    """Contiguous row block of rank `rank`: [lo, hi).  Block starts are multiples of 64 rows: every shard of an
+    aligned [N, r] array stays 16-byte aligned for any r, and the per-row vectors (d, g, v, h) of a shard start on a
+    256-byte boundary, so the tiles of the sweeps cover whole 128-byte lines."""
     per = -(-n_global // world)
-    per = (per + 3) // 4 * 4
+    per = (per + 63) // 64 * 64
     lo = min(rank * per, n_global)
     hi = min(lo + per, n_global)
     return lo, hi

@@ -106,4 +106,4 @@ def test_shard_rows_cover_and_align():
         assert edges[0][0] == 0 and edges[-1][1] == n
         for (lo, hi), (lo2, _) in zip(edges, edges[1:]):
             assert hi == lo2 and lo <= hi
-        assert all(lo % 4 == 0 for lo, hi in edges if hi > lo)
+        assert all(lo % 64 == 0 for lo, hi in edges if hi > lo)
