@@ -410,10 +410,24 @@ __device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __
   const long xi = (t.xi == 0 && t.xj == 0) ? t.si : t.xi, xj = (t.xi == 0 && t.xj == 0) ? t.sj : t.xj;
   const int n = t.n;
   const int npad = (n + 31) & ~31;
-  for (int e = tid; e < 64 * npad; e += kThreads) {
-    int v, j;
-    if (xj == 1) { j = e % npad; v = e / npad; } else { v = e & 63; j = e >> 6; }
-    S[v * pitch + j] = (v0 + v < t.nvec && j < n) ? t.X[(long)(v0 + v) * xi + (long)j * xj] : 0.0f;
+  // strip in: 8 independent loads in flight per thread (the plain loop paid one memory latency per element: the load
+  // and store phases together were ~3/4 of the kernel's time)
+  for (int e0 = tid; e0 < 64 * npad; e0 += kThreads * 8) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * kThreads;
+      int v, j;
+      if (xj == 1) { j = e % npad; v = e / npad; } else { v = e & 63; j = e >> 6; }
+      x[u] = (e < 64 * npad && v0 + v < t.nvec && j < n) ? t.X[(long)(v0 + v) * xi + (long)j * xj] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * kThreads;
+      int v, j;
+      if (xj == 1) { j = e % npad; v = e / npad; } else { v = e & 63; j = e >> 6; }
+      if (e < 64 * npad) S[v * pitch + j] = x[u];
+    }
   }
   for (int j0 = 0; j0 < n; j0 += 32) {
     for (int e = tid; e < 1024; e += kThreads) Dd[e >> 5][e & 31] = Dinv[(long)(j0 >> 5) * 1024 + e];
@@ -435,12 +449,24 @@ __device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __
     __syncthreads();
     const int c_begin = j0 + 32;
     const int ncb = (n > c_begin) ? (n - c_begin + 15) / 16 : 0;
-    for (int cb = w; cb < ncb; cb += 4) {
-      const int col = c_begin + cb * 16 + (lane & 15);
-      const bool cok = col < n;
-      float bq[8];
+    // trailing update of the strip: this wave's column blocks cb = w, w + 4, ... (at most kStripN / 64 = 8 of them).
+    // All their Q panels are requested before the first one is used, so one memory latency is paid per 32-wide
+    // sub-step instead of one per column block (the solve was a chain of ~100 exposed latencies per strip).
+    constexpr int kMaxIt = kStripN / 64;
+    float bq[kMaxIt][8];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) bq[kk] = cok ? t.Q[(long)(j0 + kk * 4 + (lane >> 4)) * t.ldq + col] : 0.0f;
+    for (int it = 0; it < kMaxIt; ++it) {
+      const int cb = w + 4 * it;
+      const int col = c_begin + cb * 16 + (lane & 15);
+      const bool cok = (cb < ncb) && (col < n);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) bq[it][kk] = cok ? t.Q[(long)(j0 + kk * 4 + (lane >> 4)) * t.ldq + col] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+      const int cb = w + 4 * it;
+      if (cb >= ncb) break;
+      const int col = c_begin + cb * 16 + (lane & 15);
       f32x4 acc[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -450,7 +476,7 @@ __device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __
       for (int kk = 0; kk < 8; ++kk) {
         const int k = j0 + kk * 4 + (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(-S[(i * 16 + (lane & 15)) * pitch + k], bq[kk], acc[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(-S[(i * 16 + (lane & 15)) * pitch + k], bq[it][kk], acc[i], 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -459,6 +485,7 @@ __device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __
     }
     __syncthreads();
   }
+#pragma unroll 8
   for (int e = tid; e < 64 * n; e += kThreads) {
     int v, j;
     if (t.sj == 1) { j = e % n; v = e / n; } else { v = e & 63; j = e >> 6; }
