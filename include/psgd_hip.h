@@ -183,7 +183,8 @@ int psgd_splu_update_f32(const float *L12, const float *l3, const float *U12, co
 
 int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 
-/* Experiment knob (not stable ABI). key 0: fp32 GEMM tile choice (0 auto, 1 = 64, 2 = 128, 3 = 32). */
+/* Experiment knob (not stable ABI). key 0: fp32 GEMM tile choice (0 auto, 1 = 64, 2 = 128, 3 = 32).
+ * key 1: 1 (default) 128-tile products run as fp32-accurate bf16 x 3 GEMMs on the bf16 matrix cores; 0 = exact fp32 MFMA. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

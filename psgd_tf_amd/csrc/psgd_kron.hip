@@ -145,6 +145,44 @@ struct GemmLds {
   float B[2][GK][T + 16];
 };
 
+// C-tile epilogue shared by the GEMM bodies: acc[i][j][e] is C[m0 + wm*W + i*16 + (lane>>4)*4 + e][n0 + wn*W + j*16 + (lane&15)]
+// (the 16x16 C/D register layout is the same for the f32 and the bf16 MFMA forms)
+template <int T>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[T / 32][T / 32], int m0, int n0) {
+  constexpr int W = T / 2, NT = T / 32;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  float vmax = 0.0f;
+  const long ccs = g.c_cs ? g.c_cs : 1;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + wm * W + i * 16 + (lane >> 4) * 4 + e;
+        const int col = n0 + wn * W + j * 16 + (lane & 15);
+        if (row < g.M && col < g.N) {
+          float v = acc[i][j][e];
+          if (g.epi == EPI_TRIU_MAX) {
+            v = (col >= row) ? v : 0.0f;
+            vmax = fmaxf(vmax, fabsf(v));
+          } else if (g.epi == EPI_D_MINUS) {
+            v = g.D[(long)row * g.ldd + col * ccs] - v;
+          } else if (g.colv) {
+            const float cv = g.colv[col];
+            v *= g.colsq ? cv * cv : cv;
+          }
+          g.C[(long)row * g.ldc + col * ccs] = v;
+        }
+      }
+  if (g.epi == EPI_TRIU_MAX) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0 && vmax > 0.0f) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+  }
+}
+
 template <int T, int GK>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, GemmLds<T, GK>& L) {
   constexpr int W = T / 2, NT = T / 32;   // wave tile edge, MFMA tiles per wave edge
@@ -219,39 +257,190 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, Gem
     __syncthreads();
   }
 
-  float vmax = 0.0f;
-  const long ccs = g.c_cs ? g.c_cs : 1;
+  gemm_epilogue<T>(g, acc, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32-accurate GEMM on the bf16 matrix cores ("bf16 x 3").  Every fp32 operand element is split on the way into
+// LDS into three bf16 terms x = h + m + l (|x - (h+m+l)| <= 2^-24 |x|, bf16 keeps fp32's exponent range), and a
+// product a*b is accumulated as  h h' + h m' + m h' + h l' + l h' + m m'  with fp32 accumulation: six
+// v_mfma_f32_16x16x32_bf16 at 16x the rate of v_mfma_f32_16x16x4_f32, i.e. up to 2.6x the fp32 matrix-core peak at
+// fp32-level accuracy (the dropped terms are below 2^-24 relative, like one fp32 rounding).  Same operand views,
+// K-range clipping, second (subtracted) operand pair and epilogues as gemm_body; 128 x 128 x 32 tile, one LDS
+// buffer of 3 planes per operand (48 KiB, 2 blocks per CU), next K tile prefetched into registers.
+typedef __bf16 bf16x8_k __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_k __attribute__((ext_vector_type(4)));
+constexpr int kX3K = 32;
+
+struct GemmLdsX3 {
+  u32x4_k P[2][3][128 * 4];    // [A|B][plane][row*4 + (chunk ^ ((row>>2)&3))], a chunk = 8 consecutive k as bf16
+};
+
+__device__ __forceinline__ void split3(float x, unsigned short (&o)[3]) {
+  const __bf16 h = static_cast<__bf16>(x);
+  const float r1 = x - static_cast<float>(h);
+  const __bf16 m = static_cast<__bf16>(r1);
+  const float r2 = r1 - static_cast<float>(m);
+  const __bf16 l = static_cast<__bf16>(r2);
+  o[0] = __builtin_bit_cast(unsigned short, h);
+  o[1] = __builtin_bit_cast(unsigned short, m);
+  o[2] = __builtin_bit_cast(unsigned short, l);
+}
+
+// Operand tile -> registers -> LDS planes.  Whatever the memory layout, a thread ends up with 16 consecutive k of ONE
+// row of the (x, k) tile, so the LDS side is always two 16-byte chunk stores per plane:
+//   K-contiguous operands (cs == 1): row = tid / 2, k half = tid % 2, four float4 loads;
+//   X-contiguous operands (rs == 1): row = tid % 128, k half = tid / 128, sixteen 4-byte loads, each coalesced
+//     across the wave (lane -> row);  anything else / edge tiles: the first mapping with guarded scalar loads.
+__device__ __forceinline__ void g2r_x3(const TileSrc& t, int x0, int k0, int khi, float mul, float (&r)[16], int& xr, int& kb) {
+  constexpr int T = 128, GK = kX3K;
+  const int tid = threadIdx.x;
+  const bool interior = (x0 + T <= t.X) && (k0 + GK <= khi);
+  if (interior && t.rs == 1) {
+    xr = tid & 127; kb = (tid >> 7) * 16;
+    const float* p = t.P + (long)(k0 + kb) * t.cs + x0 + xr;
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+    for (int u = 0; u < 16; ++u) r[u] = p[(long)u * t.cs] * mul;
+    return;
+  }
+  xr = tid >> 1; kb = (tid & 1) * 16;
+  if (interior && t.cs == 1 && (t.rs & 3) == 0 && (reinterpret_cast<uintptr_t>(t.P) & 15) == 0) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(t.P + (long)(x0 + xr) * t.rs + k0 + kb);
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = p[q];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = m0 + wm * W + i * 16 + (lane >> 4) * 4 + e;
-        const int col = n0 + wn * W + j * 16 + (lane & 15);
-        if (row < g.M && col < g.N) {
-          float v = acc[i][j][e];
-          if (g.epi == EPI_TRIU_MAX) {
-            v = (col >= row) ? v : 0.0f;
-            vmax = fmaxf(vmax, fabsf(v));
-          } else if (g.epi == EPI_D_MINUS) {
-            v = g.D[(long)row * g.ldd + col * ccs] - v;
-          } else if (g.colv) {
-            const float cv = g.colv[col];
-            v *= g.colsq ? cv * cv : cv;
-          }
-          g.C[(long)row * g.ldc + col * ccs] = v;
-        }
-      }
-  if (g.epi == EPI_TRIU_MAX) {
+      for (int e = 0; e < 4; ++e) r[4 * q + e] = v[e] * mul;
+    }
+    return;
+  }
+  const int gx = x0 + xr;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    if (lane == 0 && vmax > 0.0f) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+  for (int u = 0; u < 16; ++u) {
+    const int gk = k0 + kb + u;
+    r[u] = (gx < t.X && gk < khi) ? t.P[(long)gx * t.rs + (long)gk * t.cs] * mul : 0.0f;
   }
 }
 
+__device__ __forceinline__ void r2s_x3(const float (&r)[16], int xr, int kb, u32x4_k (*P)[128 * 4]) {
+  unsigned pk[3][8];
+#pragma unroll
+  for (int u = 0; u < 16; u += 2) {
+    unsigned short q0[3], q1[3];
+    split3(r[u], q0);
+    split3(r[u + 1], q1);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) pk[pl][u >> 1] = (unsigned)q0[pl] | ((unsigned)q1[pl] << 16);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = (kb >> 3) + h;
+    const int sl = xr * 4 + (c ^ ((xr >> 2) & 3));
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) P[pl][sl] = u32x4_k{pk[pl][4 * h], pk[pl][4 * h + 1], pk[pl][4 * h + 2], pk[pl][4 * h + 3]};
+  }
+}
+
+__device__ __forceinline__ void gemm_body_x3(const GemmArgs& g, int m0, int n0, GemmLdsX3& L) {
+  constexpr int T = 128, GK = kX3K, W = 64, NT = 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const bool tri_skip = (g.epi == EPI_TRIU_MAX) && (m0 >= n0 + T);
+
+  f32x4 acc[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float a_mul = 1.0f;
+  if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
+
+  int klo[2] = {0, 0}, khi[2] = {0, 0}, nk[2] = {0, 0};
+  if (!tri_skip) {
+    for (int p = 0; p < 2; ++p) {
+      if (p == 1 && !g.A2) break;
+      const int K = p ? g.K2 : g.K, km = p ? g.kmode2 : g.kmode;
+      int lo = 0, hi = K;
+      if (km & KLO_M) lo = max(lo, m0);
+      if (km & KLO_N) lo = max(lo, n0);
+      if (km & KHI_M) hi = min(hi, m0 + T);
+      if (km & KHI_N) hi = min(hi, n0 + T);
+      lo = (lo / GK) * GK;
+      klo[p] = lo; khi[p] = hi; nk[p] = hi > lo ? (hi - lo + GK - 1) / GK : 0;
+    }
+  }
+  const int ntile = nk[0] + nk[1];
+  const TileSrc ta[2] = {{g.A, g.a_rs, g.a_cs, g.M}, {g.A2, g.a2_rs, g.a2_cs, g.M}};
+  const TileSrc tb[2] = {{g.B, g.b_cs, g.b_rs, g.N}, {g.B2, g.b2_cs, g.b2_rs, g.N}};   // (n, k) view of B
+
+  float ra[16], rb[16];
+  int xa = 0, ka = 0, xb = 0, kbb = 0;
+  auto fetch = [&](int t) {
+    const int p = t < nk[0] ? 0 : 1;
+    const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
+    g2r_x3(ta[p], m0, k0, khi[p], p ? -a_mul : a_mul, ra, xa, ka);
+    g2r_x3(tb[p], n0, k0, khi[p], 1.0f, rb, xb, kbb);
+  };
+  auto commit = [&](int) {
+    r2s_x3(ra, xa, ka, L.P[0]);
+    r2s_x3(rb, xb, kbb, L.P[1]);
+  };
+
+  if (ntile > 0) {
+    fetch(0);
+    commit(0);
+  }
+  __syncthreads();
+  const int c = lane >> 4;
+  for (int t = 0; t < ntile; ++t) {
+    if (t + 1 < ntile) fetch(t + 1);
+    bf16x8_k a[NT][3], b[NT][3];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int row = wm * W + i * 16 + (lane & 15);
+      const int sl = row * 4 + (c ^ ((row >> 2) & 3));
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[0][pl][sl]);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * W + j * 16 + (lane & 15);
+      const int sl = row * 4 + (c ^ ((row >> 2) & 3));
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[1][pl][sl]);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 v = acc[i][j];
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], v, 0, 0, 0);   // h l'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], v, 0, 0, 0);   // l h'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], v, 0, 0, 0);   // h m'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], v, 0, 0, 0);   // m h'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], v, 0, 0, 0);   // h h'
+        acc[i][j] = v;
+      }
+    __syncthreads();                      // every wave is done reading this K tile
+    if (t + 1 < ntile) commit(t + 1);
+    __syncthreads();
+  }
+  gemm_epilogue<T>(g, acc, m0, n0);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_x3(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  int by = blockIdx.y, bx = blockIdx.x;
+  if (g.kmode & (KHI_M | KHI_N)) { by = gridDim.y - 1 - by; bx = gridDim.x - 1 - bx; }
+  gemm_body_x3(g, by * 128, bx * 128, L);
+}
+
+// T = 128: three resident blocks per CU (<= 170 registers): the 528 upper tiles of a 4096^2 triu product then run
+// as one wave of blocks instead of 512 + 16 (the second, nearly empty wave doubled those launches' time)
 template <int T, int GK>
-__global__ __launch_bounds__(kThreads) void k_gemm_f32(GemmArgs g) {
+__global__ __launch_bounds__(kThreads, (T == 128 ? 3 : 1)) void k_gemm_f32(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) GemmLds<T, GK> L;
   // longest-K tiles first (see the bf16 kernel): an upper K bound grows with the tile index
   int by = blockIdx.y, bx = blockIdx.x;
@@ -770,6 +959,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   return k;
 }
 
+static int g_gemm_x3 = 1;       // tuning key 1: large products on the bf16 matrix cores with a 3-way operand split
 static int g_force_gemm = 0;   // 0 auto, 1 always 64-tile kernel, 2 always 128-tile kernel (experiments)
 
 static int launch_gemm(const GemmArgs& g, hipStream_t st) {
@@ -781,7 +971,8 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g_force_gemm == 2) T = 128;
   if (g_force_gemm == 3) T = 32;
   dim3 grid((g.N + T - 1) / T, (g.M + T - 1) / T);
-  if (T == 128) hipLaunchKernelGGL((k_gemm_f32<128, kBigK>), grid, dim3(kThreads), 0, st, g);
+  if (T == 128 && g_gemm_x3) hipLaunchKernelGGL(k_gemm_x3, grid, dim3(kThreads), 0, st, g);
+  else if (T == 128) hipLaunchKernelGGL((k_gemm_f32<128, kBigK>), grid, dim3(kThreads), 0, st, g);
   else if (T == 64) hipLaunchKernelGGL((k_gemm_f32<64, kSmallK>), grid, dim3(kThreads), 0, st, g);
   else hipLaunchKernelGGL((k_gemm_f32<32, kSmallK>), grid, dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
@@ -933,6 +1124,7 @@ extern "C" {
 
 int psgd_kron_set_tuning(int key, int value) {
   if (key == 0) { g_force_gemm = value; return PSGD_OK; }
+  if (key == 1) { g_gemm_x3 = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

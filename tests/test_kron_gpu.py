@@ -245,23 +245,26 @@ def test_bf16_path_rejects_odd_shapes(psgd):
                                torch.ones(5, 12, device="cuda", dtype=torch.bfloat16))
 
 
-@pytest.mark.parametrize("tile_choice", [1, 2, 3])
+@pytest.mark.parametrize("tile_choice,x3", [(1, 1), (2, 1), (2, 0), (3, 1)])
 @pytest.mark.parametrize("M,N", [(257, 120), (300, 500), (1100, 530), (128, 128), (640, 256)])
-def test_every_gemm_tile_size_forced(psgd, hip_lib, M, N, tile_choice):
+def test_every_gemm_tile_size_forced(psgd, hip_lib, M, N, tile_choice, x3):
     """The fp32 GEMM picks its tile size (32 / 64 / 128) from the problem size; force each one on small
-    and ragged shapes (edge tiles, unaligned leading dimensions) and compare with the oracle."""
+    and ragged shapes (edge tiles, unaligned leading dimensions) and compare with the oracle.  The 128 tile has two
+    bodies: the bf16 x 3 split GEMM (x3 = 1, default) and the exact fp32-MFMA one (x3 = 0)."""
     rng = np.random.default_rng(M + N)
     Ql, Qr = _tri_factor(rng, M) * 2.0, _tri_factor(rng, N)
     dX, dG, G = (rng.standard_normal((M, N)) for _ in range(3))
     a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG, G)]
     a64 = [a.astype(np.float64) for a in a32]
     hip_lib.psgd_kron_set_tuning(0, tile_choice)
+    hip_lib.psgd_kron_set_tuning(1, x3)
     try:
         out = psgd.precond_grad_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[4]))
         Ql_n, Qr_n = psgd.update_precond_kron(_dev(a32[0]), _dev(a32[1]), _dev(a32[2]), _dev(a32[3]), 0.01)
         torch.cuda.synchronize()
     finally:
         hip_lib.psgd_kron_set_tuning(0, 0)
+        hip_lib.psgd_kron_set_tuning(1, 1)
     assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(a64[0], a64[1], a64[4])) < TOL
     Ql_r, Qr_r = orc.update_precond_kron(a64[0], a64[1], a64[2], a64[3], 0.01)
     assert rel_err(Ql_n.cpu().numpy(), Ql_r) < TOL and rel_err(Qr_n.cpu().numpy(), Qr_r) < TOL
