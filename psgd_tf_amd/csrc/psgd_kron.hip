@@ -593,6 +593,8 @@ __global__ __launch_bounds__(64) void k_tri_inv32(const float* __restrict__ Q, i
 // kernel above is kept for the batched small-layer path.)  Dynamic LDS: 64 x pitch + 32 x 33 floats.
 constexpr int kStripN = 512;
 
+// VB = vectors per workgroup (64, or 16 so that a solve with few thousand vectors still covers every CU)
+template <int VB>
 __device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __restrict__ Dinv, int v0, float* S,
                                               int pitch, float (*Dd)[33]) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -601,27 +603,27 @@ __device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __
   const int npad = (n + 31) & ~31;
   // strip in: 8 independent loads in flight per thread (the plain loop paid one memory latency per element: the load
   // and store phases together were ~3/4 of the kernel's time)
-  for (int e0 = tid; e0 < 64 * npad; e0 += kThreads * 8) {
+  for (int e0 = tid; e0 < VB * npad; e0 += kThreads * 8) {
     float x[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u * kThreads;
       int v, j;
-      if (xj == 1) { j = e % npad; v = e / npad; } else { v = e & 63; j = e >> 6; }
-      x[u] = (e < 64 * npad && v0 + v < t.nvec && j < n) ? t.X[(long)(v0 + v) * xi + (long)j * xj] : 0.0f;
+      if (xj == 1) { j = e % npad; v = e / npad; } else { v = e % VB; j = e / VB; }
+      x[u] = (e < VB * npad && v0 + v < t.nvec && j < n) ? t.X[(long)(v0 + v) * xi + (long)j * xj] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u * kThreads;
       int v, j;
-      if (xj == 1) { j = e % npad; v = e / npad; } else { v = e & 63; j = e >> 6; }
-      if (e < 64 * npad) S[v * pitch + j] = x[u];
+      if (xj == 1) { j = e % npad; v = e / npad; } else { v = e % VB; j = e / VB; }
+      if (e < VB * npad) S[v * pitch + j] = x[u];
     }
   }
   for (int j0 = 0; j0 < n; j0 += 32) {
     for (int e = tid; e < 1024; e += kThreads) Dd[e >> 5][e & 31] = Dinv[(long)(j0 >> 5) * 1024 + e];
     __syncthreads();
-    {   // Y_s = R_s Dinv_s : wave w owns vector block w (rows 16w..16w+15), reads and rewrites only those rows
+    if (w < VB / 16) {   // Y_s = R_s Dinv_s : wave w owns vector block w (rows 16w..16w+15), reads and rewrites only those rows
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
@@ -656,41 +658,42 @@ __device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __
       const int cb = w + 4 * it;
       if (cb >= ncb) break;
       const int col = c_begin + cb * 16 + (lane & 15);
-      f32x4 acc[4];
+      f32x4 acc[VB / 16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < VB / 16; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][e] = S[(i * 16 + (lane >> 4) * 4 + e) * pitch + col];
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const int k = j0 + kk * 4 + (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(-S[(i * 16 + (lane & 15)) * pitch + k], bq[it][kk], acc[i], 0, 0, 0);
+        for (int i = 0; i < VB / 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(-S[(i * 16 + (lane & 15)) * pitch + k], bq[it][kk], acc[i], 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < VB / 16; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) S[(i * 16 + (lane >> 4) * 4 + e) * pitch + col] = acc[i][e];
     }
     __syncthreads();
   }
 #pragma unroll 8
-  for (int e = tid; e < 64 * n; e += kThreads) {
+  for (int e = tid; e < VB * n; e += kThreads) {
     int v, j;
-    if (t.sj == 1) { j = e % n; v = e / n; } else { v = e & 63; j = e >> 6; }
+    if (t.sj == 1) { j = e % n; v = e / n; } else { v = e % VB; j = e / VB; }
     if (v0 + v < t.nvec) t.Y[(long)(v0 + v) * t.si + (long)j * t.sj] = S[v * pitch + j];
   }
 }
 
+template <int VB>
 __global__ __launch_bounds__(kThreads) void k_trsm_ut_inv(TrsmArgs t, const float* __restrict__ Dinv) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   const int pitch = ((t.n + 31) & ~31) + 2;          // == 2 (mod 32): MFMA A-operand reads (v, k) hit distinct banks
-  trsm_inv_body(t, Dinv, blockIdx.x * 64, dyn_lds, pitch, reinterpret_cast<float (*)[33]>(dyn_lds + 64 * pitch));
+  trsm_inv_body<VB>(t, Dinv, blockIdx.x * VB, dyn_lds, pitch, reinterpret_cast<float (*)[33]>(dyn_lds + VB * pitch));
 }
 
 struct TrsmBatch {
   int count;
-  int blk_end[kMaxBatch];      // inclusive prefix sums of 64-vector strips (solve) / of 32-blocks (inversion)
+  int blk_end[kMaxBatch];      // inclusive prefix sums of 16-vector strips (solve) / of 32-blocks (inversion)
   TrsmArgs t[kMaxBatch];
   const float* dinv[kMaxBatch];
 };
@@ -732,18 +735,9 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut_inv_batched(TrsmBatch b, i
   const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
   const TrsmArgs& t = b.t[p];
   const int pitch = ((t.n + 31) & ~31) + 2;
-  trsm_inv_body(t, b.dinv[p], blk * 64, dyn_lds, pitch, reinterpret_cast<float (*)[33]>(dyn_lds + 64 * pitch_max));
+  trsm_inv_body<16>(t, b.dinv[p], blk * 16, dyn_lds, pitch, reinterpret_cast<float (*)[33]>(dyn_lds + 16 * pitch_max));
 }
 
-__global__ __launch_bounds__(kThreads) void k_trsm_ut_batched(TrsmBatch b) {
-  __shared__ float red[4][64][33];
-  __shared__ float Qd[32][32];
-  int p = 0;
-  while (p + 1 < b.count && (int)blockIdx.x >= b.blk_end[p]) ++p;
-  const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
-  const TrsmArgs& t = b.t[p];
-  trsm_body(t.Q, t.n, t.ldq, t.X, t.Y, t.nvec, t.si, t.sj, t.xi, t.xj, blk * 64, red, Qd);
-}
 
 // rho = sqrt(max diag Ql / max diag Qr); QlS = Ql / rho; QrS = rho Qr      (psgd.py:166-170)
 struct BalanceBatch {
@@ -1042,13 +1036,20 @@ constexpr int kTrsmBlock = kStripN;
 static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
   static bool attr_set = false;
   const int pitch = ((t.n + 31) & ~31) + 2;
-  const size_t lds = (size_t)(64 * pitch + 32 * 33) * sizeof(float);
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trsm_ut_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trsm_ut_inv<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)((64 * (kStripN + 2) + 32 * 33) * sizeof(float))) != hipSuccess) return 1;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_trsm_ut_inv, dim3((t.nvec + 63) / 64), dim3(kThreads), lds, st, t, dinv);
+  // 64-vector workgroups keep a 4096-vector solve on 64 CUs; 16-vector ones cover the chip and shorten the per-sub-step
+  // dependency chains (one MFMA row tile per wave)
+  if ((t.nvec + 63) / 64 < 192) {
+    const size_t lds = (size_t)(16 * pitch + 32 * 33) * sizeof(float);
+    hipLaunchKernelGGL(k_trsm_ut_inv<16>, dim3((t.nvec + 15) / 16), dim3(kThreads), lds, st, t, dinv);
+  } else {
+    const size_t lds = (size_t)(64 * pitch + 32 * 33) * sizeof(float);
+    hipLaunchKernelGGL(k_trsm_ut_inv<64>, dim3((t.nvec + 63) / 64), dim3(kThreads), lds, st, t, dinv);
+  }
   return (int)hipGetLastError();
 }
 
@@ -1245,8 +1246,8 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
       t1.t[q] = {k[q].QrS, N[p], N[p], dX[p], k[q].X1, M[p], (long)N[p], 1L, 0L, 0L};
       t1.dinv[q] = k[q].dinv; t2.dinv[q] = k[q].dinv + (long)((N[p] + 31) / 32) * 1024;
       t2.t[q] = {k[q].QlS, M[p], M[p], k[q].X1, k[q].Bt, N[p], 1L, (long)N[p], 0L, 0L};
-      blk1 += (M[p] + 63) / 64; t1.blk_end[q] = blk1;
-      blk2 += (N[p] + 63) / 64; t2.blk_end[q] = blk2;
+      blk1 += (M[p] + 15) / 16; t1.blk_end[q] = blk1;      // 16-vector strips (k_trsm_ut_inv_batched)
+      blk2 += (N[p] + 15) / 16; t2.blk_end[q] = blk2;
     }
     hipLaunchKernelGGL(k_kron_balance_batched, dim3(64, nb), dim3(kThreads), 0, st, bb);
     KRON_LAUNCH((int)hipGetLastError());
@@ -1277,7 +1278,7 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
         attr_set = true;
       }
       hipLaunchKernelGGL(k_trsm_ut_inv_batched, dim3(pass ? blk2 : blk1), dim3(kThreads),
-                         (size_t)(64 * pitch_max + 32 * 33) * sizeof(float), st, tb, pitch_max);
+                         (size_t)(16 * pitch_max + 32 * 33) * sizeof(float), st, tb, pitch_max);
       KRON_LAUNCH((int)hipGetLastError());
     }
     for (int stage = 2; stage < 6; ++stage) {
