@@ -145,18 +145,36 @@ struct GemmLds {
   float B[2][GK][T + 16];
 };
 
-// Dispatch order = longest K first: blocks are handed out in linear blockIdx order (x fastest), and a triangular K
-// range makes the tile's work depend on its row (KLO_M / KHI_M) or on its column (KLO_N / KHI_N).  Row-dependent
-// work is already sorted by the row-major order (reversed for the upper bounds); column-dependent work walks the
-// tile grid column-major instead, otherwise every tile row ends with its short tiles while the long ones of the
-// last rows start late (dG Qr' at 4096^2: 823 -> ~500 us).
-__device__ __forceinline__ void gemm_tile_order(int kmode, int& by, int& bx) {
-  by = blockIdx.y; bx = blockIdx.x;
-  if ((kmode & (KLO_N | KHI_N)) && !(kmode & (KLO_M | KHI_M))) {
-    const int id = blockIdx.y * gridDim.x + blockIdx.x;
-    bx = id / gridDim.y; by = id % gridDim.y;
+// Linear block id -> output tile.
+// (1) L2 locality: blocks id, id + 8, ... run on one XCD (own 4 MiB L2).  When the tile grid is a multiple of 8 x 8,
+//     every XCD works through 8 x 8 tile PATCHES: the 64 tiles that run together share 8 A panels and 8 B panels.
+//     The large products are bound by L2-miss traffic (fp32 operands, 32 flop/B per 128^2 tile), not by the matrix
+//     cores, so this is worth more than anything inside the tile.  Patches are dealt to the XCDs in serpentine order
+//     (0..7, 7..0, ...): an XCD that got a long-K (or an all-zero, skipped) patch in one round gets the opposite in
+//     the next, which balances the triangular K ranges and the triu outputs.
+// (2) Longest K first otherwise: a triangular K range makes a tile's work depend on its row (KLO_M / KHI_M) or its
+//     column (KLO_N / KHI_N); row-dependent work is sorted by the row-major order (reversed for the upper bounds),
+//     column-dependent work walks the grid column-major (dG Qr' at 4096^2: 823 -> 485 us).
+__device__ __forceinline__ void gemm_tile_from_id(int id, int ty, int tx, int kmode, int& by, int& bx) {
+  const int nt = ty * tx;
+  const bool by_col = (kmode & (KLO_N | KHI_N)) && !(kmode & (KLO_M | KHI_M));
+  if (ty % 8 == 0 && tx % 8 == 0 && nt % 512 == 0) {
+    const int xcd = id % 8, j = id / 8, pn = (by_col ? ty : tx) / 8;
+    const int pl = j / 64, e = j % 64;
+    const int pid = (pl & 1) ? pl * 8 + 7 - xcd : pl * 8 + xcd;
+    const int major = (pid / pn) * 8 + e / 8, minor = (pid % pn) * 8 + e % 8;   // patches walk the work-sorted axis first
+    by = by_col ? minor : major;
+    bx = by_col ? major : minor;
+  } else if (by_col) {
+    bx = id / ty; by = id % ty;
+  } else {
+    by = id / tx; bx = id % tx;
   }
-  if (kmode & (KHI_M | KHI_N)) { by = gridDim.y - 1 - by; bx = gridDim.x - 1 - bx; }
+  if (kmode & (KHI_M | KHI_N)) { by = ty - 1 - by; bx = tx - 1 - bx; }
+}
+
+__device__ __forceinline__ void gemm_tile_order(int kmode, int& by, int& bx) {
+  gemm_tile_from_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.y, gridDim.x, kmode, by, bx);
 }
 
 // C-tile epilogue shared by the GEMM bodies: acc[i][j][e] is C[m0 + wm*W + i*16 + (lane>>4)*4 + e][n0 + wn*W + j*16 + (lane&15)]
@@ -448,6 +466,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
   int by, bx;
   gemm_tile_order(g.kmode, by, bx);
+  gemm_body_x3(g, by * 128, bx * 128, L);
+}
+
+// Two independent large products in one launch (the two gradient products of the update, psgd.py:175-176, then its
+// two factor updates, :179): with 528 upper tiles per 4096^2 triu product and 512 resident blocks, a launch of its own
+// ends with a nearly empty second wave of blocks; back to back in one grid the tail is paid once.
+struct GemmPair { GemmArgs g[2]; int tiles0, tx0, tx1; };
+
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_pair(GemmPair p) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
+  const GemmArgs& g = p.g[which];
+  const int id = blockIdx.x - (which ? p.tiles0 : 0);
+  const int tx = which ? p.tx1 : p.tx0;
+  const int ty = ((g.M + 127) / 128);
+  int by, bx;
+  gemm_tile_from_id(id, ty, tx, g.kmode, by, bx);       // tiles0 is a multiple of 8 whenever the patch map applies
   gemm_body_x3(g, by * 128, bx * 128, L);
 }
 
@@ -986,6 +1021,25 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+static bool gemm_uses_x3(const GemmArgs& g) {
+  const long t128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
+  return g_gemm_x3 && (g_force_gemm == 0 ? t128 >= 64 : g_force_gemm == 2);
+}
+
+static int launch_gemm_two(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+  if (!gemm_uses_x3(a) || !gemm_uses_x3(b)) {
+    const int rc = launch_gemm(a, st);
+    return rc ? rc : launch_gemm(b, st);
+  }
+  GemmPair p;
+  p.g[0] = a; p.g[1] = b;
+  p.tx0 = (a.N + 127) / 128; p.tx1 = (b.N + 127) / 128;
+  p.tiles0 = p.tx0 * ((a.M + 127) / 128);
+  const int tiles1 = p.tx1 * ((b.M + 127) / 128);
+  hipLaunchKernelGGL(k_gemm_x3_pair, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
+  return (int)hipGetLastError();
+}
+
 // C[M,N] = op(A) op(B); ta/tb: operand stored transposed (row-major [K,M] / [N,K])
 static GemmArgs gemm_args(const float* A, int lda, bool ta, const float* B, int ldb, bool tb, float* C, int ldc, int M,
                           int N, int K, int kmode = 0) {
@@ -1184,7 +1238,8 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // K2 (:174): X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
   KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st));
   KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st));
-  for (int i = 2; i < 6; ++i) KRON_LAUNCH(launch_gemm(s[i], st));
+  KRON_LAUNCH(launch_gemm_two(s[2], s[3], st));      // the two gradient products
+  KRON_LAUNCH(launch_gemm_two(s[4], s[5], st));      // the two factor updates
   return PSGD_OK;
 }
 
