@@ -669,8 +669,16 @@ __device__ __forceinline__ void trsm_inv_body(const TrsmArgs& t, const float* __
       if (e < VB * npad) S[v * pitch + j] = x[u];
     }
   }
+  float dnext[1024 / kThreads];          // next sub-step's inverted diagonal block, in flight during this sub-step
+#pragma unroll
+  for (int u = 0; u < 1024 / kThreads; ++u) dnext[u] = Dinv[tid + kThreads * u];
   for (int j0 = 0; j0 < n; j0 += 32) {
-    for (int e = tid; e < 1024; e += kThreads) Dd[e >> 5][e & 31] = Dinv[(long)(j0 >> 5) * 1024 + e];
+#pragma unroll
+    for (int u = 0; u < 1024 / kThreads; ++u) { const int e = tid + kThreads * u; Dd[e >> 5][e & 31] = dnext[u]; }
+    if (j0 + 32 < n) {
+#pragma unroll
+      for (int u = 0; u < 1024 / kThreads; ++u) dnext[u] = Dinv[(long)((j0 >> 5) + 1) * 1024 + tid + kThreads * u];
+    }
     __syncthreads();
     if (w < VB / 16) {   // Y_s = R_s Dinv_s : wave w owns vector block w (rows 16w..16w+15), reads and rewrites only those rows
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
