@@ -136,3 +136,39 @@ def ws_region(which, stage, N, r):
     off, cnt = _i64(0), _i64(0)
     check(load().psgd_uvd_ws_region(which, stage, N, r, ctypes.byref(off), ctypes.byref(cnt)), "psgd_uvd_ws_region")
     return off.value, cnt.value
+
+
+class WorkspaceCache:
+    """Device workspaces keyed by (device, problem shape), least-recently-used eviction.
+
+    The C ABI never allocates: the caller owns the scratch memory.  A model has a fixed set of shapes, so this
+    cache normally never evicts; the bounds keep a program that sweeps many shapes from accumulating
+    workspaces (they are the size of a few operand copies each).  Eviction only drops the reference: work
+    already queued on the stream keeps using the block, and torch's caching allocator reuses it in stream order."""
+
+    def __init__(self, max_entries=32, max_bytes=32 << 30):
+        import collections
+        self._d = collections.OrderedDict()
+        self.max_entries, self.max_bytes = max_entries, max_bytes
+
+    def get(self, key, make):
+        ws = self._d.get(key)
+        if ws is not None:
+            self._d.move_to_end(key)
+            return ws
+        ws = make()
+        self._d[key] = ws
+        total = sum(int(t.numel()) for t in self._d.values())
+        while len(self._d) > 1 and (len(self._d) > self.max_entries or total > self.max_bytes):
+            _, old = self._d.popitem(last=False)
+            total -= int(old.numel())
+        return ws
+
+    def __contains__(self, key):
+        return key in self._d
+
+    def __getitem__(self, key):
+        return self._d[key]
+
+    def __len__(self):
+        return len(self._d)

@@ -41,19 +41,17 @@ def _check_rank2_f32(name, *tensors, allow_bf16_last=False):
 
 
 # --------------------------------------------------------------------------- dense (x) dense: HIP
-_kron_ws = {}
+_kron_ws = _lib.WorkspaceCache()
 
 
 def _kron_workspace(device, M, N):
     key = (device.index if device.index is not None else torch.cuda.current_device(), M, N)
-    ws = _kron_ws.get(key)
-    if ws is None:
+    def make():
         nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes(M, N))
         if nbytes < 0:
             _lib.check(nbytes, "psgd_kron_dd_workspace_bytes")
-        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-        _kron_ws[key] = ws
-    return ws
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+    return _kron_ws.get(key, make)
 
 
 def _require_hip(name, *tensors):
@@ -77,7 +75,7 @@ def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
     return QlO, QrO
 
 
-_kron_ws_bf16 = {}
+_kron_ws_bf16 = _lib.WorkspaceCache()
 
 
 def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
@@ -88,10 +86,8 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
     out = torch.empty_like(Grad)
     key = (Grad.device.index, M, N)
-    ws = _kron_ws_bf16.get(key)
-    if ws is None:
-        ws = torch.empty(int(_lib.load().psgd_kron_dd_workspace_bytes_bf16(M, N)), dtype=torch.uint8, device=Grad.device)
-        _kron_ws_bf16[key] = ws
+    ws = _kron_ws_bf16.get(key, lambda: torch.empty(int(_lib.load().psgd_kron_dd_workspace_bytes_bf16(M, N)),
+                                                      dtype=torch.uint8, device=Grad.device))
     rc = _lib.load().psgd_kron_dd_apply_bf16(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
                                               ws.data_ptr(), ws.numel(),
                                               torch.cuda.current_stream(Grad.device).cuda_stream)
@@ -116,7 +112,7 @@ def _precond_grad_dense_dense(Ql, Qr, Grad):
 
 
 # --------------------------------------------------------------------------- batched (dense, dense): HIP
-_batch_ws = {}
+_batch_ws = _lib.WorkspaceCache()
 
 
 def _batched_ok(Qls, Qrs, mats):
@@ -136,14 +132,12 @@ def _int_array(vals):
 
 def _batch_workspace(device, Ms, Ns):
     key = (device.index, tuple(Ms), tuple(Ns))
-    ws = _batch_ws.get(key)
-    if ws is None:
+    def make():
         nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes_batched(_int_array(Ms), _int_array(Ns), len(Ms)))
         if nbytes < 0:
             _lib.check(nbytes, "psgd_kron_dd_workspace_bytes_batched")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _batch_ws[key] = ws
-    return ws
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _batch_ws.get(key, make)
 
 
 def precond_grad_kron_batched(Qls, Qrs, Grads):
@@ -188,19 +182,17 @@ def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
 # Canonical orientations (psgd.py:198-391).  The data matrices may be transposed views (the mirrored
 # formats of the dispatcher pass dX.t(), dG.t(), Grad.t()): their strides go straight to the kernels.
 _SPARSE_FMT = {"ds": 0, "nd": 1, "ns": 2}
-_sparse_ws = {}
+_sparse_ws = _lib.WorkspaceCache()
 
 
 def _sparse_workspace(device, fmt, M, N):
     key = (device.index, fmt, M, N)
-    ws = _sparse_ws.get(key)
-    if ws is None:
+    def make():
         nbytes = int(_lib.load().psgd_kron_sparse_workspace_bytes(_SPARSE_FMT[fmt], M, N))
         if nbytes < 0:
             _lib.check(nbytes, "psgd_kron_sparse_workspace_bytes")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _sparse_ws[key] = ws
-    return ws
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _sparse_ws.get(key, make)
 
 
 def _sparse_update(fmt, L, R, dX, dG, step):

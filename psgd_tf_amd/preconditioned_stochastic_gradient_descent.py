@@ -46,7 +46,7 @@ def manual_seed(seed):
 
 
 # --------------------------------------------------------------------------- helpers
-_ws_cache = {}
+_ws_cache = _lib.WorkspaceCache()
 
 
 def _stream_ptr(device):
@@ -73,14 +73,13 @@ def _require_hip(name, *tensors):
 def uvd_workspace(device, N, r):
     """Cached device workspace for a shard of N rows at rank r (see psgd_uvd_workspace_bytes)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), int(N), int(r))
-    ws = _ws_cache.get(key)
-    if ws is None:
+
+    def make():
         nbytes = _lib.load().psgd_uvd_workspace_bytes(N, r)
         if nbytes < 0:
             _lib.check(int(nbytes), "psgd_uvd_workspace_bytes")
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return _ws_cache.get(key, make)
 
 
 def _uvd_shapes(name, U, V, *cols):
@@ -142,14 +141,13 @@ def precond_grad_kron_batched(Qls, Qrs, Grads):
 # --------------------------------------------------------------------------- sparse LU
 def _splu_workspace(device, N, r):
     key = ("splu", device.index if device.index is not None else torch.cuda.current_device(), int(N), int(r))
-    ws = _ws_cache.get(key)
-    if ws is None:
+
+    def make():
         nbytes = int(_lib.load().psgd_splu_workspace_bytes(N, r))
         if nbytes <= 0:
             raise _lib.PsgdHipError("psgd_splu_workspace_bytes: unsupported shape N=%d r=%d (1 <= r <= 32, N >= r)" % (N, r))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _ws_cache.get(key, make)
 
 
 def _splu_shapes(name, L12, l3, U12, u3):

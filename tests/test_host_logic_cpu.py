@@ -110,3 +110,18 @@ def test_hot_path_refuses_cpu_tensors():
 def test_uvd_constants():
     assert torch.finfo(torch.float32).eps ** 0.5 == pytest.approx(2.0 ** -11.5)    # psgd.py:683
     assert math.isinf(float(psgd.UVd.__init__.__globals__["_Hyper"](math.inf)))     # psgd.py:675-676
+
+
+def test_workspace_cache_is_bounded():
+    """The Python boundary caches one device workspace per problem shape; a program that sweeps shapes must not
+    accumulate them (LRU by entry count and by bytes; the newest entry always stays)."""
+    import torch
+    from psgd_tf_amd import _lib
+    c = _lib.WorkspaceCache(max_entries=3, max_bytes=100)
+    for i in range(5):
+        c.get(i, lambda: torch.empty(10, dtype=torch.uint8))
+    assert len(c) == 3 and 4 in c and 2 in c and 0 not in c
+    hit = c.get(3, lambda: 1 / 0)                     # a hit does not rebuild and refreshes the entry
+    assert hit.numel() == 10
+    c.get(9, lambda: torch.empty(95, dtype=torch.uint8))
+    assert 9 in c and len(c) == 1                      # byte bound: everything older had to go

@@ -1,0 +1,126 @@
+"""Randomised parity sweep on the GPU: many random shapes per entry-point family against independent fp64 torch
+restatements (oracle/psgd_oracle_torch.py and local block formulas).  Development aid; the fixed-shape tests in tests/
+are the contract.  usage: python tools/fuzz_gpu.py [seconds]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import preconditioned_stochastic_gradient_descent as psgd  # noqa: E402
+from oracle import psgd_oracle_torch as ref64  # noqa: E402
+from psgd_tf_amd import _lib  # noqa: E402
+
+TINY = 1.1754943508222875e-38
+dev = torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    d = torch.linalg.vector_norm(b)
+    return float(torch.linalg.vector_norm(a - b) / (d if d > 0 else 1.0))
+
+
+def tri(n, g, off):
+    return torch.triu(torch.randn(n, n, device=dev, generator=g) * off, 1) + torch.diag(torch.exp(0.3 * torch.randn(n, device=dev, generator=g)))
+
+
+def fuzz_kron(g, it):
+    big = it % 7 == 0
+    M = int(torch.randint(1, 2600 if big else 700, (1,), generator=g, device=dev))
+    N = int(torch.randint(1, 2600 if big else 700, (1,), generator=g, device=dev))
+    off = 0.5 / max(M, N) ** 0.5
+    Ql, Qr = tri(M, g, off) * 1.7, tri(N, g, off)
+    dX = torch.randn(M, N, device=dev, generator=g)
+    dG = torch.exp(torch.empty(M, 1, device=dev).uniform_(-1, 1, generator=g)) * dX * torch.exp(torch.empty(1, N, device=dev).uniform_(-1, 1, generator=g))
+    G = torch.randn(M, N, device=dev, generator=g)
+    e1 = rel(psgd.precond_grad_kron(Ql, Qr, G), ref64.precond_grad_dense_dense(Ql.double(), Qr.double(), G.double()))
+    a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    a64, b64 = ref64.update_precond_dense_dense(Ql.double(), Qr.double(), dX.double(), dG.double(), 0.01, TINY)
+    e2 = max(rel(a, a64), rel(b, b64))
+    return "kron %dx%d" % (M, N), max(e1, e2), 1e-5
+
+
+def fuzz_kron_bf16(g, it):
+    M = 8 * int(torch.randint(1, 330, (1,), generator=g, device=dev))
+    N = 8 * int(torch.randint(1, 330, (1,), generator=g, device=dev))
+    if it % 5 == 0:
+        M, N = 256 * int(torch.randint(4, 17, (1,), generator=g, device=dev)), 256 * int(torch.randint(4, 17, (1,), generator=g, device=dev))
+    off = 0.5 / max(M, N) ** 0.5
+    Ql, Qr = tri(M, g, off), tri(N, g, off)
+    G = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    out = psgd.precond_grad_kron(Ql, Qr, G)
+    return "kron-bf16 %dx%d" % (M, N), rel(out, ref64.precond_grad_dense_dense(Ql.double(), Qr.double(), G.double())), 2e-2
+
+
+def fuzz_uvd(g, it):
+    r = int(torch.randint(1, 33, (1,), generator=g, device=dev))
+    N = int(torch.randint(max(r, 2), 400000 if it % 4 == 0 else 20000, (1,), generator=g, device=dev))
+    sc = 2.0 * (1.0 / (N * r)) ** 0.5
+    U, V = torch.randn(N, r, device=dev, generator=g) * sc, torch.randn(N, r, device=dev, generator=g) * sc
+    d = torch.exp(0.3 * torch.randn(N, 1, device=dev, generator=g))
+    gr, v = torch.randn(N, 1, device=dev, generator=g), torch.randn(N, 1, device=dev, generator=g)
+    h = v * torch.exp(torch.empty(N, 1, device=dev).uniform_(-4.6, 4.6, generator=g))
+    U64, V64, d64 = U.double(), V.double(), d.double()
+    upd = bool(it % 2)
+    bal = it % 5 == 0
+    out = psgd.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, gr, 0.01, TINY, balance=bal, update_U=upd)
+    ref64.update_precond_UVd_math_(U64, V64, d64, v.double(), h.double(), 0.01, TINY, balance=bal, update_U=upd)
+    e = max(rel(out, ref64.precond_grad_UVd_math(U64, V64, d64, gr.double())), rel(U, U64), rel(V, V64), rel(d, d64))
+    return "uvd N=%d r=%d" % (N, r), e, 1e-5
+
+
+def splu_apply64(L12, l3, U12, u3, x, r):
+    L1, L2, U1, U2 = L12[:r], L12[r:], U12[:, :r], U12[:, r:]
+    Ug1 = U1 @ x[:r] + U2 @ x[r:]
+    Qg1 = L1 @ Ug1
+    Qg2 = L2 @ Ug1 + l3 * (u3 * x[r:])
+    Lt1 = L1.t() @ Qg1 + L2.t() @ Qg2
+    return torch.cat([U1.t() @ Lt1, U2.t() @ Lt1 + u3 * (l3 * Qg2)], 0)
+
+
+def fuzz_splu(g, it):
+    r = int(torch.randint(1, 33, (1,), generator=g, device=dev))
+    N = int(torch.randint(r, 300000 if it % 4 == 0 else 20000, (1,), generator=g, device=dev))
+    sc = 0.3 / r ** 0.5
+    L12 = torch.randn(N, r, device=dev, generator=g) * (sc * 3 * (r / N) ** 0.5)
+    U12 = torch.randn(r, N, device=dev, generator=g) * (sc * 3 * (r / N) ** 0.5)
+    L12[:r] = torch.tril(torch.randn(r, r, device=dev, generator=g) * sc, -1) + torch.eye(r, device=dev)
+    U12[:, :r] = torch.triu(torch.randn(r, r, device=dev, generator=g) * sc, 1) + torch.eye(r, device=dev)
+    l3 = torch.exp(torch.empty(N - r, 1, device=dev).uniform_(-0.5, 0.5, generator=g))
+    u3 = torch.exp(torch.empty(N - r, 1, device=dev).uniform_(-0.5, 0.5, generator=g)) * 0.7
+    x = torch.randn(N, 1, device=dev, generator=g)
+    dg = x * torch.exp(torch.empty(N, 1, device=dev).uniform_(-2, 2, generator=g))
+    gr = torch.randn(N, 1, device=dev, generator=g)
+    e1 = rel(psgd.precond_grad_splu(L12, l3, U12, u3, [gr])[0], splu_apply64(L12.double(), l3.double(), U12.double(), u3.double(), gr.double(), r))
+    new = psgd.update_precond_splu(L12, l3, U12, u3, [x], [dg], 0.05)
+    # the updated factors must still give a symmetric positive P consistent with their own fp64 apply
+    e2 = rel(psgd.precond_grad_splu(*new, [gr])[0], splu_apply64(*[t.double() for t in new], gr.double(), r))
+    return "splu N=%d r=%d" % (N, r), max(e1, e2), 1e-5
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    _lib.load()
+    g = torch.Generator(device=dev).manual_seed(int(os.environ.get("FUZZ_SEED", "1")))
+    fams = [fuzz_kron, fuzz_kron_bf16, fuzz_uvd, fuzz_splu]
+    t0, it, worst, bad = time.time(), 0, {}, []
+    while time.time() - t0 < budget:
+        f = fams[it % len(fams)]
+        name, err, tol = f(g, it)
+        fam = name.split()[0]
+        if err > worst.get(fam, (0, ""))[0]:
+            worst[fam] = (err, name)
+        if not (err < tol):
+            bad.append((name, err))
+            print("FAIL", name, err, flush=True)
+        it += 1
+    print("cases", it, "failures", len(bad))
+    for fam, (e, n) in worst.items():
+        print("worst %-10s %.3e  (%s)" % (fam, e, n))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
