@@ -1,6 +1,6 @@
 """Randomised parity sweep on the GPU: many random shapes per entry-point family against independent fp64 torch
-restatements (oracle/psgd_oracle_torch.py and local block formulas).  Development aid; the fixed-shape tests in tests/
-are the contract.  usage: python tools/fuzz_gpu.py [seconds]"""
+restatements (oracle/psgd_oracle_torch.py and local block formulas).  TEST INFRASTRUCTURE (it imports oracle/).
+tests/test_fuzz_gpu.py runs it for a few seconds; longer sweeps: python tests/fuzz_gpu.py [seconds]"""
 import os
 import sys
 import time
@@ -100,10 +100,9 @@ def fuzz_splu(g, it):
     return "splu N=%d r=%d" % (N, r), max(e1, e2), 1e-5
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+def run(budget, seed=1):
     _lib.load()
-    g = torch.Generator(device=dev).manual_seed(int(os.environ.get("FUZZ_SEED", "1")))
+    g = torch.Generator(device=dev).manual_seed(seed)
     fams = [fuzz_kron, fuzz_kron_bf16, fuzz_uvd, fuzz_splu]
     t0, it, worst, bad = time.time(), 0, {}, []
     while time.time() - t0 < budget:
@@ -116,11 +115,12 @@ def main():
             bad.append((name, err))
             print("FAIL", name, err, flush=True)
         it += 1
-    print("cases", it, "failures", len(bad))
-    for fam, (e, n) in worst.items():
-        print("worst %-10s %.3e  (%s)" % (fam, e, n))
-    sys.exit(1 if bad else 0)
+    return it, bad, worst
 
 
 if __name__ == "__main__":
-    main()
+    cases, bad, worst = run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(os.environ.get("FUZZ_SEED", "1")))
+    print("cases", cases, "failures", len(bad))
+    for fam, (e, n) in worst.items():
+        print("worst %-10s %.3e  (%s)" % (fam, e, n))
+    sys.exit(1 if bad else 0)
