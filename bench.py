@@ -113,6 +113,11 @@ def kron_bench(dev, psgd, iters=20):
     Qls, Qrs, Gs = [x[0] for x in sts], [x[1] for x in sts], [x[2] for x in sts]
     t_lenet = timeit(lambda: psgd.precond_grad_kron_batched(Qls, Qrs, Gs), 50)        # one launch per stage for all layers
     t_lenet_loop = timeit(lambda: [psgd.precond_grad_kron(a, b, c) for a, b, c in sts], 50)
+    dXs = [torch.randn_like(g_) for g_ in Gs]
+    t_lenet_upd = timeit(lambda: psgd.update_precond_kron_batched(Qls, Qrs, dXs, Gs, 0.01), 50)
+    dX = torch.randn_like(G)
+    t_upd = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, G, 0.01), 5)
+    f_upd = 7 * (M * M * N + M * N * N) + 2 * (M**3 + N**3)                        # SURVEY 8d F_ref of the update
     f_big = kron_apply_flops(M, N)
     f_lenet = sum(kron_apply_flops(m, n) for m, n in LENET5)
     pmc = None                          # matrix-core counters of the same call, collected with rocprofv3 --pmc
@@ -134,7 +139,9 @@ def kron_bench(dev, psgd, iters=20):
                            "note": "fp32-accurate bf16 x 3 split GEMMs on the bf16 matrix cores (6 bf16 MFMAs per product): "
                                    "the fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
         "lenet5_set_fp32": {"us": t_lenet * 1e3, "gflops": f_lenet / t_lenet / 1e6, "bound": "launch/latency",
-                            "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop * 1e3},
+                            "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop * 1e3,
+                            "update_us": t_lenet_upd * 1e3},
+        "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6},
     }
 
 
