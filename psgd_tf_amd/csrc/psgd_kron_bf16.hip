@@ -5,8 +5,9 @@
 // extension SURVEY section 7 (hard part 5) describes: Ql, Qr stay fp32 master copies, they
 // are rounded to bf16 once per call, the gradient arrives in bf16, every product of
 // psgd.py:189-192 runs on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16) with fp32
-// accumulation, intermediates are kept in bf16, and the association order of the reference
-// (branch on M < N) is preserved.
+// accumulation and intermediates are kept in bf16.  The staged chain keeps the reference's
+// association order (branch on M < N); where both factors qualify the default re-associates the
+// Gram into the chain, out = Ql'(Ql((G Qr')Qr)), as two fused triangular pairs (see below).
 //
 // One canonical GEMM: C[M,N] = A[M,K] * Bt[N,K]'  with both operands K-contiguous, so that
 // every MFMA fragment (8 consecutive k of one row) is a single 16-byte LDS read.  All the
@@ -14,11 +15,17 @@
 // an epilogue that can store C or C' in fp32 or bf16.  Upper-triangular factors restrict the
 // K range of a tile (kmode), which removes about half of the MFMA work of the chain.
 //
-//   tile 128 x 128 x 64, 256 threads = 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 MFMA tiles
-//   LDS: 2 buffers x (A 16 KiB + B 16 KiB); 16-byte slots XOR-swizzled by (row & 7) so the
-//        16 rows of a fragment read spread over 8 slots (2-way instead of 16-way conflict)
-//   register-staged prefetch of tile k+1 while tile k is multiplied; one barrier per K tile
-//   blockIdx -> tile map is XCD-aware (consecutive tiles of one XCD share A/B panels in its L2)
+// Kernels in this file:
+//   k_hgemm_nt            128 x 128 x 64 tile, 4 waves, register-staged double buffer, XOR-swizzled LDS, XCD-aware
+//                         8 x 8 tile patches; general shapes, triangular K ranges, symmetric mode (Q'Q: upper tiles
+//                         computed, stored twice, longest-K-first with long/short pairing per CU)
+//   k_hgemm_nt_dma        the same tile on a 4-stage LDS-DMA ring (opt-in; measured slower)
+//   k_hgemm_nt_256        256 x 256 x 64 tile, 8 waves, 8-phase LDS-DMA schedule (counted vmcnt, raw barriers,
+//                         staggered wave rows) for large dense products: 1.2 PFLOP/s
+//   k_hgemm_tri_pair_256  two triangular products (Q X, then Q'(Q X)) fused into one persistent, wavefront-scheduled
+//                         launch with in-launch tile hand-offs; the default apply is two of these and no Gram
+//   k_factors_to_bf16     fp32 -> bf16 copies (plain and transposed) of both factors, upper 256-blocks only, one launch
+//   k_to_bf16             generic convert / transpose (gradient operand of the staged chain)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "psgd_hip.h"
