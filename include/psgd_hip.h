@@ -177,6 +177,29 @@ int psgd_splu_update_f32(const float *L12, const float *l3, const float *U12, co
                          const float *dg, float *L12_new, float *l3_new, float *U12_new, float *u3_new, int64_t N,
                          int r, float step, float tiny, void *ws, int64_t ws_bytes, void *stream);
 
+/* Stage forms of the two calls above, for tail rows sharded over several GPUs (one process per GPU): every rank passes
+ * its local tensors -- L12 = [L1; its rows of L2] ([r + n_local, r]), U12 = [U1, its columns of U2], its slices of
+ * l3 / u3, and flat vectors [the r corner entries (replicated); its slice of the tail] -- with N = r + n_local, and
+ * all-reduces the workspace region psgd_splu_ws_region(which, stage) reports after stage `stage`:
+ *   which 0 (fp64, SUM): stage 1: r sums (U2 x2); stage 2: 2r sums (apply uses the first r); stage 3: r sums (update)
+ *   which 1 (fp32, MAX): stage 3: 4 maxima (update)
+ * Every rank then redoes the r x r corner algebra on identical inputs and gets identical corner results.
+ * psgd_splu_stage1_f32 serves both paths (x = the flat gradient for the apply, dg for the update).
+ * has_tail (update stage 4): the GLOBAL problem has tail rows (N_global > r).                                       */
+int psgd_splu_ws_region(int which, int stage, int64_t N, int r, int64_t *offset_bytes, int64_t *count);
+int psgd_splu_stage1_f32(const float *U12, const float *x, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_splu_apply_stage2_f32(const float *L12, const float *l3, const float *U12, const float *u3, const float *g,
+                               float *out, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_splu_apply_stage3_f32(const float *L12, const float *l3, const float *U12, const float *u3, float *out,
+                               int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_splu_update_stage2_f32(const float *L12, const float *l3, const float *U12, const float *u3, const float *dx,
+                                const float *dg, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_splu_update_stage3_f32(const float *L12, const float *l3, const float *U12, const float *u3, const float *dx,
+                                const float *dg, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_splu_update_stage4_f32(const float *L12, const float *l3, const float *U12, const float *u3, const float *dx,
+                                const float *dg, float *L12_new, float *l3_new, float *U12_new, float *u3_new, int64_t N,
+                                int r, float step, float tiny, int has_tail, void *ws, int64_t ws_bytes, void *stream);
+
 /* ----------------------------------------------------------------- Kron ---
  * P = kron(Qr'Qr, Ql'Ql) with dense upper-triangular Ql [M,M], Qr [N,N]
  * (psgd.py:156-192).  G, dX, dG are [M,N] row-major.                       */

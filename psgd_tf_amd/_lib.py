@@ -59,6 +59,13 @@ SIGNATURES = {
     "psgd_splu_workspace_bytes": (_i64, [_i64, _int]),
     "psgd_splu_apply_f32": (_int, [_c_f32p] * 6 + [_i64, _int, _c_ws, _i64, _strm]),
     "psgd_splu_update_f32": (_int, [_c_f32p] * 10 + [_i64, _int, ctypes.c_float, ctypes.c_float, _c_ws, _i64, _strm]),
+    "psgd_splu_ws_region": (_int, [_int, _int, _i64, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "psgd_splu_stage1_f32": (_int, [_c_f32p] * 2 + [_i64, _int, _c_ws, _i64, _strm]),
+    "psgd_splu_apply_stage2_f32": (_int, [_c_f32p] * 6 + [_i64, _int, _c_ws, _i64, _strm]),
+    "psgd_splu_apply_stage3_f32": (_int, [_c_f32p] * 5 + [_i64, _int, _c_ws, _i64, _strm]),
+    "psgd_splu_update_stage2_f32": (_int, [_c_f32p] * 6 + [_i64, _int, _c_ws, _i64, _strm]),
+    "psgd_splu_update_stage3_f32": (_int, [_c_f32p] * 6 + [_i64, _int, _c_ws, _i64, _strm]),
+    "psgd_splu_update_stage4_f32": (_int, [_c_f32p] * 10 + [_i64, _int, ctypes.c_float, ctypes.c_float, _int, _c_ws, _i64, _strm]),
     "psgd_kron_dd_workspace_bytes": (_i64, [_int, _int]),
     "psgd_kron_set_tuning": (_int, [_int, _int]),
     "psgd_kron_dd_workspace_bytes_batched": (_i64, [ctypes.POINTER(_int), ctypes.POINTER(_int), _int]),
@@ -135,6 +142,12 @@ def check(code, what):
 def ws_region(which, stage, N, r):
     off, cnt = _i64(0), _i64(0)
     check(load().psgd_uvd_ws_region(which, stage, N, r, ctypes.byref(off), ctypes.byref(cnt)), "psgd_uvd_ws_region")
+    return off.value, cnt.value
+
+
+def splu_ws_region(which, stage, N, r):
+    off, cnt = _i64(0), _i64(0)
+    check(load().psgd_splu_ws_region(which, stage, N, r, ctypes.byref(off), ctypes.byref(cnt)), "psgd_splu_ws_region")
     return off.value, cnt.value
 
 

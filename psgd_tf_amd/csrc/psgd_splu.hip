@@ -397,40 +397,163 @@ int64_t psgd_splu_workspace_bytes(int64_t N, int r) {
   return splu_layout(N, r, nullptr, nullptr);
 }
 
+/* ---- stage entry points.  One call = stage 1..3 (apply) or 1..4 (update) back to back.  With the tail rows sharded
+ * over several GPUs (every rank holds [L1; its rows of L2], [U1, its columns of U2], its slices of l3, u3 and of the
+ * tail of the flat vectors; the r x r corner and the first r vector entries are replicated) the caller all-reduces
+ * the region psgd_splu_ws_region() reports between two stages; every rank then redoes the corner algebra on
+ * identical inputs. ---- */
+
+struct SpluCtx {
+  SpluWs w; SpluGeom ge; const SpluOps* ops; hipStream_t st; int nt, rblocks, r2blocks;
+};
+
+static int splu_ctx(int64_t N, int r, void* ws, int64_t ws_bytes, void* stream, const void* L12, SpluCtx* c) {
+  const int rc = splu_open(ws, ws_bytes, N, r, &c->w);
+  if (rc) return rc;
+  c->ge = splu_geom(N, r);
+  if (L12 && misaligned16(L12)) return PSGD_ERR_ALIGN;
+  c->ops = splu_ops_for_rank(r);
+  if (!c->ops) return PSGD_ERR_RANK;
+  c->st = static_cast<hipStream_t>(stream);
+  c->nt = policy_nt((int64_t)N * r * 8);
+  c->rblocks = (r + kWavesPerBlock - 1) / kWavesPerBlock;
+  c->r2blocks = (2 * r + kWavesPerBlock - 1) / kWavesPerBlock;
+  return PSGD_OK;
+}
+
+int psgd_splu_ws_region(int which, int stage, int64_t N, int r, int64_t* offset_bytes, int64_t* count) {
+  if (!offset_bytes || !count || r < 1 || r > PSGD_UVD_MAX_RANK || N < r) return PSGD_ERR_BAD_ARG;
+  SpluWs w;
+  char* const base = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 20);   // any aligned address: offsets only
+  splu_layout(N, r, base, &w);
+  const int64_t dbl = reinterpret_cast<char*>(w.dbl) - base;
+  const int64_t mx = reinterpret_cast<char*>(w.maxbuf) - base;
+  if (which == 0) {                    // fp64 sums (all-reduce SUM)
+    if (stage == 1) { *offset_bytes = dbl + kSumA * 8; *count = r; return PSGD_OK; }       // U2 x2        (both paths)
+    if (stage == 2) { *offset_bytes = dbl + kSumB * 8; *count = 2 * r; return PSGD_OK; }   // L2'Qg2 [, L2'iQtx2]
+    if (stage == 3) { *offset_bytes = dbl + kSumC * 8; *count = r; return PSGD_OK; }       // U2 iPx2      (update)
+  } else if (which == 1 && stage == 3) {   // fp32 maxima (all-reduce MAX): |grad L|, |grad U|, l3, u3
+    *offset_bytes = mx; *count = 4; return PSGD_OK;
+  }
+  return PSGD_ERR_BAD_ARG;
+}
+
+/* stage 1 of either path: sums A = U2 x2 (x = the flat gradient for the apply, dg for the update) */
+int psgd_splu_stage1_f32(const float* U12, const float* x, int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U12 || !x) return PSGD_ERR_BAD_ARG;
+  SpluCtx c;
+  const int rc = splu_ctx(N, r, ws, ws_bytes, stream, nullptr, &c);
+  if (rc) return rc;
+  const int h = c.ge.head;
+  const int grid = splu_grid(c.ops, r, 0, c.ge.n2s, false);
+  PSGD_CHECK_LAUNCH(c.ops->u2dot(c.nt, U12 + r + h, c.ge.ldu, x + r + h, c.ge.n2s, h, c.w.part, grid, c.st));
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(c.rblocks), dim3(kThreads), 0, c.st, c.w.part, grid, r, c.w.dbl + kSumA);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_splu_apply_stage2_f32(const float* L12, const float* l3, const float* U12, const float* u3, const float* g,
+                               float* out, int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L12 || !U12 || !g || !out) return PSGD_ERR_BAD_ARG;
+  SpluCtx c;
+  const int rc = splu_ctx(N, r, ws, ws_bytes, stream, L12, &c);
+  if (rc) return rc;
+  if (c.ge.n2 > 0 && (!l3 || !u3)) return PSGD_ERR_BAD_ARG;
+  const int h = c.ge.head;
+  hipLaunchKernelGGL(k_splu_corner1, dim3(1), dim3(kThreads), 0, c.st, L12, U12, c.ge.ldu, r, g, (const float*)nullptr,
+                     c.w.dbl, c.w.coef);
+  PSGD_CHECK_LAUNCH(last_launch());
+  const int grid = splu_grid(c.ops, r, 1, c.ge.n2s, true);
+  PSGD_CHECK_LAUNCH(c.ops->apply_s2(c.nt, L12 + (int64_t)(r + h) * r, l3 + h, u3 + h, g + r + h, out + r + h, c.ge.n2s, h,
+                                    c.w.coef, c.w.part, grid, c.st));
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(c.rblocks), dim3(kThreads), 0, c.st, c.w.part, grid, r, c.w.dbl + kSumB);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_splu_apply_stage3_f32(const float* L12, const float* l3, const float* U12, const float* u3, float* out, int64_t N,
+                               int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L12 || !U12 || !out) return PSGD_ERR_BAD_ARG;
+  SpluCtx c;
+  const int rc = splu_ctx(N, r, ws, ws_bytes, stream, L12, &c);
+  if (rc) return rc;
+  const int h = c.ge.head;
+  hipLaunchKernelGGL(k_splu_corner_apply2, dim3(1), dim3(kThreads), 0, c.st, L12, U12, c.ge.ldu, r, c.w.dbl, c.w.coef, out);
+  PSGD_CHECK_LAUNCH(last_launch());
+  if (c.ge.n2 > 0) {
+    const int grid = splu_grid(c.ops, r, 2, c.ge.n2s, false);
+    PSGD_CHECK_LAUNCH(c.ops->apply_s3(c.nt, U12 + r + h, c.ge.ldu, l3 + h, u3 + h, out + r + h, c.ge.n2s, h, c.w.coef, grid,
+                                      c.st));
+  }
+  return PSGD_OK;
+}
+
 int psgd_splu_apply_f32(const float* L12, const float* l3, const float* U12, const float* u3, const float* g, float* out,
                         int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
   if (!L12 || !U12 || !g || !out) return PSGD_ERR_BAD_ARG;
-  SpluWs w;
-  const int rc = splu_open(ws, ws_bytes, N, r, &w);
+  int rc = psgd_splu_stage1_f32(U12, g, N, r, ws, ws_bytes, stream);
   if (rc) return rc;
-  const SpluGeom ge = splu_geom(N, r);
-  if (ge.n2 > 0 && (!l3 || !u3)) return PSGD_ERR_BAD_ARG;
-  if (misaligned16(L12)) return PSGD_ERR_ALIGN;
-  const SpluOps* ops = splu_ops_for_rank(r);
-  if (!ops) return PSGD_ERR_RANK;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nt = policy_nt((int64_t)N * r * 8);
-  const float* U2 = U12 + r;
-  const float* L2s = L12 + (int64_t)(r + ge.head) * r;
-  float* out2 = out + r;
-  const int rblocks = (r + kWavesPerBlock - 1) / kWavesPerBlock;
+  rc = psgd_splu_apply_stage2_f32(L12, l3, U12, u3, g, out, N, r, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return psgd_splu_apply_stage3_f32(L12, l3, U12, u3, out, N, r, ws, ws_bytes, stream);
+}
 
-  int grid = splu_grid(ops, r, 0, ge.n2s, false);
-  PSGD_CHECK_LAUNCH(ops->u2dot(nt, U2 + ge.head, ge.ldu, g + r + ge.head, ge.n2s, ge.head, w.part, grid, st));
-  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumA);
-  hipLaunchKernelGGL(k_splu_corner1, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, g, (const float*)nullptr, w.dbl,
-                     w.coef);
+int psgd_splu_update_stage2_f32(const float* L12, const float* l3, const float* U12, const float* u3, const float* dx,
+                                const float* dg, int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L12 || !U12 || !dx || !dg) return PSGD_ERR_BAD_ARG;
+  SpluCtx c;
+  const int rc = splu_ctx(N, r, ws, ws_bytes, stream, L12, &c);
+  if (rc) return rc;
+  if (c.ge.n2 > 0 && (!l3 || !u3)) return PSGD_ERR_BAD_ARG;
+  const int h = c.ge.head;
+  hipLaunchKernelGGL(k_splu_corner1, dim3(1), dim3(kThreads), 0, c.st, L12, U12, c.ge.ldu, r, dg, dx, c.w.dbl, c.w.coef);
   PSGD_CHECK_LAUNCH(last_launch());
-  grid = splu_grid(ops, r, 1, ge.n2s, true);
-  PSGD_CHECK_LAUNCH(ops->apply_s2(nt, L2s, l3 + ge.head, u3 + ge.head, g + r + ge.head, out2 + ge.head, ge.n2s, ge.head,
-                                  w.coef, w.part, grid, st));
-  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumB);
-  hipLaunchKernelGGL(k_splu_corner_apply2, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, w.dbl, w.coef, out);
+  const int grid = splu_grid(c.ops, r, 3, c.ge.n2s, true);
+  PSGD_CHECK_LAUNCH(c.ops->upd_s2(c.nt, L12 + (int64_t)(r + h) * r, U12 + r + h, c.ge.ldu, l3 + h, u3 + h, dx + r + h,
+                                  dg + r + h, c.ge.n2s, h, c.w.coef, c.w.part, grid, c.st));
+  // sums B are stored [L2'Qg2 (r) | L2'iQtx2 (r)] contiguously
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(c.r2blocks), dim3(kThreads), 0, c.st, c.w.part, grid, 2 * r, c.w.dbl + kSumB);
   PSGD_CHECK_LAUNCH(last_launch());
-  if (ge.n2 > 0) {
-    grid = splu_grid(ops, r, 2, ge.n2s, false);
-    PSGD_CHECK_LAUNCH(ops->apply_s3(nt, U2 + ge.head, ge.ldu, l3 + ge.head, u3 + ge.head, out2 + ge.head, ge.n2s, ge.head,
-                                    w.coef, grid, st));
+  return PSGD_OK;
+}
+
+int psgd_splu_update_stage3_f32(const float* L12, const float* l3, const float* U12, const float* u3, const float* dx,
+                                const float* dg, int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L12 || !U12 || !dx || !dg) return PSGD_ERR_BAD_ARG;
+  SpluCtx c;
+  const int rc = splu_ctx(N, r, ws, ws_bytes, stream, L12, &c);
+  if (rc) return rc;
+  const int h = c.ge.head;
+  hipLaunchKernelGGL(k_splu_corner_upd2, dim3(1), dim3(kThreads), 0, c.st, L12, U12, c.ge.ldu, r, dx, c.w.dbl, c.w.coef);
+  PSGD_CHECK_LAUNCH(last_launch());
+  const int grid = splu_grid(c.ops, r, 4, c.ge.n2s, true);
+  PSGD_CHECK_LAUNCH(c.ops->upd_s3(c.nt, L12 + (int64_t)(r + h) * r, U12 + r + h, c.ge.ldu, l3 + h, u3 + h, dg + r + h,
+                                  dx + r + h, c.ge.n2s, h, c.w.coef, c.w.part, c.w.pmax, grid, c.st));
+  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(c.rblocks), dim3(kThreads), 0, c.st, c.w.part, grid, r, c.w.dbl + kSumC);
+  hipLaunchKernelGGL(k_splu_reduce_max, dim3(4), dim3(kThreads), 0, c.st, c.w.pmax, grid, c.w.maxbuf);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+/* has_tail: the GLOBAL problem has tail rows (N_global > r); a rank of a sharded call may hold none of them itself */
+int psgd_splu_update_stage4_f32(const float* L12, const float* l3, const float* U12, const float* u3, const float* dx,
+                                const float* dg, float* L12_new, float* l3_new, float* U12_new, float* u3_new, int64_t N,
+                                int r, float step, float tiny, int has_tail, void* ws, int64_t ws_bytes, void* stream) {
+  if (!L12 || !U12 || !dx || !dg || !L12_new || !U12_new) return PSGD_ERR_BAD_ARG;
+  SpluCtx c;
+  const int rc = splu_ctx(N, r, ws, ws_bytes, stream, L12, &c);
+  if (rc) return rc;
+  if (misaligned16(L12_new)) return PSGD_ERR_ALIGN;
+  if (c.ge.n2 > 0 && (!l3 || !u3 || !l3_new || !u3_new)) return PSGD_ERR_BAD_ARG;
+  const int h = c.ge.head;
+  hipLaunchKernelGGL(k_splu_corner_upd3, dim3(1), dim3(kThreads), 0, c.st, L12, U12, c.ge.ldu, r, dx, dg, has_tail ? 1 : 0,
+                     step, tiny, c.w.dbl, c.w.maxbuf, c.w.coef, L12_new, U12_new);
+  PSGD_CHECK_LAUNCH(last_launch());
+  if (c.ge.n2 > 0) {
+    const int grid = splu_grid(c.ops, r, 5, c.ge.n2s, true);
+    PSGD_CHECK_LAUNCH(c.ops->upd_s4(c.nt, L12 + (int64_t)(r + h) * r, U12 + r + h, c.ge.ldu, l3 + h, u3 + h, dg + r + h,
+                                    dx + r + h, L12_new + (int64_t)(r + h) * r, U12_new + r + h, l3_new + h, u3_new + h,
+                                    c.ge.n2s, h, c.w.coef, grid, c.st));
   }
   return PSGD_OK;
 }
@@ -439,53 +562,14 @@ int psgd_splu_update_f32(const float* L12, const float* l3, const float* U12, co
                          const float* dg, float* L12_new, float* l3_new, float* U12_new, float* u3_new, int64_t N, int r,
                          float step, float tiny, void* ws, int64_t ws_bytes, void* stream) {
   if (!L12 || !U12 || !dx || !dg || !L12_new || !U12_new) return PSGD_ERR_BAD_ARG;
-  SpluWs w;
-  const int rc = splu_open(ws, ws_bytes, N, r, &w);
+  int rc = psgd_splu_stage1_f32(U12, dg, N, r, ws, ws_bytes, stream);
   if (rc) return rc;
-  const SpluGeom ge = splu_geom(N, r);
-  if (ge.n2 > 0 && (!l3 || !u3 || !l3_new || !u3_new)) return PSGD_ERR_BAD_ARG;
-  if (misaligned16(L12) || misaligned16(L12_new)) return PSGD_ERR_ALIGN;
-  const SpluOps* ops = splu_ops_for_rank(r);
-  if (!ops) return PSGD_ERR_RANK;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nt = policy_nt((int64_t)N * r * 8);
-  const int h = ge.head;
-  const float* U2 = U12 + r;
-  const float* L2s = L12 + (int64_t)(r + h) * r;
-  const float *x2 = dx + r, *g2 = dg + r;
-  const int rblocks = (r + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int r2blocks = (2 * r + kWavesPerBlock - 1) / kWavesPerBlock;
-
-  int grid = splu_grid(ops, r, 0, ge.n2s, false);
-  PSGD_CHECK_LAUNCH(ops->u2dot(nt, U2 + h, ge.ldu, g2 + h, ge.n2s, h, w.part, grid, st));
-  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumA);
-  hipLaunchKernelGGL(k_splu_corner1, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dg, dx, w.dbl, w.coef);
-  PSGD_CHECK_LAUNCH(last_launch());
-
-  grid = splu_grid(ops, r, 3, ge.n2s, true);
-  PSGD_CHECK_LAUNCH(ops->upd_s2(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, x2 + h, g2 + h, ge.n2s, h, w.coef, w.part, grid,
-                                st));
-  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(r2blocks), dim3(kThreads), 0, st, w.part, grid, 2 * r, w.dbl + kSumB);
-  // sums B are stored [L2'Qg2 (r) | L2'iQtx2 (r)] contiguously: kSumB + r + t addresses the second half
-  hipLaunchKernelGGL(k_splu_corner_upd2, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dx, w.dbl, w.coef);
-  PSGD_CHECK_LAUNCH(last_launch());
-
-  grid = splu_grid(ops, r, 4, ge.n2s, true);
-  PSGD_CHECK_LAUNCH(ops->upd_s3(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, g2 + h, x2 + h, ge.n2s, h, w.coef, w.part, w.pmax,
-                                grid, st));
-  hipLaunchKernelGGL(k_splu_reduce_sum, dim3(rblocks), dim3(kThreads), 0, st, w.part, grid, r, w.dbl + kSumC);
-  hipLaunchKernelGGL(k_splu_reduce_max, dim3(4), dim3(kThreads), 0, st, w.pmax, grid, w.maxbuf);
-  hipLaunchKernelGGL(k_splu_corner_upd3, dim3(1), dim3(kThreads), 0, st, L12, U12, ge.ldu, r, dx, dg, ge.n2 > 0 ? 1 : 0,
-                     step, tiny, w.dbl, w.maxbuf, w.coef, L12_new, U12_new);
-  PSGD_CHECK_LAUNCH(last_launch());
-
-  if (ge.n2 > 0) {
-    grid = splu_grid(ops, r, 5, ge.n2s, true);
-    PSGD_CHECK_LAUNCH(ops->upd_s4(nt, L2s, U2 + h, ge.ldu, l3 + h, u3 + h, g2 + h, x2 + h,
-                                  L12_new + (int64_t)(r + h) * r, U12_new + r + h, l3_new + h, u3_new + h, ge.n2s, h,
-                                  w.coef, grid, st));
-  }
-  return PSGD_OK;
+  rc = psgd_splu_update_stage2_f32(L12, l3, U12, u3, dx, dg, N, r, ws, ws_bytes, stream);
+  if (rc) return rc;
+  rc = psgd_splu_update_stage3_f32(L12, l3, U12, u3, dx, dg, N, r, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return psgd_splu_update_stage4_f32(L12, l3, U12, u3, dx, dg, L12_new, l3_new, U12_new, u3_new, N, r, step, tiny,
+                                     N > r ? 1 : 0, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

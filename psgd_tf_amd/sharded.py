@@ -197,3 +197,105 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
     be.apply_sweep2_local_s1(U, d, g)
     dist.all_reduce(be.sums(2), op=dist.ReduceOp.SUM, group=group)
     return be.apply_sweep3(U, V, d, g)
+
+
+# --------------------------------------------------------------------------- sparse LU (psgd.py:396-524), tail rows sharded
+class HipSpluStages:
+    """Stage functions of the C ABI on this rank's shard of the sparse-LU preconditioner: local tensors
+    L12 = [L1; local rows of L2] ([r + n_local, r]), U12 = [U1, local columns of U2], local slices of l3 / u3, flat
+    vectors [r corner entries (replicated); local slice of the tail].  Reduced buffers are views into the workspace."""
+
+    def __init__(self, device, n_local_total, r):
+        self.device, self.N, self.r = device, int(n_local_total), int(r)
+        self.lib = _lib.load()
+        self.ws = _psgd._splu_workspace(device, self.N, self.r)
+        self._views = {}
+
+    def _w(self):
+        return self.ws.data_ptr(), self.ws.numel(), torch.cuda.current_stream(self.device).cuda_stream
+
+    def _view(self, which, stage, dtype, itemsize):
+        key = (which, stage)
+        if key not in self._views:
+            off, cnt = _lib.splu_ws_region(which, stage, self.N, self.r)
+            self._views[key] = self.ws[off:off + cnt * itemsize].view(dtype)
+        return self._views[key]
+
+    def sums(self, stage):
+        return self._view(0, stage, torch.float64, 8)
+
+    def maxbuf(self):
+        return self._view(1, 3, torch.float32, 4)
+
+    def stage1(self, U12, x):
+        _lib.check(self.lib.psgd_splu_stage1_f32(U12.data_ptr(), x.data_ptr(), self.N, self.r, *self._w()), "splu stage1")
+
+    def apply_stage2(self, L12, l3, U12, u3, g):
+        self._out = torch.empty_like(g)
+        _lib.check(self.lib.psgd_splu_apply_stage2_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(),
+                                                       g.data_ptr(), self._out.data_ptr(), self.N, self.r, *self._w()),
+                   "splu apply stage2")
+
+    def apply_stage3(self, L12, l3, U12, u3):
+        out, self._out = self._out, None
+        _lib.check(self.lib.psgd_splu_apply_stage3_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(),
+                                                       out.data_ptr(), self.N, self.r, *self._w()), "splu apply stage3")
+        return out
+
+    def update_stage2(self, L12, l3, U12, u3, dx, dg):
+        _lib.check(self.lib.psgd_splu_update_stage2_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(),
+                                                        dx.data_ptr(), dg.data_ptr(), self.N, self.r, *self._w()),
+                   "splu update stage2")
+
+    def update_stage3(self, L12, l3, U12, u3, dx, dg):
+        _lib.check(self.lib.psgd_splu_update_stage3_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(),
+                                                        dx.data_ptr(), dg.data_ptr(), self.N, self.r, *self._w()),
+                   "splu update stage3")
+
+    def update_stage4(self, L12, l3, U12, u3, dx, dg, step, tiny, has_tail):
+        new = [torch.empty_like(t) for t in (L12, l3, U12, u3)]
+        wp, wn, st = self._w()
+        _lib.check(self.lib.psgd_splu_update_stage4_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(),
+                                                        dx.data_ptr(), dg.data_ptr(), new[0].data_ptr(), new[1].data_ptr(),
+                                                        new[2].data_ptr(), new[3].data_ptr(), self.N, self.r, float(step),
+                                                        float(tiny), int(bool(has_tail)), wp, wn, st), "splu update stage4")
+        return tuple(new)
+
+
+_splu_backends = {}
+
+
+def _splu_backend_for(L12):
+    if not L12.is_cuda:
+        raise _lib.PsgdHipError("sharded sparse LU runs on HIP devices only (tensor is on %s); no CPU fallback" % L12.device)
+    key = (L12.device.index, L12.shape[0], L12.shape[1])
+    if key not in _splu_backends:
+        _splu_backends[key] = HipSpluStages(L12.device, L12.shape[0], L12.shape[1])
+    return _splu_backends[key]
+
+
+def precond_grad_splu(L12, l3, U12, u3, grad, group=None, backend=None):
+    """Sharded psgd.py:483-524.  `grad` is this rank's flat vector [r corner entries; local tail slice]; returns the
+    same layout (corner entries identical on every rank).  Exchanges: SUM of r fp64 twice."""
+    be = backend if backend is not None else _splu_backend_for(L12)
+    r = U12.shape[0]
+    be.stage1(U12, grad)
+    dist.all_reduce(be.sums(1), op=dist.ReduceOp.SUM, group=group)
+    be.apply_stage2(L12, l3, U12, u3, grad)
+    dist.all_reduce(be.sums(2)[:r], op=dist.ReduceOp.SUM, group=group)
+    return be.apply_stage3(L12, l3, U12, u3)
+
+
+def update_precond_splu(L12, l3, U12, u3, dx, dg, step=0.01, tiny=None, has_tail=True, group=None, backend=None):
+    """Sharded psgd.py:396-480 on this rank's rows; returns this rank's (L12, l3, U12, u3) (corner blocks identical on
+    every rank).  Exchanges: SUM r, SUM 2r, SUM r + MAX 4 floats.  has_tail: the global problem has tail rows."""
+    be = backend if backend is not None else _splu_backend_for(L12)
+    tiny = _psgd._tiny if tiny is None else tiny
+    be.stage1(U12, dg)
+    dist.all_reduce(be.sums(1), op=dist.ReduceOp.SUM, group=group)
+    be.update_stage2(L12, l3, U12, u3, dx, dg)
+    dist.all_reduce(be.sums(2), op=dist.ReduceOp.SUM, group=group)
+    be.update_stage3(L12, l3, U12, u3, dx, dg)
+    dist.all_reduce(be.sums(3), op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(be.maxbuf(), op=dist.ReduceOp.MAX, group=group)
+    return be.update_stage4(L12, l3, U12, u3, dx, dg, step, tiny, has_tail)

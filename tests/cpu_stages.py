@@ -123,3 +123,99 @@ class NumpyStages:
         dn = self._np(d)
         mu = step / (float(self._max[12][0]) + tiny)
         dn -= mu * dn * self.nabla
+
+
+class NumpySpluStages:
+    """CPU stage backend for the sharded sparse LU (interface of psgd_tf_amd.sharded.HipSpluStages).  fp64 NumPy
+    restatement of the staged plan of psgd_splu.hip: reductions over the tail rows -> r x r corner algebra ->
+    row-local work; the test compares its sharded result with the reference-order oracle."""
+
+    def __init__(self, r):
+        self.r = r
+        self._sums = {1: torch.zeros(r, dtype=torch.float64), 2: torch.zeros(2 * r, dtype=torch.float64),
+                      3: torch.zeros(r, dtype=torch.float64)}
+        self._max = torch.zeros(4, dtype=torch.float32)
+
+    def sums(self, stage):
+        return self._sums[stage]
+
+    def maxbuf(self):
+        return self._max
+
+    def _blocks(self, L12, U12):
+        r = self.r
+        L12, U12 = L12.numpy(), U12.numpy()
+        return L12[:r], L12[r:], U12[:, :r], U12[:, r:]
+
+    def stage1(self, U12, x):
+        r = self.r
+        self._sums[1][:] = torch.from_numpy((U12.numpy()[:, r:] @ x.numpy()[r:]).ravel())
+
+    def apply_stage2(self, L12, l3, U12, u3, g):
+        r = self.r
+        L1, L2, U1, U2 = self._blocks(L12, U12)
+        g = g.numpy()
+        Ug1 = U1 @ g[:r] + self._sums[1].numpy().reshape(-1, 1)                     # psgd.py:506
+        self.Qg1 = L1 @ Ug1                                                          # :509
+        self.Qg2 = L2 @ Ug1 + l3.numpy() * (u3.numpy() * g[r:])                      # :507,510
+        self._sums[2][:r] = torch.from_numpy((L2.T @ self.Qg2).ravel())
+
+    def apply_stage3(self, L12, l3, U12, u3):
+        r = self.r
+        L1, L2, U1, U2 = self._blocks(L12, U12)
+        Lt1 = L1.T @ self.Qg1 + self._sums[2].numpy()[:r].reshape(-1, 1)             # :512
+        out = np.concatenate([U1.T @ Lt1, U2.T @ Lt1 + u3.numpy() * (l3.numpy() * self.Qg2)], 0)   # :513-516
+        return torch.from_numpy(out)
+
+    def update_stage2(self, L12, l3, U12, u3, dx, dg):
+        r = self.r
+        L1, L2, U1, U2 = self._blocks(L12, U12)
+        x, g, l, u = dx.numpy(), dg.numpy(), l3.numpy(), u3.numpy()
+        Ug1 = U1 @ g[:r] + self._sums[1].numpy().reshape(-1, 1)                      # :430
+        self.Qg1 = L1 @ Ug1                                                          # :433
+        self.iUtx1 = np.linalg.solve(np.triu(U1).T, x[:r])                           # :436
+        self.Qg2 = L2 @ Ug1 + l * (u * g[r:])                                        # :431,434
+        self.iQtx2 = (x[r:] - U2.T @ self.iUtx1) / u / l                             # :437,439
+        self._sums[2][:] = torch.from_numpy(np.concatenate([L2.T @ self.Qg2, L2.T @ self.iQtx2]).ravel())
+
+    def update_stage3(self, L12, l3, U12, u3, dx, dg):
+        r = self.r
+        L1, L2, U1, U2 = self._blocks(L12, U12)
+        x, g, l, u = dx.numpy(), dg.numpy(), l3.numpy(), u3.numpy()
+        sB = self._sums[2].numpy()
+        self.iQtx1 = np.linalg.solve(np.tril(L1).T, self.iUtx1 - sB[r:].reshape(-1, 1))     # :440
+        self.LtQg1 = L1.T @ self.Qg1 + sB[:r].reshape(-1, 1)                          # :442
+        self.Pg1 = U1.T @ self.LtQg1                                                  # :445
+        self.iLiQtx1 = np.linalg.solve(np.tril(L1), self.iQtx1)                       # :448
+        self.Pg2 = U2.T @ self.LtQg1 + u * (l * self.Qg2)                             # :443,446
+        self.iPx2 = (self.iQtx2 - L2 @ self.iLiQtx1) / l / u                          # :449,451
+        self._sums[3][:] = torch.from_numpy((U2 @ self.iPx2).ravel())
+        n2 = L2.shape[0]
+        gL2, gL3 = self.Qg2 @ self.Qg1.T - self.iQtx2 @ self.iQtx1.T, self.Qg2 ** 2 - self.iQtx2 ** 2
+        gU2, gU3 = self.Pg1 @ g[r:].T - x[:r] @ self.iPx2.T, self.Pg2 * g[r:] - x[r:] * self.iPx2
+        mx = lambda a: float(np.max(np.abs(a))) if a.size else 0.0
+        self._max[:] = torch.tensor([max(mx(gL2), mx(gL3)), max(mx(gU2), mx(gU3)),
+                                     float(np.max(l)) if n2 else -np.inf, float(np.max(u)) if n2 else -np.inf],
+                                    dtype=torch.float32)
+
+    def update_stage4(self, L12, l3, U12, u3, dx, dg, step, tiny, has_tail):
+        r = self.r
+        L1, L2, U1, U2 = self._blocks(L12, U12)
+        x, g, l, u = dx.numpy(), dg.numpy(), l3.numpy(), u3.numpy()
+        m = self._max.numpy().astype(np.float64)
+        iPx1 = np.linalg.solve(np.triu(U1), self.iLiQtx1 - self._sums[3].numpy().reshape(-1, 1))   # :452
+        max_l = max(np.max(np.diag(L1)), m[2]) if has_tail else np.max(np.diag(L1))   # :411-413
+        max_u = max(np.max(np.diag(U1)), m[3]) if has_tail else np.max(np.diag(U1))
+        rho = np.sqrt(max_l / max_u)
+        L1s, L2s, l3s, U1s, U2s, u3s = L1 / rho, L2 / rho, l / rho, rho * U1, rho * U2, rho * u
+        gL1 = np.tril(self.Qg1 @ self.Qg1.T - self.iQtx1 @ self.iQtx1.T)               # :455-458
+        gL2, gL3 = self.Qg2 @ self.Qg1.T - self.iQtx2 @ self.iQtx1.T, self.Qg2 ** 2 - self.iQtx2 ** 2
+        s0 = step / (max(np.max(np.abs(gL1)), m[0] if has_tail else 0.0) + tiny)       # :459-462
+        nL = np.concatenate([L1s - s0 * gL1 @ L1s, L2s - s0 * gL2 @ L1s - s0 * gL3 * L2s], 0)   # :463-464
+        nl3 = l3s - s0 * gL3 * l3s                                                     # :465
+        gU1 = np.triu(self.Pg1 @ g[:r].T - x[:r] @ iPx1.T)                             # :468-471
+        gU2, gU3 = self.Pg1 @ g[r:].T - x[:r] @ self.iPx2.T, self.Pg2 * g[r:] - x[r:] * self.iPx2
+        s0 = step / (max(np.max(np.abs(gU1)), m[1] if has_tail else 0.0) + tiny)       # :472-475
+        nU = np.concatenate([U1s - U1s @ (s0 * gU1), U2s - U1s @ (s0 * gU2) - s0 * gU3.T * U2s], 1)   # :476-477
+        nu3 = u3s - s0 * gU3 * u3s                                                     # :478
+        return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in (nL, nl3, nU, nu3))

@@ -107,3 +107,67 @@ def test_shard_rows_cover_and_align():
         for (lo, hi), (lo2, _) in zip(edges, edges[1:]):
             assert hi == lo2 and lo <= hi
         assert all(lo % 64 == 0 for lo, hi in edges if hi > lo)
+
+
+# ----------------------------------------------------------------------------- sparse LU, tail rows sharded
+SPLU_N, SPLU_R = 61, 5
+
+
+def _splu_local(p, lo, hi):
+    """This rank's tensors: the r x r corner replicated, tail rows [lo, hi) (tail-relative)."""
+    r = SPLU_R
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float64)))
+    loc = {"L12": f(np.concatenate([p["L12"][:r], p["L12"][r + lo:r + hi]], 0)),
+           "U12": f(np.concatenate([p["U12"][:, :r], p["U12"][:, r + lo:r + hi]], 1)),
+           "l3": f(p["l3"][lo:hi]), "u3": f(p["u3"][lo:hi])}
+    for k in ("dx", "dg", "g"):
+        loc[k] = f(np.concatenate([p[k][:r], p[k][r + lo:r + hi]], 0))
+    return loc
+
+
+def _splu_worker(rank, world, port, outdir, cut):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from psgd_tf_amd import sharded
+        from tests.cpu_stages import NumpySpluStages
+        from tests.splu_cases import make_splu_problem
+        p = make_splu_problem(SPLU_N, SPLU_R, seed=33)
+        n2 = SPLU_N - SPLU_R
+        lo, hi = (0, cut) if rank == 0 else (cut, n2)
+        t = _splu_local(p, lo, hi)
+        be = NumpySpluStages(SPLU_R)
+        out0 = sharded.precond_grad_splu(t["L12"], t["l3"], t["U12"], t["u3"], t["g"], backend=be)
+        new = sharded.update_precond_splu(t["L12"], t["l3"], t["U12"], t["u3"], t["dx"], t["dg"], 0.1, TINY, backend=be)
+        out1 = sharded.precond_grad_splu(*new, t["g"], backend=be)
+        np.savez(os.path.join(outdir, "splu%d.npz" % rank), out0=out0.numpy(), out1=out1.numpy(),
+                 L12=new[0].numpy(), l3=new[1].numpy(), U12=new[2].numpy(), u3=new[3].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("cut", [29, 56])          # 29 + 27 rows; 56 + 0: one rank holds the corner only
+def test_sharded_splu_equals_unsharded_oracle(cut):
+    from tests.splu_cases import make_splu_problem
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_splu_worker, args=(WORLD, _free_port(), outdir, cut), nprocs=WORLD, join=True)
+        parts = [np.load(os.path.join(outdir, "splu%d.npz" % k)) for k in range(WORLD)]
+    r = SPLU_R
+    p = {k: v.astype(np.float64) for k, v in make_splu_problem(SPLU_N, SPLU_R, seed=33).items()}
+    ref0 = orc.precond_grad_splu(p["L12"], p["l3"], p["U12"], p["u3"], [p["g"]])[0]
+    new = orc.update_precond_splu(p["L12"], p["l3"], p["U12"], p["u3"], [p["dx"]], [p["dg"]], 0.1)
+    ref1 = orc.precond_grad_splu(*new, [p["g"]])[0]
+    asm_vec = lambda key: np.concatenate([parts[0][key][:r], parts[0][key][r:], parts[1][key][r:]], 0)
+    for a, b in ((parts[0]["out0"][:r], parts[1]["out0"][:r]), (parts[0]["L12"][:r], parts[1]["L12"][:r]),
+                 (parts[0]["U12"][:, :r], parts[1]["U12"][:, :r])):
+        assert np.array_equal(a, b)                     # replicated corner results are identical on both ranks
+    # the fp32 MAX buffer rounds the maxima to fp32 (as the product does), hence 1e-7 rather than 1e-13
+    assert rel_err(asm_vec("out0"), ref0) < 1e-12
+    L12 = np.concatenate([parts[0]["L12"], parts[1]["L12"][r:]], 0)
+    U12 = np.concatenate([parts[0]["U12"], parts[1]["U12"][:, r:]], 1)
+    l3, u3 = np.concatenate([parts[0]["l3"], parts[1]["l3"]], 0), np.concatenate([parts[0]["u3"], parts[1]["u3"]], 0)
+    for got, want in ((L12, new[0]), (l3, new[1]), (U12, new[2]), (u3, new[3])):
+        assert rel_err(got, want) < 1e-7
+    assert rel_err(asm_vec("out1"), ref1) < 1e-7
