@@ -164,3 +164,37 @@ def test_splu_world1_and_real_shards(pg, hip_lib):
     out = torch.cat([outs[0], outs[1][r:]], 0)
     assert torch.equal(outs[0][:r], outs[1][:r])
     assert rel_err(out.cpu().numpy(), orc.precond_grad_splu(*ref_new, [q["g"]])[0].reshape(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("N,r,cuts", [(100003, 20, (0, 40000, 100003)), (300001, 10, (0, 64, 150016, 300001))])
+def test_uvd_fused_step_on_real_shards(hip_lib, N, r, cuts):
+    """The choreography bench.py runs at --gpus N > 1 (sharded.update_precond_UVd_math_and_precond_grad): Gram SUM,
+    max MAX + p,q SUM, s2 SUM -- on real shards in one process with hand-emulated collectives, both branches."""
+    import preconditioned_stochastic_gradient_descent as psgd
+    from psgd_tf_amd import sharded
+    p = make_uvd_problem(N, r, seed=13, uv_gain=2.0, d_spread=0.3)
+    full = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    sh = [{k: torch.from_numpy(np.ascontiguousarray(v[a:b])).cuda() for k, v in p.items()} for a, b in zip(cuts, cuts[1:])]
+    bes = [sharded.HipStages(torch.device("cuda:0"), s["U"].shape[0], r) for s in sh]
+    q = {k: v.astype(np.float64) for k, v in p.items()}
+    for upd in (True, False):
+        want = psgd.update_precond_UVd_math_and_precond_grad(full["U"], full["V"], full["d"], full["v"], full["h"],
+                                                             full["g"], 0.01, TINY32, balance=False, update_U=upd)
+        orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=upd)
+        for be, s in zip(bes, sh):
+            be.update_sweep1(s["U"], s["V"], s["d"], s["v"], s["h"])
+        _allreduce_emulated([be.sums(11) for be in bes], "sum")
+        for be, s in zip(bes, sh):
+            be.update_sweep2_fused(s["U"], s["V"], s["d"], s["v"], s["h"], s["g"], 0.01, TINY32, upd)
+        _allreduce_emulated([be.maxbuf(12) for be in bes], "max")
+        _allreduce_emulated([be.sums(13) for be in bes], "sum")
+        for be, s in zip(bes, sh):
+            be.update_sweep3(s["d"], 0.01, TINY32)
+            be.fused_s1(0.01, TINY32)
+            be.apply_sweep2_local_s1(s["U"], s["d"], s["g"])
+        _allreduce_emulated([be.sums(2) for be in bes], "sum")
+        out = torch.cat([be.apply_sweep3(s["U"], s["V"], s["d"], s["g"]) for be, s in zip(bes, sh)], 0)
+        assert rel_err(out.cpu().numpy(), want.cpu().numpy()) < 2e-6, upd
+        assert rel_err(out.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < 1e-5, upd
+        for k in ("U", "V", "d"):
+            assert rel_err(torch.cat([s[k] for s in sh], 0).cpu().numpy(), full[k].cpu().numpy()) < 1e-6, (k, upd)
