@@ -48,6 +48,7 @@ struct GemmArgs {
   int kmode, kmode2;
   long c_cs;
   const float* colv; int colsq;         // EPI_STORE: C(m,n) *= colv[n] (colsq: *= colv[n]^2)
+  int sym;                              // C is symmetric (Gram X'X): tiles below the diagonal are skipped, the others stored twice
 };
 
 enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8 };
@@ -206,6 +207,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
             v *= g.colsq ? cv * cv : cv;
           }
           g.C[(long)row * g.ldc + col * ccs] = v;
+          if (g.sym && n0 > m0) g.C[(long)col * g.ldc + row * ccs] = v;      // the mirror tile is not computed
         }
       }
   if (g.epi == EPI_TRIU_MAX) {
@@ -221,7 +223,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, Gem
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1;
   // upper-triangular outputs: tiles strictly below the diagonal are all zero
-  const bool tri_skip = (g.epi == EPI_TRIU_MAX) && (m0 >= n0 + T);
+  const bool tri_skip = (g.epi == EPI_TRIU_MAX || g.sym) && (m0 >= n0 + T);
+  if (g.sym && tri_skip) return;        // written by the mirror tile's epilogue (a triu tile below the diagonal stores zeros instead)
 
   f32x4 acc[NT][NT];
 #pragma unroll
@@ -377,7 +380,8 @@ __device__ __forceinline__ void gemm_body_x3(const GemmArgs& g, int m0, int n0, 
   constexpr int T = 128, GK = kX3K, W = 64, NT = 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1;
-  const bool tri_skip = (g.epi == EPI_TRIU_MAX) && (m0 >= n0 + T);
+  const bool tri_skip = (g.epi == EPI_TRIU_MAX || g.sym) && (m0 >= n0 + T);
+  if (g.sym && tri_skip) return;        // written by the mirror tile's epilogue (a triu tile below the diagonal stores zeros instead)
 
   f32x4 acc[NT][NT];
 #pragma unroll
@@ -1066,11 +1070,13 @@ static void plan_apply(const float* Ql, const float* Qr, const float* G, float* 
                        GemmArgs (&s)[4]) {
   if (M < N) {                                                                    // psgd.py:189-190
     s[0] = gemm_args(Ql, M, true, Ql, M, false, k.g1, M, M, M, M, KHI_M | KHI_N);   // Ql'Ql
+    s[0].sym = 1;
     s[1] = gemm_args(k.g1, M, false, G, N, false, k.T, N, M, N, M);                 // (.) G
     s[2] = gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N, KLO_N);           // (.) Qr'
     s[3] = gemm_args(k.A, N, false, Qr, N, false, out, N, M, N, N, KHI_N);          // (.) Qr
   } else {                                                                        // psgd.py:191-192
     s[0] = gemm_args(Qr, N, true, Qr, N, false, k.g2, N, N, N, N, KHI_M | KHI_N);   // Qr'Qr
+    s[0].sym = 1;
     s[1] = gemm_args(G, N, false, k.g2, N, false, k.T, N, M, N, N);                 // G (.)
     s[2] = gemm_args(Ql, M, false, k.T, N, false, k.A, N, M, N, M, KLO_M);          // Ql (.)
     s[3] = gemm_args(Ql, M, true, k.A, N, false, out, N, M, N, M, KHI_M);           // Ql' (.)
