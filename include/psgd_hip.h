@@ -285,6 +285,15 @@ int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,
                             int64_t ws_bytes, void *stream);
+/* bf16-operand variant of _update_precond_dense_dense (psgd.py:156-180), the update-side companion of the entry
+ * point above (same contract: outside the reference's fp32-only API, M and N multiples of 8, upper-triangular fp32
+ * master factors in, fp32 updated factors out; dX, dG are bf16 [M,N]).  fp32 throughout: the balance (:166-170), the
+ * two triangular solves of :174, the max-norms and step sizes of :177-178 and the subtraction Q - step*grad*Q.  bf16
+ * operands with fp32 accumulation: A = Ql dG Qr' (:173), the Grams of :175-176 and grad * Q (:179-180).            */
+int64_t psgd_kron_dd_update_workspace_bytes_bf16(int M, int N);
+int psgd_kron_dd_update_bf16(const float *Ql, const float *Qr, const void *dX_bf16, const void *dG_bf16,
+                             float *QlOut, float *QrOut, int M, int N, float step, float tiny,
+                             void *ws, int64_t ws_bytes, void *stream);
 /* Debug aid (synchronises): 1 if a bounded spin of the fused triangular pair of the last bf16 apply on this
  * workspace gave up (a block was not resident), else 0.  The apply's result is invalid in that case.          */
 int psgd_kron_bf16_handoff_timeouts(const void *ws, int M, int N);

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "psgd_hip.h"
+#include "kron_shared.h"
 
 namespace psgdk {
 
@@ -1189,6 +1190,19 @@ static int launch_gemm_batch(const GemmArgs* g, int count, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// entry points shared with psgd_kron_bf16.hip (kron_shared.h)
+int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st) {
+  const long tot = (long)M * M + (long)N * N;
+  int grid = (int)((tot + kThreads - 1) / kThreads);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS);
+  return (int)hipGetLastError();
+}
+
+int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st) {
+  return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st);
+}
+
 }  // namespace psgdk
 
 using namespace psgdk;
@@ -1238,13 +1252,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
   if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
-  {                                                                               // K0: balance (:166-170)
-    const long tot = (long)M * M + (long)N * N;
-    int grid = (int)((tot + kThreads - 1) / kThreads);
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, k.QlS, k.QrS);
-    KRON_LAUNCH((int)hipGetLastError());
-  }
+  KRON_LAUNCH(kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st));                       // K0: balance (:166-170)
   GemmArgs s[6];
   plan_update(dG, QlOut, QrOut, M, N, step, tiny, k, s);
   KRON_LAUNCH(launch_gemm(s[0], st));

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "psgd_hip.h"
+#include "kron_shared.h"
 
 namespace psgdh {
 
@@ -47,7 +48,16 @@ struct HGemmArgs {
   int c_bf16, c_trans;              // element type and orientation of the stored result
   int M, N, K, kmode;
   int sym;                          // C is symmetric (A == B): tiles below the diagonal are skipped, the others stored twice
+  // k_hgemm_nt only (the bf16-operand update):
+  int epi;                          // HEPI_STORE | HEPI_TRIU_MAX (C = triu(acc), max|C| -> maxout, no mirror store) |
+                                    // HEPI_D_MINUS (C = D - step / (*scale_max + tiny) * acc, fp32)
+  int kflip;                        // > 0: the accumulators change sign before K tile `kflip` (C = -A1 B1' + A2 B2' over a
+                                    // concatenated K axis)
+  float* maxout;
+  const float* D; long ldd;
+  const float* scale_max; float step, tiny;
 };
+enum { HEPI_STORE = 0, HEPI_TRIU_MAX = 1, HEPI_D_MINUS = 2 };
 
 __device__ __forceinline__ uint16_t f2bf(float x) {
   // round-to-nearest-even; NaN stays NaN through the hardware conversion of a plain cast
@@ -154,6 +164,12 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt == g.kflip && kt > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = -acc[i][j];
+    }
 #pragma unroll
     for (int ks = 0; ks < TK / 32; ++ks) {
       bf16x8 a[4], b[4];
@@ -178,6 +194,8 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
   }
 
   // epilogue: acc[i][j][e] is C[row = ..+(lane>>4)*4+e][col = ..+(lane&15)]
+  float vmax = 0.0f;
+  const float dscale = (g.epi == HEPI_D_MINUS) ? g.step / (*g.scale_max + g.tiny) : 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -185,6 +203,18 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
       const int row0 = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
       const int col = n0 + wn * 64 + j * 16 + (lane & 15);
       if (col >= g.N) continue;
+      if (g.epi == HEPI_TRIU_MAX) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (col >= row0 + e && row0 + e < g.M) ? acc[i][j][e] : 0.0f;
+          vmax = fmaxf(vmax, fabsf(v));
+          acc[i][j][e] = v;
+        }
+      } else if (g.epi == HEPI_D_MINUS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (row0 + e < g.M) acc[i][j][e] = g.D[(long)(row0 + e) * g.ldd + col] - dscale * acc[i][j][e];
+      }
       if (g.c_trans) {
         if (row0 + 3 < g.M) {
           if (g.c_bf16) {
@@ -210,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
             if (g.c_bf16) static_cast<uint16_t*>(g.C)[(long)(row0 + e) * g.ldc + col] = f2bf(acc[i][j][e]);
             else static_cast<float*>(g.C)[(long)(row0 + e) * g.ldc + col] = acc[i][j][e];
           }
-        if (g.sym && n0 > m0) {       // mirror: C[col][row0 .. row0+3] (M == N, multiples of 8 by contract)
+        if (g.sym && n0 > m0 && g.epi == HEPI_STORE) {   // mirror: C[col][row0 .. row0+3] (M == N, multiples of 8 by contract)
           if (g.c_bf16) {
             uint16_t* p = static_cast<uint16_t*>(g.C) + (long)col * g.ldc + row0;
             if (row0 + 3 < g.M) {
@@ -227,6 +257,11 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
         }
       }
     }
+  if (g.epi == HEPI_TRIU_MAX) {     // max |triu(C)| of the whole product: one atomic per wave (values are >= 0: int order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0 && vmax > 0.0f) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -791,9 +826,15 @@ static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large den
                                   //    tile gets its own CU, else 128^2 register-staged); 4: auto without the fused pair;
                                   // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
 
-static int launch_hgemm(const uint16_t* A, long lda, const uint16_t* B, long ldb, void* C, long ldc, int c_bf16,
-                        int c_trans, int M, int N, int K, int kmode, hipStream_t st, int sym = 0) {
-  HGemmArgs g = {A, lda, B, ldb, C, ldc, c_bf16, c_trans, M, N, K, kmode, sym};
+static int launch_hgemm_args(const HGemmArgs& g, hipStream_t st) {
+  const uint16_t *A = g.A, *B = g.B;
+  const long lda = g.lda, ldb = g.ldb;
+  const int M = g.M, N = g.N, K = g.K, kmode = g.kmode, sym = g.sym;
+  if (g.epi != HEPI_STORE || g.kflip) {       // the update epilogues live in the 128^2 register-staged kernel only
+    const int tq = (M + TM - 1) / TM;
+    hipLaunchKernelGGL(k_hgemm_nt, dim3(sym ? tq * (tq + 1) / 2 : tq * ((N + TN - 1) / TN)), dim3(kThreads), 0, st, g);
+    return (int)hipGetLastError();
+  }
   const int tm_ = (M + TM - 1) / TM;
   const int nt = sym ? tm_ * (tm_ + 1) / 2 : tm_ * ((N + TN - 1) / TN);
   const bool interior = (M % TM == 0) && (N % TN == 0) && (K % TM == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
@@ -808,6 +849,12 @@ static int launch_hgemm(const uint16_t* A, long lda, const uint16_t* B, long ldb
   else if (g_hgemm_variant == 2 && interior && !sym) hipLaunchKernelGGL(k_hgemm_nt_dma, dim3(nt), dim3(kThreads), 0, st, g);
   else hipLaunchKernelGGL(k_hgemm_nt, dim3(nt), dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
+}
+
+static int launch_hgemm(const uint16_t* A, long lda, const uint16_t* B, long ldb, void* C, long ldc, int c_bf16,
+                        int c_trans, int M, int N, int K, int kmode, hipStream_t st, int sym = 0) {
+  HGemmArgs g = {A, lda, B, ldb, C, ldc, c_bf16, c_trans, M, N, K, kmode, sym};
+  return launch_hgemm_args(g, st);
 }
 
 static int device_cu_count() {
@@ -868,6 +915,50 @@ static int launch_cvt(const void* src, int src_bf16, long lds_, uint16_t* dst, l
   if (src_bf16) hipLaunchKernelGGL((k_to_bf16<true>), grid, dim3(kThreads), 0, st, src, lds_, dst, ldd, rows, cols, transpose);
   else hipLaunchKernelGGL((k_to_bf16<false>), grid, dim3(kThreads), 0, st, src, lds_, dst, ldd, rows, cols, transpose);
   return (int)hipGetLastError();
+}
+
+// dst (fp32) = src (bf16), contiguous; n multiple of 8
+__global__ __launch_bounds__(kThreads) void k_bf16_to_f32(const uint16_t* __restrict__ src, float* __restrict__ dst, long n8) {
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n8; i += (long)gridDim.x * kThreads) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 8);
+    f32x4 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      lo[2 * e] = __uint_as_float(v[e] << 16);         lo[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+      hi[2 * e] = __uint_as_float(v[2 + e] << 16);     hi[2 * e + 1] = __uint_as_float(v[2 + e] & 0xffff0000u);
+    }
+    *reinterpret_cast<f32x4*>(dst + i * 8) = lo;
+    *reinterpret_cast<f32x4*>(dst + i * 8 + 4) = hi;
+  }
+}
+
+// Workspace of the bf16-operand update.  fp32: the balanced factors, the solve chain, the two max words.
+// bf16: both orientations of the balanced factors, T' = (dG QrS')', the K-concatenated Gram operands
+// W1 = [Bt | 0 | A] (M rows) and W2 = [Bt' | 0 | A'] (N rows), and the two triangular gradients.
+struct HUpdWs {
+  float *scal, *QlS, *QrS, *X0, *X1, *Bt, *dinv;
+  uint16_t *Qlb, *QlTb, *Qrb, *QrTb, *Tt, *W1, *W2, *g1, *g2;
+  int n64, m64;             // column offset of the A part in W1 (N rounded up to the K tile) / of A' in W2
+  int64_t w1_bytes, w2_bytes, total;
+};
+
+static HUpdWs hupd_layout(char* base, int M, int N) {
+  HUpdWs k;
+  const int64_t mm = (int64_t)M * M, nn = (int64_t)N * N, mn = (int64_t)M * N;
+  k.n64 = (N + TK - 1) / TK * TK; k.m64 = (M + TK - 1) / TK * TK;
+  int64_t off = 0;
+  auto takef = [&](int64_t elems) { float* p = reinterpret_cast<float*>(base + off); off = align256(off + elems * 4); return p; };
+  auto takeh = [&](int64_t elems) { uint16_t* p = reinterpret_cast<uint16_t*>(base + off); off = align256(off + elems * 2); return p; };
+  k.scal = takef(64);
+  k.QlS = takef(mm); k.QrS = takef(nn); k.X0 = takef(mn); k.X1 = takef(mn); k.Bt = takef(mn);
+  k.dinv = takef((int64_t)((M + 31) / 32 + (N + 31) / 32) * 1024);
+  k.Qlb = takeh(mm); k.QlTb = takeh(mm); k.Qrb = takeh(nn); k.QrTb = takeh(nn);
+  k.Tt = takeh(mn);
+  k.w1_bytes = (int64_t)M * (k.n64 + N) * 2; k.w2_bytes = (int64_t)N * (k.m64 + M) * 2;
+  k.W1 = takeh(k.w1_bytes / 2); k.W2 = takeh(k.w2_bytes / 2);
+  k.g1 = takeh(mm); k.g2 = takeh(nn);
+  k.total = off;
+  return k;
 }
 
 static int launch_factors_cvt(const HWs& k, FactorJob j0, FactorJob j1, hipStream_t st) {
@@ -963,6 +1054,78 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
       // out = Ql' T3            A = Ql' [M][K=M] (k <= m), Bt = T3'
       HK(launch_hgemm(k.QlT, M, k.T3, M, out, N, 1, 0, M, N, M, KHI_M, st));
     }
+  }
+  return PSGD_OK;
+}
+
+int64_t psgd_kron_dd_update_workspace_bytes_bf16(int M, int N) {
+  if (M <= 0 || N <= 0) return PSGD_ERR_BAD_ARG;
+  return hupd_layout(nullptr, M, N).total;
+}
+
+/* update_precond_kron dense (x) dense (psgd.py:160-180) with bf16 matrix-core operands.  fp32 master factors in and
+ * out; dX, dG arrive in bf16.  What stays fp32: the balance (:166-170), both triangular solves of :174 (their
+ * conditioning is the factors'), the max-norms, the step sizes and the final subtraction Q - step * grad * Q.
+ * What runs on bf16 operands with fp32 accumulation: A = QlS dG QrS' (:173), the four Grams of :175-176 (two launches:
+ * each gradient is ONE symmetric product over a concatenated K axis, [Bt | A][Bt | A]' with the accumulators negated
+ * between the halves) and grad * Q of :179-180. */
+int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, const void* dG, float* QlOut,
+                             float* QrOut, int M, int N, float step, float tiny, void* ws, int64_t ws_bytes,
+                             void* stream) {
+  if (!Ql || !Qr || !dX || !dG || !QlOut || !QrOut) return PSGD_ERR_BAD_ARG;
+  if (M <= 0 || N <= 0 || (M % 8) || (N % 8)) return PSGD_ERR_SHAPE;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < hupd_layout(nullptr, M, N).total)
+    return PSGD_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(dX) & 15) || (reinterpret_cast<uintptr_t>(dG) & 15)) return PSGD_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HUpdWs k = hupd_layout(static_cast<char*>(ws), M, N);
+  const uint16_t* dGb = static_cast<const uint16_t*>(dG);
+  const int ld1 = k.n64 + N, ld2 = k.m64 + M;
+  if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
+  // the zero columns between the two halves of the concatenated K axis (only when N or M is not a K-tile multiple)
+  if (k.n64 != N && hipMemsetAsync(k.W1, 0, (size_t)k.w1_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
+  if (k.m64 != M && hipMemsetAsync(k.W2, 0, (size_t)k.w2_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
+  HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st));                           // :166-170
+  {
+    dim3 grid((max(M, N) + 63) / 64, (max(M, N) + 63) / 64, 2);
+    hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, FactorJob{k.QlS, k.Qlb, k.QlTb, M},
+                       FactorJob{k.QrS, k.Qrb, k.QrTb, N}, static_cast<unsigned*>(nullptr), 0);
+    HK((int)hipGetLastError());
+  }
+  // T' [N][M] = (dG QrS')'      A = dG [M][K=N], Bt[n][k] = QrS[n][k], k >= n                      (:173)
+  HK(launch_hgemm(dGb, N, k.Qrb, N, k.Tt, M, 1, 1, M, N, N, KLO_N, st));
+  // A = QlS T  -> second half of W1     A operand QlS [M][K=M], k >= m; Bt = T'
+  HK(launch_hgemm(k.Qlb, M, k.Tt, M, k.W1 + k.n64, ld1, 1, 0, M, N, M, KLO_M, st));
+  HK(launch_cvt(k.W1 + k.n64, 1, ld1, k.W2 + k.m64, ld2, M, N, 1, st));              // A' -> second half of W2
+  // Bt = QlS^-T dX QrS^-1 in fp32                                                                   (:174)
+  {
+    const long n8 = (long)M * N / 8;
+    int grid = (int)((n8 + kThreads - 1) / kThreads);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(grid), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dX), k.X0, n8);
+    HK((int)hipGetLastError());
+  }
+  HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st));
+  HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st));
+  HK(launch_cvt(k.Bt, 0, N, k.W1, ld1, M, N, 0, st));                                 // Bt  -> first half of W1
+  HK(launch_cvt(k.Bt, 0, N, k.W2, ld2, M, N, 1, st));                                 // Bt' -> first half of W2
+  // grad1 = triu(A A' - Bt Bt'), grad2 = triu(A'A - Bt'Bt)                                          (:175-176)
+  {
+    HGemmArgs g = {k.W1, ld1, k.W1, ld1, k.g1, M, 1, 0, M, M, ld1, 0, 1};
+    g.epi = HEPI_TRIU_MAX; g.kflip = k.n64 / TK; g.maxout = k.scal + 0;
+    HK(launch_hgemm_args(g, st));
+    HGemmArgs h = {k.W2, ld2, k.W2, ld2, k.g2, N, 1, 0, N, N, ld2, 0, 1};
+    h.epi = HEPI_TRIU_MAX; h.kflip = k.m64 / TK; h.maxout = k.scal + 1;
+    HK(launch_hgemm_args(h, st));
+  }
+  // Ql_new = QlS - step / (max|grad1| + tiny) grad1 QlS, same for Qr                                (:177-180)
+  {
+    HGemmArgs g = {k.g1, M, k.QlTb, M, QlOut, M, 0, 0, M, M, M, KLO_M | KHI_N, 0};
+    g.epi = HEPI_D_MINUS; g.D = k.QlS; g.ldd = M; g.scale_max = k.scal + 0; g.step = step; g.tiny = tiny;
+    HK(launch_hgemm_args(g, st));
+    HGemmArgs h = {k.g2, N, k.QrTb, N, QrOut, N, 0, 0, N, N, N, KLO_M | KHI_N, 0};
+    h.epi = HEPI_D_MINUS; h.D = k.QrS; h.ldd = N; h.scale_max = k.scal + 1; h.step = step; h.tiny = tiny;
+    HK(launch_hgemm_args(h, st));
   }
   return PSGD_OK;
 }

@@ -30,18 +30,21 @@ def kron_format(shape_l, shape_r):
     return "unknown"
 
 
-def _check_rank2_f32(name, *tensors, allow_bf16_last=False):
+def _check_rank2_f32(name, *tensors, allow_bf16_last=False, allow_bf16_from=None):
     # the reference pins its public Kron functions to rank-2 fp32 (psgd.py:67-71, 113-115);
-    # the one extension is a bf16 gradient for the (dense, dense) apply (BASELINE config 5)
+    # the one extension is bf16 data for (dense, dense): a bf16 gradient for the apply (BASELINE config 5),
+    # a bf16 (dX, dG) pair for the update.  The factors stay fp32.
+    first_bf16 = len(tensors) - 1 if allow_bf16_last else allow_bf16_from
     for i, t in enumerate(tensors):
         if t.dim() != 2:
             raise ValueError("%s: rank-2 tensors required, got shape %s" % (name, tuple(t.shape)))
-        if t.dtype != torch.float32 and not (allow_bf16_last and i == len(tensors) - 1 and t.dtype == torch.bfloat16):
+        if t.dtype != torch.float32 and not (first_bf16 is not None and i >= first_bf16 and t.dtype == torch.bfloat16):
             raise TypeError("%s: fp32 tensors required, got %s" % (name, t.dtype))
 
 
 # --------------------------------------------------------------------------- dense (x) dense: HIP
 _kron_ws = _lib.WorkspaceCache()
+_kron_ws_bf16 = _lib.WorkspaceCache()
 
 
 def _kron_workspace(device, M, N):
@@ -60,9 +63,32 @@ def _require_hip(name, *tensors):
             raise _lib.PsgdHipError("%s runs on the HIP device only (tensor is on %s); no CPU fallback" % (name, t.device))
 
 
+def _update_precond_dense_dense_bf16(Ql, Qr, dX, dG, step):
+    """psgd.py:156-179 with bf16 MFMA operands for the products (dX, dG in bf16; fp32 master factors in and out;
+    balance, triangular solves, norms and the final subtraction stay fp32)."""
+    M, N = dX.shape
+    if M % 8 or N % 8:
+        raise ValueError("update_precond_kron: the bf16 path needs M and N to be multiples of 8, got %dx%d" % (M, N))
+    Ql, Qr, dX, dG = (t.contiguous() for t in (Ql, Qr, dX, dG))
+    QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
+    key = (dX.device.index, "upd", M, N)
+    ws = _kron_ws_bf16.get(key, lambda: torch.empty(int(_lib.load().psgd_kron_dd_update_workspace_bytes_bf16(M, N)),
+                                                      dtype=torch.uint8, device=dX.device))
+    rc = _lib.load().psgd_kron_dd_update_bf16(Ql.data_ptr(), Qr.data_ptr(), dX.data_ptr(), dG.data_ptr(),
+                                               QlO.data_ptr(), QrO.data_ptr(), M, N, float(step), float(_tiny),
+                                               ws.data_ptr(), ws.numel(),
+                                               torch.cuda.current_stream(dX.device).cuda_stream)
+    _lib.check(rc, "psgd_kron_dd_update_bf16")
+    return QlO, QrO
+
+
 def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
     """psgd.py:156-179 on the GPU; pure (fresh outputs)."""
     _require_hip("update_precond_kron", Ql, Qr, dX, dG)
+    if dX.dtype != dG.dtype:
+        raise TypeError("update_precond_kron: dX and dG must share a dtype, got %s and %s" % (dX.dtype, dG.dtype))
+    if dX.dtype == torch.bfloat16:
+        return _update_precond_dense_dense_bf16(Ql, Qr, dX, dG, step)
     M, N = dX.shape
     Ql, Qr, dX, dG = (t.contiguous() for t in (Ql, Qr, dX, dG))
     QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
@@ -73,9 +99,6 @@ def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
                                               torch.cuda.current_stream(dX.device).cuda_stream)
     _lib.check(rc, "psgd_kron_dd_update_f32")
     return QlO, QrO
-
-
-_kron_ws_bf16 = _lib.WorkspaceCache()
 
 
 def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
@@ -256,8 +279,8 @@ def _precond_grad_norm_scale(ql, qr, Grad):
 
 # --------------------------------------------------------------------------- public dispatchers
 def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
-    _check_rank2_f32("update_precond_kron", Ql, Qr, dX, dG)
     fmt = kron_format(Ql.shape, Qr.shape)
+    _check_rank2_f32("update_precond_kron", Ql, Qr, dX, dG, allow_bf16_from=(2 if fmt == "dense_dense" else None))
     if fmt == "dense_dense":
         return _update_precond_dense_dense(Ql, Qr, dX, dG, step)                            # psgd.py:84
     if fmt == "dense_norm":

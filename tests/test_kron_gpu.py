@@ -239,6 +239,51 @@ def test_bf16_fused_triangular_pair(psgd, M, N):
         lib.psgd_kron_bf16_set_tuning(1, 1)
 
 
+# ----------------------------------------------------------------------------- bf16-operand update
+BF16_UPD_TOL = 2e-2        # the stated bf16 bar, on the update INCREMENT Q_new - Q_balanced (the quantity the bf16 GEMMs produce)
+BF16_UPD_STATE_TOL = 2e-4  # on the factors themselves: increment error x step (0.01) + fp32 rounding
+
+
+@pytest.mark.parametrize("M,N", [(128, 128), (256, 512), (512, 256), (136, 264), (8, 8), (200, 72), (72, 200), (64, 1000),
+                                 (1024, 768), (1160, 520)])
+def test_dense_dense_update_bf16(psgd, M, N):
+    rng = np.random.default_rng(5 * M + N)
+    Ql, Qr = (_tri_factor(rng, M) * 3.0).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    dX = rng.standard_normal((M, N))
+    Hl = np.eye(M) + 0.1 * np.diag(rng.uniform(0, 5, M))
+    Hr = np.eye(N) + 0.1 * np.diag(rng.uniform(0, 5, N))
+    dXb = torch.from_numpy(dX.astype(np.float32)).cuda().to(torch.bfloat16)
+    dGb = torch.from_numpy((Hl @ dX @ Hr).astype(np.float32)).cuda().to(torch.bfloat16)
+    Ql_new, Qr_new = psgd.update_precond_kron(_dev(Ql), _dev(Qr), dXb, dGb, 0.01)
+    assert Ql_new.dtype == torch.float32 and Qr_new.dtype == torch.float32
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    rl, rr = orc.update_precond_kron(Ql.astype(np.float64), Qr.astype(np.float64), f64(dXb), f64(dGb), 0.01)
+    assert rel_err(Ql_new.cpu().numpy(), rl) < BF16_UPD_STATE_TOL
+    assert rel_err(Qr_new.cpu().numpy(), rr) < BF16_UPD_STATE_TOL
+    # the increments (reference: psgd.py:179-180 subtracts from the balanced factors, :166-170)
+    rho = np.sqrt(np.max(np.diag(Ql.astype(np.float64))) / np.max(np.diag(Qr.astype(np.float64))))
+    assert rel_err(Ql_new.cpu().numpy().astype(np.float64) - Ql / rho, rl - Ql / rho) < BF16_UPD_TOL
+    assert rel_err(Qr_new.cpu().numpy().astype(np.float64) - Qr * rho, rr - Qr * rho) < BF16_UPD_TOL
+    # factors stay upper triangular, and the fp32 HIP update on the same data agrees to the same bars
+    assert torch.equal(Ql_new, torch.triu(Ql_new)) and torch.equal(Qr_new, torch.triu(Qr_new))
+    Ql32, Qr32 = psgd.update_precond_kron(_dev(Ql), _dev(Qr), dXb.float(), dGb.float(), 0.01)
+    assert rel_err(Ql_new.cpu().numpy(), Ql32.cpu().numpy()) < BF16_UPD_STATE_TOL
+    assert rel_err(Qr_new.cpu().numpy(), Qr32.cpu().numpy()) < BF16_UPD_STATE_TOL
+
+
+def test_bf16_update_rejects_odd_shapes_and_mixed_dtypes(psgd):
+    with pytest.raises(ValueError):
+        psgd.update_precond_kron(torch.eye(5, device="cuda"), torch.eye(12, device="cuda"),
+                                 torch.ones(5, 12, device="cuda", dtype=torch.bfloat16),
+                                 torch.ones(5, 12, device="cuda", dtype=torch.bfloat16))
+    with pytest.raises(TypeError):
+        psgd.update_precond_kron(torch.eye(8, device="cuda"), torch.eye(16, device="cuda"),
+                                 torch.ones(8, 16, device="cuda", dtype=torch.bfloat16), torch.ones(8, 16, device="cuda"))
+    with pytest.raises(TypeError):      # bf16 factors are not accepted (master copies are fp32)
+        psgd.update_precond_kron(torch.eye(8, device="cuda", dtype=torch.bfloat16), torch.eye(16, device="cuda"),
+                                 torch.ones(8, 16, device="cuda"), torch.ones(8, 16, device="cuda"))
+
+
 def test_bf16_path_rejects_odd_shapes(psgd):
     with pytest.raises(ValueError):
         psgd.precond_grad_kron(torch.eye(5, device="cuda"), torch.eye(12, device="cuda"),
