@@ -117,6 +117,8 @@ def kron_bench(dev, psgd, iters=20):
     t_lenet_upd = timeit(lambda: psgd.update_precond_kron_batched(Qls, Qrs, dXs, Gs, 0.01), 50)
     dX = torch.randn_like(G)
     t_upd = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, G, 0.01), 5)
+    dXb, dGb = dX.to(torch.bfloat16), Gb
+    t_upd_bf16 = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dXb, dGb, 0.01), 5)
     f_upd = 7 * (M * M * N + M * N * N) + 2 * (M**3 + N**3)                        # SURVEY 8d F_ref of the update
     f_big = kron_apply_flops(M, N)
     f_lenet = sum(kron_apply_flops(m, n) for m, n in LENET5)
@@ -142,6 +144,9 @@ def kron_bench(dev, psgd, iters=20):
                             "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop * 1e3,
                             "update_us": t_lenet_upd * 1e3},
         "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6},
+        "4096x4096_bf16_operands_update": {"ms": t_upd_bf16, "gflops": f_upd / t_upd_bf16 / 1e6,
+                                           "note": "products on bf16 operands; balance, triangular solves, norms and "
+                                                   "the final subtraction in fp32"},
     }
 
 

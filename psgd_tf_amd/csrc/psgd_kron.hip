@@ -753,6 +753,252 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut_inv(TrsmArgs t, const floa
   trsm_inv_body<VB>(t, Dinv, blockIdx.x * VB, dyn_lds, pitch, reinterpret_cast<float (*)[33]>(dyn_lds + VB * pitch));
 }
 
+// Register-resident form of the strip solve (the default): the workgroup's 16 vectors x n <= 512 columns live in MFMA
+// accumulators for the whole strip, TRANSPOSED -- tile (sb, h) of wave w = sb mod 4 holds
+//   acc[e] = R[v = lane & 15][col = 32 sb + 16 h + 4 (lane >> 4) + e]
+// i.e. the C layout of the tile R', rows = columns of the strip, columns = vectors.  In that layout an accumulator
+// register IS a B operand of v_mfma_f32_16x16x4_f32 for the k order (16 h + 4 g + e), so
+//   Y_s' = Dinv_s' R_s'            (8 MFMAs per 16-column half, A = Dinv_s read from global/L2)
+//   R'[later] -= Q[s, later]' Y_s' (8 MFMAs per tile, A = the Q panel read from global/L2)
+// chain through registers with no transposition through LDS.  Per 32-wide sub-step the owner wave (s mod 4) solves
+// its block, stores it, and hands its 8 registers to the other waves through a 2-KiB LDS slot (double-buffered: one
+// barrier per sub-step); every wave then updates the tiles it owns.  The Q panels and the inverted diagonal block of
+// the next sub-step are requested before the barrier.
+// The LDS-resident form above spends 68 us per 512-column strip of 4096 vectors (three barriers, a read-modify-write
+// of the whole trailing strip through LDS and one exposed L2 latency per sub-step); this general body 52 us, the
+// fully unrolled one below 40 us.
+__device__ __forceinline__ void trsm_reg_body(const TrsmArgs& t, const float* __restrict__ Dinv, int v0, float (*Ybuf)[512]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, l = lane & 15;
+  const long xi = (t.xi == 0 && t.xj == 0) ? t.si : t.xi, xj = (t.xi == 0 && t.xj == 0) ? t.sj : t.xj;
+  const int n = t.n, nsb = (n + 31) >> 5;
+  const int v = v0 + l;
+  const bool vok = v < t.nvec;
+  constexpr int kIt = kStripN / 128;            // 32-column blocks per wave
+  f32x4 acc[kIt][2];
+#pragma unroll
+  for (int it = 0; it < kIt; ++it)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 32 * (w + 4 * it) + 16 * h + 4 * g + e;
+        acc[it][h][e] = (vok && c < n) ? t.X[(long)v * xi + (long)c * xj] : 0.0f;
+      }
+  // q[it][h][mt][e] = Q[32 s + 16 mt + 4 g + e][32 sb + 16 h + l], sb = w + 4 it  (A operands of the trailing update)
+  float q[kIt][2][2][4], dv[2][4][2];
+  auto load_q = [&](int s, float (&qq)[kIt][2][2][4]) {
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int sb = w + 4 * it;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = 32 * sb + 16 * h + l;
+        const bool ok = sb > s && col < n;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qq[it][h][mt][e] = ok ? t.Q[(long)(32 * s + 16 * mt + 4 * g + e) * t.ldq + col] : 0.0f;
+      }
+    }
+  };
+  // dd[h][e][mt] = Dinv_s[16 h + 4 g + e][16 mt + l]
+  auto load_d = [&](int s, float (&dd)[2][4][2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) dd[h][e][mt] = Dinv[(long)s * 1024 + (16 * h + 4 * g + e) * 32 + 16 * mt + l];
+  };
+  load_q(0, q);
+  if (w == 0) load_d(0, dv);
+#pragma unroll
+  for (int s = 0; s < kStripN / 32; ++s) {
+    if (s >= nsb) continue;                          // uniform; `break` would keep the loop from being unrolled
+    float qn[kIt][2][2][4], dn[2][4][2];
+    const bool more = s + 1 < nsb;
+    if (more) {
+      load_q(s + 1, qn);
+      if (w == ((s + 1) & 3)) load_d(s + 1, dn);
+    }
+    if (w == (s & 3)) {                              // owner: Y_s' = Dinv_s' R_s'
+      f32x4 y[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[h][e][mt], acc[s >> 2][h][e], y[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Ybuf[s & 1][(mt * 4 + e) * 64 + lane] = -y[mt][e];
+          const int c = 32 * s + 16 * mt + 4 * g + e;
+          if (vok && c < n) t.Y[(long)v * t.si + (long)c * t.sj] = y[mt][e];
+        }
+    }
+    __syncthreads();
+    if (more) {
+      float yn[2][4];                                // -Y_s in B-operand layout
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yn[mt][e] = Ybuf[s & 1][(mt * 4 + e) * 64 + lane];
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) {
+        const int sb = w + 4 * it;
+        if (sb > s && sb < nsb) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+                acc[it][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[it][h][mt][e], yn[mt][e], acc[it][h], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < kIt; ++it)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[it][h][mt][e] = qn[it][h][mt][e];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) dv[h][e][mt] = dn[h][e][mt];
+    }
+  }
+}
+
+// The same algorithm for the case every large solve consists of: a FULL strip (n == 512) and 16 valid vectors per
+// workgroup.  Everything is unrolled (16 sub-steps) and every global access is unconditional and issued by all four
+// waves at the same program points, so the compiler can wait with COUNTED s_waitcnt vmcnt(N): with loads under
+// wave-dependent branches (the general body above) it falls back to vmcnt(0) and every sub-step pays the latency of the
+// prefetch it has just issued.  Q panels are requested two sub-steps ahead, the inverted diagonal blocks a round ahead.
+// What is left (40 us per strip of 4096 vectors, 2.5 us per sub-step) is the rate of the 64 four-row dword loads per
+// wave and sub-step that feed the A operands; an L2 warm-up pass of the strip did not help (54 us).
+__device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const float* __restrict__ Dinv, int v0, float (*Ybuf)[512]) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long xi = (t.xi == 0 && t.xj == 0) ? t.si : t.xi, xj = (t.xi == 0 && t.xj == 0) ? t.sj : t.xj;
+  const int v = v0 + l;
+  constexpr int kIt = 4, kSub = 16;
+  f32x4 acc[kIt][2];
+#pragma unroll
+  for (int it = 0; it < kIt; ++it)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc[it][h][e] = t.X[(long)v * xi + (long)(32 * (w + 4 * it) + 16 * h + 4 * g + e) * xj];
+  const float* qlane = t.Q + (long)(4 * g) * t.ldq + 32 * w + l;
+  float qb[4][kIt][2][2][4], dvb[2][2][4][2];
+  // slot `it` of the round of sub-step s (= block w + 4 ((s >> 2) + it)); slot 0 is loaded even when it is not behind
+  // s (w <= s mod 4): the access pattern must not depend on the wave
+#define TRSM_LOAD_Q(S, QQ)                                                                              \
+  _Pragma("unroll") for (int it = 0; it < kIt; ++it) {                                                  \
+    if (((S) >> 2) + it < 4) {                                                                          \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                     \
+      _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                  \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
+        QQ[it][h][mt][e] = qlane[(long)(32 * (S) + 16 * mt + e) * t.ldq + 128 * (((S) >> 2) + it) + 16 * h]; \
+    }                                                                                                   \
+  }
+#define TRSM_LOAD_D(R, DD)                                                                              \
+  _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                         \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
+  _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
+    DD[h][e][mt] = Dinv[(long)(4 * (R) + w) * 1024 + (16 * h + 4 * g + e) * 32 + 16 * mt + l];
+  TRSM_LOAD_D(0, dvb[0]);
+  TRSM_LOAD_Q(0, qb[0]);
+  TRSM_LOAD_Q(1, qb[1]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r + 1 < 4) { TRSM_LOAD_D(r + 1, dvb[(r + 1) & 1]); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = 4 * r + u;
+      if (s + 2 < kSub) { TRSM_LOAD_Q(s + 2, qb[(u + 2) & 3]); }
+      if (w == u) {                                    // owner: Y_s' = Dinv_s' R_s'; only MFMAs and LDS writes in here
+        f32x4 y[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+              y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dvb[r & 1][h][e][mt], acc[0][h][e], y[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Ybuf[u & 1][(mt * 4 + e) * 64 + lane] = -y[mt][e];
+      }
+      __syncthreads();
+      float yn[2][4];                                  // -Y_s in B-operand layout, for every wave
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yn[mt][e] = Ybuf[u & 1][(mt * 4 + e) * 64 + lane];
+      // the solved block goes out from all four waves, two registers each (same store count on every path)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int mt = k, e = w;                       // register (mt, e = w)
+        float val = yn[mt][0];
+        if (e == 1) val = yn[mt][1];
+        if (e == 2) val = yn[mt][2];
+        if (e == 3) val = yn[mt][3];
+        t.Y[(long)v * t.si + (long)(32 * s + 16 * mt + 4 * g + e) * t.sj] = -val;
+      }
+      if (s + 1 < kSub) {
+        if (w > u) {                                   // slot 0 is behind s only for the waves after the owner
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+                acc[0][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[u][0][h][mt][e], yn[mt][e], acc[0][h], 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 1; it < kIt; ++it) {
+          if (r + it < 4) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                  acc[it][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[u][it][h][mt][e], yn[mt][e], acc[it][h], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it + 1 < kIt; ++it)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[it][h] = acc[it + 1][h];
+  }
+#undef TRSM_LOAD_Q
+#undef TRSM_LOAD_D
+}
+
+__global__ __launch_bounds__(kThreads) void k_trsm_ut_reg_full(TrsmArgs t, const float* __restrict__ Dinv) {
+  __shared__ float Ybuf[2][512];
+  trsm_reg_full_body(t, Dinv, blockIdx.x * 16, Ybuf);
+}
+
+__global__ __launch_bounds__(kThreads) void k_trsm_ut_reg(TrsmArgs t, const float* __restrict__ Dinv) {
+  __shared__ float Ybuf[2][512];
+  trsm_reg_body(t, Dinv, blockIdx.x * 16, Ybuf);
+}
+
 struct TrsmBatch {
   int count;
   int blk_end[kMaxBatch];      // inclusive prefix sums of 16-vector strips (solve) / of 32-blocks (inversion)
@@ -798,6 +1044,14 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut_inv_batched(TrsmBatch b, i
   const TrsmArgs& t = b.t[p];
   const int pitch = ((t.n + 31) & ~31) + 2;
   trsm_inv_body<16>(t, b.dinv[p], blk * 16, dyn_lds, pitch, reinterpret_cast<float (*)[33]>(dyn_lds + 16 * pitch_max));
+}
+
+__global__ __launch_bounds__(kThreads) void k_trsm_ut_reg_batched(TrsmBatch b) {
+  __shared__ float Ybuf[2][512];
+  int p = 0;
+  while (p + 1 < b.count && (int)blockIdx.x >= b.blk_end[p]) ++p;
+  const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
+  trsm_reg_body(b.t[p], b.dinv[p], blk * 16, Ybuf);
 }
 
 
@@ -1116,7 +1370,16 @@ __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long 
 //                                Y[:, >jb] -= Y[:, jb] Q[jb, >jb]   (one wide MFMA GEMM, K = 512)
 constexpr int kTrsmBlock = kStripN;
 
+static int g_trsm_lds = 0;     // tuning key 2: 1 = the LDS-resident strip kernels (A/B measurements)
+
 static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
+  if (!g_trsm_lds) {
+    if (t.n == kStripN && t.nvec % 16 == 0)
+      hipLaunchKernelGGL(k_trsm_ut_reg_full, dim3(t.nvec / 16), dim3(kThreads), 0, st, t, dinv);
+    else
+      hipLaunchKernelGGL(k_trsm_ut_reg, dim3((t.nvec + 15) / 16), dim3(kThreads), 0, st, t, dinv);
+    return (int)hipGetLastError();
+  }
   static bool attr_set = false;
   const int pitch = ((t.n + 31) & ~31) + 2;
   if (!attr_set) {
@@ -1150,6 +1413,8 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
     hipLaunchKernelGGL(k_copy_strided, dim3(1024), dim3(kThreads), 0, st, X, xi, xj, Y, si, sj, nvec, n);
     if (hipGetLastError() != hipSuccess) return 1;
   }
+  // (A recursive-halving schedule -- one K = 2048 product, two K = 1024, four K = 512 at 4096^2 -- was measured equal:
+  // the 4096 x 512 x 512 products it ends with are latency-bound, 128 tiles on 256 CUs.)
   for (int j0 = 0; j0 < n; j0 += kTrsmBlock) {
     const int jw = (n - j0 < kTrsmBlock) ? (n - j0) : kTrsmBlock;
     float* Yb = Y + (long)j0 * sj;
@@ -1222,6 +1487,7 @@ extern "C" {
 int psgd_kron_set_tuning(int key, int value) {
   if (key == 0) { g_force_gemm = value; return PSGD_OK; }
   if (key == 1) { g_gemm_x3 = value; return PSGD_OK; }
+  if (key == 2) { g_trsm_lds = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -1359,6 +1625,11 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
       }
       hipLaunchKernelGGL(k_tri_inv32_batched, dim3(nblk), dim3(64), 0, st, ib);
       KRON_LAUNCH((int)hipGetLastError());
+      if (!g_trsm_lds) {
+        hipLaunchKernelGGL(k_trsm_ut_reg_batched, dim3(pass ? blk2 : blk1), dim3(kThreads), 0, st, tb);
+        KRON_LAUNCH((int)hipGetLastError());
+        continue;
+      }
       const int pitch_max = ((nmax + 31) & ~31) + 2;
       static bool attr_set = false;
       if (!attr_set) {

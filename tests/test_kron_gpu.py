@@ -239,6 +239,29 @@ def test_bf16_fused_triangular_pair(psgd, M, N):
         lib.psgd_kron_bf16_set_tuning(1, 1)
 
 
+@pytest.mark.parametrize("M,N", [(512, 384), (1100, 530), (640, 256), (1024, 1536), (48, 1040)])
+def test_triangular_solve_kernel_variants_agree(psgd, hip_lib, M, N):
+    """The strip solve has three bodies: register-resident fully unrolled (full 512-column strips with 16 valid vectors
+    per workgroup), register-resident general, and the LDS-resident one (psgd_kron_set_tuning(2, 1)).  Same block
+    algorithm, different fp32 summation orders: the updated factors agree to the parity tolerance, and with the oracle."""
+    rng = np.random.default_rng(M + 7 * N)
+    Ql, Qr = (_tri_factor(rng, M) * 2.0).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    dX = rng.standard_normal((M, N)).astype(np.float32)
+    dG = (dX * np.exp(rng.uniform(-1, 1, (1, N)))).astype(np.float32)
+    outs = []
+    try:
+        for lds in (0, 1):
+            hip_lib.psgd_kron_set_tuning(2, lds)
+            outs.append(psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01))
+    finally:
+        hip_lib.psgd_kron_set_tuning(2, 0)
+    ref = orc.update_precond_kron(*(a.astype(np.float64) for a in (Ql, Qr, dX, dG)), 0.01)
+    for k in range(2):
+        assert rel_err(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy()) < TOL
+        assert rel_err(outs[0][k].cpu().numpy(), ref[k]) < TOL
+        assert rel_err(outs[1][k].cpu().numpy(), ref[k]) < TOL
+
+
 # ----------------------------------------------------------------------------- bf16-operand update
 BF16_UPD_TOL = 2e-2        # the stated bf16 bar, on the update INCREMENT Q_new - Q_balanced (the quantity the bf16 GEMMs produce)
 BF16_UPD_STATE_TOL = 2e-4  # on the factors themselves: increment error x step (0.01) + fp32 rounding

@@ -4,6 +4,8 @@ import preconditioned_stochastic_gradient_descent as psgd
 from tools.kron_timing import state
 M = N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 Ql, Qr, dX, dG, G = state(M, N, torch.device("cuda:0"))
+if len(sys.argv) > 2 and sys.argv[2] == "bf16":
+    dX, dG = dX.bfloat16(), dG.bfloat16()
 for _ in range(3):
     psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
 torch.cuda.synchronize()

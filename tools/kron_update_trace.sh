@@ -1,7 +1,7 @@
 R=$PWD
 mkdir -p gpurun_out/kupd
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kupd/stats -- python3 $R/tools/kron_big_update.py > $R/gpurun_out/kupd/out.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kupd/stats -- python3 $R/tools/kron_big_update.py ${1:-4096} ${2:-f32} > $R/gpurun_out/kupd/out.txt 2>&1
 python3 - <<PY
 import sqlite3,glob
 db=glob.glob('$R/gpurun_out/kupd/stats/**/*_results.db',recursive=True)[0]
