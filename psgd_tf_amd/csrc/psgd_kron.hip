@@ -882,8 +882,10 @@ __device__ __forceinline__ void trsm_reg_body(const TrsmArgs& t, const float* __
 // waves at the same program points, so the compiler can wait with COUNTED s_waitcnt vmcnt(N): with loads under
 // wave-dependent branches (the general body above) it falls back to vmcnt(0) and every sub-step pays the latency of the
 // prefetch it has just issued.  Q panels are requested two sub-steps ahead, the inverted diagonal blocks a round ahead.
-// What is left (40 us per strip of 4096 vectors, 2.5 us per sub-step) is the rate of the 64 four-row dword loads per
-// wave and sub-step that feed the A operands; an L2 warm-up pass of the strip did not help (54 us).
+// Measured at 40 us per strip of 4096 vectors (2.5 us per sub-step; MFMA pipe 16 % busy, waves 54 % of their cycles in
+// s_waitcnt).  Tried without gain: 8-byte A-operand loads over interleaved column tiles (41 us), an L2 warm-up pass
+// over the strip (54), the round loop as a real loop with retired slots re-reading slot 0 (60), 32 vectors per
+// workgroup (50).
 __device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const float* __restrict__ Dinv, int v0, float (*Ybuf)[512]) {
   const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
