@@ -54,6 +54,25 @@ def fuzz_kron_bf16(g, it):
     return "kron-bf16 %dx%d" % (M, N), rel(out, ref64.precond_grad_dense_dense(Ql.double(), Qr.double(), G.double())), 2e-2
 
 
+def fuzz_kron_bf16_update(g, it):
+    M = 8 * int(torch.randint(1, 200, (1,), generator=g, device=dev))
+    N = 8 * int(torch.randint(1, 200, (1,), generator=g, device=dev))
+    if it % 6 == 0:
+        M, N = 64 * int(torch.randint(8, 40, (1,), generator=g, device=dev)), 64 * int(torch.randint(8, 40, (1,), generator=g, device=dev))
+    off = 0.5 / max(M, N) ** 0.5
+    Ql, Qr = tri(M, g, off) * 1.7, tri(N, g, off)
+    dX = torch.randn(M, N, device=dev, generator=g)
+    dG = torch.exp(torch.empty(M, 1, device=dev).uniform_(-1, 1, generator=g)) * dX * torch.exp(torch.empty(1, N, device=dev).uniform_(-1, 1, generator=g))
+    dX, dG = dX.to(torch.bfloat16), dG.to(torch.bfloat16)
+    a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    a64, b64 = ref64.update_precond_dense_dense(Ql.double(), Qr.double(), dX.double(), dG.double(), 0.01, TINY)
+    # the stated bf16 bar (2e-2) applies to the increment the bf16 GEMMs produce; on the factors it is step (0.01) times that
+    rho = (torch.diagonal(Ql).max() / torch.diagonal(Qr).max()).double().sqrt()
+    e_inc = max(rel(a.double() - Ql.double() / rho, a64 - Ql.double() / rho), rel(b.double() - Qr.double() * rho, b64 - Qr.double() * rho))
+    e_fac = max(rel(a, a64), rel(b, b64))
+    return "kron-bf16-upd %dx%d" % (M, N), max(e_inc, 100.0 * e_fac), 2e-2
+
+
 def fuzz_uvd(g, it):
     r = int(torch.randint(1, 33, (1,), generator=g, device=dev))
     N = int(torch.randint(max(r, 2), 400000 if it % 4 == 0 else 20000, (1,), generator=g, device=dev))
@@ -103,7 +122,7 @@ def fuzz_splu(g, it):
 def run(budget, seed=1):
     _lib.load()
     g = torch.Generator(device=dev).manual_seed(seed)
-    fams = [fuzz_kron, fuzz_kron_bf16, fuzz_uvd, fuzz_splu]
+    fams = [fuzz_kron, fuzz_kron_bf16, fuzz_kron_bf16_update, fuzz_uvd, fuzz_splu]
     t0, it, worst, bad = time.time(), 0, {}, []
     while time.time() - t0 < budget:
         f = fams[it % len(fams)]
