@@ -47,7 +47,8 @@ struct HGemmArgs {
   void* C; long ldc;
   int c_bf16, c_trans;              // element type and orientation of the stored result
   int M, N, K, kmode;
-  int sym;                          // C is symmetric (A == B): tiles below the diagonal are skipped, the others stored twice
+  int sym;                          // 1: C is symmetric (A == B): tiles below the diagonal are skipped, the others stored twice
+                                    // 2: C is upper triangular (k_hgemm_nt, HEPI_D_MINUS): upper tiles only, C = D below
   // k_hgemm_nt only (the bf16-operand update):
   int epi;                          // HEPI_STORE | HEPI_TRIU_MAX (C = triu(acc), max|C| -> maxout, no mirror store) |
                                     // HEPI_D_MINUS (C = D - step / (*scale_max + tiny) * acc, fp32)
@@ -70,17 +71,44 @@ __device__ __forceinline__ uint16_t f2bf(float x) {
 // instead of 34 for a 2 x 32 strip -- with 64 flop/B per 128 x 128 tile the GEMM is otherwise bound by
 // L2-miss (Infinity Cache) bandwidth, not by the MFMA rate.  Patches are dealt to XCDs so that the long
 // and the short K ranges of the triangular modes are balanced; inside a patch the longest tiles go first.
-__device__ __forceinline__ void hgemm_tile_coords(const HGemmArgs& g, int& m0, int& n0, int& klo, int& nk) {
+__device__ __forceinline__ void hgemm_tile_coords(const HGemmArgs& g, int bid, int& m0, int& n0, int& klo, int& nk) {
   const int tiles_n = (g.N + TN - 1) / TN, tiles_m = (g.M + TM - 1) / TM;
   const int nt = tiles_m * tiles_n;
   int trow, tcol;
-  if (g.sym) {
+  if (g.sym == 2) {
+    // upper-triangular OUTPUT with a K range that grows with the distance from the diagonal (triu * triu: KLO_M | KHI_N,
+    // tile (r, c) has c - r + 1 K chunks): only the T (T + 1) / 2 tiles on or above the diagonal are launched (each also
+    // copies D into its mirror tile below the diagonal).  T % 16 == 0: XCD x (blocks x, x + 8, ...) works through the
+    // tile rows 16 g + x and 16 g + 15 - x, every row from its longest tile (c = T - 1) down -- equal tile counts and
+    // within 8 % equal K chunks per XCD, the A panel of a row shared in that XCD's L2.  (8 x 8 patches in launch order
+    // put whole far-from-diagonal patches on one XCD: 2.1x imbalance, 150 us for 23 GFLOP at 4096.)
+    const int T = tiles_m;
+    if (T % 16 == 0) {
+      const int x = bid & 7;
+      int j = bid >> 3;
+      trow = 0; tcol = 0;
+      for (int grp = 0; grp < T / 16; ++grp) {
+        const int ra = 16 * grp + x, rb = 16 * grp + 15 - x;
+        if (j < T - ra) { trow = ra; tcol = T - 1 - j; break; }
+        j -= T - ra;
+        if (j < T - rb) { trow = rb; tcol = T - 1 - j; break; }
+        j -= T - rb;
+      }
+    } else {                      // rows from the top, each from its longest tile down
+      const int ntu = T * (T + 1) / 2, idx = ntu - 1 - bid;
+      int sdiag = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+      while (sdiag * (sdiag + 1) / 2 > idx) --sdiag;
+      while ((sdiag + 1) * (sdiag + 2) / 2 <= idx) ++sdiag;
+      trow = T - 1 - sdiag;
+      tcol = trow + idx - sdiag * (sdiag + 1) / 2;
+    }
+  } else if (g.sym) {
     // symmetric product (M == N, kmode = KHI_M | KHI_N): only the T (T + 1) / 2 tiles on or above the diagonal are
     // launched.  L = those tiles sorted by K length (row index) descending.  The first 256 blocks (one per CU) take
     // L[0..255]; the second 256 take the NEXT 256 entries in ascending order, so that the CU holding the longest
     // tile gets the shortest companion (two blocks are resident per CU); the rest follow in order.
     const int T = tiles_m, ntu = T * (T + 1) / 2, W = 256;
-    int idx = blockIdx.x;
+    int idx = bid;
     if (idx >= W && idx < 2 * W) { const int hi = min(ntu, 2 * W); idx = hi - 1 - (idx - W); }
     int sdiag = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
     while (sdiag * (sdiag + 1) / 2 > idx) --sdiag;
@@ -88,7 +116,7 @@ __device__ __forceinline__ void hgemm_tile_coords(const HGemmArgs& g, int& m0, i
     trow = T - 1 - sdiag;
     tcol = trow + idx - sdiag * (sdiag + 1) / 2;
   } else if (tiles_m % 8 == 0 && tiles_n % 8 == 0 && nt % 512 == 0) {
-    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;      // j-th block of this XCD
+    const int xcd = bid % 8, j = bid / 8;      // j-th block of this XCD
     const int pm = tiles_m / 8, pn = tiles_n / 8;            // patch grid
     const int npatch = pm * pn, ppx = npatch / 8;            // patches per XCD
     const int pl = j / 64, e = j % 64;                       // local patch, element in patch
@@ -101,7 +129,7 @@ __device__ __forceinline__ void hgemm_tile_coords(const HGemmArgs& g, int& m0, i
     tcol = pcol * 8 + e % 8;
     if (g.kmode & (KHI_M | KHI_N)) { trow = tiles_m - 1 - trow; tcol = tiles_n - 1 - tcol; }
   } else {
-    int id = blockIdx.x;
+    int id = bid;
     const int q = nt / 8, r = nt % 8, xcd = id % 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
     trow = id / tiles_n; tcol = id % tiles_n;
@@ -121,13 +149,12 @@ __device__ __forceinline__ void hgemm_tile_coords(const HGemmArgs& g, int& m0, i
   nk = (khi > klo) ? (khi - klo + TK - 1) / TK : 0;
 }
 
-__global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
-  __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][TM * (TK / 8)];   // [buf][A|B][row*8 + slot]
+__device__ __forceinline__ void hgemm_nt_body(const HGemmArgs& g, int bid, u32x4 (*lds)[2][TM * (TK / 8)]) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
 
   int m0, n0, klo, nk;
-  hgemm_tile_coords(g, m0, n0, klo, nk);
+  hgemm_tile_coords(g, bid, m0, n0, klo, nk);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -262,6 +289,36 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
     for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
     if (lane == 0 && vmax > 0.0f) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
   }
+  if (g.sym == 2 && n0 > m0 && g.epi == HEPI_D_MINUS) {
+    // the tile below the diagonal is not launched: its product is zero, C = D there (M == N, multiples of 8; fp32)
+    const float* D = g.D;
+    float* C = static_cast<float*>(g.C);
+#pragma unroll 4
+    for (int k = 0; k < TM * TN / 4 / kThreads; ++k) {
+      const int idx = tid + kThreads * k, row = n0 + (idx >> 5), col = m0 + 4 * (idx & 31);
+      if (row < g.M && col < g.N) *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) = *reinterpret_cast<const f32x4*>(D + (long)row * g.ldd + col);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_hgemm_nt(HGemmArgs g) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][TM * (TK / 8)];   // [buf][A|B][row*8 + slot]
+  hgemm_nt_body(g, blockIdx.x, lds);
+}
+
+// Two independent products in one launch (the two gradients / the two factor updates of the bf16-operand Kron update):
+// their blocks are interleaved in groups of 8 (one per XCD), so both start with their longest tiles and the leftover
+// tiles of one fill the CUs the other has left (2 x 528 equal tiles on 512 slots: 2.06 rounds instead of 2 x 1.03 -> 2 x 2).
+__global__ __launch_bounds__(kThreads) void k_hgemm_nt_two(HGemmArgs g0, HGemmArgs g1, int n0, int n1) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][TM * (TK / 8)];
+  const int m = (n0 < n1 ? n0 : n1) & ~7, b = blockIdx.x;
+  if (b < 2 * m) {
+    const int local = (b >> 4) * 8 + (b & 7);
+    if ((b >> 3) & 1) hgemm_nt_body(g1, local, lds); else hgemm_nt_body(g0, local, lds);
+  } else {
+    const int rest = b - 2 * m;
+    if (rest < n0 - m) hgemm_nt_body(g0, m + rest, lds); else hgemm_nt_body(g1, m + rest - (n0 - m), lds);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,7 +343,7 @@ __global__ __launch_bounds__(kThreads) void k_hgemm_nt_dma(HGemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   int m0, n0, klo, nk;
-  hgemm_tile_coords(g, m0, n0, klo, nk);
+  hgemm_tile_coords(g, blockIdx.x, m0, n0, klo, nk);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -851,6 +908,17 @@ static int launch_hgemm_args(const HGemmArgs& g, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+static int hgemm_blocks(const HGemmArgs& g) {
+  const int tq = (g.M + TM - 1) / TM;
+  return g.sym ? tq * (tq + 1) / 2 : tq * ((g.N + TN - 1) / TN);
+}
+
+static int launch_hgemm_two(const HGemmArgs& g0, const HGemmArgs& g1, hipStream_t st) {
+  const int n0 = hgemm_blocks(g0), n1 = hgemm_blocks(g1);
+  hipLaunchKernelGGL(k_hgemm_nt_two, dim3(n0 + n1), dim3(kThreads), 0, st, g0, g1, n0, n1);
+  return (int)hipGetLastError();
+}
+
 static int launch_hgemm(const uint16_t* A, long lda, const uint16_t* B, long ldb, void* C, long ldc, int c_bf16,
                         int c_trans, int M, int N, int K, int kmode, hipStream_t st, int sym = 0) {
   HGemmArgs g = {A, lda, B, ldb, C, ldc, c_bf16, c_trans, M, N, K, kmode, sym};
@@ -1113,19 +1181,17 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   {
     HGemmArgs g = {k.W1, ld1, k.W1, ld1, k.g1, M, 1, 0, M, M, ld1, 0, 1};
     g.epi = HEPI_TRIU_MAX; g.kflip = k.n64 / TK; g.maxout = k.scal + 0;
-    HK(launch_hgemm_args(g, st));
     HGemmArgs h = {k.W2, ld2, k.W2, ld2, k.g2, N, 1, 0, N, N, ld2, 0, 1};
     h.epi = HEPI_TRIU_MAX; h.kflip = k.m64 / TK; h.maxout = k.scal + 1;
-    HK(launch_hgemm_args(h, st));
+    HK(launch_hgemm_two(g, h, st));
   }
   // Ql_new = QlS - step / (max|grad1| + tiny) grad1 QlS, same for Qr                                (:177-180)
   {
-    HGemmArgs g = {k.g1, M, k.QlTb, M, QlOut, M, 0, 0, M, M, M, KLO_M | KHI_N, 0};
+    HGemmArgs g = {k.g1, M, k.QlTb, M, QlOut, M, 0, 0, M, M, M, KLO_M | KHI_N, 2};      // sym = 2: upper tiles + D copy below
     g.epi = HEPI_D_MINUS; g.D = k.QlS; g.ldd = M; g.scale_max = k.scal + 0; g.step = step; g.tiny = tiny;
-    HK(launch_hgemm_args(g, st));
-    HGemmArgs h = {k.g2, N, k.QrTb, N, QrOut, N, 0, 0, N, N, N, KLO_M | KHI_N, 0};
+    HGemmArgs h = {k.g2, N, k.QrTb, N, QrOut, N, 0, 0, N, N, N, KLO_M | KHI_N, 2};
     h.epi = HEPI_D_MINUS; h.D = k.QrS; h.ldd = N; h.scale_max = k.scal + 1; h.step = step; h.tiny = tiny;
-    HK(launch_hgemm_args(h, st));
+    HK(launch_hgemm_two(g, h, st));
   }
   return PSGD_OK;
 }
