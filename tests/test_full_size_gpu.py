@@ -112,7 +112,7 @@ def _tri(n, dev, gen, off):
 
 
 def test_kron_4096_full_size(psgd):
-    """BASELINE configs[4] (Transformer-scale 4096 x 4096 factor pair): fp32 update and apply, bf16-operand apply."""
+    """BASELINE configs[4] (Transformer-scale 4096 x 4096 factor pair): fp32 update and apply, bf16-operand apply and update."""
     _need_gb(12)
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev).manual_seed(4096)
@@ -136,6 +136,17 @@ def test_kron_4096_full_size(psgd):
     assert float(torch.max(torch.abs(torch.tril(a, -1)))) == 0.0 and float(torch.max(torch.abs(torch.tril(b, -1)))) == 0.0
     # and the preconditioned gradient with the updated factors (the mnist_with_lenet5.py:51-53 call pattern)
     assert _rel(psgd.precond_grad_kron(a, b, G), ref64.precond_grad_dense_dense(a64, b64, G.double())) < 1e-5
+
+    # bf16-operand update on the same (bf16-rounded) data: factors within step x bf16 of the fp64 update, increments
+    # within the 2e-2 bf16 bar, still upper triangular
+    dXb, dGb = dX.to(torch.bfloat16), dG.to(torch.bfloat16)
+    ab, bb = psgd.update_precond_kron(Ql, Qr, dXb, dGb, 0.01)
+    a64b, b64b = ref64.update_precond_dense_dense(Ql.double(), Qr.double(), dXb.double(), dGb.double(), 0.01, TINY32)
+    assert ab.dtype == torch.float32 and _rel(ab, a64b) < 2e-4 and _rel(bb, b64b) < 2e-4
+    rho = (torch.diagonal(Ql).max() / torch.diagonal(Qr).max()).double().sqrt()
+    assert _rel(ab.double() - Ql.double() / rho, a64b - Ql.double() / rho) < 2e-2
+    assert _rel(bb.double() - Qr.double() * rho, b64b - Qr.double() * rho) < 2e-2
+    assert float(torch.max(torch.abs(torch.tril(ab, -1)))) == 0.0 and float(torch.max(torch.abs(torch.tril(bb, -1)))) == 0.0
 
 
 def test_splu_large(psgd):
