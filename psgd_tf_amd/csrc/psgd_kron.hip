@@ -298,7 +298,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, Gem
 
 // ---------------------------------------------------------------------------------------------
 // fp32-accurate GEMM on the bf16 matrix cores ("bf16 x 3").  Every fp32 operand element is split on the way into
-// LDS into three bf16 terms x = h + m + l (|x - (h+m+l)| <= 2^-24 |x|, bf16 keeps fp32's exponent range), and a
+// LDS into three bf16 terms x = h + m + l (exactly: a truncating split, bf16 keeps fp32's exponent range), and a
 // product a*b is accumulated as  h h' + h m' + m h' + h l' + l h' + m m'  with fp32 accumulation: six
 // v_mfma_f32_16x16x32_bf16 at 16x the rate of v_mfma_f32_16x16x4_f32, i.e. up to 2.6x the fp32 matrix-core peak at
 // fp32-level accuracy (the dropped terms are below 2^-24 relative, like one fp32 rounding).  Same operand views,
@@ -312,15 +312,20 @@ struct GemmLdsX3 {
   u32x4_k P[2][3][128 * 4];    // [A|B][plane][row*4 + (chunk ^ ((row>>2)&3))], a chunk = 8 consecutive k as bf16
 };
 
-__device__ __forceinline__ void split3(float x, unsigned short (&o)[3]) {
-  const __bf16 h = static_cast<__bf16>(x);
-  const float r1 = x - static_cast<float>(h);
-  const __bf16 m = static_cast<__bf16>(r1);
-  const float r2 = r1 - static_cast<float>(m);
-  const __bf16 l = static_cast<__bf16>(r2);
-  o[0] = __builtin_bit_cast(unsigned short, h);
-  o[1] = __builtin_bit_cast(unsigned short, m);
-  o[2] = __builtin_bit_cast(unsigned short, l);
+// Two fp32 values -> three packed bf16 pairs (plane h, m, l; low half = x0).  The split TRUNCATES: h = the top 16 bits
+// of x, r1 = x - h (exact), m = the top 16 bits of r1, l = r1 - m, which has at most 8 significant bits and is a bf16
+// exactly -- so x = h + m + l holds exactly (8 + 8 + 8 mantissa bits), the dropped product terms are the same
+// 2^-24-relative ones as with a round-to-nearest split, and the whole thing is 4 full-rate VALU ops per element plus
+// one v_perm_b32 per pair and plane (the first version used three quarter-rate v_cvt_pk_bf16_f32 per element).
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned (&pk)[3]) {
+  const unsigned top = 0xFFFF0000u;
+  const float h0 = __uint_as_float(__float_as_uint(x0) & top), h1 = __uint_as_float(__float_as_uint(x1) & top);
+  const float r0 = x0 - h0, r1 = x1 - h1;
+  const float m0 = __uint_as_float(__float_as_uint(r0) & top), m1 = __uint_as_float(__float_as_uint(r1) & top);
+  const float s0 = r0 - m0, s1 = r1 - m1;
+  pk[0] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);   // (x0 >> 16) | (x1 & top)
+  pk[1] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+  pk[2] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
 // Operand tile -> registers -> LDS planes.  Whatever the memory layout, a thread ends up with 16 consecutive k of ONE
@@ -362,11 +367,10 @@ __device__ __forceinline__ void r2s_x3(const float (&r)[16], int xr, int kb, u32
   unsigned pk[3][8];
 #pragma unroll
   for (int u = 0; u < 16; u += 2) {
-    unsigned short q0[3], q1[3];
-    split3(r[u], q0);
-    split3(r[u + 1], q1);
+    unsigned q[3];
+    split3_pair(r[u], r[u + 1], q);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) pk[pl][u >> 1] = (unsigned)q0[pl] | ((unsigned)q1[pl] << 16);
+    for (int pl = 0; pl < 3; ++pl) pk[pl][u >> 1] = q[pl];
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
