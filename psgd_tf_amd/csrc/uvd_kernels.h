@@ -390,24 +390,34 @@ __global__ __launch_bounds__(kThreads) void k_rowdot_axpy(const float* M, const 
                           });
 }
 
-// 3-way bf16 split of 8 fp32 values: x = h + m + l to ~2^-24 (bf16 keeps fp32's exponent range), so that
+// 3-way bf16 split of 8 fp32 values: x = h + m + l (bf16 keeps fp32's exponent range), so that
 // x*y ~ h*h' + h*m' + m*h' + h*l' + l*h' + m*m' can run on the bf16 matrix cores (16x the fp32 MFMA rate).
 #ifndef PSGD_GRAM_BF16X3
 #define PSGD_GRAM_BF16X3 1
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// The split truncates (h = top 16 bits of x, r1 = x - h exactly, m = top 16 bits of r1, l = r1 - m, a bf16 exactly), so
+// x = h + m + l holds exactly and the work is 4 full-rate VALU ops per element plus a v_perm_b32 per pair and plane
+// (three quarter-rate v_cvt_pk_bf16_f32 per element in the first version).
 __device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+  typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+  const unsigned top = 0xFFFF0000u;
+  u32x4s ph, pm, pl;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 a = static_cast<__bf16>(x[j]);
-    const float r1 = x[j] - static_cast<float>(a);
-    const __bf16 b = static_cast<__bf16>(r1);
-    const float r2 = r1 - static_cast<float>(b);
-    h[j] = a;
-    m[j] = b;
-    l[j] = static_cast<__bf16>(r2);
+  for (int j = 0; j < 8; j += 2) {
+    const float x0 = x[j], x1 = x[j + 1];
+    const float h0 = __uint_as_float(__float_as_uint(x0) & top), h1 = __uint_as_float(__float_as_uint(x1) & top);
+    const float r0 = x0 - h0, r1 = x1 - h1;
+    const float m0 = __uint_as_float(__float_as_uint(r0) & top), m1 = __uint_as_float(__float_as_uint(r1) & top);
+    const float s0 = r0 - m0, s1 = r1 - m1;
+    ph[j >> 1] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);   // (x0 >> 16) | (x1 & top)
+    pm[j >> 1] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+    pl[j >> 1] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
   }
+  h = __builtin_bit_cast(bf16x8, ph);
+  m = __builtin_bit_cast(bf16x8, pm);
+  l = __builtin_bit_cast(bf16x8, pl);
 }
 
 // update sweep 1: Gram of W = [U | V | t | w], t = d.*h, w = v./d, on the
