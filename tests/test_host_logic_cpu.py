@@ -125,3 +125,41 @@ def test_workspace_cache_is_bounded():
     assert hit.numel() == 10
     c.get(9, lambda: torch.empty(95, dtype=torch.uint8))
     assert 9 in c and len(c) == 1                      # byte bound: everything older had to go
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch
+    it.  Static check over the product package, the root shim, tools/ and examples/, plus bench.py outside cpu_baseline."""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "preconditioned_stochastic_gradient_descent.py")]
+    for sub in ("psgd_tf_amd", "tools", "examples"):
+        for dp, _, fns in os.walk(os.path.join(root, sub)):
+            files += [os.path.join(dp, f) for f in fns if f.endswith(".py")]
+
+    def oracle_imports(tree):
+        out = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import):
+                out += [(node.lineno, a.name) for a in node.names if a.name.split(".")[0] == "oracle"]
+            elif isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "oracle":
+                out.append((node.lineno, node.module))
+        return out
+
+    for f in files:
+        assert oracle_imports(ast.parse(open(f).read())) == [], f
+    # bench.py: the only import sits inside the cpu_baseline function
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    inside = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and "cpu_baseline" in node.name:
+            inside += oracle_imports(node)
+    assert sorted(oracle_imports(tree)) == sorted(inside) and inside
+    # __graft_entry__: only smoke()
+    tree = ast.parse(open(os.path.join(root, "__graft_entry__.py")).read())
+    inside = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "smoke":
+            inside += oracle_imports(node)
+    assert sorted(oracle_imports(tree)) == sorted(inside)
