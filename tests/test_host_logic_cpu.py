@@ -163,3 +163,15 @@ def test_product_never_imports_the_oracle():
         if isinstance(node, ast.FunctionDef) and node.name == "smoke":
             inside += oracle_imports(node)
     assert sorted(oracle_imports(tree)) == sorted(inside)
+
+
+def test_committed_pmc_traffic_file_is_what_bench_reads():
+    """bench.py fills roofline.traffic from profiles/pmc_traffic.json (key k_update_s2 with the row count and rank of the
+    headline workload); a raw per-kernel table copied over it would silently turn the field into null."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))["k_update_s2"]
+    assert rec["rows"] == 100_000_000 and rec["r"] == 20
+    alg = 4 * (3 * 20 + 5) * rec["rows"]                      # bytes the fused sweep moves: 260 B/row
+    assert 0.98 * alg < rec["hbm_bytes_per_launch"] < 1.10 * alg

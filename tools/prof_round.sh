@@ -14,3 +14,4 @@ python tools/rocpd_stats.py gpurun_out/$TAG/stats > gpurun_out/$TAG/kernel_stats
 python tools/pmc_traffic.py gpurun_out/$TAG/pmc_f gpurun_out/$TAG/pmc_w > gpurun_out/$TAG/pmc_traffic.json
 rm -rf gpurun_out/$TAG/stats gpurun_out/$TAG/pmc_f gpurun_out/$TAG/pmc_w
 tail -c 400 gpurun_out/$TAG/bench.json.log
+# afterwards, in the repo: cp the three files into profiles/ as r01_bench_*_$TAG and run  python tools/curate_pmc_traffic.py gpurun_out/$TAG/pmc_traffic.json $TAG  (never copy the raw table over profiles/pmc_traffic.json: bench.py reads the curated form)
