@@ -208,7 +208,8 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 
 /* Experiment knob (not stable ABI). key 0: fp32 GEMM tile choice (0 auto, 1 = 64, 2 = 128, 3 = 32).
  * key 1: 1 (default) 128-tile products run as fp32-accurate bf16 x 3 GEMMs on the bf16 matrix cores; 0 = exact fp32 MFMA.
- * key 2: triangular-solve strips: 0 (default) register-resident kernels, 1 = the LDS-resident ones (A/B measurements). */
+ * key 2: triangular-solve strips: 0 (default) register-resident kernels, 1 = the LDS-resident ones (A/B measurements).
+ * key 3: 32 x 32-tile products: 1 (default) k_gemm_small (ring of 4 K tiles, precomputed per-thread offsets), 0 = the generic body. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

@@ -530,6 +530,128 @@ __global__ __launch_bounds__(kThreads) void k_gemm_f32_batched(GemmBatch b) {
   gemm_body<T, kSmallK>(g, (t / tn) * T, (t % tn) * T, L);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 32 x 32 tile body for problems that cannot fill the chip (LeNet5-size layers).  The block is alone on its CU, one
+// wave per SIMD: every instruction of the K loop is exposed, and so is one memory latency per K step in gemm_body
+// (one K tile of register prefetch).  Here (a) everything about a thread's 8 elements per operand tile that does not
+// change with the K step is computed once (element offset, k index, LDS slot, row guard), (b) kSmallD K tiles are in
+// flight in a ring of register stages, and (c) every global load is unconditional -- clamped address, value selected
+// afterwards -- so the waits are counted vmcnt(N) instead of vmcnt(0).
+constexpr int kSmallD = 4;
+
+struct SmallSrc {
+  const float* P; long cs; int khi;
+  unsigned off[8];          // (x0 + x) * rs + kfix * cs   (32-bit: these problems are small)
+  int kfix[8], sidx[8];     // k inside the tile; LDS index k * 48 + x
+  unsigned xok;             // bit u: x0 + x < X
+};
+
+__device__ __forceinline__ void small_src_init(SmallSrc& s, const TileSrc& t, int x0, int khi) {
+  s.P = t.P; s.cs = t.cs; s.khi = khi; s.xok = 0u;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = threadIdx.x + kThreads * u;
+    int x, k;
+    if (t.cs == 1) { k = e % kSmallK; x = e / kSmallK; } else { x = e % 32; k = e / 32; }
+    const bool ok = x0 + x < t.X;
+    s.off[u] = ok ? (unsigned)((long)(x0 + x) * t.rs + (long)k * t.cs) : 0u;
+    s.kfix[u] = k; s.sidx[u] = k * 48 + x;
+    s.xok |= ok ? (1u << u) : 0u;
+  }
+}
+
+__device__ __forceinline__ void small_fetch(const SmallSrc& s, int k0, bool live, float mul, float (&r)[8]) {
+  const float* Pk = s.P + (long)(live ? k0 : 0) * s.cs;              // uniform; a dead tile reads from the base
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const bool ok = live && ((s.xok >> u) & 1u) && (k0 + s.kfix[u] < s.khi);
+    const float v = Pk[ok ? s.off[u] : 0u];
+    r[u] = ok ? v * mul : 0.0f;
+  }
+}
+
+__device__ __forceinline__ void gemm_body_small(const GemmArgs& g, int m0, int n0, GemmLds<32, kSmallK>& L) {
+  constexpr int T = 32, GK = kSmallK, D = kSmallD;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const bool tri_skip = (g.epi == EPI_TRIU_MAX || g.sym) && (m0 >= n0 + T);
+  if (g.sym && tri_skip) return;
+
+  f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+  float a_mul = 1.0f;
+  if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
+
+  int klo[2] = {0, 0}, khi[2] = {0, 0}, nk[2] = {0, 0};
+  if (!tri_skip) {
+    for (int p = 0; p < 2; ++p) {
+      if (p == 1 && !g.A2) break;
+      const int K = p ? g.K2 : g.K, km = p ? g.kmode2 : g.kmode;
+      int lo = 0, hi = K;
+      if (km & KLO_M) lo = max(lo, m0);
+      if (km & KLO_N) lo = max(lo, n0);
+      if (km & KHI_M) hi = min(hi, m0 + T);
+      if (km & KHI_N) hi = min(hi, n0 + T);
+      lo = (lo / GK) * GK;
+      klo[p] = lo; khi[p] = hi; nk[p] = hi > lo ? (hi - lo + GK - 1) / GK : 0;
+    }
+  }
+  float* LA = &L.A[0][0][0];
+  float* LB = &L.B[0][0][0];
+  constexpr int kBuf = GK * (T + 16);
+  // one operand pair at a time (the second pair of a dual product restarts the ring: one more latency, no branches
+  // around the loads inside the loop)
+  auto run_pair = [&](const TileSrc& ta, const TileSrc& tb, int lo, int hi, int n, float mul) {
+    SmallSrc sa, sb;
+    small_src_init(sa, ta, m0, hi);
+    small_src_init(sb, tb, n0, hi);
+    float ra[D][8], rb[D][8];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      small_fetch(sa, lo + d * GK, d < n, mul, ra[d]);
+      small_fetch(sb, lo + d * GK, d < n, 1.0f, rb[d]);
+    }
+    for (int t0 = 0; t0 < n; t0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int t = t0 + d, buf = d & 1;             // D is even: the LDS buffer alternates with d
+        if (t < n) {                                    // uniform; LDS traffic and MFMAs only (no global access inside)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            LA[buf * kBuf + sa.sidx[u]] = ra[d][u];
+            LB[buf * kBuf + sb.sidx[u]] = rb[d][u];
+          }
+        }
+        small_fetch(sa, lo + (t + D) * GK, t + D < n, mul, ra[d]);      // unconditional refill of the stage just consumed
+        small_fetch(sb, lo + (t + D) * GK, t + D < n, 1.0f, rb[d]);
+        if (t < n) {
+          __syncthreads();
+#pragma unroll
+          for (int kk = 0; kk < GK / 4; ++kk) {
+            const int kr = kk * 4 + (lane >> 4);
+            const float a = L.A[buf][kr][wm * 16 + (lane & 15)];
+            const float b = L.B[buf][kr][wn * 16 + (lane & 15)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[0][0], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();                                   // the next pair may overwrite buffer 0
+  };
+  if (nk[0] > 0) run_pair(TileSrc{g.A, g.a_rs, g.a_cs, g.M}, TileSrc{g.B, g.b_cs, g.b_rs, g.N}, klo[0], khi[0], nk[0], a_mul);
+  if (nk[1] > 0) run_pair(TileSrc{g.A2, g.a2_rs, g.a2_cs, g.M}, TileSrc{g.B2, g.b2_cs, g.b2_rs, g.N}, klo[1], khi[1], nk[1], -a_mul);
+  gemm_epilogue<32>(g, acc, m0, n0);
+}
+
+__global__ __launch_bounds__(kThreads) void k_gemm_small(GemmBatch b) {
+  __shared__ __attribute__((aligned(16))) GemmLds<32, kSmallK> L;
+  int p = 0;
+  while (p + 1 < b.count && (int)blockIdx.x >= b.tile_end[p]) ++p;
+  const int t = blockIdx.x - (p ? b.tile_end[p - 1] : 0);
+  const GemmArgs& g = b.g[p];
+  const int tn = (g.N + 31) / 32;
+  gemm_body_small(g, (t / tn) * 32, (t % tn) * 32, L);
+}
+
 // Solve  y[i,:] Q = x[i,:]  for nvec independent vectors i, Q upper-triangular [n,n] row-major:
 //   y[i,j] = (x[i,j] - sum_{k<j} y[i,k] Q[k,j]) / Q[j,j]
 // Element (i,j) of X / Y lives at  i*si + j*sj.  With (si,sj) = (ld,1) this is the right solve
@@ -1277,6 +1399,7 @@ static KronWs kron_layout(char* base, int M, int N) {
 
 static int g_gemm_x3 = 1;       // tuning key 1: large products on the bf16 matrix cores with a 3-way operand split
 static int g_force_gemm = 0;   // 0 auto, 1 always 64-tile kernel, 2 always 128-tile kernel (experiments)
+static int g_small_deep = 1;   // tuning key 3: batched 32-tile products on k_gemm_small (0 = gemm_body<32, 64>)
 
 static int launch_gemm(const GemmArgs& g, hipStream_t st) {
   // the 128-tile kernel needs enough tiles to fill the chip; small problems keep 64 x 64 tiles
@@ -1290,7 +1413,11 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (T == 128 && g_gemm_x3) hipLaunchKernelGGL(k_gemm_x3, grid, dim3(kThreads), 0, st, g);
   else if (T == 128) hipLaunchKernelGGL((k_gemm_f32<128, kBigK>), grid, dim3(kThreads), 0, st, g);
   else if (T == 64) hipLaunchKernelGGL((k_gemm_f32<64, kSmallK>), grid, dim3(kThreads), 0, st, g);
-  else hipLaunchKernelGGL((k_gemm_f32<32, kSmallK>), grid, dim3(kThreads), 0, st, g);
+  else if (g_small_deep) {
+    GemmBatch b;
+    b.count = 1; b.g[0] = g; b.tile_end[0] = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL(k_gemm_small, dim3(grid.x * grid.y), dim3(kThreads), 0, st, b);
+  } else hipLaunchKernelGGL((k_gemm_f32<32, kSmallK>), grid, dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
 }
 
@@ -1457,6 +1584,7 @@ static int launch_gemm_batch(const GemmArgs* g, int count, hipStream_t st) {
     b.tile_end[p] = tiles;
   }
   if (T == 64) hipLaunchKernelGGL((k_gemm_f32_batched<64>), dim3(tiles), dim3(kThreads), 0, st, b);
+  else if (g_small_deep) hipLaunchKernelGGL(k_gemm_small, dim3(tiles), dim3(kThreads), 0, st, b);
   else hipLaunchKernelGGL((k_gemm_f32_batched<32>), dim3(tiles), dim3(kThreads), 0, st, b);
   return (int)hipGetLastError();
 }
@@ -1494,6 +1622,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 0) { g_force_gemm = value; return PSGD_OK; }
   if (key == 1) { g_gemm_x3 = value; return PSGD_OK; }
   if (key == 2) { g_trsm_lds = value; return PSGD_OK; }
+  if (key == 3) { g_small_deep = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

@@ -262,6 +262,31 @@ def test_triangular_solve_kernel_variants_agree(psgd, hip_lib, M, N):
         assert rel_err(outs[1][k].cpu().numpy(), ref[k]) < TOL
 
 
+@pytest.mark.parametrize("M,N", [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (200, 333)])
+def test_small_gemm_bodies_bitwise_equal(psgd, hip_lib, M, N):
+    """The 32 x 32-tile products have two bodies (psgd_kron_set_tuning(3, .)): same tiles, same K order, same fp32 MFMA
+    chains -> bitwise equal updates and applies (single and batched calls)."""
+    rng = np.random.default_rng(11 * M + N)
+    Ql, Qr = _dev(_tri_factor(rng, M) * 1.5), _dev(_tri_factor(rng, N))
+    dX = _dev(rng.standard_normal((M, N)))
+    dG = _dev(rng.standard_normal((M, N)) * 2.0)
+    outs = []
+    try:
+        for k in (1, 0):
+            hip_lib.psgd_kron_set_tuning(3, k)
+            a = psgd.precond_grad_kron(Ql, Qr, dG)
+            u = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+            ab = psgd.precond_grad_kron_batched([Ql], [Qr], [dG])[0]
+            ub = psgd.update_precond_kron_batched([Ql], [Qr], [dX], [dG], 0.01)[0]
+            outs.append((a, u[0], u[1], ab, ub[0], ub[1]))
+    finally:
+        hip_lib.psgd_kron_set_tuning(3, 1)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, dG)))
+    assert rel_err(outs[0][0].cpu().numpy(), ref) < TOL and rel_err(outs[0][3].cpu().numpy(), ref) < TOL
+
+
 # ----------------------------------------------------------------------------- bf16-operand update
 BF16_UPD_TOL = 2e-2        # the stated bf16 bar, on the update INCREMENT Q_new - Q_balanced (the quantity the bf16 GEMMs produce)
 BF16_UPD_STATE_TOL = 2e-4  # on the factors themselves: increment error x step (0.01) + fp32 rounding
