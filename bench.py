@@ -209,7 +209,10 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    dev = torch.device("cuda", local_rank)
+    # Test hook (not a measurement): PSGD_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 with gloo collectives, so the
+    # N > 1 code path of this script can be exercised where only one GPU exists (RCCL refuses two ranks on one device).
+    single_dev = os.environ.get("PSGD_BENCH_SINGLE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if single_dev else local_rank)
     torch.cuda.set_device(dev)
 
     import torch.distributed as dist
@@ -218,7 +221,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        if single_dev:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     import preconditioned_stochastic_gradient_descent as psgd
     from psgd_tf_amd import _lib, sharded
@@ -308,7 +314,8 @@ def main():
                                    "precond_grad_UVd_math%s), N=%d rows per GPU, r=%d"
                                    % ("" if args.unfused else ", fused call", n_local, r),
                        "rows_per_gpu": n_local, "rows_global": n_global, "rank_of_modification": r,
-                       "parallelism": "row-sharded x%d, all-reduce of r-dim sums only" % world,
+                       "parallelism": ("row-sharded x%d, all-reduce of r-dim sums only" % world) +
+                                      (" [TEST MODE: all ranks on one GPU, gloo -- not a measurement]" if single_dev else ""),
                        "step": STEP, "branches": "balance=0, update_U alternating"},
             "roofline": {"bound": "hbm", "kernel": "k_update_s2 (update sweep 2, dominant kernel)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
