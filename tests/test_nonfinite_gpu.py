@@ -60,3 +60,26 @@ def test_kron_nan_propagates_and_zero_stays_zero(psgd):
     assert torch.isnan(psgd.precond_grad_kron(Ql, Qr, G)).any()
     a, b = psgd.update_precond_kron(Ql, Qr, G, G, 0.01)
     assert torch.isnan(a).any() or torch.isnan(b).any()
+
+
+@pytest.mark.parametrize("M,N", [(640, 512), (1024, 1536)])
+def test_kron_large_and_bf16_paths_propagate_nan(psgd, M, N):
+    """The large-problem kernels (bf16 x 3 split GEMMs with the truncating split, register-resident solve strips, the
+    bf16-operand apply and update): zero in -> zero out for the apply, a NaN / Inf in the data reaches the outputs."""
+    rng = np.random.default_rng(1)
+    tri = lambda n: torch.from_numpy((np.triu(rng.standard_normal((n, n)) * (0.3 / n ** 0.5), 1) + np.eye(n)).astype(np.float32)).cuda()
+    Ql, Qr = tri(M), tri(N)
+    G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda()
+    dX = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda()
+    assert float(psgd.precond_grad_kron(Ql, Qr, torch.zeros_like(G)).abs().max()) == 0.0
+    assert float(psgd.precond_grad_kron(Ql, Qr, torch.zeros_like(G).bfloat16()).float().abs().max()) == 0.0
+    for bad in (float("nan"), float("inf")):
+        Gb = G.clone()
+        Gb[M // 3, N // 5] = bad
+        for data in (Gb, Gb.bfloat16()):
+            out = psgd.precond_grad_kron(Ql, Qr, data).float()
+            assert not torch.isfinite(out).all()
+            a, b = psgd.update_precond_kron(Ql, Qr, dX.to(data.dtype), data, 0.01)
+            assert not (torch.isfinite(a).all() and torch.isfinite(b).all())
+            a, b = psgd.update_precond_kron(Ql, Qr, data, dX.to(data.dtype), 0.01)      # through the triangular solves
+            assert not (torch.isfinite(a).all() and torch.isfinite(b).all())
