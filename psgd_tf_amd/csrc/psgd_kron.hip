@@ -652,6 +652,12 @@ __global__ __launch_bounds__(kThreads) void k_gemm_small(GemmBatch b) {
   gemm_body_small(g, (t / tn) * 32, (t % tn) * 32, L);
 }
 
+// one problem: the kernel arguments are one GemmArgs, not the 8-problem table
+__global__ __launch_bounds__(kThreads) void k_gemm_small_one(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) GemmLds<32, kSmallK> L;
+  gemm_body_small(g, blockIdx.y * 32, blockIdx.x * 32, L);
+}
+
 // Solve  y[i,:] Q = x[i,:]  for nvec independent vectors i, Q upper-triangular [n,n] row-major:
 //   y[i,j] = (x[i,j] - sum_{k<j} y[i,k] Q[k,j]) / Q[j,j]
 // Element (i,j) of X / Y lives at  i*si + j*sj.  With (si,sj) = (ld,1) this is the right solve
@@ -1413,11 +1419,9 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (T == 128 && g_gemm_x3) hipLaunchKernelGGL(k_gemm_x3, grid, dim3(kThreads), 0, st, g);
   else if (T == 128) hipLaunchKernelGGL((k_gemm_f32<128, kBigK>), grid, dim3(kThreads), 0, st, g);
   else if (T == 64) hipLaunchKernelGGL((k_gemm_f32<64, kSmallK>), grid, dim3(kThreads), 0, st, g);
-  else if (g_small_deep) {
-    GemmBatch b;
-    b.count = 1; b.g[0] = g; b.tile_end[0] = (int)(grid.x * grid.y);
-    hipLaunchKernelGGL(k_gemm_small, dim3(grid.x * grid.y), dim3(kThreads), 0, st, b);
-  } else hipLaunchKernelGGL((k_gemm_f32<32, kSmallK>), grid, dim3(kThreads), 0, st, g);
+  else if (g_small_deep && g.K > 2 * kSmallK)      // the ring pays off from the third K tile on; shorter products keep the plain body
+    hipLaunchKernelGGL(k_gemm_small_one, grid, dim3(kThreads), 0, st, g);
+  else hipLaunchKernelGGL((k_gemm_f32<32, kSmallK>), grid, dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
 }
 
