@@ -7,17 +7,24 @@ precond_grad_UVd_math(U,V,d,g) (the UVd.step call pattern, psgd.py:732 -> :748) 
 (g, v, h) already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-N > 1 row-shards the flat parameter vector: every rank holds --rows rows (weak scaling, global
-N = rows * world) and only the r-dimensional reduced buffers are all-reduced (RCCL).
+N > 1 started from a plain shell launches its own ranks: the parent process (which never touches a GPU) starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a child, relays
+rank 0's JSON line and exits with the child's code.  Started under torch.distributed.run (WORLD_SIZE set) it is
+one of the ranks.  N > 1 row-shards the flat parameter vector: every rank holds --rows rows (weak scaling,
+global N = rows * world); per step three tiny all-gathers (RCCL over xGMI) carry the r-dimensional reduced
+buffers -- never N-sized data (psgd_tf_amd/sharded.py).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel (update sweep 2), timed live with HIP events on the launch
-                  stream (psgd_prof_*), algorithmic bytes per launch / average duration vs 8 TB/s;
-                  `paths` adds the same for whole apply / update / step (SURVEY 8d byte counts).
-  cpu_baseline -- the torch-CPU restatement of the reference op sequence (oracle/, "port") timed
-                  on this host's cores on a bounded sample of the same workload (N = 1 run only).
+  roofline     -- the dominant kernel (update sweep 2), timed live with HIP events on the launch stream
+                  (psgd_prof_*) in a SECOND pass (the headline pass runs with the hooks off); algorithmic bytes
+                  per launch / average duration vs 8 TB/s.  `paths` holds the whole fused step and, at N = 1,
+                  separate legs for precond_grad_UVd_math alone and update_precond_UVd_math_ alone (SURVEY 8d
+                  byte counts and the bytes the sweeps actually move), and the same three at config 2
+                  (N = 1M, r = 10).
+  cpu_baseline -- the torch-CPU restatement of the reference op sequence (oracle/, "port") timed on this host's
+                  cores (N = 1 run only): thread-count sweep, then 2 warm-up + 5 timed steps, median, on a
+                  bounded sample of the same workload (--cpu-full: the full N if host memory allows).
 """
 import argparse
 import ctypes
@@ -53,24 +60,59 @@ def make_inputs(n_local, n_global, r, dev, seed):
     return U, V, d, grad, v, h
 
 
-def cpu_baseline(r, sample_rows, budget_s):
-    """Reference op sequence on torch-CPU (oracle/psgd_oracle_torch.py), update+apply, bounded sample."""
+def cpu_baseline(r, sample_rows, budget_s, threads=None):
+    """Reference op sequence on torch-CPU (oracle/psgd_oracle_torch.py), update + apply:
+    a quick thread-count sweep (skinny [N,r] matmuls do not scale to every core), then with the best count
+    2 warm-up + 5 timed steps, median; `sample_rows` bounds the work (stated in `sample`)."""
+    import statistics
     from oracle import psgd_oracle_torch as ref
-    cores = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
     U, V, d, grad, v, h = make_inputs(sample_rows, sample_rows, r, torch.device("cpu"), 0)
-    ref.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=True)   # warm-up
-    ref.precond_grad_UVd_math(U, V, d, grad)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        ref.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(steps % 2 == 1))
+
+    def one(i):
+        t0 = time.perf_counter()
+        ref.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+        t1 = time.perf_counter()
         ref.precond_grad_UVd_math(U, V, d, grad)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 20:
+        t2 = time.perf_counter()
+        return t2 - t0, t1 - t0, t2 - t1
+
+    t_start = time.perf_counter()
+    cands = [threads] if threads else sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu})
+    sweep = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        one(0)
+        sweep[t] = min(one(1)[0], one(2)[0])
+        if time.perf_counter() - t_start > 0.5 * budget_s:
             break
-    return {"value": sample_rows * steps / el, "unit": "params/s", "cores": cores, "kind": "port",
-            "sample": "torch-CPU restatement of psgd.py:554-627 (TensorFlow unavailable), update+apply, "
-                      "N=%d r=%d fp32, %d steps in %.1f s, %d threads" % (sample_rows, r, steps, el, cores)}
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    for i in range(2):
+        one(i)
+    runs = []
+    for i in range(5):
+        runs.append(one(i))
+        if time.perf_counter() - t_start > 2.0 * budget_s and len(runs) >= 3:
+            break
+    med = statistics.median(x[0] for x in runs)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": sample_rows / med, "unit": "params/s", "cores": best, "kind": "port",
+            "sample": "torch-CPU restatement of psgd.py:554-627 in the reference's op order (TensorFlow unavailable), "
+                      "update+apply, N=%d r=%d fp32, %d timed steps after 2 warm-up, median %.3f s (min %.3f s), "
+                      "%d threads = best of sweep %s; host: %d logical CPUs, %s"
+                      % (sample_rows, r, len(runs), med, min(x[0] for x in runs), best,
+                         {k: round(v_, 3) for k, v_ in sweep.items()}, ncpu, model),
+            "update_params_per_s": sample_rows / statistics.median(x[1] for x in runs),
+            "apply_params_per_s": sample_rows / statistics.median(x[2] for x in runs),
+            "logical_cpus": ncpu, "cpu_model": model}
 
 
 LENET5 = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10)]      # mnist_with_lenet5.py:12-16
@@ -186,6 +228,109 @@ def splu_bench(dev, psgd, N=50_000_000, r=10, iters=10):
             "frac_of_hbm_peak": bytes_row * N / ms / 1e6 / HBM_PEAK_GBS}
 
 
+PROF_SLOTS = (("apply_s1", 0), ("apply_s2", 1), ("apply_s3", 2), ("update_s1", 3), ("update_s2", 4), ("update_s3", 5))
+
+
+def prof_collect(lib):
+    """Average duration (ms) per launch of every sweep kernel since psgd_prof_enable(1)."""
+    out = {}
+    for name, slot in PROF_SLOTS:
+        tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
+        lib.psgd_prof_collect(slot, ctypes.byref(tot), ctypes.byref(cnt))
+        out[name] = (tot.value / cnt.value) if cnt.value else None
+    return out
+
+
+def uvd_bytes(r, fused):
+    """Bytes per row per launch that each sweep kernel moves."""
+    kb = {"apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 3), "apply_s3": 4 * (r + 3),
+          "update_s1": 4 * (2 * r + 3), "update_s2": 4 * (3 * r + 4), "update_s3": 12}
+    if fused:
+        kb["update_s2"] = 4 * (3 * r + 5)      # + 4 B/row for g; produces the apply's s1
+    return kb
+
+
+def uvd_legs(dev, psgd, lib, state, r, iters):
+    """precond_grad_UVd_math alone, update_precond_UVd_math_ alone (the two reference-named calls) and the fused
+    step on one resident problem: wall time per call from HIP events on the launch stream, per-kernel times from
+    the psgd_prof hooks, HBM fractions on SURVEY 8d's algorithmic bytes and on the bytes the sweeps move."""
+    U, V, d, grad, v, h = state
+    n = U.shape[0]
+
+    def timed(fn, count):
+        for i in range(2):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        lib.psgd_prof_enable(0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(count):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        wall = e0.elapsed_time(e1) / count
+        lib.psgd_prof_enable(1)                 # second pass: same calls with the per-kernel event hooks on
+        for i in range(count):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        k = prof_collect(lib)
+        lib.psgd_prof_enable(0)
+        return wall, k
+
+    def leg(wall, kms, names, alg, moved):
+        ksum = sum(kms[x] or 0.0 for x in names)
+        gbs = lambda b, ms: b * n / (ms * 1e-3) / 1e9
+        return {"wall_ms": wall, "kernel_ms": ksum, "params_per_s": n / (wall * 1e-3),
+                "alg_bytes_per_param": alg, "moved_bytes_per_param": moved,
+                "frac": gbs(alg, wall) / HBM_PEAK_GBS, "frac_moved": gbs(moved, wall) / HBM_PEAK_GBS,
+                "frac_kernels_only": gbs(alg, ksum) / HBM_PEAK_GBS if ksum else None,
+                "kernels_ms": {x: kms[x] for x in names}}
+
+    wa, ka = timed(lambda i: psgd.precond_grad_UVd_math(U, V, d, grad), iters)
+    wu, ku = timed(lambda i: psgd.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False,
+                                                           update_U=(i % 2 == 0)), iters)
+    wf, kf = timed(lambda i: psgd.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, STEP, TINY, balance=False,
+                                                                           update_U=(i % 2 == 0)), iters)
+    return {
+        "N": n, "r": r, "timed_calls": iters,
+        "apply": dict(leg(wa, ka, ("apply_s1", "apply_s2", "apply_s3"), 4 * (4 * r + 5), 4 * (3 * r + 8)),
+                      call="precond_grad_UVd_math (psgd.py:619-627)"),
+        "update": dict(leg(wu, ku, ("update_s1", "update_s2", "update_s3"), 4 * (5 * r + 10), 4 * (5 * r + 10)),
+                       call="update_precond_UVd_math_ (psgd.py:554-617)"),
+        "step_fused": dict(leg(wf, kf, ("update_s1", "update_s2", "update_s3", "apply_s2", "apply_s3"),
+                               4 * (9 * r + 15), 4 * (2 * r + 3) + 4 * (3 * r + 5) + 12 + 2 * 4 * (r + 3)),
+                           call="update_precond_UVd_math_and_precond_grad (psgd.py:732 -> :748)"),
+    }
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as a child torch.distributed.run job.  This
+    parent never initialises a GPU (device_count() does not), so nothing that holds the device is ever replaced."""
+    import socket
+    import subprocess
+    single_dev = os.environ.get("PSGD_BENCH_SINGLE_DEVICE", "0") == "1"
+    have = torch.cuda.device_count()
+    if not single_dev and have < args.gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode != 0 else (0 if lines else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,20 +340,25 @@ def main():
     ap.add_argument("--rank-r", type=int, default=20, help="rank of modification r")
     ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="fix the thread count of the CPU baseline (0 = sweep)")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the full --rows (needs ~45 B/param of host RAM x r/20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kron", action="store_true", help="skip the Kron apply GFLOP/s leg")
+    ap.add_argument("--no-kron", action="store_true", help="skip the Kron apply GFLOP/s and sparse-LU legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the apply-alone / update-alone / config-2 legs")
     ap.add_argument("--unfused", action="store_true",
                     help="time update_precond_UVd_math_ + precond_grad_UVd_math as two separate calls")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="use the multi-GPU code path (process group + all-reduces) even at world size 1")
+                    help="use the multi-GPU code path (process group + exchanges) even at world size 1")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))            # before anything touches a GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # Test hook (not a measurement): PSGD_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 with gloo collectives, so the
     # N > 1 code path of this script can be exercised where only one GPU exists (RCCL refuses two ranks on one device).
     single_dev = os.environ.get("PSGD_BENCH_SINGLE_DEVICE", "0") == "1"
@@ -217,6 +367,7 @@ def main():
 
     import torch.distributed as dist
     use_dist = world > 1 or args.force_sharded
+    backend = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -225,6 +376,7 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        backend = dist.get_backend()
 
     import preconditioned_stochastic_gradient_descent as psgd
     from psgd_tf_amd import _lib, sharded
@@ -251,23 +403,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # ---- headline pass: no profiling hooks inside the timed region
+    lib.psgd_prof_enable(0)
     for i in range(args.warmup):
         step(i)
     fence()
-    lib.psgd_prof_enable(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    slot_ms = {}
-    for name, slot in (("apply_s1", 0), ("apply_s2", 1), ("apply_s3", 2), ("update_s1", 3), ("update_s2", 4),
-                       ("update_s3", 5)):
-        tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
-        lib.psgd_prof_collect(slot, ctypes.byref(tot), ctypes.byref(cnt))
-        slot_ms[name] = (tot.value / cnt.value) if cnt.value else None
-    lib.psgd_prof_enable(0)
     assert torch.isfinite(out).all().item(), "non-finite preconditioned gradient"
+    # ---- second pass: the same steps with a HIP event pair around every sweep launch (per-kernel durations)
+    lib.psgd_prof_enable(1)
+    for i in range(args.steps):
+        step(i)
+    fence()
+    slot_ms = prof_collect(lib)
+    lib.psgd_prof_enable(0)
 
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -277,11 +430,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global * args.steps / elapsed
-        # algorithmic bytes per row per launch (DESIGN.md section 4 / SURVEY 8d)
-        kbytes = {"apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 3), "apply_s3": 4 * (r + 3),
-                  "update_s1": 4 * (2 * r + 3), "update_s2": 4 * (3 * r + 4), "update_s3": 12}
-        if not args.unfused:
-            kbytes["update_s2"] = 4 * (3 * r + 5)      # + 4 B/row for g; produces the apply's s1
+        kbytes = uvd_bytes(r, not args.unfused)
         kern = {k: {"avg_ms": slot_ms[k], "achieved_GBs": kbytes[k] * n_local / (slot_ms[k] * 1e-3) / 1e9}
                 for k in kbytes if slot_ms[k]}
         dom = "update_s2"
@@ -295,17 +444,14 @@ def main():
             except Exception:
                 traffic = None
         ach = kern[dom]["achieved_GBs"]
-        apply_ms = sum(slot_ms[k] or 0.0 for k in ("apply_s1", "apply_s2", "apply_s3"))
-        update_ms = sum(slot_ms[k] or 0.0 for k in ("update_s1", "update_s2", "update_s3"))
-        paths = {
-            "fused": not args.unfused,
-            "apply": {"alg_bytes_per_param": 4 * (4 * r + 5), "kernel_ms": apply_ms,
-                      "frac": (4 * (4 * r + 5) * n_local / (apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.unfused else None},
-            "update": {"alg_bytes_per_param": 4 * (5 * r + 10), "kernel_ms": update_ms,
-                       "frac": (4 * (5 * r + 10) * n_local / (update_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.unfused else None},
-            "step": {"alg_bytes_per_param": 4 * (9 * r + 15), "wall_ms": ms_per_step,
-                     "frac": 4 * (9 * r + 15) * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        }
+        alg_step = 4 * (9 * r + 15)
+        moved_step = (4 * (5 * r + 10) + 4 * (3 * r + 8)) if args.unfused else \
+            (4 * (2 * r + 3) + 4 * (3 * r + 5) + 12 + 2 * 4 * (r + 3))
+        gbs = lambda b: b * n_local / (ms_per_step * 1e-3) / 1e9
+        paths = {"fused": not args.unfused,
+                 "step": {"alg_bytes_per_param": alg_step, "moved_bytes_per_param": moved_step, "wall_ms": ms_per_step,
+                          "frac": gbs(alg_step) / HBM_PEAK_GBS, "frac_moved": gbs(moved_step) / HBM_PEAK_GBS,
+                          "kernel_ms": sum(slot_ms[k] or 0.0 for k in slot_ms)}}
         res = {
             "metric": "uvd_update_apply_params_per_sec", "value": value, "unit": "params/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -314,22 +460,38 @@ def main():
                                    "precond_grad_UVd_math%s), N=%d rows per GPU, r=%d"
                                    % ("" if args.unfused else ", fused call", n_local, r),
                        "rows_per_gpu": n_local, "rows_global": n_global, "rank_of_modification": r,
-                       "parallelism": ("row-sharded x%d, all-reduce of r-dim sums only" % world) +
+                       "parallelism": ("row-sharded x%d, per step %d all-gathers of r-dim reduced buffers (<= 30 KB) + "
+                                       "rank-order fold" % (world, 4 if args.unfused else 3)) +
                                       (" [TEST MODE: all ranks on one GPU, gloo -- not a measurement]" if single_dev else ""),
+                       "collective_backend": backend, "rccl_ranks": (dist.get_world_size() if use_dist else 0),
                        "step": STEP, "branches": "balance=0, update_U alternating"},
             "roofline": {"bound": "hbm", "kernel": "k_update_s2 (update sweep 2, dominant kernel)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "alg_bytes_per_launch": kbytes[dom] * n_local,
-                         "avg_launch_ms": slot_ms[dom], "kernels": kern, "paths": paths},
+                         "avg_launch_ms": slot_ms[dom], "kernels": kern, "paths": paths,
+                         "timing": "headline pass without profiling hooks; kernel durations from a second pass of the "
+                                   "same steps with HIP event pairs on the launch stream"},
         }
         if world == 1:
+            if not args.no_legs:
+                legs = uvd_legs(dev, psgd, lib, (U, V, d, grad, v, h), r, max(5, min(args.steps, 20)))
+                paths["apply"], paths["update"], paths["step_fused_events"] = legs["apply"], legs["update"], legs["step_fused"]
             del U, V, d, grad, v, h, out
             torch.cuda.empty_cache()
+            if not args.no_legs:
+                c2 = make_inputs(1_000_000, 1_000_000, 10, dev, seed=7)
+                legs2 = uvd_legs(dev, psgd, lib, c2, 10, 200)
+                legs2["note"] = ("BASELINE config 2: 88 MB working set, resident in the 256 MiB Infinity Cache -> "
+                                 "launch/latency-bound; fractions are against the HBM roof for reference only")
+                res["config2_N1M_r10"] = legs2
+                del c2
+                torch.cuda.empty_cache()
             if not args.no_kron:
                 res["kron"] = kron_bench(dev, psgd)
                 res["splu"] = splu_bench(dev, psgd)
             if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(r, args.cpu_sample_rows, args.cpu_budget_s)
+                rows = n_local if args.cpu_full else args.cpu_sample_rows
+                res["cpu_baseline"] = cpu_baseline(r, rows, args.cpu_budget_s, args.cpu_threads or None)
         print(json.dumps(res), flush=True)
 
     if use_dist:

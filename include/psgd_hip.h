@@ -47,9 +47,15 @@ extern "C" {
 
 #define PSGD_UVD_MAX_RANK 32
 
-/* workspace regions that the multi-GPU driver must all-reduce between stages */
+/* workspace regions that the multi-GPU driver exchanges between stages.  Two equivalent protocols:
+ *  (a) all-gather + fold (what psgd_tf_amd/sharded.py does): all-gather every rank's PSGD_WS_SEND_F64 region of the
+ *      stage into a [world][count] fp64 buffer and call psgd_*_fold_gathered_f64, which folds the copies in rank
+ *      order (SUM or MAX per entry).  One collective per exchange point, and the reduced values are bit-identical on
+ *      every rank whatever algorithm the collective library picks.
+ *  (b) all-reduce in place: SUM on the PSGD_WS_SUMS_F64 region and MAX on the PSGD_WS_MAX_F32 region of the stage. */
 #define PSGD_WS_SUMS_F64   0   /* double[len]: SUM over ranks  */
 #define PSGD_WS_MAX_F32    1   /* float[len]:  MAX over ranks  */
+#define PSGD_WS_SEND_F64   2   /* double[len]: this rank's contribution, to be all-gathered and folded */
 
 int         psgd_abi_version(void);
 const char *psgd_error_string(int code);
@@ -69,6 +75,11 @@ int64_t psgd_uvd_workspace_bytes(int64_t N, int r);
  * Returns 0 or an error code.                                                */
 int psgd_uvd_ws_region(int which, int stage, int64_t N, int r,
                        int64_t *offset_bytes, int64_t *count);
+/* Protocol (a): PSGD_WS_SEND_F64 regions exist for stages 1, 2, 11 (sums), 10 (2 maxima), 12 (1 maximum) and
+ * 13 ([p | q | max]: the 2r sums and the maximum of the fused sweep 2 in ONE region, so the fused step needs three
+ * exchanges: 11, 13, 2).  `gathered` = the all-gathered regions, [world][count] doubles in rank order (device).   */
+int psgd_uvd_fold_gathered_f64(int stage, const double *gathered, int world, int64_t N, int r,
+                               void *ws, int64_t ws_bytes, void *stream);
 
 /* precond_grad_UVd_math(U, V, d, g)   psgd.py:619-627 (IpUVtmatvec :540-544)
  *   out = d .* (I + V U') (I + U V') (d .* g)
@@ -187,6 +198,10 @@ int psgd_splu_update_f32(const float *L12, const float *l3, const float *U12, co
  * psgd_splu_stage1_f32 serves both paths (x = the flat gradient for the apply, dg for the update).
  * has_tail (update stage 4): the GLOBAL problem has tail rows (N_global > r).                                       */
 int psgd_splu_ws_region(int which, int stage, int64_t N, int r, int64_t *offset_bytes, int64_t *count);
+/* all-gather + fold form (protocol (a) above): PSGD_WS_SEND_F64 regions for stage 1 (r sums), 2 (2r sums) and
+ * 3 ([r sums | 4 maxima] in one region: three exchanges per update, two per apply).                                */
+int psgd_splu_fold_gathered_f64(int stage, const double *gathered, int world, int64_t N, int r, void *ws,
+                                int64_t ws_bytes, void *stream);
 int psgd_splu_stage1_f32(const float *U12, const float *x, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
 int psgd_splu_apply_stage2_f32(const float *L12, const float *l3, const float *U12, const float *u3, const float *g,
                                float *out, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("PSGD_HIP_LIB", os.path.join(_CSRC, "libpsgd_hip.so"))
 PSGD_OK = 0
 PSGD_WS_SUMS_F64 = 0
 PSGD_WS_MAX_F32 = 1
+PSGD_WS_SEND_F64 = 2
 UVD_MAX_RANK = 32
 
 
@@ -39,6 +40,8 @@ SIGNATURES = {
     "psgd_prof_collect": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_int)]),
     "psgd_uvd_workspace_bytes": (_i64, [_i64, _int]),
     "psgd_uvd_ws_region": (_int, [_int, _int, _i64, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "psgd_uvd_fold_gathered_f64": (_int, [_int, _c_f32p, _int, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_splu_fold_gathered_f64": (_int, [_int, _c_f32p, _int, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_apply_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_apply_sweep1_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_apply_sweep2_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, _c_ws, _i64, _strm]),
@@ -155,12 +158,13 @@ def splu_ws_region(which, stage, N, r):
 
 
 class WorkspaceCache:
-    """Device workspaces keyed by (device, problem shape), least-recently-used eviction.
+    """Device workspaces keyed by (device, problem shape, stream), least-recently-used eviction.
 
     The C ABI never allocates: the caller owns the scratch memory.  A model has a fixed set of shapes, so this
     cache normally never evicts; the bounds keep a program that sweeps many shapes from accumulating
     workspaces (they are the size of a few operand copies each).  Eviction only drops the reference: work
-    already queued on the stream keeps using the block, and torch's caching allocator reuses it in stream order."""
+    already queued on the stream keeps using the block, and torch's caching allocator reuses it in the order of the
+    stream it was allocated on -- which is the stream in the key, the only one that ever uses the block."""
 
     def __init__(self, max_entries=32, max_bytes=32 << 30):
         import collections

@@ -26,9 +26,10 @@ const SpluOps* splu_ops_for_rank(int r) {
 constexpr int MR = PSGD_UVD_MAX_RANK;
 
 // ------------------------------------------------------------ workspace ----
-// doubles: sums A [MR] | sums B [2 MR] | sums C [MR] | state vectors (7 x MR)
-enum { kSumA = 0, kSumB = MR, kSumC = 3 * MR, kStUg1 = 4 * MR, kStQg1 = 5 * MR, kStIUtx1 = 6 * MR, kStIQtx1 = 7 * MR,
-       kStLtQg1 = 8 * MR, kStPg1 = 9 * MR, kStILiQtx1 = 10 * MR, kDoubles = 11 * MR };
+// doubles: sums A [MR] | sums B [2 MR] | state vectors (7 x MR) | sums C [r] followed by the fp64 copies of the 4 maxima
+// (one contiguous multi-GPU send region for update stage 3)
+enum { kSumA = 0, kSumB = MR, kStUg1 = 3 * MR, kStQg1 = 4 * MR, kStIUtx1 = 5 * MR, kStIQtx1 = 6 * MR,
+       kStLtQg1 = 7 * MR, kStPg1 = 8 * MR, kStILiQtx1 = 9 * MR, kSumC = 10 * MR, kDoubles = 11 * MR + 8 };
 constexpr int64_t kCoefFloats = 9 * MR;
 constexpr int64_t kMaxFloats = 8;
 
@@ -78,12 +79,30 @@ __global__ __launch_bounds__(kThreads) void k_splu_reduce_sum(const float* __res
 
 // out[set] = max_b part[set*G + b]   (signed: the balance of psgd.py:411-412 takes max, not max|.|)
 __global__ __launch_bounds__(kThreads) void k_splu_reduce_max(const float* __restrict__ part, int G,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, double* __restrict__ outd) {
   __shared__ float red[kWavesPerBlock];
   const float* p = part + (long)blockIdx.x * G;
   float v = -INFINITY;
   for (int b = threadIdx.x; b < G; b += kThreads) v = fmaxf(v, p[b]);
   block_max_store(v, red, out + blockIdx.x);
+  __syncthreads();
+  if (threadIdx.x == 0) outd[blockIdx.x] = (double)out[blockIdx.x];
+}
+
+// multi-GPU exchange, second half: fold the all-gathered send regions ([world][count] doubles) in rank order, the first
+// nsum entries by +, the rest by max (cf. k_fold_gathered in psgd_uvd.hip)
+__global__ void k_splu_fold_gathered(const double* __restrict__ gathered, int world, int count, int nsum,
+                                     double* __restrict__ dst, float* __restrict__ maxdst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a = gathered[i];
+  if (i < nsum) {
+    for (int k = 1; k < world; ++k) a += gathered[(long)k * count + i];
+  } else {
+    for (int k = 1; k < world; ++k) a = fmax(a, gathered[(long)k * count + i]);
+    maxdst[i - nsum] = (float)a;
+  }
+  dst[i] = a;
 }
 
 // ----------------------------------------------------- r x r corner (fp64) -
@@ -434,8 +453,28 @@ int psgd_splu_ws_region(int which, int stage, int64_t N, int r, int64_t* offset_
     if (stage == 3) { *offset_bytes = dbl + kSumC * 8; *count = r; return PSGD_OK; }       // U2 iPx2      (update)
   } else if (which == 1 && stage == 3) {   // fp32 maxima (all-reduce MAX): |grad L|, |grad U|, l3, u3
     *offset_bytes = mx; *count = 4; return PSGD_OK;
+  } else if (which == PSGD_WS_SEND_F64) {  // fp64 send regions (all-gather, then psgd_splu_fold_gathered_f64)
+    if (stage == 1 || stage == 2) return psgd_splu_ws_region(0, stage, N, r, offset_bytes, count);
+    if (stage == 3) { *offset_bytes = dbl + kSumC * 8; *count = r + 4; return PSGD_OK; }   // [U2 iPx2 | 4 maxima]
   }
   return PSGD_ERR_BAD_ARG;
+}
+
+int psgd_splu_fold_gathered_f64(int stage, const double* gathered, int world, int64_t N, int r, void* ws,
+                                int64_t ws_bytes, void* stream) {
+  if (!gathered || world < 1) return PSGD_ERR_BAD_ARG;
+  SpluWs w;
+  const int rc = splu_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  int64_t off = 0, count = 0;
+  const int rr = psgd_splu_ws_region(PSGD_WS_SEND_F64, stage, N, r, &off, &count);
+  if (rr) return rr;
+  double* dst = reinterpret_cast<double*>(static_cast<char*>(ws) + off);
+  const int nsum = (stage == 3) ? r : (int)count;
+  hipLaunchKernelGGL(k_splu_fold_gathered, dim3(((int)count + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     gathered, world, (int)count, nsum, dst, w.maxbuf);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
 }
 
 /* stage 1 of either path: sums A = U2 x2 (x = the flat gradient for the apply, dg for the update) */
@@ -530,7 +569,7 @@ int psgd_splu_update_stage3_f32(const float* L12, const float* l3, const float* 
   PSGD_CHECK_LAUNCH(c.ops->upd_s3(c.nt, L12 + (int64_t)(r + h) * r, U12 + r + h, c.ge.ldu, l3 + h, u3 + h, dg + r + h,
                                   dx + r + h, c.ge.n2s, h, c.w.coef, c.w.part, c.w.pmax, grid, c.st));
   hipLaunchKernelGGL(k_splu_reduce_sum, dim3(c.rblocks), dim3(kThreads), 0, c.st, c.w.part, grid, r, c.w.dbl + kSumC);
-  hipLaunchKernelGGL(k_splu_reduce_max, dim3(4), dim3(kThreads), 0, c.st, c.w.pmax, grid, c.w.maxbuf);
+  hipLaunchKernelGGL(k_splu_reduce_max, dim3(4), dim3(kThreads), 0, c.st, c.w.pmax, grid, c.w.maxbuf, c.w.dbl + kSumC + r);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }

@@ -25,7 +25,9 @@ const UvdOps* uvd_ops_for_rank(int r) {
 
 // ------------------------------------------------------------ workspace ----
 constexpr int64_t kSumsCap = 4096;   // doubles (Gram of r = 32 needs 3840)
-constexpr int kPqSumsOff = 3840;      // the fused p,q sums (2r <= 64 doubles) live above the largest Gram
+constexpr int kPqSumsOff = 3840;      // the fused p,q sums (2r <= 64 doubles) live above the largest Gram; the fp64 copy of
+                                      // max|nablaD| follows them at [kPqSumsOff + 2r] (one contiguous send region [p | q | max])
+constexpr int kBalD64Off = 4000;      // fp64 copies of the two balance maxima (send region of stage 10)
 constexpr int64_t kCoefCap = 256;    // floats
 constexpr int64_t kMaxCap = 64;      // floats
 
@@ -218,14 +220,34 @@ __global__ __launch_bounds__(kThreads) void k_reduce_sum_t(const float* __restri
   }
 }
 
-// out[set] = max_b part[set*stride + b]
+// out[set] = max_b part[set*stride + b]; outd[set] = the same value as a double (multi-GPU send regions are fp64)
 __global__ __launch_bounds__(kThreads) void k_reduce_max(const float* __restrict__ part, int G, int stride,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, double* __restrict__ outd) {
   __shared__ float red[kWavesPerBlock];
   const float* p = part + (long)blockIdx.x * stride;
   float v = 0.0f;
   for (int b = threadIdx.x; b < G; b += kThreads) v = fmaxf(v, p[b]);
   block_max_store(v, red, out + blockIdx.x);
+  __syncthreads();
+  if (threadIdx.x == 0) outd[blockIdx.x] = (double)out[blockIdx.x];
+}
+
+// Multi-GPU exchange, second half (the first half is an all-gather of every rank's send region): `gathered` holds the
+// regions of all ranks, [world][count] doubles in rank order.  Every rank folds them in that order -- entries [0, nsum)
+// by +, the rest by max -- so all ranks end up with bit-identical reduced values whatever algorithm the collective
+// library uses for the gather.  Maxima also go back to the fp32 max buffer the next stage reads.
+__global__ void k_fold_gathered(const double* __restrict__ gathered, int world, int count, int nsum,
+                                double* __restrict__ dst, float* __restrict__ maxdst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a = gathered[i];
+  if (i < nsum) {
+    for (int k = 1; k < world; ++k) a += gathered[(long)k * count + i];
+  } else {
+    for (int k = 1; k < world; ++k) a = fmax(a, gathered[(long)k * count + i]);
+    maxdst[i - nsum] = (float)a;
+  }
+  dst[i] = a;
 }
 
 __global__ void k_publish(const double* __restrict__ sums, float* __restrict__ coef, int n) {
@@ -632,8 +654,34 @@ int psgd_uvd_ws_region(int which, int stage, int64_t N, int r, int64_t* offset_b
   } else if (which == PSGD_WS_MAX_F32) {
     if (stage == 10) { *offset_bytes = L.max_off; *count = 2; return PSGD_OK; }
     if (stage == 12) { *offset_bytes = L.max_off + 8; *count = 1; return PSGD_OK; }
+  } else if (which == PSGD_WS_SEND_F64) {
+    if (stage == 1 || stage == 2 || stage == 11) return psgd_uvd_ws_region(PSGD_WS_SUMS_F64, stage, N, r, offset_bytes, count);
+    if (stage == 10) { *offset_bytes = L.sums_off + (int64_t)kBalD64Off * 8; *count = 2; return PSGD_OK; }
+    if (stage == 12) { *offset_bytes = L.sums_off + (int64_t)(kPqSumsOff + 2 * r) * 8; *count = 1; return PSGD_OK; }
+    if (stage == 13) { *offset_bytes = L.sums_off + (int64_t)kPqSumsOff * 8; *count = 2 * r + 1; return PSGD_OK; }
   }
   return PSGD_ERR_BAD_ARG;
+}
+
+int psgd_uvd_fold_gathered_f64(int stage, const double* gathered, int world, int64_t N, int r, void* ws,
+                               int64_t ws_bytes, void* stream) {
+  if (!gathered || world < 1) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  int64_t off = 0, count = 0;
+  const int rr = psgd_uvd_ws_region(PSGD_WS_SEND_F64, stage, N, r, &off, &count);
+  if (rr) return rr;
+  double* dst = reinterpret_cast<double*>(static_cast<char*>(ws) + off);
+  int nsum = (int)count;
+  float* maxdst = nullptr;
+  if (stage == 10) { nsum = 0; maxdst = w.maxbuf; }
+  else if (stage == 12) { nsum = 0; maxdst = w.maxbuf + 2; }
+  else if (stage == 13) { nsum = 2 * r; maxdst = w.maxbuf + 2; }
+  hipLaunchKernelGGL(k_fold_gathered, dim3(((int)count + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     gathered, world, (int)count, nsum, dst, maxdst);
+  PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
 }
 
 // ---------------------------------------------------------------- apply ----
@@ -757,7 +805,7 @@ int psgd_uvd_balance_max_f32(const float* U, const float* V, int64_t N, int r, v
   const int grid = flat_grid(n);
   hipLaunchKernelGGL(k_maxabs2, dim3(grid), dim3(kThreads), 0, st, U, V, (long)n, w.pmax, grid);
   PSGD_CHECK_LAUNCH(last_launch());
-  hipLaunchKernelGGL(k_reduce_max, dim3(2), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf);
+  hipLaunchKernelGGL(k_reduce_max, dim3(2), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf, w.sums + kBalD64Off);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
@@ -823,7 +871,8 @@ static int update_sweep2_impl(float* U, float* V, const float* d, const float* v
     PSGD_CHECK_LAUNCH(last_launch());
     return PSGD_OK;
   }
-  hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf + 2);
+  hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf + 2,
+                     w.sums + kPqSumsOff + 2 * r);
   PSGD_CHECK_LAUNCH(last_launch());
   if (g) {
     hipLaunchKernelGGL(k_reduce_sum_t, dim3((2 * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,

@@ -42,13 +42,36 @@ def _check_rank2_f32(name, *tensors, allow_bf16_last=False, allow_bf16_from=None
             raise TypeError("%s: fp32 tensors required, got %s" % (name, t.dtype))
 
 
+def _check_kron_shapes(name, Ql, Qr, *mats):
+    """Every format keeps M = rows(data) in the last dimension of the left factor ((M,M), (2,M) or (1,M)) and
+    N = cols(data) in the last dimension of the right one.  The reference's matmuls raise on a mismatch; the kernels
+    take raw pointers and would read or write out of bounds, so the check is here."""
+    M, N = mats[0].shape
+    for t in mats[1:]:
+        if tuple(t.shape) != (M, N):
+            raise ValueError("%s: data matrices must share one shape, got %s and %s"
+                             % (name, tuple(mats[0].shape), tuple(t.shape)))
+    if Ql.shape[1] != M or Qr.shape[1] != N:
+        raise ValueError("%s: factors %s, %s do not match the %d x %d data matrix (left factor needs %d columns, "
+                         "right factor %d)" % (name, tuple(Ql.shape), tuple(Qr.shape), M, N, M, N))
+    dev = mats[0].device
+    for t in (Ql, Qr) + tuple(mats[1:]):
+        if t.device != dev:
+            raise ValueError("%s: all tensors must be on one device, got %s and %s" % (name, dev, t.device))
+
+
 # --------------------------------------------------------------------------- dense (x) dense: HIP
 _kron_ws = _lib.WorkspaceCache()
 _kron_ws_bf16 = _lib.WorkspaceCache()
 
 
+def _stream_key(device):
+    """Workspaces carry intermediates between the launches of one call: one per (shape, stream)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _kron_workspace(device, M, N):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), M, N)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), M, N, _stream_key(device))
     def make():
         nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes(M, N))
         if nbytes < 0:
@@ -71,7 +94,7 @@ def _update_precond_dense_dense_bf16(Ql, Qr, dX, dG, step):
         raise ValueError("update_precond_kron: the bf16 path needs M and N to be multiples of 8, got %dx%d" % (M, N))
     Ql, Qr, dX, dG = (t.contiguous() for t in (Ql, Qr, dX, dG))
     QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
-    key = (dX.device.index, "upd", M, N)
+    key = (dX.device.index, "upd", M, N, _stream_key(dX.device))
     ws = _kron_ws_bf16.get(key, lambda: torch.empty(int(_lib.load().psgd_kron_dd_update_workspace_bytes_bf16(M, N)),
                                                       dtype=torch.uint8, device=dX.device))
     rc = _lib.load().psgd_kron_dd_update_bf16(Ql.data_ptr(), Qr.data_ptr(), dX.data_ptr(), dG.data_ptr(),
@@ -108,7 +131,7 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
         raise ValueError("precond_grad_kron: the bf16 path needs M and N to be multiples of 8, got %dx%d" % (M, N))
     Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
     out = torch.empty_like(Grad)
-    key = (Grad.device.index, M, N)
+    key = (Grad.device.index, M, N, _stream_key(Grad.device))
     ws = _kron_ws_bf16.get(key, lambda: torch.empty(int(_lib.load().psgd_kron_dd_workspace_bytes_bf16(M, N)),
                                                       dtype=torch.uint8, device=Grad.device))
     rc = _lib.load().psgd_kron_dd_apply_bf16(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
@@ -154,7 +177,7 @@ def _int_array(vals):
 
 
 def _batch_workspace(device, Ms, Ns):
-    key = (device.index, tuple(Ms), tuple(Ns))
+    key = (device.index, tuple(Ms), tuple(Ns), _stream_key(device))
     def make():
         nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes_batched(_int_array(Ms), _int_array(Ns), len(Ms)))
         if nbytes < 0:
@@ -167,8 +190,13 @@ def precond_grad_kron_batched(Qls, Qrs, Grads):
     """[precond_grad_kron(Ql, Qr, G) for ...] (mnist_with_lenet5.py:53) with the same stage of every
     (dense, dense) layer in one kernel launch.  Other formats fall back to the per-layer call."""
     Qls, Qrs, Grads = list(Qls), list(Qrs), list(Grads)
+    if not (len(Qls) == len(Qrs) == len(Grads)):
+        raise ValueError("precond_grad_kron_batched: the three lists must have one length")
     if not _batched_ok(Qls, Qrs, Grads):
         return [precond_grad_kron(a, b, g) for a, b, g in zip(Qls, Qrs, Grads)]
+    for a, b, g in zip(Qls, Qrs, Grads):
+        _check_rank2_f32("precond_grad_kron_batched", a, b, g)
+        _check_kron_shapes("precond_grad_kron_batched", a, b, g)
     Qls, Qrs, Grads = ([t.contiguous() for t in ts] for ts in (Qls, Qrs, Grads))
     outs = [torch.empty_like(g) for g in Grads]
     Ms, Ns = [g.shape[0] for g in Grads], [g.shape[1] for g in Grads]
@@ -185,9 +213,14 @@ def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
     """[update_precond_kron(Ql, Qr, dX, dG, step) for ...] (mnist_with_lenet5.py:51), batched as above.
     Returns a list of (Ql_new, Qr_new)."""
     Qls, Qrs, dXs, dGs = list(Qls), list(Qrs), list(dXs), list(dGs)
+    if not (len(Qls) == len(Qrs) == len(dXs) == len(dGs)):
+        raise ValueError("update_precond_kron_batched: the four lists must have one length")
     small = all(max(x.shape) <= 512 for x in dXs)
     if not (small and _batched_ok(Qls, Qrs, dXs) and _batched_ok(Qls, Qrs, dGs)):
         return [update_precond_kron(a, b, x, g, step) for a, b, x, g in zip(Qls, Qrs, dXs, dGs)]
+    for a, b, x, g in zip(Qls, Qrs, dXs, dGs):
+        _check_rank2_f32("update_precond_kron_batched", a, b, x, g)
+        _check_kron_shapes("update_precond_kron_batched", a, b, x, g)
     Qls, Qrs, dXs, dGs = ([t.contiguous() for t in ts] for ts in (Qls, Qrs, dXs, dGs))
     QlO, QrO = [torch.empty_like(t) for t in Qls], [torch.empty_like(t) for t in Qrs]
     Ms, Ns = [x.shape[0] for x in dXs], [x.shape[1] for x in dXs]
@@ -209,7 +242,7 @@ _sparse_ws = _lib.WorkspaceCache()
 
 
 def _sparse_workspace(device, fmt, M, N):
-    key = (device.index, fmt, M, N)
+    key = (device.index, fmt, M, N, _stream_key(device))
     def make():
         nbytes = int(_lib.load().psgd_kron_sparse_workspace_bytes(_SPARSE_FMT[fmt], M, N))
         if nbytes < 0:
@@ -281,6 +314,8 @@ def _precond_grad_norm_scale(ql, qr, Grad):
 def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
     fmt = kron_format(Ql.shape, Qr.shape)
     _check_rank2_f32("update_precond_kron", Ql, Qr, dX, dG, allow_bf16_from=(2 if fmt == "dense_dense" else None))
+    if fmt != "unknown":
+        _check_kron_shapes("update_precond_kron", Ql, Qr, dX, dG)
     if fmt == "dense_dense":
         return _update_precond_dense_dense(Ql, Qr, dX, dG, step)                            # psgd.py:84
     if fmt == "dense_norm":
@@ -302,6 +337,8 @@ def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
 def precond_grad_kron(Ql, Qr, Grad):
     fmt = kron_format(Ql.shape, Qr.shape)
     _check_rank2_f32("precond_grad_kron", Ql, Qr, Grad, allow_bf16_last=(fmt == "dense_dense"))
+    if fmt != "unknown":
+        _check_kron_shapes("precond_grad_kron", Ql, Qr, Grad)
     if fmt == "dense_dense":
         return _precond_grad_dense_dense(Ql, Qr, Grad)                                      # psgd.py:126
     if fmt == "dense_norm":

@@ -71,8 +71,11 @@ def _require_hip(name, *tensors):
 
 
 def uvd_workspace(device, N, r):
-    """Cached device workspace for a shard of N rows at rank r (see psgd_uvd_workspace_bytes)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(N), int(r))
+    """Cached device workspace for a shard of N rows at rank r (see psgd_uvd_workspace_bytes).  Keyed by the current
+    stream as well: a workspace carries the reduced vectors between the sweeps of one call, so calls issued on two
+    streams must not share one (the C ABI itself is safe on several streams as long as each has its own workspace)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(N), int(r),
+           torch.cuda.current_stream(device).cuda_stream)
 
     def make():
         nbytes = _lib.load().psgd_uvd_workspace_bytes(N, r)
@@ -140,7 +143,8 @@ def precond_grad_kron_batched(Qls, Qrs, Grads):
 
 # --------------------------------------------------------------------------- sparse LU
 def _splu_workspace(device, N, r):
-    key = ("splu", device.index if device.index is not None else torch.cuda.current_device(), int(N), int(r))
+    key = ("splu", device.index if device.index is not None else torch.cuda.current_device(), int(N), int(r),
+           torch.cuda.current_stream(device).cuda_stream)
 
     def make():
         nbytes = int(_lib.load().psgd_splu_workspace_bytes(N, r))

@@ -2,16 +2,24 @@
 
 The flat parameter vector is split into contiguous row blocks: rank k owns rows
 [k N / W, (k+1) N / W) of U, V, d, g, v, h and of the output.  Every sweep is local; the only
-exchange is an all-reduce (RCCL over xGMI; `backend="nccl"` is RCCL on ROCm) of the tiny
-reduced buffers between sweeps -- never of N-sized data:
+exchange is of the tiny reduced buffers between sweeps -- never of N-sized data.  An exchange
+is ONE collective: an all-gather (RCCL over xGMI; `backend="nccl"` is RCCL on ROCm) of every
+rank's fp64 send region, followed by a local fold of the W copies in rank order (a small HIP
+kernel, psgd_*_fold_gathered_f64).  xGMI is point to point, the payloads are 8 B - 30 KB, so
+the exchanges are latency-bound: what matters is how many there are per call, and that every
+rank ends up with bit-identical reduced values (it folds the same copies in the same order,
+whatever algorithm RCCL picks), so the r x r solves and step sizes redone on every rank agree.
 
-    apply  (psgd.py:619-627):  sweep1 -> SUM r fp64 -> sweep2 -> SUM r fp64 -> sweep3
-    update (psgd.py:554-617):  [max -> MAX 2 fp32 -> scale]                      (balance, :562-567)
-                               sweep1 -> SUM Gram fp64 (<= 30 KB) -> sweep2 -> MAX 1 fp32 -> sweep3
+    apply  (psgd.py:619-627):  sweep1 -> X(r sums) -> sweep2 -> X(r sums) -> sweep3            2 exchanges
+    update (psgd.py:554-617):  [max -> X(2 maxima) -> scale]                                   (balance, :562-567)
+                               sweep1 -> X(Gram, <= 30 KB) -> sweep2 -> X(1 maximum) -> sweep3  2 exchanges
+    fused update -> apply:     sweep1 -> X(Gram) -> sweep2 -> X([p | q | max]) -> d update,
+                               apply sweep2 -> X(r sums) -> apply sweep3                        3 exchanges
 
-All ranks then hold bit-identical reduced values, so the r x r solves and step sizes computed
-redundantly on every rank agree.  The two random branches of the reference (psgd.py:562, :588)
-must agree as well: pass them explicitly or let rank 0 draw and broadcast them.
+The two random branches of the reference (psgd.py:562, :588) must agree across ranks as well:
+pass them explicitly, or let them be drawn from a branch generator whose state is synchronised
+from rank 0 ONCE (first use); afterwards every rank draws the same numbers locally -- no
+per-step broadcast and no host synchronisation.
 
 The stage backend is an object with the methods of `HipStages` (the product backend: the C ABI
 stage functions of include/psgd_hip.h).  tests/ injects a CPU backend to exercise this
@@ -51,6 +59,22 @@ class HipStages:
 
     def maxbuf(self, stage):
         return self._view(_lib.PSGD_WS_MAX_F32, stage, torch.float32, 4)
+
+    def send(self, stage):
+        """This rank's fp64 contribution to the exchange after `stage` (a view into the workspace)."""
+        return self._view(_lib.PSGD_WS_SEND_F64, stage, torch.float64, 8)
+
+    def gather_buf(self, stage, world):
+        key = ("gather", stage, world)
+        if key not in self._views:
+            self._views[key] = torch.empty(world * self.send(stage).numel(), dtype=torch.float64, device=self.device)
+        return self._views[key]
+
+    def fold(self, stage, gathered, world):
+        """Fold the all-gathered send regions ([world][count], rank order) into this rank's workspace."""
+        wp, wn, st = self._w()
+        _lib.check(self.lib.psgd_uvd_fold_gathered_f64(stage, gathered.data_ptr(), world, self.N, self.r, wp, wn, st),
+                   "fold_gathered")
 
     def _w(self):
         return self.ws.data_ptr(), self.ws.numel(), self._st()
@@ -120,7 +144,7 @@ _backends = {}
 def hip_backend_for(U):
     if not U.is_cuda:
         raise _lib.PsgdHipError("sharded UVd runs on HIP devices only (tensor is on %s); no CPU fallback" % U.device)
-    key = (U.device.index, U.shape[0], U.shape[1])
+    key = (U.device.index, U.shape[0], U.shape[1], torch.cuda.current_stream(U.device).cuda_stream)
     if key not in _backends:
         _backends[key] = HipStages(U.device, U.shape[0], U.shape[1])
     return _backends[key]
@@ -137,42 +161,81 @@ def shard_rows(n_global, rank, world):
     return lo, hi
 
 
+class BranchRng:
+    """The two coin flips of update_precond_UVd_math_ (psgd.py:562 p = 0.01, :588 p = 0.5), agreed across ranks
+    without a per-step exchange: the state of rank 0's generator is broadcast once, when the object is built (the only
+    host synchronisation, at set-up time); afterwards every rank draws the same sequence locally on the host."""
+
+    def __init__(self, generator=None, group=None, device=None):
+        src_gen = generator if generator is not None else _psgd._branch_rng
+        state = src_gen.get_state().clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            on_host = dist.get_backend(group) == "gloo" or device is None
+            buf = state if on_host else state.to(device)
+            dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            state = buf.cpu()
+        self.gen = torch.Generator(device="cpu")
+        self.gen.set_state(state)
+
+    def draw(self, p):
+        return bool(torch.rand((), generator=self.gen).item() < p)
+
+
+_branch_rngs = {}
+
+
+def branch_rng_for(generator, group, device):
+    """One BranchRng per (generator object, group): synchronised from rank 0 on first use, local draws afterwards.
+    All ranks must make the same sequence of calls with it (they do: the sharded calls are collective)."""
+    key = (id(generator) if generator is not None else None, id(group) if group is not None else None)
+    ent = _branch_rngs.get(key)
+    if ent is None or ent[0] is not generator:
+        ent = (generator, BranchRng(generator, group, device))        # the strong reference keeps id() unique
+        _branch_rngs[key] = ent
+    return ent[1]
+
+
 def _agree_on_branches(balance, update_U, generator, device, group):
     if balance is not None and update_U is not None:
         return bool(balance), bool(update_U)
-    flags = torch.zeros(2, dtype=torch.float32, device=device)
-    if dist.get_rank(group) == 0:
-        b = _psgd._draw_branch(0.01, generator) if balance is None else bool(balance)
-        u = _psgd._draw_branch(0.5, generator) if update_U is None else bool(update_U)
-        flags = torch.tensor([float(b), float(u)], dtype=torch.float32, device=device)
-    dist.broadcast(flags, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    b, u = flags.tolist()
-    return bool(b), bool(u)
+    rng = branch_rng_for(generator, group, device)
+    b = rng.draw(0.01) if balance is None else bool(balance)            # reference order: :562 then :588
+    u = rng.draw(0.5) if update_U is None else bool(update_U)
+    return b, u
+
+
+def _exchange(be, stage, group):
+    """One exchange point = one collective: all-gather the send regions, fold them in rank order on every rank."""
+    world = dist.get_world_size(group)
+    send = be.send(stage)
+    gathered = be.gather_buf(stage, world)
+    dist.all_gather_into_tensor(gathered, send, group=group)
+    be.fold(stage, gathered, world)
 
 
 def precond_grad_UVd_math(U, V, d, g, group=None, backend=None):
-    """Sharded psgd.py:619-627 on this rank's rows; returns this rank's rows of the result."""
+    """Sharded psgd.py:619-627 on this rank's rows; returns this rank's rows of the result.  2 exchanges."""
     be = backend if backend is not None else hip_backend_for(U)
     be.apply_sweep1(V, d, g)
-    dist.all_reduce(be.sums(1), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 1, group)
     be.apply_sweep2(U, d, g)
-    dist.all_reduce(be.sums(2), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 2, group)
     return be.apply_sweep3(U, V, d, g)
 
 
 def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_U=None, generator=None,
                              group=None, backend=None):
-    """Sharded psgd.py:554-617 on this rank's rows (in place, returns None)."""
+    """Sharded psgd.py:554-617 on this rank's rows (in place, returns None).  2 exchanges (+1 on the balance branch)."""
     be = backend if backend is not None else hip_backend_for(U)
     balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
     if balance:
         be.balance_max(U, V)
-        dist.all_reduce(be.maxbuf(10), op=dist.ReduceOp.MAX, group=group)
+        _exchange(be, 10, group)
         be.balance_scale(U, V)
     be.update_sweep1(U, V, d, v, h)
-    dist.all_reduce(be.sums(11), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 11, group)
     be.update_sweep2(U, V, d, v, h, step, tiny, update_U)
-    dist.all_reduce(be.maxbuf(12), op=dist.ReduceOp.MAX, group=group)
+    _exchange(be, 12, group)
     be.update_sweep3(d, step, tiny)
     return None
 
@@ -180,22 +243,21 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
 def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, balance=None, update_U=None,
                                              generator=None, group=None, backend=None):
     """Sharded fused update -> apply; returns this rank's rows of the preconditioned gradient.
-    Exchanges: SUM Gram, MAX max|nablaD| + SUM 2r (p, q), SUM r (s2) -- one all-reduce fewer than update + apply."""
+    3 exchanges: the Gram, [p | q | max|nablaD|] in one buffer, s2."""
     be = backend if backend is not None else hip_backend_for(U)
     balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
     if balance:
         be.balance_max(U, V)
-        dist.all_reduce(be.maxbuf(10), op=dist.ReduceOp.MAX, group=group)
+        _exchange(be, 10, group)
         be.balance_scale(U, V)
     be.update_sweep1(U, V, d, v, h)
-    dist.all_reduce(be.sums(11), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 11, group)
     be.update_sweep2_fused(U, V, d, v, h, g, step, tiny, update_U)
-    dist.all_reduce(be.maxbuf(12), op=dist.ReduceOp.MAX, group=group)
-    dist.all_reduce(be.sums(13), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 13, group)
     be.update_sweep3(d, step, tiny)
     be.fused_s1(step, tiny)
     be.apply_sweep2_local_s1(U, d, g)
-    dist.all_reduce(be.sums(2), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 2, group)
     return be.apply_sweep3(U, V, d, g)
 
 
@@ -226,6 +288,20 @@ class HipSpluStages:
 
     def maxbuf(self):
         return self._view(1, 3, torch.float32, 4)
+
+    def send(self, stage):
+        return self._view(_lib.PSGD_WS_SEND_F64, stage, torch.float64, 8)
+
+    def gather_buf(self, stage, world):
+        key = ("gather", stage, world)
+        if key not in self._views:
+            self._views[key] = torch.empty(world * self.send(stage).numel(), dtype=torch.float64, device=self.device)
+        return self._views[key]
+
+    def fold(self, stage, gathered, world):
+        wp, wn, st = self._w()
+        _lib.check(self.lib.psgd_splu_fold_gathered_f64(stage, gathered.data_ptr(), world, self.N, self.r, wp, wn, st),
+                   "splu fold_gathered")
 
     def stage1(self, U12, x):
         _lib.check(self.lib.psgd_splu_stage1_f32(U12.data_ptr(), x.data_ptr(), self.N, self.r, *self._w()), "splu stage1")
@@ -268,7 +344,7 @@ _splu_backends = {}
 def _splu_backend_for(L12):
     if not L12.is_cuda:
         raise _lib.PsgdHipError("sharded sparse LU runs on HIP devices only (tensor is on %s); no CPU fallback" % L12.device)
-    key = (L12.device.index, L12.shape[0], L12.shape[1])
+    key = (L12.device.index, L12.shape[0], L12.shape[1], torch.cuda.current_stream(L12.device).cuda_stream)
     if key not in _splu_backends:
         _splu_backends[key] = HipSpluStages(L12.device, L12.shape[0], L12.shape[1])
     return _splu_backends[key]
@@ -276,26 +352,24 @@ def _splu_backend_for(L12):
 
 def precond_grad_splu(L12, l3, U12, u3, grad, group=None, backend=None):
     """Sharded psgd.py:483-524.  `grad` is this rank's flat vector [r corner entries; local tail slice]; returns the
-    same layout (corner entries identical on every rank).  Exchanges: SUM of r fp64 twice."""
+    same layout (corner entries identical on every rank).  2 exchanges (r sums; 2r sums of which r are used)."""
     be = backend if backend is not None else _splu_backend_for(L12)
-    r = U12.shape[0]
     be.stage1(U12, grad)
-    dist.all_reduce(be.sums(1), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 1, group)
     be.apply_stage2(L12, l3, U12, u3, grad)
-    dist.all_reduce(be.sums(2)[:r], op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 2, group)
     return be.apply_stage3(L12, l3, U12, u3)
 
 
 def update_precond_splu(L12, l3, U12, u3, dx, dg, step=0.01, tiny=None, has_tail=True, group=None, backend=None):
     """Sharded psgd.py:396-480 on this rank's rows; returns this rank's (L12, l3, U12, u3) (corner blocks identical on
-    every rank).  Exchanges: SUM r, SUM 2r, SUM r + MAX 4 floats.  has_tail: the global problem has tail rows."""
+    every rank).  3 exchanges: r sums, 2r sums, [r sums | 4 maxima].  has_tail: the global problem has tail rows."""
     be = backend if backend is not None else _splu_backend_for(L12)
     tiny = _psgd._tiny if tiny is None else tiny
     be.stage1(U12, dg)
-    dist.all_reduce(be.sums(1), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 1, group)
     be.update_stage2(L12, l3, U12, u3, dx, dg)
-    dist.all_reduce(be.sums(2), op=dist.ReduceOp.SUM, group=group)
+    _exchange(be, 2, group)
     be.update_stage3(L12, l3, U12, u3, dx, dg)
-    dist.all_reduce(be.sums(3), op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(be.maxbuf(), op=dist.ReduceOp.MAX, group=group)
+    _exchange(be, 3, group)
     return be.update_stage4(L12, l3, U12, u3, dx, dg, step, tiny, has_tail)

@@ -10,7 +10,43 @@ import numpy as np
 import torch
 
 
-class NumpyStages:
+class _GatherFold:
+    """The exchange half of the stage interface (send / gather_buf / fold): every rank's fp64 send region is
+    all-gathered, then folded in rank order -- entries [0, nsum) by +, the rest by max (the product's
+    psgd_*_fold_gathered_f64).  Subclasses say how a stage's send region is laid out (_send_layout)."""
+
+    def send(self, stage):
+        sums, maxes = self._send_layout(stage)
+        parts = ([sums] if sums is not None else []) + ([maxes.to(torch.float64)] if maxes is not None else [])
+        return torch.cat(parts).contiguous()
+
+    def gather_buf(self, stage, world):
+        return torch.empty(world * self.send(stage).numel(), dtype=torch.float64)
+
+    def fold(self, stage, gathered, world):
+        sums, maxes = self._send_layout(stage)
+        nsum = sums.numel() if sums is not None else 0
+        g = gathered.view(world, -1)
+        acc = g[0].clone()
+        for k in range(1, world):                      # rank order
+            acc[:nsum] += g[k][:nsum]
+            acc[nsum:] = torch.maximum(acc[nsum:], g[k][nsum:])
+        if sums is not None:
+            sums[:] = acc[:nsum]
+        if maxes is not None:
+            maxes[:] = acc[nsum:].to(torch.float32)
+
+
+class NumpyStages(_GatherFold):
+    def _send_layout(self, stage):
+        if stage == 10:
+            return None, self._max[10]
+        if stage == 12:
+            return None, self._max[12]
+        if stage == 13:
+            return self._sums[13], self._max[12]       # [p | q | max] in one region
+        return self._sums[stage], None
+
     def __init__(self, r, dtype=np.float64):
         self.r = r
         self.dtype = dtype
@@ -125,10 +161,13 @@ class NumpyStages:
         dn -= mu * dn * self.nabla
 
 
-class NumpySpluStages:
+class NumpySpluStages(_GatherFold):
     """CPU stage backend for the sharded sparse LU (interface of psgd_tf_amd.sharded.HipSpluStages).  fp64 NumPy
     restatement of the staged plan of psgd_splu.hip: reductions over the tail rows -> r x r corner algebra ->
     row-local work; the test compares its sharded result with the reference-order oracle."""
+
+    def _send_layout(self, stage):
+        return (self._sums[3], self._max) if stage == 3 else (self._sums[stage], None)   # stage 3: [r sums | 4 maxima]
 
     def __init__(self, r):
         self.r = r

@@ -1,5 +1,6 @@
-"""GPU: bench.py's contract, run small.  N = 1 as the driver runs it, and the N = 2 code path (process group, barrier +
-synchronize bracket, MAX over ranks, one JSON line from rank 0) in its test mode with both ranks on the one GPU."""
+"""GPU: bench.py's contract, run small.  N = 1 as the driver runs it, and the N = 2 code path (self-launched ranks,
+process group, barrier + synchronize bracket, MAX over ranks, one JSON line from rank 0) in its test mode with both
+ranks on the one GPU."""
 import json
 import os
 import subprocess
@@ -29,17 +30,56 @@ def test_bench_single_gpu_line(hip_lib):
     assert d["metric"] == "uvd_update_apply_params_per_sec" and d["unit"] == "params/s" and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 4000000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
-    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    # the legs the north star names: apply alone and update alone with their own kernel times and non-null fractions,
+    # the fused step on bytes moved as well as on SURVEY's algorithmic bytes, and config 2 (N = 1M, r = 10)
+    paths = d["roofline"]["paths"]
+    for leg, kernels in (("apply", ("apply_s1", "apply_s2", "apply_s3")), ("update", ("update_s1", "update_s2", "update_s3"))):
+        assert paths[leg]["frac"] > 0 and paths[leg]["frac_moved"] > 0 and paths[leg]["wall_ms"] >= 0.9 * paths[leg]["kernel_ms"]
+        assert all(paths[leg]["kernels_ms"][k] > 0 for k in kernels)
+    assert paths["apply"]["alg_bytes_per_param"] == 340 and paths["apply"]["moved_bytes_per_param"] == 272
+    assert paths["update"]["alg_bytes_per_param"] == 440
+    assert paths["step"]["alg_bytes_per_param"] == 780 and paths["step"]["moved_bytes_per_param"] == 628
+    assert 0 < paths["step"]["frac_moved"] < paths["step"]["frac"]
+    c2 = d["config2_N1M_r10"]
+    assert c2["N"] == 1_000_000 and c2["r"] == 10 and c2["step_fused"]["wall_ms"] > 0 and c2["apply"]["wall_ms"] > 0
 
 
 @pytest.mark.timeout(600)
-def test_bench_two_ranks_code_path(hip_lib):
+def test_bench_two_ranks_self_launched(hip_lib):
+    """`python bench.py --gpus 2` from a plain shell (as the driver's scaling run starts it): the parent launches the two
+    ranks itself and relays rank 0's line.  Test mode: both ranks on the one GPU, gloo collectives."""
+    env = dict(os.environ, PSGD_BENCH_SINGLE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "4000000"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=580)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rows_global"] == 8000000
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["collective_backend"] == "gloo"
+    assert "TEST MODE" in d["config"]["parallelism"]
+    assert abs(d["value"] - 8000000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_under_torchrun(hip_lib):
+    """The same job started the other way the contract allows: as ranks of torch.distributed.run."""
     env = dict(os.environ, PSGD_BENCH_SINGLE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29523", "bench.py", "--gpus", "2", "--steps", "3",
                         "--warmup", "1", "--rows", "4000000"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=580)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rows_global"] == 8000000
-    assert "TEST MODE" in d["config"]["parallelism"]
-    assert abs(d["value"] - 8000000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["n_gpus"] == 2 and d["config"]["rows_global"] == 8000000
+
+
+@pytest.mark.timeout(600)
+def test_bench_one_rank_rccl_group(hip_lib):
+    """--force-sharded at world size 1: the multi-GPU code path (process group on RCCL, all-gathers, fold kernels)."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--rows", "4000000",
+                        "--force-sharded", "--no-kron", "--no-legs", "--no-cpu-baseline"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=580)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["collective_backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["value"] > 0

@@ -175,3 +175,25 @@ def test_committed_pmc_traffic_file_is_what_bench_reads():
     assert rec["rows"] == 100_000_000 and rec["r"] == 20
     alg = 4 * (3 * 20 + 5) * rec["rows"]                      # bytes the fused sweep moves: 260 B/row
     assert 0.98 * alg < rec["hbm_bytes_per_launch"] < 1.10 * alg
+
+
+@pytest.mark.parametrize("sl,sr,sx", [((5, 5), (3, 3), (3, 5)),      # wrong-orientation data matrix
+                                      ((4, 4), (3, 3), (5, 3)),      # left factor smaller than M
+                                      ((5, 5), (2, 3), (5, 4)),      # (dense, normalization) with a short right factor
+                                      ((1, 5), (3, 3), (4, 3)),      # (scaling, dense): 1 x M factor of the wrong length
+                                      ((2, 5), (1, 3), (5, 2))])
+def test_kron_factor_data_shape_mismatch_raises(sl, sr, sx):
+    """The reference's matmuls raise on mismatched shapes; the kernels take raw pointers, so the host checks (and does so
+    before anything device-side: CPU tensors are enough to see it)."""
+    import preconditioned_stochastic_gradient_descent as psgd
+    Ql, Qr, X = torch.ones(sl), torch.ones(sr), torch.ones(sx)
+    with pytest.raises(ValueError, match="do not match"):
+        psgd.precond_grad_kron(Ql, Qr, X)
+    with pytest.raises(ValueError, match="do not match"):
+        psgd.update_precond_kron(Ql, Qr, X, X, 0.01)
+
+
+def test_kron_dX_dG_shape_mismatch_raises():
+    import preconditioned_stochastic_gradient_descent as psgd
+    with pytest.raises(ValueError, match="share one shape"):
+        psgd.update_precond_kron(torch.eye(4), torch.eye(3), torch.ones(4, 3), torch.ones(3, 4), 0.01)

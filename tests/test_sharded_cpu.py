@@ -28,6 +28,15 @@ def _worker(rank, world, port, outdir):
     try:
         from psgd_tf_amd import sharded
         from tests.cpu_stages import NumpyStages
+        calls = {"all_gather_into_tensor": 0, "all_reduce": 0, "broadcast": 0}
+        for name in calls:                                  # count the collectives each sharded call issues
+            def wrap(fn, name=name):
+                def counted(*a, **k):
+                    calls[name] += 1
+                    return fn(*a, **k)
+                return counted
+            setattr(dist, name, wrap(getattr(dist, name)))
+        snap = lambda: dict(calls)
         p = make_uvd_problem(N, R, seed=21, uv_gain=2.0, d_spread=0.3)
         p["U"] *= 5.0
         lo, hi = sharded.shard_rows(N, rank, world)
@@ -38,17 +47,30 @@ def _worker(rank, world, port, outdir):
                                          update_U=True, backend=be)
         sharded.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY, balance=False,
                                          update_U=False, backend=be)
-        gen = torch.Generator().manual_seed(1234 + rank)          # different seeds: rank 0's draw must win
+        c_upd = snap()
+        assert c_upd == {"all_gather_into_tensor": 5, "all_reduce": 0, "broadcast": 0}, c_upd   # 3 (balance) + 2
+        gen = torch.Generator().manual_seed(1234 + rank)          # different seeds: rank 0's state must win
         sharded.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY, generator=gen,
                                          backend=be)
+        assert calls["broadcast"] == 1                            # the one-time generator synchronisation ...
+        gathers = calls["all_gather_into_tensor"]
         out = sharded.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"], backend=be)
+        assert calls["all_gather_into_tensor"] - gathers == 2 and calls["all_reduce"] == 0
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), U=t["U"].numpy(), V=t["V"].numpy(), d=t["d"].numpy(),
                  out=out.numpy(), lo=lo, hi=hi)
         # fused update -> apply (one V pass less): both branches, continuing from that state
         outs_f = []
         for upd in (True, False):
+            before = snap()
             outs_f.append(sharded.update_precond_UVd_math_and_precond_grad(
                 t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY, balance=False, update_U=upd, backend=be))
+            assert calls["all_gather_into_tensor"] - before["all_gather_into_tensor"] == 3      # Gram, [p|q|max], s2
+            assert calls["all_reduce"] == 0 and calls["broadcast"] == before["broadcast"]
+        # ... and later drawn calls with the same generator object exchange nothing for the branches
+        before = snap()
+        sharded.update_precond_UVd_math_(t["U"].clone(), t["V"].clone(), t["d"].clone(), t["v"], t["h"], 0.01, TINY,
+                                         generator=gen, backend=be)
+        assert calls["broadcast"] == before["broadcast"]
         np.savez(os.path.join(outdir, "fused%d.npz" % rank), U=t["U"].numpy(), V=t["V"].numpy(), d=t["d"].numpy(),
                  o0=outs_f[0].numpy(), o1=outs_f[1].numpy())
     finally:

@@ -50,7 +50,7 @@ def test_sharded_world1_equals_unsharded(pg, hip_lib, N, r):
     of_b = sharded.update_precond_UVd_math_and_precond_grad(b["U"], b["V"], b["d"], b["v"], b["h"], b["g"], 0.01,
                                                             TINY32, balance=False, update_U=True)
     assert torch.equal(of_a, of_b) and torch.equal(a["U"], b["U"]) and torch.equal(a["d"], b["d"])   # same kernels
-    # branch agreement path (rank 0 draws, broadcast) runs on the device
+    # branch agreement path (generator state synchronised from rank 0 once, local draws afterwards)
     gen = torch.Generator().manual_seed(3)
     sharded.update_precond_UVd_math_(b["U"], b["V"], b["d"], b["v"], b["h"], 0.01, TINY32, generator=gen)
     assert torch.isfinite(b["U"]).all() and torch.isfinite(b["d"]).all()
@@ -63,6 +63,15 @@ def _allreduce_emulated(views, op):
         acc = acc + v if op == "sum" else torch.maximum(acc, v)
     for v in views:
         v.copy_(acc)
+
+
+def _gather_fold_emulated(bes, stage):
+    """The product's exchange (sharded._exchange) across the stage backends of several shards living in ONE process:
+    what all_gather_into_tensor delivers is the concatenation of the send regions in rank order; every "rank" then
+    runs the product's fold kernel on it."""
+    gathered = torch.cat([be.send(stage) for be in bes]).contiguous()
+    for be in bes:
+        be.fold(stage, gathered, len(bes))
 
 
 @pytest.mark.parametrize("N,r,cuts", [(100003, 20, (0, 40000, 100003)), (5000, 7, (0, 1024, 1088, 5000))])
@@ -140,8 +149,7 @@ def test_splu_world1_and_real_shards(pg, hip_lib):
     _allreduce_emulated([be.sums(2) for be in bes], "sum")
     for be, s in zip(bes, sh):
         be.update_stage3(s["L12"], s["l3"], s["U12"], s["u3"], s["dx"], s["dg"])
-    _allreduce_emulated([be.sums(3) for be in bes], "sum")
-    _allreduce_emulated([be.maxbuf() for be in bes], "max")
+    _gather_fold_emulated(bes, 3)                          # [r sums | 4 maxima] in one exchange
     news = [be.update_stage4(s["L12"], s["l3"], s["U12"], s["u3"], s["dx"], s["dg"], 0.1, float(psgd._tiny), True)
             for be, s in zip(bes, sh)]
     assert torch.equal(news[0][0][:r], news[1][0][:r]) and torch.equal(news[0][2][:, :r], news[1][2][:, :r])
@@ -168,8 +176,9 @@ def test_splu_world1_and_real_shards(pg, hip_lib):
 
 @pytest.mark.parametrize("N,r,cuts", [(100003, 20, (0, 40000, 100003)), (300001, 10, (0, 64, 150016, 300001))])
 def test_uvd_fused_step_on_real_shards(hip_lib, N, r, cuts):
-    """The choreography bench.py runs at --gpus N > 1 (sharded.update_precond_UVd_math_and_precond_grad): Gram SUM,
-    max MAX + p,q SUM, s2 SUM -- on real shards in one process with hand-emulated collectives, both branches."""
+    """The choreography bench.py runs at --gpus N > 1 (sharded.update_precond_UVd_math_and_precond_grad): three
+    exchanges -- Gram, [p | q | max], s2 -- each an all-gather + the product's rank-order fold kernel, on real shards in
+    one process with the gather emulated by concatenation, both branches."""
     import preconditioned_stochastic_gradient_descent as psgd
     from psgd_tf_amd import sharded
     p = make_uvd_problem(N, r, seed=13, uv_gain=2.0, d_spread=0.3)
@@ -183,16 +192,16 @@ def test_uvd_fused_step_on_real_shards(hip_lib, N, r, cuts):
         orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=upd)
         for be, s in zip(bes, sh):
             be.update_sweep1(s["U"], s["V"], s["d"], s["v"], s["h"])
-        _allreduce_emulated([be.sums(11) for be in bes], "sum")
+        _gather_fold_emulated(bes, 11)
         for be, s in zip(bes, sh):
             be.update_sweep2_fused(s["U"], s["V"], s["d"], s["v"], s["h"], s["g"], 0.01, TINY32, upd)
-        _allreduce_emulated([be.maxbuf(12) for be in bes], "max")
-        _allreduce_emulated([be.sums(13) for be in bes], "sum")
+        _gather_fold_emulated(bes, 13)                     # [p | q | max] in one exchange
         for be, s in zip(bes, sh):
             be.update_sweep3(s["d"], 0.01, TINY32)
             be.fused_s1(0.01, TINY32)
             be.apply_sweep2_local_s1(s["U"], s["d"], s["g"])
-        _allreduce_emulated([be.sums(2) for be in bes], "sum")
+        _gather_fold_emulated(bes, 2)
+        assert all(torch.equal(bes[0].sums(2), be.sums(2)) for be in bes[1:])      # bit-identical on every "rank"
         out = torch.cat([be.apply_sweep3(s["U"], s["V"], s["d"], s["g"]) for be, s in zip(bes, sh)], 0)
         assert rel_err(out.cpu().numpy(), want.cpu().numpy()) < 2e-6, upd
         assert rel_err(out.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < 1e-5, upd
