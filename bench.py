@@ -12,7 +12,7 @@ N > 1 started from a plain shell launches its own ranks: the parent process (whi
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a child, relays
 rank 0's JSON line and exits with the child's code.  Started under torch.distributed.run (WORLD_SIZE set) it is
 one of the ranks.  N > 1 row-shards the flat parameter vector: every rank holds --rows rows (weak scaling,
-global N = rows * world); per step three tiny all-gathers (RCCL over xGMI) carry the r-dimensional reduced
+global N = rows * world); per step two tiny all-gathers (RCCL over xGMI) carry the r-dimensional reduced
 buffers -- never N-sized data (psgd_tf_amd/sharded.py).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
@@ -347,6 +347,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the apply-alone / update-alone / config-2 legs")
     ap.add_argument("--unfused", action="store_true",
                     help="time update_precond_UVd_math_ + precond_grad_UVd_math as two separate calls")
+    ap.add_argument("--bpc", type=int, default=0, help="experiment: cap on blocks per CU of the sweeps (psgd_set_tuning key 1)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU code path (process group + exchanges) even at world size 1")
     args = ap.parse_args()
@@ -381,6 +382,8 @@ def main():
     import preconditioned_stochastic_gradient_descent as psgd
     from psgd_tf_amd import _lib, sharded
     lib = _lib.load()            # fails loudly if the HIP extension is missing
+    if args.bpc:
+        lib.psgd_set_tuning(1, args.bpc)
 
     n_local, r = args.rows, args.rank_r
     n_global = n_local * world
@@ -461,7 +464,7 @@ def main():
                                    % ("" if args.unfused else ", fused call", n_local, r),
                        "rows_per_gpu": n_local, "rows_global": n_global, "rank_of_modification": r,
                        "parallelism": ("row-sharded x%d, per step %d all-gathers of r-dim reduced buffers (<= 30 KB) + "
-                                       "rank-order fold" % (world, 4 if args.unfused else 3)) +
+                                       "rank-order fold" % (world, 4 if args.unfused else 2)) +
                                       (" [TEST MODE: all ranks on one GPU, gloo -- not a measurement]" if single_dev else ""),
                        "collective_backend": backend, "rccl_ranks": (dist.get_world_size() if use_dist else 0),
                        "step": STEP, "branches": "balance=0, update_U alternating"},

@@ -71,13 +71,13 @@ int64_t psgd_uvd_workspace_bytes(int64_t N, int r);
  * `which` = PSGD_WS_SUMS_F64 / PSGD_WS_MAX_F32; `stage` selects what the next
  * stage consumes: apply: 1 (after sweep1: r sums), 2 (after sweep2: r sums);
  * update: 10 (balance maxima: 2 floats), 11 (after sweep1: Gram sums),
- * 12 (after sweep2: 1 float max), 13 (after the fused sweep2: 2r sums p,q).
+ * 12 (after sweep2: 1 float max), 13 (after the fused sweep2: the 4r sums [pU | pV | qU | qV]).
  * Returns 0 or an error code.                                                */
 int psgd_uvd_ws_region(int which, int stage, int64_t N, int r,
                        int64_t *offset_bytes, int64_t *count);
 /* Protocol (a): PSGD_WS_SEND_F64 regions exist for stages 1, 2, 11 (sums), 10 (2 maxima), 12 (1 maximum) and
- * 13 ([p | q | max]: the 2r sums and the maximum of the fused sweep 2 in ONE region, so the fused step needs three
- * exchanges: 11, 13, 2).  `gathered` = the all-gathered regions, [world][count] doubles in rank order (device).   */
+ * 13 ([pU | pV | qU | qV | max]: the 4r sums and the maximum of the fused sweep 2 in ONE region, so the fused step
+ * needs two exchanges: 11, 13).  `gathered` = the all-gathered regions, [world][count] doubles in rank order (device).   */
 int psgd_uvd_fold_gathered_f64(int stage, const double *gathered, int world, int64_t N, int r,
                                void *ws, int64_t ws_bytes, void *stream);
 
@@ -128,12 +128,15 @@ int psgd_uvd_update_sweep3_f32(float *d, int64_t N, int r, float step,
                                float tiny, void *ws, int64_t ws_bytes,
                                void *stream);
 
-/* Fused update -> apply (the UVd.step call pattern, psgd.py:732 -> :748).
- * Same results as psgd_uvd_update_f32 followed by psgd_uvd_apply_f32 on the updated state, with one
- * pass over V removed: update sweep 2 also reduces p = Vnew'(d.*g) and q = Vnew'(d.*g.*nablaD), and the
- * apply's first reduction is s1 = p - mu q (dnew = d - mu d.*nablaD, psgd.py:584).
- * Multi-GPU stages: ... update_sweep1 -> SUM(11) -> update_sweep2_fused -> MAX(12), SUM(13: 2r sums) ->
- * update_sweep3 -> fused_s1 -> apply_sweep2(sums_reduced = 0) -> SUM(2) -> apply_sweep3(sums_reduced = 1). */
+/* Fused update -> apply (the UVd.step call pattern, psgd.py:732 -> :748): THREE sweeps for both calls.
+ * Same U, V, d as psgd_uvd_update_f32; `out` = precond_grad_UVd_math on the updated state.  Update sweep 2 also
+ * reduces the four r-vectors [Unew | Vnew]' [d.*g, d.*g.*nablaD] (on the matrix core).  With dnew = d - mu_d d.*nablaD
+ * (psgd.py:584) both reductions of the apply follow from them and from the Gram of sweep 1:
+ *     s1' = Vnew'(dnew.*g) = pV - mu_d qV,      s2' = Unew'(dnew.*g + Unew s1') = pU - mu_d qU + (Unew'Unew) s1'
+ * (Unew'Unew = U'U plus a rank-2 correction known from the r x r algebra), so the d update and the whole apply are
+ * ONE last sweep: out = dnew .* (dnew.*g + Unew s1' + Vnew s2').  628 -> 544 bytes per parameter at r = 20.
+ * Multi-GPU stages: [balance] -> update_sweep1 -> X(11) -> update_sweep2_fused -> X(13: 4r sums | max) ->
+ * fused_post -> fused_final: two exchanges per step. */
 int psgd_uvd_update_apply_f32(float *U, float *V, float *d, const float *v, const float *h,
                               const float *g, float *out, int64_t N, int r, float step, float tiny,
                               int balance, int update_U, void *ws, int64_t ws_bytes, void *stream);
@@ -141,8 +144,11 @@ int psgd_uvd_update_sweep2_fused_f32(float *U, float *V, const float *d, const f
                                      const float *h, const float *g, int64_t N, int r, float step,
                                      float tiny, int update_U, void *ws, int64_t ws_bytes,
                                      void *stream);
-int psgd_uvd_fused_s1_f32(int64_t N, int r, float step, float tiny, void *ws, int64_t ws_bytes,
-                          void *stream);
+int psgd_uvd_fused_post_f32(int64_t N, int r, float step, float tiny, int update_U, void *ws,
+                            int64_t ws_bytes, void *stream);
+int psgd_uvd_fused_final_f32(const float *U, const float *V, float *d, const float *g, float *out,
+                             int64_t N, int r, float step, float tiny, void *ws, int64_t ws_bytes,
+                             void *stream);
 
 /* IpUVtmatvec(U, V, x)   psgd.py:540-544:  out = x + U (V' x), x is [N].   */
 int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,
@@ -152,7 +158,8 @@ int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,
 /* Tuning knobs for experiments (not part of the stable ABI).
  * key 0: streaming policy (0 = automatic: non-temporal when U,V exceed the Infinity Cache,
  *        1 = never non-temporal, 2 = always non-temporal).
- * key 1: cap on blocks per CU for the sweeps (0 = occupancy query).        */
+ * key 1: cap on blocks per CU for the sweeps (0 = occupancy query).
+ * key 2: r x r algebra of the update: 0 (default) one-row-per-lane register kernel, 1 = block-cooperative reference. */
 int psgd_set_tuning(int key, int value);
 
 /* Live kernel timing for bench.py (measurement aid, not part of the reference's surface).

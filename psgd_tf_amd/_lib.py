@@ -50,7 +50,8 @@ SIGNATURES = {
                                    _c_ws, _i64, _strm]),
     "psgd_uvd_update_apply_f32": (_int, [_c_f32p] * 7 + [_i64, _int, _flt, _flt, _int, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_update_sweep2_fused_f32": (_int, [_c_f32p] * 6 + [_i64, _int, _flt, _flt, _int, _c_ws, _i64, _strm]),
-    "psgd_uvd_fused_s1_f32": (_int, [_i64, _int, _flt, _flt, _c_ws, _i64, _strm]),
+    "psgd_uvd_fused_post_f32": (_int, [_i64, _int, _flt, _flt, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_fused_final_f32": (_int, [_c_f32p] * 5 + [_i64, _int, _flt, _flt, _c_ws, _i64, _strm]),
     "psgd_uvd_balance_max_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_balance_scale_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_update_sweep1_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64,

@@ -25,9 +25,10 @@ const UvdOps* uvd_ops_for_rank(int r) {
 
 // ------------------------------------------------------------ workspace ----
 constexpr int64_t kSumsCap = 4096;   // doubles (Gram of r = 32 needs 3840)
-constexpr int kPqSumsOff = 3840;      // the fused p,q sums (2r <= 64 doubles) live above the largest Gram; the fp64 copy of
-                                      // max|nablaD| follows them at [kPqSumsOff + 2r] (one contiguous send region [p | q | max])
+constexpr int kPqSumsOff = 3840;      // the fused sums [pU | pV | qU | qV] (4r <= 128 doubles) live above the largest Gram; the
+                                      // fp64 copy of max|nablaD| follows them at [kPqSumsOff + 4r] (one contiguous send region)
 constexpr int kBalD64Off = 4000;      // fp64 copies of the two balance maxima (send region of stage 10)
+constexpr int kPostSumsOff = 4016;    // fp64 s1', s2' of the fused step (2r <= 64 doubles; diagnostics)
 constexpr int64_t kCoefCap = 256;    // floats
 constexpr int64_t kMaxCap = 64;      // floats
 
@@ -255,60 +256,38 @@ __global__ void k_publish(const double* __restrict__ sums, float* __restrict__ c
   if (i < n) coef[i] = (float)sums[i];
 }
 
-// s1 = p - mu q with p = Vnew'(d.*g), q = Vnew'(d.*g.*nablaD), mu = step / (max|nablaD| + tiny): the first
-// reduction of the apply that follows an update (see k_update_s2 FUSE).  Writes the apply's s1 slots.
-__global__ void k_fused_s1(const double* __restrict__ pq, const float* __restrict__ maxbuf, float step, float tiny, int r,
-                           double* __restrict__ s1_sums, float* __restrict__ s1_coef) {
-  const int c = threadIdx.x;
-  if (c >= r) return;
-  const double mu = (double)(step / (maxbuf[0] + tiny));
-  const double s = pq[c] - mu * pq[r + c];
-  s1_sums[c] = s;
-  s1_coef[c] = (float)s;
-}
-
-// Single-GPU fused step: everything between update sweep 2 and the d update in ONE launch (k_reduce_max +
-// k_reduce_sum_t + k_fused_s1 of the staged path).  One wave per element c < r: it reduces the block maxima of
-// |nablaD| (every wave redundantly: G <= 2048 floats), the partial sums p_c, q_c in fp64, and publishes
-// s1_c = p_c - mu q_c; wave 0 also publishes the maximum for k_update_d.  Same arithmetic and order as the
-// staged kernels, so the two paths agree bit for bit.
-__global__ __launch_bounds__(kThreads) void k_post_s2_fused(const float* __restrict__ part, const float* __restrict__ pmax,
-                                                            int G, int r, float step, float tiny,
-                                                            double* __restrict__ pq_sums, float* __restrict__ maxout,
-                                                            double* __restrict__ s1_sums, float* __restrict__ s1_coef) {
+// Reduction behind the fused sweep 2: sums[e] = sum_b part[e * G + b] for the 4r column sums of ColSum2 (transposed fp64
+// partials: one wave per element, every lane issues its <= 32 loads before summing; fp64 shuffle tree, fixed order),
+// and max|nablaD| over the block maxima (wave 0 of block 0), as float and as the double that ends the send region.
+__global__ __launch_bounds__(kThreads) void k_reduce_pq(const double* __restrict__ part, const float* __restrict__ pmax,
+                                                        int G, int L, double* __restrict__ sums,
+                                                        float* __restrict__ maxout) {
   const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (c >= r) return;
-  float m = 0.0f;
-  for (int b = lane; b < G; b += 64) m = fmaxf(m, pmax[b]);
+  const int id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (id == 0) {
+    float m = 0.0f;
+    for (int b = lane; b < G; b += 64) m = fmaxf(m, pmax[b]);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  double pq[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const float* p = part + (long)(k * r + c) * G;
-    float x[kMaxGrid / 64];
-#pragma unroll
-    for (int u = 0; u < kMaxGrid / 64; ++u) {
-      const int b = lane + 64 * u;
-      x[u] = (b < G) ? p[b] : 0.0f;
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) {
+      *maxout = m;
+      sums[L] = (double)m;
     }
-    double s = 0.0;
-#pragma unroll
-    for (int u = 0; u < kMaxGrid / 64; ++u) s += (double)x[u];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    pq[k] = s;
   }
-  if (lane == 0) {
-    const double mu = (double)(step / (m + tiny));
-    const double s1 = pq[0] - mu * pq[1];
-    pq_sums[c] = pq[0];
-    pq_sums[r + c] = pq[1];
-    s1_sums[c] = s1;
-    s1_coef[c] = (float)s1;
-    if (c == 0) *maxout = m;
+  if (id >= L) return;
+  const double* p = part + (long)id * G;
+  double x[kMaxGrid / 64];
+#pragma unroll
+  for (int u = 0; u < kMaxGrid / 64; ++u) {
+    const int b = lane + 64 * u;
+    x[u] = (b < G) ? p[b] : 0.0;
   }
+  double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < kMaxGrid / 64; ++u) s += x[u];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) sums[id] = s;
 }
 
 // d <- d - (mu d) nablaD, mu = step / (max|nablaD| + tiny)      psgd.py:582-584
@@ -576,6 +555,287 @@ __global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restri
   }
 }
 
+// ---- the same r x r algebra, latency-oriented (what the entry points launch; k_update_coef above stays as the
+// reference form, psgd_set_tuning key 2).  The block-cooperative elimination above pays three workgroup barriers per
+// pivot and a shuffle tree per inner product: 16 us at r = 10, 30 us at r = 20 -- on the critical path between the
+// two update sweeps, and a fifth of a whole step at N = 1M.  Here the augmented matrix lives ONE ROW PER LANE in
+// registers (r <= 32 rows, the loops unrolled to RG = r rounded up to 8 with identity padding): a pivot is a DPP
+// maximum + ballot, the row exchange and the pivot-row broadcast are v_readlane, an elimination step is one fp64 fma
+// per column per lane, and nothing synchronises.  Element by element the arithmetic is the same as lu_solve_block's.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// Solves M x = rhs; lane i < r holds row i of M in a[0..RG) (columns >= r: 0) and rhs_i in a[RG]; returns x_i in lane i.
+template <int RG>
+__device__ __forceinline__ double lu_solve_rows(double (&a)[RG + 1], int r, int lane) {
+#pragma unroll
+  for (int k = 0; k < RG; ++k) {
+    if (k < r) {
+      const bool cand = lane >= k && lane < r;
+      const unsigned key = cand ? __float_as_uint(fabsf((float)a[k])) : 0u;
+      const unsigned kmax = wave32_umax(key);
+      const unsigned long long hit = __ballot(cand && key == kmax);
+      const int piv = __builtin_amdgcn_readfirstlane(hit ? (int)(__ffsll((long long)hit) - 1) : k);
+      double f = 0.0;
+#pragma unroll
+      for (int j = k; j <= RG; ++j) {
+        const double pj = readlane_f64(a[j], piv);        // pivot row, column j
+        const double kj = readlane_f64(a[j], k);
+        if (lane == k) a[j] = pj; else if (lane == piv) a[j] = kj;
+        if (j == k) f = a[k] * fast_rcp(pj);               // multiplier of this lane's row (rows > k use it)
+        else if (lane > k) a[j] -= f * pj;
+      }
+    }
+  }
+  double x = 0.0;
+#pragma unroll
+  for (int k = RG - 1; k >= 0; --k) {
+    if (k < r) {
+      const double xk = readlane_f64(a[RG], k) * fast_rcp(readlane_f64(a[k], k));
+      if (lane < k) a[RG] -= a[k] * xk;
+      if (lane == k) x = xk;
+    }
+  }
+  return x;
+}
+
+struct CoefLds {
+  double A[MR][MR + 1];     // U'U
+  double B[MR][MR + 1];     // V'V
+  double Cm[MR][MR + 1];    // V'U  (psgd.py:574)
+  double v[6][MR + 1];      // broadcast vectors: s1, x1, e1, e2 + scratch
+  double q[10][MR + 1];     // per-lane products whose sums over the lanes are needed
+  double qs[10];
+};
+
+// sums over lanes 0..r-1 of NQ per-lane values: every value goes to LDS, lane q adds up row q sequentially
+// (NQ lanes work side by side), the totals come back to all lanes.
+template <int NQ>
+__device__ __forceinline__ void lane_sums(double (&val)[NQ], int r, int tid, CoefLds& L) {
+  if (tid < r) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) L.q[q][tid] = val[q];
+  }
+  __syncthreads();
+  if (tid < NQ) {
+    double s = 0.0;
+    for (int k = 0; k < r; ++k) s += L.q[tid][k];
+    L.qs[tid] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) val[q] = L.qs[q];
+  __syncthreads();
+}
+
+// Whole block executes this (only lanes tid < r of wave 0 carry rows; the other waves idle through the barriers).
+template <int RG>
+__device__ void coef_block(const double* __restrict__ gram, int r, float step, float tiny, int update_U,
+                           float* __restrict__ coef, CoefLds& L) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool act = tid < r;
+  const int nb = (2 * r + 2 + 15) / 16;
+  auto G = [&](int a, int b) -> double {
+    if (a > b) { const int t = a; a = b; b = t; }
+    const int bi = a >> 4, bj = b >> 4, i = a & 15, j = b & 15;
+    const int p = bi * nb - (bi * (bi - 1)) / 2 + (bj - bi);
+    return gram[p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j)];
+  };
+  for (int idx = tid; idx < r * r; idx += blockDim.x) {
+    const int i = idx / r, j = idx % r;
+    L.A[i][j] = G(i, j);
+    L.B[i][j] = G(r + i, r + j);
+    L.Cm[i][j] = G(j, r + i);
+  }
+  double ut = 0.0, uw = 0.0, vt = 0.0, vw = 0.0;
+  if (act) {
+    ut = G(tid, 2 * r); uw = G(tid, 2 * r + 1); vt = G(r + tid, 2 * r); vw = G(r + tid, 2 * r + 1);
+    L.v[0][tid] = vt;                                      // s1 = V't
+  }
+  const double tt = G(2 * r, 2 * r), tw = G(2 * r, 2 * r + 1), ww = G(2 * r + 1, 2 * r + 1);
+  __syncthreads();
+  // s2 = U'Qh = U't + (U'U) s1 ; cs1 = (V'U) s1
+  const double s1 = vt;
+  double s2 = ut, cs1 = 0.0;
+  double a[RG + 1];
+  if (act) {
+    for (int k = 0; k < r; ++k) { s2 += L.A[tid][k] * L.v[0][k]; cs1 += L.Cm[tid][k] * L.v[0][k]; }
+  }
+  // x1 = solve(K', U'w), K = I + V'U            (psgd.py:575-577, adjoint=True)
+#pragma unroll
+  for (int j = 0; j < RG; ++j) a[j] = (act && j < r) ? L.Cm[j][tid] + (j == tid ? 1.0 : 0.0) : ((j == lane) ? 1.0 : 0.0);
+  a[RG] = act ? uw : 0.0;
+  const double x1 = lu_solve_rows<RG>(a, r, lane);
+  if (act) L.v[1][tid] = x1;
+  __syncthreads();
+  // p2 = V' invQtv = V'w - (V'V) x1 ; x2 = solve(K, p2)          (psgd.py:578)
+  double p2 = vw;
+  if (act) {
+    for (int k = 0; k < r; ++k) p2 -= L.B[tid][k] * L.v[1][k];
+  }
+#pragma unroll
+  for (int j = 0; j < RG; ++j) a[j] = (act && j < r) ? L.Cm[tid][j] + (j == tid ? 1.0 : 0.0) : ((j == lane) ? 1.0 : 0.0);
+  a[RG] = act ? p2 : 0.0;
+  const double x2 = lu_solve_rows<RG>(a, r, lane);
+  // a = Qh = t + U s1, b = invQtv = w - V x1                      (psgd.py:587)
+  double d7[7] = {s1 * ut, s1 * s2, x1 * vw, x1 * p2, x1 * vt, s1 * uw, x1 * cs1};
+  lane_sums<7>(d7, r, tid, L);
+  const double aa = tt + d7[0] + d7[1];          // a'a = t't + 2 s1'U't + s1'(U'U)s1
+  const double bb = ww - d7[2] - d7[3];          // b'b = w'w - 2 x1'V'w + x1'(V'V)x1
+  const double ab = tw - d7[4] + d7[5] - d7[6];  // a'b
+  // e1 = a'M, e2 = b'M with M = V (update U) or U (update V); the norm needs ||M e1'||^2 = e1 (M'M) e1' etc.
+  double e1 = 0.0, e2 = 0.0;                     //                      (psgd.py:589-596 / :603-610)
+  if (act) {
+    if (update_U) {
+      e1 = vt + cs1;                              // atV = V't + (V'U) s1
+      e2 = p2;                                    // btV = V'w - (V'V) x1
+    } else {
+      double c = uw;
+      for (int k = 0; k < r; ++k) c -= L.Cm[k][tid] * L.v[1][k];
+      e1 = s2;                                    // atU = U't + (U'U) s1
+      e2 = c;                                     // btU = U'w - (U'V) x1
+    }
+    L.v[2][tid] = e1;
+    L.v[3][tid] = e2;
+  }
+  __syncthreads();
+  double g1 = 0.0, g2 = 0.0;
+  if (act) {
+    for (int k = 0; k < r; ++k) {
+      const double m = update_U ? L.B[tid][k] : L.A[tid][k];
+      g1 += m * L.v[2][k];
+      g2 += m * L.v[3][k];
+    }
+  }
+  double d3[3] = {e1 * g1, e2 * g2, e1 * g2};
+  lane_sums<3>(d3, r, tid, L);
+  const double nrm = sqrt(fabs(aa * d3[0] + bb * d3[1] - 2.0 * ab * d3[2]));
+  const double mu = (double)step / (nrm + (double)tiny);
+  // c1, c2: update U -> (atV K), (btV K) (psgd.py:600-601); update V -> atU, btU (:614-615)
+  if (act) {
+    double c1 = e1, c2 = e2;
+    if (update_U) {                        // + e K's off-identity part
+      for (int i = 0; i < r; ++i) { c1 += L.v[2][i] * L.Cm[i][tid]; c2 += L.v[3][i] * L.Cm[i][tid]; }
+    }
+    coef[0 * r + tid] = (float)s1;
+    coef[1 * r + tid] = (float)s2;
+    coef[2 * r + tid] = (float)x1;
+    coef[3 * r + tid] = (float)x2;
+    coef[4 * r + tid] = (float)c1;
+    coef[5 * r + tid] = (float)c2;
+  }
+  if (tid == 0) {
+    coef[6 * r] = (float)mu;
+    coef[6 * r + 1] = (float)nrm;
+  }
+}
+
+template <int RG>
+__global__ __launch_bounds__(64) void k_coef_fast(const double* __restrict__ gram, int r, float step, float tiny,
+                                                  int update_U, float* __restrict__ coef) {
+  __shared__ CoefLds L;
+  coef_block<RG>(gram, r, step, tiny, update_U, coef, L);
+}
+
+static int g_tune_coef = 0;      // psgd_set_tuning key 2: 1 = the block-cooperative reference kernel
+
+static int launch_coef(hipStream_t st, const double* gram, int r, float step, float tiny, int update_U, float* coef) {
+  if (g_tune_coef == 1) {
+    hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(kThreads), 0, st, gram, r, step, tiny, update_U, coef);
+  } else if (r <= 8) {
+    hipLaunchKernelGGL(k_coef_fast<8>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef);
+  } else if (r <= 16) {
+    hipLaunchKernelGGL(k_coef_fast<16>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef);
+  } else if (r <= 24) {
+    hipLaunchKernelGGL(k_coef_fast<24>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef);
+  } else {
+    hipLaunchKernelGGL(k_coef_fast<32>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef);
+  }
+  return (int)hipGetLastError();
+}
+
+// The r x r algebra between the fused sweep 2 and the last sweep (one block, fp64).  Inputs: the reduced Gram of sweep 1
+// (U'U, V'U, V'V, U't, ...), the coefficient block sweep 2 used (s1, x1, c1, c2, mu as the floats the kernel multiplied
+// with), the reduced sums pq = [pU | pV | qU | qV] = [Unew | Vnew]' [d.*g, d.*g.*nablaD] and max|nablaD|.  Output: the
+// two r-vectors of the apply on the UPDATED state (psgd.py:625-626 after :584, :600 / :614):
+//   s1' = Vnew'(dnew.*g) = pV - mu_d qV
+//   s2' = Unew'(dnew.*g + Unew s1') = (pU - mu_d qU) + (Unew'Unew) s1'
+// Unew = U - mu (a c1' - b c2') when U was updated (psgd.py:600-601), so with Ua = U'a = U't + (U'U) s1 and
+// Ub = U'b = U'w - (U'V) x1:
+//   Unew'Unew = U'U - mu (Ua c1' + c1 Ua' - Ub c2' - c2 Ub') + mu^2 (a'a c1 c1' - a'b (c1 c2' + c2 c1') + b'b c2 c2')
+// and Unew'Unew = U'U when V was updated.  Writes coef[0, r) = s1', coef[r, 2r) = s2' (+ the fp64 values to sums).
+__global__ __launch_bounds__(kThreads) void k_fused_post(const double* __restrict__ gram, const double* __restrict__ pq,
+                                                         const float* __restrict__ maxbuf, int r, float step, float tiny,
+                                                         int update_U, float* coef, double* s_out) {
+  __shared__ double A[MR][MR + 1];    // U'U, then Unew'Unew
+  __shared__ double s1c[MR], x1c[MR], c1[MR], c2[MR], Ua[MR], Ub[MR], s1n[MR];
+  __shared__ double sc[3];
+  const int tid = threadIdx.x;
+  const int nb = (2 * r + 2 + 15) / 16;
+  auto G = [&](int a, int b) -> double {
+    if (a > b) { const int t = a; a = b; b = t; }
+    const int bi = a >> 4, bj = b >> 4, i = a & 15, j = b & 15;
+    const int p = bi * nb - (bi * (bi - 1)) / 2 + (bj - bi);
+    return gram[p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j)];
+  };
+  for (int idx = tid; idx < r * r; idx += kThreads) A[idx / r][idx % r] = G(idx / r, idx % r);
+  if (tid < r) {
+    s1c[tid] = (double)coef[0 * r + tid];
+    x1c[tid] = (double)coef[2 * r + tid];
+    c1[tid] = (double)coef[4 * r + tid];
+    c2[tid] = (double)coef[5 * r + tid];
+  }
+  const double mu = (double)coef[6 * r];
+  const double mud = (double)(step / (maxbuf[0] + tiny));          // the float expression of k_update_d / k_uvd_final
+  __syncthreads();
+  if (update_U) {
+    if (tid < r) {
+      double a = G(tid, 2 * r), b = G(tid, 2 * r + 1);                // U't, U'w
+      for (int k = 0; k < r; ++k) {
+        a += A[tid][k] * s1c[k];
+        b -= G(tid, r + k) * x1c[k];                                  // (U'V)[tid][k] = (V'U)[k][tid]
+      }
+      Ua[tid] = a;
+      Ub[tid] = b;
+    }
+    if (tid == 64) {            // a'a, a'b, b'b with the float coefficients the sweep used
+      double aa = G(2 * r, 2 * r), bb = G(2 * r + 1, 2 * r + 1), ab = G(2 * r, 2 * r + 1);
+      for (int i = 0; i < r; ++i) {
+        double As = 0.0, Bx = 0.0, Cs = 0.0;
+        for (int k = 0; k < r; ++k) {
+          As += A[i][k] * s1c[k];
+          Bx += G(r + i, r + k) * x1c[k];
+          Cs += G(k, r + i) * s1c[k];                                 // (V'U)[i][k] s1[k]
+        }
+        aa += s1c[i] * (2.0 * G(i, 2 * r) + As);
+        bb += x1c[i] * (-2.0 * G(r + i, 2 * r + 1) + Bx);
+        ab += s1c[i] * G(i, 2 * r + 1) - x1c[i] * (G(r + i, 2 * r) + Cs);
+      }
+      sc[0] = aa; sc[1] = ab; sc[2] = bb;
+    }
+    __syncthreads();
+    const double aa = sc[0], ab = sc[1], bb = sc[2];
+    for (int idx = tid; idx < r * r; idx += kThreads) {
+      const int i = idx / r, j = idx % r;
+      A[i][j] += -mu * (Ua[i] * c1[j] + c1[i] * Ua[j] - Ub[i] * c2[j] - c2[i] * Ub[j]) +
+                 mu * mu * (aa * c1[i] * c1[j] - ab * (c1[i] * c2[j] + c2[i] * c1[j]) + bb * c2[i] * c2[j]);
+    }
+  }
+  if (tid < r) s1n[tid] = pq[r + tid] - mud * pq[3 * r + tid];       // pV - mu_d qV
+  __syncthreads();
+  if (tid < r) {
+    double s2 = pq[tid] - mud * pq[2 * r + tid];                      // pU - mu_d qU
+    for (int k = 0; k < r; ++k) s2 += A[tid][k] * s1n[k];
+    coef[tid] = (float)s1n[tid];
+    coef[r + tid] = (float)s2;
+    s_out[tid] = s1n[tid];
+    s_out[r + tid] = s2;
+  }
+}
+
 }  // namespace psgd
 
 // ================================================================== C ABI ===
@@ -609,6 +869,7 @@ const char* psgd_error_string(int code) {
 int psgd_set_tuning(int key, int value) {
   if (key == 0) { g_tune_staging = value; return PSGD_OK; }
   if (key == 1) { g_tune_blocks_per_cu = value; return PSGD_OK; }
+  if (key == 2) { g_tune_coef = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -650,15 +911,15 @@ int psgd_uvd_ws_region(int which, int stage, int64_t N, int r, int64_t* offset_b
     if (stage == 1) { *offset_bytes = L.sums_off; *count = r; return PSGD_OK; }
     if (stage == 2) { *offset_bytes = L.sums_off + (int64_t)r * 8; *count = r; return PSGD_OK; }
     if (stage == 11) { *offset_bytes = L.sums_off; *count = (int64_t)np * 256; return PSGD_OK; }
-    if (stage == 13) { *offset_bytes = L.sums_off + (int64_t)kPqSumsOff * 8; *count = 2 * r; return PSGD_OK; }
+    if (stage == 13) { *offset_bytes = L.sums_off + (int64_t)kPqSumsOff * 8; *count = 4 * r; return PSGD_OK; }
   } else if (which == PSGD_WS_MAX_F32) {
     if (stage == 10) { *offset_bytes = L.max_off; *count = 2; return PSGD_OK; }
     if (stage == 12) { *offset_bytes = L.max_off + 8; *count = 1; return PSGD_OK; }
   } else if (which == PSGD_WS_SEND_F64) {
     if (stage == 1 || stage == 2 || stage == 11) return psgd_uvd_ws_region(PSGD_WS_SUMS_F64, stage, N, r, offset_bytes, count);
     if (stage == 10) { *offset_bytes = L.sums_off + (int64_t)kBalD64Off * 8; *count = 2; return PSGD_OK; }
-    if (stage == 12) { *offset_bytes = L.sums_off + (int64_t)(kPqSumsOff + 2 * r) * 8; *count = 1; return PSGD_OK; }
-    if (stage == 13) { *offset_bytes = L.sums_off + (int64_t)kPqSumsOff * 8; *count = 2 * r + 1; return PSGD_OK; }
+    if (stage == 12) { *offset_bytes = L.sums_off + (int64_t)(kPqSumsOff + 4 * r) * 8; *count = 1; return PSGD_OK; }
+    if (stage == 13) { *offset_bytes = L.sums_off + (int64_t)kPqSumsOff * 8; *count = 4 * r + 1; return PSGD_OK; }
   }
   return PSGD_ERR_BAD_ARG;
 }
@@ -677,7 +938,7 @@ int psgd_uvd_fold_gathered_f64(int stage, const double* gathered, int world, int
   float* maxdst = nullptr;
   if (stage == 10) { nsum = 0; maxdst = w.maxbuf; }
   else if (stage == 12) { nsum = 0; maxdst = w.maxbuf + 2; }
-  else if (stage == 13) { nsum = 2 * r; maxdst = w.maxbuf + 2; }
+  else if (stage == 13) { nsum = 4 * r; maxdst = w.maxbuf + 2; }
   hipLaunchKernelGGL(k_fold_gathered, dim3(((int)count + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                      gathered, world, (int)count, nsum, dst, maxdst);
   PSGD_CHECK_LAUNCH(last_launch());
@@ -848,7 +1109,7 @@ int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, c
 
 static int update_sweep2_impl(float* U, float* V, const float* d, const float* v, const float* h, const float* g,
                               int64_t N, int r, float step, float tiny, int update_U, void* ws, int64_t ws_bytes,
-                              void* stream, bool one_launch_tail = false) {
+                              void* stream) {
   if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
@@ -857,28 +1118,22 @@ static int update_sweep2_impl(float* U, float* V, const float* d, const float* v
   const UvdOps* ops = uvd_ops_for_rank(r);
   if (!ops) return PSGD_ERR_RANK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(kThreads), 0, st, w.sums, r, step, tiny, update_U, w.coef);
-  PSGD_CHECK_LAUNCH(last_launch());
+  PSGD_CHECK_LAUNCH(launch_coef(st, w.sums, r, step, tiny, update_U, w.coef));
   const int grid = sweep_grid(ops, r, g ? kOccUpdS2F : (update_U ? kOccUpdS2U : kOccUpdS2V), N, kMaxGrid);
-  float* part = static_cast<float*>(w.part);
+  double* part = static_cast<double*>(w.part);
   {
     ProfScope ps(PSGD_PROF_UPDATE_S2, st);
     PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, g, N, w.coef, w.nabla, w.pmax, part, grid, st));
   }
-  if (one_launch_tail && g) {
-    hipLaunchKernelGGL(k_post_s2_fused, dim3((r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
-                       w.pmax, grid, r, step, tiny, w.sums + kPqSumsOff, w.maxbuf + 2, w.sums, w.coef);
+  if (g) {      // block maxima -> max|nablaD|, column-sum partials -> [pU | pV | qU | qV]: one launch, one send region
+    hipLaunchKernelGGL(k_reduce_pq, dim3((4 * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
+                       w.pmax, grid, 4 * r, w.sums + kPqSumsOff, w.maxbuf + 2);
     PSGD_CHECK_LAUNCH(last_launch());
     return PSGD_OK;
   }
   hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kThreads), 0, st, w.pmax, grid, grid, w.maxbuf + 2,
-                     w.sums + kPqSumsOff + 2 * r);
+                     w.sums + kPqSumsOff + 4 * r);
   PSGD_CHECK_LAUNCH(last_launch());
-  if (g) {
-    hipLaunchKernelGGL(k_reduce_sum_t, dim3((2 * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
-                       grid, 2 * r, w.sums + kPqSumsOff, static_cast<float*>(nullptr));
-    PSGD_CHECK_LAUNCH(last_launch());
-  }
   return PSGD_OK;
 }
 
@@ -894,14 +1149,33 @@ int psgd_uvd_update_sweep2_fused_f32(float* U, float* V, const float* d, const f
   return update_sweep2_impl(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream);
 }
 
-int psgd_uvd_fused_s1_f32(int64_t N, int r, float step, float tiny, void* ws, int64_t ws_bytes, void* stream) {
+int psgd_uvd_fused_post_f32(int64_t N, int r, float step, float tiny, int update_U, void* ws, int64_t ws_bytes,
+                            void* stream) {
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_fused_s1, dim3(1), dim3(64), 0, st, w.sums + kPqSumsOff, w.maxbuf + 2, step, tiny, r, w.sums,
-                     w.coef);
+  hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(kThreads), 0, st, w.sums, w.sums + kPqSumsOff, w.maxbuf + 2, r, step,
+                     tiny, update_U, w.coef, w.sums + kPostSumsOff);
   PSGD_CHECK_LAUNCH(last_launch());
+  return PSGD_OK;
+}
+
+int psgd_uvd_fused_final_f32(const float* U, const float* V, float* d, const float* g, float* out, int64_t N, int r,
+                             float step, float tiny, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !g || !out) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = sweep_grid(ops, r, kOccFinal, N, kMaxGrid);
+  {
+    ProfScope ps(PSGD_PROF_APPLY_S3, st);
+    PSGD_CHECK_LAUNCH(ops->final_sweep(use_nt(N, r), U, V, d, w.nabla, g, out, N, w.coef, w.maxbuf + 2, step, tiny, grid, st));
+  }
   return PSGD_OK;
 }
 
@@ -940,7 +1214,9 @@ int psgd_uvd_update_f32(float* U, float* V, float* d, const float* v, const floa
 }
 
 /* update_precond_UVd_math_ followed by precond_grad_UVd_math on the updated state (the UVd.step
- * pattern, psgd.py:732 -> :748), with the apply's first reduction folded into update sweep 2. */
+ * pattern, psgd.py:732 -> :748): three sweeps.  Sweep 2 also reduces [Unew | Vnew]' [d.*g, d.*g.*nablaD]; both
+ * reductions of the apply follow from those sums and the Gram of sweep 1 (k_fused_post), so the d update and the
+ * whole apply are ONE last sweep. */
 int psgd_uvd_update_apply_f32(float* U, float* V, float* d, const float* v, const float* h, const float* g, float* out,
                               int64_t N, int r, float step, float tiny, int balance, int update_U, void* ws,
                               int64_t ws_bytes, void* stream) {
@@ -954,13 +1230,11 @@ int psgd_uvd_update_apply_f32(float* U, float* V, float* d, const float* v, cons
   }
   rc = psgd_uvd_update_sweep1_f32(U, V, d, v, h, N, r, ws, ws_bytes, stream);
   if (rc) return rc;
-  rc = update_sweep2_impl(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream, /*one_launch_tail=*/true);
+  rc = update_sweep2_impl(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream);
   if (rc) return rc;
-  rc = psgd_uvd_update_sweep3_f32(d, N, r, step, tiny, ws, ws_bytes, stream);
+  rc = psgd_uvd_fused_post_f32(N, r, step, tiny, update_U, ws, ws_bytes, stream);
   if (rc) return rc;
-  rc = psgd_uvd_apply_sweep2_f32(U, d, g, out, N, r, 0, ws, ws_bytes, stream);
-  if (rc) return rc;
-  return psgd_uvd_apply_sweep3_f32(V, d, out, N, r, 0, ws, ws_bytes, stream);
+  return psgd_uvd_fused_final_f32(U, V, d, g, out, N, r, step, tiny, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace psgd {
 
@@ -181,14 +182,25 @@ __device__ __forceinline__ void write_row(float* tile, int row, const float (&x)
   }
 }
 
+// No per-tile work (default hook of sweep_rows).
+struct NoTileHook {
+  static constexpr unsigned kStoreVecMask = 0;    // which per-row scalars s[k] the body's values are written back to LDS
+  static constexpr bool kActive = false;
+  __device__ __forceinline__ void operator()(const float*) const {}
+};
+
 // Generic row sweep.  mats: NMAT [N,R] inputs; vecs: NVEC [N] inputs;
 // WB >= 0: operand WB is modified by the body and streamed back to `mat_out`.
 // body(row, valid, x[NMAT][R], s[NVEC]).  Rows past N (tail tile only) arrive
 // zero-filled with valid == false.
-template <int R, int NMAT, int NVEC, int WB, bool NT, class Body>
+// hook (optional): called once per tile after every row of the tile has been processed, with the wave's LDS tile
+// (operands at m * kTileFloats -- operand WB holds the NEW rows --, per-row scalars at NMAT * kTileFloats +
+// k * kTileRows; the slots in Hook::kStoreVecMask hold what the body left in s[k]).  Column reductions that would
+// cost one accumulator register per column per lane run there on the matrix core instead (ColSum2).
+template <int R, int NMAT, int NVEC, int WB, bool NT, class Body, class Hook = NoTileHook>
 __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
                                            const float* const (&vecs)[NVEC > 0 ? NVEC : 1],
-                                           float* mat_out, long N, float* lds, Body&& body) {
+                                           float* mat_out, long N, float* lds, Body&& body, Hook&& hook = Hook()) {
   using C = Cfg<R>;
   const int lane = threadIdx.x & 63;
   const long gw = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -220,6 +232,14 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
       for (int k = 0; k < NVEC; ++k) s[k] = lds[NMAT * C::kTileFloats + k * C::kTileRows + rit];
       body(tile * C::kTileRows + rit, true, x, s);
       if constexpr (WB >= 0) write_row<R>(lds + WB * C::kTileFloats, rit, x[WB]);
+#pragma unroll
+      for (int k = 0; k < NVEC; ++k)
+        if ((std::remove_reference_t<Hook>::kStoreVecMask >> k) & 1u)      // compile-time after unrolling
+          lds[NMAT * C::kTileFloats + k * C::kTileRows + rit] = s[k];
+    }
+    if constexpr (std::remove_reference_t<Hook>::kActive) {
+      __builtin_amdgcn_wave_barrier();
+      hook(lds);
     }
     if constexpr (WB >= 0) {
       __builtin_amdgcn_wave_barrier();
@@ -256,6 +276,14 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
       for (int k = 0; k < NVEC; ++k) s[k] = valid ? vecs[k][row0 + rit] : 0.0f;
       body(row0 + rit, valid, x, s);
       if constexpr (WB >= 0) write_row<R>(lds + WB * C::kTileFloats, rit, x[WB]);
+#pragma unroll
+      for (int k = 0; k < NVEC; ++k)
+        if ((std::remove_reference_t<Hook>::kStoreVecMask >> k) & 1u)      // compile-time after unrolling
+          lds[NMAT * C::kTileFloats + k * C::kTileRows + rit] = s[k];
+    }
+    if constexpr (std::remove_reference_t<Hook>::kActive) {
+      __builtin_amdgcn_wave_barrier();
+      hook(lds);
     }
     if constexpr (WB >= 0) {
       __builtin_amdgcn_wave_barrier();
@@ -619,30 +647,102 @@ struct UpdCoef {
   static constexpr int kS1 = 0, kS2 = R, kX1 = 2 * R, kX2 = 3 * R, kC1 = 4 * R, kC2 = 5 * R, kMu = 6 * R;
 };
 
+// Column sums [U | V]' [x0 x1] over all the rows a wave sweeps, on the matrix core: one
+// v_mfma_f32_4x4x1_16b_f32 per row.  That instruction is 16 independent 4x4 outer products; lane l supplies
+// A = a[l] and B = b[l], and D[e][lane 4q + j] += a[lane 4q + e] * b[lane 4q + j] (layout found with
+// tools/micro/mfma4x4_probe.hip).  With a[l] = W[row][l] (column l of [U | V], l < 2R <= 64: one conflict-free LDS read
+// per lane) and b[l] = x_{l & 3}[row] for (l & 3) < 2, lane 4q + j ends up with the sums of columns 4q .. 4q + 3
+// against x_j in its four accumulator registers: 4 VGPRs instead of 4R per-lane accumulators, on a pipe the sweep
+// does not otherwise use.  fp32 chains are kFlushRows rows long, then folded into fp64.
+template <int R, int NMAT, int SLOT0, int SLOT1>
+struct ColSum2 {
+  using C = Cfg<R>;
+  static_assert(2 * R <= 64, "one lane per column of [U | V]");
+  static constexpr unsigned kStoreVecMask = (1u << SLOT0) | (1u << SLOT1);
+  static constexpr bool kActive = true;
+  static constexpr int kFlushTiles = (256 / C::kTileRows) > 0 ? (256 / C::kTileRows) : 1;
+  f32x4 acc0, acc1;
+  double acc64[4];
+  int aoff, boff, since;
+  float amask, bmask;
+  __device__ __forceinline__ ColSum2() {
+    const int l = threadIdx.x & 63;
+    acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc64[e] = 0.0;
+    since = 0;
+    aoff = (l < R) ? l : (l < 2 * R ? C::kTileFloats + (l - R) : 0);
+    amask = (l < 2 * R) ? 1.0f : 0.0f;
+    const int j = l & 3;
+    boff = NMAT * C::kTileFloats + (j == 1 ? SLOT1 : SLOT0) * C::kTileRows;
+    bmask = (j < 2) ? 1.0f : 0.0f;
+  }
+  __device__ __forceinline__ void flush() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc64[e] += (double)acc0[e] + (double)acc1[e];
+    acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    since = 0;
+  }
+  __device__ __forceinline__ void operator()(const float* lds) {
+#pragma unroll 8
+    for (int row = 0; row < C::kTileRows; row += 2) {
+      const float a0 = lds[aoff + row * R] * amask, b0 = lds[boff + row] * bmask;
+      const float a1 = lds[aoff + (row + 1) * R] * amask, b1 = lds[boff + row + 1] * bmask;
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, acc1, 0, 0, 0);
+    }
+    if (++since == kFlushTiles) flush();
+  }
+  // Block total (fixed order over the 4 waves) -> part[(j * 2R + c) * G + block], j = 0 (x0), 1 (x1), c = column of
+  // [U | V]: transposed fp64 partials, so that a reduction reads an element's G partials contiguously.
+  __device__ __forceinline__ void block_store(double* red /* [waves][4][64] */, double* part) {
+    flush();
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(w * 4 + e) * 64 + l] = acc64[e];
+    __syncthreads();
+    if (w == 0 && (l & 3) < 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * (l >> 2) + e;
+        if (c < 2 * R) {
+          const double t = ((red[(0 * 4 + e) * 64 + l] + red[(1 * 4 + e) * 64 + l]) + red[(2 * 4 + e) * 64 + l]) +
+                           red[(3 * 4 + e) * 64 + l];
+          part[(long)((l & 3) * 2 * R + c) * gridDim.x + blockIdx.x] = t;
+        }
+      }
+    }
+  }
+};
+
 // update sweep 2 (row-local; psgd.py:569-601 / :603-615 given the r-vectors):
 //   a = t + U s1 (Qh)            b = w - V x1 (invQtv)
 //   Ph = d (a + V s2)            invPv = (b - U x2) / d
 //   nablaD = Ph h - v invPv      (stored; its max|.| reduced)
 //   UPDATE_U: U <- U - mu (a c1 - b c2),  c1 = atV K, c2 = btV K
 //   else    : V <- V - mu ((a + V c1) c1 - (b + V c2) c2),  c1 = atU, c2 = btU
-// FUSE: UVd.step applies the preconditioner right after updating it (psgd.py:732 -> :748).
-// The apply's first reduction is s1 = Vnew'(dnew .* g) with dnew = d - mu d .* nablaD (psgd.py:584), i.e.
-//   s1 = Vnew'(d.*g) - mu Vnew'(d.*nablaD.*g)
-// and both column reductions can ride on this sweep (the new V row is in registers): 2R extra per-lane
-// accumulators and 4 B/row for g replace a whole extra pass over V.
+// FUSE: UVd.step applies the preconditioner right after updating it (psgd.py:732 -> :748).  Both
+// reductions of that apply can be had without another pass over U or V.  With dnew = d - mu_d d .* nablaD
+// (psgd.py:584) and tg = d .* g, tn = d .* g .* nablaD:
+//   s1' = Vnew'(dnew .* g)             = Vnew'tg - mu_d Vnew'tn
+//   s2' = Unew'(dnew .* g + Unew s1')  = Unew'tg - mu_d Unew'tn + (Unew'Unew) s1'
+// and Unew'Unew is the Gram block U'U of sweep 1 plus a rank-2 correction known from the r x r algebra (k_fused_post).
+// So this sweep also reduces the four r-vectors [Unew | Vnew]' [tg tn] (ColSum2, on the matrix core), and the apply
+// becomes ONE more sweep (k_uvd_final) instead of a d update and two sweeps.
 template <int R, bool UPDATE_U, bool NT, bool FUSE>
 __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, const float* d, const float* v,
                                                         const float* h, const float* g, long N,
                                                         const float* __restrict__ coef, float* nabla, float* part_max,
-                                                        float* part_pq) {
+                                                        double* part_pq) {
   using K = UpdCoef<R>;
   constexpr int NV = FUSE ? 4 : 3;
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 2, NV>()];
-  __shared__ float red[kWavesPerBlock * (FUSE ? 2 * R : 1)];
+  constexpr int kLdsSweep = kWavesPerBlock * sweep_lds_floats<R, 2, NV>() * 4;
+  constexpr int kLdsRed = FUSE ? kWavesPerBlock * 4 * 64 * 8 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
+  __shared__ float red[kWavesPerBlock];
+  float* lds = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * sweep_lds_floats<R, 2, NV>();
   float vmax = 0.0f;
-  float pq[FUSE ? 2 * R : 1];
-#pragma unroll
-  for (int c = 0; c < (FUSE ? 2 * R : 1); ++c) pq[c] = 0.0f;
   const float mu = coef[K::kMu];
   const float* const mats[2] = {U, V};
   const float* vecs_[4] = {d, v, h, g};
@@ -671,20 +771,43 @@ __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, cons
     }
     if constexpr (FUSE) {
       const float tg = dd * s[NV - 1];          // d .* g        (rows past N: zero-filled)
-      const float tn = tg * nd;                 // d .* g .* nablaD
-#pragma unroll
-      for (int c = 0; c < R; ++c) {
-        pq[c] = fmaf(x[1][c], tg, pq[c]);
-        pq[R + c] = fmaf(x[1][c], tn, pq[R + c]);
-      }
+      s[1] = tg;                                // -> the v and h slots of the LDS tile, read back by ColSum2
+      s[2] = tg * nd;                           // d .* g .* nablaD
     }
   };
-  sweep_rows<R, 2, NV, (UPDATE_U ? 0 : 1), NT>(mats, vecs, UPDATE_U ? U : V, N, lds[threadIdx.x >> 6], body);
   if constexpr (FUSE) {
-    block_sum_store<2 * R>(pq, red, part_pq);
+    ColSum2<R, 2, 1, 2> cs;
+    sweep_rows<R, 2, NV, (UPDATE_U ? 0 : 1), NT>(mats, vecs, UPDATE_U ? U : V, N, lds, body, cs);
+    cs.block_store(reinterpret_cast<double*>(smem), part_pq);
     __syncthreads();
+  } else {
+    sweep_rows<R, 2, NV, (UPDATE_U ? 0 : 1), NT>(mats, vecs, UPDATE_U ? U : V, N, lds, body);
   }
   block_max_store(vmax, red, part_max + blockIdx.x);
+}
+
+// Last sweep of the fused update -> apply: d <- d - (mu_d d) nablaD (psgd.py:582-584), then with the new d
+//   out = d .* (g1 + V s2'),  g1 = d .* g + U s1'        (psgd.py:625-626 on the updated state)
+// s1' = coef[0, R), s2' = coef[R, 2R) (k_fused_post); U, V are the updated factors.
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_uvd_final(const float* U, const float* V, float* d, const float* nabla,
+                                                        const float* g, float* out, long N,
+                                                        const float* __restrict__ coef, const float* __restrict__ maxbuf,
+                                                        float step, float tiny) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 2, 3>()];
+  const float mu = step / (maxbuf[0] + tiny);
+  const float* const mats[2] = {U, V};
+  const float* const vecs[3] = {d, nabla, g};
+  sweep_rows<R, 2, 3, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                              [&](long row, bool valid, float (&x)[2][R], float (&s)[3]) {
+                                const float dn = s[0] - (mu * s[0]) * s[1];
+                                const float g1 = dn * s[2] + dot_row<R>(x[0], coef);
+                                const float o = dn * (g1 + dot_row<R>(x[1], coef + R));
+                                if (valid) {
+                                  stream_store<NT>(d + row, dn);
+                                  stream_store<NT>(out + row, o);
+                                }
+                              });
 }
 
 // ------------------------------------------------------- launch table ------
@@ -698,13 +821,14 @@ struct UvdOps {
   int (*apply_s3)(int nt, const float* V, const float* d, float* out, long N, const float* coef, int grid, hipStream_t st);
   int (*rowdot_axpy)(int nt, const float* M, const float* x, float* out, long N, const float* coef, int grid, hipStream_t st);
   int (*update_gram)(int nt, const float* U, const float* V, const float* d, const float* v, const float* h, long N, double* part, int grid, hipStream_t st);
-  // g / part_pq non-null: fused form that also reduces V'(d.*g) and V'(d.*g.*nablaD) (see k_update_s2)
-  int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, const float* g, long N, const float* coef, float* nabla, float* part_max, float* part_pq, int grid, hipStream_t st);
+  // g / part_pq non-null: fused form that also reduces [Unew | Vnew]' [d.*g, d.*g.*nablaD] (see k_update_s2, ColSum2)
+  int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, const float* g, long N, const float* coef, float* nabla, float* part_max, double* part_pq, int grid, hipStream_t st);
+  int (*final_sweep)(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out, long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st);
   // max resident blocks per CU for each sweep kernel (occupancy query)
   int (*occupancy)(int which);
 };
 
-enum { kOccColreduce = 0, kOccApplyS2, kOccApplyS3, kOccRowdot, kOccGram, kOccUpdS2U, kOccUpdS2V, kOccUpdS2F };
+enum { kOccColreduce = 0, kOccApplyS2, kOccApplyS3, kOccRowdot, kOccGram, kOccUpdS2U, kOccUpdS2V, kOccUpdS2F, kOccFinal };
 
 const UvdOps* uvd_ops_for_rank(int r);   // nullptr when r is not instantiated
 

@@ -43,7 +43,7 @@ struct Launch {
     PSGD_LAUNCH((k_update_gram<R, true>), (k_update_gram<R, false>), U, V, d, v, h, N, part);
   }
   static int update_s2(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h,
-                       const float* g, long N, const float* coef, float* nabla, float* part_max, float* part_pq,
+                       const float* g, long N, const float* coef, float* nabla, float* part_max, double* part_pq,
                        int grid, hipStream_t st) {
     if (g) {
       if (update_U)
@@ -58,6 +58,10 @@ struct Launch {
     PSGD_LAUNCH((k_update_s2<R, false, true, false>), (k_update_s2<R, false, false, false>), U, V, d, v, h, g, N, coef,
                 nabla, part_max, part_pq);
   }
+  static int final_sweep(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out,
+                         long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st) {
+    PSGD_LAUNCH((k_uvd_final<R, true>), (k_uvd_final<R, false>), U, V, d, nabla, g, out, N, coef, maxbuf, step, tiny);
+  }
   static int occupancy(int which) {
     const void* f = nullptr;
     switch (which) {
@@ -69,6 +73,7 @@ struct Launch {
       case kOccUpdS2U: f = reinterpret_cast<const void*>(&k_update_s2<R, true, true, false>); break;
       case kOccUpdS2V: f = reinterpret_cast<const void*>(&k_update_s2<R, false, true, false>); break;
       case kOccUpdS2F: f = reinterpret_cast<const void*>(&k_update_s2<R, false, true, true>); break;
+      case kOccFinal: f = reinterpret_cast<const void*>(&k_uvd_final<R, true>); break;
       default: return 0;
     }
     int n = 0;
@@ -77,7 +82,7 @@ struct Launch {
   }
   static const UvdOps* ops() {
     static const UvdOps o = {Cfg<R>::kTileRows, GramCfg<R>::kLen, &colreduce, &apply_s2, &apply_s3,
-                             &rowdot_axpy,      &update_gram,     &update_s2, &occupancy};
+                             &rowdot_axpy,      &update_gram,     &update_s2, &final_sweep, &occupancy};
     return &o;
   }
 };

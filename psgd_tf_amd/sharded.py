@@ -13,8 +13,8 @@ whatever algorithm RCCL picks), so the r x r solves and step sizes redone on eve
     apply  (psgd.py:619-627):  sweep1 -> X(r sums) -> sweep2 -> X(r sums) -> sweep3            2 exchanges
     update (psgd.py:554-617):  [max -> X(2 maxima) -> scale]                                   (balance, :562-567)
                                sweep1 -> X(Gram, <= 30 KB) -> sweep2 -> X(1 maximum) -> sweep3  2 exchanges
-    fused update -> apply:     sweep1 -> X(Gram) -> sweep2 -> X([p | q | max]) -> d update,
-                               apply sweep2 -> X(r sums) -> apply sweep3                        3 exchanges
+    fused update -> apply:     sweep1 -> X(Gram) -> sweep2 -> X([pU | pV | qU | qV | max]) ->
+                               r x r algebra -> last sweep (d update + whole apply)             2 exchanges
 
 The two random branches of the reference (psgd.py:562, :588) must agree across ranks as well:
 pass them explicitly, or let them be drawn from a branch generator whose state is synchronised
@@ -121,16 +121,20 @@ class HipStages:
                                                              float(tiny), int(bool(update_U)), wp, wn, st),
                    "update_sweep2_fused")
 
-    def fused_s1(self, step, tiny):
+    def fused_post(self, step, tiny, update_U):
+        """r x r algebra of the fused step on the exchanged sums: s1', s2' of the apply on the updated state."""
         wp, wn, st = self._w()
-        _lib.check(self.lib.psgd_uvd_fused_s1_f32(self.N, self.r, float(step), float(tiny), wp, wn, st), "fused_s1")
+        _lib.check(self.lib.psgd_uvd_fused_post_f32(self.N, self.r, float(step), float(tiny), int(bool(update_U)),
+                                                    wp, wn, st), "fused_post")
 
-    def apply_sweep2_local_s1(self, U, d, g):
-        """apply sweep 2 when s1 is already in place on every rank (after fused_s1)."""
-        self._out = torch.empty_like(g)
+    def fused_final(self, U, V, d, g, step, tiny):
+        """last sweep of the fused step: d update + the whole apply; returns this rank's rows of the result."""
+        out = torch.empty_like(g)
         wp, wn, st = self._w()
-        _lib.check(self.lib.psgd_uvd_apply_sweep2_f32(U.data_ptr(), d.data_ptr(), g.data_ptr(), self._out.data_ptr(),
-                                                      self.N, self.r, 0, wp, wn, st), "apply_sweep2")
+        _lib.check(self.lib.psgd_uvd_fused_final_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), g.data_ptr(),
+                                                     out.data_ptr(), self.N, self.r, float(step), float(tiny),
+                                                     wp, wn, st), "fused_final")
+        return out
 
     def update_sweep3(self, d, step, tiny):
         wp, wn, st = self._w()
@@ -243,7 +247,7 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
 def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, balance=None, update_U=None,
                                              generator=None, group=None, backend=None):
     """Sharded fused update -> apply; returns this rank's rows of the preconditioned gradient.
-    3 exchanges: the Gram, [p | q | max|nablaD|] in one buffer, s2."""
+    2 exchanges: the Gram; the 4r column sums of sweep 2 with max|nablaD| in one buffer."""
     be = backend if backend is not None else hip_backend_for(U)
     balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
     if balance:
@@ -254,11 +258,8 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
     _exchange(be, 11, group)
     be.update_sweep2_fused(U, V, d, v, h, g, step, tiny, update_U)
     _exchange(be, 13, group)
-    be.update_sweep3(d, step, tiny)
-    be.fused_s1(step, tiny)
-    be.apply_sweep2_local_s1(U, d, g)
-    _exchange(be, 2, group)
-    return be.apply_sweep3(U, V, d, g)
+    be.fused_post(step, tiny, update_U)
+    return be.fused_final(U, V, d, g, step, tiny)
 
 
 # --------------------------------------------------------------------------- sparse LU (psgd.py:396-524), tail rows sharded

@@ -44,7 +44,7 @@ class NumpyStages(_GatherFold):
         if stage == 12:
             return None, self._max[12]
         if stage == 13:
-            return self._sums[13], self._max[12]       # [p | q | max] in one region
+            return self._sums[13], self._max[12]       # [pU | pV | qU | qV | max] in one region
         return self._sums[stage], None
 
     def __init__(self, r, dtype=np.float64):
@@ -52,7 +52,7 @@ class NumpyStages(_GatherFold):
         self.dtype = dtype
         nc = 2 * r + 2
         self._sums = {1: torch.zeros(r, dtype=torch.float64), 2: torch.zeros(r, dtype=torch.float64),
-                      11: torch.zeros(nc * nc, dtype=torch.float64), 13: torch.zeros(2 * r, dtype=torch.float64)}
+                      11: torch.zeros(nc * nc, dtype=torch.float64), 13: torch.zeros(4 * r, dtype=torch.float64)}
         self._max = {10: torch.zeros(2, dtype=torch.float32), 12: torch.zeros(1, dtype=torch.float32)}
         self.nabla = None
 
@@ -130,30 +130,51 @@ class NumpyStages(_GatherFold):
         invPv = (b - Un @ c(x2)) / dn
         self.nabla = Ph * hn - vn * invPv
         self._max[12][:] = torch.tensor([np.max(np.abs(self.nabla))], dtype=torch.float32)
+        self._upd = dict(s1=s1, x1=x1, mu=mu, aa=aa, ab=ab, bb=bb, Ua=s2, Ub=uw - C.T @ x1, A=A.copy())
         if update_U:
             c1, c2 = e1 @ K, e2 @ K
+            self._upd.update(c1=c1, c2=c2)
             Un -= mu * (a @ c(c1).T - b @ c(c2).T)
         else:
             al, be = a + Vn @ c(e1), b + Vn @ c(e2)
             Vn -= mu * (al @ c(e1).T - be @ c(e2).T)
 
     def update_sweep2_fused(self, U, V, d, v, h, g, step, tiny, update_U):
-        """sweep 2 + the two extra column reductions of the fused update->apply."""
+        """sweep 2 + the four extra column reductions of the fused update->apply:
+        [Unew | Vnew]' [d.*g, d.*g.*nablaD] with the OLD d."""
         dn, gn = self._np(d), self._np(g)
         d_old = dn.copy()
         self.update_sweep2(U, V, d, v, h, step, tiny, update_U)
-        Vn = self._np(V)                                   # the NEW V in the V branch
-        p = Vn.T @ (d_old * gn)
-        q = Vn.T @ (d_old * gn * self.nabla)
-        self._sums[13][:] = torch.from_numpy(np.concatenate([p, q]).astype(np.float64).ravel())
+        Un, Vn = self._np(U), self._np(V)                  # one of them is the NEW factor
+        tg, tn = d_old * gn, d_old * gn * self.nabla
+        sums = np.concatenate([Un.T @ tg, Vn.T @ tg, Un.T @ tn, Vn.T @ tn])
+        self._sums[13][:] = torch.from_numpy(sums.astype(np.float64).ravel())
 
-    def fused_s1(self, step, tiny):
-        mu = step / (float(self._max[12][0]) + tiny)
+    def fused_post(self, step, tiny, update_U):
+        """r x r algebra on the exchanged sums (restates k_fused_post): s1' = pV - mu_d qV,
+        s2' = pU - mu_d qU + (Unew'Unew) s1', Unew'Unew = U'U + the rank-2 correction of psgd.py:600-601."""
+        r, u = self.r, self._upd
         pq = self._sums[13].numpy()
-        self._sums[1][:] = torch.from_numpy(pq[:self.r] - mu * pq[self.r:])
+        pU, pV, qU, qV = pq[:r], pq[r:2 * r], pq[2 * r:3 * r], pq[3 * r:]
+        mud = step / (float(self._max[12][0]) + tiny)
+        A = u["A"]
+        if update_U:
+            mu, c1, c2, Ua, Ub = u["mu"], u["c1"], u["c2"], u["Ua"], u["Ub"]
+            o = np.outer
+            A = A - mu * (o(Ua, c1) + o(c1, Ua) - o(Ub, c2) - o(c2, Ub)) \
+                + mu * mu * (u["aa"] * o(c1, c1) - u["ab"] * (o(c1, c2) + o(c2, c1)) + u["bb"] * o(c2, c2))
+        s1n = pV - mud * qV
+        s2n = pU - mud * qU + A @ s1n
+        self._sums[1][:] = torch.from_numpy(s1n)
+        self._sums[2][:] = torch.from_numpy(s2n)
 
-    def apply_sweep2_local_s1(self, U, d, g):
-        self.apply_sweep2(U, d, g)
+    def fused_final(self, U, V, d, g, step, tiny):
+        """last sweep: d update (psgd.py:584), then out = d (d g + U s1' + V s2')."""
+        self.update_sweep3(d, step, tiny)
+        Un, Vn, dn, gn = map(self._np, (U, V, d, g))
+        s1 = self._sums[1].numpy().astype(self.dtype).reshape(-1, 1)
+        s2 = self._sums[2].numpy().astype(self.dtype).reshape(-1, 1)
+        return torch.from_numpy(dn * (dn * gn + Un @ s1 + Vn @ s2))
 
     def update_sweep3(self, d, step, tiny):
         dn = self._np(d)

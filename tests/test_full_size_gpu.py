@@ -106,6 +106,52 @@ def test_uvd_large_matches_fp64_restatement(psgd, N, r):
         assert _rel(a, b) < 2e-5, name                                    # three chained fp32 updates
 
 
+def _uvd_inputs_strong_lowrank(N, r, dev, c):
+    """Inputs on which the low-rank term is what the tolerance measures: ||U V'||_2 ~ c^2 = O(1) (entries ~ c / sqrt(N),
+    sqrt(r) times psgd.py:687's init), V correlated with U so that K = I + V'U (psgd.py:575) is far from the identity,
+    and gradients with an O(1) component in range(V) / range(U).  With reference-init scales the low-rank term
+    contributes only ~ gain^2 / sqrt(N r) of the output, which a 1e-5 tolerance barely sees at large N."""
+    g = torch.Generator(device=dev).manual_seed(11)
+    U = torch.randn(N, r, device=dev, generator=g) * (c / N ** 0.5)
+    R = torch.linalg.qr(torch.randn(r, r, device=dev, generator=g))[0]
+    V = 0.6 * (U @ R) + torch.randn(N, r, device=dev, generator=g) * (0.8 * c / N ** 0.5)
+    d = torch.exp(0.3 * torch.randn(N, 1, device=dev, generator=g))
+    a = torch.randn(r, 1, device=dev, generator=g)
+    gr = 0.5 * torch.randn(N, 1, device=dev, generator=g) + (V @ a) * (N ** 0.5 / c) / d      # O(1) entries, half in range(V)
+    v = torch.randn(N, 1, device=dev, generator=g)
+    h = v * torch.exp(torch.empty(N, 1, device=dev).uniform_(-2.3, 2.3, generator=g)) + (U @ a) * (N ** 0.5 / c)
+    return U.contiguous(), V.contiguous(), d, gr.contiguous(), v, h.contiguous()
+
+
+@pytest.mark.parametrize("N,r,c", [(1_000_000, 10, 1.0), (4_000_000, 20, 1.3), (1_000_003, 32, 0.8)])
+def test_uvd_strong_lowrank_matches_fp64_restatement(psgd, N, r, c):
+    """||U V'|| = O(1) at N >= 1e6: apply, both update branches and the fused step against the fp64 restatement."""
+    _need_gb(16)
+    dev = torch.device("cuda:0")
+    U, V, d, g, v, h = _uvd_inputs_strong_lowrank(N, r, dev, c)
+    U64, V64, d64, g64 = U.double(), V.double(), d.double(), g.double()
+    t64 = d64 * g64
+    low = float(torch.linalg.vector_norm(U64 @ (V64.t() @ t64)) / torch.linalg.vector_norm(t64))
+    assert low > 0.2, low                               # the low-rank term is a large part of Q (d .* g)
+    KmI = V64.t() @ U64
+    assert float(torch.linalg.matrix_norm(KmI, 2)) > 0.3
+    want = ref64.precond_grad_UVd_math(U64, V64, d64, g64)
+    assert _rel(psgd.precond_grad_UVd_math(U, V, d, g), want) < 1e-5
+    for update_U in (True, False):
+        old32 = {"U": U.double(), "V": V.double(), "d": d.double()}
+        old64 = {"U": U64.clone(), "V": V64.clone(), "d": d64.clone()}
+        psgd.update_precond_UVd_math_(U, V, d, v, h, 0.01, TINY32, balance=False, update_U=update_U)
+        ref64.update_precond_UVd_math_(U64, V64, d64, v.double(), h.double(), 0.01, TINY32, balance=False,
+                                       update_U=update_U)
+        for name, a_, b_ in (("U", U, U64), ("V", V, V64), ("d", d, d64)):
+            assert _rel(a_, b_) < 1e-5, (name, update_U)
+            if name != ("V" if update_U else "U"):      # the increment itself (~ step of the state): 2e-3 as in test_uvd_gpu
+                assert _rel(a_.double() - old32[name], b_ - old64[name]) < 2e-3, (name, update_U)
+    out = psgd.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, 0.01, TINY32, balance=False, update_U=True)
+    ref64.update_precond_UVd_math_(U64, V64, d64, v.double(), h.double(), 0.01, TINY32, balance=False, update_U=True)
+    assert _rel(out, ref64.precond_grad_UVd_math(U64, V64, d64, g64)) < 1e-5
+
+
 def _tri(n, dev, gen, off):
     return torch.triu(torch.randn(n, n, device=dev, generator=gen) * off, 1) + \
         torch.diag(torch.exp(0.3 * torch.randn(n, device=dev, generator=gen)))

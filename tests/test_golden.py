@@ -104,3 +104,43 @@ def test_hip_matches_kron_golden(path, hip_lib):
     assert rel_err(a.cpu().numpy(), z["Ql_new"]) < 1e-5 and rel_err(b.cpu().numpy(), z["Qr_new"]) < 1e-5
     out = psgd.precond_grad_kron(c("Ql"), c("Qr"), c("G"))
     assert rel_err(out.cpu().numpy(), z["pre_grad"]) < 1e-5
+
+
+# ----------------------------------------------------------------------------- reference-made fixtures (TensorFlow)
+TF_DIR = os.path.join(HERE, "tf")
+TF_FIXTURES = sorted(glob.glob(os.path.join(TF_DIR, "*.npz")))
+
+
+def test_oracle_matches_reference_fixtures():
+    """tests/golden/tf/*.npz are outputs of the REFERENCE ITSELF under TensorFlow for the inputs of the committed
+    fixtures (tests/golden/make_golden_tf.py).  Present: the oracle must reproduce them (fp32 TensorFlow against the
+    fp64 oracle: 1e-5, north_star's tolerance) and parity is pinned.  Absent (TensorFlow cannot be installed in the
+    build container): this test says so -- PARITY UNPINNED -- instead of passing silently."""
+    if not TF_FIXTURES:
+        pytest.skip("PARITY UNPINNED: no reference-made fixtures in tests/golden/tf (TensorFlow unavailable; "
+                    "run tests/golden/make_golden_tf.py where it is)")
+    for path in TF_FIXTURES:
+        name, t = os.path.basename(path), np.load(path)
+        if name.startswith("dense_"):
+            Q = orc.update_precond_dense(0.1 * np.eye(2), [np.array(1.0), np.array(0.0)], [np.array(802.0), np.array(400.0)], 0.2)
+            assert rel_err(Q, t["Q_new"]) < 1e-5
+            continue
+        z = np.load(os.path.join(HERE, name))
+        f = lambda k: z[k].astype(np.float64)
+        if name.startswith("uvd_"):
+            q = {k: f(k) for k in ("U", "V", "d", "g", "v", "h")}
+            assert rel_err(orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"]), t["pre_grad_before"]) < 1e-5, name
+            orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], float(z["step"]), float(z["tiny"]),
+                                         balance=bool(z["balance"]), update_U=bool(z["update_U"]))
+            for k in ("U", "V", "d"):
+                assert rel_err(q[k], t[k + "_new"]) < 1e-5, (name, k)
+            assert rel_err(orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"]), t["pre_grad_after"]) < 1e-5, name
+        elif name.startswith("kron_"):
+            a, b = orc.update_precond_kron(f("Ql"), f("Qr"), f("dX"), f("dG"), float(z["step"]))
+            assert rel_err(a, t["Ql_new"]) < 1e-5 and rel_err(b, t["Qr_new"]) < 1e-5, name
+            assert rel_err(orc.precond_grad_kron(f("Ql"), f("Qr"), f("G")), t["pre_grad"]) < 1e-5, name
+        else:
+            new = orc.update_precond_splu(f("L12"), f("l3"), f("U12"), f("u3"), [f("dx")], [f("dg")], float(z["step"]))
+            for k, a in zip(SPLU_KEYS, new):
+                assert rel_err(a, t[k + "_new"]) < 1e-5, (name, k)
+            assert rel_err(orc.precond_grad_splu(f("L12"), f("l3"), f("U12"), f("u3"), [f("g")])[0], t["pre_grad"]) < 1e-5

@@ -64,7 +64,7 @@ def _worker(rank, world, port, outdir):
             before = snap()
             outs_f.append(sharded.update_precond_UVd_math_and_precond_grad(
                 t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY, balance=False, update_U=upd, backend=be))
-            assert calls["all_gather_into_tensor"] - before["all_gather_into_tensor"] == 3      # Gram, [p|q|max], s2
+            assert calls["all_gather_into_tensor"] - before["all_gather_into_tensor"] == 2      # Gram, [4r sums | max]
             assert calls["all_reduce"] == 0 and calls["broadcast"] == before["broadcast"]
         # ... and later drawn calls with the same generator object exchange nothing for the branches
         before = snap()

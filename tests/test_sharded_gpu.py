@@ -176,8 +176,8 @@ def test_splu_world1_and_real_shards(pg, hip_lib):
 
 @pytest.mark.parametrize("N,r,cuts", [(100003, 20, (0, 40000, 100003)), (300001, 10, (0, 64, 150016, 300001))])
 def test_uvd_fused_step_on_real_shards(hip_lib, N, r, cuts):
-    """The choreography bench.py runs at --gpus N > 1 (sharded.update_precond_UVd_math_and_precond_grad): three
-    exchanges -- Gram, [p | q | max], s2 -- each an all-gather + the product's rank-order fold kernel, on real shards in
+    """The choreography bench.py runs at --gpus N > 1 (sharded.update_precond_UVd_math_and_precond_grad): two
+    exchanges -- Gram, [4r column sums | max] -- each an all-gather + the product's rank-order fold kernel, on real shards in
     one process with the gather emulated by concatenation, both branches."""
     import preconditioned_stochastic_gradient_descent as psgd
     from psgd_tf_amd import sharded
@@ -195,14 +195,11 @@ def test_uvd_fused_step_on_real_shards(hip_lib, N, r, cuts):
         _gather_fold_emulated(bes, 11)
         for be, s in zip(bes, sh):
             be.update_sweep2_fused(s["U"], s["V"], s["d"], s["v"], s["h"], s["g"], 0.01, TINY32, upd)
-        _gather_fold_emulated(bes, 13)                     # [p | q | max] in one exchange
-        for be, s in zip(bes, sh):
-            be.update_sweep3(s["d"], 0.01, TINY32)
-            be.fused_s1(0.01, TINY32)
-            be.apply_sweep2_local_s1(s["U"], s["d"], s["g"])
-        _gather_fold_emulated(bes, 2)
-        assert all(torch.equal(bes[0].sums(2), be.sums(2)) for be in bes[1:])      # bit-identical on every "rank"
-        out = torch.cat([be.apply_sweep3(s["U"], s["V"], s["d"], s["g"]) for be, s in zip(bes, sh)], 0)
+        _gather_fold_emulated(bes, 13)                     # [pU | pV | qU | qV | max] in one exchange
+        assert all(torch.equal(bes[0].send(13), be.send(13)) for be in bes[1:])    # bit-identical on every "rank"
+        for be in bes:
+            be.fused_post(0.01, TINY32, upd)
+        out = torch.cat([be.fused_final(s["U"], s["V"], s["d"], s["g"], 0.01, TINY32) for be, s in zip(bes, sh)], 0)
         assert rel_err(out.cpu().numpy(), want.cpu().numpy()) < 2e-6, upd
         assert rel_err(out.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < 1e-5, upd
         for k in ("U", "V", "d"):

@@ -188,3 +188,32 @@ def test_fused_update_apply_matches_oracle_and_unfused(psgd, N, r, update_U):
     q = _f64(p)
     orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=update_U)
     assert rel_err(out_f.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < APPLY_TOL
+
+
+@pytest.mark.parametrize("N,r", [(1021, 1), (3000, 5), (4099, 8), (5000, 9), (1021, 10), (4096, 16), (3001, 17), (5000, 20),
+                                 (2500, 24), (2600, 25), (2049, 32)])
+@pytest.mark.parametrize("update_U", [True, False])
+def test_register_row_coef_kernel_equals_block_reference(psgd, hip_lib, N, r, update_U):
+    """The r x r algebra of the update (two pivoted LU solves + the norm, psgd.py:574-615) has two kernels: the
+    one-row-per-lane register form the entry points launch and the block-cooperative reference form
+    (psgd_set_tuning(2, 1)).  Same elimination order element by element; only the inner products are summed in a
+    different order (fp64), so the updated states agree far inside fp32 rounding.  K = I + V'U is made far from the
+    identity (correlated U, V, gain 3) so that pivoting and both triangular phases matter."""
+    p = make_uvd_problem(N, r, seed=5 * N + r, uv_gain=3.0 * r ** 0.5, d_spread=0.3)
+    p["V"] = (0.7 * p["U"] @ np.linalg.qr(np.random.default_rng(r).standard_normal((r, r)))[0] + 0.5 * p["V"]).astype(np.float32)
+    a, b = _to_dev(p), _to_dev(p)
+    psgd.update_precond_UVd_math_(a["U"], a["V"], a["d"], a["v"], a["h"], 0.01, TINY32, balance=False, update_U=update_U)
+    try:
+        assert hip_lib.psgd_set_tuning(2, 1) == 0
+        psgd.update_precond_UVd_math_(b["U"], b["V"], b["d"], b["v"], b["h"], 0.01, TINY32, balance=False, update_U=update_U)
+        torch.cuda.synchronize()
+    finally:
+        hip_lib.psgd_set_tuning(2, 0)
+    for k in ("U", "V", "d"):
+        assert rel_err(a[k].cpu().numpy(), b[k].cpu().numpy()) < 1e-7, k
+    q = _f64(p)
+    KmI = q["V"].T @ q["U"]
+    assert np.linalg.norm(KmI, 2) > 0.5                                   # K is not a perturbation of I here
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=update_U)
+    for k in ("U", "V", "d"):
+        assert rel_err(a[k].cpu().numpy(), q[k]) < STATE_TOL, k
