@@ -159,7 +159,8 @@ int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,
  * key 0: streaming policy (0 = automatic: non-temporal when U,V exceed the Infinity Cache,
  *        1 = never non-temporal, 2 = always non-temporal).
  * key 1: cap on blocks per CU for the sweeps (0 = occupancy query).
- * key 2: r x r algebra of the update: 0 (default) one-row-per-lane register kernel, 1 = block-cooperative reference. */
+ * key 2: r x r algebra of the update: 0 (default) one-row-per-lane register kernel, 1 = block-cooperative reference.
+ * key 3: short sweeps: tiles a wave should stream at least (default 8; grids shrink to that, never below one block per CU). */
 int psgd_set_tuning(int key, int value);
 
 /* Live kernel timing for bench.py (measurement aid, not part of the reference's surface).

@@ -24,11 +24,12 @@ const UvdOps* uvd_ops_for_rank(int r) {
 }
 
 // ------------------------------------------------------------ workspace ----
-constexpr int64_t kSumsCap = 4096;   // doubles (Gram of r = 32 needs 3840)
+constexpr int64_t kSumsCap = 4352;   // doubles (Gram of r = 32 needs 3840; the small regions below follow it)
 constexpr int kPqSumsOff = 3840;      // the fused sums [pU | pV | qU | qV] (4r <= 128 doubles) live above the largest Gram; the
                                       // fp64 copy of max|nablaD| follows them at [kPqSumsOff + 4r] (one contiguous send region)
 constexpr int kBalD64Off = 4000;      // fp64 copies of the two balance maxima (send region of stage 10)
-constexpr int kPostSumsOff = 4016;    // fp64 s1', s2' of the fused step (2r <= 64 doubles; diagnostics)
+constexpr int kCoef64Off = 4016;      // fp64 by-products of the r x r algebra that k_fused_post needs: Ua | Ub | c1 | c2 (4r) + mu, a'a, a'b, b'b
+constexpr int kPostSumsOff = 4160;    // fp64 s1', s2' of the fused step (2r <= 64 doubles; diagnostics)
 constexpr int64_t kCoefCap = 256;    // floats
 constexpr int64_t kMaxCap = 64;      // floats
 
@@ -80,6 +81,7 @@ static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintpt
 // ------------------------------------------------------------ device info --
 static int g_tune_staging = 0;
 static int g_tune_blocks_per_cu = 0;
+static int g_tune_tiles_per_wave = 8;
 
 // Optional live kernel timing (bench.py): when enabled, every sweep launch is bracketed by a pair
 // of HIP events recorded on the launch stream; psgd_prof_collect() resolves them afterwards.
@@ -156,7 +158,15 @@ static int sweep_grid(const UvdOps* ops, int r, int which, int64_t N, int hard_c
   if (g_tune_blocks_per_cu < 0) occ = -g_tune_blocks_per_cu;   // experiments: force, even above the occupancy query
   const int64_t tiles = (N + ops->tile_rows - 1) / ops->tile_rows;
   int64_t grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t cap = (int64_t)num_cus() * occ;
+  int64_t cap = (int64_t)num_cus() * occ;
+  // short sweeps (cache-resident problems): a wave should stream at least ~8 tiles, or its fixed costs -- first-load
+  // latency, block reduction, one row of partials per block for the reduce kernels to read -- dominate; never fewer
+  // blocks than CUs (profiles/r02_c2_nscale.txt: one block per CU is as fast or faster up to N = 8M at r = 10)
+  if (g_tune_blocks_per_cu == 0) {
+    int64_t want = tiles / (kWavesPerBlock * (g_tune_tiles_per_wave > 0 ? g_tune_tiles_per_wave : 1));
+    if (want < num_cus()) want = num_cus();
+    if (cap > want) cap = want;
+  }
   if (grid > cap) grid = cap;
   if (grid > hard_cap) grid = hard_cap;
   if (grid < 1) grid = 1;
@@ -291,9 +301,25 @@ __global__ __launch_bounds__(kThreads) void k_reduce_pq(const double* __restrict
 }
 
 // d <- d - (mu d) nablaD, mu = step / (max|nablaD| + tiny)      psgd.py:582-584
+// pmax != nullptr (single-GPU call): max|nablaD| is still G block maxima; every block folds them itself (a maximum
+// does not depend on the order) instead of a reduction kernel of its own in front of this one.
 __global__ __launch_bounds__(kThreads) void k_update_d(float* d, const float* __restrict__ nabla, long N,
-                                                       const float* __restrict__ maxbuf, float step, float tiny) {
-  const float mu = step / (maxbuf[0] + tiny);
+                                                       float* __restrict__ maxbuf, const float* __restrict__ pmax, int G,
+                                                       float step, float tiny) {
+  __shared__ float red[kWavesPerBlock];
+  __shared__ float bmax;
+  float m;
+  if (pmax) {
+    float v = 0.0f;
+    for (int b = threadIdx.x; b < G; b += kThreads) v = fmaxf(v, pmax[b]);
+    block_max_store(v, red, &bmax);
+    __syncthreads();
+    m = bmax;
+    if (blockIdx.x == 0 && threadIdx.x == 0) maxbuf[0] = m;
+  } else {
+    m = maxbuf[0];
+  }
+  const float mu = step / (m + tiny);
   const long n4 = N / 4;
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nth = (long)gridDim.x * blockDim.x;
@@ -426,7 +452,8 @@ __device__ inline double wave_sum(double v) {
 // One 256-thread block.  Reads the reduced Gram of W = [U | V | t | w] (MFMA block layout of
 // k_update_gram) and produces the coefficient block of UpdCoef.  fp64 throughout.
 __global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restrict__ gram, int r, float step, float tiny,
-                                                          int update_U, float* __restrict__ coef) {
+                                                          int update_U, float* __restrict__ coef,
+                                                          double* __restrict__ c64) {
   __shared__ double A[MR][MR + 1];    // U'U
   __shared__ double B[MR][MR + 1];    // V'V
   __shared__ double Cm[MR][MR + 1];   // V'U  (psgd.py:574)
@@ -508,16 +535,16 @@ __global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restri
 
   // e1 = a'M, e2 = b'M with M = V (update U) or U (update V); the norm needs
   // ||M e1'||^2 = e1 (M'M) e1' etc.                       (psgd.py:589-596 / :603-610)
-  double my_e1 = 0.0, my_e2 = 0.0;
+  double my_e1 = 0.0, my_e2 = 0.0, ub = 0.0;
   if (act) {
+    ub = uw[lane];
+    for (int k = 0; k < r; ++k) ub -= Cm[k][lane] * x1[k];      // U'b = U'w - (U'V) x1
     if (update_U) {
       my_e1 = vt[lane] + cs1[lane];      // atV = V't + (V'U) s1
       my_e2 = p2[lane];                  // btV = V'w - (V'V) x1
     } else {
-      double c = uw[lane];
-      for (int k = 0; k < r; ++k) c -= Cm[k][lane] * x1[k];
       my_e1 = s2[lane];                  // atU = U't + (U'U) s1
-      my_e2 = c;                         // btU = U'w - (U'V) x1
+      my_e2 = ub;                        // btU
     }
     e1[lane] = my_e1;
     e2[lane] = my_e2;
@@ -548,10 +575,18 @@ __global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restri
     coef[3 * r + lane] = (float)x2[lane];
     coef[4 * r + lane] = (float)c1;
     coef[5 * r + lane] = (float)c2;
+    c64[0 * r + lane] = s2[lane];
+    c64[1 * r + lane] = ub;
+    c64[2 * r + lane] = (double)(float)c1;
+    c64[3 * r + lane] = (double)(float)c2;
   }
   if (lane == 0) {
     coef[6 * r] = (float)mu;
     coef[6 * r + 1] = (float)nrm;
+    c64[4 * r + 0] = (double)(float)mu;
+    c64[4 * r + 1] = aa;
+    c64[4 * r + 2] = ab;
+    c64[4 * r + 3] = bb;
   }
 }
 
@@ -568,25 +603,45 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// Solves M x = rhs; lane i < r holds row i of M in a[0..RG) (columns >= r: 0) and rhs_i in a[RG]; returns x_i in lane i.
+// 64-lane maximum of unsigned keys on DPP row shifts / broadcasts; result valid in every lane.
+__device__ __forceinline__ unsigned wave64_umax(unsigned x) {
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));   // row_shr:1
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));   // row_shr:2
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));   // row_shr:4
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));   // row_shr:8
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// Solves M x = rhs with partial pivoting; lane i < r holds row i of M in a[0..RG) (columns >= r: 0) and rhs_i in
+// a[RG]; returns x_i in lane i.  Rows are never exchanged: the pivot row of step k stays in its lane (its step number
+// is remembered), rows that have not been a pivot yet are eliminated against it, and the back substitution walks the
+// pivots in reverse.  Value by value this is lu_solve_block's arithmetic (same pivots: first row with the largest
+// |entry| among the rows still in play -- in ROW order, which is the order LAPACK's partial pivoting scans when no
+// exchange has happened; after an exchange the tie order may differ, the pivot VALUE does not).
 template <int RG>
 __device__ __forceinline__ double lu_solve_rows(double (&a)[RG + 1], int r, int lane) {
+  int mystep = (lane < r) ? RG : -1;                // step at which this lane's row was the pivot (RG: not yet)
+  int pivlane[RG];
 #pragma unroll
   for (int k = 0; k < RG; ++k) {
+    pivlane[k] = 0;
     if (k < r) {
-      const bool cand = lane >= k && lane < r;
-      const unsigned key = cand ? __float_as_uint(fabsf((float)a[k])) : 0u;
-      const unsigned kmax = wave32_umax(key);
+      const bool cand = mystep == RG;
+      const unsigned key = cand ? (__float_as_uint(fabsf((float)a[k])) | 1u) : 0u;    // |1: a candidate beats "none"
+      const unsigned kmax = wave64_umax(key);
       const unsigned long long hit = __ballot(cand && key == kmax);
-      const int piv = __builtin_amdgcn_readfirstlane(hit ? (int)(__ffsll((long long)hit) - 1) : k);
-      double f = 0.0;
+      const int piv = __builtin_amdgcn_readfirstlane((int)(__ffsll((long long)hit) - 1));
+      pivlane[k] = piv;
+      const double pk = readlane_f64(a[k], piv);
+      const double f = a[k] * fast_rcp(pk);          // multiplier of this lane's row
+      if (lane == piv) mystep = k;
+      const bool elim = mystep == RG;                // rows still in play
 #pragma unroll
-      for (int j = k; j <= RG; ++j) {
-        const double pj = readlane_f64(a[j], piv);        // pivot row, column j
-        const double kj = readlane_f64(a[j], k);
-        if (lane == k) a[j] = pj; else if (lane == piv) a[j] = kj;
-        if (j == k) f = a[k] * fast_rcp(pj);               // multiplier of this lane's row (rows > k use it)
-        else if (lane > k) a[j] -= f * pj;
+      for (int j = k + 1; j <= RG; ++j) {
+        const double pj = readlane_f64(a[j], piv);   // pivot row, column j
+        if (elim) a[j] -= f * pj;
       }
     }
   }
@@ -594,8 +649,9 @@ __device__ __forceinline__ double lu_solve_rows(double (&a)[RG + 1], int r, int 
 #pragma unroll
   for (int k = RG - 1; k >= 0; --k) {
     if (k < r) {
-      const double xk = readlane_f64(a[RG], k) * fast_rcp(readlane_f64(a[k], k));
-      if (lane < k) a[RG] -= a[k] * xk;
+      const int piv = pivlane[k];
+      const double xk = readlane_f64(a[RG], piv) * fast_rcp(readlane_f64(a[k], piv));
+      if (mystep < k && mystep >= 0) a[RG] -= a[k] * xk;      // rows that were pivots of earlier steps
       if (lane == k) x = xk;
     }
   }
@@ -634,28 +690,39 @@ __device__ __forceinline__ void lane_sums(double (&val)[NQ], int r, int tid, Coe
 // Whole block executes this (only lanes tid < r of wave 0 carry rows; the other waves idle through the barriers).
 template <int RG>
 __device__ void coef_block(const double* __restrict__ gram, int r, float step, float tiny, int update_U,
-                           float* __restrict__ coef, CoefLds& L) {
+                           float* __restrict__ coef, double* __restrict__ c64, CoefLds& L) {
   const int tid = threadIdx.x, lane = tid & 63;
   const bool act = tid < r;
   const int nb = (2 * r + 2 + 15) / 16;
-  auto G = [&](int a, int b) -> double {
-    if (a > b) { const int t = a; a = b; b = t; }
-    const int bi = a >> 4, bj = b >> 4, i = a & 15, j = b & 15;
+  // lane = row.  All 3 RG + 7 loads of a lane are issued before the first is used (branch-free, clamped indices): the
+  // kernel is one memory latency long here, not one per element.
+  auto Gi = [&](int a, int b) -> int {          // index of Gram entry (a, b) in the MFMA block layout of k_update_gram
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const int bi = lo >> 4, bj = hi >> 4, i = lo & 15, j = hi & 15;
     const int p = bi * nb - (bi * (bi - 1)) / 2 + (bj - bi);
-    return gram[p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j)];
+    return p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j);
   };
-  for (int idx = tid; idx < r * r; idx += blockDim.x) {
-    const int i = idx / r, j = idx % r;
-    L.A[i][j] = G(i, j);
-    L.B[i][j] = G(r + i, r + j);
-    L.Cm[i][j] = G(j, r + i);
+  const int row = act ? tid : 0;
+  double ra[RG], rb[RG], rc[RG];
+#pragma unroll
+  for (int j = 0; j < RG; ++j) {
+    const int jj = j < r ? j : 0;
+    ra[j] = gram[Gi(row, jj)];
+    rb[j] = gram[Gi(r + row, r + jj)];
+    rc[j] = gram[Gi(jj, r + row)];
   }
-  double ut = 0.0, uw = 0.0, vt = 0.0, vw = 0.0;
+  double ut = gram[Gi(row, 2 * r)], uw = gram[Gi(row, 2 * r + 1)], vt = gram[Gi(r + row, 2 * r)],
+         vw = gram[Gi(r + row, 2 * r + 1)];
+  const double tt = gram[Gi(2 * r, 2 * r)], tw = gram[Gi(2 * r, 2 * r + 1)], ww = gram[Gi(2 * r + 1, 2 * r + 1)];
   if (act) {
-    ut = G(tid, 2 * r); uw = G(tid, 2 * r + 1); vt = G(r + tid, 2 * r); vw = G(r + tid, 2 * r + 1);
+#pragma unroll
+    for (int j = 0; j < RG; ++j) {
+      if (j < r) { L.A[tid][j] = ra[j]; L.B[tid][j] = rb[j]; L.Cm[tid][j] = rc[j]; }
+    }
     L.v[0][tid] = vt;                                      // s1 = V't
+  } else {
+    ut = uw = vt = vw = 0.0;
   }
-  const double tt = G(2 * r, 2 * r), tw = G(2 * r, 2 * r + 1), ww = G(2 * r + 1, 2 * r + 1);
   __syncthreads();
   // s2 = U'Qh = U't + (U'U) s1 ; cs1 = (V'U) s1
   const double s1 = vt;
@@ -687,16 +754,15 @@ __device__ void coef_block(const double* __restrict__ gram, int r, float step, f
   const double bb = ww - d7[2] - d7[3];          // b'b = w'w - 2 x1'V'w + x1'(V'V)x1
   const double ab = tw - d7[4] + d7[5] - d7[6];  // a'b
   // e1 = a'M, e2 = b'M with M = V (update U) or U (update V); the norm needs ||M e1'||^2 = e1 (M'M) e1' etc.
-  double e1 = 0.0, e2 = 0.0;                     //                      (psgd.py:589-596 / :603-610)
+  double e1 = 0.0, e2 = 0.0, ub = uw;            //                      (psgd.py:589-596 / :603-610)
   if (act) {
+    for (int k = 0; k < r; ++k) ub -= L.Cm[k][tid] * L.v[1][k];      // U'b = U'w - (U'V) x1
     if (update_U) {
       e1 = vt + cs1;                              // atV = V't + (V'U) s1
       e2 = p2;                                    // btV = V'w - (V'V) x1
     } else {
-      double c = uw;
-      for (int k = 0; k < r; ++k) c -= L.Cm[k][tid] * L.v[1][k];
       e1 = s2;                                    // atU = U't + (U'U) s1
-      e2 = c;                                     // btU = U'w - (U'V) x1
+      e2 = ub;                                    // btU
     }
     L.v[2][tid] = e1;
     L.v[3][tid] = e2;
@@ -726,108 +792,127 @@ __device__ void coef_block(const double* __restrict__ gram, int r, float step, f
     coef[3 * r + tid] = (float)x2;
     coef[4 * r + tid] = (float)c1;
     coef[5 * r + tid] = (float)c2;
+    // what k_fused_post needs to correct U'U for the update of U: U'a (= s2), U'b, and c1, c2, mu as the floats the
+    // sweep multiplies with
+    c64[0 * r + tid] = s2;
+    c64[1 * r + tid] = ub;
+    c64[2 * r + tid] = (double)(float)c1;
+    c64[3 * r + tid] = (double)(float)c2;
   }
   if (tid == 0) {
     coef[6 * r] = (float)mu;
     coef[6 * r + 1] = (float)nrm;
+    c64[4 * r + 0] = (double)(float)mu;
+    c64[4 * r + 1] = aa;
+    c64[4 * r + 2] = ab;
+    c64[4 * r + 3] = bb;
   }
 }
 
 template <int RG>
 __global__ __launch_bounds__(64) void k_coef_fast(const double* __restrict__ gram, int r, float step, float tiny,
-                                                  int update_U, float* __restrict__ coef) {
+                                                  int update_U, float* __restrict__ coef, double* __restrict__ c64) {
   __shared__ CoefLds L;
-  coef_block<RG>(gram, r, step, tiny, update_U, coef, L);
+  coef_block<RG>(gram, r, step, tiny, update_U, coef, c64, L);
 }
 
 static int g_tune_coef = 0;      // psgd_set_tuning key 2: 1 = the block-cooperative reference kernel
 
-static int launch_coef(hipStream_t st, const double* gram, int r, float step, float tiny, int update_U, float* coef) {
+static int launch_coef(hipStream_t st, const double* gram, int r, float step, float tiny, int update_U, float* coef,
+                       double* c64) {
+#define PSGD_COEF_CASE(RG)                                                                                         \
+  case RG / 4:                                                                                                     \
+    hipLaunchKernelGGL(k_coef_fast<RG>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef, c64);       \
+    break;
   if (g_tune_coef == 1) {
-    hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(kThreads), 0, st, gram, r, step, tiny, update_U, coef);
-  } else if (r <= 8) {
-    hipLaunchKernelGGL(k_coef_fast<8>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef);
-  } else if (r <= 16) {
-    hipLaunchKernelGGL(k_coef_fast<16>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef);
-  } else if (r <= 24) {
-    hipLaunchKernelGGL(k_coef_fast<24>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef);
+    hipLaunchKernelGGL(k_update_coef, dim3(1), dim3(kThreads), 0, st, gram, r, step, tiny, update_U, coef, c64);
   } else {
-    hipLaunchKernelGGL(k_coef_fast<32>, dim3(1), dim3(64), 0, st, gram, r, step, tiny, update_U, coef);
+    switch ((r + 3) / 4) {
+      PSGD_COEF_CASE(4) PSGD_COEF_CASE(8) PSGD_COEF_CASE(12) PSGD_COEF_CASE(16)
+      PSGD_COEF_CASE(20) PSGD_COEF_CASE(24) PSGD_COEF_CASE(28) PSGD_COEF_CASE(32)
+      default: return (int)hipErrorInvalidValue;
+    }
   }
+#undef PSGD_COEF_CASE
   return (int)hipGetLastError();
 }
 
-// The r x r algebra between the fused sweep 2 and the last sweep (one block, fp64).  Inputs: the reduced Gram of sweep 1
-// (U'U, V'U, V'V, U't, ...), the coefficient block sweep 2 used (s1, x1, c1, c2, mu as the floats the kernel multiplied
-// with), the reduced sums pq = [pU | pV | qU | qV] = [Unew | Vnew]' [d.*g, d.*g.*nablaD] and max|nablaD|.  Output: the
-// two r-vectors of the apply on the UPDATED state (psgd.py:625-626 after :584, :600 / :614):
+// The r x r algebra between the fused sweep 2 and the last sweep (one block, fp64).  Inputs: the U'U block of the reduced
+// Gram of sweep 1, the by-products c64 of the coefficient kernel (U'a, U'b, c1, c2, mu, a'a, a'b, b'b), the sums
+// pq = [pU | pV | qU | qV] = [Unew | Vnew]' [d.*g, d.*g.*nablaD] and max|nablaD|.  Output: the two r-vectors of the
+// apply on the UPDATED state (psgd.py:625-626 after :584, :600 / :614):
 //   s1' = Vnew'(dnew.*g) = pV - mu_d qV
 //   s2' = Unew'(dnew.*g + Unew s1') = (pU - mu_d qU) + (Unew'Unew) s1'
-// Unew = U - mu (a c1' - b c2') when U was updated (psgd.py:600-601), so with Ua = U'a = U't + (U'U) s1 and
-// Ub = U'b = U'w - (U'V) x1:
+// Unew = U - mu (a c1' - b c2') when U was updated (psgd.py:600-601), so with Ua = U'a and Ub = U'b
 //   Unew'Unew = U'U - mu (Ua c1' + c1 Ua' - Ub c2' - c2 Ub') + mu^2 (a'a c1 c1' - a'b (c1 c2' + c2 c1') + b'b c2 c2')
-// and Unew'Unew = U'U when V was updated.  Writes coef[0, r) = s1', coef[r, 2r) = s2' (+ the fp64 values to sums).
-__global__ __launch_bounds__(kThreads) void k_fused_post(const double* __restrict__ gram, const double* __restrict__ pq,
-                                                         const float* __restrict__ maxbuf, int r, float step, float tiny,
-                                                         int update_U, float* coef, double* s_out) {
-  __shared__ double A[MR][MR + 1];    // U'U, then Unew'Unew
-  __shared__ double s1c[MR], x1c[MR], c1[MR], c2[MR], Ua[MR], Ub[MR], s1n[MR];
-  __shared__ double sc[3];
-  const int tid = threadIdx.x;
+// and Unew'Unew = U'U when V was updated.  Writes coef[0, r) = s1', coef[r, 2r) = s2' (+ the fp64 values to s_out).
+// REDUCE (single GPU, grids of <= 256 blocks): the block first reduces the sweep's partials itself (what k_reduce_pq
+// does in the staged path, same order per element): one launch less between the two sweeps.
+template <bool REDUCE>
+__global__ __launch_bounds__(1024) void k_fused_post(const double* __restrict__ gram, const double* __restrict__ c64,
+                                                     const double* __restrict__ part, const float* __restrict__ pmax,
+                                                     int G, double* pq, float* maxbuf, int r, float step, float tiny,
+                                                     int update_U, float* coef, double* s_out) {
+  __shared__ double A[MR][MR + 1];
+  __shared__ double s1n[MR];
+  __shared__ double pqs[4 * MR];
+  __shared__ float mx;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  if constexpr (REDUCE) {
+    if (w == nw - 1) {
+      float m = 0.0f;
+      for (int b = lane; b < G; b += 64) m = fmaxf(m, pmax[b]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      if (lane == 0) { mx = m; maxbuf[0] = m; pq[4 * r] = (double)m; }
+    }
+    for (int e = w; e < 4 * r; e += nw) {                 // G <= 256: four loads per lane, issued together
+      const double* p = part + (long)e * G;
+      double x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = (lane + 64 * u < G) ? p[lane + 64 * u] : 0.0;
+      double sum = ((x[0] + x[1]) + x[2]) + x[3];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+      if (lane == 0) { pqs[e] = sum; pq[e] = sum; }
+    }
+  } else {
+    for (int e = tid; e < 4 * r; e += blockDim.x) pqs[e] = pq[e];
+    if (tid == 0) mx = maxbuf[0];
+  }
   const int nb = (2 * r + 2 + 15) / 16;
-  auto G = [&](int a, int b) -> double {
+  auto Gm = [&](int a, int b) -> double {
     if (a > b) { const int t = a; a = b; b = t; }
     const int bi = a >> 4, bj = b >> 4, i = a & 15, j = b & 15;
     const int p = bi * nb - (bi * (bi - 1)) / 2 + (bj - bi);
     return gram[p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j)];
   };
-  for (int idx = tid; idx < r * r; idx += kThreads) A[idx / r][idx % r] = G(idx / r, idx % r);
-  if (tid < r) {
-    s1c[tid] = (double)coef[0 * r + tid];
-    x1c[tid] = (double)coef[2 * r + tid];
-    c1[tid] = (double)coef[4 * r + tid];
-    c2[tid] = (double)coef[5 * r + tid];
-  }
-  const double mu = (double)coef[6 * r];
-  const double mud = (double)(step / (maxbuf[0] + tiny));          // the float expression of k_update_d / k_uvd_final
-  __syncthreads();
-  if (update_U) {
-    if (tid < r) {
-      double a = G(tid, 2 * r), b = G(tid, 2 * r + 1);                // U't, U'w
-      for (int k = 0; k < r; ++k) {
-        a += A[tid][k] * s1c[k];
-        b -= G(tid, r + k) * x1c[k];                                  // (U'V)[tid][k] = (V'U)[k][tid]
-      }
-      Ua[tid] = a;
-      Ub[tid] = b;
+  const bool act = tid < r;
+  if (act) {
+    for (int j0 = 0; j0 < r; j0 += 8) {                  // eight independent loads in flight
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = Gm(tid, (j0 + u < r) ? j0 + u : 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u < r) A[tid][j0 + u] = t[u];
     }
-    if (tid == 64) {            // a'a, a'b, b'b with the float coefficients the sweep used
-      double aa = G(2 * r, 2 * r), bb = G(2 * r + 1, 2 * r + 1), ab = G(2 * r, 2 * r + 1);
-      for (int i = 0; i < r; ++i) {
-        double As = 0.0, Bx = 0.0, Cs = 0.0;
-        for (int k = 0; k < r; ++k) {
-          As += A[i][k] * s1c[k];
-          Bx += G(r + i, r + k) * x1c[k];
-          Cs += G(k, r + i) * s1c[k];                                 // (V'U)[i][k] s1[k]
-        }
-        aa += s1c[i] * (2.0 * G(i, 2 * r) + As);
-        bb += x1c[i] * (-2.0 * G(r + i, 2 * r + 1) + Bx);
-        ab += s1c[i] * G(i, 2 * r + 1) - x1c[i] * (G(r + i, 2 * r) + Cs);
+    if (update_U) {
+      const double mu = c64[4 * r], aa = c64[4 * r + 1], ab = c64[4 * r + 2], bb = c64[4 * r + 3];
+      const double Ua = c64[tid], Ub = c64[r + tid], c1 = c64[2 * r + tid], c2 = c64[3 * r + tid];
+      for (int j = 0; j < r; ++j) {
+        const double Uaj = c64[j], Ubj = c64[r + j], c1j = c64[2 * r + j], c2j = c64[3 * r + j];
+        A[tid][j] += -mu * (Ua * c1j + c1 * Uaj - Ub * c2j - c2 * Ubj) +
+                     mu * mu * (aa * c1 * c1j - ab * (c1 * c2j + c2 * c1j) + bb * c2 * c2j);
       }
-      sc[0] = aa; sc[1] = ab; sc[2] = bb;
-    }
-    __syncthreads();
-    const double aa = sc[0], ab = sc[1], bb = sc[2];
-    for (int idx = tid; idx < r * r; idx += kThreads) {
-      const int i = idx / r, j = idx % r;
-      A[i][j] += -mu * (Ua[i] * c1[j] + c1[i] * Ua[j] - Ub[i] * c2[j] - c2[i] * Ub[j]) +
-                 mu * mu * (aa * c1[i] * c1[j] - ab * (c1[i] * c2[j] + c2[i] * c1[j]) + bb * c2[i] * c2[j]);
     }
   }
-  if (tid < r) s1n[tid] = pq[r + tid] - mud * pq[3 * r + tid];       // pV - mu_d qV
   __syncthreads();
-  if (tid < r) {
-    double s2 = pq[tid] - mud * pq[2 * r + tid];                      // pU - mu_d qU
+  const double mud = (double)(step / (mx + tiny));          // the float expression of k_update_d / k_uvd_final
+  if (act) s1n[tid] = pqs[r + tid] - mud * pqs[3 * r + tid];          // pV - mu_d qV
+  __syncthreads();
+  if (act) {
+    double s2 = pqs[tid] - mud * pqs[2 * r + tid];                     // pU - mu_d qU
     for (int k = 0; k < r; ++k) s2 += A[tid][k] * s1n[k];
     coef[tid] = (float)s1n[tid];
     coef[r + tid] = (float)s2;
@@ -870,6 +955,7 @@ int psgd_set_tuning(int key, int value) {
   if (key == 0) { g_tune_staging = value; return PSGD_OK; }
   if (key == 1) { g_tune_blocks_per_cu = value; return PSGD_OK; }
   if (key == 2) { g_tune_coef = value; return PSGD_OK; }
+  if (key == 3) { g_tune_tiles_per_wave = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -1109,7 +1195,7 @@ int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, c
 
 static int update_sweep2_impl(float* U, float* V, const float* d, const float* v, const float* h, const float* g,
                               int64_t N, int r, float step, float tiny, int update_U, void* ws, int64_t ws_bytes,
-                              void* stream) {
+                              void* stream, bool single_gpu_tail = false) {
   if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
@@ -1118,16 +1204,37 @@ static int update_sweep2_impl(float* U, float* V, const float* d, const float* v
   const UvdOps* ops = uvd_ops_for_rank(r);
   if (!ops) return PSGD_ERR_RANK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  PSGD_CHECK_LAUNCH(launch_coef(st, w.sums, r, step, tiny, update_U, w.coef));
+  PSGD_CHECK_LAUNCH(launch_coef(st, w.sums, r, step, tiny, update_U, w.coef, w.sums + kCoef64Off));
   const int grid = sweep_grid(ops, r, g ? kOccUpdS2F : (update_U ? kOccUpdS2U : kOccUpdS2V), N, kMaxGrid);
   double* part = static_cast<double*>(w.part);
   {
     ProfScope ps(PSGD_PROF_UPDATE_S2, st);
     PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, g, N, w.coef, w.nabla, w.pmax, part, grid, st));
   }
+  if (g && single_gpu_tail && grid <= 256) {     // small grids: the post kernel reduces the partials itself
+    hipLaunchKernelGGL(k_fused_post<true>, dim3(1), dim3(1024), 0, st, w.sums, w.sums + kCoef64Off, part, w.pmax, grid,
+                       w.sums + kPqSumsOff, w.maxbuf + 2, r, step, tiny, update_U, w.coef, w.sums + kPostSumsOff);
+    PSGD_CHECK_LAUNCH(last_launch());
+    return PSGD_OK;
+  }
   if (g) {      // block maxima -> max|nablaD|, column-sum partials -> [pU | pV | qU | qV]: one launch, one send region
     hipLaunchKernelGGL(k_reduce_pq, dim3((4 * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
                        w.pmax, grid, 4 * r, w.sums + kPqSumsOff, w.maxbuf + 2);
+    PSGD_CHECK_LAUNCH(last_launch());
+    if (single_gpu_tail) {
+      hipLaunchKernelGGL(k_fused_post<false>, dim3(1), dim3(kThreads), 0, st, w.sums, w.sums + kCoef64Off,
+                         static_cast<const double*>(nullptr), static_cast<const float*>(nullptr), 0, w.sums + kPqSumsOff,
+                         w.maxbuf + 2, r, step, tiny, update_U, w.coef, w.sums + kPostSumsOff);
+      PSGD_CHECK_LAUNCH(last_launch());
+    }
+    return PSGD_OK;
+  }
+  if (single_gpu_tail) {      // the d update folds the block maxima itself
+    {
+      ProfScope ps(PSGD_PROF_UPDATE_S3, st);
+      hipLaunchKernelGGL(k_update_d, dim3(flat_grid(N)), dim3(kThreads), 0, st, const_cast<float*>(d), w.nabla, (long)N,
+                         w.maxbuf + 2, w.pmax, grid, step, tiny);
+    }
     PSGD_CHECK_LAUNCH(last_launch());
     return PSGD_OK;
   }
@@ -1155,8 +1262,9 @@ int psgd_uvd_fused_post_f32(int64_t N, int r, float step, float tiny, int update
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(kThreads), 0, st, w.sums, w.sums + kPqSumsOff, w.maxbuf + 2, r, step,
-                     tiny, update_U, w.coef, w.sums + kPostSumsOff);
+  hipLaunchKernelGGL(k_fused_post<false>, dim3(1), dim3(kThreads), 0, st, w.sums, w.sums + kCoef64Off,
+                     static_cast<const double*>(nullptr), static_cast<const float*>(nullptr), 0, w.sums + kPqSumsOff,
+                     w.maxbuf + 2, r, step, tiny, update_U, w.coef, w.sums + kPostSumsOff);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
@@ -1190,7 +1298,7 @@ int psgd_uvd_update_sweep3_f32(float* d, int64_t N, int r, float step, float tin
   {
     ProfScope ps(PSGD_PROF_UPDATE_S3, st);
     hipLaunchKernelGGL(k_update_d, dim3(flat_grid(N)), dim3(kThreads), 0, st, d, w.nabla, (long)N, w.maxbuf + 2,
-                       step, tiny);
+                       static_cast<const float*>(nullptr), 0, step, tiny);
     PSGD_CHECK_LAUNCH(last_launch());
   }
   return PSGD_OK;
@@ -1208,9 +1316,9 @@ int psgd_uvd_update_f32(float* U, float* V, float* d, const float* v, const floa
   }
   rc = psgd_uvd_update_sweep1_f32(U, V, d, v, h, N, r, ws, ws_bytes, stream);
   if (rc) return rc;
-  rc = psgd_uvd_update_sweep2_f32(U, V, d, v, h, N, r, step, tiny, update_U, ws, ws_bytes, stream);
-  if (rc) return rc;
-  return psgd_uvd_update_sweep3_f32(d, N, r, step, tiny, ws, ws_bytes, stream);
+  // sweep 2 and, behind it, the d update (which folds the block maxima of |nablaD| itself)
+  if (misaligned16(d)) return PSGD_ERR_ALIGN;
+  return update_sweep2_impl(U, V, d, v, h, nullptr, N, r, step, tiny, update_U, ws, ws_bytes, stream, /*single_gpu_tail=*/true);
 }
 
 /* update_precond_UVd_math_ followed by precond_grad_UVd_math on the updated state (the UVd.step
@@ -1230,9 +1338,7 @@ int psgd_uvd_update_apply_f32(float* U, float* V, float* d, const float* v, cons
   }
   rc = psgd_uvd_update_sweep1_f32(U, V, d, v, h, N, r, ws, ws_bytes, stream);
   if (rc) return rc;
-  rc = update_sweep2_impl(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream);
-  if (rc) return rc;
-  rc = psgd_uvd_fused_post_f32(N, r, step, tiny, update_U, ws, ws_bytes, stream);
+  rc = update_sweep2_impl(U, V, d, v, h, g, N, r, step, tiny, update_U, ws, ws_bytes, stream, /*single_gpu_tail=*/true);
   if (rc) return rc;
   return psgd_uvd_fused_final_f32(U, V, d, g, out, N, r, step, tiny, ws, ws_bytes, stream);
 }

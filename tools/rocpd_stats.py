@@ -25,6 +25,7 @@ def main(path):
     print('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"')
     for n, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         sd = statistics.pstdev(v) if len(v) > 1 else 0.0
+        n = n if len(n) < 160 else n[:157] + "..."
         print(f'"{n}",{len(v)},{sum(v)},{sum(v) / len(v):.6f},{100.0 * sum(v) / total:.2f},{min(v)},{max(v)},{sd:.6f}')
 
 
