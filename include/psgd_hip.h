@@ -155,6 +155,13 @@ int psgd_uvd_ipuvt_matvec_f32(const float *U, const float *V, const float *x,
                               float *out, int64_t N, int r,
                               void *ws, int64_t ws_bytes, void *stream);
 
+/* IpUVtmatvec with a matrix x (psgd.py:542 "matrices or column vectors"): k columns, given as HOST arrays of k device
+ * pointers to contiguous [N] vectors (xs in, outs out; outs[j] may not alias any input).  One sweep of V and one of U
+ * per group of four columns.                                                                                       */
+int psgd_uvd_ipuvt_matvec_cols_f32(const float *U, const float *V, const float *const *xs,
+                                   float *const *outs, int k, int64_t N, int r,
+                                   void *ws, int64_t ws_bytes, void *stream);
+
 /* Tuning knobs for experiments (not part of the stable ABI).
  * key 0: streaming policy (0 = automatic: non-temporal when U,V exceed the Infinity Cache,
  *        1 = never non-temporal, 2 = always non-temporal).

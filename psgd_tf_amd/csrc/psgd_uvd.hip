@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_pq(const double* __restrict
                                                         float* __restrict__ maxout) {
   const int lane = threadIdx.x & 63;
   const int id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (id == 0) {
+  if (id == 0 && pmax) {
     float m = 0.0f;
     for (int b = lane; b < G; b += 64) m = fmaxf(m, pmax[b]);
 #pragma unroll
@@ -1127,6 +1127,39 @@ int psgd_uvd_ipuvt_matvec_f32(const float* U, const float* V, const float* x, fl
   PSGD_CHECK_LAUNCH(last_launch());
   grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
   PSGD_CHECK_LAUNCH(ops->rowdot_axpy(use_nt(N, r), U, x, out, N, w.coef, grid, st));
+  return PSGD_OK;
+}
+
+/* IpUVtmatvec on k columns (psgd.py:540-544, "matrices or column vectors"): xs / outs are HOST arrays of k device pointers
+ * to contiguous [N] columns.  U and V are swept once per group of four columns. */
+int psgd_uvd_ipuvt_matvec_cols_f32(const float* U, const float* V, const float* const* xs, float* const* outs, int k,
+                                   int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !xs || !outs || k < 1) return PSGD_ERR_BAD_ARG;
+  for (int j = 0; j < k; ++j)
+    if (!xs[j] || !outs[j]) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* part = static_cast<double*>(w.part);
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    const int nc = k - j0 < 4 ? k - j0 : 4;
+    const float* x4[4];
+    float* o4[4];
+    for (int j = 0; j < 4; ++j) { x4[j] = xs[j0 + (j < nc ? j : 0)]; o4[j] = outs[j0 + (j < nc ? j : 0)]; }
+    int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
+    PSGD_CHECK_LAUNCH(ops->colreduce4(use_nt(N, r), V, x4, N, part, grid, st));
+    hipLaunchKernelGGL(k_reduce_pq, dim3((4 * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
+                       static_cast<const float*>(nullptr), grid, 4 * r, w.sums + kPqSumsOff, static_cast<float*>(nullptr));
+    PSGD_CHECK_LAUNCH(last_launch());
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, st, w.sums + kPqSumsOff, w.coef, 4 * r);
+    PSGD_CHECK_LAUNCH(last_launch());
+    grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
+    PSGD_CHECK_LAUNCH(ops->rowdot_axpy4(use_nt(N, r), U, x4, o4, nc, N, w.coef, grid, st));
+  }
   return PSGD_OK;
 }
 

@@ -647,35 +647,36 @@ struct UpdCoef {
   static constexpr int kS1 = 0, kS2 = R, kX1 = 2 * R, kX2 = 3 * R, kC1 = 4 * R, kC2 = 5 * R, kMu = 6 * R;
 };
 
-// Column sums [U | V]' [x0 x1] over all the rows a wave sweeps, on the matrix core: one
-// v_mfma_f32_4x4x1_16b_f32 per row.  That instruction is 16 independent 4x4 outer products; lane l supplies
-// A = a[l] and B = b[l], and D[e][lane 4q + j] += a[lane 4q + e] * b[lane 4q + j] (layout found with
-// tools/micro/mfma4x4_probe.hip).  With a[l] = W[row][l] (column l of [U | V], l < 2R <= 64: one conflict-free LDS read
-// per lane) and b[l] = x_{l & 3}[row] for (l & 3) < 2, lane 4q + j ends up with the sums of columns 4q .. 4q + 3
-// against x_j in its four accumulator registers: 4 VGPRs instead of 4R per-lane accumulators, on a pipe the sweep
-// does not otherwise use.  fp32 chains are kFlushRows rows long, then folded into fp64.
-template <int R, int NMAT, int SLOT0, int SLOT1>
-struct ColSum2 {
+// Column sums W' [x0 .. x_{NX-1}] over all the rows a wave sweeps, W = the first NW staged operands side by side
+// ([U | V] or one matrix), on the matrix core: one v_mfma_f32_4x4x1_16b_f32 per row.  That instruction is 16 independent
+// 4x4 outer products; lane l supplies A = a[l] and B = b[l], and D[e][lane 4q + j] += a[lane 4q + e] * b[lane 4q + j]
+// (layout found with tools/micro/mfma4x4_probe.hip).  With a[l] = W[row][l] (column l of W, l < NW * R <= 64: one
+// conflict-free LDS read per lane) and b[l] = x_{l & 3}[row], lane 4q + j ends up with the sums of columns
+// 4q .. 4q + 3 against x_j in its four accumulator registers: 4 VGPRs instead of NX * NW * R per-lane accumulators, on
+// a pipe the sweep does not otherwise use.  The x_j are the per-row scalars in LDS slots SLOT0 .. SLOT0 + NX - 1 (as
+// the body left them: kStoreVecMask).  fp32 chains are <= 256 rows long, then folded into fp64.
+template <int R, int NMAT, int NW, int NX, int SLOT0>
+struct ColSum {
   using C = Cfg<R>;
-  static_assert(2 * R <= 64, "one lane per column of [U | V]");
-  static constexpr unsigned kStoreVecMask = (1u << SLOT0) | (1u << SLOT1);
+  static_assert(NW * R <= 64 && NX <= 4 && NW <= NMAT, "one lane per column of W, one 4x4 block column per vector");
+  static constexpr unsigned kStoreVecMask = ((1u << NX) - 1u) << SLOT0;
   static constexpr bool kActive = true;
   static constexpr int kFlushTiles = (256 / C::kTileRows) > 0 ? (256 / C::kTileRows) : 1;
   f32x4 acc0, acc1;
   double acc64[4];
   int aoff, boff, since;
   float amask, bmask;
-  __device__ __forceinline__ ColSum2() {
+  __device__ __forceinline__ ColSum() {
     const int l = threadIdx.x & 63;
     acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc64[e] = 0.0;
     since = 0;
-    aoff = (l < R) ? l : (l < 2 * R ? C::kTileFloats + (l - R) : 0);
-    amask = (l < 2 * R) ? 1.0f : 0.0f;
+    aoff = (l < NW * R) ? (l / R) * C::kTileFloats + (l % R) : 0;
+    amask = (l < NW * R) ? 1.0f : 0.0f;
     const int j = l & 3;
-    boff = NMAT * C::kTileFloats + (j == 1 ? SLOT1 : SLOT0) * C::kTileRows;
-    bmask = (j < 2) ? 1.0f : 0.0f;
+    boff = NMAT * C::kTileFloats + (SLOT0 + (j < NX ? j : 0)) * C::kTileRows;
+    bmask = (j < NX) ? 1.0f : 0.0f;
   }
   __device__ __forceinline__ void flush() {
 #pragma unroll
@@ -693,8 +694,8 @@ struct ColSum2 {
     }
     if (++since == kFlushTiles) flush();
   }
-  // Block total (fixed order over the 4 waves) -> part[(j * 2R + c) * G + block], j = 0 (x0), 1 (x1), c = column of
-  // [U | V]: transposed fp64 partials, so that a reduction reads an element's G partials contiguously.
+  // Block total (fixed order over the 4 waves) -> part[(j * NW * R + c) * G + block], j = vector, c = column of W:
+  // transposed fp64 partials, so that a reduction reads an element's G partials contiguously.
   __device__ __forceinline__ void block_store(double* red /* [waves][4][64] */, double* part) {
     flush();
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -702,19 +703,56 @@ struct ColSum2 {
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[(w * 4 + e) * 64 + l] = acc64[e];
     __syncthreads();
-    if (w == 0 && (l & 3) < 2) {
+    if (w == 0 && (l & 3) < NX) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int c = 4 * (l >> 2) + e;
-        if (c < 2 * R) {
+        if (c < NW * R) {
           const double t = ((red[(0 * 4 + e) * 64 + l] + red[(1 * 4 + e) * 64 + l]) + red[(2 * 4 + e) * 64 + l]) +
                            red[(3 * 4 + e) * 64 + l];
-          part[(long)((l & 3) * 2 * R + c) * gridDim.x + blockIdx.x] = t;
+          part[(long)((l & 3) * NW * R + c) * gridDim.x + blockIdx.x] = t;
         }
       }
     }
   }
 };
+template <int R, int NMAT, int SLOT0, int SLOT1>
+using ColSum2 = ColSum<R, NMAT, 2, 2, SLOT0>;      // [U | V]' [x0 x1], x0, x1 in consecutive slots (sweep 2 of the fused step)
+
+// IpUVtmatvec on up to four columns at once (psgd.py:540-544 with a matrix x): S = V' [x0 .. x3] in ONE sweep of V
+// (the sums on the matrix core) ...
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_colreduce4(const float* M, const float* x0, const float* x1, const float* x2,
+                                                         const float* x3, long N, double* part) {
+  constexpr int kLdsSweep = kWavesPerBlock * sweep_lds_floats<R, 1, 4>() * 4;
+  constexpr int kLdsRed = kWavesPerBlock * 4 * 64 * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
+  float* lds = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * sweep_lds_floats<R, 1, 4>();
+  const float* const mats[1] = {M};
+  const float* const vecs[4] = {x0, x1, x2, x3};
+  ColSum<R, 1, 1, 4, 0> cs;
+  sweep_rows<R, 1, 4, -1, NT>(mats, vecs, nullptr, N, lds, [&](long, bool, float (&)[1][R], float (&)[4]) {}, cs);
+  cs.block_store(reinterpret_cast<double*>(smem), part);
+}
+
+// ... and out_j = x_j + M S_j for the four columns in ONE sweep of M (coef = S, [4][R]).
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_rowdot_axpy4(const float* M, const float* x0, const float* x1,
+                                                           const float* x2, const float* x3, float* o0, float* o1,
+                                                           float* o2, float* o3, int ncols, long N,
+                                                           const float* __restrict__ coef) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 4>()];
+  const float* const mats[1] = {M};
+  const float* const vecs[4] = {x0, x1, x2, x3};
+  sweep_rows<R, 1, 4, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                              [&](long row, bool valid, float (&x)[1][R], float (&s)[4]) {
+                                if (!valid) return;
+                                stream_store<NT>(o0 + row, s[0] + dot_row<R>(x[0], coef));
+                                if (ncols > 1) stream_store<NT>(o1 + row, s[1] + dot_row<R>(x[0], coef + R));
+                                if (ncols > 2) stream_store<NT>(o2 + row, s[2] + dot_row<R>(x[0], coef + 2 * R));
+                                if (ncols > 3) stream_store<NT>(o3 + row, s[3] + dot_row<R>(x[0], coef + 3 * R));
+                              });
+}
 
 // update sweep 2 (row-local; psgd.py:569-601 / :603-615 given the r-vectors):
 //   a = t + U s1 (Qh)            b = w - V x1 (invQtv)
@@ -823,6 +861,8 @@ struct UvdOps {
   int (*update_gram)(int nt, const float* U, const float* V, const float* d, const float* v, const float* h, long N, double* part, int grid, hipStream_t st);
   // g / part_pq non-null: fused form that also reduces [Unew | Vnew]' [d.*g, d.*g.*nablaD] (see k_update_s2, ColSum2)
   int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, const float* g, long N, const float* coef, float* nabla, float* part_max, double* part_pq, int grid, hipStream_t st);
+  int (*colreduce4)(int nt, const float* M, const float* const* x, long N, double* part, int grid, hipStream_t st);
+  int (*rowdot_axpy4)(int nt, const float* M, const float* const* x, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
   int (*final_sweep)(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out, long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st);
   // max resident blocks per CU for each sweep kernel (occupancy query)
   int (*occupancy)(int which);

@@ -58,6 +58,14 @@ struct Launch {
     PSGD_LAUNCH((k_update_s2<R, false, true, false>), (k_update_s2<R, false, false, false>), U, V, d, v, h, g, N, coef,
                 nabla, part_max, part_pq);
   }
+  static int colreduce4(int nt, const float* M, const float* const* x, long N, double* part, int grid, hipStream_t st) {
+    PSGD_LAUNCH((k_colreduce4<R, true>), (k_colreduce4<R, false>), M, x[0], x[1], x[2], x[3], N, part);
+  }
+  static int rowdot_axpy4(int nt, const float* M, const float* const* x, float* const* o, int ncols, long N,
+                          const float* coef, int grid, hipStream_t st) {
+    PSGD_LAUNCH((k_rowdot_axpy4<R, true>), (k_rowdot_axpy4<R, false>), M, x[0], x[1], x[2], x[3], o[0], o[1], o[2], o[3],
+                ncols, N, coef);
+  }
   static int final_sweep(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out,
                          long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st) {
     PSGD_LAUNCH((k_uvd_final<R, true>), (k_uvd_final<R, false>), U, V, d, nabla, g, out, N, coef, maxbuf, step, tiny);
@@ -82,7 +90,8 @@ struct Launch {
   }
   static const UvdOps* ops() {
     static const UvdOps o = {Cfg<R>::kTileRows, GramCfg<R>::kLen, &colreduce, &apply_s2, &apply_s3,
-                             &rowdot_axpy,      &update_gram,     &update_s2, &final_sweep, &occupancy};
+                             &rowdot_axpy,      &update_gram,     &update_s2, &colreduce4, &rowdot_axpy4,
+                             &final_sweep,      &occupancy};
     return &o;
   }
 };

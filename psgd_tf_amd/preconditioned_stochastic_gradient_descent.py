@@ -26,6 +26,7 @@ The reference draws its two branch decisions (psgd.py:562, :588) from TensorFlow
 global RNG; here they come from a torch.Generator (module default, or ``generator=``)
 or are fixed through the keyword-only ``balance=`` / ``update_U=`` arguments.
 """
+import ctypes
 import math
 
 import torch
@@ -210,10 +211,26 @@ def precond_grad_splu(L12, l3, U12, u3, grads):
 # --------------------------------------------------------------------------- UVd math
 def IpUVtmatvec(U, V, x):
     """psgd.py:540-544: (I + U V') x for a column vector x ([N] or [N,1]) or [N,k] matrix."""
-    dev = _require_hip("IpUVtmatvec", U, V, x)
     if x.dim() == 2 and x.shape[1] > 1:
-        cols = [IpUVtmatvec(U, V, x[:, j].contiguous()) for j in range(x.shape[1])]
-        return torch.stack(cols, 1)
+        # a matrix x: its columns go through as contiguous vectors (two small transposes, N k floats each), U and V are
+        # swept once per group of four columns
+        dev = _require_hip("IpUVtmatvec", U, V)
+        if not x.is_cuda or x.dtype != torch.float32:
+            _require_hip("IpUVtmatvec", x)
+        N, r = _uvd_shapes("IpUVtmatvec", U, V)
+        if x.shape[0] != N:
+            raise ValueError("IpUVtmatvec: x must have N = %d rows" % N)
+        k = x.shape[1]
+        xt = x.t().contiguous()
+        ot = torch.empty_like(xt)
+        ws = uvd_workspace(dev, N, r)
+        xs = (ctypes.c_void_p * k)(*[xt[j].data_ptr() for j in range(k)])
+        os_ = (ctypes.c_void_p * k)(*[ot[j].data_ptr() for j in range(k)])
+        rc = _lib.load().psgd_uvd_ipuvt_matvec_cols_f32(U.data_ptr(), V.data_ptr(), xs, os_, k, N, r, ws.data_ptr(),
+                                                         ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "psgd_uvd_ipuvt_matvec_cols_f32")
+        return ot.t().contiguous()
+    dev = _require_hip("IpUVtmatvec", U, V, x)
     N, r = _uvd_shapes("IpUVtmatvec", U, V, x)
     out = torch.empty_like(x)
     ws = uvd_workspace(dev, N, r)
@@ -346,9 +363,18 @@ class UVd:
         self._params_with_grad = [p for p in params if p.requires_grad]                      # :670
         p0 = self._params_with_grad[0]
         self._dtype = p0.dtype                                                               # :671
-        if self._dtype != torch.float32:
-            raise TypeError("UVd: the HIP engine computes in fp32 only")
+        if self._dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            raise TypeError("UVd: parameters must be float32, float16 or bfloat16, got %s" % self._dtype)
+        # psgd.py:657-658 allows half-precision parameters.  The preconditioner state U, V, d and all of its arithmetic
+        # stay fp32 here (mixed precision: the HIP kernels compute in fp32; v, Hv and the gradient are widened on the
+        # way in, the preconditioned gradient is narrowed on the way out).  _tiny and the finite-difference scale follow
+        # the parameter dtype as in the reference (:682-683).
+        self._state_dtype = torch.float32
         self._device = p0.device
+        r = int(rank_of_modification)
+        if not 1 <= r <= _lib.UVD_MAX_RANK:
+            raise ValueError("UVd: rank_of_modification must be in [1, %d] for the HIP kernels, got %d"
+                             % (_lib.UVD_MAX_RANK, r))
         self.lr_params = _Hyper(lr_params)                                                   # :673
         self.lr_preconditioner = _Hyper(lr_preconditioner)                                   # :674
         self.grad_clip_max_norm = _Hyper(math.inf if grad_clip_max_norm is None else grad_clip_max_norm)  # :675-678
@@ -358,12 +384,12 @@ class UVd:
         self._delta_param_scale = torch.finfo(self._dtype).eps ** 0.5                        # :683
         self._param_sizes, self._param_cumsizes = uvd_param_index(self._params_with_grad)    # :684-685
         num_params = self._param_cumsizes[-1]                                                # :686
-        r = int(rank_of_modification)
         uv_scale = (1.0 / (num_params * r)) ** 0.5                                           # :687
         self._generator = generator
-        self._U = torch.randn(num_params, r, dtype=self._dtype, device=self._device) * uv_scale      # :688
-        self._V = torch.randn(num_params, r, dtype=self._dtype, device=self._device) * uv_scale      # :689
-        self._d = torch.ones(num_params, 1, dtype=self._dtype, device=self._device) * preconditioner_init_scale  # :690
+        sd = self._state_dtype
+        self._U = torch.randn(num_params, r, dtype=sd, device=self._device) * uv_scale       # :688
+        self._V = torch.randn(num_params, r, dtype=sd, device=self._device) * uv_scale       # :689
+        self._d = torch.ones(num_params, 1, dtype=sd, device=self._device) * preconditioner_init_scale  # :690
 
     def _loss_of(self, closure_returns):
         return closure_returns if isinstance(closure_returns, torch.Tensor) else closure_returns[0]
@@ -394,13 +420,13 @@ class UVd:
                 with torch.enable_grad():
                     perturbed_grads = torch.autograd.grad(self._loss_of(closure()), params)
                 Hvs = [pg - g for pg, g in zip(perturbed_grads, grads)]
-            v = torch.cat([torch.reshape(x, [-1]) for x in vs], 0)                            # :729
-            h = torch.cat([torch.reshape(x, [-1]) for x in Hvs], 0)                           # :730
+            v = torch.cat([torch.reshape(x, [-1]) for x in vs], 0).to(self._state_dtype)      # :729
+            h = torch.cat([torch.reshape(x, [-1]) for x in Hvs], 0).to(self._state_dtype)     # :730
             if not exact:                                                                     # :734-736
                 v = v / self._delta_param_scale
                 h = h / self._delta_param_scale
-            grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0)                      # :747
-            # :732-733 then :748 as one fused call (same results, one pass over V less)
+            grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0).to(self._state_dtype)    # :747
+            # :732-733 then :748 as one fused call (same results, three sweeps instead of six)
             pre_grad = update_precond_UVd_math_and_precond_grad(
                 self._U, self._V, self._d, v[:, None].contiguous(), h[:, None].contiguous(),
                 grad[:, None].contiguous(), step=float(self.lr_preconditioner), tiny=self._tiny,
@@ -409,7 +435,7 @@ class UVd:
             with torch.enable_grad():
                 closure_returns = closure()
                 grads = torch.autograd.grad(self._loss_of(closure_returns), params)
-            grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0)                      # :747
+            grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0).to(self._state_dtype)    # :747
             pre_grad = precond_grad_UVd_math(self._U, self._V, self._d, grad[:, None].contiguous())   # :748
         max_norm = float(self.grad_clip_max_norm)
         if math.isinf(max_norm):                                                              # :750-751
@@ -420,7 +446,7 @@ class UVd:
         with torch.no_grad():                                                                 # :757-762
             undo = (not exact) and update_Q
             for k, (p, i, j) in enumerate(zip(params, self._param_sizes, self._param_cumsizes)):
-                delta = lr * torch.reshape(pre_grad[j - i:j], p.shape)
+                delta = (lr * torch.reshape(pre_grad[j - i:j], p.shape)).to(p.dtype)
                 if undo:
                     delta = delta + vs[k]
                 p.sub_(delta)

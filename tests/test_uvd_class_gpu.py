@@ -122,3 +122,56 @@ def test_no_update_branch_leaves_preconditioner_alone(hip_lib):
     U0, V0, d0 = opt._U.clone(), opt._V.clone(), opt._d.clone()
     opt.step(lambda: [_loss(params, x, y), "aux"])                         # closure may return a list (psgd.py:711)
     assert torch.equal(opt._U, U0) and torch.equal(opt._V, V0) and torch.equal(opt._d, d0)
+
+
+@pytest.mark.parametrize("pdtype", [torch.bfloat16, torch.float16])
+def test_half_precision_parameters(hip_lib, pdtype):
+    """psgd.py:657-658: half-precision parameters are allowed.  Here: parameters, gradients and v, Hv in the half type,
+    the preconditioner state and its arithmetic in fp32 (the kernels' type).  A convex quadratic goes down, the state
+    stays fp32 and finite, _tiny / the FD scale follow the parameter type (:682-683), and one step equals the oracle's
+    update + apply on the same widened (v, h, g)."""
+    import preconditioned_stochastic_gradient_descent as psgd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    A = (torch.randn(48, 48, device=dev) * 0.2)
+    H = (A @ A.t() + 0.5 * torch.eye(48, device=dev)).to(pdtype)
+    w = (torch.randn(48, 1, device=dev)).to(pdtype).requires_grad_(True)
+    b = (torch.randn(7, device=dev)).to(pdtype).requires_grad_(True)
+    closure = lambda: 0.5 * (w.t() @ H @ w).sum() + 0.5 * (b * b).sum()
+    opt = psgd.UVd([w, b], rank_of_modification=5, lr_params=0.05, lr_preconditioner=0.05,
+                   generator=torch.Generator().manual_seed(1))
+    assert opt._U.dtype == torch.float32 and opt._d.dtype == torch.float32
+    assert opt._tiny == float(torch.finfo(pdtype).tiny) and opt._delta_param_scale == float(torch.finfo(pdtype).eps) ** 0.5
+    # one step replayed through the oracle
+    U0, V0, d0 = (t.cpu().numpy().astype(np.float64) for t in (opt._U, opt._V, opt._d))
+    seen = {}
+    w0 = w.detach().clone()
+    import psgd_tf_amd.preconditioned_stochastic_gradient_descent as impl
+    impl_orig = impl.update_precond_UVd_math_and_precond_grad
+    impl.update_precond_UVd_math_and_precond_grad = lambda *a, **k: _record(impl_orig, seen, *a, **k)
+    try:
+        loss0 = float(opt.step(closure).detach())
+    finally:
+        impl.update_precond_UVd_math_and_precond_grad = impl_orig
+    assert seen["v"].dtype == torch.float32 and seen["g"].dtype == torch.float32
+    f = lambda t: t.cpu().numpy().astype(np.float64)
+    # the branch the step drew: U changed or V changed
+    upd_U = not torch.equal(opt._U.cpu(), torch.from_numpy(U0.astype(np.float32)))
+    orc.update_precond_UVd_math_(U0, V0, d0, f(seen["v"]), f(seen["h"]), 0.05, opt._tiny, balance=False, update_U=upd_U)
+    want = orc.precond_grad_UVd_math(U0, V0, d0, f(seen["g"]))
+    assert rel_err(f(seen["out"]), want) < 1e-5
+    assert rel_err(f(opt._d), d0) < 1e-5
+    # parameters moved by lr * pre_grad; the subtraction rounds to the half type (ulp(1) / step = 8 % per element in
+    # bf16, 1 % in fp16), so this only has to catch a wrong slice or sign
+    step_w = (w0.float() - w.detach().float()).cpu().numpy()
+    assert rel_err(step_w, 0.05 * want[:48].reshape(48, 1)) < (0.15 if pdtype == torch.bfloat16 else 0.03)
+    for _ in range(60):
+        loss = float(opt.step(closure).detach())
+    assert loss < 0.5 * loss0 and math.isfinite(loss)
+    assert torch.isfinite(opt._U).all() and torch.isfinite(opt._d).all() and w.dtype == pdtype
+
+
+def _record(fn, seen, U, V, d, v, h, g, **kw):
+    out = fn(U, V, d, v, h, g, **kw)
+    seen.update(v=v.clone(), h=h.clone(), g=g.clone(), out=out.clone())
+    return out

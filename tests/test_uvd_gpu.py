@@ -53,17 +53,28 @@ def test_precond_grad_matches_oracle(psgd, N, r, uv_gain, d_spread):
         assert np.array_equal(t[k].cpu().numpy(), p[k])
 
 
-@pytest.mark.parametrize("N,r", [(1021, 10), (5000, 20), (777, 3), (2049, 32)])
+@pytest.mark.parametrize("N,r", [(1021, 10), (5000, 20), (777, 3), (2049, 32), (300001, 10), (64, 1)])
 def test_ipuvt_matvec(psgd, N, r):
-    p = make_uvd_problem(N, r, seed=7)
+    p = make_uvd_problem(N, r, seed=7, uv_gain=3.0 * r ** 0.5)
     t = _to_dev(p)
     out = psgd.IpUVtmatvec(t["U"], t["V"], t["g"])
     q = _f64(p)
     assert rel_err(out.cpu().numpy(), orc.IpUVtmatvec(q["U"], q["V"], q["g"])) < APPLY_TOL
-    x2 = torch.stack([t["g"][:, 0], t["v"][:, 0]], 1).contiguous()
-    out2 = psgd.IpUVtmatvec(t["U"], t["V"], x2)
-    ref2 = orc.IpUVtmatvec(q["U"], q["V"], np.concatenate([q["g"], q["v"]], 1))
-    assert rel_err(out2.cpu().numpy(), ref2) < APPLY_TOL
+    # a matrix x (psgd.py:542): k columns in one sweep of V and one of U per group of four columns
+    cols = [q["g"], q["v"], q["h"] * 1e-2, q["g"] - q["v"], q["d"], q["g"] * q["v"]]
+    for k in (2, 4, 5, 6):
+        xk64 = np.concatenate(cols[:k], 1)
+        xk = torch.from_numpy(xk64.astype(np.float32)).cuda()
+        outk = psgd.IpUVtmatvec(t["U"], t["V"], xk)
+        assert outk.shape == (N, k) and outk.is_contiguous()
+        refk = orc.IpUVtmatvec(q["U"], q["V"], xk.cpu().numpy().astype(np.float64))
+        assert rel_err(outk.cpu().numpy(), refk) < APPLY_TOL, k
+        for j in range(k):                                   # every column on its own, not only the norm of the block
+            assert rel_err(outk[:, j].cpu().numpy(), refk[:, j]) < APPLY_TOL, (k, j)
+    # a transposed view as input (non-contiguous columns) is fine too
+    xv = torch.from_numpy(np.concatenate(cols[:4], 1).astype(np.float32).T.copy()).cuda().t()
+    assert rel_err(psgd.IpUVtmatvec(t["U"], t["V"], xv).cpu().numpy(),
+                   orc.IpUVtmatvec(q["U"], q["V"], xv.cpu().numpy().astype(np.float64))) < APPLY_TOL
 
 
 @pytest.mark.parametrize("N,r", SHAPES)
