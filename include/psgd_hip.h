@@ -312,7 +312,8 @@ int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
 /* Experiment knob (not stable ABI). key 0: bf16 GEMM variant: 0 auto (256^2 8-phase kernel for large dense
  * products, fused triangular pair when every 256^2 tile gets its own CU, 128^2 register-staged otherwise);
  * 1 128^2 register-staged everywhere; 2 128^2 LDS-DMA ring; 3 256^2 for every product; 4 auto without the fused pair.
- * key 1: 1 (default) two fused triangular pairs, (G Qr') Qr then Ql' (Ql .), where legal; 0 keep the Gram-first chain. */
+ * key 1: 1 (default) two fused triangular pairs, (G Qr') Qr then Ql' (Ql .), where legal; 0 keep the Gram-first chain.
+ * key 2: log2 of the hand-off poll bound of the fused pair (default 22 ~ 0.5 s; tests set 0 to provoke time-outs). */
 int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,
@@ -326,9 +327,15 @@ int64_t psgd_kron_dd_update_workspace_bytes_bf16(int M, int N);
 int psgd_kron_dd_update_bf16(const float *Ql, const float *Qr, const void *dX_bf16, const void *dG_bf16,
                              float *QlOut, float *QrOut, int M, int N, float step, float tiny,
                              void *ws, int64_t ws_bytes, void *stream);
-/* Debug aid (synchronises): 1 if a bounded spin of the fused triangular pair of the last bf16 apply on this
- * workspace gave up (a block was not resident), else 0.  The apply's result is invalid in that case.          */
+/* The fused triangular pairs of the bf16 apply hand tiles between workgroups inside one launch and need every
+ * workgroup of the launch resident (checked against the CU count -- which cannot see other streams or processes on
+ * the GPU).  A workgroup that has to wait for a CU only delays its consumers (bounded spin, ~0.5 s).  If the bound is
+ * hit the consumer stores NaN to its whole output tile and raises a STICKY word in the workspace: the call's result is
+ * loudly wrong, never finite garbage.  psgd_kron_bf16_handoff_timeouts (synchronises: call it at a point where the
+ * host waits anyway) returns 1 if that ever happened on this workspace since it was created or reset.  A fresh
+ * workspace must be reset once before its first use (the word lives in caller-owned memory).                        */
 int psgd_kron_bf16_handoff_timeouts(const void *ws, int M, int N);
+int psgd_kron_bf16_handoff_reset(void *ws, int M, int N, void *stream);
 
 #ifdef __cplusplus
 }

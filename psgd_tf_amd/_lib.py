@@ -90,6 +90,7 @@ SIGNATURES = {
     "psgd_kron_bf16_set_tuning": (_int, [_int, _int]),
     "psgd_kron_dd_workspace_bytes_bf16": (_i64, [_int, _int]),
     "psgd_kron_bf16_handoff_timeouts": (_int, [_c_ws, _int, _int]),
+    "psgd_kron_bf16_handoff_reset": (_int, [_c_ws, _int, _int, _strm]),
     "psgd_kron_dd_update_workspace_bytes_bf16": (_i64, [_int, _int]),
     "psgd_kron_dd_update_bf16": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _flt, _flt,
                                         _c_ws, _i64, _strm]),

@@ -676,7 +676,11 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
 // agent-scope atomic; the consumer polls that one word (one lane, relaxed, bounded), does ONE agent-scope acquire,
 // drains, and the whole block passes a barrier before any wave issues a load of the handed-off bytes.  Flags are
 // zeroed before every launch (by the factor-conversion kernel that opens the call).  All blocks must be resident (grid <= number of CUs, one block per CU:
-// checked by the launcher); every spin is bounded and reports through a timeout word.
+// checked by the launcher).  That check cannot see other streams or processes: a block of this launch may have to wait
+// for a CU.  Its consumers then spin until it has run (~0.5 s bound).  If the bound is hit -- the producer never ran --
+// the consumer does NOT go on with bytes that were never published: it raises the STICKY timeout word (never cleared
+// by the library; psgd_kron_bf16_handoff_timeouts reads it) and stores NaN to its whole output tile, so the result of
+// such a call is loudly wrong, never finite garbage.
 struct HPairArgs {
   const uint16_t* A1; long lda1;   // Ql  [M][M]   (k >= m)
   const uint16_t* B1; long ldb1;   // T2' [N][M]
@@ -686,12 +690,15 @@ struct HPairArgs {
   int M, N;                        // M = the triangular factor's dimension (tile rows), N = the other one
   int c_begin, c_count;            // tile columns of this launch (hand-offs stay inside a column)
   unsigned* flags;                 // [M/256][N/256], zeroed before the launch
-  unsigned* timeout;               // set to 1 if a spin gave up
+  unsigned* timeout;               // sticky: set to 1 if a spin gave up (the block's output tile is then NaN)
+  unsigned spin_limit;             // polls before giving up (2^22 x ~64 cycles ~ 0.5 s; tests shrink it)
 };
 
 __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];
+  __shared__ int poisoned;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) poisoned = 0;                              // ordered before its first reader by the barriers of phase A
   const int tiles_m = p.M / T2, tiles_n = p.N / T2;
   // blocks b, b + 8, ... share an XCD: give each XCD whole tile columns (the hand-offs of a column stay on one L2
   // when the column count allows); rows ascend with the block index inside a column
@@ -757,7 +764,11 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
           unsigned spins = 0;
           while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 22)) { __hip_atomic_store(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > p.spin_limit) {
+              __hip_atomic_store(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              poisoned = 1;                                // read by every wave after the barrier below
+              break;
+            }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -769,6 +780,13 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
     };
     // the first chunk is this block's own tile: its stores were drained before the barrier above
     hg256_mainloop(acc, lds, (r + 1) * 4, w, lane, src, pre);
+  }
+  if (poisoned) {                                          // a tile of T3 was never published: no finite garbage
+    const float qnan = __uint_as_float(0x7fc00000u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{qnan, qnan, qnan, qnan};
   }
   hg256_store<false>(acc, p.out, p.ldo, p.out_bf16, p.out_trans, m0, n0, w, lane);
 }
@@ -879,6 +897,7 @@ static HWs hws_layout(char* base, int M, int N) {
 }
 
 static int g_two_pairs = 1;       // tuning key 1: 0 = keep the Gram-first chain even where two fused pairs are possible
+static unsigned g_spin_limit = 1u << 22;   // psgd_kron_bf16_set_tuning key 2 (log2): hand-off polls before a consumer gives up
 static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, fused triangular pair when every
                                   //    tile gets its own CU, else 128^2 register-staged); 4: auto without the fused pair;
                                   // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
@@ -970,7 +989,7 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
   for (int c0 = 0; c0 < tiles_n; c0 += cpl) {
     const int cc = (tiles_n - c0 < cpl) ? tiles_n - c0 : cpl;
     HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, c0, cc,
-                   k.flags + 4 + flag_set * tiles_m * tiles_n, k.flags};
+                   k.flags + 4 + flag_set * tiles_m * tiles_n, k.flags, g_spin_limit};
     hipLaunchKernelGGL(k_hgemm_tri_pair_256, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
     if (hipGetLastError() != hipSuccess) return 1;
   }
@@ -1032,7 +1051,8 @@ static HUpdWs hupd_layout(char* base, int M, int N) {
 static int launch_factors_cvt(const HWs& k, FactorJob j0, FactorJob j1, hipStream_t st) {
   const int n = j0.n > j1.n ? j0.n : j1.n;
   dim3 grid((n + 63) / 64, (n + 63) / 64, 2);
-  hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, j0, j1, k.flags, (int)(k.flag_bytes / 4));
+  // words 0..3 of k.flags: the sticky timeout word (+ padding), never cleared here; the flag sets behind them are
+  hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, j0, j1, k.flags + 4, (int)(k.flag_bytes / 4) - 4);
   return (int)hipGetLastError();
 }
 
@@ -1050,6 +1070,7 @@ extern "C" {
 int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 0) { g_hgemm_variant = value; return PSGD_OK; }
   if (key == 1) { g_two_pairs = value; return PSGD_OK; }
+  if (key == 2) { g_spin_limit = (value < 0 || value > 30) ? (1u << 22) : (1u << value); return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -1059,6 +1080,13 @@ int psgd_kron_bf16_handoff_timeouts(const void* ws, int M, int N) {
   unsigned v = 0;
   if (hipMemcpy(&v, k.flags, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return PSGD_ERR_LAUNCH;
   return (int)v;
+}
+
+int psgd_kron_bf16_handoff_reset(void* ws, int M, int N, void* stream) {
+  if (!ws || M <= 0 || N <= 0) return PSGD_ERR_BAD_ARG;
+  HWs k = hws_layout(static_cast<char*>(ws), M, N);
+  if (hipMemsetAsync(k.flags, 0, 16, static_cast<hipStream_t>(stream)) != hipSuccess) return PSGD_ERR_LAUNCH;
+  return PSGD_OK;
 }
 
 int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N) {
@@ -1088,7 +1116,8 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
     int rc2 = rc1 ? rc1 : launch_tri_pair(k, k.Ql, k.QlT, k.T2, k.T3, out, N, 0, M, N, st, 1);
     if (rc1 == 0 && rc2 == 0) return PSGD_OK;
     if (rc1 == 1 || rc2 == 1) return PSGD_ERR_LAUNCH;
-    // not resident-able (2): fall through to the staged chain below (nothing was launched besides the conversions)
+    // not resident-able (2): fall through to the staged chain below, which recomputes everything from G (a first pair
+    // that did run only wrote the scratch buffers T2, T3)
   }
   if (M < N) {                                                                     // psgd.py:189-190
     HK(launch_factors_cvt(k, FactorJob{Ql, nullptr, k.QlT, M}, FactorJob{Qr, k.Qr, k.QrT, N}, st));

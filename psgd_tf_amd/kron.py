@@ -124,6 +124,27 @@ def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
     return QlO, QrO
 
 
+_bf16_apply_shapes = {}
+
+
+def check_bf16_handoffs():
+    """Raise if a fused triangular pair of any bf16 precond_grad_kron call so far gave up waiting for a workgroup that
+    never became resident (possible only when other streams or processes hold CUs for ~0.5 s while the call runs; the
+    output tiles affected are NaN).  Synchronises with the device: call it where the host waits anyway -- the end of a
+    step, before a checkpoint."""
+    for key, (M, N) in list(_bf16_apply_shapes.items()):
+        if key in _kron_ws_bf16:
+            ws = _kron_ws_bf16[key]
+            rc = _lib.load().psgd_kron_bf16_handoff_timeouts(ws.data_ptr(), M, N)
+            if rc < 0:
+                _lib.check(rc, "psgd_kron_bf16_handoff_timeouts")
+            if rc:
+                raise _lib.PsgdHipError("precond_grad_kron (bf16, %d x %d): a tile hand-off of the fused triangular pair timed "
+                                        "out; the result of that call holds NaN tiles.  The device was shared with other "
+                                        "work; psgd_kron_bf16_set_tuning(0, 4) selects the kernels without in-launch "
+                                        "hand-offs." % (M, N))
+
+
 def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     """psgd.py:182-192 with bf16 MFMA operands (Grad and result in bf16, fp32 master factors)."""
     M, N = Grad.shape
@@ -132,8 +153,14 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
     out = torch.empty_like(Grad)
     key = (Grad.device.index, M, N, _stream_key(Grad.device))
-    ws = _kron_ws_bf16.get(key, lambda: torch.empty(int(_lib.load().psgd_kron_dd_workspace_bytes_bf16(M, N)),
-                                                      dtype=torch.uint8, device=Grad.device))
+
+    def make():
+        ws = torch.empty(int(_lib.load().psgd_kron_dd_workspace_bytes_bf16(M, N)), dtype=torch.uint8, device=Grad.device)
+        _lib.check(_lib.load().psgd_kron_bf16_handoff_reset(ws.data_ptr(), M, N, _stream_key(Grad.device)),
+                   "psgd_kron_bf16_handoff_reset")
+        _bf16_apply_shapes[key] = (M, N)
+        return ws
+    ws = _kron_ws_bf16.get(key, make)
     rc = _lib.load().psgd_kron_dd_apply_bf16(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
                                               ws.data_ptr(), ws.numel(),
                                               torch.cuda.current_stream(Grad.device).cuda_stream)

@@ -232,11 +232,58 @@ def test_bf16_fused_triangular_pair(psgd, M, N):
                         if first is None:
                             first = got
                         assert torch.equal(got, first), (two_pairs, rep)
-            ws = kron._kron_ws_bf16[(Ql.device.index, M, N)]
-            assert lib.psgd_kron_bf16_handoff_timeouts(ws.data_ptr(), M, N) == 0
+            kron.check_bf16_handoffs()                      # raises if any spin ever timed out
     finally:
         lib.psgd_kron_bf16_set_tuning(0, 0)
         lib.psgd_kron_bf16_set_tuning(1, 1)
+
+
+def test_bf16_fused_pair_on_a_shared_device(psgd):
+    """The fused pair needs its workgroups resident; the launcher can only check that against the CU count, not against
+    other streams.  (a) With a second stream keeping the CUs busy (large fp32 GEMMs) the calls must still give the
+    idle-device result bit for bit -- late workgroups only delay their consumers.  (b) When a consumer does give up
+    (provoked here by a poll bound of 1), the result must be loudly wrong and the condition reported: NaN tiles, a sticky
+    word, and check_bf16_handoffs() raises -- never finite garbage."""
+    from psgd_tf_amd import _lib, kron
+    lib = _lib.load()
+    M = N = 4096
+    rng = np.random.default_rng(7)
+    Ql, Qr = _dev(_tri_factor(rng, M, 0.01).astype(np.float32)), _dev(_tri_factor(rng, N, 0.01).astype(np.float32))
+    G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16)
+    want = psgd.precond_grad_kron(Ql, Qr, G)
+    torch.cuda.synchronize()
+    kron.check_bf16_handoffs()
+    # (a) contention
+    side = torch.cuda.Stream()
+    A = torch.randn(8192, 8192, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(40):                                 # ~0.3 s of GEMMs that fill every CU
+            A = torch.mm(A, A) * 1e-4
+    outs = [psgd.precond_grad_kron(Ql, Qr, G) for _ in range(30)]
+    torch.cuda.synchronize()
+    kron.check_bf16_handoffs()
+    for o in outs:
+        assert torch.equal(o, want)
+    # (b) a consumer that gives up
+    try:
+        assert lib.psgd_kron_bf16_set_tuning(2, 0) == 0
+        bad = [psgd.precond_grad_kron(Ql, Qr, G) for _ in range(5)]
+        torch.cuda.synchronize()
+    finally:
+        lib.psgd_kron_bf16_set_tuning(2, 22)
+    gave_up = any(bool(torch.isnan(o.float()).any()) for o in bad)
+    for o in bad:                                           # every tile is either right or NaN
+        ok = torch.isnan(o.float()) | (o == want)
+        assert bool(ok.all())
+    if gave_up:
+        with pytest.raises(_lib.PsgdHipError, match="hand-off"):
+            kron.check_bf16_handoffs()
+        for key, (m, n) in kron._bf16_apply_shapes.items():          # clear the sticky word for the tests that follow
+            if key in kron._kron_ws_bf16:
+                lib.psgd_kron_bf16_handoff_reset(kron._kron_ws_bf16[key].data_ptr(), m, n, None)
+        torch.cuda.synchronize()
+    kron.check_bf16_handoffs()
+    assert torch.equal(psgd.precond_grad_kron(Ql, Qr, G), want)
 
 
 @pytest.mark.parametrize("M,N", [(512, 384), (1100, 530), (640, 256), (1024, 1536), (48, 1040)])

@@ -26,8 +26,11 @@ while time.time() - t0 < budget:
     Ql, Qr = state[(M, N)]
     G = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
     outs = [psgd.precond_grad_kron(Ql, Qr, G) for _ in range(8)]          # back to back, same operands
-    ws = kron._kron_ws_bf16[(dev.index, M, N)]
-    timeouts += lib.psgd_kron_bf16_handoff_timeouts(ws.data_ptr(), M, N)
+    try:
+        torch.cuda.synchronize()
+        kron.check_bf16_handoffs()
+    except _lib.PsgdHipError:
+        timeouts += 1
     lib.psgd_kron_bf16_set_tuning(0, 1)                                   # staged chain on the 128^2 kernel: no hand-offs
     ref = psgd.precond_grad_kron(Ql, Qr, G)
     lib.psgd_kron_bf16_set_tuning(0, 0)
