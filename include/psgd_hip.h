@@ -318,6 +318,13 @@ int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,
                             int64_t ws_bytes, void *stream);
+/* The same call in two halves.  The bf16 copies of the factors (plain and transposed, kept in ws) change only when
+ * the factors do -- after update_precond_kron -- so a caller that applies the same factors to several gradients
+ * prepares once: psgd_kron_dd_apply_bf16 == psgd_kron_bf16_prepare_factors + psgd_kron_dd_apply_bf16_prepared.      */
+int psgd_kron_bf16_prepare_factors(const float *Ql, const float *Qr, int M, int N, void *ws,
+                                   int64_t ws_bytes, void *stream);
+int psgd_kron_dd_apply_bf16_prepared(const void *G_bf16, void *out_bf16, int M, int N, void *ws,
+                                     int64_t ws_bytes, void *stream);
 /* bf16-operand variant of _update_precond_dense_dense (psgd.py:156-180), the update-side companion of the entry
  * point above (same contract: outside the reference's fp32-only API, M and N multiples of 8, upper-triangular fp32
  * master factors in, fp32 updated factors out; dX, dG are bf16 [M,N]).  fp32 throughout: the balance (:166-170), the

@@ -95,6 +95,8 @@ SIGNATURES = {
     "psgd_kron_dd_update_bf16": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _flt, _flt,
                                         _c_ws, _i64, _strm]),
     "psgd_kron_dd_apply_bf16": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_bf16_prepare_factors": (_int, [_c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_apply_bf16_prepared": (_int, [_c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
     "psgd_kron_dd_update_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _flt, _flt,
                                        _c_ws, _i64, _strm]),
 }

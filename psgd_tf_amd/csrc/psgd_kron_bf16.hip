@@ -1051,8 +1051,7 @@ static HUpdWs hupd_layout(char* base, int M, int N) {
 static int launch_factors_cvt(const HWs& k, FactorJob j0, FactorJob j1, hipStream_t st) {
   const int n = j0.n > j1.n ? j0.n : j1.n;
   dim3 grid((n + 63) / 64, (n + 63) / 64, 2);
-  // words 0..3 of k.flags: the sticky timeout word (+ padding), never cleared here; the flag sets behind them are
-  hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, j0, j1, k.flags + 4, (int)(k.flag_bytes / 4) - 4);
+  hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, j0, j1, static_cast<unsigned*>(nullptr), 0);
   return (int)hipGetLastError();
 }
 
@@ -1094,22 +1093,41 @@ int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N) {
   return hws_layout(nullptr, M, N).total;
 }
 
-int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, void* out, int M, int N, void* ws,
-                            int64_t ws_bytes, void* stream) {
-  if (!Ql || !Qr || !G || !out) return PSGD_ERR_BAD_ARG;
+static int bf16_apply_check(int M, int N, void* ws, int64_t ws_bytes) {
   if (M <= 0 || N <= 0 || (M % 8) || (N % 8)) return PSGD_ERR_SHAPE;   // 16-byte bf16 chunks along K
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < hws_layout(nullptr, M, N).total)
     return PSGD_ERR_WORKSPACE;
+  return PSGD_OK;
+}
+
+/* bf16 copies of the fp32 master factors, plain and transposed, into the workspace (one launch; only the 256-blocks on
+ * or above the diagonal are touched).  They change only when the factors do, so a caller that applies the same
+ * factors repeatedly prepares once and then calls psgd_kron_dd_apply_bf16_prepared. */
+int psgd_kron_bf16_prepare_factors(const float* Ql, const float* Qr, int M, int N, void* ws, int64_t ws_bytes,
+                                   void* stream) {
+  if (!Ql || !Qr) return PSGD_ERR_BAD_ARG;
+  const int rc = bf16_apply_check(M, N, ws, ws_bytes);
+  if (rc) return rc;
+  HWs k = hws_layout(static_cast<char*>(ws), M, N);
+  HK(launch_factors_cvt(k, FactorJob{Qr, k.Qr, k.QrT, N}, FactorJob{Ql, k.Ql, k.QlT, M}, static_cast<hipStream_t>(stream)));
+  return PSGD_OK;
+}
+
+int psgd_kron_dd_apply_bf16_prepared(const void* G, void* out, int M, int N, void* ws, int64_t ws_bytes, void* stream) {
+  if (!G || !out) return PSGD_ERR_BAD_ARG;
+  const int rc = bf16_apply_check(M, N, ws, ws_bytes);
+  if (rc) return rc;
   if ((reinterpret_cast<uintptr_t>(G) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return PSGD_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   HWs k = hws_layout(static_cast<char*>(ws), M, N);
   const uint16_t* Gb = static_cast<const uint16_t*>(G);
+  // hand-off flags of the fused pairs: zero before every call (the sticky word in front of them stays)
+  if (hipMemsetAsync(k.flags + 4, 0, (size_t)k.flag_bytes - 16, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   if (pair_legal(M, N) && g_two_pairs) {
     // Two fused triangular pairs and no Gram:  out = Ql' (Ql ((G Qr') Qr)).  Same product as psgd.py:189-192 with the
     // Gram Qr'Qr (resp. Ql'Ql) re-associated into the chain: (G Qr') Qr costs the flops of the dense G (Qr'Qr) alone,
     // and both halves have the complementary-K structure the wavefront kernel balances.  bf16 path only (one bf16
     // rounding moves from the Gram to G Qr'); the fp32 path keeps the reference's association order.
-    HK(launch_factors_cvt(k, FactorJob{Qr, k.Qr, k.QrT, N}, FactorJob{Ql, k.Ql, k.QlT, M}, st));
     // right pair: Y' [N][M] = ((G Qr') Qr)'   -- triangular factor Qr as the A operand, G [M][N] the K-contiguous B operand
     int rc1 = launch_tri_pair(k, k.Qr, k.QrT, Gb, k.T3, k.T2, M, 0, N, M, st, 0);
     // left pair: out [M][N] = Ql' (Ql Y)      -- B operand Y' [N][M]
@@ -1120,7 +1138,6 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
     // that did run only wrote the scratch buffers T2, T3)
   }
   if (M < N) {                                                                     // psgd.py:189-190
-    HK(launch_factors_cvt(k, FactorJob{Ql, nullptr, k.QlT, M}, FactorJob{Qr, k.Qr, k.QrT, N}, st));
     HK(launch_cvt(G, 1, N, k.GT, M, M, N, 1, st));
     // T1 = Ql'Ql              A = Ql' [M][K=M], Bt = Ql' ; k <= min(m, n); symmetric: upper tiles computed, stored twice
     HK(launch_hgemm(k.QlT, M, k.QlT, M, k.T1, M, 1, 0, M, M, M, KHI_M | KHI_N, st, 1));
@@ -1138,7 +1155,6 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
       HK(launch_hgemm(k.T3, N, k.QrT, N, out, N, 1, 0, M, N, N, KHI_N, st));
     }
   } else {                                                                         // psgd.py:191-192
-    HK(launch_factors_cvt(k, FactorJob{Qr, nullptr, k.QrT, N}, FactorJob{Ql, k.Ql, k.QlT, M}, st));
     // T1 = Qr'Qr  (symmetric, so it is its own Bt layout; upper tiles computed, stored twice)
     HK(launch_hgemm(k.QrT, N, k.QrT, N, k.T1, N, 1, 0, N, N, N, KHI_M | KHI_N, st, 1));
     // T2 = G T1               A = G [M][K=N], Bt = T1' = T1 ; stored transposed: T2' [N][M]
@@ -1153,6 +1169,15 @@ int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, voi
     }
   }
   return PSGD_OK;
+}
+
+/* _precond_grad_dense_dense with bf16 operands: prepare the factor copies, then apply. */
+int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, void* out, int M, int N, void* ws,
+                            int64_t ws_bytes, void* stream) {
+  if (!Ql || !Qr || !G || !out) return PSGD_ERR_BAD_ARG;
+  const int rc = psgd_kron_bf16_prepare_factors(Ql, Qr, M, N, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return psgd_kron_dd_apply_bf16_prepared(G, out, M, N, ws, ws_bytes, stream);
 }
 
 int64_t psgd_kron_dd_update_workspace_bytes_bf16(int M, int N) {

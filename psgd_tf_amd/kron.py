@@ -6,6 +6,8 @@ factors, psgd.py:198-391) are reachable through the same two public
 points and run in HIP as well: elementwise / reduction kernels for the sparse half, the same
 MFMA GEMM and triangular solve for the dense half of a mixed format.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -86,12 +88,38 @@ def _require_hip(name, *tensors):
             raise _lib.PsgdHipError("%s runs on the HIP device only (tensor is on %s); no CPU fallback" % (name, t.device))
 
 
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _padded_bf16_problem(Ql, Qr, mats):
+    """The bf16 kernels move 16-byte chunks (8 elements) along every K axis.  Other shapes run zero-padded to the next
+    multiple of 8: factors become blockdiag(Q, tiny I) (the smallest positive normal on the new diagonal keeps the
+    padded factor triangular and invertible and cannot win the max of psgd.py:166-167), data matrices get zero rows
+    and columns.  Every product and solve of psgd.py:156-192 is then block diagonal: the leading M x N (M x M, N x N)
+    block of each result is the unpadded result, the rest is zero (or tiny I)."""
+    M, N = mats[0].shape
+    Mp, Np = _pad8(M), _pad8(N)
+
+    def factor(Q, n, n_p):
+        if n == n_p:
+            return Q
+        Qp = torch.zeros(n_p, n_p, dtype=Q.dtype, device=Q.device)
+        Qp[:n, :n] = Q
+        Qp.diagonal()[n:] = _tiny
+        return Qp
+    pads = [torch.nn.functional.pad(x, (0, Np - N, 0, Mp - M)) for x in mats]
+    return factor(Ql, M, Mp), factor(Qr, N, Np), pads
+
+
 def _update_precond_dense_dense_bf16(Ql, Qr, dX, dG, step):
     """psgd.py:156-179 with bf16 MFMA operands for the products (dX, dG in bf16; fp32 master factors in and out;
     balance, triangular solves, norms and the final subtraction stay fp32)."""
     M, N = dX.shape
     if M % 8 or N % 8:
-        raise ValueError("update_precond_kron: the bf16 path needs M and N to be multiples of 8, got %dx%d" % (M, N))
+        Qlp, Qrp, (dXp, dGp) = _padded_bf16_problem(Ql, Qr, (dX, dG))
+        a, b = _update_precond_dense_dense_bf16(Qlp, Qrp, dXp, dGp, step)
+        return a[:M, :M].contiguous(), b[:N, :N].contiguous()
     Ql, Qr, dX, dG = (t.contiguous() for t in (Ql, Qr, dX, dG))
     QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
     key = (dX.device.index, "upd", M, N, _stream_key(dX.device))
@@ -125,6 +153,7 @@ def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
 
 
 _bf16_apply_shapes = {}
+_bf16_prepared = {}       # workspace key -> (weakref Ql, weakref Qr, versions, data pointers) of the factor copies it holds
 
 
 def check_bf16_handoffs():
@@ -149,22 +178,31 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     """psgd.py:182-192 with bf16 MFMA operands (Grad and result in bf16, fp32 master factors)."""
     M, N = Grad.shape
     if M % 8 or N % 8:
-        raise ValueError("precond_grad_kron: the bf16 path needs M and N to be multiples of 8, got %dx%d" % (M, N))
-    Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
+        Qlp, Qrp, (Gp,) = _padded_bf16_problem(Ql, Qr, (Grad,))
+        return _precond_grad_dense_dense_bf16(Qlp, Qrp, Gp)[:M, :N].contiguous()
+    Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))      # (.contiguous() returns the same object when it already is)
     out = torch.empty_like(Grad)
     key = (Grad.device.index, M, N, _stream_key(Grad.device))
 
     def make():
+        _bf16_prepared.pop(key, None)
         ws = torch.empty(int(_lib.load().psgd_kron_dd_workspace_bytes_bf16(M, N)), dtype=torch.uint8, device=Grad.device)
         _lib.check(_lib.load().psgd_kron_bf16_handoff_reset(ws.data_ptr(), M, N, _stream_key(Grad.device)),
                    "psgd_kron_bf16_handoff_reset")
         _bf16_apply_shapes[key] = (M, N)
         return ws
     ws = _kron_ws_bf16.get(key, make)
-    rc = _lib.load().psgd_kron_dd_apply_bf16(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
-                                              ws.data_ptr(), ws.numel(),
-                                              torch.cuda.current_stream(Grad.device).cuda_stream)
-    _lib.check(rc, "psgd_kron_dd_apply_bf16")
+    lib, st = _lib.load(), torch.cuda.current_stream(Grad.device).cuda_stream
+    # The bf16 copies of the factors live in the workspace and only change when the factors do: convert again only if
+    # these are not the very tensor objects (same storage, same version counter) the copies were made from.
+    tag = _bf16_prepared.get(key)
+    if not (tag is not None and tag[0]() is Ql and tag[1]() is Qr and tag[2:] == (Ql._version, Qr._version,
+                                                                                 Ql.data_ptr(), Qr.data_ptr())):
+        _lib.check(lib.psgd_kron_bf16_prepare_factors(Ql.data_ptr(), Qr.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st),
+                   "psgd_kron_bf16_prepare_factors")
+        _bf16_prepared[key] = (weakref.ref(Ql), weakref.ref(Qr), Ql._version, Qr._version, Ql.data_ptr(), Qr.data_ptr())
+    rc = lib.psgd_kron_dd_apply_bf16_prepared(Grad.data_ptr(), out.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st)
+    _lib.check(rc, "psgd_kron_dd_apply_bf16_prepared")
     return out
 
 

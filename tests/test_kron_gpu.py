@@ -148,7 +148,8 @@ BF16_TOL = 2e-2      # 4 chained bf16-operand GEMMs with bf16 intermediates: ~2^
 
 
 @pytest.mark.parametrize("M,N", [(128, 128), (256, 512), (512, 256), (136, 264), (1024, 1024), (8, 8), (200, 72),
-                                 (4096, 2048), (2048, 4096)])      # the last two: 8x8 tile-patch scheduling path
+                                 (4096, 2048), (2048, 4096),       # these two: 8x8 tile-patch scheduling path
+                                 (133, 260), (7, 5), (1, 3), (1027, 515), (4100, 4093)])   # not multiples of 8: padded
 def test_dense_dense_apply_bf16(psgd, M, N):
     rng = np.random.default_rng(M + 3 * N)
     Ql, Qr = _tri_factor(rng, M).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
@@ -340,7 +341,8 @@ BF16_UPD_STATE_TOL = 2e-4  # on the factors themselves: increment error x step (
 
 
 @pytest.mark.parametrize("M,N", [(128, 128), (256, 512), (512, 256), (136, 264), (8, 8), (200, 72), (72, 200), (64, 1000),
-                                 (1024, 768), (1160, 520)])
+                                 (1024, 768), (1160, 520),
+                                 (260, 133), (5, 12), (1027, 515), (85, 10)])        # not multiples of 8: padded
 def test_dense_dense_update_bf16(psgd, M, N):
     rng = np.random.default_rng(5 * M + N)
     Ql, Qr = (_tri_factor(rng, M) * 3.0).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
@@ -366,11 +368,7 @@ def test_dense_dense_update_bf16(psgd, M, N):
     assert rel_err(Qr_new.cpu().numpy(), Qr32.cpu().numpy()) < BF16_UPD_STATE_TOL
 
 
-def test_bf16_update_rejects_odd_shapes_and_mixed_dtypes(psgd):
-    with pytest.raises(ValueError):
-        psgd.update_precond_kron(torch.eye(5, device="cuda"), torch.eye(12, device="cuda"),
-                                 torch.ones(5, 12, device="cuda", dtype=torch.bfloat16),
-                                 torch.ones(5, 12, device="cuda", dtype=torch.bfloat16))
+def test_bf16_update_rejects_mixed_dtypes(psgd):
     with pytest.raises(TypeError):
         psgd.update_precond_kron(torch.eye(8, device="cuda"), torch.eye(16, device="cuda"),
                                  torch.ones(8, 16, device="cuda", dtype=torch.bfloat16), torch.ones(8, 16, device="cuda"))
@@ -379,10 +377,27 @@ def test_bf16_update_rejects_odd_shapes_and_mixed_dtypes(psgd):
                                  torch.ones(8, 16, device="cuda"), torch.ones(8, 16, device="cuda"))
 
 
-def test_bf16_path_rejects_odd_shapes(psgd):
-    with pytest.raises(ValueError):
-        psgd.precond_grad_kron(torch.eye(5, device="cuda"), torch.eye(12, device="cuda"),
-                               torch.ones(5, 12, device="cuda", dtype=torch.bfloat16))
+def test_bf16_factor_copies_follow_the_factors(psgd):
+    """The bf16 copies of the factors are cached in the workspace and rebuilt only when the factors change: same tensor
+    objects -> reused (same result); modified in place (version counter) -> rebuilt; a different tensor that the
+    allocator put at the SAME address -> rebuilt (identity of the object, not of the pointer)."""
+    M, N = 512, 256
+    rng = np.random.default_rng(3)
+    Ql, Qr = _dev(_tri_factor(rng, M).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
+    G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16)
+    ref = lambda ql, qr: orc.precond_grad_kron(ql.cpu().numpy().astype(np.float64), qr.cpu().numpy().astype(np.float64),
+                                               G.float().cpu().numpy().astype(np.float64))
+    a = psgd.precond_grad_kron(Ql, Qr, G)
+    b = psgd.precond_grad_kron(Ql, Qr, G)                          # copies reused
+    assert torch.equal(a, b) and rel_err(a.float().cpu().numpy(), ref(Ql, Qr)) < BF16_TOL
+    Ql.mul_(1.5)                                                   # in place: same object, same pointer, new version
+    c = psgd.precond_grad_kron(Ql, Qr, G)
+    assert rel_err(c.float().cpu().numpy(), ref(Ql, Qr)) < BF16_TOL and rel_err(c.float().cpu().numpy(), 2.25 * a.float().cpu().numpy()) < BF16_TOL
+    ptr = Qr.data_ptr()
+    del Qr
+    Qr2 = _dev((_tri_factor(rng, N) * 0.5).astype(np.float32))     # usually lands on the block just freed
+    d = psgd.precond_grad_kron(Ql, Qr2, G)
+    assert rel_err(d.float().cpu().numpy(), ref(Ql, Qr2)) < BF16_TOL, "stale factor copies (same address: %s)" % (Qr2.data_ptr() == ptr)
 
 
 @pytest.mark.parametrize("tile_choice,x3", [(1, 1), (2, 1), (2, 0), (3, 1)])
