@@ -162,6 +162,21 @@ int psgd_uvd_ipuvt_matvec_cols_f32(const float *U, const float *V, const float *
                                    float *const *outs, int k, int64_t N, int r,
                                    void *ws, int64_t ws_bytes, void *stream);
 
+/* Building blocks of the wide-rank path.  The sweep kernels are instantiated for ranks 1..PSGD_UVD_MAX_RANK; a
+ * preconditioner of larger rank (the reference has no limit, psgd.py:663) is handled one level up
+ * (psgd_tf_amd/uvd_wide.py) on column chunks of U and V -- each chunk a contiguous [N, rc] matrix, rc <= 32 -- with the
+ * Gram sweep (psgd_uvd_update_sweep1_f32 on pairs of chunks) and these three calls.  xs / outs: HOST arrays of k device
+ * pointers to contiguous [N] vectors; S, c: DEVICE arrays.
+ *   colsums:    S[j][0..r) = M' x_j                (fp64)
+ *   axpy_cols:  out_j = x_j + M S_j                (S fp32 [k][r]; out_j may be x_j itself)
+ *   rank2:      M <- M - (a c1' - b c2')           (c = [c1 | c2] fp32; psgd.py:600-601 / :614-615 with mu folded in)  */
+int psgd_uvd_colsums_f32(const float *M, const float *const *xs, int k, double *S, int64_t N, int r,
+                         void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_axpy_cols_f32(const float *M, const float *const *xs, float *const *outs, int k,
+                           const float *S, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_rank2_update_f32(float *M, const float *a, const float *b, const float *c, int64_t N, int r,
+                              void *ws, int64_t ws_bytes, void *stream);
+
 /* Tuning knobs for experiments (not part of the stable ABI).
  * key 0: streaming policy (0 = automatic: non-temporal when U,V exceed the Infinity Cache,
  *        1 = never non-temporal, 2 = always non-temporal).

@@ -1163,6 +1163,78 @@ int psgd_uvd_ipuvt_matvec_cols_f32(const float* U, const float* V, const float* 
   return PSGD_OK;
 }
 
+/* Building blocks of the wide-rank path (r > PSGD_UVD_MAX_RANK; psgd_tf_amd/uvd_wide.py works on column chunks of U and V,
+ * each a contiguous [N, rc] matrix with rc <= 32).  xs / outs: HOST arrays of k device pointers to contiguous [N] vectors.
+ *   colsums:   S[j][:] = M' x_j                 (fp64, device [k][r])
+ *   axpy_cols: out_j   = x_j + M S_j            (S fp32, device [k][r]; out_j may be x_j)
+ *   rank2:     M      <- M - (a c1' - b c2')    (c = [c1 | c2] fp32, device [2r])                                  */
+int psgd_uvd_colsums_f32(const float* M, const float* const* xs, int k, double* S, int64_t N, int r, void* ws,
+                         int64_t ws_bytes, void* stream) {
+  if (!M || !xs || !S || k < 1) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(M)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* part = static_cast<double*>(w.part);
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    const int nc = k - j0 < 4 ? k - j0 : 4;
+    const float* x4[4];
+    for (int j = 0; j < 4; ++j) {
+      x4[j] = xs[j0 + (j < nc ? j : 0)];
+      if (!x4[j]) return PSGD_ERR_BAD_ARG;
+    }
+    const int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
+    PSGD_CHECK_LAUNCH(ops->colreduce4(use_nt(N, r), M, x4, N, part, grid, st));
+    hipLaunchKernelGGL(k_reduce_pq, dim3((nc * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
+                       static_cast<const float*>(nullptr), grid, nc * r, S + (int64_t)j0 * r, static_cast<float*>(nullptr));
+    PSGD_CHECK_LAUNCH(last_launch());
+  }
+  return PSGD_OK;
+}
+
+int psgd_uvd_axpy_cols_f32(const float* M, const float* const* xs, float* const* outs, int k, const float* S, int64_t N,
+                           int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!M || !xs || !outs || !S || k < 1) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(M)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    const int nc = k - j0 < 4 ? k - j0 : 4;
+    const float* x4[4];
+    float* o4[4];
+    for (int j = 0; j < 4; ++j) {
+      x4[j] = xs[j0 + (j < nc ? j : 0)];
+      o4[j] = outs[j0 + (j < nc ? j : 0)];
+      if (!x4[j] || !o4[j]) return PSGD_ERR_BAD_ARG;
+    }
+    const int grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
+    PSGD_CHECK_LAUNCH(ops->rowdot_axpy4(use_nt(N, r), M, x4, o4, nc, N, S + (int64_t)j0 * r, grid, st));
+  }
+  return PSGD_OK;
+}
+
+int psgd_uvd_rank2_update_f32(float* M, const float* a, const float* b, const float* c, int64_t N, int r, void* ws,
+                              int64_t ws_bytes, void* stream) {
+  if (!M || !a || !b || !c) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(M)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
+  PSGD_CHECK_LAUNCH(ops->rank2_update(use_nt(N, r), M, a, b, N, c, grid, st));
+  return PSGD_OK;
+}
+
 // --------------------------------------------------------------- update ----
 static int flat_grid(int64_t n) {
   int64_t g = (n / 4 + kThreads - 1) / kThreads;

@@ -848,6 +848,21 @@ __global__ __launch_bounds__(kThreads) void k_uvd_final(const float* U, const fl
                               });
 }
 
+// M <- M - (a c1' - b c2')  (row-local rank-2 update of one factor, psgd.py:600-601 / :614-615 with the step size folded
+// into c1, c2): building block of the wide-rank (r > 32) path, which works on column chunks of U and V.
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_rank2_update(float* M, const float* a, const float* b, long N,
+                                                           const float* __restrict__ coef) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 2>()];
+  const float* const mats[1] = {M};
+  const float* const vecs[2] = {a, b};
+  sweep_rows<R, 1, 2, 0, NT>(mats, vecs, M, N, lds[threadIdx.x >> 6],
+                             [&](long, bool, float (&x)[1][R], float (&s)[2]) {
+#pragma unroll
+                               for (int c = 0; c < R; ++c) x[0][c] = x[0][c] - (s[0] * coef[c] - s[1] * coef[R + c]);
+                             });
+}
+
 // ------------------------------------------------------- launch table ------
 struct UvdOps {
   int tile_rows;
@@ -863,6 +878,7 @@ struct UvdOps {
   int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, const float* g, long N, const float* coef, float* nabla, float* part_max, double* part_pq, int grid, hipStream_t st);
   int (*colreduce4)(int nt, const float* M, const float* const* x, long N, double* part, int grid, hipStream_t st);
   int (*rowdot_axpy4)(int nt, const float* M, const float* const* x, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
+  int (*rank2_update)(int nt, float* M, const float* a, const float* b, long N, const float* coef, int grid, hipStream_t st);
   int (*final_sweep)(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out, long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st);
   // max resident blocks per CU for each sweep kernel (occupancy query)
   int (*occupancy)(int which);

@@ -66,6 +66,10 @@ struct Launch {
     PSGD_LAUNCH((k_rowdot_axpy4<R, true>), (k_rowdot_axpy4<R, false>), M, x[0], x[1], x[2], x[3], o[0], o[1], o[2], o[3],
                 ncols, N, coef);
   }
+  static int rank2_update(int nt, float* M, const float* a, const float* b, long N, const float* coef, int grid,
+                          hipStream_t st) {
+    PSGD_LAUNCH((k_rank2_update<R, true>), (k_rank2_update<R, false>), M, a, b, N, coef);
+  }
   static int final_sweep(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out,
                          long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st) {
     PSGD_LAUNCH((k_uvd_final<R, true>), (k_uvd_final<R, false>), U, V, d, nabla, g, out, N, coef, maxbuf, step, tiny);
@@ -91,7 +95,7 @@ struct Launch {
   static const UvdOps* ops() {
     static const UvdOps o = {Cfg<R>::kTileRows, GramCfg<R>::kLen, &colreduce, &apply_s2, &apply_s3,
                              &rowdot_axpy,      &update_gram,     &update_s2, &colreduce4, &rowdot_axpy4,
-                             &final_sweep,      &occupancy};
+                             &rank2_update,     &final_sweep,     &occupancy};
     return &o;
   }
 };

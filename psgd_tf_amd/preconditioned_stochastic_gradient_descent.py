@@ -33,6 +33,7 @@ import torch
 
 from . import _lib
 from . import kron as _kron
+from . import uvd_wide as _wide
 
 dtype = torch.float32                                  # psgd.py:20
 _tiny = torch.finfo(torch.float32).tiny                # psgd.py:22 (smallest normal fp32)
@@ -211,6 +212,9 @@ def precond_grad_splu(L12, l3, U12, u3, grads):
 # --------------------------------------------------------------------------- UVd math
 def IpUVtmatvec(U, V, x):
     """psgd.py:540-544: (I + U V') x for a column vector x ([N] or [N,1]) or [N,k] matrix."""
+    if U.dim() == 2 and U.shape[1] > _lib.UVD_MAX_RANK:
+        _require_hip("IpUVtmatvec", U, V, x)
+        return _wide.ipuvt_matvec(U, V, x, uvd_workspace)
     if x.dim() == 2 and x.shape[1] > 1:
         # a matrix x: its columns go through as contiguous vectors (two small transposes, N k floats each), U and V are
         # swept once per group of four columns
@@ -244,6 +248,8 @@ def precond_grad_UVd_math(U, V, d, g):
     """psgd.py:619-627: d .* (I + V U')(I + U V')(d .* g); returns a new tensor shaped like g."""
     dev = _require_hip("precond_grad_UVd_math", U, V, d, g)
     N, r = _uvd_shapes("precond_grad_UVd_math", U, V, d, g)
+    if r > _lib.UVD_MAX_RANK:                      # wide rank: column chunks through the same kernels (uvd_wide.py)
+        return _wide.precond_grad(U, V, d, g, uvd_workspace)
     out = torch.empty_like(g)
     ws = uvd_workspace(dev, N, r)
     rc = _lib.load().psgd_uvd_apply_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), g.data_ptr(), out.data_ptr(),
@@ -269,6 +275,8 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
         balance = _draw_branch(0.01, generator)
     if update_U is None:
         update_U = _draw_branch(0.5, generator)
+    if r > _lib.UVD_MAX_RANK:
+        return _wide.update(U, V, d, v, h, float(step), float(tiny), bool(balance), bool(update_U), uvd_workspace)
     ws = uvd_workspace(dev, N, r)
     rc = _lib.load().psgd_uvd_update_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), N, r,
                                           float(step), float(tiny), int(bool(balance)), int(bool(update_U)),
@@ -289,6 +297,9 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
         balance = _draw_branch(0.01, generator)
     if update_U is None:
         update_U = _draw_branch(0.5, generator)
+    if r > _lib.UVD_MAX_RANK:                      # no fusion on the wide-rank path: update, then apply
+        _wide.update(U, V, d, v, h, float(step), float(tiny), bool(balance), bool(update_U), uvd_workspace)
+        return _wide.precond_grad(U, V, d, g, uvd_workspace)
     out = torch.empty_like(g)
     ws = uvd_workspace(dev, N, r)
     rc = _lib.load().psgd_uvd_update_apply_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(),
@@ -372,9 +383,8 @@ class UVd:
         self._state_dtype = torch.float32
         self._device = p0.device
         r = int(rank_of_modification)
-        if not 1 <= r <= _lib.UVD_MAX_RANK:
-            raise ValueError("UVd: rank_of_modification must be in [1, %d] for the HIP kernels, got %d"
-                             % (_lib.UVD_MAX_RANK, r))
+        if r < 1:
+            raise ValueError("UVd: rank_of_modification must be >= 1, got %d" % r)
         self.lr_params = _Hyper(lr_params)                                                   # :673
         self.lr_preconditioner = _Hyper(lr_preconditioner)                                   # :674
         self.grad_clip_max_norm = _Hyper(math.inf if grad_clip_max_norm is None else grad_clip_max_norm)  # :675-678

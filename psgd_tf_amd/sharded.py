@@ -40,6 +40,9 @@ class HipStages:
 
     def __init__(self, device, n_local, r):
         self.device, self.N, self.r = device, int(n_local), int(r)
+        if self.r > _lib.UVD_MAX_RANK:
+            raise _lib.PsgdHipError("row-sharded UVd supports ranks up to %d (the wide-rank path of uvd_wide.py is "
+                                    "single-GPU), got r = %d" % (_lib.UVD_MAX_RANK, self.r))
         self.lib = _lib.load()
         self.ws = _psgd.uvd_workspace(device, self.N, self.r)
         self._views = {}

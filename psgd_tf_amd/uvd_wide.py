@@ -1,0 +1,231 @@
+"""UVd preconditioner of rank r > 32 (the reference has no rank limit, psgd.py:663).
+
+The rank-templated sweep kernels exist for r = 1..32.  A wider preconditioner is handled on column chunks:
+U = [U_1 | ... | U_c], V = [V_1 | ... | V_c], every chunk a contiguous [N, rc] matrix (rc <= 32; the last chunk is padded
+with zero columns, which change nothing: U V' is the same product and K = I + V'U only gains identity rows).  Every
+N-sized pass runs in the HIP kernels through the C ABI:
+
+    Gram blocks X'Y, X't, X'w      psgd_uvd_update_sweep1_f32 on pairs of chunks (matrix cores), one call per pair
+    S = M' [x_0 ..]                psgd_uvd_colsums_f32           (psgd.py:544 inner product)
+    out_j = x_j + M S_j            psgd_uvd_axpy_cols_f32         (psgd.py:544 outer product; two vectors per sweep)
+    M <- M - (a c1' - b c2')       psgd_uvd_rank2_update_f32      (psgd.py:600-601 / :614-615)
+
+What is left to torch is what has no N x r extent: gathering / scattering the column chunks (slicing), elementwise
+operations on N-vectors (d .* h, v ./ d, nablaD, the d update) and the r x r algebra (two fp64 solves with K, the norm
+of psgd.py:594-596 / :608-610) -- all on the device, nothing synchronises.  Same formulas, same order of operations on
+the state as psgd.py:554-627; costs (2c - 1) passes over U and V for the Gram instead of one, so r <= 32 stays on the
+specialised path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_MAXR = _lib.UVD_MAX_RANK
+
+
+def _chunks(r):
+    c = -(-r // _MAXR)
+    rc = -(-r // c)
+    return c, rc
+
+
+def _ptrs(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _Ctx:
+    def __init__(self, U, workspace_fn):
+        self.dev = U.device
+        self.N, self.r = U.shape
+        self.c, self.rc = _chunks(self.r)
+        self.lib = _lib.load()
+        self.ws = workspace_fn(self.dev, self.N, self.rc)
+        self.st = torch.cuda.current_stream(self.dev).cuda_stream
+
+    def split(self, M):
+        """contiguous column chunks [N, rc] of M [N, r] (the last one zero-padded)."""
+        out = []
+        for k in range(self.c):
+            lo, hi = k * self.rc, min((k + 1) * self.rc, self.r)
+            ch = torch.zeros(self.N, self.rc, dtype=M.dtype, device=self.dev) if hi - lo < self.rc else None
+            if ch is None:
+                ch = M[:, lo:hi].contiguous()
+            else:
+                ch[:, :hi - lo] = M[:, lo:hi]
+            out.append(ch)
+        return out
+
+    def scatter(self, M, chunks):
+        for k, ch in enumerate(chunks):
+            lo, hi = k * self.rc, min((k + 1) * self.rc, self.r)
+            M[:, lo:hi] = ch[:, :hi - lo]
+
+    def pad_vec(self, x):
+        """r-vector (device) -> [c, rc] with zero padding."""
+        out = torch.zeros(self.c * self.rc, dtype=x.dtype, device=self.dev)
+        out[:self.r] = x.reshape(-1)
+        return out.view(self.c, self.rc)
+
+    def colsums(self, M, xs):
+        S = torch.empty(len(xs), self.rc, dtype=torch.float64, device=self.dev)
+        _lib.check(self.lib.psgd_uvd_colsums_f32(M.data_ptr(), _ptrs(xs), len(xs), S.data_ptr(), self.N, self.rc,
+                                                 self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_colsums_f32")
+        return S
+
+    def axpy(self, M, xs, S):
+        """in place: x_j += M S_j  (S [k, rc] fp32)."""
+        S = S.to(torch.float32).contiguous()
+        p = _ptrs(xs)
+        _lib.check(self.lib.psgd_uvd_axpy_cols_f32(M.data_ptr(), p, p, len(xs), S.data_ptr(), self.N, self.rc,
+                                                   self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_axpy_cols_f32")
+
+    def rank2(self, M, a, b, c1, c2):
+        cc = torch.cat([c1.reshape(-1), c2.reshape(-1)]).to(torch.float32).contiguous()
+        _lib.check(self.lib.psgd_uvd_rank2_update_f32(M.data_ptr(), a.data_ptr(), b.data_ptr(), cc.data_ptr(), self.N,
+                                                      self.rc, self.ws.data_ptr(), self.ws.numel(), self.st),
+                   "psgd_uvd_rank2_update_f32")
+
+    # ---- Gram of [X | Y | t | w] for two chunks, decoded from the MFMA block layout of the workspace
+    def gram_pair(self, X, Y, d, v, h):
+        _lib.check(self.lib.psgd_uvd_update_sweep1_f32(X.data_ptr(), Y.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(),
+                                                       self.N, self.rc, self.ws.data_ptr(), self.ws.numel(), self.st),
+                   "psgd_uvd_update_sweep1_f32")
+        off, cnt = _lib.ws_region(_lib.PSGD_WS_SUMS_F64, 11, self.N, self.rc)
+        sums = self.ws[off:off + cnt * 8].view(torch.float64)
+        return sums[self._gram_index()].clone()          # dense [2rc + 2, 2rc + 2]
+
+    def _gram_index(self):
+        if not hasattr(self, "_gidx"):
+            nc = 2 * self.rc + 2
+            nb = (nc + 15) // 16
+            idx = torch.empty(nc, nc, dtype=torch.long)
+            for a in range(nc):
+                for b in range(nc):
+                    lo, hi = (a, b) if a <= b else (b, a)
+                    bi, bj, i, j = lo >> 4, hi >> 4, lo & 15, hi & 15
+                    p = bi * nb - (bi * (bi - 1)) // 2 + (bj - bi)
+                    idx[a, b] = p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j)
+            self._gidx = idx.to(self.dev)
+        return self._gidx
+
+
+def precond_grad(U, V, d, g, workspace_fn):
+    """psgd.py:619-627 for r > 32."""
+    cx = _Ctx(U, workspace_fn)
+    Uc, Vc = cx.split(U), cx.split(V)
+    shape = g.shape
+    t = (d.reshape(-1) * g.reshape(-1)).contiguous()                           # :625
+    g1 = t.clone()
+    for k in range(cx.c):                                                      # g1 = t + U (V't)          :544
+        s1 = cx.colsums(Vc[k], [t])
+        cx.axpy(Uc[k], [g1], s1)
+    out = g1.clone()
+    for k in range(cx.c):                                                      # g1 + V (U'g1)             :626
+        s2 = cx.colsums(Uc[k], [g1])
+        cx.axpy(Vc[k], [out], s2)
+    return (d.reshape(-1) * out).reshape(shape)
+
+
+def ipuvt_matvec(U, V, x, workspace_fn):
+    """psgd.py:540-544 for r > 32; x is [N], [N, 1] or [N, k]."""
+    cx = _Ctx(U, workspace_fn)
+    Uc, Vc = cx.split(U), cx.split(V)
+    cols = [x.reshape(cx.N, -1)[:, j].contiguous() for j in range(x.reshape(cx.N, -1).shape[1])]
+    outs = [c.clone() for c in cols]
+    for k in range(cx.c):
+        S = cx.colsums(Vc[k], cols)
+        cx.axpy(Uc[k], outs, S)
+    return torch.stack(outs, 1).reshape(x.shape) if x.dim() == 2 else outs[0].reshape(x.shape)
+
+
+def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn):
+    """psgd.py:554-617 for r > 32 (in place on U or V, and d)."""
+    cx = _Ctx(U, workspace_fn)
+    r, c, rc, dev = cx.r, cx.c, cx.rc, cx.dev
+    if balance:                                                                # :562-567
+        rho = torch.sqrt(torch.max(torch.abs(U)) / torch.max(torch.abs(V)))
+        U.div_(rho)
+        V.mul_(rho)
+    Uc, Vc = cx.split(U), cx.split(V)
+    dv, vv, hv = d.reshape(-1), v.reshape(-1), h.reshape(-1)
+    # ---- Gram of W = [U | V | t | w], t = d.*h, w = v./d, block by block (pairs of chunks)
+    R = c * rc
+    f64 = dict(dtype=torch.float64, device=dev)
+    UU, VV, VU = torch.zeros(R, R, **f64), torch.zeros(R, R, **f64), torch.zeros(R, R, **f64)
+    Ut, Uw, Vt, Vw = (torch.zeros(R, **f64) for _ in range(4))
+    items = [("U", k, Uc[k]) for k in range(c)] + [("V", k, Vc[k]) for k in range(c)]
+    sl = lambda k: slice(k * rc, (k + 1) * rc)
+    tt = tw = ww = None
+
+    def put(kind_a, ka, kind_b, kb, blk):                 # blk = A'B  [rc, rc]
+        if kind_a == "U" and kind_b == "U":
+            UU[sl(ka), sl(kb)] = blk
+            UU[sl(kb), sl(ka)] = blk.t()
+        elif kind_a == "V" and kind_b == "V":
+            VV[sl(ka), sl(kb)] = blk
+            VV[sl(kb), sl(ka)] = blk.t()
+        elif kind_a == "V":
+            VU[sl(ka), sl(kb)] = blk
+        else:
+            VU[sl(kb), sl(ka)] = blk.t()
+
+    for i in range(len(items)):
+        for j in range(i + 1, len(items)):
+            (ka_, ia, X), (kb_, ib, Y) = items[i], items[j]
+            G = cx.gram_pair(X, Y, dv, vv, hv)
+            put(ka_, ia, ka_, ia, G[:rc, :rc])
+            put(kb_, ib, kb_, ib, G[rc:2 * rc, rc:2 * rc])
+            put(ka_, ia, kb_, ib, G[:rc, rc:2 * rc])
+            for kind, kk, lo in ((ka_, ia, 0), (kb_, ib, rc)):
+                (Ut if kind == "U" else Vt)[sl(kk)] = G[lo:lo + rc, 2 * rc]
+                (Uw if kind == "U" else Vw)[sl(kk)] = G[lo:lo + rc, 2 * rc + 1]
+            tt, tw, ww = G[2 * rc, 2 * rc], G[2 * rc, 2 * rc + 1], G[2 * rc + 1, 2 * rc + 1]
+    # ---- r x r algebra (fp64, on the device): psgd.py:574-579, :589-597 / :603-611
+    K = torch.eye(R, **f64) + VU                                               # :575  (padded rows/columns: identity)
+    s1 = Vt                                                                    # V't
+    s2 = Ut + UU @ s1                                                          # U'Qh
+    x1 = torch.linalg.solve(K.t(), Uw)                                         # :577 (adjoint)
+    p2 = Vw - VV @ x1
+    x2 = torch.linalg.solve(K, p2)                                             # :578
+    cs1 = VU @ s1
+    aa = tt + 2 * (s1 @ Ut) + s1 @ (UU @ s1)
+    bb = ww - 2 * (x1 @ Vw) + x1 @ (VV @ x1)
+    ab = tw - x1 @ Vt + s1 @ Uw - x1 @ cs1
+    if update_U:
+        e1, e2, Mm = Vt + cs1, p2, VV                                          # atV, btV
+    else:
+        e1, e2, Mm = s2, Uw - VU.t() @ x1, UU                                  # atU, btU
+    nrm = torch.sqrt(torch.abs(aa * (e1 @ (Mm @ e1)) + bb * (e2 @ (Mm @ e2)) - 2 * ab * (e1 @ (Mm @ e2))))
+    mu = (step / (nrm + tiny)).to(torch.float32)                               # :597 / :611
+    if update_U:
+        c1, c2 = e1 @ K, e2 @ K                                                # atV K, btV K          :600-601
+    else:
+        c1, c2 = e1, e2
+    # ---- row-local part: a = Qh, b = invQtv, Ph, invPv, nablaD (psgd.py:569-581); two vectors per sweep of a chunk
+    t = (dv * hv).contiguous()
+    w = (vv / dv).contiguous()
+    a, q = t.clone(), torch.zeros_like(t)                  # a = t + U s1 ;  q = -U x2
+    b, p = w.clone(), torch.zeros_like(t)                  # b = w - V x1 ;  p = V s2
+    for k in range(c):
+        cx.axpy(Uc[k], [a, q], torch.stack([s1[sl(k)], -x2[sl(k)]]))
+        cx.axpy(Vc[k], [b, p], torch.stack([-x1[sl(k)], s2[sl(k)]]))
+    Ph = dv * (a + p)                                                          # :570
+    invPv = (b + q) / dv                                                       # :578-579
+    nabla = Ph * hv - vv * invPv                                               # :581
+    mud = step / (torch.max(torch.abs(nabla)) + tiny)                          # :582
+    dv.sub_((mud * dv) * nabla)                                                # :584 (d before U / V; a, b keep the old d)
+    c1f, c2f = (mu * c1.to(torch.float32)), (mu * c2.to(torch.float32))
+    if update_U:                                                               # :600-601
+        for k in range(c):
+            cx.rank2(Uc[k], a, b, c1f[sl(k)], c2f[sl(k)])
+        cx.scatter(U, Uc)
+    else:                                                                      # :614-615
+        al, be = a.clone(), b.clone()
+        for k in range(c):
+            cx.axpy(Vc[k], [al, be], torch.stack([c1[sl(k)], c2[sl(k)]]))
+        for k in range(c):
+            cx.rank2(Vc[k], al, be, c1f[sl(k)], c2f[sl(k)])
+        cx.scatter(V, Vc)
+    return None

@@ -170,9 +170,6 @@ def test_rejects_bad_arguments(psgd):
         psgd.precond_grad_UVd_math(t["U"].cpu(), t["V"].cpu(), t["d"].cpu(), t["g"].cpu())
     with pytest.raises(TypeError):
         psgd.precond_grad_UVd_math(t["U"].double(), t["V"].double(), t["d"].double(), t["g"].double())
-    big = torch.zeros(100, 33, device="cuda")
-    with pytest.raises(PsgdHipError):
-        psgd.precond_grad_UVd_math(big, big.clone(), t["d"], t["g"])                  # rank > 32
     with pytest.raises(ValueError):
         psgd.precond_grad_UVd_math(t["U"].t().contiguous().t(), t["V"], t["d"], t["g"])   # non-contiguous
     # a row-slice that starts at an odd row of an r = 3 matrix is not 16-byte aligned: refused, not mis-read
@@ -228,3 +225,54 @@ def test_register_row_coef_kernel_equals_block_reference(psgd, hip_lib, N, r, up
     orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=update_U)
     for k in ("U", "V", "d"):
         assert rel_err(a[k].cpu().numpy(), q[k]) < STATE_TOL, k
+
+
+@pytest.mark.parametrize("N,r", [(5000, 48), (3001, 33), (2049, 64), (1021, 100), (100003, 40)])
+def test_wide_rank_matches_oracle(psgd, N, r):
+    """r > 32 (the reference has no rank limit, psgd.py:663): column chunks of U and V through the same HIP kernels
+    (psgd_tf_amd/uvd_wide.py).  Apply, IpUVtmatvec (vector and matrix), both update branches, the balance branch and
+    the fused call against the fp64 oracle, with K = I + V'U far from the identity."""
+    p = make_uvd_problem(N, r, seed=N + r, uv_gain=2.0 * r ** 0.5, d_spread=0.3)
+    p["V"] = (0.6 * p["U"] @ np.linalg.qr(np.random.default_rng(r).standard_normal((r, r)))[0] + 0.6 * p["V"]).astype(np.float32)
+    t, q = _to_dev(p), _f64(p)
+    assert np.linalg.norm(q["V"].T @ q["U"], 2) > 0.5
+    out = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    assert out.shape == t["g"].shape
+    assert rel_err(out.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < APPLY_TOL
+    assert rel_err(psgd.IpUVtmatvec(t["U"], t["V"], t["g"]).cpu().numpy(), orc.IpUVtmatvec(q["U"], q["V"], q["g"])) < APPLY_TOL
+    x3 = torch.cat([t["g"], t["v"], t["h"] * 1e-2], 1).contiguous()
+    assert rel_err(psgd.IpUVtmatvec(t["U"], t["V"], x3).cpu().numpy(),
+                   orc.IpUVtmatvec(q["U"], q["V"], x3.cpu().numpy().astype(np.float64))) < APPLY_TOL
+    for bal, upd in ((False, True), (False, False), (True, True)):
+        before = {k: t[k].cpu().numpy().astype(np.float64) for k in ("U", "V", "d")}
+        before64 = {k: q[k].copy() for k in ("U", "V", "d")}
+        assert psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32, balance=bal,
+                                             update_U=upd) is None
+        orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=bal, update_U=upd)
+        for k in ("U", "V", "d"):
+            assert rel_err(t[k].cpu().numpy(), q[k]) < 2 * STATE_TOL, (k, bal, upd)
+        if not bal:
+            for k in (("U" if upd else "V"), "d"):
+                assert rel_err(t[k].cpu().numpy() - before[k], q[k] - before64[k]) < INCR_TOL, (k, upd)
+            frozen = "V" if upd else "U"
+            assert np.array_equal(t[frozen].cpu().numpy().astype(np.float64), before[frozen])
+    outf = psgd.update_precond_UVd_math_and_precond_grad(t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY32,
+                                                         balance=False, update_U=False)
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=False)
+    assert rel_err(outf.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < 2 * APPLY_TOL
+
+
+def test_uvd_class_wide_rank(hip_lib):
+    """class UVd with rank_of_modification = 48 on a convex quadratic: runs, stays finite, loss goes down."""
+    import preconditioned_stochastic_gradient_descent as psgd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    A = torch.randn(300, 300, device=dev) * 0.1
+    H = A @ A.t() + 0.3 * torch.eye(300, device=dev)
+    w = torch.randn(300, 1, device=dev).requires_grad_(True)
+    opt = psgd.UVd([w], rank_of_modification=48, lr_params=0.05, lr_preconditioner=0.05, generator=torch.Generator().manual_seed(2))
+    closure = lambda: 0.5 * (w.t() @ H @ w).sum()
+    l0 = float(opt.step(closure).detach())
+    for _ in range(80):
+        l = float(opt.step(closure).detach())
+    assert opt._U.shape == (300, 48) and torch.isfinite(opt._U).all() and l < 0.3 * l0
