@@ -271,7 +271,9 @@ def uvd_bytes(r, fused):
     kb = {"apply_s1": 4 * (r + 2), "apply_s2": 4 * (r + 3), "apply_s3": 4 * (r + 3),
           "update_s1": 4 * (2 * r + 3), "update_s2": 4 * (3 * r + 4), "update_s3": 12}
     if fused:
-        kb["update_s2"] = 4 * (3 * r + 5)      # + 4 B/row for g; produces the apply's s1
+        kb["update_s2"] = 4 * (3 * r + 5)      # + 4 B/row for g; also reduces [Unew | Vnew]' [d.*g, d.*g.*nablaD]
+        kb["apply_s3"] = 4 * (2 * r + 5)       # the fused step's last sweep: d update + whole apply (k_uvd_final)
+        del kb["apply_s1"], kb["apply_s2"], kb["update_s3"]
     return kb
 
 
@@ -322,8 +324,8 @@ def uvd_legs(dev, psgd, lib, state, r, iters):
                       call="precond_grad_UVd_math (psgd.py:619-627)"),
         "update": dict(leg(wu, ku, ("update_s1", "update_s2", "update_s3"), 4 * (5 * r + 10), 4 * (5 * r + 10)),
                        call="update_precond_UVd_math_ (psgd.py:554-617)"),
-        "step_fused": dict(leg(wf, kf, ("update_s1", "update_s2", "update_s3", "apply_s2", "apply_s3"),
-                               4 * (9 * r + 15), 4 * (2 * r + 3) + 4 * (3 * r + 5) + 12 + 2 * 4 * (r + 3)),
+        "step_fused": dict(leg(wf, kf, ("update_s1", "update_s2", "apply_s3"),
+                               4 * (9 * r + 15), 4 * (2 * r + 3) + 4 * (3 * r + 5) + 4 * (2 * r + 5)),
                            call="update_precond_UVd_math_and_precond_grad (psgd.py:732 -> :748)"),
     }
 
@@ -474,7 +476,7 @@ def main():
         ach = kern[dom]["achieved_GBs"]
         alg_step = 4 * (9 * r + 15)
         moved_step = (4 * (5 * r + 10) + 4 * (3 * r + 8)) if args.unfused else \
-            (4 * (2 * r + 3) + 4 * (3 * r + 5) + 12 + 2 * 4 * (r + 3))
+            (4 * (2 * r + 3) + 4 * (3 * r + 5) + 4 * (2 * r + 5))
         gbs = lambda b: b * n_local / (ms_per_step * 1e-3) / 1e9
         paths = {"fused": not args.unfused,
                  "step": {"alg_bytes_per_param": alg_step, "moved_bytes_per_param": moved_step, "wall_ms": ms_per_step,

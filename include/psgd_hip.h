@@ -134,7 +134,7 @@ int psgd_uvd_update_sweep3_f32(float *d, int64_t N, int r, float step,
  * (psgd.py:584) both reductions of the apply follow from them and from the Gram of sweep 1:
  *     s1' = Vnew'(dnew.*g) = pV - mu_d qV,      s2' = Unew'(dnew.*g + Unew s1') = pU - mu_d qU + (Unew'Unew) s1'
  * (Unew'Unew = U'U plus a rank-2 correction known from the r x r algebra), so the d update and the whole apply are
- * ONE last sweep: out = dnew .* (dnew.*g + Unew s1' + Vnew s2').  628 -> 544 bytes per parameter at r = 20.
+ * ONE last sweep: out = dnew .* (dnew.*g + Unew s1' + Vnew s2').  628 -> 612 bytes per parameter at r = 20 and 9 -> 6 launches.
  * Multi-GPU stages: [balance] -> update_sweep1 -> X(11) -> update_sweep2_fused -> X(13: 4r sums | max) ->
  * fused_post -> fused_final: two exchanges per step. */
 int psgd_uvd_update_apply_f32(float *U, float *V, float *d, const float *v, const float *h,

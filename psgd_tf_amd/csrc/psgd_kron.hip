@@ -20,6 +20,9 @@
 #include <stdint.h>
 #include "psgd_hip.h"
 #include "kron_shared.h"
+#include "nanmax.h"
+using psgd::amaxf;
+using psgd::nmaxf;
 
 namespace psgdk {
 
@@ -200,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
           float v = acc[i][j][e];
           if (g.epi == EPI_TRIU_MAX) {
             v = (col >= row) ? v : 0.0f;
-            vmax = fmaxf(vmax, fabsf(v));
+            vmax = amaxf(vmax, fabsf(v));
           } else if (g.epi == EPI_D_MINUS) {
             v = g.D[(long)row * g.ldd + col * ccs] - v;
           } else if (g.colv) {
@@ -213,8 +216,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
       }
   if (g.epi == EPI_TRIU_MAX) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    if (lane == 0 && vmax > 0.0f) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+    for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+    // integer max on the bits of a non-negative float: order-independent, and NaN (above +inf) propagates
+    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
   }
 }
 
@@ -1200,18 +1204,18 @@ struct BalanceBatch {
 __device__ __forceinline__ void balance_body(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
                                              float* QlS, float* QrS, float (*red)[4]) {
   float ml = -INFINITY, mr = -INFINITY;
-  for (int i = threadIdx.x; i < M; i += kThreads) ml = fmaxf(ml, Ql[(long)i * M + i]);
-  for (int i = threadIdx.x; i < N; i += kThreads) mr = fmaxf(mr, Qr[(long)i * N + i]);
+  for (int i = threadIdx.x; i < M; i += kThreads) ml = nmaxf(ml, Ql[(long)i * M + i]);
+  for (int i = threadIdx.x; i < N; i += kThreads) mr = nmaxf(mr, Qr[(long)i * N + i]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    ml = fmaxf(ml, __shfl_down(ml, off, 64));
-    mr = fmaxf(mr, __shfl_down(mr, off, 64));
+    ml = nmaxf(ml, __shfl_down(ml, off, 64));
+    mr = nmaxf(mr, __shfl_down(mr, off, 64));
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) { red[0][w] = ml; red[1][w] = mr; }
   __syncthreads();
-  ml = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-  mr = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  ml = nmaxf(nmaxf(red[0][0], red[0][1]), nmaxf(red[0][2], red[0][3]));
+  mr = nmaxf(nmaxf(red[1][0], red[1][1]), nmaxf(red[1][2], red[1][3]));
   const float rho = sqrtf(ml / mr);
   const long nl = (long)M * M, nr = (long)N * N;
   const long tid = (long)blockIdx.x * kThreads + threadIdx.x, nth = (long)gridDim.x * kThreads;
@@ -1329,10 +1333,10 @@ __global__ __launch_bounds__(kThreads) void k_row_stats(const float* __restrict_
 
 __device__ __forceinline__ float block_max(float v, float* red) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  for (int off = 32; off > 0; off >>= 1) v = nmaxf(v, __shfl_down(v, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float r = nmaxf(nmaxf(red[0], red[1]), nmaxf(red[2], red[3]));
   __syncthreads();
   return r;
 }
@@ -1344,7 +1348,7 @@ __global__ __launch_bounds__(kThreads) void k_norm_finalize(const float* __restr
                                                             float* qlOut) {
   __shared__ float red[4];
   float v = 0.0f;
-  for (int i = threadIdx.x; i < M; i += kThreads) v = fmaxf(v, fmaxf(fabsf(gd[i]), fabsf(gb[i])));
+  for (int i = threadIdx.x; i < M; i += kThreads) v = nmaxf(v, nmaxf(fabsf(gd[i]), fabsf(gb[i])));
   const float step1 = step / (block_max(v, red) + tiny);
   const float qlast = ql[M - 1];
   for (int i = threadIdx.x; i < M; i += kThreads) {
@@ -1358,7 +1362,7 @@ __global__ __launch_bounds__(kThreads) void k_scale_finalize(const float* __rest
                                                              int N, float step, float tiny, float* qrOut) {
   __shared__ float red[4];
   float v = 0.0f;
-  for (int i = threadIdx.x; i < N; i += kThreads) v = fmaxf(v, fabsf(g2[i]));
+  for (int i = threadIdx.x; i < N; i += kThreads) v = nmaxf(v, fabsf(g2[i]));
   const float step2 = step / (block_max(v, red) + tiny);
   for (int i = threadIdx.x; i < N; i += kThreads) qrOut[i] = qr[i] - step2 * g2[i] * qr[i];
 }
@@ -1371,8 +1375,8 @@ __global__ __launch_bounds__(kThreads) void k_balance_generic(const float* __res
                                                               int r_cnt, long r_tot, float* Lout, float* Rout) {
   __shared__ float red[4];
   float ml = -INFINITY, mr = -INFINITY;
-  for (int i = threadIdx.x; i < l_cnt; i += kThreads) ml = fmaxf(ml, L[i * l_stride]);
-  for (int i = threadIdx.x; i < r_cnt; i += kThreads) mr = fmaxf(mr, R[i * r_stride]);
+  for (int i = threadIdx.x; i < l_cnt; i += kThreads) ml = nmaxf(ml, L[i * l_stride]);
+  for (int i = threadIdx.x; i < r_cnt; i += kThreads) mr = nmaxf(mr, R[i * r_stride]);
   ml = block_max(ml, red);
   mr = block_max(mr, red);
   const float rho = sqrtf(ml / mr);

@@ -30,6 +30,9 @@
 #include <stdint.h>
 #include "psgd_hip.h"
 #include "kron_shared.h"
+#include "nanmax.h"
+using psgd::amaxf;
+using psgd::nmaxf;
 
 namespace psgdh {
 
@@ -234,7 +237,7 @@ __device__ __forceinline__ void hgemm_nt_body(const HGemmArgs& g, int bid, u32x4
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = (col >= row0 + e && row0 + e < g.M) ? acc[i][j][e] : 0.0f;
-          vmax = fmaxf(vmax, fabsf(v));
+          vmax = amaxf(vmax, fabsf(v));
           acc[i][j][e] = v;
         }
       } else if (g.epi == HEPI_D_MINUS) {
@@ -286,8 +289,8 @@ __device__ __forceinline__ void hgemm_nt_body(const HGemmArgs& g, int bid, u32x4
     }
   if (g.epi == HEPI_TRIU_MAX) {     // max |triu(C)| of the whole product: one atomic per wave (values are >= 0: int order)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    if (lane == 0 && vmax > 0.0f) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+    for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
   }
   if (g.sym == 2 && n0 > m0 && g.epi == HEPI_D_MINUS) {
     // the tile below the diagonal is not launched: its product is zero, C = D there (M == N, multiples of 8; fp32)

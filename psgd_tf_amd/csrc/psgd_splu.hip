@@ -83,8 +83,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_reduce_max(const float* __res
   __shared__ float red[kWavesPerBlock];
   const float* p = part + (long)blockIdx.x * G;
   float v = -INFINITY;
-  for (int b = threadIdx.x; b < G; b += kThreads) v = fmaxf(v, p[b]);
-  block_max_store(v, red, out + blockIdx.x);
+  for (int b = threadIdx.x; b < G; b += kThreads) v = nmaxf(v, p[b]);
+  block_max_store<true>(v, red, out + blockIdx.x);
   __syncthreads();
   if (threadIdx.x == 0) outd[blockIdx.x] = (double)out[blockIdx.x];
 }
@@ -99,7 +99,7 @@ __global__ void k_splu_fold_gathered(const double* __restrict__ gathered, int wo
   if (i < nsum) {
     for (int k = 1; k < world; ++k) a += gathered[(long)k * count + i];
   } else {
-    for (int k = 1; k < world; ++k) a = fmax(a, gathered[(long)k * count + i]);
+    for (int k = 1; k < world; ++k) a = nmax(a, gathered[(long)k * count + i]);
     maxdst[i - nsum] = (float)a;
   }
   dst[i] = a;
@@ -233,12 +233,12 @@ __global__ __launch_bounds__(kThreads) void k_splu_corner_upd2(const float* L12,
 }
 
 __device__ __forceinline__ double block_max_f64(double v, double* red) {
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  for (int off = 32; off > 0; off >>= 1) v = nmax(v, __shfl_down(v, off, 64));
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   double m = red[0];
-  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmax(m, red[k]);
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = nmax(m, red[k]);
   return m;
 }
 
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void k_splu_corner_upd3(const float* L12,
   if (t < r) { dl = c.L1[t][t]; du = c.U1[t][t]; }
   double max_l = block_max_f64(dl, red);
   double max_u = block_max_f64(du, red);
-  if (has_tail) { max_l = fmax(max_l, (double)maxbuf[2]); max_u = fmax(max_u, (double)maxbuf[3]); }
+  if (has_tail) { max_l = nmax(max_l, (double)maxbuf[2]); max_u = nmax(max_u, (double)maxbuf[3]); }
   const float rho_f = sqrtf((float)max_l / (float)max_u);
   const double rho = (double)rho_f, irho = 1.0 / rho;
 
@@ -281,10 +281,10 @@ __global__ __launch_bounds__(kThreads) void k_splu_corner_upd3(const float* L12,
     const int i = e / r, j = e % r;
     const double g = (j <= i) ? c.v[1][i] * c.v[1][j] - c.v[2][i] * c.v[2][j] : 0.0;
     G[i][j] = g;
-    m = fmax(m, fabs(g));
+    m = nmax(m, fabs(g));
   }
   m = block_max_f64(m, red);
-  if (has_tail) m = fmax(m, (double)maxbuf[0]);
+  if (has_tail) m = nmax(m, (double)maxbuf[0]);
   const double sL = (double)(step / ((float)m + tiny));
   for (int e = t; e < r * r; e += blockDim.x) {
     const int i = e / r, j = e % r;
@@ -309,10 +309,10 @@ __global__ __launch_bounds__(kThreads) void k_splu_corner_upd3(const float* L12,
     const int i = e / r, j = e % r;
     const double g = (j >= i) ? c.v[3][i] * c.v[5][j] - c.v[4][i] * c.v[0][j] : 0.0;
     G[i][j] = g;
-    m = fmax(m, fabs(g));
+    m = nmax(m, fabs(g));
   }
   m = block_max_f64(m, red);
-  if (has_tail) m = fmax(m, (double)maxbuf[1]);
+  if (has_tail) m = nmax(m, (double)maxbuf[1]);
   const double sU = (double)(step / ((float)m + tiny));
   for (int e = t; e < r * r; e += blockDim.x) {
     const int i = e / r, j = e % r;

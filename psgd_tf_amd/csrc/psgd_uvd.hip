@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_max(const float* __restrict
   __shared__ float red[kWavesPerBlock];
   const float* p = part + (long)blockIdx.x * stride;
   float v = 0.0f;
-  for (int b = threadIdx.x; b < G; b += kThreads) v = fmaxf(v, p[b]);
+  for (int b = threadIdx.x; b < G; b += kThreads) v = amaxf(v, p[b]);
   block_max_store(v, red, out + blockIdx.x);
   __syncthreads();
   if (threadIdx.x == 0) outd[blockIdx.x] = (double)out[blockIdx.x];
@@ -255,7 +255,7 @@ __global__ void k_fold_gathered(const double* __restrict__ gathered, int world, 
   if (i < nsum) {
     for (int k = 1; k < world; ++k) a += gathered[(long)k * count + i];
   } else {
-    for (int k = 1; k < world; ++k) a = fmax(a, gathered[(long)k * count + i]);
+    for (int k = 1; k < world; ++k) a = nmax(a, gathered[(long)k * count + i]);
     maxdst[i - nsum] = (float)a;
   }
   dst[i] = a;
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(kThreads) void k_reduce_pq(const double* __restrict
   const int id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (id == 0 && pmax) {
     float m = 0.0f;
-    for (int b = lane; b < G; b += 64) m = fmaxf(m, pmax[b]);
+    for (int b = lane; b < G; b += 64) m = amaxf(m, pmax[b]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_xor(m, off, 64));
     if (lane == 0) {
       *maxout = m;
       sums[L] = (double)m;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void k_update_d(float* d, const float* __
   float m;
   if (pmax) {
     float v = 0.0f;
-    for (int b = threadIdx.x; b < G; b += kThreads) v = fmaxf(v, pmax[b]);
+    for (int b = threadIdx.x; b < G; b += kThreads) v = amaxf(v, pmax[b]);
     block_max_store(v, red, &bmax);
     __syncthreads();
     m = bmax;
@@ -349,12 +349,12 @@ __global__ __launch_bounds__(kThreads) void k_maxabs2(const float* __restrict__ 
   const float4* V4 = reinterpret_cast<const float4*>(V);
   for (long i = tid; i < n4; i += nth) {
     const float4 a = U4[i], b = V4[i];
-    mu = fmaxf(mu, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
-    mv = fmaxf(mv, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+    mu = amaxf(mu, amaxf(amaxf(fabsf(a.x), fabsf(a.y)), amaxf(fabsf(a.z), fabsf(a.w))));
+    mv = amaxf(mv, amaxf(amaxf(fabsf(b.x), fabsf(b.y)), amaxf(fabsf(b.z), fabsf(b.w))));
   }
   for (long i = n4 * 4 + tid; i < n; i += nth) {
-    mu = fmaxf(mu, fabsf(U[i]));
-    mv = fmaxf(mv, fabsf(V[i]));
+    mu = amaxf(mu, fabsf(U[i]));
+    mv = amaxf(mv, fabsf(V[i]));
   }
   block_max_store(mu, red[0], part + blockIdx.x);
   __syncthreads();
@@ -861,9 +861,9 @@ __global__ __launch_bounds__(1024) void k_fused_post(const double* __restrict__ 
   if constexpr (REDUCE) {
     if (w == nw - 1) {
       float m = 0.0f;
-      for (int b = lane; b < G; b += 64) m = fmaxf(m, pmax[b]);
+      for (int b = lane; b < G; b += 64) m = amaxf(m, pmax[b]);
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_xor(m, off, 64));
       if (lane == 0) { mx = m; maxbuf[0] = m; pq[4 * r] = (double)m; }
     }
     for (int e = w; e < 4 * r; e += nw) {                 // G <= 256: four loads per lane, issued together

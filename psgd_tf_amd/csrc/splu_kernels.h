@@ -304,14 +304,14 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s3(const float* L2s, cons
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       acc[k] = fmaf(s[k], ipx2, acc[k]);
-      a = fmaxf(a, fabsf(q * coef[K::c2 + k] - iq * coef[K::c3 + k]));
-      b = fmaxf(b, fabsf(coef[K::c4 + k] * g - coef[K::c5 + k] * ipx2));
+      a = amaxf(a, fabsf(q * coef[K::c2 + k] - iq * coef[K::c3 + k]));
+      b = amaxf(b, fabsf(coef[K::c4 + k] * g - coef[K::c5 + k] * ipx2));
     }
     if (valid) {
-      mL = fmaxf(mL, a);
-      mU = fmaxf(mU, b);
-      ml3 = fmaxf(ml3, l);
-      mu3 = fmaxf(mu3, u);
+      mL = amaxf(mL, a);
+      mU = amaxf(mU, b);
+      ml3 = nmaxf(ml3, l);
+      mu3 = nmaxf(mu3, u);
     }
   };
   sweep_rows<R, 1, NV, -1, NT>(mats, vecs, nullptr, n2s, dyn_lds + (threadIdx.x >> 6) * LW, body);
@@ -323,9 +323,9 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s3(const float* L2s, cons
   __syncthreads();
   block_max_store(mU, red, pmax + G + blockIdx.x);
   __syncthreads();
-  block_max_store(ml3, red, pmax + 2 * G + blockIdx.x);
+  block_max_store<true>(ml3, red, pmax + 2 * G + blockIdx.x);
   __syncthreads();
-  block_max_store(mu3, red, pmax + 3 * G + blockIdx.x);
+  block_max_store<true>(mu3, red, pmax + 3 * G + blockIdx.x);
 }
 
 // update sweep 4: the tail of :463-465 and :476-478 on the rho-balanced factors (:414-417)

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "nanmax.h"
 
 namespace psgd {
 
@@ -316,16 +317,18 @@ __device__ __forceinline__ void block_sum_store(float (&acc)[L], float* red /* [
   }
 }
 
+// NaN-propagating (nanmax.h).  SIGNED = false: maxima of |x| (one integer max per step); true: any values.
+template <bool SIGNED = false>
 __device__ __forceinline__ void block_max_store(float v, float* red /* [waves] */, float* out) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  for (int off = 32; off > 0; off >>= 1) v = SIGNED ? nmaxf(v, __shfl_down(v, off, 64)) : amaxf(v, __shfl_down(v, off, 64));
   if (lane == 0) red[w] = v;
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = red[0];
 #pragma unroll
-    for (int k = 1; k < kWavesPerBlock; ++k) s = fmaxf(s, red[k]);
+    for (int k = 1; k < kWavesPerBlock; ++k) s = SIGNED ? nmaxf(s, red[k]) : amaxf(s, red[k]);
     *out = s;
   }
 }
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, cons
     const float nd = Ph * hh - vv * invPv;
     if (valid) {
       stream_store<NT>(nabla + row, nd);
-      vmax = fmaxf(vmax, fabsf(nd));
+      vmax = amaxf(vmax, fabsf(nd));
     }
     if constexpr (UPDATE_U) {
 #pragma unroll

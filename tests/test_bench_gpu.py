@@ -39,7 +39,7 @@ def test_bench_single_gpu_line(hip_lib):
         assert all(paths[leg]["kernels_ms"][k] > 0 for k in kernels)
     assert paths["apply"]["alg_bytes_per_param"] == 340 and paths["apply"]["moved_bytes_per_param"] == 272
     assert paths["update"]["alg_bytes_per_param"] == 440
-    assert paths["step"]["alg_bytes_per_param"] == 780 and paths["step"]["moved_bytes_per_param"] == 628
+    assert paths["step"]["alg_bytes_per_param"] == 780 and paths["step"]["moved_bytes_per_param"] == 612
     assert 0 < paths["step"]["frac_moved"] < paths["step"]["frac"]
     c2 = d["config2_N1M_r10"]
     assert c2["N"] == 1_000_000 and c2["r"] == 10 and c2["step_fused"]["wall_ms"] > 0 and c2["apply"]["wall_ms"] > 0
