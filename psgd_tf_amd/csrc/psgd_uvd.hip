@@ -659,26 +659,26 @@ __device__ __forceinline__ double lu_solve_rows(double (&a)[RG + 1], int r, int 
 }
 
 struct CoefLds {
-  double A[MR][MR + 1];     // U'U
-  double B[MR][MR + 1];     // V'V
-  double Cm[MR][MR + 1];    // V'U  (psgd.py:574)
-  double v[6][MR + 1];      // broadcast vectors: s1, x1, e1, e2 + scratch
   double q[10][MR + 1];     // per-lane products whose sums over the lanes are needed
   double qs[10];
 };
 
-// sums over lanes 0..r-1 of NQ per-lane values: every value goes to LDS, lane q adds up row q sequentially
-// (NQ lanes work side by side), the totals come back to all lanes.
-template <int NQ>
+// sums over lanes 0..r-1 of NQ per-lane values: every value goes to LDS, lane q adds up row q (NQ lanes work side by
+// side, the loads of a row issued together), the totals come back to all lanes.
+template <int NQ, int RG>
 __device__ __forceinline__ void lane_sums(double (&val)[NQ], int r, int tid, CoefLds& L) {
-  if (tid < r) {
+  if (tid < RG) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) L.q[q][tid] = val[q];
+    for (int q = 0; q < NQ; ++q) L.q[q][tid] = (tid < r) ? val[q] : 0.0;
   }
   __syncthreads();
   if (tid < NQ) {
+    double x[RG];
+#pragma unroll
+    for (int k = 0; k < RG; ++k) x[k] = L.q[tid][k];
     double s = 0.0;
-    for (int k = 0; k < r; ++k) s += L.q[tid][k];
+#pragma unroll
+    for (int k = 0; k < RG; ++k) s += x[k];
     L.qs[tid] = s;
   }
   __syncthreads();
@@ -687,15 +687,26 @@ __device__ __forceinline__ void lane_sums(double (&val)[NQ], int r, int tid, Coe
   __syncthreads();
 }
 
-// Whole block executes this (only lanes tid < r of wave 0 carry rows; the other waves idle through the barriers).
+// y_i = sum_k row[k] * x_k with x_k living in lane k: the broadcast is a v_readlane pair, no LDS
+template <int RG>
+__device__ __forceinline__ double row_dot_lanes(const double (&row)[RG], double x) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < RG; ++k) s += row[k] * readlane_f64(x, k);
+  return s;
+}
+
+// One wave (lanes tid < r carry rows; a 64-thread block).  Everything r x r stays in registers: lane i holds row i of
+// U'U, V'V, V'U and U'V (columns >= r: 0), vectors live one entry per lane, a matrix-vector product is RG fma's on
+// v_readlane broadcasts.
 template <int RG>
 __device__ void coef_block(const double* __restrict__ gram, int r, float step, float tiny, int update_U,
                            float* __restrict__ coef, double* __restrict__ c64, CoefLds& L) {
   const int tid = threadIdx.x, lane = tid & 63;
   const bool act = tid < r;
   const int nb = (2 * r + 2 + 15) / 16;
-  // lane = row.  All 3 RG + 7 loads of a lane are issued before the first is used (branch-free, clamped indices): the
-  // kernel is one memory latency long here, not one per element.
+  // All 4 RG + 7 loads of a lane are issued before the first is used (branch-free, clamped indices): the kernel is one
+  // memory latency long here, not one per element.
   auto Gi = [&](int a, int b) -> int {          // index of Gram entry (a, b) in the MFMA block layout of k_update_gram
     const int lo = a < b ? a : b, hi = a < b ? b : a;
     const int bi = lo >> 4, bj = hi >> 4, i = lo & 15, j = hi & 15;
@@ -703,89 +714,68 @@ __device__ void coef_block(const double* __restrict__ gram, int r, float step, f
     return p * 256 + (i & 3) * 64 + (((i >> 2) << 4) | j);
   };
   const int row = act ? tid : 0;
-  double ra[RG], rb[RG], rc[RG];
+  double A[RG], B[RG], C[RG], Ct[RG];           // rows of U'U, V'V, V'U (psgd.py:574) and U'V = (V'U)'
 #pragma unroll
   for (int j = 0; j < RG; ++j) {
     const int jj = j < r ? j : 0;
-    ra[j] = gram[Gi(row, jj)];
-    rb[j] = gram[Gi(r + row, r + jj)];
-    rc[j] = gram[Gi(jj, r + row)];
+    A[j] = gram[Gi(row, jj)];
+    B[j] = gram[Gi(r + row, r + jj)];
+    C[j] = gram[Gi(jj, r + row)];
+    Ct[j] = gram[Gi(row, r + jj)];
   }
   double ut = gram[Gi(row, 2 * r)], uw = gram[Gi(row, 2 * r + 1)], vt = gram[Gi(r + row, 2 * r)],
          vw = gram[Gi(r + row, 2 * r + 1)];
   const double tt = gram[Gi(2 * r, 2 * r)], tw = gram[Gi(2 * r, 2 * r + 1)], ww = gram[Gi(2 * r + 1, 2 * r + 1)];
-  if (act) {
 #pragma unroll
-    for (int j = 0; j < RG; ++j) {
-      if (j < r) { L.A[tid][j] = ra[j]; L.B[tid][j] = rb[j]; L.Cm[tid][j] = rc[j]; }
-    }
-    L.v[0][tid] = vt;                                      // s1 = V't
-  } else {
-    ut = uw = vt = vw = 0.0;
-  }
-  __syncthreads();
+  for (int j = 0; j < RG; ++j)
+    if (!act || j >= r) A[j] = B[j] = C[j] = Ct[j] = 0.0;
+  if (!act) ut = uw = vt = vw = 0.0;
   // s2 = U'Qh = U't + (U'U) s1 ; cs1 = (V'U) s1
-  const double s1 = vt;
-  double s2 = ut, cs1 = 0.0;
+  const double s1 = vt;                                                   // s1 = V't
+  const double s2 = ut + row_dot_lanes<RG>(A, s1);
+  const double cs1 = row_dot_lanes<RG>(C, s1);
   double a[RG + 1];
-  if (act) {
-    for (int k = 0; k < r; ++k) { s2 += L.A[tid][k] * L.v[0][k]; cs1 += L.Cm[tid][k] * L.v[0][k]; }
-  }
   // x1 = solve(K', U'w), K = I + V'U            (psgd.py:575-577, adjoint=True)
 #pragma unroll
-  for (int j = 0; j < RG; ++j) a[j] = (act && j < r) ? L.Cm[j][tid] + (j == tid ? 1.0 : 0.0) : ((j == lane) ? 1.0 : 0.0);
-  a[RG] = act ? uw : 0.0;
+  for (int j = 0; j < RG; ++j) a[j] = Ct[j] + ((j == lane) ? 1.0 : 0.0);
+  a[RG] = uw;
   const double x1 = lu_solve_rows<RG>(a, r, lane);
-  if (act) L.v[1][tid] = x1;
-  __syncthreads();
   // p2 = V' invQtv = V'w - (V'V) x1 ; x2 = solve(K, p2)          (psgd.py:578)
-  double p2 = vw;
-  if (act) {
-    for (int k = 0; k < r; ++k) p2 -= L.B[tid][k] * L.v[1][k];
-  }
+  const double p2 = vw - row_dot_lanes<RG>(B, x1);
 #pragma unroll
-  for (int j = 0; j < RG; ++j) a[j] = (act && j < r) ? L.Cm[tid][j] + (j == tid ? 1.0 : 0.0) : ((j == lane) ? 1.0 : 0.0);
-  a[RG] = act ? p2 : 0.0;
+  for (int j = 0; j < RG; ++j) a[j] = C[j] + ((j == lane) ? 1.0 : 0.0);
+  a[RG] = p2;
   const double x2 = lu_solve_rows<RG>(a, r, lane);
   // a = Qh = t + U s1, b = invQtv = w - V x1                      (psgd.py:587)
   double d7[7] = {s1 * ut, s1 * s2, x1 * vw, x1 * p2, x1 * vt, s1 * uw, x1 * cs1};
-  lane_sums<7>(d7, r, tid, L);
+  lane_sums<7, RG>(d7, r, tid, L);
   const double aa = tt + d7[0] + d7[1];          // a'a = t't + 2 s1'U't + s1'(U'U)s1
   const double bb = ww - d7[2] - d7[3];          // b'b = w'w - 2 x1'V'w + x1'(V'V)x1
   const double ab = tw - d7[4] + d7[5] - d7[6];  // a'b
   // e1 = a'M, e2 = b'M with M = V (update U) or U (update V); the norm needs ||M e1'||^2 = e1 (M'M) e1' etc.
-  double e1 = 0.0, e2 = 0.0, ub = uw;            //                      (psgd.py:589-596 / :603-610)
-  if (act) {
-    for (int k = 0; k < r; ++k) ub -= L.Cm[k][tid] * L.v[1][k];      // U'b = U'w - (U'V) x1
-    if (update_U) {
-      e1 = vt + cs1;                              // atV = V't + (V'U) s1
-      e2 = p2;                                    // btV = V'w - (V'V) x1
-    } else {
-      e1 = s2;                                    // atU = U't + (U'U) s1
-      e2 = ub;                                    // btU
-    }
-    L.v[2][tid] = e1;
-    L.v[3][tid] = e2;
+  const double ub = uw - row_dot_lanes<RG>(Ct, x1);                      // U'b = U'w - (U'V) x1
+  double e1, e2;                                   //                      (psgd.py:589-596 / :603-610)
+  if (update_U) {
+    e1 = vt + cs1;                                // atV = V't + (V'U) s1
+    e2 = p2;                                      // btV = V'w - (V'V) x1
+  } else {
+    e1 = s2;                                      // atU = U't + (U'U) s1
+    e2 = ub;                                      // btU
   }
-  __syncthreads();
-  double g1 = 0.0, g2 = 0.0;
-  if (act) {
-    for (int k = 0; k < r; ++k) {
-      const double m = update_U ? L.B[tid][k] : L.A[tid][k];
-      g1 += m * L.v[2][k];
-      g2 += m * L.v[3][k];
-    }
-  }
+  double g1, g2;
+  if (update_U) { g1 = row_dot_lanes<RG>(B, e1); g2 = row_dot_lanes<RG>(B, e2); }
+  else { g1 = row_dot_lanes<RG>(A, e1); g2 = row_dot_lanes<RG>(A, e2); }
   double d3[3] = {e1 * g1, e2 * g2, e1 * g2};
-  lane_sums<3>(d3, r, tid, L);
+  lane_sums<3, RG>(d3, r, tid, L);
   const double nrm = sqrt(fabs(aa * d3[0] + bb * d3[1] - 2.0 * ab * d3[2]));
   const double mu = (double)step / (nrm + (double)tiny);
   // c1, c2: update U -> (atV K), (btV K) (psgd.py:600-601); update V -> atU, btU (:614-615)
+  double c1 = e1, c2 = e2;
+  if (update_U) {                        // + e K's off-identity part: (e (V'U))_i = sum_k e_k (V'U)[k][i] = (U'V)[i][.] e
+    c1 += row_dot_lanes<RG>(Ct, e1);
+    c2 += row_dot_lanes<RG>(Ct, e2);
+  }
   if (act) {
-    double c1 = e1, c2 = e2;
-    if (update_U) {                        // + e K's off-identity part
-      for (int i = 0; i < r; ++i) { c1 += L.v[2][i] * L.Cm[i][tid]; c2 += L.v[3][i] * L.Cm[i][tid]; }
-    }
     coef[0 * r + tid] = (float)s1;
     coef[1 * r + tid] = (float)s2;
     coef[2 * r + tid] = (float)x1;
@@ -846,7 +836,7 @@ static int launch_coef(hipStream_t st, const double* gram, int r, float step, fl
 // Unew = U - mu (a c1' - b c2') when U was updated (psgd.py:600-601), so with Ua = U'a and Ub = U'b
 //   Unew'Unew = U'U - mu (Ua c1' + c1 Ua' - Ub c2' - c2 Ub') + mu^2 (a'a c1 c1' - a'b (c1 c2' + c2 c1') + b'b c2 c2')
 // and Unew'Unew = U'U when V was updated.  Writes coef[0, r) = s1', coef[r, 2r) = s2' (+ the fp64 values to s_out).
-// REDUCE (single GPU, grids of <= 256 blocks): the block first reduces the sweep's partials itself (what k_reduce_pq
+// REDUCE (single GPU, grids of <= 512 blocks): the block first reduces the sweep's partials itself (what k_reduce_pq
 // does in the staged path, same order per element): one launch less between the two sweeps.
 template <bool REDUCE>
 __global__ __launch_bounds__(1024) void k_fused_post(const double* __restrict__ gram, const double* __restrict__ c64,
@@ -866,12 +856,14 @@ __global__ __launch_bounds__(1024) void k_fused_post(const double* __restrict__ 
       for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_xor(m, off, 64));
       if (lane == 0) { mx = m; maxbuf[0] = m; pq[4 * r] = (double)m; }
     }
-    for (int e = w; e < 4 * r; e += nw) {                 // G <= 256: four loads per lane, issued together
+    for (int e = w; e < 4 * r; e += nw) {                 // G <= 512: eight loads per lane, issued together
       const double* p = part + (long)e * G;
-      double x[4];
+      double x[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) x[u] = (lane + 64 * u < G) ? p[lane + 64 * u] : 0.0;
-      double sum = ((x[0] + x[1]) + x[2]) + x[3];
+      for (int u = 0; u < 8; ++u) x[u] = (lane + 64 * u < G) ? p[lane + 64 * u] : 0.0;
+      double sum = 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += x[u];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
       if (lane == 0) { pqs[e] = sum; pq[e] = sum; }
@@ -1316,7 +1308,7 @@ static int update_sweep2_impl(float* U, float* V, const float* d, const float* v
     ProfScope ps(PSGD_PROF_UPDATE_S2, st);
     PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, g, N, w.coef, w.nabla, w.pmax, part, grid, st));
   }
-  if (g && single_gpu_tail && grid <= 256) {     // small grids: the post kernel reduces the partials itself
+  if (g && single_gpu_tail && grid <= 512) {     // small grids: the post kernel reduces the partials itself
     hipLaunchKernelGGL(k_fused_post<true>, dim3(1), dim3(1024), 0, st, w.sums, w.sums + kCoef64Off, part, w.pmax, grid,
                        w.sums + kPqSumsOff, w.maxbuf + 2, r, step, tiny, update_U, w.coef, w.sums + kPostSumsOff);
     PSGD_CHECK_LAUNCH(last_launch());
