@@ -160,10 +160,32 @@ def kron_bench(dev, psgd, iters=20):
     t_bf16_cold = timeit(cold, iters)
     del Ql2, Qr2
     t_f32 = timeit(lambda: psgd.precond_grad_kron(Ql, Qr, G), iters)
+    Ql2, Qr2 = Ql.clone(), Qr.clone()
+    pairs = [(Ql, Qr), (Ql2, Qr2)]
+    flip = [0]
+
+    def cold32():                                 # alternate two factor pairs: the prepared Gram never matches
+        flip[0] ^= 1
+        return psgd.precond_grad_kron(pairs[flip[0]][0], pairs[flip[0]][1], G)
+    t_f32_cold = timeit(cold32, iters)
+    del Ql2, Qr2, pairs
     sts = [state(m, n) for m, n in LENET5]
     Qls, Qrs, Gs = [x[0] for x in sts], [x[1] for x in sts], [x[2] for x in sts]
     t_lenet = timeit(lambda: psgd.precond_grad_kron_batched(Qls, Qrs, Gs), 50)        # one launch per stage for all layers
     t_lenet_loop = timeit(lambda: [psgd.precond_grad_kron(a, b, c) for a, b, c in sts], 50)
+    sts2 = [(a.clone(), b.clone(), c) for a, b, c in sts]
+    both = [sts, sts2]
+
+    def cold_loop():                              # per-layer calls with factors that changed since the last call
+        flip[0] ^= 1
+        return [psgd.precond_grad_kron(a, b, c) for a, b, c in both[flip[0]]]
+
+    def cold_batched():
+        flip[0] ^= 1
+        cur = both[flip[0]]
+        return psgd.precond_grad_kron_batched([x[0] for x in cur], [x[1] for x in cur], Gs)
+    t_lenet_loop_cold = timeit(cold_loop, 50)
+    t_lenet_cold = timeit(cold_batched, 50)
     dXs = [torch.randn_like(g_) for g_ in Gs]
     t_lenet_upd = timeit(lambda: psgd.update_precond_kron_batched(Qls, Qrs, dXs, Gs, 0.01), 50)
     dX = torch.randn_like(G)
@@ -205,10 +227,15 @@ def kron_bench(dev, psgd, iters=20):
                                             "them every call (a fresh factor pair per call, as right after an update)",
                                     "mfma_pmc": pmc},
         "4096x4096_fp32": {"ms": t_f32, "gflops": f_big / t_f32 / 1e6, "mfma_peak_gflops": 157.3e3,
+                           "ms_new_factors_every_call": t_f32_cold,
                            "note": "fp32-accurate bf16 x 3 split GEMMs on the bf16 matrix cores (6 bf16 MFMAs per product): "
                                    "the fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
         "lenet5_set_fp32": {"us": t_lenet * 1e3, "gflops": f_lenet / t_lenet / 1e6, "bound": "launch/latency",
                             "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop * 1e3,
+                            "us_new_factors_every_call": t_lenet_cold * 1e3,
+                            "per_layer_calls_new_factors_us": t_lenet_loop_cold * 1e3,
+                            "note": "`us` / `per_layer_calls_us`: factors unchanged between applies (their Grams stay "
+                                    "prepared: 2 launches per call); `*_new_factors*`: every call brings new factors (3 launches)",
                             "update_us": t_lenet_upd * 1e3},
         "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6},
         "4096x4096_bf16_operands_update": {"ms": t_upd_bf16, "gflops": f_upd / t_upd_bf16 / 1e6,

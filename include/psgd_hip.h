@@ -264,6 +264,14 @@ int psgd_kron_set_tuning(int key, int value);
 int psgd_kron_dd_apply_f32(const float *Ql, const float *Qr, const float *G,
                            float *out, int M, int N, void *ws,
                            int64_t ws_bytes, void *stream);
+/* The same call in two halves: what depends on the factors only (their Grams, kept in ws) and what depends on the
+ * gradient.  psgd_kron_dd_apply_f32 == prepare + apply_prepared; a caller that applies unchanged factors to several
+ * gradients prepares once.  For M, N <= 512 (every launch latency-bound) BOTH Grams are prepared and the gradient half
+ * is two products, (Ql'Ql) G (Qr'Qr) -- the reference's association on one side, re-associated on the other.        */
+int psgd_kron_dd_prepare_f32(const float *Ql, const float *Qr, int M, int N, void *ws,
+                             int64_t ws_bytes, void *stream);
+int psgd_kron_dd_apply_prepared_f32(const float *Ql, const float *Qr, const float *G, float *out,
+                                    int M, int N, void *ws, int64_t ws_bytes, void *stream);
 
 /* _update_precond_dense_dense(Ql, Qr, dX, dG, step)  psgd.py:156-179.
  * Pure: Ql, Qr are read, the new factors are written to QlOut, QrOut.      */
@@ -282,6 +290,12 @@ int psgd_kron_dd_apply_batched_f32(const float *const *Ql, const float *const *Q
                                    const float *const *G, float *const *out,
                                    const int *M, const int *N, int count,
                                    void *ws, int64_t ws_bytes, void *stream);
+int psgd_kron_dd_prepare_batched_f32(const float *const *Ql, const float *const *Qr, const int *M,
+                                     const int *N, int count, void *ws, int64_t ws_bytes, void *stream);
+int psgd_kron_dd_apply_prepared_batched_f32(const float *const *Ql, const float *const *Qr,
+                                            const float *const *G, float *const *out,
+                                            const int *M, const int *N, int count,
+                                            void *ws, int64_t ws_bytes, void *stream);
 int psgd_kron_dd_update_batched_f32(const float *const *Ql, const float *const *Qr,
                                     const float *const *dX, const float *const *dG,
                                     float *const *QlOut, float *const *QrOut,

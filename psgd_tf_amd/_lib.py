@@ -84,6 +84,12 @@ SIGNATURES = {
     "psgd_kron_dd_update_batched_f32": (_int, [ctypes.POINTER(ctypes.c_void_p)] * 6 + [ctypes.POINTER(_int)] * 2 +
                                         [_int, _flt, _flt, _c_ws, _i64, _strm]),
     "psgd_kron_dd_apply_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_prepare_f32": (_int, [_c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_apply_prepared_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_prepare_batched_f32": (_int, [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.POINTER(_int)] * 2 +
+                                         [_int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_apply_prepared_batched_f32": (_int, [ctypes.POINTER(ctypes.c_void_p)] * 4 + [ctypes.POINTER(_int)] * 2 +
+                                                [_int, _c_ws, _i64, _strm]),
     "psgd_kron_sparse_workspace_bytes": (_i64, [_int, _int, _int]),
     "psgd_kron_ds_update_f32": (_int, [_c_f32p] * 4 + [_i64, _i64, _c_f32p, _c_f32p, _int, _int, _flt, _flt, _c_ws, _i64, _strm]),
     "psgd_kron_ds_apply_f32": (_int, [_c_f32p] * 3 + [_i64, _i64, _c_f32p, _int, _int, _c_ws, _i64, _strm]),

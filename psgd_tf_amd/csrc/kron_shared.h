@@ -6,7 +6,8 @@
 namespace psgdk {
 
 // QlS = Ql * sqrt(max|Qr| / max|Ql|), QrS = Qr / that  (psgd.py:166-170).  0 on success.
-int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st);
+int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st,
+                 float* scal = nullptr);   // scal: 64 scratch words to zero in the same launch (or null)
 
 // Solve y Q = x for nvec vectors (vector i at stride si, element j at stride sj; Q upper triangular [n][n]);
 // dinv: scratch of ceil(n/32) * 1024 floats.  0 on success.

@@ -516,7 +516,8 @@ constexpr int kSmallK = 64, kBigK = 16;
 
 // One launch for the same stage of several independent problems (the layers of a small network):
 // blockIdx.x -> (problem, tile) through the prefix sums of the tile counts.  64 x 64 tiles.
-constexpr int kMaxBatch = 8;
+constexpr int kMaxBatch = 16;     // problems per batched launch (16 x 216-byte GemmArgs = 3.4 KiB of kernel arguments)
+constexpr int kMaxLayers = 8;     // layers per group of the batched calls (two independent products per layer share a launch)
 struct GemmBatch {
   int count;
   int tile_end[kMaxBatch];     // inclusive prefix sums of tiles
@@ -668,6 +669,44 @@ __global__ __launch_bounds__(kThreads) void k_gemm_small_one(GemmArgs g) {
 // Y Q = X on row-major [nvec,n]; with (si,sj) = (1,ld) it is Q'Y = X on row-major [n,nvec]
 // (tf.linalg.triangular_solve(Q, X, lower=False, adjoint=True), psgd.py:174).
 // Q has leading dimension ldq (a diagonal block of a larger factor can be passed); X may alias Y.
+// Grams Q'Q of up to 16 small upper-triangular factors in one launch (the factor-only half of the batched apply: two
+// per layer).  Compact descriptors: sixteen full GemmArgs would not fit the kernel-argument segment.
+constexpr int kMaxGrams = 16;
+struct GramBatch {
+  int count;
+  int tile_end[kMaxGrams];
+  const float* Q[kMaxGrams];
+  float* P[kMaxGrams];
+  int n[kMaxGrams];
+};
+
+__host__ __device__ inline GemmArgs gram_args(const float* Q, float* P, int n) {
+  GemmArgs g = {};
+  g.A = Q; g.a_rs = 1; g.a_cs = n;          // A = Q' (stored transposed)
+  g.B = Q; g.b_rs = n; g.b_cs = 1;
+  g.C = P; g.ldc = n; g.M = n; g.N = n; g.K = n;
+  g.epi = EPI_STORE;
+  g.kmode = KHI_M | KHI_N;                  // Q upper-triangular: k <= min(m, n)
+  g.sym = 1;
+  return g;
+}
+
+template <int T>
+__global__ __launch_bounds__(kThreads) void k_gram_batched(GramBatch b) {
+  int p = 0;
+  while (p + 1 < b.count && (int)blockIdx.x >= b.tile_end[p]) ++p;
+  const int t = blockIdx.x - (p ? b.tile_end[p - 1] : 0);
+  const GemmArgs g = gram_args(b.Q[p], b.P[p], b.n[p]);
+  const int tn = (g.N + T - 1) / T;
+  if constexpr (T == 32) {
+    __shared__ __attribute__((aligned(16))) GemmLds<32, kSmallK> L;
+    gemm_body_small(g, (t / tn) * 32, (t % tn) * 32, L);
+  } else {
+    __shared__ __attribute__((aligned(16))) GemmLds<T, kSmallK> L;
+    gemm_body<T, kSmallK>(g, (t / tn) * T, (t % tn) * T, L);
+  }
+}
+
 struct TrsmArgs {
   const float* Q; int n, ldq;
   const float* X; float* Y;
@@ -1198,6 +1237,7 @@ struct BalanceBatch {
   int count;
   const float* Ql[kMaxBatch]; const float* Qr[kMaxBatch];
   float* QlS[kMaxBatch]; float* QrS[kMaxBatch];
+  float* scal[kMaxBatch];      // the layer's 64 scratch words (max|grad| accumulators ...): zeroed here, one launch ahead
   int M[kMaxBatch], N[kMaxBatch];
 };
 
@@ -1224,14 +1264,16 @@ __device__ __forceinline__ void balance_body(const float* __restrict__ Ql, const
 }
 
 __global__ __launch_bounds__(kThreads) void k_kron_balance(const float* __restrict__ Ql, const float* __restrict__ Qr,
-                                                           int M, int N, float* QlS, float* QrS) {
+                                                           int M, int N, float* QlS, float* QrS, float* scal) {
   __shared__ float red[2][4];
+  if (scal && blockIdx.x == 0 && threadIdx.x < 64) scal[threadIdx.x] = 0.0f;   // max|grad| accumulators of the later stages
   balance_body(Ql, Qr, M, N, QlS, QrS, red);
 }
 
 __global__ __launch_bounds__(kThreads) void k_kron_balance_batched(BalanceBatch b) {
   __shared__ float red[2][4];
   const int p = blockIdx.y;
+  if (blockIdx.x == 0 && threadIdx.x < 64) b.scal[p][threadIdx.x] = 0.0f;
   balance_body(b.Ql[p], b.Qr[p], b.M[p], b.N[p], b.QlS[p], b.QrS[p], red);
 }
 
@@ -1389,7 +1431,7 @@ __global__ __launch_bounds__(kThreads) void k_balance_generic(const float* __res
 static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct KronWs {
-  float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv;
+  float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv, *Pl, *Pr;
   int64_t total;
 };
 
@@ -1403,6 +1445,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.T = take(mn); k.A = take(mn); k.X1 = take(mn); k.Bt = take(mn);
   k.g1 = take(mm); k.g2 = take(nn);
   k.dinv = take((int64_t)((M + 31) / 32 + (N + 31) / 32) * 1024 * 4);
+  k.Pl = take(mm); k.Pr = take(nn);          // Grams of the factors (psgd_kron_dd_prepare_f32): survive update calls
   k.total = off;
   return k;
 }
@@ -1460,22 +1503,46 @@ static GemmArgs gemm_args(const float* A, int lda, bool ta, const float* B, int 
   return g;
 }
 
-// The four products of _precond_grad_dense_dense in the reference's association order
-// (psgd.py:189-192) with the K ranges implied by the upper-triangular factors.
+// The products of _precond_grad_dense_dense (psgd.py:189-192), split into what depends on the factors only (`pre`,
+// np stages: Grams) and what depends on the gradient (`app`, na stages).
+//   Large problems keep the reference's association order, with the K ranges implied by the upper-triangular factors:
+//     M < N:   ((Ql'Ql) G) Qr' Qr      pre = {Ql'Ql},  app = {(.) G, (.) Qr', (.) Qr}
+//     M >= N:  Ql' (Ql (G (Qr'Qr)))    pre = {Qr'Qr},  app = {G (.), Ql (.), Ql' (.)}
+//   Small problems (M, N <= 512: every launch is latency-bound, ~7 us per dependent stage) use BOTH Grams:
+//     M < N:   ((Ql'Ql) G) (Qr'Qr)     M >= N:  (Ql'Ql) (G (Qr'Qr))
+//   -- the reference's order on one side, re-associated on the other (same product; fp32 rounding differs at the 1e-7
+//   level, tests hold it to the same 1e-5) -- so a call is three launches instead of four (the two Grams are one
+//   batched launch), and two when the caller keeps the prepared Grams (factors unchanged between applies).
+constexpr int kSmallKron = 512;
+static inline bool kron_small(int M, int N) { return M <= kSmallKron && N <= kSmallKron; }
+
 static void plan_apply(const float* Ql, const float* Qr, const float* G, float* out, int M, int N, const KronWs& k,
-                       GemmArgs (&s)[4]) {
+                       GemmArgs (&pre)[2], int& np, GemmArgs (&app)[3], int& na) {
+  GemmArgs gl = gemm_args(Ql, M, true, Ql, M, false, k.Pl, M, M, M, M, KHI_M | KHI_N);   // Ql'Ql
+  GemmArgs gr = gemm_args(Qr, N, true, Qr, N, false, k.Pr, N, N, N, N, KHI_M | KHI_N);   // Qr'Qr
+  gl.sym = gr.sym = 1;
+  if (kron_small(M, N)) {
+    pre[0] = gl; pre[1] = gr; np = 2; na = 2;
+    if (M < N) {
+      app[0] = gemm_args(k.Pl, M, false, G, N, false, k.T, N, M, N, M);               // (Ql'Ql) G
+      app[1] = gemm_args(k.T, N, false, k.Pr, N, false, out, N, M, N, N);             // (.) (Qr'Qr)
+    } else {
+      app[0] = gemm_args(G, N, false, k.Pr, N, false, k.T, N, M, N, N);               // G (Qr'Qr)
+      app[1] = gemm_args(k.Pl, M, false, k.T, N, false, out, N, M, N, M);             // (Ql'Ql) (.)
+    }
+    return;
+  }
+  np = 1; na = 3;
   if (M < N) {                                                                    // psgd.py:189-190
-    s[0] = gemm_args(Ql, M, true, Ql, M, false, k.g1, M, M, M, M, KHI_M | KHI_N);   // Ql'Ql
-    s[0].sym = 1;
-    s[1] = gemm_args(k.g1, M, false, G, N, false, k.T, N, M, N, M);                 // (.) G
-    s[2] = gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N, KLO_N);           // (.) Qr'
-    s[3] = gemm_args(k.A, N, false, Qr, N, false, out, N, M, N, N, KHI_N);          // (.) Qr
+    pre[0] = gl;
+    app[0] = gemm_args(k.Pl, M, false, G, N, false, k.T, N, M, N, M);                 // (.) G
+    app[1] = gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N, KLO_N);           // (.) Qr'
+    app[2] = gemm_args(k.A, N, false, Qr, N, false, out, N, M, N, N, KHI_N);          // (.) Qr
   } else {                                                                        // psgd.py:191-192
-    s[0] = gemm_args(Qr, N, true, Qr, N, false, k.g2, N, N, N, N, KHI_M | KHI_N);   // Qr'Qr
-    s[0].sym = 1;
-    s[1] = gemm_args(G, N, false, k.g2, N, false, k.T, N, M, N, N);                 // G (.)
-    s[2] = gemm_args(Ql, M, false, k.T, N, false, k.A, N, M, N, M, KLO_M);          // Ql (.)
-    s[3] = gemm_args(Ql, M, true, k.A, N, false, out, N, M, N, M, KHI_M);           // Ql' (.)
+    pre[0] = gr;
+    app[0] = gemm_args(G, N, false, k.Pr, N, false, k.T, N, M, N, N);                 // G (.)
+    app[1] = gemm_args(Ql, M, false, k.T, N, false, k.A, N, M, N, M, KLO_M);          // Ql (.)
+    app[2] = gemm_args(Ql, M, true, k.A, N, false, out, N, M, N, M, KHI_M);           // Ql' (.)
   }
 }
 
@@ -1597,12 +1664,33 @@ static int launch_gemm_batch(const GemmArgs* g, int count, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+static int launch_gram_batch(const GemmArgs* g, int count, hipStream_t st) {      // g: Gram problems made by plan_apply
+  for (int p0 = 0; p0 < count; p0 += kMaxGrams) {
+    GramBatch b;
+    b.count = (count - p0 < kMaxGrams) ? count - p0 : kMaxGrams;
+    long t64 = 0;
+    for (int p = 0; p < b.count; ++p) t64 += (long)((g[p0 + p].N + 63) / 64) * ((g[p0 + p].M + 63) / 64);
+    const int T = t64 >= 96 ? 64 : 32;
+    int tiles = 0;
+    for (int p = 0; p < b.count; ++p) {
+      const GemmArgs& a = g[p0 + p];
+      b.Q[p] = a.A; b.P[p] = a.C; b.n[p] = a.M;
+      tiles += ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
+      b.tile_end[p] = tiles;
+    }
+    if (T == 64) hipLaunchKernelGGL((k_gram_batched<64>), dim3(tiles), dim3(kThreads), 0, st, b);
+    else hipLaunchKernelGGL((k_gram_batched<32>), dim3(tiles), dim3(kThreads), 0, st, b);
+    if (hipGetLastError() != hipSuccess) return 1;
+  }
+  return 0;
+}
+
 // entry points shared with psgd_kron_bf16.hip (kron_shared.h)
-int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st) {
+int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal) {
   const long tot = (long)M * M + (long)N * N;
   int grid = (int)((tot + kThreads - 1) / kThreads);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS);
+  hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS, scal);
   return (int)hipGetLastError();
 }
 
@@ -1639,17 +1727,41 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N) {
   return kron_layout(nullptr, M, N).total;
 }
 
-int psgd_kron_dd_apply_f32(const float* Ql, const float* Qr, const float* G, float* out, int M, int N, void* ws,
-                           int64_t ws_bytes, void* stream) {
+/* Factor-only half of the apply: the Gram(s) of the factors into the workspace (see plan_apply). */
+int psgd_kron_dd_prepare_f32(const float* Ql, const float* Qr, int M, int N, void* ws, int64_t ws_bytes, void* stream) {
+  if (!Ql || !Qr) return PSGD_ERR_BAD_ARG;
+  if (M <= 0 || N <= 0) return PSGD_ERR_SHAPE;
+  if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KronWs k = kron_layout(static_cast<char*>(ws), M, N);
+  GemmArgs pre[2], app[3];
+  int np = 0, na = 0;
+  plan_apply(Ql, Qr, Ql /*unused*/, k.T /*unused*/, M, N, k, pre, np, app, na);
+  if (np == 2) KRON_LAUNCH(launch_gram_batch(pre, 2, st));
+  else KRON_LAUNCH(launch_gemm(pre[0], st));
+  return PSGD_OK;
+}
+
+/* Gradient-dependent half: needs the Grams psgd_kron_dd_prepare_f32 left in `ws` for these very factors. */
+int psgd_kron_dd_apply_prepared_f32(const float* Ql, const float* Qr, const float* G, float* out, int M, int N, void* ws,
+                                    int64_t ws_bytes, void* stream) {
   if (!Ql || !Qr || !G || !out) return PSGD_ERR_BAD_ARG;
   if (M <= 0 || N <= 0) return PSGD_ERR_SHAPE;
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  GemmArgs s[4];
-  plan_apply(Ql, Qr, G, out, M, N, k, s);
-  for (int i = 0; i < 4; ++i) KRON_LAUNCH(launch_gemm(s[i], st));
+  GemmArgs pre[2], app[3];
+  int np = 0, na = 0;
+  plan_apply(Ql, Qr, G, out, M, N, k, pre, np, app, na);
+  for (int i = 0; i < na; ++i) KRON_LAUNCH(launch_gemm(app[i], st));
   return PSGD_OK;
+}
+
+int psgd_kron_dd_apply_f32(const float* Ql, const float* Qr, const float* G, float* out, int M, int N, void* ws,
+                           int64_t ws_bytes, void* stream) {
+  const int rc = psgd_kron_dd_prepare_f32(Ql, Qr, M, N, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return psgd_kron_dd_apply_prepared_f32(Ql, Qr, G, out, M, N, ws, ws_bytes, stream);
 }
 
 int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, const float* dG, float* QlOut,
@@ -1660,8 +1772,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
-  KRON_LAUNCH(kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st));                       // K0: balance (:166-170)
+  KRON_LAUNCH(kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal));               // K0: balance (:166-170); zeroes k.scal
   GemmArgs s[6];
   plan_update(dG, QlOut, QrOut, M, N, step, tiny, k, s);
   KRON_LAUNCH(launch_gemm(s[0], st));
@@ -1687,32 +1798,61 @@ int64_t psgd_kron_dd_workspace_bytes_batched(const int* M, const int* N, int cou
   return tot;
 }
 
-int psgd_kron_dd_apply_batched_f32(const float* const* Ql, const float* const* Qr, const float* const* G,
-                                   float* const* out, const int* M, const int* N, int count, void* ws,
-                                   int64_t ws_bytes, void* stream) {
-  if (!Ql || !Qr || !G || !out || !M || !N || count <= 0) return PSGD_ERR_BAD_ARG;
+/* mode: 1 = factor-only half (Grams), 2 = gradient half (needs the Grams of mode 1 in ws), 3 = both */
+static int apply_batched_impl(const float* const* Ql, const float* const* Qr, const float* const* G, float* const* out,
+                              const int* M, const int* N, int count, void* ws, int64_t ws_bytes, void* stream, int mode) {
+  if (!Ql || !Qr || !M || !N || count <= 0) return PSGD_ERR_BAD_ARG;
+  if ((mode & 2) && (!G || !out)) return PSGD_ERR_BAD_ARG;
   const int64_t need = psgd_kron_dd_workspace_bytes_batched(M, N, count);
   if (need < 0) return (int)need;
   if (kron_ws_check(ws, ws_bytes, need)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* base = static_cast<char*>(ws);
-  for (int p0 = 0; p0 < count; p0 += kMaxBatch) {
-    const int nb = (count - p0 < kMaxBatch) ? count - p0 : kMaxBatch;
-    GemmArgs s[kMaxBatch][4];
+  for (int p0 = 0; p0 < count; p0 += kMaxLayers) {
+    const int nb = (count - p0 < kMaxLayers) ? count - p0 : kMaxLayers;
+    GemmArgs pre[2 * kMaxLayers], app[3][kMaxLayers];
+    int npre = 0, na_max = 0, na[kMaxLayers];
     for (int q = 0; q < nb; ++q) {
       const int p = p0 + q;
-      if (!Ql[p] || !Qr[p] || !G[p] || !out[p]) return PSGD_ERR_BAD_ARG;
+      if (!Ql[p] || !Qr[p] || ((mode & 2) && (!G[p] || !out[p]))) return PSGD_ERR_BAD_ARG;
       KronWs k = kron_layout(base, M[p], N[p]);
       base += k.total;
-      plan_apply(Ql[p], Qr[p], G[p], out[p], M[p], N[p], k, s[q]);
+      GemmArgs pr[2], ap[3];
+      int np = 0;
+      plan_apply(Ql[p], Qr[p], (mode & 2) ? G[p] : Ql[p], (mode & 2) ? out[p] : k.T, M[p], N[p], k, pr, np, ap, na[q]);
+      for (int i = 0; i < np; ++i) pre[npre++] = pr[i];
+      for (int i = 0; i < na[q]; ++i) app[i][q] = ap[i];
+      if (na[q] > na_max) na_max = na[q];
     }
-    for (int stage = 0; stage < 4; ++stage) {
-      GemmArgs g[kMaxBatch];
-      for (int q = 0; q < nb; ++q) g[q] = s[q][stage];
-      KRON_LAUNCH(launch_gemm_batch(g, nb, st));
+    if (mode & 1) KRON_LAUNCH(launch_gram_batch(pre, npre, st));
+    if (mode & 2) {
+      for (int stage = 0; stage < na_max; ++stage) {
+        GemmArgs g[kMaxBatch];
+        int ng = 0;
+        for (int q = 0; q < nb; ++q)
+          if (stage < na[q]) g[ng++] = app[stage][q];
+        KRON_LAUNCH(launch_gemm_batch(g, ng, st));
+      }
     }
   }
   return PSGD_OK;
+}
+
+int psgd_kron_dd_apply_batched_f32(const float* const* Ql, const float* const* Qr, const float* const* G,
+                                   float* const* out, const int* M, const int* N, int count, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+  return apply_batched_impl(Ql, Qr, G, out, M, N, count, ws, ws_bytes, stream, 3);
+}
+
+int psgd_kron_dd_prepare_batched_f32(const float* const* Ql, const float* const* Qr, const int* M, const int* N, int count,
+                                     void* ws, int64_t ws_bytes, void* stream) {
+  return apply_batched_impl(Ql, Qr, nullptr, nullptr, M, N, count, ws, ws_bytes, stream, 1);
+}
+
+int psgd_kron_dd_apply_prepared_batched_f32(const float* const* Ql, const float* const* Qr, const float* const* G,
+                                            float* const* out, const int* M, const int* N, int count, void* ws,
+                                            int64_t ws_bytes, void* stream) {
+  return apply_batched_impl(Ql, Qr, G, out, M, N, count, ws, ws_bytes, stream, 2);
 }
 
 int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* Qr, const float* const* dX,
@@ -1727,29 +1867,37 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
     if (M[p] > 512 || N[p] > 512) return PSGD_ERR_SHAPE;   // batched form is for small layers
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* base = static_cast<char*>(ws);
-  for (int p0 = 0; p0 < count; p0 += kMaxBatch) {
-    const int nb = (count - p0 < kMaxBatch) ? count - p0 : kMaxBatch;
-    GemmArgs s[kMaxBatch][6];
-    KronWs k[kMaxBatch];
+  for (int p0 = 0; p0 < count; p0 += kMaxLayers) {
+    const int nb = (count - p0 < kMaxLayers) ? count - p0 : kMaxLayers;
+    GemmArgs s[kMaxLayers][6];
+    KronWs k[kMaxLayers];
     BalanceBatch bb;
-    TrsmBatch t1, t2;
+    TrsmBatch t1, t2, inv;
     bb.count = t1.count = t2.count = nb;
-    int blk1 = 0, blk2 = 0;
+    inv.count = 2 * nb;
+    int blk1 = 0, blk2 = 0, nblk = 0, nmax = 0;
     for (int q = 0; q < nb; ++q) {
       const int p = p0 + q;
       if (!Ql[p] || !Qr[p] || !dX[p] || !dG[p] || !QlOut[p] || !QrOut[p]) return PSGD_ERR_BAD_ARG;
       k[q] = kron_layout(base, M[p], N[p]);
       base += k[q].total;
-      if (hipMemsetAsync(k[q].scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
       plan_update(dG[p], QlOut[p], QrOut[p], M[p], N[p], step, tiny, k[q], s[q]);
       bb.Ql[q] = Ql[p]; bb.Qr[q] = Qr[p]; bb.QlS[q] = k[q].QlS; bb.QrS[q] = k[q].QrS; bb.M[q] = M[p]; bb.N[q] = N[p];
+      bb.scal[q] = k[q].scal;
       t1.t[q] = {k[q].QrS, N[p], N[p], dX[p], k[q].X1, M[p], (long)N[p], 1L, 0L, 0L};
       t1.dinv[q] = k[q].dinv; t2.dinv[q] = k[q].dinv + (long)((N[p] + 31) / 32) * 1024;
       t2.t[q] = {k[q].QlS, M[p], M[p], k[q].X1, k[q].Bt, N[p], 1L, (long)N[p], 0L, 0L};
       blk1 += (M[p] + 15) / 16; t1.blk_end[q] = blk1;      // 16-vector strips (k_trsm_ut_inv_batched)
       blk2 += (N[p] + 15) / 16; t2.blk_end[q] = blk2;
+      // inversion of the 32 x 32 diagonal blocks: both factors of every layer in ONE launch
+      inv.t[2 * q] = t1.t[q]; inv.dinv[2 * q] = t1.dinv[q];
+      nblk += (N[p] + 31) / 32; inv.blk_end[2 * q] = nblk;
+      inv.t[2 * q + 1] = t2.t[q]; inv.dinv[2 * q + 1] = t2.dinv[q];
+      nblk += (M[p] + 31) / 32; inv.blk_end[2 * q + 1] = nblk;
+      if (M[p] > nmax) nmax = M[p];
+      if (N[p] > nmax) nmax = N[p];
     }
-    hipLaunchKernelGGL(k_kron_balance_batched, dim3(64, nb), dim3(kThreads), 0, st, bb);
+    hipLaunchKernelGGL(k_kron_balance_batched, dim3(64, nb), dim3(kThreads), 0, st, bb);   // (also zeroes the scratch words)
     KRON_LAUNCH((int)hipGetLastError());
     GemmArgs g[kMaxBatch];
     for (int stage = 0; stage < 2; ++stage) {
@@ -1757,17 +1905,10 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
       KRON_LAUNCH(launch_gemm_batch(g, nb, st));
     }
     // K2 (:174) for every layer: invert the 32 x 32 diagonal blocks of all factors, then the two solves
+    hipLaunchKernelGGL(k_tri_inv32_batched, dim3(nblk), dim3(64), 0, st, inv);
+    KRON_LAUNCH((int)hipGetLastError());
     for (int pass = 0; pass < 2; ++pass) {
       TrsmBatch& tb = pass ? t2 : t1;
-      TrsmBatch ib = tb;
-      int nblk = 0, nmax = 0;
-      for (int q = 0; q < nb; ++q) {
-        nblk += (tb.t[q].n + 31) / 32;
-        ib.blk_end[q] = nblk;
-        if (tb.t[q].n > nmax) nmax = tb.t[q].n;
-      }
-      hipLaunchKernelGGL(k_tri_inv32_batched, dim3(nblk), dim3(64), 0, st, ib);
-      KRON_LAUNCH((int)hipGetLastError());
       if (!g_trsm_lds) {
         hipLaunchKernelGGL(k_trsm_ut_reg_batched, dim3(pass ? blk2 : blk1), dim3(kThreads), 0, st, tb);
         KRON_LAUNCH((int)hipGetLastError());
@@ -1786,9 +1927,11 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
                          (size_t)(16 * pitch_max + 32 * 33) * sizeof(float), st, tb, pitch_max);
       KRON_LAUNCH((int)hipGetLastError());
     }
-    for (int stage = 2; stage < 6; ++stage) {
-      for (int q = 0; q < nb; ++q) g[q] = s[q][stage];
-      KRON_LAUNCH(launch_gemm_batch(g, nb, st));
+    // the two gradient products of a layer are independent of each other, and so are its two factor updates: each pair
+    // of stages is one launch over 2 nb problems
+    for (int stage = 2; stage < 6; stage += 2) {
+      for (int q = 0; q < nb; ++q) { g[2 * q] = s[q][stage]; g[2 * q + 1] = s[q][stage + 1]; }
+      KRON_LAUNCH(launch_gemm_batch(g, 2 * nb, st));
     }
   }
   return PSGD_OK;

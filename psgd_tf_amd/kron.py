@@ -62,6 +62,28 @@ def _check_kron_shapes(name, Ql, Qr, *mats):
             raise ValueError("%s: all tensors must be on one device, got %s and %s" % (name, dev, t.device))
 
 
+class _FactorTag:
+    """Identity of the factor tensors some prepared, factor-only data (Grams, bf16 copies) in a workspace was made
+    from: the very tensor objects (weak references), their version counters and their storage pointers.  A new tensor
+    that the allocator placed at the address of a freed one is a different object, hence a miss."""
+
+    def __init__(self, tensors):
+        self.refs = [weakref.ref(t) for t in tensors]
+        self.meta = [(t._version, t.data_ptr()) for t in tensors]
+
+    def matches(self, tensors):
+        return len(tensors) == len(self.refs) and all(r() is t and m == (t._version, t.data_ptr())
+                                                      for r, m, t in zip(self.refs, self.meta, tensors))
+
+
+_prepared = {}            # workspace key -> _FactorTag of the Grams it holds (fp32 apply, single and batched)
+
+
+def _is_prepared(key, tensors):
+    tag = _prepared.get(key)
+    return tag is not None and tag.matches(tensors)
+
+
 # --------------------------------------------------------------------------- dense (x) dense: HIP
 _kron_ws = _lib.WorkspaceCache()
 _kron_ws_bf16 = _lib.WorkspaceCache()
@@ -75,6 +97,7 @@ def _stream_key(device):
 def _kron_workspace(device, M, N):
     key = (device.index if device.index is not None else torch.cuda.current_device(), M, N, _stream_key(device))
     def make():
+        _prepared.pop(("dd",) + key, None)
         nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes(M, N))
         if nbytes < 0:
             _lib.check(nbytes, "psgd_kron_dd_workspace_bytes")
@@ -196,11 +219,10 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     # The bf16 copies of the factors live in the workspace and only change when the factors do: convert again only if
     # these are not the very tensor objects (same storage, same version counter) the copies were made from.
     tag = _bf16_prepared.get(key)
-    if not (tag is not None and tag[0]() is Ql and tag[1]() is Qr and tag[2:] == (Ql._version, Qr._version,
-                                                                                 Ql.data_ptr(), Qr.data_ptr())):
+    if not (tag is not None and tag.matches((Ql, Qr))):
         _lib.check(lib.psgd_kron_bf16_prepare_factors(Ql.data_ptr(), Qr.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st),
                    "psgd_kron_bf16_prepare_factors")
-        _bf16_prepared[key] = (weakref.ref(Ql), weakref.ref(Qr), Ql._version, Qr._version, Ql.data_ptr(), Qr.data_ptr())
+        _bf16_prepared[key] = _FactorTag((Ql, Qr))
     rc = lib.psgd_kron_dd_apply_bf16_prepared(Grad.data_ptr(), out.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "psgd_kron_dd_apply_bf16_prepared")
     return out
@@ -214,11 +236,21 @@ def _precond_grad_dense_dense(Ql, Qr, Grad):
     M, N = Grad.shape
     Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
     out = torch.empty_like(Grad)
-    ws = _kron_workspace(Grad.device, M, N)
-    rc = _lib.load().psgd_kron_dd_apply_f32(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
-                                             ws.data_ptr(), ws.numel(),
-                                             torch.cuda.current_stream(Grad.device).cuda_stream)
-    _lib.check(rc, "psgd_kron_dd_apply_f32")
+    dev = Grad.device
+    ws = _kron_workspace(dev, M, N)
+    lib, st = _lib.load(), torch.cuda.current_stream(dev).cuda_stream
+    # factor-only half (the Grams, kept in the workspace): redone only when these are not the factor tensors it was
+    # made from
+    key = ("dd", dev.index if dev.index is not None else torch.cuda.current_device(), M, N, st)
+    if _is_prepared(key, (Ql, Qr)):
+        rc = lib.psgd_kron_dd_apply_prepared_f32(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
+                                                 ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "psgd_kron_dd_apply_prepared_f32")
+    else:                                            # both halves in one call (= prepare + apply_prepared)
+        rc = lib.psgd_kron_dd_apply_f32(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
+                                        ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "psgd_kron_dd_apply_f32")
+        _prepared[key] = _FactorTag((Ql, Qr))
     return out
 
 
@@ -244,6 +276,7 @@ def _int_array(vals):
 def _batch_workspace(device, Ms, Ns):
     key = (device.index, tuple(Ms), tuple(Ns), _stream_key(device))
     def make():
+        _prepared.pop(("ddb",) + key, None)
         nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes_batched(_int_array(Ms), _int_array(Ns), len(Ms)))
         if nbytes < 0:
             _lib.check(nbytes, "psgd_kron_dd_workspace_bytes_batched")
@@ -267,10 +300,18 @@ def precond_grad_kron_batched(Qls, Qrs, Grads):
     Ms, Ns = [g.shape[0] for g in Grads], [g.shape[1] for g in Grads]
     dev = Grads[0].device
     ws = _batch_workspace(dev, Ms, Ns)
-    rc = _lib.load().psgd_kron_dd_apply_batched_f32(_ptr_array(Qls), _ptr_array(Qrs), _ptr_array(Grads),
-                                                     _ptr_array(outs), _int_array(Ms), _int_array(Ns), len(Ms),
-                                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(rc, "psgd_kron_dd_apply_batched_f32")
+    lib, st = _lib.load(), torch.cuda.current_stream(dev).cuda_stream
+    key = ("ddb", dev.index, tuple(Ms), tuple(Ns), st)
+    pl, pr, pm, pn = _ptr_array(Qls), _ptr_array(Qrs), _int_array(Ms), _int_array(Ns)
+    if _is_prepared(key, Qls + Qrs):                 # the Grams of every layer's factors are in the workspace
+        rc = lib.psgd_kron_dd_apply_prepared_batched_f32(pl, pr, _ptr_array(Grads), _ptr_array(outs), pm, pn, len(Ms),
+                                                         ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "psgd_kron_dd_apply_prepared_batched_f32")
+    else:                                            # Grams (one launch) + gradient half, one call
+        rc = lib.psgd_kron_dd_apply_batched_f32(pl, pr, _ptr_array(Grads), _ptr_array(outs), pm, pn, len(Ms),
+                                                ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "psgd_kron_dd_apply_batched_f32")
+        _prepared[key] = _FactorTag(Qls + Qrs)
     return outs
 
 

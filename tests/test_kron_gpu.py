@@ -377,6 +377,36 @@ def test_bf16_update_rejects_mixed_dtypes(psgd):
                                  torch.ones(8, 16, device="cuda"), torch.ones(8, 16, device="cuda"))
 
 
+@pytest.mark.parametrize("M,N", [(257, 120), (85, 10), (16, 40), (640, 1024)])
+def test_prepared_grams_follow_the_factors(psgd, M, N):
+    """fp32 apply: the Grams of the factors are kept in the workspace and recomputed only when the factors change (same
+    rules as the bf16 copies below); single and batched calls; small (both Grams) and large (reference-order Gram) plans."""
+    rng = np.random.default_rng(M + N)
+    Ql, Qr = _dev(_tri_factor(rng, M).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
+    G, G2 = _dev(rng.standard_normal((M, N))), _dev(rng.standard_normal((M, N)))
+    ref = lambda ql, qr, g: orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (ql, qr, g)))
+    a = psgd.precond_grad_kron(Ql, Qr, G)
+    b = psgd.precond_grad_kron(Ql, Qr, G)                          # Grams reused
+    c = psgd.precond_grad_kron(Ql, Qr, G2)                         # ... for another gradient too
+    assert torch.equal(a, b) and rel_err(a.cpu().numpy(), ref(Ql, Qr, G)) < TOL and rel_err(c.cpu().numpy(), ref(Ql, Qr, G2)) < TOL
+    # an update in between uses the same workspace: the prepared Grams must survive it
+    psgd.update_precond_kron(Ql, Qr, G, G2, 0.01)
+    assert torch.equal(psgd.precond_grad_kron(Ql, Qr, G), a)
+    Ql.mul_(1.5)                                                   # in place: new version -> recomputed
+    assert rel_err(psgd.precond_grad_kron(Ql, Qr, G).cpu().numpy(), ref(Ql, Qr, G)) < TOL
+    del Qr
+    Qr2 = _dev((_tri_factor(rng, N) * 0.5).astype(np.float32))     # a new tensor, usually at the address just freed
+    assert rel_err(psgd.precond_grad_kron(Ql, Qr2, G).cpu().numpy(), ref(Ql, Qr2, G)) < TOL
+    # batched
+    o1 = psgd.precond_grad_kron_batched([Ql, Ql], [Qr2, Qr2], [G, G2])
+    o2 = psgd.precond_grad_kron_batched([Ql, Ql], [Qr2, Qr2], [G2, G])
+    assert rel_err(o1[0].cpu().numpy(), ref(Ql, Qr2, G)) < TOL and rel_err(o2[0].cpu().numpy(), ref(Ql, Qr2, G2)) < TOL
+    assert torch.equal(o1[1], o2[0]) and torch.equal(o1[0], o2[1])
+    Qr2.add_(torch.triu(torch.full_like(Qr2, 0.01)))
+    o3 = psgd.precond_grad_kron_batched([Ql, Ql], [Qr2, Qr2], [G, G2])
+    assert rel_err(o3[0].cpu().numpy(), ref(Ql, Qr2, G)) < TOL and rel_err(o3[1].cpu().numpy(), ref(Ql, Qr2, G2)) < TOL
+
+
 def test_bf16_factor_copies_follow_the_factors(psgd):
     """The bf16 copies of the factors are cached in the workspace and rebuilt only when the factors change: same tensor
     objects -> reused (same result); modified in place (version counter) -> rebuilt; a different tensor that the
