@@ -508,3 +508,30 @@ def test_sparse_formats_large(psgd, fmt, sl, sr):
     assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(a64[0], a64[1], a64[4])) < TOL
     # inputs are never written
     assert np.array_equal(_dev(a32[0]).cpu().numpy(), a32[0])
+
+
+@pytest.mark.parametrize("M,N", [(300, 200), (1100, 530), (2048, 1536)])
+def test_update_with_ill_conditioned_factors(psgd, M, N):
+    """Factors with cond(Q) ~ 1e4 (diagonals spread over four decades, dense upper triangles): the two triangular solves of
+    psgd.py:174 carry the conditioning.  Updated factors within 1e-5 of the fp64 oracle, increments within 2e-3 -- the
+    bar any faster (e.g. inverse-based) solve has to keep."""
+    rng = np.random.default_rng(M + 13 * N)
+
+    def illcond(n):
+        d = np.exp(np.linspace(0.0, -np.log(1e4), n))
+        rng.shuffle(d)
+        Q = np.triu(rng.standard_normal((n, n)) * (0.3 / n ** 0.5), 1) * d[None, :] + np.diag(d)
+        return Q
+    Ql, Qr = illcond(M), illcond(N)
+    assert 3e3 < np.linalg.cond(Ql) < 1e6 and 3e3 < np.linalg.cond(Qr) < 1e6
+    dX = rng.standard_normal((M, N))
+    dG = np.linalg.solve(Ql.T @ Ql, dX) @ np.linalg.inv(Qr.T @ Qr) * np.exp(rng.uniform(-0.5, 0.5, (1, N)))   # near the fixed point: A ~ Bt
+    a32 = [x.astype(np.float32) for x in (Ql, Qr, dX, dG)]
+    a64 = [x.astype(np.float64) for x in a32]
+    got = psgd.update_precond_kron(*(_dev(x) for x in a32), 0.01)
+    ref = orc.update_precond_kron(*a64, 0.01)
+    rho = np.sqrt(np.max(np.diag(a64[0])) / np.max(np.diag(a64[1])))
+    for g_, r_, q0 in zip(got, ref, (a64[0] / rho, a64[1] * rho)):
+        g64 = g_.cpu().numpy().astype(np.float64)
+        assert rel_err(g64, r_) < TOL
+        assert rel_err(g64 - q0, r_ - q0) < INCR_TOL
