@@ -37,10 +37,11 @@ def _check_rank2_f32(name, *tensors, allow_bf16_last=False, allow_bf16_from=None
     # the one extension is bf16 data for (dense, dense): a bf16 gradient for the apply (BASELINE config 5),
     # a bf16 (dX, dG) pair for the update.  The factors stay fp32.
     first_bf16 = len(tensors) - 1 if allow_bf16_last else allow_bf16_from
+    f32 = torch.float32
     for i, t in enumerate(tensors):
         if t.dim() != 2:
             raise ValueError("%s: rank-2 tensors required, got shape %s" % (name, tuple(t.shape)))
-        if t.dtype != torch.float32 and not (first_bf16 is not None and i >= first_bf16 and t.dtype == torch.bfloat16):
+        if t.dtype is not f32 and not (first_bf16 is not None and i >= first_bf16 and t.dtype == torch.bfloat16):
             raise TypeError("%s: fp32 tensors required, got %s" % (name, t.dtype))
 
 
@@ -48,9 +49,10 @@ def _check_kron_shapes(name, Ql, Qr, *mats):
     """Every format keeps M = rows(data) in the last dimension of the left factor ((M,M), (2,M) or (1,M)) and
     N = cols(data) in the last dimension of the right one.  The reference's matmuls raise on a mismatch; the kernels
     take raw pointers and would read or write out of bounds, so the check is here."""
-    M, N = mats[0].shape
+    shape = mats[0].shape
+    M, N = shape
     for t in mats[1:]:
-        if tuple(t.shape) != (M, N):
+        if t.shape != shape:
             raise ValueError("%s: data matrices must share one shape, got %s and %s"
                              % (name, tuple(mats[0].shape), tuple(t.shape)))
     if Ql.shape[1] != M or Qr.shape[1] != N:
@@ -97,7 +99,6 @@ def _stream_key(device):
 def _kron_workspace(device, M, N):
     key = (device.index if device.index is not None else torch.cuda.current_device(), M, N, _stream_key(device))
     def make():
-        _prepared.pop(("dd",) + key, None)
         nbytes = int(_lib.load().psgd_kron_dd_workspace_bytes(M, N))
         if nbytes < 0:
             _lib.check(nbytes, "psgd_kron_dd_workspace_bytes")
@@ -228,29 +229,56 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     return out
 
 
+class _ApplySlot:
+    """Per (device, shape, stream): the workspace and what its prepared Grams were made from.  Small layers are
+    host-bound (a launch costs the host ~4 us, the GPU less), so the per-call Python work is kept to a handful of
+    attribute reads: the factor identity check is spelled out instead of built from generators."""
+    __slots__ = ("ws", "ws_ptr", "ws_bytes", "rl", "rr", "vl", "vr", "pl", "pr")
+
+    def __init__(self, ws):
+        self.ws, self.ws_ptr, self.ws_bytes = ws, ws.data_ptr(), ws.numel()
+        self.rl = self.rr = None
+        self.vl = self.vr = self.pl = self.pr = -1
+
+
+_apply_slots = {}
+
+
 def _precond_grad_dense_dense(Ql, Qr, Grad):
     """psgd.py:182-192 on the GPU."""
     _require_hip("precond_grad_kron", Ql, Qr, Grad)
     if Grad.dtype == torch.bfloat16:
         return _precond_grad_dense_dense_bf16(Ql, Qr, Grad)
     M, N = Grad.shape
-    Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))
+    if not Ql.is_contiguous():
+        Ql = Ql.contiguous()
+    if not Qr.is_contiguous():
+        Qr = Qr.contiguous()
+    if not Grad.is_contiguous():
+        Grad = Grad.contiguous()
     out = torch.empty_like(Grad)
     dev = Grad.device
-    ws = _kron_workspace(dev, M, N)
-    lib, st = _lib.load(), torch.cuda.current_stream(dev).cuda_stream
-    # factor-only half (the Grams, kept in the workspace): redone only when these are not the factor tensors it was
-    # made from
-    key = ("dd", dev.index if dev.index is not None else torch.cuda.current_device(), M, N, st)
-    if _is_prepared(key, (Ql, Qr)):
-        rc = lib.psgd_kron_dd_apply_prepared_f32(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
-                                                 ws.data_ptr(), ws.numel(), st)
-        _lib.check(rc, "psgd_kron_dd_apply_prepared_f32")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index, M, N, st)
+    slot = _apply_slots.get(key)
+    ws = _kron_workspace(dev, M, N)                  # (LRU touch; a fresh workspace holds no Grams)
+    if slot is None or slot.ws is not ws:
+        slot = _apply_slots[key] = _ApplySlot(ws)
+    lib = _lib.load()
+    pl, pr = Ql.data_ptr(), Qr.data_ptr()
+    # factor-only half (the Grams, kept in the workspace): redone only when these are not the very factor tensors (same
+    # objects, same version counters, same storage) it was made from
+    if (slot.rl is not None and slot.rl() is Ql and slot.rr() is Qr and slot.vl == Ql._version and slot.vr == Qr._version
+            and slot.pl == pl and slot.pr == pr):
+        rc = lib.psgd_kron_dd_apply_prepared_f32(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
+        if rc:
+            _lib.check(rc, "psgd_kron_dd_apply_prepared_f32")
     else:                                            # both halves in one call (= prepare + apply_prepared)
-        rc = lib.psgd_kron_dd_apply_f32(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N,
-                                        ws.data_ptr(), ws.numel(), st)
-        _lib.check(rc, "psgd_kron_dd_apply_f32")
-        _prepared[key] = _FactorTag((Ql, Qr))
+        rc = lib.psgd_kron_dd_apply_f32(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
+        if rc:
+            _lib.check(rc, "psgd_kron_dd_apply_f32")
+        slot.rl, slot.rr = weakref.ref(Ql), weakref.ref(Qr)
+        slot.vl, slot.vr, slot.pl, slot.pr = Ql._version, Qr._version, pl, pr
     return out
 
 
