@@ -45,6 +45,9 @@ def fuzz_kron(g, it):
 def fuzz_kron_bf16(g, it):
     M = 8 * int(torch.randint(1, 330, (1,), generator=g, device=dev))
     N = 8 * int(torch.randint(1, 330, (1,), generator=g, device=dev))
+    if it % 3 == 1:                                   # not multiples of 8: the zero-padded path
+        M, N = M - int(torch.randint(0, 8, (1,), generator=g, device=dev)), N - int(torch.randint(0, 8, (1,), generator=g, device=dev))
+        M, N = max(M, 1), max(N, 1)
     if it % 5 == 0:
         M, N = 256 * int(torch.randint(4, 17, (1,), generator=g, device=dev)), 256 * int(torch.randint(4, 17, (1,), generator=g, device=dev))
     off = 0.5 / max(M, N) ** 0.5
@@ -75,9 +78,15 @@ def fuzz_kron_bf16_update(g, it):
 
 def fuzz_uvd(g, it):
     r = int(torch.randint(1, 33, (1,), generator=g, device=dev))
+    if it % 15 == 3:                                  # wide rank: column chunks (uvd_wide.py)
+        r = int(torch.randint(33, 80, (1,), generator=g, device=dev))
     N = int(torch.randint(max(r, 2), 400000 if it % 4 == 0 else 20000, (1,), generator=g, device=dev))
-    sc = 2.0 * (1.0 / (N * r)) ** 0.5
+    # from the reference's init scale (gain 2) to ||U V'|| = O(1) (gain ~ sqrt(r)), V correlated with U every third case
+    gain = 2.0 if it % 3 else float(torch.empty(1, device=dev).uniform_(0.5, 1.5, generator=g)) * r ** 0.5
+    sc = gain * (1.0 / (N * r)) ** 0.5
     U, V = torch.randn(N, r, device=dev, generator=g) * sc, torch.randn(N, r, device=dev, generator=g) * sc
+    if it % 3 == 0 and N > 4 * r:
+        V = (0.5 * U @ torch.linalg.qr(torch.randn(r, r, device=dev, generator=g))[0] + 0.7 * V).contiguous()
     d = torch.exp(0.3 * torch.randn(N, 1, device=dev, generator=g))
     gr, v = torch.randn(N, 1, device=dev, generator=g), torch.randn(N, 1, device=dev, generator=g)
     h = v * torch.exp(torch.empty(N, 1, device=dev).uniform_(-4.6, 4.6, generator=g))
@@ -87,7 +96,14 @@ def fuzz_uvd(g, it):
     out = psgd.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, gr, 0.01, TINY, balance=bal, update_U=upd)
     ref64.update_precond_UVd_math_(U64, V64, d64, v.double(), h.double(), 0.01, TINY, balance=bal, update_U=upd)
     e = max(rel(out, ref64.precond_grad_UVd_math(U64, V64, d64, gr.double())), rel(U, U64), rel(V, V64), rel(d, d64))
-    return "uvd N=%d r=%d" % (N, r), e, 1e-5
+    if it % 2 == 0:                                   # the two reference-named calls and IpUVtmatvec on a matrix
+        psgd.update_precond_UVd_math_(U, V, d, v, h, 0.01, TINY, balance=False, update_U=not upd)
+        ref64.update_precond_UVd_math_(U64, V64, d64, v.double(), h.double(), 0.01, TINY, balance=False, update_U=not upd)
+        e = max(e, rel(psgd.precond_grad_UVd_math(U, V, d, gr), ref64.precond_grad_UVd_math(U64, V64, d64, gr.double())),
+                rel(U, U64), rel(V, V64), rel(d, d64))
+        X = torch.cat([gr, v, d], 1).contiguous()
+        e = max(e, rel(psgd.IpUVtmatvec(U, V, X), ref64.IpUVtmatvec(U.double(), V.double(), X.double())))
+    return "uvd N=%d r=%d" % (N, r), e, 2e-5 if r > 32 else 1e-5
 
 
 def splu_apply64(L12, l3, U12, u3, x, r):
