@@ -197,3 +197,45 @@ def test_kron_dX_dG_shape_mismatch_raises():
     import preconditioned_stochastic_gradient_descent as psgd
     with pytest.raises(ValueError, match="share one shape"):
         psgd.update_precond_kron(torch.eye(4), torch.eye(3), torch.ones(4, 3), torch.ones(3, 4), 0.01)
+
+
+def test_factor_tag_identity_rules():
+    """kron._FactorTag decides whether prepared, factor-only data (Grams, bf16 copies) may be reused: only for the very
+    tensor objects it was made from, unmodified."""
+    a, b = torch.eye(4), torch.eye(3)
+    tag = kron._FactorTag((a, b))
+    assert tag.matches((a, b))
+    assert not tag.matches((a.clone(), b))                 # equal values, other object
+    assert not tag.matches((b, a)) and not tag.matches((a,))
+    a.mul_(2.0)                                            # in place: version counter moves
+    assert not tag.matches((a, b))
+    tag = kron._FactorTag((a, b))
+    view = a.view(4, 4)                                    # another object on the same storage
+    assert not tag.matches((view, b))
+
+
+@pytest.mark.parametrize("M,N", [(5, 12), (13, 7), (1, 3)])
+def test_zero_padding_of_bf16_kron_shapes_is_exact_in_the_oracle(M, N):
+    """The bf16 kernels need M, N multiples of 8; other shapes run as blockdiag(Q, tiny I) with zero-padded data
+    (kron._padded_bf16_problem).  Claim: every product and solve of psgd.py:156-192 is then block diagonal, so the leading
+    block of each result is the unpadded result.  Checked here with the fp64 oracle on the padded problem."""
+    rng = np.random.default_rng(M * 31 + N)
+    tri = lambda n: np.triu(rng.standard_normal((n, n)) * 0.2, 1) + np.diag(np.exp(0.3 * rng.standard_normal(n)))
+    Ql, Qr = tri(M), tri(N)
+    dX, dG, G = (rng.standard_normal((M, N)) for _ in range(3))
+    t = lambda a: torch.from_numpy(a)
+    Qlp, Qrp, (dXp, dGp, Gp) = kron._padded_bf16_problem(t(Ql), t(Qr), (t(dX), t(dG), t(G)))
+    assert Qlp.shape[0] % 8 == 0 and Qrp.shape[0] % 8 == 0 and tuple(Gp.shape) == (Qlp.shape[0], Qrp.shape[0])
+    a, b = orc.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    ap, bp = orc.update_precond_kron(Qlp.numpy(), Qrp.numpy(), dXp.numpy(), dGp.numpy(), 0.01)
+    assert rel_err(ap[:M, :M], a) < 1e-12 and rel_err(bp[:N, :N], b) < 1e-12
+    out = orc.precond_grad_kron(Ql, Qr, G)
+    outp = orc.precond_grad_kron(Qlp.numpy(), Qrp.numpy(), Gp.numpy())
+    assert rel_err(outp[:M, :N], out) < 1e-12 and np.abs(outp[M:]).max(initial=0.0) == 0.0 and np.abs(outp[:, N:]).max(initial=0.0) == 0.0
+
+
+def test_wide_rank_chunking():
+    from psgd_tf_amd import uvd_wide
+    for r in (33, 40, 48, 64, 65, 100, 257):
+        c, rc = uvd_wide._chunks(r)
+        assert rc <= 32 and c * rc >= r and (c - 1) * rc < r and c == -(-r // 32)
