@@ -11,6 +11,8 @@ int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, flo
 
 // Solve y Q = x for nvec vectors (vector i at stride si, element j at stride sj; Q upper triangular [n][n]);
 // dinv: scratch of ceil(n/32) * 1024 floats.  0 on success.
-int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st);
+// lite: the trailing products of the blocked solve keep only the three leading terms of the bf16 x 3 split (2^-16 relative)
+int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st,
+                 int lite = 0);
 
 }  // namespace psgdk

@@ -53,6 +53,7 @@ struct GemmArgs {
   long c_cs;
   const float* colv; int colsq;         // EPI_STORE: C(m,n) *= colv[n] (colsq: *= colv[n]^2)
   int sym;                              // C is symmetric (Gram X'X): tiles below the diagonal are skipped, the others stored twice
+  int lite;                             // split GEMM: keep only h h' + h m' + m h' (2^-16 instead of 2^-24 relative per product)
 };
 
 enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8 };
@@ -81,8 +82,8 @@ __device__ __forceinline__ int tile_mode(const TileSrc& t, int x0, int k0, int k
 }
 
 template <int T, int GK>
-__device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int khi, float mul,
-                                         float (&r)[T * GK / kThreads]) {
+__device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int khi,      // loads only: any use of a value
+                                         float (&r)[T * GK / kThreads]) {                 // here stalls ahead of the MFMAs
   const int tid = threadIdx.x;
   constexpr int NV = T * GK / (4 * kThreads);   // float4 per thread
   const int mode = tile_mode<T, GK>(t, x0, k0, khi);
@@ -92,7 +93,7 @@ __device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int k
       const int f = tid + kThreads * u, row = f / (GK / 4), k4 = f % (GK / 4);
       const f32x4 v = *reinterpret_cast<const f32x4*>(t.P + (long)(x0 + row) * t.rs + k0 + 4 * k4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e] * mul;
+      for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e];
     }
   } else if (mode == 2) {
 #pragma unroll
@@ -100,7 +101,7 @@ __device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int k
       const int f = tid + kThreads * u, k = f / (T / 4), x4 = f % (T / 4);
       const f32x4 v = *reinterpret_cast<const f32x4*>(t.P + (long)(k0 + k) * t.cs + x0 + 4 * x4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e] * mul;
+      for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e];
     }
   } else {
 #pragma unroll
@@ -109,13 +110,13 @@ __device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int k
       int x, k;
       if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % T; k = e / T; }
       const int gx = x0 + x, gk = k0 + k;
-      r[u] = (gx < t.X && gk < khi) ? t.P[(long)gx * t.rs + (long)gk * t.cs] * mul : 0.0f;
+      r[u] = (gx < t.X && gk < khi) ? t.P[(long)gx * t.rs + (long)gk * t.cs] : 0.0f;
     }
   }
 }
 
 template <int T, int GK>
-__device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int khi,
+__device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int khi, float mul,
                                          const float (&r)[T * GK / kThreads], float (*S)[T + 16]) {
   const int tid = threadIdx.x;
   constexpr int NV = T * GK / (4 * kThreads);
@@ -125,13 +126,13 @@ __device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int k
     for (int u = 0; u < NV; ++u) {
       const int f = tid + kThreads * u, row = f / (GK / 4), k4 = f % (GK / 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S[4 * k4 + e][row] = r[4 * u + e];
+      for (int e = 0; e < 4; ++e) S[4 * k4 + e][row] = r[4 * u + e] * mul;
     }
   } else if (mode == 2) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int f = tid + kThreads * u, k = f / (T / 4), x4 = f % (T / 4);
-      *reinterpret_cast<f32x4*>(&S[k][4 * x4]) = f32x4{r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]};
+      *reinterpret_cast<f32x4*>(&S[k][4 * x4]) = f32x4{r[4 * u] * mul, r[4 * u + 1] * mul, r[4 * u + 2] * mul, r[4 * u + 3] * mul};
     }
   } else {
 #pragma unroll
@@ -139,7 +140,7 @@ __device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int k
       const int e = tid + kThreads * u;
       int x, k;
       if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % T; k = e / T; }
-      S[k][x] = r[u];
+      S[k][x] = r[u] * mul;
     }
   }
 }
@@ -262,14 +263,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, Gem
   auto fetch = [&](int t) {
     const int p = t < nk[0] ? 0 : 1;
     const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
-    g2r_tile<T, GK>(ta[p], m0, k0, khi[p], p ? -a_mul : a_mul, ra);
-    g2r_tile<T, GK>(tb[p], n0, k0, khi[p], 1.0f, rb);
+    g2r_tile<T, GK>(ta[p], m0, k0, khi[p], ra);
+    g2r_tile<T, GK>(tb[p], n0, k0, khi[p], rb);
   };
   auto commit = [&](int t, int buf) {
     const int p = t < nk[0] ? 0 : 1;
     const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
-    r2s_tile<T, GK>(ta[p], m0, k0, khi[p], ra, L.A[buf]);
-    r2s_tile<T, GK>(tb[p], n0, k0, khi[p], rb, L.B[buf]);
+    r2s_tile<T, GK>(ta[p], m0, k0, khi[p], p ? -a_mul : a_mul, ra, L.A[buf]);
+    r2s_tile<T, GK>(tb[p], n0, k0, khi[p], 1.0f, rb, L.B[buf]);
   };
 
   if (ntile > 0) {
@@ -333,46 +334,75 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned (&pk)[3
 }
 
 // Operand tile -> registers -> LDS planes.  Whatever the memory layout, a thread ends up with 16 consecutive k of ONE
-// row of the (x, k) tile, so the LDS side is always two 16-byte chunk stores per plane:
-//   K-contiguous operands (cs == 1): row = tid / 2, k half = tid % 2, four float4 loads;
-//   X-contiguous operands (rs == 1): row = tid % 128, k half = tid / 128, sixteen 4-byte loads, each coalesced
-//     across the wave (lane -> row);  anything else / edge tiles: the first mapping with guarded scalar loads.
-__device__ __forceinline__ void g2r_x3(const TileSrc& t, int x0, int k0, int khi, float mul, float (&r)[16], int& xr, int& kb) {
-  constexpr int T = 128, GK = kX3K;
+// row of the (x, k) tile, so the LDS side is always two 16-byte chunk stores per plane.  The layout is a COMPILE-TIME
+// mode of the K loop (x3_pass below is instantiated per mode pair and chosen once per block and operand pair):
+//   X3_KVEC  K-contiguous operands (cs == 1): row = tid / 2, k half = tid % 2, four float4 loads;
+//   X3_XROW  X-contiguous operands (rs == 1): row = tid % 128, k half = tid / 128, sixteen 4-byte loads, each coalesced
+//            across the wave (lane -> row);
+//   X3_EDGE  anything else and edge tiles: the first mapping with scalar loads from CLAMPED addresses; the elements
+//            outside the operand are zeroed when the tile is committed to LDS.
+// The fetch is straight-line code and never USES a loaded value (no scaling, no select): the loads of K tile t + 1 are
+// issued ahead of the MFMAs of tile t, and any use -- or a branch between load variants, which makes the compiler wait
+// at the join -- would put a full memory latency in front of the matrix work.  (Round 1 scaled the A operand in the
+// fetch and chose the variant inside the loop: 34 % matrix-pipe occupancy)
+enum { X3_EDGE = 0, X3_KVEC = 1, X3_XROW = 2 };
+
+// Addresses are a UNIFORM base (scalar registers, advanced per K tile) plus a 32-bit per-lane byte offset that does not
+// depend on the K tile: one VGPR per operand instead of a 64-bit address per load kept live across the loop.
+template <int MODE>
+__device__ __forceinline__ unsigned x3_lane_offset(const TileSrc& t) {
   const int tid = threadIdx.x;
-  const bool interior = (x0 + T <= t.X) && (k0 + GK <= khi);
-  if (interior && t.rs == 1) {
-    xr = tid & 127; kb = (tid >> 7) * 16;
-    const float* p = t.P + (long)(k0 + kb) * t.cs + x0 + xr;
+  if (MODE == X3_XROW) return 4u * ((unsigned)(tid >> 7) * 16u * (unsigned)t.cs + (unsigned)(tid & 127));
+  if (MODE == X3_KVEC) return 4u * ((unsigned)(tid >> 1) * (unsigned)t.rs + (unsigned)(tid & 1) * 16u);
+  return 0u;
+}
+
+template <int MODE>
+__device__ __forceinline__ void g2r_x3(const TileSrc& t, int x0, int k0, int khi, unsigned voff, float (&r)[16]) {
+  const int tid = threadIdx.x;
+  if (MODE == X3_XROW) {
+    const char* sb = reinterpret_cast<const char*>(t.P + (long)k0 * t.cs + x0);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) r[u] = p[(long)u * t.cs] * mul;
-    return;
-  }
-  xr = tid >> 1; kb = (tid & 1) * 16;
-  if (interior && t.cs == 1 && (t.rs & 3) == 0 && (reinterpret_cast<uintptr_t>(t.P) & 15) == 0) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(t.P + (long)(x0 + xr) * t.rs + k0 + kb);
+    for (int u = 0; u < 16; ++u) r[u] = *reinterpret_cast<const float*>(sb + (long)u * t.cs * 4 + voff);
+  } else if (MODE == X3_KVEC) {
+    const char* sb = reinterpret_cast<const char*>(t.P + (long)x0 * t.rs + k0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 v = p[q];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sb + 16 * q + voff);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[4 * q + e] = v[e] * mul;
+      for (int e = 0; e < 4; ++e) r[4 * q + e] = v[e];
     }
-    return;
-  }
-  const int gx = x0 + xr;
+  } else {
+    const long xo = (long)min(x0 + (tid >> 1), t.X - 1) * t.rs;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int gk = k0 + kb + u;
-    r[u] = (gx < t.X && gk < khi) ? t.P[(long)gx * t.rs + (long)gk * t.cs] * mul : 0.0f;
+    for (int u = 0; u < 16; ++u) r[u] = t.P[xo + (long)min(k0 + (tid & 1) * 16 + u, khi - 1) * t.cs];
   }
 }
 
-__device__ __forceinline__ void r2s_x3(const float (&r)[16], int xr, int kb, u32x4_k (*P)[128 * 4]) {
+// X3_DBG: what-if switches of tools/micro/x3_gemm_bench.hip (wrong results; 0 in the library): 1 = no global loads in
+// the K loop, 2 = no operand split (raw bits), 4 = no LDS commit in the K loop.
+#ifndef X3_DBG
+#define X3_DBG 0
+#endif
+
+template <int MODE>
+__device__ __forceinline__ void r2s_x3(const TileSrc& t, int x0, int k0, int khi, const float (&r)[16], float mul,
+                                       u32x4_k (*P)[128 * 4]) {
+  const int tid = threadIdx.x;
+  const int xr = MODE == X3_XROW ? (tid & 127) : (tid >> 1);
+  const int kb = MODE == X3_XROW ? (tid >> 7) * 16 : (tid & 1) * 16;
   unsigned pk[3][8];
 #pragma unroll
   for (int u = 0; u < 16; u += 2) {
+    float v0 = r[u] * mul, v1 = r[u + 1] * mul;
+    if (MODE == X3_EDGE) {
+      const bool xin = x0 + xr < t.X;
+      v0 = (xin && k0 + kb + u < khi) ? v0 : 0.0f;
+      v1 = (xin && k0 + kb + u + 1 < khi) ? v1 : 0.0f;
+    }
     unsigned q[3];
-    split3_pair(r[u], r[u + 1], q);
+    if (X3_DBG & 2) { q[0] = __float_as_uint(v0); q[1] = __float_as_uint(v1); q[2] = q[0] ^ q[1]; }
+    else split3_pair(v0, v1, q);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) pk[pl][u >> 1] = q[pl];
   }
@@ -385,61 +415,28 @@ __device__ __forceinline__ void r2s_x3(const float (&r)[16], int xr, int kb, u32
   }
 }
 
-__device__ __forceinline__ void gemm_body_x3(const GemmArgs& g, int m0, int n0, GemmLdsX3& L) {
-  constexpr int T = 128, GK = kX3K, W = 64, NT = 4;
+// n K tiles [k0 + 32 t, +32) of one operand pair, accumulated into acc.  Enters and leaves with the LDS buffer free
+// (every wave past its last fragment read).
+template <int MA, int MB, bool LITE>
+__device__ __forceinline__ void x3_pass(const TileSrc& ta, const TileSrc& tb, int m0, int n0, int k0, int khi, int n,
+                                        float mul, GemmLdsX3& L, f32x4 (&acc)[4][4]) {
+  constexpr int GK = kX3K, W = 64, NT = 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wm = w >> 1, wn = w & 1;
-  const bool tri_skip = (g.epi == EPI_TRIU_MAX || g.sym) && (m0 >= n0 + T);
-  if (g.sym && tri_skip) return;        // written by the mirror tile's epilogue (a triu tile below the diagonal stores zeros instead)
-
-  f32x4 acc[NT][NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  float a_mul = 1.0f;
-  if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
-
-  int klo[2] = {0, 0}, khi[2] = {0, 0}, nk[2] = {0, 0};
-  if (!tri_skip) {
-    for (int p = 0; p < 2; ++p) {
-      if (p == 1 && !g.A2) break;
-      const int K = p ? g.K2 : g.K, km = p ? g.kmode2 : g.kmode;
-      int lo = 0, hi = K;
-      if (km & KLO_M) lo = max(lo, m0);
-      if (km & KLO_N) lo = max(lo, n0);
-      if (km & KHI_M) hi = min(hi, m0 + T);
-      if (km & KHI_N) hi = min(hi, n0 + T);
-      lo = (lo / GK) * GK;
-      klo[p] = lo; khi[p] = hi; nk[p] = hi > lo ? (hi - lo + GK - 1) / GK : 0;
-    }
-  }
-  const int ntile = nk[0] + nk[1];
-  const TileSrc ta[2] = {{g.A, g.a_rs, g.a_cs, g.M}, {g.A2, g.a2_rs, g.a2_cs, g.M}};
-  const TileSrc tb[2] = {{g.B, g.b_cs, g.b_rs, g.N}, {g.B2, g.b2_cs, g.b2_rs, g.N}};   // (n, k) view of B
-
+  const int wm = w >> 1, wn = w & 1, c = lane >> 4;
   float ra[16], rb[16];
-  int xa = 0, ka = 0, xb = 0, kbb = 0;
-  auto fetch = [&](int t) {
-    const int p = t < nk[0] ? 0 : 1;
-    const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
-    g2r_x3(ta[p], m0, k0, khi[p], p ? -a_mul : a_mul, ra, xa, ka);
-    g2r_x3(tb[p], n0, k0, khi[p], 1.0f, rb, xb, kbb);
-  };
-  auto commit = [&](int) {
-    r2s_x3(ra, xa, ka, L.P[0]);
-    r2s_x3(rb, xb, kbb, L.P[1]);
-  };
-
-  if (ntile > 0) {
-    fetch(0);
-    commit(0);
-  }
+  const unsigned va = x3_lane_offset<MA>(ta), vb = x3_lane_offset<MB>(tb);
+  g2r_x3<MA>(ta, m0, k0, khi, va, ra);
+  g2r_x3<MB>(tb, n0, k0, khi, vb, rb);
+  r2s_x3<MA>(ta, m0, k0, khi, ra, mul, L.P[0]);
+  r2s_x3<MB>(tb, n0, k0, khi, rb, 1.0f, L.P[1]);
   __syncthreads();
-  const int c = lane >> 4;
-  for (int t = 0; t < ntile; ++t) {
-    if (t + 1 < ntile) fetch(t + 1);
+  for (int t = 0; t < n; ++t) {
+    const int kn = k0 + min(t + 1, n - 1) * GK;        // the last iteration re-reads its own tile: no branch round the loads
+    if (!(X3_DBG & 1)) {
+      g2r_x3<MA>(ta, m0, kn, khi, va, ra);
+      g2r_x3<MB>(tb, n0, kn, khi, vb, rb);
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // the loads are issued here, ahead of the matrix work, not sunk into it
     bf16x8_k a[NT][3], b[NT][3];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -460,26 +457,73 @@ __device__ __forceinline__ void gemm_body_x3(const GemmArgs& g, int m0, int n0, 
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         f32x4 v = acc[i][j];
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], v, 0, 0, 0);   // h l'
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], v, 0, 0, 0);   // l h'
+        if (!LITE) {
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], v, 0, 0, 0);   // h l'
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], v, 0, 0, 0);   // l h'
+        }
         v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], v, 0, 0, 0);   // h m'
         v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], v, 0, 0, 0);   // m h'
         v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], v, 0, 0, 0);   // h h'
         acc[i][j] = v;
       }
+    __builtin_amdgcn_sched_barrier(0);                 // ... and nothing that uses them is hoisted into it
     __syncthreads();                      // every wave is done reading this K tile
-    if (t + 1 < ntile) commit(t + 1);
+    if (t + 1 < n && !(X3_DBG & 4)) {
+      r2s_x3<MA>(ta, m0, kn, khi, ra, mul, L.P[0]);
+      r2s_x3<MB>(tb, n0, kn, khi, rb, 1.0f, L.P[1]);
+    }
     __syncthreads();
+  }
+}
+
+// The fetch modes (MA, MB) are chosen by the HOST from the operand strides (x3_host_mode below; both operand pairs of a
+// dual product must agree) and are template parameters of the kernel, so that a kernel holds two K loops only: the
+// fast one for blocks inside the operands and the clamped one for edge blocks and a ragged K tail.
+template <int MA, int MB, bool LITE>
+__device__ __forceinline__ void gemm_body_x3(const GemmArgs& g, int m0, int n0, GemmLdsX3& L) {
+  constexpr int T = 128, GK = kX3K, NT = 4;
+  const bool tri_skip = (g.epi == EPI_TRIU_MAX || g.sym) && (m0 >= n0 + T);
+  if (g.sym && tri_skip) return;        // written by the mirror tile's epilogue (a triu tile below the diagonal stores zeros instead)
+
+  f32x4 acc[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float a_mul = 1.0f;
+  if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
+  const bool fast = MA != X3_EDGE && MB != X3_EDGE && m0 + T <= g.M && n0 + T <= g.N;
+
+  // one operand pair at a time: the second pair of a dual product restarts the pipeline (one more latency per block)
+#pragma unroll 1
+  for (int p = 0; p < ((g.A2 && !tri_skip) ? 2 : (tri_skip ? 0 : 1)); ++p) {
+    const TileSrc ta = p ? TileSrc{g.A2, g.a2_rs, g.a2_cs, g.M} : TileSrc{g.A, g.a_rs, g.a_cs, g.M};
+    const TileSrc tb = p ? TileSrc{g.B2, g.b2_cs, g.b2_rs, g.N} : TileSrc{g.B, g.b_cs, g.b_rs, g.N};   // (n, k) view of B
+    const int K = p ? g.K2 : g.K, km = p ? g.kmode2 : g.kmode;
+    int lo = 0, hi = K;
+    if (km & KLO_M) lo = max(lo, m0);
+    if (km & KLO_N) lo = max(lo, n0);
+    if (km & KHI_M) hi = min(hi, m0 + T);
+    if (km & KHI_N) hi = min(hi, n0 + T);
+    lo = (lo / GK) * GK;
+    if (hi <= lo) continue;
+    const int ntot = (hi - lo + GK - 1) / GK, nfull = (hi - lo) / GK;
+    const int e0 = fast ? nfull : 0;                    // first K tile of the clamped loop (ragged tail / edge blocks)
+    const float mul = p ? -a_mul : a_mul;
+    if (MA != X3_EDGE && MB != X3_EDGE && e0 > 0) x3_pass<MA, MB, LITE>(ta, tb, m0, n0, lo, hi, e0, mul, L, acc);
+    if (ntot > e0) x3_pass<X3_EDGE, X3_EDGE, LITE>(ta, tb, m0, n0, lo + e0 * GK, hi, ntot - e0, mul, L, acc);
   }
   gemm_epilogue<T>(g, acc, m0, n0);
 }
 
+template <int MA, int MB, bool LITE>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
   int by, bx;
   gemm_tile_order(g.kmode, by, bx);
-  gemm_body_x3(g, by * 128, bx * 128, L);
+  gemm_body_x3<MA, MB, LITE>(g, by * 128, bx * 128, L);
 }
 
 // Two independent large products in one launch (the two gradient products of the update, psgd.py:175-176, then its
@@ -487,6 +531,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3(GemmArgs g) {
 // ends with a nearly empty second wave of blocks; back to back in one grid the tail is paid once.
 struct GemmPair { GemmArgs g[2]; int tiles0, tx0, tx1; };
 
+template <int MA0, int MB0, int MA1, int MB1>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_pair(GemmPair p) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
   const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
@@ -496,7 +541,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_pair(GemmPair p) {
   const int ty = ((g.M + 127) / 128);
   int by, bx;
   gemm_tile_from_id(id, ty, tx, g.kmode, by, bx);       // tiles0 is a multiple of 8 whenever the patch map applies
-  gemm_body_x3(g, by * 128, bx * 128, L);
+  if (which) gemm_body_x3<MA1, MB1, false>(g, by * 128, bx * 128, L);
+  else gemm_body_x3<MA0, MB0, false>(g, by * 128, bx * 128, L);
 }
 
 // T = 128: three resident blocks per CU (<= 170 registers): the 528 upper tiles of a 4096^2 triu product then run
@@ -565,13 +611,22 @@ __device__ __forceinline__ void small_src_init(SmallSrc& s, const TileSrc& t, in
   }
 }
 
-__device__ __forceinline__ void small_fetch(const SmallSrc& s, int k0, bool live, float mul, float (&r)[8]) {
+// Loads only (masked elements read a valid address): the values are first USED by small_commit D stages later, so that
+// no s_waitcnt for them sits between a stage's loads and its MFMAs.
+__device__ __forceinline__ void small_fetch(const SmallSrc& s, int k0, bool live, float (&r)[8]) {
   const float* Pk = s.P + (long)(live ? k0 : 0) * s.cs;              // uniform; a dead tile reads from the base
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const bool ok = live && ((s.xok >> u) & 1u) && (k0 + s.kfix[u] < s.khi);
-    const float v = Pk[ok ? s.off[u] : 0u];
-    r[u] = ok ? v * mul : 0.0f;
+    r[u] = Pk[ok ? s.off[u] : 0u];
+  }
+}
+
+__device__ __forceinline__ void small_commit(const SmallSrc& s, int k0, float mul, const float (&r)[8], float* S) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const bool ok = ((s.xok >> u) & 1u) && (k0 + s.kfix[u] < s.khi);
+    S[s.sidx[u]] = ok ? r[u] * mul : 0.0f;
   }
 }
 
@@ -612,22 +667,19 @@ __device__ __forceinline__ void gemm_body_small(const GemmArgs& g, int m0, int n
     float ra[D][8], rb[D][8];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      small_fetch(sa, lo + d * GK, d < n, mul, ra[d]);
-      small_fetch(sb, lo + d * GK, d < n, 1.0f, rb[d]);
+      small_fetch(sa, lo + d * GK, d < n, ra[d]);
+      small_fetch(sb, lo + d * GK, d < n, rb[d]);
     }
     for (int t0 = 0; t0 < n; t0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int t = t0 + d, buf = d & 1;             // D is even: the LDS buffer alternates with d
         if (t < n) {                                    // uniform; LDS traffic and MFMAs only (no global access inside)
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            LA[buf * kBuf + sa.sidx[u]] = ra[d][u];
-            LB[buf * kBuf + sb.sidx[u]] = rb[d][u];
-          }
+          small_commit(sa, lo + t * GK, mul, ra[d], LA + buf * kBuf);
+          small_commit(sb, lo + t * GK, 1.0f, rb[d], LB + buf * kBuf);
         }
-        small_fetch(sa, lo + (t + D) * GK, t + D < n, mul, ra[d]);      // unconditional refill of the stage just consumed
-        small_fetch(sb, lo + (t + D) * GK, t + D < n, 1.0f, rb[d]);
+        small_fetch(sa, lo + (t + D) * GK, t + D < n, ra[d]);      // unconditional refill of the stage just consumed
+        small_fetch(sb, lo + (t + D) * GK, t + D < n, rb[d]);
         if (t < n) {
           __syncthreads();
 #pragma unroll
@@ -1454,6 +1506,30 @@ static int g_gemm_x3 = 1;       // tuning key 1: large products on the bf16 matr
 static int g_force_gemm = 0;   // 0 auto, 1 always 64-tile kernel, 2 always 128-tile kernel (experiments)
 static int g_small_deep = 1;   // tuning key 3: batched 32-tile products on k_gemm_small (0 = gemm_body<32, 64>)
 
+// fetch mode of the split GEMM for one operand given as an (x, k) view (see g2r_x3 / x3_lane_offset: 32-bit lane offsets)
+static int x3_host_mode(const float* P, long rs, long cs) {
+  if (rs == 1 && cs > 0 && cs < (1L << 23)) return X3_XROW;
+  if (cs == 1 && rs > 0 && rs < (1L << 22) && (rs & 3) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0) return X3_KVEC;
+  return X3_EDGE;
+}
+static void x3_host_modes(const GemmArgs& g, int& ma, int& mb) {
+  ma = x3_host_mode(g.A, g.a_rs, g.a_cs);
+  mb = x3_host_mode(g.B, g.b_cs, g.b_rs);
+  if (g.A2 && (x3_host_mode(g.A2, g.a2_rs, g.a2_cs) != ma || x3_host_mode(g.B2, g.b2_cs, g.b2_rs) != mb)) ma = X3_EDGE;
+  if (ma == X3_EDGE || mb == X3_EDGE) ma = mb = X3_EDGE;
+}
+
+template <bool LITE>
+static void launch_x3(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  int ma, mb;
+  x3_host_modes(g, ma, mb);
+  if (ma == X3_KVEC && mb == X3_XROW) hipLaunchKernelGGL((k_gemm_x3<X3_KVEC, X3_XROW, LITE>), grid, dim3(kThreads), 0, st, g);
+  else if (ma == X3_KVEC && mb == X3_KVEC) hipLaunchKernelGGL((k_gemm_x3<X3_KVEC, X3_KVEC, LITE>), grid, dim3(kThreads), 0, st, g);
+  else if (ma == X3_XROW && mb == X3_XROW) hipLaunchKernelGGL((k_gemm_x3<X3_XROW, X3_XROW, LITE>), grid, dim3(kThreads), 0, st, g);
+  else if (ma == X3_XROW && mb == X3_KVEC) hipLaunchKernelGGL((k_gemm_x3<X3_XROW, X3_KVEC, LITE>), grid, dim3(kThreads), 0, st, g);
+  else hipLaunchKernelGGL((k_gemm_x3<X3_EDGE, X3_EDGE, LITE>), grid, dim3(kThreads), 0, st, g);
+}
+
 static int launch_gemm(const GemmArgs& g, hipStream_t st) {
   // the 128-tile kernel needs enough tiles to fill the chip; small problems keep 64 x 64 tiles
   const long t128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
@@ -1463,7 +1539,8 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g_force_gemm == 2) T = 128;
   if (g_force_gemm == 3) T = 32;
   dim3 grid((g.N + T - 1) / T, (g.M + T - 1) / T);
-  if (T == 128 && g_gemm_x3) hipLaunchKernelGGL(k_gemm_x3, grid, dim3(kThreads), 0, st, g);
+  if (T == 128 && g_gemm_x3 && g.lite) launch_x3<true>(g, grid, st);
+  else if (T == 128 && g_gemm_x3) launch_x3<false>(g, grid, st);
   else if (T == 128) hipLaunchKernelGGL((k_gemm_f32<128, kBigK>), grid, dim3(kThreads), 0, st, g);
   else if (T == 64) hipLaunchKernelGGL((k_gemm_f32<64, kSmallK>), grid, dim3(kThreads), 0, st, g);
   else if (g_small_deep && g.K > 2 * kSmallK)      // the ring pays off from the third K tile on; shorter products keep the plain body
@@ -1487,7 +1564,18 @@ static int launch_gemm_two(const GemmArgs& a, const GemmArgs& b, hipStream_t st)
   p.tx0 = (a.N + 127) / 128; p.tx1 = (b.N + 127) / 128;
   p.tiles0 = p.tx0 * ((a.M + 127) / 128);
   const int tiles1 = p.tx1 * ((b.M + 127) / 128);
-  hipLaunchKernelGGL(k_gemm_x3_pair, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
+  int ma0, mb0, ma1, mb1;
+  x3_host_modes(a, ma0, mb0);
+  x3_host_modes(b, ma1, mb1);
+  const dim3 grid(p.tiles0 + tiles1);
+  if (ma0 == X3_KVEC && mb0 == X3_KVEC && ma1 == X3_XROW && mb1 == X3_XROW)              // A A' - Bt Bt' with A'A - Bt'Bt
+    hipLaunchKernelGGL((k_gemm_x3_pair<X3_KVEC, X3_KVEC, X3_XROW, X3_XROW>), grid, dim3(kThreads), 0, st, p);
+  else if (ma0 == X3_KVEC && mb0 == X3_XROW && ma1 == X3_KVEC && mb1 == X3_XROW)         // the two factor updates
+    hipLaunchKernelGGL((k_gemm_x3_pair<X3_KVEC, X3_XROW, X3_KVEC, X3_XROW>), grid, dim3(kThreads), 0, st, p);
+  else {
+    const int rc = launch_gemm(a, st);
+    return rc ? rc : launch_gemm(b, st);
+  }
   return (int)hipGetLastError();
 }
 
@@ -1608,7 +1696,7 @@ static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
 }
 
 static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
-                   hipStream_t st, long xi = 0, long xj = 0) {
+                   hipStream_t st, long xi = 0, long xj = 0, int lite = 0) {
   hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
   if (hipGetLastError() != hipSuccess) return 1;
   if (n <= kStripN) {
@@ -1639,6 +1727,7 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
       g.D = Yr; g.ldd = si;                                            // in place: C = C - A B
       g.M = nvec; g.N = rest; g.K = jw;
       g.epi = EPI_D_MINUS;
+      g.lite = lite;
       e = launch_gemm(g, st);
       if (e) return e;
     }
@@ -1694,8 +1783,9 @@ int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, flo
   return (int)hipGetLastError();
 }
 
-int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st) {
-  return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st);
+int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st,
+                 int lite) {
+  return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st, 0, 0, lite);
 }
 
 }  // namespace psgdk

@@ -901,6 +901,7 @@ static HWs hws_layout(char* base, int M, int N) {
 
 static int g_two_pairs = 1;       // tuning key 1: 0 = keep the Gram-first chain even where two fused pairs are possible
 static unsigned g_spin_limit = 1u << 22;   // psgd_kron_bf16_set_tuning key 2 (log2): hand-off polls before a consumer gives up
+static int g_trsm_lite = 1;        // psgd_kron_bf16_set_tuning key 3 (experiment)
 static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, fused triangular pair when every
                                   //    tile gets its own CU, else 128^2 register-staged); 4: auto without the fused pair;
                                   // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
@@ -1072,6 +1073,7 @@ extern "C" {
 int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 0) { g_hgemm_variant = value; return PSGD_OK; }
   if (key == 1) { g_two_pairs = value; return PSGD_OK; }
+  if (key == 3) { g_trsm_lite = value; return PSGD_OK; }
   if (key == 2) { g_spin_limit = (value < 0 || value > 30) ? (1u << 22) : (1u << value); return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
@@ -1230,8 +1232,8 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(grid), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dX), k.X0, n8);
     HK((int)hipGetLastError());
   }
-  HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st));
-  HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st));
+  HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite));
+  HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st, g_trsm_lite));
   HK(launch_cvt(k.Bt, 0, N, k.W1, ld1, M, N, 0, st));                                 // Bt  -> first half of W1
   HK(launch_cvt(k.Bt, 0, N, k.W2, ld2, M, N, 1, st));                                 // Bt' -> first half of W2
   // grad1 = triu(A A' - Bt Bt'), grad2 = triu(A'A - Bt'Bt)                                          (:175-176)

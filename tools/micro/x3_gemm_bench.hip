@@ -1,0 +1,43 @@
+// Times the split (bf16 x 3) GEMM kernel of psgd_kron.hip on one M x N x K product per operand layout, with the
+// what-if switches of X3_DBG (see r2s_x3 / x3_pass) to find what bounds the K loop.  Results are wrong with X3_DBG != 0.
+//   for d in 0 1 2 4 7; do hipcc -O3 -std=c++17 --offload-arch=gfx950 -DX3_DBG=$d -Iinclude -Ipsgd_tf_amd/csrc \
+//       tools/micro/x3_gemm_bench.hip -o /tmp/x3_$d && /tmp/x3_$d; done
+#include "../../psgd_tf_amd/csrc/psgd_kron.hip"
+#include <cstdio>
+#include <vector>
+
+static float run(const GemmArgs& g, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) launch_gemm(g, 0);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) launch_gemm(g, 0);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / iters;
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 4096;
+  const size_t bytes = (size_t)n * n * sizeof(float);
+  float *A, *B, *C;
+  hipMalloc(&A, bytes); hipMalloc(&B, bytes); hipMalloc(&C, bytes);
+  std::vector<float> h((size_t)n * n);
+  unsigned s = 12345u;
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
+  hipMemcpy(A, h.data(), bytes, hipMemcpyHostToDevice);
+  hipMemcpy(B, h.data(), bytes, hipMemcpyHostToDevice);
+  const double flop = 2.0 * n * (double)n * n;
+  const char* names[4] = {"A B   (KVEC, XROW)", "A B'  (KVEC, KVEC)", "A' B  (XROW, XROW)", "A' B' (XROW, KVEC)"};
+  for (int v = 0; v < 4; ++v) {
+    GemmArgs g = gemm_args(A, n, (v & 2) != 0, B, n, (v & 1) != 0, C, n, n, n, n);
+    const float ms = run(g, 20);
+    printf("X3_DBG=%d  %d^3  %s  %.3f ms  %.1f TFLOP/s fp32-equivalent  (%.0f issued bf16)\n", X3_DBG, n, names[v], ms,
+           flop / ms * 1e-9, 6 * flop / ms * 1e-9);
+  }
+  GemmArgs g = gemm_args(A, n, false, B, n, false, C, n, n, n, n, KLO_M);
+  printf("X3_DBG=%d  triangular A (KLO_M)  %.3f ms\n", X3_DBG, run(g, 20));
+  return 0;
+}
