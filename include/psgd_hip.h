@@ -254,7 +254,9 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 /* Experiment knob (not stable ABI). key 0: fp32 GEMM tile choice (0 auto, 1 = 64, 2 = 128, 3 = 32).
  * key 1: 1 (default) 128-tile products run as fp32-accurate bf16 x 3 GEMMs on the bf16 matrix cores; 0 = exact fp32 MFMA.
  * key 2: triangular-solve strips: 0 (default) register-resident kernels, 1 = the LDS-resident ones (A/B measurements).
- * key 3: 32 x 32-tile products: 1 (default) k_gemm_small (ring of 4 K tiles, precomputed per-thread offsets), 0 = the generic body. */
+ * key 3: 32 x 32-tile products: 1 (default) k_gemm_small (ring of 4 K tiles, precomputed per-thread offsets), 0 = the generic body.
+ * key 4: M, N >= 1024: 1 (default) the products run on operands split ONCE into three bf16 planes in the workspace
+ *        (k_split3 / plane-writing epilogues, k_gemm_p3: DMA + MFMA K loop); 0 = operands split inside every GEMM tile. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.
@@ -342,7 +344,10 @@ int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
  * products, fused triangular pair when every 256^2 tile gets its own CU, 128^2 register-staged otherwise);
  * 1 128^2 register-staged everywhere; 2 128^2 LDS-DMA ring; 3 256^2 for every product; 4 auto without the fused pair.
  * key 1: 1 (default) two fused triangular pairs, (G Qr') Qr then Ql' (Ql .), where legal; 0 keep the Gram-first chain.
- * key 2: log2 of the hand-off poll bound of the fused pair (default 22 ~ 0.5 s; tests set 0 to provoke time-outs). */
+ * key 2: log2 of the hand-off poll bound of the fused pair (default 22 ~ 0.5 s; tests set 0 to provoke time-outs).
+ * key 3: bf16-operand update: 1 (default) the trailing products of its two triangular solves keep the three leading
+ *        terms of the bf16 x 3 split (h h' + h m' + m h': 2^-16 relative per product, below the bf16 rounding of the
+ *        operands); 0 = all six terms. */
 int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,

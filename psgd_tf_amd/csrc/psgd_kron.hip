@@ -545,6 +545,231 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_pair(GemmPair p) {
   else gemm_body_x3<MA0, MB0, false>(g, by * 128, bx * 128, L);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same fp32-accurate product on PRE-SPLIT operands ("planes").  k_gemm_x3 splits every operand element once per
+// output tile column/row it meets -- 32 times at 4096^2 -- and stages it through registers; measured (tools/micro/
+// x3_gemm_bench.hip) the split + LDS commit and the register-staged loads cost 35-45 % on top of the MFMA + fragment-
+// read loop.  Here an operand is split ONCE into three bf16 planes in HBM (x = h + m + l exactly, 6 B/element), K-
+// contiguous and zero-padded to whole tiles, and the K loop is DMA (global_load ... lds, no VGPR staging, no VALU) +
+// fragment reads + MFMAs.  Producers write planes directly: k_split3 for caller data and factors, and the epilogue of
+// this kernel for chained products (row-major and/or transposed planes), so an intermediate is never re-read as fp32.
+// Plane layout: K-tile-major.  Element (x, k) of plane pl is p[pl * ps + (k / 32) * ts + x * 32 + k % 32] with
+// ts = 32 * (padded x extent): the 128 rows x 32 k a block fetches per K tile and plane are ONE contiguous 8 KiB run, so
+// every DMA instruction moves whole 128-byte lines (with row-major planes a K tile touched half of each line and every
+// line was fetched twice through the 64 B/clk L1 -- the whole K loop was bound by it).  x padded to 128, k to 32, zeros.
+struct P3 {
+  const __bf16* p;
+  long ts, ps;
+};
+__host__ __device__ __forceinline__ long p3_index(long ts, long x, long k) { return (k >> 5) * ts + x * 32 + (k & 31); }
+
+struct P3Args {
+  P3 A, B;             // (m, k) and (n, k) views
+  P3 A2, B2;           // optional second pair, subtracted (K2, kmode2 in e)
+  GemmArgs e;          // M, N, K, kmode and every epilogue field of the fp32 kernels (e.C may be null; e.A .. e.B2 unused,
+                       // except e.A2 != nullptr <=> the second pair is present)
+  __bf16* Crow; long crow_ts, crow_ps;   // planes of C  (x = row, k = column)  (optional)
+  __bf16* Ccol; long ccol_ts, ccol_ps;   // planes of C' (x = column, k = row)  (optional)
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr3_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr3_t;
+#define P3_FENCE() asm volatile("" ::: "memory")
+
+// K tiles [lo, hi) of one operand pair.  LDS image as in k_gemm_x3: [A|B][plane][row * 4 + (chunk ^ swz(row))].  The DMA
+// writes linearly (wave base + 16 B * lane), so the swizzle is applied to the per-lane SOURCE address: the lane that
+// fills slot s = row * 4 + cpos fetches chunk cpos ^ swz(row) of that row.
+__device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0, int lo, int hi, GemmLdsX3& L,
+                                        f32x4 (&acc)[4][4]) {
+  constexpr int W = 64, NT = 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1, c = lane >> 4;
+  unsigned offA[2], offB[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int s = (2 * w + q) * 64 + lane, row = s >> 2, chunk = (s & 3) ^ ((row >> 2) & 3);
+    offA[q] = offB[q] = (unsigned)(row * 32 + chunk * 8);
+  }
+  const __bf16* baseA = A.p + (long)m0 * 32;
+  const __bf16* baseB = B.p + (long)n0 * 32;
+  auto issue = [&](int k0) {
+    const long ka = (long)(k0 >> 5) * A.ts, kb = (long)(k0 >> 5) * B.ts;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr3_t)(baseA + pl * A.ps + ka + offA[q]), (lds_ptr3_t)&L.P[0][pl][(2 * w + q) * 64], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr3_t)(baseB + pl * B.ps + kb + offB[q]), (lds_ptr3_t)&L.P[1][pl][(2 * w + q) * 64], 16, 0, 0);
+      }
+  };
+  if (hi <= lo) return;
+  issue(lo);
+  for (int k0 = lo; k0 < hi; k0 += kX3K) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P3_FENCE();
+    __builtin_amdgcn_s_barrier();           // every wave's part of this K tile has landed
+    P3_FENCE();
+    bf16x8_k a[NT][3], b[NT][3];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int row = wm * W + i * 16 + (lane & 15);
+      const int sl = row * 4 + (c ^ ((row >> 2) & 3));
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[0][pl][sl]);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * W + j * 16 + (lane & 15);
+      const int sl = row * 4 + (c ^ ((row >> 2) & 3));
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[1][pl][sl]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    P3_FENCE();
+    __builtin_amdgcn_s_barrier();           // every wave holds its fragments: the buffer is free
+    P3_FENCE();
+    if (k0 + kX3K < hi && !(X3_DBG & 1)) issue(k0 + kX3K);   // the next tile streams in under the MFMAs
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 v = acc[i][j];
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], v, 0, 0, 0);   // h l'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], v, 0, 0, 0);   // l h'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], v, 0, 0, 0);   // h m'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], v, 0, 0, 0);   // m h'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], v, 0, 0, 0);   // h h'
+        acc[i][j] = v;
+      }
+  }
+}
+
+// plane outputs of a C tile (pads inside the padded extents are written as zeros)
+__device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&acc)[4][4], int m0, int n0, bool do_row,
+                                                bool do_col) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row0 = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+      const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (row0 + e < g.e.M && col < g.e.N) ? acc[i][j][e] : 0.0f;
+      if (do_col) {                                       // C'[col][row0 .. row0 + 3]: 4 consecutive bf16 per plane
+        unsigned q0[3], q1[3];
+        split3_pair(v[0], v[1], q0);
+        split3_pair(v[2], v[3], q1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          *reinterpret_cast<uint2*>(g.Ccol + pl * g.ccol_ps + p3_index(g.ccol_ts, col, row0)) = make_uint2(q0[pl], q1[pl]);
+      }
+      if (do_row) {                                       // C[row][col]: lane pairs exchange so that a lane stores (col, col + 1)
+        const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
+        const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+        // even lane: rows row0, row0 + 1 at columns (col, col + 1);  odd lane: rows row0 + 2, row0 + 3 at (col - 1, col)
+        const float x00 = odd ? r0 : v[0], x01 = odd ? v[2] : r0;
+        const float x10 = odd ? r1 : v[1], x11 = odd ? v[3] : r1;
+        unsigned q0[3], q1[3];
+        split3_pair(x00, x01, q0);
+        split3_pair(x10, x11, q1);
+        const int rr = row0 + (odd ? 2 : 0), cc = col - (odd ? 1 : 0);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          *reinterpret_cast<unsigned*>(g.Crow + pl * g.crow_ps + p3_index(g.crow_ts, rr, cc)) = q0[pl];
+          *reinterpret_cast<unsigned*>(g.Crow + pl * g.crow_ps + p3_index(g.crow_ts, rr + 1, cc)) = q1[pl];
+        }
+      }
+    }
+}
+
+// 4 waves, one 48 KiB stage, two blocks per CU.  (A 256 x 128 tile with 8 waves, one block per CU and two stages -- DMA a
+// whole K step ahead, one barrier per step, 25 % less L1 traffic -- measured 0.519 against 0.532 ms at 4096^3 and far
+// worse on the triangular K ranges, 512 uneven tiles on 256 CUs: not kept.)
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  constexpr int TM = 128, TN = 128, GK = kX3K;
+  int by, bx;
+  gemm_tile_order(g.e.kmode, by, bx);
+  const int m0 = by * TM, n0 = bx * TN;
+  const bool tri_skip = (g.e.epi == EPI_TRIU_MAX || g.e.sym) && (m0 >= n0 + TN);
+  if (g.e.sym && tri_skip) return;      // written by the mirror tile's epilogue
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!tri_skip) {
+    // the subtracted pair first, then one sign flip of the accumulators
+#pragma unroll 1
+    for (int p = g.e.A2 ? 1 : 0; p >= 0; --p) {
+      const int K = p ? g.e.K2 : g.e.K, km = p ? g.e.kmode2 : g.e.kmode;
+      int lo = 0, hi = K;
+      if (km & KLO_M) lo = max(lo, m0);
+      if (km & KLO_N) lo = max(lo, n0);
+      if (km & KHI_M) hi = min(hi, m0 + TM);
+      if (km & KHI_N) hi = min(hi, n0 + TN);
+      lo = (lo / GK) * GK;
+      hi = ((hi + GK - 1) / GK) * GK;                 // the planes are zero-padded to whole K tiles
+      p3_pass(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
+      if (p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = -acc[i][j];
+      }
+    }
+  }
+  if (g.e.scale_max) {                                // (step / max) A B = step / max (A B): applied to the finished sums
+    const float mul = g.e.step / (g.e.scale_max[0] + g.e.tiny);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= mul;
+  }
+  if (g.e.C) gemm_epilogue<128>(g.e, acc, m0, n0);
+  // a symmetric product (Gram) names the same buffer twice: the mirror image is the transposed store of the tiles above
+  // the diagonal (a diagonal tile holds both halves itself)
+  if (g.Crow || g.Ccol) p3_store_planes(g, acc, m0, n0, g.Crow != nullptr, g.Ccol != nullptr && (!g.e.sym || n0 > m0));
+}
+
+// fp32 view X(r, c) = X[r * rs + c * cs], r < R, c < C  ->  planes with x = r, k = c (zeros outside R x C; the grid covers
+// the padded extents).  64 x 64 tiles through LDS so that both the read (along the view's contiguous dimension) and the
+// write (along c) are coalesced.
+__global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
+                                                     __bf16* __restrict__ P, long ts, long ps) {
+  __shared__ float S[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (cs == 1 || rs != 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = (tid >> 6) + 4 * i, c = tid & 63;
+      S[r][c] = (r0 + r < R && c0 + c < C) ? X[(long)(r0 + r) * rs + (long)(c0 + c) * cs] : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = (tid >> 6) + 4 * i, r = tid & 63;
+      S[r][c] = (r0 + r < R && c0 + c < C) ? X[(long)(r0 + r) + (long)(c0 + c) * cs] : 0.0f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
+    unsigned q0[3], q1[3];
+    split3_pair(S[r][c], S[r][c + 1], q0);
+    split3_pair(S[r][c + 2], S[r][c + 3], q1);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<uint2*>(P + pl * ps + p3_index(ts, r0 + r, c0 + c)) = make_uint2(q0[pl], q1[pl]);
+  }
+}
+
 // T = 128: three resident blocks per CU (<= 170 registers): the 528 upper tiles of a 4096^2 triu product then run
 // as one wave of blocks instead of 512 + 16 (the second, nearly empty wave doubled those launches' time)
 template <int T, int GK>
@@ -1484,8 +1709,13 @@ static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct KronWs {
   float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv, *Pl, *Pr;
+  __bf16 *PP, *F1, *F2, *Y0, *Y1, *Y2;     // operand planes of the large apply (kron_planes): Gram, factor, its transpose; 3 transients
   int64_t total;
 };
+
+// Large applies run on pre-split operand planes (k_gemm_p3).  A pure function of the shape: the workspace layout follows it.
+static inline bool kron_planes(int M, int N) { return M >= 1024 && N >= 1024; }
+static inline int pad128(int x) { return (x + 127) & ~127; }
 
 static KronWs kron_layout(char* base, int M, int N) {
   KronWs k;
@@ -1498,6 +1728,13 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.g1 = take(mm); k.g2 = take(nn);
   k.dinv = take((int64_t)((M + 31) / 32 + (N + 31) / 32) * 1024 * 4);
   k.Pl = take(mm); k.Pr = take(nn);          // Grams of the factors (psgd_kron_dd_prepare_f32): survive update calls
+  k.PP = k.F1 = k.F2 = k.Y0 = k.Y1 = k.Y2 = nullptr;
+  if (kron_planes(M, N)) {
+    const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
+    auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
+    k.PP = planes(small * small); k.F1 = planes(big * big); k.F2 = planes(big * big);      // survive update calls too
+    k.Y0 = planes(Mp * Np); k.Y1 = planes(Mp * Np); k.Y2 = planes(Mp * Np);
+  }
   k.total = off;
   return k;
 }
@@ -1774,6 +2011,85 @@ static int launch_gram_batch(const GemmArgs* g, int count, hipStream_t st) {    
   return 0;
 }
 
+static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
+
+struct P3Buf { __bf16* p; long rows, ld; };          // planes of a matrix with padded extents x = rows, k = ld (multiples of 128)
+static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld}; }
+
+static int launch_split3(const float* X, long rs, long cs, int R, int C, const P3Buf& out, hipStream_t st) {
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)(out.ld / 64), (unsigned)(out.rows / 64)), dim3(kThreads), 0, st, X, rs, cs, R, C,
+                     out.p, out.rows * 32, out.rows * out.ld);
+  return (int)hipGetLastError();
+}
+
+static P3Args p3_args(const P3Buf& A, const P3Buf& B, int M, int N, int K, int kmode) {
+  P3Args g = {};
+  g.A = p3_of(A); g.B = p3_of(B);
+  g.e.M = M; g.e.N = N; g.e.K = K; g.e.kmode = kmode; g.e.epi = EPI_STORE;
+  return g;
+}
+static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; }
+static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; }
+
+static int launch_p3(const P3Args& g, hipStream_t st) {
+  hipLaunchKernelGGL(k_gemm_p3, dim3((g.e.N + 127) / 128, (g.e.M + 127) / 128), dim3(kThreads), 0, st, g);
+  return (int)hipGetLastError();
+}
+
+// The apply of plan_apply (large branch, same association order and K ranges) on planes:
+//   M < N:   prepare  Ql' -> Y0,  PP = planes(Ql'Ql),  F1 = planes(Qr),  F2 = planes(Qr')
+//            apply    Y0 = planes(G'),  Y1 = planes(PP G),  Y2 = planes(Y1 Qr'),  out = Y2 Qr
+//   M >= N:  prepare  Qr' -> Y0,  PP = planes(Qr'Qr),  F1 = planes(Ql),  F2 = planes(Ql')
+//            apply    Y0 = planes(G),  Y1 = planes((G PP)'),  Y2 = planes((Ql Y1')'),  out = Ql' Y2'
+// Every B operand is an (n, k) view, so a product that feeds the B side of the next one stores its result transposed.
+static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const KronWs& k, hipStream_t st) {
+  const bool left = M < N;                            // Gram of the left factor
+  const int ns = left ? M : N, nb = left ? N : M;
+  const float* Qs = left ? Ql : Qr;
+  const float* Qb = left ? Qr : Ql;
+  const long nsp = pad128(ns), nbp = pad128(nb);
+  const P3Buf QsT = {k.Y0, nsp, nsp}, PP = {k.PP, nsp, nsp}, F1 = {k.F1, nbp, nbp}, F2 = {k.F2, nbp, nbp};
+  int e = launch_split3(Qs, 1, ns, ns, ns, QsT, st);                                     // (x, k) = Qs[k][x]
+  if (e) return e;
+  P3Args g = p3_args(QsT, QsT, ns, ns, ns, KHI_M | KHI_N);                              // Qs'Qs, symmetric
+  g.e.sym = 1;
+  p3_out_row(g, PP); p3_out_col(g, PP);
+  if ((e = launch_p3(g, st))) return e;
+  if ((e = launch_split3(Qb, nb, 1, nb, nb, F1, st))) return e;
+  return launch_split3(Qb, 1, nb, nb, nb, F2, st);
+}
+
+static int planes_apply(const float* G, float* out, int M, int N, const KronWs& k, hipStream_t st) {
+  const long Mp = pad128(M), Np = pad128(N);
+  int e;
+  if (M < N) {
+    const P3Buf PP = {k.PP, Mp, Mp}, F1 = {k.F1, Np, Np}, F2 = {k.F2, Np, Np};
+    const P3Buf Gt = {k.Y0, Np, Mp}, T = {k.Y1, Mp, Np}, A = {k.Y2, Mp, Np};
+    if ((e = launch_split3(G, 1, N, N, M, Gt, st))) return e;                            // (n, k = m) = G[m][n]
+    P3Args g0 = p3_args(PP, Gt, M, N, M, 0);                                             // (Ql'Ql) G
+    p3_out_row(g0, T);
+    if ((e = launch_p3(g0, st))) return e;
+    P3Args g1 = p3_args(T, F1, M, N, N, KLO_N);                                          // (.) Qr'
+    p3_out_row(g1, A);
+    if ((e = launch_p3(g1, st))) return e;
+    P3Args g2 = p3_args(A, F2, M, N, N, KHI_N);                                          // (.) Qr
+    g2.e.C = out; g2.e.ldc = N;
+    return launch_p3(g2, st);
+  }
+  const P3Buf PP = {k.PP, Np, Np}, F1 = {k.F1, Mp, Mp}, F2 = {k.F2, Mp, Mp};
+  const P3Buf Gp = {k.Y0, Mp, Np}, Tt = {k.Y1, Np, Mp}, At = {k.Y2, Np, Mp};
+  if ((e = launch_split3(G, N, 1, M, N, Gp, st))) return e;
+  P3Args g0 = p3_args(Gp, PP, M, N, N, 0);                                               // G (Qr'Qr)
+  p3_out_col(g0, Tt);
+  if ((e = launch_p3(g0, st))) return e;
+  P3Args g1 = p3_args(F1, Tt, M, N, M, KLO_M);                                           // Ql (.)
+  p3_out_col(g1, At);
+  if ((e = launch_p3(g1, st))) return e;
+  P3Args g2 = p3_args(F2, At, M, N, M, KHI_M);                                           // Ql' (.)
+  g2.e.C = out; g2.e.ldc = N;
+  return launch_p3(g2, st);
+}
+
 // entry points shared with psgd_kron_bf16.hip (kron_shared.h)
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal) {
   const long tot = (long)M * M + (long)N * N;
@@ -1809,6 +2125,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 1) { g_gemm_x3 = value; return PSGD_OK; }
   if (key == 2) { g_trsm_lds = value; return PSGD_OK; }
   if (key == 3) { g_small_deep = value; return PSGD_OK; }
+  if (key == 4) { g_planes = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -1824,6 +2141,10 @@ int psgd_kron_dd_prepare_f32(const float* Ql, const float* Qr, int M, int N, voi
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
+  if (kron_planes(M, N) && g_planes && g_gemm_x3) {
+    KRON_LAUNCH(planes_prepare(Ql, Qr, M, N, k, st));
+    return PSGD_OK;
+  }
   GemmArgs pre[2], app[3];
   int np = 0, na = 0;
   plan_apply(Ql, Qr, Ql /*unused*/, k.T /*unused*/, M, N, k, pre, np, app, na);
@@ -1840,6 +2161,10 @@ int psgd_kron_dd_apply_prepared_f32(const float* Ql, const float* Qr, const floa
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
+  if (kron_planes(M, N) && g_planes && g_gemm_x3) {
+    KRON_LAUNCH(planes_apply(G, out, M, N, k, st));
+    return PSGD_OK;
+  }
   GemmArgs pre[2], app[3];
   int np = 0, na = 0;
   plan_apply(Ql, Qr, G, out, M, N, k, pre, np, app, na);

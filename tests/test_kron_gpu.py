@@ -377,10 +377,11 @@ def test_bf16_update_rejects_mixed_dtypes(psgd):
                                  torch.ones(8, 16, device="cuda"), torch.ones(8, 16, device="cuda"))
 
 
-@pytest.mark.parametrize("M,N", [(257, 120), (85, 10), (16, 40), (640, 1024)])
+@pytest.mark.parametrize("M,N", [(257, 120), (85, 10), (16, 40), (640, 1024), (1100, 1030), (2049, 1024)])
 def test_prepared_grams_follow_the_factors(psgd, M, N):
     """fp32 apply: the Grams of the factors are kept in the workspace and recomputed only when the factors change (same
-    rules as the bf16 copies below); single and batched calls; small (both Grams) and large (reference-order Gram) plans."""
+    rules as the bf16 copies below); single and batched calls; small (both Grams), large (reference-order Gram) and
+    pre-split-plane plans (M, N >= 1024: Gram and factor planes are the prepared state)."""
     rng = np.random.default_rng(M + N)
     Ql, Qr = _dev(_tri_factor(rng, M).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
     G, G2 = _dev(rng.standard_normal((M, N))), _dev(rng.standard_normal((M, N)))
@@ -405,6 +406,29 @@ def test_prepared_grams_follow_the_factors(psgd, M, N):
     Qr2.add_(torch.triu(torch.full_like(Qr2, 0.01)))
     o3 = psgd.precond_grad_kron_batched([Ql, Ql], [Qr2, Qr2], [G, G2])
     assert rel_err(o3[0].cpu().numpy(), ref(Ql, Qr2, G)) < TOL and rel_err(o3[1].cpu().numpy(), ref(Ql, Qr2, G2)) < TOL
+
+
+@pytest.mark.parametrize("M,N", [(1024, 1024), (1030, 1100), (1024, 2049), (1500, 1027)])
+def test_large_apply_on_operand_planes(psgd, M, N):
+    """M, N >= 1024: the apply runs on operands split once into three bf16 planes (k_gemm_p3; x = h + m + l exactly, so
+    the products are the ones of the in-GEMM split).  Both paths against the fp64 oracle, shapes that are not multiples
+    of the 128-tile (zero-padded planes), and against each other."""
+    from psgd_tf_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M * 3 + N)
+    Ql, Qr = _tri_factor(rng, M).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    G = rng.standard_normal((M, N)).astype(np.float32)
+    ref = orc.precond_grad_kron(Ql.astype(np.float64), Qr.astype(np.float64), G.astype(np.float64))
+    outs = []
+    try:
+        for planes in (1, 0):
+            lib.psgd_kron_set_tuning(4, planes)
+            out = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G))          # new factor tensors: prepared state rebuilt
+            assert rel_err(out.cpu().numpy(), ref) < TOL
+            outs.append(out)
+    finally:
+        lib.psgd_kron_set_tuning(4, 1)
+    assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-6
 
 
 def test_bf16_factor_copies_follow_the_factors(psgd):

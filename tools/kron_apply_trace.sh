@@ -8,7 +8,9 @@ import preconditioned_stochastic_gradient_descent as psgd
 from tools.kron_timing import state
 M = N = 4096
 Ql, Qr, dX, dG, G = state(M, N, torch.device("cuda:0"))
+Ql2 = Ql.clone()
 for _ in range(3):
+    Ql.add_(0.0)
     psgd.precond_grad_kron(Ql, Qr, G)
 torch.cuda.synchronize()
 PY
@@ -21,6 +23,6 @@ con=sqlite3.connect(db)
 cols=[r[1] for r in con.execute("pragma table_info(kernels)")]
 name="name" if "name" in cols else "kernel_name"
 rows=list(con.execute(f"select {name}, start, duration from kernels order by start"))
-for n,s,d in rows[-4:]: print("%-50s %9.1f us" % (n[:50], d/1e3))
+for n,s,d in rows[-6:]: print("%-60s %9.1f us" % (n[:60], d/1e3))
 PY
 rm -rf $R/gpurun_out/kapp

@@ -37,6 +37,35 @@ int main(int argc, char** argv) {
     printf("X3_DBG=%d  %d^3  %s  %.3f ms  %.1f TFLOP/s fp32-equivalent  (%.0f issued bf16)\n", X3_DBG, n, names[v], ms,
            flop / ms * 1e-9, 6 * flop / ms * 1e-9);
   }
+  {   // the same product on pre-split planes (k_gemm_p3)
+    __bf16 *PA, *PB;
+    hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
+    const P3Buf a = {PA, n, n}, b = {PB, n, n};
+    launch_split3(A, n, 1, n, n, a, 0);
+    launch_split3(B, 1, n, n, n, b, 0);                      // (n, k) view of B
+    __bf16* PC;
+    hipMalloc(&PC, (size_t)n * n * 6);
+    const P3Buf c = {PC, n, n};
+    const char* outs[5] = {"fp32 C", "planes of C (row form)", "planes of C' (column form)", "fp32 C, KLO_N", "fp32 C, KHI_M"};
+    for (int o = 0; o < 5; ++o) {
+      P3Args g = p3_args(a, b, n, n, n, o == 3 ? KLO_N : (o == 4 ? KHI_M : 0));
+      if (o == 0 || o >= 3) { g.e.C = C; g.e.ldc = n; }
+      if (o == 1) p3_out_row(g, c);
+      if (o == 2) p3_out_col(g, c);
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      for (int i = 0; i < 3; ++i) launch_p3(g, 0);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 20; ++i) launch_p3(g, 0);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      ms /= 20;
+      printf("X3_DBG=%d  %d^3  planes (k_gemm_p3) -> %-27s %.3f ms  %.1f TFLOP/s fp32-equivalent  (%.0f issued bf16)\n", X3_DBG, n,
+             outs[o], ms, flop / ms * 1e-9, 6 * flop / ms * 1e-9);
+    }
+  }
   GemmArgs g = gemm_args(A, n, false, B, n, false, C, n, n, n, n, KLO_M);
   printf("X3_DBG=%d  triangular A (KLO_M)  %.3f ms\n", X3_DBG, run(g, 20));
   return 0;
