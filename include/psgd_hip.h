@@ -256,7 +256,9 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * key 2: triangular-solve strips: 0 (default) register-resident kernels, 1 = the LDS-resident ones (A/B measurements).
  * key 3: 32 x 32-tile products: 1 (default) k_gemm_small (ring of 4 K tiles, precomputed per-thread offsets), 0 = the generic body.
  * key 4: M, N >= 1024: 1 (default) the products run on operands split ONCE into three bf16 planes in the workspace
- *        (k_split3 / plane-writing epilogues, k_gemm_p3: DMA + MFMA K loop); 0 = operands split inside every GEMM tile. */
+ *        (k_split3 / plane-writing epilogues, k_gemm_p3: DMA + MFMA K loop); 0 = operands split inside every GEMM tile.
+ * key 5: blocked triangular solves: 512-column strips per group (a finished group updates the columns to its right in
+ *        one product with K = 512 * group); 0 (default) = 4 from n = 4096 on, else 1. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

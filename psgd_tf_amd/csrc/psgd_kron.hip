@@ -581,6 +581,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr3_t;
 // fills slot s = row * 4 + cpos fetches chunk cpos ^ swz(row) of that row.
 __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0, int lo, int hi, GemmLdsX3& L,
                                         f32x4 (&acc)[4][4]) {
+  constexpr int NP = 3;
   constexpr int W = 64, NT = 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, c = lane >> 4;
@@ -595,7 +596,7 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
   auto issue = [&](int k0) {
     const long ka = (long)(k0 >> 5) * A.ts, kb = (long)(k0 >> 5) * B.ts;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         __builtin_amdgcn_global_load_lds((gbl_ptr3_t)(baseA + pl * A.ps + ka + offA[q]), (lds_ptr3_t)&L.P[0][pl][(2 * w + q) * 64], 16, 0, 0);
@@ -609,20 +610,20 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     P3_FENCE();
     __builtin_amdgcn_s_barrier();           // every wave's part of this K tile has landed
     P3_FENCE();
-    bf16x8_k a[NT][3], b[NT][3];
+    bf16x8_k a[NT][NP], b[NT][NP];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int row = wm * W + i * 16 + (lane & 15);
       const int sl = row * 4 + (c ^ ((row >> 2) & 3));
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[0][pl][sl]);
+      for (int pl = 0; pl < NP; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[0][pl][sl]);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int row = wn * W + j * 16 + (lane & 15);
       const int sl = row * 4 + (c ^ ((row >> 2) & 3));
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[1][pl][sl]);
+      for (int pl = 0; pl < NP; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[1][pl][sl]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     P3_FENCE();
@@ -690,11 +691,8 @@ __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&a
 // 4 waves, one 48 KiB stage, two blocks per CU.  (A 256 x 128 tile with 8 waves, one block per CU and two stages -- DMA a
 // whole K step ahead, one barrier per step, 25 % less L1 traffic -- measured 0.519 against 0.532 ms at 4096^3 and far
 // worse on the triangular K ranges, 512 uneven tiles on 256 CUs: not kept.)
-__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
-  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+__device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLdsX3& L) {
   constexpr int TM = 128, TN = 128, GK = kX3K;
-  int by, bx;
-  gemm_tile_order(g.e.kmode, by, bx);
   const int m0 = by * TM, n0 = bx * TN;
   const bool tri_skip = (g.e.epi == EPI_TRIU_MAX || g.e.sym) && (m0 >= n0 + TN);
   if (g.e.sym && tri_skip) return;      // written by the mirror tile's epilogue
@@ -731,17 +729,56 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] *= mul;
   }
+  if (g.e.epi == EPI_TRIU_MAX && !g.e.C) {            // triu and max|.| on the registers: the planes below are the only output
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = m0 + (w >> 1) * 64 + i * 16 + (lane >> 4) * 4 + e, col = n0 + (w & 1) * 64 + j * 16 + (lane & 15);
+          const float v = (col >= row && row < g.e.M && col < g.e.N) ? acc[i][j][e] : 0.0f;
+          acc[i][j][e] = v;
+          vmax = amaxf(vmax, fabsf(v));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(g.e.maxout), __float_as_int(vmax));
+  }
   if (g.e.C) gemm_epilogue<128>(g.e, acc, m0, n0);
   // a symmetric product (Gram) names the same buffer twice: the mirror image is the transposed store of the tiles above
   // the diagonal (a diagonal tile holds both halves itself)
   if (g.Crow || g.Ccol) p3_store_planes(g, acc, m0, n0, g.Crow != nullptr, g.Ccol != nullptr && (!g.e.sym || n0 > m0));
 }
 
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  int by, bx;
+  gemm_tile_order(g.e.kmode, by, bx);
+  p3_body(g, by, bx, L);
+}
+
+// two independent products in one grid (see k_gemm_x3_pair)
+struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1; };
+
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
+  const P3Args& g = p.g[which];
+  const int id = blockIdx.x - (which ? p.tiles0 : 0);
+  int by, bx;
+  gemm_tile_from_id(id, (g.e.M + 127) / 128, which ? p.tx1 : p.tx0, g.e.kmode, by, bx);
+  p3_body(g, by, bx, L);
+}
+
 // fp32 view X(r, c) = X[r * rs + c * cs], r < R, c < C  ->  planes with x = r, k = c (zeros outside R x C; the grid covers
-// the padded extents).  64 x 64 tiles through LDS so that both the read (along the view's contiguous dimension) and the
-// write (along c) are coalesced.
+// the padded extents) and, optionally, the planes of the transposed view (x = c, k = r) from the same read.  64 x 64
+// tiles through LDS so that the read (along the view's contiguous dimension) and both writes are coalesced.
 __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
-                                                     __bf16* __restrict__ P, long ts, long ps) {
+                                                     __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
+                                                     long tts, long tps) {
   __shared__ float S[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
   if (cs == 1 || rs != 1) {
@@ -758,15 +795,29 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
     }
   }
   __syncthreads();
+  if (P) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
-    unsigned q0[3], q1[3];
-    split3_pair(S[r][c], S[r][c + 1], q0);
-    split3_pair(S[r][c + 2], S[r][c + 3], q1);
+    for (int i = 0; i < 4; ++i) {
+      const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
+      unsigned q0[3], q1[3];
+      split3_pair(S[r][c], S[r][c + 1], q0);
+      split3_pair(S[r][c + 2], S[r][c + 3], q1);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      *reinterpret_cast<uint2*>(P + pl * ps + p3_index(ts, r0 + r, c0 + c)) = make_uint2(q0[pl], q1[pl]);
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<uint2*>(P + pl * ps + p3_index(ts, r0 + r, c0 + c)) = make_uint2(q0[pl], q1[pl]);
+    }
+  }
+  if (Pt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (tid >> 4) + 16 * i, r = (tid & 15) * 4;
+      unsigned q0[3], q1[3];
+      split3_pair(S[r][c], S[r + 1][c], q0);
+      split3_pair(S[r + 2][c], S[r + 3][c], q1);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<uint2*>(Pt + pl * tps + p3_index(tts, c0 + c, r0 + r)) = make_uint2(q0[pl], q1[pl]);
+    }
   }
 }
 
@@ -1710,6 +1761,7 @@ static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 struct KronWs {
   float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv, *Pl, *Pr;
   __bf16 *PP, *F1, *F2, *Y0, *Y1, *Y2;     // operand planes of the large apply (kron_planes): Gram, factor, its transpose; 3 transients
+  __bf16 *Lr, *Lc, *Rr, *Rc, *G1, *G2, *U0, *U1, *U2, *U3;   // ... of the large update: balanced factors (both forms), gradients, 4 transients
   int64_t total;
 };
 
@@ -1729,11 +1781,15 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.dinv = take((int64_t)((M + 31) / 32 + (N + 31) / 32) * 1024 * 4);
   k.Pl = take(mm); k.Pr = take(nn);          // Grams of the factors (psgd_kron_dd_prepare_f32): survive update calls
   k.PP = k.F1 = k.F2 = k.Y0 = k.Y1 = k.Y2 = nullptr;
+  k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
     k.PP = planes(small * small); k.F1 = planes(big * big); k.F2 = planes(big * big);      // survive update calls too
     k.Y0 = planes(Mp * Np); k.Y1 = planes(Mp * Np); k.Y2 = planes(Mp * Np);
+    k.Lr = planes(Mp * Mp); k.Lc = planes(Mp * Mp); k.G1 = planes(Mp * Mp);
+    k.Rr = planes(Np * Np); k.Rc = planes(Np * Np); k.G2 = planes(Np * Np);
+    k.U0 = planes(Mp * Np); k.U1 = planes(Mp * Np); k.U2 = planes(Mp * Np); k.U3 = planes(Mp * Np);
   }
   k.total = off;
   return k;
@@ -1897,6 +1953,37 @@ __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long 
   }
 }
 
+static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
+
+struct P3Buf { __bf16* p; long rows, ld; };          // planes of a matrix with padded extents x = rows, k = ld (multiples of 128)
+static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld}; }
+
+static int launch_split3(const float* X, long rs, long cs, int R, int C, const P3Buf& out, hipStream_t st) {
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)(out.ld / 64), (unsigned)(out.rows / 64)), dim3(kThreads), 0, st, X, rs, cs, R, C,
+                     out.p, out.rows * 32, out.rows * out.ld, (__bf16*)nullptr, 0L, 0L);
+  return (int)hipGetLastError();
+}
+// planes of the view (out) and of its transpose (outT: rows/ld swapped) from one read
+static int launch_split3_both(const float* X, long rs, long cs, int R, int C, const P3Buf& out, const P3Buf& outT, hipStream_t st) {
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)(out.ld / 64), (unsigned)(out.rows / 64)), dim3(kThreads), 0, st, X, rs, cs, R, C,
+                     out.p, out.rows * 32, out.rows * out.ld, outT.p, outT.rows * 32, outT.rows * outT.ld);
+  return (int)hipGetLastError();
+}
+
+static P3Args p3_args(const P3Buf& A, const P3Buf& B, int M, int N, int K, int kmode) {
+  P3Args g = {};
+  g.A = p3_of(A); g.B = p3_of(B);
+  g.e.M = M; g.e.N = N; g.e.K = K; g.e.kmode = kmode; g.e.epi = EPI_STORE;
+  return g;
+}
+static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; }
+static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; }
+
+static int launch_p3(const P3Args& g, hipStream_t st) {
+  hipLaunchKernelGGL(k_gemm_p3, dim3((g.e.N + 127) / 128, (g.e.M + 127) / 128), dim3(kThreads), 0, st, g);
+  return (int)hipGetLastError();
+}
+
 // Solve  y[i,:] Q = x[i,:]  (see k_trsm_ut).  `dinv` is scratch for the inverted 32 x 32 diagonal sub-blocks
 // (ceil(n/32) * 1024 floats).  n <= 512: one strip kernel.  Larger n: right-looking over 512-wide column blocks,
 //   Y <- X;  for each block jb:  Y[:, jb] <- Y[:, jb] Q[jb, jb]^-1  (strip kernel, in place)
@@ -1904,6 +1991,7 @@ __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long 
 constexpr int kTrsmBlock = kStripN;
 
 static int g_trsm_lds = 0;     // tuning key 2: 1 = the LDS-resident strip kernels (A/B measurements)
+static int g_trsm_group = 0;   // tuning key 5: strips per group of the blocked solve (0 = automatic, 1 = every strip updates all columns to its right)
 
 static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
   if (!g_trsm_lds) {
@@ -1946,26 +2034,35 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
     hipLaunchKernelGGL(k_copy_strided, dim3(1024), dim3(kThreads), 0, st, X, xi, xj, Y, si, sj, nvec, n);
     if (hipGetLastError() != hipSuccess) return 1;
   }
-  // (A recursive-halving schedule -- one K = 2048 product, two K = 1024, four K = 512 at 4096^2 -- was measured equal:
-  // the 4096 x 512 x 512 products it ends with are latency-bound, 128 tiles on 256 CUs.)
-  for (int j0 = 0; j0 < n; j0 += kTrsmBlock) {
-    const int jw = (n - j0 < kTrsmBlock) ? (n - j0) : kTrsmBlock;
-    float* Yb = Y + (long)j0 * sj;
-    TrsmArgs t = {Q + (long)j0 * n + j0, jw, n, Yb, Yb, nvec, si, sj, 0L, 0L};
-    int e = launch_strip(t, dinv + (long)(j0 / 32) * 1024, st);
-    if (e) return e;
-    const int rest = n - j0 - jw;
-    if (rest > 0) {
-      GemmArgs g = {};
-      g.A = Yb; g.a_rs = si; g.a_cs = sj;                              // A(i,k) = Y[i, j0+k]
-      g.B = Q + (long)j0 * n + j0 + jw; g.b_rs = n; g.b_cs = 1;        // B(k,j) = Q[j0+k, j0+jw+j]
-      float* Yr = Y + (long)(j0 + jw) * sj;
-      g.C = Yr; g.ldc = si; g.c_cs = sj;
-      g.D = Yr; g.ldd = si;                                            // in place: C = C - A B
-      g.M = nvec; g.N = rest; g.K = jw;
-      g.epi = EPI_D_MINUS;
-      g.lite = lite;
-      e = launch_gemm(g, st);
+  // Strips are solved in GROUPS of g_trsm_group: inside a group a solved strip updates the group's remaining columns
+  // (K = 512), and the finished group updates everything to its right in one product with K = 512 * group -- the
+  // 16 K steps of a K = 512 product are dominated by the fixed parts of a block, so the wide products get a longer K.
+  auto update = [&](int k0, int kw, int c0, int cw) {                    // Y[:, c0:c0+cw] -= Y[:, k0:k0+kw] Q[k0:k0+kw, c0:c0+cw]
+    GemmArgs g = {};
+    g.A = Y + (long)k0 * sj; g.a_rs = si; g.a_cs = sj;
+    g.B = Q + (long)k0 * n + c0; g.b_rs = n; g.b_cs = 1;
+    float* Yr = Y + (long)c0 * sj;
+    g.C = Yr; g.ldc = si; g.c_cs = sj;
+    g.D = Yr; g.ldd = si;                                                // in place: C = C - A B
+    g.M = nvec; g.N = cw; g.K = kw;
+    g.epi = EPI_D_MINUS;
+    g.lite = lite;
+    return launch_gemm(g, st);
+  };
+  // measured (tools/trsm_group_ab.py): groups of 4 are 4 % of the 4096^2 updates, nothing at 2048 (one group = no wide product)
+  const int group = kTrsmBlock * (g_trsm_group > 0 ? g_trsm_group : (n >= 8 * kTrsmBlock ? 4 : 1));
+  for (int g0 = 0; g0 < n; g0 += group) {
+    const int gend = (n - g0 < group) ? n : g0 + group;
+    for (int j0 = g0; j0 < gend; j0 += kTrsmBlock) {
+      const int jw = (gend - j0 < kTrsmBlock) ? (gend - j0) : kTrsmBlock;
+      float* Yb = Y + (long)j0 * sj;
+      TrsmArgs t = {Q + (long)j0 * n + j0, jw, n, Yb, Yb, nvec, si, sj, 0L, 0L};
+      int e = launch_strip(t, dinv + (long)(j0 / 32) * 1024, st);
+      if (e) return e;
+      if (j0 + jw < gend && (e = update(j0, jw, j0 + jw, gend - j0 - jw))) return e;
+    }
+    if (gend < n) {
+      const int e = update(g0, gend - g0, gend, n - gend);
       if (e) return e;
     }
   }
@@ -2011,28 +2108,13 @@ static int launch_gram_batch(const GemmArgs* g, int count, hipStream_t st) {    
   return 0;
 }
 
-static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
-
-struct P3Buf { __bf16* p; long rows, ld; };          // planes of a matrix with padded extents x = rows, k = ld (multiples of 128)
-static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld}; }
-
-static int launch_split3(const float* X, long rs, long cs, int R, int C, const P3Buf& out, hipStream_t st) {
-  hipLaunchKernelGGL(k_split3, dim3((unsigned)(out.ld / 64), (unsigned)(out.rows / 64)), dim3(kThreads), 0, st, X, rs, cs, R, C,
-                     out.p, out.rows * 32, out.rows * out.ld);
-  return (int)hipGetLastError();
-}
-
-static P3Args p3_args(const P3Buf& A, const P3Buf& B, int M, int N, int K, int kmode) {
-  P3Args g = {};
-  g.A = p3_of(A); g.B = p3_of(B);
-  g.e.M = M; g.e.N = N; g.e.K = K; g.e.kmode = kmode; g.e.epi = EPI_STORE;
-  return g;
-}
-static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; }
-static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; }
-
-static int launch_p3(const P3Args& g, hipStream_t st) {
-  hipLaunchKernelGGL(k_gemm_p3, dim3((g.e.N + 127) / 128, (g.e.M + 127) / 128), dim3(kThreads), 0, st, g);
+static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
+  P3Pair p;
+  p.g[0] = a; p.g[1] = b;
+  p.tx0 = (a.e.N + 127) / 128; p.tx1 = (b.e.N + 127) / 128;
+  p.tiles0 = p.tx0 * ((a.e.M + 127) / 128);
+  const int tiles1 = p.tx1 * ((b.e.M + 127) / 128);
+  hipLaunchKernelGGL(k_gemm_p3_pair, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
   return (int)hipGetLastError();
 }
 
@@ -2090,6 +2172,52 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
   return launch_p3(g2, st);
 }
 
+// The GEMM stages of plan_update on planes (same products and K ranges; the solves stay on the fp32 kernels):
+//   after the balance:  Lr/Lc = planes(QlS / QlS'),  Rr/Rc = planes(QrS / QrS'),  U0 = planes(dG)
+//   s0  U1 = planes((dG QrS')')            s1  U2, U3 = planes(A), planes(A'),  A = QlS (dG QrS')
+//   after the solves:   U0, U1 = planes(Bt), planes(Bt')
+//   s2  G1 = planes(triu(A A' - Bt Bt')), max -> scal[0]     s3  G2 = planes(triu(A'A - Bt'Bt)), max -> scal[1]
+//   s4  QlOut = QlS - (step / max) G1 QlS                    s5  QrOut = QrS - (step / max) G2 QrS
+static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st) {
+  const long Mp = pad128(M), Np = pad128(N);
+  const P3Buf Lr = {k.Lr, Mp, Mp}, Lc = {k.Lc, Mp, Mp}, Rr = {k.Rr, Np, Np}, Rc = {k.Rc, Np, Np};
+  const P3Buf dGp = {k.U0, Mp, Np}, Tt = {k.U1, Np, Mp}, Ar = {k.U2, Mp, Np}, Ac = {k.U3, Np, Mp};
+  int e;
+  if ((e = launch_split3_both(k.QlS, M, 1, M, M, Lr, Lc, st))) return e;
+  if ((e = launch_split3_both(k.QrS, N, 1, N, N, Rr, Rc, st))) return e;
+  if ((e = launch_split3(dG, N, 1, M, N, dGp, st))) return e;
+  P3Args s0 = p3_args(dGp, Rr, M, N, N, KLO_N);                 // T = dG QrS'  (:173); (n, k) view of QrS' = QrS
+  p3_out_col(s0, Tt);
+  if ((e = launch_p3(s0, st))) return e;
+  P3Args s1 = p3_args(Lr, Tt, M, N, M, KLO_M);                  // A = QlS T
+  p3_out_row(s1, Ar); p3_out_col(s1, Ac);
+  return launch_p3(s1, st);
+}
+
+static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float step, float tiny, const KronWs& k, hipStream_t st) {
+  const long Mp = pad128(M), Np = pad128(N);
+  const P3Buf Lc = {k.Lc, Mp, Mp}, Rc = {k.Rc, Np, Np}, G1 = {k.G1, Mp, Mp}, G2 = {k.G2, Np, Np};
+  const P3Buf Br = {k.U0, Mp, Np}, Bc = {k.U1, Np, Mp}, Ar = {k.U2, Mp, Np}, Ac = {k.U3, Np, Mp};
+  int e;
+  if ((e = launch_split3_both(k.Bt, N, 1, M, N, Br, Bc, st))) return e;
+  P3Args s2 = p3_args(Ar, Ar, M, M, N, 0);                      // grad1 = triu(A A' - Bt Bt')  (:175)
+  s2.A2 = p3_of(Br); s2.B2 = p3_of(Br); s2.e.A2 = k.Bt; s2.e.K2 = N;
+  s2.e.epi = EPI_TRIU_MAX; s2.e.maxout = k.scal + 0;
+  p3_out_row(s2, G1);
+  P3Args s3 = p3_args(Ac, Ac, N, N, M, 0);                      // grad2 = triu(A'A - Bt'Bt)  (:176)
+  s3.A2 = p3_of(Bc); s3.B2 = p3_of(Bc); s3.e.A2 = k.Bt; s3.e.K2 = M;
+  s3.e.epi = EPI_TRIU_MAX; s3.e.maxout = k.scal + 1;
+  p3_out_row(s3, G2);
+  if ((e = launch_p3_two(s2, s3, st))) return e;
+  P3Args s4 = p3_args(G1, Lc, M, M, M, KLO_M | KHI_N);          // QlS - (step1 grad1) QlS  (:179); (n, k) view of QlS = QlS'
+  s4.e.epi = EPI_D_MINUS; s4.e.C = QlOut; s4.e.ldc = M; s4.e.D = k.QlS; s4.e.ldd = M;
+  s4.e.scale_max = k.scal + 0; s4.e.step = step; s4.e.tiny = tiny;
+  P3Args s5 = p3_args(G2, Rc, N, N, N, KLO_M | KHI_N);
+  s5.e.epi = EPI_D_MINUS; s5.e.C = QrOut; s5.e.ldc = N; s5.e.D = k.QrS; s5.e.ldd = N;
+  s5.e.scale_max = k.scal + 1; s5.e.step = step; s5.e.tiny = tiny;
+  return launch_p3_two(s4, s5, st);
+}
+
 // entry points shared with psgd_kron_bf16.hip (kron_shared.h)
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal) {
   const long tot = (long)M * M + (long)N * N;
@@ -2126,6 +2254,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 2) { g_trsm_lds = value; return PSGD_OK; }
   if (key == 3) { g_small_deep = value; return PSGD_OK; }
   if (key == 4) { g_planes = value; return PSGD_OK; }
+  if (key == 5) { g_trsm_group = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -2188,13 +2317,24 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
   KRON_LAUNCH(kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal));               // K0: balance (:166-170); zeroes k.scal
+  const bool planes = kron_planes(M, N) && g_planes && g_gemm_x3;
   GemmArgs s[6];
   plan_update(dG, QlOut, QrOut, M, N, step, tiny, k, s);
-  KRON_LAUNCH(launch_gemm(s[0], st));
-  KRON_LAUNCH(launch_gemm(s[1], st));
+  if (planes) {
+    KRON_LAUNCH(planes_update_front(dG, M, N, k, st));
+  } else {
+    KRON_LAUNCH(launch_gemm(s[0], st));
+    KRON_LAUNCH(launch_gemm(s[1], st));
+  }
   // K2 (:174): X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
+  // (the K = 512 trailing products of the solves were tried on planes too: 557 + 7 x 9 us of strip splits against 647 us
+  // per solve -- their 16 K steps per block are dominated by the fixed parts of a block either way -- so they stay on k_gemm_x3)
   KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st));
   KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st));
+  if (planes) {
+    KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st));
+    return PSGD_OK;
+  }
   KRON_LAUNCH(launch_gemm_two(s[2], s[3], st));      // the two gradient products
   KRON_LAUNCH(launch_gemm_two(s[4], s[5], st));      // the two factor updates
   return PSGD_OK;

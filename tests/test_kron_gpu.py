@@ -49,7 +49,11 @@ def test_dense_dense_apply(psgd, M, N):
     assert rel_err(out.cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("M,N", DD_SHAPES)
+# M, N >= 1024: the GEMM stages run on pre-split operand planes (tile multiples and zero-padded edges, both aspect ratios)
+PLANE_SHAPES = [(1024, 1024), (1030, 1100), (1155, 1024), (1024, 1290)]
+
+
+@pytest.mark.parametrize("M,N", DD_SHAPES + PLANE_SHAPES)
 def test_dense_dense_update(psgd, M, N):
     rng = np.random.default_rng(M * 77 + N)
     Ql, Qr = _tri_factor(rng, M) * 3.0, _tri_factor(rng, N)      # rho != 1
@@ -429,6 +433,30 @@ def test_large_apply_on_operand_planes(psgd, M, N):
     finally:
         lib.psgd_kron_set_tuning(4, 1)
     assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("M,N", [(1024, 1024), (1030, 1100)])
+def test_large_update_planes_against_in_gemm_split(psgd, M, N):
+    """The plane path of the update (tuning key 4) and the in-GEMM split produce the same factors to fp32 rounding (the
+    fp64 oracle comparison of both is test_dense_dense_update / PLANE_SHAPES with the default path)."""
+    from psgd_tf_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M + 7 * N)
+    Ql, Qr = _dev(_tri_factor(rng, M) * 2.0), _dev(_tri_factor(rng, N))
+    dX = _dev(rng.standard_normal((M, N)))
+    dG = _dev(rng.standard_normal((M, N)) * 0.5) + 1.3 * dX
+    outs = []
+    try:
+        for planes in (1, 0):
+            lib.psgd_kron_set_tuning(4, planes)
+            outs.append(psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01))
+    finally:
+        lib.psgd_kron_set_tuning(4, 1)
+    rho = torch.sqrt(Ql.diagonal().max() / Qr.diagonal().max())
+    for a, b, base in ((outs[0][0], outs[1][0], Ql / rho), (outs[0][1], outs[1][1], Qr * rho)):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+        assert rel_err((a - base).cpu().numpy(), (b - base).cpu().numpy()) < 1e-4
+        assert torch.equal(a, torch.triu(a))
 
 
 def test_bf16_factor_copies_follow_the_factors(psgd):
