@@ -200,6 +200,12 @@ def kron_bench(dev, psgd, iters=20):
     # (matches rocprofv3's MOPS_BF16 count, profiles/kron_mfma_pmc.json: 292 GFLOP at 4096^2)
     tm, tn = M // 256, N // 256
     f_issued = (tn * tm * (tn + 1) + tm * tn * (tm + 1)) * 2 * 256**3
+    # fp32 apply on planes (M >= N order, psgd_kron.hip planes_apply): tile steps of G (Qr'Qr), Ql (.), Ql' (.)
+    t128m, t128n = -(-M // 128), -(-N // 128)
+    steps = t128m * t128n * -(-N // 32)                                                   # full K = N
+    steps += sum(t128n * -(-(M - 128 * i) // 32) for i in range(t128m))                    # K from the tile row on
+    steps += sum(t128n * -(-min(M, 128 * (i + 1)) // 32) for i in range(t128m))            # K up to the tile row
+    f32_issued = steps * 6 * 2 * 128 * 128 * 32
     pmc = None                          # matrix-core counters of the same call, collected with rocprofv3 --pmc
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "kron_mfma_pmc.json")))
@@ -228,7 +234,12 @@ def kron_bench(dev, psgd, iters=20):
                                     "mfma_pmc": pmc},
         "4096x4096_fp32": {"ms": t_f32, "gflops": f_big / t_f32 / 1e6, "mfma_peak_gflops": 157.3e3,
                            "ms_new_factors_every_call": t_f32_cold,
-                           "note": "fp32-accurate bf16 x 3 split GEMMs on the bf16 matrix cores (6 bf16 MFMAs per product): "
+                           "issued_bf16_gflop_per_apply": f32_issued / 1e9,
+                           "frac_of_bf16_peak_issued": f32_issued / t_f32 / 1e6 / 2.5e6,
+                           "note": "fp32-accurate products on the bf16 matrix cores: operands split once into three bf16 planes "
+                                   "(x = h + m + l exactly), 6 bf16 MFMAs per product term, K loop = DMA + MFMA (k_gemm_p3); "
+                                   "`issued` counts the 128 x 128 x 32 tile steps the three products run (triangular K ranges "
+                                   "skipped) x 6; `ms` keeps the Gram and factor planes (factors unchanged between applies); "
                                    "the fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
         "lenet5_set_fp32": {"us": t_lenet * 1e3, "gflops": f_lenet / t_lenet / 1e6, "bound": "launch/latency",
                             "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop * 1e3,

@@ -192,6 +192,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
   const int wm = w >> 1, wn = w & 1;
   float vmax = 0.0f;
   const long ccs = g.c_cs ? g.c_cs : 1;
+  // EPI_D_MINUS: every D element of the tile is requested BEFORE the first one is used (clamped addresses, no branches):
+  // a load inside the store loop below costs one full memory latency per element -- 16 .. 64 of them in a row per block,
+  // as much as the whole K loop of a K = 512 product.
+  f32x4 dv[NT][NT];
+  if (g.epi == EPI_D_MINUS) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = min(m0 + wm * W + i * 16 + (lane >> 4) * 4 + e, g.M - 1);
+          const int col = min(n0 + wn * W + j * 16 + (lane & 15), g.N - 1);
+          dv[i][j][e] = g.D[(long)row * g.ldd + col * ccs];
+        }
+  }
+  float cvj[NT];                        // column scales (EPI_STORE with colv): one load per column of the wave tile, up front
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    cvj[j] = 1.0f;
+    if (g.epi == EPI_STORE && g.colv) {
+      const float cv = g.colv[min(n0 + wn * W + j * 16 + (lane & 15), g.N - 1)];
+      cvj[j] = g.colsq ? cv * cv : cv;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -206,10 +231,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
             v = (col >= row) ? v : 0.0f;
             vmax = amaxf(vmax, fabsf(v));
           } else if (g.epi == EPI_D_MINUS) {
-            v = g.D[(long)row * g.ldd + col * ccs] - v;
+            v = dv[i][j][e] - v;
           } else if (g.colv) {
-            const float cv = g.colv[col];
-            v *= g.colsq ? cv * cv : cv;
+            v *= cvj[j];
           }
           g.C[(long)row * g.ldc + col * ccs] = v;
           if (g.sym && n0 > m0) g.C[(long)col * g.ldc + row * ccs] = v;      // the mirror tile is not computed

@@ -226,6 +226,25 @@ __device__ __forceinline__ void hgemm_nt_body(const HGemmArgs& g, int bid, u32x4
   // epilogue: acc[i][j][e] is C[row = ..+(lane>>4)*4+e][col = ..+(lane&15)]
   float vmax = 0.0f;
   const float dscale = (g.epi == HEPI_D_MINUS) ? g.step / (*g.scale_max + g.tiny) : 0.0f;
+  if (g.epi == HEPI_D_MINUS) {
+    // all D elements of the tile are requested before the first one is used (clamped addresses): loaded one by one
+    // inside the store loop they cost a full memory latency each
+    f32x4 dv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = min(m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + e, g.M - 1);
+          const int col = min(n0 + wn * 64 + j * 16 + (lane & 15), g.N - 1);
+          dv[i][j][e] = g.D[(long)row * g.ldd + col];
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = dv[i][j] - dscale * acc[i][j];
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -240,10 +259,6 @@ __device__ __forceinline__ void hgemm_nt_body(const HGemmArgs& g, int bid, u32x4
           vmax = amaxf(vmax, fabsf(v));
           acc[i][j][e] = v;
         }
-      } else if (g.epi == HEPI_D_MINUS) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (row0 + e < g.M) acc[i][j][e] = g.D[(long)(row0 + e) * g.ldd + col] - dscale * acc[i][j][e];
       }
       if (g.c_trans) {
         if (row0 + 3 < g.M) {
