@@ -805,17 +805,25 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
                                                      long tts, long tps) {
   __shared__ float S[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  // (clamped addresses, every load issued before the first use: a guarded load compiles to load-then-wait)
+  float x[16];
   if (cs == 1 || rs != 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      x[i] = X[(long)min(r0 + (tid >> 6) + 4 * i, R - 1) * rs + (long)min(c0 + (tid & 63), C - 1) * cs];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = (tid >> 6) + 4 * i, c = tid & 63;
-      S[r][c] = (r0 + r < R && c0 + c < C) ? X[(long)(r0 + r) * rs + (long)(c0 + c) * cs] : 0.0f;
+      S[r][c] = (r0 + r < R && c0 + c < C) ? x[i] : 0.0f;
     }
   } else {
 #pragma unroll
+    for (int i = 0; i < 16; ++i)
+      x[i] = X[(long)min(r0 + (tid & 63), R - 1) + (long)min(c0 + (tid >> 6) + 4 * i, C - 1) * cs];
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int c = (tid >> 6) + 4 * i, r = tid & 63;
-      S[r][c] = (r0 + r < R && c0 + c < C) ? X[(long)(r0 + r) + (long)(c0 + c) * cs] : 0.0f;
+      S[r][c] = (r0 + r < R && c0 + c < C) ? x[i] : 0.0f;
     }
   }
   __syncthreads();

@@ -65,13 +65,10 @@ __global__ __launch_bounds__(kThreads) void k_splu_reduce_sum(const float* __res
   const float* p = part + (long)id * G;
   float x[kMaxGrid / 64];
 #pragma unroll
-  for (int u = 0; u < kMaxGrid / 64; ++u) {
-    const int b = lane + 64 * u;
-    x[u] = (b < G) ? p[b] : 0.0f;
-  }
-  double s = 0.0;
+  for (int u = 0; u < kMaxGrid / 64; ++u) x[u] = p[min(lane + 64 * u, G - 1)];      // clamped, unconditional: a guarded load
+  double s = 0.0;                                                                    // compiles to load-then-wait, one latency each
 #pragma unroll
-  for (int u = 0; u < kMaxGrid / 64; ++u) s += (double)x[u];
+  for (int u = 0; u < kMaxGrid / 64; ++u) s += (lane + 64 * u < G) ? (double)x[u] : 0.0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (lane == 0) sums[id] = s;
