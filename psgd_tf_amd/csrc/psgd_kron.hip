@@ -669,7 +669,6 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
       }
   }
 }
-
 // plane outputs of a C tile (pads inside the padded extents are written as zeros)
 __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&acc)[4][4], int m0, int n0, bool do_row,
                                                 bool do_col) {
@@ -712,9 +711,12 @@ __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&a
     }
 }
 
-// 4 waves, one 48 KiB stage, two blocks per CU.  (A 256 x 128 tile with 8 waves, one block per CU and two stages -- DMA a
-// whole K step ahead, one barrier per step, 25 % less L1 traffic -- measured 0.519 against 0.532 ms at 4096^3 and far
-// worse on the triangular K ranges, 512 uneven tiles on 256 CUs: not kept.)
+// 4 waves, one 48 KiB stage, two blocks per CU.  Measured and not kept: a 256 x 128 tile with 8 waves, one block per CU and
+// two stages (DMA a whole K step ahead, one barrier per step, 25 % less L1 traffic): 0.519 against 0.532 ms at 4096^3 and
+// far worse on the triangular K ranges (512 uneven tiles on 256 CUs); three blocks per CU with the A fragments read in
+// two halves (164 registers): 0.514-0.537.  Under this kernel the device sits at 1.98-2.13 GHz and 1260-1335 W of its
+// 1400 W (tools/clock_probe.sh): 1540 TFLOP/s issued is 72 % of the matrix peak AT THAT CLOCK, the K loop without its DMA
+// (the what-if floor, 0.42 ms) 91 % -- what is left is mostly not schedule.
 __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLdsX3& L) {
   constexpr int TM = 128, TN = 128, GK = kX3K;
   const int m0 = by * TM, n0 = bx * TN;
