@@ -66,6 +66,44 @@ int main(int argc, char** argv) {
              outs[o], ms, flop / ms * 1e-9, 6 * flop / ms * 1e-9);
     }
   }
+  {   // does the planes product depend on the data (matrix-core power) or on what ran before it?
+    __bf16 *PA, *PB;
+    hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
+    const P3Buf a = {PA, n, n}, b = {PB, n, n};
+    std::vector<float> hb((size_t)n * n);
+    unsigned s2 = 777u;
+    for (size_t i = 0; i < hb.size(); ++i) {                  // B = I + 0.02 * noise (a Gram of a near-identity factor)
+      s2 = s2 * 1664525u + 1013904223u;
+      hb[i] = 0.02f * (((s2 >> 8) & 0xFFFF) / 65536.0f - 0.5f) + ((i / n == i % n) ? 1.0f : 0.0f);
+    }
+    hipMemcpy(B, hb.data(), bytes, hipMemcpyHostToDevice);
+    launch_split3(A, n, 1, n, n, a, 0);
+    launch_split3(B, 1, n, n, n, b, 0);
+    P3Args g = p3_args(a, b, n, n, n, 0);
+    g.e.C = C; g.e.ldc = n;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0.f;
+    for (int i = 0; i < 3; ++i) launch_p3(g, 0);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 20; ++i) launch_p3(g, 0);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("planes, B = I + 0.02 noise:                     %.3f ms per product\n", ms / 20);
+    float ms2 = 0.f;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 20; ++i) launch_split3(A, n, 1, n, n, a, 0);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms2, e0, e1);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 20; ++i) { launch_split3(A, n, 1, n, n, a, 0); launch_p3(g, 0); }
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("planes, alternating with a split of A:          %.3f ms per product (+ %.3f ms per split)\n", (ms - ms2) / 20, ms2 / 20);
+  }
   GemmArgs g = gemm_args(A, n, false, B, n, false, C, n, n, n, n, KLO_M);
   printf("X3_DBG=%d  triangular A (KLO_M)  %.3f ms\n", X3_DBG, run(g, 20));
   return 0;
