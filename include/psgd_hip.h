@@ -258,7 +258,9 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * key 4: M, N >= 1024: 1 (default) the products run on operands split ONCE into three bf16 planes in the workspace
  *        (k_split3 / plane-writing epilogues, k_gemm_p3: DMA + MFMA K loop); 0 = operands split inside every GEMM tile.
  * key 5: blocked triangular solves: 512-column strips per group (a finished group updates the columns to its right in
- *        one product with K = 512 * group); 0 (default) = 4 from n = 4096 on, else 1. */
+ *        one product with K = 512 * group); 0 (default) = 4 from n = 4096 on, else 1.
+ * key 6: large fp32 update, M = N: 1 (default) the last tiles of the gradient grid are split along K over the block
+ *        slots a short last round would leave idle (partials summed in a fixed order by the last block to arrive). */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

@@ -717,7 +717,12 @@ __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&a
 // two halves (164 registers): 0.514-0.537.  Under this kernel the device sits at 1.98-2.13 GHz and 1260-1335 W of its
 // 1400 W (tools/clock_probe.sh): 1540 TFLOP/s issued is 72 % of the matrix peak AT THAT CLOCK, the K loop without its DMA
 // (the what-if floor, 0.42 ms) 91 % -- what is left is mostly not schedule.
-__device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLdsX3& L) {
+// K split of a tile (chunk >= 0): the tile's K steps are dealt to `nchunk` blocks (the subtracted pair's to the first
+// half); every block leaves its partial tile in `scratch`, and the LAST one to arrive (ticket counter) sums the partials
+// in chunk order -- a fixed order, whoever arrives last -- and runs the epilogue.  The counter is left at zero again.
+struct P3Split { int chunk, nchunk; float* scratch; unsigned* cnt; };     // scratch, cnt: of THIS tile
+
+__device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLdsX3& L, const P3Split sp = P3Split{-1, 0, nullptr, nullptr}) {
   constexpr int TM = 128, TN = 128, GK = kX3K;
   const int m0 = by * TM, n0 = bx * TN;
   const bool tri_skip = (g.e.epi == EPI_TRIU_MAX || g.e.sym) && (m0 >= n0 + TN);
@@ -727,7 +732,43 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!tri_skip) {
+  if (sp.chunk >= 0) {
+    const int npair = g.e.A2 ? 2 : 1, per_pair = sp.nchunk / npair;
+    const int p = npair - 1 - sp.chunk / per_pair, sub = sp.chunk % per_pair;     // the subtracted pair first, as below
+    const int K = p ? g.e.K2 : g.e.K, km = p ? g.e.kmode2 : g.e.kmode;
+    int lo = 0, hi = K;
+    if (km & KLO_M) lo = max(lo, m0);
+    if (km & KLO_N) lo = max(lo, n0);
+    if (km & KHI_M) hi = min(hi, m0 + TM);
+    if (km & KHI_N) hi = min(hi, n0 + TN);
+    lo = (lo / GK) * GK;
+    hi = ((hi + GK - 1) / GK) * GK;
+    const int steps = (hi - lo) / GK, per = (steps + per_pair - 1) / per_pair;
+    const int clo = lo + sub * per * GK, chi = min(hi, clo + per * GK);
+    p3_pass(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc);
+    f32x4* mine = reinterpret_cast<f32x4*>(sp.scratch) + (long)sp.chunk * (16 * kThreads);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * kThreads + threadIdx.x] = p ? -acc[i][j] : acc[i][j];
+    __threadfence();                                   // the partial is visible device-wide before the ticket is taken
+    __shared__ unsigned ticket;
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(sp.cnt, 1u);
+    __syncthreads();
+    if (ticket != (unsigned)(sp.nchunk - 1)) return;
+    __threadfence();                                   // acquire: the other blocks' partials
+    if (threadIdx.x == 0) *sp.cnt = 0u;                // ready for the next call
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(sp.scratch) + (i * 4 + j) * kThreads + threadIdx.x;
+        f32x4 v = __builtin_nontemporal_load(q);
+        for (int c = 1; c < sp.nchunk; ++c) v += __builtin_nontemporal_load(q + (long)c * (16 * kThreads));
+        acc[i][j] = v;
+      }
+  } else if (!tri_skip) {
     // the subtracted pair first, then one sign flip of the accumulators
 #pragma unroll 1
     for (int p = g.e.A2 ? 1 : 0; p >= 0; --p) {
@@ -797,6 +838,38 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
   int by, bx;
   gemm_tile_from_id(id, (g.e.M + 127) / 128, which ? p.tx1 : p.tx0, g.e.kmode, by, bx);
   p3_body(g, by, bx, L);
+}
+
+// The two gradient products of the update (psgd.py:175-176) in one grid: upper tiles only (the planes of a triu result are
+// never read below the diagonal), in row-major order of the upper triangle, and with the LAST tiles of the second product
+// split along K (P3Split).  All these tiles cost the same 2 x K / 32 steps, so without the split 1056 tiles on 512 block
+// slots are two full rounds and a third with 32 tiles (half a millisecond of idle CUs at 4096^2); with the last 64 tiles
+// as 512 eighth-size items the tail is one round of 32 steps.
+struct P3Grad { P3Args g[2]; int T0, T1, n0, n1, nsplit, nchunk; float* scratch; unsigned* cnt; };
+
+__device__ __forceinline__ void upper_tile(int idx, int T, int& r, int& c) {      // idx-th tile (r <= c) of a T x T upper triangle
+  const float b = 2.0f * T + 1.0f;
+  r = (int)((b - sqrtf(b * b - 8.0f * idx)) * 0.5f);
+  while (r > 0 && idx < r * T - (r * (r - 1)) / 2) --r;                           // (float rounding)
+  while (idx >= (r + 1) * T - ((r + 1) * r) / 2) ++r;
+  c = r + idx - (r * T - (r * (r - 1)) / 2);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  const int id = blockIdx.x, whole1 = p.n1 - p.nsplit;
+  int r, c;
+  if (id < p.n0) {
+    upper_tile(id, p.T0, r, c);
+    p3_body(p.g[0], r, c, L);
+  } else if (id < p.n0 + whole1) {
+    upper_tile(id - p.n0, p.T1, r, c);
+    p3_body(p.g[1], r, c, L);
+  } else {
+    const int s = id - p.n0 - whole1, t = s / p.nchunk;
+    upper_tile(whole1 + t, p.T1, r, c);
+    p3_body(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
+  }
 }
 
 // fp32 view X(r, c) = X[r * rs + c * cs], r < R, c < C  ->  planes with x = r, k = c (zeros outside R x C; the grid covers
@@ -1796,9 +1869,11 @@ struct KronWs {
   float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv, *Pl, *Pr;
   __bf16 *PP, *F1, *F2, *Y0, *Y1, *Y2;     // operand planes of the large apply (kron_planes): Gram, factor, its transpose; 3 transients
   __bf16 *Lr, *Lc, *Rr, *Rc, *G1, *G2, *U0, *U1, *U2, *U3;   // ... of the large update: balanced factors (both forms), gradients, 4 transients
+  float* split_scratch; unsigned* split_cnt;                 // K-split tail of the gradient grid (k_gemm_p3_grad)
   int64_t total;
 };
 
+constexpr int kGradSplitMax = 256, kGradChunks = 8;      // K-split tail of the gradient grid: at most 256 tiles in 8 chunks each
 // Large applies run on pre-split operand planes (k_gemm_p3).  A pure function of the shape: the workspace layout follows it.
 static inline bool kron_planes(int M, int N) { return M >= 1024 && N >= 1024; }
 static inline int pad128(int x) { return (x + 127) & ~127; }
@@ -1816,6 +1891,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.Pl = take(mm); k.Pr = take(nn);          // Grams of the factors (psgd_kron_dd_prepare_f32): survive update calls
   k.PP = k.F1 = k.F2 = k.Y0 = k.Y1 = k.Y2 = nullptr;
   k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
+  k.split_scratch = nullptr; k.split_cnt = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -1824,6 +1900,8 @@ static KronWs kron_layout(char* base, int M, int N) {
     k.Lr = planes(Mp * Mp); k.Lc = planes(Mp * Mp); k.G1 = planes(Mp * Mp);
     k.Rr = planes(Np * Np); k.Rc = planes(Np * Np); k.G2 = planes(Np * Np);
     k.U0 = planes(Mp * Np); k.U1 = planes(Mp * Np); k.U2 = planes(Mp * Np); k.U3 = planes(Mp * Np);
+    k.split_scratch = take((int64_t)kGradSplitMax * kGradChunks * 64 * kThreads * 4);
+    k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
   }
   k.total = off;
   return k;
@@ -2152,6 +2230,37 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+static int g_grad_split = 1;    // tuning key 6: 0 = no K split of the gradient grid's tail
+static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsigned* cnt, hipStream_t st) {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
+    slots = 2 * cus;                                   // two resident blocks per CU
+  }
+  P3Grad p;
+  p.g[0] = a; p.g[1] = b;
+  p.T0 = (a.e.M + 127) / 128; p.T1 = (b.e.M + 127) / 128;
+  p.n0 = p.T0 * (p.T0 + 1) / 2; p.n1 = p.T1 * (p.T1 + 1) / 2;
+  p.nchunk = kGradChunks; p.scratch = scratch; p.cnt = cnt;
+  const int rem = (p.n0 + p.n1) % slots;
+  p.nsplit = 0;
+  // a short last round (at most a quarter of the slots): twice that many tiles become eighth-size items, which the idle
+  // slots of the last full round and one short extra round absorb
+  // (only when the tiles of both products cost the same, M = N: measured -0.11 ms of 1.55 at 4096^2 -- blocks of a thin last
+  // round run faster than the model's, each has its SIMDs to itself -- and +0.3 ms at 3000 x 5000, where they do not)
+  if (g_grad_split && scratch && a.e.K == b.e.K && rem > 0 && rem <= slots / 4 && p.n0 + p.n1 > slots) {
+    p.nsplit = 2 * rem;
+    if (p.nsplit > p.n1) p.nsplit = p.n1;
+    if (p.nsplit > kGradSplitMax) p.nsplit = kGradSplitMax;
+    const int steps = (b.e.K + 31) / 32;               // per pair; every chunk needs at least one K step
+    if (steps < kGradChunks / 2) p.nsplit = 0;
+  }
+  if (p.nsplit && hipMemsetAsync(cnt, 0, (size_t)p.nsplit * 4, st) != hipSuccess) return 1;
+  hipLaunchKernelGGL(k_gemm_p3_grad, dim3(p.n0 + p.n1 - p.nsplit + p.nsplit * p.nchunk), dim3(kThreads), 0, st, p);
+  return (int)hipGetLastError();
+}
+
 // The apply of plan_apply (large branch, same association order and K ranges) on planes:
 //   M < N:   prepare  Ql' -> Y0,  PP = planes(Ql'Ql),  F1 = planes(Qr),  F2 = planes(Qr')
 //            apply    Y0 = planes(G'),  Y1 = planes(PP G),  Y2 = planes(Y1 Qr'),  out = Y2 Qr
@@ -2242,7 +2351,7 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
   s3.A2 = p3_of(Bc); s3.B2 = p3_of(Bc); s3.e.A2 = k.Bt; s3.e.K2 = M;
   s3.e.epi = EPI_TRIU_MAX; s3.e.maxout = k.scal + 1;
   p3_out_row(s3, G2);
-  if ((e = launch_p3_two(s2, s3, st))) return e;
+  if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st))) return e;
   P3Args s4 = p3_args(G1, Lc, M, M, M, KLO_M | KHI_N);          // QlS - (step1 grad1) QlS  (:179); (n, k) view of QlS = QlS'
   s4.e.epi = EPI_D_MINUS; s4.e.C = QlOut; s4.e.ldc = M; s4.e.D = k.QlS; s4.e.ldd = M;
   s4.e.scale_max = k.scal + 0; s4.e.step = step; s4.e.tiny = tiny;
@@ -2289,6 +2398,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 3) { g_small_deep = value; return PSGD_OK; }
   if (key == 4) { g_planes = value; return PSGD_OK; }
   if (key == 5) { g_trsm_group = value; return PSGD_OK; }
+  if (key == 6) { g_grad_split = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

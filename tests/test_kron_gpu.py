@@ -435,6 +435,34 @@ def test_large_apply_on_operand_planes(psgd, M, N):
     assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-6
 
 
+def test_gradient_grid_k_split_is_deterministic_and_equivalent(psgd):
+    """M = N = 2944: 2 x 276 upper gradient tiles on 512 block slots leave a last round of 40, so the last 80 tiles are
+    split along K over 8 blocks each (tuning key 6): same factors as the unsplit grid to fp32 rounding, bit-identical
+    from call to call (the partials are summed in chunk order, not in arrival order)."""
+    from psgd_tf_amd import _lib
+    lib = _lib.load()
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the shape is chosen for 512 block slots")
+    M = N = 2944
+    g = torch.Generator(device="cuda").manual_seed(11)
+    Ql = torch.triu(torch.randn(M, M, device="cuda", generator=g) * 0.02, 1) + torch.eye(M, device="cuda") * 1.5
+    Qr = torch.triu(torch.randn(N, N, device="cuda", generator=g) * 0.02, 1) + torch.eye(N, device="cuda")
+    dX = torch.randn(M, N, device="cuda", generator=g)
+    dG = 1.3 * dX + 0.3 * torch.randn(M, N, device="cuda", generator=g)
+    outs = []
+    try:
+        for split in (1, 1, 0):
+            lib.psgd_kron_set_tuning(6, split)
+            outs.append(psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01))
+    finally:
+        lib.psgd_kron_set_tuning(6, 1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    rho = torch.sqrt(Ql.diagonal().max() / Qr.diagonal().max())
+    for a, b, base in ((outs[0][0], outs[2][0], Ql / rho), (outs[0][1], outs[2][1], Qr * rho)):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+        assert rel_err((a - base).cpu().numpy(), (b - base).cpu().numpy()) < 1e-4
+
+
 @pytest.mark.parametrize("M,N", [(1024, 1024), (1030, 1100)])
 def test_large_update_planes_against_in_gemm_split(psgd, M, N):
     """The plane path of the update (tuning key 4) and the in-GEMM split produce the same factors to fp32 rounding (the
