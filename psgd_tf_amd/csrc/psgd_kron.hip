@@ -163,6 +163,18 @@ struct GemmLds {
 //     column-dependent work walks the grid column-major (dG Qr' at 4096^2: 823 -> 485 us).
 __device__ __forceinline__ void gemm_tile_from_id(int id, int ty, int tx, int kmode, int& by, int& bx) {
   const int nt = ty * tx;
+  if ((kmode & (KLO_M | KHI_N)) == (KLO_M | KHI_N) && !(kmode & (KLO_N | KHI_M)) && ty == tx && ty % 16 == 0) {
+    // (3) K = [m0, n0 + T): a tile's work is its distance from the diagonal (the two factor updates, psgd.py:179).  8 x 8
+    // patches give the XCD that owns the top-right corner 2.1x the mean work (1600 of 5984 K chunks at 32 x 32 tiles, and
+    // blocks are bound to XCDs by id % 8).  Instead every XCD gets whole tile ROWS, dealt in serpentine order (rows x,
+    // 15 - x, 16 + x, 31 - x, ...: within 9 % of the mean), and walks its rows from the right-hand column inwards, longest
+    // K first; the tiles of a row share its A panel in the XCD's L2.
+    const int xcd = id % 8, j = id / 8, rpx = ty / 8;
+    const int q = j % rpx, jj = j / rpx;
+    by = (q & 1) ? q * 8 + 7 - xcd : q * 8 + xcd;
+    bx = tx - 1 - jj;
+    return;
+  }
   const bool by_col = (kmode & (KLO_N | KHI_N)) && !(kmode & (KLO_M | KHI_M));
   if (ty % 8 == 0 && tx % 8 == 0 && nt % 512 == 0) {
     const int xcd = id % 8, j = id / 8, pn = (by_col ? ty : tx) / 8;
@@ -553,14 +565,31 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3(GemmArgs g) {
 // Two independent large products in one launch (the two gradient products of the update, psgd.py:175-176, then its
 // two factor updates, :179): with 528 upper tiles per 4096^2 triu product and 512 resident blocks, a launch of its own
 // ends with a nearly empty second wave of blocks; back to back in one grid the tail is paid once.
-struct GemmPair { GemmArgs g[2]; int tiles0, tx0, tx1; };
+struct GemmPair { GemmArgs g[2]; int tiles0, tx0, tx1, tiles1; };
+
+// Block -> (product, tile id) of a two-product grid.  The products are INTERLEAVED in groups of 8 + 8 blocks (a group of 8
+// keeps id % 8 = XCD): blocks are dispatched in id order, so with product 1 queued behind all of product 0 its long
+// tiles found the block slots held by product 0's long tiles and ran as a second wave -- the two factor updates
+// (work = distance from the diagonal) took 0.49 ms in one grid against 0.26 ms for one of them alone.
+__device__ __forceinline__ void pair_block(int b, int tiles0, int tiles1, int& which, int& id) {
+  const int nint = min(tiles0, tiles1) & ~7;
+  if (b < 2 * nint) {
+    const int t = b & 15;
+    which = t >> 3;
+    id = (b >> 4) * 8 + (t & 7);
+  } else {
+    const int r = b - 2 * nint, rem0 = tiles0 - nint;
+    which = r >= rem0 ? 1 : 0;
+    id = nint + (which ? r - rem0 : r);
+  }
+}
 
 template <int MA0, int MB0, int MA1, int MB1>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_pair(GemmPair p) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
-  const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
+  int which, id;
+  pair_block(blockIdx.x, p.tiles0, p.tiles1, which, id);
   const GemmArgs& g = p.g[which];
-  const int id = blockIdx.x - (which ? p.tiles0 : 0);
   const int tx = which ? p.tx1 : p.tx0;
   const int ty = ((g.M + 127) / 128);
   int by, bx;
@@ -828,13 +857,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
 }
 
 // two independent products in one grid (see k_gemm_x3_pair)
-struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1; };
+struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1, tiles1; };
 
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
-  const int which = (int)blockIdx.x >= p.tiles0 ? 1 : 0;
+  int which, id;
+  pair_block(blockIdx.x, p.tiles0, p.tiles1, which, id);
   const P3Args& g = p.g[which];
-  const int id = blockIdx.x - (which ? p.tiles0 : 0);
   int by, bx;
   gemm_tile_from_id(id, (g.e.M + 127) / 128, which ? p.tx1 : p.tx0, g.e.kmode, by, bx);
   p3_body(g, by, bx, L);
@@ -1969,6 +1998,7 @@ static int launch_gemm_two(const GemmArgs& a, const GemmArgs& b, hipStream_t st)
   p.tx0 = (a.N + 127) / 128; p.tx1 = (b.N + 127) / 128;
   p.tiles0 = p.tx0 * ((a.M + 127) / 128);
   const int tiles1 = p.tx1 * ((b.M + 127) / 128);
+  p.tiles1 = tiles1;
   int ma0, mb0, ma1, mb1;
   x3_host_modes(a, ma0, mb0);
   x3_host_modes(b, ma1, mb1);
@@ -2226,6 +2256,7 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   p.tx0 = (a.e.N + 127) / 128; p.tx1 = (b.e.N + 127) / 128;
   p.tiles0 = p.tx0 * ((a.e.M + 127) / 128);
   const int tiles1 = p.tx1 * ((b.e.M + 127) / 128);
+  p.tiles1 = tiles1;
   hipLaunchKernelGGL(k_gemm_p3_pair, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
   return (int)hipGetLastError();
 }

@@ -66,6 +66,47 @@ int main(int argc, char** argv) {
              outs[o], ms, flop / ms * 1e-9, 6 * flop / ms * 1e-9);
     }
   }
+  {   // the two factor updates of the Kron update (K = [m0, n0 + 128): work = distance from the diagonal), as one grid
+    __bf16 *PA, *PB;
+    hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
+    const P3Buf a = {PA, n, n}, b = {PB, n, n};
+    launch_split3(A, n, 1, n, n, a, 0);
+    launch_split3(B, 1, n, n, n, b, 0);
+    float* scal; hipMalloc(&scal, 256); hipMemset(scal, 0, 256);
+    for (int variant = 0; variant < 3; ++variant) {
+      P3Args g = p3_args(a, b, n, n, n, KLO_M | KHI_N);
+      g.e.C = C; g.e.ldc = n;
+      if (variant >= 1) { g.e.epi = EPI_D_MINUS; g.e.D = A; g.e.ldd = n; }
+      if (variant == 2) { g.e.scale_max = scal; g.e.step = 0.01f; g.e.tiny = 1e-30f; }
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      for (int i = 0; i < 3; ++i) launch_p3_two(g, g, 0);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 20; ++i) launch_p3_two(g, g, 0);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("two products with K = [m0, n0 + 128) in one grid, %s: %.3f ms\n",
+             variant == 0 ? "plain store" : (variant == 1 ? "C = D - A B" : "C = D - (step / max) A B"), ms / 20);
+      if (variant == 0) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 20; ++i) launch_p3(g, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("one such product alone: %.3f ms\n", ms / 20);
+        P3Args h = p3_args(a, b, n, n, n, 0);
+        h.e.C = C; h.e.ldc = n; h.e.K = 128;                 // 4 K steps per tile: the fixed parts of 1024 blocks
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 20; ++i) launch_p3(h, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("a product with K = 128 (4 steps per tile, 1024 tiles): %.3f ms\n", ms / 20);
+      }
+    }
+  }
   {   // does the planes product depend on the data (matrix-core power) or on what ran before it?
     __bf16 *PA, *PB;
     hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
