@@ -1899,6 +1899,7 @@ struct KronWs {
   __bf16 *PP, *F1, *F2, *Y0, *Y1, *Y2;     // operand planes of the large apply (kron_planes): Gram, factor, its transpose; 3 transients
   __bf16 *Lr, *Lc, *Rr, *Rc, *G1, *G2, *U0, *U1, *U2, *U3;   // ... of the large update: balanced factors (both forms), gradients, 4 transients
   float* split_scratch; unsigned* split_cnt;                 // K-split tail of the gradient grid (k_gemm_p3_grad)
+  __bf16* S0;                                                // planes of one [max(M, N) x 2048] group of the solves
   int64_t total;
 };
 
@@ -1920,7 +1921,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.Pl = take(mm); k.Pr = take(nn);          // Grams of the factors (psgd_kron_dd_prepare_f32): survive update calls
   k.PP = k.F1 = k.F2 = k.Y0 = k.Y1 = k.Y2 = nullptr;
   k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
-  k.split_scratch = nullptr; k.split_cnt = nullptr;
+  k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -1931,6 +1932,7 @@ static KronWs kron_layout(char* base, int M, int N) {
     k.U0 = planes(Mp * Np); k.U1 = planes(Mp * Np); k.U2 = planes(Mp * Np); k.U3 = planes(Mp * Np);
     k.split_scratch = take((int64_t)kGradSplitMax * kGradChunks * 64 * kThreads * 4);
     k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
+    k.S0 = planes(big * 2048);
   }
   k.total = off;
   return k;
@@ -2095,6 +2097,7 @@ __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long 
   }
 }
 
+constexpr int kTrsmPlanesK = 2048;      // group width (4 strips) whose update runs on planes when the factor's planes exist
 static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
 
 struct P3Buf { __bf16* p; long rows, ld; };          // planes of a matrix with padded extents x = rows, k = ld (multiples of 128)
@@ -2162,8 +2165,10 @@ static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// Qc / blk (optional): column-form planes of Q (x = column, k = row) and a plane buffer for [nvec x 2048] of Y: the wide
+// group updates (K = 2048) then run on planes -- the finished group is split once instead of once per column tile.
 static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
-                   hipStream_t st, long xi = 0, long xj = 0, int lite = 0) {
+                   hipStream_t st, long xi = 0, long xj = 0, int lite = 0, const P3Buf* Qc = nullptr, __bf16* blk = nullptr) {
   hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
   if (hipGetLastError() != hipSuccess) return 1;
   if (n <= kStripN) {
@@ -2180,6 +2185,18 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
   // (K = 512), and the finished group updates everything to its right in one product with K = 512 * group -- the
   // 16 K steps of a K = 512 product are dominated by the fixed parts of a block, so the wide products get a longer K.
   auto update = [&](int k0, int kw, int c0, int cw) {                    // Y[:, c0:c0+cw] -= Y[:, k0:k0+kw] Q[k0:k0+kw, c0:c0+cw]
+    if (Qc && blk && kw == kTrsmPlanesK && (long)((cw + 127) / 128) * ((nvec + 127) / 128) >= 256) {
+      const P3Buf Yg = {blk, pad128(nvec), kTrsmPlanesK};
+      int e = launch_split3(Y + (long)k0 * sj, si, sj, nvec, kw, Yg, st);            // (i, k) = Y[i, k0 + k]
+      if (e) return e;
+      P3Args g = p3_args(Yg, *Qc, nvec, cw, kw, 0);                                  // (x, k) = Q[k0 + k, c0 + x]
+      g.B.p = Qc->p + (long)(k0 / 32) * (Qc->rows * 32) + (long)c0 * 32;
+      float* Yr = Y + (long)c0 * sj;
+      g.e.C = Yr; g.e.ldc = si; g.e.c_cs = sj;
+      g.e.D = Yr; g.e.ldd = si;
+      g.e.epi = EPI_D_MINUS;
+      return launch_p3(g, st);
+    }
     GemmArgs g = {};
     g.A = Y + (long)k0 * sj; g.a_rs = si; g.a_cs = sj;
     g.B = Q + (long)k0 * n + c0; g.b_rs = n; g.b_cs = 1;
@@ -2503,9 +2520,16 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   }
   // K2 (:174): X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
   // (the K = 512 trailing products of the solves were tried on planes too: 557 + 7 x 9 us of strip splits against 647 us
-  // per solve -- their 16 K steps per block are dominated by the fixed parts of a block either way -- so they stay on k_gemm_x3)
-  KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st));
-  KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st));
+  // per solve -- their 16 K steps per block are dominated by the fixed parts of a block either way -- so only the wide
+  // K = 2048 group updates use the factors' column-form planes)
+  if (planes) {
+    const P3Buf Rc = {k.Rc, pad128(N), pad128(N)}, Lc = {k.Lc, pad128(M), pad128(M)};
+    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0));
+    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st, 0, 0, 0, &Lc, k.S0));
+  } else {
+    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st));
+    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st));
+  }
   if (planes) {
     KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st));
     return PSGD_OK;
