@@ -134,11 +134,20 @@ def kron_bench(dev, psgd, iters=20):
         # ten warm-up updates' worth of structure is not needed for timing: factors are dense upper-triangular
         return Ql, Qr, torch.randn(M, N, device=dev, generator=g)
 
-    def timeit(fn, n):
+    def timeit(fn, n, warm_ms=30.0, min_ms=20.0):
+        # Steady-state clocks: the same call runs for >= 30 ms before the timed region, which covers >= 20 ms.  After an
+        # idle gap (tensor set-up, a host sync) the device takes tens of ms to settle its clock: the same 0.5-ms GEMM
+        # measures 0.52 or 0.65 ms depending on what ran in the milliseconds before it (profiles/r02_kron_x3_whatif.txt).
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(3):
             fn()
+        e1.record()
         torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        per = max(e0.elapsed_time(e1) / 3, 1e-3)
+        for _ in range(min(2000, int(warm_ms / per))):
+            fn()
+        n = max(n, min(2000, int(min_ms / per) + 1))
         e0.record()
         for _ in range(n):
             fn()
