@@ -255,8 +255,10 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * key 1: 1 (default) 128-tile products run as fp32-accurate bf16 x 3 GEMMs on the bf16 matrix cores; 0 = exact fp32 MFMA.
  * key 2: triangular-solve strips: 0 (default) register-resident kernels, 1 = the LDS-resident ones (A/B measurements).
  * key 3: 32 x 32-tile products: 1 (default) k_gemm_small (ring of 4 K tiles, precomputed per-thread offsets), 0 = the generic body.
- * key 4: M, N >= 1024: 1 (default) the products run on operands split ONCE into three bf16 planes in the workspace
- *        (k_split3 / plane-writing epilogues, k_gemm_p3: DMA + MFMA K loop); 0 = operands split inside every GEMM tile.
+ * key 4: shapes with at least 64 output tiles of 128 x 128 (apply and update) and the update from 512 x 512 on: 1 (default)
+ *        the products run on operands split ONCE into three bf16 planes in the workspace (k_split3 / plane-writing
+ *        epilogues, k_gemm_p3: DMA + MFMA K loop, zero-padded tiles: no edge path); 0 = operands split inside every GEMM
+ *        tile.  (PSGD_KRON_PLANES_OLD=1 in the environment restores the first rule, M, N >= 1024, for A/B runs.)
  * key 5: blocked triangular solves: 512-column strips per group (a finished group updates the columns to its right in
  *        one product with K = 512 * group); 0 (default) = 4 from n = 4096 on, else 1.
  * key 6: large fp32 update, M = N: 1 (default) the last tiles of the gradient grid are split along K over the block

@@ -18,6 +18,7 @@
 // with the K range split over the four waves.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "psgd_hip.h"
 #include "kron_shared.h"
 #include "nanmax.h"
@@ -1905,7 +1906,26 @@ struct KronWs {
 
 constexpr int kGradSplitMax = 256, kGradChunks = 8;      // K-split tail of the gradient grid: at most 256 tiles in 8 chunks each
 // Large applies run on pre-split operand planes (k_gemm_p3).  A pure function of the shape: the workspace layout follows it.
-static inline bool kron_planes(int M, int N) { return M >= 1024 && N >= 1024; }
+// Which shapes run on operand planes (pure functions of the shape: the workspace layout follows them).  Measured
+// (tools/kron_planes_min_sweep.py): the planes kernels have no edge path (zero-padded tiles), so they win wherever the
+// in-GEMM split would run with partial tiles (1000^2 apply 0.34 -> 0.16 ms, 520 x 3000 0.71 -> 0.30, 300 x 4000 0.95 ->
+// 0.37, 64 x 8192 1.7 -> 0.78 even with half the tile rows padding), and the update wins from 512^2 on (0.31 -> 0.25 ms);
+// the apply of aligned 512..896 squares stays on the exact 64-tile kernels (0.06-0.13 against 0.09-0.14 ms), which is
+// what "at least 64 tiles of 128^2" selects.
+static inline int kron_planes_old() {      // PSGD_KRON_PLANES_OLD=1: the round's first rule (M, N >= 1024), for A/B runs
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PSGD_KRON_PLANES_OLD"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v;
+}
+static inline long kron_t128(int M, int N) { return (long)((M + 127) / 128) * ((N + 127) / 128); }
+static inline bool kron_planes_apply(int M, int N) {
+  if (kron_planes_old()) return M >= 1024 && N >= 1024;
+  return kron_t128(M, N) >= 64;
+}
+static inline bool kron_planes(int M, int N) {          // the update, and the workspace
+  if (kron_planes_old()) return M >= 1024 && N >= 1024;
+  return kron_planes_apply(M, N) || (M >= 512 && N >= 512);
+}
 static inline int pad128(int x) { return (x + 127) & ~127; }
 
 static KronWs kron_layout(char* base, int M, int N) {
@@ -2462,7 +2482,7 @@ int psgd_kron_dd_prepare_f32(const float* Ql, const float* Qr, int M, int N, voi
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  if (kron_planes(M, N) && g_planes && g_gemm_x3) {
+  if (kron_planes_apply(M, N) && g_planes && g_gemm_x3) {
     KRON_LAUNCH(planes_prepare(Ql, Qr, M, N, k, st));
     return PSGD_OK;
   }
@@ -2482,7 +2502,7 @@ int psgd_kron_dd_apply_prepared_f32(const float* Ql, const float* Qr, const floa
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  if (kron_planes(M, N) && g_planes && g_gemm_x3) {
+  if (kron_planes_apply(M, N) && g_planes && g_gemm_x3) {
     KRON_LAUNCH(planes_apply(G, out, M, N, k, st));
     return PSGD_OK;
   }

@@ -49,8 +49,8 @@ def test_dense_dense_apply(psgd, M, N):
     assert rel_err(out.cpu().numpy(), ref) < TOL
 
 
-# M, N >= 1024: the GEMM stages run on pre-split operand planes (tile multiples and zero-padded edges, both aspect ratios)
-PLANE_SHAPES = [(1024, 1024), (1030, 1100), (1155, 1024), (1024, 1290)]
+# shapes whose GEMM stages run on pre-split operand planes (tile multiples, zero-padded edges, both aspect ratios, skinny)
+PLANE_SHAPES = [(1024, 1024), (1030, 1100), (1155, 1024), (1024, 1290), (512, 512), (600, 530), (260, 3100), (8200, 70)]
 
 
 @pytest.mark.parametrize("M,N", DD_SHAPES + PLANE_SHAPES)
@@ -412,9 +412,10 @@ def test_prepared_grams_follow_the_factors(psgd, M, N):
     assert rel_err(o3[0].cpu().numpy(), ref(Ql, Qr2, G)) < TOL and rel_err(o3[1].cpu().numpy(), ref(Ql, Qr2, G2)) < TOL
 
 
-@pytest.mark.parametrize("M,N", [(1024, 1024), (1030, 1100), (1024, 2049), (1500, 1027)])
+@pytest.mark.parametrize("M,N", [(1024, 1024), (1030, 1100), (1024, 2049), (1500, 1027), (1000, 1000), (260, 3100), (8200, 70)])
 def test_large_apply_on_operand_planes(psgd, M, N):
-    """M, N >= 1024: the apply runs on operands split once into three bf16 planes (k_gemm_p3; x = h + m + l exactly, so
+    """At least 64 output tiles of 128 x 128 (skinny shapes included: the short side is zero-padded to a tile): the apply
+    runs on operands split once into three bf16 planes (k_gemm_p3; x = h + m + l exactly, so
     the products are the ones of the in-GEMM split).  Both paths against the fp64 oracle, shapes that are not multiples
     of the 128-tile (zero-padded planes), and against each other."""
     from psgd_tf_amd import _lib
