@@ -1910,8 +1910,10 @@ constexpr int kGradSplitMax = 256, kGradChunks = 8;      // K-split tail of the 
 // (tools/kron_planes_min_sweep.py): the planes kernels have no edge path (zero-padded tiles), so they win wherever the
 // in-GEMM split would run with partial tiles (1000^2 apply 0.34 -> 0.16 ms, 520 x 3000 0.71 -> 0.30, 300 x 4000 0.95 ->
 // 0.37, 64 x 8192 1.7 -> 0.78 even with half the tile rows padding), and the update wins from 512^2 on (0.31 -> 0.25 ms);
-// the apply of aligned 512..896 squares stays on the exact 64-tile kernels (0.06-0.13 against 0.09-0.14 ms), which is
-// what "at least 64 tiles of 128^2" selects.
+// the apply of aligned 512..896 squares stays on the exact 64-tile kernels (0.06-0.13 against 0.09-0.14 ms).  Second sweep
+// (MID=1): below 64 tiles the planes still win whenever a dimension is >= 600 and not both are tile multiples (500 x 1700
+// apply 0.35 -> 0.19 ms, 700^2 0.19 -> 0.11, 384 x 2500 0.40 -> 0.25; updates 0.58 -> 0.36 at 500 x 700, 0.47 -> 0.29 at
+// 500^2); 300^2 and smaller stay on the exact kernels (apply 0.03 against 0.06 ms).
 static inline int kron_planes_old() {      // PSGD_KRON_PLANES_OLD=1: the round's first rule (M, N >= 1024), for A/B runs
   static int v = -1;
   if (v < 0) { const char* e = getenv("PSGD_KRON_PLANES_OLD"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -1920,11 +1922,13 @@ static inline int kron_planes_old() {      // PSGD_KRON_PLANES_OLD=1: the round'
 static inline long kron_t128(int M, int N) { return (long)((M + 127) / 128) * ((N + 127) / 128); }
 static inline bool kron_planes_apply(int M, int N) {
   if (kron_planes_old()) return M >= 1024 && N >= 1024;
-  return kron_t128(M, N) >= 64;
+  const long t = kron_t128(M, N);
+  const bool aligned = M % 128 == 0 && N % 128 == 0;
+  return t >= 64 || ((M > N ? M : N) >= 600 && t >= 12 && !aligned);
 }
 static inline bool kron_planes(int M, int N) {          // the update, and the workspace
   if (kron_planes_old()) return M >= 1024 && N >= 1024;
-  return kron_planes_apply(M, N) || (M >= 512 && N >= 512);
+  return kron_planes_apply(M, N) || ((M > N ? M : N) >= 384 && kron_t128(M, N) >= 9);
 }
 static inline int pad128(int x) { return (x + 127) & ~127; }
 

@@ -6,6 +6,7 @@ factors, psgd.py:198-391) are reachable through the same two public
 points and run in HIP as well: elementwise / reduction kernels for the sparse half, the same
 MFMA GEMM and triangular solve for the dense half of a mixed format.
 """
+import collections
 import weakref
 
 import torch
@@ -116,14 +117,35 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
-def _padded_bf16_problem(Ql, Qr, mats):
-    """The bf16 kernels move 16-byte chunks (8 elements) along every K axis.  Other shapes run zero-padded to the next
-    multiple of 8: factors become blockdiag(Q, tiny I) (the smallest positive normal on the new diagonal keeps the
+def _bf16_pad_shape(M, N, apply):
+    """Padded extents of a bf16-operand problem.  Multiples of 8 always (16-byte chunks along every K axis).  The apply of
+    large shapes goes up to multiples of 256: only then do the 256 x 256 kernels (fused triangular pairs, 8-phase dense
+    kernel) take it, and they are up to 1.5x faster than the guarded 128-tile kernels on the unpadded shape (2500^2:
+    0.30 -> 0.2 ms; tools/kron_shape_scan.py) -- as long as the padding adds at most a fifth to the elements."""
+    Mp, Np = _pad8(M), _pad8(N)
+    if apply and min(M, N) >= 1024:
+        M2, N2 = (M + 255) // 256 * 256, (N + 255) // 256 * 256
+        if M2 * N2 <= 1.2 * M * N:
+            Mp, Np = M2, N2
+    return Mp, Np
+
+
+# (device, M, N, Mp, Np, stream) -> (tag of the original factors, padded Ql, padded Qr); least-recently-used, a few entries
+# (each holds two padded fp32 factors: a program that sweeps shapes must not accumulate them)
+_padded_factors = collections.OrderedDict()
+_PADDED_FACTORS_MAX = 8
+
+
+def _padded_bf16_problem(Ql, Qr, mats, apply=False):
+    """The bf16 kernels move 16-byte chunks (8 elements) along every K axis.  Other shapes run zero-padded
+    (_bf16_pad_shape): factors become blockdiag(Q, tiny I) (the smallest positive normal on the new diagonal keeps the
     padded factor triangular and invertible and cannot win the max of psgd.py:166-167), data matrices get zero rows
     and columns.  Every product and solve of psgd.py:156-192 is then block diagonal: the leading M x N (M x M, N x N)
-    block of each result is the unpadded result, the rest is zero (or tiny I)."""
+    block of each result is the unpadded result, the rest is zero (or tiny I).  For the apply the padded factors are
+    kept while the original ones are unchanged (same tensor objects and versions), so that their bf16 copies in the
+    workspace stay valid from call to call as they do for unpadded shapes."""
     M, N = mats[0].shape
-    Mp, Np = _pad8(M), _pad8(N)
+    Mp, Np = _bf16_pad_shape(M, N, apply)
 
     def factor(Q, n, n_p):
         if n == n_p:
@@ -133,7 +155,19 @@ def _padded_bf16_problem(Ql, Qr, mats):
         Qp.diagonal()[n:] = _tiny
         return Qp
     pads = [torch.nn.functional.pad(x, (0, Np - N, 0, Mp - M)) for x in mats]
-    return factor(Ql, M, Mp), factor(Qr, N, Np), pads
+    if not apply:
+        return factor(Ql, M, Mp), factor(Qr, N, Np), pads
+    key = (Ql.device.index, M, N, Mp, Np, _stream_key(Ql.device))
+    hit = _padded_factors.get(key)
+    if hit is not None and hit[0].matches((Ql, Qr)):
+        _padded_factors.move_to_end(key)
+        return hit[1], hit[2], pads
+    Qlp, Qrp = factor(Ql, M, Mp), factor(Qr, N, Np)
+    _padded_factors[key] = (_FactorTag((Ql, Qr)), Qlp, Qrp)
+    _padded_factors.move_to_end(key)
+    while len(_padded_factors) > _PADDED_FACTORS_MAX:
+        _padded_factors.popitem(last=False)
+    return Qlp, Qrp, pads
 
 
 def _update_precond_dense_dense_bf16(Ql, Qr, dX, dG, step):
@@ -201,8 +235,8 @@ def check_bf16_handoffs():
 def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     """psgd.py:182-192 with bf16 MFMA operands (Grad and result in bf16, fp32 master factors)."""
     M, N = Grad.shape
-    if M % 8 or N % 8:
-        Qlp, Qrp, (Gp,) = _padded_bf16_problem(Ql, Qr, (Grad,))
+    if _bf16_pad_shape(M, N, True) != (M, N):
+        Qlp, Qrp, (Gp,) = _padded_bf16_problem(Ql, Qr, (Grad,), apply=True)
         return _precond_grad_dense_dense_bf16(Qlp, Qrp, Gp)[:M, :N].contiguous()
     Ql, Qr, Grad = (t.contiguous() for t in (Ql, Qr, Grad))      # (.contiguous() returns the same object when it already is)
     out = torch.empty_like(Grad)
@@ -236,7 +270,8 @@ class _ApplySlot:
     __slots__ = ("ws", "ws_ptr", "ws_bytes", "rl", "rr", "vl", "vr", "pl", "pr")
 
     def __init__(self, ws):
-        self.ws, self.ws_ptr, self.ws_bytes = ws, ws.data_ptr(), ws.numel()
+        # (a weak reference: the workspace cache owns the block; a slot of a shape the cache has evicted must not keep it alive)
+        self.ws, self.ws_ptr, self.ws_bytes = weakref.ref(ws), ws.data_ptr(), ws.numel()
         self.rl = self.rr = None
         self.vl = self.vr = self.pl = self.pr = -1
 
@@ -262,7 +297,7 @@ def _precond_grad_dense_dense(Ql, Qr, Grad):
     key = (dev.index, M, N, st)
     slot = _apply_slots.get(key)
     ws = _kron_workspace(dev, M, N)                  # (LRU touch; a fresh workspace holds no Grams)
-    if slot is None or slot.ws is not ws:
+    if slot is None or slot.ws() is not ws:
         slot = _apply_slots[key] = _ApplySlot(ws)
     lib = _lib.load()
     pl, pr = Ql.data_ptr(), Qr.data_ptr()

@@ -153,7 +153,8 @@ BF16_TOL = 2e-2      # 4 chained bf16-operand GEMMs with bf16 intermediates: ~2^
 
 @pytest.mark.parametrize("M,N", [(128, 128), (256, 512), (512, 256), (136, 264), (1024, 1024), (8, 8), (200, 72),
                                  (4096, 2048), (2048, 4096),       # these two: 8x8 tile-patch scheduling path
-                                 (133, 260), (7, 5), (1, 3), (1027, 515), (4100, 4093)])   # not multiples of 8: padded
+                                 (133, 260), (7, 5), (1, 3), (1027, 515), (4100, 4093),    # not multiples of 8: padded
+                                 (2000, 2400), (1900, 2300)])      # large, not multiples of 256: padded to the 256-tile kernels
 def test_dense_dense_apply_bf16(psgd, M, N):
     rng = np.random.default_rng(M + 3 * N)
     Ql, Qr = _tri_factor(rng, M).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
@@ -486,6 +487,28 @@ def test_large_update_planes_against_in_gemm_split(psgd, M, N):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
         assert rel_err((a - base).cpu().numpy(), (b - base).cpu().numpy()) < 1e-4
         assert torch.equal(a, torch.triu(a))
+
+
+def test_bf16_padded_apply_keeps_its_padded_factors(psgd):
+    """A large bf16 apply whose shape is not a multiple of 256 runs zero-padded to one; the padded factors (and with them
+    their bf16 copies in the workspace) are kept while the caller's factors are unchanged, and rebuilt when they change."""
+    from psgd_tf_amd import kron
+    M, N = 1900, 2300
+    rng = np.random.default_rng(9)
+    Ql, Qr = _dev(_tri_factor(rng, M).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
+    G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16)
+    ref = lambda ql, qr: orc.precond_grad_kron(ql.cpu().numpy().astype(np.float64), qr.cpu().numpy().astype(np.float64),
+                                               G.float().cpu().numpy().astype(np.float64))
+    a = psgd.precond_grad_kron(Ql, Qr, G)
+    key = [k for k in kron._padded_factors if k[1:5] == (M, N, 2048, 2304)]
+    assert len(key) == 1
+    padded = kron._padded_factors[key[0]][1]
+    b = psgd.precond_grad_kron(Ql, Qr, G)
+    assert kron._padded_factors[key[0]][1] is padded and torch.equal(a, b)          # reused
+    assert rel_err(a.float().cpu().numpy(), ref(Ql, Qr)) < BF16_TOL
+    Qr.mul_(0.5)                                                                     # in place: new version -> rebuilt
+    c = psgd.precond_grad_kron(Ql, Qr, G)
+    assert kron._padded_factors[key[0]][1] is not padded and rel_err(c.float().cpu().numpy(), ref(Ql, Qr)) < BF16_TOL
 
 
 def test_bf16_factor_copies_follow_the_factors(psgd):

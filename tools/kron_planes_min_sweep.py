@@ -12,6 +12,9 @@ if __name__ == "__main__":
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     shapes = ((512, 512), (640, 640), (896, 896), (1000, 1000), (900, 1400), (520, 3000), (300, 4000), (256, 8192), (384, 2048),
               (200, 6000), (1024, 1024))
+    if os.environ.get("MID"):
+        shapes = ((384, 700), (500, 500), (500, 700), (700, 700), (384, 1000), (500, 1000), (700, 1000), (384, 1300), (500, 1300),
+                  (384, 1700), (500, 1700), (200, 1700), (384, 2500), (200, 2500), (200, 3072), (256, 1024), (300, 300))
     if os.environ.get("SKINNY"):
         shapes = ((200, 6000), (6000, 200), (64, 8192), (10, 8192), (128, 4096), (130, 5000), (30, 3000))
     for M, N in shapes:
@@ -25,4 +28,4 @@ if __name__ == "__main__":
         ta = timeit(lambda: psgd.precond_grad_kron(Ql, Qr, G), 30)
         tc = timeit(cold, 30)
         tu = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01), 20)
-        print("%s  %4dx%-4d apply %.3f (new factors %.3f) update %.3f ms" % (("old rule" if os.environ.get("PSGD_KRON_PLANES_OLD") == "1" else "new rule mindim=" + os.environ.get("PSGD_KRON_PLANES_MINDIM", "256")), M, N, ta, tc, tu))
+        print("%s  %4dx%-4d apply %.3f (new factors %.3f) update %.3f ms" % (("old rule" if os.environ.get("PSGD_KRON_PLANES_OLD") == "1" else "t128>=%s upd>=%s updt>=%s" % (os.environ.get("PSGD_KRON_PLANES_T128", "64"), os.environ.get("PSGD_KRON_PLANES_UPD", "512"), os.environ.get("PSGD_KRON_PLANES_UPD_T128", "64"))), M, N, ta, tc, tu))
