@@ -386,11 +386,15 @@ enum { X3_EDGE = 0, X3_KVEC = 1, X3_XROW = 2 };
 
 // Addresses are a UNIFORM base (scalar registers, advanced per K tile) plus a 32-bit per-lane byte offset that does not
 // depend on the K tile: one VGPR per operand instead of a 64-bit address per load kept live across the loop.
+// Blocks at the x edge of an operand (x0 + 128 > X) stay on the fast modes: the lane's ROW is clamped to the last one
+// (a duplicate load), and the commit zeroes what lies outside -- only a ragged K tail needs the scalar mode.  (Edge blocks
+// used to run every K step on clamped scalar loads: shapes that are not tile multiples cost up to 2x, e.g. the trailing
+// products of the solves at 2500 vectors.)
 template <int MODE>
-__device__ __forceinline__ unsigned x3_lane_offset(const TileSrc& t) {
-  const int tid = threadIdx.x;
-  if (MODE == X3_XROW) return 4u * ((unsigned)(tid >> 7) * 16u * (unsigned)t.cs + (unsigned)(tid & 127));
-  if (MODE == X3_KVEC) return 4u * ((unsigned)(tid >> 1) * (unsigned)t.rs + (unsigned)(tid & 1) * 16u);
+__device__ __forceinline__ unsigned x3_lane_offset(const TileSrc& t, int x0) {
+  const int tid = threadIdx.x, last = t.X - 1 - x0;
+  if (MODE == X3_XROW) return 4u * ((unsigned)(tid >> 7) * 16u * (unsigned)t.cs + (unsigned)min(tid & 127, last));
+  if (MODE == X3_KVEC) return 4u * ((unsigned)min(tid >> 1, last) * (unsigned)t.rs + (unsigned)(tid & 1) * 16u);
   return 0u;
 }
 
@@ -432,10 +436,13 @@ __device__ __forceinline__ void r2s_x3(const TileSrc& t, int x0, int k0, int khi
 #pragma unroll
   for (int u = 0; u < 16; u += 2) {
     float v0 = r[u] * mul, v1 = r[u + 1] * mul;
+    const bool xin = x0 + xr < t.X;
     if (MODE == X3_EDGE) {
-      const bool xin = x0 + xr < t.X;
       v0 = (xin && k0 + kb + u < khi) ? v0 : 0.0f;
       v1 = (xin && k0 + kb + u + 1 < khi) ? v1 : 0.0f;
+    } else {
+      v0 = xin ? v0 : 0.0f;
+      v1 = xin ? v1 : 0.0f;
     }
     unsigned q[3];
     if (X3_DBG & 2) { q[0] = __float_as_uint(v0); q[1] = __float_as_uint(v1); q[2] = q[0] ^ q[1]; }
@@ -461,7 +468,7 @@ __device__ __forceinline__ void x3_pass(const TileSrc& ta, const TileSrc& tb, in
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, c = lane >> 4;
   float ra[16], rb[16];
-  const unsigned va = x3_lane_offset<MA>(ta), vb = x3_lane_offset<MB>(tb);
+  const unsigned va = x3_lane_offset<MA>(ta, m0), vb = x3_lane_offset<MB>(tb, n0);
   g2r_x3<MA>(ta, m0, k0, khi, va, ra);
   g2r_x3<MB>(tb, n0, k0, khi, vb, rb);
   r2s_x3<MA>(ta, m0, k0, khi, ra, mul, L.P[0]);
@@ -516,7 +523,7 @@ __device__ __forceinline__ void x3_pass(const TileSrc& ta, const TileSrc& tb, in
 
 // The fetch modes (MA, MB) are chosen by the HOST from the operand strides (x3_host_mode below; both operand pairs of a
 // dual product must agree) and are template parameters of the kernel, so that a kernel holds two K loops only: the
-// fast one for blocks inside the operands and the clamped one for edge blocks and a ragged K tail.
+// fast one (blocks at the x edge included: clamped rows, masked at the commit) and the scalar one for a ragged K tail.
 template <int MA, int MB, bool LITE>
 __device__ __forceinline__ void gemm_body_x3(const GemmArgs& g, int m0, int n0, GemmLdsX3& L) {
   constexpr int T = 128, GK = kX3K, NT = 4;
@@ -531,7 +538,7 @@ __device__ __forceinline__ void gemm_body_x3(const GemmArgs& g, int m0, int n0, 
 
   float a_mul = 1.0f;
   if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
-  const bool fast = MA != X3_EDGE && MB != X3_EDGE && m0 + T <= g.M && n0 + T <= g.N;
+  const bool fast = MA != X3_EDGE && MB != X3_EDGE;
 
   // one operand pair at a time: the second pair of a dual product restarts the pipeline (one more latency per block)
 #pragma unroll 1
