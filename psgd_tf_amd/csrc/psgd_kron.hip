@@ -1914,13 +1914,13 @@ struct KronWs {
 constexpr int kGradSplitMax = 256, kGradChunks = 8;      // K-split tail of the gradient grid: at most 256 tiles in 8 chunks each
 // Large applies run on pre-split operand planes (k_gemm_p3).  A pure function of the shape: the workspace layout follows it.
 // Which shapes run on operand planes (pure functions of the shape: the workspace layout follows them).  Measured
-// (tools/kron_planes_min_sweep.py): the planes kernels have no edge path (zero-padded tiles), so they win wherever the
-// in-GEMM split would run with partial tiles (1000^2 apply 0.34 -> 0.16 ms, 520 x 3000 0.71 -> 0.30, 300 x 4000 0.95 ->
-// 0.37, 64 x 8192 1.7 -> 0.78 even with half the tile rows padding), and the update wins from 512^2 on (0.31 -> 0.25 ms);
-// the apply of aligned 512..896 squares stays on the exact 64-tile kernels (0.06-0.13 against 0.09-0.14 ms).  Second sweep
-// (MID=1): below 64 tiles the planes still win whenever a dimension is >= 600 and not both are tile multiples (500 x 1700
-// apply 0.35 -> 0.19 ms, 700^2 0.19 -> 0.11, 384 x 2500 0.40 -> 0.25; updates 0.58 -> 0.36 at 500 x 700, 0.47 -> 0.29 at
-// 500^2); 300^2 and smaller stay on the exact kernels (apply 0.03 against 0.06 ms).
+// (tools/kron_planes_min_sweep.py, against the in-GEMM split with its x-edge blocks already on the vector fetch modes):
+// the planes kernels have no edge or ragged-K path at all (zero-padded tiles) and split an operand once, so they win on
+// every shape with >= 64 output tiles (1000^2 apply 0.24 -> 0.16 ms, 520 x 3000 0.45 -> 0.30, 300 x 4000 0.52 -> 0.37,
+// 64 x 8192 with half of its tile row padding), below that whenever a dimension is >= 600 and not both are tile multiples
+// (500 x 1700 apply 0.35 -> 0.19 ms, 700^2 0.19 -> 0.11), and for every update from ~384 on (500^2 0.47 -> 0.29 ms,
+// 512^2 0.31 -> 0.25).  The apply of aligned 512..896 squares stays on the exact 64-tile kernels (0.06-0.13 against
+// 0.09-0.14 ms), 300^2 and smaller on the small-tile kernels (apply 0.03 against 0.06 ms).
 static inline int kron_planes_old() {      // PSGD_KRON_PLANES_OLD=1: the round's first rule (M, N >= 1024), for A/B runs
   static int v = -1;
   if (v < 0) { const char* e = getenv("PSGD_KRON_PLANES_OLD"); v = (e && e[0] == '1') ? 1 : 0; }
