@@ -909,6 +909,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
   }
 }
 
+// One triu product with few output tiles and a long K (the gradient of the dense factor of a sparse Kron format at
+// embedding shapes: 1000 x 1000 outputs, K = 30000, twice): upper tiles only, every tile's K steps dealt to `nchunk`
+// blocks (P3Split).  On the in-GEMM split kernel this product ran on 64 workgroups for 1.8 ms.
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk(P3Args g, int T, int nchunk, float* scratch, unsigned* cnt) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  int r, c;
+  upper_tile(t, T, r, c);
+  p3_body(g, r, c, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
+}
+
 // fp32 view X(r, c) = X[r * rs + c * cs], r < R, c < C  ->  planes with x = r, k = c (zeros outside R x C; the grid covers
 // the padded extents) and, optionally, the planes of the transposed view (x = c, k = r) from the same read.  64 x 64
 // tiles through LDS so that the read (along the view's contiguous dimension) and both writes are coalesced.
@@ -1772,26 +1783,51 @@ __global__ __launch_bounds__(kThreads) void k_norm_left(MatView X, const float* 
 }
 
 // out[n] = sum_i w_i Z[i,n];  mode 0: w_i = q1[i] / (q0[i] q0[M-1]) (psgd.py:232);  mode 1: w_i = q1[i] (psgd.py:265);
-// mode 2: out[n] = sum_i Z[i,n]^2 - Z2[i,n]^2 (psgd.py:304).  64 columns per block, 4 waves split the rows.
+// mode 2: out[n] = sum_i Z[i,n]^2 - Z2[i,n]^2 (psgd.py:304).
+// Grid (column blocks of 64, row blocks): a block sums rows [r0, r1) of its 64 columns, four waves taking every fourth
+// row with eight independent loads in flight, and writes part[rb][n]; k_col_reduce_fin adds the row blocks in order.
+// (The first version gave a column block ALL rows: an embedding-shaped operand, 30000 x 1000, ran on 16 workgroups, each
+// a chain of 7500 dependent loads -- 3 ms for 120 MB.)
+constexpr int kColRedRowBlocks = 128;
 __global__ __launch_bounds__(kThreads) void k_col_reduce(MatView Z, MatView Z2, const float* __restrict__ q0,
                                                          const float* __restrict__ q1, int M, int N, int mode,
-                                                         float* out) {
+                                                         int rows_per_block, float* part) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float acc = 0.0f;
   if (n < N) {
     const float qlast = (mode == 0) ? q0[M - 1] : 1.0f;
-    for (int i = ty; i < M; i += 4) {
-      const float z = Z.p[i * Z.rs + n * Z.cs];
-      if (mode == 0) acc += (q1[i] / (q0[i] * qlast)) * z;
-      else if (mode == 1) acc += q1[i] * z;
-      else { const float z2 = Z2.p[i * Z2.rs + n * Z2.cs]; acc += z * z - z2 * z2; }
+    const float* zp = Z.p + (long)n * Z.cs;
+    const float* zp2 = Z2.p + (long)n * Z2.cs;
+    for (int i0 = r0 + ty; i0 < r1; i0 += 32) {
+      float z[8], z2[8], w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                     // clamped rows: unconditional loads, masked below
+        const int i = min(i0 + 4 * u, r1 - 1);
+        z[u] = zp[(long)i * Z.rs];
+        z2[u] = (mode == 2) ? zp2[(long)i * Z2.rs] : 0.0f;
+        w[u] = (mode == 0) ? q1[i] / (q0[i] * qlast) : (mode == 1 ? q1[i] : 0.0f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float t = (mode == 2) ? z[u] * z[u] - z2[u] * z2[u] : w[u] * z[u];
+        acc += (i0 + 4 * u < r1) ? t : 0.0f;
+      }
     }
   }
   red[ty][tx] = acc;
   __syncthreads();
-  if (ty == 0 && n < N) out[n] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+  if (ty == 0 && n < N) part[(long)blockIdx.y * N + n] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+}
+
+__global__ __launch_bounds__(kThreads) void k_col_reduce_fin(const float* __restrict__ part, int RB, int N, float* out) {
+  const int n = blockIdx.x * kThreads + threadIdx.x;
+  if (n >= N) return;
+  float s = part[n];
+  for (int b = 1; b < RB; ++b) s += part[(long)b * N + n];
+  out[n] = s;
 }
 
 // Y[m,n] = (X[m,n] (1/q0[m]) - [m == M-1] s[n]) * (colv ? 1/colv[n] : 1)            (Ql^-T X, psgd.py:230-232,356)
@@ -2729,9 +2765,18 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
  * Data matrices are strided views (element (m,n) at p[m*rs + n*cs]); results are contiguous. */
 
 struct SparseWs {
-  float *scal, *LS, *RS, *T, *A, *Bt, *gsq, *v0, *v1, *v2, *v3, *dinv;
+  float *scal, *LS, *RS, *T, *A, *Bt, *gsq, *v0, *v1, *v2, *v3, *dinv, *cpart;
+  __bf16 *P0, *P1;              // operand planes of the dense factor's gradient when it is a few tiles with a long K
+  float* sk_scratch; unsigned* sk_cnt;
   int64_t total;
 };
+
+// the dense factor's gradient triu(X X' - Y Y') [rows x rows, K]: split-K on planes when it has few tiles and a long K
+constexpr int kSplitkMaxTiles = 160, kSplitkScratchTiles = 640;
+static inline bool sparse_splitk(int rows, int K) {
+  const long T = (rows + 127) / 128;
+  return T * (T + 1) / 2 <= kSplitkMaxTiles && K >= 4096;
+}
 
 static SparseWs sparse_layout(char* base, int fmt, int M, int N) {
   SparseWs k;
@@ -2748,8 +2793,60 @@ static SparseWs sparse_layout(char* base, int fmt, int M, int N) {
   k.gsq = take(gbytes);
   k.v0 = take(vb); k.v1 = take(vb); k.v2 = take(vb); k.v3 = take(vb);
   k.dinv = take((int64_t)(((M > N ? M : N) + 31) / 32) * 1024 * 4);
+  k.cpart = take((int64_t)kColRedRowBlocks * N * 4);             // row-block partials of k_col_reduce
+  k.P0 = k.P1 = nullptr; k.sk_scratch = nullptr; k.sk_cnt = nullptr;
+  const int grows = fmt == 0 ? M : N, gk = fmt == 0 ? N : M;     // the dense factor's gradient: [grows x grows], K = gk
+  if (fmt != 2 && sparse_splitk(grows, gk)) {
+    const int64_t pb = (int64_t)((grows + 127) & ~127) * ((gk + 127) & ~127) * 6;
+    k.P0 = reinterpret_cast<__bf16*>(take(pb)); k.P1 = reinterpret_cast<__bf16*>(take(pb));
+    k.sk_scratch = take((int64_t)kSplitkScratchTiles * 64 * kThreads * 4);
+    k.sk_cnt = reinterpret_cast<unsigned*>(take(kSplitkMaxTiles * 4));
+  }
   k.total = off;
   return k;
+}
+
+// column sums of an M x N operand (k_col_reduce + k_col_reduce_fin): enough row blocks to put ~2048 workgroups on the chip,
+// at least 256 rows each
+static int col_reduce(const SparseWs& k, MatView Z, MatView Z2, const float* q0, const float* q1, int M, int N, int mode,
+                      float* out, hipStream_t st) {
+  const int cb = (N + 63) / 64;
+  int rb = (2048 + cb - 1) / cb;
+  if (rb > kColRedRowBlocks) rb = kColRedRowBlocks;
+  if (rb > (M + 255) / 256) rb = (M + 255) / 256;
+  if (rb < 1) rb = 1;
+  const int rows = (M + rb - 1) / rb;
+  rb = (M + rows - 1) / rows;
+  hipLaunchKernelGGL(k_col_reduce, dim3(cb, rb), dim3(kThreads), 0, st, Z, Z2, q0, q1, M, N, mode, rows, rb == 1 ? out : k.cpart);
+  if (hipGetLastError() != hipSuccess) return PSGD_ERR_LAUNCH;
+  if (rb > 1) {
+    hipLaunchKernelGGL(k_col_reduce_fin, dim3((N + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)k.cpart, rb, N, out);
+    if (hipGetLastError() != hipSuccess) return PSGD_ERR_LAUNCH;
+  }
+  return PSGD_OK;
+}
+
+// grad = triu(X X' - Y Y') for X, Y given as (row, k) views [rows x K]; fp32 result + max|.| as the fused GEMM epilogue does
+static int sparse_grad_splitk(const SparseWs& k, const float* X, const float* Y, long rs, long cs, int rows, int K, float* C,
+                              float* maxout, hipStream_t st) {
+  const long rp = (rows + 127) & ~127, kp = (K + 127) & ~127;
+  const P3Buf Xp = {k.P0, rp, kp}, Yp = {k.P1, rp, kp};
+  int e;
+  if ((e = launch_split3(X, rs, cs, rows, K, Xp, st))) return e;
+  if ((e = launch_split3(Y, rs, cs, rows, K, Yp, st))) return e;
+  P3Args g = p3_args(Xp, Xp, rows, rows, K, 0);
+  g.A2 = p3_of(Yp); g.B2 = p3_of(Yp); g.e.A2 = Y; g.e.K2 = K;
+  g.e.epi = EPI_TRIU_MAX; g.e.maxout = maxout; g.e.C = C; g.e.ldc = rows;
+  const int T = (rows + 127) / 128, nt = T * (T + 1) / 2, steps = (K + 31) / 32;
+  int half = 256 / nt;                                  // chunks per operand pair: at most 512 work items, one round of blocks
+  if (half < 1) half = 1;
+  if (half > 32) half = 32;
+  while (half > 1 && steps / half < 4) --half;
+  const int nchunk = 2 * half;
+  if ((long)nt * nchunk > kSplitkScratchTiles) return 1;
+  if (hipMemsetAsync(k.sk_cnt, 0, (size_t)nt * 4, st) != hipSuccess) return 1;
+  hipLaunchKernelGGL(k_gemm_p3_splitk, dim3(nt * nchunk), dim3(kThreads), 0, st, g, T, nchunk, k.sk_scratch, k.sk_cnt);
+  return (int)hipGetLastError();
 }
 
 static inline int ew_grid(long tot) {
@@ -2795,7 +2892,9 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
   // Bt = (QlS^-T dX) .* (1/qrS)                             (:298-299); columns independent
   KRON_LAUNCH(trsm_ut(k.LS, M, dX, k.Bt, N, 1L, (long)N, k.dinv, st, (long)xcs, (long)xrs));
   SP_LAUNCH(k_col_inv_scale, ew_grid((long)M * N), k.Bt, k.RS, M, N);
-  {                                                          // grad1 = triu(A A' - Bt Bt')  (:301)
+  if (k.P0 && g_planes && g_gemm_x3) {                       // grad1 = triu(A A' - Bt Bt')  (:301): few tiles, long K
+    KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.Bt, (long)N, 1L, M, N, k.gsq, k.scal, st));
+  } else {
     GemmArgs g = gemm_args(k.A, N, false, k.A, N, true, k.gsq, M, M, M, N);
     g.A2 = k.Bt; g.a2_rs = N; g.a2_cs = 1; g.B2 = k.Bt; g.b2_rs = 1; g.b2_cs = N; g.K2 = N;
     g.epi = EPI_TRIU_MAX; g.maxout = k.scal;
@@ -2803,7 +2902,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
   }
   {                                                          // grad2 = colsum(A^2) - colsum(Bt^2)   (:304)
     MatView a = {k.A, N, 1}, b = {k.Bt, N, 1};
-    SP_LAUNCH(k_col_reduce, (N + 63) / 64, a, b, (const float*)nullptr, (const float*)nullptr, M, N, 2, k.v0);
+    if (col_reduce(k, a, b, nullptr, nullptr, M, N, 2, k.v0, st)) return PSGD_ERR_LAUNCH;
   }
   {                                                          // Ql - (step1 grad1) Ql         (:307)
     GemmArgs g = gemm_args(k.gsq, M, false, k.LS, M, false, QlOut, M, M, M, M, KLO_M | KHI_N);
@@ -2845,7 +2944,7 @@ static int norm_left_pair(const SparseWs& k, const float* dX, const float* dG, l
   const float* q1 = k.LS + M;
   MatView vx = {dX, xrs, xcs}, vg = {dG, xrs, xcs};
   SP_LAUNCH(k_norm_left, ew_grid((long)M * N), vg, q0, q1, M, N, colv, 0, A0);
-  SP_LAUNCH(k_col_reduce, (N + 63) / 64, vx, vx, q0, q1, M, N, 0, k.v0);
+  if (col_reduce(k, vx, vx, q0, q1, M, N, 0, k.v0, st)) return PSGD_ERR_LAUNCH;
   SP_LAUNCH(k_norm_left_invT, ew_grid((long)M * N), vx, q0, (const float*)k.v0, M, N, colv, Bt0);
   return PSGD_OK;
 }
@@ -2867,7 +2966,9 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
   KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.T, M, (long)N, 1L, k.dinv, st));                    // Bt QrS^-1 -> T   (:233)
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.T, M, N, k.v1, k.v2);    // (:235-237)
   SP_LAUNCH(k_norm_finalize, 1, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
-  {                                                          // grad2 = triu(A'A - Bt'Bt)     (:243)
+  if (k.P0 && g_planes && g_gemm_x3) {                       // grad2 = triu(A'A - Bt'Bt)     (:243): few tiles, long K
+    KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.T, 1L, (long)N, N, M, k.gsq, k.scal, st));
+  } else {
     GemmArgs g = gemm_args(k.A, N, true, k.A, N, false, k.gsq, N, N, N, M);
     g.A2 = k.T; g.a2_rs = 1; g.a2_cs = N; g.B2 = k.T; g.b2_rs = N; g.b2_cs = 1; g.K2 = M;
     g.epi = EPI_TRIU_MAX; g.maxout = k.scal;
@@ -2899,7 +3000,7 @@ int psgd_kron_nd_apply_f32(const float* ql, const float* Qr, const float* G, int
     KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.gsq, N, false, k.Bt, N, M, N, N), st));
   }
   MatView vz = {k.Bt, N, 1};
-  SP_LAUNCH(k_col_reduce, (N + 63) / 64, vz, vz, ql, ql + M, M, N, 1, k.v0);                             // (:265)
+  if (col_reduce(k, vz, vz, ql, ql + M, M, N, 1, k.v0, st)) return PSGD_ERR_LAUNCH;                      // (:265)
   SP_LAUNCH(k_norm_leftT, ew_grid((long)M * N), (const float*)k.Bt, ql, (const float*)k.v0, M, N, out);  // (:266-268)
   return PSGD_OK;
 }
@@ -2919,7 +3020,7 @@ int psgd_kron_ns_update_f32(const float* ql, const float* qr, const float* dX, c
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.Bt, M, N, k.v1, k.v2);   // (:358-360)
   SP_LAUNCH(k_norm_finalize, 1, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
   MatView a = {k.A, N, 1}, b = {k.Bt, N, 1};
-  SP_LAUNCH(k_col_reduce, (N + 63) / 64, a, b, (const float*)nullptr, (const float*)nullptr, M, N, 2, k.v3);   // (:366)
+  if (col_reduce(k, a, b, nullptr, nullptr, M, N, 2, k.v3, st)) return PSGD_ERR_LAUNCH;                  // (:366)
   SP_LAUNCH(k_scale_finalize, 1, (const float*)k.RS, (const float*)k.v3, N, step, tiny, qrOut);
   return PSGD_OK;
 }
@@ -2935,7 +3036,7 @@ int psgd_kron_ns_apply_f32(const float* ql, const float* qr, const float* G, int
   MatView vg = {G, grs, gcs};
   SP_LAUNCH(k_norm_left, ew_grid((long)M * N), vg, ql, ql + M, M, N, qr, 1, k.T);                       // (:383-385)
   MatView vz = {k.T, N, 1};
-  SP_LAUNCH(k_col_reduce, (N + 63) / 64, vz, vz, ql, ql + M, M, N, 1, k.v0);                             // (:386)
+  if (col_reduce(k, vz, vz, ql, ql + M, M, N, 1, k.v0, st)) return PSGD_ERR_LAUNCH;                      // (:386)
   SP_LAUNCH(k_norm_leftT, ew_grid((long)M * N), (const float*)k.T, ql, (const float*)k.v0, M, N, out);   // (:387-389)
   return PSGD_OK;
 }

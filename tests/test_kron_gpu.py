@@ -585,6 +585,10 @@ BIG_FORMATS = [
     ("dense_scale", (600, 600), (1, 37)), ("scale_dense", (1, 37), (600, 600)),
     ("norm_scale", (2, 1001), (1, 129)), ("scale_norm", (1, 129), (2, 1001)),
     ("norm_dense", (2, 33), (530, 530)), ("dense_scale", (257, 257), (1, 120)),
+    # embedding shapes: the dense factor's gradient is a few tiles with K >= 4096 (split-K on operand planes), the column
+    # reductions run over thousands of rows (row-blocked), the mirrored formats come in as transposed views
+    ("norm_dense", (2, 5000), (300, 300)), ("dense_norm", (300, 300), (2, 5000)),
+    ("dense_scale", (260, 260), (1, 4500)), ("scale_dense", (1, 4500), (260, 260)), ("norm_scale", (2, 6000), (1, 70)),
 ]
 
 
