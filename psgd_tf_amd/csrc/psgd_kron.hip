@@ -1997,8 +1997,11 @@ static KronWs kron_layout(char* base, int M, int N) {
     k.Lr = planes(Mp * Mp); k.Lc = planes(Mp * Mp); k.G1 = planes(Mp * Mp);
     k.Rr = planes(Np * Np); k.Rc = planes(Np * Np); k.G2 = planes(Np * Np);
     k.U0 = planes(Mp * Np); k.U1 = planes(Mp * Np); k.U2 = planes(Mp * Np); k.U3 = planes(Mp * Np);
-    k.split_scratch = take((int64_t)kGradSplitMax * kGradChunks * 64 * kThreads * 4);
-    k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
+    if (M == N) {                                          // (the K-split tail applies to M = N only; never more tiles than exist)
+      const int64_t T1 = Np / 128, nsp = T1 * (T1 + 1) / 2 < kGradSplitMax ? T1 * (T1 + 1) / 2 : kGradSplitMax;
+      k.split_scratch = take(nsp * kGradChunks * 64 * kThreads * 4);
+      k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
+    }
     k.S0 = planes(big * 2048);
   }
   k.total = off;
