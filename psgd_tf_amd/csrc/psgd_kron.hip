@@ -1825,8 +1825,14 @@ __global__ __launch_bounds__(kThreads) void k_col_reduce(MatView Z, MatView Z2, 
 __global__ __launch_bounds__(kThreads) void k_col_reduce_fin(const float* __restrict__ part, int RB, int N, float* out) {
   const int n = blockIdx.x * kThreads + threadIdx.x;
   if (n >= N) return;
-  float s = part[n];
-  for (int b = 1; b < RB; ++b) s += part[(long)b * N + n];
+  float s = 0.0f;
+  for (int b0 = 0; b0 < RB; b0 += 8) {                  // eight loads in flight, added in row-block order
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = part[(long)min(b0 + u, RB - 1) * N + n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (b0 + u < RB) ? x[u] : 0.0f;
+  }
   out[n] = s;
 }
 
@@ -1881,56 +1887,58 @@ __global__ __launch_bounds__(kThreads) void k_row_stats(const float* __restrict_
   if (lane == 0) { gd[m] = d; gb[m] = (m == M - 1) ? 0.0f : b; }
 }
 
-__device__ __forceinline__ float block_max(float v, float* red) {
+__device__ __forceinline__ float block_max(float v, float* red) {          // red: one float per wave (<= 16 waves)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = nmaxf(v, __shfl_down(v, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  const float r = nmaxf(nmaxf(red[0], red[1]), nmaxf(red[2], red[3]));
+  float r = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = nmaxf(r, red[w]);
   __syncthreads();
   return r;
 }
+constexpr int kFinThreads = 1024;      // the one-block kernels below: vectors of up to tens of thousands of entries
 
 // new_ql0 = ql0 - step1 gd ql0 ; new_ql1 = ql1 - step1 (gd ql1 + ql0[M-1] gb),
 // step1 = step / (max(max|gd|, max|gb|) + tiny)                                      (psgd.py:239-241); one block
-__global__ __launch_bounds__(kThreads) void k_norm_finalize(const float* __restrict__ ql, const float* __restrict__ gd,
-                                                            const float* __restrict__ gb, int M, float step, float tiny,
-                                                            float* qlOut) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(kFinThreads) void k_norm_finalize(const float* __restrict__ ql, const float* __restrict__ gd,
+                                                               const float* __restrict__ gb, int M, float step, float tiny,
+                                                               float* qlOut) {
+  __shared__ float red[16];
   float v = 0.0f;
-  for (int i = threadIdx.x; i < M; i += kThreads) v = nmaxf(v, nmaxf(fabsf(gd[i]), fabsf(gb[i])));
+  for (int i = threadIdx.x; i < M; i += blockDim.x) v = nmaxf(v, nmaxf(fabsf(gd[i]), fabsf(gb[i])));
   const float step1 = step / (block_max(v, red) + tiny);
   const float qlast = ql[M - 1];
-  for (int i = threadIdx.x; i < M; i += kThreads) {
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
     qlOut[i] = ql[i] - step1 * gd[i] * ql[i];
     qlOut[M + i] = ql[M + i] - step1 * (gd[i] * ql[M + i] + qlast * gb[i]);
   }
 }
 
 // new_qr = qr - step2 g2 qr, step2 = step / (max|g2| + tiny)                          (psgd.py:305-307); one block
-__global__ __launch_bounds__(kThreads) void k_scale_finalize(const float* __restrict__ qr, const float* __restrict__ g2,
-                                                             int N, float step, float tiny, float* qrOut) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(kFinThreads) void k_scale_finalize(const float* __restrict__ qr, const float* __restrict__ g2,
+                                                                int N, float step, float tiny, float* qrOut) {
+  __shared__ float red[16];
   float v = 0.0f;
-  for (int i = threadIdx.x; i < N; i += kThreads) v = nmaxf(v, fabsf(g2[i]));
+  for (int i = threadIdx.x; i < N; i += blockDim.x) v = nmaxf(v, fabsf(g2[i]));
   const float step2 = step / (block_max(v, red) + tiny);
-  for (int i = threadIdx.x; i < N; i += kThreads) qrOut[i] = qr[i] - step2 * g2[i] * qr[i];
+  for (int i = threadIdx.x; i < N; i += blockDim.x) qrOut[i] = qr[i] - step2 * g2[i] * qr[i];
 }
 
 // rho = sqrt(max L / max R) over the "diagonals" of the two factors (a dense factor: stride n+1; a
 // normalization factor: its first row; a scaling factor: itself); Lout = L / rho, Rout = rho R.
 // (psgd.py:211-215, 288-292, 342-346)
-__global__ __launch_bounds__(kThreads) void k_balance_generic(const float* __restrict__ L, long l_stride, int l_cnt,
-                                                              long l_tot, const float* __restrict__ R, long r_stride,
-                                                              int r_cnt, long r_tot, float* Lout, float* Rout) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(kFinThreads) void k_balance_generic(const float* __restrict__ L, long l_stride, int l_cnt,
+                                                                 long l_tot, const float* __restrict__ R, long r_stride,
+                                                                 int r_cnt, long r_tot, float* Lout, float* Rout) {
+  __shared__ float red[16];
   float ml = -INFINITY, mr = -INFINITY;
-  for (int i = threadIdx.x; i < l_cnt; i += kThreads) ml = nmaxf(ml, L[i * l_stride]);
-  for (int i = threadIdx.x; i < r_cnt; i += kThreads) mr = nmaxf(mr, R[i * r_stride]);
+  for (int i = threadIdx.x; i < l_cnt; i += blockDim.x) ml = nmaxf(ml, L[i * l_stride]);
+  for (int i = threadIdx.x; i < r_cnt; i += blockDim.x) mr = nmaxf(mr, R[i * r_stride]);
   ml = block_max(ml, red);
   mr = block_max(mr, red);
   const float rho = sqrtf(ml / mr);
-  const long tid = (long)blockIdx.x * kThreads + threadIdx.x, nth = (long)gridDim.x * kThreads;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
   for (long i = tid; i < l_tot; i += nth) Lout[i] = L[i] / rho;
   for (long i = tid; i < r_tot; i += nth) Rout[i] = rho * R[i];
 }
@@ -2857,6 +2865,11 @@ static inline int ew_grid(long tot) {
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
+#define SP_LAUNCH_WIDE(kernel, ...)   /* one block of kFinThreads */                \
+  do {                                                                          \
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(kFinThreads), 0, st, __VA_ARGS__); \
+    if (hipGetLastError() != hipSuccess) return PSGD_ERR_LAUNCH;                \
+  } while (0)
 #define SP_LAUNCH(kernel, grid, ...)                                            \
   do {                                                                          \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, st, __VA_ARGS__); \
@@ -2912,7 +2925,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
     g.epi = EPI_D_MINUS; g.D = k.LS; g.ldd = M; g.scale_max = k.scal; g.step = step; g.tiny = tiny;
     KRON_LAUNCH(launch_gemm(g, st));
   }
-  SP_LAUNCH(k_scale_finalize, 1, k.RS, k.v0, N, step, tiny, qrOut);
+  SP_LAUNCH_WIDE(k_scale_finalize, k.RS, k.v0, N, step, tiny, qrOut);
   return PSGD_OK;
 }
 
@@ -2968,7 +2981,7 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
   KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), st));   // A = T QrS'  (:220)
   KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.T, M, (long)N, 1L, k.dinv, st));                    // Bt QrS^-1 -> T   (:233)
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.T, M, N, k.v1, k.v2);    // (:235-237)
-  SP_LAUNCH(k_norm_finalize, 1, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
+  SP_LAUNCH_WIDE(k_norm_finalize, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
   if (k.P0 && g_planes && g_gemm_x3) {                       // grad2 = triu(A'A - Bt'Bt)     (:243): few tiles, long K
     KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.T, 1L, (long)N, N, M, k.gsq, k.scal, st));
   } else {
@@ -3017,14 +3030,14 @@ int psgd_kron_ns_update_f32(const float* ql, const float* qr, const float* dX, c
   const int rc = sparse_open(2, M, N, ws, ws_bytes, &k);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  SP_LAUNCH(k_balance_generic, 1, ql, 1L, M, (long)2 * M, qr, 1L, N, (long)N, k.LS, k.RS);
+  SP_LAUNCH_WIDE(k_balance_generic, ql, 1L, M, (long)2 * M, qr, 1L, N, (long)N, k.LS, k.RS);
   int e = norm_left_pair(k, dX, dG, xrs, xcs, M, N, k.RS, k.A, k.Bt, st);          // (:349-356)
   if (e) return e;
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.Bt, M, N, k.v1, k.v2);   // (:358-360)
-  SP_LAUNCH(k_norm_finalize, 1, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
+  SP_LAUNCH_WIDE(k_norm_finalize, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
   MatView a = {k.A, N, 1}, b = {k.Bt, N, 1};
   if (col_reduce(k, a, b, nullptr, nullptr, M, N, 2, k.v3, st)) return PSGD_ERR_LAUNCH;                  // (:366)
-  SP_LAUNCH(k_scale_finalize, 1, (const float*)k.RS, (const float*)k.v3, N, step, tiny, qrOut);
+  SP_LAUNCH_WIDE(k_scale_finalize, (const float*)k.RS, (const float*)k.v3, N, step, tiny, qrOut);
   return PSGD_OK;
 }
 
