@@ -76,6 +76,43 @@ def fuzz_kron_bf16_update(g, it):
     return "kron-bf16-upd %dx%d" % (M, N), max(e_inc, 100.0 * e_fac), 2e-2
 
 
+_SPARSE_KINDS = (("dense", "norm"), ("dense", "scale"), ("norm", "dense"), ("norm", "scale"), ("scale", "dense"), ("scale", "norm"))
+
+
+def fuzz_kron_sparse(g, it):
+    """The six sparse dispatch formats (psgd.py:80-152) on random shapes, incl. embedding-like ones (a long non-dense side:
+    row-blocked column reductions, split-K gradient), against the numpy fp64 oracle."""
+    import numpy as np
+    from oracle import psgd_oracle as orc
+    kl, kr = _SPARSE_KINDS[int(torch.randint(0, 6, (1,), generator=g, device=dev))]
+    long_side = it % 3 == 0
+
+    def dim(kind):
+        hi = 700 if kind == "dense" else (9000 if long_side else 400)
+        return int(torch.randint(3, hi, (1,), generator=g, device=dev))       # (below 3 the shapes of the three kinds coincide)
+    M, N = dim(kl), dim(kr)
+
+    def fac(kind, n):
+        if kind == "dense":
+            return tri(n, g, 0.5 / n ** 0.5) * 1.3
+        if kind == "norm":
+            q = torch.stack([torch.exp(0.2 * torch.randn(n, device=dev, generator=g)), 0.1 * torch.randn(n, device=dev, generator=g)])
+            q[1, -1] = 0.0
+            return q
+        return torch.exp(0.2 * torch.randn(1, n, device=dev, generator=g))
+    Ql, Qr = fac(kl, M), fac(kr, N)
+    dX = torch.randn(M, N, device=dev, generator=g)
+    dG = torch.exp(torch.empty(M, 1, device=dev).uniform_(-1, 1, generator=g)) * dX * torch.exp(torch.empty(1, N, device=dev).uniform_(-1, 1, generator=g))
+    G = torch.randn(M, N, device=dev, generator=g)
+    n64 = lambda t: t.cpu().numpy().astype(np.float64)
+    out = psgd.precond_grad_kron(Ql, Qr, G)
+    e1 = rel(out, torch.from_numpy(orc.precond_grad_kron(n64(Ql), n64(Qr), n64(G))).to(dev))
+    a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    a64, b64 = orc.update_precond_kron(n64(Ql), n64(Qr), n64(dX), n64(dG), 0.01)
+    e2 = max(rel(a, torch.from_numpy(a64).to(dev)), rel(b, torch.from_numpy(b64).to(dev)))
+    return "kron-sparse %s(x)%s %dx%d" % (kl, kr, M, N), max(e1, e2), 3e-5
+
+
 def fuzz_uvd(g, it):
     r = int(torch.randint(1, 33, (1,), generator=g, device=dev))
     if it % 15 == 3:                                  # wide rank: column chunks (uvd_wide.py)
@@ -138,7 +175,7 @@ def fuzz_splu(g, it):
 def run(budget, seed=1):
     _lib.load()
     g = torch.Generator(device=dev).manual_seed(seed)
-    fams = [fuzz_kron, fuzz_kron_bf16, fuzz_kron_bf16_update, fuzz_uvd, fuzz_splu]
+    fams = [fuzz_kron, fuzz_kron_bf16, fuzz_kron_bf16_update, fuzz_uvd, fuzz_splu, fuzz_kron_sparse]
     t0, it, worst, bad = time.time(), 0, {}, []
     while time.time() - t0 < budget:
         f = fams[it % len(fams)]
