@@ -1974,7 +1974,8 @@ static inline long kron_t128(int M, int N) { return (long)((M + 127) / 128) * ((
 static inline bool kron_planes_apply(int M, int N) {
   if (kron_planes_old()) return M >= 1024 && N >= 1024;
   const long t = kron_t128(M, N);
-  const bool aligned = M % 128 == 0 && N % 128 == 0;
+  static const int ignore_aligned = getenv("PSGD_KRON_PLANES_ALIGNED") ? 1 : 0;       // (A/B runs)
+  const bool aligned = !ignore_aligned && M % 128 == 0 && N % 128 == 0;
   return t >= 64 || ((M > N ? M : N) >= 600 && t >= 12 && !aligned);
 }
 static inline bool kron_planes(int M, int N) {          // the update, and the workspace
