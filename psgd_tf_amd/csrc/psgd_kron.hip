@@ -920,6 +920,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk(P3Args g, int T,
   p3_body(g, r, c, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
 }
 
+// The same for any product (all tiles, in the usual tile order): shapes with few output tiles -- a 128 x 4096 apply is one
+// row of 32 tiles, each a chain of 128 K steps -- leave most of the chip idle and are bound by that chain.
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk_rect(P3Args g, int ty, int tx, int nchunk, float* scratch,
+                                                                     unsigned* cnt) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  int by, bx;
+  gemm_tile_from_id(t, ty, tx, g.e.kmode, by, bx);
+  p3_body(g, by, bx, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
+}
+
 // fp32 view X(r, c) = X[r * rs + c * cs], r < R, c < C  ->  planes with x = r, k = c (zeros outside R x C; the grid covers
 // the padded extents) and, optionally, the planes of the transposed view (x = c, k = r) from the same read.  64 x 64
 // tiles through LDS so that the read (along the view's contiguous dimension) and both writes are coalesced.
@@ -1951,10 +1962,12 @@ struct KronWs {
   __bf16 *PP, *F1, *F2, *Y0, *Y1, *Y2;     // operand planes of the large apply (kron_planes): Gram, factor, its transpose; 3 transients
   __bf16 *Lr, *Lc, *Rr, *Rc, *G1, *G2, *U0, *U1, *U2, *U3;   // ... of the large update: balanced factors (both forms), gradients, 4 transients
   float* split_scratch; unsigned* split_cnt;                 // K-split tail of the gradient grid (k_gemm_p3_grad)
+  float* sk_scratch; unsigned* sk_cnt;                       // split-K of products with few output tiles (launch_p3_auto)
   __bf16* S0;                                                // planes of one [max(M, N) x 2048] group of the solves
   int64_t total;
 };
 
+constexpr int kSkMaxTiles = 160, kSkItems = 512;         // split-K of few-tile products: at most 512 partial tiles in flight
 constexpr int kGradSplitMax = 256, kGradChunks = 8;      // K-split tail of the gradient grid: at most 256 tiles in 8 chunks each
 // Large applies run on pre-split operand planes (k_gemm_p3).  A pure function of the shape: the workspace layout follows it.
 // Which shapes run on operand planes (pure functions of the shape: the workspace layout follows them).  Measured
@@ -1998,6 +2011,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.PP = k.F1 = k.F2 = k.Y0 = k.Y1 = k.Y2 = nullptr;
   k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
   k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
+  k.sk_scratch = nullptr; k.sk_cnt = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -2012,6 +2026,10 @@ static KronWs kron_layout(char* base, int M, int N) {
       k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
     }
     k.S0 = planes(big * 2048);
+    if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
+      k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
+      k.sk_cnt = reinterpret_cast<unsigned*>(take(kSkMaxTiles * 4));
+    }
   }
   k.total = off;
   return k;
@@ -2205,6 +2223,23 @@ static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = 
 
 static int launch_p3(const P3Args& g, hipStream_t st) {
   hipLaunchKernelGGL(k_gemm_p3, dim3((g.e.N + 127) / 128, (g.e.M + 127) / 128), dim3(kThreads), 0, st, g);
+  return (int)hipGetLastError();
+}
+
+// launch_p3, or the K range of every tile dealt to several blocks when the product has few output tiles and a K worth
+// splitting (scratch, cnt: KronWs::sk_*; null = never split)
+static int g_splitk = 1;        // tuning key 8: 0 = no split-K of few-tile products
+static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStream_t st) {
+  const int tx = (g.e.N + 127) / 128, ty = (g.e.M + 127) / 128, tiles = tx * ty, steps = (g.e.K + 31) / 32;
+  // Measured (tools/kron_splitk_ab.py): the partial tiles cost 64 KiB of traffic each way per item, so the split only pays for
+  // a tile or two of rows with a long K (64 x 8192 apply 0.78 -> 0.51 ms, 130 x 5000 0.44 -> 0.38); at 1000^2 it doubles
+  // the time.  Hence: K >= 4096, at most 80 tiles, at least 32 K steps per block.
+  int nchunk = (!g_splitk || !scratch || g.e.A2 || g.e.sym || tiles > 80 || steps < 128) ? 1 : kSkItems / tiles;
+  if (nchunk > 8) nchunk = 8;
+  while (nchunk > 1 && steps / nchunk < 32) --nchunk;
+  if (nchunk <= 1) return launch_p3(g, st);
+  if (hipMemsetAsync(cnt, 0, (size_t)tiles * 4, st) != hipSuccess) return 1;
+  hipLaunchKernelGGL(k_gemm_p3_splitk_rect, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
   return (int)hipGetLastError();
 }
 
@@ -2420,26 +2455,26 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
     if ((e = launch_split3(G, 1, N, N, M, Gt, st))) return e;                            // (n, k = m) = G[m][n]
     P3Args g0 = p3_args(PP, Gt, M, N, M, 0);                                             // (Ql'Ql) G
     p3_out_row(g0, T);
-    if ((e = launch_p3(g0, st))) return e;
+    if ((e = launch_p3_auto(g0, k.sk_scratch, k.sk_cnt, st))) return e;
     P3Args g1 = p3_args(T, F1, M, N, N, KLO_N);                                          // (.) Qr'
     p3_out_row(g1, A);
-    if ((e = launch_p3(g1, st))) return e;
+    if ((e = launch_p3_auto(g1, k.sk_scratch, k.sk_cnt, st))) return e;
     P3Args g2 = p3_args(A, F2, M, N, N, KHI_N);                                          // (.) Qr
     g2.e.C = out; g2.e.ldc = N;
-    return launch_p3(g2, st);
+    return launch_p3_auto(g2, k.sk_scratch, k.sk_cnt, st);
   }
   const P3Buf PP = {k.PP, Np, Np}, F1 = {k.F1, Mp, Mp}, F2 = {k.F2, Mp, Mp};
   const P3Buf Gp = {k.Y0, Mp, Np}, Tt = {k.Y1, Np, Mp}, At = {k.Y2, Np, Mp};
   if ((e = launch_split3(G, N, 1, M, N, Gp, st))) return e;
   P3Args g0 = p3_args(Gp, PP, M, N, N, 0);                                               // G (Qr'Qr)
   p3_out_col(g0, Tt);
-  if ((e = launch_p3(g0, st))) return e;
+  if ((e = launch_p3_auto(g0, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args g1 = p3_args(F1, Tt, M, N, M, KLO_M);                                           // Ql (.)
   p3_out_col(g1, At);
-  if ((e = launch_p3(g1, st))) return e;
+  if ((e = launch_p3_auto(g1, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args g2 = p3_args(F2, At, M, N, M, KHI_M);                                           // Ql' (.)
   g2.e.C = out; g2.e.ldc = N;
-  return launch_p3(g2, st);
+  return launch_p3_auto(g2, k.sk_scratch, k.sk_cnt, st);
 }
 
 // The GEMM stages of plan_update on planes (same products and K ranges; the solves stay on the fp32 kernels):
@@ -2526,6 +2561,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 4) { g_planes = value; return PSGD_OK; }
   if (key == 5) { g_trsm_group = value; return PSGD_OK; }
   if (key == 6) { g_grad_split = value; return PSGD_OK; }
+  if (key == 8) { g_splitk = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

@@ -434,7 +434,8 @@ def test_large_apply_on_operand_planes(psgd, M, N):
             outs.append(out)
     finally:
         lib.psgd_kron_set_tuning(4, 1)
-    assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-6
+    # (same products; a few-tile shape with a long K -- 8200 x 70 -- sums its K range in chunks on the planes path)
+    assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 3e-6
 
 
 def test_gradient_grid_k_split_is_deterministic_and_equivalent(psgd):
