@@ -351,7 +351,8 @@ int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
 /* Experiment knob (not stable ABI). key 0: bf16 GEMM variant: 0 auto (256^2 8-phase kernel for large dense
  * products, fused triangular pair when every 256^2 tile gets its own CU, 128^2 register-staged otherwise);
  * 1 128^2 register-staged everywhere; 2 128^2 LDS-DMA ring; 3 256^2 for every product; 4 auto without the fused pair.
- * key 1: 1 (default) two fused triangular pairs, (G Qr') Qr then Ql' (Ql .), where legal; 0 keep the Gram-first chain.
+ * key 1: 1 (default) two fused triangular pairs, (G Qr') Qr then Ql' (Ql .), where legal (M, N multiples of 256 and at
+ *        least 16 tiles of 256^2; the Python side pads the apply to such shapes when that costs <= 20 %); 0 keep the Gram-first chain.
  * key 2: log2 of the hand-off poll bound of the fused pair (default 22 ~ 0.5 s; tests set 0 to provoke time-outs).
  * key 3: bf16-operand update: 1 (default) the trailing products of its two triangular solves keep the three leading
  *        terms of the bf16 x 3 split (h h' + h m' + m h': 2^-16 relative per product, below the bf16 rounding of the

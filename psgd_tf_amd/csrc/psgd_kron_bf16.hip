@@ -28,6 +28,7 @@
 //   k_to_bf16             generic convert / transpose (gradient operand of the staged chain)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "psgd_hip.h"
 #include "kron_shared.h"
 #include "nanmax.h"
@@ -979,9 +980,11 @@ static bool pair_legal(int M, int N) {
   if (g_hgemm_variant != 0) return false;
   if ((M % T2) || (N % T2)) return false;
   const int tiles = (M / T2) * (N / T2);
-  // a launch takes whole tile columns (hand-offs stay inside a column) and must be fully resident, one block per CU;
-  // below ~128 tiles the 128^2 kernels have more parallelism
-  return tiles >= 128 && (M / T2) <= device_cu_count();
+  // a launch takes whole tile columns (hand-offs stay inside a column) and must be fully resident, one block per CU
+  // Round 2 (tools/bf16_pair_min_ab.py): the fused pairs win from 16 tiles on (2560^2 0.21 -> 0.16 ms, 1024 x 2048 0.136 ->
+  // 0.111, 256 x 4096 0.171 -> 0.133; equal at 1024^2, slower at 768^2 and below); round 1 had put the threshold at 128.
+  static const int min_tiles = getenv("PSGD_BF16_PAIR_MIN_TILES") ? atoi(getenv("PSGD_BF16_PAIR_MIN_TILES")) : 16;   // (env: A/B runs)
+  return tiles >= min_tiles && (M / T2) <= device_cu_count();
 }
 
 // Q, Qt: the triangular factor and its transpose (dimension Mk); B1: the other operand [Nk][Mk]; T3: [Nk][Mk] hand-off

@@ -118,14 +118,14 @@ def _pad8(n):
 
 
 def _bf16_pad_shape(M, N, apply):
-    """Padded extents of a bf16-operand problem.  Multiples of 8 always (16-byte chunks along every K axis).  The apply of
-    large shapes goes up to multiples of 256: only then do the 256 x 256 kernels (fused triangular pairs, 8-phase dense
-    kernel) take it, and they are up to 1.5x faster than the guarded 128-tile kernels on the unpadded shape (2500^2:
-    0.30 -> 0.2 ms; tools/kron_shape_scan.py) -- as long as the padding adds at most a fifth to the elements."""
+    """Padded extents of a bf16-operand problem.  Multiples of 8 always (16-byte chunks along every K axis).  The apply
+    goes up to multiples of 256 when that makes at least 16 tiles of 256 x 256 and adds at most a fifth to the elements:
+    only then do the 256 x 256 kernels (fused triangular pairs, 8-phase dense kernel) take it, and they are up to 1.5x
+    faster than the guarded 128-tile kernels on the unpadded shape (2500^2: 0.30 -> 0.17 ms; tools/kron_shape_scan.py)."""
     Mp, Np = _pad8(M), _pad8(N)
-    if apply and min(M, N) >= 1024:
+    if apply:
         M2, N2 = (M + 255) // 256 * 256, (N + 255) // 256 * 256
-        if M2 * N2 <= 1.2 * M * N:
+        if (M2 // 256) * (N2 // 256) >= 16 and M2 * N2 <= 1.2 * M * N:      # (the 256-tile pairs take >= 16 tiles)
             Mp, Np = M2, N2
     return Mp, Np
 
