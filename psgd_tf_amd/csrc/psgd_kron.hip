@@ -1989,7 +1989,8 @@ static inline bool kron_planes_apply(int M, int N) {
   const long t = kron_t128(M, N);
   static const int ignore_aligned = getenv("PSGD_KRON_PLANES_ALIGNED") ? 1 : 0;       // (A/B runs)
   const bool aligned = !ignore_aligned && M % 128 == 0 && N % 128 == 0;
-  return t >= 64 || ((M > N ? M : N) >= 600 && t >= 12 && !aligned);
+  const int mx = M > N ? M : N;
+  return t >= 64 || (mx >= 600 && t >= 12 && (!aligned || mx >= 2048));    // (aligned and long: 384 x 2048 0.24 -> 0.21 ms)
 }
 static inline bool kron_planes(int M, int N) {          // the update, and the workspace
   if (kron_planes_old()) return M >= 1024 && N >= 1024;
