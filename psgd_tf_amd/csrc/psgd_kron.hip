@@ -2233,9 +2233,11 @@ static int g_splitk = 1;        // tuning key 8: 0 = no split-K of few-tile prod
 static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStream_t st) {
   const int tx = (g.e.N + 127) / 128, ty = (g.e.M + 127) / 128, tiles = tx * ty, steps = (g.e.K + 31) / 32;
   // Measured (tools/kron_splitk_ab.py): the partial tiles cost 64 KiB of traffic each way per item, so the split only pays for
-  // a tile or two of rows with a long K (64 x 8192 apply 0.78 -> 0.51 ms, 130 x 5000 0.44 -> 0.38); at 1000^2 it doubles
-  // the time.  Hence: K >= 4096, at most 80 tiles, at least 32 K steps per block.
-  int nchunk = (!g_splitk || !scratch || g.e.A2 || g.e.sym || tiles > 80 || steps < 128) ? 1 : kSkItems / tiles;
+  // a tile or two of rows with a long K (64 x 8192 apply 0.78 -> 0.51 ms, 128 x 4096 0.44 -> 0.18, 200 x 3072 0.29 -> 0.18,
+  // 2048 x 256 0.20 -> 0.15); at 1000^2, in chunks of 4 K steps, it doubles the time.  Hence: K >= 2048, at most 80 tiles,
+  // at least 32 K steps per block.
+  static const int min_steps = getenv("PSGD_SPLITK_MIN_STEPS") ? atoi(getenv("PSGD_SPLITK_MIN_STEPS")) : 64;    // (env: A/B runs)
+  int nchunk = (!g_splitk || !scratch || g.e.A2 || g.e.sym || tiles > 80 || steps < min_steps) ? 1 : kSkItems / tiles;
   if (nchunk > 8) nchunk = 8;
   while (nchunk > 1 && steps / nchunk < 32) --nchunk;
   if (nchunk <= 1) return launch_p3(g, st);
