@@ -2236,10 +2236,15 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
   // a tile or two of rows with a long K (64 x 8192 apply 0.78 -> 0.51 ms, 128 x 4096 0.44 -> 0.18, 200 x 3072 0.29 -> 0.18,
   // 2048 x 256 0.20 -> 0.15); at 1000^2, in chunks of 4 K steps, it doubles the time.  Hence: K >= 2048, at most 80 tiles,
   // at least 32 K steps per block.
-  static const int min_steps = getenv("PSGD_SPLITK_MIN_STEPS") ? atoi(getenv("PSGD_SPLITK_MIN_STEPS")) : 64;    // (env: A/B runs)
+  // Up to 44 tiles and short K (200 x 1700, 384 x 1300) chunks of 16 K steps still pay (0.175 -> 0.129 ms); from there to 80
+  // tiles they do not (1000^2: 0.156 -> 0.195 with chunks of 16), chunks of 32 from K = 2048 on do.
+  static const int env_steps = getenv("PSGD_SPLITK_MIN_STEPS") ? atoi(getenv("PSGD_SPLITK_MIN_STEPS")) : 0;     // (env: A/B runs)
+  static const int env_chunk = getenv("PSGD_SPLITK_CHUNK") ? atoi(getenv("PSGD_SPLITK_CHUNK")) : 0;
+  const int min_steps = env_steps ? env_steps : (tiles <= 44 ? 32 : 64);
+  const int min_chunk = env_chunk ? env_chunk : ((tiles <= 44 && steps < 72) ? 16 : 32);   // (128 x 4096: 4 chunks of 32 beat 8 of 16)
   int nchunk = (!g_splitk || !scratch || g.e.A2 || g.e.sym || tiles > 80 || steps < min_steps) ? 1 : kSkItems / tiles;
   if (nchunk > 8) nchunk = 8;
-  while (nchunk > 1 && steps / nchunk < 32) --nchunk;
+  while (nchunk > 1 && steps / nchunk < min_chunk) --nchunk;
   if (nchunk <= 1) return launch_p3(g, st);
   if (hipMemsetAsync(cnt, 0, (size_t)tiles * 4, st) != hipSuccess) return 1;
   hipLaunchKernelGGL(k_gemm_p3_splitk_rect, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);

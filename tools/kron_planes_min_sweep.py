@@ -15,6 +15,9 @@ if __name__ == "__main__":
     if os.environ.get("MID"):
         shapes = ((384, 700), (500, 500), (500, 700), (700, 700), (384, 1000), (500, 1000), (700, 1000), (384, 1300), (500, 1300),
                   (384, 1700), (500, 1700), (200, 1700), (384, 2500), (200, 2500), (200, 3072), (256, 1024), (300, 300))
+    if os.environ.get("SPLITK2"):
+        shapes = ((500, 1700), (1000, 1000), (384, 1300), (700, 1000), (500, 1300), (384, 1700), (1024, 1024), (200, 1700), (900, 1400),
+                  (640, 1280), (1300, 500))
     if os.environ.get("SPLITK"):
         shapes = ((200, 3072), (384, 2500), (200, 2500), (256, 2048), (384, 2048), (130, 3000), (100, 2100), (500, 1700), (64, 2048),
                   (128, 4096), (3072, 200), (2048, 256))
