@@ -2501,10 +2501,10 @@ static int planes_update_front(const float* dG, int M, int N, const KronWs& k, h
   if ((e = launch_split3(dG, N, 1, M, N, dGp, st))) return e;
   P3Args s0 = p3_args(dGp, Rr, M, N, N, KLO_N);                 // T = dG QrS'  (:173); (n, k) view of QrS' = QrS
   p3_out_col(s0, Tt);
-  if ((e = launch_p3(s0, st))) return e;
+  if ((e = launch_p3_auto(s0, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args s1 = p3_args(Lr, Tt, M, N, M, KLO_M);                  // A = QlS T
   p3_out_row(s1, Ar); p3_out_col(s1, Ac);
-  return launch_p3(s1, st);
+  return launch_p3_auto(s1, k.sk_scratch, k.sk_cnt, st);
 }
 
 static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float step, float tiny, const KronWs& k, hipStream_t st) {
