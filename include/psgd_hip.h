@@ -261,8 +261,9 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  *        tile.  (PSGD_KRON_PLANES_OLD=1 in the environment restores the first rule, M, N >= 1024, for A/B runs.)
  * key 5: blocked triangular solves: 512-column strips per group (a finished group updates the columns to its right in
  *        one product with K = 512 * group); 0 (default) = 4 from n = 4096 on, else 1.
- * key 8: plane products of an apply with at most 80 output tiles and K >= 2048 (one or two tile rows, e.g. 64 x 8192):
- *        1 (default) every tile's K range is dealt to up to 8 blocks (partials summed in chunk order); 0 = one block per tile.
+ * key 8: plane products with few output tiles (at most 80 and K >= 2048, or at most 44 and K >= 1024; e.g. 64 x 8192,
+ *        200 x 1700): 1 (default) every tile's K range is dealt to up to 8 blocks (partials summed in chunk order);
+ *        0 = one block per tile.
  * key 6: large fp32 update, M = N: 1 (default) the last tiles of the gradient grid are split along K over the block
  *        slots a short last round would leave idle (partials summed in a fixed order by the last block to arrive). */
 int psgd_kron_set_tuning(int key, int value);
