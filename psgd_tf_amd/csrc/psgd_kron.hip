@@ -73,30 +73,29 @@ struct TileSrc {
   int X;                         // extent along x
 };
 
-template <int T, int GK>
-__device__ __forceinline__ int tile_mode(const TileSrc& t, int x0, int k0, int khi) {
-  const bool interior = (x0 + T <= t.X) && (k0 + GK <= khi);
-  const bool aligned = (reinterpret_cast<uintptr_t>(t.P) & 15) == 0;
-  if (interior && aligned && t.cs == 1 && (t.rs & 3) == 0) return 1;   // K-contiguous, float4 along k
-  if (interior && aligned && t.rs == 1 && (t.cs & 3) == 0) return 2;   // X-contiguous, float4 along x
-  return 0;
-}
+// Fetch modes of an operand tile (x, k), compile-time per K loop (see f32_pass; the same reasons as in the split GEMM further
+// down: a branch between load variants inside the K loop makes the compiler wait for every outstanding load at the join,
+// which put A's memory latency in front of B's loads and both in front of the MFMAs -- ~3 us per K tile):
+//   F32_KVEC  K-contiguous (cs == 1, 16-byte aligned rows): float4 along k; rows past the operand are CLAMPED to the last
+//             one and zeroed at the commit, so blocks at the x edge stay on this mode;
+//   F32_XVEC  X-contiguous (rs == 1), block inside the operand: float4 along x;
+//   F32_ANY   anything else and ragged K tails: scalar loads from clamped addresses, zeroed at the commit.
+// Nothing in g2r_* uses a loaded value.
+enum { F32_ANY = 0, F32_KVEC = 1, F32_XVEC = 2 };
 
-template <int T, int GK>
-__device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int khi,      // loads only: any use of a value
-                                         float (&r)[T * GK / kThreads]) {                 // here stalls ahead of the MFMAs
+template <int T, int GK, int MODE>
+__device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int khi, float (&r)[T * GK / kThreads]) {
   const int tid = threadIdx.x;
   constexpr int NV = T * GK / (4 * kThreads);   // float4 per thread
-  const int mode = tile_mode<T, GK>(t, x0, k0, khi);
-  if (mode == 1) {
+  if (MODE == F32_KVEC) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int f = tid + kThreads * u, row = f / (GK / 4), k4 = f % (GK / 4);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(t.P + (long)(x0 + row) * t.rs + k0 + 4 * k4);
+      const int f = tid + kThreads * u, row = min(x0 + f / (GK / 4), t.X - 1), k4 = f % (GK / 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(t.P + (long)row * t.rs + k0 + 4 * k4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[4 * u + e] = v[e];
     }
-  } else if (mode == 2) {
+  } else if (MODE == F32_XVEC) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int f = tid + kThreads * u, k = f / (T / 4), x4 = f % (T / 4);
@@ -110,26 +109,25 @@ __device__ __forceinline__ void g2r_tile(const TileSrc& t, int x0, int k0, int k
       const int e = tid + kThreads * u;
       int x, k;
       if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % T; k = e / T; }
-      const int gx = x0 + x, gk = k0 + k;
-      r[u] = (gx < t.X && gk < khi) ? t.P[(long)gx * t.rs + (long)gk * t.cs] : 0.0f;
+      r[u] = t.P[(long)min(x0 + x, t.X - 1) * t.rs + (long)min(k0 + k, khi - 1) * t.cs];
     }
   }
 }
 
-template <int T, int GK>
+template <int T, int GK, int MODE>
 __device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int khi, float mul,
                                          const float (&r)[T * GK / kThreads], float (*S)[T + 16]) {
   const int tid = threadIdx.x;
   constexpr int NV = T * GK / (4 * kThreads);
-  const int mode = tile_mode<T, GK>(t, x0, k0, khi);
-  if (mode == 1) {
+  if (MODE == F32_KVEC) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int f = tid + kThreads * u, row = f / (GK / 4), k4 = f % (GK / 4);
+      const float m = (x0 + row < t.X) ? mul : 0.0f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S[4 * k4 + e][row] = r[4 * u + e] * mul;
+      for (int e = 0; e < 4; ++e) S[4 * k4 + e][row] = r[4 * u + e] * m;
     }
-  } else if (mode == 2) {
+  } else if (MODE == F32_XVEC) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int f = tid + kThreads * u, k = f / (T / 4), x4 = f % (T / 4);
@@ -141,9 +139,17 @@ __device__ __forceinline__ void r2s_tile(const TileSrc& t, int x0, int k0, int k
       const int e = tid + kThreads * u;
       int x, k;
       if (t.cs == 1) { k = e % GK; x = e / GK; } else { x = e % T; k = e / T; }
-      S[k][x] = r[u] * mul;
+      S[k][x] = (x0 + x < t.X && k0 + k < khi) ? r[u] * mul : 0.0f;
     }
   }
+}
+
+template <int T>
+__device__ __forceinline__ int f32_mode(const TileSrc& t, int x0) {
+  const bool aligned = (reinterpret_cast<uintptr_t>(t.P) & 15) == 0;
+  if (aligned && t.cs == 1 && (t.rs & 3) == 0) return F32_KVEC;
+  if (aligned && t.rs == 1 && (t.cs & 3) == 0 && x0 + T <= t.X) return F32_XVEC;
+  return F32_ANY;
 }
 
 template <int T, int GK>
@@ -260,64 +266,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x4 (&a
   }
 }
 
-template <int T, int GK>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, GemmLds<T, GK>& L) {
-  constexpr int W = T / 2, NT = T / 32;   // wave tile edge, MFMA tiles per wave edge
+// n K tiles [k0 + GK t, +GK) of one operand pair into acc (LDS double-buffered: one barrier per K tile).  Enters and leaves
+// with both LDS buffers free.
+template <int T, int GK, int MA, int MB>
+__device__ __forceinline__ void f32_pass(const TileSrc& ta, const TileSrc& tb, int m0, int n0, int k0, int khi, int n, float mul,
+                                         GemmLds<T, GK>& L, f32x4 (&acc)[T / 32][T / 32]) {
+  constexpr int W = T / 2, NT = T / 32;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1;
-  // upper-triangular outputs: tiles strictly below the diagonal are all zero
-  const bool tri_skip = (g.epi == EPI_TRIU_MAX || g.sym) && (m0 >= n0 + T);
-  if (g.sym && tri_skip) return;        // written by the mirror tile's epilogue (a triu tile below the diagonal stores zeros instead)
-
-  f32x4 acc[NT][NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  float a_mul = 1.0f;
-  if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
-
-  int klo[2] = {0, 0}, khi[2] = {0, 0}, nk[2] = {0, 0};
-  if (!tri_skip) {
-    for (int p = 0; p < 2; ++p) {
-      if (p == 1 && !g.A2) break;
-      const int K = p ? g.K2 : g.K, km = p ? g.kmode2 : g.kmode;
-      int lo = 0, hi = K;
-      if (km & KLO_M) lo = max(lo, m0);
-      if (km & KLO_N) lo = max(lo, n0);
-      if (km & KHI_M) hi = min(hi, m0 + T);
-      if (km & KHI_N) hi = min(hi, n0 + T);
-      lo = (lo / GK) * GK;
-      klo[p] = lo; khi[p] = hi; nk[p] = hi > lo ? (hi - lo + GK - 1) / GK : 0;
-    }
-  }
-  const int ntile = nk[0] + nk[1];
-  const TileSrc ta[2] = {{g.A, g.a_rs, g.a_cs, g.M}, {g.A2, g.a2_rs, g.a2_cs, g.M}};
-  const TileSrc tb[2] = {{g.B, g.b_cs, g.b_rs, g.N}, {g.B2, g.b2_cs, g.b2_rs, g.N}};   // (n, k) view of B
-
   float ra[T * GK / kThreads], rb[T * GK / kThreads];
-  auto fetch = [&](int t) {
-    const int p = t < nk[0] ? 0 : 1;
-    const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
-    g2r_tile<T, GK>(ta[p], m0, k0, khi[p], ra);
-    g2r_tile<T, GK>(tb[p], n0, k0, khi[p], rb);
-  };
-  auto commit = [&](int t, int buf) {
-    const int p = t < nk[0] ? 0 : 1;
-    const int k0 = klo[p] + (p ? t - nk[0] : t) * GK;
-    r2s_tile<T, GK>(ta[p], m0, k0, khi[p], p ? -a_mul : a_mul, ra, L.A[buf]);
-    r2s_tile<T, GK>(tb[p], n0, k0, khi[p], 1.0f, rb, L.B[buf]);
-  };
-
-  if (ntile > 0) {
-    fetch(0);
-    commit(0, 0);
-  }
+  g2r_tile<T, GK, MA>(ta, m0, k0, khi, ra);
+  g2r_tile<T, GK, MB>(tb, n0, k0, khi, rb);
+  r2s_tile<T, GK, MA>(ta, m0, k0, khi, mul, ra, L.A[0]);
+  r2s_tile<T, GK, MB>(tb, n0, k0, khi, 1.0f, rb, L.B[0]);
   __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
+  for (int t = 0; t < n; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntile) fetch(t + 1);
+    const int kn = k0 + min(t + 1, n - 1) * GK;          // the last iteration re-reads its own tile: no branch round the loads
+    g2r_tile<T, GK, MA>(ta, m0, kn, khi, ra);
+    g2r_tile<T, GK, MB>(tb, n0, kn, khi, rb);
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
       const int kr = kk * 4 + (lane >> 4);
@@ -331,10 +298,56 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, Gem
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < ntile) commit(t + 1, buf ^ 1);
+    if (t + 1 < n) {
+      r2s_tile<T, GK, MA>(ta, m0, kn, khi, mul, ra, L.A[buf ^ 1]);
+      r2s_tile<T, GK, MB>(tb, n0, kn, khi, 1.0f, rb, L.B[buf ^ 1]);
+    }
     __syncthreads();
   }
+}
 
+template <int T, int GK>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, int m0, int n0, GemmLds<T, GK>& L) {
+  constexpr int NT = T / 32;   // MFMA tiles per wave edge
+  // upper-triangular outputs: tiles strictly below the diagonal are all zero
+  const bool tri_skip = (g.epi == EPI_TRIU_MAX || g.sym) && (m0 >= n0 + T);
+  if (g.sym && tri_skip) return;        // written by the mirror tile's epilogue (a triu tile below the diagonal stores zeros instead)
+
+  f32x4 acc[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float a_mul = 1.0f;
+  if (g.scale_max) a_mul = g.step / (g.scale_max[0] + g.tiny);
+
+  // one operand pair at a time; the fetch modes are chosen once per block and pair, outside the K loops
+#pragma unroll 1
+  for (int p = 0; p < ((g.A2 && !tri_skip) ? 2 : (tri_skip ? 0 : 1)); ++p) {
+    const TileSrc ta = p ? TileSrc{g.A2, g.a2_rs, g.a2_cs, g.M} : TileSrc{g.A, g.a_rs, g.a_cs, g.M};
+    const TileSrc tb = p ? TileSrc{g.B2, g.b2_cs, g.b2_rs, g.N} : TileSrc{g.B, g.b_cs, g.b_rs, g.N};   // (n, k) view of B
+    const int K = p ? g.K2 : g.K, km = p ? g.kmode2 : g.kmode;
+    int lo = 0, hi = K;
+    if (km & KLO_M) lo = max(lo, m0);
+    if (km & KLO_N) lo = max(lo, n0);
+    if (km & KHI_M) hi = min(hi, m0 + T);
+    if (km & KHI_N) hi = min(hi, n0 + T);
+    lo = (lo / GK) * GK;
+    if (hi <= lo) continue;
+    const int ntot = (hi - lo + GK - 1) / GK, nfull = (hi - lo) / GK;
+    const float mul = p ? -a_mul : a_mul;
+    int ma = f32_mode<T>(ta, m0), mb = f32_mode<T>(tb, n0);
+    if (ma == F32_ANY || mb == F32_ANY) ma = mb = F32_ANY;
+    const int e0 = (ma == F32_ANY) ? 0 : nfull;         // first K tile of the scalar loop (everything, or the ragged tail)
+    if (e0 > 0) {
+      if (ma == F32_KVEC && mb == F32_KVEC) f32_pass<T, GK, F32_KVEC, F32_KVEC>(ta, tb, m0, n0, lo, hi, e0, mul, L, acc);
+      else if (ma == F32_KVEC) f32_pass<T, GK, F32_KVEC, F32_XVEC>(ta, tb, m0, n0, lo, hi, e0, mul, L, acc);
+      else if (mb == F32_KVEC) f32_pass<T, GK, F32_XVEC, F32_KVEC>(ta, tb, m0, n0, lo, hi, e0, mul, L, acc);
+      else f32_pass<T, GK, F32_XVEC, F32_XVEC>(ta, tb, m0, n0, lo, hi, e0, mul, L, acc);
+    }
+    if (ntot > e0) f32_pass<T, GK, F32_ANY, F32_ANY>(ta, tb, m0, n0, lo + e0 * GK, hi, ntot - e0, mul, L, acc);
+  }
   gemm_epilogue<T>(g, acc, m0, n0);
 }
 
@@ -987,10 +1000,10 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
   }
 }
 
-// T = 128: three resident blocks per CU (<= 170 registers): the 528 upper tiles of a 4096^2 triu product then run
-// as one wave of blocks instead of 512 + 16 (the second, nearly empty wave doubled those launches' time)
+// (T = 128 is the exact-fp32 alternative to the split GEMM, psgd_kron_set_tuning(1, 0): two resident blocks per CU; with the
+// K loops per fetch mode three blocks -- 168 registers -- would spill)
 template <int T, int GK>
-__global__ __launch_bounds__(kThreads, (T == 128 ? 3 : 1)) void k_gemm_f32(GemmArgs g) {
+__global__ __launch_bounds__(kThreads, (T == 128 ? 2 : 1)) void k_gemm_f32(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) GemmLds<T, GK> L;
   // longest-K tiles first (see the bf16 kernel): an upper K bound grows with the tile index
   int by, bx;
