@@ -265,7 +265,10 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  *        200 x 1700): 1 (default) every tile's K range is dealt to up to 8 blocks (partials summed in chunk order);
  *        0 = one block per tile.
  * key 6: large fp32 update, M = N: 1 (default) the last tiles of the gradient grid are split along K over the block
- *        slots a short last round would leave idle (partials summed in a fixed order by the last block to arrive). */
+ *        slots a short last round would leave idle (partials summed in a fixed order by the last block to arrive).
+ * key 7: batched update of small layers: 1 (default) each stage of the products dG QrS' -> QlS (.) (psgd.py:173) shares
+ *        its launch with the same stage of the solves (:174) -- the two chains only meet at the gradient pair; 0 = one
+ *        launch per stage of each chain. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

@@ -1690,36 +1690,6 @@ struct TrsmBatch {
   const float* dinv[kMaxBatch];
 };
 
-__global__ __launch_bounds__(64) void k_tri_inv32_batched(TrsmBatch b) {
-  int p = 0;
-  while (p + 1 < b.count && (int)blockIdx.x >= b.blk_end[p]) ++p;
-  const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
-  const TrsmArgs& t = b.t[p];
-  // same body as k_tri_inv32 for block `blk` of problem p
-  __shared__ float Qd[32][33];
-  const int lane = threadIdx.x, j0 = blk * 32;
-  for (int e = lane; e < 1024; e += 64) {
-    const int r = e >> 5, c = e & 31;
-    Qd[r][c] = (j0 + r < t.n && j0 + c < t.n) ? t.Q[(long)(j0 + r) * t.ldq + j0 + c] : (r == c ? 1.0f : 0.0f);
-  }
-  __syncthreads();
-  if (lane < 32) {
-    float rr[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) rr[j] = (j == lane) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const float y = rr[j] / Qd[j][j];
-      rr[j] = y;
-#pragma unroll
-      for (int j2 = j + 1; j2 < 32; ++j2) rr[j2] = fmaf(-y, Qd[j][j2], rr[j2]);
-    }
-    float* out = const_cast<float*>(b.dinv[p]) + (long)blk * 1024 + lane * 32;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) out[j] = rr[j];
-  }
-}
-
 __global__ __launch_bounds__(kThreads) void k_trsm_ut_inv_batched(TrsmBatch b, int pitch_max) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   int p = 0;
@@ -1739,17 +1709,49 @@ __global__ __launch_bounds__(kThreads) void k_trsm_ut_reg_batched(TrsmBatch b) {
 }
 
 
+// One stage of each of the two independent chains of the small-layer update in a single launch: the products
+// T = dG QrS' -> A = QlS T (:173) and the solves X1 = dX QrS^-1 -> Bt = QlS^-T X1 (:174) meet only at the gradient pair,
+// and either stage alone leaves most of the chip idle.  The solve strips come first in the grid (the longer bodies).
+struct MixBatch {
+  int count, strips;           // layers; total solve strips (blocks below `strips` solve, the rest multiply)
+  int blk_end[kMaxLayers];     // inclusive prefix sums of 16-vector strips
+  int tile_end[kMaxLayers];    // inclusive prefix sums of 32 x 32 output tiles
+  TrsmArgs t[kMaxLayers];
+  const float* dinv[kMaxLayers];
+  GemmArgs g[kMaxLayers];
+};
+
+__global__ __launch_bounds__(kThreads) void k_small_stage_mixed(MixBatch b) {
+  __shared__ __attribute__((aligned(16))) GemmLds<32, kSmallK> L;
+  __shared__ float Ybuf[2][512];
+  if ((int)blockIdx.x < b.strips) {
+    int p = 0;
+    while (p + 1 < b.count && (int)blockIdx.x >= b.blk_end[p]) ++p;
+    const int blk = blockIdx.x - (p ? b.blk_end[p - 1] : 0);
+    trsm_reg_body(b.t[p], b.dinv[p], blk * 16, Ybuf);
+    return;
+  }
+  const int id = blockIdx.x - b.strips;
+  int p = 0;
+  while (p + 1 < b.count && id >= b.tile_end[p]) ++p;
+  const int t = id - (p ? b.tile_end[p - 1] : 0);
+  const GemmArgs& g = b.g[p];
+  const int tn = (g.N + 31) / 32;
+  gemm_body_small(g, (t / tn) * 32, (t % tn) * 32, L);
+}
+
 // rho = sqrt(max diag Ql / max diag Qr); QlS = Ql / rho; QrS = rho Qr      (psgd.py:166-170)
 struct BalanceBatch {
   int count;
   const float* Ql[kMaxBatch]; const float* Qr[kMaxBatch];
   float* QlS[kMaxBatch]; float* QrS[kMaxBatch];
+  float* dinv[kMaxBatch];      // inverted 32 x 32 diagonal blocks: QrS's, then QlS's
   float* scal[kMaxBatch];      // the layer's 64 scratch words (max|grad| accumulators ...): zeroed here, one launch ahead
   int M[kMaxBatch], N[kMaxBatch];
 };
 
-__device__ __forceinline__ void balance_body(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
-                                             float* QlS, float* QrS, float (*red)[4]) {
+__device__ __forceinline__ float balance_rho(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
+                                             float (*red)[4]) {
   float ml = -INFINITY, mr = -INFINITY;
   for (int i = threadIdx.x; i < M; i += kThreads) ml = nmaxf(ml, Ql[(long)i * M + i]);
   for (int i = threadIdx.x; i < N; i += kThreads) mr = nmaxf(mr, Qr[(long)i * N + i]);
@@ -1763,9 +1765,14 @@ __device__ __forceinline__ void balance_body(const float* __restrict__ Ql, const
   __syncthreads();
   ml = nmaxf(nmaxf(red[0][0], red[0][1]), nmaxf(red[0][2], red[0][3]));
   mr = nmaxf(nmaxf(red[1][0], red[1][1]), nmaxf(red[1][2], red[1][3]));
-  const float rho = sqrtf(ml / mr);
+  return sqrtf(ml / mr);
+}
+
+__device__ __forceinline__ void balance_body(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
+                                             float* QlS, float* QrS, float (*red)[4], int bid, int nblocks) {
+  const float rho = balance_rho(Ql, Qr, M, N, red);
   const long nl = (long)M * M, nr = (long)N * N;
-  const long tid = (long)blockIdx.x * kThreads + threadIdx.x, nth = (long)gridDim.x * kThreads;
+  const long tid = (long)bid * kThreads + threadIdx.x, nth = (long)nblocks * kThreads;
   for (long i = tid; i < nl; i += nth) QlS[i] = Ql[i] / rho;
   for (long i = tid; i < nr; i += nth) QrS[i] = rho * Qr[i];
 }
@@ -1774,14 +1781,56 @@ __global__ __launch_bounds__(kThreads) void k_kron_balance(const float* __restri
                                                            int M, int N, float* QlS, float* QrS, float* scal) {
   __shared__ float red[2][4];
   if (scal && blockIdx.x == 0 && threadIdx.x < 64) scal[threadIdx.x] = 0.0f;   // max|grad| accumulators of the later stages
-  balance_body(Ql, Qr, M, N, QlS, QrS, red);
+  balance_body(Ql, Qr, M, N, QlS, QrS, red, blockIdx.x, gridDim.x);
 }
 
+// Row `lane` of the inverse of an upper-triangular 32 x 32 block held in LDS (lanes 0..31 of one wave).
+__device__ __forceinline__ void tri_inv32_rows(const float (*Qd)[33], int lane, float* out) {
+  float rr[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) rr[j] = (j == lane) ? 1.0f : 0.0f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float y = rr[j] / Qd[j][j];
+    rr[j] = y;
+#pragma unroll
+    for (int j2 = j + 1; j2 < 32; ++j2) rr[j2] = fmaf(-y, Qd[j][j2], rr[j2]);
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j) out[j] = rr[j];
+}
+
+// Blocks x < kBalInvBlocks of a layer invert the 32 x 32 diagonal blocks of the *balanced* factors (one block per wave;
+// the balanced entries are formed exactly as the other blocks store them), the rest write QlS / QrS: the inversion is
+// the longer of the two and needs nothing but rho, so it shares the launch instead of waiting behind two GEMM stages.
+constexpr int kBalInvBlocks = 8;    // 4 waves each: up to 32 diagonal blocks per layer (M, N <= 512)
 __global__ __launch_bounds__(kThreads) void k_kron_balance_batched(BalanceBatch b) {
   __shared__ float red[2][4];
+  __shared__ float Qd[4][32][33];
   const int p = blockIdx.y;
-  if (blockIdx.x == 0 && threadIdx.x < 64) b.scal[p][threadIdx.x] = 0.0f;
-  balance_body(b.Ql[p], b.Qr[p], b.M[p], b.N[p], b.QlS[p], b.QrS[p], red);
+  const int M = b.M[p], N = b.N[p];
+  if ((int)blockIdx.x >= kBalInvBlocks) {
+    if (blockIdx.x == kBalInvBlocks && threadIdx.x < 64) b.scal[p][threadIdx.x] = 0.0f;
+    balance_body(b.Ql[p], b.Qr[p], M, N, b.QlS[p], b.QrS[p], red, blockIdx.x - kBalInvBlocks, gridDim.x - kBalInvBlocks);
+    return;
+  }
+  const float rho = balance_rho(b.Ql[p], b.Qr[p], M, N, red);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nbr = (N + 31) / 32, nbl = (M + 31) / 32;
+  const int bi = blockIdx.x * 4 + w;          // diagonal blocks of QrS first, then those of QlS (layout of dinv)
+  const bool act = bi < nbr + nbl;
+  const bool left = bi >= nbr;
+  const float* __restrict__ Q = left ? b.Ql[p] : b.Qr[p];
+  const int n = left ? M : N, j0 = (left ? bi - nbr : bi) * 32;
+  if (act)
+    for (int e = lane; e < 1024; e += 64) {
+      const int r = e >> 5, c = e & 31;
+      const bool in = j0 + r < n && j0 + c < n;
+      const float q = Q[(long)min(j0 + r, n - 1) * n + min(j0 + c, n - 1)];
+      Qd[w][r][c] = in ? (left ? q / rho : rho * q) : (r == c ? 1.0f : 0.0f);
+    }
+  __syncthreads();
+  if (act && lane < 32) tri_inv32_rows(Qd[w], lane, b.dinv[p] + (long)bi * 1024 + lane * 32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2209,6 +2258,7 @@ __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long 
 }
 
 constexpr int kTrsmPlanesK = 2048;      // group width (4 strips) whose update runs on planes when the factor's planes exist
+static int g_stage_mix = 1;     // tuning key 7: 0 = batched small-layer update runs its products and solves as separate launches
 static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
 
 struct P3Buf { __bf16* p; long rows, ld; };          // planes of a matrix with padded extents x = rows, k = ld (multiples of 128)
@@ -2582,6 +2632,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 4) { g_planes = value; return PSGD_OK; }
   if (key == 5) { g_trsm_group = value; return PSGD_OK; }
   if (key == 6) { g_grad_split = value; return PSGD_OK; }
+  if (key == 7) { g_stage_mix = value; return PSGD_OK; }
   if (key == 8) { g_splitk = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
@@ -2762,10 +2813,9 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
     GemmArgs s[kMaxLayers][6];
     KronWs k[kMaxLayers];
     BalanceBatch bb;
-    TrsmBatch t1, t2, inv;
+    TrsmBatch t1, t2;
     bb.count = t1.count = t2.count = nb;
-    inv.count = 2 * nb;
-    int blk1 = 0, blk2 = 0, nblk = 0, nmax = 0;
+    int blk1 = 0, blk2 = 0, nmax = 0;
     for (int q = 0; q < nb; ++q) {
       const int p = p0 + q;
       if (!Ql[p] || !Qr[p] || !dX[p] || !dG[p] || !QlOut[p] || !QrOut[p]) return PSGD_ERR_BAD_ARG;
@@ -2773,31 +2823,45 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
       base += k[q].total;
       plan_update(dG[p], QlOut[p], QrOut[p], M[p], N[p], step, tiny, k[q], s[q]);
       bb.Ql[q] = Ql[p]; bb.Qr[q] = Qr[p]; bb.QlS[q] = k[q].QlS; bb.QrS[q] = k[q].QrS; bb.M[q] = M[p]; bb.N[q] = N[p];
-      bb.scal[q] = k[q].scal;
+      bb.scal[q] = k[q].scal; bb.dinv[q] = k[q].dinv;
       t1.t[q] = {k[q].QrS, N[p], N[p], dX[p], k[q].X1, M[p], (long)N[p], 1L, 0L, 0L};
       t1.dinv[q] = k[q].dinv; t2.dinv[q] = k[q].dinv + (long)((N[p] + 31) / 32) * 1024;
       t2.t[q] = {k[q].QlS, M[p], M[p], k[q].X1, k[q].Bt, N[p], 1L, (long)N[p], 0L, 0L};
       blk1 += (M[p] + 15) / 16; t1.blk_end[q] = blk1;      // 16-vector strips (k_trsm_ut_inv_batched)
       blk2 += (N[p] + 15) / 16; t2.blk_end[q] = blk2;
-      // inversion of the 32 x 32 diagonal blocks: both factors of every layer in ONE launch
-      inv.t[2 * q] = t1.t[q]; inv.dinv[2 * q] = t1.dinv[q];
-      nblk += (N[p] + 31) / 32; inv.blk_end[2 * q] = nblk;
-      inv.t[2 * q + 1] = t2.t[q]; inv.dinv[2 * q + 1] = t2.dinv[q];
-      nblk += (M[p] + 31) / 32; inv.blk_end[2 * q + 1] = nblk;
       if (M[p] > nmax) nmax = M[p];
       if (N[p] > nmax) nmax = N[p];
     }
-    hipLaunchKernelGGL(k_kron_balance_batched, dim3(64, nb), dim3(kThreads), 0, st, bb);   // (also zeroes the scratch words)
+    // K0 (:166-170) and the inverted diagonal blocks of K2 (:174) of every layer; also zeroes the scratch words
+    hipLaunchKernelGGL(k_kron_balance_batched, dim3(kBalInvBlocks + 64, nb), dim3(kThreads), 0, st, bb);
     KRON_LAUNCH((int)hipGetLastError());
     GemmArgs g[kMaxBatch];
-    for (int stage = 0; stage < 2; ++stage) {
+    long t64 = 0;
+    for (int q = 0; q < nb; ++q) t64 += (long)((N[p0 + q] + 63) / 64) * ((M[p0 + q] + 63) / 64);
+    const bool mixed = g_stage_mix && t64 < 96 && g_small_deep && !g_trsm_lds;    // the kernels launch_gemm_batch / the solve would pick
+    if (mixed) {
+      // the products (:173) next to the solves (:174), stage by stage (their diagonal blocks were inverted by the first launch)
+      for (int stage = 0; stage < 2; ++stage) {
+        MixBatch mb;
+        const TrsmBatch& tb = stage ? t2 : t1;
+        mb.count = nb; mb.strips = stage ? blk2 : blk1;
+        int tiles = 0;
+        for (int q = 0; q < nb; ++q) {
+          mb.blk_end[q] = tb.blk_end[q]; mb.t[q] = tb.t[q]; mb.dinv[q] = tb.dinv[q];
+          mb.g[q] = s[q][stage];
+          tiles += ((mb.g[q].N + 31) / 32) * ((mb.g[q].M + 31) / 32);
+          mb.tile_end[q] = tiles;
+        }
+        hipLaunchKernelGGL(k_small_stage_mixed, dim3(mb.strips + tiles), dim3(kThreads), 0, st, mb);
+        KRON_LAUNCH((int)hipGetLastError());
+      }
+    }
+    for (int stage = 0; stage < 2 && !mixed; ++stage) {
       for (int q = 0; q < nb; ++q) g[q] = s[q][stage];
       KRON_LAUNCH(launch_gemm_batch(g, nb, st));
     }
-    // K2 (:174) for every layer: invert the 32 x 32 diagonal blocks of all factors, then the two solves
-    hipLaunchKernelGGL(k_tri_inv32_batched, dim3(nblk), dim3(64), 0, st, inv);
-    KRON_LAUNCH((int)hipGetLastError());
-    for (int pass = 0; pass < 2; ++pass) {
+    // K2 (:174) for every layer: the two solves (their diagonal blocks were inverted by the first launch)
+    for (int pass = 0; pass < 2 && !mixed; ++pass) {
       TrsmBatch& tb = pass ? t2 : t1;
       if (!g_trsm_lds) {
         hipLaunchKernelGGL(k_trsm_ut_reg_batched, dim3(pass ? blk2 : blk1), dim3(kThreads), 0, st, tb);
