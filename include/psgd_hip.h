@@ -266,9 +266,11 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  *        0 = one block per tile.
  * key 6: large fp32 update, M = N: 1 (default) the last tiles of the gradient grid are split along K over the block
  *        slots a short last round would leave idle (partials summed in a fixed order by the last block to arrive).
- * key 7: batched update of small layers: 1 (default) each stage of the products dG QrS' -> QlS (.) (psgd.py:173) shares
- *        its launch with the same stage of the solves (:174) -- the two chains only meet at the gradient pair; 0 = one
- *        launch per stage of each chain. */
+ * key 7 (bits, default 3): bit 0: in the batched update of small layers each stage of the products dG QrS' -> QlS (.)
+ *        (psgd.py:173) shares its launch with the same stage of the solves (:174) -- the two chains only meet at the
+ *        gradient pair; bit 1: psgd_kron_dd_update_f32 with M, N <= 512 takes that batched route as a batch of one
+ *        (5 launches instead of 10-13; same arithmetic).  0 = one launch per stage of each chain, single updates on
+ *        the large-layer path. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

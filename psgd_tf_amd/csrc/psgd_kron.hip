@@ -2258,7 +2258,8 @@ __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long 
 }
 
 constexpr int kTrsmPlanesK = 2048;      // group width (4 strips) whose update runs on planes when the factor's planes exist
-static int g_stage_mix = 1;     // tuning key 7: 0 = batched small-layer update runs its products and solves as separate launches
+static int g_stage_mix = 3;     // tuning key 7: bit 0 = the batched small-layer update runs a product stage and a solve stage per launch;
+                                // bit 1 = a single update with M, N <= 512 takes the batched route (5 launches instead of 10-13)
 static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
 
 struct P3Buf { __bf16* p; long rows, ld; };          // planes of a matrix with padded extents x = rows, k = ld (multiples of 128)
@@ -2693,6 +2694,9 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   if (!Ql || !Qr || !dX || !dG || !QlOut || !QrOut) return PSGD_ERR_BAD_ARG;
   if (M <= 0 || N <= 0) return PSGD_ERR_SHAPE;
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
+  // small layers are launch-bound: the batch-of-one route has half the launches (stages of independent chains share them)
+  if (M <= 512 && N <= 512 && (g_stage_mix & 2))
+    return psgd_kron_dd_update_batched_f32(&Ql, &Qr, &dX, &dG, &QlOut, &QrOut, &M, &N, 1, step, tiny, ws, ws_bytes, stream);
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
   KRON_LAUNCH(kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal));               // K0: balance (:166-170); zeroes k.scal
@@ -2838,7 +2842,7 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
     GemmArgs g[kMaxBatch];
     long t64 = 0;
     for (int q = 0; q < nb; ++q) t64 += (long)((N[p0 + q] + 63) / 64) * ((M[p0 + q] + 63) / 64);
-    const bool mixed = g_stage_mix && t64 < 96 && g_small_deep && !g_trsm_lds;    // the kernels launch_gemm_batch / the solve would pick
+    const bool mixed = (g_stage_mix & 1) && t64 < 96 && g_small_deep && !g_trsm_lds;    // the kernels launch_gemm_batch / the solve would pick
     if (mixed) {
       // the products (:173) next to the solves (:174), stage by stage (their diagonal blocks were inverted by the first launch)
       for (int stage = 0; stage < 2; ++stage) {

@@ -315,6 +315,34 @@ def test_triangular_solve_kernel_variants_agree(psgd, hip_lib, M, N):
         assert rel_err(outs[1][k].cpu().numpy(), ref[k]) < TOL
 
 
+@pytest.mark.parametrize("M,N", [(26, 6), (257, 120), (85, 10), (1, 1), (2, 3), (300, 300), (512, 40), (400, 300), (512, 512)])
+def test_small_update_routes_agree(psgd, hip_lib, M, N):
+    """psgd_kron_set_tuning(7, .): the small-layer update as one launch per stage of each chain on the large-layer path
+    (0), with product and solve stages sharing launches in the batched form (bit 0), and with single calls routed through
+    a batch of one (bit 1, default 3).  Same block algorithms: batched results bitwise equal with and without shared
+    launches; the single-call routes agree to rounding and with the oracle."""
+    rng = np.random.default_rng(5 * M + N)
+    Ql, Qr = _dev(_tri_factor(rng, M) * 1.5), _dev(_tri_factor(rng, N))
+    dX = _dev(rng.standard_normal((M, N)))
+    dG = _dev(rng.standard_normal((M, N)) * 2.0)
+    outs = {}
+    try:
+        for key in (0, 1, 3):
+            hip_lib.psgd_kron_set_tuning(7, key)
+            u = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+            ub = psgd.update_precond_kron_batched([Ql], [Qr], [dX], [dG], 0.01)[0]
+            outs[key] = [t.clone() for t in (u[0], u[1], ub[0], ub[1])]
+    finally:
+        hip_lib.psgd_kron_set_tuning(7, 3)
+    ref = orc.update_precond_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, dX, dG)), 0.01)
+    for k in range(2):
+        assert torch.equal(outs[0][2 + k], outs[1][2 + k])            # batched: shared launches change nothing
+        assert torch.equal(outs[3][k], outs[3][2 + k])                # a single call IS a batch of one
+        assert rel_err(outs[0][k].cpu().numpy(), outs[3][k].cpu().numpy()) < 1e-6
+        for key in (0, 3):
+            assert rel_err(outs[key][k].cpu().numpy(), ref[k]) < TOL
+
+
 @pytest.mark.parametrize("M,N", [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (200, 333)])
 def test_small_gemm_bodies_bitwise_equal(psgd, hip_lib, M, N):
     """The 32 x 32-tile products have two bodies (psgd_kron_set_tuning(3, .)): same tiles, same K order, same fp32 MFMA
