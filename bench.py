@@ -197,6 +197,8 @@ def kron_bench(dev, psgd, iters=20):
     t_lenet_cold = timeit(cold_batched, 50)
     dXs = [torch.randn_like(g_) for g_ in Gs]
     t_lenet_upd = timeit(lambda: psgd.update_precond_kron_batched(Qls, Qrs, dXs, Gs, 0.01), 50)
+    t_lenet_upd_loop = timeit(lambda: [psgd.update_precond_kron(a, b, x, g, 0.01)          # mnist_with_lenet5.py:51
+                                       for a, b, x, g in zip(Qls, Qrs, dXs, Gs)], 50)
     dX = torch.randn_like(G)
     t_upd = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, G, 0.01), 5)
     dXb, dGb = dX.to(torch.bfloat16), Gb
@@ -256,7 +258,7 @@ def kron_bench(dev, psgd, iters=20):
                             "per_layer_calls_new_factors_us": t_lenet_loop_cold * 1e3,
                             "note": "`us` / `per_layer_calls_us`: factors unchanged between applies (their Grams stay "
                                     "prepared: 2 launches per call); `*_new_factors*`: every call brings new factors (3 launches)",
-                            "update_us": t_lenet_upd * 1e3},
+                            "update_us": t_lenet_upd * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3},
         "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6},
         "4096x4096_bf16_operands_update": {"ms": t_upd_bf16, "gflops": f_upd / t_upd_bf16 / 1e6,
                                            "note": "products on bf16 operands; balance, triangular solves, norms and "
