@@ -7,12 +7,24 @@ namespace psgdk {
 
 // QlS = Ql * sqrt(max|Qr| / max|Ql|), QrS = Qr / that  (psgd.py:166-170).  0 on success.
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st,
-                 float* scal = nullptr);   // scal: 64 scratch words to zero in the same launch (or null)
+                 float* scal = nullptr,    // scal: 64 scratch words to zero in the same launch (or null)
+                 float* dinv = nullptr);   // dinv: (ceil(N/32) + ceil(M/32)) * 1024 floats: the same launch inverts the 32 x 32
+                                           // diagonal blocks of QrS (first) and QlS (after them) for kron_trsm_ut(..., inv_ready)
 
 // Solve y Q = x for nvec vectors (vector i at stride si, element j at stride sj; Q upper triangular [n][n]);
 // dinv: scratch of ceil(n/32) * 1024 floats.  0 on success.
 // lite: the trailing products of the blocked solve keep only the three leading terms of the bf16 x 3 split (2^-16 relative)
+// inv_ready: dinv already holds the inverted diagonal blocks of Q (kron_balance made them)
 int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st,
-                 int lite = 0);
+                 int lite = 0, bool inv_ready = false);
+
+// The update has two chains that meet only at the gradient products: the products dG QrS' -> QlS (.) (psgd.py:173) and
+// the solves (:174).  kron_fork makes `side` (a lowest-priority stream kept per device and caller stream) wait for
+// everything already on `main`; the caller puts one chain on it and kron_join makes `main` wait for that chain.
+// Event fork/join only, so it is legal inside a stream capture of `main`.  nullptr = no side stream: stay on `main`.
+struct KronFork { hipStream_t side; hipEvent_t fork, join; };
+KronFork* kron_fork(hipStream_t main);
+int kron_join(KronFork* f, hipStream_t main);          // 0 on success
+bool kron_overlap_chains(int M, int N);                // tuning key 9 and the shape rule
 
 }  // namespace psgdk

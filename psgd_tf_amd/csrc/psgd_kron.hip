@@ -19,6 +19,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "psgd_hip.h"
 #include "kron_shared.h"
 #include "nanmax.h"
@@ -1803,6 +1806,31 @@ __device__ __forceinline__ void tri_inv32_rows(const float (*Qd)[33], int lane, 
 // Blocks x < kBalInvBlocks of a layer invert the 32 x 32 diagonal blocks of the *balanced* factors (one block per wave;
 // the balanced entries are formed exactly as the other blocks store them), the rest write QlS / QrS: the inversion is
 // the longer of the two and needs nothing but rho, so it shares the launch instead of waiting behind two GEMM stages.
+// The inverted 32 x 32 diagonal blocks of the balanced factors for workgroup `bid` of the inversion part of a balance
+// launch: one block per wave, QrS's first, then QlS's (the layout of dinv the solves read).
+__device__ __forceinline__ void balance_inv_body(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
+                                                 float* dinv, float (*red)[4], float (*Qd)[32][33], int bid) {
+  const float rho = balance_rho(Ql, Qr, M, N, red);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nbr = (N + 31) / 32, nbl = (M + 31) / 32;
+  const int bi = bid * 4 + w;
+  const bool act = bi < nbr + nbl;
+  const bool left = bi >= nbr;
+  const float* __restrict__ Q = left ? Ql : Qr;
+  const int n = left ? M : N, j0 = (left ? bi - nbr : bi) * 32;
+  if (act)
+    for (int e = lane; e < 1024; e += 64) {
+      const int r = e >> 5, c = e & 31;
+      const bool in = j0 + r < n && j0 + c < n;
+      const float q = Q[(long)min(j0 + r, n - 1) * n + min(j0 + c, n - 1)];
+      Qd[w][r][c] = in ? (left ? q / rho : rho * q) : (r == c ? 1.0f : 0.0f);
+    }
+  __syncthreads();
+  if (act && lane < 32) tri_inv32_rows(Qd[w], lane, dinv + (long)bi * 1024 + lane * 32);
+}
+
+// Blocks x < kBalInvBlocks of a layer invert the diagonal blocks, the rest write QlS / QrS: the inversion is the longer of
+// the two and needs nothing but rho, so it shares the launch instead of waiting behind two GEMM stages.
 constexpr int kBalInvBlocks = 8;    // 4 waves each: up to 32 diagonal blocks per layer (M, N <= 512)
 __global__ __launch_bounds__(kThreads) void k_kron_balance_batched(BalanceBatch b) {
   __shared__ float red[2][4];
@@ -1814,23 +1842,21 @@ __global__ __launch_bounds__(kThreads) void k_kron_balance_batched(BalanceBatch 
     balance_body(b.Ql[p], b.Qr[p], M, N, b.QlS[p], b.QrS[p], red, blockIdx.x - kBalInvBlocks, gridDim.x - kBalInvBlocks);
     return;
   }
-  const float rho = balance_rho(b.Ql[p], b.Qr[p], M, N, red);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nbr = (N + 31) / 32, nbl = (M + 31) / 32;
-  const int bi = blockIdx.x * 4 + w;          // diagonal blocks of QrS first, then those of QlS (layout of dinv)
-  const bool act = bi < nbr + nbl;
-  const bool left = bi >= nbr;
-  const float* __restrict__ Q = left ? b.Ql[p] : b.Qr[p];
-  const int n = left ? M : N, j0 = (left ? bi - nbr : bi) * 32;
-  if (act)
-    for (int e = lane; e < 1024; e += 64) {
-      const int r = e >> 5, c = e & 31;
-      const bool in = j0 + r < n && j0 + c < n;
-      const float q = Q[(long)min(j0 + r, n - 1) * n + min(j0 + c, n - 1)];
-      Qd[w][r][c] = in ? (left ? q / rho : rho * q) : (r == c ? 1.0f : 0.0f);
-    }
-  __syncthreads();
-  if (act && lane < 32) tri_inv32_rows(Qd[w], lane, b.dinv[p] + (long)bi * 1024 + lane * 32);
+  balance_inv_body(b.Ql[p], b.Qr[p], M, N, b.dinv[p], red, Qd, blockIdx.x);
+}
+
+// one problem; the first inv_blocks workgroups invert the diagonal blocks (0 = balance only)
+__global__ __launch_bounds__(kThreads) void k_kron_balance_inv(const float* __restrict__ Ql, const float* __restrict__ Qr,
+                                                               int M, int N, float* QlS, float* QrS, float* scal,
+                                                               float* dinv, int inv_blocks) {
+  __shared__ float red[2][4];
+  __shared__ float Qd[4][32][33];
+  if ((int)blockIdx.x >= inv_blocks) {
+    if (scal && (int)blockIdx.x == inv_blocks && threadIdx.x < 64) scal[threadIdx.x] = 0.0f;
+    balance_body(Ql, Qr, M, N, QlS, QrS, red, blockIdx.x - inv_blocks, gridDim.x - inv_blocks);
+    return;
+  }
+  balance_inv_body(Ql, Qr, M, N, dinv, red, Qd, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2354,9 +2380,12 @@ static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
 // Qc / blk (optional): column-form planes of Q (x = column, k = row) and a plane buffer for [nvec x 2048] of Y: the wide
 // group updates (K = 2048) then run on planes -- the finished group is split once instead of once per column tile.
 static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
-                   hipStream_t st, long xi = 0, long xj = 0, int lite = 0, const P3Buf* Qc = nullptr, __bf16* blk = nullptr) {
-  hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
-  if (hipGetLastError() != hipSuccess) return 1;
+                   hipStream_t st, long xi = 0, long xj = 0, int lite = 0, const P3Buf* Qc = nullptr, __bf16* blk = nullptr,
+                   bool inv_ready = false) {
+  if (!inv_ready) {                                    // (the update's balance launch has made them already)
+    hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
+    if (hipGetLastError() != hipSuccess) return 1;
+  }
   if (n <= kStripN) {
     TrsmArgs t = {Q, n, n, X, Y, nvec, si, sj, xi, xj};
     return launch_strip(t, dinv, st);
@@ -2555,13 +2584,20 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
 //   after the solves:   U0, U1 = planes(Bt), planes(Bt')
 //   s2  G1 = planes(triu(A A' - Bt Bt')), max -> scal[0]     s3  G2 = planes(triu(A'A - Bt'Bt)), max -> scal[1]
 //   s4  QlOut = QlS - (step / max) G1 QlS                    s5  QrOut = QrS - (step / max) G2 QrS
-static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st) {
+// planes of the balanced factors (row and column forms): both chains of the update read them
+static int planes_update_factors(int M, int N, const KronWs& k, hipStream_t st) {
   const long Mp = pad128(M), Np = pad128(N);
   const P3Buf Lr = {k.Lr, Mp, Mp}, Lc = {k.Lc, Mp, Mp}, Rr = {k.Rr, Np, Np}, Rc = {k.Rc, Np, Np};
-  const P3Buf dGp = {k.U0, Mp, Np}, Tt = {k.U1, Np, Mp}, Ar = {k.U2, Mp, Np}, Ac = {k.U3, Np, Mp};
   int e;
   if ((e = launch_split3_both(k.QlS, M, 1, M, M, Lr, Lc, st))) return e;
-  if ((e = launch_split3_both(k.QrS, N, 1, N, N, Rr, Rc, st))) return e;
+  return launch_split3_both(k.QrS, N, 1, N, N, Rr, Rc, st);
+}
+
+static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st) {
+  const long Mp = pad128(M), Np = pad128(N);
+  const P3Buf Lr = {k.Lr, Mp, Mp}, Rr = {k.Rr, Np, Np};
+  const P3Buf dGp = {k.U0, Mp, Np}, Tt = {k.U1, Np, Mp}, Ar = {k.U2, Mp, Np}, Ac = {k.U3, Np, Mp};
+  int e;
   if ((e = launch_split3(dG, N, 1, M, N, dGp, st))) return e;
   P3Args s0 = p3_args(dGp, Rr, M, N, N, KLO_N);                 // T = dG QrS'  (:173); (n, k) view of QrS' = QrS
   p3_out_col(s0, Tt);
@@ -2596,17 +2632,57 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
 }
 
 // entry points shared with psgd_kron_bf16.hip (kron_shared.h)
-int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal) {
+int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal,
+                 float* dinv) {
   const long tot = (long)M * M + (long)N * N;
   int grid = (int)((tot + kThreads - 1) / kThreads);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS, scal);
+  if (dinv) {
+    const int inv_blocks = ((M + 31) / 32 + (N + 31) / 32 + 3) / 4;
+    hipLaunchKernelGGL(k_kron_balance_inv, dim3(inv_blocks + grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS, scal, dinv,
+                       inv_blocks);
+  } else {
+    hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS, scal);
+  }
   return (int)hipGetLastError();
 }
 
 int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st,
-                 int lite) {
-  return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st, 0, 0, lite);
+                 int lite, bool inv_ready) {
+  return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st, 0, 0, lite, nullptr, nullptr, inv_ready);
+}
+
+static int g_overlap = 1;       // tuning key 9: 0 = the two chains of a large update run one after the other on the caller's stream
+bool kron_overlap_chains(int M, int N) { return g_overlap != 0 && (M > 512 || N > 512); }
+
+KronFork* kron_fork(hipStream_t main) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, KronFork> tab;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  KronFork* f = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = tab.find({dev, main});
+    if (it == tab.end()) {
+      KronFork n = {};
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&n.join, hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+      it = tab.emplace(std::make_pair(dev, main), n).first;
+    }
+    f = &it->second;
+  }
+  if (hipEventRecord(f->fork, main) != hipSuccess || hipStreamWaitEvent(f->side, f->fork, 0) != hipSuccess) return nullptr;
+  return f;
+}
+
+int kron_join(KronFork* f, hipStream_t main) {
+  if (hipEventRecord(f->join, f->side) != hipSuccess) return 1;
+  return hipStreamWaitEvent(main, f->join, 0) != hipSuccess;
 }
 
 }  // namespace psgdk
@@ -2635,6 +2711,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 6) { g_grad_split = value; return PSGD_OK; }
   if (key == 7) { g_stage_mix = value; return PSGD_OK; }
   if (key == 8) { g_splitk = value; return PSGD_OK; }
+  if (key == 9) { g_overlap = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -2699,15 +2776,21 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     return psgd_kron_dd_update_batched_f32(&Ql, &Qr, &dX, &dG, &QlOut, &QrOut, &M, &N, 1, step, tiny, ws, ws_bytes, stream);
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  KRON_LAUNCH(kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal));               // K0: balance (:166-170); zeroes k.scal
+  // K0: balance (:166-170); zeroes k.scal; the same launch inverts the diagonal blocks the solves of K2 start from
+  KRON_LAUNCH(kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal, k.dinv));
+  float* dinv_l = k.dinv + (long)((N + 31) / 32) * 1024;
   const bool planes = kron_planes(M, N) && g_planes && g_gemm_x3;
   GemmArgs s[6];
   plan_update(dG, QlOut, QrOut, M, N, step, tiny, k, s);
+  if (planes) KRON_LAUNCH(planes_update_factors(M, N, k, st));
+  // the products (:173) go to the side stream, the solves (:174) stay here; they meet at the gradient products
+  KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
+  hipStream_t sf = fk ? fk->side : st;
   if (planes) {
-    KRON_LAUNCH(planes_update_front(dG, M, N, k, st));
+    KRON_LAUNCH(planes_update_front(dG, M, N, k, sf));
   } else {
-    KRON_LAUNCH(launch_gemm(s[0], st));
-    KRON_LAUNCH(launch_gemm(s[1], st));
+    KRON_LAUNCH(launch_gemm(s[0], sf));
+    KRON_LAUNCH(launch_gemm(s[1], sf));
   }
   // K2 (:174): X1 = dX QrS^-1 (rows independent), Bt = QlS^-T X1 (columns independent)
   // (the K = 512 trailing products of the solves were tried on planes too: 557 + 7 x 9 us of strip splits against 647 us
@@ -2715,12 +2798,13 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // K = 2048 group updates use the factors' column-form planes)
   if (planes) {
     const P3Buf Rc = {k.Rc, pad128(N), pad128(N)}, Lc = {k.Lc, pad128(M), pad128(M)};
-    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0));
-    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st, 0, 0, 0, &Lc, k.S0));
+    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0, true));
+    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, &Lc, k.S0, true));
   } else {
-    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st));
-    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st));
+    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, nullptr, nullptr, true));
+    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, nullptr, nullptr, true));
   }
+  if (fk) KRON_LAUNCH(kron_join(fk, st));
   if (planes) {
     KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st));
     return PSGD_OK;

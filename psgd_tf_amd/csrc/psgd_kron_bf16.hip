@@ -1230,18 +1230,21 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   // the zero columns between the two halves of the concatenated K axis (only when N or M is not a K-tile multiple)
   if (k.n64 != N && hipMemsetAsync(k.W1, 0, (size_t)k.w1_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   if (k.m64 != M && hipMemsetAsync(k.W2, 0, (size_t)k.w2_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
-  HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st));                           // :166-170
+  HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, nullptr, k.dinv));          // :166-170 (+ the solves' inverted diagonal blocks)
+  // the bf16 products of :173 go to the side stream (kron_shared.h), the fp32 solves of :174 stay on the caller's
+  psgdk::KronFork* fk = psgdk::kron_overlap_chains(M, N) ? psgdk::kron_fork(st) : nullptr;
+  hipStream_t sf = fk ? fk->side : st;
   {
     dim3 grid((max(M, N) + 63) / 64, (max(M, N) + 63) / 64, 2);
-    hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, FactorJob{k.QlS, k.Qlb, k.QlTb, M},
+    hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, sf, FactorJob{k.QlS, k.Qlb, k.QlTb, M},
                        FactorJob{k.QrS, k.Qrb, k.QrTb, N}, static_cast<unsigned*>(nullptr), 0);
     HK((int)hipGetLastError());
   }
   // T' [N][M] = (dG QrS')'      A = dG [M][K=N], Bt[n][k] = QrS[n][k], k >= n                      (:173)
-  HK(launch_hgemm(dGb, N, k.Qrb, N, k.Tt, M, 1, 1, M, N, N, KLO_N, st));
+  HK(launch_hgemm(dGb, N, k.Qrb, N, k.Tt, M, 1, 1, M, N, N, KLO_N, sf));
   // A = QlS T  -> second half of W1     A operand QlS [M][K=M], k >= m; Bt = T'
-  HK(launch_hgemm(k.Qlb, M, k.Tt, M, k.W1 + k.n64, ld1, 1, 0, M, N, M, KLO_M, st));
-  HK(launch_cvt(k.W1 + k.n64, 1, ld1, k.W2 + k.m64, ld2, M, N, 1, st));              // A' -> second half of W2
+  HK(launch_hgemm(k.Qlb, M, k.Tt, M, k.W1 + k.n64, ld1, 1, 0, M, N, M, KLO_M, sf));
+  HK(launch_cvt(k.W1 + k.n64, 1, ld1, k.W2 + k.m64, ld2, M, N, 1, sf));              // A' -> second half of W2
   // Bt = QlS^-T dX QrS^-1 in fp32                                                                   (:174)
   {
     const long n8 = (long)M * N / 8;
@@ -1250,8 +1253,9 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(grid), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dX), k.X0, n8);
     HK((int)hipGetLastError());
   }
-  HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite));
-  HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv, st, g_trsm_lite));
+  HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite, true));
+  HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv + (long)((N + 31) / 32) * 1024, st, g_trsm_lite, true));
+  if (fk) HK(psgdk::kron_join(fk, st));
   HK(launch_cvt(k.Bt, 0, N, k.W1, ld1, M, N, 0, st));                                 // Bt  -> first half of W1
   HK(launch_cvt(k.Bt, 0, N, k.W2, ld2, M, N, 1, st));                                 // Bt' -> first half of W2
   // grad1 = triu(A A' - Bt Bt'), grad2 = triu(A'A - Bt'Bt)                                          (:175-176)
