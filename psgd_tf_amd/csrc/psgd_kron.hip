@@ -2390,8 +2390,10 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
     TrsmArgs t = {Q, n, n, X, Y, nvec, si, sj, xi, xj};
     return launch_strip(t, dinv, st);
   }
-  if (xi == 0 && xj == 0) {
-    if (hipMemcpyAsync(Y, X, (size_t)nvec * n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+  // X with the strides of Y is never copied: the first strip and the two products with k0 = 0 (which between them touch
+  // every later column first) read it in place of Y
+  const bool lazy = xi == 0 && xj == 0;
+  if (lazy) {
   } else {
     hipLaunchKernelGGL(k_copy_strided, dim3(1024), dim3(kThreads), 0, st, X, xi, xj, Y, si, sj, nvec, n);
     if (hipGetLastError() != hipSuccess) return 1;
@@ -2408,7 +2410,7 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
       g.B.p = Qc->p + (long)(k0 / 32) * (Qc->rows * 32) + (long)c0 * 32;
       float* Yr = Y + (long)c0 * sj;
       g.e.C = Yr; g.e.ldc = si; g.e.c_cs = sj;
-      g.e.D = Yr; g.e.ldd = si;
+      g.e.D = (lazy && k0 == 0 ? X : Y) + (long)c0 * sj; g.e.ldd = si;
       g.e.epi = EPI_D_MINUS;
       return launch_p3(g, st);
     }
@@ -2417,7 +2419,7 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
     g.B = Q + (long)k0 * n + c0; g.b_rs = n; g.b_cs = 1;
     float* Yr = Y + (long)c0 * sj;
     g.C = Yr; g.ldc = si; g.c_cs = sj;
-    g.D = Yr; g.ldd = si;                                                // in place: C = C - A B
+    g.D = (lazy && k0 == 0 ? X : Y) + (long)c0 * sj; g.ldd = si;        // in place (or first touch: from X): C = D - A B
     g.M = nvec; g.N = cw; g.K = kw;
     g.epi = EPI_D_MINUS;
     g.lite = lite;
@@ -2430,7 +2432,7 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
     for (int j0 = g0; j0 < gend; j0 += kTrsmBlock) {
       const int jw = (gend - j0 < kTrsmBlock) ? (gend - j0) : kTrsmBlock;
       float* Yb = Y + (long)j0 * sj;
-      TrsmArgs t = {Q + (long)j0 * n + j0, jw, n, Yb, Yb, nvec, si, sj, 0L, 0L};
+      TrsmArgs t = {Q + (long)j0 * n + j0, jw, n, (lazy && j0 == 0) ? X : Yb, Yb, nvec, si, sj, 0L, 0L};
       int e = launch_strip(t, dinv + (long)(j0 / 32) * 1024, st);
       if (e) return e;
       if (j0 + jw < gend && (e = update(j0, jw, j0 + jw, gend - j0 - jw))) return e;
