@@ -270,7 +270,11 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  *        (psgd.py:173) shares its launch with the same stage of the solves (:174) -- the two chains only meet at the
  *        gradient pair; bit 1: psgd_kron_dd_update_f32 with M, N <= 512 takes that batched route as a batch of one
  *        (5 launches instead of 10-13; same arithmetic).  0 = one launch per stage of each chain, single updates on
- *        the large-layer path. */
+ *        the large-layer path.
+ * key 9: updates with M or N above 512 (fp32 and bf16 operands): 1 (default) the products of psgd.py:173 run on a
+ *        lowest-priority side stream (one per device and caller stream, made on first use) while the solves of :174 run on
+ *        the caller's stream; the call forks and joins with events only (legal inside a stream capture), so to the caller
+ *        it is still one stream-ordered operation.  0 = everything on the caller's stream.  Same kernels, same results. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

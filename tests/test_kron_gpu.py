@@ -315,6 +315,58 @@ def test_triangular_solve_kernel_variants_agree(psgd, hip_lib, M, N):
         assert rel_err(outs[1][k].cpu().numpy(), ref[k]) < TOL
 
 
+@pytest.mark.parametrize("M,N,bf16", [(600, 530, False), (1024, 1024, False), (1100, 520, False), (70, 2100, False),
+                                      (1024, 1024, True), (1536, 640, True)])
+def test_update_chains_on_two_streams_change_nothing(psgd, hip_lib, M, N, bf16):
+    """psgd_kron_set_tuning(9, .): the products of psgd.py:173 run on a side stream next to the solves of :174 (event
+    fork/join inside the call).  Same kernels, same data: bitwise equal to the serial order, call after call (the side
+    stream and its events are reused), and the next call on the caller's stream sees the finished result."""
+    rng = np.random.default_rng(M + 3 * N)
+    Ql, Qr = _dev(_tri_factor(rng, M) * 1.5), _dev(_tri_factor(rng, N))
+    dX = _dev(rng.standard_normal((M, N)))
+    dG = _dev(rng.standard_normal((M, N)) * 2.0)
+    if bf16:
+        dX, dG = dX.to(torch.bfloat16), dG.to(torch.bfloat16)
+    outs = {}
+    try:
+        for key in (0, 1):
+            hip_lib.psgd_kron_set_tuning(9, key)
+            a, b = Ql, Qr
+            for _ in range(3):                                # factors feed back: every call waits for the one before
+                a, b = psgd.update_precond_kron(a, b, dX, dG, 0.01)
+            outs[key] = (a.clone(), b.clone(), psgd.precond_grad_kron(a, b, dG).clone())
+    finally:
+        hip_lib.psgd_kron_set_tuning(9, 1)
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+
+
+def test_update_with_forked_chains_is_capturable(psgd):
+    """The fork/join is made of events only, so an update can be captured into a graph on the caller's stream; the replay
+    gives the eager result."""
+    M = N = 1024
+    rng = np.random.default_rng(77)
+    Ql, Qr = _dev(_tri_factor(rng, M) * 1.5), _dev(_tri_factor(rng, N))
+    dX, dG = _dev(rng.standard_normal((M, N))), _dev(rng.standard_normal((M, N)) * 2.0)
+    want = [t.clone() for t in psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):                                    # workspace and side stream of this stream exist before the capture
+            psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        got = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    for t in got:
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("M,N", [(26, 6), (257, 120), (85, 10), (1, 1), (2, 3), (300, 300), (512, 40), (400, 300), (512, 512)])
 def test_small_update_routes_agree(psgd, hip_lib, M, N):
     """psgd_kron_set_tuning(7, .): the small-layer update as one launch per stage of each chain on the large-layer path
