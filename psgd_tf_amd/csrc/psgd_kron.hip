@@ -3111,15 +3111,18 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   SP_LAUNCH(k_balance_generic, ew_grid((long)M * M), Ql, (long)M + 1, M, (long)M * M, qr, 1L, N, (long)N, k.LS, k.RS);
+  // the product of :295-296 on the side stream next to the solve of :298-299 (kron_fork: they meet at the gradient)
+  KronFork* fk = kron_overlap_chains(M, M) ? kron_fork(st) : nullptr;
   {                                                          // A = (QlS dG) .* qrS          (:295-296)
     GemmArgs g = gemm_args(k.LS, M, false, dG, 0, false, k.A, N, M, N, M, KLO_M);
     g.b_rs = xrs; g.b_cs = xcs;
     g.colv = k.RS;
-    KRON_LAUNCH(launch_gemm(g, st));
+    KRON_LAUNCH(launch_gemm(g, fk ? fk->side : st));
   }
   // Bt = (QlS^-T dX) .* (1/qrS)                             (:298-299); columns independent
   KRON_LAUNCH(trsm_ut(k.LS, M, dX, k.Bt, N, 1L, (long)N, k.dinv, st, (long)xcs, (long)xrs));
   SP_LAUNCH(k_col_inv_scale, ew_grid((long)M * N), k.Bt, k.RS, M, N);
+  if (fk) KRON_LAUNCH(kron_join(fk, st));
   if (k.P0 && g_planes && g_gemm_x3) {                       // grad1 = triu(A A' - Bt Bt')  (:301): few tiles, long K
     KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.Bt, (long)N, 1L, M, N, k.gsq, k.scal, st));
   } else {
@@ -3188,17 +3191,31 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   SP_LAUNCH(k_balance_generic, ew_grid((long)N * N), ql, 1L, M, (long)2 * M, Qr, (long)N + 1, N, (long)N * N, k.LS, k.RS);
-  int e = norm_left_pair(k, dX, dG, xrs, xcs, M, N, nullptr, k.T, k.Bt, st);       // T = Ql dG ; Bt = Ql^-T dX
-  if (e) return e;
-  KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), st));   // A = T QrS'  (:220)
-  KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.T, M, (long)N, 1L, k.dinv, st));                    // Bt QrS^-1 -> T   (:233)
-  SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.T, M, N, k.v1, k.v2);    // (:235-237)
+  // two chains that meet at the row statistics: T = Ql dG -> A = T QrS' (:218-220) on the side stream (kron_fork),
+  // Bt = Ql^-T dX -> Bt QrS^-1 (:222-233, solved in place) on the caller's
+  KronFork* fk = kron_overlap_chains(N, N) ? kron_fork(st) : nullptr;
+  {
+    hipStream_t sf = fk ? fk->side : st;
+    MatView vg = {dG, xrs, xcs};
+    hipLaunchKernelGGL(k_norm_left, dim3(ew_grid((long)M * N)), dim3(kThreads), 0, sf, vg, (const float*)k.LS,
+                       (const float*)(k.LS + M), M, N, (const float*)nullptr, 0, k.T);
+    if (hipGetLastError() != hipSuccess) return PSGD_ERR_LAUNCH;
+    KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), sf));   // A = T QrS'  (:220)
+  }
+  {
+    MatView vx = {dX, xrs, xcs};
+    if (col_reduce(k, vx, vx, k.LS, k.LS + M, M, N, 0, k.v0, st)) return PSGD_ERR_LAUNCH;
+    SP_LAUNCH(k_norm_left_invT, ew_grid((long)M * N), vx, (const float*)k.LS, (const float*)k.v0, M, N, (const float*)nullptr, k.Bt);
+  }
+  KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.Bt, M, (long)N, 1L, k.dinv, st));                   // Bt QrS^-1, in place  (:233)
+  if (fk) KRON_LAUNCH(kron_join(fk, st));
+  SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.Bt, M, N, k.v1, k.v2);   // (:235-237)
   SP_LAUNCH_WIDE(k_norm_finalize, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
   if (k.P0 && g_planes && g_gemm_x3) {                       // grad2 = triu(A'A - Bt'Bt)     (:243): few tiles, long K
-    KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.T, 1L, (long)N, N, M, k.gsq, k.scal, st));
+    KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.Bt, 1L, (long)N, N, M, k.gsq, k.scal, st));
   } else {
     GemmArgs g = gemm_args(k.A, N, true, k.A, N, false, k.gsq, N, N, N, M);
-    g.A2 = k.T; g.a2_rs = 1; g.a2_cs = N; g.B2 = k.T; g.b2_rs = N; g.b2_cs = 1; g.K2 = M;
+    g.A2 = k.Bt; g.a2_rs = 1; g.a2_cs = N; g.B2 = k.Bt; g.b2_rs = N; g.b2_cs = 1; g.K2 = M;
     g.epi = EPI_TRIU_MAX; g.maxout = k.scal;
     KRON_LAUNCH(launch_gemm(g, st));
   }
