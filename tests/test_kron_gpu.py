@@ -341,6 +341,34 @@ def test_update_chains_on_two_streams_change_nothing(psgd, hip_lib, M, N, bf16):
         assert torch.equal(x, y)
 
 
+def test_updates_on_two_caller_streams_keep_their_own_side_chains(psgd):
+    """Two caller streams issue updates back to back without synchronising: each has its own workspace, side stream and
+    events, so the results are those of the same calls made alone."""
+    rng = np.random.default_rng(123)
+    probs = []
+    for M, N in ((1024, 768), (640, 1100)):
+        probs.append((_dev(_tri_factor(rng, M) * 1.5), _dev(_tri_factor(rng, N)), _dev(rng.standard_normal((M, N))),
+                      _dev(rng.standard_normal((M, N)) * 2.0)))
+    want = []
+    for Ql, Qr, dX, dG in probs:
+        a, b = Ql, Qr
+        for _ in range(4):
+            a, b = psgd.update_precond_kron(a, b, dX, dG, 0.01)
+        want.append((a.clone(), b.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    state = [(p[0], p[1]) for p in probs]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    for _ in range(4):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                state[i] = psgd.update_precond_kron(state[i][0], state[i][1], probs[i][2], probs[i][3], 0.01)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(state[i][0], want[i][0]) and torch.equal(state[i][1], want[i][1])
+
+
 def test_update_with_forked_chains_is_capturable(psgd):
     """The fork/join is made of events only, so an update can be captured into a graph on the caller's stream; the replay
     gives the eager result."""
