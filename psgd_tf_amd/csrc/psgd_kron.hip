@@ -2660,8 +2660,14 @@ bool kron_overlap_chains(int M, int N) { return g_overlap != 0 && (M > 512 || N 
 KronFork* kron_fork(hipStream_t main) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, KronFork> tab;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  int cur = 0, dev = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+  dev = cur;
+  if (main) {                                           // the side stream belongs to the device of the caller's stream
+    hipDevice_t d;
+    if (hipStreamGetDevice(main, &d) != hipSuccess) return nullptr;
+    dev = (int)d;
+  }
   KronFork* f = nullptr;
   {
     std::lock_guard<std::mutex> lk(mu);
@@ -2669,11 +2675,13 @@ KronFork* kron_fork(hipStream_t main) {
     if (it == tab.end()) {
       KronFork n = {};
       int least = 0, greatest = 0;
+      if (dev != cur && hipSetDevice(dev) != hipSuccess) return nullptr;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      if (hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-      if (hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&n.join, hipEventDisableTiming) != hipSuccess)
-        return nullptr;
+      const bool ok = hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, least) == hipSuccess &&
+                      hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&n.join, hipEventDisableTiming) == hipSuccess;
+      if (dev != cur) (void)hipSetDevice(cur);
+      if (!ok) return nullptr;
       it = tab.emplace(std::make_pair(dev, main), n).first;
     }
     f = &it->second;
