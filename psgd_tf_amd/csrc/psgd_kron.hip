@@ -2673,6 +2673,9 @@ KronFork* kron_fork(hipStream_t main) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = tab.find({dev, main});
     if (it == tab.end()) {
+      // no stream or event is created while the caller's stream is being captured: that first call stays serial
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (main && (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return nullptr;
       KronFork n = {};
       int least = 0, greatest = 0;
       if (dev != cur && hipSetDevice(dev) != hipSuccess) return nullptr;

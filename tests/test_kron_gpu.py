@@ -369,10 +369,13 @@ def test_updates_on_two_caller_streams_keep_their_own_side_chains(psgd):
         assert torch.equal(state[i][0], want[i][0]) and torch.equal(state[i][1], want[i][1])
 
 
-def test_update_with_forked_chains_is_capturable(psgd):
+@pytest.mark.parametrize("warm", [True, False])
+def test_update_with_forked_chains_is_capturable(psgd, warm):
     """The fork/join is made of events only, so an update can be captured into a graph on the caller's stream; the replay
-    gives the eager result."""
-    M = N = 1024
+    gives the eager result.  warm = False: the capture stream has never made an update call, so the library has no side
+    stream for it yet and does not create one during the capture: that call stays serial (and its workspace is allocated
+    from the graph's pool)."""
+    M = N = 1024 if warm else 896
     rng = np.random.default_rng(77)
     Ql, Qr = _dev(_tri_factor(rng, M) * 1.5), _dev(_tri_factor(rng, N))
     dX, dG = _dev(rng.standard_normal((M, N))), _dev(rng.standard_normal((M, N)) * 2.0)
@@ -380,7 +383,7 @@ def test_update_with_forked_chains_is_capturable(psgd):
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        for _ in range(2):                                    # workspace and side stream of this stream exist before the capture
+        for _ in range(2 if warm else 0):                     # workspace and side stream of this stream exist before the capture
             psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
