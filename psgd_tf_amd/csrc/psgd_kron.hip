@@ -2795,11 +2795,15 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   const bool planes = kron_planes(M, N) && g_planes && g_gemm_x3;
   GemmArgs s[6];
   plan_update(dG, QlOut, QrOut, M, N, step, tiny, k, s);
-  if (planes) KRON_LAUNCH(planes_update_factors(M, N, k, st));
-  // the products (:173) go to the side stream, the solves (:174) stay here; they meet at the gradient products
+  // the products (:173) go to the side stream, the solves (:174) stay here; they meet at the gradient products.  The
+  // factors' planes belong to the product chain unless the solves read them too (their K = 2048 group products, which
+  // exist from 4096 on -- or from 2048 on with tuning key 5): then they are made before the fork.
+  const bool solves_on_planes = planes && (M > 2048 || N > 2048);
+  if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st));
   KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
   hipStream_t sf = fk ? fk->side : st;
   if (planes) {
+    if (!solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, sf));
     KRON_LAUNCH(planes_update_front(dG, M, N, k, sf));
   } else {
     KRON_LAUNCH(launch_gemm(s[0], sf));
@@ -2809,7 +2813,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // (the K = 512 trailing products of the solves were tried on planes too: 557 + 7 x 9 us of strip splits against 647 us
   // per solve -- their 16 K steps per block are dominated by the fixed parts of a block either way -- so only the wide
   // K = 2048 group updates use the factors' column-form planes)
-  if (planes) {
+  if (solves_on_planes) {
     const P3Buf Rc = {k.Rc, pad128(N), pad128(N)}, Lc = {k.Lc, pad128(M), pad128(M)};
     KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0, true));
     KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, &Lc, k.S0, true));
