@@ -33,19 +33,24 @@ def t(fn, min_ms=60.0):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for m, n in SH:
-    Ql, Qr, dX, dG, G = state(m, n, dev)
-    row = []
-    for kind in ("f32", "bf16"):
-        if kind == "bf16" and (m % 8 or n % 8):
-            continue
-        x, g = (dX, dG) if kind == "f32" else (dX.to(torch.bfloat16), dG.to(torch.bfloat16))
-        res, tm = {}, {}
-        for key in (0, 1, 0, 1):
-            lib.psgd_kron_set_tuning(9, key)
-            tm.setdefault(key, []).append(t(lambda: psgd.update_precond_kron(Ql, Qr, x, g, 0.01)))
-            res[key] = [r.clone() for r in psgd.update_precond_kron(Ql, Qr, x, g, 0.01)]
-        same = all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
-        row.append(f"{kind}: serial {min(tm[0]):.3f} ms, overlapped {min(tm[1]):.3f} ms ({min(tm[0]) / min(tm[1]):.2f}x, equal {same})")
-    print(f"{m} x {n}: " + " | ".join(row), flush=True)
-lib.psgd_kron_set_tuning(9, 1)
+def main():
+    for m, n in SH:
+        Ql, Qr, dX, dG, G = state(m, n, dev)
+        row = []
+        for kind in ("f32", "bf16"):
+            if kind == "bf16" and (m % 8 or n % 8):
+                continue
+            x, g = (dX, dG) if kind == "f32" else (dX.to(torch.bfloat16), dG.to(torch.bfloat16))
+            res, tm = {}, {}
+            for key in (0, 1, 0, 1):
+                lib.psgd_kron_set_tuning(9, key)
+                tm.setdefault(key, []).append(t(lambda: psgd.update_precond_kron(Ql, Qr, x, g, 0.01)))
+                res[key] = [r.clone() for r in psgd.update_precond_kron(Ql, Qr, x, g, 0.01)]
+            same = all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+            row.append(f"{kind}: serial {min(tm[0]):.3f} ms, overlapped {min(tm[1]):.3f} ms ({min(tm[0]) / min(tm[1]):.2f}x, equal {same})")
+        print(f"{m} x {n}: " + " | ".join(row), flush=True)
+    lib.psgd_kron_set_tuning(9, 1)
+
+
+if __name__ == "__main__":
+    main()
