@@ -652,6 +652,9 @@ struct P3Args {
 typedef __attribute__((address_space(3))) void* lds_ptr3_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr3_t;
 #define P3_FENCE() asm volatile("" ::: "memory")
+#ifndef P3_EARLY
+#define P3_EARLY 2      // MFMA columns (of 4) issued before the buffer-free barrier; 0 = all fragments first, then all MFMAs
+#endif
 
 // K tiles [lo, hi) of one operand pair.  LDS image as in k_gemm_x3: [A|B][plane][row * 4 + (chunk ^ swz(row))].  The DMA
 // writes linearly (wave base + 16 B * lane), so the swizzle is applied to the per-lane SOURCE address: the lane that
@@ -688,6 +691,25 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     __builtin_amdgcn_s_barrier();           // every wave's part of this K tile has landed
     P3_FENCE();
     bf16x8_k a[NT][NP], b[NT][NP];
+    auto read_b = [&](int j) {
+      const int row = wn * W + j * 16 + (lane & 15);
+      const int sl = row * 4 + (c ^ ((row >> 2) & 3));
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[1][pl][sl]);
+    };
+    auto mfma6 = [&](int i, int j) {
+      f32x4 v = acc[i][j];
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], v, 0, 0, 0);   // h l'
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], v, 0, 0, 0);   // l h'
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], v, 0, 0, 0);   // h m'
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], v, 0, 0, 0);   // m h'
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], v, 0, 0, 0);   // h h'
+      acc[i][j] = v;
+    };
+    // The first column of MFMAs starts as soon as ITS fragments are there (the compiler's counted lgkmcnt waits); the rest
+    // of the fragment reads return under it.  Only then: every wave holds its fragments, the buffer is free.
+    read_b(0);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int row = wm * W + i * 16 + (lane & 15);
@@ -696,30 +718,23 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
       for (int pl = 0; pl < NP; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[0][pl][sl]);
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int row = wn * W + j * 16 + (lane & 15);
-      const int sl = row * 4 + (c ^ ((row >> 2) & 3));
+    for (int j = 1; j < NT; ++j) read_b(j);
+#if P3_EARLY
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[1][pl][sl]);
-    }
+    for (int j = 0; j < P3_EARLY; ++j)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) mfma6(i, j);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     P3_FENCE();
     __builtin_amdgcn_s_barrier();           // every wave holds its fragments: the buffer is free
     P3_FENCE();
     if (k0 + kX3K < hi && !(X3_DBG & 1)) issue(k0 + kX3K);   // the next tile streams in under the MFMAs
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int j = P3_EARLY; j < NT; ++j)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        f32x4 v = acc[i][j];
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], v, 0, 0, 0);   // h l'
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], v, 0, 0, 0);   // l h'
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], v, 0, 0, 0);   // h m'
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], v, 0, 0, 0);   // m h'
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], v, 0, 0, 0);   // h h'
-        acc[i][j] = v;
-      }
+      for (int i = 0; i < NT; ++i) mfma6(i, j);
   }
 }
 // plane outputs of a C tile (pads inside the padded extents are written as zeros)
