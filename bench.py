@@ -11,9 +11,16 @@ precond_grad_UVd_math(U,V,d,g) (the UVd.step call pattern, psgd.py:732 -> :748) 
 N > 1 started from a plain shell launches its own ranks: the parent process (which never touches a GPU) starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a child, relays
 rank 0's JSON line and exits with the child's code.  Started under torch.distributed.run (WORLD_SIZE set) it is
-one of the ranks.  N > 1 row-shards the flat parameter vector: every rank holds --rows rows (weak scaling,
-global N = rows * world); per step two tiny all-gathers (RCCL over xGMI) carry the r-dimensional reduced
-buffers -- never N-sized data (psgd_tf_amd/sharded.py).
+one of the ranks.  N > 1 row-shards the flat parameter vector (psgd_tf_amd/sharded.py); per step two tiny
+all-gathers (RCCL over xGMI) carry the r-dimensional reduced buffers -- never N-sized data.  Which rows:
+  (default)        BASELINE configs[3]: N_global = 100M rows, r = 20 split over the N ranks in contiguous row blocks
+                   (12.5M rows per GPU at N = 8) -> "scaling": "strong"; the line also carries a `weak` sub-record
+                   (100M rows PER GPU, global N = 100M * world) measured right after it (--no-weak-leg skips it)
+  --global-rows G  strong scaling at G global rows only
+  --rows R         weak scaling only: every rank holds R rows
+At N = 1 both defaults are the same workload (100M rows on the one GPU = BASELINE's metric).  The N = 1 line also
+carries `exchange_overhead`: one rank's share of configs[3] (12.5M rows) run unsharded and through the multi-GPU
+path on a 1-rank RCCL group -- the us per step the two exchanges + fold kernels add (--no-exchange-leg skips it).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the dominant kernel (update sweep 2), timed live with HIP events on the launch stream
@@ -220,44 +227,53 @@ def kron_bench(dev, psgd, iters=20):
     pmc = None                          # matrix-core counters of the same call, collected with rocprofv3 --pmc
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "kron_mfma_pmc.json")))
-        pmc = {"source": "profiles/kron_mfma_pmc.json (rocprofv3 --pmc)", "issued_gflop_per_apply": pmc["issued_flops_per_apply"] / 1e9,
-               "issued_gflops": pmc["issued_flops_per_apply"] / t_bf16 / 1e6,
-               "frac_of_bf16_peak_issued": pmc["issued_flops_per_apply"] / t_bf16 / 1e6 / 2.5e6,
+        pmc = {"source": "profiles/kron_mfma_pmc.json (rocprofv3 --pmc on an earlier box, NOT counters of this run)",
+               "issued_gflop_per_apply": pmc["issued_flops_per_apply"] / 1e9,
                "MfmaUtil_percent": {k: v["mfma_util_percent"] for k, v in pmc["kernels"].items()},
                "MfmaUtil_percent_time_weighted": pmc["mfma_util_percent_time_weighted"]}
     except Exception:
         pmc = None
+    # Headline times are the NEW-FACTORS-EVERY-CALL ones: in the reference's call pattern the factors change before
+    # every apply (mnist_with_lenet5.py:51 -> :53), so the bf16 factor copies / the Gram of psgd.py:192 are made inside
+    # the timed call and every flop F_ref counts is executed (or skipped as a triangular zero block) in that time.
+    # `*_unchanged_factors` keep the prepared state across calls (factors untouched between applies).
     return {
         "metric": "kron_dense_dense_apply_gflops", "flop_count": "F_ref (dense flops of psgd.py:189-192)",
-        "roofline": {"bound": "mfma", "kernel": "k_hgemm_tri_pair_256 x 2 (bf16 apply, 4096 x 4096)",
-                     "achieved": f_issued / t_bf16 / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
-                     "frac": f_issued / t_bf16 / 1e9 / 2500.0, "issued_gflop_per_apply": f_issued / 1e9,
-                     "F_ref_gflop_per_apply": f_big / 1e9,
+        "timing": "every `ms` / `us` / `gflops` below is measured with NEW factors on every call (nothing cached "
+                  "between calls: the reference's update -> apply pattern); `*_unchanged_factors` reuse the prepared "
+                  "factor state",
+        "roofline": {"bound": "mfma", "kernel": "k_hgemm_tri_pair_256 x 2 + factor conversion (bf16 apply, 4096 x 4096)",
+                     "achieved": f_issued / t_bf16_cold / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": f_issued / t_bf16_cold / 1e9 / 2500.0, "issued_gflop_per_apply": f_issued / 1e9,
+                     "F_ref_gflop_per_apply": f_big / 1e9, "ms": t_bf16_cold,
+                     "frac_unchanged_factors": f_issued / t_bf16 / 1e9 / 2500.0,
                      "note": "fraction of the dense bf16 MFMA peak on the flops the kernels ISSUE (triangular zero blocks are "
-                             "skipped: ~0.53 of F_ref), whole call incl. the flag memset; factor copies cached across calls"},
-        "4096x4096_bf16_operands": {"ms": t_bf16, "gflops": f_big / t_bf16 / 1e6, "mfma_peak_gflops": 2.5e6,
-                                    "frac_of_bf16_peak_Fref": f_big / t_bf16 / 1e6 / 2.5e6,
-                                    "frac_of_bf16_peak_issued": f_issued / t_bf16 / 1e6 / 2.5e6,
-                                    "ms_with_factor_conversion": t_bf16_cold,
-                                    "note": "triangular K-ranges skipped: issued flops ~0.53 F_ref; `ms` reuses the bf16 factor "
-                                            "copies (factors unchanged between applies), `ms_with_factor_conversion` rebuilds "
-                                            "them every call (a fresh factor pair per call, as right after an update)",
+                             "skipped: ~0.53 of F_ref), whole call incl. the fp32 -> bf16 factor conversion and the flag memset, "
+                             "new factors every call"},
+        "4096x4096_bf16_operands": {"ms": t_bf16_cold, "gflops": f_big / t_bf16_cold / 1e6, "mfma_peak_gflops": 2.5e6,
+                                    "frac_of_bf16_peak_Fref": f_big / t_bf16_cold / 1e6 / 2.5e6,
+                                    "frac_of_bf16_peak_issued": f_issued / t_bf16_cold / 1e6 / 2.5e6,
+                                    "ms_unchanged_factors": t_bf16, "gflops_unchanged_factors": f_big / t_bf16 / 1e6,
+                                    "note": "triangular K-ranges skipped: issued flops ~0.53 F_ref; `ms` rebuilds the bf16 factor "
+                                            "copies every call (a fresh factor pair per call, as right after an update), "
+                                            "`ms_unchanged_factors` reuses them",
                                     "mfma_pmc": pmc},
-        "4096x4096_fp32": {"ms": t_f32, "gflops": f_big / t_f32 / 1e6, "mfma_peak_gflops": 157.3e3,
-                           "ms_new_factors_every_call": t_f32_cold,
-                           "issued_bf16_gflop_per_apply": f32_issued / 1e9,
-                           "frac_of_bf16_peak_issued": f32_issued / t_f32 / 1e6 / 2.5e6,
+        "4096x4096_fp32": {"ms": t_f32_cold, "gflops": f_big / t_f32_cold / 1e6, "mfma_peak_gflops": 157.3e3,
+                           "ms_unchanged_factors": t_f32, "gflops_unchanged_factors": f_big / t_f32 / 1e6,
+                           "issued_bf16_gflop_per_apply_unchanged_factors": f32_issued / 1e9,
+                           "frac_of_bf16_peak_issued_unchanged_factors": f32_issued / t_f32 / 1e6 / 2.5e6,
                            "note": "fp32-accurate products on the bf16 matrix cores: operands split once into three bf16 planes "
                                    "(x = h + m + l exactly), 6 bf16 MFMAs per product term, K loop = DMA + MFMA (k_gemm_p3); "
-                                   "`issued` counts the 128 x 128 x 32 tile steps the three products run (triangular K ranges "
-                                   "skipped) x 6; `ms` keeps the Gram and factor planes (factors unchanged between applies); "
-                                   "the fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
-        "lenet5_set_fp32": {"us": t_lenet * 1e3, "gflops": f_lenet / t_lenet / 1e6, "bound": "launch/latency",
-                            "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop * 1e3,
-                            "us_new_factors_every_call": t_lenet_cold * 1e3,
-                            "per_layer_calls_new_factors_us": t_lenet_loop_cold * 1e3,
-                            "note": "`us` / `per_layer_calls_us`: factors unchanged between applies (their Grams stay "
-                                    "prepared: 2 launches per call); `*_new_factors*`: every call brings new factors (3 launches)",
+                                   "`issued` counts the 128 x 128 x 32 tile steps the three gradient-side products run (triangular "
+                                   "K ranges skipped) x 6; `ms` makes the Gram (psgd.py:192) and the factor planes inside the call, "
+                                   "`ms_unchanged_factors` keeps them; the fp32 MFMA peak is quoted for reference, it does "
+                                   "not bound this kernel"},
+        "lenet5_set_fp32": {"us": t_lenet_cold * 1e3, "gflops": f_lenet / t_lenet_cold / 1e6, "bound": "launch/latency",
+                            "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop_cold * 1e3,
+                            "us_unchanged_factors": t_lenet * 1e3,
+                            "per_layer_calls_unchanged_factors_us": t_lenet_loop * 1e3,
+                            "note": "`us` / `per_layer_calls_us`: every call brings new factors (3 launches per call); "
+                                    "`*_unchanged_factors*`: the Grams stay prepared (2 launches)",
                             "update_us": t_lenet_upd * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3},
         "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6},
         "4096x4096_bf16_operands_update": {"ms": t_upd_bf16, "gflops": f_upd / t_upd_bf16 / 1e6,
@@ -407,17 +423,104 @@ def launch_ranks(args):
     return proc.returncode if proc.returncode != 0 else (0 if lines else 1)
 
 
+def run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_global, steps, warmup, keep_state=False):
+    """Warm-up + timed steps of the UVd update+apply on this rank's rows: `steps` steps between barrier + synchronize
+    (MAX over ranks), then a second pass of the same steps with the per-kernel HIP event hooks on."""
+    import torch.distributed as dist
+    r = args.rank_r
+    U, V, d, grad, v, h = make_inputs(n_local, n_global, r, dev, seed=1000 * rank)
+    # one step = update then apply on the updated state (psgd.py:732 -> :748).  Default: the fused call
+    # (identical results, one pass over V less); --unfused times the two reference-named calls back to back.
+    mod = sharded if use_dist else psgd
+    if args.unfused:
+        def step(i):
+            mod.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+            return mod.precond_grad_UVd_math(U, V, d, grad)
+    else:
+        def step(i):
+            return mod.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, STEP, TINY, balance=False,
+                                                                update_U=(i % 2 == 0))
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- headline pass: no profiling hooks inside the timed region
+    lib.psgd_prof_enable(0)
+    for i in range(warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all().item(), "non-finite preconditioned gradient"
+    # ---- second pass: the same steps with a HIP event pair around every sweep launch (per-kernel durations)
+    lib.psgd_prof_enable(1)
+    for i in range(steps):
+        step(i)
+    fence()
+    slot_ms = prof_collect(lib)
+    lib.psgd_prof_enable(0)
+    if use_dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    rec = {"elapsed": elapsed, "slot_ms": slot_ms, "n_local": n_local, "n_global": n_global,
+           "ms_per_step": elapsed / steps * 1e3, "value": n_global * steps / elapsed}
+    if keep_state:
+        rec["state"] = (U, V, d, grad, v, h)
+    return rec
+
+
+def exchange_overhead(args, psgd, sharded, lib, dev, rows, steps):
+    """What the multi-GPU path adds to a step on ONE rank's share of BASELINE configs[3] (12.5M rows, r = 20):
+    the fused step run unsharded, then through psgd_tf_amd/sharded.py on a 1-rank RCCL group (same sweeps + 2
+    all-gathers + 2 fold kernels + the r x r kernels as separate stage calls).  The xGMI latency of a W-rank
+    all-gather is not in it (one GPU here); host issue, the collectives' launches and the folds are."""
+    import torch.distributed as dist
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+    try:
+        res = {}
+        for name, use_dist in (("unsharded", False), ("sharded_1rank", True), ("unsharded_again", False)):
+            rec = run_uvd(args, psgd, sharded, lib, dev, 0, 1, use_dist, rows, rows, steps, 10)
+            res[name] = rec["ms_per_step"]
+            torch.cuda.empty_cache()
+        base = min(res["unsharded"], res["unsharded_again"])
+        return {"rows": rows, "r": args.rank_r, "steps": steps, "unsharded_ms": base,
+                "sharded_1rank_rccl_ms": res["sharded_1rank"], "added_us_per_step": (res["sharded_1rank"] - base) * 1e3,
+                "added_frac_of_step": (res["sharded_1rank"] - base) / base,
+                "backend": dist.get_backend(), "runs_ms": res,
+                "note": "one rank's share of BASELINE configs[3] (100M rows / 8); 1-rank RCCL group on this GPU: host "
+                        "issue + 2 all-gather launches + 2 fold kernels per step, no xGMI hop"}
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="rows of the flat parameter vector per GPU")
+    ap.add_argument("--rows", type=int, default=None,
+                    help="weak scaling: rows of the flat parameter vector PER GPU (global = rows x gpus)")
+    ap.add_argument("--global-rows", type=int, default=None,
+                    help="strong scaling: global rows, split over the ranks in contiguous blocks (default 100M = BASELINE configs[3])")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1 default mode: skip the 100M-rows-per-GPU weak sub-record")
+    ap.add_argument("--no-exchange-leg", action="store_true", help="N = 1: skip the exchange_overhead leg (1-rank RCCL group)")
     ap.add_argument("--rank-r", type=int, default=20, help="rank of modification r")
     ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="fix the thread count of the CPU baseline (0 = sweep)")
-    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the full --rows (needs ~45 B/param of host RAM x r/20)")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the full row count (needs ~45 B/param of host RAM x r/20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kron", action="store_true", help="skip the Kron apply GFLOP/s and sparse-LU legs")
     ap.add_argument("--no-legs", action="store_true", help="skip the apply-alone / update-alone / config-2 legs")
@@ -427,6 +530,8 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU code path (process group + exchanges) even at world size 1")
     args = ap.parse_args()
+    if args.rows is not None and args.global_rows is not None:
+        raise SystemExit("--rows (weak) and --global-rows (strong) are exclusive")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))            # before anything touches a GPU
@@ -461,65 +566,44 @@ def main():
     if args.bpc:
         lib.psgd_set_tuning(1, args.bpc)
 
-    n_local, r = args.rows, args.rank_r
-    n_global = n_local * world
-    U, V, d, grad, v, h = make_inputs(n_local, n_global, r, dev, seed=1000 * rank)
-
-    # one step = update then apply on the updated state (psgd.py:732 -> :748).  Default: the fused call
-    # (identical results, one pass over V less); --unfused times the two reference-named calls back to back.
-    mod = sharded if use_dist else psgd
-    if args.unfused:
-        def step(i):
-            mod.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
-            return mod.precond_grad_UVd_math(U, V, d, grad)
+    r = args.rank_r
+    # ---- which rows (see the module docstring)
+    weak_leg_rows = None
+    if args.rows is not None:
+        scaling, n_local, n_global = "weak", args.rows, args.rows * world
     else:
-        def step(i):
-            return mod.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, STEP, TINY, balance=False,
-                                                                update_U=(i % 2 == 0))
+        n_global = args.global_rows if args.global_rows is not None else 100_000_000
+        lo, hi = sharded.shard_rows(n_global, rank, world)
+        scaling, n_local = ("strong" if world > 1 or args.global_rows is not None else "weak"), hi - lo
+        if args.global_rows is None and world > 1 and not args.no_weak_leg:
+            weak_leg_rows = 100_000_000
+    if n_local < 1:
+        raise SystemExit("rank %d would hold no rows (global %d over %d ranks)" % (rank, n_global, world))
 
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # ---- headline pass: no profiling hooks inside the timed region
-    lib.psgd_prof_enable(0)
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out).all().item(), "non-finite preconditioned gradient"
-    # ---- second pass: the same steps with a HIP event pair around every sweep launch (per-kernel durations)
-    lib.psgd_prof_enable(1)
-    for i in range(args.steps):
-        step(i)
-    fence()
-    slot_ms = prof_collect(lib)
-    lib.psgd_prof_enable(0)
-
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    main_rec = run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_global, args.steps, args.warmup,
+                       keep_state=(world == 1 and not args.no_legs))
+    state = main_rec.pop("state", None)
+    weak_rec = None
+    if weak_leg_rows:
+        torch.cuda.empty_cache()
+        weak_rec = run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, weak_leg_rows, weak_leg_rows * world,
+                           args.steps, args.warmup)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_global * args.steps / elapsed
+        slot_ms, ms_per_step, value = main_rec["slot_ms"], main_rec["ms_per_step"], main_rec["value"]
         kbytes = uvd_bytes(r, not args.unfused)
         kern = {k: {"avg_ms": slot_ms[k], "achieved_GBs": kbytes[k] * n_local / (slot_ms[k] * 1e-3) / 1e9}
                 for k in kbytes if slot_ms[k]}
         dom = "update_s2"
-        traffic = None
+        traffic, traffic_source = None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 rec = json.load(open(tp)).get("k_update_s2")
                 if rec and rec.get("rows") == n_local and rec.get("r") == r:
                     traffic = rec["hbm_bytes_per_launch"]
+                    traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on an earlier "
+                                      "box (%s), NOT counters of this run" % rec.get("source", "see profiles/README.md"))
             except Exception:
                 traffic = None
         ach = kern[dom]["achieved_GBs"]
@@ -531,14 +615,22 @@ def main():
                  "step": {"alg_bytes_per_param": alg_step, "moved_bytes_per_param": moved_step, "wall_ms": ms_per_step,
                           "frac": gbs(alg_step) / HBM_PEAK_GBS, "frac_moved": gbs(moved_step) / HBM_PEAK_GBS,
                           "kernel_ms": sum(slot_ms[k] or 0.0 for k in slot_ms)}}
+        if scaling == "strong":
+            what = "N=%d rows global split over %d GPU(s) in contiguous row blocks (%d on rank 0)" % (n_global, world, n_local)
+        else:
+            what = "N=%d rows per GPU" % n_local
         res = {
             "metric": "uvd_update_apply_params_per_sec", "value": value, "unit": "params/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "UVd preconditioner update+apply (update_precond_UVd_math_ then "
-                                   "precond_grad_UVd_math%s), N=%d rows per GPU, r=%d"
-                                   % ("" if args.unfused else ", fused call", n_local, r),
+                                   "precond_grad_UVd_math%s), %s, r=%d"
+                                   % ("" if args.unfused else ", fused call", what, r),
                        "rows_per_gpu": n_local, "rows_global": n_global, "rank_of_modification": r,
+                       "baseline_config": ("configs[3]: UVd N=100M, r=20, flat-vector sharded" if
+                                           (scaling == "strong" and n_global == 100_000_000 and r == 20 and world > 1) else
+                                           ("metric config: UVd N=100M, r=20, 1 GPU" if
+                                            (n_global == 100_000_000 and r == 20 and world == 1) else None)),
                        "parallelism": ("row-sharded x%d, per step %d all-gathers of r-dim reduced buffers (<= 30 KB) + "
                                        "rank-order fold" % (world, 4 if args.unfused else 2)) +
                                       (" [TEST MODE: all ranks on one GPU, gloo -- not a measurement]" if single_dev else ""),
@@ -546,16 +638,31 @@ def main():
                        "step": STEP, "branches": "balance=0, update_U alternating"},
             "roofline": {"bound": "hbm", "kernel": "k_update_s2 (update sweep 2, dominant kernel)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "alg_bytes_per_launch": kbytes[dom] * n_local,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "alg_bytes_per_launch": kbytes[dom] * n_local,
                          "avg_launch_ms": slot_ms[dom], "kernels": kern, "paths": paths,
                          "timing": "headline pass without profiling hooks; kernel durations from a second pass of the "
                                    "same steps with HIP event pairs on the launch stream"},
         }
+        if weak_rec is not None:
+            wk = weak_rec["slot_ms"]
+            res["weak"] = {"scaling": "weak", "value": weak_rec["value"], "unit": "params/s",
+                           "ms_per_step": weak_rec["ms_per_step"], "rows_per_gpu": weak_rec["n_local"],
+                           "rows_global": weak_rec["n_global"], "steps": args.steps, "warmup": args.warmup,
+                           "frac_of_hbm_roofline_per_gpu": alg_step * weak_rec["n_local"] /
+                           (weak_rec["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "kernels_ms": {k: wk[k] for k in kbytes if wk[k]}}
         if world == 1:
-            if not args.no_legs:
-                legs = uvd_legs(dev, psgd, lib, (U, V, d, grad, v, h), r, max(5, min(args.steps, 20)))
+            if state is not None:
+                legs = uvd_legs(dev, psgd, lib, state, r, max(5, min(args.steps, 20)))
                 paths["apply"], paths["update"], paths["step_fused_events"] = legs["apply"], legs["update"], legs["step_fused"]
-            del U, V, d, grad, v, h, out
+                # the two reference-named calls back to back, next to the fused entry point the headline uses
+                two = legs["update"]["wall_ms"] + legs["apply"]["wall_ms"]
+                paths["step_two_reference_calls"] = {
+                    "wall_ms": two, "params_per_s": n_local / (two * 1e-3),
+                    "frac": alg_step * n_local / (two * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "call": "update_precond_UVd_math_ then precond_grad_UVd_math (psgd.py:732, :748), separately timed"}
+            state = None
             torch.cuda.empty_cache()
             if not args.no_legs:
                 c2 = make_inputs(1_000_000, 1_000_000, 10, dev, seed=7)
@@ -564,6 +671,13 @@ def main():
                                  "launch/latency-bound; fractions are against the HBM roof for reference only")
                 res["config2_N1M_r10"] = legs2
                 del c2
+                torch.cuda.empty_cache()
+            if not args.no_exchange_leg and not single_dev and not args.force_sharded:
+                try:
+                    res["exchange_overhead"] = exchange_overhead(args, psgd, sharded, lib, dev,
+                                                                 sharded.shard_rows(100_000_000, 0, 8)[1], 200)
+                except Exception as e:                      # a leg, never the headline: report, do not fail the line
+                    res["exchange_overhead"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
             if not args.no_kron:
                 res["kron"] = kron_bench(dev, psgd)

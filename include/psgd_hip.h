@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define PSGD_ABI_VERSION 1
+/* History: 1 = round 1; 2 = round 2 (psgd_uvd_fused_s1_f32 removed, SUMS region of stage 13 holds 4r entries,
+ * workspace layout changed); 3 = round 3 (entry points added, bf16 apply workspace carries a hand-off route word).
+ * psgd_tf_amd/_lib.py refuses a library whose psgd_abi_version() differs from the one it was written for. */
+#define PSGD_ABI_VERSION 3
 
 #define PSGD_OK                 0
 #define PSGD_ERR_BAD_ARG       (-1)   /* null pointer, N <= 0, r <= 0 ...            */

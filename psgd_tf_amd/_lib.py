@@ -13,6 +13,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PSGD_HIP_LIB", os.path.join(_CSRC, "libpsgd_hip.so"))   # override: build experiments only
 
 PSGD_OK = 0
+PSGD_ABI_VERSION = 3       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
 PSGD_WS_SUMS_F64 = 0
 PSGD_WS_MAX_F32 = 1
 PSGD_WS_SEND_F64 = 2
@@ -149,8 +150,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.psgd_abi_version() != 1:
-            raise PsgdHipError("libpsgd_hip.so ABI version mismatch")
+        if lib.psgd_abi_version() != PSGD_ABI_VERSION:
+            raise PsgdHipError("libpsgd_hip.so ABI version mismatch: %s reports %d, this binding needs %d (rebuild with "
+                               "`make -C psgd_tf_amd/csrc`)" % (LIB_PATH, lib.psgd_abi_version(), PSGD_ABI_VERSION))
         _lib = lib
     return _lib
 

@@ -27,4 +27,24 @@ KronFork* kron_fork(hipStream_t main);
 int kron_join(KronFork* f, hipStream_t main);          // 0 on success
 bool kron_overlap_chains(int M, int N);                // tuning key 9 and the shape rule
 
+// Joins on every exit path: once a fork succeeded, `main` waits for the side chain whether the function returns through
+// join() or through an early error return -- the side stream must never be left writing the workspace behind the caller's
+// back, and an unjoined stream would invalidate a capture of `main`.  The fork/join events are per (device, caller
+// stream): the entry points that fork are single-threaded per stream (two host threads must not issue on one stream).
+struct KronForkScope {
+  KronFork* f;
+  hipStream_t main;
+  bool joined;
+  KronForkScope(KronFork* f_, hipStream_t m) : f(f_), main(m), joined(false) {}
+  KronForkScope(const KronForkScope&) = delete;
+  KronForkScope& operator=(const KronForkScope&) = delete;
+  int join() {
+    joined = true;
+    return f ? kron_join(f, main) : 0;
+  }
+  ~KronForkScope() {
+    if (f && !joined) (void)kron_join(f, main);
+  }
+};
+
 }  // namespace psgdk

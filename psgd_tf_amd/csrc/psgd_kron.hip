@@ -2816,6 +2816,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   const bool solves_on_planes = planes && (M > 2048 || N > 2048);
   if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st));
   KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
+  KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
   hipStream_t sf = fk ? fk->side : st;
   if (planes) {
     if (!solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, sf));
@@ -2836,7 +2837,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, nullptr, nullptr, true));
     KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, nullptr, nullptr, true));
   }
-  if (fk) KRON_LAUNCH(kron_join(fk, st));
+  KRON_LAUNCH(fork_scope.join());
   if (planes) {
     KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st));
     return PSGD_OK;
@@ -3143,6 +3144,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
   SP_LAUNCH(k_balance_generic, ew_grid((long)M * M), Ql, (long)M + 1, M, (long)M * M, qr, 1L, N, (long)N, k.LS, k.RS);
   // the product of :295-296 on the side stream next to the solve of :298-299 (kron_fork: they meet at the gradient)
   KronFork* fk = kron_overlap_chains(M, M) ? kron_fork(st) : nullptr;
+  KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
   {                                                          // A = (QlS dG) .* qrS          (:295-296)
     GemmArgs g = gemm_args(k.LS, M, false, dG, 0, false, k.A, N, M, N, M, KLO_M);
     g.b_rs = xrs; g.b_cs = xcs;
@@ -3152,7 +3154,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
   // Bt = (QlS^-T dX) .* (1/qrS)                             (:298-299); columns independent
   KRON_LAUNCH(trsm_ut(k.LS, M, dX, k.Bt, N, 1L, (long)N, k.dinv, st, (long)xcs, (long)xrs));
   SP_LAUNCH(k_col_inv_scale, ew_grid((long)M * N), k.Bt, k.RS, M, N);
-  if (fk) KRON_LAUNCH(kron_join(fk, st));
+  KRON_LAUNCH(fork_scope.join());
   if (k.P0 && g_planes && g_gemm_x3) {                       // grad1 = triu(A A' - Bt Bt')  (:301): few tiles, long K
     KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.Bt, (long)N, 1L, M, N, k.gsq, k.scal, st));
   } else {
@@ -3224,6 +3226,7 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
   // two chains that meet at the row statistics: T = Ql dG -> A = T QrS' (:218-220) on the side stream (kron_fork),
   // Bt = Ql^-T dX -> Bt QrS^-1 (:222-233, solved in place) on the caller's
   KronFork* fk = kron_overlap_chains(N, N) ? kron_fork(st) : nullptr;
+  KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
   {
     hipStream_t sf = fk ? fk->side : st;
     MatView vg = {dG, xrs, xcs};
@@ -3238,7 +3241,7 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
     SP_LAUNCH(k_norm_left_invT, ew_grid((long)M * N), vx, (const float*)k.LS, (const float*)k.v0, M, N, (const float*)nullptr, k.Bt);
   }
   KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.Bt, M, (long)N, 1L, k.dinv, st));                   // Bt QrS^-1, in place  (:233)
-  if (fk) KRON_LAUNCH(kron_join(fk, st));
+  KRON_LAUNCH(fork_scope.join());
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.Bt, M, N, k.v1, k.v2);   // (:235-237)
   SP_LAUNCH_WIDE(k_norm_finalize, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
   if (k.P0 && g_planes && g_gemm_x3) {                       // grad2 = triu(A'A - Bt'Bt)     (:243): few tiles, long K

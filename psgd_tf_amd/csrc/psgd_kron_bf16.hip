@@ -917,7 +917,10 @@ static HWs hws_layout(char* base, int M, int N) {
 
 static int g_two_pairs = 1;       // tuning key 1: 0 = keep the Gram-first chain even where two fused pairs are possible
 static unsigned g_spin_limit = 1u << 22;   // psgd_kron_bf16_set_tuning key 2 (log2): hand-off polls before a consumer gives up
-static int g_trsm_lite = 1;        // psgd_kron_bf16_set_tuning key 3 (experiment)
+static int g_trsm_lite = 1;        // psgd_kron_bf16_set_tuning key 3: 1 = the trailing PRODUCTS of the blocked solves keep the three
+                                   // leading terms of the bf16 x 3 split (2^-16 per product, below the 2^-9 rounding dX arrives
+                                   // with); 0 = all six terms (fp32-level).  Strip substitutions and diagonal-block inverses are
+                                   // fp32 either way.  tests/test_kron_gpu.py::test_bf16_update_solves_with_ill_conditioned_factors
 static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, fused triangular pair when every
                                   //    tile gets its own CU, else 128^2 register-staged); 4: auto without the fused pair;
                                   // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
@@ -1209,8 +1212,11 @@ int64_t psgd_kron_dd_update_workspace_bytes_bf16(int M, int N) {
 }
 
 /* update_precond_kron dense (x) dense (psgd.py:160-180) with bf16 matrix-core operands.  fp32 master factors in and
- * out; dX, dG arrive in bf16.  What stays fp32: the balance (:166-170), both triangular solves of :174 (their
- * conditioning is the factors'), the max-norms, the step sizes and the final subtraction Q - step * grad * Q.
+ * out; dX, dG arrive in bf16.  What stays fp32: the balance (:166-170), the triangular solves of :174 (fp32 strip
+ * substitutions on fp32 inverted diagonal blocks; the trailing products BETWEEN strips run on bf16 x 3 splits of fp32
+ * operands with the three leading terms kept -- 2^-16 relative per product, 128x finer than the bf16 rounding of dX
+ * itself; psgd_kron_bf16_set_tuning(3, 0) keeps all six terms), the max-norms, the step sizes and the final
+ * subtraction Q - step * grad * Q.
  * What runs on bf16 operands with fp32 accumulation: A = QlS dG QrS' (:173), the four Grams of :175-176 (two launches:
  * each gradient is ONE symmetric product over a concatenated K axis, [Bt | A][Bt | A]' with the accumulators negated
  * between the halves) and grad * Q of :179-180. */
@@ -1233,6 +1239,7 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, nullptr, k.dinv));          // :166-170 (+ the solves' inverted diagonal blocks)
   // the bf16 products of :173 go to the side stream (kron_shared.h), the fp32 solves of :174 stay on the caller's
   psgdk::KronFork* fk = psgdk::kron_overlap_chains(M, N) ? psgdk::kron_fork(st) : nullptr;
+  psgdk::KronForkScope fork_scope(fk, st);   // joins on every exit path, early error returns included
   hipStream_t sf = fk ? fk->side : st;
   {
     dim3 grid((max(M, N) + 63) / 64, (max(M, N) + 63) / 64, 2);
@@ -1255,7 +1262,7 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   }
   HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite, true));
   HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv + (long)((N + 31) / 32) * 1024, st, g_trsm_lite, true));
-  if (fk) HK(psgdk::kron_join(fk, st));
+  HK(fork_scope.join());
   HK(launch_cvt(k.Bt, 0, N, k.W1, ld1, M, N, 0, st));                                 // Bt  -> first half of W1
   HK(launch_cvt(k.Bt, 0, N, k.W2, ld2, M, N, 1, st));                                 // Bt' -> first half of W2
   // grad1 = triu(A A' - Bt Bt'), grad2 = triu(A'A - Bt'Bt)                                          (:175-176)

@@ -65,6 +65,49 @@ def _check_kron_shapes(name, Ql, Qr, *mats):
             raise ValueError("%s: all tensors must be on one device, got %s and %s" % (name, dev, t.device))
 
 
+# Prepared factor-only state (the Grams of the fp32 apply, the bf16 factor copies, padded factors) is reused by the
+# next apply when the factor tensors are the very objects it was made from, at the same version and address.  That is
+# exact for the reference's call pattern (update_precond_kron returns NEW tensors, mnist_with_lenet5.py:51-52) and for
+# version-tracked in-place ops (Q.mul_(), Q.copy_(), Q[...] = ...).  It cannot see writes that bypass the version
+# counter: `Q.data.mul_()`, DLPack / raw-pointer kernels writing into the same storage.  Callers that do that must call
+# invalidate_factor_cache() after the write, or switch the reuse off with set_factor_cache(False).  The reuse is also
+# off while the current stream is being captured into a graph: the prepared-or-not decision would be frozen into the
+# graph, and replays after an in-graph factor update would read stale Grams.
+_factor_cache_enabled = True
+_factor_cache_epoch = 0
+
+
+def set_factor_cache(enabled):
+    """Switch the reuse of prepared factor-only state across applies on or off (default on).  Returns the old value."""
+    global _factor_cache_enabled
+    old, _factor_cache_enabled = _factor_cache_enabled, bool(enabled)
+    invalidate_factor_cache()
+    return old
+
+
+def invalidate_factor_cache():
+    """Forget every prepared Gram / bf16 factor copy / padded factor: the next apply of every shape rebuilds them.  Call
+    after modifying factor tensors in a way the version counter does not see (`Q.data`, external kernels)."""
+    global _factor_cache_epoch
+    _factor_cache_epoch += 1
+    _prepared.clear()
+    _bf16_prepared.clear()
+    _padded_factors.clear()
+    for slot in _apply_slots.values():
+        slot.rl = slot.rr = None
+
+
+def _cache_usable():
+    return _factor_cache_enabled and not torch.cuda.is_current_stream_capturing()
+
+
+def _version_of(t):
+    try:
+        return t._version
+    except RuntimeError:              # inference-mode tensors do not track versions: never a hit
+        return None
+
+
 class _FactorTag:
     """Identity of the factor tensors some prepared, factor-only data (Grams, bf16 copies) in a workspace was made
     from: the very tensor objects (weak references), their version counters and their storage pointers.  A new tensor
@@ -72,10 +115,10 @@ class _FactorTag:
 
     def __init__(self, tensors):
         self.refs = [weakref.ref(t) for t in tensors]
-        self.meta = [(t._version, t.data_ptr()) for t in tensors]
+        self.meta = [(_version_of(t), t.data_ptr()) for t in tensors]
 
     def matches(self, tensors):
-        return len(tensors) == len(self.refs) and all(r() is t and m == (t._version, t.data_ptr())
+        return len(tensors) == len(self.refs) and all(r() is t and m[0] is not None and m == (_version_of(t), t.data_ptr())
                                                       for r, m, t in zip(self.refs, self.meta, tensors))
 
 
@@ -84,7 +127,7 @@ _prepared = {}            # workspace key -> _FactorTag of the Grams it holds (f
 
 def _is_prepared(key, tensors):
     tag = _prepared.get(key)
-    return tag is not None and tag.matches(tensors)
+    return tag is not None and tag.matches(tensors) and _cache_usable()
 
 
 # --------------------------------------------------------------------------- dense (x) dense: HIP
@@ -138,8 +181,8 @@ _PADDED_FACTORS_MAX = 8
 
 def _padded_bf16_problem(Ql, Qr, mats, apply=False):
     """The bf16 kernels move 16-byte chunks (8 elements) along every K axis.  Other shapes run zero-padded
-    (_bf16_pad_shape): factors become blockdiag(Q, tiny I) (the smallest positive normal on the new diagonal keeps the
-    padded factor triangular and invertible and cannot win the max of psgd.py:166-167), data matrices get zero rows
+    (_bf16_pad_shape): factors become blockdiag(Q, c I) (c = tiny for the apply, max|diag Q| for the update: triangular,
+    invertible at the factor's own scale, and it cannot win the max of psgd.py:166-167), data matrices get zero rows
     and columns.  Every product and solve of psgd.py:156-192 is then block diagonal: the leading M x N (M x M, N x N)
     block of each result is the unpadded result, the rest is zero (or tiny I).  For the apply the padded factors are
     kept while the original ones are unchanged (same tensor objects and versions), so that their bf16 copies in the
@@ -152,14 +195,19 @@ def _padded_bf16_problem(Ql, Qr, mats, apply=False):
             return Q
         Qp = torch.zeros(n_p, n_p, dtype=Q.dtype, device=Q.device)
         Qp[:n, :n] = Q
-        Qp.diagonal()[n:] = _tiny
+        # apply: the pad block only ever multiplies zero data, any finite value does.  update: the pad diagonal goes
+        # through the balance (x rho or / rho, psgd.py:166-170) and is then INVERTED by the solves of :174, so it must
+        # be of the factor's own magnitude -- tiny / rho overflowed to inf for rho >= 4 and turned both new factors
+        # into NaN.  max|diag Q| cannot raise the max of :166-167 (it is one of the entries the max runs over) and the
+        # pad block stays decoupled: its rows of A and Bt are zero, so its gradient block is zero.
+        Qp.diagonal()[n:] = _tiny if apply else Q.diagonal().abs().max()
         return Qp
     pads = [torch.nn.functional.pad(x, (0, Np - N, 0, Mp - M)) for x in mats]
     if not apply:
         return factor(Ql, M, Mp), factor(Qr, N, Np), pads
     key = (Ql.device.index, M, N, Mp, Np, _stream_key(Ql.device))
     hit = _padded_factors.get(key)
-    if hit is not None and hit[0].matches((Ql, Qr)):
+    if hit is not None and hit[0].matches((Ql, Qr)) and _cache_usable():
         _padded_factors.move_to_end(key)
         return hit[1], hit[2], pads
     Qlp, Qrp = factor(Ql, M, Mp), factor(Qr, N, Np)
@@ -254,7 +302,7 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     # The bf16 copies of the factors live in the workspace and only change when the factors do: convert again only if
     # these are not the very tensor objects (same storage, same version counter) the copies were made from.
     tag = _bf16_prepared.get(key)
-    if not (tag is not None and tag.matches((Ql, Qr))):
+    if not (tag is not None and tag.matches((Ql, Qr)) and _cache_usable()):
         _lib.check(lib.psgd_kron_bf16_prepare_factors(Ql.data_ptr(), Qr.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st),
                    "psgd_kron_bf16_prepare_factors")
         _bf16_prepared[key] = _FactorTag((Ql, Qr))
@@ -303,8 +351,9 @@ def _precond_grad_dense_dense(Ql, Qr, Grad):
     pl, pr = Ql.data_ptr(), Qr.data_ptr()
     # factor-only half (the Grams, kept in the workspace): redone only when these are not the very factor tensors (same
     # objects, same version counters, same storage) it was made from
-    if (slot.rl is not None and slot.rl() is Ql and slot.rr() is Qr and slot.vl == Ql._version and slot.vr == Qr._version
-            and slot.pl == pl and slot.pr == pr):
+    vl, vr = _version_of(Ql), _version_of(Qr)
+    if (slot.rl is not None and slot.rl() is Ql and slot.rr() is Qr and slot.vl == vl and slot.vr == vr and vl is not None
+            and vr is not None and slot.pl == pl and slot.pr == pr and _cache_usable()):
         rc = lib.psgd_kron_dd_apply_prepared_f32(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
         if rc:
             _lib.check(rc, "psgd_kron_dd_apply_prepared_f32")
@@ -313,7 +362,7 @@ def _precond_grad_dense_dense(Ql, Qr, Grad):
         if rc:
             _lib.check(rc, "psgd_kron_dd_apply_f32")
         slot.rl, slot.rr = weakref.ref(Ql), weakref.ref(Qr)
-        slot.vl, slot.vr, slot.pl, slot.pr = Ql._version, Qr._version, pl, pr
+        slot.vl, slot.vr, slot.pl, slot.pr = vl, vr, pl, pr
     return out
 
 

@@ -29,7 +29,12 @@ def test_bench_single_gpu_line(hip_lib):
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["metric"] == "uvd_update_apply_params_per_sec" and d["unit"] == "params/s" and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 4000000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"} <= set(d["roofline"])
+    ex = d["exchange_overhead"]             # one rank's share of configs[3] unsharded vs through the 1-rank RCCL path
+    assert "error" not in ex, ex
+    assert ex["rows"] == 12500032 and ex["unsharded_ms"] > 0 and ex["sharded_1rank_rccl_ms"] > 0 and ex["backend"] == "nccl"
+    two = d["roofline"]["paths"]["step_two_reference_calls"]
+    assert two["wall_ms"] > 0 and two["params_per_s"] > 0
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     # the legs the north star names: apply alone and update alone with their own kernel times and non-null fractions,
     # the fused step on bytes moved as well as on SURVEY's algorithmic bytes, and config 2 (N = 1M, r = 10)
@@ -60,6 +65,42 @@ def test_bench_two_ranks_self_launched(hip_lib):
     assert d["config"]["rccl_ranks"] == 2 and d["config"]["collective_backend"] == "gloo"
     assert "TEST MODE" in d["config"]["parallelism"]
     assert abs(d["value"] - 8000000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_default_is_baseline_config3(hip_lib):
+    """`python bench.py --gpus 2` with no row flags = BASELINE configs[3]: N_global = 100M rows, r = 20, split over the
+    ranks in contiguous row blocks (strong scaling), plus the 100M-rows-per-GPU weak sub-record.  Test mode (both ranks
+    on the one GPU, gloo): checks the workload, not the speed."""
+    env = dict(os.environ, PSGD_BENCH_SINGLE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=880)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["rows_global"] == 100_000_000 and d["config"]["rows_per_gpu"] == 50_000_000
+    assert d["config"]["rank_of_modification"] == 20 and d["config"]["baseline_config"].startswith("configs[3]")
+    assert abs(d["value"] - 100_000_000 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    w = d["weak"]
+    assert w["scaling"] == "weak" and w["rows_per_gpu"] == 100_000_000 and w["rows_global"] == 200_000_000
+    assert abs(w["value"] - 200_000_000 * 2 / (w["ms_per_step"] * 2e-3)) < 1e-6 * w["value"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_strong_ragged(hip_lib):
+    """--global-rows that does not divide: rank blocks start at multiples of 64 rows, the last rank holds the rest."""
+    env = dict(os.environ, PSGD_BENCH_SINGLE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--global-rows", "5000001"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=580)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["scaling"] == "strong" and d["config"]["rows_global"] == 5000001 and d["config"]["rows_per_gpu"] == 2500032
+    assert "weak" not in d
+    assert abs(d["value"] - 5000001 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
 
 
 @pytest.mark.timeout(600)

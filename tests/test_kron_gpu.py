@@ -484,6 +484,127 @@ def test_dense_dense_update_bf16(psgd, M, N):
     assert rel_err(Qr_new.cpu().numpy(), Qr32.cpu().numpy()) < BF16_UPD_STATE_TOL
 
 
+@pytest.mark.parametrize("M,N", [(260, 133), (85, 10), (1027, 515)])
+@pytest.mark.parametrize("scale", [100.0, 0.01])
+def test_bf16_padded_update_with_unbalanced_factors(psgd, M, N, scale):
+    """Shapes that are not multiples of 8 run zero-padded.  The pad diagonal goes through the balance of psgd.py:166-170
+    and is inverted by the solves of :174: with tiny on it, max diag(Ql) / max diag(Qr) outside (1/16, 16) overflowed
+    the inverse and every entry of both new factors came back NaN.  Ql scaled by 100 and by 0.01."""
+    rng = np.random.default_rng(7 * M + N)
+    Ql, Qr = (_tri_factor(rng, M) * scale).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    dX = rng.standard_normal((M, N))
+    dXb = torch.from_numpy(dX.astype(np.float32)).cuda().to(torch.bfloat16)
+    dGb = torch.from_numpy((dX * np.exp(rng.uniform(-1, 1, (M, 1)))).astype(np.float32)).cuda().to(torch.bfloat16)
+    Ql_new, Qr_new = psgd.update_precond_kron(_dev(Ql), _dev(Qr), dXb, dGb, 0.01)
+    assert Ql_new.shape == (M, M) and Qr_new.shape == (N, N)
+    assert torch.isfinite(Ql_new).all() and torch.isfinite(Qr_new).all()
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    rl, rr = orc.update_precond_kron(Ql.astype(np.float64), Qr.astype(np.float64), f64(dXb), f64(dGb), 0.01)
+    assert rel_err(Ql_new.cpu().numpy(), rl) < BF16_UPD_STATE_TOL
+    assert rel_err(Qr_new.cpu().numpy(), rr) < BF16_UPD_STATE_TOL
+    rho = np.sqrt(np.max(np.abs(Ql.astype(np.float64))) / np.max(np.abs(Qr.astype(np.float64))))
+    assert rel_err(f64(Ql_new) - Ql / rho, rl - Ql / rho) < BF16_UPD_TOL
+    assert rel_err(f64(Qr_new) - Qr * rho, rr - Qr * rho) < BF16_UPD_TOL
+
+
+@pytest.mark.parametrize("M,N", [(1104, 528), (2048, 1536)])
+def test_bf16_update_solves_with_ill_conditioned_factors(psgd, hip_lib, M, N):
+    """The bf16-operand update keeps its triangular solves (psgd.py:174) in fp32 except for the trailing PRODUCTS between
+    strips, which by default keep three of the six bf16 x 3 split terms (2^-16 per product; tuning key 3).  With
+    cond(Q) ~ 1e4 factors (the conditioning multiplies whatever the products lose) the default must agree with the
+    all-six-terms solve far inside the bf16 bars, and both with the fp64 oracle on the bf16-rounded data."""
+    rng = np.random.default_rng(M + 13 * N)
+
+    def illcond(n):
+        d = np.exp(np.linspace(0.0, -np.log(1e4), n))
+        rng.shuffle(d)
+        return np.triu(rng.standard_normal((n, n)) * (0.3 / n ** 0.5), 1) * d[None, :] + np.diag(d)
+    Ql, Qr = illcond(M).astype(np.float32), illcond(N).astype(np.float32)
+    assert 3e3 < np.linalg.cond(Ql.astype(np.float64)) < 1e6 and 3e3 < np.linalg.cond(Qr.astype(np.float64)) < 1e6
+    dX = rng.standard_normal((M, N))
+    dG = np.linalg.solve(Ql.T.astype(np.float64) @ Ql, dX) @ np.linalg.inv(Qr.T.astype(np.float64) @ Qr) \
+        * np.exp(rng.uniform(-0.5, 0.5, (1, N)))
+    dXb = torch.from_numpy(dX.astype(np.float32)).cuda().to(torch.bfloat16)
+    dGb = torch.from_numpy(dG.astype(np.float32)).cuda().to(torch.bfloat16)
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    res = {}
+    try:
+        for lite in (1, 0):
+            hip_lib.psgd_kron_bf16_set_tuning(3, lite)
+            res[lite] = [f64(t) for t in psgd.update_precond_kron(_dev(Ql), _dev(Qr), dXb, dGb, 0.01)]
+    finally:
+        hip_lib.psgd_kron_bf16_set_tuning(3, 1)
+    rl, rr = orc.update_precond_kron(Ql.astype(np.float64), Qr.astype(np.float64), f64(dXb), f64(dGb), 0.01)
+    rho = np.sqrt(np.max(np.abs(Ql.astype(np.float64))) / np.max(np.abs(Qr.astype(np.float64))))
+    for i, (ref, q0) in enumerate(((rl, Ql.astype(np.float64) / rho), (rr, Qr.astype(np.float64) * rho))):
+        for lite in (1, 0):
+            assert np.isfinite(res[lite][i]).all()
+            assert rel_err(res[lite][i], ref) < BF16_UPD_STATE_TOL
+            assert rel_err(res[lite][i] - q0, ref - q0) < BF16_UPD_TOL
+        # three-term against six-term trailing products: an order of magnitude inside the bf16 increment bar
+        assert rel_err(res[1][i] - q0, res[0][i] - q0) < 0.1 * BF16_UPD_TOL
+
+
+def test_prepared_factor_state_rules(psgd):
+    """The reuse of prepared factor-only state (kron.py): version-tracked in-place writes are seen; writes through
+    `.data` are not (documented) until invalidate_factor_cache(); set_factor_cache(False) switches the reuse off;
+    inference-mode tensors (no version counter) work and never hit."""
+    from psgd_tf_amd import kron
+    rng = np.random.default_rng(11)
+    for M, N, dt in ((257, 120, torch.float32), (1280, 1024, torch.float32), (512, 256, torch.bfloat16)):
+        tol = TOL if dt == torch.float32 else 2e-2
+        Ql, Qr = _dev(_tri_factor(rng, M)), _dev(_tri_factor(rng, N))
+        G = _dev(rng.standard_normal((M, N))).to(dt)
+        ref = lambda: orc.precond_grad_kron(*(t.float().cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
+        o1 = psgd.precond_grad_kron(Ql, Qr, G)
+        assert rel_err(o1.float().cpu().numpy(), ref()) < tol
+        Ql.mul_(1.5)                                           # version-tracked: seen
+        assert rel_err(psgd.precond_grad_kron(Ql, Qr, G).float().cpu().numpy(), ref()) < tol
+        Qr.data.mul_(0.5)                                      # bypasses the version counter: stale until invalidated
+        kron.invalidate_factor_cache()
+        assert rel_err(psgd.precond_grad_kron(Ql, Qr, G).float().cpu().numpy(), ref()) < tol
+        old = kron.set_factor_cache(False)
+        try:
+            assert old is True
+            Qr.data.mul_(2.0)                                  # reuse off: every call rebuilds, nothing can be stale
+            assert rel_err(psgd.precond_grad_kron(Ql, Qr, G).float().cpu().numpy(), ref()) < tol
+            Ql.data.mul_(0.7)
+            assert rel_err(psgd.precond_grad_kron(Ql, Qr, G).float().cpu().numpy(), ref()) < tol
+        finally:
+            kron.set_factor_cache(True)
+        with torch.inference_mode():
+            Qli, Qri = Ql * 1.0, Qr * 1.0                      # inference tensors: ._version raises
+            for _ in range(2):
+                oi = psgd.precond_grad_kron(Qli, Qri, G)
+        assert rel_err(oi.float().cpu().numpy(), ref()) < tol
+
+
+def test_apply_captured_in_a_graph_follows_in_graph_factor_updates(psgd):
+    """While the stream is being captured the factor-only half is always part of the captured work (no reuse decision
+    is frozen into the graph): a graph of [factor update in place; apply] replays correctly."""
+    rng = np.random.default_rng(5)
+    M, N = 257, 120
+    Ql, Qr = _dev(_tri_factor(rng, M)), _dev(_tri_factor(rng, N))
+    G = _dev(rng.standard_normal((M, N)))
+    out = torch.empty_like(G)
+    psgd.precond_grad_kron(Ql, Qr, G)                           # warm: workspace made, Grams prepared for (Ql, Qr)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        psgd.precond_grad_kron(Ql, Qr, G)                       # workspace of the capture stream exists before the capture
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        Ql.mul_(1.1)
+        out.copy_(psgd.precond_grad_kron(Ql, Qr, G))
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
+        assert rel_err(out.cpu().numpy(), ref) < TOL
+
+
 def test_bf16_update_rejects_mixed_dtypes(psgd):
     with pytest.raises(TypeError):
         psgd.update_precond_kron(torch.eye(8, device="cuda"), torch.eye(16, device="cuda"),
