@@ -390,13 +390,16 @@ int64_t psgd_kron_dd_update_workspace_bytes_bf16(int M, int N);
 int psgd_kron_dd_update_bf16(const float *Ql, const float *Qr, const void *dX_bf16, const void *dG_bf16,
                              float *QlOut, float *QrOut, int M, int N, float step, float tiny,
                              void *ws, int64_t ws_bytes, void *stream);
-/* The fused triangular pairs of the bf16 apply hand tiles between workgroups inside one launch and need every
- * workgroup of the launch resident (checked against the CU count -- which cannot see other streams or processes on
- * the GPU).  A workgroup that has to wait for a CU only delays its consumers (bounded spin, ~0.5 s).  If the bound is
- * hit the consumer stores NaN to its whole output tile and raises a STICKY word in the workspace: the call's result is
- * loudly wrong, never finite garbage.  psgd_kron_bf16_handoff_timeouts (synchronises: call it at a point where the
- * host waits anyway) returns 1 if that ever happened on this workspace since it was created or reset.  A fresh
- * workspace must be reset once before its first use (the word lives in caller-owned memory).                        */
+/* The fused triangular pairs of the bf16 apply hand tiles between workgroups inside one launch.  Their schedule
+ * assumes every workgroup of the launch resident (checked against the CU count -- which cannot see other streams or
+ * processes on the GPU); their RESULT does not: a consumer that has waited for a tile for its whole bound (~0.5 s)
+ * produces that tile itself (same instructions, same inputs: the same bytes its owner would write), publishes it and
+ * redoes its own accumulation from the start, so every call returns the undisturbed bits whatever the residency.  The
+ * workspace counts such recoveries: psgd_kron_bf16_handoff_timeouts (synchronises: call it at a point where the host
+ * waits anyway) returns how many happened on this workspace since it was created or reset -- a diagnostic (a device
+ * that is persistently shared wastes up to the bound per recovery; psgd_kron_bf16_set_tuning(0, 4) selects the kernels
+ * without in-launch hand-offs).  A fresh workspace must be reset once before its first use (the word lives in
+ * caller-owned memory).                                                                                              */
 int psgd_kron_bf16_handoff_timeouts(const void *ws, int M, int N);
 int psgd_kron_bf16_handoff_reset(void *ws, int M, int N, void *stream);
 

@@ -482,3 +482,26 @@ def uvd_clip_lr(pre_grad, lr_params, max_norm, tiny):
         return dt(lr_params)
     grad_norm = np.sqrt(np.sum(pre_grad * pre_grad)) + dt(tiny)
     return dt(lr_params) * min(dt(max_norm) / grad_norm, dt(1.0))
+
+
+def uvd_step(params, grads, Hvs, vs, U, V, d, lr_params, lr_preconditioner, max_norm, tiny,
+             balance=False, update_U=True, update_Q=True, exact=True, delta_param_scale=None):
+    """psgd.py:729-762 of UVd.step, from the point where the closure has been evaluated: `grads` (and, when the
+    preconditioner is updated, the probe vectors `vs` and Hessian-vector products `Hvs`) are given per parameter.
+    Updates U, V, d in place (:732-736) and returns the list of updated parameters (:757-762).  With exact=False the
+    parameters passed in are the PERTURBED ones (:720) and the perturbation is removed again (:761-762)."""
+    dt = U.dtype
+    shapes = [np.shape(p) for p in params]
+    if update_Q:
+        v = uvd_flatten(vs, dt)[:, None]                                          # :729
+        h = uvd_flatten(Hvs, dt)[:, None]                                         # :730
+        if not exact:                                                             # :735-736
+            v, h = v / dt.type(delta_param_scale), h / dt.type(delta_param_scale)
+        update_precond_UVd_math_(U, V, d, v, h, lr_preconditioner, tiny, balance=balance, update_U=update_U)
+    grad = uvd_flatten(grads, dt)[:, None]                                        # :747
+    pre_grad = precond_grad_UVd_math(U, V, d, grad)                               # :748
+    lr = uvd_clip_lr(pre_grad, lr_params, max_norm, tiny)                         # :750-754
+    deltas = uvd_unflatten(lr * pre_grad[:, 0], shapes)                           # :758-759
+    if exact or not update_Q:
+        return [np.asarray(p, dtype=dt) - dl for p, dl in zip(params, deltas)]
+    return [np.asarray(p, dtype=dt) - (dl + np.asarray(v_, dtype=dt)) for p, dl, v_ in zip(params, deltas, vs)]   # :761-762

@@ -694,12 +694,15 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
 // atomic stores = sc1), every storing wave drains vmcnt, the block's barrier, one lane stores the flag with an
 // agent-scope atomic; the consumer polls that one word (one lane, relaxed, bounded), does ONE agent-scope acquire,
 // drains, and the whole block passes a barrier before any wave issues a load of the handed-off bytes.  Flags are
-// zeroed before every launch (by the factor-conversion kernel that opens the call).  All blocks must be resident (grid <= number of CUs, one block per CU:
-// checked by the launcher).  That check cannot see other streams or processes: a block of this launch may have to wait
-// for a CU.  Its consumers then spin until it has run (~0.5 s bound).  If the bound is hit -- the producer never ran --
-// the consumer does NOT go on with bytes that were never published: it raises the STICKY timeout word (never cleared
-// by the library; psgd_kron_bf16_handoff_timeouts reads it) and stores NaN to its whole output tile, so the result of
-// such a call is loudly wrong, never finite garbage.
+// zeroed before every launch (by the factor-conversion kernel that opens the call).  The schedule wants every block
+// resident (grid <= number of CUs, one block per CU: checked by the launcher), but CORRECTNESS does not depend on it: that
+// check cannot see other streams or processes, so a block of this launch may have to wait for a CU.  Its consumers
+// spin for a bounded time (~0.5 s).  A consumer whose bound is hit does not go on with bytes that were never published
+// and does not give up either: it PRODUCES the missing T3 tile itself (phase A of the missing tile row -- the same
+// instructions on the same inputs as the owner would run, so both write identical bytes), publishes it, and redoes
+// its phase B from the start (same chunk order, hence the same bits as an undisturbed run).  Every spin therefore ends,
+// every block finishes whatever the residency, and the result is always the undisturbed one.  The word in front of the
+// flags counts such recoveries (diagnostics: psgd_kron_bf16_handoff_timeouts; never cleared by the library).
 struct HPairArgs {
   const uint16_t* A1; long lda1;   // Ql  [M][M]   (k >= m)
   const uint16_t* B1; long ldb1;   // T2' [N][M]
@@ -709,15 +712,15 @@ struct HPairArgs {
   int M, N;                        // M = the triangular factor's dimension (tile rows), N = the other one
   int c_begin, c_count;            // tile columns of this launch (hand-offs stay inside a column)
   unsigned* flags;                 // [M/256][N/256], zeroed before the launch
-  unsigned* timeout;               // sticky: set to 1 if a spin gave up (the block's output tile is then NaN)
+  unsigned* timeout;               // recoveries so far: +1 whenever a spin gave up and the consumer produced the tile itself
   unsigned spin_limit;             // polls before giving up (2^22 x ~64 cycles ~ 0.5 s; tests shrink it)
 };
 
 __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];
-  __shared__ int poisoned;
+  __shared__ int missing;                                  // tile row whose T3 tile a poll gave up on (-1: none)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) poisoned = 0;                              // ordered before its first reader by the barriers of phase A
+  if (tid == 0) missing = -1;                              // ordered before its first reader by the barriers of phase A
   const int tiles_m = p.M / T2, tiles_n = p.N / T2;
   // blocks b, b + 8, ... share an XCD: give each XCD whole tile columns (the hand-offs of a column stay on one L2
   // when the column count allows); rows ascend with the block index inside a column
@@ -739,73 +742,84 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  zero();
 
-  // ---- phase A: T3 tile (r, c) = sum over k >= m0 of Ql[m][k] T2'[n][k]
-  {
-    long offA[2][2], offB[2][2];
-    hg256_offsets(w, lane, p.lda1, p.ldb1, offA, offB);
-    const uint16_t* Abase = p.A1 + (long)m0 * p.lda1 + m0;
-    const uint16_t* Bbase = p.B1 + (long)n0 * p.ldb1 + m0;
-    auto src = [&](int n, int t) -> const uint16_t* {
-      const int j = n & 3;
-      const long k0 = (long)(n >> 2) * TK;
-      const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
-      return ((j & 1) ? Abase : Bbase) + o + k0;
-    };
-    hg256_mainloop(acc, lds, (p.M - m0) / TK, w, lane, src, [](int) {});
-  }
-  // publish: T3'[n0 + col][m0 + row] (transposed, bf16), write-through; drain; barrier; flag
-  hg256_store<true>(acc, p.T3, p.ldt, 1, 1, m0, n0, w, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(p.flags + r * tiles_n + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // One pass = produce the T3 tile of row `prod` (this block's own row first), then consume.  A pass whose consumer
+  // gave up on a tile comes round again with prod = that tile's row; an undisturbed run is exactly one pass.
+  int prod = r;
+  for (;;) {
+    const int pm0 = prod * T2;
+    // ---- phase A: T3 tile (prod, c) = sum over k >= pm0 of Ql[m][k] T2'[n][k]
+    zero();
+    {
+      // (the lane id is made opaque per pass: otherwise the per-lane offsets of BOTH phases are hoisted out of the pass
+      // loop as invariants and their 32 registers push the kernel into scratch)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      long offA[2][2], offB[2][2];
+      hg256_offsets(w, ln, p.lda1, p.ldb1, offA, offB);
+      const uint16_t* Abase = p.A1 + (long)pm0 * p.lda1 + pm0;
+      const uint16_t* Bbase = p.B1 + (long)n0 * p.ldb1 + pm0;
+      auto src = [&](int n, int t) -> const uint16_t* {
+        const int j = n & 3;
+        const long k0 = (long)(n >> 2) * TK;
+        const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
+        return ((j & 1) ? Abase : Bbase) + o + k0;
+      };
+      hg256_mainloop(acc, lds, (p.M - pm0) / TK, w, lane, src, [](int) {});
+    }
+    // publish: T3'[n0 + col][pm0 + row] (transposed, bf16), write-through; drain; barrier; flag
+    hg256_store<true>(acc, p.T3, p.ldt, 1, 1, pm0, n0, w, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(p.flags + prod * tiles_n + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-  // ---- phase B: out tile (r, c) = sum over chunks j = r .. 0 of Ql'[m][k in chunk j] T3'[n][k in chunk j]
-  zero();
-  {
-    long offA[2][2], offB[2][2];
-    hg256_offsets(w, lane, p.lda2, p.ldt, offA, offB);
-    const uint16_t* Abase = p.A2 + (long)m0 * p.lda2;
-    const uint16_t* Bbase = p.T3 + (long)n0 * p.ldt;
-    auto src = [&](int n, int t) -> const uint16_t* {
-      const int j = n & 3, i = n >> 2;                     // i-th K tile of the sequence
-      const long k0 = (long)((r - (i >> 2)) * 4 + (i & 3)) * TK;   // chunk r - i/4, K tile i%4 inside it
-      const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
-      return ((j & 1) ? Abase : Bbase) + o + k0;
-    };
-    auto pre = [&](int n) {
-      if ((n & 15) != 0) return;                           // first half-tile of a new chunk (n > 0 here)
-      const int jchunk = r - (n >> 4);
-      if (w == 0) {
-        if (lane == 0) {
-          const unsigned* f = p.flags + jchunk * tiles_n + c;
-          unsigned spins = 0;
-          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > p.spin_limit) {
-              __hip_atomic_store(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              poisoned = 1;                                // read by every wave after the barrier below
-              break;
+    // ---- phase B: out tile (r, c) = sum over chunks j = r .. 0 of Ql'[m][k in chunk j] T3'[n][k in chunk j]
+    zero();
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      long offA[2][2], offB[2][2];
+      hg256_offsets(w, ln, p.lda2, p.ldt, offA, offB);
+      const uint16_t* Abase = p.A2 + (long)m0 * p.lda2;
+      const uint16_t* Bbase = p.T3 + (long)n0 * p.ldt;
+      auto src = [&](int n, int t) -> const uint16_t* {
+        const int j = n & 3, i = n >> 2;                     // i-th K tile of the sequence
+        const long k0 = (long)((r - (i >> 2)) * 4 + (i & 3)) * TK;   // chunk r - i/4, K tile i%4 inside it
+        const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
+        return ((j & 1) ? Abase : Bbase) + o + k0;
+      };
+      auto pre = [&](int n) {
+        if ((n & 15) != 0) return;                           // first half-tile of a new chunk (n > 0 here)
+        const int jchunk = r - (n >> 4);
+        if (w == 0) {
+          if (lane == 0 && missing < 0) {                    // (after a give-up the rest of this pass is discarded: no more polls)
+            const unsigned* f = p.flags + jchunk * tiles_n + c;
+            unsigned spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spins > p.spin_limit) {
+                __hip_atomic_fetch_add(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                missing = jchunk;                            // read by every wave after the pass (barriers in between)
+                break;
+              }
             }
           }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      HG_FENCE();
-      __builtin_amdgcn_s_barrier();
-      HG_FENCE();
-    };
-    // the first chunk is this block's own tile: its stores were drained before the barrier above
-    hg256_mainloop(acc, lds, (r + 1) * 4, w, lane, src, pre);
-  }
-  if (poisoned) {                                          // a tile of T3 was never published: no finite garbage
-    const float qnan = __uint_as_float(0x7fc00000u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{qnan, qnan, qnan, qnan};
+        HG_FENCE();
+        __builtin_amdgcn_s_barrier();
+        HG_FENCE();
+      };
+      // the first chunk is this block's own tile: its stores were drained before the barrier above
+      hg256_mainloop(acc, lds, (r + 1) * 4, w, lane, src, pre);
+    }
+    __syncthreads();
+    const int ms = missing;
+    if (ms < 0) break;                                       // the undisturbed case: one pass
+    __syncthreads();                                         // every wave has read `missing` before it is reset
+    if (tid == 0) missing = -1;
+    prod = ms;                                               // produce the tile nobody published in time, then consume again
   }
   hg256_store<false>(acc, p.out, p.ldo, p.out_bf16, p.out_trans, m0, n0, w, lane);
 }

@@ -9,7 +9,11 @@ same arrays) and writes the reference's own fp32 outputs to tests/golden/tf/<cas
 TensorFlow version.  tests/test_golden.py::test_oracle_matches_reference_fixtures then compares the
 oracle with those files; while the directory is empty it reports PARITY UNPINNED.
 
-STATUS: TensorFlow is not installable in the build container of rounds 1-2 (no wheel, no network), so
+Covered: UVd math (4 cases, both factor branches, the balance branch), one whole UVd.step per branch (uvdstep_*),
+Kron dense (x) dense (4) and the six sparse dispatch formats (kron_fmt_*, psgd.py:198-391), sparse LU (3), and the
+dense 2 x 2 first step of hello_psgd.py.
+
+STATUS: TensorFlow is not installable in the build container of rounds 1-3 (no wheel, no network), so
 this script has not run and tests/golden/tf/ is empty: parity is unpinned.  The
 fixtures are data (inputs + the reference's outputs); no reference source is copied anywhere.
 
@@ -85,6 +89,62 @@ def splu_case(ref, tf, z):
                 u3_new=new[3].numpy())
 
 
+class Normals:
+    """tf.random.normal replacement for one UVd.step call: hands out the fixture's probe vectors, one per parameter,
+    in parameter order (psgd.py:713 draws them with tf.random.normal(param.shape))."""
+
+    def __init__(self, tf, arrays):
+        self.tf, self.arrays, self.saved = tf, list(arrays), None
+
+    def __enter__(self):
+        self.saved = self.tf.random.normal
+        tf, arrays = self.tf, self.arrays
+
+        def normal(shape, *a, **k):
+            x = arrays.pop(0)
+            assert tuple(shape) == tuple(x.shape), "unexpected probe-vector shape in the reference"
+            return tf.constant(x)
+        self.tf.random.normal = normal
+        return self
+
+    def __exit__(self, *exc):
+        self.tf.random.normal = self.saved
+        assert not self.arrays, "the reference drew fewer probe vectors than expected"
+
+
+UVD_STEP_SHAPES = [(2, 30), (30, 30), (30,), (30, 1), (1,)]        # rnn_xor_UVd_preconditioner.py:28-31
+
+
+def uvd_step_case(ref, tf, z):
+    """One UVd.step of the reference itself (psgd.py:692-764) on the fixture's inputs: the closure is the separable
+    loss sum(c p^2 / 2 + b p + e p^4 / 4) (TensorFlow differentiates it twice on its own), the probe vectors and the
+    three coin flips (:703 update, :562 balance, :588 which factor) are the fixture's."""
+    def unfl(x):
+        out, i = [], 0
+        for s in UVD_STEP_SHAPES:
+            n = int(np.prod(s))
+            out.append(np.reshape(x[i:i + n], s))
+            i += n
+        return out
+    params = [tf.Variable(x) for x in unfl(z["p"])]
+    cs, bs, es = ([tf.constant(x) for x in unfl(z[k])] for k in ("c", "b", "e"))
+    max_norm = float(z["grad_clip_max_norm"])
+    opt = ref.UVd(params, rank_of_modification=int(z["rank"]), preconditioner_init_scale=1.0,
+                  lr_params=float(z["lr_params"]), lr_preconditioner=float(z["lr_preconditioner"]),
+                  grad_clip_max_norm=(None if np.isinf(max_norm) else max_norm),
+                  preconditioner_update_probability=1.0, exact_hessian_vector_product=True)
+    opt._U.assign(z["U"]); opt._V.assign(z["V"]); opt._d.assign(z["d"])
+
+    def closure():
+        return tf.add_n([tf.reduce_sum(0.5 * c * p * p + b * p + 0.25 * e * p * p * p * p)
+                         for p, c, b, e in zip(params, cs, bs, es)])
+    coins = [0.0, 0.0 if bool(z["balance"]) else 1.0, 0.0 if bool(z["update_U"]) else 1.0]
+    with Coins(tf, coins), Normals(tf, unfl(z["vs"])):
+        loss = opt.step(closure)
+    p_new = np.concatenate([np.reshape(p.numpy(), [-1]) for p in params], 0)
+    return dict(loss=np.asarray(loss.numpy()), p_new=p_new, U_new=opt._U.numpy(), V_new=opt._V.numpy(), d_new=opt._d.numpy())
+
+
 def dense_case(ref, tf):
     """hello_psgd.py:7-12,25-26 first iteration with v = (1, 0) (KAT-R of SURVEY Appendix C)."""
     Q = tf.constant(0.1 * np.eye(2, dtype=np.float32))
@@ -110,7 +170,8 @@ def main():
     for path in sorted(glob.glob(os.path.join(HERE, "*.npz"))):
         name = os.path.basename(path)
         z = np.load(path)
-        fn = uvd_case if name.startswith("uvd_") else kron_case if name.startswith("kron_") else splu_case
+        fn = (uvd_case if name.startswith("uvd_") else uvd_step_case if name.startswith("uvdstep_") else
+              kron_case if name.startswith("kron_") else splu_case)      # (kron_fmt_*: the six sparse dispatch formats)
         np.savez_compressed(os.path.join(args.out, name), **fn(ref, tf, z), **meta)
         print("wrote", name)
     np.savez_compressed(os.path.join(args.out, "dense_hello_first_step.npz"), **dense_case(ref, tf), **meta)

@@ -15,11 +15,20 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 UVD = sorted(glob.glob(os.path.join(HERE, "uvd_*.npz")))
 KRON = sorted(glob.glob(os.path.join(HERE, "kron_*.npz")))
 SPLU = sorted(glob.glob(os.path.join(HERE, "splu_*.npz")))
+STEP = sorted(glob.glob(os.path.join(HERE, "uvdstep_*.npz")))
 SPLU_KEYS = ("L12", "l3", "U12", "u3")
+UVD_STEP_SHAPES = [(2, 30), (30, 30), (30,), (30, 1), (1,)]        # rnn_xor_UVd_preconditioner.py:28-31 -> 1021 parameters
 
 
 def test_fixtures_present():
-    assert len(UVD) == 4 and len(KRON) == 4 and len(SPLU) == 3
+    assert len(UVD) == 4 and len(KRON) == 10 and len(SPLU) == 3 and len(STEP) == 2
+    # the six sparse dispatch formats of psgd.py:86-104 are all there, at the demo's shapes
+    fmts = sorted(os.path.basename(p)[len("kron_fmt_"):].rsplit("_", 1)[0] for p in KRON if "kron_fmt_" in p)
+    assert fmts == ["dense_norm", "dense_scale", "norm_dense", "norm_scale", "scale_dense", "scale_norm"]
+    for p in KRON:
+        if "kron_fmt_" in p:
+            z = np.load(p)
+            assert "kron_fmt_" + orc.kron_format(z["Ql"].shape, z["Qr"].shape) in p
 
 
 @pytest.mark.parametrize("path", UVD, ids=os.path.basename)
@@ -47,6 +56,69 @@ def test_oracle_reproduces_kron_golden(path):
     a, b = orc.update_precond_kron(f("Ql"), f("Qr"), f("dX"), f("dG"), float(z["step"]))
     assert rel_err(a, z["Ql_new"]) < 1e-13 and rel_err(b, z["Qr_new"]) < 1e-13
     assert rel_err(orc.precond_grad_kron(f("Ql"), f("Qr"), f("G")), z["pre_grad"]) < 1e-13
+
+
+def _step_oracle(z, dt):
+    f = lambda k: z[k].astype(dt)
+    p, c, b, e, vs = f("p"), f("c"), f("b"), f("e"), f("vs")
+    loss = np.sum(0.5 * c * p * p + b * p + 0.25 * e * p ** 4)
+    grad, hv = c * p + b + e * p ** 3, (c + 3.0 * e * p * p) * vs
+    U, V, d = f("U"), f("V"), f("d")
+    unfl = lambda x: orc.uvd_unflatten(x, UVD_STEP_SHAPES)
+    new = orc.uvd_step(unfl(p), unfl(grad), unfl(hv), unfl(vs), U, V, d, float(z["lr_params"]), float(z["lr_preconditioner"]),
+                       float(z["grad_clip_max_norm"]), float(z["tiny"]), balance=bool(z["balance"]), update_U=bool(z["update_U"]))
+    return loss, orc.uvd_flatten(new, dt), U, V, d
+
+
+@pytest.mark.parametrize("path", STEP, ids=os.path.basename)
+def test_oracle_reproduces_uvd_step_golden(path):
+    z = np.load(path)
+    loss, p_new, U, V, d = _step_oracle(z, np.float64)
+    assert abs(loss - float(z["loss"])) < 1e-12 * abs(float(z["loss"]))
+    for got, key in ((p_new, "p_new"), (U, "U_new"), (V, "V_new"), (d, "d_new")):
+        assert rel_err(got, z[key]) < 1e-13, key
+    assert rel_err(p_new, z["p"].astype(np.float64)) > 1e-3            # the step moved the parameters
+    loss32, p32, U32, V32, d32 = _step_oracle(z, np.float32)           # fp32 run of the same op sequence
+    for got, key in ((p32, "p_new"), (U32, "U_new"), (V32, "V_new"), (d32, "d_new")):
+        assert rel_err(got, z[key]) < 1e-5, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", STEP, ids=os.path.basename)
+def test_hip_uvd_step_matches_golden(path, hip_lib, monkeypatch):
+    """class UVd of the product on the fixture: same separable loss as a torch closure (autograd makes grads and Hv),
+    the probe vectors and the three coin flips are the fixture's (injected where the step draws them)."""
+    import torch
+    import preconditioned_stochastic_gradient_descent as shim
+    from psgd_tf_amd import preconditioned_stochastic_gradient_descent as mod
+    z = np.load(path)
+    dev = torch.device("cuda:0")
+
+    def unfl(x):
+        return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in orc.uvd_unflatten(x, UVD_STEP_SHAPES)]
+    params = [t.requires_grad_(True) for t in unfl(z["p"])]
+    cs, bs, es, vs = unfl(z["c"]), unfl(z["b"]), unfl(z["e"]), unfl(z["vs"])
+    max_norm = float(z["grad_clip_max_norm"])
+    opt = shim.UVd(params, rank_of_modification=int(z["rank"]), lr_params=float(z["lr_params"]),
+                   lr_preconditioner=float(z["lr_preconditioner"]), grad_clip_max_norm=(None if np.isinf(max_norm) else max_norm))
+    assert opt._param_sizes == [60, 900, 30, 30, 1] and opt._U.shape == (1021, 10)
+    for t, k in ((opt._U, "U"), (opt._V, "V"), (opt._d, "d")):
+        t.copy_(torch.from_numpy(z[k]).to(dev))
+    coins = [True, bool(z["balance"]), bool(z["update_U"])]            # psgd.py:703, :562, :588 in the order they are drawn
+    monkeypatch.setattr(mod, "_draw_branch", lambda p, gen: coins.pop(0))
+    queue = list(vs)
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: queue.pop(0))
+
+    def closure():
+        return sum(torch.sum(0.5 * c * p * p + b * p + 0.25 * e * p ** 4) for p, c, b, e in zip(params, cs, bs, es))
+    loss = opt.step(closure)
+    monkeypatch.undo()
+    assert not coins and not queue
+    assert abs(float(loss) - float(z["loss"])) < 1e-5 * abs(float(z["loss"]))
+    p_new = np.concatenate([p.detach().reshape(-1).cpu().numpy() for p in params])
+    assert rel_err(p_new, z["p_new"]) < 1e-5
+    for t, k in ((opt._U, "U_new"), (opt._V, "V_new"), (opt._d, "d_new")):
+        assert rel_err(t.cpu().numpy(), z[k]) < 1e-5, k
 
 
 @pytest.mark.parametrize("path", SPLU, ids=os.path.basename)
@@ -127,7 +199,12 @@ def test_oracle_matches_reference_fixtures():
             continue
         z = np.load(os.path.join(HERE, name))
         f = lambda k: z[k].astype(np.float64)
-        if name.startswith("uvd_"):
+        if name.startswith("uvdstep_"):
+            loss, p_new, U, V, d = _step_oracle(z, np.float64)
+            assert abs(loss - float(t["loss"])) < 1e-5 * abs(loss), name
+            for got, key in ((p_new, "p_new"), (U, "U_new"), (V, "V_new"), (d, "d_new")):
+                assert rel_err(got, t[key]) < 1e-5, (name, key)
+        elif name.startswith("uvd_"):
             q = {k: f(k) for k in ("U", "V", "d", "g", "v", "h")}
             assert rel_err(orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"]), t["pre_grad_before"]) < 1e-5, name
             orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], float(z["step"]), float(z["tiny"]),

@@ -238,18 +238,19 @@ def test_bf16_fused_triangular_pair(psgd, M, N):
                         if first is None:
                             first = got
                         assert torch.equal(got, first), (two_pairs, rep)
-            kron.check_bf16_handoffs()                      # raises if any spin ever timed out
+            assert kron.check_bf16_handoffs() == 0          # no hand-off ever ran into its wait bound
     finally:
         lib.psgd_kron_bf16_set_tuning(0, 0)
         lib.psgd_kron_bf16_set_tuning(1, 1)
 
 
 def test_bf16_fused_pair_on_a_shared_device(psgd):
-    """The fused pair needs its workgroups resident; the launcher can only check that against the CU count, not against
-    other streams.  (a) With a second stream keeping the CUs busy (large fp32 GEMMs) the calls must still give the
-    idle-device result bit for bit -- late workgroups only delay their consumers.  (b) When a consumer does give up
-    (provoked here by a poll bound of 1), the result must be loudly wrong and the condition reported: NaN tiles, a sticky
-    word, and check_bf16_handoffs() raises -- never finite garbage."""
+    """The fused pair's schedule assumes its workgroups resident; the launcher can only check that against the CU count,
+    not against other streams.  Its RESULT must not depend on it.  (a) With a second stream keeping the CUs busy (large
+    fp32 GEMMs) the calls give the idle-device result bit for bit -- late workgroups only delay their consumers.
+    (b) When consumers do give up waiting (provoked here by a poll bound of 1: nearly every hand-off times out), they
+    produce the missing tile themselves and start over: the result is still the idle-device result bit for bit -- finite
+    and correct, not NaN -- and the recoveries are counted."""
     from psgd_tf_amd import _lib, kron
     lib = _lib.load()
     M = N = 4096
@@ -258,7 +259,10 @@ def test_bf16_fused_pair_on_a_shared_device(psgd):
     G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16)
     want = psgd.precond_grad_kron(Ql, Qr, G)
     torch.cuda.synchronize()
-    kron.check_bf16_handoffs()
+    assert torch.isfinite(want.float()).all()
+    ref = orc.precond_grad_kron(*(t.float().cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
+    assert rel_err(want.float().cpu().numpy(), ref) < 2e-2
+    base = kron.check_bf16_handoffs()
     # (a) contention
     side = torch.cuda.Stream()
     A = torch.randn(8192, 8192, device="cuda")
@@ -267,28 +271,40 @@ def test_bf16_fused_pair_on_a_shared_device(psgd):
             A = torch.mm(A, A) * 1e-4
     outs = [psgd.precond_grad_kron(Ql, Qr, G) for _ in range(30)]
     torch.cuda.synchronize()
-    kron.check_bf16_handoffs()
     for o in outs:
         assert torch.equal(o, want)
-    # (b) a consumer that gives up
+    base = kron.check_bf16_handoffs()
+    # (b) consumers that give up: same bits, recoveries counted
     try:
         assert lib.psgd_kron_bf16_set_tuning(2, 0) == 0
-        bad = [psgd.precond_grad_kron(Ql, Qr, G) for _ in range(5)]
+        forced = [psgd.precond_grad_kron(Ql, Qr, G) for _ in range(5)]
         torch.cuda.synchronize()
     finally:
         lib.psgd_kron_bf16_set_tuning(2, 22)
-    gave_up = any(bool(torch.isnan(o.float()).any()) for o in bad)
-    for o in bad:                                           # every tile is either right or NaN
-        ok = torch.isnan(o.float()) | (o == want)
-        assert bool(ok.all())
-    if gave_up:
-        with pytest.raises(_lib.PsgdHipError, match="hand-off"):
-            kron.check_bf16_handoffs()
-        for key, (m, n) in kron._bf16_apply_shapes.items():          # clear the sticky word for the tests that follow
-            if key in kron._kron_ws_bf16:
-                lib.psgd_kron_bf16_handoff_reset(kron._kron_ws_bf16[key].data_ptr(), m, n, None)
+    for o in forced:
+        assert torch.isfinite(o.float()).all()
+        assert torch.equal(o, want)
+    assert kron.check_bf16_handoffs() > base                 # the bound of 1 poll was hit and recovered from
+    # (c) the same under contention AND the tiny bound, with changing gradients (a stale tile cannot pass)
+    Gs = [torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16) for _ in range(3)]
+    wants = [psgd.precond_grad_kron(Ql, Qr, g) for g in Gs]
+    torch.cuda.synchronize()
+    try:
+        lib.psgd_kron_bf16_set_tuning(2, 0)
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                A = torch.mm(A, A) * 1e-4
+        got = [psgd.precond_grad_kron(Ql, Qr, g) for g in Gs]
         torch.cuda.synchronize()
-    kron.check_bf16_handoffs()
+    finally:
+        lib.psgd_kron_bf16_set_tuning(2, 22)
+    for o, w_ in zip(got, wants):
+        assert torch.equal(o, w_)
+    for key, (m, n) in kron._bf16_apply_shapes.items():          # clear the counters for the tests that follow
+        if key in kron._kron_ws_bf16:
+            lib.psgd_kron_bf16_handoff_reset(kron._kron_ws_bf16[key].data_ptr(), m, n, None)
+    torch.cuda.synchronize()
+    assert kron.check_bf16_handoffs() == 0
     assert torch.equal(psgd.precond_grad_kron(Ql, Qr, G), want)
 
 

@@ -26,11 +26,8 @@ while time.time() - t0 < budget:
     Ql, Qr = state[(M, N)]
     G = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
     outs = [psgd.precond_grad_kron(Ql, Qr, G) for _ in range(8)]          # back to back, same operands
-    try:
-        torch.cuda.synchronize()
-        kron.check_bf16_handoffs()
-    except _lib.PsgdHipError:
-        timeouts += 1
+    torch.cuda.synchronize()
+    timeouts = kron.check_bf16_handoffs()                                 # recoveries so far (results are unaffected)
     lib.psgd_kron_bf16_set_tuning(0, 1)                                   # staged chain on the 128^2 kernel: no hand-offs
     ref = psgd.precond_grad_kron(Ql, Qr, G)
     lib.psgd_kron_bf16_set_tuning(0, 0)
