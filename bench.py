@@ -672,6 +672,11 @@ def main():
                 res["config2_N1M_r10"] = legs2
                 del c2
                 torch.cuda.empty_cache()
+            if not args.no_kron:
+                res["kron"] = kron_bench(dev, psgd)
+                res["splu"] = splu_bench(dev, psgd)
+            # (after the Kron leg: a process that has initialised an RCCL communicator runs the two-stream Kron updates
+            # 1.1-1.3 ms slower at 4096^2 -- tools/rccl_fork_probe.py, profiles/r03_rccl_fork_probe.txt)
             if not args.no_exchange_leg and not single_dev and not args.force_sharded:
                 try:
                     res["exchange_overhead"] = exchange_overhead(args, psgd, sharded, lib, dev,
@@ -679,9 +684,6 @@ def main():
                 except Exception as e:                      # a leg, never the headline: report, do not fail the line
                     res["exchange_overhead"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
-            if not args.no_kron:
-                res["kron"] = kron_bench(dev, psgd)
-                res["splu"] = splu_bench(dev, psgd)
             if not args.no_cpu_baseline:
                 rows = n_local if args.cpu_full else args.cpu_sample_rows
                 res["cpu_baseline"] = cpu_baseline(r, rows, args.cpu_budget_s, args.cpu_threads or None)

@@ -2671,6 +2671,8 @@ int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long
 
 static int g_overlap = 1;       // tuning key 9: 0 = the two chains of a large update run one after the other on the caller's stream
 bool kron_overlap_chains(int M, int N) { return g_overlap != 0 && (M > 512 || N > 512); }
+static int g_side_prio = 0;     // tuning key 10 (before the first forked call on a stream): 0 = side streams at the lowest priority,
+                                // 1 = at the default priority, 2 = at the highest
 
 KronFork* kron_fork(hipStream_t main) {
   static std::mutex mu;
@@ -2695,7 +2697,8 @@ KronFork* kron_fork(hipStream_t main) {
       int least = 0, greatest = 0;
       if (dev != cur && hipSetDevice(dev) != hipSuccess) return nullptr;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      const bool ok = hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, least) == hipSuccess &&
+      const int prio = g_side_prio == 2 ? greatest : g_side_prio == 1 ? 0 : least;
+      const bool ok = hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio) == hipSuccess &&
                       hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&n.join, hipEventDisableTiming) == hipSuccess;
       if (dev != cur) (void)hipSetDevice(cur);
@@ -2740,6 +2743,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 7) { g_stage_mix = value; return PSGD_OK; }
   if (key == 8) { g_splitk = value; return PSGD_OK; }
   if (key == 9) { g_overlap = value; return PSGD_OK; }
+  if (key == 10) { g_side_prio = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

@@ -1,0 +1,61 @@
+"""Does an initialised RCCL communicator in the process change the two-stream Kron update?  (Round 3: bench.py's
+exchange_overhead leg -- a 1-rank RCCL group, created and destroyed -- ran before the Kron leg, and the 4096^2 updates
+came out 1.1-1.3 ms slower than without it.)  Times the 4096^2 fp32 and bf16-operand update with the chains forked
+(tuning key 9 = 1) and serial (0), before any process group, with a live 1-rank group, and after destroying it.
+   python tools/rccl_fork_probe.py [side-stream priority: 0 lowest (default) | 1 default | 2 highest]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import preconditioned_stochastic_gradient_descent as psgd
+from psgd_tf_amd import _lib
+from tools.kron_timing import state
+
+lib = _lib.load()
+prio = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+lib.psgd_kron_set_tuning(10, prio)
+dev = torch.device("cuda:0")
+M = N = 4096
+Ql, Qr, dX, dG, G = state(M, N, dev)
+dXb, dGb = dX.bfloat16(), dG.bfloat16()
+
+
+def t_of(fn, n=10):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def row(tag):
+    out = []
+    for ov in (1, 0):
+        lib.psgd_kron_set_tuning(9, ov)
+        out.append(t_of(lambda: psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)))
+        out.append(t_of(lambda: psgd.update_precond_kron(Ql, Qr, dXb, dGb, 0.01)))
+    lib.psgd_kron_set_tuning(9, 1)
+    print("%-28s forked: f32 %.3f ms  bf16 %.3f ms | serial: f32 %.3f ms  bf16 %.3f ms" % (tag, *out), flush=True)
+
+
+print("side-stream priority mode %d" % prio)
+row("no process group")
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29571")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+row("group initialised (lazy)")
+x = torch.ones(8, device=dev)
+dist.all_reduce(x)
+torch.cuda.synchronize()
+row("after one all_reduce")
+dist.destroy_process_group()
+row("group destroyed")
