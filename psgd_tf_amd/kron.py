@@ -14,6 +14,12 @@ import torch
 from . import _lib
 
 _tiny = torch.finfo(torch.float32).tiny
+_f32 = torch.float32
+try:                                        # the current stream's handle without building a torch.cuda.Stream object
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                      # pragma: no cover
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
 
 KRON_FORMATS = ("dense_dense", "dense_norm", "dense_scale", "norm_dense",
                 "norm_scale", "scale_dense", "scale_norm", "unknown")
@@ -246,15 +252,30 @@ def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
         raise TypeError("update_precond_kron: dX and dG must share a dtype, got %s and %s" % (dX.dtype, dG.dtype))
     if dX.dtype == torch.bfloat16:
         return _update_precond_dense_dense_bf16(Ql, Qr, dX, dG, step)
-    M, N = dX.shape
-    Ql, Qr, dX, dG = (t.contiguous() for t in (Ql, Qr, dX, dG))
+    return _dd_update_f32(Ql, Qr, dX, dG, step, dX.shape[0], dX.shape[1])
+
+
+def _dd_update_f32(Ql, Qr, dX, dG, step, M, N):
+    """fp32 dense (x) dense update on checked device tensors (see _dd_apply_f32); shares the slot (workspace) of the apply."""
+    if not Ql.is_contiguous():
+        Ql = Ql.contiguous()
+    if not Qr.is_contiguous():
+        Qr = Qr.contiguous()
+    if not dX.is_contiguous():
+        dX = dX.contiguous()
+    if not dG.is_contiguous():
+        dG = dG.contiguous()
+    idx = dX.get_device()
+    st = _raw_stream(idx)
+    key = (idx, M, N, st)
+    slot = _apply_slots.get(key)
+    if slot is None or slot.ws() is None:
+        slot = _apply_slots[key] = _ApplySlot(_kron_workspace(dX.device, M, N))
     QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
-    ws = _kron_workspace(dX.device, M, N)
-    rc = _lib.load().psgd_kron_dd_update_f32(Ql.data_ptr(), Qr.data_ptr(), dX.data_ptr(), dG.data_ptr(),
-                                              QlO.data_ptr(), QrO.data_ptr(), M, N, float(step), float(_tiny),
-                                              ws.data_ptr(), ws.numel(),
-                                              torch.cuda.current_stream(dX.device).cuda_stream)
-    _lib.check(rc, "psgd_kron_dd_update_f32")
+    rc = slot.fn_update(Ql.data_ptr(), Qr.data_ptr(), dX.data_ptr(), dG.data_ptr(), QlO.data_ptr(), QrO.data_ptr(), M, N,
+                        float(step), _tiny, slot.ws_ptr, slot.ws_bytes, st)
+    if rc:
+        _lib.check(rc, "psgd_kron_dd_update_f32")
     return QlO, QrO
 
 
@@ -316,13 +337,16 @@ class _ApplySlot:
     """Per (device, shape, stream): the workspace and what its prepared Grams were made from.  Small layers are
     host-bound (a launch costs the host ~4 us, the GPU less), so the per-call Python work is kept to a handful of
     attribute reads: the factor identity check is spelled out instead of built from generators."""
-    __slots__ = ("ws", "ws_ptr", "ws_bytes", "rl", "rr", "vl", "vr", "pl", "pr")
+    __slots__ = ("ws", "ws_ptr", "ws_bytes", "rl", "rr", "vl", "vr", "pl", "pr", "fn_apply", "fn_prepared", "fn_update")
 
     def __init__(self, ws):
         # (a weak reference: the workspace cache owns the block; a slot of a shape the cache has evicted must not keep it alive)
         self.ws, self.ws_ptr, self.ws_bytes = weakref.ref(ws), ws.data_ptr(), ws.numel()
         self.rl = self.rr = None
         self.vl = self.vr = self.pl = self.pr = -1
+        lib = _lib.load()
+        self.fn_apply, self.fn_prepared = lib.psgd_kron_dd_apply_f32, lib.psgd_kron_dd_apply_prepared_f32
+        self.fn_update = lib.psgd_kron_dd_update_f32
 
 
 _apply_slots = {}
@@ -333,33 +357,40 @@ def _precond_grad_dense_dense(Ql, Qr, Grad):
     _require_hip("precond_grad_kron", Ql, Qr, Grad)
     if Grad.dtype == torch.bfloat16:
         return _precond_grad_dense_dense_bf16(Ql, Qr, Grad)
-    M, N = Grad.shape
+    return _dd_apply_f32(Ql, Qr, Grad, Grad.shape[0], Grad.shape[1])
+
+
+def _dd_apply_f32(Ql, Qr, Grad, M, N):
+    """fp32 dense (x) dense apply on device tensors whose shapes, dtypes and devices the caller has checked.  Small layers
+    are host-bound (LeNet5: a launch costs the GPU ~4 us, the reference's per-layer call pattern five calls per step), so
+    this path is a handful of attribute reads, one allocation and ONE ctypes call."""
     if not Ql.is_contiguous():
         Ql = Ql.contiguous()
     if not Qr.is_contiguous():
         Qr = Qr.contiguous()
     if not Grad.is_contiguous():
         Grad = Grad.contiguous()
-    out = torch.empty_like(Grad)
-    dev = Grad.device
-    st = torch.cuda.current_stream(dev).cuda_stream
-    key = (dev.index, M, N, st)
+    idx = Grad.get_device()
+    st = _raw_stream(idx)
+    key = (idx, M, N, st)
     slot = _apply_slots.get(key)
-    ws = _kron_workspace(dev, M, N)                  # (LRU touch; a fresh workspace holds no Grams)
-    if slot is None or slot.ws() is not ws:
-        slot = _apply_slots[key] = _ApplySlot(ws)
-    lib = _lib.load()
+    if slot is None or slot.ws() is None:            # first call for this (device, shape, stream), or the cache evicted its block
+        slot = _apply_slots[key] = _ApplySlot(_kron_workspace(Grad.device, M, N))
+        if len(_apply_slots) > 4 * _kron_ws.max_entries:     # slots of evicted workspaces: drop them
+            for k in [k for k, v in _apply_slots.items() if v.ws() is None]:
+                del _apply_slots[k]
+    out = torch.empty_like(Grad)
     pl, pr = Ql.data_ptr(), Qr.data_ptr()
     # factor-only half (the Grams, kept in the workspace): redone only when these are not the very factor tensors (same
     # objects, same version counters, same storage) it was made from
     vl, vr = _version_of(Ql), _version_of(Qr)
     if (slot.rl is not None and slot.rl() is Ql and slot.rr() is Qr and slot.vl == vl and slot.vr == vr and vl is not None
             and vr is not None and slot.pl == pl and slot.pr == pr and _cache_usable()):
-        rc = lib.psgd_kron_dd_apply_prepared_f32(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
+        rc = slot.fn_prepared(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
         if rc:
             _lib.check(rc, "psgd_kron_dd_apply_prepared_f32")
     else:                                            # both halves in one call (= prepare + apply_prepared)
-        rc = lib.psgd_kron_dd_apply_f32(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
+        rc = slot.fn_apply(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
         if rc:
             _lib.check(rc, "psgd_kron_dd_apply_f32")
         slot.rl, slot.rr = weakref.ref(Ql), weakref.ref(Qr)
@@ -533,7 +564,19 @@ def _precond_grad_norm_scale(ql, qr, Grad):
 
 
 # --------------------------------------------------------------------------- public dispatchers
+def _is_dd_f32(Ql, Qr, X):
+    """fp32 dense (x) dense operands of consistent shapes on one ROCm device: exactly what _check_rank2_f32,
+    _check_kron_shapes and _require_hip establish for that format, as one expression (the per-layer call pattern of
+    mnist_with_lenet5.py:51,53 is host-bound at LeNet5 sizes)."""
+    sl, sr, sx = Ql.shape, Qr.shape, X.shape
+    return (len(sx) == 2 and len(sl) == 2 and len(sr) == 2 and sl[0] == sl[1] == sx[0] and sr[0] == sr[1] == sx[1]
+            and X.dtype is _f32 and Ql.dtype is _f32 and Qr.dtype is _f32 and X.is_cuda
+            and Ql.device == X.device and Qr.device == X.device)
+
+
 def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
+    if _is_dd_f32(Ql, Qr, dX) and dG.shape == dX.shape and dG.dtype is _f32 and dG.device == dX.device:
+        return _dd_update_f32(Ql, Qr, dX, dG, step, dX.shape[0], dX.shape[1])                # psgd.py:84
     fmt = kron_format(Ql.shape, Qr.shape)
     _check_rank2_f32("update_precond_kron", Ql, Qr, dX, dG, allow_bf16_from=(2 if fmt == "dense_dense" else None))
     if fmt != "unknown":
@@ -557,6 +600,8 @@ def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
 
 
 def precond_grad_kron(Ql, Qr, Grad):
+    if _is_dd_f32(Ql, Qr, Grad):
+        return _dd_apply_f32(Ql, Qr, Grad, Grad.shape[0], Grad.shape[1])                     # psgd.py:126
     fmt = kron_format(Ql.shape, Qr.shape)
     _check_rank2_f32("precond_grad_kron", Ql, Qr, Grad, allow_bf16_last=(fmt == "dense_dense"))
     if fmt != "unknown":

@@ -57,5 +57,21 @@ x = torch.ones(8, device=dev)
 dist.all_reduce(x)
 torch.cuda.synchronize()
 row("after one all_reduce")
+# what bench.py's exchange_overhead leg does between creating and destroying the group: the fused UVd step at 12.5M rows,
+# unsharded and through psgd_tf_amd/sharded.py (2 all-gathers + 2 fold kernels per step)
+from psgd_tf_amd import sharded
+import bench
+U, V, d, grad, v, h = bench.make_inputs(12_500_032, 12_500_032, 20, dev, 0)
+for i in range(50):
+    psgd.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, 0.01, bench.TINY, balance=False, update_U=(i % 2 == 0))
+torch.cuda.synchronize()
+row("after 50 unsharded UVd steps")
+for i in range(50):
+    sharded.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, 0.01, bench.TINY, balance=False, update_U=(i % 2 == 0))
+torch.cuda.synchronize()
+row("after 50 sharded UVd steps")
+del U, V, d, grad, v, h
+torch.cuda.empty_cache()
+row("after empty_cache")
 dist.destroy_process_group()
 row("group destroyed")
