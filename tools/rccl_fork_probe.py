@@ -2,7 +2,7 @@
 exchange_overhead leg -- a 1-rank RCCL group, created and destroyed -- ran before the Kron leg, and the 4096^2 updates
 came out 1.1-1.3 ms slower than without it.)  Times the 4096^2 fp32 and bf16-operand update with the chains forked
 (tuning key 9 = 1) and serial (0), before any process group, with a live 1-rank group, and after destroying it.
-   python tools/rccl_fork_probe.py [side-stream priority: 0 lowest (default) | 1 default | 2 highest]"""
+   python tools/rccl_fork_probe.py [side-stream priority: 0 lowest (default) | 1 default | 2 highest] [late]"""
 import os
 import sys
 
@@ -45,7 +45,11 @@ def row(tag):
     print("%-28s forked: f32 %.3f ms  bf16 %.3f ms | serial: f32 %.3f ms  bf16 %.3f ms" % (tag, *out), flush=True)
 
 
-print("side-stream priority mode %d" % prio)
+late = len(sys.argv) > 2 and sys.argv[2] == "late"      # first forked call (= side stream creation) only after the group is gone
+print("side-stream priority mode %d%s" % (prio, " (first update after the process group)" if late else ""))
+if late:
+    _row = row
+    row = lambda tag: print("%-28s (skipped)" % tag) if tag != "group destroyed" else _row(tag)
 row("no process group")
 import torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
