@@ -35,14 +35,21 @@ def t_of(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 
+mid = {n: state(n, n, dev) for n in (1024, 2048)}       # sizes where the fork is worth 1.2-1.35x
+
+
 def row(tag):
     out = []
     for ov in (1, 0):
         lib.psgd_kron_set_tuning(9, ov)
         out.append(t_of(lambda: psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)))
         out.append(t_of(lambda: psgd.update_precond_kron(Ql, Qr, dXb, dGb, 0.01)))
+        for n in (1024, 2048):
+            a, b, x, g_, _ = mid[n]
+            out.append(t_of(lambda: psgd.update_precond_kron(a, b, x, g_, 0.01), 40))
     lib.psgd_kron_set_tuning(9, 1)
-    print("%-28s forked: f32 %.3f ms  bf16 %.3f ms | serial: f32 %.3f ms  bf16 %.3f ms" % (tag, *out), flush=True)
+    print("%-28s forked: 4096 f32 %.3f bf16 %.3f | 1024 %.3f | 2048 %.3f ms   serial: 4096 f32 %.3f bf16 %.3f | 1024 %.3f | 2048 %.3f ms"
+          % (tag, *out), flush=True)
 
 
 late = len(sys.argv) > 2 and sys.argv[2] == "late"      # first forked call (= side stream creation) only after the group is gone
