@@ -275,7 +275,7 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  *        (5 launches instead of 10-13; same arithmetic).  0 = one launch per stage of each chain, single updates on
  *        the large-layer path.
  * key 9: updates with M or N above 512 (fp32 and bf16 operands): 1 (default) the products of psgd.py:173 run on a
- *        lowest-priority side stream (one per device and caller stream, made on first use) while the solves of :174 run on
+ *        default-priority side stream (key 10: 0 lowest, 1 default, 2 highest priority; one per device and caller stream, made on first use) while the solves of :174 run on
  *        the caller's stream; the call forks and joins with events only (legal inside a stream capture), so to the caller
  *        it is still one stream-ordered operation.  0 = everything on the caller's stream.  Same kernels, same results. */
 int psgd_kron_set_tuning(int key, int value);

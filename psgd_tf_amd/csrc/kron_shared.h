@@ -19,7 +19,7 @@ int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long
                  int lite = 0, bool inv_ready = false);
 
 // The update has two chains that meet only at the gradient products: the products dG QrS' -> QlS (.) (psgd.py:173) and
-// the solves (:174).  kron_fork makes `side` (a lowest-priority stream kept per device and caller stream) wait for
+// the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for
 // everything already on `main`; the caller puts one chain on it and kron_join makes `main` wait for that chain.
 // Event fork/join only, so it is legal inside a stream capture of `main`.  nullptr = no side stream: stay on `main`.
 struct KronFork { hipStream_t side; hipEvent_t fork, join; };

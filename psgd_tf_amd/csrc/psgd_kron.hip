@@ -2671,8 +2671,11 @@ int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long
 
 static int g_overlap = 1;       // tuning key 9: 0 = the two chains of a large update run one after the other on the caller's stream
 bool kron_overlap_chains(int M, int N) { return g_overlap != 0 && (M > 512 || N > 512); }
-static int g_side_prio = 0;     // tuning key 10 (before the first forked call on a stream): 0 = side streams at the lowest priority,
-                                // 1 = at the default priority, 2 = at the highest
+static int g_side_prio = 1;     // tuning key 10 (before the first forked call on a stream): 0 = side streams at the lowest priority,
+                                // 1 = at the default priority (default), 2 = at the highest.  A lowest- (or highest-) priority
+                                // stream CREATED after an RCCL communicator has existed in the process runs the forked update up
+                                // to 2x slower than the serial order (1024^2: 0.87 vs 0.47 ms); a default-priority one is as fast
+                                // as the lowest-priority one otherwise and does not care (profiles/r03_rccl_fork_probe.txt)
 
 KronFork* kron_fork(hipStream_t main) {
   static std::mutex mu;

@@ -505,15 +505,23 @@ template <int N> struct IntC { static constexpr int value = N; };
 // instruction t (0, 1) of half-tile n (n = 4 * sequence index of the K tile + {0 B-h0, 1 A-h0, 2 B-h1, 3 A-h1});
 // pre(n) runs (uniformly, all waves) right before half-tile n is issued inside the loop.  Self-contained: the
 // stagger barrier of the second wave row at entry is matched at exit.
-template <class Src, class Pre>
+// DMAPOS: where a phase issues its two LDS-DMA pieces.  0 (the template as published): in the load half of the phase,
+// after the fragment reads and before the phase's first barrier -- there a piece costs the issuing wave 100-185 cycles
+// (MI355X_MICROARCH.md cycle constants) and the load half, not the 16 MFMAs of the other wave row, sets the length of
+// a barrier interval.  1: both pieces inside the MFMA cluster (after MFMA 4 and MFMA 10), where a piece costs ~60 cycles
+// of the wave's issue; the load half then holds only the fragment reads.  2: first piece as 0, second inside the cluster.
+// The counted wait of phase 3 follows the placement (pieces of THIS phase are not yet issued at the wait for 1).
+template <int DMAPOS, class Src, class Pre>
 __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, int nk, int w, int lane, Src&& src,
                                                Pre&& pre) {
   const int wr = w >> 2, wc = w & 3;
-  auto issue = [&](int n) {
+  auto issue1 = [&](int n, int t) {
     const int slot = ((n >> 2) & 1) * 4 + (n & 3);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src(n, t), (lds_ptr_t)&lds[slot * 1024 + (t * 8 + w) * 64], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src(n, t), (lds_ptr_t)&lds[slot * 1024 + (t * 8 + w) * 64], 16, 0, 0);
+  };
+  auto issue = [&](int n) {
+    issue1(n, 0);
+    issue1(n, 1);
   };
   // fragment read positions (16-byte units inside a slot): row*8 + (chunk ^ (row & 7)), chunk = ks*4 + (lane>>4)
   const int c0 = (lane >> 4) ^ (lane & 7);
@@ -566,14 +574,26 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
     }
     // ---- DMA of half-tile q + 7
     const int n = 4 * kt + PH + 7;
-    if (n < total) {
-      pre(n);
-      issue(n);
+    if constexpr (DMAPOS == 0) {
+      if (n < total) {
+        pre(n);
+        issue(n);
+      }
+    } else if constexpr (DMAPOS == 2) {
+      if (n < total) {
+        pre(n);
+        issue1(n, 0);
+      }
     }
     if constexpr (PH == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four B-h0 reads are done
     if constexpr (PH == 3) {
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // retire K tile kt + 1: everything but the pieces issued after its last half-tile -- 3 half-tiles (6 pieces) when this
+      // phase's own pieces are already out, 2 half-tiles + none (4) / + one piece (5) of this phase otherwise
+      if (kt + 2 < nk) {
+        if constexpr (DMAPOS == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (DMAPOS == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      } else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     HG_FENCE();
     __builtin_amdgcn_s_barrier();
@@ -582,6 +602,7 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
     constexpr int MQ = (PH >= 2) ? 1 : 0;
     constexpr int NQ = (PH == 1 || PH == 2) ? 1 : 0;
     __builtin_amdgcn_s_setprio(1);
+    int mcount = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -590,6 +611,22 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
         for (int j = 0; j < 2; ++j) {
           const bf16x8 bv = NQ ? b1[j][ks] : b0[j][ks];
           acc[4 * MQ + i][2 * NQ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bv, acc[4 * MQ + i][2 * NQ + j], 0, 0, 0);
+          ++mcount;                                          // (compile-time after unrolling)
+          if constexpr (DMAPOS == 1) {
+            if (mcount == 4 && n < total) {
+              __builtin_amdgcn_sched_barrier(0);
+              pre(n);
+              issue1(n, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if constexpr (DMAPOS != 0) {
+            if (mcount == 10 && n < total) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue1(n, 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         }
     __builtin_amdgcn_s_setprio(0);
     HG_FENCE();
@@ -656,6 +693,7 @@ __device__ __forceinline__ void hg256_store(const f32x4 (&acc)[8][4], void* C, l
     }
 }
 
+template <int DMAPOS>
 __global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];   // 8 half-tile slots, the ONLY __shared__ object
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -678,7 +716,7 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_nt_256(HGemmArgs g) {
     const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
     return ((j & 1) ? Abase : Bbase) + o + k0;
   };
-  hg256_mainloop(acc, lds, nk, w, lane, src, [](int) {});
+  hg256_mainloop<DMAPOS>(acc, lds, nk, w, lane, src, [](int) {});
   hg256_store<false>(acc, g.C, g.ldc, g.c_bf16, g.c_trans, m0, n0, w, lane);
 }
 
@@ -716,6 +754,7 @@ struct HPairArgs {
   unsigned spin_limit;             // polls before giving up (2^22 x ~64 cycles ~ 0.5 s; tests shrink it)
 };
 
+template <int DMAPOS>
 __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];
   __shared__ int missing;                                  // tile row whose T3 tile a poll gave up on (-1: none)
@@ -765,7 +804,7 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
         const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
         return ((j & 1) ? Abase : Bbase) + o + k0;
       };
-      hg256_mainloop(acc, lds, (p.M - pm0) / TK, w, lane, src, [](int) {});
+      hg256_mainloop<DMAPOS>(acc, lds, (p.M - pm0) / TK, w, lane, src, [](int) {});
     }
     // publish: T3'[n0 + col][pm0 + row] (transposed, bf16), write-through; drain; barrier; flag
     hg256_store<true>(acc, p.T3, p.ldt, 1, 1, pm0, n0, w, lane);
@@ -812,7 +851,7 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
         HG_FENCE();
       };
       // the first chunk is this block's own tile: its stores were drained before the barrier above
-      hg256_mainloop(acc, lds, (r + 1) * 4, w, lane, src, pre);
+      hg256_mainloop<DMAPOS>(acc, lds, (r + 1) * 4, w, lane, src, pre);
     }
     __syncthreads();
     const int ms = missing;
@@ -935,6 +974,7 @@ static int g_trsm_lite = 1;        // psgd_kron_bf16_set_tuning key 3: 1 = the t
                                    // leading terms of the bf16 x 3 split (2^-16 per product, below the 2^-9 rounding dX arrives
                                    // with); 0 = all six terms (fp32-level).  Strip substitutions and diagonal-block inverses are
                                    // fp32 either way.  tests/test_kron_gpu.py::test_bf16_update_solves_with_ill_conditioned_factors
+static int g_dma_pos = 0;          // psgd_kron_bf16_set_tuning key 4: where a phase of the 256^2 kernels issues its LDS-DMA pieces (hg256_mainloop)
 static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, fused triangular pair when every
                                   //    tile gets its own CU, else 128^2 register-staged); 4: auto without the fused pair;
                                   // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
@@ -958,7 +998,12 @@ static int launch_hgemm_args(const HGemmArgs& g, hipStream_t st) {
   const int nt2 = (M / T2) * (N / T2);
   const bool fills = nt2 * 5 >= ((nt2 + 255) / 256) * 256 * 4;
   const bool use256 = big && (((g_hgemm_variant == 0 || g_hgemm_variant == 4) && kmode == 0 && fills) || g_hgemm_variant == 3);
-  if (use256) hipLaunchKernelGGL(k_hgemm_nt_256, dim3((M / T2) * (N / T2)), dim3(kThreads2), 0, st, g);
+  if (use256) {
+    const dim3 grid((M / T2) * (N / T2));
+    if (g_dma_pos == 1) hipLaunchKernelGGL(k_hgemm_nt_256<1>, grid, dim3(kThreads2), 0, st, g);
+    else if (g_dma_pos == 2) hipLaunchKernelGGL(k_hgemm_nt_256<2>, grid, dim3(kThreads2), 0, st, g);
+    else hipLaunchKernelGGL(k_hgemm_nt_256<0>, grid, dim3(kThreads2), 0, st, g);
+  }
   else if (g_hgemm_variant == 2 && interior && !sym) hipLaunchKernelGGL(k_hgemm_nt_dma, dim3(nt), dim3(kThreads), 0, st, g);
   else hipLaunchKernelGGL(k_hgemm_nt, dim3(nt), dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
@@ -1015,7 +1060,7 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
   static int blocks_per_cu = -1;
   if (blocks_per_cu < 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&k_hgemm_tri_pair_256), kThreads2, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&k_hgemm_tri_pair_256<0>), kThreads2, 0) !=
         hipSuccess) n = 0;
     blocks_per_cu = n;
   }
@@ -1029,7 +1074,9 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
     const int cc = (tiles_n - c0 < cpl) ? tiles_n - c0 : cpl;
     HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, c0, cc,
                    k.flags + 4 + flag_set * tiles_m * tiles_n, k.flags, g_spin_limit};
-    hipLaunchKernelGGL(k_hgemm_tri_pair_256, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
+    if (g_dma_pos == 1) hipLaunchKernelGGL(k_hgemm_tri_pair_256<1>, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
+    else if (g_dma_pos == 2) hipLaunchKernelGGL(k_hgemm_tri_pair_256<2>, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
+    else hipLaunchKernelGGL(k_hgemm_tri_pair_256<0>, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
     if (hipGetLastError() != hipSuccess) return 1;
   }
   return 0;
@@ -1109,6 +1156,7 @@ int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 0) { g_hgemm_variant = value; return PSGD_OK; }
   if (key == 1) { g_two_pairs = value; return PSGD_OK; }
   if (key == 3) { g_trsm_lite = value; return PSGD_OK; }
+  if (key == 4) { g_dma_pos = (value >= 0 && value <= 2) ? value : 0; return PSGD_OK; }
   if (key == 2) { g_spin_limit = (value < 0 || value > 30) ? (1u << 22) : (1u << value); return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
