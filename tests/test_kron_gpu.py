@@ -867,6 +867,72 @@ def test_sparse_formats_large(psgd, fmt, sl, sr):
     assert np.array_equal(_dev(a32[0]).cpu().numpy(), a32[0])
 
 
+@pytest.mark.parametrize("M,N", [(1024, 1024), (1100, 530), (2048, 1536), (700, 3000), (4096, 1040), (2304, 2304)])
+def test_solves_through_group_inverses_agree_with_substitution(psgd, hip_lib, M, N):
+    """Factors with n >= 1024 solve psgd.py:174 through explicit inverses of their 2048-column diagonal groups (recursive
+    doubling from the inverted 32-blocks; one product per group) instead of 512-column substitution strips; tuning key 11
+    selects.  Both routes within the parity bars of the fp64 oracle, and of each other."""
+    rng = np.random.default_rng(M * 3 + N)
+    Ql, Qr = (_tri_factor(rng, M) * 2.0).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    dX = rng.standard_normal((M, N)).astype(np.float32)
+    dG = (dX * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))).astype(np.float32)
+    outs = {}
+    try:
+        for inv in (1, 0):
+            hip_lib.psgd_kron_set_tuning(11, inv)
+            outs[inv] = [t.cpu().numpy().astype(np.float64) for t in psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)]
+    finally:
+        hip_lib.psgd_kron_set_tuning(11, 1)
+    ref = orc.update_precond_kron(*(a.astype(np.float64) for a in (Ql, Qr, dX, dG)), 0.01)
+    rho = np.sqrt(np.max(np.abs(Ql.astype(np.float64))) / np.max(np.abs(Qr.astype(np.float64))))
+    for i, q0 in enumerate((Ql.astype(np.float64) / rho, Qr.astype(np.float64) * rho)):
+        for inv in (1, 0):
+            assert rel_err(outs[inv][i], ref[i]) < TOL, (inv, i)
+            assert rel_err(outs[inv][i] - q0, ref[i] - q0) < INCR_TOL, (inv, i)
+        assert rel_err(outs[1][i], outs[0][i]) < TOL
+
+
+def _spd_cholesky_factor(rng, n, cond_h):
+    """Upper-triangular Q with Q'Q = H^-1 for an SPD H with random eigenvectors and cond(H) = cond_h: what a converged
+    PSGD factor looks like (psgd.py:175-179 drives Q'Q towards H^-1); cond(Q) = sqrt(cond_h), genuinely ill-conditioned
+    (not a diagonal scaling)."""
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.exp(np.linspace(0.0, np.log(cond_h), n))
+    return np.linalg.cholesky((V / lam) @ V.T).T
+
+
+@pytest.mark.parametrize("cond_q", [1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6])
+def test_group_inverse_solves_over_condition_numbers(psgd, hip_lib, cond_q):
+    """The inverse route against substitution and the fp64 oracle for factors of condition 1 ... 1e6 (Cholesky factors of
+    SPD matrices with random eigenvectors; cond(Q) = cond_q for both factors).  The oracle comparison is on the fp32-rounded
+    factors, so what is measured is the error of the solves and products, not of the rounding of the inputs.  Bars: the
+    states at 1e-5; the increments at 2e-3 up to cond 1e4 (as test_update_with_ill_conditioned_factors); beyond, the bar
+    is the substitution route's own error x 3 -- both routes lose accuracy with the conditioning, the inverse route must
+    not lose more than that."""
+    rng = np.random.default_rng(int(np.log10(cond_q)) + 50)
+    M, N = 1024, 1152
+    Ql = _spd_cholesky_factor(rng, M, cond_q ** 2).astype(np.float32) if cond_q > 1 else np.eye(M, dtype=np.float32)
+    Qr = _spd_cholesky_factor(rng, N, cond_q ** 2).astype(np.float32) if cond_q > 1 else np.eye(N, dtype=np.float32)
+    Ql /= np.max(np.abs(Ql)); Qr /= np.max(np.abs(Qr))
+    dX = rng.standard_normal((M, N)).astype(np.float32)
+    Ql64, Qr64 = Ql.astype(np.float64), Qr.astype(np.float64)
+    dG = (np.linalg.solve(Ql64.T @ Ql64, dX) @ np.linalg.inv(Qr64.T @ Qr64) * np.exp(rng.uniform(-0.5, 0.5, (1, N)))).astype(np.float32)
+    outs = {}
+    try:
+        for inv in (1, 0):
+            hip_lib.psgd_kron_set_tuning(11, inv)
+            outs[inv] = [t.cpu().numpy().astype(np.float64) for t in psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)]
+    finally:
+        hip_lib.psgd_kron_set_tuning(11, 1)
+    ref = orc.update_precond_kron(Ql64, Qr64, dX.astype(np.float64), dG.astype(np.float64), 0.01)
+    rho = np.sqrt(np.max(np.abs(Ql64)) / np.max(np.abs(Qr64)))
+    for i, q0 in enumerate((Ql64 / rho, Qr64 * rho)):
+        e_inv, e_sub = rel_err(outs[1][i] - q0, ref[i] - q0), rel_err(outs[0][i] - q0, ref[i] - q0)
+        assert np.isfinite(outs[1][i]).all()
+        assert rel_err(outs[1][i], ref[i]) < max(TOL, 3 * rel_err(outs[0][i], ref[i])), (i, cond_q)
+        assert e_inv < (INCR_TOL if cond_q <= 1e4 else max(INCR_TOL, 3 * e_sub)), (i, cond_q, e_inv, e_sub)
+
+
 @pytest.mark.parametrize("M,N", [(300, 200), (1100, 530), (2048, 1536)])
 def test_update_with_ill_conditioned_factors(psgd, M, N):
     """Factors with cond(Q) ~ 1e4 (diagonals spread over four decades, dense upper triangles): the two triangular solves of
