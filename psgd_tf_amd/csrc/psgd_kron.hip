@@ -622,6 +622,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_pair(GemmPair p) {
   else gemm_body_x3<MA0, MB0, false>(g, by * 128, bx * 128, L);
 }
 
+// Up to 8 independent products with the same operand layouts in one grid (the levels of the group inversion: a level's
+// products are each a fraction of the chip and a chain of K steps long, so one launch per product would serialise chains
+// that can run side by side).
+constexpr int kX3Multi = 8;
+struct GemmMulti { int count; int tile_end[kX3Multi]; GemmArgs g[kX3Multi]; };
+
+template <int MA, int MB>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_multi(GemmMulti m) {
+  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  int p = 0;
+  while (p + 1 < m.count && (int)blockIdx.x >= m.tile_end[p]) ++p;
+  const int id = blockIdx.x - (p ? m.tile_end[p - 1] : 0);
+  const GemmArgs& g = m.g[p];
+  int by, bx;
+  gemm_tile_from_id(id, (g.M + 127) / 128, (g.N + 127) / 128, g.kmode, by, bx);
+  gemm_body_x3<MA, MB, false>(g, by * 128, bx * 128, L);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The same fp32-accurate product on PRE-SPLIT operands ("planes").  k_gemm_x3 splits every operand element once per
 // output tile column/row it meets -- 32 times at 4096^2 -- and stages it through registers; measured (tools/micro/
@@ -1343,7 +1361,7 @@ __global__ __launch_bounds__(64) void k_tri_inv32(const float* __restrict__ Q, i
 // ---------------------------------------------------------------------------------------------
 // Explicit inverses of the diagonal GROUPS of an upper-triangular factor (round 3; psgd.py:174 on GEMMs).
 // The blocked solve above spends its time in latency-bound pieces: 512-column strips (40 us each, matrix pipe 15 % busy)
-// and the K = 512 products between the strips of a group (16 %).  With the inverse of a whole 2048-column diagonal group
+// and the K = 512 products between the strips of a group (16 %).  With the inverse of a whole diagonal group (up to 4096 columns: the whole factor at the sizes this is for)
 // at hand, a group is ONE product  Y_g = R_g Inv_g  at the rate of the large GEMMs, followed by the wide update of the
 // columns to its right.  Inv_g comes from recursive doubling: the 32 x 32 diagonal blocks are inverted by substitution
 // (the balance launch does that already), and two inverted neighbours A^-1, C^-1 of size b merge into the inverse of
@@ -1352,9 +1370,9 @@ __global__ __launch_bounds__(64) void k_tri_inv32(const float* __restrict__ Q, i
 // diagonal factors with growing inverses) the solve through fp32 group inverses stays within 1.3-1.7x of fp32 substitution
 // (1-3e-6 relative at cond 1e7; profiles/r03_group_inverse_error_study.txt) -- triangular inversion is far more accurate
 // than its condition number suggests -- and a growth guard (max|Inv| max|T|) sends anything suspicious to substitution.
-constexpr int kInvGroup = 2048;
+constexpr int kInvGroup = 4096;
 constexpr int kInvMinN = 1024;        // factors below this keep the strip solve (one or two strips: nothing to gain)
-constexpr int kInvMaxGroups = 8;
+constexpr int kInvMaxGroups = 4;
 template <int N> struct IntK { static constexpr int value = N; };
 static inline int inv_pad(int s) { int p = 128; while (p < s) p <<= 1; return p; }   // 128 * 2^k >= s
 
@@ -2300,7 +2318,7 @@ static KronWs kron_layout(char* base, int M, int N) {
       if (pr.G) { k.invR = take(pr.elems * 4); k.invRp = planes(pr.elems); }
       if (pl.G) { k.invL = take(pl.elems * 4); k.invLp = planes(pl.elems); }
       k.invW = take((pr.elems + pl.elems));        // a level's W blocks: at most a quarter of the inverses' elements (x 4 bytes)
-      k.S1 = planes(big * 2048);
+      k.S1 = planes(big * (int64_t)kInvGroup);
     }
     if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
       k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
@@ -2387,6 +2405,41 @@ static int launch_gemm_two(const GemmArgs& a, const GemmArgs& b, hipStream_t st)
     return rc ? rc : launch_gemm(b, st);
   }
   return (int)hipGetLastError();
+}
+
+// `count` independent products in as few launches as possible: groups of up to 8 on the split GEMM when every product of a
+// group has the same operand layouts (and the products are large enough for 128-tiles), else one launch each.
+static int launch_gemm_multi(const GemmArgs* g, int count, hipStream_t st) {
+  for (int q0 = 0; q0 < count; q0 += kX3Multi) {
+    const int nb = (count - q0 < kX3Multi) ? count - q0 : kX3Multi;
+    int ma = -1, mb = -1;
+    bool uniform = g_gemm_x3 && g_force_gemm == 0;
+    GemmMulti m;
+    m.count = nb;
+    int tiles = 0;
+    for (int q = 0; q < nb && uniform; ++q) {
+      int a, b;
+      x3_host_modes(g[q0 + q], a, b);
+      if (q == 0) { ma = a; mb = b; }
+      uniform = (a == ma && b == mb && !g[q0 + q].lite && g[q0 + q].M >= 128 && g[q0 + q].N >= 128);
+      m.g[q] = g[q0 + q];
+      tiles += ((g[q0 + q].N + 127) / 128) * ((g[q0 + q].M + 127) / 128);
+      m.tile_end[q] = tiles;
+    }
+    if (!uniform) {
+      for (int q = 0; q < nb; ++q)
+        if (launch_gemm(g[q0 + q], st)) return 1;
+      continue;
+    }
+    const dim3 grid(tiles);
+    if (ma == X3_KVEC && mb == X3_XROW) hipLaunchKernelGGL((k_gemm_x3_multi<X3_KVEC, X3_XROW>), grid, dim3(kThreads), 0, st, m);
+    else if (ma == X3_KVEC && mb == X3_KVEC) hipLaunchKernelGGL((k_gemm_x3_multi<X3_KVEC, X3_KVEC>), grid, dim3(kThreads), 0, st, m);
+    else if (ma == X3_XROW && mb == X3_XROW) hipLaunchKernelGGL((k_gemm_x3_multi<X3_XROW, X3_XROW>), grid, dim3(kThreads), 0, st, m);
+    else if (ma == X3_XROW && mb == X3_KVEC) hipLaunchKernelGGL((k_gemm_x3_multi<X3_XROW, X3_KVEC>), grid, dim3(kThreads), 0, st, m);
+    else hipLaunchKernelGGL((k_gemm_x3_multi<X3_EDGE, X3_EDGE>), grid, dim3(kThreads), 0, st, m);
+    if (hipGetLastError() != hipSuccess) return 1;
+  }
+  return 0;
 }
 
 // C[M,N] = op(A) op(B); ta/tb: operand stored transposed (row-major [K,M] / [N,K])
@@ -2574,7 +2627,7 @@ static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
 struct InvCtx {
   InvPlan pl;
   const __bf16* invp;       // column-form planes (x = column, k = row) of group g's inverse at invp + 3 * pl.off[g]... see inv_planes_of
-  __bf16* rp;               // planes of [nvec x 2048] right-hand sides
+  __bf16* rp;               // planes of [nvec x kInvGroup] right-hand sides
 };
 static P3Buf inv_planes_of(const InvCtx& ic, int g) {
   return P3Buf{const_cast<__bf16*>(ic.invp) + 3 * ic.pl.off[g], (long)ic.pl.P[g], (long)ic.pl.P[g]};
@@ -2582,7 +2635,7 @@ static P3Buf inv_planes_of(const InvCtx& ic, int g) {
 
 // Qc / blk (optional): column-form planes of Q (x = column, k = row) and a plane buffer for [nvec x 2048] of Y: the wide
 // group updates (K = 2048) then run on planes -- the finished group is split once instead of once per column tile.
-// ic (optional): the inverse route -- every 2048-column group is one product with its inverse instead of strips.
+// ic (optional): the inverse route -- every group of kInvGroup columns is one product with its inverse instead of strips.
 static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
                    hipStream_t st, long xi = 0, long xj = 0, int lite = 0, const P3Buf* Qc = nullptr, __bf16* blk = nullptr,
                    bool inv_ready = false, const InvCtx* ic = nullptr) {
@@ -2756,8 +2809,7 @@ static int tri_group_inverses(const InvFactor* f, int nf, float* wbuf, hipStream
     for (int stage = 0; stage < 2; ++stage) {
       const GemmArgs* sx = stage ? s2 : s1;
       if (b >= 512) {
-        for (int q = 0; q < cnt; ++q)
-          if (launch_gemm(sx[q], st)) return 1;
+        if (launch_gemm_multi(sx, cnt, st)) return 1;
       } else {
         for (int q0 = 0; q0 < cnt; q0 += kMaxBatch)
           if (launch_gemm_batch(sx + q0, (cnt - q0 < kMaxBatch) ? cnt - q0 : kMaxBatch, st)) return 1;
@@ -3133,7 +3185,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // (the K = 512 trailing products of the solves were tried on planes too: 557 + 7 x 9 us of strip splits against 647 us
   // per solve -- their 16 K steps per block are dominated by the fixed parts of a block either way -- so only the wide
   // K = 2048 group updates use the factors' column-form planes)
-  // factors with n >= 1024: the diagonal 2048-column groups are inverted first (recursive doubling from the 32-blocks the
+  // factors with n >= 1024: the diagonal groups (kInvGroup columns: the whole factor up to 4096) are inverted first (recursive doubling from the 32-blocks the
   // balance launch inverted) and every group of a solve is one product with its inverse (tuning key 11)
   InvCtx icr = {}, icl = {};
   const InvCtx *pr = nullptr, *pl = nullptr;

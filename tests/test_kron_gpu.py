@@ -904,11 +904,12 @@ def _spd_cholesky_factor(rng, n, cond_h):
 @pytest.mark.parametrize("cond_q", [1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6])
 def test_group_inverse_solves_over_condition_numbers(psgd, hip_lib, cond_q):
     """The inverse route against substitution and the fp64 oracle for factors of condition 1 ... 1e6 (Cholesky factors of
-    SPD matrices with random eigenvectors; cond(Q) = cond_q for both factors).  The oracle comparison is on the fp32-rounded
-    factors, so what is measured is the error of the solves and products, not of the rounding of the inputs.  Bars: the
-    states at 1e-5; the increments at 2e-3 up to cond 1e4 (as test_update_with_ill_conditioned_factors); beyond, the bar
-    is the substitution route's own error x 3 -- both routes lose accuracy with the conditioning, the inverse route must
-    not lose more than that."""
+    SPD matrices with random eigenvectors; cond(Q) = cond_q for both factors).  The oracle runs on the fp32-rounded
+    factors, so what is measured is the error of the solves and products, not of the rounding of the inputs.  With genuinely
+    ill-conditioned factors (not the column scalings of test_update_with_ill_conditioned_factors) EVERY fp32 route loses
+    accuracy in the increments (eps x cond, amplified by the cancellation in A A' - Bt Bt'): the bars are the usual ones
+    (states 1e-5, increments 2e-3) or twice the substitution route's own error, whichever is larger -- the inverse route
+    must not lose more than substitution does."""
     rng = np.random.default_rng(int(np.log10(cond_q)) + 50)
     M, N = 1024, 1152
     Ql = _spd_cholesky_factor(rng, M, cond_q ** 2).astype(np.float32) if cond_q > 1 else np.eye(M, dtype=np.float32)
@@ -929,8 +930,10 @@ def test_group_inverse_solves_over_condition_numbers(psgd, hip_lib, cond_q):
     for i, q0 in enumerate((Ql64 / rho, Qr64 * rho)):
         e_inv, e_sub = rel_err(outs[1][i] - q0, ref[i] - q0), rel_err(outs[0][i] - q0, ref[i] - q0)
         assert np.isfinite(outs[1][i]).all()
-        assert rel_err(outs[1][i], ref[i]) < max(TOL, 3 * rel_err(outs[0][i], ref[i])), (i, cond_q)
-        assert e_inv < (INCR_TOL if cond_q <= 1e4 else max(INCR_TOL, 3 * e_sub)), (i, cond_q, e_inv, e_sub)
+        assert rel_err(outs[1][i], ref[i]) < max(TOL, 2 * rel_err(outs[0][i], ref[i])), (i, cond_q)
+        assert e_inv < max(INCR_TOL, 2 * e_sub), (i, cond_q, e_inv, e_sub)
+    if cond_q > 1:                      # (the key selects: the two routes are not the same arithmetic)
+        assert not (np.array_equal(outs[1][0], outs[0][0]) and np.array_equal(outs[1][1], outs[0][1]))
 
 
 @pytest.mark.parametrize("M,N", [(300, 200), (1100, 530), (2048, 1536)])
