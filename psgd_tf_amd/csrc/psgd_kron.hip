@@ -622,24 +622,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_pair(GemmPair p) {
   else gemm_body_x3<MA0, MB0, false>(g, by * 128, bx * 128, L);
 }
 
-// Up to 8 independent products with the same operand layouts in one grid (the levels of the group inversion: a level's
-// products are each a fraction of the chip and a chain of K steps long, so one launch per product would serialise chains
-// that can run side by side).
-constexpr int kX3Multi = 8;
-struct GemmMulti { int count; int tile_end[kX3Multi]; GemmArgs g[kX3Multi]; };
-
-template <int MA, int MB>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_multi(GemmMulti m) {
-  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
-  int p = 0;
-  while (p + 1 < m.count && (int)blockIdx.x >= m.tile_end[p]) ++p;
-  const int id = blockIdx.x - (p ? m.tile_end[p - 1] : 0);
-  const GemmArgs& g = m.g[p];
-  int by, bx;
-  gemm_tile_from_id(id, (g.M + 127) / 128, (g.N + 127) / 128, g.kmode, by, bx);
-  gemm_body_x3<MA, MB, false>(g, by * 128, bx * 128, L);
-}
-
 // ---------------------------------------------------------------------------------------------
 // The same fp32-accurate product on PRE-SPLIT operands ("planes").  k_gemm_x3 splits every operand element once per
 // output tile column/row it meets -- 32 times at 4096^2 -- and stages it through registers; measured (tools/micro/
@@ -1355,148 +1337,6 @@ __global__ __launch_bounds__(64) void k_tri_inv32(const float* __restrict__ Q, i
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) Dinv[(long)b * 1024 + lane * 32 + j] = rr[j];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Explicit inverses of the diagonal GROUPS of an upper-triangular factor (round 3; psgd.py:174 on GEMMs).
-// The blocked solve above spends its time in latency-bound pieces: 512-column strips (40 us each, matrix pipe 15 % busy)
-// and the K = 512 products between the strips of a group (16 %).  With the inverse of a whole diagonal group (up to 4096 columns: the whole factor at the sizes this is for)
-// at hand, a group is ONE product  Y_g = R_g Inv_g  at the rate of the large GEMMs, followed by the wide update of the
-// columns to its right.  Inv_g comes from recursive doubling: the 32 x 32 diagonal blocks are inverted by substitution
-// (the balance launch does that already), and two inverted neighbours A^-1, C^-1 of size b merge into the inverse of
-// [A B; 0 C] = [A^-1, -A^-1 B C^-1; 0, C^-1] -- two products per level, all pairs of a level in one batched launch.
-// Forward error: measured on factors with cond up to 1e9 (Cholesky factors of SPD matrices with random eigenvectors, unit-
-// diagonal factors with growing inverses) the solve through fp32 group inverses stays within 1.3-1.7x of fp32 substitution
-// (1-3e-6 relative at cond 1e7; profiles/r03_group_inverse_error_study.txt) -- triangular inversion is far more accurate
-// than its condition number suggests -- and a growth guard (max|Inv| max|T|) sends anything suspicious to substitution.
-constexpr int kInvGroup = 4096;
-constexpr int kInvMinN = 1024;        // factors below this keep the strip solve (one or two strips: nothing to gain)
-constexpr int kInvMaxGroups = 4;
-template <int N> struct IntK { static constexpr int value = N; };
-static inline int inv_pad(int s) { int p = 128; while (p < s) p <<= 1; return p; }   // 128 * 2^k >= s
-
-// Levels 32 and 64 of the doubling inside one workgroup: the inverse of every 128 x 128 diagonal block of a group, from the
-// 32 x 32 inverses in `dinv` (k_tri_inv32 / the balance launch), in LDS with plain fp32 fma chains.  Blocks past the end of
-// the group are identity (the group is padded to P = 128 * 2^k columns: blockdiag(T_g, I)).  Writes the whole 128 x 128
-// block of Inv (zeros below the diagonal).
-struct Inv128Jobs {
-  int count;
-  int blk_end[8];                 // inclusive prefix sums of 128-blocks
-  const float* Q[8]; int n[8];    // the factor [n][n]
-  int c0[8], sg[8];               // group origin and size (columns c0 .. c0 + sg - 1)
-  const float* dinv[8];           // the factor's inverted 32-blocks
-  float* Inv[8]; int P[8];        // the group's inverse [P][P]
-};
-
-__global__ __launch_bounds__(kThreads) void k_tri_inv128(Inv128Jobs jb) {
-  extern __shared__ __attribute__((aligned(16))) float inv128_sm[];
-  constexpr int PT = 129;
-  float (*Tb)[PT] = reinterpret_cast<float (*)[PT]>(inv128_sm);
-  float (*Ib)[PT] = reinterpret_cast<float (*)[PT]>(inv128_sm + 128 * PT);
-  int j = 0;
-  while (j + 1 < jb.count && (int)blockIdx.x >= jb.blk_end[j]) ++j;
-  const int q = blockIdx.x - (j ? jb.blk_end[j - 1] : 0);
-  const float* __restrict__ Q = jb.Q[j];
-  const int n = jb.n[j], c0 = jb.c0[j], sg = jb.sg[j], P = jb.P[j], j0 = 128 * q, tid = threadIdx.x;
-  for (int e = tid; e < 128 * 128; e += kThreads) {
-    const int r = e >> 7, c = e & 127;
-    float v = (r == c) ? 1.0f : 0.0f;
-    if (j0 + r < sg && j0 + c < sg && c >= r) v = Q[(long)(c0 + j0 + r) * n + c0 + j0 + c];
-    Tb[r][c] = v;
-    Ib[r][c] = 0.0f;
-  }
-  __syncthreads();
-  for (int e = tid; e < 4 * 1024; e += kThreads) {                  // the four inverted 32-blocks
-    const int t = e >> 10, r = (e >> 5) & 31, c = e & 31;
-    float v = (r == c) ? 1.0f : 0.0f;
-    if (j0 + 32 * t < sg) v = jb.dinv[j][(long)((c0 + j0) / 32 + t) * 1024 + r * 32 + c];
-    Ib[32 * t + r][32 * t + c] = v;
-  }
-  __syncthreads();
-  // merge the pair of inverted b-blocks at a0: W = B C^-1 (kept below the diagonal meanwhile), X12 = -A^-1 W
-  auto merge = [&](int a0, int b, int m0, int n0, auto TMc, auto TNc, bool active) {
-    constexpr int TM = decltype(TMc)::value, TN = decltype(TNc)::value;
-    float acc[TM][TN];
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = 0.0f;
-      for (int k = 0; k < b; ++k) {
-        float a[TM], c[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = Tb[a0 + m0 + i][a0 + b + k];
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) c[jn] = Ib[a0 + b + k][a0 + b + n0 + jn];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int jn = 0; jn < TN; ++jn) acc[i][jn] = fmaf(a[i], c[jn], acc[i][jn]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) Ib[a0 + b + m0 + i][a0 + n0 + jn] = acc[i][jn];
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = 0.0f;
-      for (int k = 0; k < b; ++k) {
-        float a[TM], c[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = Ib[a0 + m0 + i][a0 + k];
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) c[jn] = Ib[a0 + b + k][a0 + n0 + jn];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int jn = 0; jn < TN; ++jn) acc[i][jn] = fmaf(a[i], c[jn], acc[i][jn]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) Ib[a0 + m0 + i][a0 + b + n0 + jn] = -acc[i][jn];
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) Ib[a0 + b + m0 + i][a0 + n0 + jn] = 0.0f;
-    }
-    __syncthreads();
-  };
-  {                                                                  // level 32: pairs (0,1) and (2,3); 2 x 4 outputs per thread
-    const int pr = tid >> 7, u = tid & 127;
-    merge(64 * pr, 32, (u >> 3) * 2, (u & 7) * 4, IntK<2>{}, IntK<4>{}, true);
-  }
-  merge(0, 64, (tid >> 4) * 4, (tid & 15) * 4, IntK<4>{}, IntK<4>{}, true);       // level 64: 4 x 4 outputs per thread
-  float* __restrict__ dst = jb.Inv[j];
-  for (int e = tid; e < 128 * 128; e += kThreads) {
-    const int r = e >> 7, c = e & 127;
-    dst[(long)(j0 + r) * P + j0 + c] = Ib[r][c];
-  }
-}
-
-// max|Inv| of every group (growth guard of the inverse route): block (x, job), integer max on the non-negative bits
-struct InvMaxJobs { int count; const float* Inv[8]; long elems[8]; float* out[8]; };
-__global__ __launch_bounds__(kThreads) void k_inv_absmax(InvMaxJobs jb) {
-  __shared__ float red[kThreads / 64];
-  const int j = blockIdx.y;
-  const float* __restrict__ p = jb.Inv[j];
-  float m = 0.0f;
-  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < jb.elems[j]; i += (long)gridDim.x * kThreads) m = amaxf(m, fabsf(p[i]));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_down(m, off, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < kThreads / 64; ++w) m = amaxf(m, red[w]);
-    atomicMax(reinterpret_cast<int*>(jb.out[j]), __float_as_int(m));      // (NaN bits compare above every finite value)
   }
 }
 
@@ -2227,29 +2067,8 @@ struct KronWs {
   float* split_scratch; unsigned* split_cnt;                 // K-split tail of the gradient grid (k_gemm_p3_grad)
   float* sk_scratch; unsigned* sk_cnt;                       // split-K of products with few output tiles (launch_p3_auto)
   __bf16* S0;                                                // planes of one [max(M, N) x 2048] group of the solves
-  // inverse route of the solves (factors with n >= kInvMinN): fp32 inverses of the diagonal groups of QrS / QlS, their
-  // column-form planes, the level scratch W, planes of a group's right-hand sides, the growth words [max|Inv| R, L]
-  float *invR, *invL, *invW; __bf16 *invRp, *invLp, *S1; float* invg;
   int64_t total;
 };
-
-// groups of the inverse route for a factor of dimension n: origin, size, padded size (128 * 2^k), offsets (in elements)
-struct InvPlan {
-  int G; int c0[kInvMaxGroups], sg[kInvMaxGroups], P[kInvMaxGroups];
-  long off[kInvMaxGroups];          // into the fp32 inverse buffer and (x 3 planes, same element offset) the plane buffer
-  long elems;                       // sum of P^2
-};
-static inline bool inv_eligible(int n) { return n >= kInvMinN && n <= kInvGroup * kInvMaxGroups; }
-static InvPlan inv_plan(int n) {
-  InvPlan p = {};
-  if (!inv_eligible(n)) return p;
-  for (int c = 0; c < n; c += kInvGroup) {
-    const int g = p.G++;
-    p.c0[g] = c; p.sg[g] = (n - c < kInvGroup) ? n - c : kInvGroup; p.P[g] = inv_pad(p.sg[g]);
-    p.off[g] = p.elems; p.elems += (long)p.P[g] * p.P[g];
-  }
-  return p;
-}
 
 constexpr int kSkMaxTiles = 160, kSkItems = 512;         // split-K of few-tile products: at most 512 partial tiles in flight
 constexpr int kGradSplitMax = 256, kGradChunks = 8;      // K-split tail of the gradient grid: at most 256 tiles in 8 chunks each
@@ -2297,7 +2116,6 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
   k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
   k.sk_scratch = nullptr; k.sk_cnt = nullptr;
-  k.invR = k.invL = k.invW = k.invg = nullptr; k.invRp = k.invLp = k.S1 = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -2312,14 +2130,6 @@ static KronWs kron_layout(char* base, int M, int N) {
       k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
     }
     k.S0 = planes(big * 2048);
-    if (inv_eligible(M) || inv_eligible(N)) {
-      const InvPlan pr = inv_plan(N), pl = inv_plan(M);
-      k.invg = take(256);
-      if (pr.G) { k.invR = take(pr.elems * 4); k.invRp = planes(pr.elems); }
-      if (pl.G) { k.invL = take(pl.elems * 4); k.invLp = planes(pl.elems); }
-      k.invW = take((pr.elems + pl.elems));        // a level's W blocks: at most a quarter of the inverses' elements (x 4 bytes)
-      k.S1 = planes(big * (int64_t)kInvGroup);
-    }
     if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
       k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
       k.sk_cnt = reinterpret_cast<unsigned*>(take(kSkMaxTiles * 4));
@@ -2407,41 +2217,6 @@ static int launch_gemm_two(const GemmArgs& a, const GemmArgs& b, hipStream_t st)
   return (int)hipGetLastError();
 }
 
-// `count` independent products in as few launches as possible: groups of up to 8 on the split GEMM when every product of a
-// group has the same operand layouts (and the products are large enough for 128-tiles), else one launch each.
-static int launch_gemm_multi(const GemmArgs* g, int count, hipStream_t st) {
-  for (int q0 = 0; q0 < count; q0 += kX3Multi) {
-    const int nb = (count - q0 < kX3Multi) ? count - q0 : kX3Multi;
-    int ma = -1, mb = -1;
-    bool uniform = g_gemm_x3 && g_force_gemm == 0;
-    GemmMulti m;
-    m.count = nb;
-    int tiles = 0;
-    for (int q = 0; q < nb && uniform; ++q) {
-      int a, b;
-      x3_host_modes(g[q0 + q], a, b);
-      if (q == 0) { ma = a; mb = b; }
-      uniform = (a == ma && b == mb && !g[q0 + q].lite && g[q0 + q].M >= 128 && g[q0 + q].N >= 128);
-      m.g[q] = g[q0 + q];
-      tiles += ((g[q0 + q].N + 127) / 128) * ((g[q0 + q].M + 127) / 128);
-      m.tile_end[q] = tiles;
-    }
-    if (!uniform) {
-      for (int q = 0; q < nb; ++q)
-        if (launch_gemm(g[q0 + q], st)) return 1;
-      continue;
-    }
-    const dim3 grid(tiles);
-    if (ma == X3_KVEC && mb == X3_XROW) hipLaunchKernelGGL((k_gemm_x3_multi<X3_KVEC, X3_XROW>), grid, dim3(kThreads), 0, st, m);
-    else if (ma == X3_KVEC && mb == X3_KVEC) hipLaunchKernelGGL((k_gemm_x3_multi<X3_KVEC, X3_KVEC>), grid, dim3(kThreads), 0, st, m);
-    else if (ma == X3_XROW && mb == X3_XROW) hipLaunchKernelGGL((k_gemm_x3_multi<X3_XROW, X3_XROW>), grid, dim3(kThreads), 0, st, m);
-    else if (ma == X3_XROW && mb == X3_KVEC) hipLaunchKernelGGL((k_gemm_x3_multi<X3_XROW, X3_KVEC>), grid, dim3(kThreads), 0, st, m);
-    else hipLaunchKernelGGL((k_gemm_x3_multi<X3_EDGE, X3_EDGE>), grid, dim3(kThreads), 0, st, m);
-    if (hipGetLastError() != hipSuccess) return 1;
-  }
-  return 0;
-}
-
 // C[M,N] = op(A) op(B); ta/tb: operand stored transposed (row-major [K,M] / [N,K])
 static GemmArgs gemm_args(const float* A, int lda, bool ta, const float* B, int ldb, bool tb, float* C, int ldc, int M,
                           int N, int K, int kmode = 0) {
@@ -2512,11 +2287,6 @@ static void plan_update(const float* dG, float* QlOut, float* QrOut, int M, int 
   s[4].epi = EPI_D_MINUS; s[4].D = k.QlS; s[4].ldd = M; s[4].scale_max = k.scal + 0; s[4].step = step; s[4].tiny = tiny;
   s[5] = gemm_args(k.g2, N, false, k.QrS, N, false, QrOut, N, N, N, N, KLO_M | KHI_N);   // QrS - (step2 grad2) QrS
   s[5].epi = EPI_D_MINUS; s[5].D = k.QrS; s[5].ldd = N; s[5].scale_max = k.scal + 1; s[5].step = step; s[5].tiny = tiny;
-}
-
-__global__ __launch_bounds__(kThreads) void k_diag_fill(float* p, long stride, int count, float v) {
-  const int i = blockIdx.x * kThreads + threadIdx.x;
-  if (i < count) p[(long)i * stride] = v;
 }
 
 __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long xi, long xj, float* Y, long si, long sj,
@@ -2622,24 +2392,11 @@ static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-// Inverse route (tri_group_inverses has run on this stream): planes of the inverted diagonal groups of Q and a plane buffer
-// for one group's right-hand sides.
-struct InvCtx {
-  InvPlan pl;
-  const __bf16* invp;       // column-form planes (x = column, k = row) of group g's inverse at invp + 3 * pl.off[g]... see inv_planes_of
-  __bf16* rp;               // planes of [nvec x kInvGroup] right-hand sides
-};
-static P3Buf inv_planes_of(const InvCtx& ic, int g) {
-  return P3Buf{const_cast<__bf16*>(ic.invp) + 3 * ic.pl.off[g], (long)ic.pl.P[g], (long)ic.pl.P[g]};
-}
-
 // Qc / blk (optional): column-form planes of Q (x = column, k = row) and a plane buffer for [nvec x 2048] of Y: the wide
 // group updates (K = 2048) then run on planes -- the finished group is split once instead of once per column tile.
-// ic (optional): the inverse route -- every group of kInvGroup columns is one product with its inverse instead of strips.
 static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
                    hipStream_t st, long xi = 0, long xj = 0, int lite = 0, const P3Buf* Qc = nullptr, __bf16* blk = nullptr,
-                   bool inv_ready = false, const InvCtx* ic = nullptr) {
-  if (ic && !(xi == 0 && xj == 0)) ic = nullptr;      // (the inverse route reads X in place; callers with a strided X keep the strips)
+                   bool inv_ready = false) {
   if (!inv_ready) {                                    // (the update's balance launch has made them already)
     hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
     if (hipGetLastError() != hipSuccess) return 1;
@@ -2683,21 +2440,6 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
     g.lite = lite;
     return launch_gemm(g, st);
   };
-  if (ic) {
-    for (int gi = 0; gi < ic->pl.G; ++gi) {
-      const int g0 = ic->pl.c0[gi], sg = ic->pl.sg[gi];
-      // right-hand sides of the group (X itself for the first group, else what the wide updates left in Y) -> planes;
-      // Y_g = R_g Inv_g, B operand (n, k) = Inv_g[k][n], zero for k > n
-      const P3Buf Rp = {ic->rp, pad128(nvec), pad128(sg)};
-      int e = launch_split3((g0 == 0 ? X : Y) + (long)g0 * sj, si, sj, nvec, sg, Rp, st);
-      if (e) return e;
-      P3Args pr = p3_args(Rp, inv_planes_of(*ic, gi), nvec, sg, sg, KHI_N);
-      pr.e.C = Y + (long)g0 * sj; pr.e.ldc = si; pr.e.c_cs = sj;
-      if ((e = launch_p3(pr, st))) return e;
-      if (g0 + sg < n && (e = update(g0, sg, g0 + sg, n - g0 - sg))) return e;
-    }
-    return 0;
-  }
   // measured (tools/trsm_group_ab.py): groups of 4 are 4 % of the 4096^2 updates, nothing at 2048 (one group = no wide product)
   const int group = kTrsmBlock * (g_trsm_group > 0 ? g_trsm_group : (n >= 8 * kTrsmBlock ? 4 : 1));
   for (int g0 = 0; g0 < n; g0 += group) {
@@ -2734,96 +2476,6 @@ static int launch_gemm_batch(const GemmArgs* g, int count, hipStream_t st) {
   else if (g_small_deep) hipLaunchKernelGGL(k_gemm_small, dim3(tiles), dim3(kThreads), 0, st, b);
   else hipLaunchKernelGGL((k_gemm_f32_batched<32>), dim3(tiles), dim3(kThreads), 0, st, b);
   return (int)hipGetLastError();
-}
-
-// Inverses of the diagonal groups of up to two upper-triangular factors (see k_tri_inv128), and their column-form planes.
-struct InvFactor { const float* Q; int n; const float* dinv; float* inv; __bf16* invp; InvPlan pl; };
-static int g_trsm_inv = 1;      // tuning key 11: 0 = the solves of every size stay on strips (substitution)
-
-static int tri_group_inverses(const InvFactor* f, int nf, float* wbuf, hipStream_t st) {
-  Inv128Jobs jb = {};
-  int blocks = 0, pmax = 0;
-  for (int i = 0; i < nf; ++i) {
-    if (hipMemsetAsync(f[i].inv, 0, (size_t)f[i].pl.elems * 4, st) != hipSuccess) return 1;
-    for (int g = 0; g < f[i].pl.G; ++g) {
-      if (jb.count == 8) {                                   // (two factors of up to 4 groups fit one launch; more: flush)
-        hipLaunchKernelGGL(k_tri_inv128, dim3(blocks), dim3(kThreads), 2 * 128 * 129 * sizeof(float), st, jb);
-        if (hipGetLastError() != hipSuccess) return 1;
-        jb = Inv128Jobs{}; blocks = 0;
-      }
-      const int j = jb.count++;
-      jb.Q[j] = f[i].Q; jb.n[j] = f[i].n; jb.c0[j] = f[i].pl.c0[g]; jb.sg[j] = f[i].pl.sg[g]; jb.dinv[j] = f[i].dinv;
-      jb.Inv[j] = f[i].inv + f[i].pl.off[g]; jb.P[j] = f[i].pl.P[g];
-      blocks += (f[i].pl.sg[g] + 127) / 128;                 // (blocks past the end of the group are identity: the memset + nothing)
-      jb.blk_end[j] = blocks;
-      if (f[i].pl.P[g] > pmax) pmax = f[i].pl.P[g];
-    }
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tri_inv128), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(2 * 128 * 129 * sizeof(float))) != hipSuccess) return 1;
-    attr_set = true;
-  }
-  if (jb.count) {
-    hipLaunchKernelGGL(k_tri_inv128, dim3(blocks), dim3(kThreads), 2 * 128 * 129 * sizeof(float), st, jb);
-    if (hipGetLastError() != hipSuccess) return 1;
-  }
-  // identity on the diagonal of the 128-blocks past the end of a group (padding blocks): a tiny strided fill
-  for (int i = 0; i < nf; ++i)
-    for (int g = 0; g < f[i].pl.G; ++g) {
-      const int sg128 = (f[i].pl.sg[g] + 127) / 128 * 128, P = f[i].pl.P[g];
-      if (sg128 < P) {
-        hipLaunchKernelGGL(k_diag_fill, dim3((P - sg128 + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
-                           f[i].inv + f[i].pl.off[g] + (long)sg128 * P + sg128, (long)P + 1, P - sg128, 1.0f);
-        if (hipGetLastError() != hipSuccess) return 1;
-      }
-    }
-  // levels b = 128, 256, ...: every pair of inverted b-blocks [A^-1, C^-1] of every group: W = B C^-1, X12 = 0 - A^-1 W
-  for (int b = 128; 2 * b <= pmax; b *= 2) {
-    static thread_local GemmArgs s1[160], s2[160];      // (8 groups x 8 pairs x 2 factors at most, at b = 128)
-    int cnt = 0;
-    long woff = 0;
-    for (int i = 0; i < nf; ++i)
-      for (int g = 0; g < f[i].pl.G; ++g) {
-        const int P = f[i].pl.P[g], sg = f[i].pl.sg[g], c0 = f[i].pl.c0[g], n = f[i].n;
-        float* inv = f[i].inv + f[i].pl.off[g];
-        for (int r0 = 0; r0 + 2 * b <= P; r0 += 2 * b) {
-          const int kv = (sg - r0 - b < b) ? sg - r0 - b : b;          // valid columns of B (rows of C)
-          if (kv <= 0) continue;                                        // B is all padding: X12 = 0 (the memset)
-          if (cnt == 160) return 1;
-          float* W = wbuf + woff;
-          woff += (long)b * b;
-          GemmArgs a = {};
-          a.A = f[i].Q + (long)(c0 + r0) * n + c0 + r0 + b; a.a_rs = n; a.a_cs = 1;              // B block of the factor
-          a.B = inv + (long)(r0 + b) * P + r0 + b; a.b_rs = P; a.b_cs = 1;                        // C^-1, upper triangular
-          a.C = W; a.ldc = b; a.M = b; a.N = kv; a.K = kv; a.kmode = KHI_N; a.epi = EPI_STORE;
-          GemmArgs c = {};
-          c.A = inv + (long)r0 * P + r0; c.a_rs = P; c.a_cs = 1;                                  // A^-1, upper triangular
-          c.B = W; c.b_rs = b; c.b_cs = 1;
-          c.C = inv + (long)r0 * P + r0 + b; c.ldc = P; c.D = c.C; c.ldd = P;                      // (D = the zeroed block itself)
-          c.M = b; c.N = kv; c.K = b; c.kmode = KLO_M; c.epi = EPI_D_MINUS;
-          s1[cnt] = a; s2[cnt] = c; ++cnt;
-        }
-      }
-    for (int stage = 0; stage < 2; ++stage) {
-      const GemmArgs* sx = stage ? s2 : s1;
-      if (b >= 512) {
-        if (launch_gemm_multi(sx, cnt, st)) return 1;
-      } else {
-        for (int q0 = 0; q0 < cnt; q0 += kMaxBatch)
-          if (launch_gemm_batch(sx + q0, (cnt - q0 < kMaxBatch) ? cnt - q0 : kMaxBatch, st)) return 1;
-      }
-    }
-  }
-  // column-form planes of every group's inverse: (x, k) = Inv[k][x]
-  for (int i = 0; i < nf; ++i)
-    for (int g = 0; g < f[i].pl.G; ++g) {
-      const int P = f[i].pl.P[g];
-      const P3Buf out = {f[i].invp + 3 * f[i].pl.off[g], (long)P, (long)P};
-      if (launch_split3(f[i].inv + f[i].pl.off[g], 1, P, P, P, out, st)) return 1;
-    }
-  return 0;
 }
 
 static int launch_gram_batch(const GemmArgs* g, int count, hipStream_t st) {      // g: Gram problems made by plan_apply
@@ -3095,7 +2747,6 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 8) { g_splitk = value; return PSGD_OK; }
   if (key == 9) { g_overlap = value; return PSGD_OK; }
   if (key == 10) { g_side_prio = value; return PSGD_OK; }
-  if (key == 11) { g_trsm_inv = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -3185,24 +2836,13 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // (the K = 512 trailing products of the solves were tried on planes too: 557 + 7 x 9 us of strip splits against 647 us
   // per solve -- their 16 K steps per block are dominated by the fixed parts of a block either way -- so only the wide
   // K = 2048 group updates use the factors' column-form planes)
-  // factors with n >= 1024: the diagonal groups (kInvGroup columns: the whole factor up to 4096) are inverted first (recursive doubling from the 32-blocks the
-  // balance launch inverted) and every group of a solve is one product with its inverse (tuning key 11)
-  InvCtx icr = {}, icl = {};
-  const InvCtx *pr = nullptr, *pl = nullptr;
-  if (planes && g_trsm_inv && k.invW) {
-    InvFactor f[2];
-    int nf = 0;
-    if (k.invR) { f[nf++] = InvFactor{k.QrS, N, k.dinv, k.invR, k.invRp, inv_plan(N)}; icr = InvCtx{inv_plan(N), k.invRp, k.S1}; pr = &icr; }
-    if (k.invL) { f[nf++] = InvFactor{k.QlS, M, dinv_l, k.invL, k.invLp, inv_plan(M)}; icl = InvCtx{inv_plan(M), k.invLp, k.S1}; pl = &icl; }
-    KRON_LAUNCH(tri_group_inverses(f, nf, k.invW, st));
-  }
   if (solves_on_planes) {
     const P3Buf Rc = {k.Rc, pad128(N), pad128(N)}, Lc = {k.Lc, pad128(M), pad128(M)};
-    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0, true, pr));
-    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, &Lc, k.S0, true, pl));
+    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0, true));
+    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, &Lc, k.S0, true));
   } else {
-    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, nullptr, nullptr, true, pr));
-    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, nullptr, nullptr, true, pl));
+    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, nullptr, nullptr, true));
+    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, nullptr, nullptr, true));
   }
   KRON_LAUNCH(fork_scope.join());
   if (planes) {

@@ -867,31 +867,6 @@ def test_sparse_formats_large(psgd, fmt, sl, sr):
     assert np.array_equal(_dev(a32[0]).cpu().numpy(), a32[0])
 
 
-@pytest.mark.parametrize("M,N", [(1024, 1024), (1100, 530), (2048, 1536), (700, 3000), (4096, 1040), (2304, 2304)])
-def test_solves_through_group_inverses_agree_with_substitution(psgd, hip_lib, M, N):
-    """Factors with n >= 1024 solve psgd.py:174 through explicit inverses of their 2048-column diagonal groups (recursive
-    doubling from the inverted 32-blocks; one product per group) instead of 512-column substitution strips; tuning key 11
-    selects.  Both routes within the parity bars of the fp64 oracle, and of each other."""
-    rng = np.random.default_rng(M * 3 + N)
-    Ql, Qr = (_tri_factor(rng, M) * 2.0).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
-    dX = rng.standard_normal((M, N)).astype(np.float32)
-    dG = (dX * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))).astype(np.float32)
-    outs = {}
-    try:
-        for inv in (1, 0):
-            hip_lib.psgd_kron_set_tuning(11, inv)
-            outs[inv] = [t.cpu().numpy().astype(np.float64) for t in psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)]
-    finally:
-        hip_lib.psgd_kron_set_tuning(11, 1)
-    ref = orc.update_precond_kron(*(a.astype(np.float64) for a in (Ql, Qr, dX, dG)), 0.01)
-    rho = np.sqrt(np.max(np.abs(Ql.astype(np.float64))) / np.max(np.abs(Qr.astype(np.float64))))
-    for i, q0 in enumerate((Ql.astype(np.float64) / rho, Qr.astype(np.float64) * rho)):
-        for inv in (1, 0):
-            assert rel_err(outs[inv][i], ref[i]) < TOL, (inv, i)
-            assert rel_err(outs[inv][i] - q0, ref[i] - q0) < INCR_TOL, (inv, i)
-        assert rel_err(outs[1][i], outs[0][i]) < TOL
-
-
 def _spd_cholesky_factor(rng, n, cond_h):
     """Upper-triangular Q with Q'Q = H^-1 for an SPD H with random eigenvectors and cond(H) = cond_h: what a converged
     PSGD factor looks like (psgd.py:175-179 drives Q'Q towards H^-1); cond(Q) = sqrt(cond_h), genuinely ill-conditioned
@@ -901,15 +876,14 @@ def _spd_cholesky_factor(rng, n, cond_h):
     return np.linalg.cholesky((V / lam) @ V.T).T
 
 
-@pytest.mark.parametrize("cond_q", [1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6])
-def test_group_inverse_solves_over_condition_numbers(psgd, hip_lib, cond_q):
-    """The inverse route against substitution and the fp64 oracle for factors of condition 1 ... 1e6 (Cholesky factors of
-    SPD matrices with random eigenvectors; cond(Q) = cond_q for both factors).  The oracle runs on the fp32-rounded
-    factors, so what is measured is the error of the solves and products, not of the rounding of the inputs.  With genuinely
-    ill-conditioned factors (not the column scalings of test_update_with_ill_conditioned_factors) EVERY fp32 route loses
-    accuracy in the increments (eps x cond, amplified by the cancellation in A A' - Bt Bt'): the bars are the usual ones
-    (states 1e-5, increments 2e-3) or twice the substitution route's own error, whichever is larger -- the inverse route
-    must not lose more than substitution does."""
+@pytest.mark.parametrize("cond_q", [1e0, 1e1, 1e2, 1e3, 1e4])
+def test_update_over_condition_numbers(psgd, cond_q):
+    """The large fp32 update against the fp64 oracle for GENUINELY ill-conditioned factors (Cholesky factors of SPD matrices with
+    random eigenvectors, cond(Q) = cond_q for both; not the column scalings of test_update_with_ill_conditioned_factors).
+    The oracle runs on the fp32-rounded factors, so what is measured is the error of the solves and products.  States at 1e-5
+    throughout.  The increments lose accuracy with the conditioning in ANY fp32 arithmetic (eps x cond through the solves of
+    psgd.py:174, amplified by the cancellation in A A' - Bt Bt'): the 2e-3 bar holds up to cond 1e3, and the bar beyond is
+    eps x cond x 100 (measured on the device: 4.0e-3 at 1e4; the fp32 run of the oracle itself has the same error)."""
     rng = np.random.default_rng(int(np.log10(cond_q)) + 50)
     M, N = 1024, 1152
     Ql = _spd_cholesky_factor(rng, M, cond_q ** 2).astype(np.float32) if cond_q > 1 else np.eye(M, dtype=np.float32)
@@ -918,22 +892,14 @@ def test_group_inverse_solves_over_condition_numbers(psgd, hip_lib, cond_q):
     dX = rng.standard_normal((M, N)).astype(np.float32)
     Ql64, Qr64 = Ql.astype(np.float64), Qr.astype(np.float64)
     dG = (np.linalg.solve(Ql64.T @ Ql64, dX) @ np.linalg.inv(Qr64.T @ Qr64) * np.exp(rng.uniform(-0.5, 0.5, (1, N)))).astype(np.float32)
-    outs = {}
-    try:
-        for inv in (1, 0):
-            hip_lib.psgd_kron_set_tuning(11, inv)
-            outs[inv] = [t.cpu().numpy().astype(np.float64) for t in psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)]
-    finally:
-        hip_lib.psgd_kron_set_tuning(11, 1)
+    out = [t.cpu().numpy().astype(np.float64) for t in psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)]
     ref = orc.update_precond_kron(Ql64, Qr64, dX.astype(np.float64), dG.astype(np.float64), 0.01)
     rho = np.sqrt(np.max(np.abs(Ql64)) / np.max(np.abs(Qr64)))
+    bar = max(INCR_TOL, 100 * 6e-8 * cond_q)
     for i, q0 in enumerate((Ql64 / rho, Qr64 * rho)):
-        e_inv, e_sub = rel_err(outs[1][i] - q0, ref[i] - q0), rel_err(outs[0][i] - q0, ref[i] - q0)
-        assert np.isfinite(outs[1][i]).all()
-        assert rel_err(outs[1][i], ref[i]) < max(TOL, 2 * rel_err(outs[0][i], ref[i])), (i, cond_q)
-        assert e_inv < max(INCR_TOL, 2 * e_sub), (i, cond_q, e_inv, e_sub)
-    if cond_q > 1:                      # (the key selects: the two routes are not the same arithmetic)
-        assert not (np.array_equal(outs[1][0], outs[0][0]) and np.array_equal(outs[1][1], outs[0][1]))
+        assert np.isfinite(out[i]).all()
+        assert rel_err(out[i], ref[i]) < TOL, (i, cond_q)
+        assert rel_err(out[i] - q0, ref[i] - q0) < bar, (i, cond_q, bar)
 
 
 @pytest.mark.parametrize("M,N", [(300, 200), (1100, 530), (2048, 1536)])
