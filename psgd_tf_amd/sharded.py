@@ -32,6 +32,7 @@ import torch.distributed as dist
 
 from . import _lib
 from . import preconditioned_stochastic_gradient_descent as _psgd
+from . import uvd_wide as _wide
 
 
 class HipStages:
@@ -41,8 +42,8 @@ class HipStages:
     def __init__(self, device, n_local, r):
         self.device, self.N, self.r = device, int(n_local), int(r)
         if self.r > _lib.UVD_MAX_RANK:
-            raise _lib.PsgdHipError("row-sharded UVd supports ranks up to %d (the wide-rank path of uvd_wide.py is "
-                                    "single-GPU), got r = %d" % (_lib.UVD_MAX_RANK, self.r))
+            raise _lib.PsgdHipError("the stage kernels take ranks up to %d; wider preconditioners go through uvd_wide.py "
+                                    "(the sharded entry points route them there), got r = %d" % (_lib.UVD_MAX_RANK, self.r))
         self.lib = _lib.load()
         self.ws = _psgd.uvd_workspace(device, self.N, self.r)
         self._views = {}
@@ -220,8 +221,23 @@ def _exchange(be, stage, group):
     be.fold(stage, gathered, world)
 
 
+def _wide_reduce(group):
+    """Exchange of the wide-rank path (r > 32, uvd_wide.py): an all-reduce of one small stacked tensor per exchange point.
+    Every rank receives the same bits (the collective computes each element once and distributes it)."""
+    def reduce(t, op):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=group)
+        return t
+    return reduce
+
+
+def _is_wide(U, backend):
+    return backend is None and U.dim() == 2 and U.shape[1] > _lib.UVD_MAX_RANK
+
+
 def precond_grad_UVd_math(U, V, d, g, group=None, backend=None):
     """Sharded psgd.py:619-627 on this rank's rows; returns this rank's rows of the result.  2 exchanges."""
+    if _is_wide(U, backend):
+        return _wide.precond_grad(U, V, d, g, _psgd.uvd_workspace, reduce=_wide_reduce(group))
     be = backend if backend is not None else hip_backend_for(U)
     be.apply_sweep1(V, d, g)
     _exchange(be, 1, group)
@@ -233,6 +249,10 @@ def precond_grad_UVd_math(U, V, d, g, group=None, backend=None):
 def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_U=None, generator=None,
                              group=None, backend=None):
     """Sharded psgd.py:554-617 on this rank's rows (in place, returns None).  2 exchanges (+1 on the balance branch)."""
+    if _is_wide(U, backend):
+        balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
+        return _wide.update(U, V, d, v, h, float(step), float(tiny), balance, update_U, _psgd.uvd_workspace,
+                            reduce=_wide_reduce(group))
     be = backend if backend is not None else hip_backend_for(U)
     balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
     if balance:
@@ -250,7 +270,11 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
 def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, balance=None, update_U=None,
                                              generator=None, group=None, backend=None):
     """Sharded fused update -> apply; returns this rank's rows of the preconditioned gradient.
-    2 exchanges: the Gram; the 4r column sums of sweep 2 with max|nablaD| in one buffer."""
+    2 exchanges: the Gram; the 4r column sums of sweep 2 with max|nablaD| in one buffer.  (r > 32: the update, then the
+    apply, on the wide-rank path: 4 exchanges.)"""
+    if _is_wide(U, backend):
+        update_precond_UVd_math_(U, V, d, v, h, step, tiny, balance=balance, update_U=update_U, generator=generator, group=group)
+        return precond_grad_UVd_math(U, V, d, g, group=group)
     be = backend if backend is not None else hip_backend_for(U)
     balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
     if balance:

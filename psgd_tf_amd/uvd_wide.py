@@ -15,6 +15,11 @@ operations on N-vectors (d .* h, v ./ d, nablaD, the d update) and the r x r alg
 of psgd.py:594-596 / :608-610) -- all on the device, nothing synchronises.  Same formulas, same order of operations on
 the state as psgd.py:554-627; costs (2c - 1) passes over U and V for the Gram instead of one, so r <= 32 stays on the
 specialised path.
+
+Row-sharded use (psgd_tf_amd/sharded.py, round 3): every function takes `reduce(tensor, "sum" | "max")`, applied to the
+quantities that are sums or maxima over the rows -- all column sums of one stage stacked into ONE tensor, all Gram blocks
+into one, the maxima of |U|, |V| (balance branch) and of |nablaD| -- so a sharded apply costs 2 exchanges and a sharded update
+2 (+ 1 on the balance branch), like the specialised path.  The default reduces nothing (one GPU holds all rows).
 """
 import ctypes
 
@@ -111,41 +116,46 @@ class _Ctx:
         return self._gidx
 
 
-def precond_grad(U, V, d, g, workspace_fn):
+def _no_reduce(t, op):
+    return t
+
+
+def precond_grad(U, V, d, g, workspace_fn, reduce=_no_reduce):
     """psgd.py:619-627 for r > 32."""
     cx = _Ctx(U, workspace_fn)
     Uc, Vc = cx.split(U), cx.split(V)
     shape = g.shape
     t = (d.reshape(-1) * g.reshape(-1)).contiguous()                           # :625
     g1 = t.clone()
+    s1 = reduce(torch.stack([cx.colsums(Vc[k], [t]) for k in range(cx.c)]), "sum")       # V't, all chunks: one exchange
     for k in range(cx.c):                                                      # g1 = t + U (V't)          :544
-        s1 = cx.colsums(Vc[k], [t])
-        cx.axpy(Uc[k], [g1], s1)
+        cx.axpy(Uc[k], [g1], s1[k])
     out = g1.clone()
+    s2 = reduce(torch.stack([cx.colsums(Uc[k], [g1]) for k in range(cx.c)]), "sum")      # U'g1
     for k in range(cx.c):                                                      # g1 + V (U'g1)             :626
-        s2 = cx.colsums(Uc[k], [g1])
-        cx.axpy(Vc[k], [out], s2)
+        cx.axpy(Vc[k], [out], s2[k])
     return (d.reshape(-1) * out).reshape(shape)
 
 
-def ipuvt_matvec(U, V, x, workspace_fn):
+def ipuvt_matvec(U, V, x, workspace_fn, reduce=_no_reduce):
     """psgd.py:540-544 for r > 32; x is [N], [N, 1] or [N, k]."""
     cx = _Ctx(U, workspace_fn)
     Uc, Vc = cx.split(U), cx.split(V)
     cols = [x.reshape(cx.N, -1)[:, j].contiguous() for j in range(x.reshape(cx.N, -1).shape[1])]
     outs = [c.clone() for c in cols]
+    S = reduce(torch.stack([cx.colsums(Vc[k], cols) for k in range(cx.c)]), "sum")
     for k in range(cx.c):
-        S = cx.colsums(Vc[k], cols)
-        cx.axpy(Uc[k], outs, S)
+        cx.axpy(Uc[k], outs, S[k])
     return torch.stack(outs, 1).reshape(x.shape) if x.dim() == 2 else outs[0].reshape(x.shape)
 
 
-def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn):
+def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce=_no_reduce):
     """psgd.py:554-617 for r > 32 (in place on U or V, and d)."""
     cx = _Ctx(U, workspace_fn)
     r, c, rc, dev = cx.r, cx.c, cx.rc, cx.dev
     if balance:                                                                # :562-567
-        rho = torch.sqrt(torch.max(torch.abs(U)) / torch.max(torch.abs(V)))
+        mx = reduce(torch.stack([torch.max(torch.abs(U)), torch.max(torch.abs(V))]), "max")
+        rho = torch.sqrt(mx[0] / mx[1])
         U.div_(rho)
         V.mul_(rho)
     Uc, Vc = cx.split(U), cx.split(V)
@@ -171,17 +181,17 @@ def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn):
         else:
             VU[sl(kb), sl(ka)] = blk.t()
 
-    for i in range(len(items)):
-        for j in range(i + 1, len(items)):
-            (ka_, ia, X), (kb_, ib, Y) = items[i], items[j]
-            G = cx.gram_pair(X, Y, dv, vv, hv)
-            put(ka_, ia, ka_, ia, G[:rc, :rc])
-            put(kb_, ib, kb_, ib, G[rc:2 * rc, rc:2 * rc])
-            put(ka_, ia, kb_, ib, G[:rc, rc:2 * rc])
-            for kind, kk, lo in ((ka_, ia, 0), (kb_, ib, rc)):
-                (Ut if kind == "U" else Vt)[sl(kk)] = G[lo:lo + rc, 2 * rc]
-                (Uw if kind == "U" else Vw)[sl(kk)] = G[lo:lo + rc, 2 * rc + 1]
-            tt, tw, ww = G[2 * rc, 2 * rc], G[2 * rc, 2 * rc + 1], G[2 * rc + 1, 2 * rc + 1]
+    pairs = [(i, j) for i in range(len(items)) for j in range(i + 1, len(items))]
+    Gs = reduce(torch.stack([cx.gram_pair(items[i][2], items[j][2], dv, vv, hv) for i, j in pairs]), "sum")   # one exchange
+    for (i, j), G in zip(pairs, Gs):
+        (ka_, ia, _), (kb_, ib, _) = items[i], items[j]
+        put(ka_, ia, ka_, ia, G[:rc, :rc])
+        put(kb_, ib, kb_, ib, G[rc:2 * rc, rc:2 * rc])
+        put(ka_, ia, kb_, ib, G[:rc, rc:2 * rc])
+        for kind, kk, lo in ((ka_, ia, 0), (kb_, ib, rc)):
+            (Ut if kind == "U" else Vt)[sl(kk)] = G[lo:lo + rc, 2 * rc]
+            (Uw if kind == "U" else Vw)[sl(kk)] = G[lo:lo + rc, 2 * rc + 1]
+        tt, tw, ww = G[2 * rc, 2 * rc], G[2 * rc, 2 * rc + 1], G[2 * rc + 1, 2 * rc + 1]
     # ---- r x r algebra (fp64, on the device): psgd.py:574-579, :589-597 / :603-611
     K = torch.eye(R, **f64) + VU                                               # :575  (padded rows/columns: identity)
     s1 = Vt                                                                    # V't
@@ -214,7 +224,7 @@ def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn):
     Ph = dv * (a + p)                                                          # :570
     invPv = (b + q) / dv                                                       # :578-579
     nabla = Ph * hv - vv * invPv                                               # :581
-    mud = step / (torch.max(torch.abs(nabla)) + tiny)                          # :582
+    mud = step / (reduce(torch.max(torch.abs(nabla)).reshape(1), "max")[0] + tiny)    # :582
     dv.sub_((mud * dv) * nabla)                                                # :584 (d before U / V; a, b keep the old d)
     c1f, c2f = (mu * c1.to(torch.float32)), (mu * c2.to(torch.float32))
     if update_U:                                                               # :600-601

@@ -883,7 +883,7 @@ def test_update_over_condition_numbers(psgd, cond_q):
     The oracle runs on the fp32-rounded factors, so what is measured is the error of the solves and products.  States at 1e-5
     throughout.  The increments lose accuracy with the conditioning in ANY fp32 arithmetic (eps x cond through the solves of
     psgd.py:174, amplified by the cancellation in A A' - Bt Bt'): the 2e-3 bar holds up to cond 1e3, and the bar beyond is
-    eps x cond x 100 (measured on the device: 4.0e-3 at 1e4; the fp32 run of the oracle itself has the same error)."""
+    10 x eps x cond = 6e-3 at 1e4 (measured on the device: 4.0e-3)."""
     rng = np.random.default_rng(int(np.log10(cond_q)) + 50)
     M, N = 1024, 1152
     Ql = _spd_cholesky_factor(rng, M, cond_q ** 2).astype(np.float32) if cond_q > 1 else np.eye(M, dtype=np.float32)
@@ -895,7 +895,7 @@ def test_update_over_condition_numbers(psgd, cond_q):
     out = [t.cpu().numpy().astype(np.float64) for t in psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)]
     ref = orc.update_precond_kron(Ql64, Qr64, dX.astype(np.float64), dG.astype(np.float64), 0.01)
     rho = np.sqrt(np.max(np.abs(Ql64)) / np.max(np.abs(Qr64)))
-    bar = max(INCR_TOL, 100 * 6e-8 * cond_q)
+    bar = max(INCR_TOL, 10 * 6e-8 * cond_q)
     for i, q0 in enumerate((Ql64 / rho, Qr64 * rho)):
         assert np.isfinite(out[i]).all()
         assert rel_err(out[i], ref[i]) < TOL, (i, cond_q)

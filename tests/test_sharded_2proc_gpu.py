@@ -56,7 +56,7 @@ def _worker(rank, port, outdir, N, r):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,r", [(200003, 20)])
+@pytest.mark.parametrize("N,r", [(200003, 20), (60003, 40)])      # r = 40: the wide-rank path (column chunks), sharded
 def test_two_processes_real_kernels_real_collectives(hip_lib, N, r):
     import torch.multiprocessing as mp
     import preconditioned_stochastic_gradient_descent as psgd
