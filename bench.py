@@ -488,18 +488,21 @@ def exchange_overhead(args, psgd, sharded, lib, dev, rows, steps):
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
     try:
-        res = {}
-        for name, use_dist in (("unsharded", False), ("sharded_1rank", True), ("unsharded_again", False)):
-            rec = run_uvd(args, psgd, sharded, lib, dev, 0, 1, use_dist, rows, rows, steps, 10)
-            res[name] = rec["ms_per_step"]
-            torch.cuda.empty_cache()
-        base = min(res["unsharded"], res["unsharded_again"])
-        return {"rows": rows, "r": args.rank_r, "steps": steps, "unsharded_ms": base,
-                "sharded_1rank_rccl_ms": res["sharded_1rank"], "added_us_per_step": (res["sharded_1rank"] - base) * 1e3,
-                "added_frac_of_step": (res["sharded_1rank"] - base) / base,
-                "backend": dist.get_backend(), "runs_ms": res,
+        import statistics
+        runs = {"unsharded": [], "sharded_1rank": []}
+        for rnd in range(3):                                 # interleaved rounds: the two paths see the same clocks and placement
+            for name, use_dist in (("unsharded", False), ("sharded_1rank", True)):
+                rec = run_uvd(args, psgd, sharded, lib, dev, 0, 1, use_dist, rows, rows, steps, 10)
+                runs[name].append(rec["ms_per_step"])
+                torch.cuda.empty_cache()
+        base, shd = statistics.median(runs["unsharded"]), statistics.median(runs["sharded_1rank"])
+        return {"rows": rows, "r": args.rank_r, "steps": steps, "rounds": 3, "unsharded_ms": base,
+                "sharded_1rank_rccl_ms": shd, "added_us_per_step": (shd - base) * 1e3,
+                "added_frac_of_step": (shd - base) / base,
+                "backend": dist.get_backend(), "runs_ms": runs,
                 "note": "one rank's share of BASELINE configs[3] (100M rows / 8); 1-rank RCCL group on this GPU: host "
-                        "issue + 2 all-gather launches + 2 fold kernels per step, no xGMI hop"}
+                        "issue + 2 all-gather launches (each a hop to the communicator's stream and back) + 2 fold kernels "
+                        "per step, no xGMI hop; medians of 3 interleaved rounds"}
     finally:
         if own_group:
             dist.destroy_process_group()
@@ -680,7 +683,7 @@ def main():
             if not args.no_exchange_leg and not single_dev and not args.force_sharded:
                 try:
                     res["exchange_overhead"] = exchange_overhead(args, psgd, sharded, lib, dev,
-                                                                 sharded.shard_rows(100_000_000, 0, 8)[1], 200)
+                                                                 sharded.shard_rows(100_000_000, 0, 8)[1], 100)
                 except Exception as e:                      # a leg, never the headline: report, do not fail the line
                     res["exchange_overhead"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()

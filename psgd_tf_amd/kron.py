@@ -465,9 +465,21 @@ def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
     Qls, Qrs, dXs, dGs = list(Qls), list(Qrs), list(dXs), list(dGs)
     if not (len(Qls) == len(Qrs) == len(dXs) == len(dGs)):
         raise ValueError("update_precond_kron_batched: the four lists must have one length")
-    small = all(max(x.shape) <= 512 for x in dXs)
-    if not (small and _batched_ok(Qls, Qrs, dXs) and _batched_ok(Qls, Qrs, dGs)):
+    if not (_batched_ok(Qls, Qrs, dXs) and _batched_ok(Qls, Qrs, dGs)):
         return [update_precond_kron(a, b, x, g, step) for a, b, x, g in zip(Qls, Qrs, dXs, dGs)]
+    small = [i for i, x in enumerate(dXs) if max(x.shape) <= 512]
+    if len(small) < len(dXs):
+        # a mixed list (the LSTM / NMT drivers mix sizes across 512): the small layers -- launch-bound -- still share their
+        # launches, the large ones -- each fills the chip -- go one by one
+        out = [None] * len(dXs)
+        if len(small) > 1:
+            for i, res in zip(small, update_precond_kron_batched([Qls[i] for i in small], [Qrs[i] for i in small],
+                                                                  [dXs[i] for i in small], [dGs[i] for i in small], step)):
+                out[i] = res
+        for i in range(len(dXs)):
+            if out[i] is None:
+                out[i] = update_precond_kron(Qls[i], Qrs[i], dXs[i], dGs[i], step)
+        return out
     for a, b, x, g in zip(Qls, Qrs, dXs, dGs):
         _check_rank2_f32("update_precond_kron_batched", a, b, x, g)
         _check_kron_shapes("update_precond_kron_batched", a, b, x, g)

@@ -17,9 +17,10 @@ hello_psgd.py:5) carry over with torch tensors in place of tf tensors:
     class UVd(...).step(closure)                                       psgd.py:630
 
 The UVd, sparse-LU and Kron arithmetic runs in hand-written HIP kernels behind the
-C ABI of include/psgd_hip.h (bound in _lib.py).  Tensors must be fp32, contiguous and
-resident on a ROCm device; anything else raises -- there is no CPU fallback for the
-hot path.  The dense preconditioner (psgd.py:26-63) is host-side plumbing on torch ops
+C ABI of include/psgd_hip.h (bound in _lib.py).  Tensors must be fp32 and resident on a ROCm
+device; anything else raises -- there is no CPU fallback for the hot path.  Strided views are
+accepted (copied on the way in, in-place state written back on the way out); the kernels work on
+contiguous memory.  The dense preconditioner (psgd.py:26-63) is host-side plumbing on torch ops
 (2x2 matrices, never a kernel target).
 
 The reference draws its two branch decisions (psgd.py:562, :588) from TensorFlow's
@@ -70,6 +71,26 @@ def _require_hip(name, *tensors):
         if t.device != dev:
             raise ValueError("%s: all tensors must be on one device" % name)
     return dev
+
+
+def _c(t):
+    """Read-only operand as the kernels need it (contiguous): a strided view is copied, as TensorFlow's ops would
+    materialise it -- the reference has no notion of a non-contiguous tensor (SURVEY 8b's `ldU, ldV` are not in the ABI)."""
+    return t if (not isinstance(t, torch.Tensor)) or t.is_contiguous() else t.contiguous()
+
+
+class _InPlace:
+    """State tensors a call updates in place (U, V, d): contiguous ones are used as they are, strided views are worked on
+    as contiguous copies and written back when the call returns."""
+
+    def __init__(self, *tensors):
+        self.orig = tensors
+        self.work = tuple(_c(t) for t in tensors)
+
+    def writeback(self):
+        for o, w in zip(self.orig, self.work):
+            if w is not o:
+                o.copy_(w)
 
 
 def uvd_workspace(device, N, r):
@@ -176,6 +197,7 @@ def _tall(name, xs, N):
 
 def update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01):
     """psgd.py:396-480: returns (L12_new, l3_new, U12_new, u3_new); inputs are not modified."""
+    L12, l3, U12, u3 = _c(L12), _c(l3), _c(U12), _c(u3)
     dev = _require_hip("update_precond_splu", L12, l3, U12, u3)
     N, r = _splu_shapes("update_precond_splu", L12, l3, U12, u3)
     dx, dg = _tall("update_precond_splu", dxs, N), _tall("update_precond_splu", dgs, N)
@@ -192,6 +214,7 @@ def update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01):
 
 def precond_grad_splu(L12, l3, U12, u3, grads):
     """psgd.py:483-524: list of gradients in, list of preconditioned gradients (same shapes) out."""
+    L12, l3, U12, u3 = _c(L12), _c(l3), _c(U12), _c(u3)
     dev = _require_hip("precond_grad_splu", L12, l3, U12, u3)
     N, r = _splu_shapes("precond_grad_splu", L12, l3, U12, u3)
     g = _tall("precond_grad_splu", grads, N)
@@ -212,6 +235,9 @@ def precond_grad_splu(L12, l3, U12, u3, grads):
 # --------------------------------------------------------------------------- UVd math
 def IpUVtmatvec(U, V, x):
     """psgd.py:540-544: (I + U V') x for a column vector x ([N] or [N,1]) or [N,k] matrix."""
+    U, V = _c(U), _c(V)
+    if not (isinstance(x, torch.Tensor) and x.dim() == 2 and x.shape[1] > 1):
+        x = _c(x)
     if U.dim() == 2 and U.shape[1] > _lib.UVD_MAX_RANK:
         _require_hip("IpUVtmatvec", U, V, x)
         return _wide.ipuvt_matvec(U, V, x, uvd_workspace)
@@ -246,6 +272,7 @@ def IpUVtmatvec(U, V, x):
 
 def precond_grad_UVd_math(U, V, d, g):
     """psgd.py:619-627: d .* (I + V U')(I + U V')(d .* g); returns a new tensor shaped like g."""
+    U, V, d, g = _c(U), _c(V), _c(d), _c(g)
     dev = _require_hip("precond_grad_UVd_math", U, V, d, g)
     N, r = _uvd_shapes("precond_grad_UVd_math", U, V, d, g)
     if r > _lib.UVD_MAX_RANK:                      # wide rank: column chunks through the same kernels (uvd_wide.py)
@@ -269,6 +296,8 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
     balance / update_U fix the two random branches of the reference (:562 p=0.01, :588 p=0.5);
     left at None they are drawn from `generator` (a CPU torch.Generator; module default otherwise),
     in the reference's order."""
+    state = _InPlace(U, V, d)
+    (U, V, d), v, h = state.work, _c(v), _c(h)
     dev = _require_hip("update_precond_UVd_math_", U, V, d, v, h)
     N, r = _uvd_shapes("update_precond_UVd_math_", U, V, d, v, h)
     if balance is None:
@@ -276,12 +305,15 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
     if update_U is None:
         update_U = _draw_branch(0.5, generator)
     if r > _lib.UVD_MAX_RANK:
-        return _wide.update(U, V, d, v, h, float(step), float(tiny), bool(balance), bool(update_U), uvd_workspace)
+        _wide.update(U, V, d, v, h, float(step), float(tiny), bool(balance), bool(update_U), uvd_workspace)
+        state.writeback()
+        return None
     ws = uvd_workspace(dev, N, r)
     rc = _lib.load().psgd_uvd_update_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), N, r,
                                           float(step), float(tiny), int(bool(balance)), int(bool(update_U)),
                                           ws.data_ptr(), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "psgd_uvd_update_f32")
+    state.writeback()
     return None
 
 
@@ -291,6 +323,8 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
     precond_grad_UVd_math(U, V, d, g) on the updated state -- the UVd.step pattern (psgd.py:732 -> :748) --
     as one fused call that saves a pass over V.  U or V, and d, are updated in place; returns the
     preconditioned gradient."""
+    state = _InPlace(U, V, d)
+    (U, V, d), v, h, g = state.work, _c(v), _c(h), _c(g)
     dev = _require_hip("update_precond_UVd_math_and_precond_grad", U, V, d, v, h, g)
     N, r = _uvd_shapes("update_precond_UVd_math_and_precond_grad", U, V, d, v, h, g)
     if balance is None:
@@ -299,7 +333,9 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
         update_U = _draw_branch(0.5, generator)
     if r > _lib.UVD_MAX_RANK:                      # no fusion on the wide-rank path: update, then apply
         _wide.update(U, V, d, v, h, float(step), float(tiny), bool(balance), bool(update_U), uvd_workspace)
-        return _wide.precond_grad(U, V, d, g, uvd_workspace)
+        out = _wide.precond_grad(U, V, d, g, uvd_workspace)
+        state.writeback()
+        return out
     out = torch.empty_like(g)
     ws = uvd_workspace(dev, N, r)
     rc = _lib.load().psgd_uvd_update_apply_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(),
@@ -307,6 +343,7 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
                                                 int(bool(balance)), int(bool(update_U)), ws.data_ptr(), ws.numel(),
                                                 _stream_ptr(dev))
     _lib.check(rc, "psgd_uvd_update_apply_f32")
+    state.writeback()
     return out
 
 

@@ -867,6 +867,24 @@ def test_sparse_formats_large(psgd, fmt, sl, sr):
     assert np.array_equal(_dev(a32[0]).cpu().numpy(), a32[0])
 
 
+def test_batched_update_with_mixed_sizes(psgd):
+    """update_precond_kron_batched on a list that mixes small layers with layers above 512 (the LSTM / NMT drivers do): the
+    small ones still share their launches, the large ones go one by one; results as the per-layer calls, bit for bit."""
+    rng = np.random.default_rng(77)
+    shapes = [(26, 6), (700, 530), (151, 16), (85, 10), (1024, 300)]
+    Qls = [_dev(_tri_factor(rng, m) * 2.0) for m, n in shapes]
+    Qrs = [_dev(_tri_factor(rng, n)) for m, n in shapes]
+    dXs = [_dev(rng.standard_normal((m, n))) for m, n in shapes]
+    dGs = [_dev(rng.standard_normal((m, n))) for m, n in shapes]
+    got = psgd.update_precond_kron_batched(Qls, Qrs, dXs, dGs, 0.01)
+    assert len(got) == len(shapes)
+    for (a, b), Ql, Qr, x, g in zip(got, Qls, Qrs, dXs, dGs):
+        wa, wb = psgd.update_precond_kron(Ql, Qr, x, g, 0.01)
+        assert torch.equal(a, wa) and torch.equal(b, wb)
+        ra, rb = orc.update_precond_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, x, g)), 0.01)
+        assert rel_err(a.cpu().numpy(), ra) < TOL and rel_err(b.cpu().numpy(), rb) < TOL
+
+
 def _spd_cholesky_factor(rng, n, cond_h):
     """Upper-triangular Q with Q'Q = H^-1 for an SPD H with random eigenvectors and cond(H) = cond_h: what a converged
     PSGD factor looks like (psgd.py:175-179 drives Q'Q towards H^-1); cond(Q) = sqrt(cond_h), genuinely ill-conditioned

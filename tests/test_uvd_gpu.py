@@ -170,14 +170,47 @@ def test_rejects_bad_arguments(psgd):
         psgd.precond_grad_UVd_math(t["U"].cpu(), t["V"].cpu(), t["d"].cpu(), t["g"].cpu())
     with pytest.raises(TypeError):
         psgd.precond_grad_UVd_math(t["U"].double(), t["V"].double(), t["d"].double(), t["g"].double())
-    with pytest.raises(ValueError):
-        psgd.precond_grad_UVd_math(t["U"].t().contiguous().t(), t["V"], t["d"], t["g"])   # non-contiguous
     # a row-slice that starts at an odd row of an r = 3 matrix is not 16-byte aligned: refused, not mis-read
     p3 = _to_dev(make_uvd_problem(101, 3))
     with pytest.raises(PsgdHipError, match="16-byte"):
         psgd.precond_grad_UVd_math(p3["U"][1:], p3["V"][1:], p3["d"][1:], p3["g"][1:])
     with pytest.raises(ValueError):
         psgd.precond_grad_UVd_math(t["U"], t["V"][:50], t["d"], t["g"])               # shape mismatch
+
+
+@pytest.mark.parametrize("N,r", [(3001, 10), (2048, 40)])
+def test_strided_views_are_accepted(psgd, N, r):
+    """The reference's ops take whatever tensor they are given; here strided views (every second column of a wider buffer,
+    a column of a matrix) are copied on the way in and the in-place state is written back on the way out: same results as on
+    contiguous tensors, and the memory between the view's elements is untouched."""
+    p = make_uvd_problem(N, r, seed=9, uv_gain=2.0, d_spread=0.3)
+    t = _to_dev(p)
+    wide = {k: torch.full((N, 2 * r), 7.0, device="cuda") for k in ("U", "V")}
+    for k in ("U", "V"):
+        wide[k][:, ::2] = t[k]
+    cols = torch.full((N, 4), 7.0, device="cuda")
+    for j, k in enumerate(("d", "g", "v", "h")):
+        cols[:, j] = t[k][:, 0]
+    Uv, Vv = wide["U"][:, ::2], wide["V"][:, ::2]
+    dv, gv, vv, hv = (cols[:, j:j + 1] for j in range(4))
+    assert not Uv.is_contiguous() and not dv.is_contiguous()
+    out_v = psgd.precond_grad_UVd_math(Uv, Vv, dv, gv)
+    assert torch.equal(out_v, psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"]))
+    assert torch.equal(psgd.IpUVtmatvec(Uv, Vv, gv), psgd.IpUVtmatvec(t["U"], t["V"], t["g"]))
+    for upd in (True, False):
+        psgd.update_precond_UVd_math_(Uv, Vv, dv, vv, hv, 0.01, TINY32, balance=False, update_U=upd)
+        psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32, balance=False, update_U=upd)
+    o1 = psgd.update_precond_UVd_math_and_precond_grad(Uv, Vv, dv, vv, hv, gv, 0.01, TINY32, balance=False, update_U=True)
+    o2 = psgd.update_precond_UVd_math_and_precond_grad(t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY32,
+                                                       balance=False, update_U=True)
+    assert torch.equal(o1, o2)
+    assert torch.equal(wide["U"][:, ::2], t["U"]) and torch.equal(wide["V"][:, ::2], t["V"]) and torch.equal(cols[:, 0:1], t["d"])
+    assert bool((wide["U"][:, 1::2] == 7.0).all()) and bool((wide["V"][:, 1::2] == 7.0).all())
+    assert torch.equal(cols[:, 1:2], t["g"])                       # read-only operands untouched
+    q = {k: v.astype(np.float64) for k, v in p.items()}
+    for upd in (True, False, True):
+        orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=upd)
+    assert rel_err(t["U"].cpu().numpy(), q["U"]) < 1e-5 and rel_err(t["d"].cpu().numpy(), q["d"]) < 1e-5
 
 
 @pytest.mark.parametrize("N,r", [(1021, 10), (5000, 20), (4099, 7), (100003, 20), (2049, 32), (777, 3)])
