@@ -756,8 +756,12 @@ struct HPairArgs {
 
 template <int DMAPOS>
 __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
-  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];
-  __shared__ int missing;                                  // tile row whose T3 tile a poll gave up on (-1: none)
+  // ONE __shared__ object: a second one beside the LDS-DMA staging array makes hipcc drain every outstanding DMA
+  // (s_waitcnt vmcnt(0)) in front of the first fragment read of EVERY K tile (cdna_hip_programming.md section 5, "Projection
+  // GEMM" item 4a; found in this kernel's ISA in round 3: the flag word of the hand-off had been such an object since
+  // round 2).  The flag lives in a 9th-slot word of the same array.
+  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024 + 1];
+  int& missing = *reinterpret_cast<int*>(&lds[8 * 1024]);   // tile row whose T3 tile a poll gave up on (-1: none)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) missing = -1;                              // ordered before its first reader by the barriers of phase A
   const int tiles_m = p.M / T2, tiles_n = p.N / T2;
@@ -785,6 +789,7 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
   // One pass = produce the T3 tile of row `prod` (this block's own row first), then consume.  A pass whose consumer
   // gave up on a tile comes round again with prod = that tile's row; an undisturbed run is exactly one pass.
   int prod = r;
+  int gave = -1;                                           // wave 0, lane 0: its own copy of `missing` (no LDS read in the K loop)
   for (;;) {
     const int pm0 = prod * T2;
     // ---- phase A: T3 tile (prod, c) = sum over k >= pm0 of Ql[m][k] T2'[n][k]
@@ -831,14 +836,14 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
         if ((n & 15) != 0) return;                           // first half-tile of a new chunk (n > 0 here)
         const int jchunk = r - (n >> 4);
         if (w == 0) {
-          if (lane == 0 && missing < 0) {                    // (after a give-up the rest of this pass is discarded: no more polls)
+          if (lane == 0 && gave < 0) {                       // (after a give-up the rest of this pass is discarded: no more polls)
             const unsigned* f = p.flags + jchunk * tiles_n + c;
             unsigned spins = 0;
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
               __builtin_amdgcn_s_sleep(4);
               if (++spins > p.spin_limit) {
                 __hip_atomic_fetch_add(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                missing = jchunk;                            // read by every wave after the pass (barriers in between)
+                missing = gave = jchunk;                     // `missing`: read by every wave after the pass (barriers in between)
                 break;
               }
             }
@@ -858,6 +863,7 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
     if (ms < 0) break;                                       // the undisturbed case: one pass
     __syncthreads();                                         // every wave has read `missing` before it is reset
     if (tid == 0) missing = -1;
+    gave = -1;
     prod = ms;                                               // produce the tile nobody published in time, then consume again
   }
   hg256_store<false>(acc, p.out, p.ldo, p.out_bf16, p.out_trans, m0, n0, w, lane);
