@@ -35,6 +35,7 @@ import torch
 from . import _lib
 from . import kron as _kron
 from . import uvd_wide as _wide
+from . import splu_wide as _splu_wide
 
 dtype = torch.float32                                  # psgd.py:20
 _tiny = torch.finfo(torch.float32).tiny                # psgd.py:22 (smallest normal fp32)
@@ -202,6 +203,8 @@ def update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01):
     N, r = _splu_shapes("update_precond_splu", L12, l3, U12, u3)
     dx, dg = _tall("update_precond_splu", dxs, N), _tall("update_precond_splu", dgs, N)
     _require_hip("update_precond_splu", dx, dg, L12)
+    if r > _lib.UVD_MAX_RANK:                      # wide rank: column chunks of L2 and U2' (splu_wide.py)
+        return _splu_wide.update(L12, l3, U12, u3, dx, dg, float(step), float(_tiny), uvd_workspace)
     out = [torch.empty_like(t) for t in (L12, l3, U12, u3)]
     ws = _splu_workspace(dev, N, r)
     rc = _lib.load().psgd_splu_update_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(), dx.data_ptr(),
@@ -219,6 +222,14 @@ def precond_grad_splu(L12, l3, U12, u3, grads):
     N, r = _splu_shapes("precond_grad_splu", L12, l3, U12, u3)
     g = _tall("precond_grad_splu", grads, N)
     _require_hip("precond_grad_splu", g, L12)
+    if r > _lib.UVD_MAX_RANK:
+        out = _splu_wide.precond_grad(L12, l3, U12, u3, g, uvd_workspace)
+        pre_grads, idx = [], 0
+        for x in grads:
+            n = x.numel()
+            pre_grads.append(torch.reshape(out[idx:idx + n], x.shape))
+            idx += n
+        return pre_grads
     out = torch.empty_like(g)
     ws = _splu_workspace(dev, N, r)
     rc = _lib.load().psgd_splu_apply_f32(L12.data_ptr(), l3.data_ptr(), U12.data_ptr(), u3.data_ptr(), g.data_ptr(),

@@ -22,7 +22,10 @@ INCR_TOL = 2e-3
 # (N, r): no tail (N = r), tails shorter than the alignment head, odd ranks (scalar head path), tile
 # edges, every load-width class, r = 1 and r = 32
 SHAPES = [(12, 12), (13, 12), (14, 11), (23, 1), (40, 5), (64, 10), (1000, 3), (5000, 7), (4099, 9), (10007, 10),
-          (20000, 17), (3000, 32), (50000, 31), (100003, 20), (300001, 10)]
+          (20000, 17), (3000, 32), (50000, 31), (100003, 20), (300001, 10),
+          # ranks above 32 (the reference has no limit, psgd.py:420): column chunks of L2 and U2' (splu_wide.py); no tail, one
+          # chunk padded, three chunks
+          (40, 40), (5000, 33), (20011, 48), (3001, 70)]
 KEYS = ("L12", "l3", "U12", "u3")
 
 
