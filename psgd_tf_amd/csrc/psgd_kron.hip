@@ -634,10 +634,44 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_x3_pair(GemmPair p) {
 // ts = 32 * (padded x extent): the 128 rows x 32 k a block fetches per K tile and plane are ONE contiguous 8 KiB run, so
 // every DMA instruction moves whole 128-byte lines (with row-major planes a K tile touched half of each line and every
 // line was fetched twice through the 64 B/clk L1 -- the whole K loop was bound by it).  x padded to 128, k to 32, zeros.
+struct PlaneMeta { float scale, inv, amax, bound; };      // f16 x 2 format (below): 2^e, 2^-e, max|X|, the bound e was chosen from
 struct P3 {
   const __bf16* p;
   long ts, ps;
+  const PlaneMeta* meta;   // f16 x 2 format only: of the matrix these planes hold (device memory)
 };
+
+// ---- the second plane format (round 3): x 2^e = h + 2^-11 M with h, M in fp16 ("f16 x 2") -----------------------------
+// Two planes and THREE matrix-core products per term instead of three planes and six: h h' into the accumulators, M h' and
+// h M' into a second set that is folded in with 2^-11 after the K loop (206 registers, still two blocks per CU).  h =
+// fp16(x s) keeps 11 bits, the residual another 11 (x s = h + m to 2^-23; the dropped m m' is 2^-24), so a product is at
+// least as accurate as with the bf16 x 3 split, which drops three cross terms of 2^-24 (CPU emulation before it was
+// built: profiles/r03_f16x2_planes_study.txt; on the device, whole apply against fp64: 5.7e-7 against 2.6e-6 at 4096^2,
+// profiles/r03_f16x2_planes_ab.txt) at half the matrix-core work and two thirds of the LDS and DMA traffic (4096^2 apply
+// 1.22 -> 0.81 ms).  What fp16 lacks is range, so every matrix carries ONE power-of-two scale s = 2^e that puts a bound of
+// its max|x| at 2^14 (h never overflows), and the residual plane is stored pre-scaled (M = 2^11 m) so that it stays a
+// normal number wherever h is one -- without that, elements more than ~2^11 below the bound lose residual bits to fp16's
+// subnormal range and the loose a-priori bounds of chained products cost accuracy.  Scales: a matrix split from fp32 data
+// uses its actual max|x| (k_absmax ahead of the split); a matrix produced by a GEMM epilogue uses the bound
+// K max|A| max|B| computed from the ACTUAL maxima of its two operands (device scalars), and records its own actual maximum
+// for its consumers -- bounds never compound (compounded over the three products of an apply they cost 1e-4..5e-4).  The
+// accumulators are brought back to real values (x 2^-(eA + eB), exact) before any epilogue logic.  NaN / Inf: a maximum that
+// is not finite gives s = 1 and the values themselves carry the NaN / Inf through the products.
+typedef _Float16 f16x8_k __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float plane_scale_of_bound(float b) {      // 2^e with b 2^e in [2^13, 2^14)
+  if (!(b > 0.0f) || !(b < 3.0e38f)) return 1.0f;                     // zero matrix, Inf, NaN: any scale (the values decide)
+  int k;
+  (void)frexpf(b, &k);                                                // b = f 2^k, f in [0.5, 1)
+  return ldexpf(1.0f, min(14 - k, 126));                              // (subnormal-sized data: 2^e and 2^-e stay normal)
+}
+// two fp32 values (already scaled) -> packed fp16 pairs of the planes h and M = 2^11 (x - h)
+__device__ __forceinline__ void split2h_pair(float x0, float x1, unsigned (&q)[2]) {
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const _Float16 m0 = (_Float16)((x0 - (float)h0) * 2048.0f), m1 = (_Float16)((x1 - (float)h1) * 2048.0f);
+  q[0] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+  q[1] = (unsigned)__builtin_bit_cast(unsigned short, m0) | ((unsigned)__builtin_bit_cast(unsigned short, m1) << 16);
+}
 __host__ __device__ __forceinline__ long p3_index(long ts, long x, long k) { return (k >> 5) * ts + x * 32 + (k & 31); }
 
 struct P3Args {
@@ -647,6 +681,12 @@ struct P3Args {
                        // except e.A2 != nullptr <=> the second pair is present)
   __bf16* Crow; long crow_ts, crow_ps;   // planes of C  (x = row, k = column)  (optional)
   __bf16* Ccol; long ccol_ts, ccol_ps;   // planes of C' (x = column, k = row)  (optional)
+  int fmt;                               // 0: bf16 x 3 planes, 1: f16 x 2 planes (operands and plane outputs alike)
+  // f16 x 2 plane outputs: their scale comes from bound = okmul * oa->amax * ob->amax (+ okmul2 * oa2->amax * ob2->amax);
+  // ometa receives {scale, 1 / scale, max|C| (atomic; zeroed by the host beforehand), bound}
+  PlaneMeta* ometa;
+  const PlaneMeta *oa, *ob, *oa2, *ob2;
+  float okmul, okmul2;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr3_t;
@@ -659,9 +699,10 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr3_t;
 // K tiles [lo, hi) of one operand pair.  LDS image as in k_gemm_x3: [A|B][plane][row * 4 + (chunk ^ swz(row))].  The DMA
 // writes linearly (wave base + 16 B * lane), so the swizzle is applied to the per-lane SOURCE address: the lane that
 // fills slot s = row * 4 + cpos fetches chunk cpos ^ swz(row) of that row.
+template <int FMT>
 __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0, int lo, int hi, GemmLdsX3& L,
                                         f32x4 (&acc)[4][4]) {
-  constexpr int NP = 3;
+  constexpr int NP = FMT ? 2 : 3;
   constexpr int W = 64, NT = 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, c = lane >> 4;
@@ -684,6 +725,13 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
       }
   };
   if (hi <= lo) return;
+  f32x4 cross[FMT == 1 ? NT : 1][FMT == 1 ? NT : 1];
+  if constexpr (FMT == 1) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) cross[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
   issue(lo);
   for (int k0 = lo; k0 < hi; k0 += kX3K) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -699,6 +747,17 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     };
     auto mfma6 = [&](int i, int j) {
       f32x4 v = acc[i][j];
+      if constexpr (FMT == 1) {               // f16 x 2: h h' into acc, M h' + h M' into cross (folded in with 2^-11 at the end)
+        const f16x8_k ah = __builtin_bit_cast(f16x8_k, a[i][0]), aM = __builtin_bit_cast(f16x8_k, a[i][1]);
+        const f16x8_k bh = __builtin_bit_cast(f16x8_k, b[j][0]), bM = __builtin_bit_cast(f16x8_k, b[j][1]);
+        f32x4 x = cross[i][j];
+        x = __builtin_amdgcn_mfma_f32_16x16x32_f16(aM, bh, x, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, v, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bM, x, 0, 0, 0);
+        cross[i][j] = x;
+        acc[i][j] = v;
+        return;
+      }
       v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
       v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], v, 0, 0, 0);   // h l'
       v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], v, 0, 0, 0);   // l h'
@@ -736,13 +795,71 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
 #pragma unroll
       for (int i = 0; i < NT; ++i) mfma6(i, j);
   }
+  if constexpr (FMT == 1) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] += cross[i][j] * 0.00048828125f;
+  }
 }
 // plane outputs of a C tile (pads inside the padded extents are written as zeros)
+template <int FMT>
 __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&acc)[4][4], int m0, int n0, bool do_row,
                                                 bool do_col) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1;
   const bool odd = lane & 1;
+  if constexpr (FMT == 1) {
+    // the output's scale from the bound its host described (the same in every block), its actual maximum for its consumers
+    float bound = g.okmul * g.oa->amax * g.ob->amax;
+    if (g.oa2) bound += g.okmul2 * g.oa2->amax * g.ob2->amax;
+    const float sc = plane_scale_of_bound(bound);
+    if (threadIdx.x == 0) {            // (every block that gets here: under a K split any block may be a tile's last one)
+      g.ometa->scale = sc; g.ometa->inv = 1.0f / sc; g.ometa->bound = bound;
+    }
+    float vmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row0 = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+        const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (row0 + e < g.e.M && col < g.e.N) ? acc[i][j][e] : 0.0f;
+          vmax = amaxf(vmax, fabsf(v[e]));
+          v[e] *= sc;
+        }
+        if (do_col) {
+          unsigned q0[2], q1[2];
+          split2h_pair(v[0], v[1], q0);
+          split2h_pair(v[2], v[3], q1);
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            *reinterpret_cast<uint2*>(g.Ccol + pl * g.ccol_ps + p3_index(g.ccol_ts, col, row0)) = make_uint2(q0[pl], q1[pl]);
+        }
+        if (do_row) {
+          const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
+          const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+          const float x00 = odd ? r0 : v[0], x01 = odd ? v[2] : r0;
+          const float x10 = odd ? r1 : v[1], x11 = odd ? v[3] : r1;
+          unsigned q0[2], q1[2];
+          split2h_pair(x00, x01, q0);
+          split2h_pair(x10, x11, q1);
+          const int rr = row0 + (odd ? 2 : 0), cc = col - (odd ? 1 : 0);
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            *reinterpret_cast<unsigned*>(g.Crow + pl * g.crow_ps + p3_index(g.crow_ts, rr, cc)) = q0[pl];
+            *reinterpret_cast<unsigned*>(g.Crow + pl * g.crow_ps + p3_index(g.crow_ts, rr + 1, cc)) = q1[pl];
+          }
+        }
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(&g.ometa->amax), __float_as_int(vmax));
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -790,8 +907,15 @@ __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&a
 // in chunk order -- a fixed order, whoever arrives last -- and runs the epilogue.  The counter is left at zero again.
 struct P3Split { int chunk, nchunk; float* scratch; unsigned* cnt; };     // scratch, cnt: of THIS tile
 
+template <int FMT = 0>
 __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLdsX3& L, const P3Split sp = P3Split{-1, 0, nullptr, nullptr}) {
   constexpr int TM = 128, TN = 128, GK = kX3K;
+  // f16 x 2: what brings a pair's accumulators back to real values (2^-(eA + eB), exact)
+  float inv1 = 1.0f, inv2 = 1.0f;
+  if constexpr (FMT == 1) {
+    inv1 = g.A.meta->inv * g.B.meta->inv;
+    if (g.e.A2) inv2 = g.A2.meta->inv * g.B2.meta->inv;
+  }
   const int m0 = by * TM, n0 = bx * TN;
   const bool tri_skip = (g.e.epi == EPI_TRIU_MAX || g.e.sym) && (m0 >= n0 + TN);
   if (g.e.sym && tri_skip) return;      // written by the mirror tile's epilogue
@@ -813,12 +937,13 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
     hi = ((hi + GK - 1) / GK) * GK;
     const int steps = (hi - lo) / GK, per = (steps + per_pair - 1) / per_pair;
     const int clo = lo + sub * per * GK, chi = min(hi, clo + per * GK);
-    p3_pass(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc);
+    p3_pass<FMT>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc);
     f32x4* mine = reinterpret_cast<f32x4*>(sp.scratch) + (long)sp.chunk * (16 * kThreads);
+    const float pm = p ? -inv2 : inv1;                 // partials are stored as real values (f16 x 2: each pair has its own scale)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * kThreads + threadIdx.x] = p ? -acc[i][j] : acc[i][j];
+      for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * kThreads + threadIdx.x] = acc[i][j] * pm;
     __threadfence();                                   // the partial is visible device-wide before the ticket is taken
     __shared__ unsigned ticket;
     __syncthreads();
@@ -848,13 +973,20 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
       if (km & KHI_N) hi = min(hi, n0 + TN);
       lo = (lo / GK) * GK;
       hi = ((hi + GK - 1) / GK) * GK;                 // the planes are zero-padded to whole K tiles
-      p3_pass(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
-      if (p) {
+      p3_pass<FMT>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
+      if (p) {                                         // (f16 x 2: and over to the first pair's scale, a power of two)
+        const float flip = (FMT == 1) ? -(inv2 / inv1) : -1.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = -acc[i][j];
+          for (int j = 0; j < 4; ++j) acc[i][j] *= flip;
       }
+    }
+    if constexpr (FMT == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= inv1;
     }
   }
   if (g.e.scale_max) {                                // (step / max) A B = step / max (A B): applied to the finished sums
@@ -885,14 +1017,15 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
   if (g.e.C) gemm_epilogue<128>(g.e, acc, m0, n0);
   // a symmetric product (Gram) names the same buffer twice: the mirror image is the transposed store of the tiles above
   // the diagonal (a diagonal tile holds both halves itself)
-  if (g.Crow || g.Ccol) p3_store_planes(g, acc, m0, n0, g.Crow != nullptr, g.Ccol != nullptr && (!g.e.sym || n0 > m0));
+  if (g.Crow || g.Ccol) p3_store_planes<FMT>(g, acc, m0, n0, g.Crow != nullptr, g.Ccol != nullptr && (!g.e.sym || n0 > m0));
 }
 
+template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
   int by, bx;
   gemm_tile_order(g.e.kmode, by, bx);
-  p3_body(g, by, bx, L);
+  p3_body<FMT>(g, by, bx, L);
 }
 
 // two independent products in one grid (see k_gemm_x3_pair)
@@ -953,23 +1086,42 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk(P3Args g, int T,
 
 // The same for any product (all tiles, in the usual tile order): shapes with few output tiles -- a 128 x 4096 apply is one
 // row of 32 tiles, each a chain of 128 K steps -- leave most of the chip idle and are bound by that chain.
+template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk_rect(P3Args g, int ty, int tx, int nchunk, float* scratch,
                                                                      unsigned* cnt) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
   const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
   int by, bx;
   gemm_tile_from_id(t, ty, tx, g.e.kmode, by, bx);
-  p3_body(g, by, bx, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
+  p3_body<FMT>(g, by, bx, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
 }
 
 // fp32 view X(r, c) = X[r * rs + c * cs], r < R, c < C  ->  planes with x = r, k = c (zeros outside R x C; the grid covers
 // the padded extents) and, optionally, the planes of the transposed view (x = c, k = r) from the same read.  64 x 64
 // tiles through LDS so that the read (along the view's contiguous dimension) and both writes are coalesced.
+// FMT = 1: the f16 x 2 planes of X 2^e, e from meta->amax (k_absmax ran before); the first block completes *meta.
+template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
                                                      __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
-                                                     long tts, long tps) {
+                                                     long tts, long tps, PlaneMeta* meta) {
   __shared__ float S[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  constexpr int NPL = FMT ? 2 : 3;
+  float sc = 1.0f;
+  if constexpr (FMT == 1) {
+    const float amax = meta->amax;
+    sc = plane_scale_of_bound(amax);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { meta->scale = sc; meta->inv = 1.0f / sc; meta->bound = amax; }
+  }
+  auto split_pair = [&](float x0, float x1, unsigned (&q)[3]) {
+    if constexpr (FMT == 1) {
+      unsigned t[2];
+      split2h_pair(x0 * sc, x1 * sc, t);
+      q[0] = t[0]; q[1] = t[1]; q[2] = 0u;
+    } else {
+      split3_pair(x0, x1, q);
+    }
+  };
   // (clamped addresses, every load issued before the first use: a guarded load compiles to load-then-wait)
   float x[16];
   if (cs == 1 || rs != 1) {
@@ -997,10 +1149,10 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
     for (int i = 0; i < 4; ++i) {
       const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
       unsigned q0[3], q1[3];
-      split3_pair(S[r][c], S[r][c + 1], q0);
-      split3_pair(S[r][c + 2], S[r][c + 3], q1);
+      split_pair(S[r][c], S[r][c + 1], q0);
+      split_pair(S[r][c + 2], S[r][c + 3], q1);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
         *reinterpret_cast<uint2*>(P + pl * ps + p3_index(ts, r0 + r, c0 + c)) = make_uint2(q0[pl], q1[pl]);
     }
   }
@@ -1009,12 +1161,39 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
     for (int i = 0; i < 4; ++i) {
       const int c = (tid >> 4) + 16 * i, r = (tid & 15) * 4;
       unsigned q0[3], q1[3];
-      split3_pair(S[r][c], S[r + 1][c], q0);
-      split3_pair(S[r + 2][c], S[r + 3][c], q1);
+      split_pair(S[r][c], S[r + 1][c], q0);
+      split_pair(S[r + 2][c], S[r + 3][c], q1);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
         *reinterpret_cast<uint2*>(Pt + pl * tps + p3_index(tts, c0 + c, r0 + r)) = make_uint2(q0[pl], q1[pl]);
     }
+  }
+}
+
+// max |X[i]|, i < n (NaN propagates), into meta->amax, which the host zeroed on the stream beforehand
+__global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ X, long n, PlaneMeta* meta) {
+  __shared__ float red[kThreads / 64];
+  float m = 0.0f;
+  const long stride = (long)gridDim.x * kThreads, t0 = (long)blockIdx.x * kThreads + threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    const long n4 = n >> 2;
+    for (long i = t0; i < n4; i += stride) {
+      const float4 v = X4[i];
+      m = amaxf(amaxf(m, fabsf(v.x)), amaxf(amaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+    }
+    for (long i = (n4 << 2) + t0; i < n; i += stride) m = amaxf(m, fabsf(X[i]));
+  } else {
+    for (long i = t0; i < n; i += stride) m = amaxf(m, fabsf(X[i]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) m = amaxf(m, red[w]);
+    if (__float_as_uint(m) != 0u) atomicMax(reinterpret_cast<int*>(&meta->amax), __float_as_int(m));
   }
 }
 
@@ -2067,6 +2246,7 @@ struct KronWs {
   float* split_scratch; unsigned* split_cnt;                 // K-split tail of the gradient grid (k_gemm_p3_grad)
   float* sk_scratch; unsigned* sk_cnt;                       // split-K of products with few output tiles (launch_p3_auto)
   __bf16* S0;                                                // planes of one [max(M, N) x 2048] group of the solves
+  PlaneMeta* pmeta;                                          // f16 x 2 planes: scales and maxima (kPm* slots)
   int64_t total;
 };
 
@@ -2115,7 +2295,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.PP = k.F1 = k.F2 = k.Y0 = k.Y1 = k.Y2 = nullptr;
   k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
   k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
-  k.sk_scratch = nullptr; k.sk_cnt = nullptr;
+  k.sk_scratch = nullptr; k.sk_cnt = nullptr; k.pmeta = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -2130,6 +2310,7 @@ static KronWs kron_layout(char* base, int M, int N) {
       k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
     }
     k.S0 = planes(big * 2048);
+    k.pmeta = reinterpret_cast<PlaneMeta*>(take(256));
     if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
       k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
       k.sk_cnt = reinterpret_cast<unsigned*>(take(kSkMaxTiles * 4));
@@ -2303,32 +2484,65 @@ static int g_stage_mix = 3;     // tuning key 7: bit 0 = the batched small-layer
                                 // bit 1 = a single update with M, N <= 512 takes the batched route (5 launches instead of 10-13)
 static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
 
-struct P3Buf { __bf16* p; long rows, ld; };          // planes of a matrix with padded extents x = rows, k = ld (multiples of 128)
-static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld}; }
+static int g_planes_f16 = 1;    // tuning key 12: 1 = the planes of the large apply in the f16 x 2 format (0 = bf16 x 3).  Like key 4 it
+                                // changes what psgd_kron_dd_prepare_f32 leaves in the workspace: prepare again after changing it
 
+// planes of a matrix with padded extents x = rows, k = ld (multiples of 128); meta != null <=> f16 x 2 format
+struct P3Buf { __bf16* p; long rows, ld; PlaneMeta* meta = nullptr; };
+static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld, b.meta}; }
+// slots of KronWs::pmeta
+enum { kPmPP = 0, kPmF = 1, kPmQs = 2, kPmG = 4, kPmT = 5, kPmA = 6 };
+
+// f16 x 2: max|X| of the R x C matrix behind the view (dense: R * C consecutive floats) into out.meta, zeroed beforehand
+static int launch_absmax(const float* X, long n, PlaneMeta* meta, hipStream_t st) {
+  long blocks = (n / 4 + kThreads * 4 - 1) / (kThreads * 4);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(kThreads), 0, st, X, n, meta);
+  return (int)hipGetLastError();
+}
 static int launch_split3(const float* X, long rs, long cs, int R, int C, const P3Buf& out, hipStream_t st) {
-  hipLaunchKernelGGL(k_split3, dim3((unsigned)(out.ld / 64), (unsigned)(out.rows / 64)), dim3(kThreads), 0, st, X, rs, cs, R, C,
-                     out.p, out.rows * 32, out.rows * out.ld, (__bf16*)nullptr, 0L, 0L);
+  const dim3 grid((unsigned)(out.ld / 64), (unsigned)(out.rows / 64));
+  if (out.meta)
+    hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
+                       (__bf16*)nullptr, 0L, 0L, out.meta);
+  else
+    hipLaunchKernelGGL(k_split3<0>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
+                       (__bf16*)nullptr, 0L, 0L, (PlaneMeta*)nullptr);
   return (int)hipGetLastError();
 }
 // planes of the view (out) and of its transpose (outT: rows/ld swapped) from one read
 static int launch_split3_both(const float* X, long rs, long cs, int R, int C, const P3Buf& out, const P3Buf& outT, hipStream_t st) {
-  hipLaunchKernelGGL(k_split3, dim3((unsigned)(out.ld / 64), (unsigned)(out.rows / 64)), dim3(kThreads), 0, st, X, rs, cs, R, C,
-                     out.p, out.rows * 32, out.rows * out.ld, outT.p, outT.rows * 32, outT.rows * outT.ld);
+  const dim3 grid((unsigned)(out.ld / 64), (unsigned)(out.rows / 64));
+  if (out.meta)
+    hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
+                       outT.p, outT.rows * 32, outT.rows * outT.ld, out.meta);
+  else
+    hipLaunchKernelGGL(k_split3<0>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
+                       outT.p, outT.rows * 32, outT.rows * outT.ld, (PlaneMeta*)nullptr);
   return (int)hipGetLastError();
 }
 
 static P3Args p3_args(const P3Buf& A, const P3Buf& B, int M, int N, int K, int kmode) {
   P3Args g = {};
   g.A = p3_of(A); g.B = p3_of(B);
+  g.fmt = A.meta ? 1 : 0;
   g.e.M = M; g.e.N = N; g.e.K = K; g.e.kmode = kmode; g.e.epi = EPI_STORE;
   return g;
 }
-static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; }
-static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; }
+// (f16 x 2: the scale of the output from K max|A| max|B|, see PlaneMeta; one meta for both forms of the output)
+static void p3_out_meta(P3Args& g, const P3Buf& C) {
+  if (!g.fmt) return;
+  g.ometa = C.meta; g.oa = g.A.meta; g.ob = g.B.meta; g.okmul = (float)g.e.K;
+  g.oa2 = g.ob2 = nullptr; g.okmul2 = 0.0f;
+}
+static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; p3_out_meta(g, C); }
+static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; p3_out_meta(g, Ct); }
 
 static int launch_p3(const P3Args& g, hipStream_t st) {
-  hipLaunchKernelGGL(k_gemm_p3, dim3((g.e.N + 127) / 128, (g.e.M + 127) / 128), dim3(kThreads), 0, st, g);
+  const dim3 grid((g.e.N + 127) / 128, (g.e.M + 127) / 128);
+  if (g.fmt) hipLaunchKernelGGL(k_gemm_p3<1>, grid, dim3(kThreads), 0, st, g);
+  else hipLaunchKernelGGL(k_gemm_p3<0>, grid, dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
 }
 
@@ -2352,7 +2566,8 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
   while (nchunk > 1 && steps / nchunk < min_chunk) --nchunk;
   if (nchunk <= 1) return launch_p3(g, st);
   if (hipMemsetAsync(cnt, 0, (size_t)tiles * 4, st) != hipSuccess) return 1;
-  hipLaunchKernelGGL(k_gemm_p3_splitk_rect, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
+  if (g.fmt) hipLaunchKernelGGL(k_gemm_p3_splitk_rect<1>, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
+  else hipLaunchKernelGGL(k_gemm_p3_splitk_rect<0>, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
   return (int)hipGetLastError();
 }
 
@@ -2553,9 +2768,16 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
   const float* Qs = left ? Ql : Qr;
   const float* Qb = left ? Qr : Ql;
   const long nsp = pad128(ns), nbp = pad128(nb);
-  const P3Buf QsT = {k.Y0, nsp, nsp}, PP = {k.PP, nsp, nsp}, F1 = {k.F1, nbp, nbp}, F2 = {k.F2, nbp, nbp};
-  int e = launch_split3(Qs, 1, ns, ns, ns, QsT, st);                                     // (x, k) = Qs[k][x]
-  if (e) return e;
+  PlaneMeta* pm = g_planes_f16 ? k.pmeta : nullptr;
+  const P3Buf QsT = {k.Y0, nsp, nsp, pm ? pm + kPmQs : pm}, PP = {k.PP, nsp, nsp, pm ? pm + kPmPP : pm};
+  const P3Buf F1 = {k.F1, nbp, nbp, pm ? pm + kPmF : pm}, F2 = {k.F2, nbp, nbp, pm ? pm + kPmF : pm};
+  int e;
+  if (pm) {
+    if (hipMemsetAsync(pm, 0, 4 * sizeof(PlaneMeta), st) != hipSuccess) return 1;
+    if ((e = launch_absmax(Qs, (long)ns * ns, QsT.meta, st))) return e;
+    if ((e = launch_absmax(Qb, (long)nb * nb, F1.meta, st))) return e;
+  }
+  if ((e = launch_split3(Qs, 1, ns, ns, ns, QsT, st))) return e;                         // (x, k) = Qs[k][x]
   P3Args g = p3_args(QsT, QsT, ns, ns, ns, KHI_M | KHI_N);                              // Qs'Qs, symmetric
   g.e.sym = 1;
   p3_out_row(g, PP); p3_out_col(g, PP);
@@ -2567,9 +2789,16 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
 static int planes_apply(const float* G, float* out, int M, int N, const KronWs& k, hipStream_t st) {
   const long Mp = pad128(M), Np = pad128(N);
   int e;
+  PlaneMeta* pm = g_planes_f16 ? k.pmeta : nullptr;
+  PlaneMeta *mPP = pm ? pm + kPmPP : pm, *mF = pm ? pm + kPmF : pm, *mG = pm ? pm + kPmG : pm, *mT = pm ? pm + kPmT : pm,
+            *mA = pm ? pm + kPmA : pm;
+  if (pm) {
+    if (hipMemsetAsync(mG, 0, 3 * sizeof(PlaneMeta), st) != hipSuccess) return 1;
+    if ((e = launch_absmax(G, (long)M * N, mG, st))) return e;
+  }
   if (M < N) {
-    const P3Buf PP = {k.PP, Mp, Mp}, F1 = {k.F1, Np, Np}, F2 = {k.F2, Np, Np};
-    const P3Buf Gt = {k.Y0, Np, Mp}, T = {k.Y1, Mp, Np}, A = {k.Y2, Mp, Np};
+    const P3Buf PP = {k.PP, Mp, Mp, mPP}, F1 = {k.F1, Np, Np, mF}, F2 = {k.F2, Np, Np, mF};
+    const P3Buf Gt = {k.Y0, Np, Mp, mG}, T = {k.Y1, Mp, Np, mT}, A = {k.Y2, Mp, Np, mA};
     if ((e = launch_split3(G, 1, N, N, M, Gt, st))) return e;                            // (n, k = m) = G[m][n]
     P3Args g0 = p3_args(PP, Gt, M, N, M, 0);                                             // (Ql'Ql) G
     p3_out_row(g0, T);
@@ -2581,8 +2810,8 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
     g2.e.C = out; g2.e.ldc = N;
     return launch_p3_auto(g2, k.sk_scratch, k.sk_cnt, st);
   }
-  const P3Buf PP = {k.PP, Np, Np}, F1 = {k.F1, Mp, Mp}, F2 = {k.F2, Mp, Mp};
-  const P3Buf Gp = {k.Y0, Mp, Np}, Tt = {k.Y1, Np, Mp}, At = {k.Y2, Np, Mp};
+  const P3Buf PP = {k.PP, Np, Np, mPP}, F1 = {k.F1, Mp, Mp, mF}, F2 = {k.F2, Mp, Mp, mF};
+  const P3Buf Gp = {k.Y0, Mp, Np, mG}, Tt = {k.Y1, Np, Mp, mT}, At = {k.Y2, Np, Mp, mA};
   if ((e = launch_split3(G, N, 1, M, N, Gp, st))) return e;
   P3Args g0 = p3_args(Gp, PP, M, N, N, 0);                                               // G (Qr'Qr)
   p3_out_col(g0, Tt);
@@ -2747,6 +2976,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 8) { g_splitk = value; return PSGD_OK; }
   if (key == 9) { g_overlap = value; return PSGD_OK; }
   if (key == 10) { g_side_prio = value; return PSGD_OK; }
+  if (key == 12) { g_planes_f16 = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

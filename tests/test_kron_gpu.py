@@ -664,9 +664,9 @@ def test_prepared_grams_follow_the_factors(psgd, M, N):
 @pytest.mark.parametrize("M,N", [(1024, 1024), (1030, 1100), (1024, 2049), (1500, 1027), (1000, 1000), (260, 3100), (8200, 70)])
 def test_large_apply_on_operand_planes(psgd, M, N):
     """At least 64 output tiles of 128 x 128 (skinny shapes included: the short side is zero-padded to a tile): the apply
-    runs on operands split once into three bf16 planes (k_gemm_p3; x = h + m + l exactly, so
-    the products are the ones of the in-GEMM split).  Both paths against the fp64 oracle, shapes that are not multiples
-    of the 128-tile (zero-padded planes), and against each other."""
+    runs on operands split once into planes (k_gemm_p3; two fp16 planes and a power-of-two scale per matrix by default,
+    three bf16 planes -- x = h + m + l exactly, the products of the in-GEMM split -- with tuning key 12 = 0).  Every path
+    against the fp64 oracle, shapes that are not multiples of the 128-tile (zero-padded planes), and against each other."""
     from psgd_tf_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(M * 3 + N)
@@ -675,15 +675,19 @@ def test_large_apply_on_operand_planes(psgd, M, N):
     ref = orc.precond_grad_kron(Ql.astype(np.float64), Qr.astype(np.float64), G.astype(np.float64))
     outs = []
     try:
-        for planes in (1, 0):
+        for planes, f16 in ((1, 1), (1, 0), (0, 0)):
             lib.psgd_kron_set_tuning(4, planes)
+            lib.psgd_kron_set_tuning(12, f16)
             out = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G))          # new factor tensors: prepared state rebuilt
             assert rel_err(out.cpu().numpy(), ref) < TOL
+            assert torch.equal(out, psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G)))
             outs.append(out)
     finally:
         lib.psgd_kron_set_tuning(4, 1)
-    # (same products; a few-tile shape with a long K -- 8200 x 70 -- sums its K range in chunks on the planes path)
-    assert rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 3e-6
+        lib.psgd_kron_set_tuning(12, 1)
+    # (same products; a few-tile shape with a long K -- 8200 x 70 -- sums its K range in chunks on the planes paths)
+    assert rel_err(outs[1].cpu().numpy(), outs[2].cpu().numpy()) < 3e-6
+    assert rel_err(outs[0].cpu().numpy(), outs[2].cpu().numpy()) < 3e-6
 
 
 def test_gradient_grid_k_split_is_deterministic_and_equivalent(psgd):
