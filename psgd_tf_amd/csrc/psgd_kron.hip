@@ -665,6 +665,14 @@ __device__ __forceinline__ float plane_scale_of_bound(float b) {      // 2^e wit
   (void)frexpf(b, &k);                                                // b = f 2^k, f in [0.5, 1)
   return ldexpf(1.0f, min(14 - k, 126));                              // (subnormal-sized data: 2^e and 2^-e stay normal)
 }
+// *addr = max(*addr, v) for non-negative v (NaN above Inf, see amaxf).  Thousands of waves report to ONE address and atomics
+// on one address serialise in L2 (measured: 8192 of them turned the 16 us balance launch into 98 us), so a wave first looks:
+// the value only grows, a stale look costs a redundant atomic at worst.
+__device__ __forceinline__ void atomic_amax(float* addr, float v) {
+  const unsigned u = __float_as_uint(v);
+  if (u == 0u || u <= *reinterpret_cast<volatile unsigned*>(addr)) return;
+  atomicMax(reinterpret_cast<int*>(addr), (int)u);
+}
 // two fp32 values (already scaled) -> packed fp16 pairs of the planes h and M = 2^11 (x - h)
 __device__ __forceinline__ void split2h_pair(float x0, float x1, unsigned (&q)[2]) {
   const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
@@ -756,15 +764,15 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
         x = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bM, x, 0, 0, 0);
         cross[i][j] = x;
         acc[i][j] = v;
-        return;
+      } else {
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][NP - 1], v, 0, 0, 0);   // h l'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][NP - 1], b[j][0], v, 0, 0, 0);   // l h'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], v, 0, 0, 0);   // h m'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], v, 0, 0, 0);   // m h'
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], v, 0, 0, 0);   // h h'
+        acc[i][j] = v;
       }
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], v, 0, 0, 0);   // m m'
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], v, 0, 0, 0);   // h l'
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], v, 0, 0, 0);   // l h'
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], v, 0, 0, 0);   // h m'
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], v, 0, 0, 0);   // m h'
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], v, 0, 0, 0);   // h h'
-      acc[i][j] = v;
     };
     // The first column of MFMAs starts as soon as ITS fragments are there (the compiler's counted lgkmcnt waits); the rest
     // of the fragment reads return under it.  Only then: every wave holds its fragments, the buffer is free.
@@ -857,7 +865,7 @@ __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&a
       }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
-    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(&g.ometa->amax), __float_as_int(vmax));
+    if (lane == 0) atomic_amax(&g.ometa->amax, vmax);
     return;
   }
 #pragma unroll
@@ -1012,7 +1020,7 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
         }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
-    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(g.e.maxout), __float_as_int(vmax));
+    if (lane == 0) atomic_amax(g.e.maxout, vmax);
   }
   if (g.e.C) gemm_epilogue<128>(g.e, acc, m0, n0);
   // a symmetric product (Gram) names the same buffer twice: the mirror image is the transposed store of the tiles above
@@ -1031,6 +1039,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
 // two independent products in one grid (see k_gemm_x3_pair)
 struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1, tiles1; };
 
+template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
   int which, id;
@@ -1038,7 +1047,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
   const P3Args& g = p.g[which];
   int by, bx;
   gemm_tile_from_id(id, (g.e.M + 127) / 128, which ? p.tx1 : p.tx0, g.e.kmode, by, bx);
-  p3_body(g, by, bx, L);
+  p3_body<FMT>(g, by, bx, L);
 }
 
 // The two gradient products of the update (psgd.py:175-176) in one grid: upper tiles only (the planes of a triu result are
@@ -1056,20 +1065,21 @@ __device__ __forceinline__ void upper_tile(int idx, int T, int& r, int& c) {    
   c = r + idx - (r * T - (r * (r - 1)) / 2);
 }
 
+template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
   __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
   const int id = blockIdx.x, whole1 = p.n1 - p.nsplit;
   int r, c;
   if (id < p.n0) {
     upper_tile(id, p.T0, r, c);
-    p3_body(p.g[0], r, c, L);
+    p3_body<FMT>(p.g[0], r, c, L);
   } else if (id < p.n0 + whole1) {
     upper_tile(id - p.n0, p.T1, r, c);
-    p3_body(p.g[1], r, c, L);
+    p3_body<FMT>(p.g[1], r, c, L);
   } else {
     const int s = id - p.n0 - whole1, t = s / p.nchunk;
     upper_tile(whole1 + t, p.T1, r, c);
-    p3_body(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
+    p3_body<FMT>(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
   }
 }
 
@@ -1103,15 +1113,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk_rect(P3Args g, i
 template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
                                                      __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
-                                                     long tts, long tps, PlaneMeta* meta) {
+                                                     long tts, long tps, PlaneMeta* meta, const float* __restrict__ part,
+                                                     int npart) {
   __shared__ float S[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
   constexpr int NPL = FMT ? 2 : 3;
   float sc = 1.0f;
   if constexpr (FMT == 1) {
-    const float amax = meta->amax;
+    // max|X| = the maximum of the partial maxima the launch ahead left (k_absmax, the balance): every block reduces them itself
+    float amax = 0.0f;
+    for (int i = tid; i < npart; i += kThreads) amax = amaxf(amax, part[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = amaxf(amax, __shfl_down(amax, off, 64));
+    if ((tid & 63) == 0) S[0][tid >> 6] = amax;
+    __syncthreads();
+    amax = amaxf(amaxf(S[0][0], S[0][1]), amaxf(S[0][2], S[0][3]));
+    __syncthreads();
     sc = plane_scale_of_bound(amax);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { meta->scale = sc; meta->inv = 1.0f / sc; meta->bound = amax; }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { meta->scale = sc; meta->inv = 1.0f / sc; meta->amax = amax; meta->bound = amax; }
   }
   auto split_pair = [&](float x0, float x1, unsigned (&q)[3]) {
     if constexpr (FMT == 1) {
@@ -1170,21 +1189,41 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
   }
 }
 
-// max |X[i]|, i < n (NaN propagates), into meta->amax, which the host zeroed on the stream beforehand
-__global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ X, long n, PlaneMeta* meta) {
+// max |X(o, i)|, X(o, i) = X[o * os + i], o < O, i < L (NaN propagates): block b leaves ITS maximum in part[b] and the
+// split kernel behind reduces them.  A dense matrix is one run (O = 1); a column block of a row-major matrix is O runs of
+// L.  The first block also clears zero[0 .. nzero): the maxima that the epilogues of the products behind accumulate.
+__global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ X, long os, long O, long L, float* __restrict__ part,
+                                                     float* __restrict__ zero, int nzero) {
   __shared__ float red[kThreads / 64];
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nzero; i += kThreads) zero[i] = 0.0f;
   float m = 0.0f;
-  const long stride = (long)gridDim.x * kThreads, t0 = (long)blockIdx.x * kThreads + threadIdx.x;
-  if ((reinterpret_cast<uintptr_t>(X) & 15) == 0) {
-    const float4* X4 = reinterpret_cast<const float4*>(X);
-    const long n4 = n >> 2;
-    for (long i = t0; i < n4; i += stride) {
-      const float4 v = X4[i];
-      m = amaxf(amaxf(m, fabsf(v.x)), amaxf(amaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+  if (O == 1) {
+    const long n = L, stride = (long)gridDim.x * kThreads, t0 = (long)blockIdx.x * kThreads + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+      const float4* X4 = reinterpret_cast<const float4*>(X);
+      const long n4 = n >> 2;
+      for (long i = t0; i < n4; i += stride) {
+        const float4 v = X4[i];
+        m = amaxf(amaxf(m, fabsf(v.x)), amaxf(amaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+      }
+      for (long i = (n4 << 2) + t0; i < n; i += stride) m = amaxf(m, fabsf(X[i]));
+    } else {
+      for (long i = t0; i < n; i += stride) m = amaxf(m, fabsf(X[i]));
     }
-    for (long i = (n4 << 2) + t0; i < n; i += stride) m = amaxf(m, fabsf(X[i]));
   } else {
-    for (long i = t0; i < n; i += stride) m = amaxf(m, fabsf(X[i]));
+    const bool vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (os & 3) == 0 && (L & 3) == 0;
+    for (long o = blockIdx.x; o < O; o += gridDim.x) {
+      const float* __restrict__ row = X + o * os;
+      if (vec) {
+        for (long i = threadIdx.x * 4L; i < L; i += kThreads * 4L) {
+          const float4 v = *reinterpret_cast<const float4*>(row + i);
+          m = amaxf(amaxf(m, fabsf(v.x)), amaxf(amaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+        }
+      } else {
+        for (long i = threadIdx.x; i < L; i += kThreads) m = amaxf(m, fabsf(row[i]));
+      }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_down(m, off, 64));
@@ -1193,7 +1232,7 @@ __global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ X
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int w = 1; w < kThreads / 64; ++w) m = amaxf(m, red[w]);
-    if (__float_as_uint(m) != 0u) atomicMax(reinterpret_cast<int*>(&meta->amax), __float_as_int(m));
+    part[blockIdx.x] = m;
   }
 }
 
@@ -1965,13 +2004,32 @@ __device__ __forceinline__ float balance_rho(const float* __restrict__ Ql, const
   return sqrtf(ml / mr);
 }
 
+// part_l / part_r (optional): this block's max|QlS|, max|QrS| (slot `bid` of `nblocks`) for the f16 x 2 planes of the
+// factors; the split kernel reduces the slots (thousands of atomics on one address would serialise in L2: measured, they
+// turned this 16 us launch into 98 us)
 __device__ __forceinline__ void balance_body(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
-                                             float* QlS, float* QrS, float (*red)[4], int bid, int nblocks) {
+                                             float* QlS, float* QrS, float (*red)[4], int bid, int nblocks,
+                                             float* part_l = nullptr, float* part_r = nullptr) {
   const float rho = balance_rho(Ql, Qr, M, N, red);
   const long nl = (long)M * M, nr = (long)N * N;
   const long tid = (long)bid * kThreads + threadIdx.x, nth = (long)nblocks * kThreads;
-  for (long i = tid; i < nl; i += nth) QlS[i] = Ql[i] / rho;
-  for (long i = tid; i < nr; i += nth) QrS[i] = rho * Qr[i];
+  float ml = 0.0f, mr = 0.0f;
+  for (long i = tid; i < nl; i += nth) { const float q = Ql[i] / rho; QlS[i] = q; ml = amaxf(ml, fabsf(q)); }
+  for (long i = tid; i < nr; i += nth) { const float q = rho * Qr[i]; QrS[i] = q; mr = amaxf(mr, fabsf(q)); }
+  if (part_l) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ml = amaxf(ml, __shfl_down(ml, off, 64));
+      mr = amaxf(mr, __shfl_down(mr, off, 64));
+    }
+    __syncthreads();                                   // (red: balance_rho is done with it)
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ml; red[1][threadIdx.x >> 6] = mr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part_l[bid] = amaxf(amaxf(red[0][0], red[0][1]), amaxf(red[0][2], red[0][3]));
+      part_r[bid] = amaxf(amaxf(red[1][0], red[1][1]), amaxf(red[1][2], red[1][3]));
+    }
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void k_kron_balance(const float* __restrict__ Ql, const float* __restrict__ Qr,
@@ -2042,12 +2100,16 @@ __global__ __launch_bounds__(kThreads) void k_kron_balance_batched(BalanceBatch 
 // one problem; the first inv_blocks workgroups invert the diagonal blocks (0 = balance only)
 __global__ __launch_bounds__(kThreads) void k_kron_balance_inv(const float* __restrict__ Ql, const float* __restrict__ Qr,
                                                                int M, int N, float* QlS, float* QrS, float* scal,
-                                                               float* dinv, int inv_blocks) {
+                                                               float* dinv, int inv_blocks, float* part_l, float* part_r,
+                                                               float* zero, int nzero) {
   __shared__ float red[2][4];
   __shared__ float Qd[4][32][33];
   if ((int)blockIdx.x >= inv_blocks) {
-    if (scal && (int)blockIdx.x == inv_blocks && threadIdx.x < 64) scal[threadIdx.x] = 0.0f;
-    balance_body(Ql, Qr, M, N, QlS, QrS, red, blockIdx.x - inv_blocks, gridDim.x - inv_blocks);
+    if ((int)blockIdx.x == inv_blocks) {               // accumulators of the later stages (max|grad|; maxima of f16 x 2 planes)
+      if (scal && threadIdx.x < 64) scal[threadIdx.x] = 0.0f;
+      for (int i = threadIdx.x; i < nzero; i += kThreads) zero[i] = 0.0f;
+    }
+    balance_body(Ql, Qr, M, N, QlS, QrS, red, blockIdx.x - inv_blocks, gridDim.x - inv_blocks, part_l, part_r);
     return;
   }
   balance_inv_body(Ql, Qr, M, N, dinv, red, Qd, blockIdx.x);
@@ -2247,6 +2309,7 @@ struct KronWs {
   float* sk_scratch; unsigned* sk_cnt;                       // split-K of products with few output tiles (launch_p3_auto)
   __bf16* S0;                                                // planes of one [max(M, N) x 2048] group of the solves
   PlaneMeta* pmeta;                                          // f16 x 2 planes: scales and maxima (kPm* slots)
+  float* pm_part;                                            // ... partial maxima: 4 arrays of kPmPartMax (main stream, side stream, QlS, QrS)
   int64_t total;
 };
 
@@ -2295,7 +2358,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.PP = k.F1 = k.F2 = k.Y0 = k.Y1 = k.Y2 = nullptr;
   k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
   k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
-  k.sk_scratch = nullptr; k.sk_cnt = nullptr; k.pmeta = nullptr;
+  k.sk_scratch = nullptr; k.sk_cnt = nullptr; k.pmeta = nullptr; k.pm_part = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -2310,7 +2373,8 @@ static KronWs kron_layout(char* base, int M, int N) {
       k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
     }
     k.S0 = planes(big * 2048);
-    k.pmeta = reinterpret_cast<PlaneMeta*>(take(256));
+    k.pmeta = reinterpret_cast<PlaneMeta*>(take(1024));      // kPmSlots x 16 B
+    k.pm_part = take(4 * 2048 * 4);
     if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
       k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
       k.sk_cnt = reinterpret_cast<unsigned*>(take(kSkMaxTiles * 4));
@@ -2484,31 +2548,51 @@ static int g_stage_mix = 3;     // tuning key 7: bit 0 = the batched small-layer
                                 // bit 1 = a single update with M, N <= 512 takes the batched route (5 launches instead of 10-13)
 static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
 
-static int g_planes_f16 = 1;    // tuning key 12: 1 = the planes of the large apply in the f16 x 2 format (0 = bf16 x 3).  Like key 4 it
-                                // changes what psgd_kron_dd_prepare_f32 leaves in the workspace: prepare again after changing it
+static int g_planes_f16 = 2;    // tuning key 12: planes in the f16 x 2 format: 0 = none (bf16 x 3), 1 = of the large apply, 2 = and of the
+                                // large update.  Like key 4 it changes what psgd_kron_dd_prepare_f32 leaves in the workspace: prepare
+                                // again after changing it
 
 // planes of a matrix with padded extents x = rows, k = ld (multiples of 128); meta != null <=> f16 x 2 format
-struct P3Buf { __bf16* p; long rows, ld; PlaneMeta* meta = nullptr; };
+static int balance_grid(int M, int N) {                // workgroups of the balance launch that write QlS / QrS
+  const long tot = (long)M * M + (long)N * N;
+  const long grid = (tot + kThreads - 1) / kThreads;
+  return grid > 1024 ? 1024 : (int)grid;
+}
+// (f16 x 2, planes split from fp32 data: part[0 .. npart) = the partial maxima of |X| that the launch ahead left)
+struct P3Buf { __bf16* p; long rows, ld; PlaneMeta* meta = nullptr; const float* part = nullptr; int npart = 0; };
+constexpr int kPmPartMax = 2048;      // partial maxima per array (KronWs::pm_part holds four arrays)
 static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld, b.meta}; }
 // slots of KronWs::pmeta
-enum { kPmPP = 0, kPmF = 1, kPmQs = 2, kPmG = 4, kPmT = 5, kPmA = 6 };
+enum { kPmPP = 0, kPmF = 1, kPmQs = 2, kPmG = 4, kPmT = 5, kPmA = 6,                       // the apply (0, 1: prepared state)
+       kPmL = 8, kPmR = 9, kPmdG = 10, kPmUT = 11, kPmUA = 12, kPmBt = 13, kPmG1 = 14, kPmG2 = 15,   // the update ...
+       kPmStrip = 16, kPmSlots = 64 };                                                      // ... and its solves' groups
 
-// f16 x 2: max|X| of the R x C matrix behind the view (dense: R * C consecutive floats) into out.meta, zeroed beforehand
-static int launch_absmax(const float* X, long n, PlaneMeta* meta, hipStream_t st) {
+// f16 x 2: the partial maxima of |X| (n consecutive floats) for the split of `buf` behind, into `part`; zero: see k_absmax
+static int launch_absmax(const float* X, long n, P3Buf& buf, float* part, hipStream_t st, float* zero = nullptr, int nzero = 0) {
   long blocks = (n / 4 + kThreads * 4 - 1) / (kThreads * 4);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > kPmPartMax) blocks = kPmPartMax;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(kThreads), 0, st, X, n, meta);
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(kThreads), 0, st, X, 0L, 1L, n, part, zero, nzero);
+  buf.part = part; buf.npart = (int)blocks;
+  return (int)hipGetLastError();
+}
+// ... of the R x C view X(r, c) = X[r * rs + c * cs] with rs == 1 or cs == 1
+static int launch_absmax_view(const float* X, long rs, long cs, long R, long C, P3Buf& buf, float* part, hipStream_t st) {
+  const long os = cs == 1 ? rs : cs, O = cs == 1 ? R : C, L = cs == 1 ? C : R;
+  if (os == L) return launch_absmax(X, O * L, buf, part, st);
+  const long blocks = O < kPmPartMax ? O : kPmPartMax;
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(kThreads), 0, st, X, os, O, L, part, (float*)nullptr, 0);
+  buf.part = part; buf.npart = (int)blocks;
   return (int)hipGetLastError();
 }
 static int launch_split3(const float* X, long rs, long cs, int R, int C, const P3Buf& out, hipStream_t st) {
   const dim3 grid((unsigned)(out.ld / 64), (unsigned)(out.rows / 64));
   if (out.meta)
     hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       (__bf16*)nullptr, 0L, 0L, out.meta);
+                       (__bf16*)nullptr, 0L, 0L, out.meta, out.part, out.npart);
   else
     hipLaunchKernelGGL(k_split3<0>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       (__bf16*)nullptr, 0L, 0L, (PlaneMeta*)nullptr);
+                       (__bf16*)nullptr, 0L, 0L, (PlaneMeta*)nullptr, (const float*)nullptr, 0);
   return (int)hipGetLastError();
 }
 // planes of the view (out) and of its transpose (outT: rows/ld swapped) from one read
@@ -2516,10 +2600,10 @@ static int launch_split3_both(const float* X, long rs, long cs, int R, int C, co
   const dim3 grid((unsigned)(out.ld / 64), (unsigned)(out.rows / 64));
   if (out.meta)
     hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       outT.p, outT.rows * 32, outT.rows * outT.ld, out.meta);
+                       outT.p, outT.rows * 32, outT.rows * outT.ld, out.meta, out.part, out.npart);
   else
     hipLaunchKernelGGL(k_split3<0>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       outT.p, outT.rows * 32, outT.rows * outT.ld, (PlaneMeta*)nullptr);
+                       outT.p, outT.rows * 32, outT.rows * outT.ld, (PlaneMeta*)nullptr, (const float*)nullptr, 0);
   return (int)hipGetLastError();
 }
 
@@ -2535,6 +2619,7 @@ static void p3_out_meta(P3Args& g, const P3Buf& C) {
   if (!g.fmt) return;
   g.ometa = C.meta; g.oa = g.A.meta; g.ob = g.B.meta; g.okmul = (float)g.e.K;
   g.oa2 = g.ob2 = nullptr; g.okmul2 = 0.0f;
+  if (g.e.A2) { g.oa2 = g.A2.meta; g.ob2 = g.B2.meta; g.okmul2 = (float)g.e.K2; }      // (the second pair is named before the outputs)
 }
 static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; p3_out_meta(g, C); }
 static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; p3_out_meta(g, Ct); }
@@ -2611,7 +2696,7 @@ static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
 // group updates (K = 2048) then run on planes -- the finished group is split once instead of once per column tile.
 static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
                    hipStream_t st, long xi = 0, long xj = 0, int lite = 0, const P3Buf* Qc = nullptr, __bf16* blk = nullptr,
-                   bool inv_ready = false) {
+                   bool inv_ready = false, PlaneMeta* strip_meta = nullptr, int strip_slots = 0, float* part = nullptr) {
   if (!inv_ready) {                                    // (the update's balance launch has made them already)
     hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
     if (hipGetLastError() != hipSuccess) return 1;
@@ -2632,10 +2717,16 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
   // (K = 512), and the finished group updates everything to its right in one product with K = 512 * group -- the
   // 16 K steps of a K = 512 product are dominated by the fixed parts of a block, so the wide products get a longer K.
   auto update = [&](int k0, int kw, int c0, int cw) {                    // Y[:, c0:c0+cw] -= Y[:, k0:k0+kw] Q[k0:k0+kw, c0:c0+cw]
-    if (Qc && blk && kw == kTrsmPlanesK && (long)((cw + 127) / 128) * ((nvec + 127) / 128) >= 256) {
-      const P3Buf Yg = {blk, pad128(nvec), kTrsmPlanesK};
-      int e = launch_split3(Y + (long)k0 * sj, si, sj, nvec, kw, Yg, st);            // (i, k) = Y[i, k0 + k]
-      if (e) return e;
+    // (f16 x 2 planes of Q: every finished group needs a zeroed meta slot for its maximum; out of slots -> the fp32 kernel)
+    if (Qc && blk && kw == kTrsmPlanesK && (long)((cw + 127) / 128) * ((nvec + 127) / 128) >= 256 &&
+        (!Qc->meta || strip_slots > 0)) {
+      P3Buf Yg = {blk, pad128(nvec), kTrsmPlanesK};
+      int e;
+      if (Qc->meta) {
+        Yg.meta = strip_meta++; --strip_slots;
+        if ((e = launch_absmax_view(Y + (long)k0 * sj, si, sj, nvec, kw, Yg, part, st))) return e;
+      }
+      if ((e = launch_split3(Y + (long)k0 * sj, si, sj, nvec, kw, Yg, st))) return e; // (i, k) = Y[i, k0 + k]
       P3Args g = p3_args(Yg, *Qc, nvec, cw, kw, 0);                                  // (x, k) = Q[k0 + k, c0 + x]
       g.B.p = Qc->p + (long)(k0 / 32) * (Qc->rows * 32) + (long)c0 * 32;
       float* Yr = Y + (long)c0 * sj;
@@ -2721,7 +2812,8 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   p.tiles0 = p.tx0 * ((a.e.M + 127) / 128);
   const int tiles1 = p.tx1 * ((b.e.M + 127) / 128);
   p.tiles1 = tiles1;
-  hipLaunchKernelGGL(k_gemm_p3_pair, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
+  if (a.fmt) hipLaunchKernelGGL(k_gemm_p3_pair<1>, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
+  else hipLaunchKernelGGL(k_gemm_p3_pair<0>, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
   return (int)hipGetLastError();
 }
 
@@ -2752,7 +2844,9 @@ static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsi
     if (steps < kGradChunks / 2) p.nsplit = 0;
   }
   if (p.nsplit && hipMemsetAsync(cnt, 0, (size_t)p.nsplit * 4, st) != hipSuccess) return 1;
-  hipLaunchKernelGGL(k_gemm_p3_grad, dim3(p.n0 + p.n1 - p.nsplit + p.nsplit * p.nchunk), dim3(kThreads), 0, st, p);
+  const dim3 grid(p.n0 + p.n1 - p.nsplit + p.nsplit * p.nchunk);
+  if (a.fmt) hipLaunchKernelGGL(k_gemm_p3_grad<1>, grid, dim3(kThreads), 0, st, p);
+  else hipLaunchKernelGGL(k_gemm_p3_grad<0>, grid, dim3(kThreads), 0, st, p);
   return (int)hipGetLastError();
 }
 
@@ -2769,21 +2863,19 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
   const float* Qb = left ? Qr : Ql;
   const long nsp = pad128(ns), nbp = pad128(nb);
   PlaneMeta* pm = g_planes_f16 ? k.pmeta : nullptr;
-  const P3Buf QsT = {k.Y0, nsp, nsp, pm ? pm + kPmQs : pm}, PP = {k.PP, nsp, nsp, pm ? pm + kPmPP : pm};
-  const P3Buf F1 = {k.F1, nbp, nbp, pm ? pm + kPmF : pm}, F2 = {k.F2, nbp, nbp, pm ? pm + kPmF : pm};
+  P3Buf QsT = {k.Y0, nsp, nsp, pm ? pm + kPmQs : pm}, F1 = {k.F1, nbp, nbp, pm ? pm + kPmF : pm};
+  const P3Buf PP = {k.PP, nsp, nsp, pm ? pm + kPmPP : pm};
   int e;
-  if (pm) {
-    if (hipMemsetAsync(pm, 0, 4 * sizeof(PlaneMeta), st) != hipSuccess) return 1;
-    if ((e = launch_absmax(Qs, (long)ns * ns, QsT.meta, st))) return e;
-    if ((e = launch_absmax(Qb, (long)nb * nb, F1.meta, st))) return e;
-  }
+  if (pm && (e = launch_absmax(Qs, (long)ns * ns, QsT, k.pm_part, st, &pm[kPmPP].amax, 1))) return e;
   if ((e = launch_split3(Qs, 1, ns, ns, ns, QsT, st))) return e;                         // (x, k) = Qs[k][x]
   P3Args g = p3_args(QsT, QsT, ns, ns, ns, KHI_M | KHI_N);                              // Qs'Qs, symmetric
   g.e.sym = 1;
   p3_out_row(g, PP); p3_out_col(g, PP);
   if ((e = launch_p3(g, st))) return e;
-  if ((e = launch_split3(Qb, nb, 1, nb, nb, F1, st))) return e;
-  return launch_split3(Qb, 1, nb, nb, nb, F2, st);
+  if (pm && (e = launch_absmax(Qb, (long)nb * nb, F1, k.pm_part, st))) return e;         // (the split above is done with the array)
+  P3Buf F2 = F1;
+  F2.p = k.F2;
+  return launch_split3_both(Qb, nb, 1, nb, nb, F1, F2, st);                              // both forms from one read
 }
 
 static int planes_apply(const float* G, float* out, int M, int N, const KronWs& k, hipStream_t st) {
@@ -2792,13 +2884,12 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
   PlaneMeta* pm = g_planes_f16 ? k.pmeta : nullptr;
   PlaneMeta *mPP = pm ? pm + kPmPP : pm, *mF = pm ? pm + kPmF : pm, *mG = pm ? pm + kPmG : pm, *mT = pm ? pm + kPmT : pm,
             *mA = pm ? pm + kPmA : pm;
-  if (pm) {
-    if (hipMemsetAsync(mG, 0, 3 * sizeof(PlaneMeta), st) != hipSuccess) return 1;
-    if ((e = launch_absmax(G, (long)M * N, mG, st))) return e;
-  }
+  P3Buf Gin = {k.Y0, M < N ? Np : Mp, M < N ? Mp : Np, mG};                              // planes of G' (M < N) or G
+  // (the maxima of the two intermediates, slots kPmT and kPmA, start from zero: consecutive PlaneMeta, 8 floats)
+  if (pm && (e = launch_absmax(G, (long)M * N, Gin, k.pm_part, st, &mT->scale, 8))) return e;
   if (M < N) {
     const P3Buf PP = {k.PP, Mp, Mp, mPP}, F1 = {k.F1, Np, Np, mF}, F2 = {k.F2, Np, Np, mF};
-    const P3Buf Gt = {k.Y0, Np, Mp, mG}, T = {k.Y1, Mp, Np, mT}, A = {k.Y2, Mp, Np, mA};
+    const P3Buf Gt = Gin, T = {k.Y1, Mp, Np, mT}, A = {k.Y2, Mp, Np, mA};
     if ((e = launch_split3(G, 1, N, N, M, Gt, st))) return e;                            // (n, k = m) = G[m][n]
     P3Args g0 = p3_args(PP, Gt, M, N, M, 0);                                             // (Ql'Ql) G
     p3_out_row(g0, T);
@@ -2811,7 +2902,7 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
     return launch_p3_auto(g2, k.sk_scratch, k.sk_cnt, st);
   }
   const P3Buf PP = {k.PP, Np, Np, mPP}, F1 = {k.F1, Mp, Mp, mF}, F2 = {k.F2, Mp, Mp, mF};
-  const P3Buf Gp = {k.Y0, Mp, Np, mG}, Tt = {k.Y1, Np, Mp, mT}, At = {k.Y2, Np, Mp, mA};
+  const P3Buf Gp = Gin, Tt = {k.Y1, Np, Mp, mT}, At = {k.Y2, Np, Mp, mA};
   if ((e = launch_split3(G, N, 1, M, N, Gp, st))) return e;
   P3Args g0 = p3_args(Gp, PP, M, N, N, 0);                                               // G (Qr'Qr)
   p3_out_col(g0, Tt);
@@ -2831,19 +2922,25 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
 //   s2  G1 = planes(triu(A A' - Bt Bt')), max -> scal[0]     s3  G2 = planes(triu(A'A - Bt'Bt)), max -> scal[1]
 //   s4  QlOut = QlS - (step / max) G1 QlS                    s5  QrOut = QrS - (step / max) G2 QrS
 // planes of the balanced factors (row and column forms): both chains of the update read them
-static int planes_update_factors(int M, int N, const KronWs& k, hipStream_t st) {
+static int planes_update_factors(int M, int N, const KronWs& k, hipStream_t st, PlaneMeta* pm) {
   const long Mp = pad128(M), Np = pad128(N);
-  const P3Buf Lr = {k.Lr, Mp, Mp}, Lc = {k.Lc, Mp, Mp}, Rr = {k.Rr, Np, Np}, Rc = {k.Rc, Np, Np};
+  PlaneMeta *mL = pm ? pm + kPmL : pm, *mR = pm ? pm + kPmR : pm;        // (f16 x 2: the balance launch left the partial maxima)
+  const int nb = balance_grid(M, N);
+  const P3Buf Lr = {k.Lr, Mp, Mp, mL, k.pm_part + 2 * kPmPartMax, nb}, Lc = {k.Lc, Mp, Mp, mL};
+  const P3Buf Rr = {k.Rr, Np, Np, mR, k.pm_part + 3 * kPmPartMax, nb}, Rc = {k.Rc, Np, Np, mR};
   int e;
   if ((e = launch_split3_both(k.QlS, M, 1, M, M, Lr, Lc, st))) return e;
   return launch_split3_both(k.QrS, N, 1, N, N, Rr, Rc, st);
 }
 
-static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st) {
+static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st, PlaneMeta* pm) {
   const long Mp = pad128(M), Np = pad128(N);
-  const P3Buf Lr = {k.Lr, Mp, Mp}, Rr = {k.Rr, Np, Np};
-  const P3Buf dGp = {k.U0, Mp, Np}, Tt = {k.U1, Np, Mp}, Ar = {k.U2, Mp, Np}, Ac = {k.U3, Np, Mp};
+  auto slot = [&](int i) { return pm ? pm + i : pm; };
+  const P3Buf Lr = {k.Lr, Mp, Mp, slot(kPmL)}, Rr = {k.Rr, Np, Np, slot(kPmR)};
+  P3Buf dGp = {k.U0, Mp, Np, slot(kPmdG)};
+  const P3Buf Tt = {k.U1, Np, Mp, slot(kPmUT)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
   int e;
+  if (pm && (e = launch_absmax(dG, (long)M * N, dGp, k.pm_part + kPmPartMax, st))) return e;     // (the side stream's array)
   if ((e = launch_split3(dG, N, 1, M, N, dGp, st))) return e;
   P3Args s0 = p3_args(dGp, Rr, M, N, N, KLO_N);                 // T = dG QrS'  (:173); (n, k) view of QrS' = QrS
   p3_out_col(s0, Tt);
@@ -2853,11 +2950,16 @@ static int planes_update_front(const float* dG, int M, int N, const KronWs& k, h
   return launch_p3_auto(s1, k.sk_scratch, k.sk_cnt, st);
 }
 
-static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float step, float tiny, const KronWs& k, hipStream_t st) {
+static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float step, float tiny, const KronWs& k, hipStream_t st,
+                              PlaneMeta* pm) {
   const long Mp = pad128(M), Np = pad128(N);
-  const P3Buf Lc = {k.Lc, Mp, Mp}, Rc = {k.Rc, Np, Np}, G1 = {k.G1, Mp, Mp}, G2 = {k.G2, Np, Np};
-  const P3Buf Br = {k.U0, Mp, Np}, Bc = {k.U1, Np, Mp}, Ar = {k.U2, Mp, Np}, Ac = {k.U3, Np, Mp};
+  auto slot = [&](int i) { return pm ? pm + i : pm; };
+  const P3Buf Lc = {k.Lc, Mp, Mp, slot(kPmL)}, Rc = {k.Rc, Np, Np, slot(kPmR)}, G1 = {k.G1, Mp, Mp, slot(kPmG1)},
+              G2 = {k.G2, Np, Np, slot(kPmG2)};
+  P3Buf Br = {k.U0, Mp, Np, slot(kPmBt)};
+  const P3Buf Bc = {k.U1, Np, Mp, slot(kPmBt)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
   int e;
+  if (pm && (e = launch_absmax(k.Bt, (long)M * N, Br, k.pm_part, st))) return e;
   if ((e = launch_split3_both(k.Bt, N, 1, M, N, Br, Bc, st))) return e;
   P3Args s2 = p3_args(Ar, Ar, M, M, N, 0);                      // grad1 = triu(A A' - Bt Bt')  (:175)
   s2.A2 = p3_of(Br); s2.B2 = p3_of(Br); s2.e.A2 = k.Bt; s2.e.K2 = N;
@@ -2878,15 +2980,22 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
 }
 
 // entry points shared with psgd_kron_bf16.hip (kron_shared.h)
+// part_l, part_r: balance_grid(M, N) partial maxima of |QlS|, |QrS| each; zero[0 .. nzero) is cleared (all optional)
+static int kron_balance_amax(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal,
+                             float* dinv, float* part_l, float* part_r, float* zero, int nzero) {
+  const int grid = balance_grid(M, N);
+  const int inv_blocks = ((M + 31) / 32 + (N + 31) / 32 + 3) / 4;
+  hipLaunchKernelGGL(k_kron_balance_inv, dim3(inv_blocks + grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS, scal, dinv,
+                     inv_blocks, part_l, part_r, zero, nzero);
+  return (int)hipGetLastError();
+}
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal,
                  float* dinv) {
   const long tot = (long)M * M + (long)N * N;
   int grid = (int)((tot + kThreads - 1) / kThreads);
   if (grid > 1024) grid = 1024;
   if (dinv) {
-    const int inv_blocks = ((M + 31) / 32 + (N + 31) / 32 + 3) / 4;
-    hipLaunchKernelGGL(k_kron_balance_inv, dim3(inv_blocks + grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS, scal, dinv,
-                       inv_blocks);
+    return kron_balance_amax(Ql, Qr, M, N, QlS, QrS, st, scal, dinv, nullptr, nullptr, nullptr, 0);
   } else {
     hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS, scal);
   }
@@ -3041,23 +3150,27 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     return psgd_kron_dd_update_batched_f32(&Ql, &Qr, &dX, &dG, &QlOut, &QrOut, &M, &N, 1, step, tiny, ws, ws_bytes, stream);
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  // K0: balance (:166-170); zeroes k.scal; the same launch inverts the diagonal blocks the solves of K2 start from
-  KRON_LAUNCH(kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal, k.dinv));
-  float* dinv_l = k.dinv + (long)((N + 31) / 32) * 1024;
   const bool planes = kron_planes(M, N) && g_planes && g_gemm_x3;
+  PlaneMeta* pm = (planes && g_planes_f16 > 1) ? k.pmeta : nullptr;        // f16 x 2 planes of the update
+  // K0: balance (:166-170); zeroes k.scal (and the update's plane maxima); the same launch inverts the diagonal blocks the
+  // solves of K2 start from
+  KRON_LAUNCH(kron_balance_amax(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal, k.dinv, pm ? k.pm_part + 2 * kPmPartMax : nullptr,
+                                pm ? k.pm_part + 3 * kPmPartMax : nullptr, pm ? &pm[kPmL].scale : nullptr,
+                                pm ? (kPmSlots - kPmL) * 4 : 0));
+  float* dinv_l = k.dinv + (long)((N + 31) / 32) * 1024;
   GemmArgs s[6];
   plan_update(dG, QlOut, QrOut, M, N, step, tiny, k, s);
   // the products (:173) go to the side stream, the solves (:174) stay here; they meet at the gradient products.  The
   // factors' planes belong to the product chain unless the solves read them too (their K = 2048 group products, which
   // exist from 4096 on -- or from 2048 on with tuning key 5): then they are made before the fork.
   const bool solves_on_planes = planes && (M > 2048 || N > 2048);
-  if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st));
+  if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st, pm));
   KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
   KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
   hipStream_t sf = fk ? fk->side : st;
   if (planes) {
-    if (!solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, sf));
-    KRON_LAUNCH(planes_update_front(dG, M, N, k, sf));
+    if (!solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, sf, pm));
+    KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
   } else {
     KRON_LAUNCH(launch_gemm(s[0], sf));
     KRON_LAUNCH(launch_gemm(s[1], sf));
@@ -3067,16 +3180,19 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // per solve -- their 16 K steps per block are dominated by the fixed parts of a block either way -- so only the wide
   // K = 2048 group updates use the factors' column-form planes)
   if (solves_on_planes) {
-    const P3Buf Rc = {k.Rc, pad128(N), pad128(N)}, Lc = {k.Lc, pad128(M), pad128(M)};
-    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0, true));
-    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, &Lc, k.S0, true));
+    const P3Buf Rc = {k.Rc, pad128(N), pad128(N), pm ? pm + kPmR : pm}, Lc = {k.Lc, pad128(M), pad128(M), pm ? pm + kPmL : pm};
+    constexpr int half = (kPmSlots - kPmStrip) / 2;                    // meta slots of the groups of either solve
+    KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0, true, pm ? pm + kPmStrip : pm, half,
+                        k.pm_part));
+    KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, &Lc, k.S0, true,
+                        pm ? pm + kPmStrip + half : pm, half, k.pm_part));
   } else {
     KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, nullptr, nullptr, true));
     KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, nullptr, nullptr, true));
   }
   KRON_LAUNCH(fork_scope.join());
   if (planes) {
-    KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st));
+    KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st, pm));
     return PSGD_OK;
   }
   KRON_LAUNCH(launch_gemm_two(s[2], s[3], st));      // the two gradient products

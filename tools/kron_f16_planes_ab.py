@@ -43,8 +43,45 @@ def run(lib, Ql, Qr, G, label, reps=30):
           (label, a[0], b[0], a[1], b[1], (b[1] / a[1] - 1) * 100, a[2], b[2], a[3], b[3], b[4], b[5]))
 
 
+def update_ref64(Ql, Qr, dX, dG, step):
+    """psgd.py:156-179 in fp64 on the device"""
+    Ql, Qr, dX, dG = (t.double() for t in (Ql, Qr, dX, dG))
+    rho = torch.sqrt(Ql.diagonal().max() / Qr.diagonal().max())
+    Ql, Qr = Ql / rho, Qr * rho
+    A = Ql @ (dG @ Qr.T)
+    X1 = torch.linalg.solve_triangular(Qr, dX, upper=True, left=False)               # dX Qr^-1
+    Bt = torch.linalg.solve_triangular(Ql.T, X1, upper=False, left=True)             # Ql^-T (.)
+    g1, g2 = torch.triu(A @ A.T - Bt @ Bt.T), torch.triu(A.T @ A - Bt.T @ Bt)
+    tiny = torch.finfo(torch.float32).tiny
+    return Ql - (step / (g1.abs().max() + tiny)) * g1 @ Ql, Qr - (step / (g2.abs().max() + tiny)) * g2 @ Qr, Ql, Qr
+
+
+def run_update(lib, M, N, g, label, reps=10):
+    Ql, Qr = tri(M, g), tri(N, g)
+    dX = torch.randn(M, N, device="cuda", generator=g)
+    dG = dX * torch.exp(torch.rand(M, 1, device="cuda", generator=g) * 2 - 1) * torch.exp(torch.rand(1, N, device="cuda", generator=g) * 2 - 1)
+    rl, rr, bl, br = update_ref64(Ql, Qr, dX, dG, 0.01)
+    res = []
+    for f16 in (0, 2):
+        lib.psgd_kron_set_tuning(12, f16)
+        t = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01), reps)
+        a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+        a2, b2 = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+        # error of the INCREMENT (new - balanced old), relative to its norm: what the step size multiplies
+        il = ((a.double() - bl) - (rl - bl)).norm() / (rl - bl).norm()
+        ir = ((b.double() - br) - (rr - br)).norm() / (rr - br).norm()
+        res.append((t, errs(a, rl)[0], errs(b, rr)[0], il.item(), ir.item(), torch.equal(a, a2) and torch.equal(b, b2)))
+    a, b = res
+    print("%-14s update %.3f -> %.3f ms (%+.0f%%)  rel %.1e/%.1e -> %.1e/%.1e  increment %.1e/%.1e -> %.1e/%.1e  rep %s" %
+          (label, a[0], b[0], (b[0] / a[0] - 1) * 100, a[1], a[2], b[1], b[2], a[3], a[4], b[3], b[4], b[5]))
+
+
 if __name__ == "__main__":
     lib = _lib.load()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for M, N in ((4096, 4096), (2048, 4096), (4096, 1024), (2944, 2944), (1000, 1000), (1024, 1024), (520, 3000), (500, 500),
+                 (8192, 1024)):
+        run_update(lib, M, N, g, "%dx%d" % (M, N))
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     for M, N in ((4096, 4096), (2048, 4096), (4096, 1024), (1000, 1000), (1024, 1024), (520, 3000), (300, 4000), (128, 4096),
                  (64, 8192), (2048, 512), (700, 700)):
