@@ -223,7 +223,7 @@ def kron_bench(dev, psgd, iters=20):
     steps = t128m * t128n * -(-N // 32)                                                   # full K = N
     steps += sum(t128n * -(-(M - 128 * i) // 32) for i in range(t128m))                    # K from the tile row on
     steps += sum(t128n * -(-min(M, 128 * (i + 1)) // 32) for i in range(t128m))            # K up to the tile row
-    f32_issued = steps * 6 * 2 * 128 * 128 * 32
+    f32_issued = steps * 3 * 2 * 128 * 128 * 32                                           # f16 x 2 planes: 3 MFMAs per term
     pmc = None                          # matrix-core counters of the same call, collected with rocprofv3 --pmc
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "kron_mfma_pmc.json")))
@@ -260,14 +260,14 @@ def kron_bench(dev, psgd, iters=20):
                                     "mfma_pmc": pmc},
         "4096x4096_fp32": {"ms": t_f32_cold, "gflops": f_big / t_f32_cold / 1e6, "mfma_peak_gflops": 157.3e3,
                            "ms_unchanged_factors": t_f32, "gflops_unchanged_factors": f_big / t_f32 / 1e6,
-                           "issued_bf16_gflop_per_apply_unchanged_factors": f32_issued / 1e9,
-                           "frac_of_bf16_peak_issued_unchanged_factors": f32_issued / t_f32 / 1e6 / 2.5e6,
-                           "note": "fp32-accurate products on the bf16 matrix cores: operands split once into three bf16 planes "
-                                   "(x = h + m + l exactly), 6 bf16 MFMAs per product term, K loop = DMA + MFMA (k_gemm_p3); "
-                                   "`issued` counts the 128 x 128 x 32 tile steps the three gradient-side products run (triangular "
-                                   "K ranges skipped) x 6; `ms` makes the Gram (psgd.py:192) and the factor planes inside the call, "
-                                   "`ms_unchanged_factors` keeps them; the fp32 MFMA peak is quoted for reference, it does "
-                                   "not bound this kernel"},
+                           "issued_f16_gflop_per_apply_unchanged_factors": f32_issued / 1e9,
+                           "frac_of_f16_peak_issued_unchanged_factors": f32_issued / t_f32 / 1e6 / 2.5e6,
+                           "note": "fp32-accurate products on the fp16 matrix cores (same dense peak as bf16): operands split once "
+                                   "into two fp16 planes and a power-of-two scale per matrix (x 2^e = h + 2^-11 M), 3 MFMAs per "
+                                   "product term, K loop = DMA + MFMA (k_gemm_p3<1>); `issued` counts the 128 x 128 x 32 tile steps "
+                                   "the three gradient-side products run (triangular K ranges skipped) x 3; `ms` makes the Gram "
+                                   "(psgd.py:192) and the factor planes inside the call, `ms_unchanged_factors` keeps them; the "
+                                   "fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
         "lenet5_set_fp32": {"us": t_lenet_cold * 1e3, "gflops": f_lenet / t_lenet_cold / 1e6, "bound": "launch/latency",
                             "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop_cold * 1e3,
                             "us_unchanged_factors": t_lenet * 1e3,

@@ -2544,6 +2544,14 @@ __global__ __launch_bounds__(kThreads) void k_copy_strided(const float* X, long 
 }
 
 constexpr int kTrsmPlanesK = 2048;      // group width (4 strips) whose update runs on planes when the factor's planes exist
+// Which update products of the solves run on planes (the finished strips are split once instead of once per column tile).
+// Measured on the f16 x 2 planes (tools/trsm_planes_k_ab.py, profiles/r03_trsm_planes_k_ab.txt): the in-group K = 512 updates
+// too, from 64 output tiles on: 4096^2 update 3.24 -> 3.20 ms, 2560^2 1.32 -> 1.25, 3072^2 2.34 -> 2.25, 6144^2 9.05 -> 8.91
+// (on the bf16 x 3 planes of round 2 they did not pay: 557 + 7 x 9 us of strip splits against 647 us per solve).
+static int g_trsm_planes_min_k = 512;         // tuning key 13: least K of a solve's update product that runs on planes
+static int g_trsm_planes_min_tiles = 64;      // tuning key 14: ... and its least number of output tiles
+static int g_trsm_planes_min_n = 1100;        // tuning key 15: the solves use planes when M or N exceeds this (tools/trsm_planes_n_ab.py:
+                                              // 1300^2 0.629 -> 0.618 ms, 2048^2 0.915 -> 0.898, but 1024^2 0.342 -> 0.351)
 static int g_stage_mix = 3;     // tuning key 7: bit 0 = the batched small-layer update runs a product stage and a solve stage per launch;
                                 // bit 1 = a single update with M, N <= 512 takes the batched route (5 launches instead of 10-13)
 static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
@@ -2718,9 +2726,9 @@ static int trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, lo
   // 16 K steps of a K = 512 product are dominated by the fixed parts of a block, so the wide products get a longer K.
   auto update = [&](int k0, int kw, int c0, int cw) {                    // Y[:, c0:c0+cw] -= Y[:, k0:k0+kw] Q[k0:k0+kw, c0:c0+cw]
     // (f16 x 2 planes of Q: every finished group needs a zeroed meta slot for its maximum; out of slots -> the fp32 kernel)
-    if (Qc && blk && kw == kTrsmPlanesK && (long)((cw + 127) / 128) * ((nvec + 127) / 128) >= 256 &&
-        (!Qc->meta || strip_slots > 0)) {
-      P3Buf Yg = {blk, pad128(nvec), kTrsmPlanesK};
+    if (Qc && blk && kw >= g_trsm_planes_min_k && kw <= kTrsmPlanesK && kw % 128 == 0 &&
+        (long)((cw + 127) / 128) * ((nvec + 127) / 128) >= g_trsm_planes_min_tiles && (!Qc->meta || strip_slots > 0)) {
+      P3Buf Yg = {blk, pad128(nvec), kw};
       int e;
       if (Qc->meta) {
         Yg.meta = strip_meta++; --strip_slots;
@@ -3086,6 +3094,9 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 9) { g_overlap = value; return PSGD_OK; }
   if (key == 10) { g_side_prio = value; return PSGD_OK; }
   if (key == 12) { g_planes_f16 = value; return PSGD_OK; }
+  if (key == 13) { g_trsm_planes_min_k = value; return PSGD_OK; }
+  if (key == 14) { g_trsm_planes_min_tiles = value; return PSGD_OK; }
+  if (key == 15) { g_trsm_planes_min_n = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -3163,7 +3174,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // the products (:173) go to the side stream, the solves (:174) stay here; they meet at the gradient products.  The
   // factors' planes belong to the product chain unless the solves read them too (their K = 2048 group products, which
   // exist from 4096 on -- or from 2048 on with tuning key 5): then they are made before the fork.
-  const bool solves_on_planes = planes && (M > 2048 || N > 2048);
+  const bool solves_on_planes = planes && (M > g_trsm_planes_min_n || N > g_trsm_planes_min_n);
   if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st, pm));
   KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
   KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
