@@ -660,7 +660,8 @@ struct P3 {
 typedef _Float16 f16x8_k __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float plane_scale_of_bound(float b) {      // 2^e with b 2^e in [2^13, 2^14)
-  if (!(b > 0.0f) || !(b < 3.0e38f)) return 1.0f;                     // zero matrix, Inf, NaN: any scale (the values decide)
+  if (!(b > 0.0f)) return 1.0f;                                       // zero matrix, NaN: any scale (the values decide)
+  if (!(b < 1.7e38f)) return 1.1754944e-38f * 32768.0f;               // a bound at the top of the range or beyond: 2^-111
   int k;
   (void)frexpf(b, &k);                                                // b = f 2^k, f in [0.5, 1)
   return ldexpf(1.0f, min(14 - k, 126));                              // (subnormal-sized data: 2^e and 2^-e stay normal)
@@ -970,9 +971,13 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
         acc[i][j] = v;
       }
   } else if (!tri_skip) {
-    // the subtracted pair first, then one sign flip of the accumulators
+    // the subtracted pair first, then one sign flip of the accumulators.  (f16 x 2: the pairs have their own units,
+    // 2^-(eA + eB); the pair with the FINER unit goes first and its sums are carried over to the coarser unit -- a factor
+    // <= 1, so nothing overflows however far apart the two products are)
+    const bool swap = FMT == 1 && g.e.A2 && inv2 > inv1;
 #pragma unroll 1
-    for (int p = g.e.A2 ? 1 : 0; p >= 0; --p) {
+    for (int it = g.e.A2 ? 1 : 0; it >= 0; --it) {
+      const int p = swap ? 1 - it : it;
       const int K = p ? g.e.K2 : g.e.K, km = p ? g.e.kmode2 : g.e.kmode;
       int lo = 0, hi = K;
       if (km & KLO_M) lo = max(lo, m0);
@@ -982,19 +987,20 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
       lo = (lo / GK) * GK;
       hi = ((hi + GK - 1) / GK) * GK;                 // the planes are zero-padded to whole K tiles
       p3_pass<FMT>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
-      if (p) {                                         // (f16 x 2: and over to the first pair's scale, a power of two)
-        const float flip = (FMT == 1) ? -(inv2 / inv1) : -1.0f;
+      if (it) {                                        // (f16 x 2: and over to the other pair's unit, a power of two)
+        const float flip = (FMT == 1) ? -((p ? inv2 : inv1) / (p ? inv1 : inv2)) : -1.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] *= flip;
       }
     }
-    if constexpr (FMT == 1) {
+    if constexpr (FMT == 1) {                          // back to real values (the last pair's unit; A - B either way)
+      const float fin = swap ? -inv2 : inv1;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] *= inv1;
+        for (int j = 0; j < 4; ++j) acc[i][j] *= fin;
     }
   }
   if (g.e.scale_max) {                                // (step / max) A B = step / max (A B): applied to the finished sums

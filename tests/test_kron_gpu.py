@@ -742,6 +742,82 @@ def test_large_update_planes_against_in_gemm_split(psgd, M, N):
         assert torch.equal(a, torch.triu(a))
 
 
+@pytest.mark.parametrize("M,N", [(1030, 1100), (260, 3100), (2200, 1300)])
+def test_plane_formats_of_the_large_update_agree(psgd, M, N):
+    """Tuning key 12: the large update on f16 x 2 planes (2, default), with only the apply on them (1) and on bf16 x 3
+    planes (0) -- same factors to fp32 rounding, each inside the bars of test_dense_dense_update against the fp64
+    oracle.  (2200 x 1300: the solves' update products run on the factors' planes too, tuning keys 13-15.)"""
+    from psgd_tf_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5 * M + N)
+    a32 = [a.astype(np.float32) for a in (_tri_factor(rng, M) * 2.0, _tri_factor(rng, N), rng.standard_normal((M, N)))]
+    a32.append((a32[2] * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))).astype(np.float32))
+    ref = orc.update_precond_kron(*(a.astype(np.float64) for a in a32), 0.01)
+    rho = np.sqrt(np.max(np.diag(a32[0])) / np.max(np.diag(a32[1])))
+    base = (a32[0].astype(np.float64) / rho, a32[1].astype(np.float64) * rho)
+    dev = [_dev(a) for a in a32]
+    outs = []
+    try:
+        for fmt in (2, 1, 0):
+            lib.psgd_kron_set_tuning(12, fmt)
+            out = psgd.update_precond_kron(*dev, 0.01)
+            again = psgd.update_precond_kron(*dev, 0.01)
+            assert torch.equal(out[0], again[0]) and torch.equal(out[1], again[1])
+            for got, r, b in zip(out, ref, base):
+                g = got.cpu().numpy().astype(np.float64)
+                assert rel_err(g, r) < TOL and rel_err(g - b, r - b) < INCR_TOL
+                assert torch.equal(got, torch.triu(got))
+            outs.append(out)
+    finally:
+        lib.psgd_kron_set_tuning(12, 2)
+    for other in outs[1:]:
+        for a, b, bb in zip(outs[0], other, base):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+            assert rel_err(a.cpu().numpy() - bb, b.cpu().numpy() - bb) < 1e-4
+
+
+@pytest.mark.parametrize("scale", [1e-37, 1e-25, 1e-8, 1e8, 1e25])
+def test_f16_planes_follow_the_magnitude_of_the_data(psgd, scale):
+    """f16 x 2 planes carry one power-of-two scale per matrix taken from its actual maximum: data of any fp32 magnitude
+    (1e-37: the scale exponent is clamped so that 2^e stays a normal number) gives the accuracy of O(1) data.  The
+    update is invariant to a common scale of dX / 1/dG up to the step normalisation, so it is run on dG * s, dX / s."""
+    M, N = 1030, 1100
+    rng = np.random.default_rng(11)
+    Ql, Qr = _tri_factor(rng, M).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    G = (rng.standard_normal((M, N)) * scale).astype(np.float32)
+    ref = orc.precond_grad_kron(Ql.astype(np.float64), Qr.astype(np.float64), G.astype(np.float64))
+    out = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G))
+    assert rel_err(out.cpu().numpy(), ref) < TOL
+    if 1e-30 < scale < 1e30:                               # (beyond: dG dX products leave the fp32 range in the reference too)
+        s = np.float32(scale) ** np.float32(0.5)
+        dX = (rng.standard_normal((M, N)) / s).astype(np.float32)
+        dG = (dX.astype(np.float64) * s * s * np.exp(rng.uniform(-1, 1, (M, 1)))).astype(np.float32)
+        r = orc.update_precond_kron(*(a.astype(np.float64) for a in (Ql, Qr, dX, dG)), 0.01)
+        got = psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)
+        for g, rr in zip(got, r):
+            assert rel_err(g.cpu().numpy(), rr) < TOL
+
+
+def test_f16_planes_with_a_wide_range_inside_one_matrix(psgd):
+    """Elements far below a matrix' maximum: rows of G over e^+-14 and factors whose diagonals span 10^+-3 -- the residual
+    plane is stored pre-scaled (M = 2^11 m), so small elements keep their second 11 bits; norm-wise and element-wise
+    (relative to the largest element) the result stays at the accuracy of uniform data."""
+    M, N = 1100, 1030
+    rng = np.random.default_rng(12)
+    wide = lambda n: (np.triu(rng.standard_normal((n, n)) * 0.02, 1) * np.exp(np.linspace(-3.45, 3.45, n))[:, None]
+                      + np.diag(rng.permutation(np.exp(np.linspace(-3.45, 3.45, n))))).astype(np.float32)
+    Ql, Qr = wide(M), wide(N)
+    G = (rng.standard_normal((M, N)) * np.exp(np.linspace(-14, 14, M))[:, None]).astype(np.float32)
+    ref = orc.precond_grad_kron(Ql.astype(np.float64), Qr.astype(np.float64), G.astype(np.float64))
+    out = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G)).cpu().numpy().astype(np.float64)
+    assert rel_err(out, ref) < TOL
+    assert np.max(np.abs(out - ref)) < TOL * np.max(np.abs(ref))
+    single = np.zeros((M, N), np.float32)
+    single[5, 7] = 3.0
+    ref = orc.precond_grad_kron(Ql.astype(np.float64), Qr.astype(np.float64), single.astype(np.float64))
+    assert rel_err(psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(single)).cpu().numpy(), ref) < TOL
+
+
 def test_bf16_padded_apply_keeps_its_padded_factors(psgd):
     """A large bf16 apply whose shape is not a multiple of 256 runs zero-padded to one; the padded factors (and with them
     their bf16 copies in the workspace) are kept while the caller's factors are unchanged, and rebuilt when they change."""
