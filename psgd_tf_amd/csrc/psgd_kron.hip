@@ -651,12 +651,16 @@ struct P3 {
 // 1.22 -> 0.81 ms).  What fp16 lacks is range, so every matrix carries ONE power-of-two scale s = 2^e that puts a bound of
 // its max|x| at 2^14 (h never overflows), and the residual plane is stored pre-scaled (M = 2^11 m) so that it stays a
 // normal number wherever h is one -- without that, elements more than ~2^11 below the bound lose residual bits to fp16's
-// subnormal range and the loose a-priori bounds of chained products cost accuracy.  Scales: a matrix split from fp32 data
-// uses its actual max|x| (k_absmax ahead of the split); a matrix produced by a GEMM epilogue uses the bound
-// K max|A| max|B| computed from the ACTUAL maxima of its two operands (device scalars), and records its own actual maximum
-// for its consumers -- bounds never compound (compounded over the three products of an apply they cost 1e-4..5e-4).  The
-// accumulators are brought back to real values (x 2^-(eA + eB), exact) before any epilogue logic.  NaN / Inf: a maximum that
-// is not finite gives s = 1 and the values themselves carry the NaN / Inf through the products.
+// subnormal range.  Scales come from ACTUAL maxima: a matrix split from fp32 data (caller data, factors, solve results) is
+// preceded by a reduction (k_absmax, or the balance launch for the balanced factors: per-block partial maxima that the split
+// kernel reduces -- thousands of atomics on one address serialise in L2); a product that feeds the next product writes
+// fp32 and accumulates max|C| in its epilogue, and a split launch makes its planes (p3_chain).  The first version let the
+// epilogue write the planes itself with a scale from the bound K max|A| max|B| (still there: tuning key 16 = 0): bounds
+// compounded over a chain cost 1e-4 .. 5e-4, and even a single bound is loose by the conditioning of the factors -- products
+// like QlS (dG QrS') cancel by orders of magnitude -- which cost the update's increments two decimal digits on factors with
+// cond 1e4 (tools/illcond_increment_probe.py, profiles/r03_f16x2_illcond_probe.txt).  The accumulators are brought back to
+// real values (x 2^-(eA + eB), exact) before any epilogue logic.  NaN / Inf: a maximum that is not finite gives s = 1 (NaN)
+// or the smallest scale (Inf) and the values themselves carry the NaN / Inf through the products.
 typedef _Float16 f16x8_k __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float plane_scale_of_bound(float b) {      // 2^e with b 2^e in [2^13, 2^14)
@@ -705,11 +709,21 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr3_t;
 #define P3_EARLY 2      // MFMA columns (of 4) issued before the buffer-free barrier; 0 = all fragments first, then all MFMAs
 #endif
 
+// LDS of the plane kernels, ONE object (a second __shared__ object makes hipcc guard its accesses with vmcnt(0) while DMA
+// into the first is in flight).  bf16 x 3: one 48 KiB stage, the layout of GemmLdsX3.  f16 x 2: TWO 32 KiB stages -- with
+// half the MFMAs per K step a step no longer covers the latency of the next step's DMA, so tiles are requested two steps
+// ahead and awaited with a counted vmcnt (64 KiB per block, still two blocks per CU).
+template <int FMT>
+struct P3Lds {
+  u32x4_k P[FMT ? 2 : 1][2][FMT ? 2 : 3][128 * 4];    // [stage][A|B][plane][row * 4 + (chunk ^ ((row >> 2) & 3))]
+  unsigned ticket[4];                                  // (split-K: the arrival number of this block)
+};
+
 // K tiles [lo, hi) of one operand pair.  LDS image as in k_gemm_x3: [A|B][plane][row * 4 + (chunk ^ swz(row))].  The DMA
 // writes linearly (wave base + 16 B * lane), so the swizzle is applied to the per-lane SOURCE address: the lane that
 // fills slot s = row * 4 + cpos fetches chunk cpos ^ swz(row) of that row.
 template <int FMT>
-__device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0, int lo, int hi, GemmLdsX3& L,
+__device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0, int lo, int hi, P3Lds<FMT>& L,
                                         f32x4 (&acc)[4][4]) {
   constexpr int NP = FMT ? 2 : 3;
   constexpr int W = 64, NT = 4;
@@ -723,14 +737,15 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
   }
   const __bf16* baseA = A.p + (long)m0 * 32;
   const __bf16* baseB = B.p + (long)n0 * 32;
-  auto issue = [&](int k0) {
+  constexpr int NS = FMT ? 2 : 1;           // stages
+  auto issue = [&](int k0, int st) {
     const long ka = (long)(k0 >> 5) * A.ts, kb = (long)(k0 >> 5) * B.ts;
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        __builtin_amdgcn_global_load_lds((gbl_ptr3_t)(baseA + pl * A.ps + ka + offA[q]), (lds_ptr3_t)&L.P[0][pl][(2 * w + q) * 64], 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr3_t)(baseB + pl * B.ps + kb + offB[q]), (lds_ptr3_t)&L.P[1][pl][(2 * w + q) * 64], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr3_t)(baseA + pl * A.ps + ka + offA[q]), (lds_ptr3_t)&L.P[st][0][pl][(2 * w + q) * 64], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr3_t)(baseB + pl * B.ps + kb + offB[q]), (lds_ptr3_t)&L.P[st][1][pl][(2 * w + q) * 64], 16, 0, 0);
       }
   };
   if (hi <= lo) return;
@@ -741,9 +756,13 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
 #pragma unroll
       for (int j = 0; j < NT; ++j) cross[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
-  issue(lo);
-  for (int k0 = lo; k0 < hi; k0 += kX3K) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue(lo, 0);
+  if (NS == 2 && lo + kX3K < hi) issue(lo + kX3K, 1);
+  int st = 0;
+  for (int k0 = lo; k0 < hi; k0 += kX3K, st ^= (NS - 1)) {
+    // this step's tile has landed: everything but the (2 x 2 planes x 2 halves =) 8 DMA instructions of the next step's
+    if (NS == 2 && k0 + kX3K < hi) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P3_FENCE();
     __builtin_amdgcn_s_barrier();           // every wave's part of this K tile has landed
     P3_FENCE();
@@ -752,7 +771,7 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
       const int row = wn * W + j * 16 + (lane & 15);
       const int sl = row * 4 + (c ^ ((row >> 2) & 3));
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[1][pl][sl]);
+      for (int pl = 0; pl < NP; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[st][1][pl][sl]);
     };
     auto mfma6 = [&](int i, int j) {
       f32x4 v = acc[i][j];
@@ -783,7 +802,7 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
       const int row = wm * W + i * 16 + (lane & 15);
       const int sl = row * 4 + (c ^ ((row >> 2) & 3));
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[0][pl][sl]);
+      for (int pl = 0; pl < NP; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[st][0][pl][sl]);
     }
 #pragma unroll
     for (int j = 1; j < NT; ++j) read_b(j);
@@ -798,7 +817,7 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     P3_FENCE();
     __builtin_amdgcn_s_barrier();           // every wave holds its fragments: the buffer is free
     P3_FENCE();
-    if (k0 + kX3K < hi && !(X3_DBG & 1)) issue(k0 + kX3K);   // the next tile streams in under the MFMAs
+    if (k0 + NS * kX3K < hi && !(X3_DBG & 1)) issue(k0 + NS * kX3K, st);   // the next tile for this stage streams in under the MFMAs
 #pragma unroll
     for (int j = P3_EARLY; j < NT; ++j)
 #pragma unroll
@@ -917,7 +936,7 @@ __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&a
 struct P3Split { int chunk, nchunk; float* scratch; unsigned* cnt; };     // scratch, cnt: of THIS tile
 
 template <int FMT = 0>
-__device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLdsX3& L, const P3Split sp = P3Split{-1, 0, nullptr, nullptr}) {
+__device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<FMT>& L, const P3Split sp = P3Split{-1, 0, nullptr, nullptr}) {
   constexpr int TM = 128, TN = 128, GK = kX3K;
   // f16 x 2: what brings a pair's accumulators back to real values (2^-(eA + eB), exact)
   float inv1 = 1.0f, inv2 = 1.0f;
@@ -954,11 +973,10 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
 #pragma unroll
       for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * kThreads + threadIdx.x] = acc[i][j] * pm;
     __threadfence();                                   // the partial is visible device-wide before the ticket is taken
-    __shared__ unsigned ticket;
     __syncthreads();
-    if (threadIdx.x == 0) ticket = atomicAdd(sp.cnt, 1u);
+    if (threadIdx.x == 0) L.ticket[0] = atomicAdd(sp.cnt, 1u);
     __syncthreads();
-    if (ticket != (unsigned)(sp.nchunk - 1)) return;
+    if (L.ticket[0] != (unsigned)(sp.nchunk - 1)) return;
     __threadfence();                                   // acquire: the other blocks' partials
     if (threadIdx.x == 0) *sp.cnt = 0u;                // ready for the next call
 #pragma unroll
@@ -1028,6 +1046,25 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
     for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
     if (lane == 0) atomic_amax(g.e.maxout, vmax);
   }
+  if constexpr (FMT == 1) {
+    // an fp32 result that a split launch turns into f16 x 2 planes afterwards: its exact max|C| for that launch
+    if (g.ometa && !g.Crow && !g.Ccol) {
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      float vmax = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = m0 + (w >> 1) * 64 + i * 16 + (lane >> 4) * 4 + e, col = n0 + (w & 1) * 64 + j * 16 + (lane & 15);
+            vmax = amaxf(vmax, (row < g.e.M && col < g.e.N) ? fabsf(acc[i][j][e]) : 0.0f);
+          }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+      if (lane == 0) atomic_amax(&g.ometa->amax, vmax);
+    }
+  }
   if (g.e.C) gemm_epilogue<128>(g.e, acc, m0, n0);
   // a symmetric product (Gram) names the same buffer twice: the mirror image is the transposed store of the tiles above
   // the diagonal (a diagonal tile holds both halves itself)
@@ -1036,7 +1073,7 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, GemmLds
 
 template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
-  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   int by, bx;
   gemm_tile_order(g.e.kmode, by, bx);
   p3_body<FMT>(g, by, bx, L);
@@ -1047,7 +1084,7 @@ struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1, tiles1; };
 
 template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
-  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   int which, id;
   pair_block(blockIdx.x, p.tiles0, p.tiles1, which, id);
   const P3Args& g = p.g[which];
@@ -1073,7 +1110,7 @@ __device__ __forceinline__ void upper_tile(int idx, int T, int& r, int& c) {    
 
 template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
-  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   const int id = blockIdx.x, whole1 = p.n1 - p.nsplit;
   int r, c;
   if (id < p.n0) {
@@ -1093,7 +1130,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
 // embedding shapes: 1000 x 1000 outputs, K = 30000, twice): upper tiles only, every tile's K steps dealt to `nchunk`
 // blocks (P3Split).  On the in-GEMM split kernel this product ran on 64 workgroups for 1.8 ms.
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk(P3Args g, int T, int nchunk, float* scratch, unsigned* cnt) {
-  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  __shared__ __attribute__((aligned(16))) P3Lds<0> L;
   const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
   int r, c;
   upper_tile(t, T, r, c);
@@ -1105,7 +1142,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk(P3Args g, int T,
 template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk_rect(P3Args g, int ty, int tx, int nchunk, float* scratch,
                                                                      unsigned* cnt) {
-  __shared__ __attribute__((aligned(16))) GemmLdsX3 L;
+  __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
   int by, bx;
   gemm_tile_from_id(t, ty, tx, g.e.kmode, by, bx);
@@ -2670,6 +2707,36 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
   return (int)hipGetLastError();
 }
 
+// A product whose result the next product reads as planes (`row`: x = row, k = column; `col`: the transposed form; either
+// or both).  bf16 x 3: the epilogue writes the planes, the result never exists in fp32.  f16 x 2: the scale of a matrix
+// has to come from its ACTUAL maximum -- a bound K max|A| max|B| from the operands' maxima is loose by the conditioning of
+// the factors (products like QlS (dG QrS') cancel by orders of magnitude), and every factor of two of looseness is a bit
+// of fp16 range lost at the bottom: on factors with cond 1e4 the update's increments came out at 4e-3 .. 1.5e-2 instead of
+// 4e-5 (tools/illcond_increment_probe.py).  So the epilogue writes fp32 into `tmp` [M x N, row-major] and accumulates
+// max|C| (into the planes' meta, or wherever `amax` points for an epilogue that has its own: EPI_TRIU_MAX), and a split
+// launch makes the planes.  Tuning key 16 = 0 keeps the epilogue planes with bound scales (A/B runs).
+static int g_planes_exact = 1;
+static int p3_chain(P3Args& g, float* tmp, const P3Buf* row, const P3Buf* col, const float* amax, float* sk_scratch,
+                    unsigned* sk_cnt, hipStream_t st) {
+  const P3Buf& any = row ? *row : *col;
+  int e;
+  if (!g.fmt || !g_planes_exact) {
+    if (row) p3_out_row(g, *row);
+    if (col) p3_out_col(g, *col);
+    return launch_p3_auto(g, sk_scratch, sk_cnt, st);
+  }
+  g.e.C = tmp; g.e.ldc = g.e.N;
+  if (!amax) { g.ometa = any.meta; amax = &any.meta->amax; }
+  if ((e = launch_p3_auto(g, sk_scratch, sk_cnt, st))) return e;
+  P3Buf r = any, c = any;
+  if (row) r = *row;
+  if (col) c = *col;
+  r.part = c.part = amax; r.npart = c.npart = 1;
+  if (row && col) return launch_split3_both(tmp, g.e.N, 1, g.e.M, g.e.N, r, c, st);
+  if (row) return launch_split3(tmp, g.e.N, 1, g.e.M, g.e.N, r, st);
+  return launch_split3(tmp, 1, g.e.N, g.e.N, g.e.M, c, st);                         // (x, k) = C[k][x]
+}
+
 // Solve  y[i,:] Q = x[i,:]  (see k_trsm_ut).  `dinv` is scratch for the inverted 32 x 32 diagonal sub-blocks
 // (ceil(n/32) * 1024 floats).  n <= 512: one strip kernel.  Larger n: right-looking over 512-wide column blocks,
 //   Y <- X;  for each block jb:  Y[:, jb] <- Y[:, jb] Q[jb, jb]^-1  (strip kernel, in place)
@@ -2884,8 +2951,12 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
   if ((e = launch_split3(Qs, 1, ns, ns, ns, QsT, st))) return e;                         // (x, k) = Qs[k][x]
   P3Args g = p3_args(QsT, QsT, ns, ns, ns, KHI_M | KHI_N);                              // Qs'Qs, symmetric
   g.e.sym = 1;
-  p3_out_row(g, PP); p3_out_col(g, PP);
-  if ((e = launch_p3(g, st))) return e;
+  if (g.fmt && g_planes_exact) {                      // (fp32 Gram in the workspace's Gram buffer, mirrored by the epilogue)
+    if ((e = p3_chain(g, left ? k.Pl : k.Pr, &PP, nullptr, nullptr, nullptr, nullptr, st))) return e;
+  } else {
+    p3_out_row(g, PP); p3_out_col(g, PP);
+    if ((e = launch_p3(g, st))) return e;
+  }
   if (pm && (e = launch_absmax(Qb, (long)nb * nb, F1, k.pm_part, st))) return e;         // (the split above is done with the array)
   P3Buf F2 = F1;
   F2.p = k.F2;
@@ -2906,11 +2977,9 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
     const P3Buf Gt = Gin, T = {k.Y1, Mp, Np, mT}, A = {k.Y2, Mp, Np, mA};
     if ((e = launch_split3(G, 1, N, N, M, Gt, st))) return e;                            // (n, k = m) = G[m][n]
     P3Args g0 = p3_args(PP, Gt, M, N, M, 0);                                             // (Ql'Ql) G
-    p3_out_row(g0, T);
-    if ((e = launch_p3_auto(g0, k.sk_scratch, k.sk_cnt, st))) return e;
+    if ((e = p3_chain(g0, k.T, &T, nullptr, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
     P3Args g1 = p3_args(T, F1, M, N, N, KLO_N);                                          // (.) Qr'
-    p3_out_row(g1, A);
-    if ((e = launch_p3_auto(g1, k.sk_scratch, k.sk_cnt, st))) return e;
+    if ((e = p3_chain(g1, k.A, &A, nullptr, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
     P3Args g2 = p3_args(A, F2, M, N, N, KHI_N);                                          // (.) Qr
     g2.e.C = out; g2.e.ldc = N;
     return launch_p3_auto(g2, k.sk_scratch, k.sk_cnt, st);
@@ -2919,11 +2988,9 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
   const P3Buf Gp = Gin, Tt = {k.Y1, Np, Mp, mT}, At = {k.Y2, Np, Mp, mA};
   if ((e = launch_split3(G, N, 1, M, N, Gp, st))) return e;
   P3Args g0 = p3_args(Gp, PP, M, N, N, 0);                                               // G (Qr'Qr)
-  p3_out_col(g0, Tt);
-  if ((e = launch_p3_auto(g0, k.sk_scratch, k.sk_cnt, st))) return e;
+  if ((e = p3_chain(g0, k.T, nullptr, &Tt, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args g1 = p3_args(F1, Tt, M, N, M, KLO_M);                                           // Ql (.)
-  p3_out_col(g1, At);
-  if ((e = launch_p3_auto(g1, k.sk_scratch, k.sk_cnt, st))) return e;
+  if ((e = p3_chain(g1, k.A, nullptr, &At, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args g2 = p3_args(F2, At, M, N, M, KHI_M);                                           // Ql' (.)
   g2.e.C = out; g2.e.ldc = N;
   return launch_p3_auto(g2, k.sk_scratch, k.sk_cnt, st);
@@ -2957,11 +3024,9 @@ static int planes_update_front(const float* dG, int M, int N, const KronWs& k, h
   if (pm && (e = launch_absmax(dG, (long)M * N, dGp, k.pm_part + kPmPartMax, st))) return e;     // (the side stream's array)
   if ((e = launch_split3(dG, N, 1, M, N, dGp, st))) return e;
   P3Args s0 = p3_args(dGp, Rr, M, N, N, KLO_N);                 // T = dG QrS'  (:173); (n, k) view of QrS' = QrS
-  p3_out_col(s0, Tt);
-  if ((e = launch_p3_auto(s0, k.sk_scratch, k.sk_cnt, st))) return e;
+  if ((e = p3_chain(s0, k.T, nullptr, &Tt, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args s1 = p3_args(Lr, Tt, M, N, M, KLO_M);                  // A = QlS T
-  p3_out_row(s1, Ar); p3_out_col(s1, Ac);
-  return launch_p3_auto(s1, k.sk_scratch, k.sk_cnt, st);
+  return p3_chain(s1, k.A, &Ar, &Ac, nullptr, k.sk_scratch, k.sk_cnt, st);
 }
 
 static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float step, float tiny, const KronWs& k, hipStream_t st,
@@ -2978,12 +3043,24 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
   P3Args s2 = p3_args(Ar, Ar, M, M, N, 0);                      // grad1 = triu(A A' - Bt Bt')  (:175)
   s2.A2 = p3_of(Br); s2.B2 = p3_of(Br); s2.e.A2 = k.Bt; s2.e.K2 = N;
   s2.e.epi = EPI_TRIU_MAX; s2.e.maxout = k.scal + 0;
-  p3_out_row(s2, G1);
   P3Args s3 = p3_args(Ac, Ac, N, N, M, 0);                      // grad2 = triu(A'A - Bt'Bt)  (:176)
   s3.A2 = p3_of(Bc); s3.B2 = p3_of(Bc); s3.e.A2 = k.Bt; s3.e.K2 = M;
   s3.e.epi = EPI_TRIU_MAX; s3.e.maxout = k.scal + 1;
-  p3_out_row(s3, G2);
-  if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st))) return e;
+  if (pm && g_planes_exact) {
+    // f16 x 2 (see p3_chain): the gradients in fp32 (the epilogue's triu and max|.| as on the fp32 route), then their planes
+    // with the scale of that very maximum.  Tiles below the diagonal are not written and not read (K ranges of s4 / s5).
+    s2.e.C = k.g1; s2.e.ldc = M;
+    s3.e.C = k.g2; s3.e.ldc = N;
+    if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st))) return e;
+    P3Buf g1p = G1, g2p = G2;
+    g1p.part = k.scal + 0; g2p.part = k.scal + 1; g1p.npart = g2p.npart = 1;
+    if ((e = launch_split3(k.g1, M, 1, M, M, g1p, st))) return e;
+    if ((e = launch_split3(k.g2, N, 1, N, N, g2p, st))) return e;
+  } else {
+    p3_out_row(s2, G1);
+    p3_out_row(s3, G2);
+    if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st))) return e;
+  }
   P3Args s4 = p3_args(G1, Lc, M, M, M, KLO_M | KHI_N);          // QlS - (step1 grad1) QlS  (:179); (n, k) view of QlS = QlS'
   s4.e.epi = EPI_D_MINUS; s4.e.C = QlOut; s4.e.ldc = M; s4.e.D = k.QlS; s4.e.ldd = M;
   s4.e.scale_max = k.scal + 0; s4.e.step = step; s4.e.tiny = tiny;
@@ -3103,6 +3180,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 13) { g_trsm_planes_min_k = value; return PSGD_OK; }
   if (key == 14) { g_trsm_planes_min_tiles = value; return PSGD_OK; }
   if (key == 15) { g_trsm_planes_min_n = value; return PSGD_OK; }
+  if (key == 16) { g_planes_exact = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
