@@ -277,7 +277,16 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * key 9: updates with M or N above 512 (fp32 and bf16 operands): 1 (default) the products of psgd.py:173 run on a
  *        default-priority side stream (key 10: 0 lowest, 1 default, 2 highest priority; one per device and caller stream, made on first use) while the solves of :174 run on
  *        the caller's stream; the call forks and joins with events only (legal inside a stream capture), so to the caller
- *        it is still one stream-ordered operation.  0 = everything on the caller's stream.  Same kernels, same results. */
+ *        it is still one stream-ordered operation.  0 = everything on the caller's stream.  Same kernels, same results.
+ * key 12: operand-plane format of the plane products (key 4): 2 (default) two fp16 planes and one power-of-two scale per
+ *        matrix (x 2^e = h + 2^-11 M; three fp16 MFMAs per term) in the large apply and the large update; 1 = in the apply
+ *        only; 0 = three bf16 planes (x = h + m + l; six bf16 MFMAs per term) everywhere.  It changes what
+ *        psgd_kron_dd_prepare_f32 leaves in the workspace: prepare again after changing it (like key 4).
+ * key 13 / 14 / 15: the update products of the blocked triangular solves run on the factor's planes when their K is at least
+ *        key 13 (default 512), they have at least key 14 output tiles (64) and M or N exceeds key 15 (1100).
+ * key 16: f16 x 2 planes of a product that feeds the next product: 1 (default) the product writes fp32 and its max|C|, a
+ *        split launch makes the planes with that exact scale; 0 = the product's epilogue writes the planes with a scale from
+ *        the bound K max|A| max|B| (faster by a launch per intermediate; loses accuracy on ill-conditioned factors). */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

@@ -1,0 +1,22 @@
+"""One shape's fp32 Kron apply (prepared factors) in a loop, for `rocprofv3 --kernel-trace`:
+    python tools/kron_apply_trace.py M N key12 [reps]
+"""
+import sys
+import torch
+
+sys.path.insert(0, ".")
+import preconditioned_stochastic_gradient_descent as psgd  # noqa: E402
+from psgd_tf_amd import _lib  # noqa: E402
+from tools.kron_bf16_update_timing import tri  # noqa: E402
+
+if __name__ == "__main__":
+    M, N, key = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+    lib = _lib.load()
+    lib.psgd_kron_set_tuning(12, key)
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    Ql, Qr = tri(M, g), tri(N, g)
+    G = torch.randn(M, N, device="cuda", generator=g)
+    for _ in range(reps):
+        psgd.precond_grad_kron(Ql, Qr, G)
+    torch.cuda.synchronize()
