@@ -436,6 +436,8 @@ __device__ __forceinline__ void g2r_x3(const TileSrc& t, int x0, int k0, int khi
   }
 }
 
+// (plane kernels, p3_pass: 1 = no DMA after the first tiles, 8 = every lane reads slot 0 of LDS after the first step: no bank
+// conflicts, one broadcast line; 16 = no barriers)
 // X3_DBG: what-if switches of tools/micro/x3_gemm_bench.hip (wrong results; 0 in the library): 1 = no global loads in
 // the K loop, 2 = no operand split (raw bits), 4 = no LDS commit in the K loop.
 #ifndef X3_DBG
@@ -764,14 +766,15 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     if (NS == 2 && k0 + kX3K < hi) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P3_FENCE();
-    __builtin_amdgcn_s_barrier();           // every wave's part of this K tile has landed
+    if (!(X3_DBG & 16)) __builtin_amdgcn_s_barrier();           // every wave's part of this K tile has landed
     P3_FENCE();
     bf16x8_k a[NT][NP], b[NT][NP];
+    const bool skip_reads = (X3_DBG & 8) && k0 != lo;           // (what-if: fragments of the first step reused)
     auto read_b = [&](int j) {
       const int row = wn * W + j * 16 + (lane & 15);
       const int sl = row * 4 + (c ^ ((row >> 2) & 3));
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[st][1][pl][sl]);
+      for (int pl = 0; pl < NP; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8_k, L.P[st][1][pl][skip_reads ? 0 : sl]);
     };
     auto mfma6 = [&](int i, int j) {
       f32x4 v = acc[i][j];
@@ -802,7 +805,7 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
       const int row = wm * W + i * 16 + (lane & 15);
       const int sl = row * 4 + (c ^ ((row >> 2) & 3));
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[st][0][pl][sl]);
+      for (int pl = 0; pl < NP; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8_k, L.P[st][0][pl][skip_reads ? 0 : sl]);
     }
 #pragma unroll
     for (int j = 1; j < NT; ++j) read_b(j);
@@ -813,9 +816,11 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
       for (int i = 0; i < NT; ++i) mfma6(i, j);
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    // (measured and not kept: ONE barrier per step with the next tile requested right behind it into the other stage --
+    // 4096^3 0.317 -> 0.302 ms, but the triangular K ranges 0.173 -> 0.194)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     P3_FENCE();
-    __builtin_amdgcn_s_barrier();           // every wave holds its fragments: the buffer is free
+    if (!(X3_DBG & 16)) __builtin_amdgcn_s_barrier();           // every wave holds its fragments: the buffer is free
     P3_FENCE();
     if (k0 + NS * kX3K < hi && !(X3_DBG & 1)) issue(k0 + NS * kX3K, st);   // the next tile for this stage streams in under the MFMAs
 #pragma unroll

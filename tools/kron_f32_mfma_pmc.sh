@@ -2,7 +2,7 @@
 R=$PWD
 mkdir -p gpurun_out/mfma32
 cd /tmp && export TMPDIR=/tmp
-for c in "MfmaUtil" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
+for c in "MfmaUtil" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $c -d $R/gpurun_out/mfma32/$tag -- python3 $R/tools/kron_f32_probe.py 4096 > $R/gpurun_out/mfma32/$tag.log 2>&1
 done

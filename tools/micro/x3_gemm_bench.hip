@@ -66,6 +66,35 @@ int main(int argc, char** argv) {
              outs[o], ms, flop / ms * 1e-9, 6 * flop / ms * 1e-9);
     }
   }
+  {   // the same on f16 x 2 planes (k_gemm_p3<1>)
+    __bf16 *PA, *PB;
+    hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
+    PlaneMeta* pm; float* part;
+    hipMalloc(&pm, 64 * sizeof(PlaneMeta)); hipMalloc(&part, 4 * 2048 * 4);
+    hipMemset(pm, 0, 64 * sizeof(PlaneMeta));
+    P3Buf a = {PA, n, n, pm}, b = {PB, n, n, pm + 1};
+    launch_absmax(A, (long)n * n, a, part, 0);
+    launch_split3(A, n, 1, n, n, a, 0);
+    launch_absmax(B, (long)n * n, b, part, 0);
+    launch_split3(B, 1, n, n, n, b, 0);
+    const char* outs[3] = {"fp32 C", "fp32 C, KLO_N", "fp32 C, KHI_M"};
+    for (int o = 0; o < 3; ++o) {
+      P3Args g = p3_args(a, b, n, n, n, o == 1 ? KLO_N : (o == 2 ? KHI_M : 0));
+      g.e.C = C; g.e.ldc = n;
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      for (int i = 0; i < 3; ++i) launch_p3(g, 0);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 20; ++i) launch_p3(g, 0);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      ms /= 20;
+      printf("X3_DBG=%d  %d^3  f16 x 2 planes (k_gemm_p3<1>) -> %-16s %.3f ms  %.1f TFLOP/s fp32-equivalent  (%.0f issued f16)\n", X3_DBG, n,
+             outs[o], ms, flop / ms * 1e-9, 3 * flop / ms * 1e-9);
+    }
+  }
   {   // the two factor updates of the Kron update (K = [m0, n0 + 128): work = distance from the diagonal), as one grid
     __bf16 *PA, *PB;
     hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
