@@ -54,13 +54,16 @@ struct GemmArgs {
   //   KLO_M: k >= m0 (A upper-triangular, A(m,k) = 0 for k < m)      KHI_M: k < m0 + BM (A = U', zero for k > m)
   //   KLO_N: k >= n0 (B(k,n) = 0 for k < n, e.g. B = U')             KHI_N: k < n0 + BN (B upper-triangular)
   int kmode, kmode2;
+  int kblk;                             // KBLK_*: the size 2b of the diagonal blocks whose halves bound the K range (first pair only)
   long c_cs;
   const float* colv; int colsq;         // EPI_STORE: C(m,n) *= colv[n] (colsq: *= colv[n]^2)
   int sym;                              // C is symmetric (Gram X'X): tiles below the diagonal are skipped, the others stored twice
   int lite;                             // split GEMM: keep only h h' + h m' + m h' (2^-16 instead of 2^-24 relative per product)
 };
 
-enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8 };
+// KBLK_HI_M: k < start of the second half of the kblk-block that holds row m0;  KBLK_LO_N: k >= start of the second half
+// of the kblk-block that holds column n0  (the two products of one doubling level of a triangular inverse, see tri_inverse)
+enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8, KBLK_HI_M = 16, KBLK_LO_N = 32 };
 
 // ---------------------------------------------------------------------------------------------
 // fp32 GEMM on the matrix cores, one template for two square tile sizes T (64 for small problems
@@ -966,6 +969,8 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
     if (km & KLO_N) lo = max(lo, n0);
     if (km & KHI_M) hi = min(hi, m0 + TM);
     if (km & KHI_N) hi = min(hi, n0 + TN);
+    if (km & KBLK_HI_M) hi = min(hi, (m0 / g.e.kblk) * g.e.kblk + g.e.kblk / 2);
+    if (km & KBLK_LO_N) lo = max(lo, (n0 / g.e.kblk) * g.e.kblk + g.e.kblk / 2);
     lo = (lo / GK) * GK;
     hi = ((hi + GK - 1) / GK) * GK;
     const int steps = (hi - lo) / GK, per = (steps + per_pair - 1) / per_pair;
@@ -1007,6 +1012,8 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
       if (km & KLO_N) lo = max(lo, n0);
       if (km & KHI_M) hi = min(hi, m0 + TM);
       if (km & KHI_N) hi = min(hi, n0 + TN);
+      if (km & KBLK_HI_M) hi = min(hi, (m0 / g.e.kblk) * g.e.kblk + g.e.kblk / 2);
+      if (km & KBLK_LO_N) lo = max(lo, (n0 / g.e.kblk) * g.e.kblk + g.e.kblk / 2);
       lo = (lo / GK) * GK;
       hi = ((hi + GK - 1) / GK) * GK;                 // the planes are zero-padded to whole K tiles
       p3_pass<FMT>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
@@ -1084,6 +1091,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
   p3_body<FMT>(g, by, bx, L);
 }
 
+// The off-diagonal b x b blocks (rows of the first half, columns of the second half) of every 2b-block on the diagonal of
+// an n x n product: the tiles of one doubling level of a triangular inverse (tri_inverse), b a multiple of 128.
+template <int FMT>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_blk(P3Args g, int b) {
+  __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
+  const int tb = b / 128, per = tb * tb;
+  const int p = blockIdx.x / per, r = blockIdx.x % per;
+  const int by = (p * 2 * b) / 128 + r / tb, bx = (p * 2 * b + b) / 128 + r % tb;
+  if (by * 128 >= g.e.M || bx * 128 >= g.e.N) return;
+  p3_body<FMT>(g, by, bx, L);
+}
+
 // two independent products in one grid (see k_gemm_x3_pair)
 struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1, tiles1; };
 
@@ -1158,13 +1177,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk_rect(P3Args g, i
 // the padded extents) and, optionally, the planes of the transposed view (x = c, k = r) from the same read.  64 x 64
 // tiles through LDS so that the read (along the view's contiguous dimension) and both writes are coalesced.
 // FMT = 1: the f16 x 2 planes of X 2^e, e from meta->amax (k_absmax ran before); the first block completes *meta.
+// SplitOpt (the triangular inverse): tri = 1 keeps c >= r of the view, 2 keeps c <= r (zeros elsewhere); blk > 0 with
+// off = 0: only the tiles inside the blk x blk blocks on the diagonal are made, off = 1: only the (first half, second half)
+// off-diagonal quarter of every such block; neg: the planes of -X.
+struct SplitOpt { int tri, blk, off, neg; };
 template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
                                                      __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
                                                      long tts, long tps, PlaneMeta* meta, const float* __restrict__ part,
-                                                     int npart) {
+                                                     int npart, SplitOpt opt) {
   __shared__ float S[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (opt.blk) {
+    if (r0 / opt.blk != c0 / opt.blk) return;
+    if (opt.off && !((r0 % opt.blk) < opt.blk / 2 && (c0 % opt.blk) >= opt.blk / 2)) return;
+  }
   constexpr int NPL = FMT ? 2 : 3;
   float sc = 1.0f;
   if constexpr (FMT == 1) {
@@ -1178,7 +1205,10 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
     amax = amaxf(amaxf(S[0][0], S[0][1]), amaxf(S[0][2], S[0][3]));
     __syncthreads();
     sc = plane_scale_of_bound(amax);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { meta->scale = sc; meta->inv = 1.0f / sc; meta->amax = amax; meta->bound = amax; }
+    // (the first block that exists under a block filter: tile (0, 0), or the first off-diagonal quarter's first tile)
+    const bool first = opt.off ? (r0 == 0 && c0 == opt.blk / 2) : (r0 == 0 && c0 == 0);
+    if (first && tid == 0) { meta->scale = sc; meta->inv = 1.0f / sc; meta->amax = amax; meta->bound = amax; }
+    if (opt.neg) sc = -sc;
   }
   auto split_pair = [&](float x0, float x1, unsigned (&q)[3]) {
     if constexpr (FMT == 1) {
@@ -1198,7 +1228,8 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = (tid >> 6) + 4 * i, c = tid & 63;
-      S[r][c] = (r0 + r < R && c0 + c < C) ? x[i] : 0.0f;
+      const bool keep = opt.tri == 0 || (opt.tri == 1 ? c0 + c >= r0 + r : c0 + c <= r0 + r);
+      S[r][c] = (r0 + r < R && c0 + c < C && keep) ? x[i] : 0.0f;
     }
   } else {
 #pragma unroll
@@ -1207,7 +1238,8 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int c = (tid >> 6) + 4 * i, r = tid & 63;
-      S[r][c] = (r0 + r < R && c0 + c < C) ? x[i] : 0.0f;
+      const bool keep = opt.tri == 0 || (opt.tri == 1 ? c0 + c >= r0 + r : c0 + c <= r0 + r);
+      S[r][c] = (r0 + r < R && c0 + c < C && keep) ? x[i] : 0.0f;
     }
   }
   __syncthreads();
@@ -1235,6 +1267,101 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
         *reinterpret_cast<uint2*>(Pt + pl * tps + p3_index(tts, c0 + c, r0 + r)) = make_uint2(q0[pl], q1[pl]);
     }
   }
+}
+
+// The inverse of every 128 x 128 diagonal block of an upper-triangular Q [n x n] from its inverted 32 x 32 diagonal blocks
+// (`dinv`: k_tri_inv32 / the balance launch): levels 32 and 64 of the doubling  [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1]
+// inside one workgroup, in LDS with plain fp32 fma chains (the matrix-core levels start at 128, tri_inverse).  Rows and
+// columns past n count as identity.  Writes the block of Inv [n x n] (zeros below the diagonal) and max|.| into *amax.
+template <int N> struct IntK { static constexpr int value = N; };
+__global__ __launch_bounds__(kThreads) void k_tri_inv128(const float* __restrict__ Q, int n, const float* __restrict__ dinv,
+                                                         float* __restrict__ Inv, float* amax) {
+  extern __shared__ __attribute__((aligned(16))) float inv128_sm[];
+  constexpr int PT = 129;
+  float (*Tb)[PT] = reinterpret_cast<float (*)[PT]>(inv128_sm);
+  float (*Ib)[PT] = reinterpret_cast<float (*)[PT]>(inv128_sm + 128 * PT);
+  const int j0 = 128 * blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < 128 * 128; e += kThreads) {
+    const int r = e >> 7, c = e & 127;
+    float v = (r == c) ? 1.0f : 0.0f;
+    if (j0 + r < n && j0 + c < n && c >= r) v = Q[(long)(j0 + r) * n + j0 + c];
+    Tb[r][c] = v;
+    Ib[r][c] = 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 4 * 1024; e += kThreads) {                  // the four inverted 32-blocks
+    const int t = e >> 10, r = (e >> 5) & 31, c = e & 31;
+    float v = (r == c) ? 1.0f : 0.0f;
+    if (j0 + 32 * t < n) v = dinv[(long)(j0 / 32 + t) * 1024 + r * 32 + c];
+    Ib[32 * t + r][32 * t + c] = v;
+  }
+  __syncthreads();
+  // merge the pair of inverted b-blocks at a0: W = B C^-1 (kept below the diagonal meanwhile), X12 = -A^-1 W
+  auto merge = [&](int a0, int b, int m0, int n0, auto TMc, auto TNc) {
+    constexpr int TM = decltype(TMc)::value, TN = decltype(TNc)::value;
+    float acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) acc[i][jn] = 0.0f;
+    for (int k = 0; k < b; ++k) {
+      float a[TM], c[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Tb[a0 + m0 + i][a0 + b + k];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) c[jn] = Ib[a0 + b + k][a0 + b + n0 + jn];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = fmaf(a[i], c[jn], acc[i][jn]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) Ib[a0 + b + m0 + i][a0 + n0 + jn] = acc[i][jn];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) acc[i][jn] = 0.0f;
+    for (int k = 0; k < b; ++k) {
+      float a[TM], c[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ib[a0 + m0 + i][a0 + k];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) c[jn] = Ib[a0 + b + k][a0 + n0 + jn];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = fmaf(a[i], c[jn], acc[i][jn]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) Ib[a0 + m0 + i][a0 + b + n0 + jn] = -acc[i][jn];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) Ib[a0 + b + m0 + i][a0 + n0 + jn] = 0.0f;
+    __syncthreads();
+  };
+  {                                                                  // level 32: pairs (0,1) and (2,3); 2 x 4 outputs per thread
+    const int pr = tid >> 7, u = tid & 127;
+    merge(64 * pr, 32, (u >> 3) * 2, (u & 7) * 4, IntK<2>{}, IntK<4>{});
+  }
+  merge(0, 64, (tid >> 4) * 4, (tid & 15) * 4, IntK<4>{}, IntK<4>{});             // level 64: 4 x 4 outputs per thread
+  float m = 0.0f;
+  for (int e = tid; e < 128 * 128; e += kThreads) {
+    const int r = e >> 7, c = e & 127;
+    if (j0 + r < n && j0 + c < n) {
+      Inv[(long)(j0 + r) * n + j0 + c] = Ib[r][c];
+      m = amaxf(m, fabsf(Ib[r][c]));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_down(m, off, 64));
+  if ((tid & 63) == 0) atomic_amax(amax, m);
 }
 
 // max |X(o, i)|, X(o, i) = X[o * os + i], o < O, i < L (NaN propagates): block b leaves ITS maximum in part[b] and the
@@ -2358,6 +2485,10 @@ struct KronWs {
   __bf16* S0;                                                // planes of one [max(M, N) x 2048] group of the solves
   PlaneMeta* pmeta;                                          // f16 x 2 planes: scales and maxima (kPm* slots)
   float* pm_part;                                            // ... partial maxima: 4 arrays of kPmPartMax (main stream, side stream, QlS, QrS)
+  // the solves through explicit inverses (kron_inv_route): column-form planes of the two inverses, planes and fp32 of the
+  // levels' intermediate A^-1 B, planes of dX and of X1'
+  __bf16 *IcL, *IcR, *TpL, *TpR, *DXp, *X1p;
+  float *TfL, *TfR;
   int64_t total;
 };
 
@@ -2391,6 +2522,12 @@ static inline bool kron_planes(int M, int N) {          // the update, and the w
   return kron_planes_apply(M, N) || ((M > N ? M : N) >= 384 && kron_t128(M, N) >= 9);
 }
 static inline int pad128(int x) { return (x + 127) & ~127; }
+// The two triangular solves of the large fp32 update through explicit inverses (tri_inverse): both factors at least 2048 and one
+// larger -- below, a solve is a few strips and the inversion's chain of launches costs more than it saves (tools/trsm_inv_ab.py:
+// 4096^2 3.35 -> 2.94 ms, 2944^2 1.89 -> 1.70, 2048 x 4096 1.83 -> 1.70, 6144^2 9.35 -> 8.33, but 2048^2 0.87 -> 0.91, 1024^2
+// 0.34 -> 0.51, 8192 x 1024 3.87 -> 4.24).  A pure function of the shape (workspace).
+constexpr int kInvMinN = 2048;
+static inline bool kron_inv_route(int M, int N) { return M >= kInvMinN && N >= kInvMinN && (M > kInvMinN || N > kInvMinN); }
 
 static KronWs kron_layout(char* base, int M, int N) {
   KronWs k;
@@ -2407,6 +2544,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
   k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
   k.sk_scratch = nullptr; k.sk_cnt = nullptr; k.pmeta = nullptr; k.pm_part = nullptr;
+  k.IcL = k.IcR = k.TpL = k.TpR = k.DXp = k.X1p = nullptr; k.TfL = k.TfR = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -2423,6 +2561,11 @@ static KronWs kron_layout(char* base, int M, int N) {
     k.S0 = planes(big * 2048);
     k.pmeta = reinterpret_cast<PlaneMeta*>(take(1024));      // kPmSlots x 16 B
     k.pm_part = take(4 * 2048 * 4);
+    if (kron_inv_route(M, N)) {
+      k.IcL = planes(Mp * Mp); k.TpL = planes(Mp * Mp); k.TfL = take(mm);
+      k.IcR = planes(Np * Np); k.TpR = planes(Np * Np); k.TfR = take(nn);
+      k.DXp = planes(Mp * Np); k.X1p = planes(Mp * Np);
+    }
     if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
       k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
       k.sk_cnt = reinterpret_cast<unsigned*>(take(kSkMaxTiles * 4));
@@ -2621,7 +2764,9 @@ static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld, b.m
 // slots of KronWs::pmeta
 enum { kPmPP = 0, kPmF = 1, kPmQs = 2, kPmG = 4, kPmT = 5, kPmA = 6,                       // the apply (0, 1: prepared state)
        kPmL = 8, kPmR = 9, kPmdG = 10, kPmUT = 11, kPmUA = 12, kPmBt = 13, kPmG1 = 14, kPmG2 = 15,   // the update ...
-       kPmStrip = 16, kPmSlots = 64 };                                                      // ... and its solves' groups
+       kPmStrip = 16, kPmStripEnd = 48,                                                     // ... its solves' groups (strips)
+       kPmInvR = 48, kPmInvL = 49, kPmdX = 50, kPmX1 = 51, kPmTR = 52, kPmTL = 58,          // ... or the inverse route (6 levels each)
+       kPmSlots = 64 };
 
 // f16 x 2: the partial maxima of |X| (n consecutive floats) for the split of `buf` behind, into `part`; zero: see k_absmax
 static int launch_absmax(const float* X, long n, P3Buf& buf, float* part, hipStream_t st, float* zero = nullptr, int nzero = 0) {
@@ -2641,25 +2786,27 @@ static int launch_absmax_view(const float* X, long rs, long cs, long R, long C, 
   buf.part = part; buf.npart = (int)blocks;
   return (int)hipGetLastError();
 }
-static int launch_split3(const float* X, long rs, long cs, int R, int C, const P3Buf& out, hipStream_t st) {
+static int launch_split3(const float* X, long rs, long cs, int R, int C, const P3Buf& out, hipStream_t st,
+                         SplitOpt opt = SplitOpt{0, 0, 0, 0}) {
   const dim3 grid((unsigned)(out.ld / 64), (unsigned)(out.rows / 64));
   if (out.meta)
     hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       (__bf16*)nullptr, 0L, 0L, out.meta, out.part, out.npart);
+                       (__bf16*)nullptr, 0L, 0L, out.meta, out.part, out.npart, opt);
   else
     hipLaunchKernelGGL(k_split3<0>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       (__bf16*)nullptr, 0L, 0L, (PlaneMeta*)nullptr, (const float*)nullptr, 0);
+                       (__bf16*)nullptr, 0L, 0L, (PlaneMeta*)nullptr, (const float*)nullptr, 0, opt);
   return (int)hipGetLastError();
 }
 // planes of the view (out) and of its transpose (outT: rows/ld swapped) from one read
-static int launch_split3_both(const float* X, long rs, long cs, int R, int C, const P3Buf& out, const P3Buf& outT, hipStream_t st) {
+static int launch_split3_both(const float* X, long rs, long cs, int R, int C, const P3Buf& out, const P3Buf& outT, hipStream_t st,
+                              SplitOpt opt = SplitOpt{0, 0, 0, 0}) {
   const dim3 grid((unsigned)(out.ld / 64), (unsigned)(out.rows / 64));
   if (out.meta)
     hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       outT.p, outT.rows * 32, outT.rows * outT.ld, out.meta, out.part, out.npart);
+                       outT.p, outT.rows * 32, outT.rows * outT.ld, out.meta, out.part, out.npart, opt);
   else
     hipLaunchKernelGGL(k_split3<0>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       outT.p, outT.rows * 32, outT.rows * outT.ld, (PlaneMeta*)nullptr, (const float*)nullptr, 0);
+                       outT.p, outT.rows * 32, outT.rows * outT.ld, (PlaneMeta*)nullptr, (const float*)nullptr, 0, opt);
   return (int)hipGetLastError();
 }
 
@@ -3035,7 +3182,7 @@ static int planes_update_front(const float* dG, int M, int N, const KronWs& k, h
 }
 
 static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float step, float tiny, const KronWs& k, hipStream_t st,
-                              PlaneMeta* pm) {
+                              PlaneMeta* pm, bool bt_planes_ready = false) {
   const long Mp = pad128(M), Np = pad128(N);
   auto slot = [&](int i) { return pm ? pm + i : pm; };
   const P3Buf Lc = {k.Lc, Mp, Mp, slot(kPmL)}, Rc = {k.Rc, Np, Np, slot(kPmR)}, G1 = {k.G1, Mp, Mp, slot(kPmG1)},
@@ -3043,8 +3190,10 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
   P3Buf Br = {k.U0, Mp, Np, slot(kPmBt)};
   const P3Buf Bc = {k.U1, Np, Mp, slot(kPmBt)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
   int e;
-  if (pm && (e = launch_absmax(k.Bt, (long)M * N, Br, k.pm_part, st))) return e;
-  if ((e = launch_split3_both(k.Bt, N, 1, M, N, Br, Bc, st))) return e;
+  if (!bt_planes_ready) {                               // (the inverse route's last product has made them)
+    if (pm && (e = launch_absmax(k.Bt, (long)M * N, Br, k.pm_part, st))) return e;
+    if ((e = launch_split3_both(k.Bt, N, 1, M, N, Br, Bc, st))) return e;
+  }
   P3Args s2 = p3_args(Ar, Ar, M, M, N, 0);                      // grad1 = triu(A A' - Bt Bt')  (:175)
   s2.A2 = p3_of(Br); s2.B2 = p3_of(Br); s2.e.A2 = k.Bt; s2.e.K2 = N;
   s2.e.epi = EPI_TRIU_MAX; s2.e.maxout = k.scal + 0;
@@ -3073,6 +3222,60 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
   s5.e.epi = EPI_D_MINUS; s5.e.C = QrOut; s5.e.ldc = N; s5.e.D = k.QrS; s5.e.ldd = N;
   s5.e.scale_max = k.scal + 1; s5.e.step = step; s5.e.tiny = tiny;
   return launch_p3_two(s4, s5, st);
+}
+
+// ---- the triangular solves of psgd.py:174 through explicit inverses (large fp32 update on f16 x 2 planes) ---------------
+// Round 3 costed this route on the bf16 x 3 planes at break-even (profiles/r03_trsm_inverse_route.txt): a solve as one
+// product was 0.33 ms and the inversion another n^3 / 3 per factor.  On the f16 x 2 planes a triangular 4096^3 product is
+// 0.17 ms, and the substitution strips (16 launches of 41 us, 14 update products between them) are what is left of the
+// update's critical path.  Inv = Q^-1 by recursive doubling, [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1]: the 128-blocks
+// in one launch (k_tri_inv128, from the 32-blocks the balance launch inverted), then per level b = 128, 256, ... four
+// launches for ALL pairs of b-blocks: planes of the b-blocks inverted so far (both forms, one scale from the running
+// max|Inv|), T = A^-1 B (fp32 + max), planes of -T, W = (-T) C^-1 straight into Inv (fp32 + running max).  K ranges:
+// A^-1 upper (k >= m0) and inside A's half (KBLK_HI_M); C^-1 upper (k <= n0 + 127) and inside C's half (KBLK_LO_N).  At
+// the end the whole inverse is split once into column-form planes, the form both solves read:
+//   X1 = dX Ri   (B operand (n, k) = Ri[k][n], k <= n)         Bt = Li' X1   (A operand (m, k) = Li[k][m], k <= m)
+// Accuracy: tools/group_inverse_error_study.py -- the solve through fp32 inverses stays within 1.3-1.7x of fp32
+// substitution up to cond 1e9; the parity tests on ill-conditioned factors hold their bars on this route.
+struct InvSide {
+  const float* Q; int n; const float* dinv;      // balanced factor, its inverted 32-blocks
+  float* Inv; float* Tf;                         // fp32 [n x n]: the inverse; the levels' A^-1 B
+  P3Buf Qc, Ir, Ic, Tp;                          // column-form planes of Q; planes of the inverse (row / column form); of -T
+  PlaneMeta* mT;                                 // 6 slots: one per level
+};
+static int g_trsm_inv = 1;      // tuning key 11: 0 = the solves of every size stay on the substitution strips
+
+static int tri_inverse(InvSide f, hipStream_t st) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)2 * 128 * 129 * sizeof(float);
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tri_inv128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) return 1;
+    attr_set = true;
+  }
+  const int n = f.n;
+  int e;
+  hipLaunchKernelGGL(k_tri_inv128, dim3((n + 127) / 128), dim3(kThreads), lds, st, f.Q, n, f.dinv, f.Inv, &f.Ir.meta->amax);
+  if (hipGetLastError() != hipSuccess) return 1;
+  f.Ir.part = f.Ic.part = &f.Ir.meta->amax;
+  f.Ir.npart = f.Ic.npart = 1;
+  int level = 0;
+  for (int b = 128; b < n; b *= 2, ++level) {
+    if ((e = launch_split3_both(f.Inv, n, 1, n, n, f.Ir, f.Ic, st, SplitOpt{1, b, 0, 0}))) return e;   // the inverted b-blocks
+    const int tb = b / 128, pairs = (n + 2 * b - 1) / (2 * b);
+    P3Args g1 = p3_args(f.Ir, f.Qc, n, n, n, KLO_M | KBLK_HI_M);                   // T = A^-1 B
+    g1.e.kblk = 2 * b; g1.e.C = f.Tf; g1.e.ldc = n; g1.ometa = f.mT + level;
+    hipLaunchKernelGGL(k_gemm_p3_blk<1>, dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
+    if (hipGetLastError() != hipSuccess) return 1;
+    P3Buf tp = f.Tp;
+    tp.meta = f.mT + level; tp.part = &tp.meta->amax; tp.npart = 1;
+    if ((e = launch_split3(f.Tf, n, 1, n, n, tp, st, SplitOpt{0, 2 * b, 1, 1}))) return e;            // planes of -T
+    P3Args g2 = p3_args(tp, f.Ic, n, n, n, KHI_N | KBLK_LO_N);                     // W = (-T) C^-1 into Inv
+    g2.e.kblk = 2 * b; g2.e.C = f.Inv; g2.e.ldc = n; g2.ometa = f.Ir.meta;
+    hipLaunchKernelGGL(k_gemm_p3_blk<1>, dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
+    if (hipGetLastError() != hipSuccess) return 1;
+  }
+  return launch_split3(f.Inv, 1, n, n, n, f.Ic, st, SplitOpt{2, 0, 0, 0});          // (x, k) = Inv[k][x], k <= x
 }
 
 // entry points shared with psgd_kron_bf16.hip (kron_shared.h)
@@ -3181,6 +3384,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 8) { g_splitk = value; return PSGD_OK; }
   if (key == 9) { g_overlap = value; return PSGD_OK; }
   if (key == 10) { g_side_prio = value; return PSGD_OK; }
+  if (key == 11) { g_trsm_inv = value; return PSGD_OK; }
   if (key == 12) { g_planes_f16 = value; return PSGD_OK; }
   if (key == 13) { g_trsm_planes_min_k = value; return PSGD_OK; }
   if (key == 14) { g_trsm_planes_min_tiles = value; return PSGD_OK; }
@@ -3263,11 +3467,38 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // the products (:173) go to the side stream, the solves (:174) stay here; they meet at the gradient products.  The
   // factors' planes belong to the product chain unless the solves read them too (their K = 2048 group products, which
   // exist from 4096 on -- or from 2048 on with tuning key 5): then they are made before the fork.
-  const bool solves_on_planes = planes && (M > g_trsm_planes_min_n || N > g_trsm_planes_min_n);
+  const bool inv_route = pm && g_trsm_inv && kron_inv_route(M, N) && M <= 8192 && N <= 8192;    // (6 levels of meta slots)
+  const bool solves_on_planes = planes && (inv_route || M > g_trsm_planes_min_n || N > g_trsm_planes_min_n);
   if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st, pm));
   KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
   KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
   hipStream_t sf = fk ? fk->side : st;
+  if (inv_route) {
+    // K2 through explicit inverses (tri_inverse): Qr's on this stream, then X1 = dX Ri; Ql's on the side stream ahead of the
+    // products of :173; after the join Bt = Li' X1, whose epilogue leaves max|Bt| for the planes of the gradient products.
+    const long Mp = pad128(M), Np = pad128(N);
+    InvSide L = {k.QlS, M, dinv_l, k.g1, k.TfL, P3Buf{k.Lc, Mp, Mp, pm + kPmL}, P3Buf{k.G1, Mp, Mp, pm + kPmInvL},
+                 P3Buf{k.IcL, Mp, Mp, pm + kPmInvL}, P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
+    InvSide R = {k.QrS, N, k.dinv, k.g2, k.TfR, P3Buf{k.Rc, Np, Np, pm + kPmR}, P3Buf{k.G2, Np, Np, pm + kPmInvR},
+                 P3Buf{k.IcR, Np, Np, pm + kPmInvR}, P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
+    // Order: the full-chip products of :173 run beside the launch-bound lower levels of Qr's inversion, Ql's inversion beside the
+    // product X1 = dX Ri (with the two inversions first and the products colliding afterwards the join came 0.3 ms later).
+    KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
+    KRON_LAUNCH(tri_inverse(L, sf));
+    P3Buf dXp = {k.DXp, Mp, Np, pm + kPmdX};
+    const P3Buf X1c = {k.X1p, Np, Mp, pm + kPmX1};
+    KRON_LAUNCH(launch_absmax(dX, (long)M * N, dXp, k.pm_part, st));
+    KRON_LAUNCH(launch_split3(dX, N, 1, M, N, dXp, st));
+    KRON_LAUNCH(tri_inverse(R, st));
+    P3Args x1 = p3_args(dXp, R.Ic, M, N, N, KHI_N);                                   // X1 = dX Ri
+    KRON_LAUNCH(p3_chain(x1, k.X1, nullptr, &X1c, nullptr, k.sk_scratch, k.sk_cnt, st));
+    KRON_LAUNCH(fork_scope.join());
+    const P3Buf Br = {k.U0, Mp, Np, pm + kPmBt}, Bc = {k.U1, Np, Mp, pm + kPmBt};
+    P3Args bt = p3_args(L.Ic, X1c, M, N, M, KHI_M);                                   // Bt = Li' X1
+    KRON_LAUNCH(p3_chain(bt, k.Bt, &Br, &Bc, nullptr, k.sk_scratch, k.sk_cnt, st));
+    KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st, pm, true));
+    return PSGD_OK;
+  }
   if (planes) {
     if (!solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, sf, pm));
     KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
@@ -3281,7 +3512,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   // K = 2048 group updates use the factors' column-form planes)
   if (solves_on_planes) {
     const P3Buf Rc = {k.Rc, pad128(N), pad128(N), pm ? pm + kPmR : pm}, Lc = {k.Lc, pad128(M), pad128(M), pm ? pm + kPmL : pm};
-    constexpr int half = (kPmSlots - kPmStrip) / 2;                    // meta slots of the groups of either solve
+    constexpr int half = (kPmStripEnd - kPmStrip) / 2;                 // meta slots of the groups of either solve
     KRON_LAUNCH(trsm_ut(k.QrS, N, dX, k.X1, M, (long)N, 1L, k.dinv, st, 0, 0, 0, &Rc, k.S0, true, pm ? pm + kPmStrip : pm, half,
                         k.pm_part));
     KRON_LAUNCH(trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, dinv_l, st, 0, 0, 0, &Lc, k.S0, true,

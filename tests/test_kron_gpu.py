@@ -818,6 +818,40 @@ def test_f16_planes_with_a_wide_range_inside_one_matrix(psgd):
     assert rel_err(psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(single)).cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("M,N", [(2304, 2048), (2100, 3000)])
+def test_solves_through_inverses_agree_with_substitution(psgd, M, N):
+    """Both factors >= 2048: the solves of psgd.py:174 run as products with explicit inverses (tuning key 11, default) built by
+    recursive doubling on the f16 x 2 planes; key 11 = 0 keeps the substitution strips.  Same factors to fp32 rounding, each
+    route inside the bars of test_dense_dense_update against the fp64 oracle (2100 x 3000: sizes that are not multiples of the
+    128-tile or of a doubling level)."""
+    from psgd_tf_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3 * M + N)
+    a32 = [a.astype(np.float32) for a in (_tri_factor(rng, M, 0.02) * 2.0, _tri_factor(rng, N, 0.02), rng.standard_normal((M, N)))]
+    a32.append((a32[2] * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))).astype(np.float32))
+    ref = orc.update_precond_kron(*(a.astype(np.float64) for a in a32), 0.01)
+    rho = np.sqrt(np.max(np.diag(a32[0])) / np.max(np.diag(a32[1])))
+    base = (a32[0].astype(np.float64) / rho, a32[1].astype(np.float64) * rho)
+    dev = [_dev(a) for a in a32]
+    outs = []
+    try:
+        for inv in (1, 0):
+            lib.psgd_kron_set_tuning(11, inv)
+            out = psgd.update_precond_kron(*dev, 0.01)
+            again = psgd.update_precond_kron(*dev, 0.01)
+            assert torch.equal(out[0], again[0]) and torch.equal(out[1], again[1])
+            for got, r, b in zip(out, ref, base):
+                g = got.cpu().numpy().astype(np.float64)
+                assert rel_err(g, r) < TOL and rel_err(g - b, r - b) < INCR_TOL
+                assert torch.equal(got, torch.triu(got))
+            outs.append(out)
+    finally:
+        lib.psgd_kron_set_tuning(11, 1)
+    for a, b, bb in zip(outs[0], outs[1], base):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+        assert rel_err(a.cpu().numpy() - bb, b.cpu().numpy() - bb) < 1e-3
+
+
 def test_bf16_padded_apply_keeps_its_padded_factors(psgd):
     """A large bf16 apply whose shape is not a multiple of 256 runs zero-padded to one; the padded factors (and with them
     their bf16 copies in the workspace) are kept while the caller's factors are unchanged, and rebuilt when they change."""
@@ -1000,7 +1034,7 @@ def test_update_over_condition_numbers(psgd, cond_q):
         assert rel_err(out[i] - q0, ref[i] - q0) < bar, (i, cond_q, bar)
 
 
-@pytest.mark.parametrize("M,N", [(300, 200), (1100, 530), (2048, 1536)])
+@pytest.mark.parametrize("M,N", [(300, 200), (1100, 530), (2048, 1536), (2176, 2048)])
 def test_update_with_ill_conditioned_factors(psgd, M, N):
     """Factors with cond(Q) ~ 1e4 (diagonals spread over four decades, dense upper triangles): the two triangular solves of
     psgd.py:174 carry the conditioning.  Updated factors within 1e-5 of the fp64 oracle, increments within 2e-3 -- the

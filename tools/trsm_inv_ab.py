@@ -1,47 +1,39 @@
-"""A/B of the solves of psgd.py:174: explicit inverses of the 2048-column diagonal groups (tuning key 11 = 1) against the
-512-column substitution strips (0), fp32 and bf16-operand updates, interleaved rounds in one process.
-   python tools/trsm_inv_ab.py [sizes ...]"""
-import os
+"""The solves of the large fp32 Kron update: substitution strips (tuning key 11 = 0) against explicit inverses on f16 x 2 planes
+(key 11 = 1): time, error of the new factors and of their increments against an fp64 run.
+    python tools/trsm_inv_ab.py
+"""
 import sys
-
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import preconditioned_stochastic_gradient_descent as psgd
-from psgd_tf_amd import _lib
-from tools.kron_timing import state
+sys.path.insert(0, ".")
+import preconditioned_stochastic_gradient_descent as psgd  # noqa: E402
+from psgd_tf_amd import _lib  # noqa: E402
+from tools.kron_bf16_update_timing import tri, timeit  # noqa: E402
+from tools.kron_f16_planes_ab import update_ref64, errs  # noqa: E402
 
-lib = _lib.load()
-dev = torch.device("cuda:0")
-sizes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(1024, 1024), (1536, 1536), (2048, 2048), (3072, 3072),
-                                                                        (4096, 4096), (1100, 530), (4096, 1024), (1024, 4096)]
-
-
-def t_of(fn, n):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
-
-
-for M, N in sizes:
-    Ql, Qr, dX, dG, G = state(M, N, dev)
-    dXb, dGb = dX.bfloat16(), dG.bfloat16()
-    n = 40 if max(M, N) <= 2048 else 10
-    res = {(i, b): [] for i in (1, 0) for b in (0, 1)}
-    for rnd in range(3):
-        for inv in (1, 0):
-            lib.psgd_kron_set_tuning(11, inv)
-            res[(inv, 0)].append(t_of(lambda: psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01), n))
-            res[(inv, 1)].append(t_of(lambda: psgd.update_precond_kron(Ql, Qr, dXb, dGb, 0.01), n))
+if __name__ == "__main__":
+    lib = _lib.load()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for M, N in ((4096, 4096), (2048, 2048), (1024, 1024), (1300, 1100), (3000, 2048), (2048, 4096), (8192, 1024), (2944, 2944),
+                 (6144, 6144)):
+        Ql, Qr = tri(M, g), tri(N, g)
+        dX = torch.randn(M, N, device="cuda", generator=g)
+        dG = dX * torch.exp(torch.rand(M, 1, device="cuda", generator=g) * 2 - 1) * torch.exp(torch.rand(1, N, device="cuda", generator=g) * 2 - 1)
+        rl, rr, bl, br = update_ref64(Ql, Qr, dX, dG, 0.01)
+        res = []
+        for rnd in range(2):
+            for i, key in enumerate((0, 1)):
+                lib.psgd_kron_set_tuning(11, key)
+                t = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01), 8)
+                if rnd == 0:
+                    a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+                    a2, b2 = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+                    il = ((a.double() - bl) - (rl - bl)).norm() / (rl - bl).norm()
+                    ir = ((b.double() - br) - (rr - br)).norm() / (rr - br).norm()
+                    res.append([t, errs(a, rl)[0], errs(b, rr)[0], il.item(), ir.item(), torch.equal(a, a2) and torch.equal(b, b2)])
+                else:
+                    res[i][0] = min(res[i][0], t)
+        a, b = res
+        print("%-10s update %.3f -> %.3f ms (%+.0f%%)  rel %.1e/%.1e -> %.1e/%.1e  increment %.1e/%.1e -> %.1e/%.1e  rep %s" %
+              ("%dx%d" % (M, N), a[0], b[0], (b[0] / a[0] - 1) * 100, a[1], a[2], b[1], b[2], a[3], a[4], b[3], b[4], b[5]))
     lib.psgd_kron_set_tuning(11, 1)
-    med = lambda v: sorted(v)[len(v) // 2]
-    print("%5d x %-5d fp32 update: inverses %.3f ms  strips %.3f ms  (%.2fx) | bf16 operands: inverses %.3f ms  strips %.3f ms  (%.2fx)"
-          % (M, N, med(res[(1, 0)]), med(res[(0, 0)]), med(res[(0, 0)]) / med(res[(1, 0)]),
-             med(res[(1, 1)]), med(res[(0, 1)]), med(res[(0, 1)]) / med(res[(1, 1)])), flush=True)
