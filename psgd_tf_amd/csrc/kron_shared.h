@@ -18,6 +18,20 @@ int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, flo
 int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st,
                  int lite = 0, bool inv_ready = false);
 
+// The two solves of psgd.py:174 as products with explicit inverses of the balanced factors (psgd_kron.hip: tri_inverse; fp32-
+// accurate f16 x 2 plane products), for callers that hold QlS / QrS / the inverted 32-blocks of kron_balance themselves:
+//   Bt = QlS^-T X0 QrS^-1,  X0, X1 (scratch), Bt fp32 [M x N] row-major.
+// kron_inv_solves_bytes: workspace (256-aligned), 0 when the route does not apply to the shape (kron_inv_route); kron_inv_solves_on:
+// the shape rule and the tuning keys (11, 4, 12) say "use it".
+// kron_inv_prepare on `main` BEFORE the fork; kron_inv_solves_front puts Qr's side and X1 on `main` and Ql's inversion on `side`
+// (behind whatever the caller has queued there; side == main is fine); after the caller's join, kron_inv_solves_back makes Bt.
+int64_t kron_inv_solves_bytes(int M, int N);
+bool kron_inv_solves_on(int M, int N);
+int kron_inv_prepare(void* ws, int M, int N, hipStream_t main);
+int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
+                          int M, int N, void* ws, hipStream_t main, hipStream_t side);
+int kron_inv_solves_back(float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
+
 // The update has two chains that meet only at the gradient products: the products dG QrS' -> QlS (.) (psgd.py:173) and
 // the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for
 // everything already on `main`; the caller puts one chain on it and kron_join makes `main` wait for that chain.

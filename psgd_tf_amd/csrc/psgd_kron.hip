@@ -3278,6 +3278,77 @@ static int tri_inverse(InvSide f, hipStream_t st) {
   return launch_split3(f.Inv, 1, n, n, n, f.Ic, st, SplitOpt{2, 0, 0, 0});          // (x, k) = Inv[k][x], k <= x
 }
 
+// The route for callers outside this file (kron_shared.h: the bf16-operand update): own workspace, same launches.
+struct InvSolveWs {
+  PlaneMeta* pm; float* part;
+  __bf16 *Lc, *Rc, *IrL, *IcL, *TpL, *IrR, *IcR, *TpR, *DXp, *X1p;
+  float *InvL, *InvR, *TfL, *TfR;
+  int64_t total;
+};
+static InvSolveWs inv_solve_layout(char* base, int M, int N) {
+  InvSolveWs k;
+  const int64_t Mp = pad128(M), Np = pad128(N);
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = base + off; off = align256(off + bytes); return p; };
+  auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 4)); };        // (two fp16 planes)
+  k.pm = reinterpret_cast<PlaneMeta*>(take(kPmSlots * sizeof(PlaneMeta)));
+  k.part = reinterpret_cast<float*>(take(4 * kPmPartMax * 4));
+  k.Lc = planes(Mp * Mp); k.IrL = planes(Mp * Mp); k.IcL = planes(Mp * Mp); k.TpL = planes(Mp * Mp);
+  k.Rc = planes(Np * Np); k.IrR = planes(Np * Np); k.IcR = planes(Np * Np); k.TpR = planes(Np * Np);
+  k.DXp = planes(Mp * Np); k.X1p = planes(Mp * Np);
+  k.InvL = reinterpret_cast<float*>(take((int64_t)M * M * 4)); k.TfL = reinterpret_cast<float*>(take((int64_t)M * M * 4));
+  k.InvR = reinterpret_cast<float*>(take((int64_t)N * N * 4)); k.TfR = reinterpret_cast<float*>(take((int64_t)N * N * 4));
+  k.total = off;
+  return k;
+}
+int64_t kron_inv_solves_bytes(int M, int N) {           // (the shape alone: a workspace sized once stays valid whatever the keys)
+  return (kron_inv_route(M, N) && M <= 8192 && N <= 8192) ? inv_solve_layout(nullptr, M, N).total : 0;
+}
+bool kron_inv_solves_on(int M, int N) {
+  return g_trsm_inv && g_planes && g_gemm_x3 && g_planes_f16 > 1 && kron_inv_solves_bytes(M, N) > 0;
+}
+
+int kron_inv_prepare(void* ws, int M, int N, hipStream_t main) {
+  const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
+  return hipMemsetAsync(k.pm, 0, kPmSlots * sizeof(PlaneMeta), main) != hipSuccess;
+}
+
+int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
+                          int M, int N, void* ws, hipStream_t main, hipStream_t side) {
+  const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
+  const long Mp = pad128(M), Np = pad128(N);
+  PlaneMeta* pm = k.pm;
+  int e;
+  // column-form planes of the balanced factors (the B operand of T = A^-1 B)
+  P3Buf Lc = {k.Lc, Mp, Mp, pm + kPmL}, Rc = {k.Rc, Np, Np, pm + kPmR};
+  if ((e = launch_absmax(QlS, (long)M * M, Lc, k.part + kPmPartMax, side))) return e;
+  if ((e = launch_split3(QlS, 1, M, M, M, Lc, side))) return e;                        // (x, k) = QlS[k][x]
+  InvSide L = {QlS, M, dinv_l, k.InvL, k.TfL, Lc, P3Buf{k.IrL, Mp, Mp, pm + kPmInvL}, P3Buf{k.IcL, Mp, Mp, pm + kPmInvL},
+               P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
+  if ((e = tri_inverse(L, side))) return e;
+  if ((e = launch_absmax(QrS, (long)N * N, Rc, k.part, main))) return e;
+  if ((e = launch_split3(QrS, 1, N, N, N, Rc, main))) return e;
+  P3Buf dXp = {k.DXp, Mp, Np, pm + kPmdX};
+  if ((e = launch_absmax(X0, (long)M * N, dXp, k.part, main))) return e;               // (the split above is done with the array)
+  if ((e = launch_split3(X0, N, 1, M, N, dXp, main))) return e;
+  InvSide R = {QrS, N, dinv_r, k.InvR, k.TfR, Rc, P3Buf{k.IrR, Np, Np, pm + kPmInvR}, P3Buf{k.IcR, Np, Np, pm + kPmInvR},
+               P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
+  if ((e = tri_inverse(R, main))) return e;
+  const P3Buf X1c = {k.X1p, Np, Mp, pm + kPmX1};
+  P3Args x1 = p3_args(dXp, R.Ic, M, N, N, KHI_N);                                      // X1 = X0 Ri
+  return p3_chain(x1, X1, nullptr, &X1c, nullptr, nullptr, nullptr, main);
+}
+
+int kron_inv_solves_back(float* X1, float* Bt, int M, int N, void* ws, hipStream_t main) {
+  const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
+  const long Mp = pad128(M), Np = pad128(N);
+  const P3Buf IcL = {k.IcL, Mp, Mp, k.pm + kPmInvL}, X1c = {k.X1p, Np, Mp, k.pm + kPmX1};
+  P3Args bt = p3_args(IcL, X1c, M, N, M, KHI_M);                                       // Bt = Li' X1
+  bt.e.C = Bt; bt.e.ldc = N;
+  (void)X1;
+  return launch_p3(bt, main);
+}
+
 // entry points shared with psgd_kron_bf16.hip (kron_shared.h)
 // part_l, part_r: balance_grid(M, N) partial maxima of |QlS|, |QrS| each; zero[0 .. nzero) is cleared (all optional)
 static int kron_balance_amax(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal,

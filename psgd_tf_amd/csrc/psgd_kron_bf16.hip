@@ -1116,6 +1116,7 @@ __global__ __launch_bounds__(kThreads) void k_bf16_to_f32(const uint16_t* __rest
 // W1 = [Bt | 0 | A] (M rows) and W2 = [Bt' | 0 | A'] (N rows), and the two triangular gradients.
 struct HUpdWs {
   float *scal, *QlS, *QrS, *X0, *X1, *Bt, *dinv;
+  void* inv_ws;             // the solves through explicit inverses (kron_shared.h), null when the route does not apply
   uint16_t *Qlb, *QlTb, *Qrb, *QrTb, *Tt, *W1, *W2, *g1, *g2;
   int n64, m64;             // column offset of the A part in W1 (N rounded up to the K tile) / of A' in W2
   int64_t w1_bytes, w2_bytes, total;
@@ -1136,6 +1137,9 @@ static HUpdWs hupd_layout(char* base, int M, int N) {
   k.w1_bytes = (int64_t)M * (k.n64 + N) * 2; k.w2_bytes = (int64_t)N * (k.m64 + M) * 2;
   k.W1 = takeh(k.w1_bytes / 2); k.W2 = takeh(k.w2_bytes / 2);
   k.g1 = takeh(mm); k.g2 = takeh(nn);
+  const int64_t ib = psgdk::kron_inv_solves_bytes(M, N);       // (a function of the shape)
+  k.inv_ws = ib > 0 ? static_cast<void*>(base + off) : nullptr;
+  off = align256(off + ib);
   k.total = off;
   return k;
 }
@@ -1305,6 +1309,8 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   if (k.n64 != N && hipMemsetAsync(k.W1, 0, (size_t)k.w1_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   if (k.m64 != M && hipMemsetAsync(k.W2, 0, (size_t)k.w2_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, nullptr, k.dinv));          // :166-170 (+ the solves' inverted diagonal blocks)
+  const bool inv_route = k.inv_ws && psgdk::kron_inv_solves_on(M, N);
+  if (inv_route) HK(psgdk::kron_inv_prepare(k.inv_ws, M, N, st));
   // the bf16 products of :173 go to the side stream (kron_shared.h), the fp32 solves of :174 stay on the caller's
   psgdk::KronFork* fk = psgdk::kron_overlap_chains(M, N) ? psgdk::kron_fork(st) : nullptr;
   psgdk::KronForkScope fork_scope(fk, st);   // joins on every exit path, early error returns included
@@ -1328,9 +1334,17 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(grid), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dX), k.X0, n8);
     HK((int)hipGetLastError());
   }
-  HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite, true));
-  HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv + (long)((N + 31) / 32) * 1024, st, g_trsm_lite, true));
-  HK(fork_scope.join());
+  if (inv_route) {
+    // factors from 2048 on: the solves as products with explicit inverses (fp32-accurate f16 x 2 plane products; psgd_kron.hip
+    // tri_inverse).  Ql's inversion goes behind the bf16 products on the side stream, the rest stays here.
+    HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, k.dinv + (long)((N + 31) / 32) * 1024, k.X0, k.X1, M, N, k.inv_ws, st, sf));
+    HK(fork_scope.join());
+    HK(psgdk::kron_inv_solves_back(k.X1, k.Bt, M, N, k.inv_ws, st));
+  } else {
+    HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite, true));
+    HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv + (long)((N + 31) / 32) * 1024, st, g_trsm_lite, true));
+    HK(fork_scope.join());
+  }
   HK(launch_cvt(k.Bt, 0, N, k.W1, ld1, M, N, 0, st));                                 // Bt  -> first half of W1
   HK(launch_cvt(k.Bt, 0, N, k.W2, ld2, M, N, 1, st));                                 // Bt' -> first half of W2
   // grad1 = triu(A A' - Bt Bt'), grad2 = triu(A'A - Bt'Bt)                                          (:175-176)

@@ -473,7 +473,7 @@ BF16_UPD_STATE_TOL = 2e-4  # on the factors themselves: increment error x step (
 
 
 @pytest.mark.parametrize("M,N", [(128, 128), (256, 512), (512, 256), (136, 264), (8, 8), (200, 72), (72, 200), (64, 1000),
-                                 (1024, 768), (1160, 520),
+                                 (1024, 768), (1160, 520), (2304, 2048),             # (2304 x 2048: the solves through inverses)
                                  (260, 133), (5, 12), (1027, 515), (85, 10)])        # not multiples of 8: padded
 def test_dense_dense_update_bf16(psgd, M, N):
     rng = np.random.default_rng(5 * M + N)

@@ -36,4 +36,25 @@ if __name__ == "__main__":
         a, b = res
         print("%-10s update %.3f -> %.3f ms (%+.0f%%)  rel %.1e/%.1e -> %.1e/%.1e  increment %.1e/%.1e -> %.1e/%.1e  rep %s" %
               ("%dx%d" % (M, N), a[0], b[0], (b[0] / a[0] - 1) * 100, a[1], a[2], b[1], b[2], a[3], a[4], b[3], b[4], b[5]))
+    # bf16 operands for the products, fp32 solves (psgd_kron_dd_update_bf16): the same two routes for the solves
+    for M, N in ((4096, 4096), (2304, 2048), (2048, 4096), (6144, 6144)):
+        Ql, Qr = tri(M, g), tri(N, g)
+        dX = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+        dG = (dX.float() * 1.5).bfloat16()
+        rl, rr, bl, br = update_ref64(Ql, Qr, dX.float(), dG.float(), 0.01)
+        res = []
+        for rnd in range(2):
+            for i, key in enumerate((0, 1)):
+                lib.psgd_kron_set_tuning(11, key)
+                t = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01), 8)
+                if rnd == 0:
+                    a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+                    il = ((a.double() - bl) - (rl - bl)).norm() / (rl - bl).norm()
+                    ir = ((b.double() - br) - (rr - br)).norm() / (rr - br).norm()
+                    res.append([t, il.item(), ir.item()])
+                else:
+                    res[i][0] = min(res[i][0], t)
+        a, b = res
+        print("%-10s bf16-operand update %.3f -> %.3f ms (%+.0f%%)  increment error %.1e/%.1e -> %.1e/%.1e" %
+              ("%dx%d" % (M, N), a[0], b[0], (b[0] / a[0] - 1) * 100, a[1], a[2], b[1], b[2]))
     lib.psgd_kron_set_tuning(11, 1)
