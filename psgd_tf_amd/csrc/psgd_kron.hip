@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
 // split along K (P3Split).  All these tiles cost the same 2 x K / 32 steps, so without the split 1056 tiles on 512 block
 // slots are two full rounds and a third with 32 tiles (half a millisecond of idle CUs at 4096^2); with the last 64 tiles
 // as 512 eighth-size items the tail is one round of 32 steps.
-struct P3Grad { P3Args g[2]; int T0, T1, n0, n1, nsplit, nchunk; float* scratch; unsigned* cnt; };
+struct P3Grad { P3Args g[2]; int T0, T1, n0, n1, nsplit, nchunk; float* scratch; unsigned* cnt; int order; };
 
 __device__ __forceinline__ void upper_tile(int idx, int T, int& r, int& c) {      // idx-th tile (r <= c) of a T x T upper triangle
   const float b = 2.0f * T + 1.0f;
@@ -1132,20 +1132,50 @@ __device__ __forceinline__ void upper_tile(int idx, int T, int& r, int& c) {    
   c = r + idx - (r * T - (r * (r - 1)) / 2);
 }
 
+// idx-th tile (r <= c) of a T x T upper triangle in PATCH order: 4 x 4 tile patches in row-major order of the patch triangle
+// (T a multiple of 4), the tiles of a patch in row-major order (10 in a diagonal patch, 16 elsewhere)
+__device__ __forceinline__ void upper_tile_patched(int idx, int T, int& r, int& c) {
+  const int P = T >> 2;
+  int pr = 0;
+  for (;; ++pr) {                                       // patch row: 10 + 16 (P - pr - 1) tiles
+    const int in_row = 10 + 16 * (P - pr - 1);
+    if (idx < in_row) break;
+    idx -= in_row;
+  }
+  int pc = pr, tr, tc;
+  if (idx < 10) {
+    upper_tile(idx, 4, tr, tc);
+  } else {
+    idx -= 10;
+    pc = pr + 1 + (idx >> 4);
+    tr = (idx & 15) >> 2; tc = idx & 3;
+  }
+  r = 4 * pr + tr; c = 4 * pc + tc;
+}
+
 template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
-  const int id = blockIdx.x, whole1 = p.n1 - p.nsplit;
+  const int whole1 = p.n1 - p.nsplit;
+  int id = blockIdx.x;
+  // order (tuning key 17): 1 = every XCD (blocks b, b + 8, ...) works through a CONTIGUOUS run of the whole tiles' list, so
+  // the tiles in flight on one L2 are neighbours of one or two tile rows; 2 = the same over 4 x 4 tile patches of the triangle
+  const int whole = p.n0 + whole1;
+  if (p.order && id < whole) {
+    const int x = id & 7, j = id >> 3, q = whole >> 3, rem = whole & 7;
+    id = x * q + min(x, rem) + j;
+  }
   int r, c;
+  const bool patched = p.order == 2 && !(p.T0 & 3) && !(p.T1 & 3);
   if (id < p.n0) {
-    upper_tile(id, p.T0, r, c);
+    if (patched) upper_tile_patched(id, p.T0, r, c); else upper_tile(id, p.T0, r, c);
     p3_body<FMT>(p.g[0], r, c, L);
   } else if (id < p.n0 + whole1) {
-    upper_tile(id - p.n0, p.T1, r, c);
+    if (patched) upper_tile_patched(id - p.n0, p.T1, r, c); else upper_tile(id - p.n0, p.T1, r, c);
     p3_body<FMT>(p.g[1], r, c, L);
   } else {
     const int s = id - p.n0 - whole1, t = s / p.nchunk;
-    upper_tile(whole1 + t, p.T1, r, c);
+    if (patched) upper_tile_patched(whole1 + t, p.T1, r, c); else upper_tile(whole1 + t, p.T1, r, c);
     p3_body<FMT>(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
   }
 }
@@ -3051,6 +3081,9 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
 }
 
 static int g_grad_split = 1;    // tuning key 6: 0 = no K split of the gradient grid's tail
+static int g_grad_order = 1;    // tuning key 17: tile order of the gradient grid for M = N (see k_gemm_p3_grad; tools/grad_order_ab.py:
+                                // 4096^2 update 2.95-2.98 -> 2.87-2.88 ms, 6144^2 8.5 -> 8.3; patches of 4 x 4 tiles (2) are no better:
+                                // L2 locality is not what bounds this grid; 2048 x 4096 loses 9 % with either)
 static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsigned* cnt, hipStream_t st) {
   static int slots = 0;
   if (!slots) {
@@ -3063,6 +3096,7 @@ static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsi
   p.T0 = (a.e.M + 127) / 128; p.T1 = (b.e.M + 127) / 128;
   p.n0 = p.T0 * (p.T0 + 1) / 2; p.n1 = p.T1 * (p.T1 + 1) / 2;
   p.nchunk = kGradChunks; p.scratch = scratch; p.cnt = cnt;
+  p.order = a.e.K == b.e.K ? g_grad_order : 0;       // (M != N: the two products' tiles cost differently, contiguous runs unbalance the XCDs)
   const int rem = (p.n0 + p.n1) % slots;
   p.nsplit = 0;
   // a short last round (at most a quarter of the slots): twice that many tiles become eighth-size items, which the idle
@@ -3461,6 +3495,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 14) { g_trsm_planes_min_tiles = value; return PSGD_OK; }
   if (key == 15) { g_trsm_planes_min_n = value; return PSGD_OK; }
   if (key == 16) { g_planes_exact = value; return PSGD_OK; }
+  if (key == 17) { g_grad_order = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

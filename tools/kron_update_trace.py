@@ -1,5 +1,5 @@
-"""One shape's fp32 Kron update (and apply) in a loop, for `rocprofv3 --kernel-trace --stats`:
-    python tools/kron_update_trace.py M N key12 [reps]
+"""One shape's Kron update in a loop, for `rocprofv3 --kernel-trace --stats`:
+    python tools/kron_update_trace.py M N key12 [reps] [bf16]
 """
 import sys
 import torch
@@ -12,12 +12,15 @@ from tools.kron_bf16_update_timing import tri  # noqa: E402
 if __name__ == "__main__":
     M, N, key = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+    bf16 = len(sys.argv) > 5 and sys.argv[5] == "bf16"
     lib = _lib.load()
     lib.psgd_kron_set_tuning(12, key)
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     Ql, Qr = tri(M, g), tri(N, g)
     dX = torch.randn(M, N, device="cuda", generator=g)
     dG = dX * 1.5
+    if bf16:
+        dX, dG = dX.bfloat16(), dG.bfloat16()
     for _ in range(reps):
         psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
     torch.cuda.synchronize()
