@@ -2219,8 +2219,28 @@ __device__ __forceinline__ void balance_body(const float* __restrict__ Ql, const
   const long nl = (long)M * M, nr = (long)N * N;
   const long tid = (long)bid * kThreads + threadIdx.x, nth = (long)nblocks * kThreads;
   float ml = 0.0f, mr = 0.0f;
-  for (long i = tid; i < nl; i += nth) { const float q = Ql[i] / rho; QlS[i] = q; ml = amaxf(ml, fabsf(q)); }
-  for (long i = tid; i < nr; i += nth) { const float q = rho * Qr[i]; QrS[i] = q; mr = amaxf(mr, fabsf(q)); }
+  // 16-byte accesses where the four pointers allow it (4096^2: 104 -> 6x us for 268 MB), element by element otherwise
+  const bool v4 = ((reinterpret_cast<uintptr_t>(Ql) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(QlS) |
+                    reinterpret_cast<uintptr_t>(QrS)) & 15) == 0;
+  long dl = 0, dr = 0;
+  if (v4) {
+    const long nl4 = nl >> 2, nr4 = nr >> 2;
+    for (long i = tid; i < nl4; i += nth) {
+      const float4 v = reinterpret_cast<const float4*>(Ql)[i];
+      const float4 q = make_float4(v.x / rho, v.y / rho, v.z / rho, v.w / rho);
+      reinterpret_cast<float4*>(QlS)[i] = q;
+      ml = amaxf(amaxf(ml, fabsf(q.x)), amaxf(amaxf(fabsf(q.y), fabsf(q.z)), fabsf(q.w)));
+    }
+    for (long i = tid; i < nr4; i += nth) {
+      const float4 v = reinterpret_cast<const float4*>(Qr)[i];
+      const float4 q = make_float4(rho * v.x, rho * v.y, rho * v.z, rho * v.w);
+      reinterpret_cast<float4*>(QrS)[i] = q;
+      mr = amaxf(amaxf(mr, fabsf(q.x)), amaxf(amaxf(fabsf(q.y), fabsf(q.z)), fabsf(q.w)));
+    }
+    dl = nl4 << 2; dr = nr4 << 2;
+  }
+  for (long i = dl + tid; i < nl; i += nth) { const float q = Ql[i] / rho; QlS[i] = q; ml = amaxf(ml, fabsf(q)); }
+  for (long i = dr + tid; i < nr; i += nth) { const float q = rho * Qr[i]; QrS[i] = q; mr = amaxf(mr, fabsf(q)); }
   if (part_l) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -3279,7 +3299,7 @@ struct InvSide {
 };
 static int g_trsm_inv = 1;      // tuning key 11: 0 = the solves of every size stay on the substitution strips
 
-static int tri_inverse(InvSide f, hipStream_t st) {
+static int tri_inverse_blocks(InvSide& f, hipStream_t st) {           // the inverted 128-blocks
   static bool attr_set = false;
   const size_t lds = (size_t)2 * 128 * 129 * sizeof(float);
   if (!attr_set) {
@@ -3287,29 +3307,43 @@ static int tri_inverse(InvSide f, hipStream_t st) {
         hipSuccess) return 1;
     attr_set = true;
   }
-  const int n = f.n;
-  int e;
-  hipLaunchKernelGGL(k_tri_inv128, dim3((n + 127) / 128), dim3(kThreads), lds, st, f.Q, n, f.dinv, f.Inv, &f.Ir.meta->amax);
-  if (hipGetLastError() != hipSuccess) return 1;
+  hipLaunchKernelGGL(k_tri_inv128, dim3((f.n + 127) / 128), dim3(kThreads), lds, st, f.Q, f.n, f.dinv, f.Inv, &f.Ir.meta->amax);
   f.Ir.part = f.Ic.part = &f.Ir.meta->amax;
   f.Ir.npart = f.Ic.npart = 1;
+  return (int)hipGetLastError();
+}
+static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st) {     // b-blocks -> 2b-blocks
+  const int n = f.n;
+  int e;
+  if ((e = launch_split3_both(f.Inv, n, 1, n, n, f.Ir, f.Ic, st, SplitOpt{1, b, 0, 0}))) return e;     // the inverted b-blocks
+  const int tb = b / 128, pairs = (n + 2 * b - 1) / (2 * b);
+  P3Args g1 = p3_args(f.Ir, f.Qc, n, n, n, KLO_M | KBLK_HI_M);                     // T = A^-1 B
+  g1.e.kblk = 2 * b; g1.e.C = f.Tf; g1.e.ldc = n; g1.ometa = f.mT + level;
+  hipLaunchKernelGGL(k_gemm_p3_blk<1>, dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
+  if (hipGetLastError() != hipSuccess) return 1;
+  P3Buf tp = f.Tp;
+  tp.meta = f.mT + level; tp.part = &tp.meta->amax; tp.npart = 1;
+  if ((e = launch_split3(f.Tf, n, 1, n, n, tp, st, SplitOpt{0, 2 * b, 1, 1}))) return e;              // planes of -T
+  P3Args g2 = p3_args(tp, f.Ic, n, n, n, KHI_N | KBLK_LO_N);                       // W = (-T) C^-1 into Inv
+  g2.e.kblk = 2 * b; g2.e.C = f.Inv; g2.e.ldc = n; g2.ometa = f.Ir.meta;
+  hipLaunchKernelGGL(k_gemm_p3_blk<1>, dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
+  return (int)hipGetLastError();
+}
+static int tri_inverse_planes(const InvSide& f, hipStream_t st) {     // column-form planes of the whole inverse: (x, k) = Inv[k][x], k <= x
+  return launch_split3(f.Inv, 1, f.n, f.n, f.n, f.Ic, st, SplitOpt{2, 0, 0, 0});
+}
+// Two inversions on two streams, their launches queued level by level in turn (either stream has work early: a caller whose
+// host thread is not far ahead of the device would otherwise leave the second stream idle for the ~25 launches of the first)
+static int tri_inverse_pair(InvSide a, hipStream_t sa, InvSide b, hipStream_t sb) {
+  int e;
+  if ((e = tri_inverse_blocks(a, sa)) || (e = tri_inverse_blocks(b, sb))) return e;
   int level = 0;
-  for (int b = 128; b < n; b *= 2, ++level) {
-    if ((e = launch_split3_both(f.Inv, n, 1, n, n, f.Ir, f.Ic, st, SplitOpt{1, b, 0, 0}))) return e;   // the inverted b-blocks
-    const int tb = b / 128, pairs = (n + 2 * b - 1) / (2 * b);
-    P3Args g1 = p3_args(f.Ir, f.Qc, n, n, n, KLO_M | KBLK_HI_M);                   // T = A^-1 B
-    g1.e.kblk = 2 * b; g1.e.C = f.Tf; g1.e.ldc = n; g1.ometa = f.mT + level;
-    hipLaunchKernelGGL(k_gemm_p3_blk<1>, dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
-    if (hipGetLastError() != hipSuccess) return 1;
-    P3Buf tp = f.Tp;
-    tp.meta = f.mT + level; tp.part = &tp.meta->amax; tp.npart = 1;
-    if ((e = launch_split3(f.Tf, n, 1, n, n, tp, st, SplitOpt{0, 2 * b, 1, 1}))) return e;            // planes of -T
-    P3Args g2 = p3_args(tp, f.Ic, n, n, n, KHI_N | KBLK_LO_N);                     // W = (-T) C^-1 into Inv
-    g2.e.kblk = 2 * b; g2.e.C = f.Inv; g2.e.ldc = n; g2.ometa = f.Ir.meta;
-    hipLaunchKernelGGL(k_gemm_p3_blk<1>, dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
-    if (hipGetLastError() != hipSuccess) return 1;
+  for (int w = 128; w < a.n || w < b.n; w *= 2, ++level) {
+    if (w < a.n && (e = tri_inverse_level(a, w, level, sa))) return e;
+    if (w < b.n && (e = tri_inverse_level(b, w, level, sb))) return e;
   }
-  return launch_split3(f.Inv, 1, n, n, n, f.Ic, st, SplitOpt{2, 0, 0, 0});          // (x, k) = Inv[k][x], k <= x
+  if ((e = tri_inverse_planes(a, sa))) return e;
+  return tri_inverse_planes(b, sb);
 }
 
 // The route for callers outside this file (kron_shared.h: the bf16-operand update): own workspace, same launches.
@@ -3355,19 +3389,18 @@ int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_
   int e;
   // column-form planes of the balanced factors (the B operand of T = A^-1 B)
   P3Buf Lc = {k.Lc, Mp, Mp, pm + kPmL}, Rc = {k.Rc, Np, Np, pm + kPmR};
-  if ((e = launch_absmax(QlS, (long)M * M, Lc, k.part + kPmPartMax, side))) return e;
-  if ((e = launch_split3(QlS, 1, M, M, M, Lc, side))) return e;                        // (x, k) = QlS[k][x]
-  InvSide L = {QlS, M, dinv_l, k.InvL, k.TfL, Lc, P3Buf{k.IrL, Mp, Mp, pm + kPmInvL}, P3Buf{k.IcL, Mp, Mp, pm + kPmInvL},
-               P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
-  if ((e = tri_inverse(L, side))) return e;
   if ((e = launch_absmax(QrS, (long)N * N, Rc, k.part, main))) return e;
-  if ((e = launch_split3(QrS, 1, N, N, N, Rc, main))) return e;
+  if ((e = launch_split3(QrS, 1, N, N, N, Rc, main))) return e;                        // (x, k) = QrS[k][x]
+  if ((e = launch_absmax(QlS, (long)M * M, Lc, k.part + kPmPartMax, side))) return e;
+  if ((e = launch_split3(QlS, 1, M, M, M, Lc, side))) return e;
   P3Buf dXp = {k.DXp, Mp, Np, pm + kPmdX};
   if ((e = launch_absmax(X0, (long)M * N, dXp, k.part, main))) return e;               // (the split above is done with the array)
   if ((e = launch_split3(X0, N, 1, M, N, dXp, main))) return e;
+  InvSide L = {QlS, M, dinv_l, k.InvL, k.TfL, Lc, P3Buf{k.IrL, Mp, Mp, pm + kPmInvL}, P3Buf{k.IcL, Mp, Mp, pm + kPmInvL},
+               P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
   InvSide R = {QrS, N, dinv_r, k.InvR, k.TfR, Rc, P3Buf{k.IrR, Np, Np, pm + kPmInvR}, P3Buf{k.IcR, Np, Np, pm + kPmInvR},
                P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
-  if ((e = tri_inverse(R, main))) return e;
+  if ((e = tri_inverse_pair(R, main, L, side))) return e;
   const P3Buf X1c = {k.X1p, Np, Mp, pm + kPmX1};
   P3Args x1 = p3_args(dXp, R.Ic, M, N, N, KHI_N);                                      // X1 = X0 Ri
   return p3_chain(x1, X1, nullptr, &X1c, nullptr, nullptr, nullptr, main);
@@ -3590,12 +3623,11 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     // Order: the full-chip products of :173 run beside the launch-bound lower levels of Qr's inversion, Ql's inversion beside the
     // product X1 = dX Ri (with the two inversions first and the products colliding afterwards the join came 0.3 ms later).
     KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
-    KRON_LAUNCH(tri_inverse(L, sf));
     P3Buf dXp = {k.DXp, Mp, Np, pm + kPmdX};
     const P3Buf X1c = {k.X1p, Np, Mp, pm + kPmX1};
     KRON_LAUNCH(launch_absmax(dX, (long)M * N, dXp, k.pm_part, st));
     KRON_LAUNCH(launch_split3(dX, N, 1, M, N, dXp, st));
-    KRON_LAUNCH(tri_inverse(R, st));
+    KRON_LAUNCH(tri_inverse_pair(R, st, L, sf));
     P3Args x1 = p3_args(dXp, R.Ic, M, N, N, KHI_N);                                   // X1 = dX Ri
     KRON_LAUNCH(p3_chain(x1, k.X1, nullptr, &X1c, nullptr, k.sk_scratch, k.sk_cnt, st));
     KRON_LAUNCH(fork_scope.join());
