@@ -943,14 +943,26 @@ __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&a
 // in chunk order -- a fixed order, whoever arrives last -- and runs the epilogue.  The counter is left at zero again.
 struct P3Split { int chunk, nchunk; float* scratch; unsigned* cnt; };     // scratch, cnt: of THIS tile
 
+__device__ __forceinline__ void pow2_halves(double v, float& m1, float& m2) {   // v = 2^e (> 0)  ->  m1 m2 = v, exponents e/2 each
+  int e;
+  (void)frexp(v, &e);                                   // v = 0.5 * 2^e
+  e -= 1;
+  const int h = e / 2;
+  m1 = ldexpf(1.0f, h); m2 = ldexpf(1.0f, e - h);
+}
+
 template <int FMT = 0>
 __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<FMT>& L, const P3Split sp = P3Split{-1, 0, nullptr, nullptr}) {
   constexpr int TM = 128, TN = 128, GK = kX3K;
   // f16 x 2: what brings a pair's accumulators back to real values (2^-(eA + eB), exact)
-  float inv1 = 1.0f, inv2 = 1.0f;
+  // (2^-(eA + eB) can leave the fp32 range where the real result does not: kept in double, applied as two balanced
+  // power-of-two factors -- the intermediate lies between the accumulator and the result, so it is in range when they are)
+  float ia1 = 1.0f, ib1 = 1.0f, ia2 = 1.0f, ib2 = 1.0f;
+  double inv1 = 1.0, inv2 = 1.0;
   if constexpr (FMT == 1) {
-    inv1 = g.A.meta->inv * g.B.meta->inv;
-    if (g.e.A2) inv2 = g.A2.meta->inv * g.B2.meta->inv;
+    inv1 = (double)g.A.meta->inv * g.B.meta->inv;
+    pow2_halves(inv1, ia1, ib1);
+    if (g.e.A2) { inv2 = (double)g.A2.meta->inv * g.B2.meta->inv; pow2_halves(inv2, ia2, ib2); }
   }
   const int m0 = by * TM, n0 = bx * TN;
   const bool tri_skip = (g.e.epi == EPI_TRIU_MAX || g.e.sym) && (m0 >= n0 + TN);
@@ -977,11 +989,11 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
     const int clo = lo + sub * per * GK, chi = min(hi, clo + per * GK);
     p3_pass<FMT>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc);
     f32x4* mine = reinterpret_cast<f32x4*>(sp.scratch) + (long)sp.chunk * (16 * kThreads);
-    const float pm = p ? -inv2 : inv1;                 // partials are stored as real values (f16 x 2: each pair has its own scale)
+    const float pa = p ? -ia2 : ia1, pb = p ? ib2 : ib1;   // partials are stored as real values (f16 x 2: each pair has its own scale)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * kThreads + threadIdx.x] = acc[i][j] * pm;
+      for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * kThreads + threadIdx.x] = (acc[i][j] * pa) * pb;
     __threadfence();                                   // the partial is visible device-wide before the ticket is taken
     __syncthreads();
     if (threadIdx.x == 0) L.ticket[0] = atomicAdd(sp.cnt, 1u);
@@ -1018,7 +1030,7 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
       hi = ((hi + GK - 1) / GK) * GK;                 // the planes are zero-padded to whole K tiles
       p3_pass<FMT>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
       if (it) {                                        // (f16 x 2: and over to the other pair's unit, a power of two)
-        const float flip = (FMT == 1) ? -((p ? inv2 : inv1) / (p ? inv1 : inv2)) : -1.0f;
+        const float flip = (FMT == 1) ? -(float)((p ? inv2 : inv1) / (p ? inv1 : inv2)) : -1.0f;     // (<= 1 in magnitude)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1026,11 +1038,11 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
       }
     }
     if constexpr (FMT == 1) {                          // back to real values (the last pair's unit; A - B either way)
-      const float fin = swap ? -inv2 : inv1;
+      const float fa = swap ? -ia2 : ia1, fb = swap ? ib2 : ib1;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] *= fin;
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * fa) * fb;
     }
   }
   if (g.e.scale_max) {                                // (step / max) A B = step / max (A B): applied to the finished sums
