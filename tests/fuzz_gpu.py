@@ -30,11 +30,17 @@ def fuzz_kron(g, it):
     big = it % 7 == 0
     M = int(torch.randint(1, 2600 if big else 700, (1,), generator=g, device=dev))
     N = int(torch.randint(1, 2600 if big else 700, (1,), generator=g, device=dev))
+    if it % 42 == 0:                                  # both factors from 2048 on: the solves through explicit inverses
+        M = int(torch.randint(2048, 3000, (1,), generator=g, device=dev))
+        N = int(torch.randint(2049, 3000, (1,), generator=g, device=dev))
     off = 0.5 / max(M, N) ** 0.5
     Ql, Qr = tri(M, g, off) * 1.7, tri(N, g, off)
     dX = torch.randn(M, N, device=dev, generator=g)
     dG = torch.exp(torch.empty(M, 1, device=dev).uniform_(-1, 1, generator=g)) * dX * torch.exp(torch.empty(1, N, device=dev).uniform_(-1, 1, generator=g))
     G = torch.randn(M, N, device=dev, generator=g)
+    if it % 3 == 0:                                   # data of any magnitude (the plane formats carry their own scales)
+        s = 10.0 ** float(torch.empty(1, device=dev).uniform_(-12, 12, generator=g))
+        G, dX, dG = G * s, dX * s, dG / s
     e1 = rel(psgd.precond_grad_kron(Ql, Qr, G), ref64.precond_grad_dense_dense(Ql.double(), Qr.double(), G.double()))
     a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
     a64, b64 = ref64.update_precond_dense_dense(Ql.double(), Qr.double(), dX.double(), dG.double(), 0.01, TINY)
@@ -62,6 +68,8 @@ def fuzz_kron_bf16_update(g, it):
     N = 8 * int(torch.randint(1, 200, (1,), generator=g, device=dev))
     if it % 6 == 0:
         M, N = 64 * int(torch.randint(8, 40, (1,), generator=g, device=dev)), 64 * int(torch.randint(8, 40, (1,), generator=g, device=dev))
+    if it % 60 == 2:                                  # the fp32 solves through explicit inverses
+        M, N = 64 * int(torch.randint(32, 44, (1,), generator=g, device=dev)), 64 * int(torch.randint(33, 44, (1,), generator=g, device=dev))
     off = 0.5 / max(M, N) ** 0.5
     Ql, Qr = tri(M, g, off) * 1.7, tri(N, g, off)
     dX = torch.randn(M, N, device=dev, generator=g)
