@@ -30,7 +30,7 @@ def fuzz_kron(g, it):
     big = it % 7 == 0
     M = int(torch.randint(1, 2600 if big else 700, (1,), generator=g, device=dev))
     N = int(torch.randint(1, 2600 if big else 700, (1,), generator=g, device=dev))
-    if it % 42 == 0:                                  # both factors from 2048 on: the solves through explicit inverses
+    if it % 28 == 27:                                 # both factors from 2048 on: the solves through explicit inverses
         M = int(torch.randint(2048, 3000, (1,), generator=g, device=dev))
         N = int(torch.randint(2049, 3000, (1,), generator=g, device=dev))
     off = 0.5 / max(M, N) ** 0.5
@@ -68,7 +68,7 @@ def fuzz_kron_bf16_update(g, it):
     N = 8 * int(torch.randint(1, 200, (1,), generator=g, device=dev))
     if it % 6 == 0:
         M, N = 64 * int(torch.randint(8, 40, (1,), generator=g, device=dev)), 64 * int(torch.randint(8, 40, (1,), generator=g, device=dev))
-    if it % 60 == 2:                                  # the fp32 solves through explicit inverses
+    if it % 30 == 29:                                 # the fp32 solves through explicit inverses
         M, N = 64 * int(torch.randint(32, 44, (1,), generator=g, device=dev)), 64 * int(torch.randint(33, 44, (1,), generator=g, device=dev))
     off = 0.5 / max(M, N) ** 0.5
     Ql, Qr = tri(M, g, off) * 1.7, tri(N, g, off)
@@ -205,7 +205,7 @@ def run(budget, seed=1):
     t0, it, worst, bad = time.time(), 0, {}, []
     while time.time() - t0 < budget:
         f = fams[it % len(fams)]
-        name, err, tol = f(g, it)
+        name, err, tol = f(g, it // len(fams))           # the family's own counter: its `it % k` switches see every residue
         fam = name.split()[0]
         if err > worst.get(fam, (0, ""))[0]:
             worst[fam] = (err, name)
