@@ -289,7 +289,9 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  *        key 13 (default 512), they have at least key 14 output tiles (64) and M or N exceeds key 15 (1100).
  * key 16: f16 x 2 planes of a product that feeds the next product: 1 (default) the product writes fp32 and its max|C|, a
  *        split launch makes the planes with that exact scale; 0 = the product's epilogue writes the planes with a scale from
- *        the bound K max|A| max|B| (faster by a launch per intermediate; loses accuracy on ill-conditioned factors). */
+ *        the bound K max|A| max|B| (faster by a launch per intermediate; loses accuracy on ill-conditioned factors).
+ * key 17: gradient grid of the large fp32 update with M = N: 1 (default) every XCD works through a contiguous run of the
+ *        tile list, 2 = over 4 x 4 tile patches, 0 = tiles dealt to the XCDs one by one. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.
