@@ -760,8 +760,9 @@ def test_plane_formats_of_the_large_update_agree(psgd, M, N):
     dev = [_dev(a) for a in a32]
     outs = []
     try:
-        for fmt in (2, 1, 0):
+        for fmt, exact in ((2, 1), (1, 1), (0, 1), (2, 0)):     # (2, 0): chained products write their planes at bound scales (key 16)
             lib.psgd_kron_set_tuning(12, fmt)
+            lib.psgd_kron_set_tuning(16, exact)
             out = psgd.update_precond_kron(*dev, 0.01)
             again = psgd.update_precond_kron(*dev, 0.01)
             assert torch.equal(out[0], again[0]) and torch.equal(out[1], again[1])
@@ -772,6 +773,7 @@ def test_plane_formats_of_the_large_update_agree(psgd, M, N):
             outs.append(out)
     finally:
         lib.psgd_kron_set_tuning(12, 2)
+        lib.psgd_kron_set_tuning(16, 1)
     for other in outs[1:]:
         for a, b, bb in zip(outs[0], other, base):
             assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
