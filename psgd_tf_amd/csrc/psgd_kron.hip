@@ -3112,7 +3112,10 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-static int g_grad_split = 1;    // tuning key 6: 0 = no K split of the gradient grid's tail
+static int g_grad_split = 0;    // tuning key 6: 1 = K split of the gradient grid's tail.  On the bf16 x 3 planes of round 2 it was worth 0.11 ms of
+                                // 1.55 at 4096^2; on the f16 x 2 planes with the XCD-contiguous tile order it never pays and costs up to 2x of
+                                // the launch where the last round is long (profiles/r03_grad_grid_isolated.txt: 3072^2 0.745 vs 0.363 ms,
+                                // 5120^2 1.97 vs 1.48; whole update 3072^2 2.04 -> 1.69 ms, 5120^2 5.75 -> 5.34, 4096^2 3.02 -> 2.96)
 static int g_grad_order = 1;    // tuning key 17: tile order of the gradient grid for M = N (see k_gemm_p3_grad; tools/grad_order_ab.py:
                                 // 4096^2 update 2.95-2.98 -> 2.87-2.88 ms, 6144^2 8.5 -> 8.3; patches of 4 x 4 tiles (2) are no better:
                                 // L2 locality is not what bounds this grid; 2048 x 4096 loses 9 % with either)

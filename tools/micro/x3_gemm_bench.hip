@@ -21,6 +21,7 @@ static float run(const GemmArgs& g, int iters) {
 
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 4096;
+  for (int i = 2; i + 1 < argc; i += 2) psgd_kron_set_tuning(atoi(argv[i]), atoi(argv[i + 1]));     // [key value] ...
   const size_t bytes = (size_t)n * n * sizeof(float);
   float *A, *B, *C;
   hipMalloc(&A, bytes); hipMalloc(&B, bytes); hipMalloc(&C, bytes);
@@ -94,6 +95,38 @@ int main(int argc, char** argv) {
       printf("X3_DBG=%d  %d^3  f16 x 2 planes (k_gemm_p3<1>) -> %-16s %.3f ms  %.1f TFLOP/s fp32-equivalent  (%.0f issued f16)\n", X3_DBG, n,
              outs[o], ms, flop / ms * 1e-9, 3 * flop / ms * 1e-9);
     }
+  }
+  {   // the gradient grid of the Kron update on f16 x 2 planes: triu(A A' - B B') and triu(A'A - B'B) in one launch (fp32 + max)
+    __bf16* P[4];
+    for (auto& q : P) hipMalloc(&q, (size_t)n * n * 6);
+    PlaneMeta* pm; float *part, *G1, *G2, *scal, *scratch; unsigned* cnt;
+    hipMalloc(&pm, 64 * sizeof(PlaneMeta)); hipMalloc(&part, 4 * 2048 * 4);
+    hipMalloc(&G1, bytes); hipMalloc(&G2, bytes); hipMalloc(&scal, 256);
+    hipMalloc(&scratch, (size_t)kGradSplitMax * kGradChunks * 64 * kThreads * 4); hipMalloc(&cnt, kGradSplitMax * 4);
+    hipMemset(pm, 0, 64 * sizeof(PlaneMeta)); hipMemset(scal, 0, 256);
+    P3Buf Ar = {P[0], n, n, pm}, Ac = {P[1], n, n, pm}, Br = {P[2], n, n, pm + 1}, Bc = {P[3], n, n, pm + 1};
+    launch_absmax(A, (long)n * n, Ar, part, 0); Ac.part = Ar.part; Ac.npart = Ar.npart;
+    launch_split3_both(A, n, 1, n, n, Ar, Ac, 0);
+    launch_absmax(B, (long)n * n, Br, part, 0); Bc.part = Br.part; Bc.npart = Br.npart;
+    launch_split3_both(B, n, 1, n, n, Br, Bc, 0);
+    P3Args s2 = p3_args(Ar, Ar, n, n, n, 0);
+    s2.A2 = p3_of(Br); s2.B2 = p3_of(Br); s2.e.A2 = B; s2.e.K2 = n;
+    s2.e.epi = EPI_TRIU_MAX; s2.e.maxout = scal; s2.e.C = G1; s2.e.ldc = n;
+    P3Args s3 = p3_args(Ac, Ac, n, n, n, 0);
+    s3.A2 = p3_of(Bc); s3.B2 = p3_of(Bc); s3.e.A2 = B; s3.e.K2 = n;
+    s3.e.epi = EPI_TRIU_MAX; s3.e.maxout = scal + 1; s3.e.C = G2; s3.e.ldc = n;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch_p3_grad(s2, s3, scratch, cnt, 0);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 20; ++i) launch_p3_grad(s2, s3, scratch, cnt, 0);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 20;
+    printf("X3_DBG=%d  %d^2  gradient grid on f16 x 2 planes (k_gemm_p3_grad<1>, both gradients)  %.3f ms  (%.0f issued f16 TFLOP/s)\n", X3_DBG, n, ms,
+           3.0 * 2.0 * flop / ms * 1e-9);
   }
   {   // the two factor updates of the Kron update (K = [m0, n0 + 128): work = distance from the diagonal), as one grid
     __bf16 *PA, *PB;
