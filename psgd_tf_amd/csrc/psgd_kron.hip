@@ -713,6 +713,12 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr3_t;
 #ifndef P3_EARLY
 #define P3_EARLY 2      // MFMA columns (of 4) issued before the buffer-free barrier; 0 = all fragments first, then all MFMAs
 #endif
+// The f16 x 2 kernels exist in both forms (template parameter ER, chosen by the launcher): grids of at least a full round of
+// block slots run with none -- with half the MFMAs per step the next tile's DMA wants to go out as early as it can (tools/micro:
+// 4096^3 0.305-0.324 -> 0.282 ms, triangular K ranges 0.166 -> 0.157, the gradient grid at 6144^2 2.53 -> 2.33, at 2048^2
+// 0.151 -> 0.128) -- smaller ones keep two (a lone workgroup per CU loses 3-5 % without: 1024^3 0.036 -> 0.037, 1000^2 apply
+// 0.124 -> 0.131).  A run-time switch inside the loop instead of two instantiations cost 35 % (4096^2 apply 0.78 -> 1.11 ms).
+constexpr int p3_early(int FMT, int ER) { return FMT ? ER : P3_EARLY; }
 
 // LDS of the plane kernels, ONE object (a second __shared__ object makes hipcc guard its accesses with vmcnt(0) while DMA
 // into the first is in flight).  bf16 x 3: one 48 KiB stage, the layout of GemmLdsX3.  f16 x 2: TWO 32 KiB stages -- with
@@ -727,9 +733,10 @@ struct P3Lds {
 // K tiles [lo, hi) of one operand pair.  LDS image as in k_gemm_x3: [A|B][plane][row * 4 + (chunk ^ swz(row))].  The DMA
 // writes linearly (wave base + 16 B * lane), so the swizzle is applied to the per-lane SOURCE address: the lane that
 // fills slot s = row * 4 + cpos fetches chunk cpos ^ swz(row) of that row.
-template <int FMT>
+template <int FMT, int ER>
 __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0, int lo, int hi, P3Lds<FMT>& L,
                                         f32x4 (&acc)[4][4]) {
+  constexpr int EARLY = p3_early(FMT, ER);
   constexpr int NP = FMT ? 2 : 3;
   constexpr int W = 64, NT = 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -812,13 +819,13 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     }
 #pragma unroll
     for (int j = 1; j < NT; ++j) read_b(j);
-#if P3_EARLY
+    if constexpr (EARLY > 0) {
 #pragma unroll
-    for (int j = 0; j < P3_EARLY; ++j)
+      for (int j = 0; j < EARLY; ++j)
 #pragma unroll
-      for (int i = 0; i < NT; ++i) mfma6(i, j);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+        for (int i = 0; i < NT; ++i) mfma6(i, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // (measured and not kept: ONE barrier per step with the next tile requested right behind it into the other stage --
     // 4096^3 0.317 -> 0.302 ms, but the triangular K ranges 0.173 -> 0.194)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -827,7 +834,7 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     P3_FENCE();
     if (k0 + NS * kX3K < hi && !(X3_DBG & 1)) issue(k0 + NS * kX3K, st);   // the next tile for this stage streams in under the MFMAs
 #pragma unroll
-    for (int j = P3_EARLY; j < NT; ++j)
+    for (int j = EARLY; j < NT; ++j)
 #pragma unroll
       for (int i = 0; i < NT; ++i) mfma6(i, j);
   }
@@ -951,7 +958,7 @@ __device__ __forceinline__ void pow2_halves(double v, float& m1, float& m2) {   
   m1 = ldexpf(1.0f, h); m2 = ldexpf(1.0f, e - h);
 }
 
-template <int FMT = 0>
+template <int FMT = 0, int ER = 2>
 __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<FMT>& L, const P3Split sp = P3Split{-1, 0, nullptr, nullptr}) {
   constexpr int TM = 128, TN = 128, GK = kX3K;
   // f16 x 2: what brings a pair's accumulators back to real values (2^-(eA + eB), exact)
@@ -987,7 +994,7 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
     hi = ((hi + GK - 1) / GK) * GK;
     const int steps = (hi - lo) / GK, per = (steps + per_pair - 1) / per_pair;
     const int clo = lo + sub * per * GK, chi = min(hi, clo + per * GK);
-    p3_pass<FMT>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc);
+    p3_pass<FMT, ER>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc);
     f32x4* mine = reinterpret_cast<f32x4*>(sp.scratch) + (long)sp.chunk * (16 * kThreads);
     const float pa = p ? -ia2 : ia1, pb = p ? ib2 : ib1;   // partials are stored as real values (f16 x 2: each pair has its own scale)
 #pragma unroll
@@ -1028,7 +1035,7 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
       if (km & KBLK_LO_N) lo = max(lo, (n0 / g.e.kblk) * g.e.kblk + g.e.kblk / 2);
       lo = (lo / GK) * GK;
       hi = ((hi + GK - 1) / GK) * GK;                 // the planes are zero-padded to whole K tiles
-      p3_pass<FMT>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
+      p3_pass<FMT, ER>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
       if (it) {                                        // (f16 x 2: and over to the other pair's unit, a power of two)
         const float flip = (FMT == 1) ? -(float)((p ? inv2 : inv1) / (p ? inv1 : inv2)) : -1.0f;     // (<= 1 in magnitude)
 #pragma unroll
@@ -1095,30 +1102,30 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
   if (g.Crow || g.Ccol) p3_store_planes<FMT>(g, acc, m0, n0, g.Crow != nullptr, g.Ccol != nullptr && (!g.e.sym || n0 > m0));
 }
 
-template <int FMT>
+template <int FMT, int ER = 2>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   int by, bx;
   gemm_tile_order(g.e.kmode, by, bx);
-  p3_body<FMT>(g, by, bx, L);
+  p3_body<FMT, ER>(g, by, bx, L);
 }
 
 // The off-diagonal b x b blocks (rows of the first half, columns of the second half) of every 2b-block on the diagonal of
 // an n x n product: the tiles of one doubling level of a triangular inverse (tri_inverse), b a multiple of 128.
-template <int FMT>
+template <int FMT, int ER = 2>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_blk(P3Args g, int b) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   const int tb = b / 128, per = tb * tb;
   const int p = blockIdx.x / per, r = blockIdx.x % per;
   const int by = (p * 2 * b) / 128 + r / tb, bx = (p * 2 * b + b) / 128 + r % tb;
   if (by * 128 >= g.e.M || bx * 128 >= g.e.N) return;
-  p3_body<FMT>(g, by, bx, L);
+  p3_body<FMT, ER>(g, by, bx, L);
 }
 
 // two independent products in one grid (see k_gemm_x3_pair)
 struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1, tiles1; };
 
-template <int FMT>
+template <int FMT, int ER = 2>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   int which, id;
@@ -1126,7 +1133,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
   const P3Args& g = p.g[which];
   int by, bx;
   gemm_tile_from_id(id, (g.e.M + 127) / 128, which ? p.tx1 : p.tx0, g.e.kmode, by, bx);
-  p3_body<FMT>(g, by, bx, L);
+  p3_body<FMT, ER>(g, by, bx, L);
 }
 
 // The two gradient products of the update (psgd.py:175-176) in one grid: upper tiles only (the planes of a triu result are
@@ -1165,7 +1172,7 @@ __device__ __forceinline__ void upper_tile_patched(int idx, int T, int& r, int& 
   r = 4 * pr + tr; c = 4 * pc + tc;
 }
 
-template <int FMT>
+template <int FMT, int ER = 2>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   const int whole1 = p.n1 - p.nsplit;
@@ -1181,14 +1188,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
   const bool patched = p.order == 2 && !(p.T0 & 3) && !(p.T1 & 3);
   if (id < p.n0) {
     if (patched) upper_tile_patched(id, p.T0, r, c); else upper_tile(id, p.T0, r, c);
-    p3_body<FMT>(p.g[0], r, c, L);
+    p3_body<FMT, ER>(p.g[0], r, c, L);
   } else if (id < p.n0 + whole1) {
     if (patched) upper_tile_patched(id - p.n0, p.T1, r, c); else upper_tile(id - p.n0, p.T1, r, c);
-    p3_body<FMT>(p.g[1], r, c, L);
+    p3_body<FMT, ER>(p.g[1], r, c, L);
   } else {
     const int s = id - p.n0 - whole1, t = s / p.nchunk;
     if (patched) upper_tile_patched(whole1 + t, p.T1, r, c); else upper_tile(whole1 + t, p.T1, r, c);
-    p3_body<FMT>(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
+    p3_body<FMT, ER>(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
   }
 }
 
@@ -2889,10 +2896,20 @@ static void p3_out_meta(P3Args& g, const P3Buf& C) {
 static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; p3_out_meta(g, C); }
 static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; p3_out_meta(g, Ct); }
 
+static int p3_block_slots() {           // two resident blocks per CU
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 512;
+    slots = 2 * cus;
+  }
+  return slots;
+}
 static int launch_p3(const P3Args& g, hipStream_t st) {
   const dim3 grid((g.e.N + 127) / 128, (g.e.M + 127) / 128);
-  if (g.fmt) hipLaunchKernelGGL(k_gemm_p3<1>, grid, dim3(kThreads), 0, st, g);
-  else hipLaunchKernelGGL(k_gemm_p3<0>, grid, dim3(kThreads), 0, st, g);
+  if (!g.fmt) hipLaunchKernelGGL((k_gemm_p3<0, 2>), grid, dim3(kThreads), 0, st, g);
+  else if ((long)grid.x * grid.y >= p3_block_slots()) hipLaunchKernelGGL((k_gemm_p3<1, 0>), grid, dim3(kThreads), 0, st, g);   // (see P3_EARLY)
+  else hipLaunchKernelGGL((k_gemm_p3<1, 2>), grid, dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
 }
 
@@ -3107,8 +3124,10 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   p.tiles0 = p.tx0 * ((a.e.M + 127) / 128);
   const int tiles1 = p.tx1 * ((b.e.M + 127) / 128);
   p.tiles1 = tiles1;
-  if (a.fmt) hipLaunchKernelGGL(k_gemm_p3_pair<1>, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
-  else hipLaunchKernelGGL(k_gemm_p3_pair<0>, dim3(p.tiles0 + tiles1), dim3(kThreads), 0, st, p);
+  const dim3 grid(p.tiles0 + tiles1);
+  if (!a.fmt) hipLaunchKernelGGL((k_gemm_p3_pair<0, 2>), grid, dim3(kThreads), 0, st, p);
+  else if ((p.tiles0 + tiles1) / 2 >= p3_block_slots()) hipLaunchKernelGGL((k_gemm_p3_pair<1, 0>), grid, dim3(kThreads), 0, st, p);
+  else hipLaunchKernelGGL((k_gemm_p3_pair<1, 2>), grid, dim3(kThreads), 0, st, p);        // (half of the factor-update tiles are copies)
   return (int)hipGetLastError();
 }
 
@@ -3147,8 +3166,9 @@ static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsi
   }
   if (p.nsplit && hipMemsetAsync(cnt, 0, (size_t)p.nsplit * 4, st) != hipSuccess) return 1;
   const dim3 grid(p.n0 + p.n1 - p.nsplit + p.nsplit * p.nchunk);
-  if (a.fmt) hipLaunchKernelGGL(k_gemm_p3_grad<1>, grid, dim3(kThreads), 0, st, p);
-  else hipLaunchKernelGGL(k_gemm_p3_grad<0>, grid, dim3(kThreads), 0, st, p);
+  if (!a.fmt) hipLaunchKernelGGL((k_gemm_p3_grad<0, 2>), grid, dim3(kThreads), 0, st, p);
+  else if (p.n0 + p.n1 >= slots) hipLaunchKernelGGL((k_gemm_p3_grad<1, 0>), grid, dim3(kThreads), 0, st, p);
+  else hipLaunchKernelGGL((k_gemm_p3_grad<1, 2>), grid, dim3(kThreads), 0, st, p);
   return (int)hipGetLastError();
 }
 
@@ -3334,14 +3354,17 @@ static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st)
   const int tb = b / 128, pairs = (n + 2 * b - 1) / (2 * b);
   P3Args g1 = p3_args(f.Ir, f.Qc, n, n, n, KLO_M | KBLK_HI_M);                     // T = A^-1 B
   g1.e.kblk = 2 * b; g1.e.C = f.Tf; g1.e.ldc = n; g1.ometa = f.mT + level;
-  hipLaunchKernelGGL(k_gemm_p3_blk<1>, dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
+  const bool full = pairs * tb * tb >= p3_block_slots() / 2;                        // (two inversions share the chip)
+  if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
+  else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
   if (hipGetLastError() != hipSuccess) return 1;
   P3Buf tp = f.Tp;
   tp.meta = f.mT + level; tp.part = &tp.meta->amax; tp.npart = 1;
   if ((e = launch_split3(f.Tf, n, 1, n, n, tp, st, SplitOpt{0, 2 * b, 1, 1}))) return e;              // planes of -T
   P3Args g2 = p3_args(tp, f.Ic, n, n, n, KHI_N | KBLK_LO_N);                       // W = (-T) C^-1 into Inv
   g2.e.kblk = 2 * b; g2.e.C = f.Inv; g2.e.ldc = n; g2.ometa = f.Ir.meta;
-  hipLaunchKernelGGL(k_gemm_p3_blk<1>, dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
+  if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
+  else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
   return (int)hipGetLastError();
 }
 static int tri_inverse_planes(const InvSide& f, hipStream_t st) {     // column-form planes of the whole inverse: (x, k) = Inv[k][x], k <= x
