@@ -131,8 +131,14 @@ int main(int argc, char** argv) {
   {   // the two factor updates of the Kron update (K = [m0, n0 + 128): work = distance from the diagonal), as one grid
     __bf16 *PA, *PB;
     hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
-    const P3Buf a = {PA, n, n}, b = {PB, n, n};
+    PlaneMeta* pm2; float* part2;
+    hipMalloc(&pm2, 64 * sizeof(PlaneMeta)); hipMalloc(&part2, 4 * 2048 * 4);
+    hipMemset(pm2, 0, 64 * sizeof(PlaneMeta));
+    const bool f16 = getenv("PAIR_F16") != nullptr;          // PAIR_F16=1: the same leg on f16 x 2 planes
+    P3Buf a = {PA, n, n, f16 ? pm2 : nullptr}, b = {PB, n, n, f16 ? pm2 + 1 : nullptr};
+    if (f16) launch_absmax(A, (long)n * n, a, part2, 0);
     launch_split3(A, n, 1, n, n, a, 0);
+    if (f16) launch_absmax(B, (long)n * n, b, part2, 0);
     launch_split3(B, 1, n, n, n, b, 0);
     float* scal; hipMalloc(&scal, 256); hipMemset(scal, 0, 256);
     for (int variant = 0; variant < 3; ++variant) {
