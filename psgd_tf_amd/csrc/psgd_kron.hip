@@ -718,6 +718,10 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr3_t;
 // 4096^3 0.305-0.324 -> 0.282 ms, triangular K ranges 0.166 -> 0.157, the gradient grid at 6144^2 2.53 -> 2.33, at 2048^2
 // 0.151 -> 0.128) -- smaller ones keep two (a lone workgroup per CU loses 3-5 % without: 1024^3 0.036 -> 0.037, 1000^2 apply
 // 0.124 -> 0.131).  A run-time switch inside the loop instead of two instantiations cost 35 % (4096^2 apply 0.78 -> 1.11 ms).
+// Per kernel and size (tuning key 19 forces a form; micro bench, ms, none / two): plain product 2048^3 0.065 / 0.063, 2560^3 0.087 /
+// 0.098, 4096^3 0.285 / 0.310; gradient grid 1536^2 0.095 / 0.093, 2048^2 0.128 / 0.151, 2560^2 0.173 / 0.193, 4096^2 0.760 / 0.761;
+// factor-update pair 2048^2 0.063 / 0.063, 2560^2 0.089 / 0.098, 4096^2 0.188 / 0.208 -- hence "none" from 3/4 of the block slots on
+// (products, pair) and from half of them on (gradient grid).
 constexpr int p3_early(int FMT, int ER) { return FMT ? ER : P3_EARLY; }
 
 // LDS of the plane kernels, ONE object (a second __shared__ object makes hipcc guard its accesses with vmcnt(0) while DMA
@@ -2896,6 +2900,8 @@ static void p3_out_meta(P3Args& g, const P3Buf& C) {
 static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; p3_out_meta(g, C); }
 static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; p3_out_meta(g, Ct); }
 
+static int g_force_er = -1;     // tuning key 19: -1 = the launchers choose the form of the f16 x 2 kernels (P3_EARLY), 0 / 2 = always that one
+static inline bool p3_no_early(bool auto_choice) { return g_force_er < 0 ? auto_choice : g_force_er == 0; }
 static int p3_block_slots() {           // two resident blocks per CU
   static int slots = 0;
   if (!slots) {
@@ -2908,7 +2914,7 @@ static int p3_block_slots() {           // two resident blocks per CU
 static int launch_p3(const P3Args& g, hipStream_t st) {
   const dim3 grid((g.e.N + 127) / 128, (g.e.M + 127) / 128);
   if (!g.fmt) hipLaunchKernelGGL((k_gemm_p3<0, 2>), grid, dim3(kThreads), 0, st, g);
-  else if ((long)grid.x * grid.y >= p3_block_slots()) hipLaunchKernelGGL((k_gemm_p3<1, 0>), grid, dim3(kThreads), 0, st, g);   // (see P3_EARLY)
+  else if (p3_no_early((long)grid.x * grid.y >= p3_block_slots() * 3 / 4)) hipLaunchKernelGGL((k_gemm_p3<1, 0>), grid, dim3(kThreads), 0, st, g);   // (see P3_EARLY)
   else hipLaunchKernelGGL((k_gemm_p3<1, 2>), grid, dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
 }
@@ -3126,7 +3132,7 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   p.tiles1 = tiles1;
   const dim3 grid(p.tiles0 + tiles1);
   if (!a.fmt) hipLaunchKernelGGL((k_gemm_p3_pair<0, 2>), grid, dim3(kThreads), 0, st, p);
-  else if ((p.tiles0 + tiles1) / 2 >= p3_block_slots()) hipLaunchKernelGGL((k_gemm_p3_pair<1, 0>), grid, dim3(kThreads), 0, st, p);
+  else if (p3_no_early((p.tiles0 + tiles1) / 2 >= p3_block_slots() * 3 / 4)) hipLaunchKernelGGL((k_gemm_p3_pair<1, 0>), grid, dim3(kThreads), 0, st, p);
   else hipLaunchKernelGGL((k_gemm_p3_pair<1, 2>), grid, dim3(kThreads), 0, st, p);        // (half of the factor-update tiles are copies)
   return (int)hipGetLastError();
 }
@@ -3167,7 +3173,7 @@ static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsi
   if (p.nsplit && hipMemsetAsync(cnt, 0, (size_t)p.nsplit * 4, st) != hipSuccess) return 1;
   const dim3 grid(p.n0 + p.n1 - p.nsplit + p.nsplit * p.nchunk);
   if (!a.fmt) hipLaunchKernelGGL((k_gemm_p3_grad<0, 2>), grid, dim3(kThreads), 0, st, p);
-  else if (p.n0 + p.n1 >= slots) hipLaunchKernelGGL((k_gemm_p3_grad<1, 0>), grid, dim3(kThreads), 0, st, p);
+  else if (p3_no_early(p.n0 + p.n1 >= slots / 2)) hipLaunchKernelGGL((k_gemm_p3_grad<1, 0>), grid, dim3(kThreads), 0, st, p);
   else hipLaunchKernelGGL((k_gemm_p3_grad<1, 2>), grid, dim3(kThreads), 0, st, p);
   return (int)hipGetLastError();
 }
@@ -3354,7 +3360,7 @@ static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st)
   const int tb = b / 128, pairs = (n + 2 * b - 1) / (2 * b);
   P3Args g1 = p3_args(f.Ir, f.Qc, n, n, n, KLO_M | KBLK_HI_M);                     // T = A^-1 B
   g1.e.kblk = 2 * b; g1.e.C = f.Tf; g1.e.ldc = n; g1.ometa = f.mT + level;
-  const bool full = pairs * tb * tb >= p3_block_slots() / 2;                        // (two inversions share the chip)
+  const bool full = p3_no_early(pairs * tb * tb >= p3_block_slots() / 2);           // (two inversions share the chip)
   if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
   else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
   if (hipGetLastError() != hipSuccess) return 1;
@@ -3567,6 +3573,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 15) { g_trsm_planes_min_n = value; return PSGD_OK; }
   if (key == 16) { g_planes_exact = value; return PSGD_OK; }
   if (key == 17) { g_grad_order = value; return PSGD_OK; }
+  if (key == 19) { g_force_er = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
