@@ -127,6 +127,18 @@ int main(int argc, char** argv) {
     ms /= 20;
     printf("X3_DBG=%d  %d^2  gradient grid on f16 x 2 planes (k_gemm_p3_grad<1>, both gradients)  %.3f ms  (%.0f issued f16 TFLOP/s)\n", X3_DBG, n, ms,
            3.0 * 2.0 * flop / ms * 1e-9);
+    if (getenv("GRAD_COLD")) {          // the same with the caches swept between the launches (1 GiB memset), the memsets timed alone too
+      char* junk; hipMalloc(&junk, (size_t)1 << 30);
+      float mset = 0.f, both = 0.f;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 10; ++i) hipMemsetAsync(junk, i, (size_t)1 << 30, 0);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&mset, e0, e1);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 10; ++i) { hipMemsetAsync(junk, i, (size_t)1 << 30, 0); launch_p3_grad(s2, s3, scratch, cnt, 0); }
+      hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&both, e0, e1);
+      printf("    ... behind a 1 GiB memset each time: %.3f ms per launch (memset alone %.3f ms)\n", (both - mset) / 10, mset / 10);
+      hipFree(junk);
+    }
   }
   {   // the two factor updates of the Kron update (K = [m0, n0 + 128): work = distance from the diagonal), as one grid
     __bf16 *PA, *PB;
