@@ -267,9 +267,9 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * key 8: plane products with few output tiles (at most 80 and K >= 2048, or at most 44 and K >= 1024; e.g. 64 x 8192,
  *        200 x 1700): 1 (default) every tile's K range is dealt to up to 8 blocks (partials summed in chunk order);
  *        0 = one block per tile.
- * key 6: large fp32 update, M = N: 1 = the last tiles of the gradient grid are split along K over the block
- *        slots a short last round would leave idle (partials summed in a fixed order by the last block to arrive); 0 (default
- *        since the f16 x 2 planes: it stopped paying) = whole tiles only.
+ * key 6: large fp32 update, M = N: 1 (default) the last tiles of the gradient grid are split along K over the block
+ *        slots a short last round (at most an eighth of them) would leave idle (partials summed in a fixed order by the last
+ *        block to arrive); 0 = whole tiles only.
  * key 7 (bits, default 3): bit 0: in the batched update of small layers each stage of the products dG QrS' -> QlS (.)
  *        (psgd.py:173) shares its launch with the same stage of the solves (:174) -- the two chains only meet at the
  *        gradient pair; bit 1: psgd_kron_dd_update_f32 with M, N <= 512 takes that batched route as a batch of one

@@ -1001,17 +1001,28 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
     p3_pass<FMT, ER>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc);
     f32x4* mine = reinterpret_cast<f32x4*>(sp.scratch) + (long)sp.chunk * (16 * kThreads);
     const float pa = p ? -ia2 : ia1, pb = p ? ib2 : ib1;   // partials are stored as real values (f16 x 2: each pair has its own scale)
+    // Hand-off (the fused bf16 pair's recipe): the partial goes out write-through (8-byte agent-scope stores), every wave
+    // drains its stores, the block's barrier, one lane takes the ticket; the last block to arrive does one agent-scope
+    // acquire.  A __threadfence() here instead is a release of the WHOLE L2 (buffer_wbl2) per block: it made a split item
+    // cost ~100 us more than its K steps (3072^2 gradient grid with 1408 items: 0.745 ms against 0.363 unsplit).
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * kThreads + threadIdx.x] = (acc[i][j] * pa) * pb;
-    __threadfence();                                   // the partial is visible device-wide before the ticket is taken
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = (acc[i][j] * pa) * pb;
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(mine + (i * 4 + j) * kThreads + threadIdx.x);
+        __hip_atomic_store(q, (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) L.ticket[0] = atomicAdd(sp.cnt, 1u);
+    if (threadIdx.x == 0) L.ticket[0] = __hip_atomic_fetch_add(sp.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (L.ticket[0] != (unsigned)(sp.nchunk - 1)) return;
-    __threadfence();                                   // acquire: the other blocks' partials
-    if (threadIdx.x == 0) *sp.cnt = 0u;                // ready for the next call
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other blocks' partials
+    if (threadIdx.x == 0) __hip_atomic_store(sp.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -3137,10 +3148,10 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-static int g_grad_split = 0;    // tuning key 6: 1 = K split of the gradient grid's tail.  On the bf16 x 3 planes of round 2 it was worth 0.11 ms of
-                                // 1.55 at 4096^2; on the f16 x 2 planes with the XCD-contiguous tile order it never pays and costs up to 2x of
-                                // the launch where the last round is long (profiles/r03_grad_grid_isolated.txt: 3072^2 0.745 vs 0.363 ms,
-                                // 5120^2 1.97 vs 1.48; whole update 3072^2 2.04 -> 1.69 ms, 5120^2 5.75 -> 5.34, 4096^2 3.02 -> 2.96)
+static int g_grad_split = 1;    // tuning key 6: 0 = no K split of the gradient grid's tail.  (While the split's hand-off was a __threadfence() per
+                                // block -- a release of the whole L2 -- it cost more than it saved on the f16 x 2 planes and was off for a
+                                // while: profiles/r03_grad_grid_isolated.txt.  With the write-through hand-off: 4096^2 0.762 -> 0.665 ms,
+                                // 2944^2 0.365 -> 0.328; a long last round is still better left whole: 3072^2 0.376 -> 0.440.)
 static int g_grad_order = 1;    // tuning key 17: tile order of the gradient grid for M = N (see k_gemm_p3_grad; tools/grad_order_ab.py:
                                 // 4096^2 update 2.95-2.98 -> 2.87-2.88 ms, 6144^2 8.5 -> 8.3; patches of 4 x 4 tiles (2) are no better:
                                 // L2 locality is not what bounds this grid; 2048 x 4096 loses 9 % with either)
@@ -3159,11 +3170,11 @@ static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsi
   p.order = a.e.K == b.e.K ? g_grad_order : 0;       // (M != N: the two products' tiles cost differently, contiguous runs unbalance the XCDs)
   const int rem = (p.n0 + p.n1) % slots;
   p.nsplit = 0;
-  // a short last round (at most a quarter of the slots): twice that many tiles become eighth-size items, which the idle
+  // a short last round (at most an eighth of the slots): twice that many tiles become eighth-size items, which the idle
   // slots of the last full round and one short extra round absorb
   // (only when the tiles of both products cost the same, M = N: measured -0.11 ms of 1.55 at 4096^2 -- blocks of a thin last
   // round run faster than the model's, each has its SIMDs to itself -- and +0.3 ms at 3000 x 5000, where they do not)
-  if (g_grad_split && scratch && a.e.K == b.e.K && rem > 0 && rem <= slots / 4 && p.n0 + p.n1 > slots) {
+  if (g_grad_split && scratch && a.e.K == b.e.K && rem > 0 && rem <= slots / 8 && p.n0 + p.n1 > slots) {
     p.nsplit = 2 * rem;
     if (p.nsplit > p.n1) p.nsplit = p.n1;
     if (p.nsplit > kGradSplitMax) p.nsplit = kGradSplitMax;

@@ -712,7 +712,7 @@ def test_gradient_grid_k_split_is_deterministic_and_equivalent(psgd):
             lib.psgd_kron_set_tuning(6, split)
             outs.append(psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01))
     finally:
-        lib.psgd_kron_set_tuning(6, 0)                         # (off by default since the f16 x 2 planes: it stopped paying)
+        lib.psgd_kron_set_tuning(6, 1)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     rho = torch.sqrt(Ql.diagonal().max() / Qr.diagonal().max())
     for a, b, base in ((outs[0][0], outs[2][0], Ql / rho), (outs[0][1], outs[2][1], Qr * rho)):

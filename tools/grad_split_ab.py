@@ -29,4 +29,4 @@ if __name__ == "__main__":
             print("Kron fp32 update %dx%d split=%d: %.3f ms, repeatable %s" % (M, N, split, t, same))
         d = max(((x - y).norm() / y.norm()).item() for x, y in zip(outs[1], outs[0]))
         print("      rel diff of the factors split vs whole: %.1e" % d)
-    lib.psgd_kron_set_tuning(6, 0)
+    lib.psgd_kron_set_tuning(6, 1)

@@ -127,6 +127,25 @@ int main(int argc, char** argv) {
     ms /= 20;
     printf("X3_DBG=%d  %d^2  gradient grid on f16 x 2 planes (k_gemm_p3_grad<1>, both gradients)  %.3f ms  (%.0f issued f16 TFLOP/s)\n", X3_DBG, n, ms,
            3.0 * 2.0 * flop / ms * 1e-9);
+    if (getenv("GRAD_WHATIF")) {        // where the grid's time goes: without the fp32 store, with one operand pair only
+      auto timeit = [&](P3Args x, P3Args y, const char* what) {
+        for (int i = 0; i < 3; ++i) launch_p3_grad(x, y, scratch, cnt, 0);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 20; ++i) launch_p3_grad(x, y, scratch, cnt, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float t = 0.f; hipEventElapsedTime(&t, e0, e1);
+        printf("    ... %s: %.3f ms\n", what, t / 20);
+      };
+      P3Args a2 = s2, a3 = s3;
+      a2.e.C = nullptr; a3.e.C = nullptr;
+      timeit(a2, a3, "no fp32 store (triu + max on the registers only)");
+      P3Args b2 = s2, b3 = s3;
+      b2.e.A2 = nullptr; b3.e.A2 = nullptr;
+      timeit(b2, b3, "one operand pair (A A' only)");
+      P3Args c2 = p3_args(Ar, Ar, n, n, n, 0), c3 = p3_args(Ac, Ac, n, n, n, 0);
+      c2.e.C = G1; c2.e.ldc = n; c3.e.C = G2; c3.e.ldc = n;
+      timeit(c2, c3, "one operand pair, plain store of the upper tiles");
+    }
     if (getenv("GRAD_COLD")) {          // the same with the caches swept between the launches (1 GiB memset), the memsets timed alone too
       char* junk; hipMalloc(&junk, (size_t)1 << 30);
       float mset = 0.f, both = 0.f;
