@@ -2943,8 +2943,10 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
   // tiles they do not (1000^2: 0.156 -> 0.195 with chunks of 16), chunks of 32 from K = 2048 on do.
   static const int env_steps = getenv("PSGD_SPLITK_MIN_STEPS") ? atoi(getenv("PSGD_SPLITK_MIN_STEPS")) : 0;     // (env: A/B runs)
   static const int env_chunk = getenv("PSGD_SPLITK_CHUNK") ? atoi(getenv("PSGD_SPLITK_CHUNK")) : 0;
-  const int min_steps = env_steps ? env_steps : (tiles <= 44 ? 32 : 64);
-  const int min_chunk = env_chunk ? env_chunk : ((tiles <= 44 && steps < 72) ? 16 : 32);   // (128 x 4096: 4 chunks of 32 beat 8 of 16)
+  // (round 3, after the split's hand-off stopped releasing the whole L2: the stricter rule for 45 .. 80 tiles -- 64 steps, chunks of
+  //  32 -- is gone: 500 x 1700 apply 0.147 -> 0.129 ms, 900 x 1400 update 0.60 -> 0.53; chunks of 8 steps still lose 20 %)
+  const int min_steps = env_steps ? env_steps : 32;
+  const int min_chunk = env_chunk ? env_chunk : (steps < 72 ? 16 : 32);   // (128 x 4096: 4 chunks of 32 beat 8 of 16)
   int nchunk = (!g_splitk || !scratch || g.e.A2 || g.e.sym || tiles > 80 || steps < min_steps) ? 1 : kSkItems / tiles;
   if (nchunk > 8) nchunk = 8;
   while (nchunk > 1 && steps / nchunk < min_chunk) --nchunk;
