@@ -291,6 +291,10 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * key 16: f16 x 2 planes of a product that feeds the next product: 1 (default) the product writes fp32 and its max|C|, a
  *        split launch makes the planes with that exact scale; 0 = the product's epilogue writes the planes with a scale from
  *        the bound K max|A| max|B| (faster by a launch per intermediate; loses accuracy on ill-conditioned factors).
+ * key 19: form of the f16 x 2 plane kernels: -1 (default) chosen per launch by the grid size, 0 / 2 = always that many MFMA
+ *        columns ahead of the buffer-free barrier.
+ * key 20: sparse formats: 1 (default) data-sized products against a dense factor (>= 512, data >= 1M elements) run on f16 x 2
+ *        operand planes, 0 = on the in-GEMM split kernels.
  * key 17: gradient grid of the large fp32 update with M = N: 1 (default) every XCD works through a contiguous run of the
  *        tile list, 2 = over 4 x 4 tile patches, 0 = tiles dealt to the XCDs one by one. */
 int psgd_kron_set_tuning(int key, int value);

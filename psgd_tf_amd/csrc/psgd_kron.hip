@@ -2911,6 +2911,7 @@ static void p3_out_meta(P3Args& g, const P3Buf& C) {
 static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; p3_out_meta(g, C); }
 static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; p3_out_meta(g, Ct); }
 
+static int g_sparse_planes = 1;     // tuning key 20: 0 = every product of the sparse formats on launch_gemm (see sparse_gemm)
 static int g_force_er = -1;     // tuning key 19: -1 = the launchers choose the form of the f16 x 2 kernels (P3_EARLY), 0 / 2 = always that one
 static inline bool p3_no_early(bool auto_choice) { return g_force_er < 0 ? auto_choice : g_force_er == 0; }
 static int p3_block_slots() {           // two resident blocks per CU
@@ -3587,6 +3588,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 16) { g_planes_exact = value; return PSGD_OK; }
   if (key == 17) { g_grad_order = value; return PSGD_OK; }
   if (key == 19) { g_force_er = value; return PSGD_OK; }
+  if (key == 20) { g_sparse_planes = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -3902,6 +3904,8 @@ struct SparseWs {
   float *scal, *LS, *RS, *T, *A, *Bt, *gsq, *v0, *v1, *v2, *v3, *dinv, *cpart;
   __bf16 *P0, *P1;              // operand planes of the dense factor's gradient when it is a few tiles with a long K
   float* sk_scratch; unsigned* sk_cnt;
+  // f16 x 2 operand planes for the data-sized products (sparse_gemm): two sets (caller's stream, side stream) of an A and a B buffer
+  __bf16* GP[2][2]; PlaneMeta* gmeta; float* gpart; int64_t gcap;
   int64_t total;
 };
 
@@ -3935,6 +3939,16 @@ static SparseWs sparse_layout(char* base, int fmt, int M, int N) {
     k.P0 = reinterpret_cast<__bf16*>(take(pb)); k.P1 = reinterpret_cast<__bf16*>(take(pb));
     k.sk_scratch = take((int64_t)kSplitkScratchTiles * 64 * kThreads * 4);
     k.sk_cnt = reinterpret_cast<unsigned*>(take(kSplitkMaxTiles * 4));
+  }
+  k.gmeta = nullptr; k.gpart = nullptr; k.gcap = 0;
+  k.GP[0][0] = k.GP[0][1] = k.GP[1][0] = k.GP[1][1] = nullptr;
+  if (fmt != 2 && grows >= 512 && (int64_t)M * N >= (int64_t)1 << 20) {      // a dense factor worth the planes (sparse_gemm)
+    const int64_t Mp = pad128(M), Np = pad128(N), dp = pad128(grows);
+    k.gcap = Mp * Np > dp * dp ? Mp * Np : dp * dp;
+    for (int s = 0; s < 2; ++s)
+      for (int o = 0; o < 2; ++o) k.GP[s][o] = reinterpret_cast<__bf16*>(take(k.gcap * 4));
+    k.gmeta = reinterpret_cast<PlaneMeta*>(take(256));
+    k.gpart = take(4 * kPmPartMax * 4);
   }
   k.total = off;
   return k;
@@ -3983,6 +3997,31 @@ static int sparse_grad_splitk(const SparseWs& k, const float* X, const float* Y,
   return (int)hipGetLastError();
 }
 
+// One product of a sparse-format flow.  Data-sized products against a dense factor (an embedding's 1000 x 1000 factor times
+// its 1000 x 30000 gradient) run on f16 x 2 operand planes like the dense (x) dense paths: both operands are split once
+// (absmax + split each: four memory-bound launches) and the product is a plane GEMM with the fp32 epilogue of the caller's
+// GemmArgs (column scales, D - A B, ...); the in-GEMM split kernel re-splits an operand element once per tile column it meets.
+// set: 0 = the caller's stream, 1 = the side stream (their own plane buffers).  Small products, second operand pairs and views
+// without a unit stride stay on launch_gemm.
+static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int set = 0) {
+  const bool unit = (g.a_rs == 1 || g.a_cs == 1) && (g.b_rs == 1 || g.b_cs == 1);
+  const int64_t Mp = pad128(g.M), Np = pad128(g.N), Kp = pad128(g.K);
+  const bool fits = k.gcap > 0 && Mp * Kp <= k.gcap && Np * Kp <= k.gcap;
+  const bool big = (double)g.M * g.N * g.K >= 4e9 && g.M >= 256 && g.N >= 256 && g.K >= 256;
+  if (!g_sparse_planes || !g_planes || !g_gemm_x3 || !g_planes_f16 || g.A2 || g.sym || !unit || !fits || !big) return launch_gemm(g, st);
+  P3Buf A = {k.GP[set][0], Mp, Kp, k.gmeta + 2 * set}, B = {k.GP[set][1], Np, Kp, k.gmeta + 2 * set + 1};
+  float* part = k.gpart + (long)set * 2 * kPmPartMax;
+  int e;
+  if ((e = launch_absmax_view(g.A, g.a_rs, g.a_cs, g.M, g.K, A, part, st))) return e;
+  if ((e = launch_split3(g.A, g.a_rs, g.a_cs, g.M, g.K, A, st))) return e;                     // (x, k) = A(m, k)
+  if ((e = launch_absmax_view(g.B, g.b_cs, g.b_rs, g.N, g.K, B, part + kPmPartMax, st))) return e;
+  if ((e = launch_split3(g.B, g.b_cs, g.b_rs, g.N, g.K, B, st))) return e;                     // (x, k) = B(k, n)
+  P3Args p = p3_args(A, B, g.M, g.N, g.K, g.kmode);
+  p.e = g;
+  p.e.A2 = nullptr; p.e.kblk = 0;
+  return launch_p3_auto(p, k.sk_scratch, k.sk_cnt, st);
+}
+
 static inline int ew_grid(long tot) {
   long g = (tot + kThreads - 1) / kThreads;
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -4029,7 +4068,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
     GemmArgs g = gemm_args(k.LS, M, false, dG, 0, false, k.A, N, M, N, M, KLO_M);
     g.b_rs = xrs; g.b_cs = xcs;
     g.colv = k.RS;
-    KRON_LAUNCH(launch_gemm(g, fk ? fk->side : st));
+    KRON_LAUNCH(sparse_gemm(k, g, fk ? fk->side : st, fk ? 1 : 0));
   }
   // Bt = (QlS^-T dX) .* (1/qrS)                             (:298-299); columns independent
   KRON_LAUNCH(trsm_ut(k.LS, M, dX, k.Bt, N, 1L, (long)N, k.dinv, st, (long)xcs, (long)xrs));
@@ -4041,7 +4080,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
     GemmArgs g = gemm_args(k.A, N, false, k.A, N, true, k.gsq, M, M, M, N);
     g.A2 = k.Bt; g.a2_rs = N; g.a2_cs = 1; g.B2 = k.Bt; g.b2_rs = 1; g.b2_cs = N; g.K2 = N;
     g.epi = EPI_TRIU_MAX; g.maxout = k.scal;
-    KRON_LAUNCH(launch_gemm(g, st));
+    KRON_LAUNCH(sparse_gemm(k, g, st));
   }
   {                                                          // grad2 = colsum(A^2) - colsum(Bt^2)   (:304)
     MatView a = {k.A, N, 1}, b = {k.Bt, N, 1};
@@ -4050,7 +4089,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
   {                                                          // Ql - (step1 grad1) Ql         (:307)
     GemmArgs g = gemm_args(k.gsq, M, false, k.LS, M, false, QlOut, M, M, M, M, KLO_M | KHI_N);
     g.epi = EPI_D_MINUS; g.D = k.LS; g.ldd = M; g.scale_max = k.scal; g.step = step; g.tiny = tiny;
-    KRON_LAUNCH(launch_gemm(g, st));
+    KRON_LAUNCH(sparse_gemm(k, g, st));
   }
   SP_LAUNCH_WIDE(k_scale_finalize, k.RS, k.v0, N, step, tiny, qrOut);
   return PSGD_OK;
@@ -4065,17 +4104,17 @@ int psgd_kron_ds_apply_f32(const float* Ql, const float* qr, const float* G, int
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (M < N) {                                               // (Ql'Ql) G                     (:318-319)
-    KRON_LAUNCH(launch_gemm(gemm_args(Ql, M, true, Ql, M, false, k.gsq, M, M, M, M, KHI_M | KHI_N), st));
+    KRON_LAUNCH(sparse_gemm(k, gemm_args(Ql, M, true, Ql, M, false, k.gsq, M, M, M, M, KHI_M | KHI_N), st));
     GemmArgs g = gemm_args(k.gsq, M, false, G, 0, false, out, N, M, N, M);
     g.b_rs = grs; g.b_cs = gcs; g.colv = qr; g.colsq = 1;
-    KRON_LAUNCH(launch_gemm(g, st));
+    KRON_LAUNCH(sparse_gemm(k, g, st));
   } else {                                                   // Ql' (Ql G)                    (:320-321)
     GemmArgs g1 = gemm_args(Ql, M, false, G, 0, false, k.T, N, M, N, M, KLO_M);
     g1.b_rs = grs; g1.b_cs = gcs;
-    KRON_LAUNCH(launch_gemm(g1, st));
+    KRON_LAUNCH(sparse_gemm(k, g1, st));
     GemmArgs g2 = gemm_args(Ql, M, true, k.T, N, false, out, N, M, N, M, KHI_M);
     g2.colv = qr; g2.colsq = 1;                              // .* (qr qr)                     (:322)
-    KRON_LAUNCH(launch_gemm(g2, st));
+    KRON_LAUNCH(sparse_gemm(k, g2, st));
   }
   return PSGD_OK;
 }
@@ -4113,7 +4152,7 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
     hipLaunchKernelGGL(k_norm_left, dim3(ew_grid((long)M * N)), dim3(kThreads), 0, sf, vg, (const float*)k.LS,
                        (const float*)(k.LS + M), M, N, (const float*)nullptr, 0, k.T);
     if (hipGetLastError() != hipSuccess) return PSGD_ERR_LAUNCH;
-    KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), sf));   // A = T QrS'  (:220)
+    KRON_LAUNCH(sparse_gemm(k, gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), sf, fk ? 1 : 0));   // A = T QrS'  (:220)
   }
   {
     MatView vx = {dX, xrs, xcs};
@@ -4130,12 +4169,12 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
     GemmArgs g = gemm_args(k.A, N, true, k.A, N, false, k.gsq, N, N, N, M);
     g.A2 = k.Bt; g.a2_rs = 1; g.a2_cs = N; g.B2 = k.Bt; g.b2_rs = N; g.b2_cs = 1; g.K2 = M;
     g.epi = EPI_TRIU_MAX; g.maxout = k.scal;
-    KRON_LAUNCH(launch_gemm(g, st));
+    KRON_LAUNCH(sparse_gemm(k, g, st));
   }
   {                                                          // Qr - (step2 grad2) Qr         (:246)
     GemmArgs g = gemm_args(k.gsq, N, false, k.RS, N, false, QrOut, N, N, N, N, KLO_M | KHI_N);
     g.epi = EPI_D_MINUS; g.D = k.RS; g.ldd = N; g.scale_max = k.scal; g.step = step; g.tiny = tiny;
-    KRON_LAUNCH(launch_gemm(g, st));
+    KRON_LAUNCH(sparse_gemm(k, g, st));
   }
   return PSGD_OK;
 }
@@ -4151,11 +4190,11 @@ int psgd_kron_nd_apply_f32(const float* ql, const float* Qr, const float* G, int
   MatView vg = {G, grs, gcs};
   SP_LAUNCH(k_norm_left, ew_grid((long)M * N), vg, ql, ql + M, M, N, (const float*)nullptr, 0, k.T);   // Ql G (:258-259)
   if (M < N) {                                               // (P Qr') Qr                    (:260-261)
-    KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N, KLO_N), st));
-    KRON_LAUNCH(launch_gemm(gemm_args(k.A, N, false, Qr, N, false, k.Bt, N, M, N, N, KHI_N), st));
+    KRON_LAUNCH(sparse_gemm(k, gemm_args(k.T, N, false, Qr, N, true, k.A, N, M, N, N, KLO_N), st));
+    KRON_LAUNCH(sparse_gemm(k, gemm_args(k.A, N, false, Qr, N, false, k.Bt, N, M, N, N, KHI_N), st));
   } else {                                                   // P (Qr'Qr)                     (:263)
-    KRON_LAUNCH(launch_gemm(gemm_args(Qr, N, true, Qr, N, false, k.gsq, N, N, N, N, KHI_M | KHI_N), st));
-    KRON_LAUNCH(launch_gemm(gemm_args(k.T, N, false, k.gsq, N, false, k.Bt, N, M, N, N), st));
+    KRON_LAUNCH(sparse_gemm(k, gemm_args(Qr, N, true, Qr, N, false, k.gsq, N, N, N, N, KHI_M | KHI_N), st));
+    KRON_LAUNCH(sparse_gemm(k, gemm_args(k.T, N, false, k.gsq, N, false, k.Bt, N, M, N, N), st));
   }
   MatView vz = {k.Bt, N, 1};
   if (col_reduce(k, vz, vz, ql, ql + M, M, N, 1, k.v0, st)) return PSGD_ERR_LAUNCH;                      // (:265)

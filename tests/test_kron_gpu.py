@@ -956,6 +956,10 @@ BIG_FORMATS = [
     # reductions run over thousands of rows (row-blocked), the mirrored formats come in as transposed views
     ("norm_dense", (2, 5000), (300, 300)), ("dense_norm", (300, 300), (2, 5000)),
     ("dense_scale", (260, 260), (1, 4500)), ("scale_dense", (1, 4500), (260, 260)), ("norm_scale", (2, 6000), (1, 70)),
+    # a dense factor from 512 on with a data matrix of at least 1M elements: the data-sized products run on f16 x 2 operand
+    # planes (sparse_gemm), on the caller's stream and on the side stream
+    ("dense_scale", (1024, 1024), (1, 4100)), ("norm_dense", (2, 4000), (1100, 1100)), ("dense_norm", (1536, 1536), (2, 1500)),
+    ("scale_dense", (1, 1300), (2048, 2048)),
 ]
 
 
