@@ -3906,6 +3906,8 @@ struct SparseWs {
   float* sk_scratch; unsigned* sk_cnt;
   // f16 x 2 operand planes for the data-sized products (sparse_gemm): two sets (caller's stream, side stream) of an A and a B buffer
   __bf16* GP[2][2]; PlaneMeta* gmeta; float* gpart; int64_t gcap;
+  // the dense factor's solve through its explicit inverse when there are many vectors (sparse_solve): planes and fp32 of tri_inverse
+  __bf16 *IQc, *IIr, *IIc, *ITp; float *IInv, *ITf; PlaneMeta* imeta;
   int64_t total;
 };
 
@@ -3941,6 +3943,7 @@ static SparseWs sparse_layout(char* base, int fmt, int M, int N) {
     k.sk_cnt = reinterpret_cast<unsigned*>(take(kSplitkMaxTiles * 4));
   }
   k.gmeta = nullptr; k.gpart = nullptr; k.gcap = 0;
+  k.IQc = k.IIr = k.IIc = k.ITp = nullptr; k.IInv = k.ITf = nullptr; k.imeta = nullptr;
   k.GP[0][0] = k.GP[0][1] = k.GP[1][0] = k.GP[1][1] = nullptr;
   if (fmt != 2 && grows >= 512 && (int64_t)M * N >= (int64_t)1 << 20) {      // a dense factor worth the planes (sparse_gemm)
     const int64_t Mp = pad128(M), Np = pad128(N), dp = pad128(grows);
@@ -3948,7 +3951,11 @@ static SparseWs sparse_layout(char* base, int fmt, int M, int N) {
     for (int s = 0; s < 2; ++s)
       for (int o = 0; o < 2; ++o) k.GP[s][o] = reinterpret_cast<__bf16*>(take(k.gcap * 4));
     k.gmeta = reinterpret_cast<PlaneMeta*>(take(256));
-    k.gpart = take(4 * kPmPartMax * 4);
+    k.gpart = take(6 * kPmPartMax * 4);                     // (two per plane set, one for sparse_solve's factor)
+    k.IQc = reinterpret_cast<__bf16*>(take(dp * dp * 4)); k.IIr = reinterpret_cast<__bf16*>(take(dp * dp * 4));
+    k.IIc = reinterpret_cast<__bf16*>(take(dp * dp * 4)); k.ITp = reinterpret_cast<__bf16*>(take(dp * dp * 4));
+    k.IInv = take((int64_t)grows * grows * 4); k.ITf = take((int64_t)grows * grows * 4);
+    k.imeta = reinterpret_cast<PlaneMeta*>(take(256));
   }
   k.total = off;
   return k;
@@ -3997,6 +4004,16 @@ static int sparse_grad_splitk(const SparseWs& k, const float* X, const float* Y,
   return (int)hipGetLastError();
 }
 
+__global__ __launch_bounds__(kThreads) void k_zero_below_diag(float* __restrict__ A, int n) {
+  const long tot = (long)n * n;
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < tot; e += (long)gridDim.x * kThreads)
+    if (e % n < e / n) A[e] = 0.0f;
+}
+static inline int ew_grid_fwd(long tot) {
+  long g = (tot + kThreads - 1) / kThreads;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
 // One product of a sparse-format flow.  Data-sized products against a dense factor (an embedding's 1000 x 1000 factor times
 // its 1000 x 30000 gradient) run on f16 x 2 operand planes like the dense (x) dense paths: both operands are split once
 // (absmax + split each: four memory-bound launches) and the product is a plane GEMM with the fp32 epilogue of the caller's
@@ -4020,6 +4037,42 @@ static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int
   p.e = g;
   p.e.A2 = nullptr; p.e.kblk = 0;
   return launch_p3_auto(p, k.sk_scratch, k.sk_cnt, st);
+}
+
+// The solve y Q = x of a sparse-format flow (see trsm_ut for the arguments).  With many vectors per column of Q -- an embedding's
+// 30000 rows against its 1000 x 1000 factor -- the substitution strips are throughput-bound (1875 workgroups per strip: 0.83 ms
+// for the two strips and the update between them), and the solve is cheaper as ONE product with the explicit inverse (tri_inverse:
+// ~13 launches for n = 1000, then a plane product through sparse_gemm): from 8 vectors per column on, 512 <= n <= 8192.
+static int sparse_solve(const SparseWs& k, const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
+                        hipStream_t st, long xi = 0, long xj = 0) {
+  if (xi == 0 && xj == 0) { xi = si; xj = sj; }
+  const bool inv = g_sparse_planes && g_trsm_inv && g_planes && g_gemm_x3 && g_planes_f16 && k.IInv && n >= 512 && n <= 8192 &&
+                   (long)nvec >= 8L * n;
+  if (!inv) return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st, xi == si && xj == sj ? 0 : xi, xi == si && xj == sj ? 0 : xj);
+  const long np = pad128(n);
+  int e;
+  hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
+  if (hipGetLastError() != hipSuccess) return 1;
+  if (hipMemsetAsync(k.imeta, 0, 256, st) != hipSuccess) return 1;                      // (the running maxima start from zero)
+  P3Buf Qc = {k.IQc, np, np, k.imeta + 0};
+  if ((e = launch_absmax(Q, (long)n * n, Qc, k.gpart + 4 * kPmPartMax, st))) return e;
+  if ((e = launch_split3(Q, 1, n, n, n, Qc, st))) return e;                             // (x, k) = Q[k][x]
+  InvSide f = {Q, n, dinv, k.IInv, k.ITf, Qc, P3Buf{k.IIr, np, np, k.imeta + 1}, P3Buf{k.IIc, np, np, k.imeta + 1},
+               P3Buf{k.ITp, np, np, nullptr}, k.imeta + 2};
+  if ((e = tri_inverse_blocks(f, st))) return e;
+  int level = 0;
+  for (int b = 128; b < n; b *= 2, ++level)
+    if ((e = tri_inverse_level(f, b, level, st))) return e;
+  // the strict lower triangle of Inv was never written: the product's K range (k <= column) and the split's triangle mask
+  // would need it zero -- sparse_gemm splits the whole matrix, so clear it by writing the upper triangle's complement here
+  hipLaunchKernelGGL(k_zero_below_diag, dim3(ew_grid_fwd((long)n * n)), dim3(kThreads), 0, st, k.IInv, n);
+  if (hipGetLastError() != hipSuccess) return 1;
+  GemmArgs g = {};
+  g.A = X; g.a_rs = xi; g.a_cs = xj;
+  g.B = k.IInv; g.b_rs = n; g.b_cs = 1;
+  g.C = Y; g.ldc = si; g.c_cs = sj;
+  g.M = nvec; g.N = n; g.K = n; g.kmode = KHI_N; g.epi = EPI_STORE;
+  return sparse_gemm(k, g, st, 0);
 }
 
 static inline int ew_grid(long tot) {
@@ -4071,7 +4124,7 @@ int psgd_kron_ds_update_f32(const float* Ql, const float* qr, const float* dX, c
     KRON_LAUNCH(sparse_gemm(k, g, fk ? fk->side : st, fk ? 1 : 0));
   }
   // Bt = (QlS^-T dX) .* (1/qrS)                             (:298-299); columns independent
-  KRON_LAUNCH(trsm_ut(k.LS, M, dX, k.Bt, N, 1L, (long)N, k.dinv, st, (long)xcs, (long)xrs));
+  KRON_LAUNCH(sparse_solve(k, k.LS, M, dX, k.Bt, N, 1L, (long)N, k.dinv, st, (long)xcs, (long)xrs));
   SP_LAUNCH(k_col_inv_scale, ew_grid((long)M * N), k.Bt, k.RS, M, N);
   KRON_LAUNCH(fork_scope.join());
   if (k.P0 && g_planes && g_gemm_x3) {                       // grad1 = triu(A A' - Bt Bt')  (:301): few tiles, long K
@@ -4159,7 +4212,7 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
     if (col_reduce(k, vx, vx, k.LS, k.LS + M, M, N, 0, k.v0, st)) return PSGD_ERR_LAUNCH;
     SP_LAUNCH(k_norm_left_invT, ew_grid((long)M * N), vx, (const float*)k.LS, (const float*)k.v0, M, N, (const float*)nullptr, k.Bt);
   }
-  KRON_LAUNCH(trsm_ut(k.RS, N, k.Bt, k.Bt, M, (long)N, 1L, k.dinv, st));                   // Bt QrS^-1, in place  (:233)
+  KRON_LAUNCH(sparse_solve(k, k.RS, N, k.Bt, k.Bt, M, (long)N, 1L, k.dinv, st));             // Bt QrS^-1, in place  (:233)
   KRON_LAUNCH(fork_scope.join());
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.Bt, M, N, k.v1, k.v2);   // (:235-237)
   SP_LAUNCH_WIDE(k_norm_finalize, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);

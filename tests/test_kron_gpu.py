@@ -960,6 +960,8 @@ BIG_FORMATS = [
     # planes (sparse_gemm), on the caller's stream and on the side stream
     ("dense_scale", (1024, 1024), (1, 4100)), ("norm_dense", (2, 4000), (1100, 1100)), ("dense_norm", (1536, 1536), (2, 1500)),
     ("scale_dense", (1, 1300), (2048, 2048)),
+    # ... and at least 8 vectors per column of the dense factor: its solve runs as a product with the explicit inverse (sparse_solve)
+    ("norm_dense", (2, 5200), (600, 600)), ("dense_scale", (640, 640), (1, 5400)), ("dense_norm", (520, 520), (2, 4300)),
 ]
 
 
