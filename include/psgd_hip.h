@@ -279,7 +279,7 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  *        default-priority side stream (key 10: 0 lowest, 1 default, 2 highest priority; one per device and caller stream, made on first use) while the solves of :174 run on
  *        the caller's stream; the call forks and joins with events only (legal inside a stream capture), so to the caller
  *        it is still one stream-ordered operation.  0 = everything on the caller's stream.  Same kernels, same results.
- * key 11: large fp32 update on f16 x 2 planes with M, N >= 2048 (one of them larger; at most 8192): 1 (default) the two triangular
+ * key 11: large fp32 update on f16 x 2 planes with M, N >= 2048 (at most 8192): 1 (default) the two triangular
  *        solves of psgd.py:174 run as products with explicit inverses of the balanced factors (recursive doubling on the
  *        planes); 0 = substitution strips.
  * key 12: operand-plane format of the plane products (key 4): 2 (default) two fp16 planes and one power-of-two scale per

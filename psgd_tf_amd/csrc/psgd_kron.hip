@@ -2606,12 +2606,12 @@ static inline bool kron_planes(int M, int N) {          // the update, and the w
   return kron_planes_apply(M, N) || ((M > N ? M : N) >= 384 && kron_t128(M, N) >= 9);
 }
 static inline int pad128(int x) { return (x + 127) & ~127; }
-// The two triangular solves of the large fp32 update through explicit inverses (tri_inverse): both factors at least 2048 and one
-// larger -- below, a solve is a few strips and the inversion's chain of launches costs more than it saves (tools/trsm_inv_ab.py:
-// 4096^2 3.35 -> 2.94 ms, 2944^2 1.89 -> 1.70, 2048 x 4096 1.83 -> 1.70, 6144^2 9.35 -> 8.33, but 2048^2 0.87 -> 0.91, 1024^2
-// 0.34 -> 0.51, 8192 x 1024 3.87 -> 4.24).  A pure function of the shape (workspace).
+// The two triangular solves of the large fp32 update through explicit inverses (tri_inverse): both factors at least 2048 -- below,
+// a solve is a few strips and the inversion's chain of launches costs more than it saves (tools/trsm_inv_ab.py: 4096^2 3.35 -> 2.94
+// ms, 2944^2 1.89 -> 1.70, 2048 x 4096 1.83 -> 1.70, 6144^2 9.35 -> 8.33; at the end of the round, `mid`: 2048^2 0.895 -> 0.866,
+// 1792^2 0.789 -> 0.789, 1536^2 0.60 -> 0.71, 1024^2 0.35 -> 0.51, 2048 x 1024 0.62 -> 0.76).  A pure function of the shape (workspace).
 constexpr int kInvMinN = 2048;
-static inline bool kron_inv_route(int M, int N) { return M >= kInvMinN && N >= kInvMinN && (M > kInvMinN || N > kInvMinN); }
+static inline bool kron_inv_route(int M, int N) { return M >= kInvMinN && N >= kInvMinN; }
 
 static KronWs kron_layout(char* base, int M, int N) {
   KronWs k;

@@ -14,8 +14,10 @@ from tools.kron_f16_planes_ab import update_ref64, errs  # noqa: E402
 if __name__ == "__main__":
     lib = _lib.load()
     g = torch.Generator(device="cuda"); g.manual_seed(1)
-    for M, N in ((4096, 4096), (2048, 2048), (1024, 1024), (1300, 1100), (3000, 2048), (2048, 4096), (8192, 1024), (2944, 2944),
-                 (6144, 6144)):
+    shapes = ((4096, 4096), (2048, 2048), (1024, 1024), (1300, 1100), (3000, 2048), (2048, 4096), (8192, 1024), (2944, 2944), (6144, 6144))
+    if len(sys.argv) > 1 and sys.argv[1] == "mid":
+        shapes = ((1024, 1024), (1280, 1280), (1536, 1536), (1792, 1792), (2048, 2048), (1300, 1100), (1024, 4096), (1536, 3072), (2048, 1024))
+    for M, N in shapes:
         Ql, Qr = tri(M, g), tri(N, g)
         dX = torch.randn(M, N, device="cuda", generator=g)
         dG = dX * torch.exp(torch.rand(M, 1, device="cuda", generator=g) * 2 - 1) * torch.exp(torch.rand(1, N, device="cuda", generator=g) * 2 - 1)
