@@ -2061,13 +2061,16 @@ __device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const floa
   float qb[4][kIt][2][2][4], dvb[2][2][4][2];
   // slot `it` of the round of sub-step s (= block w + 4 ((s >> 2) + it)); slot 0 is loaded even when it is not behind
   // s (w <= s mod 4): the access pattern must not depend on the wave
+#ifndef TRSM_DBG
+#define TRSM_DBG 0      // what-if switches of tools/micro/x3_gemm_bench.hip (wrong results): 1 = every Q panel load from one line, 2 = no stores of Y
+#endif
 #define TRSM_LOAD_Q(S, QQ)                                                                              \
   _Pragma("unroll") for (int it = 0; it < kIt; ++it) {                                                  \
     if (((S) >> 2) + it < 4) {                                                                          \
       _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                     \
       _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                  \
       _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
-        QQ[it][h][mt][e] = qlane[(long)(32 * (S) + 16 * mt + e) * t.ldq + 128 * (((S) >> 2) + it) + 16 * h]; \
+        QQ[it][h][mt][e] = (TRSM_DBG & 1) ? qlane[16 * h + e] : qlane[(long)(32 * (S) + 16 * mt + e) * t.ldq + 128 * (((S) >> 2) + it) + 16 * h]; \
     }                                                                                                   \
   }
 #define TRSM_LOAD_D(R, DD)                                                                              \
@@ -2105,15 +2108,27 @@ __device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const floa
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) yn[mt][e] = Ybuf[u & 1][(mt * 4 + e) * 64 + lane];
-      // the solved block goes out from all four waves, two registers each (same store count on every path)
+      // the solved block (16 vectors x 32 columns) goes out from all four waves, two values per lane (same store count on every
+      // path).  Vectors as rows (sj == 1): every lane takes two NEIGHBOURING columns of one vector, read back from the LDS slot, so
+      // that 16 lanes write one 128-byte run -- with the register layout (lanes along the vectors) every store instruction of this
+      // case scattered 64 single floats over 16 rows, which was 17 us of the 51 a strip of 4096 vectors took (tools/micro,
+      // TRSM_DBG).  Vectors as columns (si == 1): the register layout is already the coalesced one (16 lanes = 64 bytes).
+      if (t.sj == 1 && !(t.si & 1) && !(reinterpret_cast<uintptr_t>(t.Y) & 7)) {
+        const int sv = threadIdx.x >> 4, c2 = (threadIdx.x & 15) * 2;                 // vector, first of its two columns
+        const int smt = c2 >> 4, sg = (c2 & 15) >> 2, se = c2 & 3;                   // c2 = 16 mt + 4 g + e (e = 0 or 2)
+        const float* src = &Ybuf[u & 1][(smt * 4 + se) * 64 + sg * 16 + sv];
+        const float2 val = make_float2(-src[0], -src[64]);
+        if (!(TRSM_DBG & 2)) *reinterpret_cast<float2*>(t.Y + (long)(v0 + sv) * t.si + 32 * s + c2) = val;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int mt = k, e = w;                       // register (mt, e = w)
-        float val = yn[mt][0];
-        if (e == 1) val = yn[mt][1];
-        if (e == 2) val = yn[mt][2];
-        if (e == 3) val = yn[mt][3];
-        t.Y[(long)v * t.si + (long)(32 * s + 16 * mt + 4 * g + e) * t.sj] = -val;
+        for (int k = 0; k < 2; ++k) {
+          const int mt = k, e = w;                       // register (mt, e = w)
+          float val = yn[mt][0];
+          if (e == 1) val = yn[mt][1];
+          if (e == 2) val = yn[mt][2];
+          if (e == 3) val = yn[mt][3];
+          if (!(TRSM_DBG & 2)) t.Y[(long)v * t.si + (long)(32 * s + 16 * mt + 4 * g + e) * t.sj] = -val;
+        }
       }
       if (s + 1 < kSub) {
         if (w > u) {                                   // slot 0 is behind s only for the waves after the owner

@@ -206,6 +206,24 @@ int main(int argc, char** argv) {
       }
     }
   }
+  {   // one substitution strip of the blocked solves: 512 columns, n vectors (k_trsm_ut_reg_full), TRSM_DBG what-ifs
+    float *Qs, *Xs, *Ys, *dinv;
+    hipMalloc(&Qs, 512 * 512 * 4); hipMalloc(&Xs, (size_t)n * 512 * 4); hipMalloc(&Ys, (size_t)n * 512 * 4); hipMalloc(&dinv, 16 * 1024 * 4);
+    std::vector<float> hq(512 * 512, 0.f);
+    for (int i = 0; i < 512; ++i) { hq[i * 512 + i] = 1.0f; for (int j = i + 1; j < 512; ++j) hq[i * 512 + j] = 0.001f * ((i * 7 + j) % 13 - 6); }
+    hipMemcpy(Qs, hq.data(), 512 * 512 * 4, hipMemcpyHostToDevice);
+    hipMemcpy(Xs, A, (size_t)n * 512 * 4, hipMemcpyDeviceToDevice);
+    hipLaunchKernelGGL(k_tri_inv32, dim3(16), dim3(64), 0, 0, Qs, 512, 512, dinv);
+    TrsmArgs t = {Qs, 512, 512, Xs, Ys, n, 512L, 1L, 0L, 0L};
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch_strip(t, dinv, 0);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 50; ++i) launch_strip(t, dinv, 0);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    printf("TRSM_DBG=%d  substitution strip, 512 columns x %d vectors: %.1f us\n", TRSM_DBG, n, ms / 50 * 1e3);
+  }
   {   // does the planes product depend on the data (matrix-core power) or on what ran before it?
     __bf16 *PA, *PB;
     hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
