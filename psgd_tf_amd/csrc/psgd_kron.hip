@@ -1930,6 +1930,7 @@ __device__ __forceinline__ void trsm_reg_body(const TrsmArgs& t, const float* __
   const int n = t.n, nsb = (n + 31) >> 5;
   const int v = v0 + l;
   const bool vok = v < t.nvec;
+  const bool coal = t.sj == 1 && !(t.si & 1) && !(reinterpret_cast<uintptr_t>(t.Y) & 7);   // coalesced stores of a solved block
   constexpr int kIt = kStripN / 128;            // 32-column blocks per wave
   f32x4 acc[kIt][2];
 #pragma unroll
@@ -1993,10 +1994,21 @@ __device__ __forceinline__ void trsm_reg_body(const TrsmArgs& t, const float* __
         for (int e = 0; e < 4; ++e) {
           Ybuf[s & 1][(mt * 4 + e) * 64 + lane] = -y[mt][e];
           const int c = 32 * s + 16 * mt + 4 * g + e;
-          if (vok && c < n) t.Y[(long)v * t.si + (long)c * t.sj] = y[mt][e];
+          if (!coal && vok && c < n) t.Y[(long)v * t.si + (long)c * t.sj] = y[mt][e];
         }
     }
     __syncthreads();
+    if (coal) {                                        // (vectors as rows: 16 lanes write one 128-byte run, see the full-strip body)
+      const int sv = threadIdx.x >> 4, c2 = (threadIdx.x & 15) * 2;
+      const int smt = c2 >> 4, sg = (c2 & 15) >> 2, se = c2 & 3;
+      const float* src = &Ybuf[s & 1][(smt * 4 + se) * 64 + sg * 16 + sv];
+      const int c = 32 * s + c2;
+      if (v0 + sv < t.nvec) {
+        float* dst = t.Y + (long)(v0 + sv) * t.si + c;
+        if (c + 1 < n) *reinterpret_cast<float2*>(dst) = make_float2(-src[0], -src[64]);
+        else if (c < n) dst[0] = -src[0];
+      }
+    }
     if (more) {
       float yn[2][4];                                // -Y_s in B-operand layout
 #pragma unroll
