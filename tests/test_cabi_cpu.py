@@ -67,6 +67,31 @@ def test_workspace_queries_and_argument_checks(lib):
     assert lib.psgd_kron_dd_workspace_bytes(257, 120) > 4 * (2 * 257 * 257 + 2 * 120 * 120 + 4 * 257 * 120)
 
 
+def test_kron_workspace_layout_rules(lib):
+    """Workspace sizes are pure functions of the shape (a workspace sized once stays valid whatever the tuning keys): the plane
+    buffers appear from the planes threshold on, the buffers of the solves through explicit inverses from 2048 x 2048 on --
+    in the fp32 workspace and in the bf16-operand update's alike -- and tuning keys do not move the sizes."""
+    ws = lib.psgd_kron_dd_workspace_bytes
+    fp32_only = lambda m, n: 4 * (4 * m * m + 2 * n * n + 4 * m * n)          # a lower bound of the fp32 buffers
+    assert ws(300, 300) < 3 * fp32_only(300, 300)                             # no planes at 300^2
+    assert ws(1024, 1024) > fp32_only(1024, 1024) + 16 * 1024 * 1024 * 6      # planes of the large paths (6 B per element)
+    per = lambda n: ws(n, n) / float(n * n)
+    assert per(2048) > per(1920) + 4 * 4                                     # inverse route: more bytes per element from 2048^2 on
+    upd = lib.psgd_kron_dd_update_workspace_bytes_bf16
+    assert upd(2048, 2048) / float(2048 * 2048) > upd(1920, 1920) / float(1920 * 1920) + 4 * 4
+    before = (ws(2048, 2048), upd(2048, 2048), ws(1024, 1024))
+    try:
+        for key, val in ((11, 0), (12, 0), (4, 0)):
+            assert lib.psgd_kron_set_tuning(key, val) == 0
+        assert (ws(2048, 2048), upd(2048, 2048), ws(1024, 1024)) == before
+    finally:
+        for key, val in ((11, 1), (12, 2), (4, 1)):
+            lib.psgd_kron_set_tuning(key, val)
+    assert lib.psgd_kron_set_tuning(999, 0) == -1                             # unknown key: PSGD_ERR_BAD_ARG
+    sp = lib.psgd_kron_sparse_workspace_bytes
+    assert sp(1, 30000, 1000) > sp(1, 30000, 500) and sp(2, 30000, 1000) < sp(1, 30000, 1000)      # (norm, dense) vs (norm, scaling)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
