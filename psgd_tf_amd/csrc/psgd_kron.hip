@@ -1217,12 +1217,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
 // One triu product with few output tiles and a long K (the gradient of the dense factor of a sparse Kron format at
 // embedding shapes: 1000 x 1000 outputs, K = 30000, twice): upper tiles only, every tile's K steps dealt to `nchunk`
 // blocks (P3Split).  On the in-GEMM split kernel this product ran on 64 workgroups for 1.8 ms.
+template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk(P3Args g, int T, int nchunk, float* scratch, unsigned* cnt) {
-  __shared__ __attribute__((aligned(16))) P3Lds<0> L;
+  __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
   int r, c;
   upper_tile(t, T, r, c);
-  p3_body(g, r, c, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
+  p3_body<FMT, FMT ? 0 : 2>(g, r, c, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
 }
 
 // The same for any product (all tiles, in the usual tile order): shapes with few output tiles -- a 128 x 4096 apply is one
@@ -2938,7 +2939,7 @@ static void p3_out_meta(P3Args& g, const P3Buf& C) {
 static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; p3_out_meta(g, C); }
 static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; p3_out_meta(g, Ct); }
 
-static int g_sparse_planes = 1;     // tuning key 20: 0 = every product of the sparse formats on launch_gemm (see sparse_gemm)
+static int g_sparse_planes = 1;     // tuning key 20: 0 = every product of the sparse formats on launch_gemm / bf16 x 3 planes (see sparse_gemm)
 static int g_force_er = -1;     // tuning key 19: -1 = the launchers choose the form of the f16 x 2 kernels (P3_EARLY), 0 / 2 = always that one
 static inline bool p3_no_early(bool auto_choice) { return g_force_er < 0 ? auto_choice : g_force_er == 0; }
 static int p3_block_slots() {           // two resident blocks per CU
@@ -4009,12 +4010,23 @@ static int col_reduce(const SparseWs& k, MatView Z, MatView Z2, const float* q0,
 }
 
 // grad = triu(X X' - Y Y') for X, Y given as (row, k) views [rows x K]; fp32 result + max|.| as the fused GEMM epilogue does
+// amaxX / amaxY (optional, f16 x 2 planes): device words with max|X|, max|Y| that the producing products left (sparse_gemm's
+// `track`); without them a reduction launch per operand finds the maxima.
 static int sparse_grad_splitk(const SparseWs& k, const float* X, const float* Y, long rs, long cs, int rows, int K, float* C,
-                              float* maxout, hipStream_t st) {
+                              float* maxout, hipStream_t st, const float* amaxX = nullptr, const float* amaxY = nullptr) {
   const long rp = (rows + 127) & ~127, kp = (K + 127) & ~127;
-  const P3Buf Xp = {k.P0, rp, kp}, Yp = {k.P1, rp, kp};
+  const bool f16 = g_sparse_planes && g_planes_f16 && k.gmeta && (rs == 1 || cs == 1);
+  P3Buf Xp = {k.P0, rp, kp, f16 ? k.gmeta + 4 : nullptr}, Yp = {k.P1, rp, kp, f16 ? k.gmeta + 5 : nullptr};
   int e;
+  if (f16) {
+    if (amaxX) { Xp.part = amaxX; Xp.npart = 1; }
+    else if ((e = launch_absmax_view(X, rs, cs, rows, K, Xp, k.gpart + 5 * kPmPartMax, st))) return e;
+  }
   if ((e = launch_split3(X, rs, cs, rows, K, Xp, st))) return e;
+  if (f16) {
+    if (amaxY) { Yp.part = amaxY; Yp.npart = 1; }
+    else if ((e = launch_absmax_view(Y, rs, cs, rows, K, Yp, k.gpart + 5 * kPmPartMax, st))) return e;   // (the split above is done with the array)
+  }
   if ((e = launch_split3(Y, rs, cs, rows, K, Yp, st))) return e;
   P3Args g = p3_args(Xp, Xp, rows, rows, K, 0);
   g.A2 = p3_of(Yp); g.B2 = p3_of(Yp); g.e.A2 = Y; g.e.K2 = K;
@@ -4027,7 +4039,8 @@ static int sparse_grad_splitk(const SparseWs& k, const float* X, const float* Y,
   const int nchunk = 2 * half;
   if ((long)nt * nchunk > kSplitkScratchTiles) return 1;
   if (hipMemsetAsync(k.sk_cnt, 0, (size_t)nt * 4, st) != hipSuccess) return 1;
-  hipLaunchKernelGGL(k_gemm_p3_splitk, dim3(nt * nchunk), dim3(kThreads), 0, st, g, T, nchunk, k.sk_scratch, k.sk_cnt);
+  if (f16) hipLaunchKernelGGL(k_gemm_p3_splitk<1>, dim3(nt * nchunk), dim3(kThreads), 0, st, g, T, nchunk, k.sk_scratch, k.sk_cnt);
+  else hipLaunchKernelGGL(k_gemm_p3_splitk<0>, dim3(nt * nchunk), dim3(kThreads), 0, st, g, T, nchunk, k.sk_scratch, k.sk_cnt);
   return (int)hipGetLastError();
 }
 
@@ -4047,7 +4060,9 @@ static inline int ew_grid_fwd(long tot) {
 // GemmArgs (column scales, D - A B, ...); the in-GEMM split kernel re-splits an operand element once per tile column it meets.
 // set: 0 = the caller's stream, 1 = the side stream (their own plane buffers).  Small products, second operand pairs and views
 // without a unit stride stay on launch_gemm.
-static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int set = 0) {
+static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int set = 0, PlaneMeta* track = nullptr,
+                       bool* tracked = nullptr) {
+  if (tracked) *tracked = false;
   const bool unit = (g.a_rs == 1 || g.a_cs == 1) && (g.b_rs == 1 || g.b_cs == 1);
   const int64_t Mp = pad128(g.M), Np = pad128(g.N), Kp = pad128(g.K);
   const bool fits = k.gcap > 0 && Mp * Kp <= k.gcap && Np * Kp <= k.gcap;
@@ -4063,6 +4078,10 @@ static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int
   P3Args p = p3_args(A, B, g.M, g.N, g.K, g.kmode);
   p.e = g;
   p.e.A2 = nullptr; p.e.kblk = 0;
+  if (track && !g.colv && g.epi == EPI_STORE) {            // max|C| for a consumer that splits C into planes (accumulated: zeroed by the caller)
+    p.ometa = track;
+    if (tracked) *tracked = true;
+  }
   return launch_p3_auto(p, k.sk_scratch, k.sk_cnt, st);
 }
 
@@ -4071,7 +4090,8 @@ static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int
 // for the two strips and the update between them), and the solve is cheaper as ONE product with the explicit inverse (tri_inverse:
 // ~13 launches for n = 1000, then a plane product through sparse_gemm): from 8 vectors per column on, 512 <= n <= 8192.
 static int sparse_solve(const SparseWs& k, const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
-                        hipStream_t st, long xi = 0, long xj = 0) {
+                        hipStream_t st, long xi = 0, long xj = 0, PlaneMeta* track = nullptr, bool* tracked = nullptr) {
+  if (tracked) *tracked = false;
   if (xi == 0 && xj == 0) { xi = si; xj = sj; }
   const bool inv = g_sparse_planes && g_trsm_inv && g_planes && g_gemm_x3 && g_planes_f16 && k.IInv && n >= 512 && n <= 8192 &&
                    (long)nvec >= 8L * n;
@@ -4099,7 +4119,7 @@ static int sparse_solve(const SparseWs& k, const float* Q, int n, const float* X
   g.B = k.IInv; g.b_rs = n; g.b_cs = 1;
   g.C = Y; g.ldc = si; g.c_cs = sj;
   g.M = nvec; g.N = n; g.K = n; g.kmode = KHI_N; g.epi = EPI_STORE;
-  return sparse_gemm(k, g, st, 0);
+  return sparse_gemm(k, g, st, 0, track, tracked);
 }
 
 static inline int ew_grid(long tot) {
@@ -4222,6 +4242,7 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   SP_LAUNCH(k_balance_generic, ew_grid((long)N * N), ql, 1L, M, (long)2 * M, Qr, (long)N + 1, N, (long)N * N, k.LS, k.RS);
+  bool trackA = false, trackB = false;
   // two chains that meet at the row statistics: T = Ql dG -> A = T QrS' (:218-220) on the side stream (kron_fork),
   // Bt = Ql^-T dX -> Bt QrS^-1 (:222-233, solved in place) on the caller's
   KronFork* fk = kron_overlap_chains(N, N) ? kron_fork(st) : nullptr;
@@ -4232,19 +4253,23 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
     hipLaunchKernelGGL(k_norm_left, dim3(ew_grid((long)M * N)), dim3(kThreads), 0, sf, vg, (const float*)k.LS,
                        (const float*)(k.LS + M), M, N, (const float*)nullptr, 0, k.T);
     if (hipGetLastError() != hipSuccess) return PSGD_ERR_LAUNCH;
-    KRON_LAUNCH(sparse_gemm(k, gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), sf, fk ? 1 : 0));   // A = T QrS'  (:220)
+    // (max|A| and max|Bt| ride on the producing products when they run on planes: words of k.scal, zeroed above)
+    KRON_LAUNCH(sparse_gemm(k, gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), sf, fk ? 1 : 0,
+                            reinterpret_cast<PlaneMeta*>(k.scal + 32), &trackA));                        // A = T QrS'  (:220)
   }
   {
     MatView vx = {dX, xrs, xcs};
     if (col_reduce(k, vx, vx, k.LS, k.LS + M, M, N, 0, k.v0, st)) return PSGD_ERR_LAUNCH;
     SP_LAUNCH(k_norm_left_invT, ew_grid((long)M * N), vx, (const float*)k.LS, (const float*)k.v0, M, N, (const float*)nullptr, k.Bt);
   }
-  KRON_LAUNCH(sparse_solve(k, k.RS, N, k.Bt, k.Bt, M, (long)N, 1L, k.dinv, st));             // Bt QrS^-1, in place  (:233)
+  KRON_LAUNCH(sparse_solve(k, k.RS, N, k.Bt, k.Bt, M, (long)N, 1L, k.dinv, st, 0, 0, reinterpret_cast<PlaneMeta*>(k.scal + 36),
+                           &trackB));                                                          // Bt QrS^-1, in place  (:233)
   KRON_LAUNCH(fork_scope.join());
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.Bt, M, N, k.v1, k.v2);   // (:235-237)
   SP_LAUNCH_WIDE(k_norm_finalize, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
   if (k.P0 && g_planes && g_gemm_x3) {                       // grad2 = triu(A'A - Bt'Bt)     (:243): few tiles, long K
-    KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.Bt, 1L, (long)N, N, M, k.gsq, k.scal, st));
+    KRON_LAUNCH(sparse_grad_splitk(k, k.A, k.Bt, 1L, (long)N, N, M, k.gsq, k.scal, st, trackA ? k.scal + 34 : nullptr,
+                                   trackB ? k.scal + 38 : nullptr));
   } else {
     GemmArgs g = gemm_args(k.A, N, true, k.A, N, false, k.gsq, N, N, N, M);
     g.A2 = k.Bt; g.a2_rs = 1; g.a2_cs = N; g.B2 = k.Bt; g.b2_rs = N; g.b2_cs = 1; g.K2 = M;

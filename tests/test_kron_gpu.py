@@ -962,6 +962,8 @@ BIG_FORMATS = [
     ("scale_dense", (1, 1300), (2048, 2048)),
     # ... and at least 8 vectors per column of the dense factor: its solve runs as a product with the explicit inverse (sparse_solve)
     ("norm_dense", (2, 5200), (600, 600)), ("dense_scale", (640, 640), (1, 5400)), ("dense_norm", (520, 520), (2, 4300)),
+    # ... and products big enough for the planes whose maxima the gradient's planes then reuse (sparse_grad_splitk on f16 x 2 planes)
+    ("norm_dense", (2, 12000), (640, 640)),
 ]
 
 
