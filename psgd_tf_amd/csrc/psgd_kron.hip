@@ -4089,13 +4089,13 @@ static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int
 // 30000 rows against its 1000 x 1000 factor -- the substitution strips are throughput-bound (1875 workgroups per strip: 0.83 ms
 // for the two strips and the update between them), and the solve is cheaper as ONE product with the explicit inverse (tri_inverse:
 // ~13 launches for n = 1000, then a plane product through sparse_gemm): from 8 vectors per column on, 512 <= n <= 8192.
-static int sparse_solve(const SparseWs& k, const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
-                        hipStream_t st, long xi = 0, long xj = 0, PlaneMeta* track = nullptr, bool* tracked = nullptr) {
-  if (tracked) *tracked = false;
-  if (xi == 0 && xj == 0) { xi = si; xj = sj; }
-  const bool inv = g_sparse_planes && g_trsm_inv && g_planes && g_gemm_x3 && g_planes_f16 && k.IInv && n >= 512 && n <= 8192 &&
-                   (long)nvec >= 8L * n;
-  if (!inv) return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st, xi == si && xj == sj ? 0 : xi, xi == si && xj == sj ? 0 : xj);
+static inline bool sparse_solve_inverse(const SparseWs& k, int n, int nvec) {
+  return g_sparse_planes && g_trsm_inv && g_planes && g_gemm_x3 && g_planes_f16 && k.IInv && n >= 512 && n <= 8192 && (long)nvec >= 8L * n;
+}
+// The factor-only half (the inversion: a chain of small launches that depends on Q alone), for callers that have other work to
+// put behind it on the stream; sparse_solve(..., prepared = true) then only runs the product.  No-op when the strips are used.
+static int sparse_solve_prepare(const SparseWs& k, const float* Q, int n, int nvec, float* dinv, hipStream_t st) {
+  if (!sparse_solve_inverse(k, n, nvec)) return 0;
   const long np = pad128(n);
   int e;
   hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, st, Q, n, n, dinv);
@@ -4113,7 +4113,17 @@ static int sparse_solve(const SparseWs& k, const float* Q, int n, const float* X
   // the strict lower triangle of Inv was never written: the product's K range (k <= column) and the split's triangle mask
   // would need it zero -- sparse_gemm splits the whole matrix, so clear it by writing the upper triangle's complement here
   hipLaunchKernelGGL(k_zero_below_diag, dim3(ew_grid_fwd((long)n * n)), dim3(kThreads), 0, st, k.IInv, n);
-  if (hipGetLastError() != hipSuccess) return 1;
+  return (int)hipGetLastError();
+}
+static int sparse_solve(const SparseWs& k, const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv,
+                        hipStream_t st, long xi = 0, long xj = 0, PlaneMeta* track = nullptr, bool* tracked = nullptr,
+                        bool prepared = false) {
+  if (tracked) *tracked = false;
+  if (xi == 0 && xj == 0) { xi = si; xj = sj; }
+  if (!sparse_solve_inverse(k, n, nvec))
+    return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st, xi == si && xj == sj ? 0 : xi, xi == si && xj == sj ? 0 : xj);
+  int e;
+  if (!prepared && (e = sparse_solve_prepare(k, Q, n, nvec, dinv, st))) return e;
   GemmArgs g = {};
   g.A = X; g.a_rs = xi; g.a_cs = xj;
   g.B = k.IInv; g.b_rs = n; g.b_cs = 1;
@@ -4257,13 +4267,16 @@ int psgd_kron_nd_update_f32(const float* ql, const float* Qr, const float* dX, c
     KRON_LAUNCH(sparse_gemm(k, gemm_args(k.T, N, false, k.RS, N, true, k.A, N, M, N, N, KLO_N), sf, fk ? 1 : 0,
                             reinterpret_cast<PlaneMeta*>(k.scal + 32), &trackA));                        // A = T QrS'  (:220)
   }
+  // (the inversion behind Bt's solve depends on QrS alone: queued first, its small launches -- k_tri_inv128 needs whole CUs --
+  //  are through before the side stream's full-chip product starts: 173 -> ~50 us for that launch)
+  KRON_LAUNCH(sparse_solve_prepare(k, k.RS, N, M, k.dinv, st));
   {
     MatView vx = {dX, xrs, xcs};
     if (col_reduce(k, vx, vx, k.LS, k.LS + M, M, N, 0, k.v0, st)) return PSGD_ERR_LAUNCH;
     SP_LAUNCH(k_norm_left_invT, ew_grid((long)M * N), vx, (const float*)k.LS, (const float*)k.v0, M, N, (const float*)nullptr, k.Bt);
   }
   KRON_LAUNCH(sparse_solve(k, k.RS, N, k.Bt, k.Bt, M, (long)N, 1L, k.dinv, st, 0, 0, reinterpret_cast<PlaneMeta*>(k.scal + 36),
-                           &trackB));                                                          // Bt QrS^-1, in place  (:233)
+                           &trackB, true));                                                          // Bt QrS^-1, in place  (:233)
   KRON_LAUNCH(fork_scope.join());
   SP_LAUNCH(k_row_stats, (M + 3) / 4, (const float*)k.A, (const float*)k.Bt, M, N, k.v1, k.v2);   // (:235-237)
   SP_LAUNCH_WIDE(k_norm_finalize, (const float*)k.LS, (const float*)k.v1, (const float*)k.v2, M, step, tiny, qlOut);
