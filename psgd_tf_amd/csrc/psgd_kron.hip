@@ -1346,19 +1346,22 @@ __global__ __launch_bounds__(kThreads) void k_tri_inv128(const float* __restrict
   float (*Tb)[PT] = reinterpret_cast<float (*)[PT]>(inv128_sm);
   float (*Ib)[PT] = reinterpret_cast<float (*)[PT]>(inv128_sm + 128 * PT);
   const int j0 = 128 * blockIdx.x, tid = threadIdx.x;
-  for (int e = tid; e < 128 * 128; e += kThreads) {
-    const int r = e >> 7, c = e & 127;
-    float v = (r == c) ? 1.0f : 0.0f;
-    if (j0 + r < n && j0 + c < n && c >= r) v = Q[(long)(j0 + r) * n + j0 + c];
-    Tb[r][c] = v;
+  // (clamped addresses, eight loads in flight: a guarded load compiles to load-then-wait, 64 L2 round trips in a row per thread
+  //  -- 47 us for a launch whose arithmetic is ~10)
+#pragma unroll 8
+  for (int it = 0; it < 128 * 128 / kThreads; ++it) {
+    const int e = tid + it * kThreads, r = e >> 7, c = e & 127;
+    const float q = Q[(long)min(j0 + r, n - 1) * n + min(j0 + c, n - 1)];
+    Tb[r][c] = (j0 + r < n && j0 + c < n && c >= r) ? q : ((r == c) ? 1.0f : 0.0f);
     Ib[r][c] = 0.0f;
   }
   __syncthreads();
-  for (int e = tid; e < 4 * 1024; e += kThreads) {                  // the four inverted 32-blocks
-    const int t = e >> 10, r = (e >> 5) & 31, c = e & 31;
-    float v = (r == c) ? 1.0f : 0.0f;
-    if (j0 + 32 * t < n) v = dinv[(long)(j0 / 32 + t) * 1024 + r * 32 + c];
-    Ib[32 * t + r][32 * t + c] = v;
+  const int nb32 = (n + 31) / 32;
+#pragma unroll 8
+  for (int it = 0; it < 4 * 1024 / kThreads; ++it) {                // the four inverted 32-blocks
+    const int e = tid + it * kThreads, t = e >> 10, r = (e >> 5) & 31, c = e & 31;
+    const float d = dinv[(long)min(j0 / 32 + t, nb32 - 1) * 1024 + r * 32 + c];
+    Ib[32 * t + r][32 * t + c] = (j0 + 32 * t < n) ? d : ((r == c) ? 1.0f : 0.0f);
   }
   __syncthreads();
   // merge the pair of inverted b-blocks at a0: W = B C^-1 (kept below the diagonal meanwhile), X12 = -A^-1 W
