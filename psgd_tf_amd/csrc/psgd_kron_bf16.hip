@@ -511,6 +511,9 @@ template <int N> struct IntC { static constexpr int value = N; };
 // a barrier interval.  1: both pieces inside the MFMA cluster (after MFMA 4 and MFMA 10), where a piece costs ~60 cycles
 // of the wave's issue; the load half then holds only the fragment reads.  2: first piece as 0, second inside the cluster.
 // The counted wait of phase 3 follows the placement (pieces of THIS phase are not yet issued at the wait for 1).
+#ifndef HG_DBG
+#define HG_DBG 0      // what-if builds (wrong results, timing only): 1 = no DMA after the prologue, 2 = every fragment read from one LDS
+#endif                // address, 4 = no barriers inside the phases
 template <int DMAPOS, class Src, class Pre>
 __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, int nk, int w, int lane, Src&& src,
                                                Pre&& pre) {
@@ -526,8 +529,8 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
   // fragment read positions (16-byte units inside a slot): row*8 + (chunk ^ (row & 7)), chunk = ks*4 + (lane>>4)
   const int c0 = (lane >> 4) ^ (lane & 7);
   const int rowA = (wr * 64 + (lane & 15)) * 8, rowB = (wc * 32 + (lane & 15)) * 8;
-  const int posA[2] = {rowA + c0, rowA + (c0 ^ 4)};
-  const int posB[2] = {rowB + c0, rowB + (c0 ^ 4)};
+  const int posA[2] = {(HG_DBG & 2) ? 0 : rowA + c0, (HG_DBG & 2) ? 0 : rowA + (c0 ^ 4)};
+  const int posB[2] = {(HG_DBG & 2) ? 0 : rowB + c0, (HG_DBG & 2) ? 0 : rowB + (c0 ^ 4)};
 
   bf16x8 a[4][2], b0[2][2], b1[2][2];
   const int total = 4 * nk;
@@ -577,7 +580,7 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
     if constexpr (DMAPOS == 0) {
       if (n < total) {
         pre(n);
-        issue(n);
+        if (!(HG_DBG & 1)) issue(n);
       }
     } else if constexpr (DMAPOS == 2) {
       if (n < total) {
@@ -596,7 +599,7 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
       } else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     HG_FENCE();
-    __builtin_amdgcn_s_barrier();
+    if (!(HG_DBG & 4)) __builtin_amdgcn_s_barrier();
     HG_FENCE();
     // ---- 16 MFMAs: one 64 x 32 quadrant x K = 64
     constexpr int MQ = (PH >= 2) ? 1 : 0;
@@ -630,7 +633,7 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
         }
     __builtin_amdgcn_s_setprio(0);
     HG_FENCE();
-    __builtin_amdgcn_s_barrier();
+    if (!(HG_DBG & 4)) __builtin_amdgcn_s_barrier();
     HG_FENCE();
   };
 
