@@ -224,6 +224,25 @@ int main(int argc, char** argv) {
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
     printf("TRSM_DBG=%d  substitution strip, 512 columns x %d vectors: %.1f us\n", TRSM_DBG, n, ms / 50 * 1e3);
   }
+  {   // the 128-block inversion of tri_inverse (k_tri_inv128: n / 128 workgroups, 132 KiB of LDS each) on its own
+    float *Qt, *Inv, *dinv, *amax;
+    hipMalloc(&Qt, bytes); hipMalloc(&Inv, bytes); hipMalloc(&dinv, (size_t)(n / 32 + 1) * 1024 * 4); hipMalloc(&amax, 256);
+    hipMemset(amax, 0, 256);
+    std::vector<float> hq((size_t)n * n, 0.f);
+    for (int i = 0; i < n; ++i) { hq[(size_t)i * n + i] = 1.0f + 0.001f * (i % 7); for (int j = i + 1; j < n && j < i + 200; ++j) hq[(size_t)i * n + j] = 0.001f * ((i * 7 + j) % 13 - 6); }
+    hipMemcpy(Qt, hq.data(), bytes, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_tri_inv32, dim3((n + 31) / 32), dim3(64), 0, 0, Qt, n, n, dinv);
+    const size_t lds = (size_t)2 * 128 * 129 * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tri_inv128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_tri_inv128, dim3((n + 127) / 128), dim3(kThreads), lds, 0, Qt, n, dinv, Inv, amax);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(k_tri_inv128, dim3((n + 127) / 128), dim3(kThreads), lds, 0, Qt, n, dinv, Inv, amax);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    printf("k_tri_inv128, n = %d (%d workgroups): %.1f us\n", n, (n + 127) / 128, ms / 50 * 1e3);
+  }
   {   // does the planes product depend on the data (matrix-core power) or on what ran before it?
     __bf16 *PA, *PB;
     hipMalloc(&PA, (size_t)n * n * 6); hipMalloc(&PB, (size_t)n * n * 6);
