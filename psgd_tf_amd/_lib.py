@@ -202,6 +202,11 @@ class WorkspaceCache:
             total -= int(old.numel())
         return ws
 
+    def touch(self, key):
+        """Mark `key` as just used (callers that keep their own handle to a block call this instead of get())."""
+        if key in self._d:
+            self._d.move_to_end(key)
+
     def __contains__(self, key):
         return key in self._d
 

@@ -2733,6 +2733,8 @@ static void launch_x3(const GemmArgs& g, dim3 grid, hipStream_t st) {
 }
 
 static int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  // tiles of one launch read A, B while other tiles write C: an output that IS an operand is a race whatever the timing
+  if (g.C == g.A || g.C == g.B || (g.A2 && (g.C == g.A2 || g.C == g.B2))) return PSGD_ERR_BAD_ARG;
   // the 128-tile kernel needs enough tiles to fill the chip; small problems keep 64 x 64 tiles
   const long t128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
   const long t64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64);
@@ -3362,8 +3364,10 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
     if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st))) return e;
     P3Buf g1p = G1, g2p = G2;
     g1p.part = k.scal + 0; g2p.part = k.scal + 1; g1p.npart = g2p.npart = 1;
-    if ((e = launch_split3(k.g1, M, 1, M, M, g1p, st))) return e;
-    if ((e = launch_split3(k.g2, N, 1, N, N, g2p, st))) return e;
+    // (tri: the gradient grid wrote the upper tiles only; what lies below the diagonal in k.g1 / k.g2 is whatever the workspace
+    //  held -- on the inverse route the fp32 inverses -- and becomes defined zeros in the planes)
+    if ((e = launch_split3(k.g1, M, 1, M, M, g1p, st, SplitOpt{1, 0, 0, 0}))) return e;
+    if ((e = launch_split3(k.g2, N, 1, N, N, g2p, st, SplitOpt{1, 0, 0, 0}))) return e;
   } else {
     p3_out_row(s2, G1);
     p3_out_row(s3, G2);
@@ -4077,14 +4081,24 @@ static inline int ew_grid_fwd(long tot) {
 // GemmArgs (column scales, D - A B, ...); the in-GEMM split kernel re-splits an operand element once per tile column it meets.
 // set: 0 = the caller's stream, 1 = the side stream (their own plane buffers).  Small products, second operand pairs and views
 // without a unit stride stay on launch_gemm.
+// ONE predicate for "this product runs on planes": sparse_gemm and sparse_solve's choice of route both read it (the explicit-
+// inverse solve is only in-place safe as a plane product: the planes are a copy of X, so Y may be X; launch_gemm reads its
+// operands while other tiles write C).
+static inline bool sparse_gemm_shape_on_planes(const SparseWs& k, long M, long N, long K) {
+  const int64_t Mp = pad128(M), Np = pad128(N), Kp = pad128(K);
+  const bool fits = k.gcap > 0 && Mp * Kp <= k.gcap && Np * Kp <= k.gcap;
+  const bool big = (double)M * N * K >= 4e9 && M >= 256 && N >= 256 && K >= 256;
+  return g_sparse_planes && g_planes && g_gemm_x3 && g_planes_f16 && fits && big;
+}
+static inline bool sparse_gemm_on_planes(const SparseWs& k, const GemmArgs& g) {
+  const bool unit = (g.a_rs == 1 || g.a_cs == 1) && (g.b_rs == 1 || g.b_cs == 1);
+  return !g.A2 && !g.sym && unit && sparse_gemm_shape_on_planes(k, g.M, g.N, g.K);
+}
 static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int set = 0, PlaneMeta* track = nullptr,
                        bool* tracked = nullptr) {
   if (tracked) *tracked = false;
-  const bool unit = (g.a_rs == 1 || g.a_cs == 1) && (g.b_rs == 1 || g.b_cs == 1);
+  if (!sparse_gemm_on_planes(k, g)) return launch_gemm(g, st);
   const int64_t Mp = pad128(g.M), Np = pad128(g.N), Kp = pad128(g.K);
-  const bool fits = k.gcap > 0 && Mp * Kp <= k.gcap && Np * Kp <= k.gcap;
-  const bool big = (double)g.M * g.N * g.K >= 4e9 && g.M >= 256 && g.N >= 256 && g.K >= 256;
-  if (!g_sparse_planes || !g_planes || !g_gemm_x3 || !g_planes_f16 || g.A2 || g.sym || !unit || !fits || !big) return launch_gemm(g, st);
   P3Buf A = {k.GP[set][0], Mp, Kp, k.gmeta + 2 * set}, B = {k.GP[set][1], Np, Kp, k.gmeta + 2 * set + 1};
   float* part = k.gpart + (long)set * 2 * kPmPartMax;
   int e;
@@ -4107,7 +4121,8 @@ static int sparse_gemm(const SparseWs& k, const GemmArgs& g, hipStream_t st, int
 // for the two strips and the update between them), and the solve is cheaper as ONE product with the explicit inverse (tri_inverse:
 // ~13 launches for n = 1000, then a plane product through sparse_gemm): from 8 vectors per column on, 512 <= n <= 8192.
 static inline bool sparse_solve_inverse(const SparseWs& k, int n, int nvec) {
-  return g_sparse_planes && g_trsm_inv && g_planes && g_gemm_x3 && g_planes_f16 && k.IInv && n >= 512 && n <= 8192 && (long)nvec >= 8L * n;
+  return g_trsm_inv && k.IInv && n >= 512 && n <= 8192 && (long)nvec >= 8L * n &&
+         sparse_gemm_shape_on_planes(k, nvec, n, n);          // (the route exists for the plane product; see sparse_solve)
 }
 // The factor-only half (the inversion: a chain of small launches that depends on Q alone), for callers that have other work to
 // put behind it on the stream; sparse_solve(..., prepared = true) then only runs the product.  No-op when the strips are used.
@@ -4146,6 +4161,9 @@ static int sparse_solve(const SparseWs& k, const float* Q, int n, const float* X
   g.B = k.IInv; g.b_rs = n; g.b_cs = 1;
   g.C = Y; g.ldc = si; g.c_cs = sj;
   g.M = nvec; g.N = n; g.K = n; g.kmode = KHI_N; g.epi = EPI_STORE;
+  // in place (Y = X) the product must read a COPY of X: only the plane path does.  A view the planes cannot take (no unit
+  // stride) falls back to the substitution strips, which are in-place safe (the inversion above was then wasted, not wrong).
+  if (static_cast<const float*>(Y) == X && !sparse_gemm_on_planes(k, g)) return trsm_ut(Q, n, X, Y, nvec, si, sj, dinv, st);
   return sparse_gemm(k, g, st, 0, track, tracked);
 }
 

@@ -103,6 +103,14 @@ def invalidate_factor_cache():
         slot.rl = slot.rr = None
 
 
+def set_tuning(key, value):
+    """psgd_kron_set_tuning through the Python boundary: keys that change what the prepared state in a workspace means
+    (4: operand planes or not, 12: their format) also drop every prepared Gram / plane set, as the header requires."""
+    _lib.check(_lib.load().psgd_kron_set_tuning(int(key), int(value)), "psgd_kron_set_tuning")
+    if int(key) in (4, 12):
+        invalidate_factor_cache()
+
+
 def _cache_usable():
     return _factor_cache_enabled and not torch.cuda.is_current_stream_capturing()
 
@@ -271,6 +279,8 @@ def _dd_update_f32(Ql, Qr, dX, dG, step, M, N):
     slot = _apply_slots.get(key)
     if slot is None or slot.ws() is None:
         slot = _apply_slots[key] = _ApplySlot(_kron_workspace(dX.device, M, N))
+    else:
+        _kron_ws.touch(key)                          # (same key as _kron_workspace: the hot shape must not age out of the LRU)
     QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
     rc = slot.fn_update(Ql.data_ptr(), Qr.data_ptr(), dX.data_ptr(), dG.data_ptr(), QlO.data_ptr(), QrO.data_ptr(), M, N,
                         float(step), _tiny, slot.ws_ptr, slot.ws_bytes, st)
@@ -379,6 +389,8 @@ def _dd_apply_f32(Ql, Qr, Grad, M, N):
         if len(_apply_slots) > 4 * _kron_ws.max_entries:     # slots of evicted workspaces: drop them
             for k in [k for k, v in _apply_slots.items() if v.ws() is None]:
                 del _apply_slots[k]
+    else:
+        _kron_ws.touch(key)
     out = torch.empty_like(Grad)
     pl, pr = Ql.data_ptr(), Qr.data_ptr()
     # factor-only half (the Grams, kept in the workspace): redone only when these are not the very factor tensors (same

@@ -203,8 +203,14 @@ def branch_rng_for(generator, group, device):
     return ent[1]
 
 
+CHECK_EXPLICIT_BRANCHES = False     # debugging aid: verify (one all-reduce + a host read per call) that every rank passed the
+                                    # same explicit balance / update_U values; drawn values agree by construction
+
+
 def _agree_on_branches(balance, update_U, generator, device, group):
     if balance is not None and update_U is not None:
+        if CHECK_EXPLICIT_BRANCHES:
+            _check_explicit_branches_agree(balance, update_U, device, group)
         return bool(balance), bool(update_U)
     rng = branch_rng_for(generator, group, device)
     b = rng.draw(0.01) if balance is None else bool(balance)            # reference order: :562 then :588
@@ -234,8 +240,31 @@ def _is_wide(U, backend):
     return backend is None and U.dim() == 2 and U.shape[1] > _lib.UVD_MAX_RANK
 
 
+def _check_local(name, U, V, *cols):
+    """The single-GPU entry points' checks on this rank's tensors (device, dtype, contiguity, shapes): the stage kernels
+    and the wide-rank chunks take raw pointers.  Only for the product backend (the CPU test backend takes CPU tensors)."""
+    _psgd._require_hip(name, U, V, *cols)
+    _psgd._uvd_shapes(name, U, V, *cols)
+
+
+def _check_explicit_branches_agree(balance, update_U, device, group):
+    """Explicit branch values must be the same on every rank (drawn ones are, by construction): the ranks would otherwise
+    run different stage sequences and hang or mix branches.  One tiny MAX/MIN pair rides on a single all-reduce."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return
+    b, u = float(bool(balance)), float(bool(update_U))
+    on_host = dist.get_backend(group) == "gloo"
+    t = torch.tensor([b, -b, u, -u], dtype=torch.float32, device="cpu" if on_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    t = t.cpu()
+    if float(t[0]) != -float(t[1]) or float(t[2]) != -float(t[3]):
+        raise ValueError("sharded UVd: ranks passed different explicit balance / update_U values")
+
+
 def precond_grad_UVd_math(U, V, d, g, group=None, backend=None):
     """Sharded psgd.py:619-627 on this rank's rows; returns this rank's rows of the result.  2 exchanges."""
+    if backend is None:
+        _check_local("sharded precond_grad_UVd_math", U, V, d, g)
     if _is_wide(U, backend):
         return _wide.precond_grad(U, V, d, g, _psgd.uvd_workspace, reduce=_wide_reduce(group))
     be = backend if backend is not None else hip_backend_for(U)
@@ -249,6 +278,8 @@ def precond_grad_UVd_math(U, V, d, g, group=None, backend=None):
 def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_U=None, generator=None,
                              group=None, backend=None):
     """Sharded psgd.py:554-617 on this rank's rows (in place, returns None).  2 exchanges (+1 on the balance branch)."""
+    if backend is None:
+        _check_local("sharded update_precond_UVd_math_", U, V, d, v, h)
     if _is_wide(U, backend):
         balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
         return _wide.update(U, V, d, v, h, float(step), float(tiny), balance, update_U, _psgd.uvd_workspace,
@@ -272,8 +303,12 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
     """Sharded fused update -> apply; returns this rank's rows of the preconditioned gradient.
     2 exchanges: the Gram; the 4r column sums of sweep 2 with max|nablaD| in one buffer.  (r > 32: the update, then the
     apply, on the wide-rank path: 4 exchanges.)"""
+    if backend is None:
+        _check_local("sharded update_precond_UVd_math_and_precond_grad", U, V, d, v, h, g)
     if _is_wide(U, backend):
-        update_precond_UVd_math_(U, V, d, v, h, step, tiny, balance=balance, update_U=update_U, generator=generator, group=group)
+        # (the branches are agreed HERE, once, so the nested update cannot draw a second pair on some ranks only)
+        balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
+        update_precond_UVd_math_(U, V, d, v, h, step, tiny, balance=balance, update_U=update_U, group=group)
         return precond_grad_UVd_math(U, V, d, g, group=group)
     be = backend if backend is not None else hip_backend_for(U)
     balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)

@@ -54,11 +54,13 @@ class _Ctx:
         out = []
         for k in range(self.c):
             lo, hi = k * self.rc, min((k + 1) * self.rc, self.r)
-            ch = torch.zeros(self.N, self.rc, dtype=M.dtype, device=self.dev) if hi - lo < self.rc else None
-            if ch is None:
-                ch = M[:, lo:hi].contiguous()
-            else:
+            # always a COPY in fresh (aligned) memory: a [1, rc] slice is "contiguous" as it stands, and callers update chunks in place
+            if hi - lo < self.rc:
+                ch = torch.zeros(self.N, self.rc, dtype=M.dtype, device=self.dev)
                 ch[:, :hi - lo] = M[:, lo:hi]
+            else:
+                ch = torch.empty(self.N, self.rc, dtype=M.dtype, device=self.dev)
+                ch.copy_(M[:, lo:hi])
             out.append(ch)
         return out
 

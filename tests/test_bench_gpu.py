@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,9 +71,14 @@ def test_bench_two_ranks_self_launched(hip_lib):
 @pytest.mark.timeout(900)
 def test_bench_two_ranks_default_is_baseline_config3(hip_lib):
     """`python bench.py --gpus 2` with no row flags = BASELINE configs[3]: N_global = 100M rows, r = 20, split over the
-    ranks in contiguous row blocks (strong scaling), plus the 100M-rows-per-GPU weak sub-record.  Test mode (both ranks
-    on the one GPU, gloo): checks the workload, not the speed."""
-    env = dict(os.environ, PSGD_BENCH_SINGLE_DEVICE="1")
+    ranks in contiguous row blocks (strong scaling), plus the 100M-rows-per-GPU weak sub-record.  On a box with one GPU:
+    test mode (both ranks on it, gloo) -- checks the workload, not the speed.  With two or more GPUs visible: the real thing,
+    rank k on cuda:k over RCCL."""
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ)
+    env.pop("PSGD_BENCH_SINGLE_DEVICE", None)
+    if not two:
+        env["PSGD_BENCH_SINGLE_DEVICE"] = "1"
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"],
@@ -80,6 +86,8 @@ def test_bench_two_ranks_default_is_baseline_config3(hip_lib):
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["collective_backend"] == ("nccl" if two else "gloo")
+    assert ("TEST MODE" in d["config"]["parallelism"]) == (not two)
     assert d["config"]["rows_global"] == 100_000_000 and d["config"]["rows_per_gpu"] == 50_000_000
     assert d["config"]["rank_of_modification"] == 20 and d["config"]["baseline_config"].startswith("configs[3]")
     assert abs(d["value"] - 100_000_000 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]

@@ -108,24 +108,26 @@ FORMATS = {
 }
 
 
-def _factor_for(rng, shape, other_dim):
+def _factor_for(rng, shape, other_dim, last=0.0):
     m, n = shape
     if m == n:
         return _tri_factor(rng, m)
     if m == 2:
         q = np.stack([np.exp(0.2 * rng.standard_normal(n)), 0.1 * rng.standard_normal(n)])
-        q[1, -1] = 0.0      # psgd.py:205: the last entry of the stored column is unused and stays 0
+        # psgd.py:205 documents the last entry of the stored column as unused (it starts at 0 and the update keeps it 0:
+        # grad1_bias ends with 0, :238), but the arithmetic of :219, :232, :265 READS it: a caller's non-zero value takes part
+        q[1, -1] = last
         return q
     return np.exp(0.2 * rng.standard_normal((1, n)))
 
 
-@pytest.mark.parametrize("fmt", sorted(FORMATS))
-def test_sparse_formats_through_dispatcher(psgd, fmt):
+@pytest.mark.parametrize("fmt,last", [(f, 0.0) for f in sorted(FORMATS)] + [(f, 0.07) for f in sorted(FORMATS) if "norm" in f])
+def test_sparse_formats_through_dispatcher(psgd, fmt, last):
     sl, sr = FORMATS[fmt]
     assert orc.kron_format(sl, sr) == fmt
     rng = np.random.default_rng(len(fmt))
     M, N = sl[1], sr[1]
-    Ql, Qr = _factor_for(rng, sl, M), _factor_for(rng, sr, N)
+    Ql, Qr = _factor_for(rng, sl, M, last), _factor_for(rng, sr, N, last)
     dX, G = rng.standard_normal((M, N)), rng.standard_normal((M, N))
     dG = dX * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))
     a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG, G)]
@@ -964,6 +966,9 @@ BIG_FORMATS = [
     ("norm_dense", (2, 5200), (600, 600)), ("dense_scale", (640, 640), (1, 5400)), ("dense_norm", (520, 520), (2, 4300)),
     # ... and products big enough for the planes whose maxima the gradient's planes then reuse (sparse_grad_splitk on f16 x 2 planes)
     ("norm_dense", (2, 12000), (640, 640)),
+    # ... many vectors, but a product BELOW the planes' threshold (13100 x 544^2 < 4e9): the in-place solve must stay on the
+    # substitution strips -- an explicit-inverse product on launch_gemm would read Bt while other tiles overwrite it (515 tiles)
+    ("norm_dense", (2, 13100), (544, 544)),
 ]
 
 
@@ -1044,6 +1049,42 @@ def test_update_over_condition_numbers(psgd, cond_q):
         assert np.isfinite(out[i]).all()
         assert rel_err(out[i], ref[i]) < TOL, (i, cond_q)
         assert rel_err(out[i] - q0, ref[i] - q0) < bar, (i, cond_q, bar)
+
+
+@pytest.mark.parametrize("cond_q", [1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6])
+def test_update_over_condition_numbers_inverse_route(psgd, hip_lib, cond_q):
+    """The same sweep at a shape whose solves run as products with EXPLICIT INVERSES (M, N >= 2048: tri_inverse), up to the
+    conditioning that is ordinary for a converged PSGD factor (cond(Q)^2 = cond(P): 1e5 - 1e6).  States at 1e-5, increments at
+    max(2e-3, 10 eps cond), and at every cond the inverse route's errors stay within 2x of the substitution strips' on the very
+    same inputs (psgd_kron_set_tuning(11, 0)) -- the route has no condition estimate and no fallback, so this is its licence."""
+    rng = np.random.default_rng(int(np.log10(cond_q)) + 70)
+    M, N = 2048, 2304
+    Ql = _spd_cholesky_factor(rng, M, cond_q ** 2).astype(np.float32) if cond_q > 1 else np.eye(M, dtype=np.float32)
+    Qr = _spd_cholesky_factor(rng, N, cond_q ** 2).astype(np.float32) if cond_q > 1 else np.eye(N, dtype=np.float32)
+    Ql /= np.max(np.abs(Ql)); Qr /= np.max(np.abs(Qr))
+    dX = rng.standard_normal((M, N)).astype(np.float32)
+    Ql64, Qr64 = Ql.astype(np.float64), Qr.astype(np.float64)
+    dG = (np.linalg.solve(Ql64.T @ Ql64, dX) @ np.linalg.inv(Qr64.T @ Qr64) * np.exp(rng.uniform(-0.5, 0.5, (1, N)))).astype(np.float32)
+    ref = orc.update_precond_kron(Ql64, Qr64, dX.astype(np.float64), dG.astype(np.float64), 0.01)
+    rho = np.sqrt(np.max(np.abs(Ql64)) / np.max(np.abs(Qr64)))
+    bases = (Ql64 / rho, Qr64 * rho)
+    args = (_dev(Ql), _dev(Qr), _dev(dX), _dev(dG))
+
+    def errors():
+        out = [t.cpu().numpy().astype(np.float64) for t in psgd.update_precond_kron(*args, 0.01)]
+        assert all(np.isfinite(o).all() for o in out)
+        return [(rel_err(out[i], ref[i]), rel_err(out[i] - bases[i], ref[i] - bases[i])) for i in range(2)]
+    e_inv = errors()
+    hip_lib.psgd_kron_set_tuning(11, 0)
+    try:
+        e_sub = errors()
+    finally:
+        hip_lib.psgd_kron_set_tuning(11, 1)
+    bar = max(INCR_TOL, 10 * 6e-8 * cond_q)
+    for i in range(2):
+        assert e_inv[i][0] < TOL, (i, cond_q, e_inv, e_sub)
+        assert e_inv[i][1] < bar, (i, cond_q, e_inv, e_sub, bar)
+        assert e_inv[i][0] <= 2 * e_sub[i][0] + 1e-7 and e_inv[i][1] <= 2 * e_sub[i][1] + 1e-5, (i, cond_q, e_inv, e_sub)
 
 
 @pytest.mark.parametrize("M,N", [(300, 200), (1100, 530), (2048, 1536), (2176, 2048)])

@@ -1,8 +1,12 @@
-"""GPU, two PROCESSES on one device: the sharded drivers with the product's HIP stage kernels on each rank's row shard
-and REAL collectives between the processes (gloo over device tensors: RCCL refuses two ranks on one GPU, and only one
-GPU is available to the tests).  Complements tests/test_sharded_gpu.py (collectives emulated inside one process) and
-tests/test_sharded_cpu.py (real collectives, NumPy stage kernels): here both are real.  Rank 0 compares the
-concatenated shards with the unsharded HIP call and the oracle."""
+"""GPU, two PROCESSES: the sharded drivers with the product's HIP stage kernels on each rank's row shard and REAL
+collectives between the processes.  Two transports:
+  gloo-one-device   both ranks on cuda:0, gloo over device tensors (RCCL refuses two ranks on one GPU): what a 1-GPU box can run
+  rccl-two-devices  rank k on cuda:k, backend "nccl" (= RCCL over xGMI): runs wherever torch.cuda.device_count() >= 2, skipped
+                    otherwise -- the first multi-GPU box exercises RCCL here, not only through bench.py
+Complements tests/test_sharded_gpu.py (collectives emulated inside one process) and tests/test_sharded_cpu.py (real
+collectives, NumPy stage kernels): here both are real.  Rank 0 compares the concatenated shards with the unsharded HIP call
+and the oracle, and the REDUCED workspace regions of the two ranks bit for bit (the property the all-gather + rank-order fold
+exists for: every rank redoes the r x r algebra on identical numbers)."""
 import os
 import sys
 import tempfile
@@ -19,22 +23,37 @@ pytestmark = pytest.mark.gpu
 WORLD = 2
 
 
-def _worker(rank, port, outdir, N, r):
+def _worker(rank, port, outdir, N, r, two_devices):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dev = torch.device("cuda", rank if two_devices else 0)
+    torch.cuda.set_device(dev)
+    if two_devices:
+        dist.init_process_group("nccl", rank=rank, world_size=WORLD, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from psgd_tf_amd import sharded
-    dev = torch.device("cuda:0")
+    from psgd_tf_amd import _lib, sharded
     p = make_uvd_problem(N, r, seed=21, uv_gain=2.0, d_spread=0.3)
     lo, hi = sharded.shard_rows(N, rank, WORLD)
     t = {k: torch.from_numpy(np.ascontiguousarray(v[lo:hi])).to(dev) for k, v in p.items()}
+    red = {}                                      # reduced workspace regions, snapshot right after the call that made them
+    be = sharded.hip_backend_for(t["U"]) if r <= _lib.UVD_MAX_RANK else None      # (r > 32: the wide path all-reduces tensors)
     for upd in (True, False):
         sharded.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32, balance=False, update_U=upd)
+        if be is not None:
+            red["upd%d_gram" % upd] = be.sums(11).cpu().numpy().copy()
+            red["upd%d_max" % upd] = be.maxbuf(12).cpu().numpy().copy()
     out = sharded.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    if be is not None:
+        red["apply_s2"] = be.sums(2).cpu().numpy().copy()
     outf = sharded.update_precond_UVd_math_and_precond_grad(t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY32,
                                                             balance=False, update_U=True)
+    if be is not None:
+        red["fused_gram"] = be.sums(11).cpu().numpy().copy()
+        red["fused_s13"] = be.sums(13).cpu().numpy().copy()
     # sparse LU: the r x r corner replicated, the tail rows split between the ranks (tests/test_sharded_cpu.py layout)
     n, rr = N // 4, 7
     s = make_splu_problem(n, rr, seed=5)
@@ -48,22 +67,42 @@ def _worker(rank, port, outdir, N, r):
     loc = {k: f(np.concatenate([s[k][:rr], s[k][rr + lo2:rr + hi2]], 0)) for k in ("dx", "dg", "g")}
     pre0 = sharded.precond_grad_splu(L12, l3, U12, u3, loc["g"])
     new = sharded.update_precond_splu(L12, l3, U12, u3, loc["dx"], loc["dg"], 0.1, TINY32)
+    sb = sharded._splu_backend_for(L12)
+    red["splu_s3"] = sb.sums(3).cpu().numpy().copy()
+    red["splu_max"] = sb.maxbuf().cpu().numpy().copy()
     pre1 = sharded.precond_grad_splu(*new, loc["g"])
+    red["splu_apply_s2"] = sb.sums(2).cpu().numpy().copy()
     np.savez(os.path.join(outdir, "r%d.npz" % rank), U=t["U"].cpu().numpy(), V=t["V"].cpu().numpy(), d=t["d"].cpu().numpy(),
              out=out.cpu().numpy(), outf=outf.cpu().numpy(), pre0=pre0.cpu().numpy(), pre1=pre1.cpu().numpy(),
-             L12=new[0].cpu().numpy(), l3=new[1].cpu().numpy(), U12=new[2].cpu().numpy(), u3=new[3].cpu().numpy())
+             L12=new[0].cpu().numpy(), l3=new[1].cpu().numpy(), U12=new[2].cpu().numpy(), u3=new[3].cpu().numpy(),
+             backend=np.array(dist.get_backend()), device=np.array(dev.index), **{"red_" + k: v for k, v in red.items()})
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _two_devices():
+    return torch.cuda.device_count() >= 2          # (counting devices does not initialise the GPU runtime)
+
+
+@pytest.mark.parametrize("transport", [
+    "gloo-one-device",
+    pytest.param("rccl-two-devices", marks=pytest.mark.skipif(not _two_devices(), reason="needs two GPUs (rank k on cuda:k over RCCL)"))])
 @pytest.mark.parametrize("N,r", [(200003, 20), (60003, 40)])      # r = 40: the wide-rank path (column chunks), sharded
-def test_two_processes_real_kernels_real_collectives(hip_lib, N, r):
+def test_two_processes_real_kernels_real_collectives(hip_lib, N, r, transport):
     import torch.multiprocessing as mp
     import preconditioned_stochastic_gradient_descent as psgd
     outdir = tempfile.mkdtemp()
     port = 29600 + os.getpid() % 300
-    mp.start_processes(_worker, args=(port, outdir, N, r), nprocs=WORLD, join=True, start_method="spawn")
+    two = transport == "rccl-two-devices"
+    mp.start_processes(_worker, args=(port, outdir, N, r, two), nprocs=WORLD, join=True, start_method="spawn")
     sh = [np.load(os.path.join(outdir, "r%d.npz" % k)) for k in range(WORLD)]
+    assert str(sh[0]["backend"]) == ("nccl" if two else "gloo")
+    assert [int(s["device"]) for s in sh] == ([0, 1] if two else [0, 0])
+    # every reduced region is the same BITS on both ranks (fold of the same copies in the same order)
+    reds = [k for k in sh[0].files if k.startswith("red_")]
+    assert ("red_fused_s13" in reds) == (r <= 32) and "red_splu_s3" in reds
+    for k in reds:
+        assert sh[0][k].tobytes() == sh[1][k].tobytes(), k
     got = {k: np.concatenate([s[k] for s in sh], 0) for k in ("U", "V", "d", "out", "outf")}
     p = make_uvd_problem(N, r, seed=21, uv_gain=2.0, d_spread=0.3)
     a = {k: torch.from_numpy(v).cuda() for k, v in p.items()}

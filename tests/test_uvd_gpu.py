@@ -80,9 +80,9 @@ def test_ipuvt_matvec(psgd, N, r):
 @pytest.mark.parametrize("N,r", SHAPES)
 @pytest.mark.parametrize("update_U", [True, False])
 def test_update_matches_oracle(psgd, N, r, update_U):
-    if N < r:   # K = I + V'U stays well conditioned only with enough rows; N = 1 covered below
-        pytest.skip("degenerate")
-    p = make_uvd_problem(N, r, seed=3 * N + r, uv_gain=2.0, d_spread=0.3)
+    # (N < r: K = I + V'U is the identity plus a matrix of rank N; a smaller gain keeps it well conditioned -- psgd.py:574-578
+    #  treats such a shape like any other, and so does this test)
+    p = make_uvd_problem(N, r, seed=3 * N + r, uv_gain=2.0 if N >= r else 0.5, d_spread=0.3)
     t = _to_dev(p)
     ret = psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32,
                                         balance=False, update_U=update_U)
@@ -101,6 +101,30 @@ def test_update_matches_oracle(psgd, N, r, update_U):
         assert rel_err(inc_got, inc_ref) < INCR_TOL, k
     # v, h read-only
     assert np.array_equal(t["v"].cpu().numpy(), p["v"]) and np.array_equal(t["h"].cpu().numpy(), p["h"])
+
+
+@pytest.mark.parametrize("N,r", [(1, 4), (3, 10), (17, 20), (2, 32), (31, 32)])
+@pytest.mark.parametrize("update_U", [True, False])
+@pytest.mark.parametrize("balance", [False, True])
+def test_update_with_fewer_rows_than_rank(psgd, N, r, update_U, balance):
+    """N < r (psgd.py:574-578: the r x r solves with K = I + V'U do not care that U, V have fewer rows than columns):
+    the update, then the apply and the fused update -> apply on the updated state, against the fp64 oracle."""
+    p = make_uvd_problem(N, r, seed=7 * N + r, uv_gain=0.5, d_spread=0.3)
+    if balance:
+        p["U"] *= 3.0
+    t, q = _to_dev(p), _f64(p)
+    psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32, balance=balance, update_U=update_U)
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=balance, update_U=update_U)
+    for k in ("U", "V", "d"):
+        assert rel_err(t[k].cpu().numpy(), q[k]) < STATE_TOL, k
+    out = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+    assert rel_err(out.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < APPLY_TOL
+    outf = psgd.update_precond_UVd_math_and_precond_grad(t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY32,
+                                                         balance=False, update_U=not update_U)
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=not update_U)
+    for k in ("U", "V", "d"):
+        assert rel_err(t[k].cpu().numpy(), q[k]) < STATE_TOL, k
+    assert rel_err(outf.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < APPLY_TOL
 
 
 @pytest.mark.parametrize("N,r", [(5000, 20), (1021, 10), (4099, 7)])
