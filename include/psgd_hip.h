@@ -36,9 +36,10 @@ extern "C" {
 #endif
 
 /* History: 1 = round 1; 2 = round 2 (psgd_uvd_fused_s1_f32 removed, SUMS region of stage 13 holds 4r entries,
- * workspace layout changed); 3 = round 3 (entry points added, bf16 apply workspace carries a hand-off route word).
+ * workspace layout changed); 3 = round 3 (entry points added, bf16 apply workspace carries a hand-off route word);
+ * 4 = round 4 (Kron dense (x) dense workspaces of small layers carry the scratch of the fused strip kernels).
  * psgd_tf_amd/_lib.py refuses a library whose psgd_abi_version() differs from the one it was written for. */
-#define PSGD_ABI_VERSION 3
+#define PSGD_ABI_VERSION 4
 
 #define PSGD_OK                 0
 #define PSGD_ERR_BAD_ARG       (-1)   /* null pointer, N <= 0, r <= 0 ...            */
@@ -296,7 +297,11 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * key 20: sparse formats: 1 (default) data-sized products against a dense factor (>= 512, data >= 1M elements) run on f16 x 2
  *        operand planes, 0 = on the in-GEMM split kernels.
  * key 17: gradient grid of the large fp32 update with M = N: 1 (default) every XCD works through a contiguous run of the
- *        tile list, 2 = over 4 x 4 tile patches, 0 = tiles dealt to the XCDs one by one. */
+ *        tile list, 2 = over 4 x 4 tile patches, 0 = tiles dealt to the XCDs one by one.
+ * key 21: single calls on small layers (M <= 512, N <= 256, at most 160 tiles of 16 x 16): 1 = the fused strip kernels
+ *        of psgd_kron_small.hip (one launch per call, or one per phase: 2 for the apply, 4 for the update; no Grams, no
+ *        prepared state; parity-green, measured slower: opt-in); 0 (default) = the stage kernels the batched entry points
+ *        use (Grams + products; batch-of-one update).  Changes what prepared state means: prepare again after changing it. */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

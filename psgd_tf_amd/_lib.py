@@ -13,7 +13,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PSGD_HIP_LIB", os.path.join(_CSRC, "libpsgd_hip.so"))   # override: build experiments only
 
 PSGD_OK = 0
-PSGD_ABI_VERSION = 3       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
+PSGD_ABI_VERSION = 4       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
 PSGD_WS_SUMS_F64 = 0
 PSGD_WS_MAX_F32 = 1
 PSGD_WS_SEND_F64 = 2

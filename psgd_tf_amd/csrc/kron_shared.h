@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 namespace psgdk {
 
 // QlS = Ql * sqrt(max|Qr| / max|Ql|), QrS = Qr / that  (psgd.py:166-170).  0 on success.
@@ -31,6 +33,15 @@ int kron_inv_prepare(void* ws, int M, int N, hipStream_t main);
 int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
                           int M, int N, void* ws, hipStream_t main, hipStream_t side);
 int kron_inv_solves_back(float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
+
+// Small layers (M, N <= 512; LeNet5) through the reference's per-layer calls: fused strip kernels (psgd_kron_small.hip), one launch
+// per call when one workgroup finishes the layer quickly, one per phase otherwise.  kron_small_fused: the shape rule (a pure
+// function of the shape); scratch: kron_small_ws_bytes(M, N) bytes, 256-aligned, contents need not survive between calls.
+bool kron_small_fused(int M, int N);
+int64_t kron_small_ws_bytes(int M, int N);
+int kron_small_apply(const float* Ql, const float* Qr, const float* G, float* out, int M, int N, void* scratch, hipStream_t st);
+int kron_small_update(const float* Ql, const float* Qr, const float* dX, const float* dG, float* QlOut, float* QrOut, int M, int N,
+                      float step, float tiny, void* scratch, hipStream_t st);
 
 // The update has two chains that meet only at the gradient products: the products dG QrS' -> QlS (.) (psgd.py:173) and
 // the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for

@@ -105,9 +105,10 @@ def invalidate_factor_cache():
 
 def set_tuning(key, value):
     """psgd_kron_set_tuning through the Python boundary: keys that change what the prepared state in a workspace means
-    (4: operand planes or not, 12: their format) also drop every prepared Gram / plane set, as the header requires."""
+    (4: operand planes or not, 12: their format, 21: small layers with or without Grams) also drop every prepared Gram / plane
+    set, as the header requires."""
     _lib.check(_lib.load().psgd_kron_set_tuning(int(key), int(value)), "psgd_kron_set_tuning")
-    if int(key) in (4, 12):
+    if int(key) in (4, 12, 21):
         invalidate_factor_cache()
 
 

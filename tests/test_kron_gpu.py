@@ -37,6 +37,17 @@ def psgd(hip_lib):
     return m
 
 
+@pytest.fixture
+def stage_kernels(hip_lib):
+    """Single calls on small layers on the STAGE kernels (Grams + products, batch-of-one update: what the batched entry
+    points run; the default) and not on the opt-in fused strip kernels of psgd_kron_small.hip -- for the tests of those
+    stages' own variants."""
+    from psgd_tf_amd import kron
+    kron.set_tuning(21, 0)             # (the default; the wrapper also drops the prepared factor state, which differs per route)
+    yield
+    kron.set_tuning(21, 0)
+
+
 @pytest.mark.parametrize("M,N", DD_SHAPES)
 def test_dense_dense_apply(psgd, M, N):
     rng = np.random.default_rng(M * 1000 + N)
@@ -419,7 +430,7 @@ def test_update_with_forked_chains_is_capturable(psgd, warm, big):
 
 
 @pytest.mark.parametrize("M,N", [(26, 6), (257, 120), (85, 10), (1, 1), (2, 3), (300, 300), (512, 40), (400, 300), (512, 512)])
-def test_small_update_routes_agree(psgd, hip_lib, M, N):
+def test_small_update_routes_agree(psgd, hip_lib, stage_kernels, M, N):
     """psgd_kron_set_tuning(7, .): the small-layer update as one launch per stage of each chain on the large-layer path
     (0), with product and solve stages sharing launches in the batched form (bit 0), and with single calls routed through
     a batch of one (bit 1, default 3).  Same block algorithms: batched results bitwise equal with and without shared
@@ -447,7 +458,7 @@ def test_small_update_routes_agree(psgd, hip_lib, M, N):
 
 
 @pytest.mark.parametrize("M,N", [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (200, 333)])
-def test_small_gemm_bodies_bitwise_equal(psgd, hip_lib, M, N):
+def test_small_gemm_bodies_bitwise_equal(psgd, hip_lib, stage_kernels, M, N):
     """The 32 x 32-tile products have two bodies (psgd_kron_set_tuning(3, .)): same tiles, same K order, same fp32 MFMA
     chains -> bitwise equal updates and applies (single and batched calls)."""
     rng = np.random.default_rng(11 * M + N)
@@ -469,6 +480,83 @@ def test_small_gemm_bodies_bitwise_equal(psgd, hip_lib, M, N):
         assert torch.equal(x, y)
     ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, dG)))
     assert rel_err(outs[0][0].cpu().numpy(), ref) < TOL and rel_err(outs[0][3].cpu().numpy(), ref) < TOL
+
+
+SMALL_FUSED_SHAPES = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (1, 1), (1, 7), (31, 1), (2, 2), (16, 16), (17, 15),
+                      (15, 17), (33, 250), (512, 40), (500, 256), (63, 120), (128, 200), (300, 120), (160, 256), (48, 33)]
+
+
+@pytest.mark.parametrize("M,N", SMALL_FUSED_SHAPES)
+def test_small_fused_kernels_agree_with_stage_kernels(psgd, hip_lib, M, N):
+    """Single calls on small layers (the reference's call pattern, mnist_with_lenet5.py:51,53) have a second implementation,
+    the fused strip kernels of psgd_kron_small.hip (one launch, or one per phase; psgd_kron_set_tuning(21, 1): opt-in, measured
+    slower than the stage kernels); the default and the batched entry points run the stage kernels.  Same mathematics,
+    another association: the two agree to fp32 rounding, both hold the parity bars against the fp64 oracle, inputs are never
+    written, the new factors are upper triangular with the lower part of the balanced input (zeros), and a sequence of calls
+    on one workspace repeats bit for bit (no state left behind)."""
+    rng = np.random.default_rng(31 * M + N)
+    Ql, Qr = _tri_factor(rng, M) * 2.5, _tri_factor(rng, N)
+    dX, G = rng.standard_normal((M, N)), rng.standard_normal((M, N))
+    dG = (np.eye(M) + 0.1 * np.diag(rng.uniform(0, 5, M))) @ dX @ (np.eye(N) + 0.1 * np.diag(rng.uniform(0, 5, N)))
+    a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG, G)]
+    a64 = [a.astype(np.float64) for a in a32]
+    t = [_dev(a) for a in a32]
+    from psgd_tf_amd import kron
+    res = {}
+    try:
+        for fused in (1, 0, 1):
+            kron.set_tuning(21, fused)
+            out = psgd.precond_grad_kron(t[0], t[1], t[4])
+            new = psgd.update_precond_kron(t[0], t[1], t[2], t[3], 0.01)
+            if fused and fused in res:
+                assert torch.equal(out, res[1][0]) and torch.equal(new[0], res[1][1]) and torch.equal(new[1], res[1][2])
+            res[fused] = (out, new[0], new[1])
+    finally:
+        kron.set_tuning(21, 0)
+    for a, b in zip(t, a32):
+        assert np.array_equal(a.cpu().numpy(), b)
+    ref_out = orc.precond_grad_kron(a64[0], a64[1], a64[4])
+    ref_new = orc.update_precond_kron(a64[0], a64[1], a64[2], a64[3], 0.01)
+    rho = np.sqrt(np.max(np.diag(a64[0])) / np.max(np.diag(a64[1])))
+    for fused in (1, 0):
+        out, ql, qr = (x.cpu().numpy() for x in res[fused])
+        assert rel_err(out, ref_out) < TOL, fused
+        for got, want, base in ((ql, ref_new[0], a64[0] / rho), (qr, ref_new[1], a64[1] * rho)):
+            assert rel_err(got, want) < TOL, fused
+            if np.linalg.norm(want - base) > 0:
+                assert rel_err(got.astype(np.float64) - base, want - base) < INCR_TOL, fused
+            assert np.array_equal(got, np.triu(got)) and (np.diag(got) > 0).all()
+    for i in range(3):
+        assert rel_err(res[1][i].cpu().numpy(), res[0][i].cpu().numpy()) < 2e-6, i
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_small_update_propagates_nan_and_ignores_the_lower_triangle(psgd, fused):
+    """NaN in the data reaches both new factors (tf.reduce_max semantics of psgd.py:177-178); whatever lies below the diagonal of
+    an input factor is not read by any product or solve (stage kernels and fused strip kernels)."""
+    from psgd_tf_amd import kron
+    kron.set_tuning(21, fused)
+    try:
+        _nan_and_lower_triangle_case(psgd)
+    finally:
+        kron.set_tuning(21, 0)
+
+
+def _nan_and_lower_triangle_case(psgd):
+    rng = np.random.default_rng(3)
+    M, N = 121, 84
+    Ql, Qr = _tri_factor(rng, M), _tri_factor(rng, N)
+    dX, dG = rng.standard_normal((M, N)), rng.standard_normal((M, N))
+    ref = orc.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    junk_l = Ql + np.tril(np.full((M, M), np.nan), -1)
+    got = psgd.update_precond_kron(_dev(junk_l), _dev(Qr), _dev(dX), _dev(dG), 0.01)
+    assert rel_err(np.triu(got[0].cpu().numpy()), ref[0]) < TOL and rel_err(got[1].cpu().numpy(), ref[1]) < TOL
+    out = psgd.precond_grad_kron(_dev(junk_l), _dev(Qr), _dev(dG))
+    assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(Ql, Qr, dG)) < TOL
+    dXn = dX.copy()
+    dXn[5, 7] = np.nan
+    bad = psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dXn), _dev(dG), 0.01)
+    assert torch.isnan(bad[0]).any() and torch.isnan(bad[1]).any()
 
 
 # ----------------------------------------------------------------------------- bf16-operand update
@@ -634,11 +722,22 @@ def test_bf16_update_rejects_mixed_dtypes(psgd):
                                  torch.ones(8, 16, device="cuda"), torch.ones(8, 16, device="cuda"))
 
 
-@pytest.mark.parametrize("M,N", [(257, 120), (85, 10), (16, 40), (640, 1024), (1100, 1030), (2049, 1024)])
-def test_prepared_grams_follow_the_factors(psgd, M, N):
+@pytest.mark.parametrize("M,N,fused", [(257, 120, 1), (257, 120, 0), (85, 10, 1), (85, 10, 0), (16, 40, 0), (640, 1024, 1),
+                                       (1100, 1030, 1), (2049, 1024, 1)])
+def test_prepared_grams_follow_the_factors(psgd, hip_lib, M, N, fused):
     """fp32 apply: the Grams of the factors are kept in the workspace and recomputed only when the factors change (same
-    rules as the bf16 copies below); single and batched calls; small (both Grams), large (reference-order Gram) and
-    pre-split-plane plans (M, N >= 1024: Gram and factor planes are the prepared state)."""
+    rules as the bf16 copies below); single and batched calls; small (both Grams: the stage kernels, fused = 0; the opt-in
+    fused strip kernels have no prepared state and must behave the same), large (reference-order Gram) and pre-split-plane
+    plans (M, N >= 1024: Gram and factor planes are the prepared state)."""
+    from psgd_tf_amd import kron
+    kron.set_tuning(21, fused)
+    try:
+        _prepared_grams_case(psgd, M, N)
+    finally:
+        kron.set_tuning(21, 0)
+
+
+def _prepared_grams_case(psgd, M, N):
     rng = np.random.default_rng(M + N)
     Ql, Qr = _dev(_tri_factor(rng, M).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
     G, G2 = _dev(rng.standard_normal((M, N))), _dev(rng.standard_normal((M, N)))
@@ -905,7 +1004,7 @@ def test_bf16_factor_copies_follow_the_factors(psgd):
 
 @pytest.mark.parametrize("tile_choice,x3", [(1, 1), (2, 1), (2, 0), (3, 1)])
 @pytest.mark.parametrize("M,N", [(257, 120), (300, 500), (1100, 530), (128, 128), (640, 256)])
-def test_every_gemm_tile_size_forced(psgd, hip_lib, M, N, tile_choice, x3):
+def test_every_gemm_tile_size_forced(psgd, hip_lib, stage_kernels, M, N, tile_choice, x3):
     """The fp32 GEMM picks its tile size (32 / 64 / 128) from the problem size; force each one on small
     and ragged shapes (edge tiles, unaligned leading dimensions) and compare with the oracle.  The 128 tile has two
     bodies: the bf16 x 3 split GEMM (x3 = 1, default) and the exact fp32-MFMA one (x3 = 0)."""
@@ -928,9 +1027,20 @@ def test_every_gemm_tile_size_forced(psgd, hip_lib, M, N, tile_choice, x3):
     assert rel_err(Ql_n.cpu().numpy(), Ql_r) < TOL and rel_err(Qr_n.cpu().numpy(), Qr_r) < TOL
 
 
-def test_batched_lenet_set_equals_per_layer(psgd):
-    """The batched calls must agree with the per-layer results (bitwise for the GEMM-only apply; the update's
-    triangular solves may take a different blocking per path, so those agree to rounding)."""
+@pytest.mark.parametrize("fused", [0, 1])
+def test_batched_lenet_set_equals_per_layer(psgd, hip_lib, fused):
+    """The batched calls must agree with the per-layer results.  Per-layer calls on the stage kernels (fused = 0): bitwise for
+    the GEMM-only apply; the update's triangular solves may take a different blocking per path, so those agree to rounding.
+    Per-layer calls on the fused strip kernels (opt-in): another association of the same products -- to rounding."""
+    from psgd_tf_amd import kron
+    kron.set_tuning(21, fused)
+    try:
+        _batched_vs_per_layer(psgd, fused)
+    finally:
+        kron.set_tuning(21, 0)
+
+
+def _batched_vs_per_layer(psgd, fused):
     shapes = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (1, 1), (3, 3)]   # > 8: two chunks
     rng = np.random.default_rng(5)
     Qls = [_dev(_tri_factor(rng, m) * 2.0) for m, n in shapes]
@@ -941,7 +1051,11 @@ def test_batched_lenet_set_equals_per_layer(psgd):
     outs = psgd.precond_grad_kron_batched(Qls, Qrs, Gs)
     news = psgd.update_precond_kron_batched(Qls, Qrs, dXs, dGs, 0.01)
     for i, (m, n) in enumerate(shapes):
-        assert torch.equal(outs[i], psgd.precond_grad_kron(Qls[i], Qrs[i], Gs[i])), (m, n)
+        one = psgd.precond_grad_kron(Qls[i], Qrs[i], Gs[i])
+        if fused:
+            assert rel_err(outs[i].cpu().numpy(), one.cpu().numpy()) < 2e-6, (m, n)
+        else:
+            assert torch.equal(outs[i], one), (m, n)
         a, b = psgd.update_precond_kron(Qls[i], Qrs[i], dXs[i], dGs[i], 0.01)
         assert rel_err(news[i][0].cpu().numpy(), a.cpu().numpy()) < 2e-6, (m, n)
         assert rel_err(news[i][1].cpu().numpy(), b.cpu().numpy()) < 2e-6, (m, n)
@@ -1080,8 +1194,11 @@ def test_update_over_condition_numbers_inverse_route(psgd, hip_lib, cond_q):
         e_sub = errors()
     finally:
         hip_lib.psgd_kron_set_tuning(11, 1)
-    bar = max(INCR_TOL, 10 * 6e-8 * cond_q)
     for i in range(2):
+        # the increment is read off an fp32 state: what the state's own rounding (eps |Q|) leaves of it is a floor no route can beat
+        # (cond 1e5: the normalised step moves Ql by ~4e-8 |Ql|, below one ulp -- both routes return the balanced factor, bit for bit)
+        floor = 2 * 6e-8 * np.linalg.norm(ref[i]) / max(np.linalg.norm(ref[i] - bases[i]), 1e-300)
+        bar = max(INCR_TOL, 10 * 6e-8 * cond_q, floor)
         assert e_inv[i][0] < TOL, (i, cond_q, e_inv, e_sub)
         assert e_inv[i][1] < bar, (i, cond_q, e_inv, e_sub, bar)
         assert e_inv[i][0] <= 2 * e_sub[i][0] + 1e-7 and e_inv[i][1] <= 2 * e_sub[i][1] + 1e-5, (i, cond_q, e_inv, e_sub)
