@@ -1137,6 +1137,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_blk(P3Args g, int b) {
   p3_body<FMT, ER>(g, by, bx, L);
 }
 
+// ... with every tile's K range dealt to `nchunk` blocks (P3Split; partials summed in chunk order by the last block to arrive).
+// The top levels of an inversion are a few hundred tiles with chains of up to 64 K steps each, one workgroup per CU at the
+// 1.5 us per step a lone workgroup reaches: the chain is what bounds them, not the chip.  cnt: one word per tile, zero on entry
+// and left at zero.
+template <int FMT>
+__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_blk_splitk(P3Args g, int b, int nchunk, float* scratch, unsigned* cnt) {
+  __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
+  const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  const int tb = b / 128, per = tb * tb;
+  const int p = t / per, r = t % per;
+  const int by = (p * 2 * b) / 128 + r / tb, bx = (p * 2 * b + b) / 128 + r % tb;
+  if (by * 128 >= g.e.M || bx * 128 >= g.e.N) return;        // (every chunk of such a tile: its counter stays untouched)
+  p3_body<FMT, FMT ? 0 : 2>(g, by, bx, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
+}
+
 // two independent products in one grid (see k_gemm_x3_pair)
 struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1, tiles1; };
 
@@ -2059,7 +2074,11 @@ __device__ __forceinline__ void trsm_reg_body(const TrsmArgs& t, const float* __
 // s_waitcnt).  Tried without gain: 8-byte A-operand loads over interleaved column tiles (41 us), an L2 warm-up pass
 // over the strip (54), the round loop as a real loop with retired slots re-reading slot 0 (60), 32 vectors per
 // workgroup (50).
-__device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const float* __restrict__ Dinv, int v0, float (*Ybuf)[512]) {
+// IDENT: the right-hand side is the identity (vector v = unit vector v: the strip's rows of the INVERSE of the 512-block, see
+// k_tri_inv512); amax (optional) receives max|Y| of the workgroup's 16 vectors.
+template <bool IDENT = false>
+__device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const float* __restrict__ Dinv, int v0, float (*Ybuf)[512],
+                                                   float* amax = nullptr) {
   const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long xi = (t.xi == 0 && t.xj == 0) ? t.si : t.xi, xj = (t.xi == 0 && t.xj == 0) ? t.sj : t.xj;
@@ -2072,7 +2091,9 @@ __device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const floa
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        acc[it][h][e] = t.X[(long)v * xi + (long)(32 * (w + 4 * it) + 16 * h + 4 * g + e) * xj];
+        acc[it][h][e] = IDENT ? ((32 * (w + 4 * it) + 16 * h + 4 * g + e == v) ? 1.0f : 0.0f)
+                              : t.X[(long)v * xi + (long)(32 * (w + 4 * it) + 16 * h + 4 * g + e) * xj];
+  float ymax = 0.0f;
   const float* qlane = t.Q + (long)(4 * g) * t.ldq + 32 * w + l;
   float qb[4][kIt][2][2][4], dvb[2][2][4][2];
   // slot `it` of the round of sub-step s (= block w + 4 ((s >> 2) + it)); slot 0 is loaded even when it is not behind
@@ -2134,6 +2155,7 @@ __device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const floa
         const int smt = c2 >> 4, sg = (c2 & 15) >> 2, se = c2 & 3;                   // c2 = 16 mt + 4 g + e (e = 0 or 2)
         const float* src = &Ybuf[u & 1][(smt * 4 + se) * 64 + sg * 16 + sv];
         const float2 val = make_float2(-src[0], -src[64]);
+        if (IDENT) ymax = amaxf(ymax, amaxf(fabsf(val.x), fabsf(val.y)));
         if (!(TRSM_DBG & 2)) *reinterpret_cast<float2*>(t.Y + (long)(v0 + sv) * t.si + 32 * s + c2) = val;
       } else {
 #pragma unroll
@@ -2175,6 +2197,11 @@ __device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const floa
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[it][h] = acc[it + 1][h];
   }
+  if (IDENT && amax) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ymax = amaxf(ymax, __shfl_down(ymax, off, 64));
+    if (lane == 0) atomic_amax(amax, ymax);
+  }
 #undef TRSM_LOAD_Q
 #undef TRSM_LOAD_D
 }
@@ -2182,6 +2209,20 @@ __device__ __forceinline__ void trsm_reg_full_body(const TrsmArgs& t, const floa
 __global__ __launch_bounds__(kThreads) void k_trsm_ut_reg_full(TrsmArgs t, const float* __restrict__ Dinv) {
   __shared__ float Ybuf[2][512];
   trsm_reg_full_body(t, Dinv, blockIdx.x * 16, Ybuf);
+}
+
+// The inverse of every 512 x 512 diagonal block of an upper-triangular Q [n x n], n a multiple of 512, in ONE launch: the strip
+// solve Y Q_d = I (row v of Y = row v of Q_d^-1), 32 workgroups of 16 rows per block, from the inverted 32-blocks `dinv` of the
+// balance launch.  Replaces k_tri_inv128 and the doubling levels 128 and 256 of tri_inverse (nine launch-bound launches, ~160 us
+// inside the update) by one of the strip kernel's ~40 us.  Same arithmetic as the substitution route's strips (fp32 fma chains).
+// Writes the blocks of Inv (zeros below the diagonal come out of the substitution itself) and accumulates max|.| into *amax.
+__global__ __launch_bounds__(kThreads) void k_tri_inv512(const float* __restrict__ Q, int n, const float* __restrict__ dinv,
+                                                         float* __restrict__ Inv, float* amax) {
+  __shared__ float Ybuf[2][512];
+  const int d = blockIdx.x >> 5, v0 = (blockIdx.x & 31) * 16;
+  const long o = (long)(512 * d) * n + 512 * d;
+  TrsmArgs t = {Q + o, 512, n, nullptr, Inv + o, 512, (long)n, 1L, 0L, 0L};
+  trsm_reg_full_body<true>(t, dinv + (long)(16 * d) * 1024, v0, Ybuf, amax);
 }
 
 __global__ __launch_bounds__(kThreads) void k_trsm_ut_reg(TrsmArgs t, const float* __restrict__ Dinv) {
@@ -2618,6 +2659,7 @@ struct KronWs {
   // levels' intermediate A^-1 B, planes of dX and of X1'
   __bf16 *IcL, *IcR, *TpL, *TpR, *DXp, *X1p;
   float *TfL, *TfR;
+  float* inv_sk; unsigned* inv_sk_cnt;                       // ... and the K split of their top levels: 2 x (kInvSkItems partial tiles, kInvSkTiles words)
   char* small;                                               // scratch of the fused small-layer kernels (kron_small_fused shapes)
   int64_t total;
 };
@@ -2675,6 +2717,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
   k.sk_scratch = nullptr; k.sk_cnt = nullptr; k.pmeta = nullptr; k.pm_part = nullptr;
   k.IcL = k.IcR = k.TpL = k.TpR = k.DXp = k.X1p = nullptr; k.TfL = k.TfR = nullptr;
+  k.inv_sk = nullptr; k.inv_sk_cnt = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -2695,6 +2738,8 @@ static KronWs kron_layout(char* base, int M, int N) {
       k.IcL = planes(Mp * Mp); k.TpL = planes(Mp * Mp); k.TfL = take(mm);
       k.IcR = planes(Np * Np); k.TpR = planes(Np * Np); k.TfR = take(nn);
       k.DXp = planes(Mp * Np); k.X1p = planes(Mp * Np);
+      k.inv_sk = take((int64_t)2 * 512 * 64 * kThreads * 4);
+      k.inv_sk_cnt = reinterpret_cast<unsigned*>(take(2 * 256 * 4));
     }
     if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
       k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
@@ -3408,10 +3453,25 @@ struct InvSide {
   float* Inv; float* Tf;                         // fp32 [n x n]: the inverse; the levels' A^-1 B
   P3Buf Qc, Ir, Ic, Tp;                          // column-form planes of Q; planes of the inverse (row / column form); of -T
   PlaneMeta* mT;                                 // 6 slots: one per level
+  int b0 = 128;                                  // size of the diagonal blocks tri_inverse_blocks inverted (the first level's b)
+  float* sk = nullptr; unsigned* sk_cnt = nullptr;   // K split of the top levels' products: kInvSkItems partial tiles, kInvSkTiles words (zero)
 };
+constexpr int kInvSkItems = 512, kInvSkTiles = 256;
+static int g_inv_splitk = 0;    // tuning key 22: 1 = the K ranges of the top levels' tiles dealt to 2-4 blocks (k_gemm_p3_blk_splitk).  Built and
+                                // measured SLOWER (profiles/r04_inv_ab.txt: 4096^2 fp32 update 2.74 -> 2.82 ms, bf16 operands 2.06 -> 2.19): the levels
+                                // run beside full-chip products of the other chain, and twice the workgroups mean twice the slots to wait for
 static int g_trsm_inv = 1;      // tuning key 11: 0 = the solves of every size stay on the substitution strips
 
-static int tri_inverse_blocks(InvSide& f, hipStream_t st) {           // the inverted 128-blocks
+static int g_inv_strip512 = 1;  // tuning key 23: 0 = the inversion starts from k_tri_inv128 + levels 128, 256 for every n
+static int tri_inverse_blocks(InvSide& f, hipStream_t st) {           // the inverted 128-blocks (f.b0 = 128) or 512-blocks (512)
+  if (g_inv_strip512 && f.n % 512 == 0 && (f.n & 1) == 0) {
+    hipLaunchKernelGGL(k_tri_inv512, dim3((f.n / 512) * 32), dim3(kThreads), 0, st, f.Q, f.n, f.dinv, f.Inv, &f.Ir.meta->amax);
+    f.Ir.part = f.Ic.part = &f.Ir.meta->amax;
+    f.Ir.npart = f.Ic.npart = 1;
+    f.b0 = 512;
+    return (int)hipGetLastError();
+  }
+  f.b0 = 128;
   static bool attr_set = false;
   const size_t lds = (size_t)2 * 128 * 129 * sizeof(float);
   if (!attr_set) {
@@ -3432,7 +3492,16 @@ static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st)
   P3Args g1 = p3_args(f.Ir, f.Qc, n, n, n, KLO_M | KBLK_HI_M);                     // T = A^-1 B
   g1.e.kblk = 2 * b; g1.e.C = f.Tf; g1.e.ldc = n; g1.ometa = f.mT + level;
   const bool full = p3_no_early(pairs * tb * tb >= p3_block_slots() / 2);           // (two inversions share the chip)
-  if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
+  // K split: chunks of at least 16 steps (a tile's longest K range is b / 32 steps), at most kInvSkItems items
+  int nch = 1;
+  if (g_inv_splitk && f.sk && pairs * tb * tb <= kInvSkTiles) {
+    nch = (b / 32) / 16;
+    while (nch > 1 && pairs * tb * tb * nch > kInvSkItems) --nch;
+    if (nch > 4) nch = 4;
+    if (nch < 1) nch = 1;
+  }
+  if (nch > 1) hipLaunchKernelGGL(k_gemm_p3_blk_splitk<1>, dim3(pairs * tb * tb * nch), dim3(kThreads), 0, st, g1, b, nch, f.sk, f.sk_cnt);
+  else if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
   else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
   if (hipGetLastError() != hipSuccess) return 1;
   P3Buf tp = f.Tp;
@@ -3440,7 +3509,8 @@ static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st)
   if ((e = launch_split3(f.Tf, n, 1, n, n, tp, st, SplitOpt{0, 2 * b, 1, 1}))) return e;              // planes of -T
   P3Args g2 = p3_args(tp, f.Ic, n, n, n, KHI_N | KBLK_LO_N);                       // W = (-T) C^-1 into Inv
   g2.e.kblk = 2 * b; g2.e.C = f.Inv; g2.e.ldc = n; g2.ometa = f.Ir.meta;
-  if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
+  if (nch > 1) hipLaunchKernelGGL(k_gemm_p3_blk_splitk<1>, dim3(pairs * tb * tb * nch), dim3(kThreads), 0, st, g2, b, nch, f.sk, f.sk_cnt);
+  else if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
   else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
   return (int)hipGetLastError();
 }
@@ -3454,8 +3524,8 @@ static int tri_inverse_pair(InvSide a, hipStream_t sa, InvSide b, hipStream_t sb
   if ((e = tri_inverse_blocks(a, sa)) || (e = tri_inverse_blocks(b, sb))) return e;
   int level = 0;
   for (int w = 128; w < a.n || w < b.n; w *= 2, ++level) {
-    if (w < a.n && (e = tri_inverse_level(a, w, level, sa))) return e;
-    if (w < b.n && (e = tri_inverse_level(b, w, level, sb))) return e;
+    if (w >= a.b0 && w < a.n && (e = tri_inverse_level(a, w, level, sa))) return e;
+    if (w >= b.b0 && w < b.n && (e = tri_inverse_level(b, w, level, sb))) return e;
   }
   if ((e = tri_inverse_planes(a, sa))) return e;
   return tri_inverse_planes(b, sb);
@@ -3466,6 +3536,7 @@ struct InvSolveWs {
   PlaneMeta* pm; float* part;
   __bf16 *Lc, *Rc, *IrL, *IcL, *TpL, *IrR, *IcR, *TpR, *DXp, *X1p;
   float *InvL, *InvR, *TfL, *TfR;
+  float* sk; unsigned* sk_cnt;
   int64_t total;
 };
 static InvSolveWs inv_solve_layout(char* base, int M, int N) {
@@ -3481,6 +3552,8 @@ static InvSolveWs inv_solve_layout(char* base, int M, int N) {
   k.DXp = planes(Mp * Np); k.X1p = planes(Mp * Np);
   k.InvL = reinterpret_cast<float*>(take((int64_t)M * M * 4)); k.TfL = reinterpret_cast<float*>(take((int64_t)M * M * 4));
   k.InvR = reinterpret_cast<float*>(take((int64_t)N * N * 4)); k.TfR = reinterpret_cast<float*>(take((int64_t)N * N * 4));
+  k.sk = reinterpret_cast<float*>(take((int64_t)2 * kInvSkItems * 64 * kThreads * 4));
+  k.sk_cnt = reinterpret_cast<unsigned*>(take(2 * kInvSkTiles * 4));
   k.total = off;
   return k;
 }
@@ -3493,6 +3566,7 @@ bool kron_inv_solves_on(int M, int N) {
 
 int kron_inv_prepare(void* ws, int M, int N, hipStream_t main) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
+  if (hipMemsetAsync(k.sk_cnt, 0, 2 * kInvSkTiles * 4, main) != hipSuccess) return 1;
   return hipMemsetAsync(k.pm, 0, kPmSlots * sizeof(PlaneMeta), main) != hipSuccess;
 }
 
@@ -3515,6 +3589,8 @@ int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_
                P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
   InvSide R = {QrS, N, dinv_r, k.InvR, k.TfR, Rc, P3Buf{k.IrR, Np, Np, pm + kPmInvR}, P3Buf{k.IcR, Np, Np, pm + kPmInvR},
                P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
+  L.sk = k.sk; L.sk_cnt = k.sk_cnt;
+  R.sk = k.sk + (long)kInvSkItems * 64 * kThreads; R.sk_cnt = k.sk_cnt + kInvSkTiles;
   if ((e = tri_inverse_pair(R, main, L, side))) return e;
   const P3Buf X1c = {k.X1p, Np, Mp, pm + kPmX1};
   P3Args x1 = p3_args(dXp, R.Ic, M, N, N, KHI_N);                                      // X1 = X0 Ri
@@ -3647,6 +3723,8 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 19) { g_force_er = value; return PSGD_OK; }
   if (key == 20) { g_sparse_planes = value; return PSGD_OK; }
   if (key == 21) { g_small_fused = value; return PSGD_OK; }
+  if (key == 22) { g_inv_splitk = value; return PSGD_OK; }
+  if (key == 23) { g_inv_strip512 = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -3738,6 +3816,8 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   const bool inv_route = pm && g_trsm_inv && kron_inv_route(M, N) && M <= 8192 && N <= 8192;    // (6 levels of meta slots)
   const bool solves_on_planes = planes && (inv_route || M > g_trsm_planes_min_n || N > g_trsm_planes_min_n);
   if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st, pm));
+  // (the K-split tickets of the inversions' top levels: zero before either stream uses them; every launch leaves them at zero)
+  if (inv_route && k.inv_sk_cnt && hipMemsetAsync(k.inv_sk_cnt, 0, 2 * kInvSkTiles * 4, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
   KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
   hipStream_t sf = fk ? fk->side : st;
@@ -3749,6 +3829,8 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
                  P3Buf{k.IcL, Mp, Mp, pm + kPmInvL}, P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
     InvSide R = {k.QrS, N, k.dinv, k.g2, k.TfR, P3Buf{k.Rc, Np, Np, pm + kPmR}, P3Buf{k.G2, Np, Np, pm + kPmInvR},
                  P3Buf{k.IcR, Np, Np, pm + kPmInvR}, P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
+    L.sk = k.inv_sk; L.sk_cnt = k.inv_sk_cnt;
+    R.sk = k.inv_sk + (long)kInvSkItems * 64 * kThreads; R.sk_cnt = k.inv_sk_cnt + kInvSkTiles;
     // Order: the full-chip products of :173 run beside the launch-bound lower levels of Qr's inversion, Ql's inversion beside the
     // product X1 = dX Ri (with the two inversions first and the products colliding afterwards the join came 0.3 ms later).
     KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
@@ -4160,7 +4242,7 @@ static int sparse_solve_prepare(const SparseWs& k, const float* Q, int n, int nv
                P3Buf{k.ITp, np, np, nullptr}, k.imeta + 2};
   if ((e = tri_inverse_blocks(f, st))) return e;
   int level = 0;
-  for (int b = 128; b < n; b *= 2, ++level)
+  for (int b = f.b0; b < n; b *= 2, ++level)
     if ((e = tri_inverse_level(f, b, level, st))) return e;
   // the strict lower triangle of Inv was never written: the product's K range (k <= column) and the split's triangle mask
   // would need it zero -- sparse_gemm splits the whole matrix, so clear it by writing the upper triangle's complement here
