@@ -31,8 +31,8 @@ int64_t kron_inv_solves_bytes(int M, int N);
 bool kron_inv_solves_on(int M, int N);
 int kron_inv_prepare(void* ws, int M, int N, hipStream_t main);
 int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
-                          int M, int N, void* ws, hipStream_t main, hipStream_t side);
-int kron_inv_solves_back(float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
+                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side);      // (Bt: scratch here)
+int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
 
 // Small layers (M, N <= 512; LeNet5) through the reference's per-layer calls: fused strip kernels (psgd_kron_small.hip), one launch
 // per call when one workgroup finishes the layer quickly, one per phase otherwise.  kron_small_fused: the shape rule (a pure

@@ -3514,21 +3514,126 @@ static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st)
   else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
   return (int)hipGetLastError();
 }
-static int tri_inverse_planes(const InvSide& f, hipStream_t st) {     // column-form planes of the whole inverse: (x, k) = Inv[k][x], k <= x
-  return launch_split3(f.Inv, 1, f.n, f.n, f.n, f.Ic, st, SplitOpt{2, 0, 0, 0});
+// column-form planes of the inverted h-blocks on the diagonal: (x, k) = Inv[k][x], k <= x, both inside one block (h >= n: the whole inverse)
+static int tri_inverse_planes(const InvSide& f, int h, hipStream_t st) {
+  return launch_split3(f.Inv, 1, f.n, f.n, f.n, f.Ic, st, SplitOpt{2, h < f.n ? h : 0, 0, 0});
 }
 // Two inversions on two streams, their launches queued level by level in turn (either stream has work early: a caller whose
-// host thread is not far ahead of the device would otherwise leave the second stream idle for the ~25 launches of the first)
-static int tri_inverse_pair(InvSide a, hipStream_t sa, InvSide b, hipStream_t sb) {
+// host thread is not far ahead of the device would otherwise leave the second stream idle for the ~25 launches of the first).
+// h: the doubling stops at diagonal blocks of h (a power of two times 128; >= n: the whole inverse).
+static int tri_inverse_pair(InvSide a, hipStream_t sa, InvSide b, hipStream_t sb, int h) {
   int e;
   if ((e = tri_inverse_blocks(a, sa)) || (e = tri_inverse_blocks(b, sb))) return e;
   int level = 0;
-  for (int w = 128; w < a.n || w < b.n; w *= 2, ++level) {
+  for (int w = 128; w < h && (w < a.n || w < b.n); w *= 2, ++level) {
     if (w >= a.b0 && w < a.n && (e = tri_inverse_level(a, w, level, sa))) return e;
     if (w >= b.b0 && w < b.n && (e = tri_inverse_level(b, w, level, sb))) return e;
   }
-  if ((e = tri_inverse_planes(a, sa))) return e;
-  return tri_inverse_planes(b, sb);
+  if ((e = tri_inverse_planes(a, h, sa))) return e;
+  return tri_inverse_planes(b, h, sb);
+}
+
+// ---- the two solves of psgd.py:174 through the inverses of the DIAGONAL h-BLOCKS of the balanced factors (round 4) --------------
+// The doubling's top level is its most expensive and least efficient one (n = 4096: two products of 256 tiles with K chains of up
+// to 64 steps, one workgroup per CU: 190 us alone, 330 beside a full-chip product), and it only exists to turn the solve into ONE
+// product.  Stopping at h-blocks (h = 2048) and solving blocked, right-looking over the n / h block columns,
+//     X1_j = W_j Ri_jj,        W_{>j} -= X1_j R[j, >j]        (W = dX at the start)
+//     Bt_i = Li_ii' V_i,       V_{>i} -= L[i, >i]' Bt_i       (V = X1 at the start)
+// costs the same product flops (M n^2 / 2 per solve: the trailing updates are what the top level's T = A^-1 B, W = -T C^-1 would have
+// folded into the inverse) in products of 512 full-K tiles each, and drops that level from both inversion chains.  Every piece that
+// feeds a product is split into f16 x 2 planes at its actual maximum (the running max|.| its producers accumulate), like p3_chain.
+static int g_inv_blk = 2048;    // tuning key 24: h (0 = whole inverses and one product per solve, the round-3 form)
+struct BlkSolve {
+  int M, N, h;
+  PlaneMeta* pm;                 // kPmSlots slots, zero on entry
+  float* part;                   // kPmPartMax partial maxima (main stream)
+  InvSide L, R;
+  const float* X0;               // dX, fp32 [M x N]
+  P3Buf X0p;                     // its row-form planes (made here)
+  float *X1, *Bt;                // fp32 [M x N]; Bt doubles as the W of the right solve
+  P3Buf pa, pb;                  // two transient plane buffers, pad128(M) x pad128(N) elements each
+  P3Buf Br, Bc;                  // planes of Bt, row / column form (p = nullptr: not wanted)
+};
+static P3 p3_sub(const P3Buf& b, long x0, long k0) {              // the (x >= x0, k >= k0) corner of a plane set (k0 a multiple of 32)
+  P3 v = p3_of(b);
+  v.p += (k0 / 32) * v.ts + x0 * 32;
+  return v;
+}
+static P3Args blk_product(const P3& A, const P3& B, int M, int N, int K, int kmode, float* C, int ldc, const float* D, int ldd,
+                          PlaneMeta* ometa) {
+  P3Args g = {};
+  g.A = A; g.B = B; g.fmt = 1;
+  g.e.M = M; g.e.N = N; g.e.K = K; g.e.kmode = kmode;
+  g.e.epi = D ? EPI_D_MINUS : EPI_STORE;
+  g.e.C = C; g.e.ldc = ldc; g.e.D = D; g.e.ldd = ldd;
+  g.ometa = ometa;
+  return g;
+}
+enum { kPmPieceX = kPmStrip, kPmPieceW = kPmStrip + 8, kPmPieceV = kPmStrip + 16 };      // (the strips' slots: free on this route)
+
+// dX planes, both inversions (R on `main`, L on `side`), then X1 = dX R^-1 on `main`
+static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side) {
+  const int M = s.M, N = s.N, h = s.h;
+  int e;
+  if ((e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, main))) return e;
+  if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, main))) return e;
+  if ((e = tri_inverse_pair(s.R, main, s.L, side, h))) return e;
+  PlaneMeta* mX1 = s.pm + kPmX1;
+  const int nb = (N + h - 1) / h;
+  for (int j = 0; j < nb; ++j) {
+    const int c0 = j * h, hj = N - c0 < h ? N - c0 : h;
+    P3 Wp = j == 0 ? p3_sub(s.X0p, 0, 0) : p3_of(s.pb);
+    if (j == 0) Wp.meta = s.X0p.meta;
+    // X1_j = W_j Ri_jj   (B operand (n, k) = Ri[k][n], k <= n)
+    P3Args d = blk_product(Wp, p3_sub(s.R.Ic, c0, c0), M, hj, hj, KHI_N, s.X1 + c0, N, nullptr, 0, mX1);
+    if ((e = launch_p3(d, main))) return e;
+    if (j == nb - 1) break;
+    P3Buf Xj = s.pa;                                                  // row-form planes of X1_j (the running max|X1| as their scale)
+    Xj.ld = pad128(hj); Xj.meta = s.pm + kPmPieceX + j; Xj.part = &mX1->amax; Xj.npart = 1;
+    if ((e = launch_split3(s.X1 + c0, N, 1, M, hj, Xj, main))) return e;
+    // W_{>j} = W_{>j} - X1_j R[j, >j]   (B operand (n, k) = R[k][n]: the factor's column-form planes)
+    const int c1 = c0 + hj;
+    PlaneMeta* mW = s.pm + kPmPieceW + j;
+    P3Args t = blk_product(p3_of(Xj), p3_sub(s.R.Qc, c1, c0), M, N - c1, hj, 0, s.Bt + c1, N, (j == 0 ? s.X0 : s.Bt) + c1, N, mW);
+    if ((e = launch_p3(t, main))) return e;
+    const int hn = N - c1 < h ? N - c1 : h;
+    P3Buf Wn = s.pb;                                                  // row-form planes of W_{j+1}
+    Wn.ld = pad128(hn); Wn.meta = s.pm + kPmPieceW + j; Wn.part = &mW->amax; Wn.npart = 1;
+    if ((e = launch_split3(s.Bt + c1, N, 1, M, hn, Wn, main))) return e;
+    s.pb.ld = Wn.ld; s.pb.meta = Wn.meta;
+  }
+  return 0;
+}
+
+// Bt = L^-T X1 (after the caller's join: needs L's inverse), and the planes of Bt when wanted
+static int blk_solves_back(BlkSolve& s, hipStream_t main) {
+  const int M = s.M, N = s.N, h = s.h;
+  int e;
+  PlaneMeta *mX1 = s.pm + kPmX1, *mBt = s.pm + kPmBt;
+  const int mb = (M + h - 1) / h;
+  for (int i = 0; i < mb; ++i) {
+    const int r0 = i * h, hi = M - r0 < h ? M - r0 : h;
+    P3Buf Vi = s.pb;                                                  // column-form planes of V_i: (x = n, k = m) = V[m][n]
+    Vi.rows = pad128(N); Vi.ld = pad128(hi); Vi.meta = s.pm + kPmPieceV + i;
+    Vi.part = i == 0 ? &mX1->amax : &(s.pm + kPmPieceV + 8 + i - 1)->amax; Vi.npart = 1;
+    if ((e = launch_split3(s.X1 + (long)r0 * N, 1, N, N, hi, Vi, main))) return e;
+    // Bt_i = Li_ii' V_i   (A operand (m, k) = Li[k][m], k <= m)
+    P3Args d = blk_product(p3_sub(s.L.Ic, r0, r0), p3_of(Vi), hi, N, hi, KHI_M, s.Bt + (long)r0 * N, N, nullptr, 0, mBt);
+    if ((e = launch_p3(d, main))) return e;
+    if (i == mb - 1) break;
+    P3Buf Bi = s.pa;                                                  // column-form planes of Bt_i
+    Bi.rows = pad128(N); Bi.ld = pad128(hi); Bi.meta = s.pm + kPmPieceX + 4 + i; Bi.part = &mBt->amax; Bi.npart = 1;
+    if ((e = launch_split3(s.Bt + (long)r0 * N, 1, N, N, hi, Bi, main))) return e;
+    // V_{>i} = V_{>i} - L[i, >i]' Bt_i   (A operand (m, k) = L[k][m]: the factor's column-form planes), in place in X1
+    const int r1 = r0 + hi;
+    P3Args t = blk_product(p3_sub(s.L.Qc, r1, r0), p3_of(Bi), M - r1, N, hi, 0, s.X1 + (long)r1 * N, N, s.X1 + (long)r1 * N, N,
+                           s.pm + kPmPieceV + 8 + i);
+    if ((e = launch_p3(t, main))) return e;
+  }
+  if (!s.Br.p) return 0;
+  P3Buf br = s.Br, bc = s.Bc;
+  br.part = bc.part = &mBt->amax; br.npart = bc.npart = 1;
+  return launch_split3_both(s.Bt, N, 1, M, N, br, bc, main);
 }
 
 // The route for callers outside this file (kron_shared.h: the bf16-operand update): own workspace, same launches.
@@ -3537,6 +3642,7 @@ struct InvSolveWs {
   __bf16 *Lc, *Rc, *IrL, *IcL, *TpL, *IrR, *IcR, *TpR, *DXp, *X1p;
   float *InvL, *InvR, *TfL, *TfR;
   float* sk; unsigned* sk_cnt;
+  __bf16 *Pa, *Pb;                 // transient planes of the blocked solves' pieces
   int64_t total;
 };
 static InvSolveWs inv_solve_layout(char* base, int M, int N) {
@@ -3554,6 +3660,7 @@ static InvSolveWs inv_solve_layout(char* base, int M, int N) {
   k.InvR = reinterpret_cast<float*>(take((int64_t)N * N * 4)); k.TfR = reinterpret_cast<float*>(take((int64_t)N * N * 4));
   k.sk = reinterpret_cast<float*>(take((int64_t)2 * kInvSkItems * 64 * kThreads * 4));
   k.sk_cnt = reinterpret_cast<unsigned*>(take(2 * kInvSkTiles * 4));
+  k.Pa = planes(Mp * Np); k.Pb = planes(Mp * Np);
   k.total = off;
   return k;
 }
@@ -3570,41 +3677,43 @@ int kron_inv_prepare(void* ws, int M, int N, hipStream_t main) {
   return hipMemsetAsync(k.pm, 0, kPmSlots * sizeof(PlaneMeta), main) != hipSuccess;
 }
 
-int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
-                          int M, int N, void* ws, hipStream_t main, hipStream_t side) {
-  const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
+static inline int inv_blk(int M, int N) { return g_inv_blk > 0 ? g_inv_blk : (1 << 30); }
+static BlkSolve inv_solve_problem(const InvSolveWs& k, const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l,
+                                  const float* X0, float* X1, float* Bt, int M, int N) {
   const long Mp = pad128(M), Np = pad128(N);
   PlaneMeta* pm = k.pm;
-  int e;
-  // column-form planes of the balanced factors (the B operand of T = A^-1 B)
-  P3Buf Lc = {k.Lc, Mp, Mp, pm + kPmL}, Rc = {k.Rc, Np, Np, pm + kPmR};
-  if ((e = launch_absmax(QrS, (long)N * N, Rc, k.part, main))) return e;
-  if ((e = launch_split3(QrS, 1, N, N, N, Rc, main))) return e;                        // (x, k) = QrS[k][x]
-  if ((e = launch_absmax(QlS, (long)M * M, Lc, k.part + kPmPartMax, side))) return e;
-  if ((e = launch_split3(QlS, 1, M, M, M, Lc, side))) return e;
-  P3Buf dXp = {k.DXp, Mp, Np, pm + kPmdX};
-  if ((e = launch_absmax(X0, (long)M * N, dXp, k.part, main))) return e;               // (the split above is done with the array)
-  if ((e = launch_split3(X0, N, 1, M, N, dXp, main))) return e;
-  InvSide L = {QlS, M, dinv_l, k.InvL, k.TfL, Lc, P3Buf{k.IrL, Mp, Mp, pm + kPmInvL}, P3Buf{k.IcL, Mp, Mp, pm + kPmInvL},
-               P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
-  InvSide R = {QrS, N, dinv_r, k.InvR, k.TfR, Rc, P3Buf{k.IrR, Np, Np, pm + kPmInvR}, P3Buf{k.IcR, Np, Np, pm + kPmInvR},
-               P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
-  L.sk = k.sk; L.sk_cnt = k.sk_cnt;
-  R.sk = k.sk + (long)kInvSkItems * 64 * kThreads; R.sk_cnt = k.sk_cnt + kInvSkTiles;
-  if ((e = tri_inverse_pair(R, main, L, side))) return e;
-  const P3Buf X1c = {k.X1p, Np, Mp, pm + kPmX1};
-  P3Args x1 = p3_args(dXp, R.Ic, M, N, N, KHI_N);                                      // X1 = X0 Ri
-  return p3_chain(x1, X1, nullptr, &X1c, nullptr, nullptr, nullptr, main);
+  BlkSolve s = {};
+  s.M = M; s.N = N; s.h = inv_blk(M, N); s.pm = pm; s.part = k.part;
+  s.L = InvSide{QlS, M, dinv_l, k.InvL, k.TfL, P3Buf{k.Lc, Mp, Mp, pm + kPmL}, P3Buf{k.IrL, Mp, Mp, pm + kPmInvL},
+                P3Buf{k.IcL, Mp, Mp, pm + kPmInvL}, P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
+  s.R = InvSide{QrS, N, dinv_r, k.InvR, k.TfR, P3Buf{k.Rc, Np, Np, pm + kPmR}, P3Buf{k.IrR, Np, Np, pm + kPmInvR},
+                P3Buf{k.IcR, Np, Np, pm + kPmInvR}, P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
+  s.L.sk = k.sk; s.L.sk_cnt = k.sk_cnt;
+  s.R.sk = k.sk + (long)kInvSkItems * 64 * kThreads; s.R.sk_cnt = k.sk_cnt + kInvSkTiles;
+  s.X0 = X0; s.X0p = P3Buf{k.DXp, Mp, Np, pm + kPmdX};
+  s.X1 = X1; s.Bt = Bt;
+  s.pa = P3Buf{k.Pa, Mp, Np, nullptr}; s.pb = P3Buf{k.Pb, Mp, Np, nullptr};
+  s.Br = P3Buf{nullptr, 0, 0, nullptr}; s.Bc = s.Br;
+  return s;
 }
 
-int kron_inv_solves_back(float* X1, float* Bt, int M, int N, void* ws, hipStream_t main) {
+int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
+                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
-  const long Mp = pad128(M), Np = pad128(N);
-  const P3Buf IcL = {k.IcL, Mp, Mp, k.pm + kPmInvL}, X1c = {k.X1p, Np, Mp, k.pm + kPmX1};
-  P3Args bt = p3_args(IcL, X1c, M, N, M, KHI_M);                                       // Bt = Li' X1
-  bt.e.C = Bt; bt.e.ldc = N;
-  (void)X1;
-  return launch_p3(bt, main);
+  int e;
+  // column-form planes of the balanced factors (the B operand of T = A^-1 B, and of the blocked solves' trailing updates)
+  BlkSolve s = inv_solve_problem(k, QlS, QrS, dinv_r, dinv_l, X0, X1, Bt, M, N);
+  if ((e = launch_absmax(QrS, (long)N * N, s.R.Qc, k.part + 2 * kPmPartMax, main))) return e;
+  if ((e = launch_split3(QrS, 1, N, N, N, s.R.Qc, main))) return e;                    // (x, k) = QrS[k][x]
+  if ((e = launch_absmax(QlS, (long)M * M, s.L.Qc, k.part + kPmPartMax, side))) return e;
+  if ((e = launch_split3(QlS, 1, M, M, M, s.L.Qc, side))) return e;
+  return blk_solves_front(s, main, side);
+}
+
+int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main) {
+  const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
+  BlkSolve s = inv_solve_problem(k, QlS, nullptr, nullptr, nullptr, nullptr, X1, Bt, M, N);
+  return blk_solves_back(s, main);
 }
 
 // entry points shared with psgd_kron_bf16.hip (kron_shared.h)
@@ -3725,6 +3834,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 21) { g_small_fused = value; return PSGD_OK; }
   if (key == 22) { g_inv_splitk = value; return PSGD_OK; }
   if (key == 23) { g_inv_strip512 = value; return PSGD_OK; }
+  if (key == 24) { g_inv_blk = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -3832,19 +3942,18 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     L.sk = k.inv_sk; L.sk_cnt = k.inv_sk_cnt;
     R.sk = k.inv_sk + (long)kInvSkItems * 64 * kThreads; R.sk_cnt = k.inv_sk_cnt + kInvSkTiles;
     // Order: the full-chip products of :173 run beside the launch-bound lower levels of Qr's inversion, Ql's inversion beside the
-    // product X1 = dX Ri (with the two inversions first and the products colliding afterwards the join came 0.3 ms later).
+    // products of X1 = dX R^-1 (with the two inversions first and the products colliding afterwards the join came 0.3 ms later).
     KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
-    P3Buf dXp = {k.DXp, Mp, Np, pm + kPmdX};
-    const P3Buf X1c = {k.X1p, Np, Mp, pm + kPmX1};
-    KRON_LAUNCH(launch_absmax(dX, (long)M * N, dXp, k.pm_part, st));
-    KRON_LAUNCH(launch_split3(dX, N, 1, M, N, dXp, st));
-    KRON_LAUNCH(tri_inverse_pair(R, st, L, sf));
-    P3Args x1 = p3_args(dXp, R.Ic, M, N, N, KHI_N);                                   // X1 = dX Ri
-    KRON_LAUNCH(p3_chain(x1, k.X1, nullptr, &X1c, nullptr, k.sk_scratch, k.sk_cnt, st));
+    BlkSolve bs = {};
+    bs.M = M; bs.N = N; bs.h = inv_blk(M, N); bs.pm = pm; bs.part = k.pm_part;
+    bs.L = L; bs.R = R;
+    bs.X0 = dX; bs.X0p = P3Buf{k.DXp, Mp, Np, pm + kPmdX};
+    bs.X1 = k.X1; bs.Bt = k.Bt;
+    bs.pa = P3Buf{k.Y0, Mp, Np, nullptr}; bs.pb = P3Buf{k.Y1, Mp, Np, nullptr};      // (transients of the apply: free during an update)
+    bs.Br = P3Buf{k.U0, Mp, Np, pm + kPmBt}; bs.Bc = P3Buf{k.U1, Np, Mp, pm + kPmBt};
+    KRON_LAUNCH(blk_solves_front(bs, st, sf));
     KRON_LAUNCH(fork_scope.join());
-    const P3Buf Br = {k.U0, Mp, Np, pm + kPmBt}, Bc = {k.U1, Np, Mp, pm + kPmBt};
-    P3Args bt = p3_args(L.Ic, X1c, M, N, M, KHI_M);                                   // Bt = Li' X1
-    KRON_LAUNCH(p3_chain(bt, k.Bt, &Br, &Bc, nullptr, k.sk_scratch, k.sk_cnt, st));
+    KRON_LAUNCH(blk_solves_back(bs, st));                         // (leaves max|Bt| and the planes of Bt for the gradient products)
     KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st, pm, true));
     return PSGD_OK;
   }

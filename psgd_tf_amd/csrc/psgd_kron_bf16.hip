@@ -1340,9 +1340,9 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   if (inv_route) {
     // factors from 2048 on: the solves as products with explicit inverses (fp32-accurate f16 x 2 plane products; psgd_kron.hip
     // tri_inverse).  Ql's inversion goes behind the bf16 products on the side stream, the rest stays here.
-    HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, k.dinv + (long)((N + 31) / 32) * 1024, k.X0, k.X1, M, N, k.inv_ws, st, sf));
+    HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, k.dinv + (long)((N + 31) / 32) * 1024, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf));
     HK(fork_scope.join());
-    HK(psgdk::kron_inv_solves_back(k.X1, k.Bt, M, N, k.inv_ws, st));
+    HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
   } else {
     HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite, true));
     HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv + (long)((N + 31) / 32) * 1024, st, g_trsm_lite, true));
