@@ -31,7 +31,10 @@ int64_t kron_inv_solves_bytes(int M, int N);
 bool kron_inv_solves_on(int M, int N);
 int kron_inv_prepare(void* ws, int M, int N, hipStream_t main);
 int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
-                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side);      // (Bt: scratch here)
+                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side,      // (Bt: scratch here)
+                          hipEvent_t l_ready = nullptr);     // l_ready: recorded on `side` behind Ql's inversion (for callers that queue
+                                                             // more work on `side` and let `main` wait for this point only)
+bool kron_inv_first(int M, int N);                           // the order rule (tuning key 25): both inversions ahead of the products of :173
 int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
 
 // Small layers (M, N <= 512; LeNet5) through the reference's per-layer calls: fused strip kernels (psgd_kron_small.hip), one launch
@@ -47,7 +50,7 @@ int kron_small_update(const float* Ql, const float* Qr, const float* dX, const f
 // the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for
 // everything already on `main`; the caller puts one chain on it and kron_join makes `main` wait for that chain.
 // Event fork/join only, so it is legal inside a stream capture of `main`.  nullptr = no side stream: stay on `main`.
-struct KronFork { hipStream_t side; hipEvent_t fork, join; };
+struct KronFork { hipStream_t side; hipEvent_t fork, join, mid; };     // mid: a point inside the side chain the caller's stream waits for
 KronFork* kron_fork(hipStream_t main);
 int kron_join(KronFork* f, hipStream_t main);          // 0 on success
 bool kron_overlap_chains(int M, int N);                // tuning key 9 and the shape rule

@@ -1137,21 +1137,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_blk(P3Args g, int b) {
   p3_body<FMT, ER>(g, by, bx, L);
 }
 
-// ... with every tile's K range dealt to `nchunk` blocks (P3Split; partials summed in chunk order by the last block to arrive).
-// The top levels of an inversion are a few hundred tiles with chains of up to 64 K steps each, one workgroup per CU at the
-// 1.5 us per step a lone workgroup reaches: the chain is what bounds them, not the chip.  cnt: one word per tile, zero on entry
-// and left at zero.
-template <int FMT>
-__global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_blk_splitk(P3Args g, int b, int nchunk, float* scratch, unsigned* cnt) {
-  __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
-  const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
-  const int tb = b / 128, per = tb * tb;
-  const int p = t / per, r = t % per;
-  const int by = (p * 2 * b) / 128 + r / tb, bx = (p * 2 * b + b) / 128 + r % tb;
-  if (by * 128 >= g.e.M || bx * 128 >= g.e.N) return;        // (every chunk of such a tile: its counter stays untouched)
-  p3_body<FMT, FMT ? 0 : 2>(g, by, bx, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
-}
-
 // two independent products in one grid (see k_gemm_x3_pair)
 struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1, tiles1; };
 
@@ -1261,16 +1246,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk_rect(P3Args g, i
 // off = 0: only the tiles inside the blk x blk blocks on the diagonal are made, off = 1: only the (first half, second half)
 // off-diagonal quarter of every such block; neg: the planes of -X.
 struct SplitOpt { int tri, blk, off, neg; };
+// At most 48 registers per lane (40 as compiled: keep it so).  Split launches sit inside chains that run BESIDE full-chip plane products of the
+// other stream (232 registers, two workgroups per CU = 464 of a SIMD's 512): at 54 registers a split workgroup could not join a CU
+// until one of the product's workgroups had finished its whole K loop, and a 15-us split took 105-160 us (profiles/r04_kron_update_trace_f32.txt).
 template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
                                                      __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
                                                      long tts, long tps, PlaneMeta* meta, const float* __restrict__ part,
                                                      int npart, SplitOpt opt) {
   __shared__ float S[64][65];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
   if (opt.blk) {
-    if (r0 / opt.blk != c0 / opt.blk) return;
-    if (opt.off && !((r0 % opt.blk) < opt.blk / 2 && (c0 % opt.blk) >= opt.blk / 2)) return;
+    // a COMPACT grid: x, y run over the 64-tiles of one blk x blk diagonal block (off: of its first-half x second-half quarter),
+    // z over the blocks -- with one workgroup per tile of the whole matrix (n = 4096, blk = 512: 4096 workgroups, 7/8 of which
+    // return at once) this launch took 157 us instead of 16 beside a full-chip product: every workgroup queues for a slot
+    r0 += blockIdx.z * opt.blk;
+    c0 += blockIdx.z * opt.blk + (opt.off ? opt.blk / 2 : 0);
+    const long xp = P ? ts / 32 : tps / (tts / 32), kp = P ? ps / (ts / 32) : tts / 32;     // padded extents of the view (x = r, k = c)
+    if (r0 >= xp || c0 >= kp) return;                            // (the last block of a ragged matrix)
   }
   constexpr int NPL = FMT ? 2 : 3;
   float sc = 1.0f;
@@ -1299,27 +1293,35 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
       split3_pair(x0, x1, q);
     }
   };
-  // (clamped addresses, every load issued before the first use: a guarded load compiles to load-then-wait)
-  float x[16];
+  // (clamped addresses, every load of a half issued before its first use: a guarded load compiles to load-then-wait.  Two halves of
+  //  eight loads, not sixteen at once: the kernel has to stay within 48 registers -- see the launch bounds)
   if (cs == 1 || rs != 1) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      x[i] = X[(long)min(r0 + (tid >> 6) + 4 * i, R - 1) * rs + (long)min(c0 + (tid & 63), C - 1) * cs];
+    for (int hh = 0; hh < 2; ++hh) {
+      float x[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = (tid >> 6) + 4 * i, c = tid & 63;
-      const bool keep = opt.tri == 0 || (opt.tri == 1 ? c0 + c >= r0 + r : c0 + c <= r0 + r);
-      S[r][c] = (r0 + r < R && c0 + c < C && keep) ? x[i] : 0.0f;
+      for (int i = 0; i < 8; ++i)
+        x[i] = X[(long)min(r0 + (tid >> 6) + 4 * (i + 8 * hh), R - 1) * rs + (long)min(c0 + (tid & 63), C - 1) * cs];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = (tid >> 6) + 4 * (i + 8 * hh), c = tid & 63;
+        const bool keep = opt.tri == 0 || (opt.tri == 1 ? c0 + c >= r0 + r : c0 + c <= r0 + r);
+        S[r][c] = (r0 + r < R && c0 + c < C && keep) ? x[i] : 0.0f;
+      }
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      x[i] = X[(long)min(r0 + (tid & 63), R - 1) + (long)min(c0 + (tid >> 6) + 4 * i, C - 1) * cs];
+    for (int hh = 0; hh < 2; ++hh) {
+      float x[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = (tid >> 6) + 4 * i, r = tid & 63;
-      const bool keep = opt.tri == 0 || (opt.tri == 1 ? c0 + c >= r0 + r : c0 + c <= r0 + r);
-      S[r][c] = (r0 + r < R && c0 + c < C && keep) ? x[i] : 0.0f;
+      for (int i = 0; i < 8; ++i)
+        x[i] = X[(long)min(r0 + (tid & 63), R - 1) + (long)min(c0 + (tid >> 6) + 4 * (i + 8 * hh), C - 1) * cs];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = (tid >> 6) + 4 * (i + 8 * hh), r = tid & 63;
+        const bool keep = opt.tri == 0 || (opt.tri == 1 ? c0 + c >= r0 + r : c0 + c <= r0 + r);
+        S[r][c] = (r0 + r < R && c0 + c < C && keep) ? x[i] : 0.0f;
+      }
     }
   }
   __syncthreads();
@@ -2659,7 +2661,6 @@ struct KronWs {
   // levels' intermediate A^-1 B, planes of dX and of X1'
   __bf16 *IcL, *IcR, *TpL, *TpR, *DXp, *X1p;
   float *TfL, *TfR;
-  float* inv_sk; unsigned* inv_sk_cnt;                       // ... and the K split of their top levels: 2 x (kInvSkItems partial tiles, kInvSkTiles words)
   char* small;                                               // scratch of the fused small-layer kernels (kron_small_fused shapes)
   int64_t total;
 };
@@ -2717,7 +2718,6 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
   k.sk_scratch = nullptr; k.sk_cnt = nullptr; k.pmeta = nullptr; k.pm_part = nullptr;
   k.IcL = k.IcR = k.TpL = k.TpR = k.DXp = k.X1p = nullptr; k.TfL = k.TfR = nullptr;
-  k.inv_sk = nullptr; k.inv_sk_cnt = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
     auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 6)); };
@@ -2738,8 +2738,6 @@ static KronWs kron_layout(char* base, int M, int N) {
       k.IcL = planes(Mp * Mp); k.TpL = planes(Mp * Mp); k.TfL = take(mm);
       k.IcR = planes(Np * Np); k.TpR = planes(Np * Np); k.TfR = take(nn);
       k.DXp = planes(Mp * Np); k.X1p = planes(Mp * Np);
-      k.inv_sk = take((int64_t)2 * 512 * 64 * kThreads * 4);
-      k.inv_sk_cnt = reinterpret_cast<unsigned*>(take(2 * 256 * 4));
     }
     if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
       k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
@@ -2970,9 +2968,16 @@ static int launch_absmax_view(const float* X, long rs, long cs, long R, long C, 
   buf.part = part; buf.npart = (int)blocks;
   return (int)hipGetLastError();
 }
+// grid of a split launch: one workgroup per 64 x 64 tile of the padded view, or -- under a block filter -- per tile of the blocks kept
+static dim3 split_grid(long rows, long ld, const SplitOpt& opt) {
+  if (!opt.blk) return dim3((unsigned)(ld / 64), (unsigned)(rows / 64));
+  const long nblk = ((rows > ld ? rows : ld) + opt.blk - 1) / opt.blk;
+  const unsigned t = (unsigned)(opt.blk / 64);
+  return opt.off ? dim3(t / 2, t / 2, (unsigned)nblk) : dim3(t, t, (unsigned)nblk);
+}
 static int launch_split3(const float* X, long rs, long cs, int R, int C, const P3Buf& out, hipStream_t st,
                          SplitOpt opt = SplitOpt{0, 0, 0, 0}) {
-  const dim3 grid((unsigned)(out.ld / 64), (unsigned)(out.rows / 64));
+  const dim3 grid = split_grid(out.rows, out.ld, opt);
   if (out.meta)
     hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
                        (__bf16*)nullptr, 0L, 0L, out.meta, out.part, out.npart, opt);
@@ -2984,7 +2989,7 @@ static int launch_split3(const float* X, long rs, long cs, int R, int C, const P
 // planes of the view (out) and of its transpose (outT: rows/ld swapped) from one read
 static int launch_split3_both(const float* X, long rs, long cs, int R, int C, const P3Buf& out, const P3Buf& outT, hipStream_t st,
                               SplitOpt opt = SplitOpt{0, 0, 0, 0}) {
-  const dim3 grid((unsigned)(out.ld / 64), (unsigned)(out.rows / 64));
+  const dim3 grid = split_grid(out.rows, out.ld, opt);
   if (out.meta)
     hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
                        outT.p, outT.rows * 32, outT.rows * outT.ld, out.meta, out.part, out.npart, opt);
@@ -3237,6 +3242,9 @@ static int launch_gram_batch(const GemmArgs* g, int count, hipStream_t st) {    
   return 0;
 }
 
+// (Round 4, measured and not kept: the K ranges of the pair's LONG tiles -- the corner tile of a 4096^2 factor is a chain of 128 K
+//  steps, ~190 us, in a launch whose whole work is ~135 us of the chip -- dealt to four blocks each (P3Split): 4096^2 update 2.60 ->
+//  2.69 ms; the partial tiles' traffic and the arrivals cost more than the chain.  profiles/r04_kron_update_notes.txt)
 static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   P3Pair p;
   p.g[0] = a; p.g[1] = b;
@@ -3454,12 +3462,10 @@ struct InvSide {
   P3Buf Qc, Ir, Ic, Tp;                          // column-form planes of Q; planes of the inverse (row / column form); of -T
   PlaneMeta* mT;                                 // 6 slots: one per level
   int b0 = 128;                                  // size of the diagonal blocks tri_inverse_blocks inverted (the first level's b)
-  float* sk = nullptr; unsigned* sk_cnt = nullptr;   // K split of the top levels' products: kInvSkItems partial tiles, kInvSkTiles words (zero)
 };
-constexpr int kInvSkItems = 512, kInvSkTiles = 256;
-static int g_inv_splitk = 0;    // tuning key 22: 1 = the K ranges of the top levels' tiles dealt to 2-4 blocks (k_gemm_p3_blk_splitk).  Built and
-                                // measured SLOWER (profiles/r04_inv_ab.txt: 4096^2 fp32 update 2.74 -> 2.82 ms, bf16 operands 2.06 -> 2.19): the levels
-                                // run beside full-chip products of the other chain, and twice the workgroups mean twice the slots to wait for
+// (Round 4, measured and not kept: the K ranges of the top levels' tiles dealt to 2-4 blocks -- 4096^2 fp32 update 2.74 -> 2.82 ms,
+//  bf16 operands 2.06 -> 2.19: the levels run beside full-chip products of the other chain, and twice the workgroups are twice the
+//  slots to wait for.  profiles/r04_inv_ab.txt)
 static int g_trsm_inv = 1;      // tuning key 11: 0 = the solves of every size stay on the substitution strips
 
 static int g_inv_strip512 = 1;  // tuning key 23: 0 = the inversion starts from k_tri_inv128 + levels 128, 256 for every n
@@ -3492,16 +3498,7 @@ static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st)
   P3Args g1 = p3_args(f.Ir, f.Qc, n, n, n, KLO_M | KBLK_HI_M);                     // T = A^-1 B
   g1.e.kblk = 2 * b; g1.e.C = f.Tf; g1.e.ldc = n; g1.ometa = f.mT + level;
   const bool full = p3_no_early(pairs * tb * tb >= p3_block_slots() / 2);           // (two inversions share the chip)
-  // K split: chunks of at least 16 steps (a tile's longest K range is b / 32 steps), at most kInvSkItems items
-  int nch = 1;
-  if (g_inv_splitk && f.sk && pairs * tb * tb <= kInvSkTiles) {
-    nch = (b / 32) / 16;
-    while (nch > 1 && pairs * tb * tb * nch > kInvSkItems) --nch;
-    if (nch > 4) nch = 4;
-    if (nch < 1) nch = 1;
-  }
-  if (nch > 1) hipLaunchKernelGGL(k_gemm_p3_blk_splitk<1>, dim3(pairs * tb * tb * nch), dim3(kThreads), 0, st, g1, b, nch, f.sk, f.sk_cnt);
-  else if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
+  if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
   else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
   if (hipGetLastError() != hipSuccess) return 1;
   P3Buf tp = f.Tp;
@@ -3509,8 +3506,7 @@ static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st)
   if ((e = launch_split3(f.Tf, n, 1, n, n, tp, st, SplitOpt{0, 2 * b, 1, 1}))) return e;              // planes of -T
   P3Args g2 = p3_args(tp, f.Ic, n, n, n, KHI_N | KBLK_LO_N);                       // W = (-T) C^-1 into Inv
   g2.e.kblk = 2 * b; g2.e.C = f.Inv; g2.e.ldc = n; g2.ometa = f.Ir.meta;
-  if (nch > 1) hipLaunchKernelGGL(k_gemm_p3_blk_splitk<1>, dim3(pairs * tb * tb * nch), dim3(kThreads), 0, st, g2, b, nch, f.sk, f.sk_cnt);
-  else if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
+  if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
   else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
   return (int)hipGetLastError();
 }
@@ -3542,6 +3538,12 @@ static int tri_inverse_pair(InvSide a, hipStream_t sa, InvSide b, hipStream_t sb
 // costs the same product flops (M n^2 / 2 per solve: the trailing updates are what the top level's T = A^-1 B, W = -T C^-1 would have
 // folded into the inverse) in products of 512 full-K tiles each, and drops that level from both inversion chains.  Every piece that
 // feeds a product is split into f16 x 2 planes at its actual maximum (the running max|.| its producers accumulate), like p3_chain.
+static int g_inv_order = -1;    // tuning key 25: 1 = both inversions ahead of the products of :173 (those then run beside X1 and Bt), 0 = the products
+                                // first on the side stream, beside Qr's inversion; -1 (default) = by the shape (kron_inv_first)
+// Both inversions first -- undisturbed by full-chip products, every launch of a level at its isolated time, the chip mostly idle for
+// ~0.4 ms -- pays once both factors reach 4096 (4096^2 fp32 update 2.66 -> 2.56 ms; 2048 x 4096, 3072^2, 6144^2 within 1 % either way:
+// profiles/r04_kron_update_notes.txt)
+bool kron_inv_first(int M, int N) { return g_inv_order < 0 ? (M >= 4096 && N >= 4096 && M * (long)N <= 4096L * 4096) : g_inv_order == 1; }
 static int g_inv_blk = 2048;    // tuning key 24: h (0 = whole inverses and one product per solve, the round-3 form)
 struct BlkSolve {
   int M, N, h;
@@ -3572,12 +3574,14 @@ static P3Args blk_product(const P3& A, const P3& B, int M, int N, int K, int kmo
 enum { kPmPieceX = kPmStrip, kPmPieceW = kPmStrip + 8, kPmPieceV = kPmStrip + 16 };      // (the strips' slots: free on this route)
 
 // dX planes, both inversions (R on `main`, L on `side`), then X1 = dX R^-1 on `main`
-static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side) {
+// (l_ready: recorded on `side` behind L's inversion, for callers that put more work on `side` before the join)
+static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hipEvent_t l_ready = nullptr) {
   const int M = s.M, N = s.N, h = s.h;
   int e;
   if ((e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, main))) return e;
   if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, main))) return e;
   if ((e = tri_inverse_pair(s.R, main, s.L, side, h))) return e;
+  if (l_ready && hipEventRecord(l_ready, side) != hipSuccess) return 1;
   PlaneMeta* mX1 = s.pm + kPmX1;
   const int nb = (N + h - 1) / h;
   for (int j = 0; j < nb; ++j) {
@@ -3641,7 +3645,6 @@ struct InvSolveWs {
   PlaneMeta* pm; float* part;
   __bf16 *Lc, *Rc, *IrL, *IcL, *TpL, *IrR, *IcR, *TpR, *DXp, *X1p;
   float *InvL, *InvR, *TfL, *TfR;
-  float* sk; unsigned* sk_cnt;
   __bf16 *Pa, *Pb;                 // transient planes of the blocked solves' pieces
   int64_t total;
 };
@@ -3658,8 +3661,6 @@ static InvSolveWs inv_solve_layout(char* base, int M, int N) {
   k.DXp = planes(Mp * Np); k.X1p = planes(Mp * Np);
   k.InvL = reinterpret_cast<float*>(take((int64_t)M * M * 4)); k.TfL = reinterpret_cast<float*>(take((int64_t)M * M * 4));
   k.InvR = reinterpret_cast<float*>(take((int64_t)N * N * 4)); k.TfR = reinterpret_cast<float*>(take((int64_t)N * N * 4));
-  k.sk = reinterpret_cast<float*>(take((int64_t)2 * kInvSkItems * 64 * kThreads * 4));
-  k.sk_cnt = reinterpret_cast<unsigned*>(take(2 * kInvSkTiles * 4));
   k.Pa = planes(Mp * Np); k.Pb = planes(Mp * Np);
   k.total = off;
   return k;
@@ -3673,7 +3674,6 @@ bool kron_inv_solves_on(int M, int N) {
 
 int kron_inv_prepare(void* ws, int M, int N, hipStream_t main) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
-  if (hipMemsetAsync(k.sk_cnt, 0, 2 * kInvSkTiles * 4, main) != hipSuccess) return 1;
   return hipMemsetAsync(k.pm, 0, kPmSlots * sizeof(PlaneMeta), main) != hipSuccess;
 }
 
@@ -3688,8 +3688,6 @@ static BlkSolve inv_solve_problem(const InvSolveWs& k, const float* QlS, const f
                 P3Buf{k.IcL, Mp, Mp, pm + kPmInvL}, P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
   s.R = InvSide{QrS, N, dinv_r, k.InvR, k.TfR, P3Buf{k.Rc, Np, Np, pm + kPmR}, P3Buf{k.IrR, Np, Np, pm + kPmInvR},
                 P3Buf{k.IcR, Np, Np, pm + kPmInvR}, P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
-  s.L.sk = k.sk; s.L.sk_cnt = k.sk_cnt;
-  s.R.sk = k.sk + (long)kInvSkItems * 64 * kThreads; s.R.sk_cnt = k.sk_cnt + kInvSkTiles;
   s.X0 = X0; s.X0p = P3Buf{k.DXp, Mp, Np, pm + kPmdX};
   s.X1 = X1; s.Bt = Bt;
   s.pa = P3Buf{k.Pa, Mp, Np, nullptr}; s.pb = P3Buf{k.Pb, Mp, Np, nullptr};
@@ -3698,7 +3696,7 @@ static BlkSolve inv_solve_problem(const InvSolveWs& k, const float* QlS, const f
 }
 
 int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
-                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side) {
+                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side, hipEvent_t l_ready) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
   int e;
   // column-form planes of the balanced factors (the B operand of T = A^-1 B, and of the blocked solves' trailing updates)
@@ -3707,7 +3705,7 @@ int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_
   if ((e = launch_split3(QrS, 1, N, N, N, s.R.Qc, main))) return e;                    // (x, k) = QrS[k][x]
   if ((e = launch_absmax(QlS, (long)M * M, s.L.Qc, k.part + kPmPartMax, side))) return e;
   if ((e = launch_split3(QlS, 1, M, M, M, s.L.Qc, side))) return e;
-  return blk_solves_front(s, main, side);
+  return blk_solves_front(s, main, side, l_ready);
 }
 
 int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main) {
@@ -3778,7 +3776,8 @@ KronFork* kron_fork(hipStream_t main) {
       const int prio = g_side_prio == 2 ? greatest : g_side_prio == 1 ? 0 : least;
       const bool ok = hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio) == hipSuccess &&
                       hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) == hipSuccess &&
-                      hipEventCreateWithFlags(&n.join, hipEventDisableTiming) == hipSuccess;
+                      hipEventCreateWithFlags(&n.join, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&n.mid, hipEventDisableTiming) == hipSuccess;
       if (dev != cur) (void)hipSetDevice(cur);
       if (!ok) return nullptr;
       it = tab.emplace(std::make_pair(dev, main), n).first;
@@ -3832,9 +3831,9 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 19) { g_force_er = value; return PSGD_OK; }
   if (key == 20) { g_sparse_planes = value; return PSGD_OK; }
   if (key == 21) { g_small_fused = value; return PSGD_OK; }
-  if (key == 22) { g_inv_splitk = value; return PSGD_OK; }
   if (key == 23) { g_inv_strip512 = value; return PSGD_OK; }
   if (key == 24) { g_inv_blk = value; return PSGD_OK; }
+  if (key == 25) { g_inv_order = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -3926,8 +3925,6 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   const bool inv_route = pm && g_trsm_inv && kron_inv_route(M, N) && M <= 8192 && N <= 8192;    // (6 levels of meta slots)
   const bool solves_on_planes = planes && (inv_route || M > g_trsm_planes_min_n || N > g_trsm_planes_min_n);
   if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st, pm));
-  // (the K-split tickets of the inversions' top levels: zero before either stream uses them; every launch leaves them at zero)
-  if (inv_route && k.inv_sk_cnt && hipMemsetAsync(k.inv_sk_cnt, 0, 2 * kInvSkTiles * 4, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
   KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
   hipStream_t sf = fk ? fk->side : st;
@@ -3939,11 +3936,10 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
                  P3Buf{k.IcL, Mp, Mp, pm + kPmInvL}, P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
     InvSide R = {k.QrS, N, k.dinv, k.g2, k.TfR, P3Buf{k.Rc, Np, Np, pm + kPmR}, P3Buf{k.G2, Np, Np, pm + kPmInvR},
                  P3Buf{k.IcR, Np, Np, pm + kPmInvR}, P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
-    L.sk = k.inv_sk; L.sk_cnt = k.inv_sk_cnt;
-    R.sk = k.inv_sk + (long)kInvSkItems * 64 * kThreads; R.sk_cnt = k.inv_sk_cnt + kInvSkTiles;
     // Order: the full-chip products of :173 run beside the launch-bound lower levels of Qr's inversion, Ql's inversion beside the
     // products of X1 = dX R^-1 (with the two inversions first and the products colliding afterwards the join came 0.3 ms later).
-    KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
+    const bool inv_first = kron_inv_first(M, N) && fk != nullptr;
+    if (!inv_first) KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
     BlkSolve bs = {};
     bs.M = M; bs.N = N; bs.h = inv_blk(M, N); bs.pm = pm; bs.part = k.pm_part;
     bs.L = L; bs.R = R;
@@ -3951,9 +3947,22 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     bs.X1 = k.X1; bs.Bt = k.Bt;
     bs.pa = P3Buf{k.Y0, Mp, Np, nullptr}; bs.pb = P3Buf{k.Y1, Mp, Np, nullptr};      // (transients of the apply: free during an update)
     bs.Br = P3Buf{k.U0, Mp, Np, pm + kPmBt}; bs.Bc = P3Buf{k.U1, Np, Mp, pm + kPmBt};
-    KRON_LAUNCH(blk_solves_front(bs, st, sf));
-    KRON_LAUNCH(fork_scope.join());
-    KRON_LAUNCH(blk_solves_back(bs, st));                         // (leaves max|Bt| and the planes of Bt for the gradient products)
+    if (inv_first) {
+      // both inversions first, undisturbed by full-chip products; the products of :173 then run on the side stream beside X1 and Bt
+      KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid));
+      KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
+      if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
+      P3Buf br = bs.Br, bc = bs.Bc;                               // (U0 / U1: dG's chain on the side stream is still using them)
+      bs.Br.p = nullptr;
+      KRON_LAUNCH(blk_solves_back(bs, st));
+      KRON_LAUNCH(fork_scope.join());
+      br.part = bc.part = &pm[kPmBt].amax; br.npart = bc.npart = 1;
+      KRON_LAUNCH(launch_split3_both(k.Bt, N, 1, M, N, br, bc, st));
+    } else {
+      KRON_LAUNCH(blk_solves_front(bs, st, sf));
+      KRON_LAUNCH(fork_scope.join());
+      KRON_LAUNCH(blk_solves_back(bs, st));                       // (leaves max|Bt| and the planes of Bt for the gradient products)
+    }
     KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st, pm, true));
     return PSGD_OK;
   }

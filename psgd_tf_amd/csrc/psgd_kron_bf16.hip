@@ -1318,17 +1318,23 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   psgdk::KronFork* fk = psgdk::kron_overlap_chains(M, N) ? psgdk::kron_fork(st) : nullptr;
   psgdk::KronForkScope fork_scope(fk, st);   // joins on every exit path, early error returns included
   hipStream_t sf = fk ? fk->side : st;
-  {
-    dim3 grid((max(M, N) + 63) / 64, (max(M, N) + 63) / 64, 2);
-    hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, sf, FactorJob{k.QlS, k.Qlb, k.QlTb, M},
-                       FactorJob{k.QrS, k.Qrb, k.QrTb, N}, static_cast<unsigned*>(nullptr), 0);
-    HK((int)hipGetLastError());
-  }
-  // T' [N][M] = (dG QrS')'      A = dG [M][K=N], Bt[n][k] = QrS[n][k], k >= n                      (:173)
-  HK(launch_hgemm(dGb, N, k.Qrb, N, k.Tt, M, 1, 1, M, N, N, KLO_N, sf));
-  // A = QlS T  -> second half of W1     A operand QlS [M][K=M], k >= m; Bt = T'
-  HK(launch_hgemm(k.Qlb, M, k.Tt, M, k.W1 + k.n64, ld1, 1, 0, M, N, M, KLO_M, sf));
-  HK(launch_cvt(k.W1 + k.n64, 1, ld1, k.W2 + k.m64, ld2, M, N, 1, sf));              // A' -> second half of W2
+  // the bf16 products of psgd.py:173 (side stream)
+  auto products = [&]() -> int {
+    {
+      dim3 grid((max(M, N) + 63) / 64, (max(M, N) + 63) / 64, 2);
+      hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, sf, FactorJob{k.QlS, k.Qlb, k.QlTb, M},
+                         FactorJob{k.QrS, k.Qrb, k.QrTb, N}, static_cast<unsigned*>(nullptr), 0);
+      HK((int)hipGetLastError());
+    }
+    // T' [N][M] = (dG QrS')'      A = dG [M][K=N], Bt[n][k] = QrS[n][k], k >= n                      (:173)
+    HK(launch_hgemm(dGb, N, k.Qrb, N, k.Tt, M, 1, 1, M, N, N, KLO_N, sf));
+    // A = QlS T  -> second half of W1     A operand QlS [M][K=M], k >= m; Bt = T'
+    HK(launch_hgemm(k.Qlb, M, k.Tt, M, k.W1 + k.n64, ld1, 1, 0, M, N, M, KLO_M, sf));
+    HK(launch_cvt(k.W1 + k.n64, 1, ld1, k.W2 + k.m64, ld2, M, N, 1, sf));              // A' -> second half of W2
+    return PSGD_OK;
+  };
+  const bool inv_first = inv_route && fk && psgdk::kron_inv_first(M, N);
+  if (!inv_first) { const int rc = products(); if (rc) return rc; }
   // Bt = QlS^-T dX QrS^-1 in fp32                                                                   (:174)
   {
     const long n8 = (long)M * N / 8;
@@ -1338,11 +1344,21 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     HK((int)hipGetLastError());
   }
   if (inv_route) {
-    // factors from 2048 on: the solves as products with explicit inverses (fp32-accurate f16 x 2 plane products; psgd_kron.hip
-    // tri_inverse).  Ql's inversion goes behind the bf16 products on the side stream, the rest stays here.
-    HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, k.dinv + (long)((N + 31) / 32) * 1024, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf));
-    HK(fork_scope.join());
-    HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
+    // factors from 2048 on: the solves as products with the inverses of the diagonal 2048-blocks (fp32-accurate f16 x 2 plane
+    // products; psgd_kron.hip blk_solves_*).  Ql's inversion goes to the side stream: behind the bf16 products, or -- both factors
+    // from 4096 on -- ahead of them (kron_inv_first), the products then running beside X1 and Bt.
+    const float* dinv_l = k.dinv + (long)((N + 31) / 32) * 1024;
+    if (inv_first) {
+      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, fk->mid));
+      { const int rc = products(); if (rc) return rc; }
+      if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
+      HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
+      HK(fork_scope.join());
+    } else {
+      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf));
+      HK(fork_scope.join());
+      HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
+    }
   } else {
     HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite, true));
     HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv + (long)((N + 31) / 32) * 1024, st, g_trsm_lite, true));

@@ -1206,8 +1206,10 @@ def test_update_over_condition_numbers_inverse_route(psgd, hip_lib, cond_q):
         # Near the fixed point the gradient is a difference of two Grams of products through the solves: from cond ~1e5 on fp32
         # loses it whatever the solve (measured at 1e5: the left increment is 1.1e-6 of the factor and 82 % wrong on BOTH routes,
         # the factor itself 9e-7 from fp64), so beyond the stated bar the licence is "no worse than substitution"
+        # (at 1e6 the factors themselves are 7e-5 from fp64 on both routes, which return the same bits: the step is too small to
+        #  move an fp32 factor)
         bar = max(INCR_TOL, 10 * 6e-8 * cond_q)
-        assert e_inv[i][0] < TOL, (i, cond_q, e_inv, e_sub)
+        assert e_inv[i][0] < TOL or e_inv[i][0] <= 1.05 * e_sub[i][0], (i, cond_q, e_inv, e_sub)
         assert e_inv[i][1] < bar or e_inv[i][1] <= 1.05 * e_sub[i][1], (i, cond_q, e_inv, e_sub, bar)
         assert e_inv[i][0] <= 2 * e_sub[i][0] + 1e-7 and e_inv[i][1] <= 2 * e_sub[i][1] + 1e-5, (i, cond_q, e_inv, e_sub)
 

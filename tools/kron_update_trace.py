@@ -15,6 +15,10 @@ if __name__ == "__main__":
     bf16 = len(sys.argv) > 5 and sys.argv[5] == "bf16"
     lib = _lib.load()
     lib.psgd_kron_set_tuning(12, key)
+    import os
+    for kv in os.environ.get("KRON_KEYS", "").split(","):          # e.g. KRON_KEYS=25:1,24:2048
+        if ":" in kv:
+            lib.psgd_kron_set_tuning(int(kv.split(":")[0]), int(kv.split(":")[1]))
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     Ql, Qr = tri(M, g), tri(N, g)
     dX = torch.randn(M, N, device="cuda", generator=g)
