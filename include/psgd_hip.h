@@ -181,6 +181,21 @@ int psgd_uvd_axpy_cols_f32(const float *M, const float *const *xs, float *const 
 int psgd_uvd_rank2_update_f32(float *M, const float *a, const float *b, const float *c, int64_t N, int r,
                               void *ws, int64_t ws_bytes, void *stream);
 
+/* The same building blocks on a strided VIEW (round 4): M (U, V) is an [N, r] column block of a wider row-major matrix, element
+ * (row, c) at M[row * ld + c], ld >= r in floats -- psgd_tf_amd/uvd_wide.py and splu_wide.py pass column views of U, V, L2
+ * instead of copies of them (SURVEY 8b's `ldU, ldV`).  ld and the byte address of the view must be multiples of the rank's access
+ * width (r % 4 == 0: 16 bytes, r % 2 == 0: 8, odd r: 4), else PSGD_ERR_ALIGN (the callers then copy that chunk).  ld == r is the
+ * contiguous call.  psgd_uvd_update_sweep1_ld_f32 is the Gram sweep (stage 11) of a pair of such views. */
+int psgd_uvd_colsums_ld_f32(const float *M, int64_t ld, const float *const *xs, int k, double *S, int64_t N, int r,
+                            void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_axpy_cols_ld_f32(const float *M, int64_t ld, const float *const *xs, float *const *outs, int k,
+                              const float *S, int64_t N, int r, void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_rank2_update_ld_f32(float *M, int64_t ld, const float *a, const float *b, const float *c, int64_t N, int r,
+                                 void *ws, int64_t ws_bytes, void *stream);
+int psgd_uvd_update_sweep1_ld_f32(const float *U, int64_t ldU, const float *V, int64_t ldV, const float *d,
+                                  const float *v, const float *h, int64_t N, int r, void *ws, int64_t ws_bytes,
+                                  void *stream);
+
 /* Tuning knobs for experiments (not part of the stable ABI).
  * key 0: streaming policy (0 = automatic: non-temporal when U,V exceed the Infinity Cache,
  *        1 = never non-temporal, 2 = always non-temporal).

@@ -67,6 +67,12 @@ SIGNATURES = {
     "psgd_uvd_axpy_cols_f32": (_int, [_c_f32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _int, _c_f32p,
                                       _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_rank2_update_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_colsums_ld_f32": (_int, [_c_f32p, _i64, ctypes.POINTER(ctypes.c_void_p), _int, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_axpy_cols_ld_f32": (_int, [_c_f32p, _i64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _int, _c_f32p,
+                                         _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_rank2_update_ld_f32": (_int, [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_update_sweep1_ld_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64,
+                                             _strm]),
     "psgd_splu_workspace_bytes": (_i64, [_i64, _int]),
     "psgd_splu_apply_f32": (_int, [_c_f32p] * 6 + [_i64, _int, _c_ws, _i64, _strm]),
     "psgd_splu_update_f32": (_int, [_c_f32p] * 10 + [_i64, _int, ctypes.c_float, ctypes.c_float, _c_ws, _i64, _strm]),

@@ -1157,15 +1157,22 @@ int psgd_uvd_ipuvt_matvec_cols_f32(const float* U, const float* V, const float* 
  *   colsums:   S[j][:] = M' x_j                 (fp64, device [k][r])
  *   axpy_cols: out_j   = x_j + M S_j            (S fp32, device [k][r]; out_j may be x_j)
  *   rank2:     M      <- M - (a c1' - b c2')    (c = [c1 | c2] fp32, device [2r])                                  */
-int psgd_uvd_colsums_f32(const float* M, const float* const* xs, int k, double* S, int64_t N, int r, void* ws,
-                         int64_t ws_bytes, void* stream) {
-  if (!M || !xs || !S || k < 1) return PSGD_ERR_BAD_ARG;
+// a strided view [N, r] with row stride ld (floats): usable by the *_ld kernels when ld and the base are multiples of the rank's
+// access width (4, 2 or 1 floats)
+static inline bool view_misaligned(const void* p, int64_t ld, int load_vec) {
+  return ld < 1 || (ld % load_vec) != 0 || (reinterpret_cast<uintptr_t>(p) % (4u * (unsigned)load_vec)) != 0;
+}
+
+int psgd_uvd_colsums_ld_f32(const float* M, int64_t ld, const float* const* xs, int k, double* S, int64_t N, int r, void* ws,
+                            int64_t ws_bytes, void* stream) {
+  if (!M || !xs || !S || k < 1 || ld < r) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
   if (rc) return rc;
-  if (misaligned16(M)) return PSGD_ERR_ALIGN;
   const UvdOps* ops = uvd_ops_for_rank(r);
   if (!ops) return PSGD_ERR_RANK;
+  const bool strided = ld != r;
+  if (strided ? view_misaligned(M, ld, ops->load_vec) : misaligned16(M)) return PSGD_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   double* part = static_cast<double*>(w.part);
   for (int j0 = 0; j0 < k; j0 += 4) {
@@ -1176,23 +1183,29 @@ int psgd_uvd_colsums_f32(const float* M, const float* const* xs, int k, double* 
       if (!x4[j]) return PSGD_ERR_BAD_ARG;
     }
     const int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
-    PSGD_CHECK_LAUNCH(ops->colreduce4(use_nt(N, r), M, x4, N, part, grid, st));
+    if (strided) PSGD_CHECK_LAUNCH(ops->colreduce4_ld(M, ld, x4, N, part, grid, st));
+    else PSGD_CHECK_LAUNCH(ops->colreduce4(use_nt(N, r), M, x4, N, part, grid, st));
     hipLaunchKernelGGL(k_reduce_pq, dim3((nc * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
                        static_cast<const float*>(nullptr), grid, nc * r, S + (int64_t)j0 * r, static_cast<float*>(nullptr));
     PSGD_CHECK_LAUNCH(last_launch());
   }
   return PSGD_OK;
 }
+int psgd_uvd_colsums_f32(const float* M, const float* const* xs, int k, double* S, int64_t N, int r, void* ws,
+                         int64_t ws_bytes, void* stream) {
+  return psgd_uvd_colsums_ld_f32(M, r, xs, k, S, N, r, ws, ws_bytes, stream);
+}
 
-int psgd_uvd_axpy_cols_f32(const float* M, const float* const* xs, float* const* outs, int k, const float* S, int64_t N,
-                           int r, void* ws, int64_t ws_bytes, void* stream) {
-  if (!M || !xs || !outs || !S || k < 1) return PSGD_ERR_BAD_ARG;
+int psgd_uvd_axpy_cols_ld_f32(const float* M, int64_t ld, const float* const* xs, float* const* outs, int k, const float* S,
+                              int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!M || !xs || !outs || !S || k < 1 || ld < r) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
   if (rc) return rc;
-  if (misaligned16(M)) return PSGD_ERR_ALIGN;
   const UvdOps* ops = uvd_ops_for_rank(r);
   if (!ops) return PSGD_ERR_RANK;
+  const bool strided = ld != r;
+  if (strided ? view_misaligned(M, ld, ops->load_vec) : misaligned16(M)) return PSGD_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int j0 = 0; j0 < k; j0 += 4) {
     const int nc = k - j0 < 4 ? k - j0 : 4;
@@ -1204,24 +1217,35 @@ int psgd_uvd_axpy_cols_f32(const float* M, const float* const* xs, float* const*
       if (!x4[j] || !o4[j]) return PSGD_ERR_BAD_ARG;
     }
     const int grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
-    PSGD_CHECK_LAUNCH(ops->rowdot_axpy4(use_nt(N, r), M, x4, o4, nc, N, S + (int64_t)j0 * r, grid, st));
+    if (strided) PSGD_CHECK_LAUNCH(ops->rowdot_axpy4_ld(M, ld, x4, o4, nc, N, S + (int64_t)j0 * r, grid, st));
+    else PSGD_CHECK_LAUNCH(ops->rowdot_axpy4(use_nt(N, r), M, x4, o4, nc, N, S + (int64_t)j0 * r, grid, st));
   }
   return PSGD_OK;
 }
+int psgd_uvd_axpy_cols_f32(const float* M, const float* const* xs, float* const* outs, int k, const float* S, int64_t N,
+                           int r, void* ws, int64_t ws_bytes, void* stream) {
+  return psgd_uvd_axpy_cols_ld_f32(M, r, xs, outs, k, S, N, r, ws, ws_bytes, stream);
+}
 
-int psgd_uvd_rank2_update_f32(float* M, const float* a, const float* b, const float* c, int64_t N, int r, void* ws,
-                              int64_t ws_bytes, void* stream) {
-  if (!M || !a || !b || !c) return PSGD_ERR_BAD_ARG;
+int psgd_uvd_rank2_update_ld_f32(float* M, int64_t ld, const float* a, const float* b, const float* c, int64_t N, int r,
+                                 void* ws, int64_t ws_bytes, void* stream) {
+  if (!M || !a || !b || !c || ld < r) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
   if (rc) return rc;
-  if (misaligned16(M)) return PSGD_ERR_ALIGN;
   const UvdOps* ops = uvd_ops_for_rank(r);
   if (!ops) return PSGD_ERR_RANK;
+  const bool strided = ld != r;
+  if (strided ? view_misaligned(M, ld, ops->load_vec) : misaligned16(M)) return PSGD_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
-  PSGD_CHECK_LAUNCH(ops->rank2_update(use_nt(N, r), M, a, b, N, c, grid, st));
+  if (strided) PSGD_CHECK_LAUNCH(ops->rank2_update_ld(M, ld, a, b, N, c, grid, st));
+  else PSGD_CHECK_LAUNCH(ops->rank2_update(use_nt(N, r), M, a, b, N, c, grid, st));
   return PSGD_OK;
+}
+int psgd_uvd_rank2_update_f32(float* M, const float* a, const float* b, const float* c, int64_t N, int r, void* ws,
+                              int64_t ws_bytes, void* stream) {
+  return psgd_uvd_rank2_update_ld_f32(M, r, a, b, c, N, r, ws, ws_bytes, stream);
 }
 
 // --------------------------------------------------------------- update ----
@@ -1264,27 +1288,35 @@ int psgd_uvd_balance_scale_f32(float* U, float* V, int64_t N, int r, void* ws, i
   return PSGD_OK;
 }
 
-int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, const float* v, const float* h,
-                               int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
-  if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
+int psgd_uvd_update_sweep1_ld_f32(const float* U, int64_t ldU, const float* V, int64_t ldV, const float* d, const float* v,
+                                  const float* h, int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !v || !h || ldU < r || ldV < r) return PSGD_ERR_BAD_ARG;
   Ws w;
   const int rc = ws_open(ws, ws_bytes, N, r, &w);
   if (rc) return rc;
-  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
   const UvdOps* ops = uvd_ops_for_rank(r);
   if (!ops) return PSGD_ERR_RANK;
+  const bool strided = ldU != r || ldV != r;
+  if (strided ? (view_misaligned(U, ldU, ops->load_vec) || view_misaligned(V, ldV, ops->load_vec))
+              : (misaligned16(U) || misaligned16(V))) return PSGD_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = sweep_grid(ops, r, kOccGram, N, kGramMaxGrid);
   double* part = static_cast<double*>(w.part);
   {
     ProfScope ps(PSGD_PROF_UPDATE_S1, st);
-    PSGD_CHECK_LAUNCH(ops->update_gram(use_nt(N, r), U, V, d, v, h, N, part, grid, st));
+    if (strided) PSGD_CHECK_LAUNCH(ops->update_gram_ld(U, ldU, V, ldV, d, v, h, N, part, grid, st));
+    else PSGD_CHECK_LAUNCH(ops->update_gram(use_nt(N, r), U, V, d, v, h, N, part, grid, st));
   }
   const int L = ops->gram_len;
   hipLaunchKernelGGL((k_reduce_sum<double>), dim3((L + 63) / 64), dim3(kThreads), 0, st, part, grid, L, w.sums,
                      static_cast<float*>(nullptr));
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
+}
+
+int psgd_uvd_update_sweep1_f32(const float* U, const float* V, const float* d, const float* v, const float* h,
+                               int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  return psgd_uvd_update_sweep1_ld_f32(U, r, V, r, d, v, h, N, r, ws, ws_bytes, stream);
 }
 
 static int update_sweep2_impl(float* U, float* V, const float* d, const float* v, const float* h, const float* g,

@@ -146,6 +146,62 @@ __device__ __forceinline__ void commit_tile(const Prefetch<R, NMAT, NVEC>& pf, f
 template <int R, int NMAT, int NVEC>
 constexpr int sweep_lds_floats() { return NMAT * Cfg<R>::kTileFloats + NVEC * Cfg<R>::kTileRows; }
 
+// ---- strided operands (round 4): an [N, R] matrix given as a column VIEW of a wider one -- element (row, c) at M[row * ld + c] --
+// for the wide-rank paths (uvd_wide.py / splu_wide.py work on column chunks of U, V, L2, U2' without copying them).  Same tiles,
+// same LDS image; only the global side differs: a lane's vectors are Cfg<R>::kVec floats wide (they never straddle a row), row and
+// column of a vector come from its flat index by a division by the compile-time R.  The host checks that ld and the view's base
+// are multiples of kVec floats.
+template <int R, int NMAT, int NVEC>
+struct PrefetchS {
+  static constexpr int kV = Cfg<R>::kVec;
+  static constexpr int kItems = Cfg<R>::kTileFloats / (64 * kV);
+  typename VecT<kV>::type m[NMAT][kItems];
+  float s[NVEC > 0 ? NVEC : 1][Cfg<R>::kRowsPerLane];
+};
+struct RowStrides { long ld[2]; };       // per operand (sweeps with strided operands have at most two)
+
+template <int R, int NMAT, int NVEC>
+__device__ __forceinline__ void issue_tile_s(PrefetchS<R, NMAT, NVEC>& pf, const float* const (&mats)[NMAT], const RowStrides& rs,
+                                             const float* const (&vecs)[NVEC > 0 ? NVEC : 1], long tile, int lane) {
+  using C = Cfg<R>;
+  using P = PrefetchS<R, NMAT, NVEC>;
+  typedef typename VecT<P::kV>::type VT;
+  const long row0 = tile * C::kTileRows;
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m) {
+#pragma unroll
+    for (int j = 0; j < P::kItems; ++j) {
+      const int idx = (lane + 64 * j) * P::kV, row = idx / R, col = idx - row * R;
+      pf.m[m][j] = *reinterpret_cast<const VT*>(mats[m] + (row0 + row) * rs.ld[m] + col);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NVEC; ++k) {
+#pragma unroll
+    for (int i = 0; i < C::kRowsPerLane; ++i) pf.s[k][i] = vecs[k][row0 + lane + 64 * i];
+  }
+}
+template <int R, int NMAT, int NVEC>
+__device__ __forceinline__ void commit_tile_s(const PrefetchS<R, NMAT, NVEC>& pf, float* lds, int lane) {
+  using C = Cfg<R>;
+  using P = PrefetchS<R, NMAT, NVEC>;
+  typedef typename VecT<P::kV>::type VT;
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m) {
+    VT* dst = reinterpret_cast<VT*>(lds + m * C::kTileFloats);
+#pragma unroll
+    for (int j = 0; j < P::kItems; ++j) dst[lane + 64 * j] = pf.m[m][j];
+  }
+  float* sv = lds + NMAT * C::kTileFloats;
+#pragma unroll
+  for (int k = 0; k < NVEC; ++k)
+#pragma unroll
+    for (int i = 0; i < C::kRowsPerLane; ++i) sv[k * C::kTileRows + lane + 64 * i] = pf.s[k][i];
+}
+// (tail tile / write-back helpers of the strided form: flat tile index -> address)
+template <int R>
+__device__ __forceinline__ long strided_off(int idx, long ld) { const int row = idx / R; return (long)row * ld + (idx - row * R); }
+
 template <int R>
 __device__ __forceinline__ void read_row(const float* tile, int row, float (&x)[R]) {
   const float* p = tile + row * R;
@@ -198,17 +254,22 @@ struct NoTileHook {
 // (operands at m * kTileFloats -- operand WB holds the NEW rows --, per-row scalars at NMAT * kTileFloats +
 // k * kTileRows; the slots in Hook::kStoreVecMask hold what the body left in s[k]).  Column reductions that would
 // cost one accumulator register per column per lane run there on the matrix core instead (ColSum2).
-template <int R, int NMAT, int NVEC, int WB, bool NT, class Body, class Hook = NoTileHook>
+template <int R, int NMAT, int NVEC, int WB, bool NT, bool STR = false, class Body, class Hook = NoTileHook>
 __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
                                            const float* const (&vecs)[NVEC > 0 ? NVEC : 1],
-                                           float* mat_out, long N, float* lds, Body&& body, Hook&& hook = Hook()) {
+                                           float* mat_out, long N, float* lds, Body&& body, Hook&& hook = Hook(),
+                                           const RowStrides rs = RowStrides{{R, R}}) {
   using C = Cfg<R>;
   const int lane = threadIdx.x & 63;
   const long gw = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const long nw = (long)gridDim.x * kWavesPerBlock;
   const long nfull = N / C::kTileRows;
 
-  Prefetch<R, NMAT, NVEC> pf;
+  std::conditional_t<STR, PrefetchS<R, NMAT, NVEC>, Prefetch<R, NMAT, NVEC>> pf;
+  auto issue = [&](long t) {
+    if constexpr (STR) issue_tile_s<R, NMAT, NVEC>(pf, mats, rs, vecs, t, lane);
+    else issue_tile<R, NMAT, NVEC, NT>(pf, mats, vecs, t, lane);
+  };
   // tile order of one wave: chunks of kTileChunk consecutive tiles, chunks dealt round-robin over the waves
   constexpr int CH = kTileChunk;
   long it = 0;
@@ -216,11 +277,12 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
   long tile = tile_at(0);
   // The prefetch is unconditional (the last iteration re-reads its own tile) so that the
   // buffers stay in registers and the loads stay in flight across the compute phase.
-  if (tile < nfull) issue_tile<R, NMAT, NVEC, NT>(pf, mats, vecs, tile, lane);
+  if (tile < nfull) issue(tile);
   while (tile < nfull) {
-    commit_tile<R, NMAT, NVEC>(pf, lds, lane);
+    if constexpr (STR) commit_tile_s<R, NMAT, NVEC>(pf, lds, lane);
+    else commit_tile<R, NMAT, NVEC>(pf, lds, lane);
     const long next = tile_at(++it);
-    issue_tile<R, NMAT, NVEC, NT>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
+    issue((next < nfull) ? next : tile);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < C::kRowsPerLane; ++i) {
@@ -242,7 +304,17 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
       __builtin_amdgcn_wave_barrier();
       hook(lds);
     }
-    if constexpr (WB >= 0) {
+    if constexpr (WB >= 0 && STR) {
+      __builtin_amdgcn_wave_barrier();
+      using P = PrefetchS<R, NMAT, NVEC>;
+      typedef typename VecT<P::kV>::type VT;
+      const VT* src = reinterpret_cast<const VT*>(lds + WB * C::kTileFloats);
+      float* dst = mat_out + tile * C::kTileRows * rs.ld[WB];
+#pragma unroll
+      for (int j = 0; j < P::kItems; ++j)
+        *reinterpret_cast<VT*>(dst + strided_off<R>((lane + 64 * j) * P::kV, rs.ld[WB])) = src[lane + 64 * j];
+      __builtin_amdgcn_wave_barrier();
+    } else if constexpr (WB >= 0) {
       __builtin_amdgcn_wave_barrier();
       const typename C::LoadT* src = reinterpret_cast<const typename C::LoadT*>(lds + WB * C::kTileFloats);
       typename C::LoadT* dst = reinterpret_cast<typename C::LoadT*>(mat_out + tile * C::kTileRows * R);
@@ -260,9 +332,10 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
     const long tail_floats = tail_rows * R;
 #pragma unroll
     for (int m = 0; m < NMAT; ++m) {
-      const float* src = mats[m] + row0 * R;
+      const float* src = mats[m] + row0 * (STR ? rs.ld[m] : (long)R);
       float* dst = lds + m * C::kTileFloats;
-      for (int idx = lane; idx < C::kTileFloats; idx += 64) dst[idx] = (idx < tail_floats) ? src[idx] : 0.0f;
+      for (int idx = lane; idx < C::kTileFloats; idx += 64)
+        dst[idx] = (idx < tail_floats) ? src[STR ? strided_off<R>(idx, rs.ld[m]) : (long)idx] : 0.0f;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -289,8 +362,8 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
     if constexpr (WB >= 0) {
       __builtin_amdgcn_wave_barrier();
       const float* src = lds + WB * C::kTileFloats;
-      float* dst = mat_out + row0 * R;
-      for (int idx = lane; idx < tail_floats; idx += 64) dst[idx] = src[idx];
+      float* dst = mat_out + row0 * (STR ? rs.ld[WB] : (long)R);
+      for (int idx = lane; idx < tail_floats; idx += 64) dst[STR ? strided_off<R>(idx, rs.ld[WB]) : (long)idx] = src[idx];
     }
   }
 }
@@ -456,9 +529,10 @@ __device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& h, bf16
 // holds every inner product psgd.py:569-615 needs: V'U (:574), U'U, V'V, V't,
 // U't, U'w, V'w, t't, w'w, t'w.  Only block pairs bi <= bj are computed.
 // Chains are 1 tile long; tile results are accumulated in fp64.
-template <int R, bool NT>
+template <int R, bool NT, bool STR = false>
 __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const float* V, const float* d,
-                                                          const float* v, const float* h, long N, double* part) {
+                                                          const float* v, const float* h, long N, double* part,
+                                                          RowStrides rs = RowStrides{{R, R}}) {
   using C = Cfg<R>;
   using GC = GramCfg<R>;
   constexpr int kSv = 2 * C::kTileFloats;             // staged d, v, h (3 x kTileRows) from commit_tile
@@ -564,11 +638,16 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
     if (++since_flush == kFlushTiles) flush();
   };
 
-  Prefetch<R, 2, 3> pf;
+  std::conditional_t<STR, PrefetchS<R, 2, 3>, Prefetch<R, 2, 3>> pf;
+  auto issue = [&](long t) {
+    if constexpr (STR) issue_tile_s<R, 2, 3>(pf, mats, rs, vecs, t, lane);
+    else issue_tile<R, 2, 3, NT>(pf, mats, vecs, t, lane);
+  };
   long tile = gw;
-  if (tile < nfull) issue_tile<R, 2, 3, NT>(pf, mats, vecs, tile, lane);
+  if (tile < nfull) issue(tile);
   while (tile < nfull) {
-    commit_tile<R, 2, 3>(pf, lds, lane);
+    if constexpr (STR) commit_tile_s<R, 2, 3>(pf, lds, lane);
+    else commit_tile<R, 2, 3>(pf, lds, lane);
 #pragma unroll
     for (int i = 0; i < C::kRowsPerLane; ++i) {
       const float dd = lds[kSv + 0 * C::kTileRows + lane + 64 * i];
@@ -577,7 +656,7 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
       reinterpret_cast<f32x2*>(lds + kTw)[lane + 64 * i] = f32x2{dd * hh, vv / dd};
     }
     const long next = tile + nw;
-    issue_tile<R, 2, 3, NT>(pf, mats, vecs, (next < nfull) ? next : tile, lane);
+    issue((next < nfull) ? next : tile);
     __builtin_amdgcn_wave_barrier();
     gram_tile();
     __builtin_amdgcn_wave_barrier();
@@ -588,9 +667,10 @@ __global__ __launch_bounds__(kThreads) void k_update_gram(const float* U, const 
     const long tail_floats = tail_rows * R;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const float* src = mats[m] + row0 * R;
+      const float* src = mats[m] + row0 * (STR ? rs.ld[m] : (long)R);
       float* dst = lds + m * C::kTileFloats;
-      for (int idx = lane; idx < C::kTileFloats; idx += 64) dst[idx] = (idx < tail_floats) ? src[idx] : 0.0f;
+      for (int idx = lane; idx < C::kTileFloats; idx += 64)
+        dst[idx] = (idx < tail_floats) ? src[STR ? strided_off<R>(idx, rs.ld[m]) : (long)idx] : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < C::kRowsPerLane; ++i) {
@@ -724,9 +804,9 @@ using ColSum2 = ColSum<R, NMAT, 2, 2, SLOT0>;      // [U | V]' [x0 x1], x0, x1 i
 
 // IpUVtmatvec on up to four columns at once (psgd.py:540-544 with a matrix x): S = V' [x0 .. x3] in ONE sweep of V
 // (the sums on the matrix core) ...
-template <int R, bool NT>
+template <int R, bool NT, bool STR = false>
 __global__ __launch_bounds__(kThreads) void k_colreduce4(const float* M, const float* x0, const float* x1, const float* x2,
-                                                         const float* x3, long N, double* part) {
+                                                         const float* x3, long N, double* part, long ld = R) {
   constexpr int kLdsSweep = kWavesPerBlock * sweep_lds_floats<R, 1, 4>() * 4;
   constexpr int kLdsRed = kWavesPerBlock * 4 * 64 * 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
@@ -734,27 +814,28 @@ __global__ __launch_bounds__(kThreads) void k_colreduce4(const float* M, const f
   const float* const mats[1] = {M};
   const float* const vecs[4] = {x0, x1, x2, x3};
   ColSum<R, 1, 1, 4, 0> cs;
-  sweep_rows<R, 1, 4, -1, NT>(mats, vecs, nullptr, N, lds, [&](long, bool, float (&)[1][R], float (&)[4]) {}, cs);
+  sweep_rows<R, 1, 4, -1, NT, STR>(mats, vecs, nullptr, N, lds, [&](long, bool, float (&)[1][R], float (&)[4]) {}, cs,
+                                   RowStrides{{ld, ld}});
   cs.block_store(reinterpret_cast<double*>(smem), part);
 }
 
 // ... and out_j = x_j + M S_j for the four columns in ONE sweep of M (coef = S, [4][R]).
-template <int R, bool NT>
+template <int R, bool NT, bool STR = false>
 __global__ __launch_bounds__(kThreads) void k_rowdot_axpy4(const float* M, const float* x0, const float* x1,
                                                            const float* x2, const float* x3, float* o0, float* o1,
                                                            float* o2, float* o3, int ncols, long N,
-                                                           const float* __restrict__ coef) {
+                                                           const float* __restrict__ coef, long ld = R) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 4>()];
   const float* const mats[1] = {M};
   const float* const vecs[4] = {x0, x1, x2, x3};
-  sweep_rows<R, 1, 4, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
-                              [&](long row, bool valid, float (&x)[1][R], float (&s)[4]) {
-                                if (!valid) return;
-                                stream_store<NT>(o0 + row, s[0] + dot_row<R>(x[0], coef));
-                                if (ncols > 1) stream_store<NT>(o1 + row, s[1] + dot_row<R>(x[0], coef + R));
-                                if (ncols > 2) stream_store<NT>(o2 + row, s[2] + dot_row<R>(x[0], coef + 2 * R));
-                                if (ncols > 3) stream_store<NT>(o3 + row, s[3] + dot_row<R>(x[0], coef + 3 * R));
-                              });
+  sweep_rows<R, 1, 4, -1, NT, STR>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                                   [&](long row, bool valid, float (&x)[1][R], float (&s)[4]) {
+                                     if (!valid) return;
+                                     stream_store<NT>(o0 + row, s[0] + dot_row<R>(x[0], coef));
+                                     if (ncols > 1) stream_store<NT>(o1 + row, s[1] + dot_row<R>(x[0], coef + R));
+                                     if (ncols > 2) stream_store<NT>(o2 + row, s[2] + dot_row<R>(x[0], coef + 2 * R));
+                                     if (ncols > 3) stream_store<NT>(o3 + row, s[3] + dot_row<R>(x[0], coef + 3 * R));
+                                   }, NoTileHook(), RowStrides{{ld, ld}});
 }
 
 // update sweep 2 (row-local; psgd.py:569-601 / :603-615 given the r-vectors):
@@ -853,17 +934,17 @@ __global__ __launch_bounds__(kThreads) void k_uvd_final(const float* U, const fl
 
 // M <- M - (a c1' - b c2')  (row-local rank-2 update of one factor, psgd.py:600-601 / :614-615 with the step size folded
 // into c1, c2): building block of the wide-rank (r > 32) path, which works on column chunks of U and V.
-template <int R, bool NT>
+template <int R, bool NT, bool STR = false>
 __global__ __launch_bounds__(kThreads) void k_rank2_update(float* M, const float* a, const float* b, long N,
-                                                           const float* __restrict__ coef) {
+                                                           const float* __restrict__ coef, long ld = R) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 2>()];
   const float* const mats[1] = {M};
   const float* const vecs[2] = {a, b};
-  sweep_rows<R, 1, 2, 0, NT>(mats, vecs, M, N, lds[threadIdx.x >> 6],
-                             [&](long, bool, float (&x)[1][R], float (&s)[2]) {
+  sweep_rows<R, 1, 2, 0, NT, STR>(mats, vecs, M, N, lds[threadIdx.x >> 6],
+                                  [&](long, bool, float (&x)[1][R], float (&s)[2]) {
 #pragma unroll
-                               for (int c = 0; c < R; ++c) x[0][c] = x[0][c] - (s[0] * coef[c] - s[1] * coef[R + c]);
-                             });
+                                    for (int c = 0; c < R; ++c) x[0][c] = x[0][c] - (s[0] * coef[c] - s[1] * coef[R + c]);
+                                  }, NoTileHook(), RowStrides{{ld, ld}});
 }
 
 // ------------------------------------------------------- launch table ------
@@ -883,6 +964,13 @@ struct UvdOps {
   int (*rowdot_axpy4)(int nt, const float* M, const float* const* x, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
   int (*rank2_update)(int nt, float* M, const float* a, const float* b, long N, const float* coef, int grid, hipStream_t st);
   int (*final_sweep)(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out, long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st);
+  // strided forms of the wide-rank building blocks (element (row, c) at M[row * ld + c]); load_vec: floats per global access --
+  // ld and the byte address of the view must be multiples of it
+  int load_vec;
+  int (*update_gram_ld)(const float* U, long ldU, const float* V, long ldV, const float* d, const float* v, const float* h, long N, double* part, int grid, hipStream_t st);
+  int (*colreduce4_ld)(const float* M, long ld, const float* const* x, long N, double* part, int grid, hipStream_t st);
+  int (*rowdot_axpy4_ld)(const float* M, long ld, const float* const* x, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
+  int (*rank2_update_ld)(float* M, long ld, const float* a, const float* b, long N, const float* coef, int grid, hipStream_t st);
   // max resident blocks per CU for each sweep kernel (occupancy query)
   int (*occupancy)(int which);
 };

@@ -74,6 +74,26 @@ struct Launch {
                          long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st) {
     PSGD_LAUNCH((k_uvd_final<R, true>), (k_uvd_final<R, false>), U, V, d, nabla, g, out, N, coef, maxbuf, step, tiny);
   }
+  static int update_gram_ld(const float* U, long ldU, const float* V, long ldV, const float* d, const float* v, const float* h,
+                            long N, double* part, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_update_gram<R, false, true>), dim3(grid), dim3(kThreads), 0, st, U, V, d, v, h, N, part, RowStrides{{ldU, ldV}});
+    return (int)hipGetLastError();
+  }
+  static int colreduce4_ld(const float* M, long ld, const float* const* x, long N, double* part, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_colreduce4<R, false, true>), dim3(grid), dim3(kThreads), 0, st, M, x[0], x[1], x[2], x[3], N, part, ld);
+    return (int)hipGetLastError();
+  }
+  static int rowdot_axpy4_ld(const float* M, long ld, const float* const* x, float* const* o, int ncols, long N,
+                             const float* coef, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_rowdot_axpy4<R, false, true>), dim3(grid), dim3(kThreads), 0, st, M, x[0], x[1], x[2], x[3], o[0], o[1],
+                       o[2], o[3], ncols, N, coef, ld);
+    return (int)hipGetLastError();
+  }
+  static int rank2_update_ld(float* M, long ld, const float* a, const float* b, long N, const float* coef, int grid,
+                             hipStream_t st) {
+    hipLaunchKernelGGL((k_rank2_update<R, false, true>), dim3(grid), dim3(kThreads), 0, st, M, a, b, N, coef, ld);
+    return (int)hipGetLastError();
+  }
   static int occupancy(int which) {
     const void* f = nullptr;
     switch (which) {
@@ -95,7 +115,8 @@ struct Launch {
   static const UvdOps* ops() {
     static const UvdOps o = {Cfg<R>::kTileRows, GramCfg<R>::kLen, &colreduce, &apply_s2, &apply_s3,
                              &rowdot_axpy,      &update_gram,     &update_s2, &colreduce4, &rowdot_axpy4,
-                             &rank2_update,     &final_sweep,     &occupancy};
+                             &rank2_update,     &final_sweep,     Cfg<R>::kVec,     &update_gram_ld, &colreduce4_ld,
+                             &rowdot_axpy4_ld,  &rank2_update_ld, &occupancy};
     return &o;
   }
 };

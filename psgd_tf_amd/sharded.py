@@ -33,6 +33,7 @@ import torch.distributed as dist
 from . import _lib
 from . import preconditioned_stochastic_gradient_descent as _psgd
 from . import uvd_wide as _wide
+from . import splu_wide as _splu_wide
 
 
 class HipStages:
@@ -413,9 +414,18 @@ def _splu_backend_for(L12):
     return _splu_backends[key]
 
 
+def _splu_is_wide(L12, backend):
+    return backend is None and L12.dim() == 2 and L12.shape[1] > _lib.UVD_MAX_RANK
+
+
 def precond_grad_splu(L12, l3, U12, u3, grad, group=None, backend=None):
     """Sharded psgd.py:483-524.  `grad` is this rank's flat vector [r corner entries; local tail slice]; returns the
-    same layout (corner entries identical on every rank).  2 exchanges (r sums; 2r sums of which r are used)."""
+    same layout (corner entries identical on every rank).  2 exchanges (r sums; 2r sums of which r are used).  Ranks above 32
+    (the reference has no limit, psgd.py:420) run on column chunks (splu_wide.py) with an all-reduce per exchange."""
+    if _splu_is_wide(L12, backend):
+        _psgd._require_hip("sharded precond_grad_splu", L12, l3, U12, u3, grad)
+        return _splu_wide.precond_grad(L12, l3, U12, u3, grad.reshape(-1), _psgd.uvd_workspace,
+                                       reduce=_wide_reduce(group)).reshape(grad.shape)
     be = backend if backend is not None else _splu_backend_for(L12)
     be.stage1(U12, grad)
     _exchange(be, 1, group)
@@ -427,8 +437,12 @@ def precond_grad_splu(L12, l3, U12, u3, grad, group=None, backend=None):
 def update_precond_splu(L12, l3, U12, u3, dx, dg, step=0.01, tiny=None, has_tail=True, group=None, backend=None):
     """Sharded psgd.py:396-480 on this rank's rows; returns this rank's (L12, l3, U12, u3) (corner blocks identical on
     every rank).  3 exchanges: r sums, 2r sums, [r sums | 4 maxima].  has_tail: the global problem has tail rows."""
-    be = backend if backend is not None else _splu_backend_for(L12)
     tiny = _psgd._tiny if tiny is None else tiny
+    if _splu_is_wide(L12, backend):
+        _psgd._require_hip("sharded update_precond_splu", L12, l3, U12, u3, dx, dg)
+        return _splu_wide.update(L12, l3, U12, u3, dx.reshape(-1), dg.reshape(-1), float(step), float(tiny), _psgd.uvd_workspace,
+                                 reduce=_wide_reduce(group))
+    be = backend if backend is not None else _splu_backend_for(L12)
     be.stage1(U12, dg)
     _exchange(be, 1, group)
     be.update_stage2(L12, l3, U12, u3, dx, dg)

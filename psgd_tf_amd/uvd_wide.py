@@ -1,9 +1,11 @@
 """UVd preconditioner of rank r > 32 (the reference has no rank limit, psgd.py:663).
 
 The rank-templated sweep kernels exist for r = 1..32.  A wider preconditioner is handled on column chunks:
-U = [U_1 | ... | U_c], V = [V_1 | ... | V_c], every chunk a contiguous [N, rc] matrix (rc <= 32; the last chunk is padded
-with zero columns, which change nothing: U V' is the same product and K = I + V'U only gains identity rows).  Every
-N-sized pass runs in the HIP kernels through the C ABI:
+U = [U_1 | ... | U_c], V = [V_1 | ... | V_c], every chunk an [N, rc] matrix, rc <= 32.  When r splits evenly (r = c rc with
+c = ceil(r / 32) or one more: 40, 48, 50, 64, 96, 100, 128 ...) the chunks are column VIEWS of U and V -- row stride r, the
+`*_ld` entry points of the C ABI (round 4) -- and nothing is copied; otherwise contiguous copies, the last one padded with zero
+columns (which change nothing: U V' is the same product and K = I + V'U only gains identity rows).  Every N-sized pass runs in
+the HIP kernels through the C ABI:
 
     Gram blocks X'Y, X't, X'w      psgd_uvd_update_sweep1_f32 on pairs of chunks (matrix cores), one call per pair
     S = M' [x_0 ..]                psgd_uvd_colsums_f32           (psgd.py:544 inner product)
@@ -22,6 +24,7 @@ into one, the maxima of |U|, |V| (balance branch) and of |nablaD| -- so a sharde
 2 (+ 1 on the balance branch), like the specialised path.  The default reduces nothing (one GPU holds all rows).
 """
 import ctypes
+import os
 
 import torch
 
@@ -31,9 +34,15 @@ _MAXR = _lib.UVD_MAX_RANK
 
 
 def _chunks(r):
+    """(chunks, chunk width, views): with c = ceil(r / 32) or c + 1 chunks of EQUAL width r / c the chunks are column VIEWS of
+    the [N, r] matrix (row stride r: the *_ld entry points; an equal split keeps every view aligned to its rank's access width);
+    otherwise c zero-padded copies of width ceil(r / c)."""
     c = -(-r // _MAXR)
-    rc = -(-r // c)
-    return c, rc
+    if os.environ.get("PSGD_WIDE_COPIES") != "1":             # (A/B switch of tools/r04_wide_rank_time.py: the round-3 chunk copies)
+        for cc in (c, c + 1):
+            if r % cc == 0 and r // cc <= _MAXR:
+                return cc, r // cc, True
+    return c, -(-r // c), False
 
 
 def _ptrs(tensors):
@@ -44,13 +53,16 @@ class _Ctx:
     def __init__(self, U, workspace_fn):
         self.dev = U.device
         self.N, self.r = U.shape
-        self.c, self.rc = _chunks(self.r)
+        self.c, self.rc, self.views = _chunks(self.r)
         self.lib = _lib.load()
         self.ws = workspace_fn(self.dev, self.N, self.rc)
         self.st = torch.cuda.current_stream(self.dev).cuda_stream
 
-    def split(self, M):
-        """contiguous column chunks [N, rc] of M [N, r] (the last one zero-padded)."""
+    def split(self, M, copy=False):
+        """column chunks [N, rc] of M [N, r]: views of M (no copy; in-place kernels then update M itself) when the rank splits
+        evenly and M is row-major, else contiguous copies (the last one zero-padded; scatter() writes them back)."""
+        if self.views and not copy and M.dim() == 2 and M.stride(1) == 1 and self._view_ok(M):
+            return [M[:, k * self.rc:(k + 1) * self.rc] for k in range(self.c)]
         out = []
         for k in range(self.c):
             lo, hi = k * self.rc, min((k + 1) * self.rc, self.r)
@@ -64,8 +76,15 @@ class _Ctx:
             out.append(ch)
         return out
 
+    def _view_ok(self, M):
+        """alignment of the column views of M for the rank's access width (4, 2 or 1 floats)."""
+        lv = 4 if self.rc % 4 == 0 else (2 if self.rc % 2 == 0 else 1)
+        return M.stride(0) >= self.r and M.stride(0) % lv == 0 and M.data_ptr() % (4 * lv) == 0
+
     def scatter(self, M, chunks):
         for k, ch in enumerate(chunks):
+            if ch.data_ptr() == M.data_ptr() + k * self.rc * M.element_size() and ch.stride(0) == M.stride(0):
+                continue                                       # a view of M: already in place
             lo, hi = k * self.rc, min((k + 1) * self.rc, self.r)
             M[:, lo:hi] = ch[:, :hi - lo]
 
@@ -77,28 +96,28 @@ class _Ctx:
 
     def colsums(self, M, xs):
         S = torch.empty(len(xs), self.rc, dtype=torch.float64, device=self.dev)
-        _lib.check(self.lib.psgd_uvd_colsums_f32(M.data_ptr(), _ptrs(xs), len(xs), S.data_ptr(), self.N, self.rc,
-                                                 self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_colsums_f32")
+        _lib.check(self.lib.psgd_uvd_colsums_ld_f32(M.data_ptr(), M.stride(0), _ptrs(xs), len(xs), S.data_ptr(), self.N, self.rc,
+                                                    self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_colsums_ld_f32")
         return S
 
     def axpy(self, M, xs, S):
         """in place: x_j += M S_j  (S [k, rc] fp32)."""
         S = S.to(torch.float32).contiguous()
         p = _ptrs(xs)
-        _lib.check(self.lib.psgd_uvd_axpy_cols_f32(M.data_ptr(), p, p, len(xs), S.data_ptr(), self.N, self.rc,
-                                                   self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_axpy_cols_f32")
+        _lib.check(self.lib.psgd_uvd_axpy_cols_ld_f32(M.data_ptr(), M.stride(0), p, p, len(xs), S.data_ptr(), self.N, self.rc,
+                                                      self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_axpy_cols_ld_f32")
 
     def rank2(self, M, a, b, c1, c2):
         cc = torch.cat([c1.reshape(-1), c2.reshape(-1)]).to(torch.float32).contiguous()
-        _lib.check(self.lib.psgd_uvd_rank2_update_f32(M.data_ptr(), a.data_ptr(), b.data_ptr(), cc.data_ptr(), self.N,
-                                                      self.rc, self.ws.data_ptr(), self.ws.numel(), self.st),
-                   "psgd_uvd_rank2_update_f32")
+        _lib.check(self.lib.psgd_uvd_rank2_update_ld_f32(M.data_ptr(), M.stride(0), a.data_ptr(), b.data_ptr(), cc.data_ptr(),
+                                                         self.N, self.rc, self.ws.data_ptr(), self.ws.numel(), self.st),
+                   "psgd_uvd_rank2_update_ld_f32")
 
     # ---- Gram of [X | Y | t | w] for two chunks, decoded from the MFMA block layout of the workspace
     def gram_pair(self, X, Y, d, v, h):
-        _lib.check(self.lib.psgd_uvd_update_sweep1_f32(X.data_ptr(), Y.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(),
-                                                       self.N, self.rc, self.ws.data_ptr(), self.ws.numel(), self.st),
-                   "psgd_uvd_update_sweep1_f32")
+        _lib.check(self.lib.psgd_uvd_update_sweep1_ld_f32(X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), d.data_ptr(),
+                                                          v.data_ptr(), h.data_ptr(), self.N, self.rc, self.ws.data_ptr(),
+                                                          self.ws.numel(), self.st), "psgd_uvd_update_sweep1_ld_f32")
         off, cnt = _lib.ws_region(_lib.PSGD_WS_SUMS_F64, 11, self.N, self.rc)
         sums = self.ws[off:off + cnt * 8].view(torch.float64)
         return sums[self._gram_index()].clone()          # dense [2rc + 2, 2rc + 2]

@@ -236,6 +236,14 @@ def test_zero_padding_of_bf16_kron_shapes_is_exact_in_the_oracle(M, N):
 
 def test_wide_rank_chunking():
     from psgd_tf_amd import uvd_wide
-    for r in (33, 40, 48, 64, 65, 100, 257):
-        c, rc = uvd_wide._chunks(r)
-        assert rc <= 32 and c * rc >= r and (c - 1) * rc < r and c == -(-r // 32)
+    for r in (33, 36, 40, 48, 50, 64, 65, 70, 96, 100, 128, 257):
+        c, rc, views = uvd_wide._chunks(r)
+        cmin = -(-r // 32)
+        assert rc <= 32 and c * rc >= r and (c - 1) * rc < r and c in (cmin, cmin + 1)
+        if views:                                   # column views need an even split; their widths keep every view aligned
+            assert c * rc == r
+            lv = 4 if rc % 4 == 0 else (2 if rc % 2 == 0 else 1)
+            assert r % lv == 0 and all((k * rc) % lv == 0 for k in range(c))
+        else:
+            assert c == cmin and r % cmin != 0 and (r % (cmin + 1) != 0 or r // (cmin + 1) > 32)
+    assert uvd_wide._chunks(40) == (2, 20, True) and uvd_wide._chunks(33) == (3, 11, True) and uvd_wide._chunks(70) == (3, 24, False)

@@ -25,7 +25,7 @@ SHAPES = [(12, 12), (13, 12), (14, 11), (23, 1), (40, 5), (64, 10), (1000, 3), (
           (20000, 17), (3000, 32), (50000, 31), (100003, 20), (300001, 10),
           # ranks above 32 (the reference has no limit, psgd.py:420): column chunks of L2 and U2' (splu_wide.py); no tail, one
           # chunk padded, three chunks
-          (40, 40), (5000, 33), (20011, 48), (3001, 70)]
+          (40, 40), (41, 40), (44, 40), (5000, 33), (20011, 48), (3001, 70), (6007, 64)]
 KEYS = ("L12", "l3", "U12", "u3")
 
 

@@ -284,7 +284,45 @@ def test_register_row_coef_kernel_equals_block_reference(psgd, hip_lib, N, r, up
         assert rel_err(a[k].cpu().numpy(), q[k]) < STATE_TOL, k
 
 
-@pytest.mark.parametrize("N,r", [(5000, 48), (3001, 33), (2049, 64), (1021, 100), (100003, 40)])
+def test_strided_building_blocks_of_the_wide_rank_path(hip_lib):
+    """The `*_ld` entry points (include/psgd_hip.h): column VIEWS of a wider row-major matrix as operands -- column sums, axpy,
+    rank-2 update and the Gram sweep against torch on the same views; what is outside the view is never written; a view that
+    is not aligned to its rank's access width is refused (PSGD_ERR_ALIGN), never mis-read."""
+    import ctypes
+    from psgd_tf_amd import _lib, uvd_wide
+    import preconditioned_stochastic_gradient_descent as m
+    torch.manual_seed(3)
+    for N, rtot, lo, rc in ((5000, 40, 20, 20), (3001, 50, 25, 25), (1000, 36, 18, 18), (777, 96, 32, 32), (64, 33, 22, 11), (130, 40, 0, 20)):
+        W = torch.randn(N, rtot, device="cuda") * 0.1
+        W0 = W.clone()
+        view = W[:, lo:lo + rc]
+        cx = uvd_wide._Ctx(torch.empty(N, rc, device="cuda"), m.uvd_workspace)
+        assert cx.rc == rc and cx.c == 1
+        x, y = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
+        S = cx.colsums(view, [x, y])
+        want = torch.stack([view.double().t() @ x.double(), view.double().t() @ y.double()])
+        assert float((S - want).norm() / want.norm()) < 1e-6
+        out = [x.clone(), y.clone()]
+        coef = torch.randn(2, rc, device="cuda")
+        cx.axpy(view, out, coef)
+        for j, base in enumerate((x, y)):
+            w_ = base.double() + view.double() @ coef[j].double()
+            assert float((out[j].double() - w_).norm() / w_.norm()) < 1e-6
+        c1, c2 = torch.randn(rc, device="cuda"), torch.randn(rc, device="cuda")
+        want = view.double() - (torch.outer(x.double(), c1.double()) - torch.outer(y.double(), c2.double()))
+        cx.rank2(view, x, y, c1, c2)
+        assert float((view.double() - want).norm() / want.norm()) < 1e-6
+        keep = torch.ones(rtot, dtype=torch.bool, device="cuda")
+        keep[lo:lo + rc] = False
+        assert torch.equal(W[:, keep], W0[:, keep])                       # nothing outside the view was touched
+    # a misaligned view of a rank with 16-byte accesses
+    W = torch.randn(512, 41, device="cuda")
+    cx = uvd_wide._Ctx(torch.empty(512, 20, device="cuda"), m.uvd_workspace)
+    with pytest.raises(_lib.PsgdHipError):
+        cx.colsums(W[:, 1:21], [torch.randn(512, device="cuda")])
+
+
+@pytest.mark.parametrize("N,r", [(5000, 48), (3001, 33), (2049, 64), (1021, 100), (100003, 40), (4001, 70), (2500, 65), (1, 40), (3, 50)])
 def test_wide_rank_matches_oracle(psgd, N, r):
     """r > 32 (the reference has no rank limit, psgd.py:663): column chunks of U and V through the same HIP kernels
     (psgd_tf_amd/uvd_wide.py).  Apply, IpUVtmatvec (vector and matrix), both update branches, the balance branch and
