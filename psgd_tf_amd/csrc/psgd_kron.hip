@@ -2916,9 +2916,9 @@ constexpr int kTrsmPlanesK = 2048;      // group width (4 strips) whose update r
 // Measured on the f16 x 2 planes (tools/trsm_planes_k_ab.py, profiles/r03_trsm_planes_k_ab.txt): the in-group K = 512 updates
 // too, from 64 output tiles on: 4096^2 update 3.24 -> 3.20 ms, 2560^2 1.32 -> 1.25, 3072^2 2.34 -> 2.25, 6144^2 9.05 -> 8.91
 // (on the bf16 x 3 planes of round 2 they did not pay: 557 + 7 x 9 us of strip splits against 647 us per solve).
-static int g_trsm_planes_min_k = 512;         // tuning key 13: least K of a solve's update product that runs on planes
-static int g_trsm_planes_min_tiles = 64;      // tuning key 14: ... and its least number of output tiles
-static int g_trsm_planes_min_n = 1100;        // tuning key 15: the solves use planes when M or N exceeds this (tools/trsm_planes_n_ab.py:
+constexpr int g_trsm_planes_min_k = 512;         // (frozen in round 4, was tuning key 13) least K of a solve's update product that runs on planes
+constexpr int g_trsm_planes_min_tiles = 64;      // (frozen in round 4, was tuning key 14) ... and its least number of output tiles
+constexpr int g_trsm_planes_min_n = 1100;        // (frozen in round 4, was tuning key 15) the solves use planes when M or N exceeds this (tools/trsm_planes_n_ab.py:
                                               // 1300^2 0.629 -> 0.618 ms, 2048^2 0.915 -> 0.898, but 1024^2 0.342 -> 0.351)
 static int g_small_fused = 0;   // tuning key 21: 1 = single calls on small layers (kron_small_fused) run the fused strip kernels of
                                 // psgd_kron_small.hip; 0 (default) = the stage kernels: Grams + products, batch-of-one update.  Built to cut the
@@ -3016,8 +3016,8 @@ static void p3_out_meta(P3Args& g, const P3Buf& C) {
 static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; p3_out_meta(g, C); }
 static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; p3_out_meta(g, Ct); }
 
-static int g_sparse_planes = 1;     // tuning key 20: 0 = every product of the sparse formats on launch_gemm / bf16 x 3 planes (see sparse_gemm)
-static int g_force_er = -1;     // tuning key 19: -1 = the launchers choose the form of the f16 x 2 kernels (P3_EARLY), 0 / 2 = always that one
+constexpr int g_sparse_planes = 1;     // (frozen in round 4, was tuning key 20) 0 = every product of the sparse formats on launch_gemm / bf16 x 3 planes (see sparse_gemm)
+constexpr int g_force_er = -1;     // (frozen in round 4, was tuning key 19) -1 = the launchers choose the form of the f16 x 2 kernels (P3_EARLY), 0 / 2 = always that one
 static inline bool p3_no_early(bool auto_choice) { return g_force_er < 0 ? auto_choice : g_force_er == 0; }
 static int p3_block_slots() {           // two resident blocks per CU
   static int slots = 0;
@@ -3038,7 +3038,7 @@ static int launch_p3(const P3Args& g, hipStream_t st) {
 
 // launch_p3, or the K range of every tile dealt to several blocks when the product has few output tiles and a K worth
 // splitting (scratch, cnt: KronWs::sk_*; null = never split)
-static int g_splitk = 1;        // tuning key 8: 0 = no split-K of few-tile products
+constexpr int g_splitk = 1;        // (frozen in round 4, was tuning key 8) 0 = no split-K of few-tile products
 static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStream_t st) {
   const int tx = (g.e.N + 127) / 128, ty = (g.e.M + 127) / 128, tiles = tx * ty, steps = (g.e.K + 31) / 32;
   // Measured (tools/kron_splitk_ab.py): the partial tiles cost 64 KiB of traffic each way per item, so the split only pays for
@@ -3100,7 +3100,7 @@ static int p3_chain(P3Args& g, float* tmp, const P3Buf* row, const P3Buf* col, c
 constexpr int kTrsmBlock = kStripN;
 
 static int g_trsm_lds = 0;     // tuning key 2: 1 = the LDS-resident strip kernels (A/B measurements)
-static int g_trsm_group = 0;   // tuning key 5: strips per group of the blocked solve (0 = automatic, 1 = every strip updates all columns to its right)
+constexpr int g_trsm_group = 0;   // (frozen in round 4, was tuning key 5) strips per group of the blocked solve (0 = automatic, 1 = every strip updates all columns to its right)
 
 static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
   if (!g_trsm_lds) {
@@ -3263,7 +3263,7 @@ static int g_grad_split = 1;    // tuning key 6: 0 = no K split of the gradient 
                                 // block -- a release of the whole L2 -- it cost more than it saved on the f16 x 2 planes and was off for a
                                 // while: profiles/r03_grad_grid_isolated.txt.  With the write-through hand-off: 4096^2 0.762 -> 0.665 ms,
                                 // 2944^2 0.365 -> 0.328; a long last round is still better left whole: 3072^2 0.376 -> 0.440.)
-static int g_grad_order = 1;    // tuning key 17: tile order of the gradient grid for M = N (see k_gemm_p3_grad; tools/grad_order_ab.py:
+constexpr int g_grad_order = 1;    // (frozen in round 4, was tuning key 17) tile order of the gradient grid for M = N (see k_gemm_p3_grad; tools/grad_order_ab.py:
                                 // 4096^2 update 2.95-2.98 -> 2.87-2.88 ms, 6144^2 8.5 -> 8.3; patches of 4 x 4 tiles (2) are no better:
                                 // L2 locality is not what bounds this grid; 2048 x 4096 loses 9 % with either)
 static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsigned* cnt, hipStream_t st) {
@@ -3744,7 +3744,7 @@ int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long
 
 static int g_overlap = 1;       // tuning key 9: 0 = the two chains of a large update run one after the other on the caller's stream
 bool kron_overlap_chains(int M, int N) { return g_overlap != 0 && (M > 512 || N > 512); }
-static int g_side_prio = 1;     // tuning key 10 (before the first forked call on a stream): 0 = side streams at the lowest priority,
+constexpr int g_side_prio = 1;     // (frozen in round 4, was tuning key 10) (before the first forked call on a stream): 0 = side streams at the lowest priority,
                                 // 1 = at the default priority (default), 2 = at the highest.  A lowest- (or highest-) priority
                                 // stream CREATED after an RCCL communicator has existed in the process runs the forked update up
                                 // to 2x slower than the serial order (1024^2: 0.87 vs 0.47 ms); a default-priority one is as fast
@@ -3815,21 +3815,12 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 2) { g_trsm_lds = value; return PSGD_OK; }
   if (key == 3) { g_small_deep = value; return PSGD_OK; }
   if (key == 4) { g_planes = value; return PSGD_OK; }
-  if (key == 5) { g_trsm_group = value; return PSGD_OK; }
   if (key == 6) { g_grad_split = value; return PSGD_OK; }
   if (key == 7) { g_stage_mix = value; return PSGD_OK; }
-  if (key == 8) { g_splitk = value; return PSGD_OK; }
   if (key == 9) { g_overlap = value; return PSGD_OK; }
-  if (key == 10) { g_side_prio = value; return PSGD_OK; }
   if (key == 11) { g_trsm_inv = value; return PSGD_OK; }
   if (key == 12) { g_planes_f16 = value; return PSGD_OK; }
-  if (key == 13) { g_trsm_planes_min_k = value; return PSGD_OK; }
-  if (key == 14) { g_trsm_planes_min_tiles = value; return PSGD_OK; }
-  if (key == 15) { g_trsm_planes_min_n = value; return PSGD_OK; }
   if (key == 16) { g_planes_exact = value; return PSGD_OK; }
-  if (key == 17) { g_grad_order = value; return PSGD_OK; }
-  if (key == 19) { g_force_er = value; return PSGD_OK; }
-  if (key == 20) { g_sparse_planes = value; return PSGD_OK; }
   if (key == 21) { g_small_fused = value; return PSGD_OK; }
   if (key == 23) { g_inv_strip512 = value; return PSGD_OK; }
   if (key == 24) { g_inv_blk = value; return PSGD_OK; }

@@ -983,7 +983,8 @@ static int g_trsm_lite = 1;        // psgd_kron_bf16_set_tuning key 3: 1 = the t
                                    // leading terms of the bf16 x 3 split (2^-16 per product, below the 2^-9 rounding dX arrives
                                    // with); 0 = all six terms (fp32-level).  Strip substitutions and diagonal-block inverses are
                                    // fp32 either way.  tests/test_kron_gpu.py::test_bf16_update_solves_with_ill_conditioned_factors
-static int g_dma_pos = 0;          // psgd_kron_bf16_set_tuning key 4: where a phase of the 256^2 kernels issues its LDS-DMA pieces (hg256_mainloop)
+// (where a phase of the 256^2 kernels issues its LDS-DMA pieces -- hg256_mainloop's template parameter -- was tuning key 4 until round 4:
+// the published template's placement, 0, wins; 1 / 2 measured 5-12 % slower, profiles/r03_bf16_dmapos_ab.txt)
 static int g_hgemm_variant = 0;   // 0: auto (256^2 8-phase kernel for large dense products, fused triangular pair when every
                                   //    tile gets its own CU, else 128^2 register-staged); 4: auto without the fused pair;
                                   // 1: always 128^2 register-staged; 2: 128^2 LDS-DMA ring; 3: 256^2 wherever its shape contract holds
@@ -1009,9 +1010,7 @@ static int launch_hgemm_args(const HGemmArgs& g, hipStream_t st) {
   const bool use256 = big && (((g_hgemm_variant == 0 || g_hgemm_variant == 4) && kmode == 0 && fills) || g_hgemm_variant == 3);
   if (use256) {
     const dim3 grid((M / T2) * (N / T2));
-    if (g_dma_pos == 1) hipLaunchKernelGGL(k_hgemm_nt_256<1>, grid, dim3(kThreads2), 0, st, g);
-    else if (g_dma_pos == 2) hipLaunchKernelGGL(k_hgemm_nt_256<2>, grid, dim3(kThreads2), 0, st, g);
-    else hipLaunchKernelGGL(k_hgemm_nt_256<0>, grid, dim3(kThreads2), 0, st, g);
+    hipLaunchKernelGGL(k_hgemm_nt_256<0>, grid, dim3(kThreads2), 0, st, g);
   }
   else if (g_hgemm_variant == 2 && interior && !sym) hipLaunchKernelGGL(k_hgemm_nt_dma, dim3(nt), dim3(kThreads), 0, st, g);
   else hipLaunchKernelGGL(k_hgemm_nt, dim3(nt), dim3(kThreads), 0, st, g);
@@ -1083,9 +1082,7 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
     const int cc = (tiles_n - c0 < cpl) ? tiles_n - c0 : cpl;
     HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, c0, cc,
                    k.flags + 4 + flag_set * tiles_m * tiles_n, k.flags, g_spin_limit};
-    if (g_dma_pos == 1) hipLaunchKernelGGL(k_hgemm_tri_pair_256<1>, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
-    else if (g_dma_pos == 2) hipLaunchKernelGGL(k_hgemm_tri_pair_256<2>, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
-    else hipLaunchKernelGGL(k_hgemm_tri_pair_256<0>, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
+    hipLaunchKernelGGL(k_hgemm_tri_pair_256<0>, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
     if (hipGetLastError() != hipSuccess) return 1;
   }
   return 0;
@@ -1169,7 +1166,6 @@ int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 0) { g_hgemm_variant = value; return PSGD_OK; }
   if (key == 1) { g_two_pairs = value; return PSGD_OK; }
   if (key == 3) { g_trsm_lite = value; return PSGD_OK; }
-  if (key == 4) { g_dma_pos = (value >= 0 && value <= 2) ? value : 0; return PSGD_OK; }
   if (key == 2) { g_spin_limit = (value < 0 || value > 30) ? (1u << 22) : (1u << value); return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
