@@ -270,53 +270,21 @@ int psgd_splu_update_stage4_f32(const float *L12, const float *l3, const float *
 
 int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 
-/* Experiment knob (not stable ABI). key 0: fp32 GEMM tile choice (0 auto, 1 = 64, 2 = 128, 3 = 32).
- * key 1: 1 (default) 128-tile products run as fp32-accurate bf16 x 3 GEMMs on the bf16 matrix cores; 0 = exact fp32 MFMA.
- * key 2: triangular-solve strips: 0 (default) register-resident kernels, 1 = the LDS-resident ones (A/B measurements).
- * key 3: 32 x 32-tile products: 1 (default) k_gemm_small (ring of 4 K tiles, precomputed per-thread offsets), 0 = the generic body.
- * key 4: shapes with at least 64 output tiles of 128 x 128 (apply and update) and the update from 512 x 512 on: 1 (default)
- *        the products run on operands split ONCE into three bf16 planes in the workspace (k_split3 / plane-writing
- *        epilogues, k_gemm_p3: DMA + MFMA K loop, zero-padded tiles: no edge path); 0 = operands split inside every GEMM
- *        tile.  (PSGD_KRON_PLANES_OLD=1 in the environment restores the first rule, M, N >= 1024, for A/B runs.)
- * key 5: blocked triangular solves: 512-column strips per group (a finished group updates the columns to its right in
- *        one product with K = 512 * group); 0 (default) = 4 from n = 4096 on, else 1.
- * key 8: plane products with few output tiles (at most 80 and K >= 2048, or at most 44 and K >= 1024; e.g. 64 x 8192,
- *        200 x 1700): 1 (default) every tile's K range is dealt to up to 8 blocks (partials summed in chunk order);
- *        0 = one block per tile.
- * key 6: large fp32 update, M = N: 1 (default) the last tiles of the gradient grid are split along K over the block
- *        slots a short last round (at most an eighth of them) would leave idle (partials summed in a fixed order by the last
- *        block to arrive); 0 = whole tiles only.
- * key 7 (bits, default 3): bit 0: in the batched update of small layers each stage of the products dG QrS' -> QlS (.)
- *        (psgd.py:173) shares its launch with the same stage of the solves (:174) -- the two chains only meet at the
- *        gradient pair; bit 1: psgd_kron_dd_update_f32 with M, N <= 512 takes that batched route as a batch of one
- *        (5 launches instead of 10-13; same arithmetic).  0 = one launch per stage of each chain, single updates on
- *        the large-layer path.
- * key 9: updates with M or N above 512 (fp32 and bf16 operands): 1 (default) the products of psgd.py:173 run on a
- *        default-priority side stream (key 10: 0 lowest, 1 default, 2 highest priority; one per device and caller stream, made on first use) while the solves of :174 run on
- *        the caller's stream; the call forks and joins with events only (legal inside a stream capture), so to the caller
- *        it is still one stream-ordered operation.  0 = everything on the caller's stream.  Same kernels, same results.
- * key 11: large fp32 update on f16 x 2 planes with M, N >= 2048 (at most 8192): 1 (default) the two triangular
- *        solves of psgd.py:174 run as products with explicit inverses of the balanced factors (recursive doubling on the
- *        planes); 0 = substitution strips.
- * key 12: operand-plane format of the plane products (key 4): 2 (default) two fp16 planes and one power-of-two scale per
- *        matrix (x 2^e = h + 2^-11 M; three fp16 MFMAs per term) in the large apply and the large update; 1 = in the apply
- *        only; 0 = three bf16 planes (x = h + m + l; six bf16 MFMAs per term) everywhere.  It changes what
- *        psgd_kron_dd_prepare_f32 leaves in the workspace: prepare again after changing it (like key 4).
- * key 13 / 14 / 15: the update products of the blocked triangular solves run on the factor's planes when their K is at least
- *        key 13 (default 512), they have at least key 14 output tiles (64) and M or N exceeds key 15 (1100).
- * key 16: f16 x 2 planes of a product that feeds the next product: 1 (default) the product writes fp32 and its max|C|, a
- *        split launch makes the planes with that exact scale; 0 = the product's epilogue writes the planes with a scale from
- *        the bound K max|A| max|B| (faster by a launch per intermediate; loses accuracy on ill-conditioned factors).
- * key 19: form of the f16 x 2 plane kernels: -1 (default) chosen per launch by the grid size, 0 / 2 = always that many MFMA
- *        columns ahead of the buffer-free barrier.
- * key 20: sparse formats: 1 (default) data-sized products against a dense factor (>= 512, data >= 1M elements) run on f16 x 2
- *        operand planes, 0 = on the in-GEMM split kernels.
- * key 17: gradient grid of the large fp32 update with M = N: 1 (default) every XCD works through a contiguous run of the
- *        tile list, 2 = over 4 x 4 tile patches, 0 = tiles dealt to the XCDs one by one.
- * key 21: single calls on small layers (M <= 512, N <= 256, at most 160 tiles of 16 x 16): 1 = the fused strip kernels
- *        of psgd_kron_small.hip (one launch per call, or one per phase: 2 for the apply, 4 for the update; no Grams, no
- *        prepared state; parity-green, measured slower: opt-in); 0 (default) = the stage kernels the batched entry points
- *        use (Grams + products; batch-of-one update).  Changes what prepared state means: prepare again after changing it. */
+/* Experiment knobs (not stable ABI; defaults in brackets).  Settled A/B keys were frozen into constants in round 4 (5, 8, 10, 13-15,
+ * 17, 19, 20).  Keys 4, 12, 21 change what prepared state in a workspace means: prepare again after changing them.
+ *  0 fp32 GEMM tile: [0] auto, 1 = 64, 2 = 128, 3 = 32        1 [1] 128-tile products as fp32-accurate bf16 x 3 GEMMs, 0 = exact fp32 MFMA
+ *  2 solve strips: [0] register-resident, 1 = LDS-resident      3 32-tile products: [1] k_gemm_small (ring of 4 K tiles), 0 = generic body
+ *  4 [1] large products on operands split ONCE into planes (k_split3 / k_gemm_p3), 0 = split inside every GEMM tile
+ *  6 [1] K split of the tail of the gradient grid (large fp32 update, M = N), 0 = whole tiles
+ *  7 bits [3]: 1 = batched small update shares launches between product and solve stages; 2 = single small updates as a batch of one
+ *  9 [1] large updates fork the products of psgd.py:173 onto a side stream (events only: capturable), 0 = one stream
+ * 11 [1] M, N >= 2048: the solves of :174 as products with explicit inverses of diagonal blocks, 0 = substitution strips
+ * 12 plane format: [2] f16 x 2 (x 2^e = h + 2^-11 M) in the large apply and update, 1 = apply only, 0 = bf16 x 3 everywhere
+ * 16 [1] chained products write fp32 + max|C| and a split launch makes exact-scale planes, 0 = epilogue planes at a bound scale
+ * 21 [0] small layers (M <= 512, N <= 256) on the stage kernels, 1 = fused strip kernels of psgd_kron_small.hip (opt-in, slower)
+ * 23 [1] 512-blocks of an inverse from one strip launch (k_tri_inv512), 0 = k_tri_inv128 + doubling levels 128, 256
+ * 24 [2048] block size h of the blocked solves on inverses of diagonal h-blocks, 0 = whole inverses, one product per solve
+ * 25 [-1] stream order of the inverse route: by shape (both inversions first from 4096^2 on), 0 / 1 = products / inversions first */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.
