@@ -206,6 +206,28 @@ def kron_bench(dev, psgd, iters=20):
     t_lenet_upd = timeit(lambda: psgd.update_precond_kron_batched(Qls, Qrs, dXs, Gs, 0.01), 50)
     t_lenet_upd_loop = timeit(lambda: [psgd.update_precond_kron(a, b, x, g, 0.01)          # mnist_with_lenet5.py:51
                                        for a, b, x, g in zip(Qls, Qrs, dXs, Gs)], 50)
+
+    def graphed(fn):
+        """The reference's per-layer list comprehension captured ONCE in a graph and replayed: the drop-in route that removes the
+        host cost of five Python calls per step (capture is legal for both entry points: tests/test_kron_gpu.py)."""
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()                                  # workspaces of the capture stream exist before the capture
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            fn()
+        return gr.replay
+    try:
+        t_lenet_loop_graph = timeit(graphed(lambda: [psgd.precond_grad_kron(a, b, c) for a, b, c in sts]), 50)       # :53
+        t_lenet_upd_loop_graph = timeit(graphed(lambda: [psgd.update_precond_kron(a, b, x, g, 0.01)                  # :51
+                                                         for a, b, x, g in zip(Qls, Qrs, dXs, Gs)]), 50)
+    except Exception as exc:                          # a graph failure must not take the bench line down
+        print("lenet graph leg failed: %r" % (exc,), file=sys.stderr)
+        t_lenet_loop_graph = t_lenet_upd_loop_graph = float("nan")
     dX = torch.randn_like(G)
     t_upd = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, G, 0.01), 5)
     dXb, dGb = dX.to(torch.bfloat16), Gb
@@ -268,13 +290,20 @@ def kron_bench(dev, psgd, iters=20):
                                    "the three gradient-side products run (triangular K ranges skipped) x 3; `ms` makes the Gram "
                                    "(psgd.py:192) and the factor planes inside the call, `ms_unchanged_factors` keeps them; the "
                                    "fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
-        "lenet5_set_fp32": {"us": t_lenet_cold * 1e3, "gflops": f_lenet / t_lenet_cold / 1e6, "bound": "launch/latency",
-                            "call": "precond_grad_kron_batched", "per_layer_calls_us": t_lenet_loop_cold * 1e3,
-                            "us_unchanged_factors": t_lenet * 1e3,
+        "lenet5_set_fp32": {"us": t_lenet_loop_cold * 1e3, "gflops": f_lenet / t_lenet_loop_cold / 1e6, "bound": "launch/latency",
+                            "call": "[precond_grad_kron(Ql, Qr, G) for each layer]  (the reference's pattern, mnist_with_lenet5.py:53)",
+                            "per_layer_calls_us": t_lenet_loop_cold * 1e3,
                             "per_layer_calls_unchanged_factors_us": t_lenet_loop * 1e3,
-                            "note": "`us` / `per_layer_calls_us`: every call brings new factors (3 launches per call); "
-                                    "`*_unchanged_factors*`: the Grams stay prepared (2 launches)",
-                            "update_us": t_lenet_upd * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3},
+                            "per_layer_calls_graph_us": t_lenet_loop_graph * 1e3,
+                            "batched_us": t_lenet_cold * 1e3, "batched_us_unchanged_factors": t_lenet * 1e3,
+                            "batched_call": "precond_grad_kron_batched (extension: one launch per stage for all layers)",
+                            "note": "`us` = `per_layer_calls_us`: five per-layer calls, new factors on every call (3 launches each); "
+                                    "`*_unchanged_factors*`: the Grams stay prepared (2 launches); `*_graph_us`: the same list "
+                                    "comprehension captured once in a CUDA graph and replayed (no host cost; inside a capture the "
+                                    "Grams are always rebuilt); `batched_us`: the batched extension, new factors",
+                            "update_us": t_lenet_upd_loop * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3,
+                            "per_layer_update_calls_graph_us": t_lenet_upd_loop_graph * 1e3,
+                            "batched_update_us": t_lenet_upd * 1e3},
         "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6},
         "4096x4096_bf16_operands_update": {"ms": t_upd_bf16, "gflops": f_upd / t_upd_bf16 / 1e6,
                                            "note": "products on bf16 operands; balance, triangular solves, norms and "

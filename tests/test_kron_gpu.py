@@ -1239,3 +1239,16 @@ def test_update_with_ill_conditioned_factors(psgd, M, N):
         g64 = g_.cpu().numpy().astype(np.float64)
         assert rel_err(g64, r_) < TOL
         assert rel_err(g64 - q0, r_ - q0) < INCR_TOL
+
+
+def test_lenet5_example_whitens_through_a_replayed_graph(hip_lib):
+    """examples/lenet5_kron_step.py: the reference's per-layer call pattern (mnist_with_lenet5.py:51,53) captured once in a CUDA
+    graph and replayed on static buffers -- the factors it produces precondition the synthetic Kronecker Hessians."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "lenet5_kron_step.py")
+    spec = importlib.util.spec_from_file_location("lenet5_kron_step", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    worst0, worst = mod.main(250)
+    assert np.isfinite(worst) and worst < 0.6 * worst0, (worst0, worst)
