@@ -228,6 +228,26 @@ def kron_bench(dev, psgd, iters=20):
     except Exception as exc:                          # a graph failure must not take the bench line down
         print("lenet graph leg failed: %r" % (exc,), file=sys.stderr)
         t_lenet_loop_graph = t_lenet_upd_loop_graph = float("nan")
+    # the same per-layer calls, each on its own forked stream (`with kron.layer_streams():` around the list comprehension: the
+    # layers are independent and each call is a chain of 3-5 dependent launches); eager, and as a graph with one branch per layer
+    from psgd_tf_amd import kron as _kron
+
+    def forked_apply():                           # (new factors on every call, like cold_loop; inside a capture the Grams are always rebuilt)
+        flip[0] ^= 1
+        with _kron.layer_streams():
+            return [psgd.precond_grad_kron(a, b, c) for a, b, c in both[flip[0]]]
+
+    def forked_update():
+        with _kron.layer_streams():
+            return [psgd.update_precond_kron(a, b, x, g, 0.01) for a, b, x, g in zip(Qls, Qrs, dXs, Gs)]
+    t_lenet_forked = t_lenet_upd_forked = t_lenet_forked_graph = t_lenet_upd_forked_graph = float("nan")
+    try:
+        t_lenet_forked = timeit(forked_apply, 50)
+        t_lenet_upd_forked = timeit(forked_update, 50)
+        t_lenet_forked_graph = timeit(graphed(forked_apply), 50)
+        t_lenet_upd_forked_graph = timeit(graphed(forked_update), 50)
+    except Exception as exc:
+        print("lenet forked-streams leg failed: %r" % (exc,), file=sys.stderr)
     dX = torch.randn_like(G)
     t_upd = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, G, 0.01), 5)
     dXb, dGb = dX.to(torch.bfloat16), Gb
@@ -303,6 +323,12 @@ def kron_bench(dev, psgd, iters=20):
                                     "Grams are always rebuilt); `batched_us`: the batched extension, new factors",
                             "update_us": t_lenet_upd_loop * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3,
                             "per_layer_update_calls_graph_us": t_lenet_upd_loop_graph * 1e3,
+                            "layer_streams": {"per_layer_calls_us": t_lenet_forked * 1e3, "per_layer_calls_graph_us": t_lenet_forked_graph * 1e3,
+                                              "per_layer_update_calls_us": t_lenet_upd_forked * 1e3,
+                                              "per_layer_update_calls_graph_us": t_lenet_upd_forked_graph * 1e3,
+                                              "note": "the same per-layer calls inside `with psgd_tf_amd.kron.layer_streams():` -- every "
+                                                      "call on its own forked stream, joined when the block ends; `*_graph_us`: captured once, "
+                                                      "the graph has one branch per layer"},
                             "batched_update_us": t_lenet_upd * 1e3},
         "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6},
         "4096x4096_bf16_operands_update": {"ms": t_upd_bf16, "gflops": f_upd / t_upd_bf16 / 1e6,

@@ -50,12 +50,7 @@ int kron_small_update(const float* Ql, const float* Qr, const float* dX, const f
 // the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for
 // everything already on `main`; the caller puts one chain on it and kron_join makes `main` wait for that chain.
 // Event fork/join only, so it is legal inside a stream capture of `main`.  nullptr = no side stream: stay on `main`.
-struct KronFork {
-  hipStream_t side; hipEvent_t fork, join, mid;     // mid: a point inside the side chain the caller's stream waits for
-  // CU-masked streams (tuning key 26): chain[0], chain[1] own c CUs each (the launch-bound inversion chains), wide the other 256 - 2c
-  hipStream_t chain[2], wide; hipEvent_t cev[3], cmid; int masked_cus, masked_live;
-};
-bool kron_fork_masked(KronFork* f, hipStream_t main);  // forks chain[0..1] and wide off f->fork; false = not available (stay on side)
+struct KronFork { hipStream_t side; hipEvent_t fork, join, mid; };     // mid: a point inside the side chain the caller's stream waits for
 KronFork* kron_fork(hipStream_t main);
 int kron_join(KronFork* f, hipStream_t main);          // 0 on success
 bool kron_overlap_chains(int M, int N);                // tuning key 9 and the shape rule

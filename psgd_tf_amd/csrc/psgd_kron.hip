@@ -3575,23 +3575,13 @@ enum { kPmPieceX = kPmStrip, kPmPieceW = kPmStrip + 8, kPmPieceV = kPmStrip + 16
 
 // dX planes, both inversions (R on `main`, L on `side`), then X1 = dX R^-1 on `main`
 // (l_ready: recorded on `side` behind L's inversion, for callers that put more work on `side` before the join)
-// (inv_r: a stream of its own for R's inversion -- `main` then waits for r_ready before the first product with R's inverse)
-static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hipEvent_t l_ready = nullptr, hipStream_t inv_r = nullptr,
-                            hipEvent_t r_ready = nullptr) {
+static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hipEvent_t l_ready = nullptr) {
   const int M = s.M, N = s.N, h = s.h;
   int e;
-  if (!inv_r) {
-    if ((e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, main))) return e;
-    if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, main))) return e;
-  }
-  if ((e = tri_inverse_pair(s.R, inv_r ? inv_r : main, s.L, side, h))) return e;
+  if ((e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, main))) return e;
+  if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, main))) return e;
+  if ((e = tri_inverse_pair(s.R, main, s.L, side, h))) return e;
   if (l_ready && hipEventRecord(l_ready, side) != hipSuccess) return 1;
-  if (inv_r) {
-    if (hipEventRecord(r_ready, inv_r) != hipSuccess) return 1;
-    if ((e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, main))) return e;
-    if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, main))) return e;
-    if (hipStreamWaitEvent(main, r_ready, 0) != hipSuccess) return 1;
-  }
   PlaneMeta* mX1 = s.pm + kPmX1;
   const int nb = (N + h - 1) / h;
   for (int j = 0; j < nb; ++j) {
@@ -3798,41 +3788,12 @@ KronFork* kron_fork(hipStream_t main) {
   return f;
 }
 
-static int g_cu_chain = 0;      // tuning key 26: CUs of each of the two masked chain streams (0 = no masked streams)
-bool kron_fork_masked(KronFork* f, hipStream_t main) {
-  if (!f || g_cu_chain <= 0 || g_cu_chain > 64) return false;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;      // a graph replay would not keep the masks: captured calls keep the plain order
-  if (main && (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return false;
-  if (f->masked_cus != g_cu_chain) {
-    if (f->masked_cus) return false;                            // (streams of another width exist: one width per process)
-    uint32_t m[3][8] = {};
-    const int c = g_cu_chain;
-    for (int i = 0; i < 256; ++i) m[i < c ? 0 : i < 2 * c ? 1 : 2][i >> 5] |= 1u << (i & 31);
-    hipStream_t s[3] = {};
-    hipEvent_t e[3] = {};
-    bool ok = true;
-    for (int i = 0; i < 3 && ok; ++i)
-      ok = hipExtStreamCreateWithCUMask(&s[i], 8, m[i]) == hipSuccess && hipEventCreateWithFlags(&e[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) return false;
-    f->chain[0] = s[0]; f->chain[1] = s[1]; f->wide = s[2];
-    for (int i = 0; i < 3; ++i) f->cev[i] = e[i];
-    if (hipEventCreateWithFlags(&f->cmid, hipEventDisableTiming) != hipSuccess) return false;
-    f->masked_cus = c;
-  }
-  hipStream_t s[3] = {f->chain[0], f->chain[1], f->wide};
-  for (int i = 0; i < 3; ++i)
-    if (hipStreamWaitEvent(s[i], f->fork, 0) != hipSuccess) return false;
-  f->masked_live = 1;
-  return true;
-}
-
+// (Round 4, measured and not kept: CU-masked streams, hipExtStreamCreateWithCUMask -- the two inversion chains on c CUs each, the
+//  products of :173 beside them on the other 256 - 2c.  The chains are launch-bound on the whole chip but WORK-bound on a slice of it
+//  (k_tri_inv512 alone is 256 workgroups): 4096^2 fp32 update 2.56 -> 3.99 / 3.52 / 3.66 ms at c = 16 / 32 / 64; and masked streams
+//  are blocking streams, so with the legacy default stream as the caller's they serialise against it: 5.1-5.4 ms.
+//  profiles/r04_cumask_ab.txt)
 int kron_join(KronFork* f, hipStream_t main) {
-  if (f->masked_live) {
-    f->masked_live = 0;
-    hipStream_t s[3] = {f->chain[0], f->chain[1], f->wide};
-    for (int i = 0; i < 3; ++i)
-      if (hipEventRecord(f->cev[i], s[i]) != hipSuccess || hipStreamWaitEvent(main, f->cev[i], 0) != hipSuccess) return 1;
-  }
   if (hipEventRecord(f->join, f->side) != hipSuccess) return 1;
   return hipStreamWaitEvent(main, f->join, 0) != hipSuccess;
 }
@@ -3869,7 +3830,6 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 23) { g_inv_strip512 = value; return PSGD_OK; }
   if (key == 24) { g_inv_blk = value; return PSGD_OK; }
   if (key == 25) { g_inv_order = value; return PSGD_OK; }
-  if (key == 26) { g_cu_chain = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -3985,15 +3945,8 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     bs.Br = P3Buf{k.U0, Mp, Np, pm + kPmBt}; bs.Bc = P3Buf{k.U1, Np, Mp, pm + kPmBt};
     if (inv_first) {
       // both inversions first, undisturbed by full-chip products; the products of :173 then run on the side stream beside X1 and Bt
-      if (kron_fork_masked(fk, st)) {
-        // CU-masked streams (tuning key 26): the inversions' launch-bound chains on CUs of their own, the products of :173 beside
-        // them on the rest of the chip
-        KRON_LAUNCH(planes_update_front(dG, M, N, k, fk->wide, pm));
-        KRON_LAUNCH(blk_solves_front(bs, st, fk->chain[1], fk->mid, fk->chain[0], fk->cmid));
-      } else {
-        KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid));
-        KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
-      }
+      KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid));
+      KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
       if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
       P3Buf br = bs.Br, bc = bs.Bc;                               // (U0 / U1: dG's chain on the side stream is still using them)
       bs.Br.p = nullptr;

@@ -112,6 +112,72 @@ def set_tuning(key, value):
         invalidate_factor_cache()
 
 
+# --------------------------------------------------------------------------- independent per-layer calls on forked streams
+_layer_ctx = None
+_layer_pool = {}          # device index -> list of streams (made once, reused by every block)
+
+
+class layer_streams:
+    """`with kron.layer_streams():` around the reference's per-layer list comprehensions (mnist_with_lenet5.py:51, :53).
+
+    The update_precond_kron / precond_grad_kron calls inside the block must be INDEPENDENT of each other (one per layer: no
+    call reads what another call of the same block returns).  Each runs on the next stream of a small pool that first waits
+    for the caller's stream; leaving the block makes the caller's stream wait for all of them, so everything after the
+    block sees the results in stream order.  Small layers are bound by their chain of 3 (apply) / 5 (update) dependent
+    launches, not by work, so the chains of different layers overlap.  Event fork/join only: inside `torch.cuda.graph` the
+    captured graph gets one branch per call and a replay runs the layers side by side with no host cost at all.
+    Workspaces are per (shape, stream), so two layers of one shape never share scratch."""
+
+    def __init__(self, streams=8):
+        self.n = int(streams)
+        if self.n < 1:
+            raise ValueError("layer_streams: streams must be >= 1")
+
+    def __enter__(self):
+        global _layer_ctx
+        if _layer_ctx is not None:
+            raise RuntimeError("layer_streams blocks do not nest")
+        self.main = None
+        self.used = []
+        self.count = 0
+        _layer_ctx = self
+        return self
+
+    def __exit__(self, *exc):
+        global _layer_ctx
+        _layer_ctx = None
+        for s in self.used:
+            self.main.wait_stream(s)
+        return False
+
+    def run(self, fn, args):
+        global _layer_ctx
+        first = args[0]
+        if not (torch.is_tensor(first) and first.is_cuda):
+            return fn(*args)
+        if self.main is None:
+            self.main = torch.cuda.current_stream(first.device)
+            pool = _layer_pool.setdefault(first.get_device(), [])
+            while len(pool) < self.n:
+                pool.append(torch.cuda.Stream(device=first.device))
+            self.pool = pool
+        s = self.pool[self.count % self.n]
+        self.count += 1
+        if s not in self.used:
+            s.wait_stream(self.main)
+            self.used.append(s)
+        _layer_ctx = None                            # (the call itself must not fork again)
+        try:
+            with torch.cuda.stream(s):
+                out = fn(*args)
+        finally:
+            _layer_ctx = self
+        for t in (out if isinstance(out, (tuple, list)) else (out,)):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.main)           # allocated on the side stream, consumed on the caller's
+        return out
+
+
 def _cache_usable():
     return _factor_cache_enabled and not torch.cuda.is_current_stream_capturing()
 
@@ -600,6 +666,8 @@ def _is_dd_f32(Ql, Qr, X):
 
 
 def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
+    if _layer_ctx is not None:
+        return _layer_ctx.run(update_precond_kron, (Ql, Qr, dX, dG, step))
     if _is_dd_f32(Ql, Qr, dX) and dG.shape == dX.shape and dG.dtype is _f32 and dG.device == dX.device:
         return _dd_update_f32(Ql, Qr, dX, dG, step, dX.shape[0], dX.shape[1])                # psgd.py:84
     fmt = kron_format(Ql.shape, Qr.shape)
@@ -625,6 +693,8 @@ def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
 
 
 def precond_grad_kron(Ql, Qr, Grad):
+    if _layer_ctx is not None:
+        return _layer_ctx.run(precond_grad_kron, (Ql, Qr, Grad))
     if _is_dd_f32(Ql, Qr, Grad):
         return _dd_apply_f32(Ql, Qr, Grad, Grad.shape[0], Grad.shape[1])                     # psgd.py:126
     fmt = kron_format(Ql.shape, Qr.shape)

@@ -1252,3 +1252,57 @@ def test_lenet5_example_whitens_through_a_replayed_graph(hip_lib):
     spec.loader.exec_module(mod)
     worst0, worst = mod.main(250)
     assert np.isfinite(worst) and worst < 0.6 * worst0, (worst0, worst)
+
+
+def test_layer_streams_block_equals_serial_calls(psgd):
+    """kron.layer_streams: the per-layer calls of mnist_with_lenet5.py:51,53 on forked streams (eager and as a captured graph with
+    one branch per layer) return bit for bit what the same calls return one after the other; later work on the caller's stream sees
+    the results (the block joins)."""
+    from psgd_tf_amd import kron
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (257, 120), (640, 300)]    # (one shape twice: separate workspaces)
+    Qs = [(torch.triu(torch.randn(m, m, device="cuda", generator=g)) * 0.1 + torch.eye(m, device="cuda"),
+           torch.triu(torch.randn(n, n, device="cuda", generator=g)) * 0.1 + torch.eye(n, device="cuda")) for m, n in shapes]
+    dXs = [torch.randn(m, n, device="cuda", generator=g) for m, n in shapes]
+    dGs = [torch.randn(m, n, device="cuda", generator=g) for m, n in shapes]
+    ref_u = [psgd.update_precond_kron(ql, qr, dx, dg, 0.02) for (ql, qr), dx, dg in zip(Qs, dXs, dGs)]
+    ref_a = [psgd.precond_grad_kron(ql, qr, dg) for (ql, qr), dg in zip(Qs, dGs)]
+    for n_streams in (8, 3):
+        with kron.layer_streams(n_streams):
+            got_u = [psgd.update_precond_kron(ql, qr, dx, dg, 0.02) for (ql, qr), dx, dg in zip(Qs, dXs, dGs)]
+        sums = [a.sum() + b.sum() for a, b in got_u]                  # (consumed on the caller's stream right after the block)
+        with kron.layer_streams(n_streams):
+            got_a = [psgd.precond_grad_kron(ql, qr, dg) for (ql, qr), dg in zip(Qs, dGs)]
+        for (a, b), (c, d), s_ in zip(got_u, ref_u, sums):
+            assert torch.equal(a, c) and torch.equal(b, d)
+            assert torch.equal(s_, c.sum() + d.sum())
+        for a, c in zip(got_a, ref_a):
+            assert torch.equal(a, c)
+    with pytest.raises(RuntimeError):
+        with kron.layer_streams():
+            with kron.layer_streams():
+                pass
+    # captured: one branch per call
+    outs = [torch.empty_like(x) for x in dGs]
+
+    def fn():
+        with kron.layer_streams():
+            res = [psgd.precond_grad_kron(ql, qr, dg) for (ql, qr), dg in zip(Qs, dGs)]
+        for o, r_ in zip(outs, res):
+            o.copy_(r_)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for o in outs:
+        o.zero_()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=side):
+        fn()
+    for _ in range(3):
+        gr.replay()
+    torch.cuda.synchronize()
+    for o, c in zip(outs, ref_a):
+        assert torch.equal(o, c)
