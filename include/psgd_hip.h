@@ -409,7 +409,6 @@ int psgd_kron_dd_update_bf16(const float *Ql, const float *Qr, const void *dX_bf
  * caller-owned memory).                                                                                              */
 int psgd_kron_bf16_handoff_timeouts(const void *ws, int M, int N);
 int psgd_kron_bf16_handoff_reset(void *ws, int M, int N, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

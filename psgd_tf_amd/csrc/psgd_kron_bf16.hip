@@ -514,9 +514,9 @@ template <int N> struct IntC { static constexpr int value = N; };
 #ifndef HG_DBG
 #define HG_DBG 0      // what-if builds (wrong results, timing only): 1 = no DMA after the prologue, 2 = every fragment read from one LDS
 #endif                // address, 4 = no barriers inside the phases
-template <int DMAPOS, class Src, class Pre>
+template <int DMAPOS, class Src, class Pre, class Top>
 __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, int nk, int w, int lane, Src&& src,
-                                               Pre&& pre) {
+                                               Pre&& pre, Top&& top) {      // top(kt): every wave, before the math of K tile kt
   const int wr = w >> 2, wc = w & 3;
   auto issue1 = [&](int n, int t) {
     const int slot = ((n >> 2) & 1) * 4 + (n & 3);
@@ -638,6 +638,7 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
   };
 
   for (int kt = 0; kt < nk; ++kt) {
+    top(kt);
     phase(IntC<0>{}, kt);
     phase(IntC<1>{}, kt);
     phase(IntC<2>{}, kt);
@@ -645,6 +646,11 @@ __device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, i
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();            // matches the stagger barrier of the other wave row
   HG_FENCE();
+}
+
+template <int DMAPOS, class Src, class Pre>
+__device__ __forceinline__ void hg256_mainloop(f32x4 (&acc)[8][4], u32x4* lds, int nk, int w, int lane, Src&& src, Pre&& pre) {
+  hg256_mainloop<DMAPOS>(acc, lds, nk, w, lane, src, pre, [](int) {});
 }
 
 // per-lane element offsets of the two DMA instructions of each half type inside an operand tile whose row 0 is
@@ -872,6 +878,317 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
   hg256_store<false>(acc, p.out, p.ldo, p.out_bf16, p.out_trans, m0, n0, w, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stream-K over 256 x 256 tiles (round 4): products of the bf16-operand UPDATE on the 8-phase main loop.
+// The two gradients (psgd.py:175-176) are 2 x 136 equal upper tiles -- 272 on 256 CUs: two rounds for 1.06 rounds of work -- and
+// the factor updates (:179) have K ranges that grow with the distance from the diagonal (the full-K tile is the critical path).
+// They ran on the 128 x 128 register-staged kernel (22 % of the matrix peak against this loop's 55 %).  Here the launch is ONE
+// workgroup per CU; the K tiles of all output tiles, in tile order, form one line of `total` units, and workgroup b (in
+// XCD-contiguous order) takes the units [total b / G, total (b + 1) / G) -- at most one unit more than any other.  A range covers
+// pieces of one or more tiles: a piece that is a WHOLE tile goes through the epilogue at once; any other piece is stored as an
+// fp32 partial tile (at most two per workgroup: the tail of the tile its range starts in, the head of the tile it ends in), and
+// a second, small launch (k_hgemm_sk_fix: 32 workgroups per cut tile) adds the pieces of every cut tile in the order of
+// the K axis and runs the epilogue.  No workgroup ever waits for another one: nothing here depends on residency, on other
+// streams or on launch order, and the sums are reproducible.  (An earlier form finished cut tiles inside the main launch --
+// flags, bounded polls, a recovery path: two concurrent launches of it could starve each other, and its second inlined copy of
+// the main loop pushed the kernel into scratch, which costs ~350 us per LAUNCH on this stack.)
+// Contract: M, N multiples of 256, K ranges multiples of 64 (launcher: sk_legal).
+struct SkArgs {
+  HGemmArgs g[2];
+  int nprob;
+  int total, units0;       // K tiles (TK = 64) of all tiles of the launch / of the first product's
+  int dp_rounds, dp_nk;    // whole-tile rounds ahead of the stream-K part (tiles of dp_nk K tiles each; see k_hgemm_sk_256)
+  float* partial;          // [grid][2][65536]: slot 0 = a piece that does not hold its tile's first K tile, slot 1 = one that does
+};
+
+// Tile order of one product: patches of 4 x 8 tiles (ragged at the edges), patch rows from the top, the patches of a row from the
+// left (an upper-triangular output: from the patch that holds the diagonal), the tiles of a patch row by row; `upper` skips c < r.
+// Consecutive ranges run on one XCD: the 32 workgroups of an XCD then work on ~one patch, whose K step pulls 4 + 8 operand panels
+// through that L2 (tile-row order pulled 1 + 30: the gradients ran at 340 us instead of 230, bound by Infinity-Cache traffic).
+constexpr int kSkPR = 4, kSkPC = 8;
+__device__ __host__ __forceinline__ int sk_nk(int K, int kmode, int r, int c, int& klo) {
+  const int m0 = r * T2, n0 = c * T2;
+  int lo = 0, hi = K;
+  if (kmode & KLO_M) lo = lo > m0 ? lo : m0;
+  if (kmode & KLO_N) lo = lo > n0 ? lo : n0;
+  if (kmode & KHI_M) hi = hi < m0 + T2 ? hi : m0 + T2;
+  if (kmode & KHI_N) hi = hi < n0 + T2 ? hi : n0 + T2;
+  klo = (lo / TK) * TK;
+  return hi > klo ? (hi - klo + TK - 1) / TK : 0;
+}
+__device__ __host__ __forceinline__ bool sk_next(int Tm, int Tn, int upper, int& r, int& c) {      // false: past the last tile
+  do {
+    const int c0 = c & ~(kSkPC - 1), r0 = r & ~(kSkPR - 1);
+    if (((c + 1) & (kSkPC - 1)) != 0 && c + 1 < Tn) {
+      ++c;
+    } else if (((r + 1) & (kSkPR - 1)) != 0 && r + 1 < Tm) {
+      ++r; c = c0;
+    } else if (c0 + kSkPC < Tn) {
+      c = c0 + kSkPC; r = r0;
+    } else {
+      r = r0 + kSkPR;
+      if (r >= Tm) return false;
+      c = upper ? (r & ~(kSkPC - 1)) : 0;
+    }
+  } while (upper && c < r);
+  return true;
+}
+__device__ __forceinline__ bool sk_prev(int Tm, int Tn, int upper, int& r, int& c) {               // false: before the first tile
+  do {
+    const int c0 = c & ~(kSkPC - 1), r0 = r & ~(kSkPR - 1);
+    if (c > c0) {
+      --c;
+    } else if (r > r0) {
+      --r; c = (c0 + kSkPC < Tn ? c0 + kSkPC : Tn) - 1;
+    } else if (c0 > (upper ? (r0 & ~(kSkPC - 1)) : 0)) {
+      c = c0 - 1; r = (r0 + kSkPR < Tm ? r0 + kSkPR : Tm) - 1;
+    } else {
+      if (r0 == 0) return false;
+      r = r0 - 1; c = Tn - 1;
+    }
+  } while (upper && c < r);
+  return true;
+}
+
+__device__ __forceinline__ void sk_negate(f32x4 (&acc)[8][4]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = -acc[i][j];
+}
+
+// acc = the K tiles [a, b) (counted from the tile's klo) of tile (m0, n0), from zero
+__device__ __forceinline__ void sk_piece(f32x4 (&acc)[8][4], u32x4* lds, const HGemmArgs& g, int m0, int n0, int klo, int a, int b) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int td = threadIdx.x;
+  asm volatile("" : "+v"(td));                       // (keeps the per-lane offsets of the pieces from being hoisted together)
+  const int lane = td & 63, w = td >> 6;
+  long offA[2][2], offB[2][2];
+  hg256_offsets(w, lane, g.lda, g.ldb, offA, offB);
+  const uint16_t* Abase = g.A + (long)m0 * g.lda + klo + (long)a * TK;
+  const uint16_t* Bbase = g.B + (long)n0 * g.ldb + klo + (long)a * TK;
+  auto src = [&](int n, int t) -> const uint16_t* {
+    const int j = n & 3;
+    const long k0 = (long)(n >> 2) * TK;
+    const long o = (j == 0) ? offB[0][t] : (j == 1) ? offA[0][t] : (j == 2) ? offB[1][t] : offA[1][t];
+    return ((j & 1) ? Abase : Bbase) + o + k0;
+  };
+  // kflip (C = -A1 B1' + A2 B2' over a concatenated K axis): the accumulators change sign before K tile kflip
+  const int flip = g.kflip > 0 ? g.kflip - klo / TK - a : -1;
+#ifdef SK_NOHOOK
+  hg256_mainloop<0>(acc, lds, b - a, w, lane, src, [](int) {});
+#else
+  hg256_mainloop<0>(acc, lds, b - a, w, lane, src, [](int) {}, [&](int kt) {
+    if (kt == flip && kt > 0) sk_negate(acc);
+  });
+#endif
+  if (g.kflip > 0 && flip >= b - a) sk_negate(acc);  // the whole piece lies in the negated half
+}
+
+// partial tiles: [q = i * 4 + j][thread] f32x4.  ONE per-lane pointer walks the 32 rows and is made opaque at every step: left to
+// itself the compiler materialises all 32 addresses ahead of the accesses and spills them and the accumulators.
+__device__ __forceinline__ void sk_put(const f32x4 (&acc)[8][4], float* dst, int tid) {
+  f32x4* d = reinterpret_cast<f32x4*>(dst) + tid;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" : "+v"(d));
+      *d = acc[i][j];
+      d += kThreads2;
+    }
+}
+// epilogues on the 256^2 accumulator layout: acc[i][j][e] = C[m0 + wr*128 + (ibase + i)*16 + (lane>>4)*4 + e][n0 + wc*64 + j*16 + (lane&15)];
+// NI = 8, NJ = 4, ibase = jbase = 0: a whole tile (main launch); NI = NJ = 1: one 16 x 16 block per wave (fix-up launch)
+// red: eight floats of LDS for one max per WORKGROUP (fix-up launch: 32 x 8 waves per cut tile all finish together, and thousands of
+// atomics on one address serialise in L2 -- 40 of that launch's 49 us); nullptr: one atomic per wave (main launch: spread over its run)
+template <int NI, int NJ>
+__device__ __forceinline__ void sk_epilogue(const HGemmArgs& g, f32x4 (&acc)[NI][NJ], int ibase, int jbase, int m0, int n0, int w, int lane,
+                                            float* red = nullptr) {
+  const int wr = w >> 2, wc = w & 3;
+  if (g.epi == HEPI_TRIU_MAX) {
+    float vmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row0 = m0 + wr * 128 + (ibase + i) * 16 + (lane >> 4) * 4, col = n0 + wc * 64 + (jbase + j) * 16 + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (col >= row0 + e) ? acc[i][j][e] : 0.0f;
+          vmax = amaxf(vmax, fabsf(v));
+          acc[i][j][e] = v;
+        }
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+    if (red) {
+      if (lane == 0) red[w] = vmax;
+      __syncthreads();
+      if (w == 0) {
+        vmax = lane < kThreads2 / 64 ? red[lane] : 0.0f;
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+      }
+      if (w != 0) vmax = 0.0f;
+    }
+    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row0 = m0 + wr * 128 + (ibase + i) * 16 + (lane >> 4) * 4, col = n0 + wc * 64 + (jbase + j) * 16 + (lane & 15);
+      if (g.c_trans) {
+        if (g.c_bf16) {
+          const unsigned long long pk = (unsigned long long)f2bf(acc[i][j][0]) | ((unsigned long long)f2bf(acc[i][j][1]) << 16) |
+                                        ((unsigned long long)f2bf(acc[i][j][2]) << 32) | ((unsigned long long)f2bf(acc[i][j][3]) << 48);
+          *reinterpret_cast<unsigned long long*>(static_cast<uint16_t*>(g.C) + (long)col * g.ldc + row0) = pk;
+        } else {
+          *reinterpret_cast<f32x4*>(static_cast<float*>(g.C) + (long)col * g.ldc + row0) = acc[i][j];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (g.c_bf16) static_cast<uint16_t*>(g.C)[(long)(row0 + e) * g.ldc + col] = f2bf(acc[i][j][e]);
+          else static_cast<float*>(g.C)[(long)(row0 + e) * g.ldc + col] = acc[i][j][e];
+        }
+      }
+    }
+}
+
+// the tile that holds unit u (0 <= u < total): its problem, coordinates, first unit, K range.
+// NOT a walk over the tiles: a tile-by-tile scan is ~100 dependent scalar instructions per tile -- 50 us for the last workgroups of a
+// 272-tile launch, in the main launch and again in the fix-up.  The K-tile count of a tile is affine in its column (sk_legal's
+// modes), so a run of tiles of one row sums in closed form: patch rows, then the patches of the row, then the rows of the patch, then
+// the tiles of the row -- T/4 + T/8 + 4 + 8 short steps, in the order sk_next walks.
+struct SkAt { int prob, r, c, ubase, klo, nk, Tm, Tn, upper, K, kmode; };
+__device__ __forceinline__ void sk_dims(const SkArgs& p, int prob, SkAt& t) {
+  const HGemmArgs& g = prob ? p.g[1] : p.g[0];
+  t.Tm = g.M / T2; t.Tn = g.N / T2; t.upper = g.sym != 0; t.K = g.K; t.kmode = g.kmode;
+}
+__device__ __forceinline__ int sk_seg(const SkAt& t, int r, int ca, int cb) {       // units of the tiles (r, ca .. cb)
+  if (t.upper && ca < r) ca = r;
+  if (cb >= t.Tn) cb = t.Tn - 1;
+  if (cb < ca) return 0;
+  int klo;
+  return (sk_nk(t.K, t.kmode, r, ca, klo) + sk_nk(t.K, t.kmode, r, cb, klo)) * (cb - ca + 1) / 2;
+}
+__device__ __forceinline__ void sk_locate(const SkArgs& p, int u, SkAt& t) {
+  t.prob = (p.nprob > 1 && u >= p.units0) ? 1 : 0;
+  t.ubase = t.prob ? p.units0 : 0;
+  sk_dims(p, t.prob, t);
+  int left = u - t.ubase, r0 = 0, c0, s;
+  for (;; r0 += kSkPR) {                                             // patch rows
+    s = 0;
+    for (int r = r0; r < r0 + kSkPR && r < t.Tm; ++r) s += sk_seg(t, r, 0, t.Tn - 1);
+    if (left < s || r0 + kSkPR >= t.Tm) break;
+    left -= s; t.ubase += s;
+  }
+  for (c0 = t.upper ? (r0 & ~(kSkPC - 1)) : 0;; c0 += kSkPC) {        // the patches of that row
+    s = 0;
+    for (int r = r0; r < r0 + kSkPR && r < t.Tm; ++r) s += sk_seg(t, r, c0, c0 + kSkPC - 1);
+    if (left < s || c0 + kSkPC >= t.Tn) break;
+    left -= s; t.ubase += s;
+  }
+  for (t.r = r0;; ++t.r) {                                            // the rows of that patch
+    s = sk_seg(t, t.r, c0, c0 + kSkPC - 1);
+    if (left < s || t.r + 1 >= t.Tm || ((t.r + 1) & (kSkPR - 1)) == 0) break;
+    left -= s; t.ubase += s;
+  }
+  for (t.c = (t.upper && c0 < t.r) ? t.r : c0;; ++t.c) {              // the tiles of that row
+    t.nk = sk_nk(t.K, t.kmode, t.r, t.c, t.klo);
+    if (left < t.nk || t.c + 1 >= t.Tn) break;
+    left -= t.nk; t.ubase += t.nk;
+  }
+}
+__device__ __forceinline__ int sk_lb(int G) {       // blocks b, b + 8, ... share an XCD: consecutive ranges (neighbouring tiles) on one L2
+  return (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+}
+
+// Whole-tile rounds first.  Workgroups that share operand panels must walk K TOGETHER: with every range starting at its own K offset
+// (pure stream-K) a panel slice is fetched by one workgroup at a time, nothing is reused in the 4-MiB L2 and the gradients ran at 62 %
+// of the dense kernel's rate on Infinity-Cache traffic.  So while all tiles cost the same (dp_nk K tiles: the gradients when M = N),
+// tiles [round G, (round + 1) G) are taken one per workgroup from their first K tile, like the dense kernel, and only the tiles of
+// the last, incomplete round are dealt out as ranges of units.
+__global__ __launch_bounds__(kThreads2) void k_hgemm_sk_256(SkArgs p) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024];          // ONE __shared__ object (see k_hgemm_tri_pair_256)
+  const int G = gridDim.x, lb = sk_lb(G);
+  SkAt t;
+  f32x4 acc[8][4];
+  const int dp_units = p.dp_rounds * G * p.dp_nk;
+  for (int round = 0; round < p.dp_rounds; ++round) {
+    const int u = (round * G + lb) * p.dp_nk;
+    if (u >= p.total) break;                           // (a last round that is not full)
+    sk_locate(p, u, t);
+    const HGemmArgs g = t.prob ? p.g[1] : p.g[0];
+    sk_piece(acc, lds, g, t.r * T2, t.c * T2, t.klo, 0, t.nk);
+    int td = threadIdx.x;
+    asm volatile("" : "+v"(td));
+    sk_epilogue<8, 4>(g, acc, 0, 0, t.r * T2, t.c * T2, td >> 6, td & 63);
+  }
+  if (dp_units >= p.total) return;
+  auto start = [&](int b) { return dp_units + (int)((unsigned)(p.total - dp_units) * (unsigned)b / (unsigned)G); };      // (total * G < 2^31: launcher)
+  const int u0 = start(lb), u1 = start(lb + 1);
+  if (u1 <= u0) return;
+  sk_locate(p, u0, t);
+  int lo = u0;
+  for (;;) {
+    const HGemmArgs g = t.prob ? p.g[1] : p.g[0];
+    const int end = t.ubase + t.nk, hi = u1 < end ? u1 : end;
+    const int a = lo - t.ubase, b = hi - t.ubase;      // K tiles [a, b) of tile t
+    const int m0 = t.r * T2, n0 = t.c * T2;
+    sk_piece(acc, lds, g, m0, n0, t.klo, a, b);
+    // (the thread id is made opaque per piece: otherwise the per-lane offsets of the partial-tile accesses and of every epilogue are
+    //  hoisted out of the piece loop as invariants, stay live across the K loop and push it into scratch -- a reload inside the K
+    //  loop is followed by s_waitcnt vmcnt(0), which drains the LDS-DMA pipeline on every K tile)
+    int td = threadIdx.x;
+    asm volatile("" : "+v"(td));
+    if (a == 0 && b == t.nk) sk_epilogue<8, 4>(g, acc, 0, 0, m0, n0, td >> 6, td & 63);
+    else sk_put(acc, p.partial + ((long)lb * 2 + (a == 0 ? 1 : 0)) * 65536, td);
+    lo = hi;
+    if (lo >= u1) break;
+    t.ubase = end;
+    if (!sk_next(t.Tm, t.Tn, t.upper, t.r, t.c)) {
+      ++t.prob; t.r = t.c = 0;
+      sk_dims(p, t.prob, t);
+    }
+    t.nk = sk_nk(t.K, t.kmode, t.r, t.c, t.klo);
+  }
+}
+
+// 32 workgroups (one per 16 x 16 block of the wave tiles: one f32x4 per lane) per CUT TILE, named by the first range boundary b
+// inside it (the launcher lists them: a launch over all G - 1 boundaries spent 145 us on workgroups that only found out they had
+// nothing to do).  They finish the tile: the head
+// piece of workgroup b - 1, then the pieces of b, b + 1, ... while their ranges reach into the tile, added in that order (the
+// loads of eight pieces are in flight together: one memory latency per eight pieces, not per piece); epilogue.
+constexpr int kSkMaxGrid = 256;   // workgroups of a stream-K launch (one per CU); sizes the partial-tile scratch
+// the cut tiles of a launch (host: launch_hgemm_sk): first boundary inside, number of boundaries inside (= pieces after the head), tile
+struct SkCuts { int n; unsigned char b[kSkMaxGrid], cnt[kSkMaxGrid], prob[kSkMaxGrid], r[kSkMaxGrid], c[kSkMaxGrid]; };
+__global__ __launch_bounds__(kThreads2) void k_hgemm_sk_fix(SkArgs p, SkCuts cuts) {
+  const int ci = blockIdx.x / 32, blk = blockIdx.x % 32;
+  const int b = cuts.b[ci], cnt = cuts.cnt[ci];
+  const HGemmArgs g = cuts.prob[ci] ? p.g[1] : p.g[0];
+  const int tid = threadIdx.x;
+  const f32x4* base = reinterpret_cast<const f32x4*>(p.partial) + (long)blk * kThreads2 + tid;      // this lane's f32x4 of slot 0 of workgroup 0
+  f32x4 acc[1][1];
+  const f32x4 head = base[((long)(b - 1) * 2 + 1) * 16384];
+  for (int k0 = 0; k0 < cnt; k0 += 16) {               // (sixteen pieces in flight: one memory latency for the usual cut tile)
+    f32x4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (k0 + k < cnt) ? base[(long)(b + k0 + k) * 2 * 16384] : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (k0 == 0) acc[0][0] = head;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k0 + k < cnt) acc[0][0] += v[k];
+  }
+  __shared__ float red[kThreads2 / 64];
+  sk_epilogue<1, 1>(g, acc, blk >> 2, blk & 3, cuts.r[ci] * T2, cuts.c[ci] * T2, tid >> 6, tid & 63, red);
+}
+
 // dst (bf16) = src or src', 64 x 64 tiles through LDS.  SRC_BF16 selects the source element type.
 template <bool SRC_BF16>
 __global__ __launch_bounds__(kThreads) void k_to_bf16(const void* src, long lds_, uint16_t* dst, long ldd, int rows,
@@ -1028,6 +1345,90 @@ static int launch_hgemm_two(const HGemmArgs& g0, const HGemmArgs& g1, hipStream_
   return (int)hipGetLastError();
 }
 
+static int device_cu_count();
+// ---- stream-K launches (k_hgemm_sk_256) ---------------------------------------------------------------------------------
+static int g_streamk = 1;         // psgd_kron_bf16_set_tuning key 4: 0 = the update's products stay on the 128^2 register-staged kernel,
+                                  // 2 = stream-K for every shape the kernel can take (tests), 3 = 2 without whole-tile rounds
+static bool sk_legal(const HGemmArgs& g) {
+  if (g.M <= 0 || g.N <= 0 || (g.M % T2) || (g.N % T2) || (g.K % TK) || (g.lda % 8) || (g.ldb % 8)) return false;
+  if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) return false;
+  if (g.sym && g.M != g.N) return false;
+  if (g.kflip && g.kmode) return false;
+  if (g.kmode != 0 && g.kmode != KLO_M && g.kmode != KLO_N && g.kmode != (KLO_M | KHI_N)) return false;      // (sk_locate: K tiles affine in the column)
+  if (g.epi == HEPI_STORE) return g.sym == 0;
+  return g.epi == HEPI_TRIU_MAX && g.sym == 1;       // (the factor updates' HEPI_D_MINUS stays on the 128^2 kernel: see the call)
+}
+static int sk_units(const HGemmArgs& g) {            // K tiles of all tiles of one product
+  const int Tm = g.M / T2, Tn = g.N / T2, o = g.sym != 0;
+  int r = 0, c = 0, klo, tot = 0;
+  do tot += sk_nk(g.K, g.kmode, r, c, klo); while (sk_next(Tm, Tn, o, r, c));
+  return tot;
+}
+// one or two products in one launch (+ the fix-up launch); returns 2 when the shapes are not the kernel's (the caller falls back)
+static int launch_hgemm_sk(const HGemmArgs* g, int n, float* partial, hipStream_t st) {
+  if (!g_streamk || !partial || n < 1 || n > 2) return 2;
+  SkArgs a = {};
+  a.nprob = n;
+  for (int i = 0; i < n; ++i) {
+    if (!sk_legal(g[i])) return 2;
+    a.g[i] = g[i];
+    if (i == 0) a.units0 = sk_units(g[0]);
+    a.total += sk_units(g[i]);
+  }
+  int grid = device_cu_count();
+  if (grid > kSkMaxGrid) grid = kSkMaxGrid;
+  if ((long)a.total * grid >= (1L << 31)) return 2;
+  if (g_streamk >= 2) {                              // (tests: every legal shape, however small -- ranges of a few K tiles, tiles cut many times)
+    if (grid > a.total / 2) grid = a.total / 2 > 0 ? a.total / 2 : 1;
+  } else if (a.total < 8 * grid) {
+    return 2;                                        // too little work for one workgroup per CU
+  }
+  if (grid >= 8) grid = grid / 8 * 8;
+  a.partial = partial;
+  // whole-tile rounds while every tile costs the same; a last round that would be more than ~60 % full is run as a round too
+  // (ranges of units run at ~0.6 of the lockstep rate: no operand reuse in L2)
+  bool uniform = g[0].kmode == 0;
+  for (int i = 1; i < n; ++i) uniform = uniform && g[i].kmode == 0 && g[i].K == g[0].K;
+  if (uniform && g_streamk != 3) {
+    a.dp_nk = g[0].K / TK;
+    const int tiles = a.total / a.dp_nk;
+    a.dp_rounds = tiles / grid;
+    if ((tiles % grid) * 10 > grid * 6 || (tiles % grid) * a.dp_nk < 2 * grid) ++a.dp_rounds;      // (... or too short to deal out)
+    if (tiles % grid == 0 && a.dp_rounds > tiles / grid) --a.dp_rounds;
+  }
+  // (ranges only -- no whole-tile round: M != N, or fewer tiles than workgroups -- measured no better than the 128^2 kernels:
+  //  2048 x 4096 1.17 -> 1.23 ms, 2048^2 0.65 -> 0.68: profiles/r04_streamk_ab.txt)
+  if (g_streamk == 1 && a.dp_rounds == 0) return 2;
+  hipLaunchKernelGGL(k_hgemm_sk_256, dim3(grid), dim3(kThreads2), 0, st, a);
+  if (hipGetLastError() != hipSuccess) return 1;
+  if (grid > 1 && (long)a.dp_rounds * grid * a.dp_nk < a.total) {
+    // the cut tiles: walk the tiles and the range boundaries of the stream-K part together (both ascend along the line of units)
+    SkCuts cuts = {};
+    const int dp_units = a.dp_rounds * grid * a.dp_nk;
+    auto start = [&](int q) { return dp_units + (int)((unsigned)(a.total - dp_units) * (unsigned)q / (unsigned)grid); };
+    int prob = 0, r = 0, c = 0, ubase = 0, klo, b = 1;
+    for (;;) {
+      const HGemmArgs& gp = g[prob];
+      const int nk = sk_nk(gp.K, gp.kmode, r, c, klo), end = ubase + nk;
+      while (b < grid && start(b) <= ubase) ++b;                       // boundaries at or before this tile's first unit cut nothing here
+      if (b < grid && start(b) < end) {                                // the first boundary strictly inside this tile
+        const int i = cuts.n++;
+        cuts.b[i] = (unsigned char)b; cuts.prob[i] = (unsigned char)prob; cuts.r[i] = (unsigned char)r; cuts.c[i] = (unsigned char)c;
+        int cnt = 0;
+        while (b < grid && start(b) < end) { ++b; ++cnt; }
+        cuts.cnt[i] = (unsigned char)cnt;
+      }
+      ubase = end;
+      if (!sk_next(gp.M / T2, gp.N / T2, gp.sym != 0, r, c)) {
+        if (++prob >= n) break;
+        r = c = 0;
+      }
+    }
+    if (cuts.n) hipLaunchKernelGGL(k_hgemm_sk_fix, dim3(cuts.n * 32), dim3(kThreads2), 0, st, a, cuts);
+  }
+  return (int)hipGetLastError();
+}
+
 static int launch_hgemm(const uint16_t* A, long lda, const uint16_t* B, long ldb, void* C, long ldc, int c_bf16,
                         int c_trans, int M, int N, int K, int kmode, hipStream_t st, int sym = 0) {
   HGemmArgs g = {A, lda, B, ldb, C, ldc, c_bf16, c_trans, M, N, K, kmode, sym};
@@ -1118,7 +1519,9 @@ struct HUpdWs {
   float *scal, *QlS, *QrS, *X0, *X1, *Bt, *dinv;
   void* inv_ws;             // the solves through explicit inverses (kron_shared.h), null when the route does not apply
   uint16_t *Qlb, *QlTb, *Qrb, *QrTb, *Tt, *W1, *W2, *g1, *g2;
+  float* skp;               // stream-K partial tiles (null when M or N is not a multiple of 256)
   int n64, m64;             // column offset of the A part in W1 (N rounded up to the K tile) / of A' in W2
+  int ld1, ld2;             // row strides of W1 / W2: n64 + N (m64 + M) plus a pad that keeps them off multiples of 4 KiB
   int64_t w1_bytes, w2_bytes, total;
 };
 
@@ -1134,9 +1537,15 @@ static HUpdWs hupd_layout(char* base, int M, int N) {
   k.dinv = takef((int64_t)((M + 31) / 32 + (N + 31) / 32) * 1024);
   k.Qlb = takeh(mm); k.QlTb = takeh(mm); k.Qrb = takeh(nn); k.QrTb = takeh(nn);
   k.Tt = takeh(mn);
-  k.w1_bytes = (int64_t)M * (k.n64 + N) * 2; k.w2_bytes = (int64_t)N * (k.m64 + M) * 2;
+  // (a row stride that is a multiple of 4 KiB puts the rows a DMA instruction touches on few memory channels: +64 elements)
+  static const int pad = getenv("PSGD_SK_PAD") ? atoi(getenv("PSGD_SK_PAD")) : 64;
+  k.ld1 = k.n64 + N; k.ld2 = k.m64 + M;
+  if (k.ld1 % 2048 == 0) k.ld1 += pad;
+  if (k.ld2 % 2048 == 0) k.ld2 += pad;
+  k.w1_bytes = (int64_t)M * k.ld1 * 2; k.w2_bytes = (int64_t)N * k.ld2 * 2;
   k.W1 = takeh(k.w1_bytes / 2); k.W2 = takeh(k.w2_bytes / 2);
   k.g1 = takeh(mm); k.g2 = takeh(nn);
+  k.skp = (M % T2 == 0 && N % T2 == 0) ? takef((int64_t)2 * kSkMaxGrid * 65536) : nullptr;
   const int64_t ib = psgdk::kron_inv_solves_bytes(M, N);       // (a function of the shape)
   k.inv_ws = ib > 0 ? static_cast<void*>(base + off) : nullptr;
   off = align256(off + ib);
@@ -1166,6 +1575,7 @@ int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 0) { g_hgemm_variant = value; return PSGD_OK; }
   if (key == 1) { g_two_pairs = value; return PSGD_OK; }
   if (key == 3) { g_trsm_lite = value; return PSGD_OK; }
+  if (key == 4) { g_streamk = value; return PSGD_OK; }
   if (key == 2) { g_spin_limit = (value < 0 || value > 30) ? (1u << 22) : (1u << value); return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
@@ -1302,7 +1712,7 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   HUpdWs k = hupd_layout(static_cast<char*>(ws), M, N);
   const uint16_t* dGb = static_cast<const uint16_t*>(dG);
-  const int ld1 = k.n64 + N, ld2 = k.m64 + M;
+  const int ld1 = k.ld1, ld2 = k.ld2;
   if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   // the zero columns between the two halves of the concatenated K axis (only when N or M is not a K-tile multiple)
   if (k.n64 != N && hipMemsetAsync(k.W1, 0, (size_t)k.w1_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
@@ -1323,6 +1733,9 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
       HK((int)hipGetLastError());
     }
     // T' [N][M] = (dG QrS')'      A = dG [M][K=N], Bt[n][k] = QrS[n][k], k >= n                      (:173)
+    // (these two run BESIDE the fp32 solves' plane products: a 128-KiB-LDS workgroup only starts on a CU the other chain has left
+    //  entirely and then keeps it for its whole range -- as stream-K launches they took 291 + 340 us instead of 178 + 166 and
+    //  stretched the solves' splits from 70-90 to 180 us: they stay on the 64-KiB one-tile kernel, profiles/r04_streamk_ab.txt)
     HK(launch_hgemm(dGb, N, k.Qrb, N, k.Tt, M, 1, 1, M, N, N, KLO_N, sf));
     // A = QlS T  -> second half of W1     A operand QlS [M][K=M], k >= m; Bt = T'
     HK(launch_hgemm(k.Qlb, M, k.Tt, M, k.W1 + k.n64, ld1, 1, 0, M, N, M, KLO_M, sf));
@@ -1364,11 +1777,13 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   HK(launch_cvt(k.Bt, 0, N, k.W2, ld2, M, N, 1, st));                                 // Bt' -> first half of W2
   // grad1 = triu(A A' - Bt Bt'), grad2 = triu(A'A - Bt'Bt)                                          (:175-176)
   {
-    HGemmArgs g = {k.W1, ld1, k.W1, ld1, k.g1, M, 1, 0, M, M, ld1, 0, 1};
+    HGemmArgs g = {k.W1, ld1, k.W1, ld1, k.g1, M, 1, 0, M, M, k.n64 + N, 0, 1};
     g.epi = HEPI_TRIU_MAX; g.kflip = k.n64 / TK; g.maxout = k.scal + 0;
-    HGemmArgs h = {k.W2, ld2, k.W2, ld2, k.g2, N, 1, 0, N, N, ld2, 0, 1};
+    HGemmArgs h = {k.W2, ld2, k.W2, ld2, k.g2, N, 1, 0, N, N, k.m64 + M, 0, 1};
     h.epi = HEPI_TRIU_MAX; h.kflip = k.m64 / TK; h.maxout = k.scal + 1;
-    HK(launch_hgemm_two(g, h, st));
+    const HGemmArgs two[2] = {g, h};
+    const int rc = launch_hgemm_sk(two, 2, k.skp, st);
+    if (rc == 2) HK(launch_hgemm_two(g, h, st)); else HK(rc);
   }
   // Ql_new = QlS - step / (max|grad1| + tiny) grad1 QlS, same for Qr                                (:177-180)
   {
@@ -1376,6 +1791,7 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     g.epi = HEPI_D_MINUS; g.D = k.QlS; g.ldd = M; g.scale_max = k.scal + 0; g.step = step; g.tiny = tiny;
     HGemmArgs h = {k.g2, N, k.QrTb, N, QrOut, N, 0, 0, N, N, N, KLO_M | KHI_N, 2};
     h.epi = HEPI_D_MINUS; h.D = k.QrS; h.ldd = N; h.scale_max = k.scal + 1; h.step = step; h.tiny = tiny;
+    // (as a stream-K launch: 136 + 70 us against 137 -- short K ranges, nearly every tile cut, a D tile read per epilogue)
     HK(launch_hgemm_two(g, h, st));
   }
   return PSGD_OK;

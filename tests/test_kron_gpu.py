@@ -595,6 +595,48 @@ def test_dense_dense_update_bf16(psgd, M, N):
     assert rel_err(Qr_new.cpu().numpy(), Qr32.cpu().numpy()) < BF16_UPD_STATE_TOL
 
 
+@pytest.mark.parametrize("M,N", [(256, 512), (768, 768), (1024, 256), (1280, 1024), (2304, 2048), (2304, 2304)])
+def test_bf16_update_stream_k_products(psgd, hip_lib, M, N):
+    """The bf16-operand update's gradient products as stream-K launches (k_hgemm_sk_256 + k_hgemm_sk_fix; by default from ~2048 on,
+    here forced for every shape the kernel takes -- mode 2: whole-tile rounds + ranges of K tiles for the rest when M = N, ranges only
+    otherwise; mode 3: ranges only: a few K tiles each, tiles cut several times).  Against the fp64 oracle on the bf16-rounded data;
+    against the one-tile-per-workgroup kernels (same bf16 products, another fp32 summation order); reproducible bit for bit from call
+    to call, also with a second stream keeping the CUs busy (no workgroup waits for another)."""
+    rng = np.random.default_rng(3 * M + N)
+    Ql, Qr = (_tri_factor(rng, M) * 2.0).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    dX = rng.standard_normal((M, N))
+    dXb = torch.from_numpy(dX.astype(np.float32)).cuda().to(torch.bfloat16)
+    dGb = torch.from_numpy((dX * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))).astype(np.float32)).cuda().to(torch.bfloat16)
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    res = {}
+    try:
+        for mode in (0, 3, 2):
+            hip_lib.psgd_kron_bf16_set_tuning(4, mode)
+            res[mode] = psgd.update_precond_kron(_dev(Ql), _dev(Qr), dXb, dGb, 0.01)
+            torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        A = torch.randn(4096, 4096, device="cuda")
+        with torch.cuda.stream(side):
+            for _ in range(10):
+                A = torch.mm(A, A) * 1e-4
+        again = [psgd.update_precond_kron(_dev(Ql), _dev(Qr), dXb, dGb, 0.01) for _ in range(3)]
+        torch.cuda.synchronize()
+    finally:
+        hip_lib.psgd_kron_bf16_set_tuning(4, 1)
+    rl, rr = orc.update_precond_kron(Ql.astype(np.float64), Qr.astype(np.float64), f64(dXb), f64(dGb), 0.01)
+    rho = np.sqrt(np.max(np.abs(Ql.astype(np.float64))) / np.max(np.abs(Qr.astype(np.float64))))
+    for i, (ref, q0) in enumerate(((rl, Ql.astype(np.float64) / rho), (rr, Qr.astype(np.float64) * rho))):
+        for mode in (0, 2, 3):
+            got = f64(res[mode][i])
+            assert rel_err(got, ref) < BF16_UPD_STATE_TOL
+            assert rel_err(got - q0, ref - q0) < BF16_UPD_TOL
+        for mode in (2, 3):
+            assert rel_err(f64(res[mode][i]) - q0, f64(res[0][i]) - q0) < 1e-3   # same bf16 products, fp32 summation order only
+        assert torch.equal(res[2][i], torch.triu(res[2][i]))
+        for f in again:
+            assert torch.equal(f[i], res[2][i])
+
+
 @pytest.mark.parametrize("M,N", [(260, 133), (85, 10), (1027, 515)])
 @pytest.mark.parametrize("scale", [100.0, 0.01])
 def test_bf16_padded_update_with_unbalanced_factors(psgd, M, N, scale):
