@@ -376,7 +376,11 @@ int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
  * key 2: log2 of the hand-off poll bound of the fused pair (default 22 ~ 0.5 s; tests set 0 to provoke time-outs).
  * key 3: bf16-operand update: 1 (default) the trailing products of its two triangular solves keep the three leading
  *        terms of the bf16 x 3 split (h h' + h m' + m h': 2^-16 relative per product, below the bf16 rounding of the
- *        operands); 0 = all six terms. */
+ *        operands); 0 = all six terms.
+ * key 4: bf16-operand update, the two gradient products (psgd.py:175-176): 1 (default) on the 256^2 8-phase loop as whole-tile
+ *        rounds + a stream-K tail finished by a second launch (M = N multiples of 256 with at least one tile per CU: 4096^2
+ *        502 -> 262 us); 0 = the 128^2 one-tile-per-workgroup kernel for every shape; 2 / 3 = the stream-K launches for every
+ *        shape the kernel can take, with / without whole-tile rounds (tests). */
 int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,

@@ -306,7 +306,7 @@ __device__ __forceinline__ void hgemm_nt_body(const HGemmArgs& g, int bid, u32x4
   if (g.epi == HEPI_TRIU_MAX) {     // max |triu(C)| of the whole product: one atomic per wave (values are >= 0: int order)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
-    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+    if (lane == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(g.maxout)) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));      // (looks first: atomics on one address serialise in L2)
   }
   if (g.sym == 2 && n0 > m0 && g.epi == HEPI_D_MINUS) {
     // the tile below the diagonal is not launched: its product is zero, C = D there (M == N, multiples of 8; fp32)
@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void sk_epilogue(const HGemmArgs& g, f32x4 (&acc)[NI]
       }
       if (w != 0) vmax = 0.0f;
     }
-    if (lane == 0 && __float_as_uint(vmax) != 0u) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));
+    if (lane == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(g.maxout)) atomicMax(reinterpret_cast<int*>(g.maxout), __float_as_int(vmax));      // (looks first: atomics on one address serialise in L2)
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -1791,7 +1791,8 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     g.epi = HEPI_D_MINUS; g.D = k.QlS; g.ldd = M; g.scale_max = k.scal + 0; g.step = step; g.tiny = tiny;
     HGemmArgs h = {k.g2, N, k.QrTb, N, QrOut, N, 0, 0, N, N, N, KLO_M | KHI_N, 2};
     h.epi = HEPI_D_MINUS; h.D = k.QrS; h.ldd = N; h.scale_max = k.scal + 1; h.step = step; h.tiny = tiny;
-    // (as a stream-K launch: 136 + 70 us against 137 -- short K ranges, nearly every tile cut, a D tile read per epilogue)
+    // (as a stream-K launch, twice: 136 + 70 and, with the final fix-up launch, 136 + 53 us against 137 -- short K ranges, ~5 pieces per
+    //  workgroup, nearly every tile cut, a D tile read per epilogue)
     HK(launch_hgemm_two(g, h, st));
   }
   return PSGD_OK;
