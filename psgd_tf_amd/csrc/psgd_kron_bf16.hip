@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_sk_fix(SkArgs p, SkCuts cut
 // dst (bf16) = src or src', 64 x 64 tiles through LDS.  SRC_BF16 selects the source element type.
 template <bool SRC_BF16>
 __global__ __launch_bounds__(kThreads) void k_to_bf16(const void* src, long lds_, uint16_t* dst, long ldd, int rows,
-                                                      int cols, int transpose) {
+                                                      int cols, int transpose, uint16_t* dst2 = nullptr, long ldd2 = 0) {
   __shared__ uint16_t tile[64][66];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   for (int e = threadIdx.x; e < 64 * 64; e += kThreads) {
@@ -1212,6 +1212,7 @@ __global__ __launch_bounds__(kThreads) void k_to_bf16(const void* src, long lds_
     } else {
       if (r0 + a < rows && c0 + b < cols) dst[(long)(r0 + a) * ldd + c0 + b] = tile[a][b];
     }
+    if (dst2 && c0 + a < cols && r0 + b < rows) dst2[(long)(c0 + a) * ldd2 + r0 + b] = tile[b][a];      // (+ the transposed copy from the same read)
   }
 }
 
@@ -1490,10 +1491,10 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
 }
 
 static int launch_cvt(const void* src, int src_bf16, long lds_, uint16_t* dst, long ldd, int rows, int cols,
-                      int transpose, hipStream_t st) {
+                      int transpose, hipStream_t st, uint16_t* dstT = nullptr, long lddT = 0) {      // dstT: also the transposed copy (transpose = 0)
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
-  if (src_bf16) hipLaunchKernelGGL((k_to_bf16<true>), grid, dim3(kThreads), 0, st, src, lds_, dst, ldd, rows, cols, transpose);
-  else hipLaunchKernelGGL((k_to_bf16<false>), grid, dim3(kThreads), 0, st, src, lds_, dst, ldd, rows, cols, transpose);
+  if (src_bf16) hipLaunchKernelGGL((k_to_bf16<true>), grid, dim3(kThreads), 0, st, src, lds_, dst, ldd, rows, cols, transpose, dstT, lddT);
+  else hipLaunchKernelGGL((k_to_bf16<false>), grid, dim3(kThreads), 0, st, src, lds_, dst, ldd, rows, cols, transpose, dstT, lddT);
   return (int)hipGetLastError();
 }
 
@@ -1773,8 +1774,7 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     HK(psgdk::kron_trsm_ut(k.QlS, M, k.X1, k.Bt, N, 1L, (long)N, k.dinv + (long)((N + 31) / 32) * 1024, st, g_trsm_lite, true));
     HK(fork_scope.join());
   }
-  HK(launch_cvt(k.Bt, 0, N, k.W1, ld1, M, N, 0, st));                                 // Bt  -> first half of W1
-  HK(launch_cvt(k.Bt, 0, N, k.W2, ld2, M, N, 1, st));                                 // Bt' -> first half of W2
+  HK(launch_cvt(k.Bt, 0, N, k.W1, ld1, M, N, 0, st, k.W2, ld2));                      // Bt -> first half of W1, Bt' -> first half of W2
   // grad1 = triu(A A' - Bt Bt'), grad2 = triu(A'A - Bt'Bt)                                          (:175-176)
   {
     HGemmArgs g = {k.W1, ld1, k.W1, ld1, k.g1, M, 1, 0, M, M, k.n64 + N, 0, 1};
