@@ -10,8 +10,10 @@ namespace psgdk {
 // QlS = Ql * sqrt(max|Qr| / max|Ql|), QrS = Qr / that  (psgd.py:166-170).  0 on success.
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st,
                  float* scal = nullptr,    // scal: 64 scratch words to zero in the same launch (or null)
-                 float* dinv = nullptr);   // dinv: (ceil(N/32) + ceil(M/32)) * 1024 floats: the same launch inverts the 32 x 32
+                 float* dinv = nullptr,    // dinv: (ceil(N/32) + ceil(M/32)) * 1024 floats: the same launch inverts the 32 x 32
                                            // diagonal blocks of QrS (first) and QlS (after them) for kron_trsm_ut(..., inv_ready)
+                 void* inv_ws = nullptr);  // the workspace of kron_inv_solves_*: the launch also does kron_inv_prepare's zeroing and leaves
+                                           // the partial maxima of QlS / QrS there (then kron_inv_solves_front(..., maxima_ready = true))
 
 // Solve y Q = x for nvec vectors (vector i at stride si, element j at stride sj; Q upper triangular [n][n]);
 // dinv: scratch of ceil(n/32) * 1024 floats.  0 on success.
@@ -32,8 +34,9 @@ bool kron_inv_solves_on(int M, int N);
 int kron_inv_prepare(void* ws, int M, int N, hipStream_t main);
 int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
                           float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side,      // (Bt: scratch here)
-                          hipEvent_t l_ready = nullptr);     // l_ready: recorded on `side` behind Ql's inversion (for callers that queue
+                          hipEvent_t l_ready = nullptr,      // l_ready: recorded on `side` behind Ql's inversion (for callers that queue
                                                              // more work on `side` and let `main` wait for this point only)
+                          bool maxima_ready = false);        // kron_balance(..., inv_ws) left the factors' partial maxima: no k_absmax launches
 bool kron_inv_first(int M, int N);                           // the order rule (tuning key 25): both inversions ahead of the products of :173
 int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
 

@@ -3696,14 +3696,19 @@ static BlkSolve inv_solve_problem(const InvSolveWs& k, const float* QlS, const f
 }
 
 int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
-                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side, hipEvent_t l_ready) {
+                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side, hipEvent_t l_ready, bool maxima_ready) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
   int e;
   // column-form planes of the balanced factors (the B operand of T = A^-1 B, and of the blocked solves' trailing updates)
   BlkSolve s = inv_solve_problem(k, QlS, QrS, dinv_r, dinv_l, X0, X1, Bt, M, N);
-  if ((e = launch_absmax(QrS, (long)N * N, s.R.Qc, k.part + 2 * kPmPartMax, main))) return e;
+  if (maxima_ready) {                                  // (the balance launch left one partial maximum per workgroup of its grid)
+    s.R.Qc.part = k.part + 2 * kPmPartMax; s.L.Qc.part = k.part + kPmPartMax;
+    s.R.Qc.npart = s.L.Qc.npart = balance_grid(M, N);
+  } else {
+    if ((e = launch_absmax(QrS, (long)N * N, s.R.Qc, k.part + 2 * kPmPartMax, main))) return e;
+    if ((e = launch_absmax(QlS, (long)M * M, s.L.Qc, k.part + kPmPartMax, side))) return e;
+  }
   if ((e = launch_split3(QrS, 1, N, N, N, s.R.Qc, main))) return e;                    // (x, k) = QrS[k][x]
-  if ((e = launch_absmax(QlS, (long)M * M, s.L.Qc, k.part + kPmPartMax, side))) return e;
   if ((e = launch_split3(QlS, 1, M, M, M, s.L.Qc, side))) return e;
   return blk_solves_front(s, main, side, l_ready);
 }
@@ -3725,10 +3730,15 @@ static int kron_balance_amax(const float* Ql, const float* Qr, int M, int N, flo
   return (int)hipGetLastError();
 }
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal,
-                 float* dinv) {
+                 float* dinv, void* inv_ws) {
   const long tot = (long)M * M + (long)N * N;
   int grid = (int)((tot + kThreads - 1) / kThreads);
   if (grid > 1024) grid = 1024;
+  if (dinv && inv_ws) {
+    const InvSolveWs k = inv_solve_layout(static_cast<char*>(inv_ws), M, N);
+    return kron_balance_amax(Ql, Qr, M, N, QlS, QrS, st, scal, dinv, k.part + kPmPartMax, k.part + 2 * kPmPartMax,
+                             reinterpret_cast<float*>(k.pm), kPmSlots * (int)(sizeof(PlaneMeta) / sizeof(float)));
+  }
   if (dinv) {
     return kron_balance_amax(Ql, Qr, M, N, QlS, QrS, st, scal, dinv, nullptr, nullptr, nullptr, 0);
   } else {

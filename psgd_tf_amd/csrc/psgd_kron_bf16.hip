@@ -1718,9 +1718,9 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   // the zero columns between the two halves of the concatenated K axis (only when N or M is not a K-tile multiple)
   if (k.n64 != N && hipMemsetAsync(k.W1, 0, (size_t)k.w1_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   if (k.m64 != M && hipMemsetAsync(k.W2, 0, (size_t)k.w2_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
-  HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, nullptr, k.dinv));          // :166-170 (+ the solves' inverted diagonal blocks)
   const bool inv_route = k.inv_ws && psgdk::kron_inv_solves_on(M, N);
-  if (inv_route) HK(psgdk::kron_inv_prepare(k.inv_ws, M, N, st));
+  // :166-170 (+ the solves' inverted diagonal blocks; on the inverse route also the zeroed plane metas and the factors' partial maxima)
+  HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, nullptr, k.dinv, inv_route ? k.inv_ws : nullptr));
   // the bf16 products of :173 go to the side stream (kron_shared.h), the fp32 solves of :174 stay on the caller's
   psgdk::KronFork* fk = psgdk::kron_overlap_chains(M, N) ? psgdk::kron_fork(st) : nullptr;
   psgdk::KronForkScope fork_scope(fk, st);   // joins on every exit path, early error returns included
@@ -1759,13 +1759,13 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     // from 4096 on -- ahead of them (kron_inv_first), the products then running beside X1 and Bt.
     const float* dinv_l = k.dinv + (long)((N + 31) / 32) * 1024;
     if (inv_first) {
-      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, fk->mid));
+      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, fk->mid, true));
       { const int rc = products(); if (rc) return rc; }
       if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
       HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
       HK(fork_scope.join());
     } else {
-      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf));
+      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, nullptr, true));
       HK(fork_scope.join());
       HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
     }
