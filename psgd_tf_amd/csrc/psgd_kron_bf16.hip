@@ -1736,7 +1736,10 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     // T' [N][M] = (dG QrS')'      A = dG [M][K=N], Bt[n][k] = QrS[n][k], k >= n                      (:173)
     // (these two run BESIDE the fp32 solves' plane products: a 128-KiB-LDS workgroup only starts on a CU the other chain has left
     //  entirely and then keeps it for its whole range -- as stream-K launches they took 291 + 340 us instead of 178 + 166 and
-    //  stretched the solves' splits from 70-90 to 180 us: they stay on the 64-KiB one-tile kernel, profiles/r04_streamk_ab.txt)
+    //  stretched the solves' splits from 70-90 to 180 us: they stay on the 64-KiB one-tile kernel, profiles/r04_streamk_ab.txt.
+    //  Also measured: the same launches on 64 / 128 / 192 workgroups only, on a third stream from the start of the call -- half
+    //  the CUs stay free for the inversions' launch-bound chains and the solves then run alone: 1.75 / 1.72 / 1.73 ms against
+    //  1.70 -- the chains stretch by what the solves gain, 470 us of inversions instead of 270)
     HK(launch_hgemm(dGb, N, k.Qrb, N, k.Tt, M, 1, 1, M, N, N, KLO_N, sf));
     // A = QlS T  -> second half of W1     A operand QlS [M][K=M], k >= m; Bt = T'
     HK(launch_hgemm(k.Qlb, M, k.Tt, M, k.W1 + k.n64, ld1, 1, 0, M, N, M, KLO_M, sf));
