@@ -36,7 +36,10 @@ int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_
                           float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side,      // (Bt: scratch here)
                           hipEvent_t l_ready = nullptr,      // l_ready: recorded on `side` behind Ql's inversion (for callers that queue
                                                              // more work on `side` and let `main` wait for this point only)
-                          bool maxima_ready = false);        // kron_balance(..., inv_ws) left the factors' partial maxima: no k_absmax launches
+                          bool maxima_ready = false,         // kron_balance(..., inv_ws) left the factors' partial maxima: no k_absmax launches
+                          int x0_parts = 0);                 // > 0: kron_inv_part(ws)[0 .. x0_parts) hold the partial maxima of |X0| already
+float* kron_inv_part(void* ws, int M, int N);                // the array for X0's partial maxima (kron_inv_part_max() floats)
+int kron_inv_part_max();
 bool kron_inv_first(int M, int N);                           // the order rule (tuning key 25): both inversions ahead of the products of :173
 int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
 

@@ -3578,7 +3578,7 @@ enum { kPmPieceX = kPmStrip, kPmPieceW = kPmStrip + 8, kPmPieceV = kPmStrip + 16
 static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hipEvent_t l_ready = nullptr) {
   const int M = s.M, N = s.N, h = s.h;
   int e;
-  if ((e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, main))) return e;
+  if (!s.X0p.part && (e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, main))) return e;      // (unless the caller has the maxima)
   if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, main))) return e;
   if ((e = tri_inverse_pair(s.R, main, s.L, side, h))) return e;
   if (l_ready && hipEventRecord(l_ready, side) != hipSuccess) return 1;
@@ -3696,7 +3696,8 @@ static BlkSolve inv_solve_problem(const InvSolveWs& k, const float* QlS, const f
 }
 
 int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
-                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side, hipEvent_t l_ready, bool maxima_ready) {
+                          float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side, hipEvent_t l_ready, bool maxima_ready,
+                          int x0_parts) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
   int e;
   // column-form planes of the balanced factors (the B operand of T = A^-1 B, and of the blocked solves' trailing updates)
@@ -3710,8 +3711,12 @@ int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_
   }
   if ((e = launch_split3(QrS, 1, N, N, N, s.R.Qc, main))) return e;                    // (x, k) = QrS[k][x]
   if ((e = launch_split3(QlS, 1, M, M, M, s.L.Qc, side))) return e;
+  if (x0_parts > 0) { s.X0p.part = k.part; s.X0p.npart = x0_parts; }
   return blk_solves_front(s, main, side, l_ready);
 }
+
+float* kron_inv_part(void* ws, int M, int N) { return inv_solve_layout(static_cast<char*>(ws), M, N).part; }
+int kron_inv_part_max() { return kPmPartMax; }
 
 int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);

@@ -1499,7 +1499,12 @@ static int launch_cvt(const void* src, int src_bf16, long lds_, uint16_t* dst, l
 }
 
 // dst (fp32) = src (bf16), contiguous; n multiple of 8
-__global__ __launch_bounds__(kThreads) void k_bf16_to_f32(const uint16_t* __restrict__ src, float* __restrict__ dst, long n8) {
+// part (or null): block b leaves max|x| of what it converted in part[b] (NaN propagates) -- the partial maxima the split launch of the
+// inverse-route solves wants (psgd_kron.hip k_absmax), without a second pass over the fp32 copy
+__global__ __launch_bounds__(kThreads) void k_bf16_to_f32(const uint16_t* __restrict__ src, float* __restrict__ dst, long n8,
+                                                          float* __restrict__ part) {
+  __shared__ float red[kThreads / 64];
+  float m = 0.0f;
   for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n8; i += (long)gridDim.x * kThreads) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 8);
     f32x4 lo, hi;
@@ -1510,6 +1515,17 @@ __global__ __launch_bounds__(kThreads) void k_bf16_to_f32(const uint16_t* __rest
     }
     *reinterpret_cast<f32x4*>(dst + i * 8) = lo;
     *reinterpret_cast<f32x4*>(dst + i * 8 + 4) = hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = amaxf(amaxf(m, fabsf(lo[e])), fabsf(hi[e]));
+  }
+  if (!part) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / 64; ++w) m = amaxf(m, red[w]);
+    part[blockIdx.x] = m;
   }
 }
 
@@ -1749,12 +1765,16 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   const bool inv_first = inv_route && fk && psgdk::kron_inv_first(M, N);
   if (!inv_first) { const int rc = products(); if (rc) return rc; }
   // Bt = QlS^-T dX QrS^-1 in fp32                                                                   (:174)
+  int x0_parts = 0;
   {
     const long n8 = (long)M * N / 8;
     int grid = (int)((n8 + kThreads - 1) / kThreads);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_bf16_to_f32, dim3(grid), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dX), k.X0, n8);
+    x0_parts = inv_route ? psgdk::kron_inv_part_max() : 0;            // (the inverse route: dX's partial maxima from this launch)
+    if (grid > (x0_parts ? x0_parts : 4096)) grid = x0_parts ? x0_parts : 4096;
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(grid), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dX), k.X0, n8,
+                       x0_parts ? psgdk::kron_inv_part(k.inv_ws, M, N) : static_cast<float*>(nullptr));
     HK((int)hipGetLastError());
+    if (x0_parts) x0_parts = grid;
   }
   if (inv_route) {
     // factors from 2048 on: the solves as products with the inverses of the diagonal 2048-blocks (fp32-accurate f16 x 2 plane
@@ -1762,13 +1782,13 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     // from 4096 on -- ahead of them (kron_inv_first), the products then running beside X1 and Bt.
     const float* dinv_l = k.dinv + (long)((N + 31) / 32) * 1024;
     if (inv_first) {
-      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, fk->mid, true));
+      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, fk->mid, true, x0_parts));
       { const int rc = products(); if (rc) return rc; }
       if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
       HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
       HK(fork_scope.join());
     } else {
-      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, nullptr, true));
+      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, nullptr, true, x0_parts));
       HK(fork_scope.join());
       HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
     }
