@@ -1352,6 +1352,7 @@ static int g_streamk = 1;         // psgd_kron_bf16_set_tuning key 4: 0 = the up
                                   // 2 = stream-K for every shape the kernel can take (tests), 3 = 2 without whole-tile rounds
 static bool sk_legal(const HGemmArgs& g) {
   if (g.M <= 0 || g.N <= 0 || (g.M % T2) || (g.N % T2) || (g.K % TK) || (g.lda % 8) || (g.ldb % 8)) return false;
+  if (g.M / T2 > 255 || g.N / T2 > 255) return false;          // (SkCuts names tiles in bytes)
   if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) return false;
   if (g.sym && g.M != g.N) return false;
   if (g.kflip && g.kmode) return false;
@@ -1562,7 +1563,14 @@ static HUpdWs hupd_layout(char* base, int M, int N) {
   k.w1_bytes = (int64_t)M * k.ld1 * 2; k.w2_bytes = (int64_t)N * k.ld2 * 2;
   k.W1 = takeh(k.w1_bytes / 2); k.W2 = takeh(k.w2_bytes / 2);
   k.g1 = takeh(mm); k.g2 = takeh(nn);
-  k.skp = (M % T2 == 0 && N % T2 == 0) ? takef((int64_t)2 * kSkMaxGrid * 65536) : nullptr;
+  k.skp = nullptr;
+  if (M % T2 == 0 && N % T2 == 0) {
+    // two partial-tile slots per workgroup of the gradient launch: at most kSkMaxGrid workgroups, never more than half its units
+    const int64_t tm = M / T2, tn = N / T2;
+    const int64_t units = tm * (tm + 1) / 2 * ((k.n64 + N) / TK) + tn * (tn + 1) / 2 * ((k.m64 + M) / TK);
+    const int64_t g = units / 2 < kSkMaxGrid ? (units / 2 > 0 ? units / 2 : 1) : kSkMaxGrid;
+    k.skp = takef(2 * g * 65536);
+  }
   const int64_t ib = psgdk::kron_inv_solves_bytes(M, N);       // (a function of the shape)
   k.inv_ws = ib > 0 ? static_cast<void*>(base + off) : nullptr;
   off = align256(off + ib);
