@@ -1,0 +1,46 @@
+// Micro bench of the f16 x 2 plane product kernel (k_gemm_p3): time against the number of K steps at fixed output size -> per-launch
+// fixed cost and per-step cost (round 4).
+// build (repo root): hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Ipsgd_tf_amd/csrc tools/micro/p3_bench.hip -Lpsgd_tf_amd/csrc -lpsgd_hip -Wl,-rpath,'$ORIGIN/../../psgd_tf_amd/csrc' -o tools/micro/p3_bench
+#include "../../psgd_tf_amd/csrc/psgd_kron.hip"
+#include <cstdio>
+#include <vector>
+#include <functional>
+static float time_us(hipStream_t st, int reps, const std::function<void()>& f) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  f(); hipStreamSynchronize(st);
+  hipEventRecord(e0, st);
+  for (int i = 0; i < reps; ++i) f();
+  hipEventRecord(e1, st);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps * 1e3f;
+}
+int main() {
+  const long cap = 4096L * 4096 * 2;               // two planes of a 4096 x 4096 operand
+  std::vector<uint16_t> h(cap);
+  unsigned s = 1;
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3000 + ((s >> 16) & 0x7ff)); }   // f16 in [0.125, 0.5)
+  __bf16 *A, *B; float* C; PlaneMeta* meta;
+  hipMalloc(&A, cap * 2); hipMalloc(&B, cap * 2); hipMalloc(&C, 4096L * 4096 * 4); hipMalloc(&meta, 4 * sizeof(PlaneMeta));
+  hipMemcpy(A, h.data(), cap * 2, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), cap * 2, hipMemcpyHostToDevice);
+  PlaneMeta pm[4] = {{1.f, 1.f, 0.5f, 0.5f}, {1.f, 1.f, 0.5f, 0.5f}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  hipMemcpy(meta, pm, sizeof(pm), hipMemcpyHostToDevice);
+  hipStream_t st; hipStreamCreate(&st);
+  struct Case { int M, N, K, kmode; const char* what; };
+  const Case cases[] = {{4096, 4096, 32, 0, "1024 tiles"}, {4096, 4096, 256, 0, ""}, {4096, 4096, 1024, 0, ""}, {4096, 4096, 2048, 0, ""},
+                        {4096, 4096, 4096, 0, ""}, {4096, 2048, 32, 0, "512 tiles"}, {4096, 2048, 512, 0, ""}, {4096, 2048, 2048, 0, ""},
+                        {4096, 2048, 2048, KHI_N, "512 tiles, K <= n0 + 127 (a solve's diagonal product)"},
+                        {1024, 1024, 32, 0, "64 tiles"}, {1024, 1024, 512, 0, ""}, {2048, 2048, 32, 0, "256 tiles"}, {2048, 2048, 1024, 0, ""}};
+  for (const Case& c : cases) {
+    P3Buf a = {A, pad128(c.M), (long)((c.K + 31) / 32 * 32), meta}, b = {B, pad128(c.N), (long)((c.K + 31) / 32 * 32), meta + 1};
+    P3Args g = p3_args(a, b, c.M, c.N, c.K, c.kmode);
+    g.e.C = C; g.e.ldc = c.N; g.ometa = meta + 2;
+    const float us = time_us(st, 20, [&] { launch_p3(g, st); });
+    printf("%4d x %4d x %4d kmode %d: %7.1f us  (%d K steps) %s\n", c.M, c.N, c.K, c.kmode, us, c.K / 32, c.what);
+  }
+  // an empty kernel on the same stream, back to back: the launch floor
+  const float e = time_us(st, 50, [&] { hipLaunchKernelGGL(k_absmax, dim3(1), dim3(kThreads), 0, st, C, 0L, 1L, 4L, C + 1024, (float*)nullptr, 0); });
+  printf("one-block kernel, back to back: %.1f us\n", e);
+  return 0;
+}
