@@ -70,18 +70,29 @@ def fuzz_kron_bf16_update(g, it):
         M, N = 64 * int(torch.randint(8, 40, (1,), generator=g, device=dev)), 64 * int(torch.randint(8, 40, (1,), generator=g, device=dev))
     if it % 30 == 29:                                 # the fp32 solves through explicit inverses
         M, N = 64 * int(torch.randint(32, 44, (1,), generator=g, device=dev)), 64 * int(torch.randint(33, 44, (1,), generator=g, device=dev))
+    sk = 0
+    if it % 4 == 1:                                   # the gradient products as stream-K launches on shapes their default rule skips
+        M = 256 * int(torch.randint(1, 10, (1,), generator=g, device=dev))
+        N = M if it % 8 == 1 else 256 * int(torch.randint(1, 10, (1,), generator=g, device=dev))
+        sk = 2 + (it // 4) % 2                        # 2: whole-tile rounds + ranges, 3: ranges only
     off = 0.5 / max(M, N) ** 0.5
     Ql, Qr = tri(M, g, off) * 1.7, tri(N, g, off)
     dX = torch.randn(M, N, device=dev, generator=g)
     dG = torch.exp(torch.empty(M, 1, device=dev).uniform_(-1, 1, generator=g)) * dX * torch.exp(torch.empty(1, N, device=dev).uniform_(-1, 1, generator=g))
     dX, dG = dX.to(torch.bfloat16), dG.to(torch.bfloat16)
-    a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    if sk:
+        _lib.load().psgd_kron_bf16_set_tuning(4, sk)
+    try:
+        a, b = psgd.update_precond_kron(Ql, Qr, dX, dG, 0.01)
+    finally:
+        if sk:
+            _lib.load().psgd_kron_bf16_set_tuning(4, 1)
     a64, b64 = ref64.update_precond_dense_dense(Ql.double(), Qr.double(), dX.double(), dG.double(), 0.01, TINY)
     # the stated bf16 bar (2e-2) applies to the increment the bf16 GEMMs produce; on the factors it is step (0.01) times that
     rho = (torch.diagonal(Ql).max() / torch.diagonal(Qr).max()).double().sqrt()
     e_inc = max(rel(a.double() - Ql.double() / rho, a64 - Ql.double() / rho), rel(b.double() - Qr.double() * rho, b64 - Qr.double() * rho))
     e_fac = max(rel(a, a64), rel(b, b64))
-    return "kron-bf16-upd %dx%d" % (M, N), max(e_inc, 100.0 * e_fac), 2e-2
+    return "kron-bf16-upd %dx%d%s" % (M, N, " sk%d" % sk if sk else ""), max(e_inc, 100.0 * e_fac), 2e-2
 
 
 _SPARSE_KINDS = (("dense", "norm"), ("dense", "scale"), ("norm", "dense"), ("norm", "scale"), ("scale", "dense"), ("scale", "norm"))
