@@ -284,7 +284,8 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * 21 [0] small layers (M <= 512, N <= 256) on the stage kernels, 1 = fused strip kernels of psgd_kron_small.hip (opt-in, slower)
  * 23 [1] 512-blocks of an inverse from one strip launch (k_tri_inv512), 0 = k_tri_inv128 + doubling levels 128, 256
  * 24 [2048] block size h of the blocked solves on inverses of diagonal h-blocks, 0 = whole inverses, one product per solve
- * 25 [-1] stream order of the inverse route: by shape (both inversions first from 4096^2 on), 0 / 1 = products / inversions first */
+ * 25 [-1] stream order of the inverse route: by shape (both inversions first from 4096^2 on), 0 / 1 = products / inversions first
+ * 27 [1] the factor updates (:179) of the large update walk their tiles in 4 x 4 patches per XCD (from 32 x 32 tiles on), 0 = whole tile rows */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.
@@ -380,7 +381,8 @@ int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
  * key 4: bf16-operand update, the two gradient products (psgd.py:175-176): 1 (default) on the 256^2 8-phase loop as whole-tile
  *        rounds + a stream-K tail finished by a second launch (M = N multiples of 256 with at least one tile per CU: 4096^2
  *        502 -> 262 us); 0 = the 128^2 one-tile-per-workgroup kernel for every shape; 2 / 3 = the stream-K launches for every
- *        shape the kernel can take, with / without whole-tile rounds (tests). */
+ *        shape the kernel can take, with / without whole-tile rounds (tests).
+ * key 5: bf16-operand update, the factor updates (:179): 1 (default) tiles in 4 x 4 patches per XCD, 0 = whole tile rows. */
 int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,

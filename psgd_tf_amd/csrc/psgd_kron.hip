@@ -63,7 +63,8 @@ struct GemmArgs {
 
 // KBLK_HI_M: k < start of the second half of the kblk-block that holds row m0;  KBLK_LO_N: k >= start of the second half
 // of the kblk-block that holds column n0  (the two products of one doubling level of a triangular inverse, see tri_inverse)
-enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8, KBLK_HI_M = 16, KBLK_LO_N = 32 };
+enum { KLO_M = 1, KHI_M = 2, KLO_N = 4, KHI_N = 8, KBLK_HI_M = 16, KBLK_LO_N = 32,
+       KORD_PATCH = 64 };      // (not a K range: the tile order of gemm_tile_from_id's case 3)
 
 // ---------------------------------------------------------------------------------------------
 // fp32 GEMM on the matrix cores, one template for two square tile sizes T (64 for small problems
@@ -176,6 +177,50 @@ struct GemmLds {
 //     column-dependent work walks the grid column-major (dG Qr' at 4096^2: 823 -> 485 us).
 __device__ __forceinline__ void gemm_tile_from_id(int id, int ty, int tx, int kmode, int& by, int& bx) {
   const int nt = ty * tx;
+  if ((kmode & KORD_PATCH) && (kmode & (KLO_M | KHI_N)) == (KLO_M | KHI_N) && ty == tx && ty % 4 == 0 && ty >= 32) {
+    // (3') the same product in 4 x 4 tile PATCHES (tuning key 27).  Row order shares a row's A panel in the XCD's L2 but every
+    // tile reads a B panel of its own: 30 % L2 hits on the 4096^2 factor updates, and the launch is bound by its longest tile's
+    // chain of K steps, each a load that misses (profiles/r04_p3_update_pmc.txt).  The tiles of a patch share four A and four B
+    // panels at K offsets a few steps apart.  Upper tiles first: the patches by decreasing distance from the diagonal (= work),
+    // the tiles of a patch by decreasing K length; that list is dealt to the XCDs in runs of 16 tiles, serpentine per round of
+    // 128 (within 6 % of the mean work at 32 x 32 tiles, 3 % at 48 x 48); then the tiles below the diagonal (copies of D).
+    const int T = ty, P = T >> 2, ntu = T * (T + 1) / 2;
+    if (id >= ntu) {
+      const int q = id - ntu;                                                     // q-th tile below the diagonal, row by row
+      int r = (int)((1.0f + sqrtf(1.0f + 8.0f * q)) * 0.5f);
+      while (r * (r - 1) / 2 > q) --r;
+      while ((r + 1) * r / 2 <= q) ++r;
+      by = r; bx = q - r * (r - 1) / 2;
+      return;
+    }
+    const int full = ntu & ~127, x = id & 7, j = id >> 3;
+    int pos;
+    if (j < (full >> 3)) {
+      const int m = j >> 4, xx = (m & 1) ? 7 - x : x;
+      pos = m * 128 + 16 * xx + (j & 15);
+    } else {
+      pos = id;                                                                   // (the last ntu % 128 tiles: one by one)
+    }
+    const int noff = 16 * (P * (P - 1) / 2);                                      // tiles of the patches off the diagonal
+    // (r', c') of a patch's tiles by decreasing c' - r': (0,3) (0,2) (1,3) (0,1) (1,2) (2,3) (0,0) (1,1) (2,2) (3,3), then the six below
+    const unsigned long long ord = 0xcd8e94fa50b61723ULL;                         // nibble t = (r' << 2) | c' of the t-th tile
+    int pr, pc, t;
+    if (pos < noff) {
+      const int sidx = pos >> 4;
+      t = pos & 15;
+      int k = (int)((sqrtf(8.0f * sidx + 1.0f) - 1.0f) * 0.5f);                   // diagonal P - 1 - k: k (k + 1) / 2 patches before it
+      while (k * (k + 1) / 2 > sidx) --k;
+      while ((k + 1) * (k + 2) / 2 <= sidx) ++k;
+      const int d = P - 1 - k;
+      pr = sidx - k * (k + 1) / 2; pc = pr + d;
+    } else {
+      const int u = pos - noff;
+      pr = pc = u / 10; t = u % 10;
+    }
+    const int nib = (int)((ord >> (4 * t)) & 15ULL);
+    by = 4 * pr + (nib >> 2); bx = 4 * pc + (nib & 3);
+    return;
+  }
   if ((kmode & (KLO_M | KHI_N)) == (KLO_M | KHI_N) && !(kmode & (KLO_N | KHI_M)) && ty == tx && ty % 16 == 0) {
     // (3) K = [m0, n0 + T): a tile's work is its distance from the diagonal (the two factor updates, psgd.py:179).  8 x 8
     // patches give the XCD that owns the top-right corner 2.1x the mean work (1600 of 5984 K chunks at 32 x 32 tiles, and
@@ -3398,6 +3443,8 @@ static int planes_update_front(const float* dG, int M, int N, const KronWs& k, h
   return p3_chain(s1, k.A, &Ar, &Ac, nullptr, k.sk_scratch, k.sk_cnt, st);
 }
 
+static int g_pair_order = 1;    // tuning key 27: 1 (default) = the factor updates' tiles in 4 x 4 patches (gemm_tile_from_id case 3': 4096^2 update
+                                // 2.54 -> 2.48 ms, the launch 251 -> 183 us; 6144^2 7.10 -> 6.91; bit-identical results), 0 = whole tile rows per XCD
 static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float step, float tiny, const KronWs& k, hipStream_t st,
                               PlaneMeta* pm, bool bt_planes_ready = false) {
   const long Mp = pad128(M), Np = pad128(N);
@@ -3434,10 +3481,11 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
     p3_out_row(s3, G2);
     if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st))) return e;
   }
-  P3Args s4 = p3_args(G1, Lc, M, M, M, KLO_M | KHI_N);          // QlS - (step1 grad1) QlS  (:179); (n, k) view of QlS = QlS'
+  const int pord = g_pair_order ? KORD_PATCH : 0;
+  P3Args s4 = p3_args(G1, Lc, M, M, M, KLO_M | KHI_N | pord);   // QlS - (step1 grad1) QlS  (:179); (n, k) view of QlS = QlS'
   s4.e.epi = EPI_D_MINUS; s4.e.C = QlOut; s4.e.ldc = M; s4.e.D = k.QlS; s4.e.ldd = M;
   s4.e.scale_max = k.scal + 0; s4.e.step = step; s4.e.tiny = tiny;
-  P3Args s5 = p3_args(G2, Rc, N, N, N, KLO_M | KHI_N);
+  P3Args s5 = p3_args(G2, Rc, N, N, N, KLO_M | KHI_N | pord);
   s5.e.epi = EPI_D_MINUS; s5.e.C = QrOut; s5.e.ldc = N; s5.e.D = k.QrS; s5.e.ldd = N;
   s5.e.scale_max = k.scal + 1; s5.e.step = step; s5.e.tiny = tiny;
   return launch_p3_two(s4, s5, st);
@@ -3845,6 +3893,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 23) { g_inv_strip512 = value; return PSGD_OK; }
   if (key == 24) { g_inv_blk = value; return PSGD_OK; }
   if (key == 25) { g_inv_order = value; return PSGD_OK; }
+  if (key == 27) { g_pair_order = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

@@ -61,8 +61,10 @@ struct HGemmArgs {
   float* maxout;
   const float* D; long ldd;
   const float* scale_max; float step, tiny;
+  int patch_order;                  // sym == 2: the tiles in 4 x 4 patches (tuning key 5)
 };
 enum { HEPI_STORE = 0, HEPI_TRIU_MAX = 1, HEPI_D_MINUS = 2 };
+__device__ __forceinline__ bool g_pair_patch_dev(const HGemmArgs& g) { return g.patch_order != 0; }
 
 __device__ __forceinline__ uint16_t f2bf(float x) {
   // round-to-nearest-even; NaN stays NaN through the hardware conversion of a plain cast
@@ -87,7 +89,32 @@ __device__ __forceinline__ void hgemm_tile_coords(const HGemmArgs& g, int bid, i
     // within 8 % equal K chunks per XCD, the A panel of a row shared in that XCD's L2.  (8 x 8 patches in launch order
     // put whole far-from-diagonal patches on one XCD: 2.1x imbalance, 150 us for 23 GFLOP at 4096.)
     const int T = tiles_m;
-    if (T % 16 == 0) {
+    if (g_pair_patch_dev(g) && T % 4 == 0 && T >= 32) {
+      // 4 x 4 tile patches (psgd_kron.hip gemm_tile_from_id case 3'): the patches by decreasing distance from the diagonal, the tiles
+      // of a patch by decreasing K length, dealt to the XCDs in runs of 16, serpentine per round of 128
+      const int P = T >> 2, ntu = T * (T + 1) / 2, full = ntu & ~127, x = bid & 7, j = bid >> 3;
+      int pos = bid;
+      if (j < (full >> 3)) {
+        const int m = j >> 4, xx = (m & 1) ? 7 - x : x;
+        pos = m * 128 + 16 * xx + (j & 15);
+      }
+      const int noff = 16 * (P * (P - 1) / 2);
+      const unsigned long long ord = 0xcd8e94fa50b61723ULL;      // nibble t = (r' << 2) | c' of a patch's t-th tile
+      int pr, pc, t;
+      if (pos < noff) {
+        const int sidx = pos >> 4;
+        t = pos & 15;
+        int kk = (int)((sqrtf(8.0f * sidx + 1.0f) - 1.0f) * 0.5f);
+        while (kk * (kk + 1) / 2 > sidx) --kk;
+        while ((kk + 1) * (kk + 2) / 2 <= sidx) ++kk;
+        pr = sidx - kk * (kk + 1) / 2; pc = pr + (P - 1 - kk);
+      } else {
+        const int u = pos - noff;
+        pr = pc = u / 10; t = u % 10;
+      }
+      const int nib = (int)((ord >> (4 * t)) & 15ULL);
+      trow = 4 * pr + (nib >> 2); tcol = 4 * pc + (nib & 3);
+    } else if (T % 16 == 0) {
       const int x = bid & 7;
       int j = bid >> 3;
       trow = 0; tcol = 0;
@@ -1348,6 +1375,8 @@ static int launch_hgemm_two(const HGemmArgs& g0, const HGemmArgs& g1, hipStream_
 
 static int device_cu_count();
 // ---- stream-K launches (k_hgemm_sk_256) ---------------------------------------------------------------------------------
+static int g_pair_patch = 1;      // psgd_kron_bf16_set_tuning key 5: 1 (default) = the factor updates' tiles in 4 x 4 patches (hgemm_tile_coords,
+                                  // sym == 2; from 32 x 32 tiles of 128 on: 4096^2 update 1.716 -> 1.698 ms, equal elsewhere), 0 = tile rows
 static int g_streamk = 1;         // psgd_kron_bf16_set_tuning key 4: 0 = the update's products stay on the 128^2 register-staged kernel,
                                   // 2 = stream-K for every shape the kernel can take (tests), 3 = 2 without whole-tile rounds
 static bool sk_legal(const HGemmArgs& g) {
@@ -1601,6 +1630,7 @@ int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 1) { g_two_pairs = value; return PSGD_OK; }
   if (key == 3) { g_trsm_lite = value; return PSGD_OK; }
   if (key == 4) { g_streamk = value; return PSGD_OK; }
+  if (key == 5) { g_pair_patch = value; return PSGD_OK; }
   if (key == 2) { g_spin_limit = (value < 0 || value > 30) ? (1u << 22) : (1u << value); return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
@@ -1822,6 +1852,7 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     g.epi = HEPI_D_MINUS; g.D = k.QlS; g.ldd = M; g.scale_max = k.scal + 0; g.step = step; g.tiny = tiny;
     HGemmArgs h = {k.g2, N, k.QrTb, N, QrOut, N, 0, 0, N, N, N, KLO_M | KHI_N, 2};
     h.epi = HEPI_D_MINUS; h.D = k.QrS; h.ldd = N; h.scale_max = k.scal + 1; h.step = step; h.tiny = tiny;
+    g.patch_order = h.patch_order = g_pair_patch;
     // (as a stream-K launch, twice: 136 + 70 and, with the final fix-up launch, 136 + 53 us against 137 -- short K ranges, ~5 pieces per
     //  workgroup, nearly every tile cut, a D tile read per epilogue)
     HK(launch_hgemm_two(g, h, st));
