@@ -1295,19 +1295,18 @@ struct SplitOpt { int tri, blk, off, neg; };
 // other stream (232 registers, two workgroups per CU = 464 of a SIMD's 512): at 54 registers a split workgroup could not join a CU
 // until one of the product's workgroups had finished its whole K loop, and a 15-us split took 105-160 us (profiles/r04_kron_update_trace_f32.txt).
 template <int FMT>
-__global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
-                                                     __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
-                                                     long tts, long tps, PlaneMeta* meta, const float* __restrict__ part,
-                                                     int npart, SplitOpt opt) {
-  __shared__ float S[64][65];
-  int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+__device__ __forceinline__ void split3_body(const float* __restrict__ X, long rs, long cs, int R, int C,
+                                            __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
+                                            long tts, long tps, PlaneMeta* meta, const float* __restrict__ part,
+                                            int npart, SplitOpt opt, int bx, int by, int bz, float (*S)[65]) {
+  int r0 = by * 64, c0 = bx * 64;
   const int tid = threadIdx.x;
   if (opt.blk) {
     // a COMPACT grid: x, y run over the 64-tiles of one blk x blk diagonal block (off: of its first-half x second-half quarter),
     // z over the blocks -- with one workgroup per tile of the whole matrix (n = 4096, blk = 512: 4096 workgroups, 7/8 of which
     // return at once) this launch took 157 us instead of 16 beside a full-chip product: every workgroup queues for a slot
-    r0 += blockIdx.z * opt.blk;
-    c0 += blockIdx.z * opt.blk + (opt.off ? opt.blk / 2 : 0);
+    r0 += bz * opt.blk;
+    c0 += bz * opt.blk + (opt.off ? opt.blk / 2 : 0);
     const long xp = P ? ts / 32 : tps / (tts / 32), kp = P ? ps / (ts / 32) : tts / 32;     // padded extents of the view (x = r, k = c)
     if (r0 >= xp || c0 >= kp) return;                            // (the last block of a ragged matrix)
   }
@@ -1340,7 +1339,10 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
   };
   // (clamped addresses, every load of a half issued before its first use: a guarded load compiles to load-then-wait.  Two halves of
   //  eight loads, not sixteen at once: the kernel has to stay within 48 registers -- see the launch bounds)
-  if (cs == 1 || rs != 1) {
+  const bool masked = (opt.tri == 1 && c0 + 63 < r0) || (opt.tri == 2 && c0 > r0 + 63);      // nothing of this tile is kept: zeros, no loads
+  if (masked) {
+    for (int e = tid; e < 64 * 64; e += kThreads) S[e >> 6][e & 63] = 0.0f;
+  } else if (cs == 1 || rs != 1) {
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       float x[8];
@@ -1394,6 +1396,26 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
         *reinterpret_cast<uint2*>(Pt + pl * tps + p3_index(tts, c0 + c, r0 + r)) = make_uint2(q0[pl], q1[pl]);
     }
   }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
+                                                     __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
+                                                     long tts, long tps, PlaneMeta* meta, const float* __restrict__ part,
+                                                     int npart, SplitOpt opt) {
+  __shared__ float S[64][65];
+  split3_body<FMT>(X, rs, cs, R, C, P, ts, ps, Pt, tts, tps, meta, part, npart, opt, blockIdx.x, blockIdx.y, blockIdx.z, S);
+}
+// two independent splits in one launch (the two gradients of the large update): job 0 on the rows y < y0 of the grid, job 1 behind
+struct SplitJob { const float* X; long rs, cs; int R, C; __bf16* P; long ts, ps; PlaneMeta* meta; const float* part; int npart; SplitOpt opt; int gx; };
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void k_split3_two(SplitJob a, SplitJob b, int y0) {
+  __shared__ float S[64][65];
+  const bool second = (int)blockIdx.y >= y0;
+  const SplitJob j = second ? b : a;
+  if ((int)blockIdx.x >= j.gx) return;
+  split3_body<FMT>(j.X, j.rs, j.cs, j.R, j.C, j.P, j.ts, j.ps, (__bf16*)nullptr, 0L, 0L, j.meta, j.part, j.npart, j.opt, blockIdx.x,
+                   second ? blockIdx.y - y0 : blockIdx.y, 0, S);
 }
 
 // The inverse of every 128 x 128 diagonal block of an upper-triangular Q [n x n] from its inverted 32 x 32 diagonal blocks
@@ -3032,6 +3054,16 @@ static int launch_split3(const float* X, long rs, long cs, int R, int C, const P
   return (int)hipGetLastError();
 }
 // planes of the view (out) and of its transpose (outT: rows/ld swapped) from one read
+// two row-major matrices [Ra x Ca] (row stride Ca) and [Rb x Cb], f16 x 2 row-form planes each, in ONE launch
+static int launch_split3_two(const float* Xa, int Ra, int Ca, const P3Buf& oa, const float* Xb, int Rb, int Cb, const P3Buf& ob,
+                             hipStream_t st, SplitOpt opt) {
+  if (!oa.meta || !ob.meta || opt.blk) return 1;
+  const dim3 ga = split_grid(oa.rows, oa.ld, opt), gb = split_grid(ob.rows, ob.ld, opt);
+  SplitJob a = {Xa, (long)Ca, 1L, Ra, Ca, oa.p, oa.rows * 32, oa.rows * oa.ld, oa.meta, oa.part, oa.npart, opt, (int)ga.x};
+  SplitJob b = {Xb, (long)Cb, 1L, Rb, Cb, ob.p, ob.rows * 32, ob.rows * ob.ld, ob.meta, ob.part, ob.npart, opt, (int)gb.x};
+  hipLaunchKernelGGL(k_split3_two<1>, dim3(ga.x > gb.x ? ga.x : gb.x, ga.y + gb.y), dim3(kThreads), 0, st, a, b, (int)ga.y);
+  return (int)hipGetLastError();
+}
 static int launch_split3_both(const float* X, long rs, long cs, int R, int C, const P3Buf& out, const P3Buf& outT, hipStream_t st,
                               SplitOpt opt = SplitOpt{0, 0, 0, 0}) {
   const dim3 grid = split_grid(out.rows, out.ld, opt);
@@ -3474,8 +3506,7 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
     g1p.part = k.scal + 0; g2p.part = k.scal + 1; g1p.npart = g2p.npart = 1;
     // (tri: the gradient grid wrote the upper tiles only; what lies below the diagonal in k.g1 / k.g2 is whatever the workspace
     //  held -- on the inverse route the fp32 inverses -- and becomes defined zeros in the planes)
-    if ((e = launch_split3(k.g1, M, 1, M, M, g1p, st, SplitOpt{1, 0, 0, 0}))) return e;
-    if ((e = launch_split3(k.g2, N, 1, N, N, g2p, st, SplitOpt{1, 0, 0, 0}))) return e;
+    if ((e = launch_split3_two(k.g1, M, M, g1p, k.g2, N, N, g2p, st, SplitOpt{1, 0, 0, 0}))) return e;      // (one launch for both)
   } else {
     p3_out_row(s2, G1);
     p3_out_row(s3, G2);
