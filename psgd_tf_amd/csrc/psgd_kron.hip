@@ -3394,7 +3394,7 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
   const P3Buf PP = {k.PP, nsp, nsp, pm ? pm + kPmPP : pm};
   int e;
   if (pm && (e = launch_absmax(Qs, (long)ns * ns, QsT, k.pm_part, st, &pm[kPmPP].amax, 1))) return e;
-  if ((e = launch_split3(Qs, 1, ns, ns, ns, QsT, st))) return e;                         // (x, k) = Qs[k][x]
+  if ((e = launch_split3(Qs, 1, ns, ns, ns, QsT, st, SplitOpt{2, 0, 0, 0}))) return e;   // (x, k) = Qs[k][x]: zero where k > x, unread
   P3Args g = p3_args(QsT, QsT, ns, ns, ns, KHI_M | KHI_N);                              // Qs'Qs, symmetric
   g.e.sym = 1;
   if (g.fmt && g_planes_exact) {                      // (fp32 Gram in the workspace's Gram buffer, mirrored by the epilogue)
@@ -3406,7 +3406,7 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
   if (pm && (e = launch_absmax(Qb, (long)nb * nb, F1, k.pm_part, st))) return e;         // (the split above is done with the array)
   P3Buf F2 = F1;
   F2.p = k.F2;
-  return launch_split3_both(Qb, nb, 1, nb, nb, F1, F2, st);                              // both forms from one read
+  return launch_split3_both(Qb, nb, 1, nb, nb, F1, F2, st, SplitOpt{1, 0, 0, 0});        // both forms from one read (upper tiles only)
 }
 
 static int planes_apply(const float* G, float* out, int M, int N, const KronWs& k, hipStream_t st) {
@@ -3456,8 +3456,9 @@ static int planes_update_factors(int M, int N, const KronWs& k, hipStream_t st, 
   const P3Buf Lr = {k.Lr, Mp, Mp, mL, k.pm_part + 2 * kPmPartMax, nb}, Lc = {k.Lc, Mp, Mp, mL};
   const P3Buf Rr = {k.Rr, Np, Np, mR, k.pm_part + 3 * kPmPartMax, nb}, Rc = {k.Rc, Np, Np, mR};
   int e;
-  if ((e = launch_split3_both(k.QlS, M, 1, M, M, Lr, Lc, st))) return e;
-  return launch_split3_both(k.QrS, N, 1, N, N, Rr, Rc, st);
+  // (tri: the factors are upper triangular by contract -- the tiles below the diagonal become zeros without being read)
+  if ((e = launch_split3_both(k.QlS, M, 1, M, M, Lr, Lc, st, SplitOpt{1, 0, 0, 0}))) return e;
+  return launch_split3_both(k.QrS, N, 1, N, N, Rr, Rc, st, SplitOpt{1, 0, 0, 0});
 }
 
 static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st, PlaneMeta* pm) {
@@ -3788,8 +3789,9 @@ int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_
     if ((e = launch_absmax(QrS, (long)N * N, s.R.Qc, k.part + 2 * kPmPartMax, main))) return e;
     if ((e = launch_absmax(QlS, (long)M * M, s.L.Qc, k.part + kPmPartMax, side))) return e;
   }
-  if ((e = launch_split3(QrS, 1, N, N, N, s.R.Qc, main))) return e;                    // (x, k) = QrS[k][x]
-  if ((e = launch_split3(QlS, 1, M, M, M, s.L.Qc, side))) return e;
+  // (tri 2: the view is the transposed factor -- nonzero where k <= x; the other tiles become zeros without being read)
+  if ((e = launch_split3(QrS, 1, N, N, N, s.R.Qc, main, SplitOpt{2, 0, 0, 0}))) return e;   // (x, k) = QrS[k][x]
+  if ((e = launch_split3(QlS, 1, M, M, M, s.L.Qc, side, SplitOpt{2, 0, 0, 0}))) return e;
   if (x0_parts > 0) { s.X0p.part = k.part; s.X0p.npart = x0_parts; }
   return blk_solves_front(s, main, side, l_ready);
 }
