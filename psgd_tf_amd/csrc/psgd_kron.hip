@@ -1407,14 +1407,14 @@ __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X
   split3_body<FMT>(X, rs, cs, R, C, P, ts, ps, Pt, tts, tps, meta, part, npart, opt, blockIdx.x, blockIdx.y, blockIdx.z, S);
 }
 // two independent splits in one launch (the two gradients of the large update): job 0 on the rows y < y0 of the grid, job 1 behind
-struct SplitJob { const float* X; long rs, cs; int R, C; __bf16* P; long ts, ps; PlaneMeta* meta; const float* part; int npart; SplitOpt opt; int gx; };
+struct SplitJob { const float* X; long rs, cs; int R, C; __bf16* P; long ts, ps; __bf16* Pt; long tts, tps; PlaneMeta* meta; const float* part; int npart; SplitOpt opt; int gx; };
 template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_split3_two(SplitJob a, SplitJob b, int y0) {
   __shared__ float S[64][65];
   const bool second = (int)blockIdx.y >= y0;
   const SplitJob j = second ? b : a;
   if ((int)blockIdx.x >= j.gx) return;
-  split3_body<FMT>(j.X, j.rs, j.cs, j.R, j.C, j.P, j.ts, j.ps, (__bf16*)nullptr, 0L, 0L, j.meta, j.part, j.npart, j.opt, blockIdx.x,
+  split3_body<FMT>(j.X, j.rs, j.cs, j.R, j.C, j.P, j.ts, j.ps, j.Pt, j.tts, j.tps, j.meta, j.part, j.npart, j.opt, blockIdx.x,
                    second ? blockIdx.y - y0 : blockIdx.y, 0, S);
 }
 
@@ -3054,13 +3054,16 @@ static int launch_split3(const float* X, long rs, long cs, int R, int C, const P
   return (int)hipGetLastError();
 }
 // planes of the view (out) and of its transpose (outT: rows/ld swapped) from one read
-// two row-major matrices [Ra x Ca] (row stride Ca) and [Rb x Cb], f16 x 2 row-form planes each, in ONE launch
+// two row-major matrices [Ra x Ca] (row stride Ca) and [Rb x Cb], f16 x 2 row-form planes each (+ the column-form planes when oaT / obT
+// are given), in ONE launch
 static int launch_split3_two(const float* Xa, int Ra, int Ca, const P3Buf& oa, const float* Xb, int Rb, int Cb, const P3Buf& ob,
-                             hipStream_t st, SplitOpt opt) {
+                             hipStream_t st, SplitOpt opt, const P3Buf* oaT = nullptr, const P3Buf* obT = nullptr) {
   if (!oa.meta || !ob.meta || opt.blk) return 1;
   const dim3 ga = split_grid(oa.rows, oa.ld, opt), gb = split_grid(ob.rows, ob.ld, opt);
-  SplitJob a = {Xa, (long)Ca, 1L, Ra, Ca, oa.p, oa.rows * 32, oa.rows * oa.ld, oa.meta, oa.part, oa.npart, opt, (int)ga.x};
-  SplitJob b = {Xb, (long)Cb, 1L, Rb, Cb, ob.p, ob.rows * 32, ob.rows * ob.ld, ob.meta, ob.part, ob.npart, opt, (int)gb.x};
+  SplitJob a = {Xa, (long)Ca, 1L, Ra, Ca, oa.p, oa.rows * 32, oa.rows * oa.ld, oaT ? oaT->p : nullptr, oaT ? oaT->rows * 32 : 0L,
+                oaT ? oaT->rows * oaT->ld : 0L, oa.meta, oa.part, oa.npart, opt, (int)ga.x};
+  SplitJob b = {Xb, (long)Cb, 1L, Rb, Cb, ob.p, ob.rows * 32, ob.rows * ob.ld, obT ? obT->p : nullptr, obT ? obT->rows * 32 : 0L,
+                obT ? obT->rows * obT->ld : 0L, ob.meta, ob.part, ob.npart, opt, (int)gb.x};
   hipLaunchKernelGGL(k_split3_two<1>, dim3(ga.x > gb.x ? ga.x : gb.x, ga.y + gb.y), dim3(kThreads), 0, st, a, b, (int)ga.y);
   return (int)hipGetLastError();
 }
@@ -3456,7 +3459,9 @@ static int planes_update_factors(int M, int N, const KronWs& k, hipStream_t st, 
   const P3Buf Lr = {k.Lr, Mp, Mp, mL, k.pm_part + 2 * kPmPartMax, nb}, Lc = {k.Lc, Mp, Mp, mL};
   const P3Buf Rr = {k.Rr, Np, Np, mR, k.pm_part + 3 * kPmPartMax, nb}, Rc = {k.Rc, Np, Np, mR};
   int e;
-  // (tri: the factors are upper triangular by contract -- the tiles below the diagonal become zeros without being read)
+  // (tri: the factors are upper triangular by contract -- the tiles below the diagonal become zeros without being read;
+  //  f16 x 2: both factors, both forms, one launch)
+  if (pm) return launch_split3_two(k.QlS, M, M, Lr, k.QrS, N, N, Rr, st, SplitOpt{1, 0, 0, 0}, &Lc, &Rc);
   if ((e = launch_split3_both(k.QlS, M, 1, M, M, Lr, Lc, st, SplitOpt{1, 0, 0, 0}))) return e;
   return launch_split3_both(k.QrS, N, 1, N, N, Rr, Rc, st, SplitOpt{1, 0, 0, 0});
 }
