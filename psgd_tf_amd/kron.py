@@ -126,7 +126,8 @@ class layer_streams:
     block sees the results in stream order.  Small layers are bound by their chain of 3 (apply) / 5 (update) dependent
     launches, not by work, so the chains of different layers overlap.  Event fork/join only: inside `torch.cuda.graph` the
     captured graph gets one branch per call and a replay runs the layers side by side with no host cost at all.
-    Workspaces are per (shape, stream), so two layers of one shape never share scratch."""
+    Workspaces are per (shape, stream), so two layers of one shape never share scratch.  One block at a time, from one host
+    thread (the switch is a module global, like the factor cache)."""
 
     def __init__(self, streams=8):
         self.n = int(streams)
@@ -153,8 +154,12 @@ class layer_streams:
     def run(self, fn, args):
         global _layer_ctx
         first = args[0]
-        if not (torch.is_tensor(first) and first.is_cuda):
-            return fn(*args)
+        if not (torch.is_tensor(first) and first.is_cuda):       # (not a device call: let the entry point raise its own error, unforked)
+            _layer_ctx = None
+            try:
+                return fn(*args)
+            finally:
+                _layer_ctx = self
         if self.main is None:
             self.main = torch.cuda.current_stream(first.device)
             pool = _layer_pool.setdefault(first.get_device(), [])

@@ -247,3 +247,17 @@ def test_wide_rank_chunking():
         else:
             assert c == cmin and r % cmin != 0 and (r % (cmin + 1) != 0 or r // (cmin + 1) > 32)
     assert uvd_wide._chunks(40) == (2, 20, True) and uvd_wide._chunks(33) == (3, 11, True) and uvd_wide._chunks(70) == (3, 24, False)
+
+
+def test_layer_streams_block_on_cpu_tensors_raises_the_entry_points_error():
+    """kron.layer_streams only forks device calls: a CPU tensor inside the block reaches the entry point unforked (which refuses it:
+    no CPU fallback) instead of recursing, and the block's switch is cleared on the way out."""
+    import torch
+    import preconditioned_stochastic_gradient_descent as psgd
+    from psgd_tf_amd import _lib, kron
+    with pytest.raises(_lib.PsgdHipError):
+        with kron.layer_streams():
+            psgd.precond_grad_kron(torch.eye(3), torch.eye(2), torch.ones(3, 2))
+    assert kron._layer_ctx is None
+    with pytest.raises(ValueError):
+        kron.layer_streams(0)
