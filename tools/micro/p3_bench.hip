@@ -39,6 +39,27 @@ int main() {
     const float us = time_us(st, 20, [&] { launch_p3(g, st); });
     printf("%4d x %4d x %4d kmode %d: %7.1f us  (%d K steps) %s\n", c.M, c.N, c.K, c.kmode, us, c.K / 32, c.what);
   }
+  // the gradient grid of the large update (two gradients, upper tiles, each tile two operand pairs of K = 4096: A A' - Bt Bt') against
+  // one symmetric product with a single pair of K = 8192 (same MFMA work per tile)
+  {
+    const int n = 4096;
+    __bf16 *A2, *B2;                                   // (8192-deep planes for the single-pair case)
+    hipMalloc(&A2, cap * 4); hipMemcpy(A2, h.data(), cap * 2, hipMemcpyHostToDevice); hipMemcpy(A2 + cap, h.data(), cap * 2, hipMemcpyHostToDevice);
+    float* scratch; unsigned* cnt;
+    hipMalloc(&scratch, 512L * 64 * kThreads * 4 * 2); hipMalloc(&cnt, 4096); hipMemset(cnt, 0, 4096);
+    P3Buf a = {A, pad128(n), (long)n, meta}, b = {B, pad128(n), (long)n, meta + 1};
+    P3Args g1 = p3_args(a, a, n, n, n, 0);
+    g1.A2 = p3_of(b); g1.B2 = p3_of(b); g1.e.A2 = C; g1.e.K2 = n;
+    g1.e.epi = EPI_TRIU_MAX; g1.e.maxout = reinterpret_cast<float*>(meta + 3); g1.e.C = C; g1.e.ldc = n;
+    P3Args g2 = g1;
+    const float us = time_us(st, 10, [&] { launch_p3_grad(g1, g2, scratch, cnt, st); });
+    printf("gradient grid, 2 x 528 tiles x (128 + 128) K steps: %.1f us\n", us);
+    P3Buf a8 = {A2, pad128(n), 8192L, meta};
+    P3Args s1 = p3_args(a8, a8, n, n, 8192, 0);
+    s1.e.sym = 0; s1.e.epi = EPI_TRIU_MAX; s1.e.maxout = reinterpret_cast<float*>(meta + 3); s1.e.C = C; s1.e.ldc = n;
+    const float us2 = time_us(st, 10, [&] { launch_p3(s1, st); });
+    printf("one product 4096 x 4096 x 8192, triu epilogue (1024 tiles launched, the 496 below the diagonal skip their K loop): %.1f us  -> x 2 gradients = %.1f us\n", us2, 2 * us2);
+  }
   // an empty kernel on the same stream, back to back: the launch floor
   const float e = time_us(st, 50, [&] { hipLaunchKernelGGL(k_absmax, dim3(1), dim3(kThreads), 0, st, C, 0L, 1L, 4L, C + 1024, (float*)nullptr, 0); });
   printf("one-block kernel, back to back: %.1f us\n", e);
