@@ -55,6 +55,13 @@ int main() {
     const float us = time_us(st, 10, [&] { launch_p3_grad(g1, g2, scratch, cnt, st); });
     printf("gradient grid, 2 x 528 tiles x (128 + 128) K steps: %.1f us\n", us);
     P3Buf a8 = {A2, pad128(n), 8192L, meta};
+    {
+      P3Args q = p3_args(a8, a8, n, n, 8192, 0);                   // the same grid, every tile ONE pair of 256 K steps
+      q.e.epi = EPI_TRIU_MAX; q.e.maxout = reinterpret_cast<float*>(meta + 3); q.e.C = C; q.e.ldc = n;
+      P3Args q2 = q;
+      const float us3 = time_us(st, 10, [&] { launch_p3_grad(q, q2, scratch, cnt, st); });
+      printf("gradient grid, 2 x 528 tiles x 256 K steps in ONE pair: %.1f us\n", us3);
+    }
     P3Args s1 = p3_args(a8, a8, n, n, 8192, 0);
     s1.e.sym = 0; s1.e.epi = EPI_TRIU_MAX; s1.e.maxout = reinterpret_cast<float*>(meta + 3); s1.e.C = C; s1.e.ldc = n;
     const float us2 = time_us(st, 10, [&] { launch_p3(s1, st); });
