@@ -1563,6 +1563,34 @@ __global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ X
   }
 }
 
+// max|.| of the UPPER triangles of two row-major square matrices in one launch (the factors of a Kron apply: upper triangular by
+// contract): blocks [0, ba) leave the partial maxima of A in partA[0 .. ba), the rest those of B in partB; a block reads rows
+// b, b + nb, ... of its matrix from the (4-aligned) column of the diagonal on -- half the bytes of two flat scans, one launch.
+// zero[0 .. nzero) as in k_absmax.  Contract: both base addresses 16-byte aligned, nA % 4 == nB % 4 == 0 (launcher: else two k_absmax).
+__global__ __launch_bounds__(kThreads) void k_absmax_tri2(const float* __restrict__ A, int nA, float* __restrict__ partA, int ba,
+                                                          const float* __restrict__ B, int nB, float* __restrict__ partB,
+                                                          float* __restrict__ zero, int nzero) {
+  __shared__ float red[kThreads / 64];
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nzero; i += kThreads) zero[i] = 0.0f;
+  const bool second = (int)blockIdx.x >= ba;
+  const float* __restrict__ X = second ? B : A;
+  const int n = second ? nB : nA, b = second ? blockIdx.x - ba : blockIdx.x, nb = second ? gridDim.x - ba : ba;
+  float m = 0.0f;
+  for (int r = b; r < n; r += nb) {
+    const float* __restrict__ row = X + (long)r * n;
+    for (int c = (r & ~3) + threadIdx.x * 4; c < n; c += kThreads * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(row + c);
+      m = amaxf(amaxf(m, c >= r ? fabsf(v.x) : 0.0f), amaxf(amaxf(c + 1 >= r ? fabsf(v.y) : 0.0f, c + 2 >= r ? fabsf(v.z) : 0.0f), fabsf(v.w)));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = amaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) (second ? partB : partA)[b] = amaxf(amaxf(red[0], red[1]), amaxf(red[2], red[3]));
+}
+
 // (T = 128 is the exact-fp32 alternative to the split GEMM, psgd_kron_set_tuning(1, 0): two resident blocks per CU; with the
 // K loops per fetch mode three blocks -- 168 registers -- would spill)
 template <int T, int GK>
@@ -3396,7 +3424,16 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
   P3Buf QsT = {k.Y0, nsp, nsp, pm ? pm + kPmQs : pm}, F1 = {k.F1, nbp, nbp, pm ? pm + kPmF : pm};
   const P3Buf PP = {k.PP, nsp, nsp, pm ? pm + kPmPP : pm};
   int e;
-  if (pm && (e = launch_absmax(Qs, (long)ns * ns, QsT, k.pm_part, st, &pm[kPmPP].amax, 1))) return e;
+  // the maxima of both factors from one launch over their upper triangles (second array of the partial maxima for the bigger factor)
+  const bool both = pm && ((reinterpret_cast<uintptr_t>(Qs) | reinterpret_cast<uintptr_t>(Qb)) & 15) == 0 && ns % 4 == 0 && nb % 4 == 0;
+  if (both) {
+    const int ba = ns < 1024 ? ns : 1024, bb = nb < 1024 ? nb : 1024;
+    hipLaunchKernelGGL(k_absmax_tri2, dim3(ba + bb), dim3(kThreads), 0, st, Qs, ns, k.pm_part, ba, Qb, nb, k.pm_part + kPmPartMax,
+                       &pm[kPmPP].amax, 1);
+    if (hipGetLastError() != hipSuccess) return 1;
+    QsT.part = k.pm_part; QsT.npart = ba;
+    F1.part = k.pm_part + kPmPartMax; F1.npart = bb;
+  } else if (pm && (e = launch_absmax(Qs, (long)ns * ns, QsT, k.pm_part, st, &pm[kPmPP].amax, 1))) return e;
   if ((e = launch_split3(Qs, 1, ns, ns, ns, QsT, st, SplitOpt{2, 0, 0, 0}))) return e;   // (x, k) = Qs[k][x]: zero where k > x, unread
   P3Args g = p3_args(QsT, QsT, ns, ns, ns, KHI_M | KHI_N);                              // Qs'Qs, symmetric
   g.e.sym = 1;
@@ -3406,7 +3443,7 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
     p3_out_row(g, PP); p3_out_col(g, PP);
     if ((e = launch_p3(g, st))) return e;
   }
-  if (pm && (e = launch_absmax(Qb, (long)nb * nb, F1, k.pm_part, st))) return e;         // (the split above is done with the array)
+  if (pm && !both && (e = launch_absmax(Qb, (long)nb * nb, F1, k.pm_part, st))) return e;   // (the split above is done with the array)
   P3Buf F2 = F1;
   F2.p = k.F2;
   return launch_split3_both(Qb, nb, 1, nb, nb, F1, F2, st, SplitOpt{1, 0, 0, 0});        // both forms from one read (upper tiles only)
