@@ -39,7 +39,7 @@ extern "C" {
  * workspace layout changed); 3 = round 3 (entry points added, bf16 apply workspace carries a hand-off route word);
  * 4 = round 4 (Kron dense (x) dense workspaces of small layers carry the scratch of the fused strip kernels).
  * psgd_tf_amd/_lib.py refuses a library whose psgd_abi_version() differs from the one it was written for. */
-#define PSGD_ABI_VERSION 4
+#define PSGD_ABI_VERSION 5
 
 #define PSGD_OK                 0
 #define PSGD_ERR_BAD_ARG       (-1)   /* null pointer, N <= 0, r <= 0 ...            */
@@ -303,6 +303,14 @@ int psgd_kron_dd_prepare_f32(const float *Ql, const float *Qr, int M, int N, voi
                              int64_t ws_bytes, void *stream);
 int psgd_kron_dd_apply_prepared_f32(const float *Ql, const float *Qr, const float *G, float *out,
                                     int M, int N, void *ws, int64_t ws_bytes, void *stream);
+/* The apply for factors that are NEW on every call (the reference's pattern: an apply right after an update): no Gram, nothing
+ * prepared -- out = Ql' (Ql ((G Qr') Qr)) as four chained triangular products where the f16 x 2 plane products apply (large
+ * layers: 4096^2 1.01 -> 0.93 ms); the same as psgd_kron_dd_apply_f32 elsewhere.  Leaves no prepared state in ws:
+ * psgd_kron_dd_apply_prepared_f32 needs psgd_kron_dd_prepare_f32 (or psgd_kron_dd_apply_f32) for these factors first.  */
+int psgd_kron_dd_apply_direct_f32(const float *Ql, const float *Qr, const float *G, float *out, int M, int N, void *ws,
+                                  int64_t ws_bytes, void *stream);
+/* 1 when the call above is a path of its own for this shape under the current tuning, 0 when it is psgd_kron_dd_apply_f32 */
+int psgd_kron_dd_apply_direct_distinct(int M, int N);
 
 /* _update_precond_dense_dense(Ql, Qr, dX, dG, step)  psgd.py:156-179.
  * Pure: Ql, Qr are read, the new factors are written to QlOut, QrOut.      */

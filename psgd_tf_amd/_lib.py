@@ -13,7 +13,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PSGD_HIP_LIB", os.path.join(_CSRC, "libpsgd_hip.so"))   # override: build experiments only
 
 PSGD_OK = 0
-PSGD_ABI_VERSION = 4       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
+PSGD_ABI_VERSION = 5       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
 PSGD_WS_SUMS_F64 = 0
 PSGD_WS_MAX_F32 = 1
 PSGD_WS_SEND_F64 = 2
@@ -114,6 +114,8 @@ SIGNATURES = {
     "psgd_kron_dd_apply_bf16": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
     "psgd_kron_bf16_prepare_factors": (_int, [_c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
     "psgd_kron_dd_apply_bf16_prepared": (_int, [_c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_apply_direct_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _c_ws, _i64, _strm]),
+    "psgd_kron_dd_apply_direct_distinct": (_int, [_int, _int]),
     "psgd_kron_dd_update_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _flt, _flt,
                                        _c_ws, _i64, _strm]),
 }

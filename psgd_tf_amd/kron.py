@@ -101,6 +101,7 @@ def invalidate_factor_cache():
     _padded_factors.clear()
     for slot in _apply_slots.values():
         slot.rl = slot.rr = None
+        slot.prepared = False
 
 
 def set_tuning(key, value):
@@ -110,6 +111,8 @@ def set_tuning(key, value):
     _lib.check(_lib.load().psgd_kron_set_tuning(int(key), int(value)), "psgd_kron_set_tuning")
     if int(key) in (4, 12, 21):
         invalidate_factor_cache()
+    if int(key) in (1, 4, 12, 16, 21):
+        _apply_slots.clear()                         # (which apply paths a shape has is asked when its slot is made)
 
 
 # --------------------------------------------------------------------------- independent per-layer calls on forked streams
@@ -350,7 +353,7 @@ def _dd_update_f32(Ql, Qr, dX, dG, step, M, N):
     key = (idx, M, N, st)
     slot = _apply_slots.get(key)
     if slot is None or slot.ws() is None:
-        slot = _apply_slots[key] = _ApplySlot(_kron_workspace(dX.device, M, N))
+        slot = _apply_slots[key] = _ApplySlot(_kron_workspace(dX.device, M, N), M, N)
     else:
         _kron_ws.touch(key)                          # (same key as _kron_workspace: the hot shape must not age out of the LRU)
     QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
@@ -419,9 +422,10 @@ class _ApplySlot:
     """Per (device, shape, stream): the workspace and what its prepared Grams were made from.  Small layers are
     host-bound (a launch costs the host ~4 us, the GPU less), so the per-call Python work is kept to a handful of
     attribute reads: the factor identity check is spelled out instead of built from generators."""
-    __slots__ = ("ws", "ws_ptr", "ws_bytes", "rl", "rr", "vl", "vr", "pl", "pr", "fn_apply", "fn_prepared", "fn_update")
+    __slots__ = ("ws", "ws_ptr", "ws_bytes", "rl", "rr", "vl", "vr", "pl", "pr", "fn_apply", "fn_prepared", "fn_update", "fn_direct",
+                 "prepared", "path")
 
-    def __init__(self, ws):
+    def __init__(self, ws, M, N):
         # (a weak reference: the workspace cache owns the block; a slot of a shape the cache has evicted must not keep it alive)
         self.ws, self.ws_ptr, self.ws_bytes = weakref.ref(ws), ws.data_ptr(), ws.numel()
         self.rl = self.rr = None
@@ -429,6 +433,11 @@ class _ApplySlot:
         lib = _lib.load()
         self.fn_apply, self.fn_prepared = lib.psgd_kron_dd_apply_f32, lib.psgd_kron_dd_apply_prepared_f32
         self.fn_update = lib.psgd_kron_dd_update_f32
+        # large layers: factors seen for the first time go through the Gram-free chain (nothing prepared); the Gram is made when
+        # the SAME factors come a second time.  fn_direct is None where that chain is not a path of its own (small layers).
+        self.fn_direct = lib.psgd_kron_dd_apply_direct_f32 if lib.psgd_kron_dd_apply_direct_distinct(M, N) == 1 else None
+        self.prepared = False
+        self.path = ""                               # which of "direct" / "both" / "prepared" the last apply took (tests)
 
 
 _apply_slots = {}
@@ -457,7 +466,7 @@ def _dd_apply_f32(Ql, Qr, Grad, M, N):
     key = (idx, M, N, st)
     slot = _apply_slots.get(key)
     if slot is None or slot.ws() is None:            # first call for this (device, shape, stream), or the cache evicted its block
-        slot = _apply_slots[key] = _ApplySlot(_kron_workspace(Grad.device, M, N))
+        slot = _apply_slots[key] = _ApplySlot(_kron_workspace(Grad.device, M, N), M, N)
         if len(_apply_slots) > 4 * _kron_ws.max_entries:     # slots of evicted workspaces: drop them
             for k in [k for k, v in _apply_slots.items() if v.ws() is None]:
                 del _apply_slots[k]
@@ -470,13 +479,30 @@ def _dd_apply_f32(Ql, Qr, Grad, M, N):
     vl, vr = _version_of(Ql), _version_of(Qr)
     if (slot.rl is not None and slot.rl() is Ql and slot.rr() is Qr and slot.vl == vl and slot.vr == vr and vl is not None
             and vr is not None and slot.pl == pl and slot.pr == pr and _cache_usable()):
-        rc = slot.fn_prepared(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
-        if rc:
-            _lib.check(rc, "psgd_kron_dd_apply_prepared_f32")
-    else:                                            # both halves in one call (= prepare + apply_prepared)
-        rc = slot.fn_apply(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
-        if rc:
-            _lib.check(rc, "psgd_kron_dd_apply_f32")
+        if slot.prepared:
+            rc = slot.fn_prepared(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
+            if rc:
+                _lib.check(rc, "psgd_kron_dd_apply_prepared_f32")
+            slot.path = "prepared"
+        else:                                        # the same factors a second time: now their Gram pays (prepare + apply_prepared)
+            rc = slot.fn_apply(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
+            if rc:
+                _lib.check(rc, "psgd_kron_dd_apply_f32")
+            slot.prepared = True
+            slot.path = "both"
+    else:
+        if slot.fn_direct is not None:               # new factors, large layer: the Gram-free chain, nothing prepared
+            rc = slot.fn_direct(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
+            if rc:
+                _lib.check(rc, "psgd_kron_dd_apply_direct_f32")
+            slot.prepared = False
+            slot.path = "direct"
+        else:                                        # both halves in one call (= prepare + apply_prepared)
+            rc = slot.fn_apply(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
+            if rc:
+                _lib.check(rc, "psgd_kron_dd_apply_f32")
+            slot.prepared = True
+            slot.path = "both"
         slot.rl, slot.rr = weakref.ref(Ql), weakref.ref(Qr)
         slot.vl, slot.vr, slot.pl, slot.pr = vl, vr, pl, pr
     return out

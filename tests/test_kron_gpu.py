@@ -787,9 +787,11 @@ def _prepared_grams_case(psgd, M, N):
     Ql, Qr = _dev(_tri_factor(rng, M).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
     G, G2 = _dev(rng.standard_normal((M, N))), _dev(rng.standard_normal((M, N)))
     ref = lambda ql, qr, g: orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (ql, qr, g)))
-    a = psgd.precond_grad_kron(Ql, Qr, G)
-    b = psgd.precond_grad_kron(Ql, Qr, G)                          # Grams reused
+    first = psgd.precond_grad_kron(Ql, Qr, G)                      # (large layers: new factors take the Gram-free chain, another association)
+    a = psgd.precond_grad_kron(Ql, Qr, G)                          # the same factors again: their Grams are made ...
+    b = psgd.precond_grad_kron(Ql, Qr, G)                          # ... and reused
     c = psgd.precond_grad_kron(Ql, Qr, G2)                         # ... for another gradient too
+    assert rel_err(first.cpu().numpy(), ref(Ql, Qr, G)) < TOL
     assert torch.equal(a, b) and rel_err(a.cpu().numpy(), ref(Ql, Qr, G)) < TOL and rel_err(c.cpu().numpy(), ref(Ql, Qr, G2)) < TOL
     # an update in between uses the same workspace: the prepared Grams must survive it
     psgd.update_precond_kron(Ql, Qr, G, G2, 0.01)
@@ -1348,3 +1350,27 @@ def test_layer_streams_block_equals_serial_calls(psgd):
     torch.cuda.synchronize()
     for o, c in zip(outs, ref_a):
         assert torch.equal(o, c)
+
+
+@pytest.mark.parametrize("M,N", [(1024, 1024), (1100, 520), (640, 2304), (2048, 1536)])
+def test_large_apply_paths_direct_both_prepared(psgd, M, N):
+    """Large fp32 layers: factors seen for the first time take the Gram-free chain Ql' (Ql ((G Qr') Qr)) (psgd_kron_dd_apply_direct_f32:
+    nothing prepared), the same factor tensors a second time make their Gram (prepare + apply), from then on the prepared half runs.
+    All three agree with the fp64 oracle to the parity tolerance; an in-place change of a factor starts over."""
+    from psgd_tf_amd import kron
+    rng = np.random.default_rng(M + 3 * N)
+    Ql, Qr = _dev((_tri_factor(rng, M) * 1.3).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
+    Gs = [_dev(rng.standard_normal((M, N)).astype(np.float32)) for _ in range(4)]
+    key = (Gs[0].get_device(), M, N, kron._raw_stream(Gs[0].get_device()))
+    paths = []
+    for G in Gs:
+        out = psgd.precond_grad_kron(Ql, Qr, G)
+        ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
+        assert rel_err(out.cpu().numpy(), ref) < TOL
+        paths.append(kron._apply_slots[key].path)
+    assert paths == ["direct", "both", "prepared", "prepared"], paths
+    Ql.mul_(1.01)                                          # (version counter moves: new factors)
+    out = psgd.precond_grad_kron(Ql, Qr, Gs[0])
+    assert kron._apply_slots[key].path == "direct"
+    ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, Gs[0])))
+    assert rel_err(out.cpu().numpy(), ref) < TOL
