@@ -307,8 +307,10 @@ def kron_bench(dev, psgd, iters=20):
                            "note": "fp32-accurate products on the fp16 matrix cores (same dense peak as bf16): operands split once "
                                    "into two fp16 planes and a power-of-two scale per matrix (x 2^e = h + 2^-11 M), 3 MFMAs per "
                                    "product term, K loop = DMA + MFMA (k_gemm_p3<1>); `issued` counts the 128 x 128 x 32 tile steps "
-                                   "the three gradient-side products run (triangular K ranges skipped) x 3; `ms` makes the Gram "
-                                   "(psgd.py:192) and the factor planes inside the call, `ms_unchanged_factors` keeps them; the "
+                                   "the three gradient-side products of the prepared form run (triangular K ranges skipped) x 3; `ms` = new factors on "
+                                   "every call: no Gram, out = Ql'(Ql((G Qr')Qr)) as four chained triangular products with the factors' "
+                                   "planes made inside the call; `ms_unchanged_factors` = the prepared form (Gram of psgd.py:192 and factor "
+                                   "planes kept from the second call with the same factor tensors on); the "
                                    "fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
         "lenet5_set_fp32": {"us": t_lenet_loop_cold * 1e3, "gflops": f_lenet / t_lenet_loop_cold / 1e6, "bound": "launch/latency",
                             "call": "[precond_grad_kron(Ql, Qr, G) for each layer]  (the reference's pattern, mnist_with_lenet5.py:53)",
