@@ -84,15 +84,27 @@ def cpu_baseline(r, sample_rows, budget_s, threads=None):
         t2 = time.perf_counter()
         return t2 - t0, t1 - t0, t2 - t1
 
+    # thread sweep up to every logical CPU on the first `sweep_rows` rows of the sample, so that it fits
+    # the budget; the timed steps then run on the whole sample with the best count
+    sweep_rows = min(sample_rows, 1_000_000)
+    Us, Vs, ds, gs_, vs, hs = (x[:sweep_rows].clone() for x in (U, V, d, grad, v, h))
+
+    def one_small(i):
+        t0 = time.perf_counter()
+        ref.update_precond_UVd_math_(Us, Vs, ds, vs, hs, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+        ref.precond_grad_UVd_math(Us, Vs, ds, gs_)
+        return time.perf_counter() - t0
+
     t_start = time.perf_counter()
-    cands = [threads] if threads else sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu})
+    cands = [threads] if threads else sorted({t for t in (4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu})
     sweep = {}
     for t in cands:
         torch.set_num_threads(t)
-        one(0)
-        sweep[t] = min(one(1)[0], one(2)[0])
+        one_small(0)
+        sweep[t] = min(one_small(1), one_small(2))
         if time.perf_counter() - t_start > 0.5 * budget_s:
             break
+    del Us, Vs, ds, gs_, vs, hs
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     for i in range(2):
@@ -111,15 +123,25 @@ def cpu_baseline(r, sample_rows, budget_s, threads=None):
                 break
     except OSError:
         pass
+    full = None                                  # the last recorded run of this leg on the metric's full N (--cpu-full)
+    try:
+        fp = os.path.join(ROOT, "profiles", "r03_bench_cpu_full_n100m.json.log")
+        fr = json.loads(open(fp).read().strip().splitlines()[-1])["cpu_baseline"]
+        full = {"value": fr["value"], "cores": fr["cores"], "rows": 100_000_000,
+                "source": "profiles/r03_bench_cpu_full_n100m.json.log (bench.py --cpu-full --cpu-threads 16, an earlier box)"}
+    except Exception:
+        full = None
     return {"value": sample_rows / med, "unit": "params/s", "cores": best, "kind": "port",
-            "sample": "torch-CPU restatement of psgd.py:554-627 in the reference's op order (TensorFlow unavailable), "
-                      "update+apply, N=%d r=%d fp32, %d timed steps after 2 warm-up, median %.3f s (min %.3f s), "
-                      "%d threads = best of sweep %s; host: %d logical CPUs, %s"
-                      % (sample_rows, r, len(runs), med, min(x[0] for x in runs), best,
-                         {k: round(v_, 3) for k, v_ in sweep.items()}, ncpu, model),
+            "sample": "update+apply on N=%d rows (of the metric's 100M), r=%d fp32: %d timed steps, median %.3f s; %d threads"
+                      % (sample_rows, r, len(runs), med, best),
+            "sample_detail": "torch-CPU restatement of psgd.py:554-627 in the reference's op order (TensorFlow unavailable), "
+                             "2 warm-up steps, min %.3f s; thread sweep on %d rows (s per step): %s; host: %d logical CPUs, %s"
+                             % (min(x[0] for x in runs), sweep_rows, {k: round(v_, 3) for k, v_ in sweep.items()}, ncpu, model),
             "update_params_per_s": sample_rows / statistics.median(x[1] for x in runs),
             "apply_params_per_s": sample_rows / statistics.median(x[2] for x in runs),
-            "logical_cpus": ncpu, "cpu_model": model}
+            "thread_sweep_max": max(sweep), "logical_cpus": ncpu, "cpu_model": model,
+            "full_n_value": full["value"] if full else None, "full_n_cores": full["cores"] if full else None,
+            "full_n_source": full["source"] if full else None}
 
 
 LENET5 = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10)]      # mnist_with_lenet5.py:12-16
@@ -248,6 +270,23 @@ def kron_bench(dev, psgd, iters=20):
         t_lenet_upd_forked_graph = timeit(graphed(forked_update), 50)
     except Exception as exc:
         print("lenet forked-streams leg failed: %r" % (exc,), file=sys.stderr)
+    # ... and inside `with kron.layer_batch():` -- the calls only queue, leaving the block issues ONE batched launch sequence per kind
+    def lb_apply():                               # (new factors on every call, like cold_loop)
+        flip[0] ^= 1
+        with _kron.layer_batch():
+            return [psgd.precond_grad_kron(a, b, c) for a, b, c in both[flip[0]]]
+
+    def lb_update():
+        with _kron.layer_batch():
+            return [psgd.update_precond_kron(a, b, x, g, 0.01) for a, b, x, g in zip(Qls, Qrs, dXs, Gs)]
+    t_lb = t_lb_upd = t_lb_graph = t_lb_upd_graph = float("nan")
+    try:
+        t_lb = timeit(lb_apply, 50)
+        t_lb_upd = timeit(lb_update, 50)
+        t_lb_graph = timeit(graphed(lb_apply), 50)
+        t_lb_upd_graph = timeit(graphed(lb_update), 50)
+    except Exception as exc:
+        print("lenet layer_batch leg failed: %r" % (exc,), file=sys.stderr)
     dX = torch.randn_like(G)
     t_upd = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, G, 0.01), 5)
     dXb, dGb = dX.to(torch.bfloat16), Gb
@@ -312,9 +351,14 @@ def kron_bench(dev, psgd, iters=20):
                                    "planes made inside the call; `ms_unchanged_factors` = the prepared form (Gram of psgd.py:192 and factor "
                                    "planes kept from the second call with the same factor tensors on); the "
                                    "fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
-        "lenet5_set_fp32": {"us": t_lenet_loop_cold * 1e3, "gflops": f_lenet / t_lenet_loop_cold / 1e6, "bound": "launch/latency",
-                            "call": "[precond_grad_kron(Ql, Qr, G) for each layer]  (the reference's pattern, mnist_with_lenet5.py:53)",
+        "lenet5_set_fp32": {"us": t_lb * 1e3, "gflops": f_lenet / t_lb / 1e6, "bound": "launch/latency",
+                            "call": "with kron.layer_batch(): [precond_grad_kron(Ql, Qr, G) for each layer]  (the reference's pattern, "
+                                    "mnist_with_lenet5.py:53, inside the deferred-batching block); `per_layer_calls_us` = the bare pattern",
                             "per_layer_calls_us": t_lenet_loop_cold * 1e3,
+                            "layer_batch": {"per_layer_calls_us": t_lb * 1e3, "per_layer_calls_graph_us": t_lb_graph * 1e3,
+                                            "per_layer_update_calls_us": t_lb_upd * 1e3,
+                                            "per_layer_update_calls_graph_us": t_lb_upd_graph * 1e3,
+                                            "ratio_to_batched": t_lb / t_lenet_cold, "update_ratio_to_batched": t_lb_upd / t_lenet_upd},
                             "per_layer_calls_unchanged_factors_us": t_lenet_loop * 1e3,
                             "per_layer_calls_graph_us": t_lenet_loop_graph * 1e3,
                             "batched_us": t_lenet_cold * 1e3, "batched_us_unchanged_factors": t_lenet * 1e3,
@@ -323,7 +367,7 @@ def kron_bench(dev, psgd, iters=20):
                                     "`*_unchanged_factors*`: the Grams stay prepared (2 launches); `*_graph_us`: the same list "
                                     "comprehension captured once in a CUDA graph and replayed (no host cost; inside a capture the "
                                     "Grams are always rebuilt); `batched_us`: the batched extension, new factors",
-                            "update_us": t_lenet_upd_loop * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3,
+                            "update_us": t_lb_upd * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3,
                             "per_layer_update_calls_graph_us": t_lenet_upd_loop_graph * 1e3,
                             "layer_streams": {"per_layer_calls_us": t_lenet_forked * 1e3, "per_layer_calls_graph_us": t_lenet_forked_graph * 1e3,
                                               "per_layer_update_calls_us": t_lenet_upd_forked * 1e3,
@@ -450,6 +494,74 @@ def uvd_legs(dev, psgd, lib, state, r, iters):
                                4 * (9 * r + 15), 4 * (2 * r + 3) + 4 * (3 * r + 5) + 4 * (2 * r + 5)),
                            call="update_precond_UVd_math_and_precond_grad (psgd.py:732 -> :748)"),
     }
+
+
+_DROP_KEYS = {"note", "call", "timing", "batched_call", "flop_count", "runs_ms", "mfma_pmc", "sample_detail", "kernels_ms_detail"}
+
+
+def _strip(x):
+    """The full record without its prose: drops the keys of _DROP_KEYS at any depth and cuts strings to 120 characters (what
+    the driver's record keeps of a string)."""
+    if isinstance(x, dict):
+        return {k: _strip(v) for k, v in x.items() if k not in _DROP_KEYS}
+    if isinstance(x, list):
+        return [_strip(v) for v in x]
+    if isinstance(x, str) and len(x) > 120:
+        return x[:117] + "..."
+    if isinstance(x, float):
+        return float("%.8g" % x)                 # (value / ms_per_step pairs stay consistent to 1e-7)
+    return x
+
+
+def compact_line(res, limit=7800):
+    """The ONE line of the contract: every number of the full record, no prose (the key glossary is DESIGN.md section 5), with
+    the figures the north star names hoisted into `roofline` as scalars -- apply_frac / apply_ms (precond_grad_UVd_math alone on
+    SURVEY's 340 B/param), update_frac, step_two_reference_calls_ms, kron_bf16_apply_frac_issued, kron_mfma_util ... -- because the
+    driver's record keeps the scalar entries of `roofline` and `cpu_baseline` and an 8-KB tail."""
+    line = _strip(res)
+    for k in ("value", "ms_per_step"):           # the contract's own numbers: untouched
+        line[k] = res[k]
+    rf = line["roofline"]
+    paths = rf.get("paths", {})
+    hoist = {}
+    if "apply" in paths:
+        a, u = paths["apply"], paths["update"]
+        hoist.update(apply_ms=a["wall_ms"], apply_frac=a["frac"], apply_frac_moved=a["frac_moved"],
+                     update_ms=u["wall_ms"], update_frac=u["frac"],
+                     step_two_reference_calls_ms=paths["step_two_reference_calls"]["wall_ms"])
+    if "step" in paths:
+        hoist.update(step_frac=paths["step"]["frac"], step_frac_moved=paths["step"]["frac_moved"])
+    kr = res.get("kron")
+    if kr:
+        hoist.update(kron_bf16_apply_ms=kr["4096x4096_bf16_operands"]["ms"],
+                     kron_bf16_apply_gflops_Fref=kr["4096x4096_bf16_operands"]["gflops"],
+                     kron_bf16_apply_frac_issued=kr["roofline"]["frac"],
+                     kron_fp32_apply_ms=kr["4096x4096_fp32"]["ms"], kron_fp32_update_ms=kr["4096x4096_fp32_update"]["ms"],
+                     kron_bf16ops_update_ms=kr["4096x4096_bf16_operands_update"]["ms"],
+                     lenet5_apply_us=kr["lenet5_set_fp32"]["us"], lenet5_update_us=kr["lenet5_set_fp32"]["update_us"],
+                     lenet5_apply_bare_calls_us=kr["lenet5_set_fp32"]["per_layer_calls_us"],
+                     lenet5_update_bare_calls_us=kr["lenet5_set_fp32"]["per_layer_update_calls_us"],
+                     lenet5_batched_apply_us=kr["lenet5_set_fp32"]["batched_us"],
+                     lenet5_batched_update_us=kr["lenet5_set_fp32"]["batched_update_us"])
+        pm = kr["4096x4096_bf16_operands"].get("mfma_pmc")
+        if pm:
+            hoist["kron_mfma_util"] = pm["MfmaUtil_percent_time_weighted"] / 100.0
+    c2 = res.get("config2_N1M_r10")
+    if c2:
+        hoist["config2_step_us"] = c2["step_fused"]["wall_ms"] * 1e3
+    rf.update({k: float("%.6g" % v) for k, v in hoist.items() if v is not None})
+    # size guard: drop the least important sub-records first (they stay in the BENCH_DETAIL line on stderr)
+    for victim in (("kron", "lenet5_set_fp32", "layer_streams"), ("roofline", "paths", "step_fused_events"),
+                   ("config2_N1M_r10", "step_fused", "kernels_ms"), ("config2_N1M_r10", "apply", "kernels_ms"),
+                   ("config2_N1M_r10", "update", "kernels_ms"), ("splu",), ("config2_N1M_r10",), ("roofline", "kernels")):
+        if len(json.dumps(line)) <= limit:
+            break
+        node = line
+        for k in victim[:-1]:
+            node = node.get(k, {}) if isinstance(node, dict) else {}
+        if isinstance(node, dict):
+            node.pop(victim[-1], None)
+    return line
 
 
 def launch_ranks(args):
@@ -587,6 +699,8 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="time update_precond_UVd_math_ + precond_grad_UVd_math as two separate calls")
     ap.add_argument("--bpc", type=int, default=0, help="experiment: cap on blocks per CU of the sweeps (psgd_set_tuning key 1)")
+    ap.add_argument("--detail-json", default=None, help="also write the full record (every leg, notes) to this file; stdout "
+                    "carries the compact line (< 8 KB), stderr a BENCH_DETAIL line with the full record")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU code path (process group + exchanges) even at world size 1")
     args = ap.parse_args()
@@ -662,8 +776,7 @@ def main():
                 rec = json.load(open(tp)).get("k_update_s2")
                 if rec and rec.get("rows") == n_local and rec.get("r") == r:
                     traffic = rec["hbm_bytes_per_launch"]
-                    traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on an earlier "
-                                      "box (%s), NOT counters of this run" % rec.get("source", "see profiles/README.md"))
+                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes on an earlier box, NOT counters of this run)"
             except Exception:
                 traffic = None
         ach = kern[dom]["achieved_GBs"]
@@ -676,23 +789,21 @@ def main():
                           "frac": gbs(alg_step) / HBM_PEAK_GBS, "frac_moved": gbs(moved_step) / HBM_PEAK_GBS,
                           "kernel_ms": sum(slot_ms[k] or 0.0 for k in slot_ms)}}
         if scaling == "strong":
-            what = "N=%d rows global split over %d GPU(s) in contiguous row blocks (%d on rank 0)" % (n_global, world, n_local)
+            what = "N=%d rows global over %d GPU(s), contiguous blocks (%d on rank 0)" % (n_global, world, n_local)
         else:
             what = "N=%d rows per GPU" % n_local
         res = {
             "metric": "uvd_update_apply_params_per_sec", "value": value, "unit": "params/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UVd preconditioner update+apply (update_precond_UVd_math_ then "
-                                   "precond_grad_UVd_math%s), %s, r=%d"
-                                   % ("" if args.unfused else ", fused call", what, r),
+            "config": {"workload": "UVd update+apply (psgd.py:732->:748%s), %s, r=%d" % ("" if args.unfused else ", fused call", what, r),
                        "rows_per_gpu": n_local, "rows_global": n_global, "rank_of_modification": r,
                        "baseline_config": ("configs[3]: UVd N=100M, r=20, flat-vector sharded" if
                                            (scaling == "strong" and n_global == 100_000_000 and r == 20 and world > 1) else
                                            ("metric config: UVd N=100M, r=20, 1 GPU" if
                                             (n_global == 100_000_000 and r == 20 and world == 1) else None)),
-                       "parallelism": ("row-sharded x%d, per step %d all-gathers of r-dim reduced buffers (<= 30 KB) + "
-                                       "rank-order fold" % (world, 4 if args.unfused else 2)) +
+                       "parallelism": ("row-sharded x%d: %d all-gathers/step of r-dim buffers (<= 30 KB) + rank-order fold"
+                                       % (world, 4 if args.unfused else 2) if use_dist else "one GPU, no exchange") +
                                       (" [TEST MODE: all ranks on one GPU, gloo -- not a measurement]" if single_dev else ""),
                        "collective_backend": backend, "rccl_ranks": (dist.get_world_size() if use_dist else 0),
                        "step": STEP, "branches": "balance=0, update_U alternating"},
@@ -747,7 +858,12 @@ def main():
             if not args.no_cpu_baseline:
                 rows = n_local if args.cpu_full else args.cpu_sample_rows
                 res["cpu_baseline"] = cpu_baseline(r, rows, args.cpu_budget_s, args.cpu_threads or None)
-        print(json.dumps(res), flush=True)
+        detail = json.dumps(res)
+        if args.detail_json:
+            with open(args.detail_json, "w") as fh:
+                fh.write(detail + "\n")
+        print("BENCH_DETAIL " + detail, file=sys.stderr, flush=True)
+        print(json.dumps(compact_line(res)), flush=True)
 
     if use_dist:
         dist.barrier()

@@ -2,8 +2,9 @@
 reference's own call pattern (:51, :53) -- one update_precond_kron / precond_grad_kron call per layer -- eager and captured once in
 a CUDA graph (the five Python calls of a step then cost the host nothing; the calls are the same, the graph is replayed).
 The layers are independent of each other, and a small layer's call is a chain of 3-5 dependent launches, so the third form
-wraps each list comprehension in `with kron.layer_streams():` -- every call on its own forked stream, joined at the end of the block --
-and the captured graph has one branch per layer.
+wraps each list comprehension in `with kron.layer_batch():` -- the calls inside only queue their work and return their (not yet
+filled) outputs; leaving the block issues ONE batched launch sequence for the whole layer set (5 launches for the five updates,
+3 for the five applies).  (`kron.layer_streams()` is the other one-line form: every call on its own forked stream.)
 
 Synthetic data: there is no MNIST here.  A step = preconditioner update on a (dX, dG) pair with dG = Hl dX Hr for fixed SPD
 Hl, Hr (what a quadratic loss would give), then the preconditioned gradient.  After a few hundred steps Ql'Ql (x) Qr'Qr has
@@ -41,8 +42,8 @@ def main(steps=300):
             dXs[i].normal_(generator=g)
             torch.matmul(torch.matmul(Hl[i], dXs[i]), Hr[i], out=dGs[i])
 
-    def step(forked=False):                                               # the reference's two list comprehensions
-        block = kron.layer_streams if forked else contextlib.nullcontext
+    def step(batched=False):                                              # the reference's two list comprehensions
+        block = kron.layer_batch if batched else contextlib.nullcontext
         with block():
             new = [psgd.update_precond_kron(ql, qr, dx, dg, 0.05) for (ql, qr), dx, dg in zip(Qs, dXs, dGs)]      # :51
         for q, (a, b) in zip(Qs, new):
@@ -63,16 +64,21 @@ def main(steps=300):
     eager_us = (time.perf_counter() - t0) / 50 * 1e6
     side = torch.cuda.Stream()
     graphs = []
-    for forked in (False, True):
+    for batched in (False, True):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            step(forked)                                                  # (warm-up on the capture stream: workspaces exist before the capture)
+            step(batched)                                                 # (warm-up on the capture stream: workspaces exist before the capture)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
-            step(forked)
+            step(batched)
         graphs.append(graph)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        step(True)
+    torch.cuda.synchronize()
+    eager_batch_us = (time.perf_counter() - t0) / 50 * 1e6
     t_graph = [0.0, 0.0]
     for it in range(steps):
         draw()
@@ -93,9 +99,10 @@ def main(steps=300):
         worst = max(worst, float(dev_l), float(dev_r))
         assert torch.isfinite(c)
     half = max(steps // 2, 1)
-    print("LeNet5 layer set, per-layer calls: eager %.0f us per step (update + apply), graph replay %.0f us, graph replay with one "
-          "branch per layer (kron.layer_streams) %.0f us; max ||P H / mean - I||_2 over the ten factors: %.3f after %d steps "
-          "(%.3f without a preconditioner)" % (eager_us, t_graph[0] / (steps - steps // 2) * 1e6, t_graph[1] / half * 1e6, worst, steps, worst0))
+    print("LeNet5 layer set, per-layer calls: eager %.0f us per step (update + apply), graph replay %.0f us; inside kron.layer_batch "
+          "blocks: eager %.0f us, graph replay %.0f us; max ||P H / mean - I||_2 over the ten factors: %.3f after %d steps "
+          "(%.3f without a preconditioner)" % (eager_us, t_graph[0] / (steps - steps // 2) * 1e6, eager_batch_us,
+                                               t_graph[1] / half * 1e6, worst, steps, worst0))
     return worst0, worst
 
 

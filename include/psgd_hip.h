@@ -37,9 +37,14 @@ extern "C" {
 
 /* History: 1 = round 1; 2 = round 2 (psgd_uvd_fused_s1_f32 removed, SUMS region of stage 13 holds 4r entries,
  * workspace layout changed); 3 = round 3 (entry points added, bf16 apply workspace carries a hand-off route word);
- * 4 = round 4 (Kron dense (x) dense workspaces of small layers carry the scratch of the fused strip kernels).
+ * 4 = round 4 (Kron dense (x) dense workspaces of small layers carry the scratch of the fused strip kernels);
+ * 5 = round 4, late (the *_ld row-stride forms of the wide-rank building blocks and psgd_kron_dd_apply_direct_f32 added; Kron tuning
+ * keys retired / renumbered -- bf16 key 4 now selects the stream-K gradient launches, not the DMA position; the workspace of
+ * psgd_kron_dd_update_bf16 gained the stream-K partial tiles (up to 128 MiB more for M, N multiples of 256) and padded W1 / W2
+ * row strides: always size it with psgd_kron_dd_update_workspace_bytes_bf16);
+ * 6 = round 5 (psgd_uvd_apply_cols_f32 added: precond_grad_UVd_math on a matrix g; no layout change).
  * psgd_tf_amd/_lib.py refuses a library whose psgd_abi_version() differs from the one it was written for. */
-#define PSGD_ABI_VERSION 5
+#define PSGD_ABI_VERSION 6
 
 #define PSGD_OK                 0
 #define PSGD_ERR_BAD_ARG       (-1)   /* null pointer, N <= 0, r <= 0 ...            */
@@ -166,6 +171,14 @@ int psgd_uvd_ipuvt_matvec_cols_f32(const float *U, const float *V, const float *
                                    float *const *outs, int k, int64_t N, int r,
                                    void *ws, int64_t ws_bytes, void *stream);
 
+/* precond_grad_UVd_math(U, V, d, g) with a MATRIX g (psgd.py:619-627; docstring :623 "either matrices or column vectors": d
+ * broadcasts over the columns, psgd.py:625-626): k columns as HOST arrays of k device pointers to contiguous [N] vectors (gs in,
+ * outs out; outs[j] may be gs[j], otherwise no aliasing).  Per group of four columns: S1 = V'(d.*G), G1 = d.*G + U S1 with
+ * S2 = U'G1 from the same sweep, out = d.*(G1 + V S2) -- three sweeps (V, U, V) per FOUR columns.                      */
+int psgd_uvd_apply_cols_f32(const float *U, const float *V, const float *d, const float *const *gs,
+                            float *const *outs, int k, int64_t N, int r,
+                            void *ws, int64_t ws_bytes, void *stream);
+
 /* Building blocks of the wide-rank path.  The sweep kernels are instantiated for ranks 1..PSGD_UVD_MAX_RANK; a
  * preconditioner of larger rank (the reference has no limit, psgd.py:663) is handled one level up
  * (psgd_tf_amd/uvd_wide.py) on column chunks of U and V -- each chunk a contiguous [N, rc] matrix, rc <= 32 -- with the
@@ -271,7 +284,7 @@ int psgd_splu_update_stage4_f32(const float *L12, const float *l3, const float *
 int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 
 /* Experiment knobs (not stable ABI; defaults in brackets).  Settled A/B keys were frozen into constants in round 4 (5, 8, 10, 13-15,
- * 17, 19, 20).  Keys 4, 12, 21 change what prepared state in a workspace means: prepare again after changing them.
+ * 17, 19, 20).  Keys 1, 4, 12, 16, 21 change what prepared state in a workspace means: prepare again after changing them.
  *  0 fp32 GEMM tile: [0] auto, 1 = 64, 2 = 128, 3 = 32        1 [1] 128-tile products as fp32-accurate bf16 x 3 GEMMs, 0 = exact fp32 MFMA
  *  2 solve strips: [0] register-resident, 1 = LDS-resident      3 32-tile products: [1] k_gemm_small (ring of 4 K tiles), 0 = generic body
  *  4 [1] large products on operands split ONCE into planes (k_split3 / k_gemm_p3), 0 = split inside every GEMM tile
@@ -283,7 +296,8 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * 16 [1] chained products write fp32 + max|C| and a split launch makes exact-scale planes, 0 = epilogue planes at a bound scale
  * 21 [0] small layers (M <= 512, N <= 256) on the stage kernels, 1 = fused strip kernels of psgd_kron_small.hip (opt-in, slower)
  * 23 [1] 512-blocks of an inverse from one strip launch (k_tri_inv512), 0 = k_tri_inv128 + doubling levels 128, 256
- * 24 [2048] block size h of the blocked solves on inverses of diagonal h-blocks, 0 = whole inverses, one product per solve
+ * 24 [2048] block size h of the blocked solves on inverses of diagonal h-blocks, 0 = whole inverses, one product per solve;
+ *    a value that would make more than 4 block columns per side (ceil(max(M, N) / h) > 4) is replaced by 2048 for that call
  * 25 [-1] stream order of the inverse route: by shape (both inversions first from 4096^2 on), 0 / 1 = products / inversions first
  * 27 [1] the factor updates (:179) of the large update walk their tiles in 4 x 4 patches per XCD (from 32 x 32 tiles on), 0 = whole tile rows */
 int psgd_kron_set_tuning(int key, int value);

@@ -13,7 +13,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PSGD_HIP_LIB", os.path.join(_CSRC, "libpsgd_hip.so"))   # override: build experiments only
 
 PSGD_OK = 0
-PSGD_ABI_VERSION = 5       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
+PSGD_ABI_VERSION = 6       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
 PSGD_WS_SUMS_F64 = 0
 PSGD_WS_MAX_F32 = 1
 PSGD_WS_SEND_F64 = 2
@@ -63,6 +63,8 @@ SIGNATURES = {
     "psgd_uvd_ipuvt_matvec_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_ipuvt_matvec_cols_f32": (_int, [_c_f32p, _c_f32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                               _int, _i64, _int, _c_ws, _i64, _strm]),
+    "psgd_uvd_apply_cols_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                       _int, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_colsums_f32": (_int, [_c_f32p, ctypes.POINTER(ctypes.c_void_p), _int, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_axpy_cols_f32": (_int, [_c_f32p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _int, _c_f32p,
                                       _i64, _int, _c_ws, _i64, _strm]),

@@ -7,6 +7,15 @@
 
 namespace psgdk {
 
+// hipFuncSetAttribute (MaxDynamicSharedMemorySize above the 64 KiB default) is PER DEVICE: one flag per device ordinal, so that a
+// process which drives a second GPU sets the attribute there too (a single process-wide flag made that launch fail).
+struct DeviceOnce {
+  unsigned long long mask = 0;
+  int dev = 0;
+  bool needed() { (void)hipGetDevice(&dev); return !((mask >> (dev & 63)) & 1ull); }
+  void done() { mask |= 1ull << (dev & 63); }
+};
+
 // QlS = Ql * sqrt(max|Qr| / max|Ql|), QrS = Qr / that  (psgd.py:166-170).  0 on success.
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st,
                  float* scal = nullptr,    // scal: 64 scratch words to zero in the same launch (or null)

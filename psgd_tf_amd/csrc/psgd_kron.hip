@@ -3230,12 +3230,12 @@ static int launch_strip(const TrsmArgs& t, const float* dinv, hipStream_t st) {
       hipLaunchKernelGGL(k_trsm_ut_reg, dim3((t.nvec + 15) / 16), dim3(kThreads), 0, st, t, dinv);
     return (int)hipGetLastError();
   }
-  static bool attr_set = false;
+  static DeviceOnce attr_set;
   const int pitch = ((t.n + 31) & ~31) + 2;
-  if (!attr_set) {
+  if (attr_set.needed()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trsm_ut_inv<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)((64 * (kStripN + 2) + 32 * 33) * sizeof(float))) != hipSuccess) return 1;
-    attr_set = true;
+    attr_set.done();
   }
   // 64-vector workgroups keep a 4096-vector solve on 64 CUs; 16-vector ones cover the chip and shorten the per-sub-step
   // dependency chains (one MFMA row tile per wave)
@@ -3648,12 +3648,12 @@ static int tri_inverse_blocks(InvSide& f, hipStream_t st) {           // the inv
     return (int)hipGetLastError();
   }
   f.b0 = 128;
-  static bool attr_set = false;
+  static DeviceOnce attr_set;
   const size_t lds = (size_t)2 * 128 * 129 * sizeof(float);
-  if (!attr_set) {
+  if (attr_set.needed()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tri_inv128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) return 1;
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL(k_tri_inv128, dim3((f.n + 127) / 128), dim3(kThreads), lds, st, f.Q, f.n, f.dinv, f.Inv, &f.Ir.meta->amax);
   f.Ir.part = f.Ic.part = &f.Ir.meta->amax;
@@ -3847,7 +3847,14 @@ int kron_inv_prepare(void* ws, int M, int N, hipStream_t main) {
   return hipMemsetAsync(k.pm, 0, kPmSlots * sizeof(PlaneMeta), main) != hipSuccess;
 }
 
-static inline int inv_blk(int M, int N) { return g_inv_blk > 0 ? g_inv_blk : (1 << 30); }
+// h of the blocked solves.  The pieces' PlaneMeta slots (kPmPieceX/W/V: the strips' range) hold at most FOUR block columns per side:
+// a key-24 value that would make more (h = 512 at 4096: the slots overlap; h <= 256: they run into kPmInvR .. kPmX1) falls back to
+// 2048, which is <= 4 blocks for every shape this route takes (M, N <= 8192).
+static inline int inv_blk(int M, int N) {
+  if (g_inv_blk <= 0) return 1 << 30;
+  const int n = M > N ? M : N;
+  return ((n + g_inv_blk - 1) / g_inv_blk > 4) ? 2048 : g_inv_blk;
+}
 static BlkSolve inv_solve_problem(const InvSolveWs& k, const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l,
                                   const float* X0, float* X1, float* Bt, int M, int N) {
   const long Mp = pad128(M), Np = pad128(N);
@@ -4346,13 +4353,13 @@ int psgd_kron_dd_update_batched_f32(const float* const* Ql, const float* const* 
         continue;
       }
       const int pitch_max = ((nmax + 31) & ~31) + 2;
-      static bool attr_set = false;
-      if (!attr_set) {
+      static DeviceOnce attr_set;
+      if (attr_set.needed()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trsm_ut_inv_batched),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)((64 * (kStripN + 2) + 32 * 33) * sizeof(float))) != hipSuccess)
           return PSGD_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.done();
       }
       hipLaunchKernelGGL(k_trsm_ut_inv_batched, dim3(pass ? blk2 : blk1), dim3(kThreads),
                          (size_t)(16 * pitch_max + 32 * 33) * sizeof(float), st, tb, pitch_max);

@@ -648,11 +648,11 @@ SmallWs small_layout(char* base, int M, int N) {
 constexpr size_t kUpdateLds = (32 * 256 + 32 * 256 + 16 * 16 * 17 + 8) * sizeof(float);   // tiles, inverted blocks, staging, red
 
 int set_lds_once() {
-  static int done = 0;
-  if (done) return 0;
+  static DeviceOnce once;                       // (the attribute is per device)
+  if (!once.needed()) return 0;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kron_small_update), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kUpdateLds) != hipSuccess) return 1;
-  done = 1;
+  once.done();
   return 0;
 }
 

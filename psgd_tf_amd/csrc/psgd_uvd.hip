@@ -1152,6 +1152,49 @@ int psgd_uvd_ipuvt_matvec_cols_f32(const float* U, const float* V, const float* 
   return PSGD_OK;
 }
 
+/* precond_grad_UVd_math on the k columns of a matrix g (psgd.py:619-627; docstring :623 "either matrices or column vectors"):
+ * gs / outs are HOST arrays of k device pointers to contiguous [N] columns (outs[j] may be gs[j]).  Per group of four columns the
+ * three sweeps of the single-column apply (V, U, V), so U and V are read 1.5 times per FOUR columns. */
+int psgd_uvd_apply_cols_f32(const float* U, const float* V, const float* d, const float* const* gs, float* const* outs, int k,
+                            int64_t N, int r, void* ws, int64_t ws_bytes, void* stream) {
+  if (!U || !V || !d || !gs || !outs || k < 1) return PSGD_ERR_BAD_ARG;
+  for (int j = 0; j < k; ++j)
+    if (!gs[j] || !outs[j]) return PSGD_ERR_BAD_ARG;
+  Ws w;
+  const int rc = ws_open(ws, ws_bytes, N, r, &w);
+  if (rc) return rc;
+  if (misaligned16(U) || misaligned16(V)) return PSGD_ERR_ALIGN;
+  const UvdOps* ops = uvd_ops_for_rank(r);
+  if (!ops) return PSGD_ERR_RANK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* part = static_cast<double*>(w.part);
+  const int nt = use_nt(N, r);
+  auto reduce_publish = [&](int grid) -> int {
+    hipLaunchKernelGGL(k_reduce_pq, dim3((4 * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, part,
+                       static_cast<const float*>(nullptr), grid, 4 * r, w.sums + kPqSumsOff, static_cast<float*>(nullptr));
+    PSGD_CHECK_LAUNCH(last_launch());
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, st, w.sums + kPqSumsOff, w.coef, 4 * r);
+    PSGD_CHECK_LAUNCH(last_launch());
+    return PSGD_OK;
+  };
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    const int nc = k - j0 < 4 ? k - j0 : 4;
+    const float* x4[4];
+    float* o4[4];
+    for (int j = 0; j < 4; ++j) { x4[j] = gs[j0 + (j < nc ? j : 0)]; o4[j] = outs[j0 + (j < nc ? j : 0)]; }
+    int grid = sweep_grid(ops, r, kOccColreduce, N, kMaxGrid);
+    PSGD_CHECK_LAUNCH(ops->apply4_s1(nt, V, d, x4, N, part, grid, st));
+    int rr = reduce_publish(grid);
+    if (rr) return rr;
+    grid = sweep_grid(ops, r, kOccRowdot, N, kMaxGrid);
+    PSGD_CHECK_LAUNCH(ops->apply4_s2(nt, U, d, x4, o4, nc, N, w.coef, part, grid, st));
+    rr = reduce_publish(grid);
+    if (rr) return rr;
+    PSGD_CHECK_LAUNCH(ops->apply4_s3(nt, V, d, o4, nc, N, w.coef, grid, st));
+  }
+  return PSGD_OK;
+}
+
 /* Building blocks of the wide-rank path (r > PSGD_UVD_MAX_RANK; psgd_tf_amd/uvd_wide.py works on column chunks of U and V,
  * each a contiguous [N, rc] matrix with rc <= 32).  xs / outs: HOST arrays of k device pointers to contiguous [N] vectors.
  *   colsums:   S[j][:] = M' x_j                 (fp64, device [k][r])

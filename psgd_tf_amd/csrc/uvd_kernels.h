@@ -838,6 +838,70 @@ __global__ __launch_bounds__(kThreads) void k_rowdot_axpy4(const float* M, const
                                    }, NoTileHook(), RowStrides{{ld, ld}});
 }
 
+// precond_grad_UVd_math on up to four columns of a MATRIX g at once (psgd.py:619-627, docstring :623 "either matrices or
+// column vectors": d*g broadcasts d over the columns and both IpUVtmatvec calls take [N, k]).  The three sweeps of the
+// single-column apply, each over four columns, so U and V are read 1.5 times per group of four columns instead of per column:
+//   sweep 1  S1 = V'(d .* G)                          (matrix core; the body leaves d .* g_j in the LDS slots ColSum reads)
+//   sweep 2  G1 = d .* G + U S1 (stored to out_j),  S2 = U'G1
+//   sweep 3  out_j = d .* (G1_j + V S2_j)             (in place on out_j)
+// coef = [4][R].  Columns past ncols are duplicates of column 0 on the way in (the launcher's x[j], o[j]) and never stored.
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_apply4_s1(const float* V, const float* d, const float* x0, const float* x1,
+                                                        const float* x2, const float* x3, long N, double* part) {
+  constexpr int kLdsSweep = kWavesPerBlock * sweep_lds_floats<R, 1, 5>() * 4;
+  constexpr int kLdsRed = kWavesPerBlock * 4 * 64 * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
+  float* lds = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * sweep_lds_floats<R, 1, 5>();
+  const float* const mats[1] = {V};
+  const float* const vecs[5] = {x0, x1, x2, x3, d};
+  ColSum<R, 1, 1, 4, 0> cs;
+  sweep_rows<R, 1, 5, -1, NT>(mats, vecs, nullptr, N, lds, [&](long, bool, float (&)[1][R], float (&s)[5]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] *= s[4];
+  }, cs);
+  cs.block_store(reinterpret_cast<double*>(smem), part);
+}
+
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_apply4_s2(const float* U, const float* d, const float* x0, const float* x1,
+                                                        const float* x2, const float* x3, float* o0, float* o1, float* o2,
+                                                        float* o3, int ncols, long N, const float* __restrict__ coef,
+                                                        double* part) {
+  constexpr int kLdsSweep = kWavesPerBlock * sweep_lds_floats<R, 1, 5>() * 4;
+  constexpr int kLdsRed = kWavesPerBlock * 4 * 64 * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
+  float* lds = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * sweep_lds_floats<R, 1, 5>();
+  const float* const mats[1] = {U};
+  const float* const vecs[5] = {x0, x1, x2, x3, d};
+  float* const outs[4] = {o0, o1, o2, o3};
+  ColSum<R, 1, 1, 4, 0> cs;
+  sweep_rows<R, 1, 5, -1, NT>(mats, vecs, nullptr, N, lds, [&](long row, bool valid, float (&x)[1][R], float (&s)[5]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g1 = s[4] * s[j] + dot_row<R>(x[0], coef + j * R);         // rows past N: all zeros
+      if (valid && j < ncols) stream_store<NT>(outs[j] + row, g1);
+      s[j] = g1;
+    }
+  }, cs);
+  cs.block_store(reinterpret_cast<double*>(smem), part);
+}
+
+template <int R, bool NT>
+__global__ __launch_bounds__(kThreads) void k_apply4_s3(const float* V, const float* d, float* o0, float* o1, float* o2,
+                                                        float* o3, int ncols, long N, const float* __restrict__ coef) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 5>()];
+  const float* const mats[1] = {V};
+  const float* const vecs[5] = {o0, o1, o2, o3, d};
+  float* const outs[4] = {o0, o1, o2, o3};
+  sweep_rows<R, 1, 5, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+                              [&](long row, bool valid, float (&x)[1][R], float (&s)[5]) {
+                                if (!valid) return;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                  if (j < ncols) stream_store<NT>(outs[j] + row, s[4] * (s[j] + dot_row<R>(x[0], coef + j * R)));
+                              });
+}
+
 // update sweep 2 (row-local; psgd.py:569-601 / :603-615 given the r-vectors):
 //   a = t + U s1 (Qh)            b = w - V x1 (invQtv)
 //   Ph = d (a + V s2)            invPv = (b - U x2) / d
@@ -964,6 +1028,10 @@ struct UvdOps {
   int (*rowdot_axpy4)(int nt, const float* M, const float* const* x, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
   int (*rank2_update)(int nt, float* M, const float* a, const float* b, long N, const float* coef, int grid, hipStream_t st);
   int (*final_sweep)(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out, long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st);
+  // precond_grad_UVd_math on four columns of a matrix g per sweep (k_apply4_s1 .. s3)
+  int (*apply4_s1)(int nt, const float* V, const float* d, const float* const* x, long N, double* part, int grid, hipStream_t st);
+  int (*apply4_s2)(int nt, const float* U, const float* d, const float* const* x, float* const* o, int ncols, long N, const float* coef, double* part, int grid, hipStream_t st);
+  int (*apply4_s3)(int nt, const float* V, const float* d, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
   // strided forms of the wide-rank building blocks (element (row, c) at M[row * ld + c]); load_vec: floats per global access --
   // ld and the byte address of the view must be multiples of it
   int load_vec;

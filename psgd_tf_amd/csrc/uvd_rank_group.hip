@@ -74,6 +74,19 @@ struct Launch {
                          long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st) {
     PSGD_LAUNCH((k_uvd_final<R, true>), (k_uvd_final<R, false>), U, V, d, nabla, g, out, N, coef, maxbuf, step, tiny);
   }
+  static int apply4_s1(int nt, const float* V, const float* d, const float* const* x, long N, double* part, int grid,
+                       hipStream_t st) {
+    PSGD_LAUNCH((k_apply4_s1<R, true>), (k_apply4_s1<R, false>), V, d, x[0], x[1], x[2], x[3], N, part);
+  }
+  static int apply4_s2(int nt, const float* U, const float* d, const float* const* x, float* const* o, int ncols, long N,
+                       const float* coef, double* part, int grid, hipStream_t st) {
+    PSGD_LAUNCH((k_apply4_s2<R, true>), (k_apply4_s2<R, false>), U, d, x[0], x[1], x[2], x[3], o[0], o[1], o[2], o[3], ncols,
+                N, coef, part);
+  }
+  static int apply4_s3(int nt, const float* V, const float* d, float* const* o, int ncols, long N, const float* coef,
+                       int grid, hipStream_t st) {
+    PSGD_LAUNCH((k_apply4_s3<R, true>), (k_apply4_s3<R, false>), V, d, o[0], o[1], o[2], o[3], ncols, N, coef);
+  }
   static int update_gram_ld(const float* U, long ldU, const float* V, long ldV, const float* d, const float* v, const float* h,
                             long N, double* part, int grid, hipStream_t st) {
     hipLaunchKernelGGL((k_update_gram<R, false, true>), dim3(grid), dim3(kThreads), 0, st, U, V, d, v, h, N, part, RowStrides{{ldU, ldV}});
@@ -115,7 +128,7 @@ struct Launch {
   static const UvdOps* ops() {
     static const UvdOps o = {Cfg<R>::kTileRows, GramCfg<R>::kLen, &colreduce, &apply_s2, &apply_s3,
                              &rowdot_axpy,      &update_gram,     &update_s2, &colreduce4, &rowdot_axpy4,
-                             &rank2_update,     &final_sweep,     Cfg<R>::kVec,     &update_gram_ld, &colreduce4_ld,
+                             &rank2_update,     &final_sweep,     &apply4_s1,  &apply4_s2,  &apply4_s3,  Cfg<R>::kVec,     &update_gram_ld, &colreduce4_ld,
                              &rowdot_axpy4_ld,  &rank2_update_ld, &occupancy};
     return &o;
   }

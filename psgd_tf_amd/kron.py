@@ -106,12 +106,12 @@ def invalidate_factor_cache():
 
 def set_tuning(key, value):
     """psgd_kron_set_tuning through the Python boundary: keys that change what the prepared state in a workspace means
-    (4: operand planes or not, 12: their format, 21: small layers with or without Grams) also drop every prepared Gram / plane
-    set, as the header requires."""
+    (1: plane products or the in-GEMM split, 4: operand planes or not, 12: their format, 16: exact or bound-based scales -- the
+    C side gates the prepared form on all of them: fp32 Grams against planes --, 21: small layers with or without Grams) also
+    drop every prepared Gram / plane set, as the header requires."""
     _lib.check(_lib.load().psgd_kron_set_tuning(int(key), int(value)), "psgd_kron_set_tuning")
-    if int(key) in (4, 12, 21):
-        invalidate_factor_cache()
     if int(key) in (1, 4, 12, 16, 21):
+        invalidate_factor_cache()
         _apply_slots.clear()                         # (which apply paths a shape has is asked when its slot is made)
 
 
@@ -139,10 +139,11 @@ class layer_streams:
 
     def __enter__(self):
         global _layer_ctx
-        if _layer_ctx is not None:
-            raise RuntimeError("layer_streams blocks do not nest")
+        if _layer_ctx is not None or _batch_ctx is not None:
+            raise RuntimeError("layer_streams / layer_batch blocks do not nest")
         self.main = None
         self.used = []
+        self.keep = []
         self.count = 0
         _layer_ctx = self
         return self
@@ -152,6 +153,7 @@ class layer_streams:
         _layer_ctx = None
         for s in self.used:
             self.main.wait_stream(s)
+        self.keep = []
         return False
 
     def run(self, fn, args):
@@ -171,9 +173,18 @@ class layer_streams:
             self.pool = pool
         s = self.pool[self.count % self.n]
         self.count += 1
+        # EVERY call waits for what the caller's stream holds at this point, not only a stream's first call of the block: with more
+        # calls than streams (any model with more than `streams` layers) a later call's arguments may have been produced on the
+        # caller's stream after the pool stream last waited (`precond_grad_kron(ql, qr, g * scale)` inside the comprehension).
+        s.wait_stream(self.main)
         if s not in self.used:
-            s.wait_stream(self.main)
             self.used.append(s)
+        # ... and its arguments stay alive until the block joins: a temporary allocated on the caller's stream and dropped when the
+        # call returns must not be handed out again (to the next allocation on that stream) while the side stream still reads it
+        self.keep.append(args)
+        for t in args:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(s)
         _layer_ctx = None                            # (the call itself must not fork again)
         try:
             with torch.cuda.stream(s):
@@ -183,6 +194,101 @@ class layer_streams:
         for t in (out if isinstance(out, (tuple, list)) else (out,)):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(self.main)           # allocated on the side stream, consumed on the caller's
+        return out
+
+
+# --------------------------------------------------------------------------- route of the large fp32 apply
+_apply_route = "auto"
+
+
+def set_apply_route(route):
+    """Which chain the fp32 (dense, dense) apply of a LARGE layer runs.  Returns the old value.
+
+    "auto" (default): factors seen for the first time take the Gram-free chain Ql'(Ql((G Qr')Qr)), the same factor tensors a
+        second time make the Gram of psgd.py:190 / :192 and later calls reuse it -- fastest for the reference's update -> apply
+        pattern, but calls 1, 2 and 3 on identical inputs return bits that differ in the last places (3e-6 between the routes,
+        tests/test_kron_gpu.py), and for M >= N the first-sight association order is not the reference's.
+    "reference": always the association order of psgd.py:189-192 -- the Gram of the smaller side, then the products of :190 /
+        :192 -- whatever was seen before: identical inputs give identical bits on every call (the prepared Gram is reused when
+        the factors are unchanged; it is the same Gram, bit for bit, that a fresh call would make)."""
+    global _apply_route
+    if route not in ("auto", "reference"):
+        raise ValueError("set_apply_route: 'auto' or 'reference', got %r" % (route,))
+    old, _apply_route = _apply_route, route
+    return old
+
+
+# --------------------------------------------------------------------------- deferred batching of independent per-layer calls
+_batch_ctx = None
+_BATCH_MAX_DIM = 512          # layers the batched kernels are for (launch-bound); larger ones fill the chip and run at once
+
+
+class layer_batch:
+    """`with kron.layer_batch():` around the reference's per-layer list comprehensions (mnist_with_lenet5.py:51, :53).
+
+    Inside the block update_precond_kron / precond_grad_kron on small fp32 (dense, dense) layers (M, N <= 512) do not launch
+    anything: they allocate and return their output tensors and queue a descriptor; leaving the block issues ONE batched call
+    per kind (psgd_kron_dd_{update,apply}_batched_f32: 5 / 3 launches for the whole set instead of per layer) that fills them.
+    Same one-line intrusion and the same requirement as layer_streams: the calls of one comprehension are independent of each
+    other, and nothing reads a returned tensor before the block ends.  A call of the other kind flushes what is queued first, so
+    `Qs = [update ...]` followed by `[apply with the new Qs ...]` in ONE block is in order.  Results are bit for bit those of the
+    batched entry points (= the per-layer calls).  Other formats, bf16 operands and larger layers run at once, as outside the
+    block.  Capturable: the block then records the batched launches."""
+
+    def __enter__(self):
+        global _batch_ctx
+        if _batch_ctx is not None or _layer_ctx is not None:
+            raise RuntimeError("layer_batch / layer_streams blocks do not nest")
+        self.kind, self.items, self.step = None, [], None
+        _batch_ctx = self
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        global _batch_ctx
+        _batch_ctx = None
+        if exc_type is None:
+            self.flush()
+        return False
+
+    def flush(self):
+        global _batch_ctx
+        items, kind, self.items, self.kind = self.items, self.kind, [], None
+        if not items:
+            return
+        saved, _batch_ctx = _batch_ctx, None
+        try:
+            if kind == "update":
+                if len(items) == 1:
+                    a, b, x, g, o = items[0]
+                    _dd_update_f32(a, b, x, g, self.step, x.shape[0], x.shape[1], outs=o)
+                else:
+                    update_precond_kron_batched([i[0] for i in items], [i[1] for i in items], [i[2] for i in items],
+                                                [i[3] for i in items], self.step, outs=[i[4] for i in items])
+            else:
+                if len(items) == 1:
+                    a, b, g, o = items[0]
+                    _dd_apply_f32(a, b, g, g.shape[0], g.shape[1], out=o)
+                else:
+                    precond_grad_kron_batched([i[0] for i in items], [i[1] for i in items], [i[2] for i in items],
+                                              outs=[i[3] for i in items])
+        finally:
+            _batch_ctx = saved
+
+    def update(self, Ql, Qr, dX, dG, step):
+        if self.kind not in (None, "update") or (self.items and step != self.step):
+            self.flush()
+        self.kind, self.step = "update", step
+        outs = (torch.empty((Ql.shape[0], Ql.shape[1]), dtype=_f32, device=Ql.device),
+                torch.empty((Qr.shape[0], Qr.shape[1]), dtype=_f32, device=Qr.device))
+        self.items.append((Ql, Qr, dX, dG, outs))
+        return outs
+
+    def apply(self, Ql, Qr, Grad):
+        if self.kind not in (None, "apply"):
+            self.flush()
+        self.kind = "apply"
+        out = torch.empty((Grad.shape[0], Grad.shape[1]), dtype=_f32, device=Grad.device)
+        self.items.append((Ql, Qr, Grad, out))
         return out
 
 
@@ -338,8 +444,9 @@ def _update_precond_dense_dense(Ql, Qr, dX, dG, step):
     return _dd_update_f32(Ql, Qr, dX, dG, step, dX.shape[0], dX.shape[1])
 
 
-def _dd_update_f32(Ql, Qr, dX, dG, step, M, N):
-    """fp32 dense (x) dense update on checked device tensors (see _dd_apply_f32); shares the slot (workspace) of the apply."""
+def _dd_update_f32(Ql, Qr, dX, dG, step, M, N, outs=None):
+    """fp32 dense (x) dense update on checked device tensors (see _dd_apply_f32); shares the slot (workspace) of the apply.
+    outs: (QlOut, QrOut) to fill instead of fresh tensors (layer_batch)."""
     if not Ql.is_contiguous():
         Ql = Ql.contiguous()
     if not Qr.is_contiguous():
@@ -356,7 +463,7 @@ def _dd_update_f32(Ql, Qr, dX, dG, step, M, N):
         slot = _apply_slots[key] = _ApplySlot(_kron_workspace(dX.device, M, N), M, N)
     else:
         _kron_ws.touch(key)                          # (same key as _kron_workspace: the hot shape must not age out of the LRU)
-    QlO, QrO = torch.empty_like(Ql), torch.empty_like(Qr)
+    QlO, QrO = outs if outs is not None else (torch.empty_like(Ql), torch.empty_like(Qr))
     rc = slot.fn_update(Ql.data_ptr(), Qr.data_ptr(), dX.data_ptr(), dG.data_ptr(), QlO.data_ptr(), QrO.data_ptr(), M, N,
                         float(step), _tiny, slot.ws_ptr, slot.ws_bytes, st)
     if rc:
@@ -451,7 +558,7 @@ def _precond_grad_dense_dense(Ql, Qr, Grad):
     return _dd_apply_f32(Ql, Qr, Grad, Grad.shape[0], Grad.shape[1])
 
 
-def _dd_apply_f32(Ql, Qr, Grad, M, N):
+def _dd_apply_f32(Ql, Qr, Grad, M, N, out=None):
     """fp32 dense (x) dense apply on device tensors whose shapes, dtypes and devices the caller has checked.  Small layers
     are host-bound (LeNet5: a launch costs the GPU ~4 us, the reference's per-layer call pattern five calls per step), so
     this path is a handful of attribute reads, one allocation and ONE ctypes call."""
@@ -472,7 +579,8 @@ def _dd_apply_f32(Ql, Qr, Grad, M, N):
                 del _apply_slots[k]
     else:
         _kron_ws.touch(key)
-    out = torch.empty_like(Grad)
+    if out is None:
+        out = torch.empty_like(Grad)
     pl, pr = Ql.data_ptr(), Qr.data_ptr()
     # factor-only half (the Grams, kept in the workspace): redone only when these are not the very factor tensors (same
     # objects, same version counters, same storage) it was made from
@@ -491,7 +599,7 @@ def _dd_apply_f32(Ql, Qr, Grad, M, N):
             slot.prepared = True
             slot.path = "both"
     else:
-        if slot.fn_direct is not None:               # new factors, large layer: the Gram-free chain, nothing prepared
+        if slot.fn_direct is not None and _apply_route == "auto":      # new factors, large layer: the Gram-free chain, nothing prepared
             rc = slot.fn_direct(pl, pr, Grad.data_ptr(), out.data_ptr(), M, N, slot.ws_ptr, slot.ws_bytes, st)
             if rc:
                 _lib.check(rc, "psgd_kron_dd_apply_direct_f32")
@@ -538,9 +646,10 @@ def _batch_workspace(device, Ms, Ns):
     return _batch_ws.get(key, make)
 
 
-def precond_grad_kron_batched(Qls, Qrs, Grads):
+def precond_grad_kron_batched(Qls, Qrs, Grads, outs=None):
     """[precond_grad_kron(Ql, Qr, G) for ...] (mnist_with_lenet5.py:53) with the same stage of every
-    (dense, dense) layer in one kernel launch.  Other formats fall back to the per-layer call."""
+    (dense, dense) layer in one kernel launch.  Other formats fall back to the per-layer call.
+    outs: contiguous fp32 tensors to fill (layer_batch; only with lists the batched kernels take)."""
     Qls, Qrs, Grads = list(Qls), list(Qrs), list(Grads)
     if not (len(Qls) == len(Qrs) == len(Grads)):
         raise ValueError("precond_grad_kron_batched: the three lists must have one length")
@@ -550,7 +659,8 @@ def precond_grad_kron_batched(Qls, Qrs, Grads):
         _check_rank2_f32("precond_grad_kron_batched", a, b, g)
         _check_kron_shapes("precond_grad_kron_batched", a, b, g)
     Qls, Qrs, Grads = ([t.contiguous() for t in ts] for ts in (Qls, Qrs, Grads))
-    outs = [torch.empty_like(g) for g in Grads]
+    if outs is None:
+        outs = [torch.empty_like(g) for g in Grads]
     Ms, Ns = [g.shape[0] for g in Grads], [g.shape[1] for g in Grads]
     dev = Grads[0].device
     ws = _batch_workspace(dev, Ms, Ns)
@@ -569,9 +679,9 @@ def precond_grad_kron_batched(Qls, Qrs, Grads):
     return outs
 
 
-def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
+def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01, outs=None):
     """[update_precond_kron(Ql, Qr, dX, dG, step) for ...] (mnist_with_lenet5.py:51), batched as above.
-    Returns a list of (Ql_new, Qr_new)."""
+    Returns a list of (Ql_new, Qr_new).  outs: list of (QlOut, QrOut) to fill (layer_batch; all layers <= 512 only)."""
     Qls, Qrs, dXs, dGs = list(Qls), list(Qrs), list(dXs), list(dGs)
     if not (len(Qls) == len(Qrs) == len(dXs) == len(dGs)):
         raise ValueError("update_precond_kron_batched: the four lists must have one length")
@@ -594,7 +704,10 @@ def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01):
         _check_rank2_f32("update_precond_kron_batched", a, b, x, g)
         _check_kron_shapes("update_precond_kron_batched", a, b, x, g)
     Qls, Qrs, dXs, dGs = ([t.contiguous() for t in ts] for ts in (Qls, Qrs, dXs, dGs))
-    QlO, QrO = [torch.empty_like(t) for t in Qls], [torch.empty_like(t) for t in Qrs]
+    if outs is not None:
+        QlO, QrO = [o[0] for o in outs], [o[1] for o in outs]
+    else:
+        QlO, QrO = [torch.empty_like(t) for t in Qls], [torch.empty_like(t) for t in Qrs]
     Ms, Ns = [x.shape[0] for x in dXs], [x.shape[1] for x in dXs]
     dev = dXs[0].device
     ws = _batch_workspace(dev, Ms, Ns)
@@ -700,7 +813,13 @@ def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
     if _layer_ctx is not None:
         return _layer_ctx.run(update_precond_kron, (Ql, Qr, dX, dG, step))
     if _is_dd_f32(Ql, Qr, dX) and dG.shape == dX.shape and dG.dtype is _f32 and dG.device == dX.device:
+        if _batch_ctx is not None:
+            if dX.shape[0] <= _BATCH_MAX_DIM and dX.shape[1] <= _BATCH_MAX_DIM:
+                return _batch_ctx.update(Ql, Qr, dX, dG, step)
+            _batch_ctx.flush()                                                              # (keeps the issue order of the block)
         return _dd_update_f32(Ql, Qr, dX, dG, step, dX.shape[0], dX.shape[1])                # psgd.py:84
+    if _batch_ctx is not None:
+        _batch_ctx.flush()
     fmt = kron_format(Ql.shape, Qr.shape)
     _check_rank2_f32("update_precond_kron", Ql, Qr, dX, dG, allow_bf16_from=(2 if fmt == "dense_dense" else None))
     if fmt != "unknown":
@@ -727,7 +846,13 @@ def precond_grad_kron(Ql, Qr, Grad):
     if _layer_ctx is not None:
         return _layer_ctx.run(precond_grad_kron, (Ql, Qr, Grad))
     if _is_dd_f32(Ql, Qr, Grad):
+        if _batch_ctx is not None:
+            if Grad.shape[0] <= _BATCH_MAX_DIM and Grad.shape[1] <= _BATCH_MAX_DIM:
+                return _batch_ctx.apply(Ql, Qr, Grad)
+            _batch_ctx.flush()
         return _dd_apply_f32(Ql, Qr, Grad, Grad.shape[0], Grad.shape[1])                     # psgd.py:126
+    if _batch_ctx is not None:
+        _batch_ctx.flush()
     fmt = kron_format(Ql.shape, Qr.shape)
     _check_rank2_f32("precond_grad_kron", Ql, Qr, Grad, allow_bf16_last=(fmt == "dense_dense"))
     if fmt != "unknown":

@@ -281,9 +281,38 @@ def IpUVtmatvec(U, V, x):
     return out
 
 
+def _cols_of(name, x, N):
+    """A matrix operand [N, k] as k contiguous columns: its transpose, materialised once ([k, N] row-major; a transposed view of a
+    [k, N] tensor is used as it is)."""
+    if x.shape[0] != N:
+        raise ValueError("%s: the matrix must have N = %d rows" % (name, N))
+    xt = x.t()
+    return xt if xt.is_contiguous() else xt.contiguous()
+
+
 def precond_grad_UVd_math(U, V, d, g):
-    """psgd.py:619-627: d .* (I + V U')(I + U V')(d .* g); returns a new tensor shaped like g."""
-    U, V, d, g = _c(U), _c(V), _c(d), _c(g)
+    """psgd.py:619-627: d .* (I + V U')(I + U V')(d .* g); returns a new tensor shaped like g.
+    g is a column vector ([N] or [N, 1]) or, as the reference's docstring allows (:623), a matrix [N, k]: d broadcasts over
+    the columns and U, V are swept once per group of four columns (psgd_uvd_apply_cols_f32)."""
+    U, V, d = _c(U), _c(V), _c(d)
+    if isinstance(g, torch.Tensor) and g.dim() == 2 and g.shape[1] > 1:
+        dev = _require_hip("precond_grad_UVd_math", U, V, d)
+        if not g.is_cuda or g.dtype != torch.float32 or g.device != dev:
+            _require_hip("precond_grad_UVd_math", U, g)
+        N, r = _uvd_shapes("precond_grad_UVd_math", U, V, d)
+        gt = _cols_of("precond_grad_UVd_math", g, N)
+        k = gt.shape[0]
+        if r > _lib.UVD_MAX_RANK:
+            return _wide.precond_grad(U, V, d, [gt[j] for j in range(k)], uvd_workspace).t().contiguous()
+        ot = torch.empty_like(gt)
+        ws = uvd_workspace(dev, N, r)
+        gs = (ctypes.c_void_p * k)(*[gt[j].data_ptr() for j in range(k)])
+        os_ = (ctypes.c_void_p * k)(*[ot[j].data_ptr() for j in range(k)])
+        rc = _lib.load().psgd_uvd_apply_cols_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), gs, os_, k, N, r, ws.data_ptr(),
+                                                  ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "psgd_uvd_apply_cols_f32")
+        return ot.t().contiguous()
+    g = _c(g)
     dev = _require_hip("precond_grad_UVd_math", U, V, d, g)
     N, r = _uvd_shapes("precond_grad_UVd_math", U, V, d, g)
     if r > _lib.UVD_MAX_RANK:                      # wide rank: column chunks through the same kernels (uvd_wide.py)

@@ -142,20 +142,22 @@ def _no_reduce(t, op):
 
 
 def precond_grad(U, V, d, g, workspace_fn, reduce=_no_reduce):
-    """psgd.py:619-627 for r > 32."""
+    """psgd.py:619-627 for r > 32.  g: a column vector, or a LIST of k contiguous [N] columns of a matrix g (returns [k, N])."""
     cx = _Ctx(U, workspace_fn)
     Uc, Vc = cx.split(U), cx.split(V)
-    shape = g.shape
-    t = (d.reshape(-1) * g.reshape(-1)).contiguous()                           # :625
-    g1 = t.clone()
-    s1 = reduce(torch.stack([cx.colsums(Vc[k], [t]) for k in range(cx.c)]), "sum")       # V't, all chunks: one exchange
+    many = isinstance(g, (list, tuple))
+    dv = d.reshape(-1)
+    g1 = [(dv * x.reshape(-1)).contiguous() for x in (g if many else [g])]     # :625  t = d .* g
+    s1 = reduce(torch.stack([cx.colsums(Vc[k], g1) for k in range(cx.c)]), "sum")        # V't, all chunks: one exchange
     for k in range(cx.c):                                                      # g1 = t + U (V't)          :544
-        cx.axpy(Uc[k], [g1], s1[k])
-    out = g1.clone()
-    s2 = reduce(torch.stack([cx.colsums(Uc[k], [g1]) for k in range(cx.c)]), "sum")      # U'g1
+        cx.axpy(Uc[k], g1, s1[k])
+    out = [x.clone() for x in g1]
+    s2 = reduce(torch.stack([cx.colsums(Uc[k], g1) for k in range(cx.c)]), "sum")        # U'g1
     for k in range(cx.c):                                                      # g1 + V (U'g1)             :626
-        cx.axpy(Vc[k], [out], s2[k])
-    return (d.reshape(-1) * out).reshape(shape)
+        cx.axpy(Vc[k], out, s2[k])
+    if many:
+        return torch.stack([dv * x for x in out])
+    return (dv * out[0]).reshape(g.shape)
 
 
 def ipuvt_matvec(U, V, x, workspace_fn, reduce=_no_reduce):

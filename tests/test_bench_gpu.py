@@ -27,7 +27,21 @@ def test_bench_single_gpu_line(hip_lib):
                         "--no-kron", "--cpu-budget-s", "2"], cwd=ROOT, capture_output=True, text=True, timeout=580)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
+    # the ONE line stays under the 8 KB the driver's record keeps; the prose lives in DESIGN.md, the full record on stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][0]
+    assert len(line) < 8000 and '"note"' not in line
+    full = [l for l in r.stderr.splitlines() if l.startswith("BENCH_DETAIL ")]
+    assert len(full) == 1 and json.loads(full[0][13:])["value"] == pytest.approx(d["value"], rel=1e-5)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    # the figures the north star names, as scalars of `roofline` (what the driver's record keeps)
+    rf = d["roofline"]
+    for k in ("apply_ms", "apply_frac", "apply_frac_moved", "update_ms", "update_frac", "step_frac", "step_frac_moved",
+              "step_two_reference_calls_ms", "config2_step_us"):
+        assert isinstance(rf[k], float) and rf[k] > 0, k
+    assert rf["apply_frac"] == pytest.approx(340 * 4000000 / (rf["apply_ms"] * 1e-3) / 8e12, rel=1e-3)
+    cb = d["cpu_baseline"]
+    assert 1 <= cb["cores"] <= cb["thread_sweep_max"] <= cb["logical_cpus"]          # (the default 15-s budget sweeps to every CPU)
+    assert cb["full_n_value"] is None or cb["full_n_value"] > 1e6
     assert d["metric"] == "uvd_update_apply_params_per_sec" and d["unit"] == "params/s" and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 4000000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"} <= set(d["roofline"])

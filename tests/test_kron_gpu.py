@@ -1352,6 +1352,150 @@ def test_layer_streams_block_equals_serial_calls(psgd):
         assert torch.equal(o, c)
 
 
+def test_layer_streams_with_more_calls_than_streams_and_inline_arguments(psgd):
+    """with more calls than pool streams, call number streams + 1 onward ran on a stream that had waited for the
+    caller's stream only once, at its first use -- an argument computed inside the comprehension (on the caller's stream) could be
+    read before it was written, and a temporary dropped at the end of the call could be handed out again while still in use.
+    Now every call waits and its arguments are held until the block joins: 12 layers on 2 streams, every argument a temporary."""
+    from psgd_tf_amd import kron
+    g = torch.Generator(device="cuda").manual_seed(23)
+    shapes = [(151, 16), (257, 120), (121, 84), (85, 10), (300, 200), (26, 6)] * 2
+    Qs = [(torch.triu(torch.randn(m, m, device="cuda", generator=g)) * 0.1 + torch.eye(m, device="cuda"),
+           torch.triu(torch.randn(n, n, device="cuda", generator=g)) * 0.1 + torch.eye(n, device="cuda")) for m, n in shapes]
+    Gs = [torch.randn(m, n, device="cuda", generator=g) for m, n in shapes]
+    big = torch.randn(4096, 4096, device="cuda", generator=g)
+    ref = [psgd.precond_grad_kron(ql, qr, (gr * 1.5 + 0.25)) for (ql, qr), gr in zip(Qs, Gs)]
+    ref_u = [psgd.update_precond_kron(ql, qr, gr * 0.5, gr * 1.5 + 0.25, 0.02) for (ql, qr), gr in zip(Qs, Gs)]
+    torch.cuda.synchronize()
+    for rep in range(5):
+        junk = big @ big                                                  # the caller's stream is busy when the block starts
+        with kron.layer_streams(2):
+            got = [psgd.precond_grad_kron(ql, qr, (gr * 1.5 + 0.25)) for (ql, qr), gr in zip(Qs, Gs)]
+        with kron.layer_streams(2):
+            got_u = [psgd.update_precond_kron(ql, qr, gr * 0.5, gr * 1.5 + 0.25, 0.02) for (ql, qr), gr in zip(Qs, Gs)]
+        for a, c in zip(got, ref):
+            assert torch.equal(a, c), rep
+        for (a, b), (c, d) in zip(got_u, ref_u):
+            assert torch.equal(a, c) and torch.equal(b, d), rep
+        del junk
+
+
+def test_layer_batch_block_equals_the_batched_entry_points(psgd):
+    """kron.layer_batch: the reference's per-layer list comprehensions (mnist_with_lenet5.py:51, :53) inside the block run as ONE
+    batched call per kind when the block ends -- bit for bit the batched entry points' results, eager and captured; a layer above 512,
+    another format and bf16 operands inside the block run at once, in order; update -> apply with the NEW factors in one block works."""
+    from psgd_tf_amd import kron
+    rng = np.random.default_rng(17)
+    shapes = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (63, 120), (31, 1), (1, 1), (3, 3), (500, 512)]
+    Qls = [_dev(_tri_factor(rng, m) * 2.0) for m, n in shapes]
+    Qrs = [_dev(_tri_factor(rng, n)) for m, n in shapes]
+    dXs = [_dev(rng.standard_normal((m, n))) for m, n in shapes]
+    dGs = [_dev(rng.standard_normal((m, n))) for m, n in shapes]
+    Gs = [_dev(rng.standard_normal((m, n))) for m, n in shapes]
+    want_a = psgd.precond_grad_kron_batched(Qls, Qrs, Gs)
+    want_u = psgd.update_precond_kron_batched(Qls, Qrs, dXs, dGs, 0.01)
+    with kron.layer_batch():
+        got_u = [psgd.update_precond_kron(a, b, x, g, 0.01) for a, b, x, g in zip(Qls, Qrs, dXs, dGs)]        # :51
+    with kron.layer_batch():
+        got_a = [psgd.precond_grad_kron(a, b, g) for a, b, g in zip(Qls, Qrs, Gs)]                            # :53
+    for (a, b), (c, d) in zip(got_u, want_u):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    for a, c in zip(got_a, want_a):
+        assert torch.equal(a, c)
+    # one block for both comprehensions: the applies see the updated factors (a call of the other kind flushes the queue)
+    with kron.layer_batch():
+        new = [psgd.update_precond_kron(a, b, x, g, 0.01) for a, b, x, g in zip(Qls, Qrs, dXs, dGs)]
+        pre = [psgd.precond_grad_kron(a, b, g) for (a, b), g in zip(new, Gs)]
+    want_pre = psgd.precond_grad_kron_batched([a for a, _ in want_u], [b for _, b in want_u], Gs)
+    for a, c in zip(pre, want_pre):
+        assert torch.equal(a, c)
+    # a large layer, a sparse format and bf16 operands inside a block: they run at once, the small ones around them batched
+    M = 640
+    QlB, QrB = _dev(_tri_factor(rng, M)), _dev(_tri_factor(rng, 300))
+    GB = _dev(rng.standard_normal((M, 300)))
+    qn = _dev(np.stack([np.ones(77), np.zeros(77)]) + 0.01 * rng.standard_normal((2, 77)))
+    Gn = _dev(rng.standard_normal((26, 77)))
+    ref_big = psgd.precond_grad_kron(QlB.clone(), QrB.clone(), GB)
+    ref_nd = psgd.precond_grad_kron(Qls[0], qn, Gn)
+    ref_bf = psgd.precond_grad_kron(Qls[2], Qrs[2], Gs[2].bfloat16())
+    with kron.layer_batch():
+        mixed = [psgd.precond_grad_kron(Qls[0], Qrs[0], Gs[0]), psgd.precond_grad_kron(QlB.clone(), QrB.clone(), GB),
+                 psgd.precond_grad_kron(Qls[1], Qrs[1], Gs[1]), psgd.precond_grad_kron(Qls[0], qn, Gn),
+                 psgd.precond_grad_kron(Qls[2], Qrs[2], Gs[2].bfloat16()), psgd.precond_grad_kron(Qls[3], Qrs[3], Gs[3])]
+    for got, want in zip(mixed, (want_a[0], ref_big, want_a[1], ref_nd, ref_bf, want_a[3])):
+        assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        with kron.layer_batch():
+            with kron.layer_streams():
+                pass
+    # an exception inside the block leaves the module usable (nothing is launched for the abandoned queue)
+    with pytest.raises(ZeroDivisionError):
+        with kron.layer_batch():
+            psgd.precond_grad_kron(Qls[0], Qrs[0], Gs[0])
+            1 / 0
+    assert torch.equal(psgd.precond_grad_kron(Qls[0], Qrs[0], Gs[0]), want_a[0])
+    # captured: the graph holds the batched launches
+    n5 = 5
+    outs = [torch.empty_like(x) for x in Gs[:n5]]
+
+    def fn():
+        with kron.layer_batch():
+            res = [psgd.precond_grad_kron(a, b, g) for a, b, g in zip(Qls[:n5], Qrs[:n5], Gs[:n5])]
+        for o, r_ in zip(outs, res):
+            o.copy_(r_)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for o in outs:
+        o.zero_()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=side):
+        fn()
+    for _ in range(3):
+        gr.replay()
+    torch.cuda.synchronize()
+    for o, c in zip(outs, want_a[:n5]):
+        assert torch.equal(o, c)
+
+
+@pytest.mark.parametrize("M,N", [(4096, 4096), (2048, 1536), (1100, 2304), (257, 120)])
+def test_reference_apply_route_is_reproducible(psgd, M, N):
+    """kron.set_apply_route("reference"): always the association order of psgd.py:189-192 (Gram of the smaller side), no
+    first- / second-sight switch: three consecutive calls with identical inputs return identical bits (the default route's three
+    calls take three paths -- direct, prepare + apply, prepared -- whose bits differ in the last places at large shapes)."""
+    from psgd_tf_amd import kron
+    rng = np.random.default_rng(M + 5 * N)
+    Ql, Qr = _dev((_tri_factor(rng, M) * 1.3).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
+    G = _dev(rng.standard_normal((M, N)).astype(np.float32))
+    key = (G.get_device(), M, N, kron._raw_stream(G.get_device()))
+    old = kron.set_apply_route("reference")
+    try:
+        assert old == "auto"
+        kron.invalidate_factor_cache()
+        outs, paths = [], []
+        for _ in range(3):
+            outs.append(psgd.precond_grad_kron(Ql, Qr, G))
+            paths.append(kron._apply_slots[key].path)
+        assert paths == ["both", "prepared", "prepared"], paths
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        fresh = psgd.precond_grad_kron(Ql.clone(), Qr.clone(), G)          # new tensor objects, same values: same bits again
+        assert kron._apply_slots[key].path == "both" and torch.equal(fresh, outs[0])
+        if min(M, N) <= 2304:
+            ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
+            assert rel_err(outs[0].cpu().numpy(), ref) < TOL
+    finally:
+        kron.set_apply_route(old)
+    with pytest.raises(ValueError):
+        kron.set_apply_route("fastest")
+    if kron._apply_slots[key].fn_direct is not None:                       # large layer: the default route starts on the direct chain again
+        kron.invalidate_factor_cache()
+        psgd.precond_grad_kron(Ql, Qr, G)
+        assert kron._apply_slots[key].path == "direct"
+
+
 @pytest.mark.parametrize("M,N", [(1024, 1024), (1100, 520), (640, 2304), (2048, 1536)])
 def test_large_apply_paths_direct_both_prepared(psgd, M, N):
     """Large fp32 layers: factors seen for the first time take the Gram-free chain Ql' (Ql ((G Qr') Qr)) (psgd_kron_dd_apply_direct_f32:

@@ -77,6 +77,39 @@ def test_ipuvt_matvec(psgd, N, r):
                    orc.IpUVtmatvec(q["U"], q["V"], xv.cpu().numpy().astype(np.float64))) < APPLY_TOL
 
 
+@pytest.mark.parametrize("N,r", [(1021, 10), (5000, 20), (777, 3), (2049, 32), (300001, 10), (64, 1), (65, 17), (1, 4),
+                                 (3001, 40), (2500, 64), (1900, 50)])
+def test_precond_grad_with_a_matrix_g(psgd, N, r):
+    """psgd.py:619-627 with g a matrix (docstring :623 "either matrices or column vectors"): d broadcasts over the columns
+    (:625-626).  Every column against the fp64 oracle at 1e-5, and against the column-vector call on that column (the
+    four-column sweeps reduce on the matrix core in another order, so that comparison is to rounding, not bitwise)."""
+    p = make_uvd_problem(N, r, seed=5 * N + r, uv_gain=2.0, d_spread=0.4)
+    t, q = _to_dev(p), _f64(p)
+    cols = [q["g"], q["v"], q["h"] * 1e-2, q["g"] - q["v"], q["d"], q["g"] * q["v"]]
+    for k in (2, 4, 5):
+        G64 = np.concatenate(cols[:k], 1)
+        G = torch.from_numpy(G64.astype(np.float32)).cuda()
+        G0 = G.clone()
+        out = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], G)
+        assert out.shape == (N, k) and out.dtype == torch.float32 and out.is_contiguous()
+        assert torch.equal(G, G0)                                                # the input is not modified
+        ref = orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], G.cpu().numpy().astype(np.float64))
+        assert ref.shape == (N, k)
+        for j in range(k):
+            assert rel_err(out[:, j].cpu().numpy(), ref[:, j]) < APPLY_TOL, (k, j)
+            # ... and the column-vector call on the same column agrees to rounding
+            one = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], G[:, j:j + 1].contiguous())
+            assert rel_err(out[:, j:j + 1].cpu().numpy(), one.cpu().numpy().astype(np.float64)) < 1e-5, (k, j)
+    # a transposed view ([k, N] storage) goes in without a copy; d as [N] instead of [N, 1]
+    Gv = torch.from_numpy(np.concatenate(cols[:4], 1).astype(np.float32).T.copy()).cuda().t()
+    assert N == 1 or not Gv.is_contiguous()
+    out = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"].reshape(-1), Gv)
+    ref = orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], Gv.cpu().numpy().astype(np.float64))
+    assert rel_err(out.cpu().numpy(), ref) < APPLY_TOL
+    with pytest.raises(ValueError):
+        psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], torch.zeros(N + 1, 3, device="cuda"))
+
+
 @pytest.mark.parametrize("N,r", SHAPES)
 @pytest.mark.parametrize("update_U", [True, False])
 def test_update_matches_oracle(psgd, N, r, update_U):
