@@ -42,7 +42,8 @@ extern "C" {
  * keys retired / renumbered -- bf16 key 4 now selects the stream-K gradient launches, not the DMA position; the workspace of
  * psgd_kron_dd_update_bf16 gained the stream-K partial tiles (up to 128 MiB more for M, N multiples of 256) and padded W1 / W2
  * row strides: always size it with psgd_kron_dd_update_workspace_bytes_bf16);
- * 6 = round 5 (psgd_uvd_apply_cols_f32 added: precond_grad_UVd_math on a matrix g; no layout change).
+ * 6 = round 5 (psgd_uvd_apply_cols_f32 added: precond_grad_UVd_math on a matrix g; the fused strip kernels of small Kron layers
+ * and their tuning key 21 removed: Kron workspaces of small layers shrink back by that scratch).
  * psgd_tf_amd/_lib.py refuses a library whose psgd_abi_version() differs from the one it was written for. */
 #define PSGD_ABI_VERSION 6
 
@@ -284,7 +285,7 @@ int psgd_splu_update_stage4_f32(const float *L12, const float *l3, const float *
 int64_t psgd_kron_dd_workspace_bytes(int M, int N);
 
 /* Experiment knobs (not stable ABI; defaults in brackets).  Settled A/B keys were frozen into constants in round 4 (5, 8, 10, 13-15,
- * 17, 19, 20).  Keys 1, 4, 12, 16, 21 change what prepared state in a workspace means: prepare again after changing them.
+ * 17, 19, 20).  Keys 1, 4, 12, 16 change what prepared state in a workspace means: prepare again after changing them.
  *  0 fp32 GEMM tile: [0] auto, 1 = 64, 2 = 128, 3 = 32        1 [1] 128-tile products as fp32-accurate bf16 x 3 GEMMs, 0 = exact fp32 MFMA
  *  2 solve strips: [0] register-resident, 1 = LDS-resident      3 32-tile products: [1] k_gemm_small (ring of 4 K tiles), 0 = generic body
  *  4 [1] large products on operands split ONCE into planes (k_split3 / k_gemm_p3), 0 = split inside every GEMM tile
@@ -294,7 +295,6 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * 11 [1] M, N >= 2048: the solves of :174 as products with explicit inverses of diagonal blocks, 0 = substitution strips
  * 12 plane format: [2] f16 x 2 (x 2^e = h + 2^-11 M) in the large apply and update, 1 = apply only, 0 = bf16 x 3 everywhere
  * 16 [1] chained products write fp32 + max|C| and a split launch makes exact-scale planes, 0 = epilogue planes at a bound scale
- * 21 [0] small layers (M <= 512, N <= 256) on the stage kernels, 1 = fused strip kernels of psgd_kron_small.hip (opt-in, slower)
  * 23 [1] 512-blocks of an inverse from one strip launch (k_tri_inv512), 0 = k_tri_inv128 + doubling levels 128, 256
  * 24 [2048] block size h of the blocked solves on inverses of diagonal h-blocks, 0 = whole inverses, one product per solve;
  *    a value that would make more than 4 block columns per side (ceil(max(M, N) / h) > 4) is replaced by 2048 for that call

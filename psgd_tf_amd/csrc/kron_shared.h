@@ -52,15 +52,6 @@ int kron_inv_part_max();
 bool kron_inv_first(int M, int N);                           // the order rule (tuning key 25): both inversions ahead of the products of :173
 int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
 
-// Small layers (M, N <= 512; LeNet5) through the reference's per-layer calls: fused strip kernels (psgd_kron_small.hip), one launch
-// per call when one workgroup finishes the layer quickly, one per phase otherwise.  kron_small_fused: the shape rule (a pure
-// function of the shape); scratch: kron_small_ws_bytes(M, N) bytes, 256-aligned, contents need not survive between calls.
-bool kron_small_fused(int M, int N);
-int64_t kron_small_ws_bytes(int M, int N);
-int kron_small_apply(const float* Ql, const float* Qr, const float* G, float* out, int M, int N, void* scratch, hipStream_t st);
-int kron_small_update(const float* Ql, const float* Qr, const float* dX, const float* dG, float* QlOut, float* QrOut, int M, int N,
-                      float step, float tiny, void* scratch, hipStream_t st);
-
 // The update has two chains that meet only at the gradient products: the products dG QrS' -> QlS (.) (psgd.py:173) and
 // the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for
 // everything already on `main`; the caller puts one chain on it and kron_join makes `main` wait for that chain.

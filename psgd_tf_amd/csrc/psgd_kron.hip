@@ -2768,7 +2768,6 @@ struct KronWs {
   // levels' intermediate A^-1 B, planes of dX and of X1'
   __bf16 *IcL, *IcR, *TpL, *TpR, *DXp, *X1p;
   float *TfL, *TfR;
-  char* small;                                               // scratch of the fused small-layer kernels (kron_small_fused shapes)
   int64_t total;
 };
 
@@ -2851,8 +2850,6 @@ static KronWs kron_layout(char* base, int M, int N) {
       k.sk_cnt = reinterpret_cast<unsigned*>(take(kSkMaxTiles * 4));
     }
   }
-  k.small = nullptr;
-  if (kron_small_fused(M, N)) k.small = reinterpret_cast<char*>(take(kron_small_ws_bytes(M, N)));
   k.total = off;
   return k;
 }
@@ -3027,11 +3024,9 @@ constexpr int g_trsm_planes_min_k = 512;         // (frozen in round 4, was tuni
 constexpr int g_trsm_planes_min_tiles = 64;      // (frozen in round 4, was tuning key 14) ... and its least number of output tiles
 constexpr int g_trsm_planes_min_n = 1100;        // (frozen in round 4, was tuning key 15) the solves use planes when M or N exceeds this (tools/trsm_planes_n_ab.py:
                                               // 1300^2 0.629 -> 0.618 ms, 2048^2 0.915 -> 0.898, but 1024^2 0.342 -> 0.351)
-static int g_small_fused = 0;   // tuning key 21: 1 = single calls on small layers (kron_small_fused) run the fused strip kernels of
-                                // psgd_kron_small.hip; 0 (default) = the stage kernels: Grams + products, batch-of-one update.  Built to cut the
-                                // launches of the reference's per-layer call pattern (2 / 5 -> 1, or 1 per phase), parity-green, and SLOWER as
-                                // measured (profiles/r04_lenet_fused_ab.txt: LeNet5 set apply 106 vs 67 us, update 551 vs 299): one wave per
-                                // SIMD spends ~100 VALU instructions per 16-chunk on offsets and masks of unpadded operands; see DESIGN.md
+// (Round 4 built fused strip kernels for single calls on small layers -- psgd_kron_small.hip, tuning key 21: one launch per call --
+//  parity-green and SLOWER than the stage kernels (LeNet5 set: apply 106 vs 67 us, update 551 vs 299; profiles/r04_lenet_fused_ab.txt).
+//  Round 5 gave the per-layer call pattern the batched launches instead (kron.layer_batch: 53 / 84 us) and deleted them.)
 static int g_stage_mix = 3;     // tuning key 7: bit 0 = the batched small-layer update runs a product stage and a solve stage per launch;
                                 // bit 1 = a single update with M, N <= 512 takes the batched route (5 launches instead of 10-13)
 static int g_planes = 1;        // tuning key 4: 0 = large applies on k_gemm_x3 (operands split inside the GEMM)
@@ -4019,7 +4014,6 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 11) { g_trsm_inv = value; return PSGD_OK; }
   if (key == 12) { g_planes_f16 = value; return PSGD_OK; }
   if (key == 16) { g_planes_exact = value; return PSGD_OK; }
-  if (key == 21) { g_small_fused = value; return PSGD_OK; }
   if (key == 23) { g_inv_strip512 = value; return PSGD_OK; }
   if (key == 24) { g_inv_blk = value; return PSGD_OK; }
   if (key == 25) { g_inv_order = value; return PSGD_OK; }
@@ -4039,7 +4033,6 @@ int psgd_kron_dd_prepare_f32(const float* Ql, const float* Qr, int M, int N, voi
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  if (k.small && g_small_fused) return PSGD_OK;          // (the fused small-layer apply has no factor-only half)
   if (kron_planes_apply(M, N) && g_planes && g_gemm_x3) {
     KRON_LAUNCH(planes_prepare(Ql, Qr, M, N, k, st));
     return PSGD_OK;
@@ -4060,10 +4053,6 @@ int psgd_kron_dd_apply_prepared_f32(const float* Ql, const float* Qr, const floa
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   KronWs k = kron_layout(static_cast<char*>(ws), M, N);
-  if (k.small && g_small_fused) {
-    KRON_LAUNCH(kron_small_apply(Ql, Qr, G, out, M, N, k.small, st));
-    return PSGD_OK;
-  }
   if (kron_planes_apply(M, N) && g_planes && g_gemm_x3) {
     KRON_LAUNCH(planes_apply(G, out, M, N, k, st));
     return PSGD_OK;
@@ -4086,7 +4075,7 @@ int psgd_kron_dd_apply_f32(const float* Ql, const float* Qr, const float* G, flo
  * apply; the same as psgd_kron_dd_apply_f32 elsewhere.  Leaves no prepared state: psgd_kron_dd_apply_prepared_f32 needs a
  * psgd_kron_dd_prepare_f32 (or psgd_kron_dd_apply_f32) for these factors first. */
 static bool apply_direct_is_distinct(int M, int N) {
-  return !(g_small_fused && kron_small_fused(M, N)) && kron_planes_apply(M, N) && g_planes && g_gemm_x3 && g_planes_f16 && g_planes_exact;
+  return kron_planes_apply(M, N) && g_planes && g_gemm_x3 && g_planes_f16 && g_planes_exact;
 }
 /* 1 when psgd_kron_dd_apply_direct_f32 is a path of its own for this shape under the current tuning (else it is psgd_kron_dd_apply_f32,
  * which leaves prepared state) */
@@ -4110,13 +4099,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   if (!Ql || !Qr || !dX || !dG || !QlOut || !QrOut) return PSGD_ERR_BAD_ARG;
   if (M <= 0 || N <= 0) return PSGD_ERR_SHAPE;
   if (kron_ws_check(ws, ws_bytes, kron_layout(nullptr, M, N).total)) return PSGD_ERR_WORKSPACE;
-  // small layers are launch-bound: one launch (or one per phase) of the fused strip kernels
-  if (g_small_fused && kron_small_fused(M, N)) {
-    KronWs ks = kron_layout(static_cast<char*>(ws), M, N);
-    KRON_LAUNCH(kron_small_update(Ql, Qr, dX, dG, QlOut, QrOut, M, N, step, tiny, ks.small, static_cast<hipStream_t>(stream)));
-    return PSGD_OK;
-  }
-  // ... or the batch-of-one route with half the launches of the large-layer path (stages of independent chains share them)
+  // small layers are launch-bound: the batch-of-one route with half the launches of the large-layer path (stages of independent chains share them)
   if (M <= 512 && N <= 512 && (g_stage_mix & 2))
     return psgd_kron_dd_update_batched_f32(&Ql, &Qr, &dX, &dG, &QlOut, &QrOut, &M, &N, 1, step, tiny, ws, ws_bytes, stream);
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -107,10 +107,10 @@ def invalidate_factor_cache():
 def set_tuning(key, value):
     """psgd_kron_set_tuning through the Python boundary: keys that change what the prepared state in a workspace means
     (1: plane products or the in-GEMM split, 4: operand planes or not, 12: their format, 16: exact or bound-based scales -- the
-    C side gates the prepared form on all of them: fp32 Grams against planes --, 21: small layers with or without Grams) also
-    drop every prepared Gram / plane set, as the header requires."""
+    C side gates the prepared form on all of them: fp32 Grams against planes) also drop every prepared Gram / plane set, as the
+    header requires."""
     _lib.check(_lib.load().psgd_kron_set_tuning(int(key), int(value)), "psgd_kron_set_tuning")
-    if int(key) in (1, 4, 12, 16, 21):
+    if int(key) in (1, 4, 12, 16):
         invalidate_factor_cache()
         _apply_slots.clear()                         # (which apply paths a shape has is asked when its slot is made)
 

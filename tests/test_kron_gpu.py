@@ -39,13 +39,9 @@ def psgd(hip_lib):
 
 @pytest.fixture
 def stage_kernels(hip_lib):
-    """Single calls on small layers on the STAGE kernels (Grams + products, batch-of-one update: what the batched entry
-    points run; the default) and not on the opt-in fused strip kernels of psgd_kron_small.hip -- for the tests of those
-    stages' own variants."""
-    from psgd_tf_amd import kron
-    kron.set_tuning(21, 0)             # (the default; the wrapper also drops the prepared factor state, which differs per route)
+    """(Round 4's opt-in fused strip kernels are gone: single calls on small layers always run the stage kernels -- Grams + products,
+    batch-of-one update -- which the tests taking this fixture vary.)"""
     yield
-    kron.set_tuning(21, 0)
 
 
 @pytest.mark.parametrize("M,N", DD_SHAPES)
@@ -482,80 +478,12 @@ def test_small_gemm_bodies_bitwise_equal(psgd, hip_lib, stage_kernels, M, N):
     assert rel_err(outs[0][0].cpu().numpy(), ref) < TOL and rel_err(outs[0][3].cpu().numpy(), ref) < TOL
 
 
-SMALL_FUSED_SHAPES = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10), (1, 1), (1, 7), (31, 1), (2, 2), (16, 16), (17, 15),
-                      (15, 17), (33, 250), (512, 40), (500, 256), (63, 120), (128, 200), (300, 120), (160, 256), (48, 33)]
-
-
-@pytest.mark.parametrize("M,N", SMALL_FUSED_SHAPES)
-def test_small_fused_kernels_agree_with_stage_kernels(psgd, hip_lib, M, N):
-    """Single calls on small layers (the reference's call pattern, mnist_with_lenet5.py:51,53) have a second implementation,
-    the fused strip kernels of psgd_kron_small.hip (one launch, or one per phase; psgd_kron_set_tuning(21, 1): opt-in, measured
-    slower than the stage kernels); the default and the batched entry points run the stage kernels.  Same mathematics,
-    another association: the two agree to fp32 rounding, both hold the parity bars against the fp64 oracle, inputs are never
-    written, the new factors are upper triangular with the lower part of the balanced input (zeros), and a sequence of calls
-    on one workspace repeats bit for bit (no state left behind)."""
-    rng = np.random.default_rng(31 * M + N)
-    Ql, Qr = _tri_factor(rng, M) * 2.5, _tri_factor(rng, N)
-    dX, G = rng.standard_normal((M, N)), rng.standard_normal((M, N))
-    dG = (np.eye(M) + 0.1 * np.diag(rng.uniform(0, 5, M))) @ dX @ (np.eye(N) + 0.1 * np.diag(rng.uniform(0, 5, N)))
-    a32 = [a.astype(np.float32) for a in (Ql, Qr, dX, dG, G)]
-    a64 = [a.astype(np.float64) for a in a32]
-    t = [_dev(a) for a in a32]
-    from psgd_tf_amd import kron
-    res = {}
-    try:
-        for fused in (1, 0, 1):
-            kron.set_tuning(21, fused)
-            out = psgd.precond_grad_kron(t[0], t[1], t[4])
-            new = psgd.update_precond_kron(t[0], t[1], t[2], t[3], 0.01)
-            if fused and fused in res:
-                assert torch.equal(out, res[1][0]) and torch.equal(new[0], res[1][1]) and torch.equal(new[1], res[1][2])
-            res[fused] = (out, new[0], new[1])
-    finally:
-        kron.set_tuning(21, 0)
-    for a, b in zip(t, a32):
-        assert np.array_equal(a.cpu().numpy(), b)
-    ref_out = orc.precond_grad_kron(a64[0], a64[1], a64[4])
-    ref_new = orc.update_precond_kron(a64[0], a64[1], a64[2], a64[3], 0.01)
-    rho = np.sqrt(np.max(np.diag(a64[0])) / np.max(np.diag(a64[1])))
-    for fused in (1, 0):
-        out, ql, qr = (x.cpu().numpy() for x in res[fused])
-        assert rel_err(out, ref_out) < TOL, fused
-        for got, want, base in ((ql, ref_new[0], a64[0] / rho), (qr, ref_new[1], a64[1] * rho)):
-            assert rel_err(got, want) < TOL, fused
-            if np.linalg.norm(want - base) > 0:
-                assert rel_err(got.astype(np.float64) - base, want - base) < INCR_TOL, fused
-            assert np.array_equal(got, np.triu(got)) and (np.diag(got) > 0).all()
-    for i in range(3):
-        assert rel_err(res[1][i].cpu().numpy(), res[0][i].cpu().numpy()) < 2e-6, i
-
-
-@pytest.mark.parametrize("fused", [0, 1])
-def test_small_update_propagates_nan_and_ignores_the_lower_triangle(psgd, fused):
-    """NaN in the data reaches both new factors (tf.reduce_max semantics of psgd.py:177-178).  The fused strip kernels mask the
-    triangle element by element: whatever lies below the diagonal of an input factor is not read by any of their products or
-    solves (the stage kernels skip whole tiles below the diagonal and multiply the zeros of a diagonal tile, as the reference's
-    dense products do)."""
-    from psgd_tf_amd import kron
-    kron.set_tuning(21, fused)
-    try:
-        _nan_and_lower_triangle_case(psgd, fused)
-    finally:
-        kron.set_tuning(21, 0)
-
-
-def _nan_and_lower_triangle_case(psgd, fused):
+def test_small_update_propagates_nan(psgd):
+    """NaN in the data reaches both new factors (tf.reduce_max semantics of psgd.py:177-178)."""
     rng = np.random.default_rng(3)
     M, N = 121, 84
     Ql, Qr = _tri_factor(rng, M), _tri_factor(rng, N)
     dX, dG = rng.standard_normal((M, N)), rng.standard_normal((M, N))
-    ref = orc.update_precond_kron(Ql, Qr, dX, dG, 0.01)
-    if fused:
-        junk_l = Ql + np.tril(np.full((M, M), np.nan), -1)
-        got = psgd.update_precond_kron(_dev(junk_l), _dev(Qr), _dev(dX), _dev(dG), 0.01)
-        assert rel_err(np.triu(got[0].cpu().numpy()), ref[0]) < TOL and rel_err(got[1].cpu().numpy(), ref[1]) < TOL
-        out = psgd.precond_grad_kron(_dev(junk_l), _dev(Qr), _dev(dG))
-        assert rel_err(out.cpu().numpy(), orc.precond_grad_kron(Ql, Qr, dG)) < TOL
     dXn = dX.copy()
     dXn[5, 7] = np.nan
     bad = psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dXn), _dev(dG), 0.01)
@@ -767,19 +695,12 @@ def test_bf16_update_rejects_mixed_dtypes(psgd):
                                  torch.ones(8, 16, device="cuda"), torch.ones(8, 16, device="cuda"))
 
 
-@pytest.mark.parametrize("M,N,fused", [(257, 120, 1), (257, 120, 0), (85, 10, 1), (85, 10, 0), (16, 40, 0), (640, 1024, 1),
-                                       (1100, 1030, 1), (2049, 1024, 1)])
-def test_prepared_grams_follow_the_factors(psgd, hip_lib, M, N, fused):
+@pytest.mark.parametrize("M,N", [(257, 120), (85, 10), (16, 40), (640, 1024), (1100, 1030), (2049, 1024)])
+def test_prepared_grams_follow_the_factors(psgd, hip_lib, M, N):
     """fp32 apply: the Grams of the factors are kept in the workspace and recomputed only when the factors change (same
-    rules as the bf16 copies below); single and batched calls; small (both Grams: the stage kernels, fused = 0; the opt-in
-    fused strip kernels have no prepared state and must behave the same), large (reference-order Gram) and pre-split-plane
-    plans (M, N >= 1024: Gram and factor planes are the prepared state)."""
-    from psgd_tf_amd import kron
-    kron.set_tuning(21, fused)
-    try:
-        _prepared_grams_case(psgd, M, N)
-    finally:
-        kron.set_tuning(21, 0)
+    rules as the bf16 copies below); single and batched calls; small (both Grams), large (reference-order Gram) and
+    pre-split-plane plans (M, N >= 1024: Gram and factor planes are the prepared state)."""
+    _prepared_grams_case(psgd, M, N)
 
 
 def _prepared_grams_case(psgd, M, N):
@@ -1074,17 +995,10 @@ def test_every_gemm_tile_size_forced(psgd, hip_lib, stage_kernels, M, N, tile_ch
     assert rel_err(Ql_n.cpu().numpy(), Ql_r) < TOL and rel_err(Qr_n.cpu().numpy(), Qr_r) < TOL
 
 
-@pytest.mark.parametrize("fused", [0, 1])
-def test_batched_lenet_set_equals_per_layer(psgd, hip_lib, fused):
-    """The batched calls must agree with the per-layer results.  Per-layer calls on the stage kernels (fused = 0): bitwise for
-    the GEMM-only apply; the update's triangular solves may take a different blocking per path, so those agree to rounding.
-    Per-layer calls on the fused strip kernels (opt-in): another association of the same products -- to rounding."""
-    from psgd_tf_amd import kron
-    kron.set_tuning(21, fused)
-    try:
-        _batched_vs_per_layer(psgd, fused)
-    finally:
-        kron.set_tuning(21, 0)
+def test_batched_lenet_set_equals_per_layer(psgd, hip_lib):
+    """The batched calls must agree with the per-layer results: bitwise for the GEMM-only apply; the update's triangular solves
+    may take a different blocking per path, so those agree to rounding."""
+    _batched_vs_per_layer(psgd, 0)
 
 
 def _batched_vs_per_layer(psgd, fused):
