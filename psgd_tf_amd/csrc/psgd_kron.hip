@@ -701,7 +701,12 @@ struct P3 {
   const __bf16* p;
   long ts, ps;
   const PlaneMeta* meta;   // f16 x 2 format only: of the matrix these planes hold (device memory)
+  const int* te;           // f16 x 2, TILE scales (round 5; see "tile scales" below): te[xb * kTeLd + kb] = e with scale 2^e of the
+                           // 128 x 128 tile (x block xb, k block kb) of this view, kTeAny for an all-zero tile; nullptr = one scale (meta)
 };
+constexpr int kTeLd = 64;                 // tiles per table row: extents up to 8192
+constexpr int kTeAny = -(1 << 30);        // an all-zero tile: any scale
+constexpr int kTeUnset = -(1 << 30) + 1;  // (p3_pass: no tile seen yet)
 
 // ---- the second plane format (round 3): x 2^e = h + 2^-11 M with h, M in fp16 ("f16 x 2") -----------------------------
 // Two planes and THREE matrix-core products per term instead of three planes and six: h h' into the accumulators, M h' and
@@ -762,6 +767,11 @@ struct P3Args {
   PlaneMeta* ometa;
   const PlaneMeta *oa, *ob, *oa2, *ob2;
   float okmul, okmul2;
+  // f16 x 2 plane outputs with TILE scales: every 128 x 128 tile of C at the scale of its own maximum, written by the epilogue that
+  // holds it -- no fp32 round trip, no max|C| over the grid, no split launch.  te_row[(m0 / 128) * kTeLd + n0 / 128] / te_col[(n0 / 128) *
+  // kTeLd + m0 / 128] receive the tile's exponent (the tables of Crow / Ccol).  Null: the output's scale comes from ometa as before.
+  int *te_row, *te_col;
+  int neg;               // (tile-scale outputs only) the result is -(A B ...): the inverse levels' -T = -(A^-1 B)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr3_t;
@@ -789,14 +799,35 @@ template <int FMT>
 struct P3Lds {
   u32x4_k P[FMT ? 2 : 1][2][FMT ? 2 : 3][128 * 4];    // [stage][A|B][plane][row * 4 + (chunk ^ lds_swz(row))]
   unsigned ticket[4];                                  // (split-K: the arrival number of this block)
+  float red[4];                                        // (tile scales: the waves' maxima of the finished tile)
 };
+
+// ---- tile scales (round 5) ------------------------------------------------------------------------------------------------------
+// A matrix-wide scale needs max|C| over the whole grid before the first plane element can be written: every chained product was
+// "product (fp32 out + atomic max) -> split launch", and those launches were a quarter of the large update's critical path (657 of
+// 2616 us at 4096^2, two of them 140 us each beside a full-chip product of the other stream; profiles/r04_kron_update_trace_f32.txt).
+// A scale only has to be constant along the K range ONE accumulation runs over -- and fp32 accumulators can be moved from one
+// power-of-two scale to another exactly (v_ldexp_f32).  So a producer tile writes its planes at the scale of ITS OWN maximum, straight
+// from the accumulators, and leaves the exponent in a table; a consumer's K loop looks up the exponents of its A and B tiles at every
+// 128-k boundary (lane-held: one v_readlane each) and, when their sum differs from the scale its accumulators are at, shifts the
+// accumulators (128 v_ldexp_f32, only when the scale changes).  Tighter scales than one per matrix, no extra launch, no fp32 round trip.
+// Accumulators are at the scale of the tile in hand: they overflow only if a row of tiles spans > 2^80 in magnitude.
+__device__ __forceinline__ int p3_exp_of_scale(float s) { return (int)((__float_as_uint(s) >> 23) & 255u) - 127; }
+template <int FMT>
+__device__ __forceinline__ int p3_tile_exps(const P3& X, int x0, int lo, int hi) {      // lane l: exponent of K tile (lo / 128 + l)
+  if constexpr (FMT != 1) return 0;
+  const int lane = threadIdx.x & 63;
+  if (!X.te) return p3_exp_of_scale(X.meta->scale);
+  const int kb0 = lo >> 7, nkb = ((hi + 127) >> 7) - kb0;
+  return X.te[(x0 >> 7) * kTeLd + kb0 + min(lane, nkb - 1)];
+}
 
 // K tiles [lo, hi) of one operand pair.  LDS image as in k_gemm_x3: [A|B][plane][row * 4 + (chunk ^ swz(row))].  The DMA
 // writes linearly (wave base + 16 B * lane), so the swizzle is applied to the per-lane SOURCE address: the lane that
 // fills slot s = row * 4 + cpos fetches chunk cpos ^ swz(row) of that row.
-template <int FMT, int ER>
+template <int FMT, int ER, bool TS = false>
 __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0, int lo, int hi, P3Lds<FMT>& L,
-                                        f32x4 (&acc)[4][4]) {
+                                        f32x4 (&acc)[4][4], int* cur_exp = nullptr) {
   constexpr int EARLY = p3_early(FMT, ER);
   constexpr int NP = FMT ? 2 : 3;
   constexpr int W = 64, NT = 4;
@@ -829,6 +860,13 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
 #pragma unroll
       for (int j = 0; j < NT; ++j) cross[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
+  // tile scales: the exponents of this row of A tiles / B tiles, one K tile per lane (requested ahead of the DMA: older in vmcnt order)
+  int vexpA = 0, vexpB = 0, cur = kTeUnset;
+  if constexpr (TS) {
+    vexpA = p3_tile_exps<FMT>(A, m0, lo, hi);
+    vexpB = p3_tile_exps<FMT>(B, n0, lo, hi);
+    cur = *cur_exp;
+  }
   issue(lo, 0);
   if (NS == 2 && lo + kX3K < hi) issue(lo + kX3K, 1);
   int st = 0;
@@ -839,6 +877,28 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     P3_FENCE();
     if (!(X3_DBG & 16)) __builtin_amdgcn_s_barrier();           // every wave's part of this K tile has landed
     P3_FENCE();
+    if constexpr (TS && FMT == 1) {
+      if ((k0 & 127) == 0 || k0 == lo) {                        // a new 128-k tile: are the accumulators at its scale?
+        const int kb = __builtin_amdgcn_readfirstlane((k0 >> 7) - (lo >> 7));
+        const int ea = __builtin_amdgcn_readlane(vexpA, kb), eb = __builtin_amdgcn_readlane(vexpB, kb);
+        if (ea != kTeAny && eb != kTeAny) {                     // (an all-zero tile adds zeros at any scale)
+          const int c = ea + eb;
+          if (cur != kTeUnset && c != cur) {
+            const int d = c - cur;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  acc[i][j][e] = ldexpf(acc[i][j][e], d);
+                  cross[i][j][e] = ldexpf(cross[i][j][e], d);
+                }
+          }
+          cur = c;
+        }
+      }
+    }
     bf16x8_k a[NT][NP], b[NT][NP];
     const bool skip_reads = (X3_DBG & 8) && k0 != lo;           // (what-if: fragments of the first step reused)
     auto read_b = [&](int j) {
@@ -905,21 +965,25 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] += cross[i][j] * 0.00048828125f;
   }
+  if constexpr (TS) *cur_exp = cur;
 }
 // plane outputs of a C tile (pads inside the padded extents are written as zeros)
 template <int FMT>
 __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&acc)[4][4], int m0, int n0, bool do_row,
-                                                bool do_col) {
+                                                bool do_col, float tile_sc = 0.0f) {      // tile_sc != 0: this tile's own scale (tile scales)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1;
   const bool odd = lane & 1;
   if constexpr (FMT == 1) {
     // the output's scale from the bound its host described (the same in every block), its actual maximum for its consumers
-    float bound = g.okmul * g.oa->amax * g.ob->amax;
-    if (g.oa2) bound += g.okmul2 * g.oa2->amax * g.ob2->amax;
-    const float sc = plane_scale_of_bound(bound);
-    if (threadIdx.x == 0) {            // (every block that gets here: under a K split any block may be a tile's last one)
-      g.ometa->scale = sc; g.ometa->inv = 1.0f / sc; g.ometa->bound = bound;
+    float sc = tile_sc;
+    if (tile_sc == 0.0f) {
+      float bound = g.okmul * g.oa->amax * g.ob->amax;
+      if (g.oa2) bound += g.okmul2 * g.oa2->amax * g.ob2->amax;
+      sc = plane_scale_of_bound(bound);
+      if (threadIdx.x == 0) {            // (every block that gets here: under a K split any block may be a tile's last one)
+        g.ometa->scale = sc; g.ometa->inv = 1.0f / sc; g.ometa->bound = bound;
+      }
     }
     float vmax = 0.0f;
 #pragma unroll
@@ -959,6 +1023,7 @@ __device__ __forceinline__ void p3_store_planes(const P3Args& g, const f32x4 (&a
           }
         }
       }
+    if (tile_sc != 0.0f) return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
     if (lane == 0) atomic_amax(&g.ometa->amax, vmax);
@@ -1019,15 +1084,17 @@ __device__ __forceinline__ void pow2_halves(double v, float& m1, float& m2) {   
   m1 = ldexpf(1.0f, h); m2 = ldexpf(1.0f, e - h);
 }
 
-template <int FMT = 0, int ER = 2>
+template <int FMT = 0, int ER = 2, bool TS = false>
 __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<FMT>& L, const P3Split sp = P3Split{-1, 0, nullptr, nullptr}) {
   constexpr int TM = 128, TN = 128, GK = kX3K;
+  static_assert(!TS || FMT == 1, "tile scales are a property of the f16 x 2 format");
+  int cur = kTeUnset;                   // (TS) the power-of-two scale the accumulators are at
   // f16 x 2: what brings a pair's accumulators back to real values (2^-(eA + eB), exact)
   // (2^-(eA + eB) can leave the fp32 range where the real result does not: kept in double, applied as two balanced
   // power-of-two factors -- the intermediate lies between the accumulator and the result, so it is in range when they are)
   float ia1 = 1.0f, ib1 = 1.0f, ia2 = 1.0f, ib2 = 1.0f;
   double inv1 = 1.0, inv2 = 1.0;
-  if constexpr (FMT == 1) {
+  if constexpr (FMT == 1 && !TS) {
     inv1 = (double)g.A.meta->inv * g.B.meta->inv;
     pow2_halves(inv1, ia1, ib1);
     if (g.e.A2) { inv2 = (double)g.A2.meta->inv * g.B2.meta->inv; pow2_halves(inv2, ia2, ib2); }
@@ -1055,9 +1122,19 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
     hi = ((hi + GK - 1) / GK) * GK;
     const int steps = (hi - lo) / GK, per = (steps + per_pair - 1) / per_pair;
     const int clo = lo + sub * per * GK, chi = min(hi, clo + per * GK);
-    p3_pass<FMT, ER>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc);
+    p3_pass<FMT, ER, TS>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, clo, chi, L, acc, &cur);
     f32x4* mine = reinterpret_cast<f32x4*>(sp.scratch) + (long)sp.chunk * (16 * kThreads);
-    const float pa = p ? -ia2 : ia1, pb = p ? ib2 : ib1;   // partials are stored as real values (f16 x 2: each pair has its own scale)
+    float pa = p ? -ia2 : ia1, pb = p ? ib2 : ib1;   // partials are stored as real values (f16 x 2: each pair has its own scale)
+    if constexpr (TS) {                                // (tile scales: back from wherever the chunk's last tile left the accumulators)
+      const int back = cur == kTeUnset ? 0 : -cur;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = ldexpf(acc[i][j][e], back);
+      pa = p ? -1.0f : 1.0f; pb = 1.0f;
+    }
     // Hand-off (the fused bf16 pair's recipe): the partial goes out write-through (8-byte agent-scope stores), every wave
     // drains its stores, the block's barrier, one lane takes the ticket; the last block to arrive does one agent-scope
     // acquire.  A __threadfence() here instead is a release of the WHOLE L2 (buffer_wbl2) per block: it made a split item
@@ -1093,7 +1170,7 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
     // the subtracted pair first, then one sign flip of the accumulators.  (f16 x 2: the pairs have their own units,
     // 2^-(eA + eB); the pair with the FINER unit goes first and its sums are carried over to the coarser unit -- a factor
     // <= 1, so nothing overflows however far apart the two products are)
-    const bool swap = FMT == 1 && g.e.A2 && inv2 > inv1;
+    const bool swap = FMT == 1 && !TS && g.e.A2 && inv2 > inv1;
 #pragma unroll 1
     for (int it = g.e.A2 ? 1 : 0; it >= 0; --it) {
       const int p = swap ? 1 - it : it;
@@ -1107,21 +1184,31 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
       if (km & KBLK_LO_N) lo = max(lo, (n0 / g.e.kblk) * g.e.kblk + g.e.kblk / 2);
       lo = (lo / GK) * GK;
       hi = ((hi + GK - 1) / GK) * GK;                 // the planes are zero-padded to whole K tiles
-      p3_pass<FMT, ER>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc);
+      p3_pass<FMT, ER, TS>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc, &cur);
       if (it) {                                        // (f16 x 2: and over to the other pair's unit, a power of two)
-        const float flip = (FMT == 1) ? -(float)((p ? inv2 : inv1) / (p ? inv1 : inv2)) : -1.0f;     // (<= 1 in magnitude)
+        // (tile scales: only the sign -- the second pass moves the accumulators to its own tiles' scales like any change of tile)
+        const float flip = (FMT == 1 && !TS) ? -(float)((p ? inv2 : inv1) / (p ? inv1 : inv2)) : -1.0f;     // (<= 1 in magnitude)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] *= flip;
       }
     }
-    if constexpr (FMT == 1) {                          // back to real values (the last pair's unit; A - B either way)
+    if constexpr (FMT == 1 && !TS) {                   // back to real values (the last pair's unit; A - B either way)
       const float fa = swap ? -ia2 : ia1, fb = swap ? ib2 : ib1;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] * fa) * fb;
+    }
+    if constexpr (TS) {
+      const int back = cur == kTeUnset ? 0 : -cur;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = ldexpf(acc[i][j][e], back);
     }
   }
   if (g.e.scale_max) {                                // (step / max) A B = step / max (A B): applied to the finished sums
@@ -1168,36 +1255,93 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
       if (lane == 0) atomic_amax(&g.ometa->amax, vmax);
     }
   }
+  if constexpr (TS) {
+    if (g.te_row || g.te_col) {
+      // tile scales: this tile's planes at the scale of its own maximum, from the registers that hold it.  The fp32 store (when the
+      // caller wants one) happens here too, because the planes are of the FINAL values: D - acc for a D-minus epilogue, col >= row
+      // for a triu epilogue, -acc under g.neg.  (No column scales, no mirrored store: the launchers keep such products off this path.)
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      const long ccs = g.e.c_cs ? g.e.c_cs : 1;
+      if (g.e.epi == EPI_D_MINUS) {                      // every D element requested before the first use (see gemm_epilogue)
+        f32x4 dv[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int row = min(m0 + (w >> 1) * 64 + i * 16 + (lane >> 4) * 4 + e, g.e.M - 1);
+              const int col = min(n0 + (w & 1) * 64 + j * 16 + (lane & 15), g.e.N - 1);
+              dv[i][j][e] = g.e.D[(long)row * g.e.ldd + col * ccs];
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = dv[i][j] - acc[i][j];
+      }
+      float vmax = 0.0f;
+      const float sgn = g.neg ? -1.0f : 1.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = m0 + (w >> 1) * 64 + i * 16 + (lane >> 4) * 4 + e, col = n0 + (w & 1) * 64 + j * 16 + (lane & 15);
+            const bool in = row < g.e.M && col < g.e.N;
+            const float v = (in && (g.e.epi != EPI_TRIU_MAX || col >= row)) ? acc[i][j][e] * sgn : 0.0f;
+            acc[i][j][e] = v;
+            vmax = amaxf(vmax, fabsf(v));
+            if (g.e.C && in) g.e.C[(long)row * g.e.ldc + col * ccs] = v;
+          }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+      if (g.e.epi == EPI_TRIU_MAX && g.e.C && lane == 0) atomic_amax(g.e.maxout, vmax);     // (C == nullptr: done on the registers above)
+      __syncthreads();
+      if (lane == 0) L.red[w] = vmax;
+      __syncthreads();
+      vmax = amaxf(amaxf(L.red[0], L.red[1]), amaxf(L.red[2], L.red[3]));
+      const float sc = plane_scale_of_bound(vmax);
+      const bool do_col = g.Ccol != nullptr && (!g.e.sym || n0 > m0);
+      if (threadIdx.x == 0) {
+        const int ex = (__float_as_uint(vmax) == 0u) ? kTeAny : p3_exp_of_scale(sc);
+        if (g.te_row) g.te_row[(m0 >> 7) * kTeLd + (n0 >> 7)] = ex;
+        if (g.te_col && do_col) g.te_col[(n0 >> 7) * kTeLd + (m0 >> 7)] = ex;
+      }
+      p3_store_planes<FMT>(g, acc, m0, n0, g.Crow != nullptr, do_col, sc);
+      return;
+    }
+  }
   if (g.e.C) gemm_epilogue<128>(g.e, acc, m0, n0);
   // a symmetric product (Gram) names the same buffer twice: the mirror image is the transposed store of the tiles above
   // the diagonal (a diagonal tile holds both halves itself)
   if (g.Crow || g.Ccol) p3_store_planes<FMT>(g, acc, m0, n0, g.Crow != nullptr, g.Ccol != nullptr && (!g.e.sym || n0 > m0));
 }
 
-template <int FMT, int ER = 2>
+template <int FMT, int ER = 2, bool TS = false>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3(P3Args g) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   int by, bx;
   gemm_tile_order(g.e.kmode, by, bx);
-  p3_body<FMT, ER>(g, by, bx, L);
+  p3_body<FMT, ER, TS>(g, by, bx, L);
 }
 
 // The off-diagonal b x b blocks (rows of the first half, columns of the second half) of every 2b-block on the diagonal of
 // an n x n product: the tiles of one doubling level of a triangular inverse (tri_inverse), b a multiple of 128.
-template <int FMT, int ER = 2>
+template <int FMT, int ER = 2, bool TS = false>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_blk(P3Args g, int b) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   const int tb = b / 128, per = tb * tb;
   const int p = blockIdx.x / per, r = blockIdx.x % per;
   const int by = (p * 2 * b) / 128 + r / tb, bx = (p * 2 * b + b) / 128 + r % tb;
   if (by * 128 >= g.e.M || bx * 128 >= g.e.N) return;
-  p3_body<FMT, ER>(g, by, bx, L);
+  p3_body<FMT, ER, TS>(g, by, bx, L);
 }
 
 // two independent products in one grid (see k_gemm_x3_pair)
 struct P3Pair { P3Args g[2]; int tiles0, tx0, tx1, tiles1; };
 
-template <int FMT, int ER = 2>
+template <int FMT, int ER = 2, bool TS = false>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   int which, id;
@@ -1205,7 +1349,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_pair(P3Pair p) {
   const P3Args& g = p.g[which];
   int by, bx;
   gemm_tile_from_id(id, (g.e.M + 127) / 128, which ? p.tx1 : p.tx0, g.e.kmode, by, bx);
-  p3_body<FMT, ER>(g, by, bx, L);
+  p3_body<FMT, ER, TS>(g, by, bx, L);
 }
 
 // The two gradient products of the update (psgd.py:175-176) in one grid: upper tiles only (the planes of a triu result are
@@ -1244,7 +1388,7 @@ __device__ __forceinline__ void upper_tile_patched(int idx, int T, int& r, int& 
   r = 4 * pr + tr; c = 4 * pc + tc;
 }
 
-template <int FMT, int ER = 2>
+template <int FMT, int ER = 2, bool TS = false>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   const int whole1 = p.n1 - p.nsplit;
@@ -1260,14 +1404,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
   const bool patched = p.order == 2 && !(p.T0 & 3) && !(p.T1 & 3);
   if (id < p.n0) {
     if (patched) upper_tile_patched(id, p.T0, r, c); else upper_tile(id, p.T0, r, c);
-    p3_body<FMT, ER>(p.g[0], r, c, L);
+    p3_body<FMT, ER, TS>(p.g[0], r, c, L);
   } else if (id < p.n0 + whole1) {
     if (patched) upper_tile_patched(id - p.n0, p.T1, r, c); else upper_tile(id - p.n0, p.T1, r, c);
-    p3_body<FMT, ER>(p.g[1], r, c, L);
+    p3_body<FMT, ER, TS>(p.g[1], r, c, L);
   } else {
     const int s = id - p.n0 - whole1, t = s / p.nchunk;
     if (patched) upper_tile_patched(whole1 + t, p.T1, r, c); else upper_tile(whole1 + t, p.T1, r, c);
-    p3_body<FMT, ER>(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
+    p3_body<FMT, ER, TS>(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
   }
 }
 
@@ -1285,14 +1429,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk(P3Args g, int T,
 
 // The same for any product (all tiles, in the usual tile order): shapes with few output tiles -- a 128 x 4096 apply is one
 // row of 32 tiles, each a chain of 128 K steps -- leave most of the chip idle and are bound by that chain.
-template <int FMT>
+template <int FMT, bool TS = false>
 __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_splitk_rect(P3Args g, int ty, int tx, int nchunk, float* scratch,
                                                                      unsigned* cnt) {
   __shared__ __attribute__((aligned(16))) P3Lds<FMT> L;
   const int t = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
   int by, bx;
   gemm_tile_from_id(t, ty, tx, g.e.kmode, by, bx);
-  p3_body<FMT>(g, by, bx, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
+  p3_body<FMT, 2, TS>(g, by, bx, L, P3Split{chunk, nchunk, scratch + (long)t * nchunk * (64 * kThreads), cnt + t});
 }
 
 // fp32 view X(r, c) = X[r * rs + c * cs], r < R, c < C  ->  planes with x = r, k = c (zeros outside R x C; the grid covers
@@ -2755,6 +2899,8 @@ __global__ __launch_bounds__(kFinThreads) void k_balance_generic(const float* __
 // ------------------------------------------------------------- host side ----
 static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
+// tile-exponent tables (KronWs::te), one per transient plane buffer
+enum { kTeU0 = 0, kTeU1, kTeU2, kTeU3, kTeY0, kTeY1, kTeY2, kTeG1, kTeG2, kTeIcL, kTeIcR, kTeTpL, kTeTpR, kTeDXp, kTeX1p, kTeSlots = 16 };
 struct KronWs {
   float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv, *Pl, *Pr;
   __bf16 *PP, *F1, *F2, *Y0, *Y1, *Y2;     // operand planes of the large apply (kron_planes): Gram, factor, its transpose; 3 transients
@@ -2763,6 +2909,7 @@ struct KronWs {
   float* sk_scratch; unsigned* sk_cnt;                       // split-K of products with few output tiles (launch_p3_auto)
   __bf16* S0;                                                // planes of one [max(M, N) x 2048] group of the solves
   PlaneMeta* pmeta;                                          // f16 x 2 planes: scales and maxima (kPm* slots)
+  int* te;                                                   // ... tile-exponent tables of the transient plane sets (kTe* slots of kTeTable ints)
   float* pm_part;                                            // ... partial maxima: 4 arrays of kPmPartMax (main stream, side stream, QlS, QrS)
   // the solves through explicit inverses (kron_inv_route): column-form planes of the two inverses, planes and fp32 of the
   // levels' intermediate A^-1 B, planes of dX and of X1'
@@ -2822,7 +2969,7 @@ static KronWs kron_layout(char* base, int M, int N) {
   k.PP = k.F1 = k.F2 = k.Y0 = k.Y1 = k.Y2 = nullptr;
   k.Lr = k.Lc = k.Rr = k.Rc = k.G1 = k.G2 = k.U0 = k.U1 = k.U2 = k.U3 = nullptr;
   k.split_scratch = nullptr; k.split_cnt = nullptr; k.S0 = nullptr;
-  k.sk_scratch = nullptr; k.sk_cnt = nullptr; k.pmeta = nullptr; k.pm_part = nullptr;
+  k.sk_scratch = nullptr; k.sk_cnt = nullptr; k.pmeta = nullptr; k.pm_part = nullptr; k.te = nullptr;
   k.IcL = k.IcR = k.TpL = k.TpR = k.DXp = k.X1p = nullptr; k.TfL = k.TfR = nullptr;
   if (kron_planes(M, N)) {
     const int64_t Mp = pad128(M), Np = pad128(N), small = Mp < Np ? Mp : Np, big = Mp < Np ? Np : Mp;
@@ -2840,6 +2987,7 @@ static KronWs kron_layout(char* base, int M, int N) {
     k.S0 = planes(big * 2048);
     k.pmeta = reinterpret_cast<PlaneMeta*>(take(1024));      // kPmSlots x 16 B
     k.pm_part = take(4 * 2048 * 4);
+    k.te = reinterpret_cast<int*>(take((int64_t)kTeSlots * kTeLd * kTeLd * 4));
     if (kron_inv_route(M, N)) {
       k.IcL = planes(Mp * Mp); k.TpL = planes(Mp * Mp); k.TfL = take(mm);
       k.IcR = planes(Np * Np); k.TpR = planes(Np * Np); k.TfR = take(nn);
@@ -3042,9 +3190,12 @@ static int balance_grid(int M, int N) {                // workgroups of the bala
   return grid > 1024 ? 1024 : (int)grid;
 }
 // (f16 x 2, planes split from fp32 data: part[0 .. npart) = the partial maxima of |X| that the launch ahead left)
-struct P3Buf { __bf16* p; long rows, ld; PlaneMeta* meta = nullptr; const float* part = nullptr; int npart = 0; };
+// te: the table of tile exponents of a plane set written with TILE scales (kTeLd x kTeLd ints, indexed [x / 128][k / 128]); null = one
+// scale for the matrix (meta)
+struct P3Buf { __bf16* p; long rows, ld; PlaneMeta* meta = nullptr; const float* part = nullptr; int npart = 0; int* te = nullptr; };
 constexpr int kPmPartMax = 2048;      // partial maxima per array (KronWs::pm_part holds four arrays)
-static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld, b.meta}; }
+static P3 p3_of(const P3Buf& b) { return P3{b.p, b.rows * 32, b.rows * b.ld, b.meta, b.te}; }
+constexpr int kTeTable = kTeLd * kTeLd;        // ints per table
 // slots of KronWs::pmeta
 enum { kPmPP = 0, kPmF = 1, kPmQs = 2, kPmG = 4, kPmT = 5, kPmA = 6,                       // the apply (0, 1: prepared state)
        kPmL = 8, kPmR = 9, kPmdG = 10, kPmUT = 11, kPmUA = 12, kPmBt = 13, kPmG1 = 14, kPmG2 = 15,   // the update ...
@@ -3128,8 +3279,18 @@ static void p3_out_meta(P3Args& g, const P3Buf& C) {
   g.oa2 = g.ob2 = nullptr; g.okmul2 = 0.0f;
   if (g.e.A2) { g.oa2 = g.A2.meta; g.ob2 = g.B2.meta; g.okmul2 = (float)g.e.K2; }      // (the second pair is named before the outputs)
 }
-static void p3_out_row(P3Args& g, const P3Buf& C) { g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld; p3_out_meta(g, C); }
-static void p3_out_col(P3Args& g, const P3Buf& Ct) { g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld; p3_out_meta(g, Ct); }
+static void p3_out_row(P3Args& g, const P3Buf& C) {
+  g.Crow = C.p; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld;
+  if (C.te) g.te_row = C.te; else p3_out_meta(g, C);
+}
+static void p3_out_col(P3Args& g, const P3Buf& Ct) {
+  g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld;
+  if (Ct.te) g.te_col = Ct.te; else p3_out_meta(g, Ct);
+}
+// does this product read or write planes with tile scales (the TS kernels)?
+static inline bool p3_uses_te(const P3Args& g) {
+  return g.fmt && (g.A.te || g.B.te || (g.e.A2 && (g.A2.te || g.B2.te)) || g.te_row || g.te_col);
+}
 
 constexpr int g_sparse_planes = 1;     // (frozen in round 4, was tuning key 20) 0 = every product of the sparse formats on launch_gemm / bf16 x 3 planes (see sparse_gemm)
 constexpr int g_force_er = -1;     // (frozen in round 4, was tuning key 19) -1 = the launchers choose the form of the f16 x 2 kernels (P3_EARLY), 0 / 2 = always that one
@@ -3145,8 +3306,12 @@ static int p3_block_slots() {           // two resident blocks per CU
 }
 static int launch_p3(const P3Args& g, hipStream_t st) {
   const dim3 grid((g.e.N + 127) / 128, (g.e.M + 127) / 128);
+  const bool none = p3_no_early((long)grid.x * grid.y >= p3_block_slots() * 3 / 4);                         // (see P3_EARLY)
   if (!g.fmt) hipLaunchKernelGGL((k_gemm_p3<0, 2>), grid, dim3(kThreads), 0, st, g);
-  else if (p3_no_early((long)grid.x * grid.y >= p3_block_slots() * 3 / 4)) hipLaunchKernelGGL((k_gemm_p3<1, 0>), grid, dim3(kThreads), 0, st, g);   // (see P3_EARLY)
+  else if (p3_uses_te(g)) {
+    if (none) hipLaunchKernelGGL((k_gemm_p3<1, 0, true>), grid, dim3(kThreads), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_p3<1, 2, true>), grid, dim3(kThreads), 0, st, g);
+  } else if (none) hipLaunchKernelGGL((k_gemm_p3<1, 0>), grid, dim3(kThreads), 0, st, g);
   else hipLaunchKernelGGL((k_gemm_p3<1, 2>), grid, dim3(kThreads), 0, st, g);
   return (int)hipGetLastError();
 }
@@ -3173,7 +3338,8 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
   while (nchunk > 1 && steps / nchunk < min_chunk) --nchunk;
   if (nchunk <= 1) return launch_p3(g, st);
   if (hipMemsetAsync(cnt, 0, (size_t)tiles * 4, st) != hipSuccess) return 1;
-  if (g.fmt) hipLaunchKernelGGL(k_gemm_p3_splitk_rect<1>, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
+  if (g.fmt && p3_uses_te(g)) hipLaunchKernelGGL((k_gemm_p3_splitk_rect<1, true>), dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
+  else if (g.fmt) hipLaunchKernelGGL(k_gemm_p3_splitk_rect<1>, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
   else hipLaunchKernelGGL(k_gemm_p3_splitk_rect<0>, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
   return (int)hipGetLastError();
 }
@@ -3187,11 +3353,14 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
 // max|C| (into the planes' meta, or wherever `amax` points for an epilogue that has its own: EPI_TRIU_MAX), and a split
 // launch makes the planes.  Tuning key 16 = 0 keeps the epilogue planes with bound scales (A/B runs).
 static int g_planes_exact = 1;
+static int g_tile_scales = 1;   // tuning key 28: chained f16 x 2 products write their planes with TILE scales from the epilogue (default); 0 = fp32
+                                // out + max|C| + a split launch per chained product (the round-3/4 form, one scale per matrix)
+static inline bool kron_tile_scales(int M, int N) { return g_tile_scales && g_planes_exact && g_planes_f16 > 0 && M <= 8192 && N <= 8192; }
 static int p3_chain(P3Args& g, float* tmp, const P3Buf* row, const P3Buf* col, const float* amax, float* sk_scratch,
                     unsigned* sk_cnt, hipStream_t st) {
   const P3Buf& any = row ? *row : *col;
   int e;
-  if (!g.fmt || !g_planes_exact) {
+  if (!g.fmt || !g_planes_exact || any.te) {          // (te: tile scales -- the epilogue writes the planes at each tile's own maximum)
     if (row) p3_out_row(g, *row);
     if (col) p3_out_col(g, *col);
     return launch_p3_auto(g, sk_scratch, sk_cnt, st);
@@ -3368,8 +3537,12 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   const int tiles1 = p.tx1 * ((b.e.M + 127) / 128);
   p.tiles1 = tiles1;
   const dim3 grid(p.tiles0 + tiles1);
+  const bool none = p3_no_early((p.tiles0 + tiles1) / 2 >= p3_block_slots() * 3 / 4);
   if (!a.fmt) hipLaunchKernelGGL((k_gemm_p3_pair<0, 2>), grid, dim3(kThreads), 0, st, p);
-  else if (p3_no_early((p.tiles0 + tiles1) / 2 >= p3_block_slots() * 3 / 4)) hipLaunchKernelGGL((k_gemm_p3_pair<1, 0>), grid, dim3(kThreads), 0, st, p);
+  else if (p3_uses_te(a) || p3_uses_te(b)) {
+    if (none) hipLaunchKernelGGL((k_gemm_p3_pair<1, 0, true>), grid, dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_p3_pair<1, 2, true>), grid, dim3(kThreads), 0, st, p);
+  } else if (none) hipLaunchKernelGGL((k_gemm_p3_pair<1, 0>), grid, dim3(kThreads), 0, st, p);
   else hipLaunchKernelGGL((k_gemm_p3_pair<1, 2>), grid, dim3(kThreads), 0, st, p);        // (half of the factor-update tiles are copies)
   return (int)hipGetLastError();
 }
@@ -3409,8 +3582,12 @@ static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsi
   }
   if (p.nsplit && hipMemsetAsync(cnt, 0, (size_t)p.nsplit * 4, st) != hipSuccess) return 1;
   const dim3 grid(p.n0 + p.n1 - p.nsplit + p.nsplit * p.nchunk);
+  const bool none = p3_no_early(p.n0 + p.n1 >= slots / 2);
   if (!a.fmt) hipLaunchKernelGGL((k_gemm_p3_grad<0, 2>), grid, dim3(kThreads), 0, st, p);
-  else if (p3_no_early(p.n0 + p.n1 >= slots / 2)) hipLaunchKernelGGL((k_gemm_p3_grad<1, 0>), grid, dim3(kThreads), 0, st, p);
+  else if (p3_uses_te(a) || p3_uses_te(b)) {
+    if (none) hipLaunchKernelGGL((k_gemm_p3_grad<1, 0, true>), grid, dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_p3_grad<1, 2, true>), grid, dim3(kThreads), 0, st, p);
+  } else if (none) hipLaunchKernelGGL((k_gemm_p3_grad<1, 0>), grid, dim3(kThreads), 0, st, p);
   else hipLaunchKernelGGL((k_gemm_p3_grad<1, 2>), grid, dim3(kThreads), 0, st, p);
   return (int)hipGetLastError();
 }
@@ -3513,7 +3690,10 @@ static int planes_apply_direct(const float* Ql, const float* Qr, const float* G,
   P3Buf Gp = {k.U0, Mp, Np, pm + kPmG};
   if ((e = launch_absmax(G, (long)M * N, Gp, k.pm_part, st))) return e;                    // (the factors' split is done with the array)
   if ((e = launch_split3(G, N, 1, M, N, Gp, st))) return e;
-  const P3Buf T1r = {k.U2, Mp, Np, pm + kPmT}, T2c = {k.U1, Np, Mp, pm + kPmA}, T3c = {k.U3, Np, Mp, pm + kPmA + 1};
+  P3Buf T1r = {k.U2, Mp, Np, pm + kPmT}, T2c = {k.U1, Np, Mp, pm + kPmA}, T3c = {k.U3, Np, Mp, pm + kPmA + 1};
+  if (kron_tile_scales(M, N)) {                                 // the chained results at tile scales: no fp32 round trip, no split launches
+    T1r.te = k.te + kTeU2 * kTeTable; T2c.te = k.te + kTeU1 * kTeTable; T3c.te = k.te + kTeU3 * kTeTable;
+  }
   P3Args s0 = p3_args(Gp, Rr, M, N, N, KLO_N);                  // T1 = G Qr'     (n, k) view of Qr' = Qr, k >= n
   if ((e = p3_chain(s0, k.T, &T1r, nullptr, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args s1 = p3_args(T1r, Rc, M, N, N, KHI_N);                 // T2 = T1 Qr     (n, k) = Qr[k][n], k <= n
@@ -3551,7 +3731,8 @@ static int planes_update_front(const float* dG, int M, int N, const KronWs& k, h
   auto slot = [&](int i) { return pm ? pm + i : pm; };
   const P3Buf Lr = {k.Lr, Mp, Mp, slot(kPmL)}, Rr = {k.Rr, Np, Np, slot(kPmR)};
   P3Buf dGp = {k.U0, Mp, Np, slot(kPmdG)};
-  const P3Buf Tt = {k.U1, Np, Mp, slot(kPmUT)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
+  P3Buf Tt = {k.U1, Np, Mp, slot(kPmUT)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
+  if (pm && kron_tile_scales(M, N)) { Tt.te = k.te + kTeU1 * kTeTable; Ar.te = k.te + kTeU2 * kTeTable; Ac.te = k.te + kTeU3 * kTeTable; }
   int e;
   if (pm && (e = launch_absmax(dG, (long)M * N, dGp, k.pm_part + kPmPartMax, st))) return e;     // (the side stream's array)
   if ((e = launch_split3(dG, N, 1, M, N, dGp, st))) return e;
@@ -3564,13 +3745,19 @@ static int planes_update_front(const float* dG, int M, int N, const KronWs& k, h
 static int g_pair_order = 1;    // tuning key 27: 1 (default) = the factor updates' tiles in 4 x 4 patches (gemm_tile_from_id case 3': 4096^2 update
                                 // 2.54 -> 2.48 ms, the launch 251 -> 183 us; 6144^2 7.10 -> 6.91; bit-identical results), 0 = whole tile rows per XCD
 static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float step, float tiny, const KronWs& k, hipStream_t st,
-                              PlaneMeta* pm, bool bt_planes_ready = false) {
+                              PlaneMeta* pm, bool bt_planes_ready = false, const P3Buf* bt_br = nullptr, const P3Buf* bt_bc = nullptr) {
   const long Mp = pad128(M), Np = pad128(N);
   auto slot = [&](int i) { return pm ? pm + i : pm; };
-  const P3Buf Lc = {k.Lc, Mp, Mp, slot(kPmL)}, Rc = {k.Rc, Np, Np, slot(kPmR)}, G1 = {k.G1, Mp, Mp, slot(kPmG1)},
-              G2 = {k.G2, Np, Np, slot(kPmG2)};
+  const bool ts = pm && kron_tile_scales(M, N);
+  const P3Buf Lc = {k.Lc, Mp, Mp, slot(kPmL)}, Rc = {k.Rc, Np, Np, slot(kPmR)};
+  P3Buf G1 = {k.G1, Mp, Mp, slot(kPmG1)}, G2 = {k.G2, Np, Np, slot(kPmG2)};
   P3Buf Br = {k.U0, Mp, Np, slot(kPmBt)};
-  const P3Buf Bc = {k.U1, Np, Mp, slot(kPmBt)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
+  P3Buf Bc = {k.U1, Np, Mp, slot(kPmBt)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
+  if (ts) {                                             // (planes_update_front left A's planes at tile scales)
+    Ar.te = k.te + kTeU2 * kTeTable; Ac.te = k.te + kTeU3 * kTeTable;
+    G1.te = k.te + kTeG1 * kTeTable; G2.te = k.te + kTeG2 * kTeTable;
+  }
+  if (bt_br) { Br = *bt_br; Bc = *bt_bc; }              // (the solves left Bt's planes elsewhere)
   int e;
   if (!bt_planes_ready) {                               // (the inverse route's last product has made them)
     if (pm && (e = launch_absmax(k.Bt, (long)M * N, Br, k.pm_part, st))) return e;
@@ -3582,7 +3769,13 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
   P3Args s3 = p3_args(Ac, Ac, N, N, M, 0);                      // grad2 = triu(A'A - Bt'Bt)  (:176)
   s3.A2 = p3_of(Bc); s3.B2 = p3_of(Bc); s3.e.A2 = k.Bt; s3.e.K2 = M;
   s3.e.epi = EPI_TRIU_MAX; s3.e.maxout = k.scal + 1;
-  if (pm && g_planes_exact) {
+  if (ts) {
+    // tile scales: the gradient grid's epilogue does triu and max|.| on its registers (the step size of :177-178) and writes the planes
+    // of every upper tile at that tile's own maximum -- no fp32 gradients, no split launch
+    p3_out_row(s2, G1);
+    p3_out_row(s3, G2);
+    if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st))) return e;
+  } else if (pm && g_planes_exact) {
     // f16 x 2 (see p3_chain): the gradients in fp32 (the epilogue's triu and max|.| as on the fp32 route), then their planes
     // with the scale of that very maximum.  Tiles below the diagonal are not written and not read (K ranges of s4 / s5).
     s2.e.C = k.g1; s2.e.ldc = M;
@@ -3721,9 +3914,10 @@ struct BlkSolve {
   P3Buf pa, pb;                  // two transient plane buffers, pad128(M) x pad128(N) elements each
   P3Buf Br, Bc;                  // planes of Bt, row / column form (p = nullptr: not wanted)
 };
-static P3 p3_sub(const P3Buf& b, long x0, long k0) {              // the (x >= x0, k >= k0) corner of a plane set (k0 a multiple of 32)
-  P3 v = p3_of(b);
+static P3 p3_sub(const P3Buf& b, long x0, long k0) {              // the (x >= x0, k >= k0) corner of a plane set (k0 a multiple of 32;
+  P3 v = p3_of(b);                                                  // of 128, like x0, when the set has tile scales)
   v.p += (k0 / 32) * v.ts + x0 * 32;
+  if (v.te) v.te += (x0 / 128) * kTeLd + k0 / 128;
   return v;
 }
 static P3Args blk_product(const P3& A, const P3& B, int M, int N, int K, int kmode, float* C, int ldc, const float* D, int ldd,
@@ -4018,6 +4212,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 24) { g_inv_blk = value; return PSGD_OK; }
   if (key == 25) { g_inv_order = value; return PSGD_OK; }
   if (key == 27) { g_pair_order = value; return PSGD_OK; }
+  if (key == 28) { g_tile_scales = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
