@@ -707,6 +707,10 @@ struct P3 {
 constexpr int kTeLd = 64;                 // tiles per table row: extents up to 8192
 constexpr int kTeAny = -(1 << 30);        // an all-zero tile: any scale
 constexpr int kTeUnset = -(1 << 30) + 1;  // (p3_pass: no tile seen yet)
+#ifndef PSGD_TE_QUANT
+#define PSGD_TE_QUANT 8
+#endif
+constexpr int kTeQuant = PSGD_TE_QUANT;   // tile exponents are multiples of this
 
 // ---- the second plane format (round 3): x 2^e = h + 2^-11 M with h, M in fp16 ("f16 x 2") -----------------------------
 // Two planes and THREE matrix-core products per term instead of three planes and six: h h' into the accumulators, M h' and
@@ -1301,7 +1305,14 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
       if (lane == 0) L.red[w] = vmax;
       __syncthreads();
       vmax = amaxf(amaxf(L.red[0], L.red[1]), amaxf(L.red[2], L.red[3]));
-      const float sc = plane_scale_of_bound(vmax);
+      // Exponents in steps of kTeQuant (rounded towards the smaller scale: the maximum lands in [2^(14 - kTeQuant), 2^14) instead of
+      // [2^13, 2^14), which costs kTeQuant - 1 of fp16's ~28 binades below the maximum).  Neighbouring tiles of ordinary data differ by
+      // a binade or two: unquantised, a consumer shifted its accumulators at nearly every 128-k boundary (the gradient grid 715 -> 764 us).
+      float sc = plane_scale_of_bound(vmax);
+      {
+        const int e0 = p3_exp_of_scale(sc), eq = e0 - (((e0 % kTeQuant) + kTeQuant) % kTeQuant);
+        sc = ldexpf(1.0f, max(eq, -126));
+      }
       const bool do_col = g.Ccol != nullptr && (!g.e.sym || n0 > m0);
       if (threadIdx.x == 0) {
         const int ex = (__float_as_uint(vmax) == 0u) ? kTeAny : p3_exp_of_scale(sc);
@@ -3287,6 +3298,16 @@ static void p3_out_col(P3Args& g, const P3Buf& Ct) {
   g.Ccol = Ct.p; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld;
   if (Ct.te) g.te_col = Ct.te; else p3_out_meta(g, Ct);
 }
+// plane outputs into a corner of a larger plane set (tile scales only): C(x = x0 + row, k = k0 + col) / C'(x = x0 + col, k = k0 + row);
+// x0, k0 multiples of 128
+static void p3_out_row_at(P3Args& g, const P3Buf& C, long x0, long k0) {
+  g.Crow = C.p + (k0 / 32) * (C.rows * 32) + x0 * 32; g.crow_ts = C.rows * 32; g.crow_ps = C.rows * C.ld;
+  g.te_row = C.te + (x0 / 128) * kTeLd + k0 / 128;
+}
+static void p3_out_col_at(P3Args& g, const P3Buf& Ct, long x0, long k0) {
+  g.Ccol = Ct.p + (k0 / 32) * (Ct.rows * 32) + x0 * 32; g.ccol_ts = Ct.rows * 32; g.ccol_ps = Ct.rows * Ct.ld;
+  g.te_col = Ct.te + (x0 / 128) * kTeLd + k0 / 128;
+}
 // does this product read or write planes with tile scales (the TS kernels)?
 static inline bool p3_uses_te(const P3Args& g) {
   return g.fmt && (g.A.te || g.B.te || (g.e.A2 && (g.A2.te || g.B2.te)) || g.te_row || g.te_col);
@@ -3913,7 +3934,11 @@ struct BlkSolve {
   float *X1, *Bt;                // fp32 [M x N]; Bt doubles as the W of the right solve
   P3Buf pa, pb;                  // two transient plane buffers, pad128(M) x pad128(N) elements each
   P3Buf Br, Bc;                  // planes of Bt, row / column form (p = nullptr: not wanted)
+  // tile scales (pa.te, pb.te, x1c.te, Br.te, Bc.te all set): every piece's planes come out of the epilogue of the product that makes it
+  P3Buf x1c;                     // column-form planes of X1 / V: (x = n, k = m), [pad128(N) x pad128(M)]
+  bool bt_fp32 = true;           // the caller reads Bt in fp32 as well
 };
+static inline bool blk_tile_scales(const BlkSolve& s) { return s.pa.te && s.pb.te && s.x1c.te && s.h % 128 == 0; }
 static P3 p3_sub(const P3Buf& b, long x0, long k0) {              // the (x >= x0, k >= k0) corner of a plane set (k0 a multiple of 32;
   P3 v = p3_of(b);                                                  // of 128, like x0, when the set has tile scales)
   v.p += (k0 / 32) * v.ts + x0 * 32;
@@ -3943,7 +3968,27 @@ static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hip
   if (l_ready && hipEventRecord(l_ready, side) != hipSuccess) return 1;
   PlaneMeta* mX1 = s.pm + kPmX1;
   const int nb = (N + h - 1) / h;
-  for (int j = 0; j < nb; ++j) {
+  const bool ts = blk_tile_scales(s);
+  for (int j = 0; j < nb && ts; ++j) {
+    // Tile scales: the product that makes a piece writes that piece's planes (row form for the trailing update, column form of X1 for
+    // the left solve) -- the chain is  d_0, t_0, d_1, ...  with nothing in between (it was d, split, t, split: the splits 140 us each
+    // beside the full-chip products of the other stream).
+    const int c0 = j * h, hj = N - c0 < h ? N - c0 : h;
+    P3 Wp = j == 0 ? p3_sub(s.X0p, 0, 0) : p3_of(s.pb);
+    P3Args d = blk_product(Wp, p3_sub(s.R.Ic, c0, c0), M, hj, hj, KHI_N, s.X1 + c0, N, nullptr, 0, nullptr);     // X1_j = W_j Ri_jj
+    P3Buf Xj = s.pa;
+    Xj.ld = pad128(hj);
+    if (j < nb - 1) p3_out_row(d, Xj);
+    p3_out_col_at(d, s.x1c, c0, 0);
+    if ((e = launch_p3(d, main))) return e;
+    if (j == nb - 1) break;
+    const int c1 = c0 + hj;
+    P3Args t = blk_product(p3_of(Xj), p3_sub(s.R.Qc, c1, c0), M, N - c1, hj, 0, s.Bt + c1, N, (j == 0 ? s.X0 : s.Bt) + c1, N, nullptr);
+    s.pb.ld = pad128(N - c1);                                         // W_{>j}: the next block column is its first h columns
+    p3_out_row(t, s.pb);
+    if ((e = launch_p3(t, main))) return e;
+  }
+  for (int j = 0; j < nb && !ts; ++j) {
     const int c0 = j * h, hj = N - c0 < h ? N - c0 : h;
     P3 Wp = j == 0 ? p3_sub(s.X0p, 0, 0) : p3_of(s.pb);
     if (j == 0) Wp.meta = s.X0p.meta;
@@ -3974,6 +4019,25 @@ static int blk_solves_back(BlkSolve& s, hipStream_t main) {
   int e;
   PlaneMeta *mX1 = s.pm + kPmX1, *mBt = s.pm + kPmBt;
   const int mb = (M + h - 1) / h;
+  if (blk_tile_scales(s) && s.Br.te && s.Bc.te) {
+    // tile scales: V's column-form planes are in x1c (the products of the right solve and the trailing updates below write them),
+    // every Bt_i goes straight into the planes of Bt the gradient grid reads, and its column form is the trailing update's operand
+    for (int i = 0; i < mb; ++i) {
+      const int r0 = i * h, hi = M - r0 < h ? M - r0 : h;
+      P3Args d = blk_product(p3_sub(s.L.Ic, r0, r0), p3_sub(s.x1c, 0, r0), hi, N, hi, KHI_M,
+                             s.bt_fp32 ? s.Bt + (long)r0 * N : nullptr, N, nullptr, 0, nullptr);             // Bt_i = Li_ii' V_i
+      p3_out_row_at(d, s.Br, r0, 0);
+      p3_out_col_at(d, s.Bc, 0, r0);
+      if ((e = launch_p3(d, main))) return e;
+      if (i == mb - 1) break;
+      const int r1 = r0 + hi;
+      P3Args t = blk_product(p3_sub(s.L.Qc, r1, r0), p3_sub(s.Bc, 0, r0), M - r1, N, hi, 0, s.X1 + (long)r1 * N, N,
+                             s.X1 + (long)r1 * N, N, nullptr);                                                // V_{>i} -= L[i, >i]' Bt_i
+      p3_out_col_at(t, s.x1c, 0, r1);
+      if ((e = launch_p3(t, main))) return e;
+    }
+    return 0;
+  }
   for (int i = 0; i < mb; ++i) {
     const int r0 = i * h, hi = M - r0 < h ? M - r0 : h;
     P3Buf Vi = s.pb;                                                  // column-form planes of V_i: (x = n, k = m) = V[m][n]
@@ -4337,6 +4401,27 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     bs.X1 = k.X1; bs.Bt = k.Bt;
     bs.pa = P3Buf{k.Y0, Mp, Np, nullptr}; bs.pb = P3Buf{k.Y1, Mp, Np, nullptr};      // (transients of the apply: free during an update)
     bs.Br = P3Buf{k.U0, Mp, Np, pm + kPmBt}; bs.Bc = P3Buf{k.U1, Np, Mp, pm + kPmBt};
+    const bool ts = kron_tile_scales(M, N) && bs.h % 128 == 0;
+    if (ts) {
+      // tile scales: X1's column form lives in X1p; Bt's planes go to Y0 / Y1 (the pieces' buffers of the right solve: free by then),
+      // whichever stream order -- U0 / U1 stay with the products of :173
+      bs.pa.te = k.te + kTeY0 * kTeTable; bs.pb.te = k.te + kTeY1 * kTeTable;
+      bs.x1c = P3Buf{k.X1p, Np, Mp, nullptr, nullptr, 0, k.te + kTeX1p * kTeTable};
+      bs.bt_fp32 = false;
+      if (!inv_first) KRON_LAUNCH(blk_solves_front(bs, st, sf));
+      else {
+        KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid));
+        KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
+        if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
+      }
+      bs.Br = P3Buf{k.Y0, Mp, Np, nullptr, nullptr, 0, k.te + kTeY0 * kTeTable};
+      bs.Bc = P3Buf{k.Y1, Np, Mp, nullptr, nullptr, 0, k.te + kTeY1 * kTeTable};
+      if (!inv_first) KRON_LAUNCH(fork_scope.join());                 // (Ql's inverse is made on the side stream)
+      KRON_LAUNCH(blk_solves_back(bs, st));
+      if (inv_first) KRON_LAUNCH(fork_scope.join());
+      KRON_LAUNCH(planes_update_back(QlOut, QrOut, M, N, step, tiny, k, st, pm, true, &bs.Br, &bs.Bc));
+      return PSGD_OK;
+    }
     if (inv_first) {
       // both inversions first, undisturbed by full-chip products; the products of :173 then run on the side stream beside X1 and Bt
       KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid));
