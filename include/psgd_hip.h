@@ -301,7 +301,8 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * 25 [-1] stream order of the inverse route: by shape (both inversions first from 4096^2 on), 0 / 1 = products / inversions first
  * 27 [1] the factor updates (:179) of the large update walk their tiles in 4 x 4 patches per XCD (from 32 x 32 tiles on), 0 = whole tile rows
  * 28 [1] chained f16 x 2 plane products write their planes from the epilogue at TILE scales (each 128 x 128 tile at its own maximum; the
- *    consumer's K loop shifts its accumulators when the scale changes), 0 = fp32 out + max|C| + a split launch (one scale per matrix) */
+ *    consumer's K loop shifts its accumulators when the scale changes), 0 = fp32 out + max|C| + a split launch (one scale per matrix)
+ * 29 [1] large fp32 update with both inversions first: dX's planes on the side stream ahead of Ql's inversion, 0 = on the caller's stream */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

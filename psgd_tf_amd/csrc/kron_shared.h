@@ -56,7 +56,7 @@ int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, v
 // the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for
 // everything already on `main`; the caller puts one chain on it and kron_join makes `main` wait for that chain.
 // Event fork/join only, so it is legal inside a stream capture of `main`.  nullptr = no side stream: stay on `main`.
-struct KronFork { hipStream_t side; hipEvent_t fork, join, mid; };     // mid: a point inside the side chain the caller's stream waits for
+struct KronFork { hipStream_t side; hipEvent_t fork, join, mid, aux; };     // mid: a point inside the side chain the caller's stream waits for
 KronFork* kron_fork(hipStream_t main);
 int kron_join(KronFork* f, hipStream_t main);          // 0 on success
 bool kron_overlap_chains(int M, int N);                // tuning key 9 and the shape rule

@@ -1174,12 +1174,9 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
     // the subtracted pair first, then one sign flip of the accumulators.  (f16 x 2: the pairs have their own units,
     // 2^-(eA + eB); the pair with the FINER unit goes first and its sums are carried over to the coarser unit -- a factor
     // <= 1, so nothing overflows however far apart the two products are)
-    const bool swap = FMT == 1 && !TS && g.e.A2 && inv2 > inv1;
-#pragma unroll 1
-    for (int it = g.e.A2 ? 1 : 0; it >= 0; --it) {
-      const int p = swap ? 1 - it : it;
+    auto k_range = [&](int p, int& lo, int& hi) {
       const int K = p ? g.e.K2 : g.e.K, km = p ? g.e.kmode2 : g.e.kmode;
-      int lo = 0, hi = K;
+      lo = 0; hi = K;
       if (km & KLO_M) lo = max(lo, m0);
       if (km & KLO_N) lo = max(lo, n0);
       if (km & KHI_M) hi = min(hi, m0 + TM);
@@ -1188,6 +1185,34 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
       if (km & KBLK_LO_N) lo = max(lo, (n0 / g.e.kblk) * g.e.kblk + g.e.kblk / 2);
       lo = (lo / GK) * GK;
       hi = ((hi + GK - 1) / GK) * GK;                 // the planes are zero-padded to whole K tiles
+    };
+    bool swap = FMT == 1 && !TS && g.e.A2 && inv2 > inv1;
+    if constexpr (TS) {
+      // tile scales: the same rule per output tile -- the pair whose FINEST tile scale is finer goes first, so the accumulators are only
+      // ever carried to coarser units between the pairs (dX ~ 1e12 against dG ~ 1e-13: the other order is a shift by 2^+166)
+      if (g.e.A2) {
+        int fin[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          int lo, hi;
+          k_range(p, lo, hi);
+          int c = kTeAny;
+          if (hi > lo) {
+            const int ea = p3_tile_exps<FMT>(p ? g.A2 : g.A, m0, lo, hi), eb = p3_tile_exps<FMT>(p ? g.B2 : g.B, n0, lo, hi);
+            c = (ea == kTeAny || eb == kTeAny) ? kTeAny : ea + eb;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c = max(c, __shfl_xor(c, off, 64));
+          }
+          fin[p] = __builtin_amdgcn_readfirstlane(c);
+        }
+        swap = fin[1] < fin[0];
+      }
+    }
+#pragma unroll 1
+    for (int it = g.e.A2 ? 1 : 0; it >= 0; --it) {
+      const int p = swap ? 1 - it : it;
+      int lo, hi;
+      k_range(p, lo, hi);
       p3_pass<FMT, ER, TS>(p ? g.A2 : g.A, p ? g.B2 : g.B, m0, n0, lo, hi, L, acc, &cur);
       if (it) {                                        // (f16 x 2: and over to the other pair's unit, a power of two)
         // (tile scales: only the sign -- the second pass moves the accumulators to its own tiles' scales like any change of tile)
@@ -1207,12 +1232,13 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
     }
     if constexpr (TS) {
       const int back = cur == kTeUnset ? 0 : -cur;
+      const float sg = swap ? -1.0f : 1.0f;            // (A - B either way)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i][j][e] = ldexpf(acc[i][j][e], back);
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = ldexpf(acc[i][j][e] * sg, back);
     }
   }
   if (g.e.scale_max) {                                // (step / max) A B = step / max (A B): applied to the finished sums
@@ -1465,7 +1491,8 @@ template <int FMT>
 __device__ __forceinline__ void split3_body(const float* __restrict__ X, long rs, long cs, int R, int C,
                                             __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
                                             long tts, long tps, PlaneMeta* meta, const float* __restrict__ part,
-                                            int npart, SplitOpt opt, int bx, int by, int bz, float (*S)[65]) {
+                                            int npart, SplitOpt opt, int bx, int by, int bz, float (*S)[65],
+                                            int* te = nullptr, int* tet = nullptr) {       // te / tet: tile-exponent tables of P / Pt to fill
   int r0 = by * 64, c0 = bx * 64;
   const int tid = threadIdx.x;
   if (opt.blk) {
@@ -1493,6 +1520,11 @@ __device__ __forceinline__ void split3_body(const float* __restrict__ X, long rs
     // (the first block that exists under a block filter: tile (0, 0), or the first off-diagonal quarter's first tile)
     const bool first = opt.off ? (r0 == 0 && c0 == opt.blk / 2) : (r0 == 0 && c0 == 0);
     if (first && tid == 0) { meta->scale = sc; meta->inv = 1.0f / sc; meta->amax = amax; meta->bound = amax; }
+    // (planes that products with tile scales read: every 128-tile this launch writes carries the matrix's one exponent)
+    if (tid == 0 && !(r0 & 127) && !(c0 & 127)) {
+      if (te) te[(r0 >> 7) * kTeLd + (c0 >> 7)] = p3_exp_of_scale(sc);
+      if (tet) tet[(c0 >> 7) * kTeLd + (r0 >> 7)] = p3_exp_of_scale(sc);
+    }
     if (opt.neg) sc = -sc;
   }
   auto split_pair = [&](float x0, float x1, unsigned (&q)[3]) {
@@ -1569,9 +1601,9 @@ template <int FMT>
 __global__ __launch_bounds__(kThreads) void k_split3(const float* __restrict__ X, long rs, long cs, int R, int C,
                                                      __bf16* __restrict__ P, long ts, long ps, __bf16* __restrict__ Pt,
                                                      long tts, long tps, PlaneMeta* meta, const float* __restrict__ part,
-                                                     int npart, SplitOpt opt) {
+                                                     int npart, SplitOpt opt, int* te = nullptr, int* tet = nullptr) {
   __shared__ float S[64][65];
-  split3_body<FMT>(X, rs, cs, R, C, P, ts, ps, Pt, tts, tps, meta, part, npart, opt, blockIdx.x, blockIdx.y, blockIdx.z, S);
+  split3_body<FMT>(X, rs, cs, R, C, P, ts, ps, Pt, tts, tps, meta, part, npart, opt, blockIdx.x, blockIdx.y, blockIdx.z, S, te, tet);
 }
 // two independent splits in one launch (the two gradients of the large update): job 0 on the rows y < y0 of the grid, job 1 behind
 struct SplitJob { const float* X; long rs, cs; int R, C; __bf16* P; long ts, ps; __bf16* Pt; long tts, tps; PlaneMeta* meta; const float* part; int npart; SplitOpt opt; int gx; };
@@ -3269,7 +3301,7 @@ static int launch_split3_both(const float* X, long rs, long cs, int R, int C, co
   const dim3 grid = split_grid(out.rows, out.ld, opt);
   if (out.meta)
     hipLaunchKernelGGL(k_split3<1>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
-                       outT.p, outT.rows * 32, outT.rows * outT.ld, out.meta, out.part, out.npart, opt);
+                       outT.p, outT.rows * 32, outT.rows * outT.ld, out.meta, out.part, out.npart, opt, out.te, outT.te);
   else
     hipLaunchKernelGGL(k_split3<0>, grid, dim3(kThreads), 0, st, X, rs, cs, R, C, out.p, out.rows * 32, out.rows * out.ld,
                        outT.p, outT.rows * 32, outT.rows * outT.ld, (PlaneMeta*)nullptr, (const float*)nullptr, 0, opt);
@@ -3374,6 +3406,7 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
 // max|C| (into the planes' meta, or wherever `amax` points for an epilogue that has its own: EPI_TRIU_MAX), and a split
 // launch makes the planes.  Tuning key 16 = 0 keeps the epilogue planes with bound scales (A/B runs).
 static int g_planes_exact = 1;
+static int g_x0_side = 1;        // tuning key 29: 1 = (both inversions first) dX's planes on the side stream ahead of Ql's inversion
 static int g_tile_scales = 1;   // tuning key 28: chained f16 x 2 products write their planes with TILE scales from the epilogue (default); 0 = fp32
                                 // out + max|C| + a split launch per chained product (the round-3/4 form, one scale per matrix)
 static inline bool kron_tile_scales(int M, int N) { return g_tile_scales && g_planes_exact && g_planes_f16 > 0 && M <= 8192 && N <= 8192; }
@@ -3889,6 +3922,28 @@ static int tri_inverse_level(const InvSide& f, int b, int level, hipStream_t st)
   else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
   return (int)hipGetLastError();
 }
+// The same level with tile scales (f.Ir.te, f.Ic.te, f.Tp.te): T's epilogue writes the planes of -T, W's epilogue the planes of the new
+// off-diagonal blocks of the inverse in both forms -- two launches per level instead of four, nothing in fp32, and no final split: the
+// inverted b0-blocks are split once (tri_inverse_pair), every later tile of Ir / Ic comes out of the product that makes it.
+static inline bool inv_tile_scales(const InvSide& f) { return f.Ir.te && f.Ic.te && f.Tp.te; }
+static int tri_inverse_level_ts(const InvSide& f, int b, hipStream_t st) {
+  const int n = f.n;
+  const int tb = b / 128, pairs = (n + 2 * b - 1) / (2 * b);
+  const bool full = p3_no_early(pairs * tb * tb >= p3_block_slots() / 2);
+  P3Args g1 = p3_args(f.Ir, f.Qc, n, n, n, KLO_M | KBLK_HI_M);                     // -T = -(A^-1 B)
+  g1.e.kblk = 2 * b; g1.neg = 1;
+  p3_out_row(g1, f.Tp);
+  if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0, true>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
+  else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2, true>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g1, b);
+  if (hipGetLastError() != hipSuccess) return 1;
+  P3Args g2 = p3_args(f.Tp, f.Ic, n, n, n, KHI_N | KBLK_LO_N);                     // W = (-T) C^-1: the block of the inverse
+  g2.e.kblk = 2 * b;
+  p3_out_row(g2, f.Ir);
+  p3_out_col(g2, f.Ic);
+  if (full) hipLaunchKernelGGL((k_gemm_p3_blk<1, 0, true>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
+  else hipLaunchKernelGGL((k_gemm_p3_blk<1, 2, true>), dim3(pairs * tb * tb), dim3(kThreads), 0, st, g2, b);
+  return (int)hipGetLastError();
+}
 // column-form planes of the inverted h-blocks on the diagonal: (x, k) = Inv[k][x], k <= x, both inside one block (h >= n: the whole inverse)
 static int tri_inverse_planes(const InvSide& f, int h, hipStream_t st) {
   return launch_split3(f.Inv, 1, f.n, f.n, f.n, f.Ic, st, SplitOpt{2, h < f.n ? h : 0, 0, 0});
@@ -3899,13 +3954,17 @@ static int tri_inverse_planes(const InvSide& f, int h, hipStream_t st) {
 static int tri_inverse_pair(InvSide a, hipStream_t sa, InvSide b, hipStream_t sb, int h) {
   int e;
   if ((e = tri_inverse_blocks(a, sa)) || (e = tri_inverse_blocks(b, sb))) return e;
+  const bool tsa = inv_tile_scales(a), tsb = inv_tile_scales(b);
+  // tile scales: the planes (both forms) of the inverted b0-blocks, once
+  if (tsa && (e = launch_split3_both(a.Inv, a.n, 1, a.n, a.n, a.Ir, a.Ic, sa, SplitOpt{1, a.b0, 0, 0}))) return e;
+  if (tsb && (e = launch_split3_both(b.Inv, b.n, 1, b.n, b.n, b.Ir, b.Ic, sb, SplitOpt{1, b.b0, 0, 0}))) return e;
   int level = 0;
   for (int w = 128; w < h && (w < a.n || w < b.n); w *= 2, ++level) {
-    if (w >= a.b0 && w < a.n && (e = tri_inverse_level(a, w, level, sa))) return e;
-    if (w >= b.b0 && w < b.n && (e = tri_inverse_level(b, w, level, sb))) return e;
+    if (w >= a.b0 && w < a.n && (e = tsa ? tri_inverse_level_ts(a, w, sa) : tri_inverse_level(a, w, level, sa))) return e;
+    if (w >= b.b0 && w < b.n && (e = tsb ? tri_inverse_level_ts(b, w, sb) : tri_inverse_level(b, w, level, sb))) return e;
   }
-  if ((e = tri_inverse_planes(a, h, sa))) return e;
-  return tri_inverse_planes(b, h, sb);
+  if (!tsa && (e = tri_inverse_planes(a, h, sa))) return e;
+  return tsb ? 0 : tri_inverse_planes(b, h, sb);
 }
 
 // ---- the two solves of psgd.py:174 through the inverses of the DIAGONAL h-BLOCKS of the balanced factors (round 4) --------------
@@ -3959,13 +4018,19 @@ enum { kPmPieceX = kPmStrip, kPmPieceW = kPmStrip + 8, kPmPieceV = kPmStrip + 16
 
 // dX planes, both inversions (R on `main`, L on `side`), then X1 = dX R^-1 on `main`
 // (l_ready: recorded on `side` behind L's inversion, for callers that put more work on `side` before the join)
-static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hipEvent_t l_ready = nullptr) {
+// (x0_ready: an event of the caller's.  Given one, dX's planes are made on `side` AHEAD of L's inversion -- which is not needed before
+//  the left solve -- so that R's inversion, the head of the critical path, starts ~75 us earlier; `main` waits for the event before X1.)
+static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hipEvent_t l_ready = nullptr, hipEvent_t x0_ready = nullptr) {
   const int M = s.M, N = s.N, h = s.h;
   int e;
-  if (!s.X0p.part && (e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, main))) return e;      // (unless the caller has the maxima)
-  if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, main))) return e;
+  const bool x0_side = x0_ready && side != main;
+  hipStream_t sx = x0_side ? side : main;
+  if (!s.X0p.part && (e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, sx))) return e;      // (unless the caller has the maxima)
+  if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, sx))) return e;
+  if (x0_side && hipEventRecord(x0_ready, side) != hipSuccess) return 1;
   if ((e = tri_inverse_pair(s.R, main, s.L, side, h))) return e;
   if (l_ready && hipEventRecord(l_ready, side) != hipSuccess) return 1;
+  if (x0_side && hipStreamWaitEvent(main, x0_ready, 0) != hipSuccess) return 1;
   PlaneMeta* mX1 = s.pm + kPmX1;
   const int nb = (N + h - 1) / h;
   const bool ts = blk_tile_scales(s);
@@ -4019,14 +4084,14 @@ static int blk_solves_back(BlkSolve& s, hipStream_t main) {
   int e;
   PlaneMeta *mX1 = s.pm + kPmX1, *mBt = s.pm + kPmBt;
   const int mb = (M + h - 1) / h;
-  if (blk_tile_scales(s) && s.Br.te && s.Bc.te) {
+  if (blk_tile_scales(s) && s.Bc.te) {
     // tile scales: V's column-form planes are in x1c (the products of the right solve and the trailing updates below write them),
     // every Bt_i goes straight into the planes of Bt the gradient grid reads, and its column form is the trailing update's operand
     for (int i = 0; i < mb; ++i) {
       const int r0 = i * h, hi = M - r0 < h ? M - r0 : h;
       P3Args d = blk_product(p3_sub(s.L.Ic, r0, r0), p3_sub(s.x1c, 0, r0), hi, N, hi, KHI_M,
                              s.bt_fp32 ? s.Bt + (long)r0 * N : nullptr, N, nullptr, 0, nullptr);             // Bt_i = Li_ii' V_i
-      p3_out_row_at(d, s.Br, r0, 0);
+      if (s.Br.p) p3_out_row_at(d, s.Br, r0, 0);
       p3_out_col_at(d, s.Bc, 0, r0);
       if ((e = launch_p3(d, main))) return e;
       if (i == mb - 1) break;
@@ -4065,7 +4130,7 @@ static int blk_solves_back(BlkSolve& s, hipStream_t main) {
 
 // The route for callers outside this file (kron_shared.h: the bf16-operand update): own workspace, same launches.
 struct InvSolveWs {
-  PlaneMeta* pm; float* part;
+  PlaneMeta* pm; float* part; int* te;
   __bf16 *Lc, *Rc, *IrL, *IcL, *TpL, *IrR, *IcR, *TpR, *DXp, *X1p;
   float *InvL, *InvR, *TfL, *TfR;
   __bf16 *Pa, *Pb;                 // transient planes of the blocked solves' pieces
@@ -4079,6 +4144,7 @@ static InvSolveWs inv_solve_layout(char* base, int M, int N) {
   auto planes = [&](int64_t elems) { return reinterpret_cast<__bf16*>(take(elems * 4)); };        // (two fp16 planes)
   k.pm = reinterpret_cast<PlaneMeta*>(take(kPmSlots * sizeof(PlaneMeta)));
   k.part = reinterpret_cast<float*>(take(4 * kPmPartMax * 4));
+  k.te = reinterpret_cast<int*>(take((int64_t)kTeSlots * kTeTable * 4));
   k.Lc = planes(Mp * Mp); k.IrL = planes(Mp * Mp); k.IcL = planes(Mp * Mp); k.TpL = planes(Mp * Mp);
   k.Rc = planes(Np * Np); k.IrR = planes(Np * Np); k.IcR = planes(Np * Np); k.TpR = planes(Np * Np);
   k.DXp = planes(Mp * Np); k.X1p = planes(Mp * Np);
@@ -4122,6 +4188,17 @@ static BlkSolve inv_solve_problem(const InvSolveWs& k, const float* QlS, const f
   s.X1 = X1; s.Bt = Bt;
   s.pa = P3Buf{k.Pa, Mp, Np, nullptr}; s.pb = P3Buf{k.Pb, Mp, Np, nullptr};
   s.Br = P3Buf{nullptr, 0, 0, nullptr}; s.Bc = s.Br;
+  if (kron_tile_scales(M, N) && s.h % 128 == 0) {
+    // tile scales (see blk_solves_*): every piece's planes from the epilogue of the product that makes it.  Bt stays fp32 for this
+    // caller (the bf16-operand update converts it); its column form -- the trailing updates' operand -- goes to Pa, free by then.
+    s.L.Ir.te = k.te + kTeG1 * kTeTable; s.L.Ic.te = k.te + kTeIcL * kTeTable; s.L.Tp.te = k.te + kTeTpL * kTeTable;
+    s.R.Ir.te = k.te + kTeG2 * kTeTable; s.R.Ic.te = k.te + kTeIcR * kTeTable; s.R.Tp.te = k.te + kTeTpR * kTeTable;
+    s.L.Tp.meta = pm + kPmTL; s.R.Tp.meta = pm + kPmTR;
+    s.pa.te = k.te + kTeY0 * kTeTable; s.pb.te = k.te + kTeY1 * kTeTable;
+    s.x1c = P3Buf{k.X1p, Np, Mp, nullptr, nullptr, 0, k.te + kTeX1p * kTeTable};
+    s.Bc = P3Buf{k.Pa, Np, Mp, nullptr, nullptr, 0, k.te + kTeY0 * kTeTable};
+    s.bt_fp32 = true;
+  }
   return s;
 }
 
@@ -4223,7 +4300,8 @@ KronFork* kron_fork(hipStream_t main) {
       const bool ok = hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio) == hipSuccess &&
                       hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&n.join, hipEventDisableTiming) == hipSuccess &&
-                      hipEventCreateWithFlags(&n.mid, hipEventDisableTiming) == hipSuccess;
+                      hipEventCreateWithFlags(&n.mid, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&n.aux, hipEventDisableTiming) == hipSuccess;
       if (dev != cur) (void)hipSetDevice(cur);
       if (!ok) return nullptr;
       it = tab.emplace(std::make_pair(dev, main), n).first;
@@ -4277,6 +4355,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 25) { g_inv_order = value; return PSGD_OK; }
   if (key == 27) { g_pair_order = value; return PSGD_OK; }
   if (key == 28) { g_tile_scales = value; return PSGD_OK; }
+  if (key == 29) { g_x0_side = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -4403,6 +4482,9 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     bs.Br = P3Buf{k.U0, Mp, Np, pm + kPmBt}; bs.Bc = P3Buf{k.U1, Np, Mp, pm + kPmBt};
     const bool ts = kron_tile_scales(M, N) && bs.h % 128 == 0;
     if (ts) {
+      bs.L.Ir.te = k.te + kTeG1 * kTeTable; bs.L.Ic.te = k.te + kTeIcL * kTeTable; bs.L.Tp.te = k.te + kTeTpL * kTeTable;
+      bs.R.Ir.te = k.te + kTeG2 * kTeTable; bs.R.Ic.te = k.te + kTeIcR * kTeTable; bs.R.Tp.te = k.te + kTeTpR * kTeTable;
+      bs.L.Tp.meta = pm + kPmTL; bs.R.Tp.meta = pm + kPmTR;        // (fmt of p3_args: any meta)
       // tile scales: X1's column form lives in X1p; Bt's planes go to Y0 / Y1 (the pieces' buffers of the right solve: free by then),
       // whichever stream order -- U0 / U1 stay with the products of :173
       bs.pa.te = k.te + kTeY0 * kTeTable; bs.pb.te = k.te + kTeY1 * kTeTable;
@@ -4410,7 +4492,7 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
       bs.bt_fp32 = false;
       if (!inv_first) KRON_LAUNCH(blk_solves_front(bs, st, sf));
       else {
-        KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid));
+        KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid, g_x0_side ? fk->aux : nullptr));
         KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
         if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
       }
