@@ -3981,7 +3981,10 @@ static int g_inv_order = -1;    // tuning key 25: 1 = both inversions ahead of t
 // Both inversions first -- undisturbed by full-chip products, every launch of a level at its isolated time, the chip mostly idle for
 // ~0.4 ms -- pays once both factors reach 4096 (4096^2 fp32 update 2.66 -> 2.56 ms; 2048 x 4096, 3072^2, 6144^2 within 1 % either way:
 // profiles/r04_kron_update_notes.txt)
-bool kron_inv_first(int M, int N) { return g_inv_order < 0 ? (M >= 4096 && N >= 4096 && M * (long)N <= 4096L * 4096) : g_inv_order == 1; }
+// Round 5, with tile scales (no split launches left inside the chains): both inversions first wins or ties on every shape up to 4096^2
+// elements (2304 x 2048 0.887 -> 0.812 ms, 4096 x 2048 1.425 -> 1.310, 8192 x 2048 3.69 -> 3.62, bf16 operands 2.69 -> 2.47; 3072^2 equal)
+// and loses 2 % at 6144^2, where the products dwarf the chains (profiles/r05_order_ab.txt).
+bool kron_inv_first(int M, int N) { return g_inv_order < 0 ? (M * (long)N <= 4096L * 4096) : g_inv_order == 1; }
 static int g_inv_blk = 2048;    // tuning key 24: h (0 = whole inverses and one product per solve, the round-3 form)
 struct BlkSolve {
   int M, N, h;

@@ -30,7 +30,7 @@ def fuzz_kron(g, it):
     big = it % 7 == 0
     M = int(torch.randint(1, 2600 if big else 700, (1,), generator=g, device=dev))
     N = int(torch.randint(1, 2600 if big else 700, (1,), generator=g, device=dev))
-    if it % 28 == 27:                                 # both factors from 2048 on: the solves through explicit inverses
+    if it % 28 == 27 or (os.environ.get("FUZZ_BIG") == "1" and it % 3 == 2):   # both factors from 2048 on: the solves through explicit inverses
         M = int(torch.randint(2048, 3000, (1,), generator=g, device=dev))
         N = int(torch.randint(2049, 3000, (1,), generator=g, device=dev))
     off = 0.5 / max(M, N) ** 0.5

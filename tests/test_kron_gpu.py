@@ -871,6 +871,98 @@ def test_f16_planes_follow_the_magnitude_of_the_data(psgd, scale):
             assert rel_err(g.cpu().numpy(), rr) < TOL
 
 
+@pytest.mark.parametrize("M,N", [(2304, 2048), (2100, 3000), (1030, 1100), (4096, 4096), (640, 2304)])
+def test_tile_scales_agree_with_matrix_scales(psgd, M, N):
+    """Round 5, tuning key 28: chained f16 x 2 plane products write their planes from the epilogue with one power-of-two scale per
+    128 x 128 TILE (exponents in a table; the consumer's K loop shifts its accumulators when the scale changes) instead of fp32 out +
+    max|C| + a split launch with one scale per matrix.  A power-of-two scale does not change a value's bits unless it underflows, so
+    the two forms agree to fp32 rounding; both hold the parity bars.  Update (both stream orders of the inverse route, blocks of 1024
+    and 2048), apply with new factors, bf16-operand update."""
+    from psgd_tf_amd import kron
+    rng = np.random.default_rng(7 * M + N)
+    a32 = [a.astype(np.float32) for a in (_tri_factor(rng, M, 0.02) * 2.0, _tri_factor(rng, N, 0.02), rng.standard_normal((M, N)))]
+    a32.append((a32[2] * np.exp(rng.uniform(-1, 1, (M, 1))) * np.exp(rng.uniform(-1, 1, (1, N)))).astype(np.float32))
+    G = rng.standard_normal((M, N)).astype(np.float32)
+    dev = [_dev(a) for a in a32]
+    check_oracle = M * N <= 2304 * 3000
+    if check_oracle:
+        ref = orc.update_precond_kron(*(a.astype(np.float64) for a in a32), 0.01)
+        ref_a = orc.precond_grad_kron(a32[0].astype(np.float64), a32[1].astype(np.float64), G.astype(np.float64))
+    rho = np.sqrt(np.max(np.diag(a32[0])) / np.max(np.diag(a32[1])))
+    base = (a32[0].astype(np.float64) / rho, a32[1].astype(np.float64) * rho)
+    res = {}
+    try:
+        for ts, order, blk in ((0, -1, 2048), (1, -1, 2048), (1, 0, 2048), (1, 1, 1024)):
+            kron.set_tuning(28, ts); kron.set_tuning(25, order); kron.set_tuning(24, blk)
+            up = psgd.update_precond_kron(*dev, 0.01)
+            again = psgd.update_precond_kron(*dev, 0.01)
+            assert torch.equal(up[0], again[0]) and torch.equal(up[1], again[1])            # run to run: bitwise
+            ap = psgd.precond_grad_kron(dev[0].clone(), dev[1].clone(), _dev(G))            # new factor tensors: the Gram-free chain
+            ub = psgd.update_precond_kron(dev[0], dev[1], dev[2].bfloat16(), dev[3].bfloat16(), 0.01)
+            res[(ts, order, blk)] = (up, ap, ub)
+            if check_oracle:
+                for got, r, b in zip(up, ref, base):
+                    g = got.cpu().numpy().astype(np.float64)
+                    assert rel_err(g, r) < TOL and rel_err(g - b, r - b) < INCR_TOL, (ts, order, blk)
+                    assert torch.equal(got, torch.triu(got))
+                assert rel_err(ap.cpu().numpy(), ref_a) < TOL
+    finally:
+        kron.set_tuning(28, 1); kron.set_tuning(25, -1); kron.set_tuning(24, 2048)
+    first = res[(0, -1, 2048)]
+    for key, (up, ap, ub) in res.items():
+        for a, b, bb in zip(first[0], up, base):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6, key
+            assert rel_err(a.cpu().numpy() - bb, b.cpu().numpy() - bb) < 1e-4, key
+        assert rel_err(first[1].cpu().numpy(), ap.cpu().numpy()) < 1e-6, key
+        for a, b in zip(first[2], ub):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6, key
+
+
+@pytest.mark.parametrize("direction", ["rising", "falling", "blocks"])
+def test_tile_scales_with_magnitudes_that_change_along_k(psgd, direction):
+    """The consumer of tile-scaled planes moves its accumulators from one power-of-two scale to the next at 128-k boundaries (exactly:
+    v_ldexp_f32).  Data whose magnitude rises / falls by 2^40 along the contraction index of the chained products (rows of G scaled,
+    so that K of the left-factor products runs over them), and data with whole all-zero tile rows and columns (exponent `any`: the
+    accumulators stay where they are): the apply and the update stay at the accuracy of uniform data."""
+    M, N = 2304, 2048
+    rng = np.random.default_rng(21)
+    Ql, Qr = _tri_factor(rng, M, 0.02).astype(np.float32), _tri_factor(rng, N, 0.02).astype(np.float32)
+    G = rng.standard_normal((M, N))
+    if direction == "blocks":
+        G[256:512, :] = 0.0
+        G[:, 1024:1280] = 0.0
+        G[1500:1700, 100:900] *= 1e-6
+    else:
+        ramp = np.exp(np.linspace(-14, 14, M))
+        G = G * (ramp if direction == "rising" else ramp[::-1])[:, None]
+    G = G.astype(np.float32)
+    ref = orc.precond_grad_kron(Ql.astype(np.float64), Qr.astype(np.float64), G.astype(np.float64))
+    out = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G)).cpu().numpy().astype(np.float64)
+    assert np.isfinite(out).all() and rel_err(out, ref) < TOL
+    assert np.max(np.abs(out - ref)) < TOL * np.max(np.abs(ref))
+    dX = (rng.standard_normal((M, N)) * (1.0 if direction == "blocks" else 1.0 / np.exp(np.linspace(-3, 3, M))[:, None])).astype(np.float32)
+    dG = (G if direction == "blocks" else G * np.exp(-np.abs(np.linspace(-11, 11, M)))[:, None]).astype(np.float32)
+    r = orc.update_precond_kron(*(a.astype(np.float64) for a in (Ql, Qr, dX, dG)), 0.01)
+    got = psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)
+    for g, rr in zip(got, r):
+        assert torch.isfinite(g).all() and rel_err(g.cpu().numpy(), rr) < TOL
+
+
+def test_large_update_propagates_nan_through_tile_scales(psgd):
+    """A NaN in the data reaches both new factors on the large path too (a tile that holds one gets scale 1; the values carry it)."""
+    M, N = 2048, 2176
+    rng = np.random.default_rng(2)
+    Ql, Qr = _tri_factor(rng, M, 0.02).astype(np.float32), _tri_factor(rng, N, 0.02).astype(np.float32)
+    dX, dG = rng.standard_normal((M, N)).astype(np.float32), rng.standard_normal((M, N)).astype(np.float32)
+    dG[700, 900] = np.nan
+    got = psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dX), _dev(dG), 0.01)
+    assert torch.isnan(got[0]).any() and torch.isnan(got[1]).any()
+    G = dX.copy()
+    G[3, 5] = np.inf
+    out = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G))
+    assert not torch.isfinite(out).all()
+
+
 def test_f16_planes_with_a_wide_range_inside_one_matrix(psgd):
     """Elements far below a matrix' maximum: rows of G over e^+-14 and factors whose diagonals span 10^+-3 -- the residual
     plane is stored pre-scaled (M = 2^11 m), so small elements keep their second 11 bits; norm-wise and element-wise
