@@ -791,12 +791,7 @@ struct HPairArgs {
 };
 
 template <int DMAPOS>
-__global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
-  // ONE __shared__ object: a second one beside the LDS-DMA staging array makes hipcc drain every outstanding DMA
-  // (s_waitcnt vmcnt(0)) in front of the first fragment read of EVERY K tile (cdna_hip_programming.md section 5, "Projection
-  // GEMM" item 4a; found in this kernel's ISA in round 3: the flag word of the hand-off had been such an object since
-  // round 2).  The flag lives in a 9th-slot word of the same array.
-  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024 + 1];
+__device__ __forceinline__ void tri_pair_body(const HPairArgs& p, const int bid, u32x4* lds) {
   int& missing = *reinterpret_cast<int*>(&lds[8 * 1024]);   // tile row whose T3 tile a poll gave up on (-1: none)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) missing = -1;                              // ordered before its first reader by the barriers of phase A
@@ -805,12 +800,12 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
   // when the column count allows); rows ascend with the block index inside a column
   int r, c;
   if (p.c_count % 8 == 0) {
-    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8, cpx = p.c_count / 8;
+    const int xcd = bid % 8, j = bid / 8, cpx = p.c_count / 8;
     c = p.c_begin + xcd * cpx + j / tiles_m;
     r = j % tiles_m;
   } else {
-    c = p.c_begin + blockIdx.x / tiles_m;
-    r = blockIdx.x % tiles_m;
+    c = p.c_begin + bid / tiles_m;
+    r = bid % tiles_m;
   }
   const int m0 = r * T2, n0 = c * T2;
 
@@ -903,6 +898,27 @@ __global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
     prod = ms;                                               // produce the tile nobody published in time, then consume again
   }
   hg256_store<false>(acc, p.out, p.ldo, p.out_bf16, p.out_trans, m0, n0, w, lane);
+}
+
+template <int DMAPOS>
+__global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair_256(HPairArgs p) {
+  // ONE __shared__ object: a second one beside the LDS-DMA staging array makes hipcc drain every outstanding DMA
+  // (s_waitcnt vmcnt(0)) in front of the first fragment read of EVERY K tile (cdna_hip_programming.md section 5, "Projection
+  // GEMM" item 4a; found in this kernel's ISA in round 3: the flag word of the hand-off had been such an object since
+  // round 2).  The flag lives in a 9th-slot word of the same array.
+  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024 + 1];
+  tri_pair_body<DMAPOS>(p, (int)blockIdx.x, lds);
+}
+
+// WHAT-IF (round 5; timing only, WRONG results; psgd_kron_bf16_set_tuning(6, 1)): both fused pairs of the apply as
+// ONE grid -- blocks [0, n0) are the first pair's, the rest the second pair's, which start on the CUs the first pair's blocks leave and
+// do NOT wait for the tiles of Y they read.  What this launch gains over two launches is the most a real one-grid merge (with a second
+// hand-off protocol between the pairs) could gain.  profiles/r05_bf16_pair_merge_whatif.txt
+template <int DMAPOS>
+__global__ __launch_bounds__(kThreads2) void k_hgemm_tri_pair2_256(HPairArgs p0, HPairArgs p1, int n0) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[8 * 1024 + 1];
+  if ((int)blockIdx.x < n0) tri_pair_body<DMAPOS>(p0, (int)blockIdx.x, lds);
+  else tri_pair_body<DMAPOS>(p1, (int)blockIdx.x - n0, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1375,6 +1391,7 @@ static int launch_hgemm_two(const HGemmArgs& g0, const HGemmArgs& g1, hipStream_
 
 static int device_cu_count();
 // ---- stream-K launches (k_hgemm_sk_256) ---------------------------------------------------------------------------------
+static int g_pair_merge_whatif = 0;   // psgd_kron_bf16_set_tuning key 6: 1 = WHAT-IF, wrong results: the apply's two fused pairs as one grid (see k_hgemm_tri_pair2_256)
 static int g_pair_patch = 1;      // psgd_kron_bf16_set_tuning key 5: 1 (default) = the factor updates' tiles in 4 x 4 patches (hgemm_tile_coords,
                                   // sym == 2; from 32 x 32 tiles of 128 on: 4096^2 update 1.716 -> 1.698 ms, equal elsewhere), 0 = tile rows
 static int g_streamk = 1;         // psgd_kron_bf16_set_tuning key 4: 0 = the update's products stay on the 128^2 register-staged kernel,
@@ -1631,6 +1648,7 @@ int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 3) { g_trsm_lite = value; return PSGD_OK; }
   if (key == 4) { g_streamk = value; return PSGD_OK; }
   if (key == 5) { g_pair_patch = value; return PSGD_OK; }
+  if (key == 6) { g_pair_merge_whatif = value; return PSGD_OK; }
   if (key == 2) { g_spin_limit = (value < 0 || value > 30) ? (1u << 22) : (1u << value); return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
@@ -1690,6 +1708,13 @@ int psgd_kron_dd_apply_bf16_prepared(const void* G, void* out, int M, int N, voi
     // Gram Qr'Qr (resp. Ql'Ql) re-associated into the chain: (G Qr') Qr costs the flops of the dense G (Qr'Qr) alone,
     // and both halves have the complementary-K structure the wavefront kernel balances.  bf16 path only (one bf16
     // rounding moves from the Gram to G Qr'); the fp32 path keeps the reference's association order.
+    if (g_pair_merge_whatif && (N / T2) * (M / T2) <= device_cu_count()) {      // WHAT-IF (timing only): see k_hgemm_tri_pair2_256
+      const int tm0 = N / T2, tn0 = M / T2, tm1 = M / T2, tn1 = N / T2;
+      HPairArgs p0 = {k.Qr, N, Gb, N, k.T3, N, k.QrT, N, k.T2, M, 1, 0, N, M, 0, tn0, k.flags + 4, k.flags, g_spin_limit};
+      HPairArgs p1 = {k.Ql, M, k.T2, M, k.GT, M, k.QlT, M, out, N, 1, 0, M, N, 0, tn1, k.flags + 4 + tm0 * tn0, k.flags, g_spin_limit};    // (GT: free on this route)
+      hipLaunchKernelGGL(k_hgemm_tri_pair2_256<0>, dim3(tm0 * tn0 + tm1 * tn1), dim3(kThreads2), 0, st, p0, p1, tm0 * tn0);
+      return hipGetLastError() == hipSuccess ? PSGD_OK : PSGD_ERR_LAUNCH;
+    }
     // right pair: Y' [N][M] = ((G Qr') Qr)'   -- triangular factor Qr as the A operand, G [M][N] the K-contiguous B operand
     int rc1 = launch_tri_pair(k, k.Qr, k.QrT, Gb, k.T3, k.T2, M, 0, N, M, st, 0);
     // left pair: out [M][N] = Ql' (Ql Y)      -- B operand Y' [N][M]
