@@ -42,7 +42,7 @@ extern "C" {
  * keys retired / renumbered -- bf16 key 4 now selects the stream-K gradient launches, not the DMA position; the workspace of
  * psgd_kron_dd_update_bf16 gained the stream-K partial tiles (up to 128 MiB more for M, N multiples of 256) and padded W1 / W2
  * row strides: always size it with psgd_kron_dd_update_workspace_bytes_bf16);
- * 6 = round 5 (psgd_uvd_apply_cols_f32 added: precond_grad_UVd_math on a matrix g; the fused strip kernels of small Kron layers
+ * 6 = round 5 (psgd_uvd_apply_cols_f32 added: precond_grad_UVd_math on a matrix g; psgd_uvd_gram_wide_f32 and the psgd_uvd_wide_* entry points of ranks 33 .. 64 added; the fused strip kernels of small Kron layers
  * and their tuning key 21 removed: Kron workspaces of small layers shrink back by that scratch).
  * psgd_tf_amd/_lib.py refuses a library whose psgd_abi_version() differs from the one it was written for. */
 #define PSGD_ABI_VERSION 6
@@ -179,6 +179,38 @@ int psgd_uvd_ipuvt_matvec_cols_f32(const float *U, const float *V, const float *
 int psgd_uvd_apply_cols_f32(const float *U, const float *V, const float *d, const float *const *gs,
                             float *const *outs, int k, int64_t N, int r,
                             void *ws, int64_t ws_bytes, void *stream);
+
+/* The Gram of update_precond_UVd_math_ (psgd.py:569-615: every inner product of the columns of W = [U | V | d .* h | v ./ d]) for
+ * ranks PSGD_UVD_MAX_RANK < r <= 2 PSGD_UVD_MAX_RANK in ONE sweep over U and V (round 5; the chunked wide-rank path needed three):
+ * G [2r + 2][2r + 2], fp64, row-major, symmetric.  U, V contiguous [N, r] (16-byte aligned when r % 4 == 0); scratch:
+ * psgd_uvd_gram_wide_scratch_bytes(N, r) bytes, 256-byte aligned, contents need not survive.                                      */
+int64_t psgd_uvd_gram_wide_scratch_bytes(int64_t N, int r);
+int psgd_uvd_gram_wide_f32(const float *U, const float *V, const float *d, const float *v, const float *h,
+                           int64_t N, int r, double *G, void *scratch, int64_t scratch_bytes, void *stream);
+
+/* Ranks PSGD_UVD_MAX_RANK < r <= 2 PSGD_UVD_MAX_RANK on the whole contiguous [N, r] matrices (round 5; 16-byte aligned): the three
+ * sweeps of precond_grad_UVd_math on k columns (k = 1: the column-vector call), and the four-column building blocks of the update's
+ * row-local part -- S = M'[x_0 ..] (fp64 [k][r]), out_j = x_j + M S_j (S fp32 [k][r]), M <- M - (a c1' - b c2') (c = [c1 | c2] fp32).
+ * scratch: psgd_uvd_wide_scratch_bytes(N, r) bytes, 256-byte aligned, contents need not survive.  (Ranks above 64, and strided
+ * views, stay on the column-chunk blocks below.)                                                                                     */
+int64_t psgd_uvd_wide_scratch_bytes(int64_t N, int r);
+int psgd_uvd_wide_apply_cols_f32(const float *U, const float *V, const float *d, const float *const *gs, float *const *outs,
+                                 int k, int64_t N, int r, void *scratch, int64_t scratch_bytes, void *stream);
+int psgd_uvd_wide_colsums_f32(const float *M, const float *const *xs, int k, double *S, int64_t N, int r,
+                              void *scratch, int64_t scratch_bytes, void *stream);
+int psgd_uvd_wide_axpy_cols_f32(const float *M, const float *const *xs, float *const *outs, int k, const float *S,
+                                int64_t N, int r, void *stream);
+int psgd_uvd_wide_rank2_update_f32(float *M, const float *a, const float *b, const float *c, int64_t N, int r, void *stream);
+
+/* update_precond_UVd_math_ (psgd.py:554-617 without the balancing of :562-567, which stays with the caller) for
+ * PSGD_UVD_MAX_RANK < r <= 2 PSGD_UVD_MAX_RANK on one GPU, in place on U or V (update_U) and d: the Gram of
+ * psgd_uvd_gram_wide_f32, the r x r algebra in one workgroup (fp64, partial pivoting), one sweep that reads U and V and
+ * writes the updated factor and nablaD, and the update of d -- 5r + 10 floats per row, the traffic of the specialised ranks.
+ * U, V contiguous [N, r], 16-byte aligned, d 16-byte aligned; scratch: psgd_uvd_wide_update_scratch_bytes(N, r) bytes
+ * (about 4 N), 256-byte aligned, contents need not survive.                                                              */
+int64_t psgd_uvd_wide_update_scratch_bytes(int64_t N, int r);
+int psgd_uvd_wide_update_f32(float *U, float *V, float *d, const float *v, const float *h, int64_t N, int r,
+                             float step, float tiny, int update_U, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* Building blocks of the wide-rank path.  The sweep kernels are instantiated for ranks 1..PSGD_UVD_MAX_RANK; a
  * preconditioner of larger rank (the reference has no limit, psgd.py:663) is handled one level up

@@ -13,6 +13,20 @@ const UvdOps* uvd_ops_group1(int r);
 const UvdOps* uvd_ops_group2(int r);
 const UvdOps* uvd_ops_group3(int r);
 
+const UvdWideOps* uvd_wide_group0(int r);
+const UvdWideOps* uvd_wide_group1(int r);
+const UvdWideOps* uvd_wide_group2(int r);
+const UvdWideOps* uvd_wide_group3(int r);
+const UvdWideOps* uvd_wide_ops_for_rank(int r) {
+  if (r <= PSGD_UVD_MAX_RANK || r > 2 * PSGD_UVD_MAX_RANK) return nullptr;
+  switch ((r - 33) / 8) {
+    case 0: return uvd_wide_group0(r);
+    case 1: return uvd_wide_group1(r);
+    case 2: return uvd_wide_group2(r);
+    default: return uvd_wide_group3(r);
+  }
+}
+
 const UvdOps* uvd_ops_for_rank(int r) {
   if (r < 1 || r > PSGD_UVD_MAX_RANK) return nullptr;
   switch ((r - 1) / 8) {
@@ -406,15 +420,26 @@ __device__ __forceinline__ unsigned wave32_umax(unsigned x) {
   return (unsigned)__builtin_amdgcn_readlane((int)x, 31);
 }
 
-__device__ void lu_solve_block(double (*Mx)[MR + 2], int r, double* xs, int* piv_s) {
+// 64-lane maximum of unsigned keys on DPP row shifts / broadcasts; result valid in every lane.
+__device__ __forceinline__ unsigned wave64_umax(unsigned x) {
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));   // row_shr:1
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));   // row_shr:2
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));   // row_shr:4
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));   // row_shr:8
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+template <int CAP>
+__device__ void lu_solve_block(double (*Mx)[CAP + 2], int r, double* xs) {
   const int tid = threadIdx.x;
-  (void)piv_s;
   for (int k = 0; k < r; ++k) {
     // pivot = first row i >= k with the largest |Mx[i][k]| (compared as fp32 keys): every wave finds it
     // redundantly (lane l looks at row k + l), so no broadcast and no extra barrier is needed
     const int lane = tid & 63;
     const unsigned key = (lane < r - k) ? __float_as_uint(fabsf((float)Mx[k + lane][k])) : 0u;
-    const unsigned kmax = wave32_umax(key);
+    const unsigned kmax = (CAP <= 32) ? wave32_umax(key) : wave64_umax(key);
     const unsigned long long hit = __ballot(key == kmax && lane < r - k);
     const int piv = hit ? k + (__ffsll((long long)hit) - 1) : k;
     __syncthreads();                                   // all scans done before rows move
@@ -446,22 +471,32 @@ __device__ inline double wave_sum(double v) {
   return __shfl(v, 0, 64);
 }
 
-// One 256-thread block.  Reads the reduced Gram of W = [U | V | t | w] (MFMA block layout of
-// k_update_gram) and produces the coefficient block of UpdCoef.  fp64 throughout.
-__global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restrict__ gram, int r, float step, float tiny,
-                                                          int update_U, float* __restrict__ coef,
-                                                          double* __restrict__ c64) {
-  __shared__ double A[MR][MR + 1];    // U'U
-  __shared__ double B[MR][MR + 1];    // V'V
-  __shared__ double Cm[MR][MR + 1];   // V'U  (psgd.py:574)
-  __shared__ double Mx[MR][MR + 2];   // augmented elimination matrix
-  __shared__ double ut[MR], uw[MR], vt[MR], vw[MR], s1[MR], s2[MR], x1[MR], x2[MR], p2[MR], cs1[MR];
-  __shared__ double e1[MR], e2[MR];
-  __shared__ double sc[3];
-  __shared__ int piv_s;
+// LDS of the block-cooperative r x r algebra, r <= CAP.
+template <int CAP>
+struct CoefBlockLds {
+  double A[CAP][CAP + 1];    // U'U
+  double B[CAP][CAP + 1];    // V'V
+  double Cm[CAP][CAP + 1];   // V'U  (psgd.py:574)
+  double Mx[CAP][CAP + 2];   // augmented elimination matrix
+  double ut[CAP], uw[CAP], vt[CAP], vw[CAP], s1[CAP], s2[CAP], x1[CAP], x2[CAP], p2[CAP], cs1[CAP];
+  double e1[CAP], e2[CAP];
+  double sc[3];
+};
+
+// One 256-thread block.  Reads the reduced Gram of W = [U | V | t | w] -- DENSE = false: the MFMA block layout of
+// k_update_gram; DENSE = true: row-major [2r + 2][2r + 2] (k_gram_wide_finish, ranks 33 .. 64) -- and produces the
+// coefficient block of UpdCoef.  fp64 throughout.
+template <int CAP, bool DENSE>
+__device__ void coef_block_ref(const double* __restrict__ gram, int r, float step, float tiny, int update_U,
+                               float* __restrict__ coef, double* __restrict__ c64, CoefBlockLds<CAP>& L) {
+  auto& A = L.A; auto& B = L.B; auto& Cm = L.Cm; auto& Mx = L.Mx;
+  auto& ut = L.ut; auto& uw = L.uw; auto& vt = L.vt; auto& vw = L.vw; auto& s1 = L.s1; auto& s2 = L.s2;
+  auto& x1 = L.x1; auto& x2 = L.x2; auto& p2 = L.p2; auto& cs1 = L.cs1; auto& e1 = L.e1; auto& e2 = L.e2; auto& sc = L.sc;
   const int tid = threadIdx.x;
   const int nb = (2 * r + 2 + 15) / 16;
+  const int ncol = 2 * r + 2;
   auto G = [&](int a, int b) -> double {
+    if constexpr (DENSE) return gram[a * ncol + b];
     if (a > b) { const int t = a; a = b; b = t; }
     const int bi = a >> 4, bj = b >> 4, i = a & 15, j = b & 15;
     const int p = bi * nb - (bi * (bi - 1)) / 2 + (bj - bi);
@@ -497,7 +532,7 @@ __global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restri
   }
   if (tid < r) Mx[tid][r] = uw[tid];
   __syncthreads();
-  lu_solve_block(Mx, r, x1, &piv_s);
+  lu_solve_block<CAP>(Mx, r, x1);
   __syncthreads();
   // p2 = V' invQtv = V'w - (V'V) x1 ; x2 = solve(K, p2)          (psgd.py:578)
   if (tid < r) {
@@ -511,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restri
     Mx[i][j] = Cm[i][j] + (i == j ? 1.0 : 0.0);
   }
   __syncthreads();
-  lu_solve_block(Mx, r, x2, &piv_s);
+  lu_solve_block<CAP>(Mx, r, x2);
   __syncthreads();
   if (tid >= 64) return;                                  // the rest is one wave of r-vector algebra
 
@@ -572,19 +607,37 @@ __global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restri
     coef[3 * r + lane] = (float)x2[lane];
     coef[4 * r + lane] = (float)c1;
     coef[5 * r + lane] = (float)c2;
-    c64[0 * r + lane] = s2[lane];
-    c64[1 * r + lane] = ub;
-    c64[2 * r + lane] = (double)(float)c1;
-    c64[3 * r + lane] = (double)(float)c2;
+    if (c64) {
+      c64[0 * r + lane] = s2[lane];
+      c64[1 * r + lane] = ub;
+      c64[2 * r + lane] = (double)(float)c1;
+      c64[3 * r + lane] = (double)(float)c2;
+    }
   }
   if (lane == 0) {
     coef[6 * r] = (float)mu;
     coef[6 * r + 1] = (float)nrm;
-    c64[4 * r + 0] = (double)(float)mu;
-    c64[4 * r + 1] = aa;
-    c64[4 * r + 2] = ab;
-    c64[4 * r + 3] = bb;
+    if (c64) {
+      c64[4 * r + 0] = (double)(float)mu;
+      c64[4 * r + 1] = aa;
+      c64[4 * r + 2] = ab;
+      c64[4 * r + 3] = bb;
+    }
   }
+}
+
+__global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restrict__ gram, int r, float step, float tiny,
+                                                          int update_U, float* __restrict__ coef,
+                                                          double* __restrict__ c64) {
+  __shared__ CoefBlockLds<MR> L;
+  coef_block_ref<MR, false>(gram, r, step, tiny, update_U, coef, c64, L);
+}
+
+// ranks 33 .. 64 (psgd_uvd_wide_update_f32): 137 KiB of LDS, requested at the launch
+__global__ __launch_bounds__(kThreads) void k_wide_coef(const double* __restrict__ gram, int r, float step, float tiny,
+                                                        int update_U, float* __restrict__ coef, double* __restrict__ c64) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wide_coef_lds[];
+  coef_block_ref<2 * MR, true>(gram, r, step, tiny, update_U, coef, c64, *reinterpret_cast<CoefBlockLds<2 * MR>*>(wide_coef_lds));
 }
 
 // ---- the same r x r algebra, latency-oriented (what the entry points launch; k_update_coef above stays as the
@@ -598,17 +651,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
-}
-
-// 64-lane maximum of unsigned keys on DPP row shifts / broadcasts; result valid in every lane.
-__device__ __forceinline__ unsigned wave64_umax(unsigned x) {
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));   // row_shr:1
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));   // row_shr:2
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));   // row_shr:4
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));   // row_shr:8
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
-  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
 // Solves M x = rhs with partial pivoting; lane i < r holds row i of M in a[0..RG) (columns >= r: 0) and rhs_i in
@@ -1192,6 +1234,201 @@ int psgd_uvd_apply_cols_f32(const float* U, const float* V, const float* d, cons
     if (rr) return rr;
     PSGD_CHECK_LAUNCH(ops->apply4_s3(nt, V, d, o4, nc, N, w.coef, grid, st));
   }
+  return PSGD_OK;
+}
+
+/* ---- ranks 33 .. 64 on the whole [N, r] matrices (round 5; uvd_wide_group.hip) -------------------------------------------------
+ * scratch (caller-owned, 256-byte aligned, psgd_uvd_wide_scratch_bytes): [part: 4 r kMaxGrid doubles | sums: 4 r doubles | coef: 4 r floats] */
+struct WideWs { double* part; double* sums; float* coef; };
+static int64_t wide_scratch_layout(int r, char* base, WideWs* w) {
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off = align256(off + bytes); return p; };
+  double* part = reinterpret_cast<double*>(take((int64_t)4 * r * kMaxGrid * 8));
+  double* sums = reinterpret_cast<double*>(take((int64_t)4 * r * 8));
+  float* coef = reinterpret_cast<float*>(take((int64_t)4 * r * 4));
+  if (w) { w->part = part; w->sums = sums; w->coef = coef; }
+  return off;
+}
+static int wide_grid(const UvdWideOps* ops, int64_t N) {
+  const int64_t tiles = (N + ops->tile_rows - 1) / ops->tile_rows;
+  int64_t grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t cap = (int64_t)num_cus() * 2;        // 60-70 KiB of LDS per workgroup: two per CU
+  if (grid > cap) grid = cap;
+  if (grid > kMaxGrid) grid = kMaxGrid;
+  return grid < 1 ? 1 : (int)grid;
+}
+static int wide_open(const float* A, const float* B, int64_t N, int r, void* scratch, int64_t scratch_bytes, const UvdWideOps** ops,
+                     WideWs* w) {
+  if (N <= 0) return PSGD_ERR_BAD_ARG;
+  *ops = uvd_wide_ops_for_rank(r);
+  if (!*ops) return PSGD_ERR_RANK;
+  if (w) {
+    if (!scratch || (reinterpret_cast<uintptr_t>(scratch) & 255) || scratch_bytes < wide_scratch_layout(r, nullptr, nullptr)) return PSGD_ERR_WORKSPACE;
+    wide_scratch_layout(r, static_cast<char*>(scratch), w);
+  }
+  if (misaligned16(A) || (B && misaligned16(B))) return PSGD_ERR_ALIGN;      // (the tile loads are 16 / 8 / 4 bytes wide by rank)
+  return PSGD_OK;
+}
+
+int64_t psgd_uvd_wide_scratch_bytes(int64_t N, int r) {
+  if (N <= 0 || r <= PSGD_UVD_MAX_RANK || r > 2 * PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  return wide_scratch_layout(r, nullptr, nullptr);
+}
+
+/* precond_grad_UVd_math for 32 < r <= 64 on k columns (k = 1: the column-vector call): the three sweeps of psgd_uvd_apply_cols_f32. */
+int psgd_uvd_wide_apply_cols_f32(const float* U, const float* V, const float* d, const float* const* gs, float* const* outs, int k,
+                                 int64_t N, int r, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!U || !V || !d || !gs || !outs || k < 1) return PSGD_ERR_BAD_ARG;
+  for (int j = 0; j < k; ++j)
+    if (!gs[j] || !outs[j]) return PSGD_ERR_BAD_ARG;
+  const UvdWideOps* ops;
+  WideWs w;
+  const int rc = wide_open(U, V, N, r, scratch, scratch_bytes, &ops, &w);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nt = use_nt(N, r), grid = wide_grid(ops, N);
+  auto reduce_publish = [&]() -> int {
+    hipLaunchKernelGGL(k_reduce_pq, dim3((4 * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, w.part,
+                       static_cast<const float*>(nullptr), grid, 4 * r, w.sums, static_cast<float*>(nullptr));
+    PSGD_CHECK_LAUNCH(last_launch());
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, w.sums, w.coef, 4 * r);
+    PSGD_CHECK_LAUNCH(last_launch());
+    return PSGD_OK;
+  };
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    const int nc = k - j0 < 4 ? k - j0 : 4;
+    const float* x4[4];
+    float* o4[4];
+    for (int j = 0; j < 4; ++j) { x4[j] = gs[j0 + (j < nc ? j : 0)]; o4[j] = outs[j0 + (j < nc ? j : 0)]; }
+    PSGD_CHECK_LAUNCH(ops->apply4_s1(nt, V, d, x4, N, w.part, grid, st));
+    int rr = reduce_publish();
+    if (rr) return rr;
+    PSGD_CHECK_LAUNCH(ops->apply4_s2(nt, U, d, x4, o4, nc, N, w.coef, w.part, grid, st));
+    rr = reduce_publish();
+    if (rr) return rr;
+    PSGD_CHECK_LAUNCH(ops->apply4_s3(nt, V, d, o4, nc, N, w.coef, grid, st));
+  }
+  return PSGD_OK;
+}
+
+/* S[j][:] = M' x_j (fp64, device [k][r]);  out_j = x_j + M S_j (S fp32 [k][r]);  M <- M - (a c1' - b c2') (c = [c1 | c2]): the building
+ * blocks of psgd_uvd_colsums_f32 / _axpy_cols_f32 / _rank2_update_f32 for 32 < r <= 64, on the whole contiguous [N, r] matrix. */
+int psgd_uvd_wide_colsums_f32(const float* M, const float* const* xs, int k, double* S, int64_t N, int r, void* scratch,
+                              int64_t scratch_bytes, void* stream) {
+  if (!M || !xs || !S || k < 1) return PSGD_ERR_BAD_ARG;
+  const UvdWideOps* ops;
+  WideWs w;
+  const int rc = wide_open(M, nullptr, N, r, scratch, scratch_bytes, &ops, &w);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = wide_grid(ops, N);
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    const int nc = k - j0 < 4 ? k - j0 : 4;
+    const float* x4[4];
+    for (int j = 0; j < 4; ++j) {
+      x4[j] = xs[j0 + (j < nc ? j : 0)];
+      if (!x4[j]) return PSGD_ERR_BAD_ARG;
+    }
+    PSGD_CHECK_LAUNCH(ops->colreduce4(use_nt(N, r), M, x4, N, w.part, grid, st));
+    hipLaunchKernelGGL(k_reduce_pq, dim3((nc * r + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, st, w.part,
+                       static_cast<const float*>(nullptr), grid, nc * r, S + (int64_t)j0 * r, static_cast<float*>(nullptr));
+    PSGD_CHECK_LAUNCH(last_launch());
+  }
+  return PSGD_OK;
+}
+
+int psgd_uvd_wide_axpy_cols_f32(const float* M, const float* const* xs, float* const* outs, int k, const float* S, int64_t N, int r,
+                                void* stream) {
+  if (!M || !xs || !outs || !S || k < 1) return PSGD_ERR_BAD_ARG;
+  const UvdWideOps* ops;
+  const int rc = wide_open(M, nullptr, N, r, nullptr, 0, &ops, nullptr);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = wide_grid(ops, N);
+  for (int j0 = 0; j0 < k; j0 += 4) {
+    const int nc = k - j0 < 4 ? k - j0 : 4;
+    const float* x4[4];
+    float* o4[4];
+    for (int j = 0; j < 4; ++j) {
+      x4[j] = xs[j0 + (j < nc ? j : 0)];
+      o4[j] = outs[j0 + (j < nc ? j : 0)];
+      if (!x4[j] || !o4[j]) return PSGD_ERR_BAD_ARG;
+    }
+    PSGD_CHECK_LAUNCH(ops->rowdot_axpy4(use_nt(N, r), M, x4, o4, nc, N, S + (int64_t)j0 * r, grid, st));
+  }
+  return PSGD_OK;
+}
+
+int psgd_uvd_wide_rank2_update_f32(float* M, const float* a, const float* b, const float* c, int64_t N, int r, void* stream) {
+  if (!M || !a || !b || !c) return PSGD_ERR_BAD_ARG;
+  const UvdWideOps* ops;
+  const int rc = wide_open(M, nullptr, N, r, nullptr, 0, &ops, nullptr);
+  if (rc) return rc;
+  PSGD_CHECK_LAUNCH(ops->rank2_update(use_nt(N, r), M, a, b, N, c, wide_grid(ops, N), static_cast<hipStream_t>(stream)));
+  return PSGD_OK;
+}
+
+static int flat_grid(int64_t n);
+
+// ---- the whole update for 32 < r <= 64 on one GPU: Gram (one sweep over U and V, uvd_wide_gram.hip) -> r x r algebra (one block,
+// fp64) -> sweep 2 (reads U and V, writes the updated factor and nablaD) -> d.  5r + 10 floats per row, as for the specialised ranks.
+struct WideUpd { char* gram_scr; int64_t gram_bytes; double* G; float* coef; float* nabla; float* pmax; float* maxbuf; };
+static int64_t wide_update_layout(int64_t N, int r, char* base, WideUpd* w) {
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off = align256(off + bytes); return p; };
+  const int64_t gb = psgd_uvd_gram_wide_scratch_bytes(N, r);
+  const int ncol = 2 * r + 2;
+  char* gs = take(gb);
+  double* G = reinterpret_cast<double*>(take((int64_t)ncol * ncol * 8));
+  float* coef = reinterpret_cast<float*>(take((int64_t)(6 * r + 2) * 4));
+  float* nabla = reinterpret_cast<float*>(take(N * 4));
+  float* pmax = reinterpret_cast<float*>(take((int64_t)kMaxGrid * 4));
+  float* maxbuf = reinterpret_cast<float*>(take(16));
+  if (w) { w->gram_scr = gs; w->gram_bytes = gb; w->G = G; w->coef = coef; w->nabla = nabla; w->pmax = pmax; w->maxbuf = maxbuf; }
+  return off;
+}
+
+int64_t psgd_uvd_wide_update_scratch_bytes(int64_t N, int r) {
+  if (N <= 0 || r <= PSGD_UVD_MAX_RANK || r > 2 * PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  return wide_update_layout(N, r, nullptr, nullptr);
+}
+
+int psgd_uvd_wide_update_f32(float* U, float* V, float* d, const float* v, const float* h, int64_t N, int r, float step, float tiny,
+                             int update_U, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!U || !V || !d || !v || !h) return PSGD_ERR_BAD_ARG;
+  const UvdWideOps* ops;
+  int rc = wide_open(U, V, N, r, nullptr, 0, &ops, nullptr);
+  if (rc) return rc;
+  if (misaligned16(d)) return PSGD_ERR_ALIGN;
+  if (!scratch || (reinterpret_cast<uintptr_t>(scratch) & 255) || scratch_bytes < wide_update_layout(N, r, nullptr, nullptr))
+    return PSGD_ERR_WORKSPACE;
+  WideUpd w;
+  wide_update_layout(N, r, static_cast<char*>(scratch), &w);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  rc = psgd_uvd_gram_wide_f32(U, V, d, v, h, N, r, w.G, w.gram_scr, w.gram_bytes, stream);
+  if (rc) return rc;
+  {
+    static bool attr_done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PSGD_ERR_LAUNCH;
+    const int lds = (int)sizeof(CoefBlockLds<2 * MR>);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_coef), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return PSGD_ERR_LAUNCH;
+      if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(k_wide_coef, dim3(1), dim3(kThreads), lds, st, w.G, r, step, tiny, update_U, w.coef, static_cast<double*>(nullptr));
+    PSGD_CHECK_LAUNCH(last_launch());
+  }
+  // sweep 2 holds a tile of U and one of V per wave (up to 131 KiB per workgroup): one workgroup per CU
+  const int64_t tiles = (N + ops->tile_rows - 1) / ops->tile_rows;
+  int64_t grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (grid > num_cus()) grid = num_cus();
+  if (grid > kMaxGrid) grid = kMaxGrid;
+  if (grid < 1) grid = 1;
+  PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, N, w.coef, w.nabla, w.pmax, (int)grid, st));
+  hipLaunchKernelGGL(k_update_d, dim3(flat_grid(N)), dim3(kThreads), 0, st, d, w.nabla, (long)N, w.maxbuf, w.pmax, (int)grid, step, tiny);
+  PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }
 

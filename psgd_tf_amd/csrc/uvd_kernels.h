@@ -60,13 +60,15 @@ __device__ __forceinline__ T stream_load(const T* p) {
 // loads, 64 lanes wide.  Preference: 16-byte loads; fall back to 8- or 4-byte
 // loads when a 16-byte-loadable tile would exceed 2048 floats (8 KiB) of LDS.
 constexpr int kMaxTileFloats = 2048;
+// (ranks 33..64 -- the building blocks of the wide-rank path, round 5 -- take 64-row tiles of up to 16 KiB)
+constexpr int max_tile_floats(int R) { return R <= 32 ? kMaxTileFloats : 2 * kMaxTileFloats; }
 constexpr int cfg_rows_per_lane(int R, int lv) {
   // smallest rpl in {1,2,4} with 64*rpl*R divisible by 64*lv
   return (R % lv == 0) ? 1 : ((2 * R) % lv == 0 ? 2 : 4);
 }
 constexpr int cfg_load_vec(int R) {
-  return (64 * cfg_rows_per_lane(R, 4) * R <= kMaxTileFloats) ? 4
-       : (64 * cfg_rows_per_lane(R, 2) * R <= kMaxTileFloats) ? 2 : 1;
+  return (64 * cfg_rows_per_lane(R, 4) * R <= max_tile_floats(R)) ? 4
+       : (64 * cfg_rows_per_lane(R, 2) * R <= max_tile_floats(R)) ? 2 : 1;
 }
 // native clang vector types (HIP's float4 is a struct-with-union that blocks SROA of
 // register arrays: the prefetch buffers ended up in scratch memory with it)
@@ -86,7 +88,7 @@ struct Cfg {
   static constexpr int kLoadsPerLane = kTileFloats / (64 * kLoadVec);       // vector loads per lane per tile
   typedef typename VecT<kLoadVec>::type LoadT;
   static_assert(kTileFloats % (64 * kLoadVec) == 0, "tile must be whole wave-wide vector loads");
-  static_assert(kTileFloats <= kMaxTileFloats, "tile exceeds LDS budget");
+  static_assert(kTileFloats <= max_tile_floats(R), "tile exceeds LDS budget");
 };
 
 template <int R>
@@ -1042,6 +1044,20 @@ struct UvdOps {
   // max resident blocks per CU for each sweep kernel (occupancy query)
   int (*occupancy)(int which);
 };
+
+// Ranks 33 .. 64 (round 5): the kernels the wide-rank path needs, on the whole [N, r] matrix instead of column chunks -- the four-column
+// building blocks and the three sweeps of the apply (uvd_wide_group.hip instantiates them; psgd_uvd_wide_* in psgd_uvd.hip)
+struct UvdWideOps {
+  int tile_rows;
+  int (*colreduce4)(int nt, const float* M, const float* const* x, long N, double* part, int grid, hipStream_t st);
+  int (*rowdot_axpy4)(int nt, const float* M, const float* const* x, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
+  int (*rank2_update)(int nt, float* M, const float* a, const float* b, long N, const float* coef, int grid, hipStream_t st);
+  int (*apply4_s1)(int nt, const float* V, const float* d, const float* const* x, long N, double* part, int grid, hipStream_t st);
+  int (*apply4_s2)(int nt, const float* U, const float* d, const float* const* x, float* const* o, int ncols, long N, const float* coef, double* part, int grid, hipStream_t st);
+  int (*apply4_s3)(int nt, const float* V, const float* d, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
+  int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N, const float* coef, float* nabla, float* part_max, int grid, hipStream_t st);
+};
+const UvdWideOps* uvd_wide_ops_for_rank(int r);   // nullptr outside 33 .. 64
 
 enum { kOccColreduce = 0, kOccApplyS2, kOccApplyS3, kOccRowdot, kOccGram, kOccUpdS2U, kOccUpdS2V, kOccUpdS2F, kOccFinal };
 

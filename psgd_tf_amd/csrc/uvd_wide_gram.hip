@@ -1,0 +1,355 @@
+// uvd_wide_gram.hip -- the Gram of W = [U | V | t | w] (t = d .* h, w = v ./ d; psgd.py:569-615 needs every inner product of these
+// 2r + 2 columns) for ranks 32 < r <= 64 in ONE sweep over U and V (round 5).
+//
+// The rank-templated Gram kernel (uvd_kernels.h: k_update_gram, r <= 32) keeps one fp32 MFMA accumulator set and one fp64 set per
+// pair of 16-column blocks in every wave's registers: 15 pairs at r = 32, 45 at r = 64 -- 540 registers.  The wide-rank path therefore
+// ran it on PAIRS OF COLUMN CHUNKS (uvd_wide.py), one sweep per pair: three passes over U and V at r = 64 (six pair sweeps), and the
+// update reached 0.23 of the specialised rate.  Here a workgroup shares one 32-row tile: every element is split 3-way into bf16
+// (x = h + m + l exactly, as in k_update_gram) ONCE, into column-major bf16 planes in LDS, and the block pairs are dealt to eight waves
+// (<= 6 pairs each at r = 64: six v_mfma_f32_16x16x32_bf16 per pair, fp32 chains of 256 rows folded into fp64).  Partials: one fp64
+// tile set per workgroup (each pair is owned by exactly one wave: no cross-wave reduction), reduced in block order and scattered into
+// the dense symmetric Gram [ncol][ncol] by k_gram_wide_finish (fixed order: reproducible).
+#include "uvd_kernels.h"
+
+#include "psgd_hip.h"
+
+#include <cstdlib>
+
+namespace psgd {
+
+#ifndef GW_DBG
+#define GW_DBG 0        // what-if builds (wrong results): 1 = no global loads, 2 = no MFMA phase, 4 = no split / plane writes
+#endif
+constexpr int kGwRows = 32;                  // rows per tile = the K extent of one MFMA
+constexpr int kGwThreads = 1024;             // sixteen waves: eight split, eight multiply
+constexpr int kGwMulWaves = 11;              // waves 5 .. 15 multiply: block pair p belongs to wave p mod 11, accumulator slot p / 11
+constexpr int kGwDepth = 4;                  // tiles the split role requests ahead (even: a tile's plane buffer is its ordinal's parity)
+
+__host__ __device__ constexpr int gw_pair_index(int NB, int bi, int bj) { return bi * NB - (bi * (bi - 1)) / 2 + (bj - bi); }
+__host__ __device__ constexpr int gw_max_pairs(int NB) { return (NB * (NB + 1) / 2 + kGwMulWaves - 1) / kGwMulWaves; }
+
+template <int N> struct GwInt { static constexpr int value = N; };
+template <int I, int N, class F>
+__device__ __forceinline__ void gw_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(GwInt<I>{});
+    gw_static_for<I + 1, N>(f);
+  }
+}
+
+// 16-byte unit of the bf16 planes that holds rows 8 rg .. 8 rg + 7 of column col.  The XOR keeps a fragment read (lane -> column
+// lane & 15 of a block, row group lane >> 4) conflict-free for the lane groups ds_read_b128 is served in (MI355X_MICROARCH.md, LDS).
+__device__ __forceinline__ int gw_unit(int col, int rg) { return col * 4 + (rg ^ ((col >> 2) & 2)); }
+
+// Sixteen waves, two roles.  Waves 0-7 ("split"): tile t + 1 from global memory straight into the bf16 planes -- a thread owns (column, 8
+// rows) items; its 8 loads are each coalesced across the wave (64 consecutive floats of one row), so there is no fp32 stage and no
+// transposing pass; the loads of tile t + 2 are in flight while tile t + 1 is split.  Waves 8-15 ("mfma"): the block pairs of tile t from
+// the other plane buffer.  ONE barrier per tile swaps the buffers.  The matrix work of a tile is 270 MFMAs = 1080 cycles per SIMD -- two
+// thirds of the time HBM gives a 16.6-KiB tile per CU at r = 64 -- so the split has to run beside it, not before it: a version with all
+// waves doing load -> split -> barrier -> MFMA -> barrier ran at 2.1 TB/s (1.6 with four waves of 12 pairs), whatever the prefetch depth.
+// TAIL = false: the tiles [0, ntiles) are whole (no row is checked against N: the loads are a per-tile scalar base + a per-thread offset
+// computed once); TAIL = true: one workgroup on the last, partial tile `tile0`, every row clamped and masked.
+template <int NB, bool NT, bool TAIL>
+__global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restrict__ U, const float* __restrict__ V,
+                                                          const float* __restrict__ d, const float* __restrict__ v,
+                                                          const float* __restrict__ h, long N, int r, long ntiles, long tile0,
+                                                          double* __restrict__ part) {
+  constexpr int NC = NB * 16;                       // padded columns
+  constexpr int NPW = gw_max_pairs(NB);
+  constexpr int NP = NB * (NB + 1) / 2;
+  typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) u32x4g PL[2][3][NC * 4 + 16];     // (+ 16 units: the t / w scratch of the mfma role)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long G = gridDim.x;
+  const long tfirst = TAIL ? tile0 : (long)blockIdx.x;       // this workgroup's first tile; TAIL: its only one
+  if (TAIL) ntiles = tile0 + 1;
+
+  // The roles are separate code paths with their own loops (their states must not be live at the same time: 128 registers); all of
+  // them execute the same number of barriers: one after the planes are zeroed, one after the prologue, one per tile.
+  auto tile_loop = [&](auto&& prologue, auto&& step) {   // step(q, t): iteration of tile t, ordinal q mod depth (compile time)
+    __syncthreads();
+    prologue();
+    __syncthreads();
+    for (long tb = tfirst; tb < ntiles; tb += kGwDepth * G)
+      gw_static_for<0, kGwDepth>([&](auto ic) {
+        const long t = tb + decltype(ic)::value * G;
+        if (t < ntiles) {                            // (uniform over the workgroup)
+          step(ic, t);
+          __syncthreads();
+        }
+      });
+  };
+  if (wave < 4) {
+    // ---- split role: thread (column c < r, row group g < 4) -- 4r <= 256 threads -- owns the items (c, g) of U and (r + c, g) of V:
+    // 8 + 8 loads per tile, each coalesced across the wave, every address a per-tile SCALAR base plus one 32-bit per-thread offset.
+    // Every load is unconditional and nothing else in this role loads: a branch between load variants, or a conditional load beside
+    // the ring, makes the compiler wait for EVERY outstanding load at the join (0.6 TB/s with branches per element).  kGwDepth tiles
+    // are requested ahead (a ring of register buffers, the tile loop unrolled by the depth).
+    const int col = tid % r, g0 = tid / r;
+    const bool on = g0 < 4;
+    const unsigned e0 = on ? (unsigned)(g0 * 8 * r + col) : 0u;       // element offset of the item's first value inside a tile
+    const int un0 = gw_unit(col, on ? g0 : 0), un1 = gw_unit(r + col, on ? g0 : 0);
+    for (int i = tid; i < 2 * 3 * (NC * 4 + 16); i += 256) (&PL[0][0][0])[i] = u32x4g{0u, 0u, 0u, 0u};     // (pad columns stay zero)
+    float px[kGwDepth][16];
+    auto fetch = [&](long t, auto ic) {
+      constexpr int ib = decltype(ic)::value;
+      if constexpr (!TAIL) {
+        // (the tile bases are kept opaque: left visible, the compiler turns each of the 64 loads of the ring into its own 64-bit
+        //  induction pointer -- 128 registers of addresses, spilled to scratch)
+        long toff = t * kGwRows * r;                 // (uniform; the OFFSET is the opaque value, so that the loads stay global loads)
+        asm volatile("" : "+s"(toff));
+        const float* ub = U + toff;
+        const float* vb = V + toff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          px[ib][j] = stream_load<NT>((ub + j * r) + e0);
+          px[ib][8 + j] = stream_load<NT>((vb + j * r) + e0);
+        }
+      } else {
+        const long row0 = t * kGwRows + (on ? g0 : 0) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const long row = row0 + j, rc = (row < N ? row : N - 1) * r + col;
+          const float xu = stream_load<NT>(U + rc), xv = stream_load<NT>(V + rc);
+          px[ib][j] = (on && row < N) ? xu : 0.0f;
+          px[ib][8 + j] = (on && row < N) ? xv : 0.0f;
+        }
+      }
+    };
+    auto split_to = [&](int buf, auto ic) {
+      constexpr int ib = decltype(ic)::value;
+      if ((GW_DBG & 4) || !on) return;
+      bf16x8 fh, fm, fl;
+      float x[8];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = px[ib][hh * 8 + j];
+        split3_bf16(x, fh, fm, fl);
+        const int un = hh ? un1 : un0;
+        PL[buf][0][un] = __builtin_bit_cast(u32x4g, fh);
+        PL[buf][1][un] = __builtin_bit_cast(u32x4g, fm);
+        PL[buf][2][un] = __builtin_bit_cast(u32x4g, fl);
+      }
+    };
+    const long t0 = tfirst;
+    tile_loop(
+        [&]() {      // tiles 0 .. depth - 1 requested (ring slot = ordinal mod depth), tile 0 split into buffer 0, its slot refilled
+          gw_static_for<0, kGwDepth>([&](auto ic) {
+            const long t = t0 + decltype(ic)::value * G;
+            if (t < ntiles) fetch(t, ic);
+          });
+          if (t0 < ntiles) split_to(0, GwInt<0>{});
+          if (t0 + kGwDepth * G < ntiles) fetch(t0 + kGwDepth * G, GwInt<0>{});
+        },
+        [&](auto ic, long t) {                       // while tile t is multiplied: tile t + 1 into the other buffer, its slot refilled
+          constexpr int q = decltype(ic)::value, slot = (q + 1) % kGwDepth;
+          if (t + G < ntiles) {
+            split_to((q + 1) & 1, GwInt<slot>{});
+            if (t + (1 + kGwDepth) * G < ntiles) fetch(t + (1 + kGwDepth) * G, GwInt<slot>{});
+          }
+        });
+    return;
+  }
+  if (wave == 4) {
+    // ---- the columns t = d .* h and w = v ./ d: lane l computes ONE value of the tile's 8 items (item l >> 3 = (column (l >> 3) & 1,
+    // row group l >> 4), row l & 7), the wave passes the 64 values through a 256-byte LDS scratch, lanes 0-7 split 8 values each.
+    // Same ring as the split role.  (Under `if (tid < 8)` inside the split role these loads made the compiler wait for that role's
+    // whole ring at the join; one tile ahead in the mfma role an iteration lasted one memory latency.)
+    float* TW = reinterpret_cast<float*>(&PL[1][2][NC * 4]);          // (behind the planes: 16 extra units)
+    const int tw_un = gw_unit(2 * r + (lane & 1), (lane >> 1) & 3);
+    float ptw[kGwDepth];
+    auto fetch = [&](long t, auto ic) {
+      const int it = lane >> 3;
+      const long row = t * kGwRows + (it >> 1) * 8 + (lane & 7), rc = row < N ? row : N - 1;
+      float dd = d[rc], hh = h[rc], vv = v[rc];
+      asm volatile("" : "+v"(dd), "+v"(hh), "+v"(vv));   // (all three loads issued before any use, on every lane)
+      const float wv = vv / dd, tv = dd * hh;
+      ptw[decltype(ic)::value] = row < N ? ((it & 1) ? wv : tv) : 0.0f;
+    };
+    auto split_to = [&](int b, auto ic) {
+      TW[lane] = ptw[decltype(ic)::value];             // [item][row]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = TW[lane * 8 + j];
+        bf16x8 fh, fm, fl;
+        split3_bf16(x, fh, fm, fl);
+        PL[b][0][tw_un] = __builtin_bit_cast(u32x4g, fh);
+        PL[b][1][tw_un] = __builtin_bit_cast(u32x4g, fm);
+        PL[b][2][tw_un] = __builtin_bit_cast(u32x4g, fl);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();                 // (the scratch is free again)
+    };
+    const long t0 = tfirst;
+    tile_loop(
+        [&]() {
+          gw_static_for<0, kGwDepth>([&](auto ic) {
+            const long t = t0 + decltype(ic)::value * G;
+            if (t < ntiles) fetch(t, ic);
+          });
+          if (t0 < ntiles) split_to(0, GwInt<0>{});
+          if (t0 + kGwDepth * G < ntiles) fetch(t0 + kGwDepth * G, GwInt<0>{});
+        },
+        [&](auto ic, long t) {
+          constexpr int q = decltype(ic)::value, slot = (q + 1) % kGwDepth;
+          if (t + G < ntiles) {
+            split_to((q + 1) & 1, GwInt<slot>{});
+            if (t + (1 + kGwDepth) * G < ntiles) fetch(t + (1 + kGwDepth) * G, GwInt<slot>{});
+          }
+        });
+    return;
+  }
+  // ---- mfma role: waves 5 .. 15
+  const int mw = wave - 5;
+  f32x4 acc[NPW];
+  double acc64[NPW][4];
+#pragma unroll
+  for (int p = 0; p < NPW; ++p) {
+    acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc64[p][e] = 0.0;
+  }
+  int since = 0;
+  tile_loop([]() {}, [&](auto ic, long) {
+    const int buf = decltype(ic)::value & 1;         // (depth is even: the buffer of a tile is its ordinal's parity)
+    auto frag = [&](int b, bf16x8 (&f)[3]) {
+      const int un = gw_unit(b * 16 + (lane & 15), lane >> 4);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) f[pl] = __builtin_bit_cast(bf16x8, PL[buf][pl][un]);
+    };
+    gw_static_for<0, NB>([&](auto bic) {
+      constexpr int bi = decltype(bic)::value;
+      gw_static_for<bi, NB>([&](auto bjc) {
+        constexpr int bj = decltype(bjc)::value;
+        constexpr int pi = gw_pair_index(NB, bi, bj), ps = pi / kGwMulWaves;
+        if (mw == pi % kGwMulWaves && !(GW_DBG & 2)) {
+          bf16x8 fa[3], fb[3];
+          frag(bj, fb);
+          if constexpr (bi == bj) { fa[0] = fb[0]; fa[1] = fb[1]; fa[2] = fb[2]; }
+          else frag(bi, fa);
+          f32x4 a = acc[ps];
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1], a, 0, 0, 0);     // m m'
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2], a, 0, 0, 0);     // h l'
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0], a, 0, 0, 0);     // l h'
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1], a, 0, 0, 0);     // h m'
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0], a, 0, 0, 0);     // m h'
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0], a, 0, 0, 0);     // h h'
+          acc[ps] = a;
+        }
+      });
+    });
+    if (++since == 256 / kGwRows) {
+#pragma unroll
+      for (int p = 0; p < NPW; ++p) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
+        acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      since = 0;
+    }
+  });
+#pragma unroll
+  for (int p = 0; p < NPW; ++p)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
+  // every pair is owned by one wave: its partial goes straight out, [block][pair][e * 64 + lane]
+  double* dst = part + (long)blockIdx.x * NP * 256;
+#pragma unroll
+  for (int p = 0; p < NPW; ++p) {
+    const int pi = p * kGwMulWaves + mw;             // the pair in slot p
+    if (pi < NP) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[pi * 256 + e * 64 + lane] = acc64[p][e];
+    }
+  }
+}
+
+// the workgroups' partials summed in block order, scattered into the dense symmetric Gram G [ncol][ncol] (fp64)
+__global__ __launch_bounds__(kThreads) void k_gram_wide_finish(const double* __restrict__ part, int nblocks, int NB, int ncol,
+                                                               double* __restrict__ G) {
+  const int NP = NB * (NB + 1) / 2;
+  const int idx = blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= NP * 256) return;
+  const int p = idx >> 8, q = idx & 255, e = q >> 6, l = q & 63;
+  int bi = 0, rem = p;
+  while (rem >= NB - bi) { rem -= NB - bi; ++bi; }
+  const int bj = bi + rem;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += part[((long)b * NP + p) * 256 + q];
+  const int i = 16 * bi + 4 * (l >> 4) + e, j = 16 * bj + (l & 15);
+  if (i < ncol && j < ncol) {
+    G[(long)i * ncol + j] = s;
+    if (bi != bj) G[(long)j * ncol + i] = s;
+  }
+}
+
+template <int NB>
+static int launch_gram_wide(int nt, const float* U, const float* V, const float* d, const float* v, const float* h, long N, int r,
+                            double* part, int grid, hipStream_t st) {
+  const long nfull = N / kGwRows;                      // whole tiles: `grid` workgroups; the partial last tile: one more, its partial behind
+  if (nfull > 0) {
+    if (nt) hipLaunchKernelGGL((k_gram_wide<NB, true, false>), dim3(grid), dim3(kGwThreads), 0, st, U, V, d, v, h, N, r, nfull, 0L, part);
+    else hipLaunchKernelGGL((k_gram_wide<NB, false, false>), dim3(grid), dim3(kGwThreads), 0, st, U, V, d, v, h, N, r, nfull, 0L, part);
+    if (hipGetLastError() != hipSuccess) return 1;
+  }
+  if (N % kGwRows) {
+    double* tail = part + (long)(nfull > 0 ? grid : 0) * (NB * (NB + 1) / 2) * 256;
+    hipLaunchKernelGGL((k_gram_wide<NB, false, true>), dim3(1), dim3(kGwThreads), 0, st, U, V, d, v, h, N, r, nfull + 1, nfull, tail);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace psgd
+
+using namespace psgd;
+
+static int gram_wide_grid(int64_t N) {
+  const int64_t tiles = N / kGwRows;
+  int64_t g = (int64_t)device_cus();                // one 16-wave workgroup per CU
+  if (g > tiles) g = tiles;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" {
+
+int64_t psgd_uvd_gram_wide_scratch_bytes(int64_t N, int r) {
+  if (N <= 0 || r <= PSGD_UVD_MAX_RANK || r > 2 * PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  const int NB = (2 * r + 2 + 15) / 16;
+  return (int64_t)(gram_wide_grid(N) + 1) * (NB * (NB + 1) / 2) * 256 * 8;      // (+ 1: the partial last tile's workgroup)
+}
+
+/* G [2r + 2][2r + 2] (fp64, row-major, symmetric) = W'W for W = [U | V | d .* h | v ./ d], 32 < r <= 64, in one sweep over U and V
+ * (contiguous [N, r] fp32).  scratch: psgd_uvd_gram_wide_scratch_bytes(N, r) bytes, 256-aligned. */
+int psgd_uvd_gram_wide_f32(const float* U, const float* V, const float* d, const float* v, const float* h, int64_t N, int r,
+                           double* G, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!U || !V || !d || !v || !h || !G || N <= 0) return PSGD_ERR_BAD_ARG;
+  if (r <= PSGD_UVD_MAX_RANK || r > 2 * PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  const int64_t need = psgd_uvd_gram_wide_scratch_bytes(N, r);
+  if (!scratch || (reinterpret_cast<uintptr_t>(scratch) & 255) || scratch_bytes < need) return PSGD_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int NB = (2 * r + 2 + 15) / 16, grid = gram_wide_grid(N);
+  static const int env_nt = getenv("PSGD_GW_NT") ? atoi(getenv("PSGD_GW_NT")) : -1;      // (A/B runs)
+  const int nt = env_nt >= 0 ? env_nt : policy_nt(2 * N * r * 4);
+  double* part = static_cast<double*>(scratch);
+  int e = 1;
+  switch (NB) {
+    case 5: e = launch_gram_wide<5>(nt, U, V, d, v, h, N, r, part, grid, st); break;
+    case 6: e = launch_gram_wide<6>(nt, U, V, d, v, h, N, r, part, grid, st); break;
+    case 7: e = launch_gram_wide<7>(nt, U, V, d, v, h, N, r, part, grid, st); break;
+    case 8: e = launch_gram_wide<8>(nt, U, V, d, v, h, N, r, part, grid, st); break;
+    case 9: e = launch_gram_wide<9>(nt, U, V, d, v, h, N, r, part, grid, st); break;
+    default: return PSGD_ERR_RANK;
+  }
+  if (e) return PSGD_ERR_LAUNCH;
+  const int NP = NB * (NB + 1) / 2, ncol = 2 * r + 2;
+  const int nsets = (N / kGwRows > 0 ? grid : 0) + (N % kGwRows ? 1 : 0);
+  hipLaunchKernelGGL(k_gram_wide_finish, dim3((NP * 256 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, part, nsets, NB, ncol, G);
+  return hipGetLastError() == hipSuccess ? PSGD_OK : PSGD_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -31,6 +31,8 @@ import torch
 from . import _lib
 
 _MAXR = _lib.UVD_MAX_RANK
+_gram_scratch = {}        # (device, N, r) -> scratch of the wide Gram kernel (a few entries)
+_update_scratch = {}      # (device, stream, N, r) -> scratch of psgd_uvd_wide_update_f32 (holds nablaD: about 4 N bytes)
 
 
 def _chunks(r):
@@ -49,18 +51,46 @@ def _ptrs(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def _full_ok(*mats):
+    """Ranks 33 .. 64 run on the WHOLE matrices (round 5: psgd_uvd_wide_*): contiguous [N, r], 16-byte aligned.  PSGD_WIDE_FULL=0: the
+    column-chunk path (A/B runs)."""
+    if os.environ.get("PSGD_WIDE_FULL") == "0" or os.environ.get("PSGD_WIDE_GRAM") == "0":
+        return False
+    r = mats[0].shape[1]
+    return _MAXR < r <= 2 * _MAXR and all(m.dim() == 2 and m.is_contiguous() and m.data_ptr() % 16 == 0 for m in mats)
+
+
+_wide_scratch = {}        # (device, stream, r) -> scratch of the psgd_uvd_wide_* entry points
+
+
 class _Ctx:
-    def __init__(self, U, workspace_fn):
+    def __init__(self, U, workspace_fn, full=False):
         self.dev = U.device
         self.N, self.r = U.shape
-        self.c, self.rc, self.views = _chunks(self.r)
         self.lib = _lib.load()
-        self.ws = workspace_fn(self.dev, self.N, self.rc)
         self.st = torch.cuda.current_stream(self.dev).cuda_stream
+        self.full = bool(full)
+        if self.full:                                    # one "chunk": the matrix itself, through the rank 33 .. 64 kernels
+            self.c, self.rc, self.views = 1, self.r, True
+            key = (self.dev.index, self.st, self.r)
+            n = int(self.lib.psgd_uvd_wide_scratch_bytes(self.N, self.r))
+            if n < 0:
+                _lib.check(n, "psgd_uvd_wide_scratch_bytes")
+            scr = _wide_scratch.get(key)
+            if scr is None or scr.numel() < n:
+                scr = _wide_scratch[key] = torch.empty(n, dtype=torch.uint8, device=self.dev)
+                while len(_wide_scratch) > 8:
+                    _wide_scratch.pop(next(iter(_wide_scratch)))
+            self.ws = scr
+            return
+        self.c, self.rc, self.views = _chunks(self.r)
+        self.ws = workspace_fn(self.dev, self.N, self.rc)
 
     def split(self, M, copy=False):
         """column chunks [N, rc] of M [N, r]: views of M (no copy; in-place kernels then update M itself) when the rank splits
         evenly and M is row-major, else contiguous copies (the last one zero-padded; scatter() writes them back)."""
+        if self.full and not copy:
+            return [M]
         if self.views and not copy and M.dim() == 2 and M.stride(1) == 1 and self._view_ok(M):
             return [M[:, k * self.rc:(k + 1) * self.rc] for k in range(self.c)]
         out = []
@@ -96,6 +126,10 @@ class _Ctx:
 
     def colsums(self, M, xs):
         S = torch.empty(len(xs), self.rc, dtype=torch.float64, device=self.dev)
+        if self.full:
+            _lib.check(self.lib.psgd_uvd_wide_colsums_f32(M.data_ptr(), _ptrs(xs), len(xs), S.data_ptr(), self.N, self.r,
+                                                          self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_wide_colsums_f32")
+            return S
         _lib.check(self.lib.psgd_uvd_colsums_ld_f32(M.data_ptr(), M.stride(0), _ptrs(xs), len(xs), S.data_ptr(), self.N, self.rc,
                                                     self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_colsums_ld_f32")
         return S
@@ -104,14 +138,38 @@ class _Ctx:
         """in place: x_j += M S_j  (S [k, rc] fp32)."""
         S = S.to(torch.float32).contiguous()
         p = _ptrs(xs)
+        if self.full:
+            _lib.check(self.lib.psgd_uvd_wide_axpy_cols_f32(M.data_ptr(), p, p, len(xs), S.data_ptr(), self.N, self.r, self.st),
+                       "psgd_uvd_wide_axpy_cols_f32")
+            return
         _lib.check(self.lib.psgd_uvd_axpy_cols_ld_f32(M.data_ptr(), M.stride(0), p, p, len(xs), S.data_ptr(), self.N, self.rc,
                                                       self.ws.data_ptr(), self.ws.numel(), self.st), "psgd_uvd_axpy_cols_ld_f32")
 
     def rank2(self, M, a, b, c1, c2):
         cc = torch.cat([c1.reshape(-1), c2.reshape(-1)]).to(torch.float32).contiguous()
+        if self.full:
+            _lib.check(self.lib.psgd_uvd_wide_rank2_update_f32(M.data_ptr(), a.data_ptr(), b.data_ptr(), cc.data_ptr(), self.N, self.r,
+                                                               self.st), "psgd_uvd_wide_rank2_update_f32")
+            return
         _lib.check(self.lib.psgd_uvd_rank2_update_ld_f32(M.data_ptr(), M.stride(0), a.data_ptr(), b.data_ptr(), cc.data_ptr(),
                                                          self.N, self.rc, self.ws.data_ptr(), self.ws.numel(), self.st),
                    "psgd_uvd_rank2_update_ld_f32")
+
+    def gram_wide(self, U, V, d, v, h):
+        """dense fp64 Gram [2r + 2, 2r + 2] of [U | V | d .* h | v ./ d], 32 < r <= 64, one sweep (psgd_uvd_gram_wide_f32)."""
+        n = int(self.lib.psgd_uvd_gram_wide_scratch_bytes(self.N, self.r))
+        if n < 0:
+            _lib.check(n, "psgd_uvd_gram_wide_scratch_bytes")
+        key = (self.dev.index, self.N, self.r)
+        scr = _gram_scratch.get(key)
+        if scr is None or scr.numel() < n:
+            scr = _gram_scratch[key] = torch.empty(n, dtype=torch.uint8, device=self.dev)
+            while len(_gram_scratch) > 4:
+                _gram_scratch.pop(next(iter(_gram_scratch)))
+        G = torch.empty(2 * self.r + 2, 2 * self.r + 2, dtype=torch.float64, device=self.dev)
+        _lib.check(self.lib.psgd_uvd_gram_wide_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), self.N, self.r,
+                                                   G.data_ptr(), scr.data_ptr(), scr.numel(), self.st), "psgd_uvd_gram_wide_f32")
+        return G
 
     # ---- Gram of [X | Y | t | w] for two chunks, decoded from the MFMA block layout of the workspace
     def gram_pair(self, X, Y, d, v, h):
@@ -141,12 +199,38 @@ def _no_reduce(t, op):
     return t
 
 
+def _update_native_ok(U, V, dv):
+    """psgd_uvd_wide_update_f32: whole contiguous matrices, d contiguous and 16-byte aligned (updated in place).  PSGD_WIDE_UPDATE=0: the
+    building-block route (A/B runs, and what a row-sharded update takes)."""
+    if os.environ.get("PSGD_WIDE_UPDATE") == "0":
+        return False
+    return _full_ok(U, V) and _gram_wide_ok(U, V) and dv.is_contiguous() and dv.data_ptr() % 16 == 0
+
+
+def _gram_wide_ok(U, V):
+    """psgd_uvd_gram_wide_f32 takes contiguous [N, r] matrices (16-byte aligned when r % 4 == 0); PSGD_WIDE_GRAM=0: the pair-of-chunks
+    route (A/B runs)."""
+    if os.environ.get("PSGD_WIDE_GRAM") == "0":
+        return False
+    al = 16 if U.shape[1] % 4 == 0 else 4
+    return U.is_contiguous() and V.is_contiguous() and U.data_ptr() % al == 0 and V.data_ptr() % al == 0
+
+
 def precond_grad(U, V, d, g, workspace_fn, reduce=_no_reduce):
     """psgd.py:619-627 for r > 32.  g: a column vector, or a LIST of k contiguous [N] columns of a matrix g (returns [k, N])."""
-    cx = _Ctx(U, workspace_fn)
-    Uc, Vc = cx.split(U), cx.split(V)
     many = isinstance(g, (list, tuple))
     dv = d.reshape(-1)
+    if reduce is _no_reduce and _full_ok(U, V):
+        # ranks 33 .. 64 on one GPU: the three sweeps of the specialised apply on four columns at a time (psgd_uvd_wide_apply_cols_f32)
+        cx = _Ctx(U, workspace_fn, full=True)
+        cols = [x.reshape(-1).contiguous() for x in (g if many else [g])]
+        outs = [torch.empty_like(x) for x in cols]
+        dc = dv.contiguous()
+        _lib.check(cx.lib.psgd_uvd_wide_apply_cols_f32(U.data_ptr(), V.data_ptr(), dc.data_ptr(), _ptrs(cols), _ptrs(outs), len(cols),
+                                                       cx.N, cx.r, cx.ws.data_ptr(), cx.ws.numel(), cx.st), "psgd_uvd_wide_apply_cols_f32")
+        return torch.stack(outs) if many else outs[0].reshape(g.shape)
+    cx = _Ctx(U, workspace_fn, full=_full_ok(U, V))
+    Uc, Vc = cx.split(U), cx.split(V)
     g1 = [(dv * x.reshape(-1)).contiguous() for x in (g if many else [g])]     # :625  t = d .* g
     s1 = reduce(torch.stack([cx.colsums(Vc[k], g1) for k in range(cx.c)]), "sum")        # V't, all chunks: one exchange
     for k in range(cx.c):                                                      # g1 = t + U (V't)          :544
@@ -162,7 +246,7 @@ def precond_grad(U, V, d, g, workspace_fn, reduce=_no_reduce):
 
 def ipuvt_matvec(U, V, x, workspace_fn, reduce=_no_reduce):
     """psgd.py:540-544 for r > 32; x is [N], [N, 1] or [N, k]."""
-    cx = _Ctx(U, workspace_fn)
+    cx = _Ctx(U, workspace_fn, full=_full_ok(U, V))
     Uc, Vc = cx.split(U), cx.split(V)
     cols = [x.reshape(cx.N, -1)[:, j].contiguous() for j in range(x.reshape(cx.N, -1).shape[1])]
     outs = [c.clone() for c in cols]
@@ -174,15 +258,31 @@ def ipuvt_matvec(U, V, x, workspace_fn, reduce=_no_reduce):
 
 def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce=_no_reduce):
     """psgd.py:554-617 for r > 32 (in place on U or V, and d)."""
-    cx = _Ctx(U, workspace_fn)
+    cx = _Ctx(U, workspace_fn, full=_full_ok(U, V))
     r, c, rc, dev = cx.r, cx.c, cx.rc, cx.dev
     if balance:                                                                # :562-567
         mx = reduce(torch.stack([torch.max(torch.abs(U)), torch.max(torch.abs(V))]), "max")
         rho = torch.sqrt(mx[0] / mx[1])
         U.div_(rho)
         V.mul_(rho)
-    Uc, Vc = cx.split(U), cx.split(V)
     dv, vv, hv = d.reshape(-1), v.reshape(-1), h.reshape(-1)
+    if reduce is _no_reduce and _update_native_ok(U, V, dv):
+        # ranks 33 .. 64 on one GPU: the four launches of psgd_uvd_wide_update_f32 (Gram, r x r algebra, sweep 2, d) -- no host step
+        vc, hc = vv.contiguous(), hv.contiguous()
+        n = int(cx.lib.psgd_uvd_wide_update_scratch_bytes(cx.N, cx.r))
+        if n < 0:
+            _lib.check(n, "psgd_uvd_wide_update_scratch_bytes")
+        key = (cx.dev.index, cx.st, cx.N, cx.r)
+        scr = _update_scratch.get(key)
+        if scr is None or scr.numel() < n:
+            scr = _update_scratch[key] = torch.empty(n, dtype=torch.uint8, device=cx.dev)
+            while len(_update_scratch) > 4:
+                _update_scratch.pop(next(iter(_update_scratch)))
+        _lib.check(cx.lib.psgd_uvd_wide_update_f32(U.data_ptr(), V.data_ptr(), dv.data_ptr(), vc.data_ptr(), hc.data_ptr(), cx.N, cx.r,
+                                                   float(step), float(tiny), int(bool(update_U)), scr.data_ptr(), scr.numel(), cx.st),
+                   "psgd_uvd_wide_update_f32")
+        return None
+    Uc, Vc = cx.split(U), cx.split(V)
     # ---- Gram of W = [U | V | t | w], t = d.*h, w = v./d, block by block (pairs of chunks)
     R = c * rc
     f64 = dict(dtype=torch.float64, device=dev)
@@ -204,17 +304,25 @@ def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce=_n
         else:
             VU[sl(kb), sl(ka)] = blk.t()
 
-    pairs = [(i, j) for i in range(len(items)) for j in range(i + 1, len(items))]
-    Gs = reduce(torch.stack([cx.gram_pair(items[i][2], items[j][2], dv, vv, hv) for i, j in pairs]), "sum")   # one exchange
-    for (i, j), G in zip(pairs, Gs):
-        (ka_, ia, _), (kb_, ib, _) = items[i], items[j]
-        put(ka_, ia, ka_, ia, G[:rc, :rc])
-        put(kb_, ib, kb_, ib, G[rc:2 * rc, rc:2 * rc])
-        put(ka_, ia, kb_, ib, G[:rc, rc:2 * rc])
-        for kind, kk, lo in ((ka_, ia, 0), (kb_, ib, rc)):
-            (Ut if kind == "U" else Vt)[sl(kk)] = G[lo:lo + rc, 2 * rc]
-            (Uw if kind == "U" else Vw)[sl(kk)] = G[lo:lo + rc, 2 * rc + 1]
-        tt, tw, ww = G[2 * rc, 2 * rc], G[2 * rc, 2 * rc + 1], G[2 * rc + 1, 2 * rc + 1]
+    if _MAXR < r <= 2 * _MAXR and _gram_wide_ok(U, V):
+        # round 5: the whole Gram of [U | V | t | w] from ONE sweep over U and V (psgd_uvd_gram_wide_f32: the four waves of a workgroup
+        # share a row tile and split the block pairs); the pair-of-chunks route below needs 2c - 1 passes
+        G = reduce(cx.gram_wide(U, V, dv, vv, hv), "sum")                      # one exchange
+        UU[:r, :r], VV[:r, :r], VU[:r, :r] = G[:r, :r], G[r:2 * r, r:2 * r], G[r:2 * r, :r]
+        Ut[:r], Uw[:r], Vt[:r], Vw[:r] = G[:r, 2 * r], G[:r, 2 * r + 1], G[r:2 * r, 2 * r], G[r:2 * r, 2 * r + 1]
+        tt, tw, ww = G[2 * r, 2 * r], G[2 * r, 2 * r + 1], G[2 * r + 1, 2 * r + 1]
+    else:
+        pairs = [(i, j) for i in range(len(items)) for j in range(i + 1, len(items))]
+        Gs = reduce(torch.stack([cx.gram_pair(items[i][2], items[j][2], dv, vv, hv) for i, j in pairs]), "sum")   # one exchange
+        for (i, j), G in zip(pairs, Gs):
+            (ka_, ia, _), (kb_, ib, _) = items[i], items[j]
+            put(ka_, ia, ka_, ia, G[:rc, :rc])
+            put(kb_, ib, kb_, ib, G[rc:2 * rc, rc:2 * rc])
+            put(ka_, ia, kb_, ib, G[:rc, rc:2 * rc])
+            for kind, kk, lo in ((ka_, ia, 0), (kb_, ib, rc)):
+                (Ut if kind == "U" else Vt)[sl(kk)] = G[lo:lo + rc, 2 * rc]
+                (Uw if kind == "U" else Vw)[sl(kk)] = G[lo:lo + rc, 2 * rc + 1]
+            tt, tw, ww = G[2 * rc, 2 * rc], G[2 * rc, 2 * rc + 1], G[2 * rc + 1, 2 * rc + 1]
     # ---- r x r algebra (fp64, on the device): psgd.py:574-579, :589-597 / :603-611
     K = torch.eye(R, **f64) + VU                                               # :575  (padded rows/columns: identity)
     s1 = Vt                                                                    # V't
