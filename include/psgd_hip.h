@@ -56,6 +56,7 @@ extern "C" {
 #define PSGD_ERR_SHAPE         (-6)   /* Kron: shapes inconsistent / unsupported     */
 
 #define PSGD_UVD_MAX_RANK 32
+#define PSGD_SPLU_MAX_RANK 64   /* the sparse-LU entry points (round 5: the tail kernels are instantiated for 1 .. 64) */
 
 /* workspace regions that the multi-GPU driver exchanges between stages.  Two equivalent protocols:
  *  (a) all-gather + fold (what psgd_tf_amd/sharded.py does): all-gather every rank's PSGD_WS_SEND_F64 region of the
@@ -267,7 +268,8 @@ int psgd_prof_collect(int slot, double *total_ms, int *count);
 /* ------------------------------------------------------------ sparse LU ---
  * P = Q'Q, Q = L U, L = [L1 0; L2 diag(l3)], U = [U1 U2; 0 diag(u3)]  (psgd.py:396-404).
  * Layout is the reference's: L12 = [L1; L2] is [N, r] row-major (L1 lower triangular), U12 = [U1, U2]
- * is [r, N] row-major (U1 upper triangular), l3 and u3 are [N - r].  1 <= r <= PSGD_UVD_MAX_RANK,
+ * is [r, N] row-major (U1 upper triangular), l3 and u3 are [N - r].  1 <= r <= PSGD_SPLU_MAX_RANK
+ * (64 since round 5: ranks above 32 take 64-row tiles, one workgroup per CU, and about 0.6 of the rate of the ranks below),
  * N >= r.  L12 (and L12_new) must be 16-byte aligned; vectors need 4-byte alignment only.
  *
  * psgd_splu_apply_f32  replaces precond_grad_splu(L12, l3, U12, u3, grads)   psgd.py:483-524

@@ -18,6 +18,7 @@ PSGD_WS_SUMS_F64 = 0
 PSGD_WS_MAX_F32 = 1
 PSGD_WS_SEND_F64 = 2
 UVD_MAX_RANK = 32
+SPLU_MAX_RANK = 64       # PSGD_SPLU_MAX_RANK: the native sparse-LU entry points (round 5)
 
 
 class PsgdHipError(RuntimeError):

@@ -12,18 +12,26 @@ const SpluOps* splu_ops_group0(int r);
 const SpluOps* splu_ops_group1(int r);
 const SpluOps* splu_ops_group2(int r);
 const SpluOps* splu_ops_group3(int r);
+const SpluOps* splu_wide_group0(int r);      // ranks 33 .. 64 (round 5): the same kernels on 64-row tiles, one workgroup per CU
+const SpluOps* splu_wide_group1(int r);
+const SpluOps* splu_wide_group2(int r);
+const SpluOps* splu_wide_group3(int r);
 
 const SpluOps* splu_ops_for_rank(int r) {
-  if (r < 1 || r > PSGD_UVD_MAX_RANK) return nullptr;
+  if (r < 1 || r > PSGD_SPLU_MAX_RANK) return nullptr;
   switch ((r - 1) / 8) {
     case 0: return splu_ops_group0(r);
     case 1: return splu_ops_group1(r);
     case 2: return splu_ops_group2(r);
-    default: return splu_ops_group3(r);
+    case 3: return splu_ops_group3(r);
+    case 4: return splu_wide_group0(r);
+    case 5: return splu_wide_group1(r);
+    case 6: return splu_wide_group2(r);
+    default: return splu_wide_group3(r);
   }
 }
 
-constexpr int MR = PSGD_UVD_MAX_RANK;
+constexpr int MR = PSGD_SPLU_MAX_RANK;       // capacity of the corner algebra and of the workspace regions
 
 // ------------------------------------------------------------ workspace ----
 // doubles: sums A [MR] | sums B [2 MR] | state vectors (7 x MR) | sums C [r] followed by the fp64 copies of the 4 maxima
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void k_splu_corner_upd3(const float* L12,
 static inline int col_tile_rows(int nvec) { return 64 * ((nvec <= 12) ? 4 : ((nvec <= 24) ? 2 : 1)); }
 
 static int splu_grid(const SpluOps* ops, int r, int which, int64_t rows, bool tiled) {
-  static int occ_cache[PSGD_UVD_MAX_RANK + 1][6];
+  static int occ_cache[PSGD_SPLU_MAX_RANK + 1][6];
   int occ = occ_cache[r][which];
   if (occ == 0) {
     occ = ops->occupancy(which);
@@ -398,7 +406,7 @@ static inline int last_launch() { return (int)hipGetLastError(); }
 static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 
 static int splu_open(void* ws, int64_t ws_bytes, int64_t N, int r, SpluWs* w) {
-  if (r < 1 || r > PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  if (r < 1 || r > PSGD_SPLU_MAX_RANK) return PSGD_ERR_RANK;
   if (N < r) return PSGD_ERR_BAD_ARG;
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return PSGD_ERR_WORKSPACE;
   if (ws_bytes < splu_layout(N, r, nullptr, nullptr)) return PSGD_ERR_WORKSPACE;
@@ -409,7 +417,7 @@ static int splu_open(void* ws, int64_t ws_bytes, int64_t N, int r, SpluWs* w) {
 extern "C" {
 
 int64_t psgd_splu_workspace_bytes(int64_t N, int r) {
-  if (r < 1 || r > PSGD_UVD_MAX_RANK || N < r) return 0;
+  if (r < 1 || r > PSGD_SPLU_MAX_RANK || N < r) return 0;
   return splu_layout(N, r, nullptr, nullptr);
 }
 
@@ -438,7 +446,7 @@ static int splu_ctx(int64_t N, int r, void* ws, int64_t ws_bytes, void* stream, 
 }
 
 int psgd_splu_ws_region(int which, int stage, int64_t N, int r, int64_t* offset_bytes, int64_t* count) {
-  if (!offset_bytes || !count || r < 1 || r > PSGD_UVD_MAX_RANK || N < r) return PSGD_ERR_BAD_ARG;
+  if (!offset_bytes || !count || r < 1 || r > PSGD_SPLU_MAX_RANK || N < r) return PSGD_ERR_BAD_ARG;
   SpluWs w;
   char* const base = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 20);   // any aligned address: offsets only
   splu_layout(N, r, base, &w);

@@ -28,6 +28,45 @@ constexpr int kGwDepth = 4;                  // tiles the split role requests ah
 __host__ __device__ constexpr int gw_pair_index(int NB, int bi, int bj) { return bi * NB - (bi * (bi - 1)) / 2 + (bj - bi); }
 __host__ __device__ constexpr int gw_max_pairs(int NB) { return (NB * (NB + 1) / 2 + kGwMulWaves - 1) / kGwMulWaves; }
 
+// The multiplying waves work on 2 x 2 groups of 16-column blocks ("super pairs"): the four fragments (x 3 planes) of a group are read
+// once for its (up to) four block pairs -- 135 fragment reads per tile at r = 64 instead of 243 with one pair at a time, and LDS
+// bandwidth is what the kernel runs out of first.  Super pairs are dealt to the waves at compile time, heaviest first onto the least
+// loaded wave; a wave's pairs sit in consecutive accumulator slots.
+struct GwPlan {
+  int owner[15];       // multiplying wave of super pair sp = gw_pair_index(NS, si, sj)
+  int slot0[15];       // its first accumulator slot
+  int max_load;        // accumulator slots a wave needs
+};
+template <int NB>
+constexpr GwPlan gw_make_plan() {
+  constexpr int NS = (NB + 1) / 2, NSP = NS * (NS + 1) / 2;
+  GwPlan p{};
+  int load[kGwMulWaves] = {};
+  int wt[15] = {};
+  bool placed[15] = {};
+  for (int si = 0; si < NS; ++si)
+    for (int sj = si; sj < NS; ++sj) {
+      const int na = (NB - 2 * si) < 2 ? (NB - 2 * si) : 2, nb = (NB - 2 * sj) < 2 ? (NB - 2 * sj) : 2;
+      wt[gw_pair_index(NS, si, sj)] = si == sj ? na * (na + 1) / 2 : na * nb;
+    }
+  for (int round = 0; round < NSP; ++round) {
+    int best = -1;
+    for (int sp = 0; sp < NSP; ++sp)
+      if (!placed[sp] && (best < 0 || wt[sp] > wt[best])) best = sp;
+    int w = 0;
+    for (int k = 1; k < kGwMulWaves; ++k)
+      if (load[k] < load[w]) w = k;
+    p.owner[best] = w;
+    p.slot0[best] = load[w];
+    load[w] += wt[best];
+    placed[best] = true;
+  }
+  for (int k = 0; k < kGwMulWaves; ++k)
+    if (load[k] > p.max_load) p.max_load = load[k];
+  return p;
+}
+template <int NB> struct GwPlanOf { static constexpr GwPlan value = gw_make_plan<NB>(); };
+
 template <int N> struct GwInt { static constexpr int value = N; };
 template <int I, int N, class F>
 __device__ __forceinline__ void gw_static_for(F&& f) {
@@ -37,9 +76,16 @@ __device__ __forceinline__ void gw_static_for(F&& f) {
   }
 }
 
-// 16-byte unit of the bf16 planes that holds rows 8 rg .. 8 rg + 7 of column col.  The XOR keeps a fragment read (lane -> column
-// lane & 15 of a block, row group lane >> 4) conflict-free for the lane groups ds_read_b128 is served in (MI355X_MICROARCH.md, LDS).
-__device__ __forceinline__ int gw_unit(int col, int rg) { return col * 4 + (rg ^ ((col >> 2) & 2)); }
+// 16-byte unit of the bf16 planes that holds rows 8 rg .. 8 rg + 7 of column col: row-group major, NC (a multiple of 16) columns per
+// group.  A fragment read (lane -> column lane & 15 of a block, row group lane >> 4) takes 16 consecutive units of four groups, and the
+// groups' bases are 16-unit aligned: distinct banks inside every lane group ds_read_b128 is served in (MI355X_MICROARCH.md, LDS).  The
+// split role's writes (a wave = 64 consecutive columns of one row group) are 1 KiB contiguous; with the column-major units of the first
+// version (col * 4 + rg) they were four-way bank conflicts, a third of the kernel's LDS time.
+#ifndef GW_UNIT_COLMAJOR
+template <int NC> __device__ __forceinline__ int gw_unit(int col, int rg) { return rg * NC + col; }
+#else
+template <int NC> __device__ __forceinline__ int gw_unit(int col, int rg) { return col * 4 + (rg ^ ((col >> 2) & 2)); }
+#endif
 
 // Sixteen waves, two roles.  Waves 0-7 ("split"): tile t + 1 from global memory straight into the bf16 planes -- a thread owns (column, 8
 // rows) items; its 8 loads are each coalesced across the wave (64 consecutive floats of one row), so there is no fp32 stage and no
@@ -55,7 +101,7 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
                                                           const float* __restrict__ h, long N, int r, long ntiles, long tile0,
                                                           double* __restrict__ part) {
   constexpr int NC = NB * 16;                       // padded columns
-  constexpr int NPW = gw_max_pairs(NB);
+  constexpr int NPW = GwPlanOf<NB>::value.max_load;
   constexpr int NP = NB * (NB + 1) / 2;
   typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) u32x4g PL[2][3][NC * 4 + 16];     // (+ 16 units: the t / w scratch of the mfma role)
@@ -66,17 +112,21 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
 
   // The roles are separate code paths with their own loops (their states must not be live at the same time: 128 registers); all of
   // them execute the same number of barriers: one after the planes are zeroed, one after the prologue, one per tile.
+  // Every workgroup runs its tile count rounded up to a multiple of the ring depth, with NO condition around anything that loads: the
+  // loading roles clamp the tile index to the workgroup's last tile (a few re-reads at the end, into buffers nobody multiplies), the
+  // multiplying role skips the padding iterations.  (With `if (t < ntiles) fetch(..)` the compiler cannot count the loads in flight at
+  // the join and waits for ALL of them at the next use: the ring of four tiles was one tile deep, 0.62 us per tile whatever its size.)
+  const long nmine = (ntiles - tfirst + G - 1) / G;                         // >= 1
+  const long tlast = tfirst + (nmine - 1) * G;
+  auto clampt = [&](long t) { return t < tlast ? t : tlast; };
   auto tile_loop = [&](auto&& prologue, auto&& step) {   // step(q, t): iteration of tile t, ordinal q mod depth (compile time)
     __syncthreads();
     prologue();
     __syncthreads();
-    for (long tb = tfirst; tb < ntiles; tb += kGwDepth * G)
+    for (long i = 0; i < nmine; i += kGwDepth)
       gw_static_for<0, kGwDepth>([&](auto ic) {
-        const long t = tb + decltype(ic)::value * G;
-        if (t < ntiles) {                            // (uniform over the workgroup)
-          step(ic, t);
-          __syncthreads();
-        }
+        step(ic, tfirst + (i + decltype(ic)::value) * G);
+        __syncthreads();
       });
   };
   if (wave < 4) {
@@ -88,7 +138,7 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     const int col = tid % r, g0 = tid / r;
     const bool on = g0 < 4;
     const unsigned e0 = on ? (unsigned)(g0 * 8 * r + col) : 0u;       // element offset of the item's first value inside a tile
-    const int un0 = gw_unit(col, on ? g0 : 0), un1 = gw_unit(r + col, on ? g0 : 0);
+    const int un0 = gw_unit<NC>(col, on ? g0 : 0), un1 = gw_unit<NC>(r + col, on ? g0 : 0);
     for (int i = tid; i < 2 * 3 * (NC * 4 + 16); i += 256) (&PL[0][0][0])[i] = u32x4g{0u, 0u, 0u, 0u};     // (pad columns stay zero)
     float px[kGwDepth][16];
     auto fetch = [&](long t, auto ic) {
@@ -135,19 +185,14 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     const long t0 = tfirst;
     tile_loop(
         [&]() {      // tiles 0 .. depth - 1 requested (ring slot = ordinal mod depth), tile 0 split into buffer 0, its slot refilled
-          gw_static_for<0, kGwDepth>([&](auto ic) {
-            const long t = t0 + decltype(ic)::value * G;
-            if (t < ntiles) fetch(t, ic);
-          });
-          if (t0 < ntiles) split_to(0, GwInt<0>{});
-          if (t0 + kGwDepth * G < ntiles) fetch(t0 + kGwDepth * G, GwInt<0>{});
+          gw_static_for<0, kGwDepth>([&](auto ic) { fetch(clampt(t0 + decltype(ic)::value * G), ic); });
+          split_to(0, GwInt<0>{});
+          fetch(clampt(t0 + kGwDepth * G), GwInt<0>{});
         },
         [&](auto ic, long t) {                       // while tile t is multiplied: tile t + 1 into the other buffer, its slot refilled
           constexpr int q = decltype(ic)::value, slot = (q + 1) % kGwDepth;
-          if (t + G < ntiles) {
-            split_to((q + 1) & 1, GwInt<slot>{});
-            if (t + (1 + kGwDepth) * G < ntiles) fetch(t + (1 + kGwDepth) * G, GwInt<slot>{});
-          }
+          split_to((q + 1) & 1, GwInt<slot>{});
+          fetch(clampt(t + (1 + kGwDepth) * G), GwInt<slot>{});
         });
     return;
   }
@@ -157,7 +202,7 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     // Same ring as the split role.  (Under `if (tid < 8)` inside the split role these loads made the compiler wait for that role's
     // whole ring at the join; one tile ahead in the mfma role an iteration lasted one memory latency.)
     float* TW = reinterpret_cast<float*>(&PL[1][2][NC * 4]);          // (behind the planes: 16 extra units)
-    const int tw_un = gw_unit(2 * r + (lane & 1), (lane >> 1) & 3);
+    const int tw_un = gw_unit<NC>(2 * r + (lane & 1), (lane >> 1) & 3);
     float ptw[kGwDepth];
     auto fetch = [&](long t, auto ic) {
       const int it = lane >> 3;
@@ -187,19 +232,14 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     const long t0 = tfirst;
     tile_loop(
         [&]() {
-          gw_static_for<0, kGwDepth>([&](auto ic) {
-            const long t = t0 + decltype(ic)::value * G;
-            if (t < ntiles) fetch(t, ic);
-          });
-          if (t0 < ntiles) split_to(0, GwInt<0>{});
-          if (t0 + kGwDepth * G < ntiles) fetch(t0 + kGwDepth * G, GwInt<0>{});
+          gw_static_for<0, kGwDepth>([&](auto ic) { fetch(clampt(t0 + decltype(ic)::value * G), ic); });
+          split_to(0, GwInt<0>{});
+          fetch(clampt(t0 + kGwDepth * G), GwInt<0>{});
         },
         [&](auto ic, long t) {
           constexpr int q = decltype(ic)::value, slot = (q + 1) % kGwDepth;
-          if (t + G < ntiles) {
-            split_to((q + 1) & 1, GwInt<slot>{});
-            if (t + (1 + kGwDepth) * G < ntiles) fetch(t + (1 + kGwDepth) * G, GwInt<slot>{});
-          }
+          split_to((q + 1) & 1, GwInt<slot>{});
+          fetch(clampt(t + (1 + kGwDepth) * G), GwInt<slot>{});
         });
     return;
   }
@@ -214,31 +254,42 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     for (int e = 0; e < 4; ++e) acc64[p][e] = 0.0;
   }
   int since = 0;
-  tile_loop([]() {}, [&](auto ic, long) {
+  tile_loop([]() {}, [&](auto ic, long t) {
+    if (t >= ntiles) return;                         // (padding iteration of the last round)
     const int buf = decltype(ic)::value & 1;         // (depth is even: the buffer of a tile is its ordinal's parity)
     auto frag = [&](int b, bf16x8 (&f)[3]) {
-      const int un = gw_unit(b * 16 + (lane & 15), lane >> 4);
+      const int un = gw_unit<NC>(b * 16 + (lane & 15), lane >> 4);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) f[pl] = __builtin_bit_cast(bf16x8, PL[buf][pl][un]);
     };
-    gw_static_for<0, NB>([&](auto bic) {
-      constexpr int bi = decltype(bic)::value;
-      gw_static_for<bi, NB>([&](auto bjc) {
-        constexpr int bj = decltype(bjc)::value;
-        constexpr int pi = gw_pair_index(NB, bi, bj), ps = pi / kGwMulWaves;
-        if (mw == pi % kGwMulWaves && !(GW_DBG & 2)) {
-          bf16x8 fa[3], fb[3];
-          frag(bj, fb);
-          if constexpr (bi == bj) { fa[0] = fb[0]; fa[1] = fb[1]; fa[2] = fb[2]; }
-          else frag(bi, fa);
-          f32x4 a = acc[ps];
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1], a, 0, 0, 0);     // m m'
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2], a, 0, 0, 0);     // h l'
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0], a, 0, 0, 0);     // l h'
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1], a, 0, 0, 0);     // h m'
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0], a, 0, 0, 0);     // m h'
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0], a, 0, 0, 0);     // h h'
-          acc[ps] = a;
+    constexpr int NS = (NB + 1) / 2;
+    gw_static_for<0, NS>([&](auto sic) {
+      constexpr int si = decltype(sic)::value;
+      gw_static_for<si, NS>([&](auto sjc) {
+        constexpr int sj = decltype(sjc)::value;
+        constexpr int sp = gw_pair_index(NS, si, sj);
+        constexpr int own = GwPlanOf<NB>::value.owner[sp], s0 = GwPlanOf<NB>::value.slot0[sp];
+        constexpr int na = (NB - 2 * si) < 2 ? (NB - 2 * si) : 2, nb = (NB - 2 * sj) < 2 ? (NB - 2 * sj) : 2;
+        if (mw == own && !(GW_DBG & 2)) {
+          bf16x8 fa[2][3], fb[2][3];
+          gw_static_for<0, nb>([&](auto c) { frag(2 * sj + decltype(c)::value, fb[decltype(c)::value]); });
+          if constexpr (si != sj) gw_static_for<0, na>([&](auto c) { frag(2 * si + decltype(c)::value, fa[decltype(c)::value]); });
+          // the six products of a pair keep their order (smallest first); the group's pairs are interleaved product by product, so
+          // that consecutive MFMAs belong to different accumulators
+          gw_static_for<0, 6>([&](auto tc) {
+            constexpr int term = decltype(tc)::value;
+            constexpr int pa = term == 0 ? 1 : term == 1 ? 0 : term == 2 ? 2 : term == 3 ? 0 : term == 4 ? 1 : 0;   // m h l h m h
+            constexpr int pb = term == 0 ? 1 : term == 1 ? 2 : term == 2 ? 0 : term == 3 ? 1 : term == 4 ? 0 : 0;   // m l h m h h
+            gw_static_for<0, na>([&](auto ac) {
+              constexpr int a = decltype(ac)::value;
+              gw_static_for<(si == sj ? a : 0), nb>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                constexpr int slot = s0 + (si == sj ? (a == 0 ? b : nb + (b - 1)) : a * nb + b);
+                if constexpr (si == sj) acc[slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[a][pa], fb[b][pb], acc[slot], 0, 0, 0);
+                else acc[slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][pa], fb[b][pb], acc[slot], 0, 0, 0);
+              });
+            });
+          });
         }
       });
     });
@@ -258,13 +309,29 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
   // every pair is owned by one wave: its partial goes straight out, [block][pair][e * 64 + lane]
   double* dst = part + (long)blockIdx.x * NP * 256;
+  {
+    constexpr int NS = (NB + 1) / 2;
+    gw_static_for<0, NS>([&](auto sic) {
+      constexpr int si = decltype(sic)::value;
+      gw_static_for<si, NS>([&](auto sjc) {
+        constexpr int sj = decltype(sjc)::value;
+        constexpr int sp = gw_pair_index(NS, si, sj);
+        constexpr int own = GwPlanOf<NB>::value.owner[sp], s0 = GwPlanOf<NB>::value.slot0[sp];
+        constexpr int na = (NB - 2 * si) < 2 ? (NB - 2 * si) : 2, nb = (NB - 2 * sj) < 2 ? (NB - 2 * sj) : 2;
+        if (mw == own) {
+          gw_static_for<0, na>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            gw_static_for<(si == sj ? a : 0), nb>([&](auto bc) {
+              constexpr int b = decltype(bc)::value;
+              constexpr int slot = s0 + (si == sj ? (a == 0 ? b : nb + (b - 1)) : a * nb + b);
+              constexpr int pi = gw_pair_index(NB, 2 * si + a, 2 * sj + b);
 #pragma unroll
-  for (int p = 0; p < NPW; ++p) {
-    const int pi = p * kGwMulWaves + mw;             // the pair in slot p
-    if (pi < NP) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dst[pi * 256 + e * 64 + lane] = acc64[p][e];
-    }
+              for (int e = 0; e < 4; ++e) dst[pi * 256 + e * 64 + lane] = acc64[slot][e];
+            });
+          });
+        }
+      });
+    });
   }
 }
 

@@ -203,7 +203,7 @@ def update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01):
     N, r = _splu_shapes("update_precond_splu", L12, l3, U12, u3)
     dx, dg = _tall("update_precond_splu", dxs, N), _tall("update_precond_splu", dgs, N)
     _require_hip("update_precond_splu", dx, dg, L12)
-    if r > _lib.UVD_MAX_RANK:                      # wide rank: column chunks of L2 and U2' (splu_wide.py)
+    if r > _lib.SPLU_MAX_RANK:                     # wide rank: column chunks of L2 and U2' (splu_wide.py)
         return _splu_wide.update(L12, l3, U12, u3, dx, dg, float(step), float(_tiny), uvd_workspace)
     out = [torch.empty_like(t) for t in (L12, l3, U12, u3)]
     ws = _splu_workspace(dev, N, r)
@@ -222,7 +222,7 @@ def precond_grad_splu(L12, l3, U12, u3, grads):
     N, r = _splu_shapes("precond_grad_splu", L12, l3, U12, u3)
     g = _tall("precond_grad_splu", grads, N)
     _require_hip("precond_grad_splu", g, L12)
-    if r > _lib.UVD_MAX_RANK:
+    if r > _lib.SPLU_MAX_RANK:
         out = _splu_wide.precond_grad(L12, l3, U12, u3, g, uvd_workspace)
         pre_grads, idx = [], 0
         for x in grads:

@@ -415,7 +415,7 @@ def _splu_backend_for(L12):
 
 
 def _splu_is_wide(L12, backend):
-    return backend is None and L12.dim() == 2 and L12.shape[1] > _lib.UVD_MAX_RANK
+    return backend is None and L12.dim() == 2 and L12.shape[1] > _lib.SPLU_MAX_RANK
 
 
 def precond_grad_splu(L12, l3, U12, u3, grad, group=None, backend=None):

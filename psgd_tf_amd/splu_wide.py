@@ -44,7 +44,9 @@ class _Blocks:
         self.l3, self.u3 = l3.reshape(-1), u3.reshape(-1)
         if self.n2 > 0:
             L2 = L12[r:] if L2_work is None else L2_work
-            self.cx = _w._Ctx(L2, workspace_fn)                      # rows = N - r, columns = r -> c chunks of rc
+            # rows = N - r, columns = r -> c chunks of rc; ranks 33 .. 64 (round 5): ONE "chunk", the block itself, through the
+            # whole-matrix kernels of the wide UVd path (psgd_uvd_wide_*) when L2 is contiguous and 16-byte aligned
+            self.cx = _w._Ctx(L2, workspace_fn, full=reduce is _no_reduce and _w._full_ok(L2))
             self.Lc = self.cx.split(L2)
             self.L2 = L2
             rc = self.cx.rc
