@@ -49,7 +49,7 @@ extern "C" {
 
 #define PSGD_OK                 0
 #define PSGD_ERR_BAD_ARG       (-1)   /* null pointer, N <= 0, r <= 0 ...            */
-#define PSGD_ERR_RANK          (-2)   /* rank r outside [1, PSGD_UVD_MAX_RANK]       */
+#define PSGD_ERR_RANK          (-2)   /* rank r outside the entry point's range      */
 #define PSGD_ERR_WORKSPACE     (-3)   /* workspace missing, too small or misaligned  */
 #define PSGD_ERR_ALIGN         (-4)   /* a matrix pointer is not 16-byte aligned     */
 #define PSGD_ERR_LAUNCH        (-5)   /* HIP reported a launch error                 */

@@ -13,6 +13,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PSGD_HIP_LIB", os.path.join(_CSRC, "libpsgd_hip.so"))   # override: build experiments only
 
 PSGD_OK = 0
+PSGD_ERR_BAD_ARG, PSGD_ERR_RANK, PSGD_ERR_WORKSPACE, PSGD_ERR_ALIGN, PSGD_ERR_LAUNCH, PSGD_ERR_SHAPE = -1, -2, -3, -4, -5, -6
 PSGD_ABI_VERSION = 6       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
 PSGD_WS_SUMS_F64 = 0
 PSGD_WS_MAX_F32 = 1

@@ -348,9 +348,10 @@ __global__ __launch_bounds__(kThreads) void k_gram_wide_finish(const double* __r
   double s = 0.0;
   for (int b = 0; b < nblocks; ++b) s += part[((long)b * NP + p) * 256 + q];
   const int i = 16 * bi + 4 * (l >> 4) + e, j = 16 * bj + (l & 15);
-  if (i < ncol && j < ncol) {
+  // (a diagonal block holds both triangles, summed in different orders: the upper one is kept, so that G is symmetric to the bit)
+  if (i < ncol && j < ncol && (bi != bj || i <= j)) {
     G[(long)i * ncol + j] = s;
-    if (bi != bj) G[(long)j * ncol + i] = s;
+    G[(long)j * ncol + i] = s;
   }
 }
 

@@ -20,12 +20,14 @@ STATE_TOL = 1e-5
 INCR_TOL = 2e-3
 
 # (N, r): no tail (N = r), tails shorter than the alignment head, odd ranks (scalar head path), tile
-# edges, every load-width class, r = 1 and r = 32
+# edges, every load-width class, r = 1, r = 32 and r = 64
 SHAPES = [(12, 12), (13, 12), (14, 11), (23, 1), (40, 5), (64, 10), (1000, 3), (5000, 7), (4099, 9), (10007, 10),
           (20000, 17), (3000, 32), (50000, 31), (100003, 20), (300001, 10),
-          # ranks above 32 (the reference has no limit, psgd.py:420): column chunks of L2 and U2' (splu_wide.py); no tail, one
+          # ranks above 32 (the reference has no limit, psgd.py:420); column chunks of L2 and U2' (splu_wide.py): no tail, one
           # chunk padded, three chunks
-          (40, 40), (41, 40), (44, 40), (5000, 33), (20011, 48), (3001, 70), (6007, 64)]
+          # round 5: ranks 33 .. 64 run on the native tail kernels (64-row tiles), above 64 on the chunks
+          (40, 40), (41, 40), (44, 40), (5000, 33), (20011, 48), (3001, 70), (6007, 64), (64, 64), (65, 64), (100003, 40),
+          (50021, 64), (30011, 57), (70000, 63), (4001, 100)]
 KEYS = ("L12", "l3", "U12", "u3")
 
 

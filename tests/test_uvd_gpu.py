@@ -355,7 +355,8 @@ def test_strided_building_blocks_of_the_wide_rank_path(hip_lib):
         cx.colsums(W[:, 1:21], [torch.randn(512, device="cuda")])
 
 
-@pytest.mark.parametrize("N,r", [(5000, 48), (3001, 33), (2049, 64), (1021, 100), (100003, 40), (4001, 70), (2500, 65), (1, 40), (3, 50)])
+@pytest.mark.parametrize("N,r", [(5000, 48), (3001, 33), (2049, 64), (1021, 100), (100003, 40), (4001, 70), (2500, 65), (1, 40), (3, 50),
+                                 (31, 64), (32, 57), (200003, 64), (70016, 41)])
 def test_wide_rank_matches_oracle(psgd, N, r):
     """r > 32 (the reference has no rank limit, psgd.py:663): column chunks of U and V through the same HIP kernels
     (psgd_tf_amd/uvd_wide.py).  Apply, IpUVtmatvec (vector and matrix), both update branches, the balance branch and
@@ -404,3 +405,87 @@ def test_uvd_class_wide_rank(hip_lib):
     for _ in range(80):
         l = float(opt.step(closure).detach())
     assert opt._U.shape == (300, 48) and torch.isfinite(opt._U).all() and l < 0.3 * l0
+
+
+@pytest.mark.parametrize("N,r", [(1, 33), (31, 40), (32, 64), (33, 64), (1000, 33), (4099, 40), (65536, 48), (100003, 57), (300001, 64)])
+def test_wide_gram_matches_fp64(hip_lib, N, r):
+    """psgd_uvd_gram_wide_f32 (ranks 33 .. 64, one sweep): every inner product of the columns of [U | V | d.*h | v./d] (psgd.py:569-615)
+    against the fp64 product of the same fp32 matrices.  The bf16 x 3 split is exact, the products are accumulated in fp32 chains of
+    256 rows and folded in fp64: a few 1e-7 of sqrt(G_ii G_jj).  Fewer rows than a tile, exactly one tile, ragged ends, many
+    workgroups."""
+    from psgd_tf_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(N + r)
+    U = torch.randn(N, r, device="cuda", generator=g) * 3e-3
+    V = torch.randn(N, r, device="cuda", generator=g) * 2e-1
+    V[:, 0] = 0.0                                                   # a zero column stays exactly zero
+    d = torch.rand(N, device="cuda", generator=g) + 0.5
+    v, h = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    n = int(hip_lib.psgd_uvd_gram_wide_scratch_bytes(N, r))
+    assert n > 0
+    scr = torch.empty(n, dtype=torch.uint8, device="cuda")
+    G = torch.full((2 * r + 2, 2 * r + 2), float("nan"), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(hip_lib.psgd_uvd_gram_wide_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), N, r, G.data_ptr(),
+                                              scr.data_ptr(), n, st), "psgd_uvd_gram_wide_f32")
+    W = torch.cat([U.double(), V.double(), (d * h).double()[:, None], (v / d).double()[:, None]], 1)
+    ref = W.T @ W
+    sc = ref.diagonal().sqrt().clamp_min(1e-30)
+    assert torch.equal(G, G.T)
+    assert float(((G - ref).abs() / (sc[:, None] * sc[None, :])).max()) < 5e-7
+    assert torch.equal(G[r], torch.zeros_like(G[r]))                # (column r of W = V[:, 0])
+    G2 = torch.empty_like(G)
+    _lib.check(hip_lib.psgd_uvd_gram_wide_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), N, r, G2.data_ptr(),
+                                              scr.data_ptr(), n, st), "psgd_uvd_gram_wide_f32")
+    assert torch.equal(G, G2)                                       # fixed reduction order
+    assert hip_lib.psgd_uvd_gram_wide_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), N, 32, G.data_ptr(),
+                                          scr.data_ptr(), n, st) == _lib.PSGD_ERR_RANK
+    assert hip_lib.psgd_uvd_gram_wide_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), N, r, G.data_ptr(),
+                                          scr.data_ptr(), n - 1, st) == _lib.PSGD_ERR_WORKSPACE
+
+
+@pytest.mark.parametrize("N,r", [(5000, 48), (100003, 40), (2049, 64), (70001, 33)])
+@pytest.mark.parametrize("update_U", [True, False])
+def test_wide_update_routes_agree(psgd, monkeypatch, N, r, update_U):
+    """The three routes of the rank 33 .. 64 update -- psgd_uvd_wide_update_f32 (four launches), the whole-matrix building blocks
+    (PSGD_WIDE_UPDATE=0: what a row-sharded update takes) and the column chunks of rounds 3-4 (PSGD_WIDE_FULL=0) -- against the oracle
+    and against each other."""
+    p = make_uvd_problem(N, r, seed=N + r, uv_gain=2.0 * r ** 0.5, d_spread=0.3)
+    q = _f64(p)
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=update_U)
+    got = {}
+    for route, env in (("native", {}), ("blocks", {"PSGD_WIDE_UPDATE": "0"}), ("chunks", {"PSGD_WIDE_FULL": "0"})):
+        for k in ("PSGD_WIDE_UPDATE", "PSGD_WIDE_FULL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        t = _to_dev(p)
+        psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32, balance=False, update_U=update_U)
+        got[route] = {k: t[k].cpu().numpy() for k in ("U", "V", "d")}
+        for k in ("U", "V", "d"):
+            assert rel_err(got[route][k], q[k]) < 2 * STATE_TOL, (route, k)
+            assert rel_err(got[route][k] - p[k], q[k] - p[k].astype(np.float64)) < INCR_TOL, (route, k)
+        frozen = "V" if update_U else "U"
+        assert np.array_equal(got[route][frozen], p[frozen]), route
+    for k in ("U", "V", "d"):
+        assert rel_err(got["native"][k], got["blocks"][k]) < STATE_TOL
+        assert rel_err(got["native"][k], got["chunks"][k]) < STATE_TOL
+
+
+def test_wide_update_rejects_bad_arguments(hip_lib):
+    from psgd_tf_amd import _lib
+    N, r = 1000, 40
+    U, V = torch.randn(N, r, device="cuda"), torch.randn(N, r, device="cuda")
+    d, v, h = torch.ones(N, device="cuda"), torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
+    n = int(hip_lib.psgd_uvd_wide_update_scratch_bytes(N, r))
+    scr = torch.empty(n, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    call = lambda Uq, rr, nn: hip_lib.psgd_uvd_wide_update_f32(Uq, V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(), N, rr, 0.01, 1e-30,
+                                                               1, scr.data_ptr(), nn, st)
+    assert hip_lib.psgd_uvd_wide_update_scratch_bytes(N, 32) == _lib.PSGD_ERR_RANK
+    assert hip_lib.psgd_uvd_wide_update_scratch_bytes(N, 65) == _lib.PSGD_ERR_RANK
+    assert call(U.data_ptr(), 20, n) == _lib.PSGD_ERR_RANK
+    assert call(U.data_ptr(), r, n - 1) == _lib.PSGD_ERR_WORKSPACE
+    assert call(U.data_ptr() + 4, r, n) == _lib.PSGD_ERR_ALIGN
+    assert call(0, r, n) == _lib.PSGD_ERR_BAD_ARG
+    assert call(U.data_ptr(), r, n) == _lib.PSGD_OK
+    torch.cuda.synchronize()
