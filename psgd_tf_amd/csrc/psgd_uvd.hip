@@ -443,17 +443,36 @@ __device__ void lu_solve_block(double (*Mx)[CAP + 2], int r, double* xs) {
     const unsigned long long hit = __ballot(key == kmax && lane < r - k);
     const int piv = hit ? k + (__ffsll((long long)hit) - 1) : k;
     __syncthreads();                                   // all scans done before rows move
-    if (piv != k && tid <= r) {
-      const double t = Mx[k][tid];
-      Mx[k][tid] = Mx[piv][tid];
-      Mx[piv][tid] = t;
+    if (piv != k) {                                    // (uniform: every wave found the same pivot)
+      if (tid <= r) {
+        const double t = Mx[k][tid];
+        Mx[k][tid] = Mx[piv][tid];
+        Mx[piv][tid] = t;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     const double rpk = fast_rcp(Mx[k][k]);
-    const int nrow = r - k - 1, ncol = r - k;          // rows k+1..r-1, columns k+1..r (incl. rhs)
-    for (int e = tid; e < nrow * ncol; e += blockDim.x) {
-      const int i = k + 1 + e / ncol, j = k + 1 + e % ncol;
-      Mx[i][j] -= (Mx[i][k] * rpk) * Mx[k][j];
+    // rows k+1..r-1, columns k+1..r (incl. rhs; at most 64 of them): a thread keeps one column and every fourth row; all its LDS
+    // reads are issued before the first use (the step is a few LDS latencies long, not one per row), no integer division per entry
+    {
+      static_assert(CAP <= 64, "one column per lane of a 64-column group");
+      constexpr int NI = (CAP + 3) / 4;
+      const int j = k + 1 + (tid & 63), i0 = k + 1 + (tid >> 6);
+      if (j <= r && i0 < r) {
+        const double pj = Mx[k][j];
+        double mik[NI], mij[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+          const int i = i0 + 4 * u, ic = i < r ? i : r - 1;
+          mik[u] = Mx[ic][k];
+          mij[u] = Mx[ic][j];
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+          const int i = i0 + 4 * u;
+          if (i < r) Mx[i][j] = mij[u] - (mik[u] * rpk) * pj;
+        }
+      }
     }
     __syncthreads();
   }

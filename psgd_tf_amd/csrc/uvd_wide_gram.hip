@@ -346,7 +346,17 @@ __global__ __launch_bounds__(kThreads) void k_gram_wide_finish(const double* __r
   while (rem >= NB - bi) { rem -= NB - bi; ++bi; }
   const int bj = bi + rem;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += part[((long)b * NP + p) * 256 + q];
+  const double* src = part + (long)p * 256 + q;
+  const long st = (long)NP * 256;
+  int b = 0;
+  for (; b + 8 <= nblocks; b += 8) {                 // eight loads in flight, the additions in block order
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = src[(b + u) * st];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += x[u];
+  }
+  for (; b < nblocks; ++b) s += src[b * st];
   const int i = 16 * bi + 4 * (l >> 4) + e, j = 16 * bj + (l & 15);
   // (a diagonal block holds both triangles, summed in different orders: the upper one is kept, so that G is symmetric to the bit)
   if (i < ncol && j < ncol && (bi != bj || i <= j)) {

@@ -6,10 +6,11 @@ For each rank: (1) the Gram of a ragged N (1 000 003 rows) against the fp64 prod
 the bound is that of a bf16 x 3 split: a few 1e-7 of sqrt(G_ii G_jj)), (2) the launch time at N rows (default 20 M) and the U + V
 bytes it streams per second.  Output is the table of profiles/r05_wide_rank.txt.
 """
+import os
 import sys
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from psgd_tf_amd import _lib   # noqa: E402
 
 lib = _lib.load()
