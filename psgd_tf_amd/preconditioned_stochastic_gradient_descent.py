@@ -28,6 +28,7 @@ global RNG; here they come from a torch.Generator (module default, or ``generato
 or are fixed through the keyword-only ``balance=`` / ``update_U=`` arguments.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -196,6 +197,12 @@ def _tall(name, xs, N):
     return flat.contiguous()
 
 
+def _splu_chunked(r):
+    """ranks above PSGD_SPLU_MAX_RANK (64) run on column chunks (splu_wide.py); PSGD_SPLU_CHUNKS=1 sends ranks 33 .. 64 there too
+    (the route of rounds 3-4: A/B runs of tools/r05_wide_rank.py)."""
+    return r > _lib.SPLU_MAX_RANK or (r > _lib.UVD_MAX_RANK and os.environ.get("PSGD_SPLU_CHUNKS") == "1")
+
+
 def update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01):
     """psgd.py:396-480: returns (L12_new, l3_new, U12_new, u3_new); inputs are not modified."""
     L12, l3, U12, u3 = _c(L12), _c(l3), _c(U12), _c(u3)
@@ -203,7 +210,7 @@ def update_precond_splu(L12, l3, U12, u3, dxs, dgs, step=0.01):
     N, r = _splu_shapes("update_precond_splu", L12, l3, U12, u3)
     dx, dg = _tall("update_precond_splu", dxs, N), _tall("update_precond_splu", dgs, N)
     _require_hip("update_precond_splu", dx, dg, L12)
-    if r > _lib.SPLU_MAX_RANK:                     # wide rank: column chunks of L2 and U2' (splu_wide.py)
+    if _splu_chunked(r):                           # wide rank: column chunks of L2 and U2' (splu_wide.py)
         return _splu_wide.update(L12, l3, U12, u3, dx, dg, float(step), float(_tiny), uvd_workspace)
     out = [torch.empty_like(t) for t in (L12, l3, U12, u3)]
     ws = _splu_workspace(dev, N, r)
@@ -222,7 +229,7 @@ def precond_grad_splu(L12, l3, U12, u3, grads):
     N, r = _splu_shapes("precond_grad_splu", L12, l3, U12, u3)
     g = _tall("precond_grad_splu", grads, N)
     _require_hip("precond_grad_splu", g, L12)
-    if r > _lib.SPLU_MAX_RANK:
+    if _splu_chunked(r):
         out = _splu_wide.precond_grad(L12, l3, U12, u3, g, uvd_workspace)
         pre_grads, idx = [], 0
         for x in grads:

@@ -81,6 +81,29 @@ def test_update_matches_oracle(psgd, N, r, step):
         assert np.array_equal(t[k].cpu().numpy(), p[k])
 
 
+@pytest.mark.parametrize("N,r", [(5000, 33), (20011, 48), (6007, 64)])
+def test_chunk_route_of_ranks_33_to_64_agrees_with_the_native_kernels(psgd, monkeypatch, N, r):
+    """Ranks 33 .. 64 run on the native tail kernels since round 5; PSGD_SPLU_CHUNKS=1 keeps the column-chunk route of splu_wide.py
+    (what ranks above 64 take) reachable for them: both against the oracle and against each other."""
+    p = make_splu_problem(N, r, seed=7 * N + r)
+    t, q = _dev(p), _f64(p)
+    ref_a = orc.precond_grad_splu(q["L12"], q["l3"], q["U12"], q["u3"], [q["g"]])[0]
+    ref_u = orc.update_precond_splu(q["L12"], q["l3"], q["U12"], q["u3"], [q["dx"]], [q["dg"]], 0.01)
+    got = {}
+    for route in ("native", "chunks"):
+        monkeypatch.delenv("PSGD_SPLU_CHUNKS", raising=False)
+        if route == "chunks":
+            monkeypatch.setenv("PSGD_SPLU_CHUNKS", "1")
+        a = psgd.precond_grad_splu(t["L12"], t["l3"], t["U12"], t["u3"], [t["g"]])[0].cpu().numpy()
+        u = [x.cpu().numpy() for x in psgd.update_precond_splu(t["L12"], t["l3"], t["U12"], t["u3"], [t["dx"]], [t["dg"]], 0.01)]
+        assert rel_err(a, ref_a) < APPLY_TOL, route
+        for k, x, b in zip(KEYS, u, ref_u):
+            assert rel_err(x, b) < STATE_TOL, (route, k)
+        got[route] = [a] + u
+    for x, y in zip(got["native"], got["chunks"]):
+        assert rel_err(x, y) < STATE_TOL
+
+
 def test_demo_initial_state(psgd):
     """demo_usage_of_all_preconditioners.py:47-51 state, tensor-decomposition parameter count (R*(I+J+K) = 400)."""
     N, r = 400, 10

@@ -3,7 +3,7 @@ reference's arithmetic needs per parameter over the time.   python tools/r05_wid
 
 UVd: apply 4 (4r + 5), update 4 (5r + 10) bytes per row; sparse-LU: apply 4 (3r + 9), update 4 (9r + 15).
 Each configuration runs in its own process; the second block is the round-4 route (column chunks of width <= 32:
-PSGD_WIDE_FULL=0) on the same box.
+PSGD_WIDE_FULL=0, PSGD_SPLU_CHUNKS=1) on the same box.
 """
 import os
 import subprocess
@@ -74,6 +74,6 @@ if __name__ == "__main__":
         sys.exit(0)
     N = sys.argv[1] if len(sys.argv) > 1 else "20000000"
     print("N = %s rows" % N)
-    for env in ({}, {"PSGD_WIDE_FULL": "0"}):
+    for env in ({}, {"PSGD_WIDE_FULL": "0", "PSGD_SPLU_CHUNKS": "1"}):
         r = subprocess.run([sys.executable, __file__, N, "child"], env=dict(os.environ, **env), capture_output=True, text=True)
         print(r.stdout.strip() if r.returncode == 0 else (r.stdout + r.stderr[-3000:]))
