@@ -423,6 +423,68 @@ def splu_bench(dev, psgd, N=50_000_000, r=10, iters=10):
             "frac_of_hbm_peak": bytes_row * N / ms / 1e6 / HBM_PEAK_GBS}
 
 
+def wide_rank_bench(dev, psgd, N=20_000_000, iters=6):
+    """Secondary leg (review item 8): ranks above 32 of both low-rank preconditioners beside a specialised rank at the same N --
+    UVd r = 32 / 64 and sparse LU r = 32 / 40, apply and update separately, on the bytes the reference's arithmetic needs
+    (UVd 4(4r+5) / 4(5r+10), sparse LU 4(3r+9) / 4(9r+15) per row: DESIGN 4.1, 4.5).  `x_spec` = rate / rate of the rank-32 line."""
+    def timeit(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / iters
+
+    out, base = {"N": N}, {}
+    for r in (32, 64):
+        g = torch.Generator(device=dev).manual_seed(r)
+        sc = (1.0 / (N * r)) ** 0.5
+        U, V = torch.randn(N, r, device=dev, generator=g) * sc, torch.randn(N, r, device=dev, generator=g) * sc
+        d = torch.ones(N, 1, device=dev)
+        gr, v = torch.randn(N, 1, device=dev, generator=g), torch.randn(N, 1, device=dev, generator=g)
+        h = v * 1.5
+        ta = timeit(lambda: psgd.precond_grad_UVd_math(U, V, d, gr))
+        flip = [0]
+
+        def upd():
+            flip[0] ^= 1
+            psgd.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=bool(flip[0]))
+        tu = timeit(upd)
+        ra, ru = 4 * (4 * r + 5) * N / ta / 1e6, 4 * (5 * r + 10) * N / tu / 1e6
+        if r == 32:
+            base["uvd"] = (ra, ru)
+        out["uvd_r%d" % r] = {"apply_ms": ta, "update_ms": tu, "apply_GBs": ra, "update_GBs": ru,
+                              "apply_x_spec": ra / base["uvd"][0], "update_x_spec": ru / base["uvd"][1]}
+        del U, V, d, gr, v, h
+        torch.cuda.empty_cache()
+    for r in (32, 40):
+        g = torch.Generator(device=dev).manual_seed(3)
+        n2, sc = N - r, 0.3 / r ** 0.5
+        L12 = torch.randn(N, r, device=dev, generator=g) * (sc * 3 * (r / N) ** 0.5)
+        U12 = torch.randn(r, N, device=dev, generator=g) * (sc * 3 * (r / N) ** 0.5)
+        L12[:r] = torch.tril(torch.randn(r, r, device=dev, generator=g) * sc, -1) + torch.eye(r, device=dev)
+        U12[:, :r] = torch.triu(torch.randn(r, r, device=dev, generator=g) * sc, 1) + torch.eye(r, device=dev)
+        l3 = torch.exp(torch.empty(n2, 1, device=dev).uniform_(-0.5, 0.5, generator=g))
+        u3 = torch.exp(torch.empty(n2, 1, device=dev).uniform_(-0.5, 0.5, generator=g)) * 0.7
+        dx = torch.randn(N, 1, device=dev, generator=g)
+        dg = dx * torch.exp(torch.empty(N, 1, device=dev).uniform_(-2.3, 2.3, generator=g))
+        gr = torch.randn(N, 1, device=dev, generator=g)
+        tu = timeit(lambda: psgd.update_precond_splu(L12, l3, U12, u3, [dx], [dg], 0.01))
+        ta = timeit(lambda: psgd.precond_grad_splu(L12, l3, U12, u3, [gr]))
+        ra, ru = 4 * (3 * r + 9) * N / ta / 1e6, 4 * (9 * r + 15) * N / tu / 1e6
+        if r == 32:
+            base["lu"] = (ra, ru)
+        out["splu_r%d" % r] = {"apply_ms": ta, "update_ms": tu, "apply_GBs": ra, "update_GBs": ru,
+                               "apply_x_spec": ra / base["lu"][0], "update_x_spec": ru / base["lu"][1]}
+        del L12, U12, l3, u3, dx, dg, gr
+        torch.cuda.empty_cache()
+    return out
+
+
 PROF_SLOTS = (("apply_s1", 0), ("apply_s2", 1), ("apply_s3", 2), ("update_s1", 3), ("update_s2", 4), ("update_s3", 5))
 
 
@@ -553,11 +615,16 @@ def compact_line(res, limit=7800):
     c2 = res.get("config2_N1M_r10")
     if c2:
         hoist["config2_step_us"] = c2["step_fused"]["wall_ms"] * 1e3
+    wr = res.get("wide_rank")
+    if wr:
+        hoist.update(uvd_r64_apply_ms=wr["uvd_r64"]["apply_ms"], uvd_r64_update_ms=wr["uvd_r64"]["update_ms"],
+                     uvd_r64_apply_x_spec=wr["uvd_r64"]["apply_x_spec"], uvd_r64_update_x_spec=wr["uvd_r64"]["update_x_spec"],
+                     splu_r40_apply_x_spec=wr["splu_r40"]["apply_x_spec"], splu_r40_update_x_spec=wr["splu_r40"]["update_x_spec"])
     rf.update({k: float("%.6g" % v) for k, v in hoist.items() if v is not None})
     # size guard: drop the least important sub-records first (they stay in the BENCH_DETAIL line on stderr)
     for victim in (("kron", "lenet5_set_fp32", "layer_streams"), ("roofline", "paths", "step_fused_events"),
                    ("config2_N1M_r10", "step_fused", "kernels_ms"), ("config2_N1M_r10", "apply", "kernels_ms"),
-                   ("config2_N1M_r10", "update", "kernels_ms"), ("splu",), ("config2_N1M_r10",), ("roofline", "kernels")):
+                   ("config2_N1M_r10", "update", "kernels_ms"), ("wide_rank",), ("splu",), ("config2_N1M_r10",), ("roofline", "kernels")):
         if len(json.dumps(line)) <= limit:
             break
         node = line
@@ -700,6 +767,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kron", action="store_true", help="skip the Kron apply GFLOP/s and sparse-LU legs")
     ap.add_argument("--no-legs", action="store_true", help="skip the apply-alone / update-alone / config-2 legs")
+    ap.add_argument("--no-wide-rank", action="store_true", help="skip the rank 33..64 leg (UVd r = 64, sparse LU r = 40 beside r = 32)")
+    ap.add_argument("--wide-rows", type=int, default=20_000_000, help="rows of the rank 33..64 leg")
     ap.add_argument("--unfused", action="store_true",
                     help="time update_precond_UVd_math_ + precond_grad_UVd_math as two separate calls")
     ap.add_argument("--bpc", type=int, default=0, help="experiment: cap on blocks per CU of the sweeps (psgd_set_tuning key 1)")
@@ -850,6 +919,8 @@ def main():
             if not args.no_kron:
                 res["kron"] = kron_bench(dev, psgd)
                 res["splu"] = splu_bench(dev, psgd)
+            if not args.no_wide_rank:
+                res["wide_rank"] = wide_rank_bench(dev, psgd, N=args.wide_rows)
             # (after the Kron leg: a process that has initialised an RCCL communicator runs the two-stream Kron updates
             # 1.1-1.3 ms slower at 4096^2 -- tools/rccl_fork_probe.py, profiles/r03_rccl_fork_probe.txt)
             if not args.no_exchange_leg and not single_dev and not args.force_sharded:
