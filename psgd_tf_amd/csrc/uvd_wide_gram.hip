@@ -18,7 +18,7 @@
 namespace psgd {
 
 #ifndef GW_DBG
-#define GW_DBG 0        // what-if builds (wrong results): 1 = no global loads, 2 = no MFMA phase, 4 = no split / plane writes
+#define GW_DBG 0        // what-if builds (wrong results): 2 = no MFMA phase, 4 = no split / plane writes (loads stay), 8 = no t / w columns
 #endif
 constexpr int kGwRows = 32;                  // rows per tile = the K extent of one MFMA
 constexpr int kGwThreads = 1024;             // sixteen waves: eight split, eight multiply
@@ -168,7 +168,12 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     };
     auto split_to = [&](int buf, auto ic) {
       constexpr int ib = decltype(ic)::value;
-      if ((GW_DBG & 4) || !on) return;
+      if (GW_DBG & 4) {                              // (what-if: the loads stay, consumed by nothing but this statement)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) asm volatile("" ::"v"(px[ib][j]));
+        return;
+      }
+      if (!on) return;
       bf16x8 fh, fm, fl;
       float x[8];
 #pragma unroll
@@ -203,17 +208,27 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     // whole ring at the join; one tile ahead in the mfma role an iteration lasted one memory latency.)
     float* TW = reinterpret_cast<float*>(&PL[1][2][NC * 4]);          // (behind the planes: 16 extra units)
     const int tw_un = gw_unit<NC>(2 * r + (lane & 1), (lane >> 1) & 3);
-    float ptw[kGwDepth];
+    // The ring holds the RAW d, h, v of the lane's row: the quotient and the product are formed when the tile is split.  (Forming them
+    // in `fetch` -- or pinning the three loads there with an empty asm -- makes that statement wait for the loads it has just issued:
+    // one full memory latency per tile on this wave, 0.58 us, which every other wave then spends at the barrier.)
+    float pd[kGwDepth], ph[kGwDepth], pv[kGwDepth];
+    bool pok[kGwDepth];                                 // (rows past N exist in the TAIL launch only; they are loaded from row N - 1)
+    const int it = lane >> 3;
     auto fetch = [&](long t, auto ic) {
-      const int it = lane >> 3;
-      const long row = t * kGwRows + (it >> 1) * 8 + (lane & 7), rc = row < N ? row : N - 1;
-      float dd = d[rc], hh = h[rc], vv = v[rc];
-      asm volatile("" : "+v"(dd), "+v"(hh), "+v"(vv));   // (all three loads issued before any use, on every lane)
-      const float wv = vv / dd, tv = dd * hh;
-      ptw[decltype(ic)::value] = row < N ? ((it & 1) ? wv : tv) : 0.0f;
+      const long row = t * kGwRows + (it >> 1) * 8 + (lane & 7), rc = (!TAIL || row < N) ? row : N - 1;
+      pd[decltype(ic)::value] = d[rc];
+      ph[decltype(ic)::value] = h[rc];
+      pv[decltype(ic)::value] = v[rc];
+      pok[decltype(ic)::value] = !TAIL || row < N;
     };
     auto split_to = [&](int b, auto ic) {
-      TW[lane] = ptw[decltype(ic)::value];             // [item][row]
+      const float dd = pd[decltype(ic)::value], hh = ph[decltype(ic)::value], vv = pv[decltype(ic)::value];
+      if (GW_DBG & 8) {                              // (what-if: no t / w columns)
+        asm volatile("" ::"v"(dd), "v"(hh), "v"(vv));
+        return;
+      }
+      const float val = (it & 1) ? vv / dd : dd * hh;
+      TW[lane] = pok[decltype(ic)::value] ? val : 0.0f;        // [item][row]
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (lane < 8) {
