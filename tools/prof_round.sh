@@ -3,14 +3,14 @@
 TAG=${1:-v6}
 set -x
 mkdir -p gpurun_out/$TAG
-python bench.py > gpurun_out/$TAG/bench.json.log 2>gpurun_out/$TAG/bench.err
+python bench.py --detail-json gpurun_out/$TAG/bench_detail.json > gpurun_out/$TAG/bench.json.log 2>gpurun_out/$TAG/bench.err
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 # (the profiled passes skip the exchange_overhead leg: it runs the same r = 20 kernels at 12.5M rows, which would be averaged into the
 #  per-kernel figures of the N = 100M workload; tools/sharded_step_trace.sh profiles that leg on its own)
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/stats -- python3 $R/bench.py --no-cpu-baseline --no-exchange-leg > $R/gpurun_out/$TAG/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/$TAG/pmc_f -- python3 $R/bench.py --no-cpu-baseline --no-kron --no-exchange-leg --steps 3 --warmup 1 > $R/gpurun_out/$TAG/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/$TAG/pmc_w -- python3 $R/bench.py --no-cpu-baseline --no-kron --no-exchange-leg --steps 3 --warmup 1 > $R/gpurun_out/$TAG/pmc_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/$TAG/pmc_f -- python3 $R/bench.py --no-cpu-baseline --no-kron --no-wide-rank --no-exchange-leg --steps 3 --warmup 1 > $R/gpurun_out/$TAG/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/$TAG/pmc_w -- python3 $R/bench.py --no-cpu-baseline --no-kron --no-wide-rank --no-exchange-leg --steps 3 --warmup 1 > $R/gpurun_out/$TAG/pmc_w.log 2>&1
 cd $R
 python tools/rocpd_stats.py gpurun_out/$TAG/stats > gpurun_out/$TAG/kernel_stats.csv
 python tools/pmc_traffic.py gpurun_out/$TAG/pmc_f gpurun_out/$TAG/pmc_w > gpurun_out/$TAG/pmc_traffic.json
