@@ -33,9 +33,10 @@ namespace psgd {
 // rows [-head, 0) relative to the (already shifted) sweep pointers, one lane each, block 0 only
 template <int R, int NVEC, int WB, class Body>
 __device__ __forceinline__ void sweep_head(const float* L2s, const float* const (&vecs)[NVEC], float* mat_out,
-                                           int head, Body&& body) {
-  if (blockIdx.x == 0 && (int)threadIdx.x < head) {
-    const long row = (long)threadIdx.x - head;
+                                           int head, int wv, Body&& body) {
+  const int tid = wv * 64 + lane_from_exec();        // (not threadIdx.x: see wave_in_block in uvd_kernels.h)
+  if (blockIdx.x == 0 && tid < head) {
+    const long row = (long)tid - head;
     float x[1][R];
     float s[NVEC];
 #pragma unroll
@@ -67,10 +68,10 @@ struct ColCfg {
 };
 
 template <int NVEC, bool NT, class Body>
-__device__ __forceinline__ void sweep_cols(const float* const (&vecs)[NVEC], long N, float* lds, Body&& body) {
+__device__ __forceinline__ void sweep_cols(const float* const (&vecs)[NVEC], long N, float* lds, int wv, Body&& body) {
   using C = ColCfg<NVEC>;
   const int lane = threadIdx.x & 63;
-  const long gw = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const long gw = (long)blockIdx.x * kWavesPerBlock + wv;
   const long nw = (long)gridDim.x * kWavesPerBlock;
   const long nfull = N / C::kTileRows;
   float pf[NVEC][C::kRowsPerLane];
@@ -103,6 +104,7 @@ __device__ __forceinline__ void sweep_cols(const float* const (&vecs)[NVEC], lon
   }
   const long tail_rows = N - nfull * C::kTileRows;
   if (tail_rows > 0 && (nfull % nw) == gw) {
+    const int lane = lane_from_exec();
     const long row0 = nfull * C::kTileRows;
 #pragma unroll
     for (int i = 0; i < C::kRowsPerLane; ++i) {
@@ -118,9 +120,10 @@ __device__ __forceinline__ void sweep_cols(const float* const (&vecs)[NVEC], lon
 
 // rows [-head, 0) relative to the (already shifted) pointers of a column sweep, one lane each, block 0 only
 template <int NVEC, class Body>
-__device__ __forceinline__ void cols_head(const float* const (&vecs)[NVEC], int head, Body&& body) {
-  if (blockIdx.x == 0 && (int)threadIdx.x < head) {
-    const long row = (long)threadIdx.x - head;
+__device__ __forceinline__ void cols_head(const float* const (&vecs)[NVEC], int head, int wv, Body&& body) {
+  const int tid = wv * 64 + lane_from_exec();
+  if (blockIdx.x == 0 && tid < head) {
+    const long row = (long)tid - head;
     float s[NVEC];
 #pragma unroll
     for (int k = 0; k < NVEC; ++k) s[k] = vecs[k][row];
@@ -132,6 +135,7 @@ __device__ __forceinline__ void cols_head(const float* const (&vecs)[NVEC], int 
 template <int R, bool NT>
 __global__ __launch_bounds__(kThreads) void k_splu_u2dot(const float* U2, long ldu, const float* x, long n2, int head,
                                                          float* part) {
+  const int wv = wave_in_block();
   constexpr int NV = R + 1;
   __shared__ float lds[kWavesPerBlock][ColCfg<NV>::kLdsFloats];
   __shared__ float red[kWavesPerBlock * R];
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_u2dot(const float* U2, long l
 #pragma unroll
     for (int k = 0; k < R; ++k) acc[k] = fmaf(s[k], s[R], acc[k]);
   };
-  sweep_cols<NV, NT>(vecs, n2, lds[threadIdx.x >> 6], body);
-  cols_head<NV>(vecs, head, body);
+  sweep_cols<NV, NT>(vecs, n2, lds[wv], wv, body);
+  cols_head<NV>(vecs, head, wv, body);
   block_sum_store<R>(acc, red, part);
 }
 
@@ -157,6 +161,7 @@ template <int R, bool NT>
 __global__ __launch_bounds__(kThreads) void k_splu_apply_s2(const float* L2s, const float* l3, const float* u3,
                                                             const float* g2, float* qg2, long n2s, int head,
                                                             const float* __restrict__ coef, float* part) {
+  const int wv = wave_in_block();
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   constexpr int LW = sweep_lds_floats<R, 1, 3>();
   float* red = dyn_lds + kWavesPerBlock * LW;
@@ -171,8 +176,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_apply_s2(const float* L2s, co
 #pragma unroll
     for (int c = 0; c < R; ++c) acc[c] = fmaf(x[0][c], q, acc[c]);
   };
-  sweep_rows<R, 1, 3, -1, NT>(mats, vecs, nullptr, n2s, dyn_lds + (threadIdx.x >> 6) * LW, body);
-  sweep_head<R, 3, -1>(L2s, vecs, nullptr, head, body);
+  sweep_rows<R, 1, 3, -1, NT>(mats, vecs, nullptr, n2s, dyn_lds + wv * LW, body);
+  sweep_head<R, 3, -1>(L2s, vecs, nullptr, head, wv, body);
   block_sum_store<R>(acc, red, part);
 }
 
@@ -181,6 +186,7 @@ template <int R, bool NT>
 __global__ __launch_bounds__(kThreads) void k_splu_apply_s3(const float* U2, long ldu, const float* l3, const float* u3,
                                                             float* out2, long n2, int head,
                                                             const float* __restrict__ coef) {
+  const int wv = wave_in_block();
   constexpr int NV = R + 3;
   __shared__ float lds[kWavesPerBlock][ColCfg<NV>::kLdsFloats];
   const float* vecs_[NV];
@@ -194,8 +200,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_apply_s3(const float* U2, lon
     for (int k = 0; k < R; ++k) o = fmaf(s[k], coef[k], o);
     if (valid) stream_store<NT>(out2 + row, o);
   };
-  sweep_cols<NV, NT>(vecs, n2, lds[threadIdx.x >> 6], body);
-  cols_head<NV>(vecs, head, body);
+  sweep_cols<NV, NT>(vecs, n2, lds[wv], wv, body);
+  cols_head<NV>(vecs, head, wv, body);
 }
 
 // coefficient block of update sweeps 3 and 4 (floats)
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s2(const float* L2s, cons
                                                           const float* l3, const float* u3, const float* x2,
                                                           const float* g2, long n2s, int head,
                                                           const float* __restrict__ coef, float* part) {
+  const int wv = wave_in_block();
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   constexpr int NV = R + 4;
   constexpr int LW = sweep_lds_floats<R, 1, NV>();
@@ -267,8 +274,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s2(const float* L2s, cons
       acc[R + c] = fmaf(x[0][c], iq, acc[R + c]);
     }
   };
-  sweep_rows<R, 1, NV, -1, NT>(mats, vecs, nullptr, n2s, dyn_lds + (threadIdx.x >> 6) * LW, body);
-  sweep_head<R, NV, -1>(L2s, vecs, nullptr, head, body);
+  sweep_rows<R, 1, NV, -1, NT>(mats, vecs, nullptr, n2s, dyn_lds + wv * LW, body);
+  sweep_head<R, NV, -1>(L2s, vecs, nullptr, head, wv, body);
   block_sum_store<2 * R>(acc, red, part);
 }
 
@@ -279,6 +286,7 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s3(const float* L2s, cons
                                                           const float* l3, const float* u3, const float* g2,
                                                           const float* x2, long n2s, int head,
                                                           const float* __restrict__ coef, float* part, float* pmax) {
+  const int wv = wave_in_block();
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   using K = SpluCoef<R>;
   constexpr int NV = R + 4;
@@ -314,8 +322,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s3(const float* L2s, cons
       mu3 = nmaxf(mu3, u);
     }
   };
-  sweep_rows<R, 1, NV, -1, NT>(mats, vecs, nullptr, n2s, dyn_lds + (threadIdx.x >> 6) * LW, body);
-  sweep_head<R, NV, -1>(L2s, vecs, nullptr, head, body);
+  sweep_rows<R, 1, NV, -1, NT>(mats, vecs, nullptr, n2s, dyn_lds + wv * LW, body);
+  sweep_head<R, NV, -1>(L2s, vecs, nullptr, head, wv, body);
   block_sum_store<R>(acc, red, part);
   __syncthreads();
   const int G = gridDim.x;
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s4(const float* L2s, cons
                                                           const float* x2, float* L2o, float* U2o, float* l3o,
                                                           float* u3o, long n2s, int head,
                                                           const float* __restrict__ coef) {
+  const int wv = wave_in_block();
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   using K = SpluCoef<R>;
   constexpr int NV = R + 4;
@@ -369,8 +378,8 @@ __global__ __launch_bounds__(kThreads) void k_splu_upd_s4(const float* L2s, cons
       stream_store<NT>(u3o + row, us - gu3 * us);
     }
   };
-  sweep_rows<R, 1, NV, 0, NT>(mats, vecs, L2o, n2s, dyn_lds + (threadIdx.x >> 6) * LW, body);
-  sweep_head<R, NV, 0>(L2s, vecs, L2o, head, body);
+  sweep_rows<R, 1, NV, 0, NT>(mats, vecs, L2o, n2s, dyn_lds + wv * LW, body);
+  sweep_head<R, NV, 0>(L2s, vecs, L2o, head, wv, body);
 }
 
 // ------------------------------------------------------- launch table ------

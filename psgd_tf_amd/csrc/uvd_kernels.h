@@ -46,6 +46,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (profiles/r01_nt_variants.txt).  It is only chosen when the operands exceed the 256 MiB
 // Infinity Cache; smaller problems keep the default policy so that the three sweeps of one call
 // can hit in L2 / Infinity Cache.
+// The wave's index in its workgroup as a SCALAR (v_readfirstlane), and the lane index recomputed from the execution mask.  The sweeps
+// of ranks 33 .. 64 run with 256 VGPRs + AGPRs; values derived from threadIdx.x that stay live across the tile loop get parked in
+// AGPRs there, and in k_splu_upd_s4<41> / <47> (hipcc 7.0/7.2, -O2 and -O3 alike) the copy was written inside the divergent
+// `if (tile < nfull)` region: a wave that owned the partial last tile but no whole tile came back from it with lane = 0 in every lane
+// and the tail rows were never written (found by the randomised sweep, round 5).  A scalar cannot be lost that way, and the tail
+// takes its lane index from the hardware again.
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int lane_from_exec() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 template <bool NT, class T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
@@ -263,7 +276,7 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
                                            const RowStrides rs = RowStrides{{R, R}}) {
   using C = Cfg<R>;
   const int lane = threadIdx.x & 63;
-  const long gw = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const long gw = (long)blockIdx.x * kWavesPerBlock + wave_in_block();
   const long nw = (long)gridDim.x * kWavesPerBlock;
   const long nfull = N / C::kTileRows;
 
@@ -330,7 +343,9 @@ __device__ __forceinline__ void sweep_rows(const float* const (&mats)[NMAT],
   // tail tile (N % kTileRows rows): guarded scalar staging, owned by one wave
   const long tail_rows = N - nfull * C::kTileRows;
   if (tail_rows > 0 && ((nfull / CH) % nw) == gw) {
+    const int lane = lane_from_exec();               // (all 64 lanes are here: the condition is wave-uniform)
     const long row0 = nfull * C::kTileRows;
+
     const long tail_floats = tail_rows * R;
 #pragma unroll
     for (int m = 0; m < NMAT; ++m) {
@@ -436,10 +451,10 @@ __global__ __launch_bounds__(kThreads) void k_colreduce(const float* M, const fl
   };
   if constexpr (NVEC == 2) {
     const float* const vecs[2] = {a, b};
-    sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
+    sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[wave_in_block()], body);
   } else {
     const float* const vecs[1] = {a};
-    sweep_rows<R, 1, 1, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6], body);
+    sweep_rows<R, 1, 1, -1, NT>(mats, vecs, nullptr, N, lds[wave_in_block()], body);
   }
   block_sum_store<R>(acc, red, part);
 }
@@ -457,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_s2(const float* U, const flo
   for (int c = 0; c < R; ++c) acc[c] = 0.0f;
   const float* const mats[1] = {U};
   const float* const vecs[2] = {d, g};
-  sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+  sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[wave_in_block()],
                           [&](long row, bool valid, float (&x)[1][R], float (&s)[2]) {
                             const float t = s[0] * s[1];
                             const float g1 = t + dot_row<R>(x[0], coef);
@@ -475,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void k_apply_s3(const float* V, const flo
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 2>()];
   const float* const mats[1] = {V};
   const float* const vecs[2] = {d, out};
-  sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+  sweep_rows<R, 1, 2, -1, NT>(mats, vecs, nullptr, N, lds[wave_in_block()],
                           [&](long row, bool valid, float (&x)[1][R], float (&s)[2]) {
                             const float o = s[0] * (s[1] + dot_row<R>(x[0], coef + R));
                             if (valid) stream_store<NT>(out + row, o);
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(kThreads) void k_rowdot_axpy(const float* M, const 
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 1>()];
   const float* const mats[1] = {M};
   const float* const vecs[1] = {xin};
-  sweep_rows<R, 1, 1, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+  sweep_rows<R, 1, 1, -1, NT>(mats, vecs, nullptr, N, lds[wave_in_block()],
                           [&](long row, bool valid, float (&x)[1][R], float (&s)[1]) {
                             const float o = s[0] + dot_row<R>(x[0], coef);
                             if (valid) stream_store<NT>(out + row, o);
@@ -812,7 +827,7 @@ __global__ __launch_bounds__(kThreads) void k_colreduce4(const float* M, const f
   constexpr int kLdsSweep = kWavesPerBlock * sweep_lds_floats<R, 1, 4>() * 4;
   constexpr int kLdsRed = kWavesPerBlock * 4 * 64 * 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
-  float* lds = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * sweep_lds_floats<R, 1, 4>();
+  float* lds = reinterpret_cast<float*>(smem) + wave_in_block() * sweep_lds_floats<R, 1, 4>();
   const float* const mats[1] = {M};
   const float* const vecs[4] = {x0, x1, x2, x3};
   ColSum<R, 1, 1, 4, 0> cs;
@@ -830,7 +845,7 @@ __global__ __launch_bounds__(kThreads) void k_rowdot_axpy4(const float* M, const
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 4>()];
   const float* const mats[1] = {M};
   const float* const vecs[4] = {x0, x1, x2, x3};
-  sweep_rows<R, 1, 4, -1, NT, STR>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+  sweep_rows<R, 1, 4, -1, NT, STR>(mats, vecs, nullptr, N, lds[wave_in_block()],
                                    [&](long row, bool valid, float (&x)[1][R], float (&s)[4]) {
                                      if (!valid) return;
                                      stream_store<NT>(o0 + row, s[0] + dot_row<R>(x[0], coef));
@@ -853,7 +868,7 @@ __global__ __launch_bounds__(kThreads) void k_apply4_s1(const float* V, const fl
   constexpr int kLdsSweep = kWavesPerBlock * sweep_lds_floats<R, 1, 5>() * 4;
   constexpr int kLdsRed = kWavesPerBlock * 4 * 64 * 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
-  float* lds = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * sweep_lds_floats<R, 1, 5>();
+  float* lds = reinterpret_cast<float*>(smem) + wave_in_block() * sweep_lds_floats<R, 1, 5>();
   const float* const mats[1] = {V};
   const float* const vecs[5] = {x0, x1, x2, x3, d};
   ColSum<R, 1, 1, 4, 0> cs;
@@ -872,7 +887,7 @@ __global__ __launch_bounds__(kThreads) void k_apply4_s2(const float* U, const fl
   constexpr int kLdsSweep = kWavesPerBlock * sweep_lds_floats<R, 1, 5>() * 4;
   constexpr int kLdsRed = kWavesPerBlock * 4 * 64 * 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
-  float* lds = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * sweep_lds_floats<R, 1, 5>();
+  float* lds = reinterpret_cast<float*>(smem) + wave_in_block() * sweep_lds_floats<R, 1, 5>();
   const float* const mats[1] = {U};
   const float* const vecs[5] = {x0, x1, x2, x3, d};
   float* const outs[4] = {o0, o1, o2, o3};
@@ -895,7 +910,7 @@ __global__ __launch_bounds__(kThreads) void k_apply4_s3(const float* V, const fl
   const float* const mats[1] = {V};
   const float* const vecs[5] = {o0, o1, o2, o3, d};
   float* const outs[4] = {o0, o1, o2, o3};
-  sweep_rows<R, 1, 5, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+  sweep_rows<R, 1, 5, -1, NT>(mats, vecs, nullptr, N, lds[wave_in_block()],
                               [&](long row, bool valid, float (&x)[1][R], float (&s)[5]) {
                                 if (!valid) return;
 #pragma unroll
@@ -929,7 +944,7 @@ __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, cons
   constexpr int kLdsRed = FUSE ? kWavesPerBlock * 4 * 64 * 8 : 0;
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsSweep > kLdsRed ? kLdsSweep : kLdsRed];
   __shared__ float red[kWavesPerBlock];
-  float* lds = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * sweep_lds_floats<R, 2, NV>();
+  float* lds = reinterpret_cast<float*>(smem) + wave_in_block() * sweep_lds_floats<R, 2, NV>();
   float vmax = 0.0f;
   const float mu = coef[K::kMu];
   const float* const mats[2] = {U, V};
@@ -986,7 +1001,7 @@ __global__ __launch_bounds__(kThreads) void k_uvd_final(const float* U, const fl
   const float mu = step / (maxbuf[0] + tiny);
   const float* const mats[2] = {U, V};
   const float* const vecs[3] = {d, nabla, g};
-  sweep_rows<R, 2, 3, -1, NT>(mats, vecs, nullptr, N, lds[threadIdx.x >> 6],
+  sweep_rows<R, 2, 3, -1, NT>(mats, vecs, nullptr, N, lds[wave_in_block()],
                               [&](long row, bool valid, float (&x)[2][R], float (&s)[3]) {
                                 const float dn = s[0] - (mu * s[0]) * s[1];
                                 const float g1 = dn * s[2] + dot_row<R>(x[0], coef);
@@ -1006,7 +1021,7 @@ __global__ __launch_bounds__(kThreads) void k_rank2_update(float* M, const float
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][sweep_lds_floats<R, 1, 2>()];
   const float* const mats[1] = {M};
   const float* const vecs[2] = {a, b};
-  sweep_rows<R, 1, 2, 0, NT, STR>(mats, vecs, M, N, lds[threadIdx.x >> 6],
+  sweep_rows<R, 1, 2, 0, NT, STR>(mats, vecs, M, N, lds[wave_in_block()],
                                   [&](long, bool, float (&x)[1][R], float (&s)[2]) {
 #pragma unroll
                                     for (int c = 0; c < R; ++c) x[0][c] = x[0][c] - (s[0] * coef[c] - s[1] * coef[R + c]);

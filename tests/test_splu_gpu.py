@@ -27,7 +27,7 @@ SHAPES = [(12, 12), (13, 12), (14, 11), (23, 1), (40, 5), (64, 10), (1000, 3), (
           # chunk padded, three chunks
           # round 5: ranks 33 .. 64 run on the native tail kernels (64-row tiles), above 64 on the chunks
           (40, 40), (41, 40), (44, 40), (5000, 33), (20011, 48), (3001, 70), (6007, 64), (64, 64), (65, 64), (100003, 40),
-          (50021, 64), (30011, 57), (70000, 63), (4001, 100)]
+          (50021, 64), (30011, 57), (70000, 63), (4001, 100), (9257, 41), (30751, 47), (273, 41)]
 KEYS = ("L12", "l3", "U12", "u3")
 
 
@@ -102,6 +102,23 @@ def test_chunk_route_of_ranks_33_to_64_agrees_with_the_native_kernels(psgd, monk
         got[route] = [a] + u
     for x, y in zip(got["native"], got["chunks"]):
         assert rel_err(x, y) < STATE_TOL
+
+
+@pytest.mark.parametrize("r", list(range(1, 65)))
+def test_every_rank_with_a_partial_last_tile(psgd, r):
+    """Regression (round 5, found by the randomised sweep): at r = 41 and r = 47 the update left the rows of the partial last tile
+    unwritten -- the wave that owns that tile lost its lane index (uvd_kernels.h: wave_in_block).  Every native rank, a tail of 1 ..
+    63 rows behind two whole tiles, and a second shape where the owner wave has no whole tile of its own."""
+    for N in (r + 64 * 2 + 1 + (r * 7) % 63 + ((32 - r % 32) % 32), 257 + r):
+        p = make_splu_problem(N, r, seed=11 * N + r)
+        t, q = _dev(p), _f64(p)
+        new = psgd.update_precond_splu(t["L12"], t["l3"], t["U12"], t["u3"], [t["dx"]], [t["dg"]], 0.05)
+        ref = orc.update_precond_splu(q["L12"], q["l3"], q["U12"], q["u3"], [q["dx"]], [q["dg"]], 0.05)
+        for k, a, b in zip(KEYS, new, ref):
+            if b.size:
+                assert rel_err(a.cpu().numpy(), b) < STATE_TOL, (N, k)
+        out = psgd.precond_grad_splu(*new, [t["g"]])[0]
+        assert rel_err(out.cpu().numpy(), orc.precond_grad_splu(*ref, [q["g"]])[0]) < 2 * APPLY_TOL, N
 
 
 def test_demo_initial_state(psgd):
