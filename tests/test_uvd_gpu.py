@@ -489,3 +489,21 @@ def test_wide_update_rejects_bad_arguments(hip_lib):
     assert call(0, r, n) == _lib.PSGD_ERR_BAD_ARG
     assert call(U.data_ptr(), r, n) == _lib.PSGD_OK
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("r", list(range(1, 65)))
+def test_every_rank_with_a_partial_last_tile(psgd, r):
+    """Every specialised rank (1 .. 32) and every whole-matrix rank (33 .. 64) with partial last tiles -- one shape where the wave
+    that owns the tail has whole tiles of its own, one where it has none (the case that lost its lane index in the sparse-LU update at
+    r = 41 / 47, uvd_kernels.h: wave_in_block): apply and both update branches against the oracle."""
+    for N in (9000 + 13 * r, 257 + r):
+        p = make_uvd_problem(N, r, seed=5 * N + r, uv_gain=1.5, d_spread=0.3)
+        for upd in (True, False):
+            t, q = _to_dev(p), _f64(p)
+            psgd.update_precond_UVd_math_(t["U"], t["V"], t["d"], t["v"], t["h"], 0.01, TINY32, balance=False, update_U=upd)
+            orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=False, update_U=upd)
+            for k in ("U", "V", "d"):
+                assert rel_err(t[k].cpu().numpy(), q[k]) < 2 * STATE_TOL, (N, upd, k)
+                assert rel_err(t[k].cpu().numpy() - p[k], q[k] - p[k].astype(np.float64)) < INCR_TOL or k == ("V" if upd else "U"), (N, upd, k)
+            out = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
+            assert rel_err(out.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < 2 * APPLY_TOL, (N, upd)
