@@ -132,10 +132,15 @@ def fuzz_kron_sparse(g, it):
     return "kron-sparse %s(x)%s %dx%d" % (kl, kr, M, N), max(e1, e2), 3e-5
 
 
+_WIDE_ONLY = os.environ.get("FUZZ_ONLY") == "wide"     # only ranks 33 .. 64 of the two low-rank preconditioners (round 5's kernels)
+
+
 def fuzz_uvd(g, it):
     r = int(torch.randint(1, 33, (1,), generator=g, device=dev))
-    if it % 15 == 3:                                  # wide rank: column chunks (uvd_wide.py)
+    if it % 15 == 3:                                  # wide rank: whole-matrix kernels to 64, column chunks above (uvd_wide.py)
         r = int(torch.randint(33, 80, (1,), generator=g, device=dev))
+    if _WIDE_ONLY:
+        r = int(torch.randint(33, 65, (1,), generator=g, device=dev))
     N = int(torch.randint(max(r, 2), 400000 if it % 4 == 0 else 20000, (1,), generator=g, device=dev))
     # from the reference's init scale (gain 2) to ||U V'|| = O(1) (gain ~ sqrt(r)), V correlated with U every third case
     gain = 2.0 if it % 3 else float(torch.empty(1, device=dev).uniform_(0.5, 1.5, generator=g)) * r ** 0.5
@@ -160,6 +165,8 @@ def fuzz_uvd(g, it):
                 rel(U, U64), rel(V, V64), rel(d, d64))
         X = torch.cat([gr, v, d], 1).contiguous()
         e = max(e, rel(psgd.IpUVtmatvec(U, V, X), ref64.IpUVtmatvec(U.double(), V.double(), X.double())))
+        if r > 32:                                    # precond_grad_UVd_math on a matrix g (three columns)
+            e = max(e, rel(psgd.precond_grad_UVd_math(U, V, d, X), ref64.precond_grad_UVd_math(U64, V64, d64, X.double())))
     tol = 2e-5 if r > 32 else 1e-5
     if not e < tol:
         # Before calling it a failure: how far does the fp64 update itself move when its fp32 inputs are perturbed by
@@ -193,6 +200,8 @@ def fuzz_splu(g, it):
     r = int(torch.randint(1, 33, (1,), generator=g, device=dev))
     if it % 5 == 2:                                   # ranks 33 .. 64: the native kernels on 64-row tiles (round 5); above: column chunks
         r = int(torch.randint(33, 72, (1,), generator=g, device=dev))
+    if _WIDE_ONLY:
+        r = int(torch.randint(33, 65, (1,), generator=g, device=dev))
     N = int(torch.randint(r, 300000 if it % 4 == 0 else 20000, (1,), generator=g, device=dev))
     sc = 0.3 / r ** 0.5
     L12 = torch.randn(N, r, device=dev, generator=g) * (sc * 3 * (r / N) ** 0.5)
@@ -215,6 +224,8 @@ def run(budget, seed=1):
     _lib.load()
     g = torch.Generator(device=dev).manual_seed(seed)
     fams = [fuzz_kron, fuzz_kron_bf16, fuzz_kron_bf16_update, fuzz_uvd, fuzz_splu, fuzz_kron_sparse]
+    if _WIDE_ONLY:
+        fams = [fuzz_uvd, fuzz_splu]
     t0, it, worst, bad = time.time(), 0, {}, []
     while time.time() - t0 < budget:
         f = fams[it % len(fams)]
