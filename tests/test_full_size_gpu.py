@@ -232,3 +232,24 @@ def test_splu_large(psgd):
     assert abs(dot(g, Pn2) - dot(Pn, g2)) <= 1e-5 * (dot(g, Pn) * dot(g2, Pn2)) ** 0.5
     assert _rel(Pn, apply64(*[t.double() for t in new], g.double())) < 1e-5
     assert 0 < _rel(Pn, Pg) < 0.2
+
+
+@pytest.mark.parametrize("r", [64])
+def test_wide_rank_at_36M_rows_against_fp64(psgd, r):
+    """Ranks 33 .. 64 (round 5: whole-matrix kernels, the one-sweep Gram, psgd_uvd_wide_update_f32) at a size where element offsets
+    pass 2^31 (36 M x 64 = 2.3e9 floats per factor): update (both branches) and apply against the fp64 run of the reference's op
+    sequence on the GPU."""
+    _need_gb(100)
+    dev = torch.device("cuda:0")
+    N = 36_000_000
+    U, V, d, g, v, h = _uvd_inputs(N, r, dev)
+    for upd in (True, False):
+        U64, V64, d64 = U.double(), V.double(), d.double()
+        psgd.update_precond_UVd_math_(U, V, d, v, h, 0.01, TINY32, balance=False, update_U=upd)
+        ref64.update_precond_UVd_math_(U64, V64, d64, v.double(), h.double(), 0.01, TINY32, balance=False, update_U=upd)
+        assert max(_rel(U, U64), _rel(V, V64), _rel(d, d64)) < 2e-5, upd
+        del U64, V64, d64
+    out = psgd.precond_grad_UVd_math(U, V, d, g)
+    assert _rel(out, ref64.precond_grad_UVd_math(U.double(), V.double(), d.double(), g.double())) < 1e-5
+    # the last rows (the partial tile of a ragged N is covered elsewhere; here: the last whole tiles of a 64-bit offset)
+    assert torch.isfinite(U[-64:]).all() and torch.isfinite(out[-64:]).all()
