@@ -52,7 +52,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // `if (tile < nfull)` region: a wave that owned the partial last tile but no whole tile came back from it with lane = 0 in every lane
 // and the tail rows were never written (found by the randomised sweep, round 5).  A scalar cannot be lost that way, and the tail
 // takes its lane index from the hardware again.
+#ifndef PSGD_WAVE_ID_VGPR
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#else       // (A/B builds only: the form before the fix)
+__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
+#endif
 __device__ __forceinline__ int lane_from_exec() {
   int l;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
