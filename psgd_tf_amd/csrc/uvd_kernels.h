@@ -531,11 +531,15 @@ __device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& h, bf16
   u32x4s ph, pm, pl;
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
-    const float x0 = x[j], x1 = x[j + 1];
-    const float h0 = __uint_as_float(__float_as_uint(x0) & top), h1 = __uint_as_float(__float_as_uint(x1) & top);
-    const float r0 = x0 - h0, r1 = x1 - h1;
-    const float m0 = __uint_as_float(__float_as_uint(r0) & top), m1 = __uint_as_float(__float_as_uint(r1) & top);
-    const float s0 = r0 - m0, s1 = r1 - m1;
+    // (pairs as two-element vectors: the two subtractions of a pair are one v_pk_add_f32 each)
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+    const f32x2s xx = {x[j], x[j + 1]};
+    const f32x2s hh = __builtin_bit_cast(f32x2s, __builtin_bit_cast(u32x2s, xx) & top);
+    const f32x2s rr = xx - hh;
+    const f32x2s mm = __builtin_bit_cast(f32x2s, __builtin_bit_cast(u32x2s, rr) & top);
+    const f32x2s ss = rr - mm;
+    const float x0 = xx[0], x1 = xx[1], r0 = rr[0], r1 = rr[1], s0 = ss[0], s1 = ss[1];
     ph[j >> 1] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);   // (x0 >> 16) | (x1 & top)
     pm[j >> 1] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
     pl[j >> 1] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);

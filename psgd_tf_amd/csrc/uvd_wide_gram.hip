@@ -138,22 +138,27 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
     const int col = tid % r, g0 = tid / r;
     const bool on = g0 < 4;
     const unsigned e0 = on ? (unsigned)(g0 * 8 * r + col) : 0u;       // element offset of the item's first value inside a tile
+    const unsigned eb0 = e0 * 4u;
     const int un0 = gw_unit<NC>(col, on ? g0 : 0), un1 = gw_unit<NC>(r + col, on ? g0 : 0);
     for (int i = tid; i < 2 * 3 * (NC * 4 + 16); i += 256) (&PL[0][0][0])[i] = u32x4g{0u, 0u, 0u, 0u};     // (pad columns stay zero)
     float px[kGwDepth][16];
     auto fetch = [&](long t, auto ic) {
       constexpr int ib = decltype(ic)::value;
       if constexpr (!TAIL) {
-        // (the tile bases are kept opaque: left visible, the compiler turns each of the 64 loads of the ring into its own 64-bit
-        //  induction pointer -- 128 registers of addresses, spilled to scratch)
-        long toff = t * kGwRows * r;                 // (uniform; the OFFSET is the opaque value, so that the loads stay global loads)
-        asm volatile("" : "+s"(toff));
-        const float* ub = U + toff;
-        const float* vb = V + toff;
+        // Buffer loads: descriptor = the tile of U (V), built from scalars only; the thread's byte offset in the 32-bit voffset, the
+        // row's in the scalar soffset -- no 64-bit vector add per load, and nothing the compiler can turn into 64 induction pointers
+        // (with plain pointers it did: 128 registers of addresses, spilled).
+        const long toff0 = t * kGwRows * r;
+        const long toff = ((long)__builtin_amdgcn_readfirstlane((int)(toff0 >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)toff0);
+        const unsigned tbytes = (unsigned)(kGwRows * r * 4);
+        const auto ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U + toff), 0, tbytes, 0x00020000);
+        const auto rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V + toff), 0, tbytes, 0x00020000);
+        constexpr int aux = NT ? 2 : 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          px[ib][j] = stream_load<NT>((ub + j * r) + e0);
-          px[ib][8 + j] = stream_load<NT>((vb + j * r) + e0);
+          px[ib][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, eb0, j * r * 4, aux));
+          px[ib][8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, eb0, j * r * 4, aux));
         }
       } else {
         const long row0 = t * kGwRows + (on ? g0 : 0) * 8;
