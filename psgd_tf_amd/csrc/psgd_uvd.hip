@@ -525,7 +525,7 @@ __device__ void coef_block_ref(const double* __restrict__ gram, int r, float ste
     const int i = idx / r, j = idx % r;
     A[i][j] = G(i, j);
     B[i][j] = G(r + i, r + j);
-    Cm[i][j] = G(j, r + i);
+    Cm[i][j] = DENSE ? G(r + i, j) : G(j, r + i);      // (the dense Gram is symmetric to the bit: the coalesced of the two reads)
   }
   if (tid < r) {
     ut[tid] = G(tid, 2 * r);
