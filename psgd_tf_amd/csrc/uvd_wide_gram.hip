@@ -4,11 +4,12 @@
 // The rank-templated Gram kernel (uvd_kernels.h: k_update_gram, r <= 32) keeps one fp32 MFMA accumulator set and one fp64 set per
 // pair of 16-column blocks in every wave's registers: 15 pairs at r = 32, 45 at r = 64 -- 540 registers.  The wide-rank path therefore
 // ran it on PAIRS OF COLUMN CHUNKS (uvd_wide.py), one sweep per pair: three passes over U and V at r = 64 (six pair sweeps), and the
-// update reached 0.23 of the specialised rate.  Here a workgroup shares one 32-row tile: every element is split 3-way into bf16
-// (x = h + m + l exactly, as in k_update_gram) ONCE, into column-major bf16 planes in LDS, and the block pairs are dealt to eight waves
-// (<= 6 pairs each at r = 64: six v_mfma_f32_16x16x32_bf16 per pair, fp32 chains of 256 rows folded into fp64).  Partials: one fp64
-// tile set per workgroup (each pair is owned by exactly one wave: no cross-wave reduction), reduced in block order and scattered into
-// the dense symmetric Gram [ncol][ncol] by k_gram_wide_finish (fixed order: reproducible).
+// update reached 0.23 of the specialised rate.  Here a workgroup of sixteen waves shares one 32-row tile: every element is split 3-way
+// into bf16 (x = h + m + l exactly, as in k_update_gram) ONCE, into bf16 planes in LDS (16-byte units of 8 rows of one column, row-group
+// major), and the block pairs are dealt, in 2 x 2 groups, to eleven multiplying waves (<= 5 pairs each at r = 64: six
+// v_mfma_f32_16x16x32_bf16 per pair, fp32 chains of 256 rows folded into fp64).  Partials: one fp64 tile set per workgroup (each pair
+// is owned by exactly one wave: no cross-wave reduction), reduced in block order and scattered into the dense symmetric Gram
+// [ncol][ncol] by k_gram_wide_finish (fixed order: reproducible, symmetric to the bit).
 #include "uvd_kernels.h"
 
 #include "psgd_hip.h"
@@ -21,7 +22,7 @@ namespace psgd {
 #define GW_DBG 0        // what-if builds (wrong results): 2 = no MFMA phase, 4 = no split / plane writes (loads stay), 8 = no t / w columns
 #endif
 constexpr int kGwRows = 32;                  // rows per tile = the K extent of one MFMA
-constexpr int kGwThreads = 1024;             // sixteen waves: eight split, eight multiply
+constexpr int kGwThreads = 1024;             // sixteen waves: four split, one for t / w, eleven multiply
 constexpr int kGwMulWaves = 11;              // waves 5 .. 15 multiply: block pair p belongs to wave p mod 11, accumulator slot p / 11
 constexpr int kGwDepth = 4;                  // tiles the split role requests ahead (even: a tile's plane buffer is its ordinal's parity)
 
@@ -87,12 +88,13 @@ template <int NC> __device__ __forceinline__ int gw_unit(int col, int rg) { retu
 template <int NC> __device__ __forceinline__ int gw_unit(int col, int rg) { return col * 4 + (rg ^ ((col >> 2) & 2)); }
 #endif
 
-// Sixteen waves, two roles.  Waves 0-7 ("split"): tile t + 1 from global memory straight into the bf16 planes -- a thread owns (column, 8
-// rows) items; its 8 loads are each coalesced across the wave (64 consecutive floats of one row), so there is no fp32 stage and no
-// transposing pass; the loads of tile t + 2 are in flight while tile t + 1 is split.  Waves 8-15 ("mfma"): the block pairs of tile t from
-// the other plane buffer.  ONE barrier per tile swaps the buffers.  The matrix work of a tile is 270 MFMAs = 1080 cycles per SIMD -- two
-// thirds of the time HBM gives a 16.6-KiB tile per CU at r = 64 -- so the split has to run beside it, not before it: a version with all
-// waves doing load -> split -> barrier -> MFMA -> barrier ran at 2.1 TB/s (1.6 with four waves of 12 pairs), whatever the prefetch depth.
+// Sixteen waves, three roles, ONE barrier per tile that swaps the two plane buffers.  Waves 0-3 ("split"): thread (column, 8-row
+// group) brings its 8 + 8 values of U and V straight from global memory into registers -- every load coalesced across the wave, a ring of
+// kGwDepth tiles in flight -- and writes tile t + 1's planes while tile t is multiplied; there is no fp32 stage and no transposing
+// pass.  Wave 4: the t = d .* h and w = v ./ d columns.  Waves 5-15 ("mfma"): the block pairs of tile t from the other buffer.  The
+// matrix work of a tile is 270 MFMAs = 1080 cycles per SIMD -- most of the time HBM gives a 16-KiB tile per CU at r = 64 -- so the split
+// has to run beside it, not before it: a version with all waves doing load -> split -> barrier -> MFMA -> barrier ran at 2.1 TB/s (1.6
+// with four waves of 12 pairs), whatever the prefetch depth.
 // TAIL = false: the tiles [0, ntiles) are whole (no row is checked against N: the loads are a per-tile scalar base + a per-thread offset
 // computed once); TAIL = true: one workgroup on the last, partial tile `tile0`, every row clamped and masked.
 template <int NB, bool NT, bool TAIL>
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
   constexpr int NPW = GwPlanOf<NB>::value.max_load;
   constexpr int NP = NB * (NB + 1) / 2;
   typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) u32x4g PL[2][3][NC * 4 + 16];     // (+ 16 units: the t / w scratch of the mfma role)
+  __shared__ __attribute__((aligned(16))) u32x4g PL[2][3][NC * 4 + 16];     // (+ 16 units: the scratch of the t / w wave)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long G = gridDim.x;
   const long tfirst = TAIL ? tile0 : (long)blockIdx.x;       // this workgroup's first tile; TAIL: its only one
