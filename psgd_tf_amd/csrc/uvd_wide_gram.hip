@@ -27,7 +27,6 @@ constexpr int kGwMulWaves = 11;              // waves 5 .. 15 multiply: block pa
 constexpr int kGwDepth = 4;                  // tiles the split role requests ahead (even: a tile's plane buffer is its ordinal's parity)
 
 __host__ __device__ constexpr int gw_pair_index(int NB, int bi, int bj) { return bi * NB - (bi * (bi - 1)) / 2 + (bj - bi); }
-__host__ __device__ constexpr int gw_max_pairs(int NB) { return (NB * (NB + 1) / 2 + kGwMulWaves - 1) / kGwMulWaves; }
 
 // The multiplying waves work on 2 x 2 groups of 16-column blocks ("super pairs"): the four fragments (x 3 planes) of a group are read
 // once for its (up to) four block pairs -- 135 fragment reads per tile at r = 64 instead of 243 with one pair at a time, and LDS
