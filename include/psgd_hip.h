@@ -212,6 +212,14 @@ int psgd_uvd_wide_rank2_update_f32(float *M, const float *a, const float *b, con
  * U, V contiguous [N, r], 16-byte aligned, d 16-byte aligned; scratch: psgd_uvd_wide_update_scratch_bytes(N, r) bytes
  * (about 4 N), 256-byte aligned, contents need not survive.                                                              */
 int64_t psgd_uvd_wide_update_scratch_bytes(int64_t N, int r);
+/* ... followed by precond_grad_UVd_math on the updated state (the UVd.step pattern, psgd.py:732 -> :748; what
+ * psgd_uvd_update_apply_f32 is for r <= 32): sweep 2 also reduces [Unew | Vnew]' [d.*g, d.*g.*nablaD], one small kernel turns those
+ * sums and the Gram into the two r-vectors of the apply, one last sweep updates d and writes out -- U and V are read three times.
+ * g, out: [N], out must not alias g.  Same results as the two calls within rounding (tests: 2e-5).                              */
+int64_t psgd_uvd_wide_update_apply_scratch_bytes(int64_t N, int r);
+int psgd_uvd_wide_update_apply_f32(float *U, float *V, float *d, const float *v, const float *h, const float *g, float *out,
+                                   int64_t N, int r, float step, float tiny, int update_U,
+                                   void *scratch, int64_t scratch_bytes, void *stream);
 int psgd_uvd_wide_update_f32(float *U, float *V, float *d, const float *v, const float *h, int64_t N, int r,
                              float step, float tiny, int update_U, void *scratch, int64_t scratch_bytes, void *stream);
 

@@ -77,6 +77,8 @@ SIGNATURES = {
                                            _i64, _int, _strm]),
     "psgd_uvd_wide_rank2_update_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, _strm]),
     "psgd_uvd_wide_update_scratch_bytes": (_i64, [_i64, _int]),
+    "psgd_uvd_wide_update_apply_scratch_bytes": (_i64, [_i64, _int]),
+    "psgd_uvd_wide_update_apply_f32": (_int, [_c_f32p] * 7 + [_i64, _int, ctypes.c_float, ctypes.c_float, _int, _c_ws, _i64, _strm]),
     "psgd_uvd_wide_update_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, ctypes.c_float, ctypes.c_float, _int,
                                         _c_ws, _i64, _strm]),
     "psgd_uvd_colsums_f32": (_int, [_c_f32p, ctypes.POINTER(ctypes.c_void_p), _int, _c_f32p, _i64, _int, _c_ws, _i64, _strm]),

@@ -896,14 +896,14 @@ static int launch_coef(hipStream_t st, const double* gram, int r, float step, fl
 // and Unew'Unew = U'U when V was updated.  Writes coef[0, r) = s1', coef[r, 2r) = s2' (+ the fp64 values to s_out).
 // REDUCE (single GPU, grids of <= 512 blocks): the block first reduces the sweep's partials itself (what k_reduce_pq
 // does in the staged path, same order per element): one launch less between the two sweeps.
-template <bool REDUCE>
+template <bool REDUCE, int CAP = MR, bool DENSE = false>       // (CAP = 64, DENSE: ranks 33 .. 64, the row-major Gram of k_gram_wide_finish)
 __global__ __launch_bounds__(1024) void k_fused_post(const double* __restrict__ gram, const double* __restrict__ c64,
                                                      const double* __restrict__ part, const float* __restrict__ pmax,
                                                      int G, double* pq, float* maxbuf, int r, float step, float tiny,
                                                      int update_U, float* coef, double* s_out) {
-  __shared__ double A[MR][MR + 1];
-  __shared__ double s1n[MR];
-  __shared__ double pqs[4 * MR];
+  __shared__ double A[CAP][CAP + 1];
+  __shared__ double s1n[CAP];
+  __shared__ double pqs[4 * CAP];
   __shared__ float mx;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
   if constexpr (REDUCE) {
@@ -932,6 +932,7 @@ __global__ __launch_bounds__(1024) void k_fused_post(const double* __restrict__ 
   }
   const int nb = (2 * r + 2 + 15) / 16;
   auto Gm = [&](int a, int b) -> double {
+    if constexpr (DENSE) return gram[a * (2 * r + 2) + b];
     if (a > b) { const int t = a; a = b; b = t; }
     const int bi = a >> 4, bj = b >> 4, i = a & 15, j = b & 15;
     const int p = bi * nb - (bi * (bi - 1)) / 2 + (bj - bi);
@@ -1407,6 +1408,72 @@ static int64_t wide_update_layout(int64_t N, int r, char* base, WideUpd* w) {
   return off;
 }
 
+// ---- update followed by the apply on the updated state (the UVd.step pattern, psgd.py:732 -> :748) for 32 < r <= 64: the fused
+// sequence of the specialised ranks -- sweep 2 also reduces [Unew | Vnew]' [d.*g, d.*g.*nablaD], k_fused_post turns those sums and the
+// Gram into the two r-vectors of the apply, one last sweep updates d and forms the output: U and V are read three times, not four.
+struct WideStep { WideUpd u; double* part_pq; double* c64; double* pq; double* post; };
+static int64_t wide_step_layout(int64_t N, int r, char* base, WideStep* w) {
+  int64_t off = wide_update_layout(N, r, base, w ? &w->u : nullptr);
+  auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off = align256(off + bytes); return p; };
+  double* part_pq = reinterpret_cast<double*>(take((int64_t)4 * r * 512 * 8));     // (grids of at most 512 workgroups: k_fused_post<true>)
+  double* c64 = reinterpret_cast<double*>(take((int64_t)(4 * r + 4) * 8));
+  double* pq = reinterpret_cast<double*>(take((int64_t)(4 * r + 1) * 8));
+  double* post = reinterpret_cast<double*>(take((int64_t)2 * r * 8));
+  if (w) { w->part_pq = part_pq; w->c64 = c64; w->pq = pq; w->post = post; }
+  return off;
+}
+
+int64_t psgd_uvd_wide_update_apply_scratch_bytes(int64_t N, int r) {
+  if (N <= 0 || r <= PSGD_UVD_MAX_RANK || r > 2 * PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
+  return wide_step_layout(N, r, nullptr, nullptr);
+}
+
+static int wide_coef_launch(hipStream_t st, const double* G, int r, float step, float tiny, int update_U, float* coef, double* c64) {
+  static bool attr_done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  const int lds = (int)sizeof(CoefBlockLds<2 * MR>);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_coef), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return 1;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(k_wide_coef, dim3(1), dim3(kThreads), lds, st, G, r, step, tiny, update_U, coef, c64);
+  return (int)hipGetLastError();
+}
+
+static int wide_s2_grid(const UvdWideOps* ops, int64_t N) {       // a tile of U and one of V per wave: one workgroup per CU
+  const int64_t tiles = (N + ops->tile_rows - 1) / ops->tile_rows;
+  int64_t grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (grid > num_cus()) grid = num_cus();
+  if (grid > 512) grid = 512;
+  return grid < 1 ? 1 : (int)grid;
+}
+
+int psgd_uvd_wide_update_apply_f32(float* U, float* V, float* d, const float* v, const float* h, const float* g, float* out, int64_t N,
+                                   int r, float step, float tiny, int update_U, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!U || !V || !d || !v || !h || !g || !out) return PSGD_ERR_BAD_ARG;
+  const UvdWideOps* ops;
+  int rc = wide_open(U, V, N, r, nullptr, 0, &ops, nullptr);
+  if (rc) return rc;
+  if (misaligned16(d)) return PSGD_ERR_ALIGN;
+  if (!scratch || (reinterpret_cast<uintptr_t>(scratch) & 255) || scratch_bytes < wide_step_layout(N, r, nullptr, nullptr))
+    return PSGD_ERR_WORKSPACE;
+  WideStep w;
+  wide_step_layout(N, r, static_cast<char*>(scratch), &w);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  rc = psgd_uvd_gram_wide_f32(U, V, d, v, h, N, r, w.u.G, w.u.gram_scr, w.u.gram_bytes, stream);
+  if (rc) return rc;
+  PSGD_CHECK_LAUNCH(wide_coef_launch(st, w.u.G, r, step, tiny, update_U, w.u.coef, w.c64));
+  const int grid = wide_s2_grid(ops, N);
+  PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, g, N, w.u.coef, w.u.nabla, w.u.pmax, w.part_pq, grid, st));
+  hipLaunchKernelGGL((k_fused_post<true, 2 * MR, true>), dim3(1), dim3(1024), 0, st, w.u.G, w.c64, w.part_pq, w.u.pmax, grid, w.pq,
+                     w.u.maxbuf, r, step, tiny, update_U, w.u.coef, w.post);
+  PSGD_CHECK_LAUNCH(last_launch());
+  PSGD_CHECK_LAUNCH(ops->final_sweep(use_nt(N, r), U, V, d, w.u.nabla, g, out, N, w.u.coef, w.u.maxbuf, step, tiny, grid, st));
+  return PSGD_OK;
+}
+
 int64_t psgd_uvd_wide_update_scratch_bytes(int64_t N, int r) {
   if (N <= 0 || r <= PSGD_UVD_MAX_RANK || r > 2 * PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
   return wide_update_layout(N, r, nullptr, nullptr);
@@ -1426,27 +1493,10 @@ int psgd_uvd_wide_update_f32(float* U, float* V, float* d, const float* v, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   rc = psgd_uvd_gram_wide_f32(U, V, d, v, h, N, r, w.G, w.gram_scr, w.gram_bytes, stream);
   if (rc) return rc;
-  {
-    static bool attr_done[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return PSGD_ERR_LAUNCH;
-    const int lds = (int)sizeof(CoefBlockLds<2 * MR>);
-    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_coef), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return PSGD_ERR_LAUNCH;
-      if (dev >= 0 && dev < 64) attr_done[dev] = true;
-    }
-    hipLaunchKernelGGL(k_wide_coef, dim3(1), dim3(kThreads), lds, st, w.G, r, step, tiny, update_U, w.coef, static_cast<double*>(nullptr));
-    PSGD_CHECK_LAUNCH(last_launch());
-  }
-  // sweep 2 holds a tile of U and one of V per wave (up to 131 KiB per workgroup): one workgroup per CU
-  const int64_t tiles = (N + ops->tile_rows - 1) / ops->tile_rows;
-  int64_t grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (grid > num_cus()) grid = num_cus();
-  if (grid > kMaxGrid) grid = kMaxGrid;
-  if (grid < 1) grid = 1;
-  PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, N, w.coef, w.nabla, w.pmax, (int)grid, st));
-  hipLaunchKernelGGL(k_update_d, dim3(flat_grid(N)), dim3(kThreads), 0, st, d, w.nabla, (long)N, w.maxbuf, w.pmax, (int)grid, step, tiny);
+  PSGD_CHECK_LAUNCH(wide_coef_launch(st, w.G, r, step, tiny, update_U, w.coef, nullptr));
+  const int grid = wide_s2_grid(ops, N);
+  PSGD_CHECK_LAUNCH(ops->update_s2(use_nt(N, r), update_U, U, V, d, v, h, nullptr, N, w.coef, w.nabla, w.pmax, nullptr, grid, st));
+  hipLaunchKernelGGL(k_update_d, dim3(flat_grid(N)), dim3(kThreads), 0, st, d, w.nabla, (long)N, w.maxbuf, w.pmax, grid, step, tiny);
   PSGD_CHECK_LAUNCH(last_launch());
   return PSGD_OK;
 }

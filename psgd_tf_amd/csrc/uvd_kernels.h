@@ -763,10 +763,10 @@ struct UpdCoef {
 // 4q .. 4q + 3 against x_j in its four accumulator registers: 4 VGPRs instead of NX * NW * R per-lane accumulators, on
 // a pipe the sweep does not otherwise use.  The x_j are the per-row scalars in LDS slots SLOT0 .. SLOT0 + NX - 1 (as
 // the body left them: kStoreVecMask).  fp32 chains are <= 256 rows long, then folded into fp64.
-template <int R, int NMAT, int NW, int NX, int SLOT0>
+template <int R, int NMAT, int NW, int NX, int SLOT0, int OP = 0>       // OP: the first of the NW staged operands that form W
 struct ColSum {
   using C = Cfg<R>;
-  static_assert(NW * R <= 64 && NX <= 4 && NW <= NMAT, "one lane per column of W, one 4x4 block column per vector");
+  static_assert(NW * R <= 64 && NX <= 4 && OP + NW <= NMAT, "one lane per column of W, one 4x4 block column per vector");
   static constexpr unsigned kStoreVecMask = ((1u << NX) - 1u) << SLOT0;
   static constexpr bool kActive = true;
   static constexpr int kFlushTiles = (256 / C::kTileRows) > 0 ? (256 / C::kTileRows) : 1;
@@ -780,7 +780,7 @@ struct ColSum {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc64[e] = 0.0;
     since = 0;
-    aoff = (l < NW * R) ? (l / R) * C::kTileFloats + (l % R) : 0;
+    aoff = (l < NW * R) ? (OP + l / R) * C::kTileFloats + (l % R) : 0;
     amask = (l < NW * R) ? 1.0f : 0.0f;
     const int j = l & 3;
     boff = NMAT * C::kTileFloats + (SLOT0 + (j < NX ? j : 0)) * C::kTileRows;
@@ -804,7 +804,8 @@ struct ColSum {
   }
   // Block total (fixed order over the 4 waves) -> part[(j * NW * R + c) * G + block], j = vector, c = column of W:
   // transposed fp64 partials, so that a reduction reads an element's G partials contiguously.
-  __device__ __forceinline__ void block_store(double* red /* [waves][4][64] */, double* part) {
+  // (col0, ncols: this W as columns col0 .. of a wider one with ncols columns -- ColSumPair below)
+  __device__ __forceinline__ void block_store(double* red /* [waves][4][64] */, double* part, int col0 = 0, int ncols = NW * R) {
     flush();
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
@@ -818,7 +819,7 @@ struct ColSum {
         if (c < NW * R) {
           const double t = ((red[(0 * 4 + e) * 64 + l] + red[(1 * 4 + e) * 64 + l]) + red[(2 * 4 + e) * 64 + l]) +
                            red[(3 * 4 + e) * 64 + l];
-          part[(long)((l & 3) * NW * R + c) * gridDim.x + blockIdx.x] = t;
+          part[(long)((l & 3) * ncols + col0 + c) * gridDim.x + blockIdx.x] = t;
         }
       }
     }
@@ -826,6 +827,20 @@ struct ColSum {
 };
 template <int R, int NMAT, int SLOT0, int SLOT1>
 using ColSum2 = ColSum<R, NMAT, 2, 2, SLOT0>;      // [U | V]' [x0 x1], x0, x1 in consecutive slots (sweep 2 of the fused step)
+// The same sums for ranks 33 .. 64, where [U | V] has more than 64 columns: one ColSum per operand (U' [x0 x1], then V' [x0 x1]),
+// stored as the columns [0, R) and [R, 2R) of the same partial layout.
+template <int R, int SLOT0>
+struct ColSumPair {
+  ColSum<R, 2, 1, 2, SLOT0, 0> u;
+  ColSum<R, 2, 1, 2, SLOT0, 1> v;
+  static constexpr unsigned kStoreVecMask = ColSum<R, 2, 1, 2, SLOT0, 0>::kStoreVecMask;
+  static constexpr bool kActive = true;
+  __device__ __forceinline__ void operator()(const float* lds) { u(lds); v(lds); }
+  __device__ __forceinline__ void block_store(double* red, double* part) {
+    u.block_store(red, part, 0, 2 * R);
+    v.block_store(red, part, R, 2 * R);
+  }
+};
 
 // IpUVtmatvec on up to four columns at once (psgd.py:540-544 with a matrix x): S = V' [x0 .. x3] in ONE sweep of V
 // (the sums on the matrix core) ...
@@ -987,7 +1002,7 @@ __global__ __launch_bounds__(kThreads) void k_update_s2(float* U, float* V, cons
     }
   };
   if constexpr (FUSE) {
-    ColSum2<R, 2, 1, 2> cs;
+    std::conditional_t<(2 * R <= 64), ColSum2<R, 2, 1, 2>, ColSumPair<R, 1>> cs;
     sweep_rows<R, 2, NV, (UPDATE_U ? 0 : 1), NT>(mats, vecs, UPDATE_U ? U : V, N, lds, body, cs);
     cs.block_store(reinterpret_cast<double*>(smem), part_pq);
     __syncthreads();
@@ -1078,7 +1093,8 @@ struct UvdWideOps {
   int (*apply4_s1)(int nt, const float* V, const float* d, const float* const* x, long N, double* part, int grid, hipStream_t st);
   int (*apply4_s2)(int nt, const float* U, const float* d, const float* const* x, float* const* o, int ncols, long N, const float* coef, double* part, int grid, hipStream_t st);
   int (*apply4_s3)(int nt, const float* V, const float* d, float* const* o, int ncols, long N, const float* coef, int grid, hipStream_t st);
-  int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N, const float* coef, float* nabla, float* part_max, int grid, hipStream_t st);
+  int (*update_s2)(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, const float* g, long N, const float* coef, float* nabla, float* part_max, double* part_pq, int grid, hipStream_t st);
+  int (*final_sweep)(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out, long N, const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st);
 };
 const UvdWideOps* uvd_wide_ops_for_rank(int r);   // nullptr outside 33 .. 64
 

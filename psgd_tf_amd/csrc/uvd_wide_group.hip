@@ -42,18 +42,27 @@ struct WideLaunch {
                        hipStream_t st) {
     PSGD_LAUNCH((k_apply4_s3<R, true>), (k_apply4_s3<R, false>), V, d, o[0], o[1], o[2], o[3], ncols, N, coef);
   }
-  // sweep 2 of the update (psgd.py:569-584, :600-601 / :614-615), the kernel of the specialised ranks on 64-row tiles of U and V
-  static int update_s2(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, long N,
-                       const float* coef, float* nabla, float* part_max, int grid, hipStream_t st) {
-    const float* g = nullptr;
-    double* pq = nullptr;
+  // sweep 2 of the update (psgd.py:569-584, :600-601 / :614-615), the kernel of the specialised ranks on 64-row tiles of U and V;
+  // g / part_pq non-null: the fused form that also reduces [Unew | Vnew]' [d.*g, d.*g.*nablaD] (one ColSum per operand)
+  static int update_s2(int nt, int update_U, float* U, float* V, const float* d, const float* v, const float* h, const float* g, long N,
+                       const float* coef, float* nabla, float* part_max, double* part_pq, int grid, hipStream_t st) {
+    if (g) {
+      if (update_U)
+        PSGD_LAUNCH((k_update_s2<R, true, true, true>), (k_update_s2<R, true, false, true>), U, V, d, v, h, g, N, coef, nabla, part_max, part_pq);
+      PSGD_LAUNCH((k_update_s2<R, false, true, true>), (k_update_s2<R, false, false, true>), U, V, d, v, h, g, N, coef, nabla, part_max, part_pq);
+    }
     if (update_U)
-      PSGD_LAUNCH((k_update_s2<R, true, true, false>), (k_update_s2<R, true, false, false>), U, V, d, v, h, g, N, coef, nabla, part_max, pq);
-    PSGD_LAUNCH((k_update_s2<R, false, true, false>), (k_update_s2<R, false, false, false>), U, V, d, v, h, g, N, coef, nabla, part_max, pq);
+      PSGD_LAUNCH((k_update_s2<R, true, true, false>), (k_update_s2<R, true, false, false>), U, V, d, v, h, g, N, coef, nabla, part_max, part_pq);
+    PSGD_LAUNCH((k_update_s2<R, false, true, false>), (k_update_s2<R, false, false, false>), U, V, d, v, h, g, N, coef, nabla, part_max, part_pq);
+  }
+  // last sweep of the fused update -> apply (k_uvd_final)
+  static int final_sweep(int nt, const float* U, const float* V, float* d, const float* nabla, const float* g, float* out, long N,
+                         const float* coef, const float* maxbuf, float step, float tiny, int grid, hipStream_t st) {
+    PSGD_LAUNCH((k_uvd_final<R, true>), (k_uvd_final<R, false>), U, V, d, nabla, g, out, N, coef, maxbuf, step, tiny);
   }
   static const UvdWideOps* ops() {
     static const UvdWideOps o = {Cfg<R>::kTileRows, &colreduce4, &rowdot_axpy4, &rank2_update, &apply4_s1, &apply4_s2, &apply4_s3,
-                                 &update_s2};
+                                 &update_s2, &final_sweep};
     return &o;
   }
 };

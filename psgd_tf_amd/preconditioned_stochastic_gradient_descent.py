@@ -378,9 +378,8 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
         balance = _draw_branch(0.01, generator)
     if update_U is None:
         update_U = _draw_branch(0.5, generator)
-    if r > _lib.UVD_MAX_RANK:                      # no fusion on the wide-rank path: update, then apply
-        _wide.update(U, V, d, v, h, float(step), float(tiny), bool(balance), bool(update_U), uvd_workspace)
-        out = _wide.precond_grad(U, V, d, g, uvd_workspace)
+    if r > _lib.UVD_MAX_RANK:                      # ranks 33 .. 64: the fused sequence of uvd_wide.update_apply; above: update, then apply
+        out = _wide.update_apply(U, V, d, v, h, g, float(step), float(tiny), bool(balance), bool(update_U), uvd_workspace)
         state.writeback()
         return out
     out = torch.empty_like(g)

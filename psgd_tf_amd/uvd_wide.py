@@ -256,28 +256,60 @@ def ipuvt_matvec(U, V, x, workspace_fn, reduce=_no_reduce):
     return torch.stack(outs, 1).reshape(x.shape) if x.dim() == 2 else outs[0].reshape(x.shape)
 
 
+def _balance(U, V, reduce):
+    """psgd.py:562-567"""
+    mx = reduce(torch.stack([torch.max(torch.abs(U)), torch.max(torch.abs(V))]), "max")
+    rho = torch.sqrt(mx[0] / mx[1])
+    U.div_(rho)
+    V.mul_(rho)
+
+
+def _native_scratch(cx, fn_name):
+    n = int(getattr(cx.lib, fn_name)(cx.N, cx.r))
+    if n < 0:
+        _lib.check(n, fn_name)
+    key = (cx.dev.index, cx.st, cx.N, cx.r)
+    scr = _update_scratch.get(key)
+    if scr is None or scr.numel() < n:
+        scr = _update_scratch[key] = torch.empty(n, dtype=torch.uint8, device=cx.dev)
+        while len(_update_scratch) > 4:
+            _update_scratch.pop(next(iter(_update_scratch)))
+    return scr
+
+
+def update_apply(U, V, d, v, h, g, step, tiny, balance, update_U, workspace_fn, reduce=_no_reduce):
+    """update_precond_UVd_math_ followed by precond_grad_UVd_math on the updated state (psgd.py:732 -> :748) for r > 32.  Ranks 33 .. 64
+    on one GPU with a column-vector g: psgd_uvd_wide_update_apply_f32 (three reads of U and V); otherwise the two calls.
+    PSGD_WIDE_STEP=0: always the two calls (A/B runs)."""
+    dv = d.reshape(-1)
+    if (reduce is _no_reduce and os.environ.get("PSGD_WIDE_STEP") != "0" and not isinstance(g, (list, tuple)) and g.numel() == U.shape[0]
+            and _update_native_ok(U, V, dv)):
+        cx = _Ctx(U, workspace_fn, full=True)
+        if balance:
+            _balance(U, V, reduce)
+        vc, hc, gc = v.reshape(-1).contiguous(), h.reshape(-1).contiguous(), g.reshape(-1).contiguous()
+        out = torch.empty_like(gc)
+        scr = _native_scratch(cx, "psgd_uvd_wide_update_apply_scratch_bytes")
+        _lib.check(cx.lib.psgd_uvd_wide_update_apply_f32(U.data_ptr(), V.data_ptr(), dv.data_ptr(), vc.data_ptr(), hc.data_ptr(),
+                                                         gc.data_ptr(), out.data_ptr(), cx.N, cx.r, float(step), float(tiny),
+                                                         int(bool(update_U)), scr.data_ptr(), scr.numel(), cx.st),
+                   "psgd_uvd_wide_update_apply_f32")
+        return out.reshape(g.shape)
+    update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce)
+    return precond_grad(U, V, d, g, workspace_fn, reduce)
+
+
 def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce=_no_reduce):
     """psgd.py:554-617 for r > 32 (in place on U or V, and d)."""
     cx = _Ctx(U, workspace_fn, full=_full_ok(U, V))
     r, c, rc, dev = cx.r, cx.c, cx.rc, cx.dev
     if balance:                                                                # :562-567
-        mx = reduce(torch.stack([torch.max(torch.abs(U)), torch.max(torch.abs(V))]), "max")
-        rho = torch.sqrt(mx[0] / mx[1])
-        U.div_(rho)
-        V.mul_(rho)
+        _balance(U, V, reduce)
     dv, vv, hv = d.reshape(-1), v.reshape(-1), h.reshape(-1)
     if reduce is _no_reduce and _update_native_ok(U, V, dv):
         # ranks 33 .. 64 on one GPU: the four launches of psgd_uvd_wide_update_f32 (Gram, r x r algebra, sweep 2, d) -- no host step
         vc, hc = vv.contiguous(), hv.contiguous()
-        n = int(cx.lib.psgd_uvd_wide_update_scratch_bytes(cx.N, cx.r))
-        if n < 0:
-            _lib.check(n, "psgd_uvd_wide_update_scratch_bytes")
-        key = (cx.dev.index, cx.st, cx.N, cx.r)
-        scr = _update_scratch.get(key)
-        if scr is None or scr.numel() < n:
-            scr = _update_scratch[key] = torch.empty(n, dtype=torch.uint8, device=cx.dev)
-            while len(_update_scratch) > 4:
-                _update_scratch.pop(next(iter(_update_scratch)))
+        scr = _native_scratch(cx, "psgd_uvd_wide_update_scratch_bytes")
         _lib.check(cx.lib.psgd_uvd_wide_update_f32(U.data_ptr(), V.data_ptr(), dv.data_ptr(), vc.data_ptr(), hc.data_ptr(), cx.N, cx.r,
                                                    float(step), float(tiny), int(bool(update_U)), scr.data_ptr(), scr.numel(), cx.st),
                    "psgd_uvd_wide_update_f32")

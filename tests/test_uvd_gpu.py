@@ -507,3 +507,30 @@ def test_every_rank_with_a_partial_last_tile(psgd, r):
                 assert rel_err(t[k].cpu().numpy() - p[k], q[k] - p[k].astype(np.float64)) < INCR_TOL or k == ("V" if upd else "U"), (N, upd, k)
             out = psgd.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
             assert rel_err(out.cpu().numpy(), orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])) < 2 * APPLY_TOL, (N, upd)
+
+
+@pytest.mark.parametrize("N,r", [(5000, 48), (100003, 40), (2049, 64), (70001, 33), (31, 57), (257, 41)])
+@pytest.mark.parametrize("update_U", [True, False])
+@pytest.mark.parametrize("balance", [False, True])
+def test_wide_fused_step_matches_oracle_and_the_two_calls(psgd, monkeypatch, N, r, update_U, balance):
+    """psgd_uvd_wide_update_apply_f32 (ranks 33 .. 64: sweep 2 also reduces the sums of the apply, three reads of U and V) against the
+    oracle's update followed by its apply, and against the two separate calls (PSGD_WIDE_STEP=0)."""
+    p = make_uvd_problem(N, r, seed=N + 3 * r, uv_gain=2.0 * r ** 0.5, d_spread=0.3)
+    q = _f64(p)
+    orc.update_precond_UVd_math_(q["U"], q["V"], q["d"], q["v"], q["h"], 0.01, TINY32, balance=balance, update_U=update_U)
+    ref = orc.precond_grad_UVd_math(q["U"], q["V"], q["d"], q["g"])
+    got = {}
+    for route in ("fused", "two_calls"):
+        monkeypatch.delenv("PSGD_WIDE_STEP", raising=False)
+        if route == "two_calls":
+            monkeypatch.setenv("PSGD_WIDE_STEP", "0")
+        t = _to_dev(p)
+        out = psgd.update_precond_UVd_math_and_precond_grad(t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY32,
+                                                            balance=balance, update_U=update_U)
+        assert out.shape == t["g"].shape
+        assert rel_err(out.cpu().numpy(), ref) < 2 * APPLY_TOL, route
+        for k in ("U", "V", "d"):
+            assert rel_err(t[k].cpu().numpy(), q[k]) < 2 * STATE_TOL, (route, k)
+        got[route] = [out.cpu().numpy()] + [t[k].cpu().numpy() for k in ("U", "V", "d")]
+    for a, b in zip(got["fused"], got["two_calls"]):
+        assert rel_err(a, b) < STATE_TOL
