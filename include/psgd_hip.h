@@ -43,7 +43,7 @@ extern "C" {
  * psgd_kron_dd_update_bf16 gained the stream-K partial tiles (up to 128 MiB more for M, N multiples of 256) and padded W1 / W2
  * row strides: always size it with psgd_kron_dd_update_workspace_bytes_bf16);
  * 6 = round 5 (psgd_uvd_apply_cols_f32 added: precond_grad_UVd_math on a matrix g; psgd_uvd_gram_wide_f32 and the psgd_uvd_wide_*
- * entry points of ranks 33 .. 64 added; the sparse-LU entry points take ranks up to PSGD_SPLU_MAX_RANK = 64 and their workspace
+ * entry points of ranks 33 .. 64 added (building blocks, update, fused update -> apply); the sparse-LU entry points take ranks up to PSGD_SPLU_MAX_RANK = 64 and their workspace
  * regions have that capacity -- offsets from psgd_splu_ws_region changed; the fused strip kernels of small Kron layers and their
  * tuning key 21 removed: Kron workspaces of small layers shrink back by that scratch).
  * psgd_tf_amd/_lib.py refuses a library whose psgd_abi_version() differs from the one it was written for. */
