@@ -454,11 +454,17 @@ def wide_rank_bench(dev, psgd, N=20_000_000, iters=6):
             flip[0] ^= 1
             psgd.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=bool(flip[0]))
         tu = timeit(upd)
-        ra, ru = 4 * (4 * r + 5) * N / ta / 1e6, 4 * (5 * r + 10) * N / tu / 1e6
+
+        def fused():                                   # the UVd.step pattern: update, then apply on the updated state, one call
+            flip[0] ^= 1
+            return psgd.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, gr, STEP, TINY, balance=False, update_U=bool(flip[0]))
+        ts = timeit(fused)
+        ra, ru, rs = 4 * (4 * r + 5) * N / ta / 1e6, 4 * (5 * r + 10) * N / tu / 1e6, 4 * (9 * r + 15) * N / ts / 1e6
         if r == 32:
-            base["uvd"] = (ra, ru)
-        out["uvd_r%d" % r] = {"apply_ms": ta, "update_ms": tu, "apply_GBs": ra, "update_GBs": ru,
-                              "apply_x_spec": ra / base["uvd"][0], "update_x_spec": ru / base["uvd"][1]}
+            base["uvd"] = (ra, ru, rs)
+        out["uvd_r%d" % r] = {"apply_ms": ta, "update_ms": tu, "step_ms": ts, "apply_GBs": ra, "update_GBs": ru, "step_GBs": rs,
+                              "apply_x_spec": ra / base["uvd"][0], "update_x_spec": ru / base["uvd"][1],
+                              "step_x_spec": rs / base["uvd"][2]}
         del U, V, d, gr, v, h
         torch.cuda.empty_cache()
     for r in (32, 40):
@@ -619,6 +625,7 @@ def compact_line(res, limit=7800):
     if wr:
         hoist.update(uvd_r64_apply_ms=wr["uvd_r64"]["apply_ms"], uvd_r64_update_ms=wr["uvd_r64"]["update_ms"],
                      uvd_r64_apply_x_spec=wr["uvd_r64"]["apply_x_spec"], uvd_r64_update_x_spec=wr["uvd_r64"]["update_x_spec"],
+                     uvd_r64_step_ms=wr["uvd_r64"]["step_ms"], uvd_r64_step_x_spec=wr["uvd_r64"]["step_x_spec"],
                      splu_r40_apply_x_spec=wr["splu_r40"]["apply_x_spec"], splu_r40_update_x_spec=wr["splu_r40"]["update_x_spec"])
     rf.update({k: float("%.6g" % v) for k, v in hoist.items() if v is not None})
     # size guard: drop the least important sub-records first (they stay in the BENCH_DETAIL line on stderr)
