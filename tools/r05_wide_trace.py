@@ -1,4 +1,4 @@
-"""One wide-rank UVd update / apply in a loop for rocprofv3 --kernel-trace --stats:  python tools/r05_wide_trace.py N r [update|apply] [reps]"""
+"""One wide-rank UVd update / apply / fused step in a loop for rocprofv3 --kernel-trace --stats:  python tools/r05_wide_trace.py N r [update|apply|step] [reps]"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -16,6 +16,8 @@ h = v * 1.5
 for i in range(reps):
     if what == "update":
         psgd.update_precond_UVd_math_(U, V, d, v, h, 0.01, 1e-38, balance=False, update_U=(i % 2 == 0))
+    elif what == "step":
+        psgd.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, gr, 0.01, 1e-38, balance=False, update_U=(i % 2 == 0))
     else:
         psgd.precond_grad_UVd_math(U, V, d, gr)
 torch.cuda.synchronize()
