@@ -835,7 +835,21 @@ struct ColSumPair {
   ColSum<R, 2, 1, 2, SLOT0, 1> v;
   static constexpr unsigned kStoreVecMask = ColSum<R, 2, 1, 2, SLOT0, 0>::kStoreVecMask;
   static constexpr bool kActive = true;
-  __device__ __forceinline__ void operator()(const float* lds) { u(lds); v(lds); }
+  // one pass over the tile's rows for both operands: the two per-row scalars are read once, four accumulator chains are in flight
+  __device__ __forceinline__ void operator()(const float* lds) {
+    using C = Cfg<R>;
+#pragma unroll 8
+    for (int row = 0; row < C::kTileRows; row += 2) {
+      const float b0 = lds[u.boff + row] * u.bmask, b1 = lds[u.boff + row + 1] * u.bmask;
+      const float a0 = lds[u.aoff + row * R] * u.amask, a1 = lds[u.aoff + (row + 1) * R] * u.amask;
+      const float c0 = lds[v.aoff + row * R] * v.amask, c1 = lds[v.aoff + (row + 1) * R] * v.amask;
+      u.acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, u.acc0, 0, 0, 0);
+      v.acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(c0, b0, v.acc0, 0, 0, 0);
+      u.acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, u.acc1, 0, 0, 0);
+      v.acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(c1, b1, v.acc1, 0, 0, 0);
+    }
+    if (++u.since == ColSum<R, 2, 1, 2, SLOT0, 0>::kFlushTiles) { u.flush(); v.flush(); }
+  }
   __device__ __forceinline__ void block_store(double* red, double* part) {
     u.block_store(red, part, 0, 2 * R);
     v.block_store(red, part, R, 2 * R);
