@@ -452,7 +452,7 @@ class UVd:
     def __init__(self, params_with_grad, rank_of_modification: int = 10, preconditioner_init_scale=1.0,
                  lr_params=0.01, lr_preconditioner=0.01,
                  grad_clip_max_norm=None, preconditioner_update_probability=1.0,
-                 exact_hessian_vector_product: bool = True, generator=None):
+                 exact_hessian_vector_product: bool = True, generator=None, state_dtype=None):
         params = _flatten_params(params_with_grad)
         self._params_with_grad = [p for p in params if p.requires_grad]                      # :670
         p0 = self._params_with_grad[0]
@@ -463,7 +463,17 @@ class UVd:
         # stay fp32 here (mixed precision: the HIP kernels compute in fp32; v, Hv and the gradient are widened on the
         # way in, the preconditioned gradient is narrowed on the way out).  _tiny and the finite-difference scale follow
         # the parameter dtype as in the reference (:682-683).
+        # state_dtype (extension; default None = fp32): "param" or a torch dtype STORES U, V, d in that type, as the reference does
+        # for half-precision parameters (psgd.py:688-690) -- every step widens them, runs the fp32 kernels and rounds the updated
+        # state back, so the memory held between steps and the rounding of the state once per step are the reference's; its
+        # arithmetic (every TF op in the parameters' type) is not reproduced.
         self._state_dtype = torch.float32
+        if state_dtype is None:
+            self._store_dtype = torch.float32
+        else:
+            self._store_dtype = self._dtype if state_dtype == "param" else state_dtype
+            if self._store_dtype not in (torch.float32, torch.float16, torch.bfloat16):
+                raise TypeError("UVd: state_dtype must be None, 'param', float32, float16 or bfloat16, got %r" % (state_dtype,))
         self._device = p0.device
         r = int(rank_of_modification)
         if r < 1:
@@ -483,6 +493,20 @@ class UVd:
         self._U = torch.randn(num_params, r, dtype=sd, device=self._device) * uv_scale       # :688
         self._V = torch.randn(num_params, r, dtype=sd, device=self._device) * uv_scale       # :689
         self._d = torch.ones(num_params, 1, dtype=sd, device=self._device) * preconditioner_init_scale  # :690
+        if self._store_dtype != sd:
+            self._U, self._V, self._d = (x.to(self._store_dtype) for x in (self._U, self._V, self._d))
+
+    def _state_fp32(self):
+        """the state the kernels work on: the stored tensors themselves, or fp32 copies of a half-precision state"""
+        if self._store_dtype == torch.float32:
+            return self._U, self._V, self._d
+        return self._U.float(), self._V.float(), self._d.float()
+
+    def _state_store(self, U, V, d):
+        if self._store_dtype != torch.float32:
+            self._U.copy_(U)
+            self._V.copy_(V)
+            self._d.copy_(d)
 
     def _loss_of(self, closure_returns):
         return closure_returns if isinstance(closure_returns, torch.Tensor) else closure_returns[0]
@@ -520,16 +544,18 @@ class UVd:
                 h = h / self._delta_param_scale
             grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0).to(self._state_dtype)    # :747
             # :732-733 then :748 as one fused call (same results, three sweeps instead of six)
+            U, V, d = self._state_fp32()
             pre_grad = update_precond_UVd_math_and_precond_grad(
-                self._U, self._V, self._d, v[:, None].contiguous(), h[:, None].contiguous(),
+                U, V, d, v[:, None].contiguous(), h[:, None].contiguous(),
                 grad[:, None].contiguous(), step=float(self.lr_preconditioner), tiny=self._tiny,
                 generator=self._generator)
+            self._state_store(U, V, d)
         else:                                                                                 # :737-744
             with torch.enable_grad():
                 closure_returns = closure()
                 grads = torch.autograd.grad(self._loss_of(closure_returns), params)
             grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0).to(self._state_dtype)    # :747
-            pre_grad = precond_grad_UVd_math(self._U, self._V, self._d, grad[:, None].contiguous())   # :748
+            pre_grad = precond_grad_UVd_math(*self._state_fp32(), grad[:, None].contiguous())         # :748
         max_norm = float(self.grad_clip_max_norm)
         if math.isinf(max_norm):                                                              # :750-751
             lr = float(self.lr_params)

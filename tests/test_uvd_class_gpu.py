@@ -175,3 +175,37 @@ def _record(fn, seen, U, V, d, v, h, g, **kw):
     out = fn(U, V, d, v, h, g, **kw)
     seen.update(v=v.clone(), h=h.clone(), g=g.clone(), out=out.clone())
     return out
+
+
+@pytest.mark.parametrize("pdtype", [torch.bfloat16, torch.float16])
+def test_state_in_the_parameters_dtype(hip_lib, pdtype):
+    """state_dtype="param" (extension): U, V, d are STORED in the parameters' type as in the reference (psgd.py:688-690), widened
+    for the fp32 kernels and rounded back once per step; the default keeps an fp32 state.  Runs, stays finite, the loss goes down,
+    and the stored state equals the rounded fp32 state of a twin optimizer after one step from the same seed."""
+    import preconditioned_stochastic_gradient_descent as psgd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    A = torch.randn(200, 200, device=dev) * 0.1
+    H = (A @ A.t() + 0.3 * torch.eye(200, device=dev))
+
+    def make(state_dtype):
+        torch.manual_seed(3)
+        w = (torch.randn(200, 1, device=dev) * 0.5).to(pdtype).requires_grad_(True)
+        opt = psgd.UVd([w], rank_of_modification=10, lr_params=0.05, lr_preconditioner=0.05, generator=torch.Generator().manual_seed(2),
+                       state_dtype=state_dtype)
+        return w, opt, (lambda: 0.5 * (w.float().t() @ H @ w.float()).sum())
+    w, opt, closure = make("param")
+    assert opt._U.dtype == pdtype and opt._V.dtype == pdtype and opt._d.dtype == pdtype
+    w2, opt2, closure2 = make(None)
+    assert opt2._U.dtype == torch.float32
+    opt2._U.copy_(opt._U.float()); opt2._V.copy_(opt._V.float()); opt2._d.copy_(opt._d.float())   # the same (rounded) starting state
+    torch.manual_seed(5)
+    l0 = float(opt.step(closure).detach())
+    torch.manual_seed(5)
+    opt2.step(closure2)
+    assert torch.equal(opt._U, opt2._U.to(pdtype)) and torch.equal(opt._d, opt2._d.to(pdtype))
+    for _ in range(60):
+        l = float(opt.step(closure).detach())
+    assert torch.isfinite(opt._U.float()).all() and torch.isfinite(w.float()).all() and l < 0.5 * l0
+    with pytest.raises(TypeError):
+        psgd.UVd([w], state_dtype=torch.float64)
