@@ -1,6 +1,7 @@
-"""Sparse-LU preconditioner of rank r > 32 (the reference has no rank limit, psgd.py:396-524).
+"""Sparse-LU preconditioner of rank r > 64 (the reference has no rank limit, psgd.py:396-524); ranks 33 .. 64 only under
+PSGD_SPLU_CHUNKS=1 (A/B runs): since round 5 the native tail kernels cover r = 1..64.
 
-The tail-row kernels of csrc/psgd_splu.hip are instantiated for r = 1..32.  A wider preconditioner runs on column chunks
+This route builds on the rank <= 32 building blocks of the wide UVd path.  A wider preconditioner runs on column chunks
 of its two tall blocks -- L2 [N - r, r] and U2' [N - r, r], every chunk an [N - r, rc] matrix with rc <= 32: column VIEWS of L2
 when the rank splits evenly (round 4: the `*_ld` entry points), contiguous copies otherwise (the last one zero-padded) and for
 U2' (its rows lie along the columns of U12: one transpose per chunk) -- through the same three building blocks of the C ABI as the

@@ -1,6 +1,15 @@
 """UVd preconditioner of rank r > 32 (the reference has no rank limit, psgd.py:663).
 
-The rank-templated sweep kernels exist for r = 1..32.  A wider preconditioner is handled on column chunks:
+Round 5 -- ranks 33 .. 64 on one GPU, contiguous 16-byte aligned U and V: whole-matrix entry points of the C ABI, no chunks --
+    precond_grad          psgd_uvd_wide_apply_cols_f32        (three sweeps per four columns of g)
+    update                psgd_uvd_wide_update_f32            (one-sweep Gram, r x r block, sweep 2, d: four launches)
+    update + precond_grad psgd_uvd_wide_update_apply_f32      (the UVd.step pattern: U and V read three times)
+row-sharded runs of those ranks use the whole-matrix building blocks (psgd_uvd_gram_wide_f32, psgd_uvd_wide_colsums_f32,
+psgd_uvd_wide_axpy_cols_f32, psgd_uvd_wide_rank2_update_f32) with one exchange per stage.  Everything else -- ranks above 64,
+strided views, unaligned matrices, the A/B switches PSGD_WIDE_FULL / PSGD_WIDE_UPDATE / PSGD_WIDE_STEP = 0 -- takes the route of
+rounds 3-4 described below.
+
+The rank-templated sweep kernels of that route exist for r = 1..32.  A wider preconditioner is handled on column chunks:
 U = [U_1 | ... | U_c], V = [V_1 | ... | V_c], every chunk an [N, rc] matrix, rc <= 32.  When r splits evenly (r = c rc with
 c = ceil(r / 32) or one more: 40, 48, 50, 64, 96, 100, 128 ...) the chunks are column VIEWS of U and V -- row stride r, the
 `*_ld` entry points of the C ABI (round 4) -- and nothing is copied; otherwise contiguous copies, the last one padded with zero
