@@ -490,6 +490,9 @@ __device__ inline double wave_sum(double v) {
   return __shfl(v, 0, 64);
 }
 
+template <int RG>
+__device__ __forceinline__ double lu_solve_rows(double (&a)[RG + 1], int r, int lane);      // (defined with the register-row kernels below)
+
 // LDS of the block-cooperative r x r algebra, r <= CAP.
 template <int CAP>
 struct CoefBlockLds {
@@ -505,7 +508,10 @@ struct CoefBlockLds {
 // One 256-thread block.  Reads the reduced Gram of W = [U | V | t | w] -- DENSE = false: the MFMA block layout of
 // k_update_gram; DENSE = true: row-major [2r + 2][2r + 2] (k_gram_wide_finish, ranks 33 .. 64) -- and produces the
 // coefficient block of UpdCoef.  fp64 throughout.
-template <int CAP, bool DENSE>
+// ROWLU: the two solves by ONE wave with a row of the matrix per lane in registers (lu_solve_rows: no barrier, no LDS traffic in the
+// elimination) instead of the block-cooperative elimination in LDS -- at r = 64 the latter is 77 us per solve, two barriers and a chain
+// of LDS latencies per step.
+template <int CAP, bool DENSE, bool ROWLU = false, int RG = CAP>       // RG: columns a lane's register row holds (r <= RG <= CAP)
 __device__ void coef_block_ref(const double* __restrict__ gram, int r, float step, float tiny, int update_U,
                                float* __restrict__ coef, double* __restrict__ c64, CoefBlockLds<CAP>& L) {
   auto& A = L.A; auto& B = L.B; auto& Cm = L.Cm; auto& Mx = L.Mx;
@@ -544,6 +550,30 @@ __device__ void coef_block_ref(const double* __restrict__ gram, int r, float ste
     s2[tid] = a;
     cs1[tid] = c;
   }
+  if constexpr (ROWLU) {
+    __syncthreads();
+    if (tid >= 64) return;
+    const bool actl = tid < r;
+    double a[RG + 1];
+    // x1 = solve(K', U'w): lane i holds row i of K' = column i of K = I + V'U
+#pragma unroll
+    for (int j = 0; j < RG; ++j) a[j] = (actl && j < r) ? Cm[j][tid] + ((j == tid) ? 1.0 : 0.0) : 0.0;
+    a[RG] = actl ? uw[tid] : 0.0;
+    const double x1v = lu_solve_rows<RG>(a, r, tid);
+    if (actl) x1[tid] = x1v;
+    __builtin_amdgcn_wave_barrier();
+    // p2 = V'w - (V'V) x1 ; x2 = solve(K, p2)
+    double pv = actl ? vw[tid] : 0.0;
+    if (actl)
+      for (int k = 0; k < r; ++k) pv -= B[tid][k] * x1[k];
+    if (actl) p2[tid] = pv;
+#pragma unroll
+    for (int j = 0; j < RG; ++j) a[j] = (actl && j < r) ? Cm[tid][j] + ((j == tid) ? 1.0 : 0.0) : 0.0;
+    a[RG] = pv;
+    const double x2v = lu_solve_rows<RG>(a, r, tid);
+    if (actl) x2[tid] = x2v;
+    __builtin_amdgcn_wave_barrier();
+  } else {
   // x1 = solve(K', U'w), K = I + V'U            (psgd.py:575-577, adjoint=True)
   for (int idx = tid; idx < r * r; idx += kThreads) {
     const int i = idx / r, j = idx % r;
@@ -567,6 +597,7 @@ __device__ void coef_block_ref(const double* __restrict__ gram, int r, float ste
   __syncthreads();
   lu_solve_block<CAP>(Mx, r, x2);
   __syncthreads();
+  }
   if (tid >= 64) return;                                  // the rest is one wave of r-vector algebra
 
   const int lane = tid;
@@ -653,10 +684,33 @@ __global__ __launch_bounds__(kThreads) void k_update_coef(const double* __restri
 }
 
 // ranks 33 .. 64 (psgd_uvd_wide_update_f32): 137 KiB of LDS, requested at the launch
+template <int RG>
 __global__ __launch_bounds__(kThreads) void k_wide_coef(const double* __restrict__ gram, int r, float step, float tiny,
                                                         int update_U, float* __restrict__ coef, double* __restrict__ c64) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wide_coef_lds[];
-  coef_block_ref<2 * MR, true>(gram, r, step, tiny, update_U, coef, c64, *reinterpret_cast<CoefBlockLds<2 * MR>*>(wide_coef_lds));
+  coef_block_ref<2 * MR, true, true, RG>(gram, r, step, tiny, update_U, coef, c64,
+                                         *reinterpret_cast<CoefBlockLds<2 * MR>*>(wide_coef_lds));
+}
+
+template <int RG>
+static int wide_coef_launch_rg(hipStream_t st, const double* G, int r, float step, float tiny, int update_U, float* coef, double* c64) {
+  static bool attr_done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  const int lds = (int)sizeof(CoefBlockLds<2 * MR>);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_coef<RG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return 1;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(k_wide_coef<RG>, dim3(1), dim3(kThreads), lds, st, G, r, step, tiny, update_U, coef, c64);
+  return (int)hipGetLastError();
+}
+static int wide_coef_launch(hipStream_t st, const double* G, int r, float step, float tiny, int update_U, float* coef, double* c64) {
+  if (r <= 40) return wide_coef_launch_rg<40>(st, G, r, step, tiny, update_U, coef, c64);      // (the register rows of the two solves:
+  if (r <= 48) return wide_coef_launch_rg<48>(st, G, r, step, tiny, update_U, coef, c64);      //  work grows with RG^2)
+  if (r <= 56) return wide_coef_launch_rg<56>(st, G, r, step, tiny, update_U, coef, c64);
+  return wide_coef_launch_rg<64>(st, G, r, step, tiny, update_U, coef, c64);
 }
 
 // ---- the same r x r algebra, latency-oriented (what the entry points launch; k_update_coef above stays as the
@@ -1426,20 +1480,6 @@ static int64_t wide_step_layout(int64_t N, int r, char* base, WideStep* w) {
 int64_t psgd_uvd_wide_update_apply_scratch_bytes(int64_t N, int r) {
   if (N <= 0 || r <= PSGD_UVD_MAX_RANK || r > 2 * PSGD_UVD_MAX_RANK) return PSGD_ERR_RANK;
   return wide_step_layout(N, r, nullptr, nullptr);
-}
-
-static int wide_coef_launch(hipStream_t st, const double* G, int r, float step, float tiny, int update_U, float* coef, double* c64) {
-  static bool attr_done[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 1;
-  const int lds = (int)sizeof(CoefBlockLds<2 * MR>);
-  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_coef), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return 1;
-    if (dev >= 0 && dev < 64) attr_done[dev] = true;
-  }
-  hipLaunchKernelGGL(k_wide_coef, dim3(1), dim3(kThreads), lds, st, G, r, step, tiny, update_U, coef, c64);
-  return (int)hipGetLastError();
 }
 
 static int wide_s2_grid(const UvdWideOps* ops, int64_t N) {       // a tile of U and one of V per wave: one workgroup per CU
