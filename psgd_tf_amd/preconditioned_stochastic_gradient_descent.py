@@ -418,6 +418,11 @@ class _Hyper:
         return "_Hyper(%r)" % (self.value,)
 
 
+def _randn_like(p):
+    """The draw of psgd.py:713 / :721 (one place, so that a test can supply the global vector's slices)."""
+    return torch.randn_like(p)
+
+
 def uvd_param_index(params):
     """psgd.py:684-686: sizes and cumulative sizes of the parameters, in list order."""
     sizes = [int(p.numel()) for p in params]
@@ -452,7 +457,15 @@ class UVd:
     def __init__(self, params_with_grad, rank_of_modification: int = 10, preconditioner_init_scale=1.0,
                  lr_params=0.01, lr_preconditioner=0.01,
                  grad_clip_max_norm=None, preconditioner_update_probability=1.0,
-                 exact_hessian_vector_product: bool = True, generator=None, state_dtype=None):
+                 exact_hessian_vector_product: bool = True, generator=None, state_dtype=None, group=None,
+                 stage_backend=None):
+        # group (extension): a torch.distributed process group (dist.group.WORLD for the default one) makes this a
+        # ROW-SHARDED optimizer: `params_with_grad` are THIS rank's parameters, the global flat vector of psgd.py:729-730 is the
+        # concatenation of the ranks' vectors in rank order, and U, V, d hold this rank's rows only.  A step then costs three
+        # collectives: the two exchanges of sharded.update_precond_UVd_math_and_precond_grad (r-dimensional sums, never N-sized
+        # data) and one scalar all-reduce for the clip norm of :753 (none without clipping); the coins of :703, :562, :588 come
+        # from one generator whose state rank 0 broadcasts once.  The closure returns this rank's loss; its gradient and
+        # Hessian-vector product with respect to this rank's parameters are what a model-parallel closure computes.
         params = _flatten_params(params_with_grad)
         self._params_with_grad = [p for p in params if p.requires_grad]                      # :670
         p0 = self._params_with_grad[0]
@@ -487,8 +500,14 @@ class UVd:
         self._delta_param_scale = torch.finfo(self._dtype).eps ** 0.5                        # :683
         self._param_sizes, self._param_cumsizes = uvd_param_index(self._params_with_grad)    # :684-685
         num_params = self._param_cumsizes[-1]                                                # :686
-        uv_scale = (1.0 / (num_params * r)) ** 0.5                                           # :687
         self._generator = generator
+        self._group, self._stage_backend, self._num_params_global = group, stage_backend, num_params
+        if group is not None:
+            from . import sharded as _sharded
+            self._sharded = _sharded
+            self._num_params_global = _sharded.global_rows(num_params, self._device, group)  # :686 over all ranks (set-up time)
+            self._coins = _sharded.branch_rng_for(generator, group, self._device)
+        uv_scale = (1.0 / (self._num_params_global * r)) ** 0.5                              # :687 (the GLOBAL N)
         sd = self._state_dtype
         self._U = torch.randn(num_params, r, dtype=sd, device=self._device) * uv_scale       # :688
         self._V = torch.randn(num_params, r, dtype=sd, device=self._device) * uv_scale       # :689
@@ -514,7 +533,10 @@ class UVd:
     def step(self, closure):
         """psgd.py:692-764."""
         params = self._params_with_grad
-        update_Q = _draw_branch(float(self.preconditioner_update_probability), self._generator)   # :703
+        if self._group is None:
+            update_Q = _draw_branch(float(self.preconditioner_update_probability), self._generator)   # :703
+        else:
+            update_Q = self._coins.draw(float(self.preconditioner_update_probability))       # the same coin on every rank
         exact = bool(self.exact_hessian_vector_product)
         vs = None
         if update_Q:
@@ -523,14 +545,14 @@ class UVd:
                     closure_returns = closure()
                     loss = self._loss_of(closure_returns)
                     grads = torch.autograd.grad(loss, params, create_graph=True)
-                    vs = [torch.randn_like(p) for p in params]
+                    vs = [_randn_like(p) for p in params]
                     Hvs = torch.autograd.grad(grads, params, vs)
                 grads = [g.detach() for g in grads]
             else:                                                                             # :715-727
                 with torch.enable_grad():
                     closure_returns = closure()
                     grads = torch.autograd.grad(self._loss_of(closure_returns), params)
-                vs = [torch.randn_like(p) * self._delta_param_scale for p in params]
+                vs = [_randn_like(p) * self._delta_param_scale for p in params]
                 with torch.no_grad():
                     for p, v in zip(params, vs):
                         p.add_(v)
@@ -545,22 +567,35 @@ class UVd:
             grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0).to(self._state_dtype)    # :747
             # :732-733 then :748 as one fused call (same results, three sweeps instead of six)
             U, V, d = self._state_fp32()
-            pre_grad = update_precond_UVd_math_and_precond_grad(
-                U, V, d, v[:, None].contiguous(), h[:, None].contiguous(),
-                grad[:, None].contiguous(), step=float(self.lr_preconditioner), tiny=self._tiny,
-                generator=self._generator)
+            if self._group is None:
+                pre_grad = update_precond_UVd_math_and_precond_grad(
+                    U, V, d, v[:, None].contiguous(), h[:, None].contiguous(),
+                    grad[:, None].contiguous(), step=float(self.lr_preconditioner), tiny=self._tiny,
+                    generator=self._generator)
+            else:                                  # this rank's rows; 2 exchanges; :562, :588 from the synchronised generator
+                pre_grad = self._sharded.update_precond_UVd_math_and_precond_grad(
+                    U, V, d, v[:, None].contiguous(), h[:, None].contiguous(),
+                    grad[:, None].contiguous(), float(self.lr_preconditioner), self._tiny,
+                    generator=self._generator, group=self._group, backend=self._stage_backend)
             self._state_store(U, V, d)
         else:                                                                                 # :737-744
             with torch.enable_grad():
                 closure_returns = closure()
                 grads = torch.autograd.grad(self._loss_of(closure_returns), params)
             grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0).to(self._state_dtype)    # :747
-            pre_grad = precond_grad_UVd_math(*self._state_fp32(), grad[:, None].contiguous())         # :748
+            if self._group is None:
+                pre_grad = precond_grad_UVd_math(*self._state_fp32(), grad[:, None].contiguous())     # :748
+            else:
+                pre_grad = self._sharded.precond_grad_UVd_math(*self._state_fp32(), grad[:, None].contiguous(),
+                                                               group=self._group, backend=self._stage_backend)
         max_norm = float(self.grad_clip_max_norm)
         if math.isinf(max_norm):                                                              # :750-751
             lr = float(self.lr_params)
         else:                                                                                 # :753-754
-            grad_norm = torch.sqrt(torch.sum(pre_grad * pre_grad)) + self._tiny
+            if self._group is None:
+                grad_norm = torch.sqrt(torch.sum(pre_grad * pre_grad)) + self._tiny
+            else:                                  # the norm of the GLOBAL vector: one scalar all-reduce, no host read
+                grad_norm = self._sharded.global_norm(pre_grad, self._group) + self._tiny
             lr = float(self.lr_params) * torch.clamp(max_norm / grad_norm, max=1.0)
         with torch.no_grad():                                                                 # :757-762
             undo = (not exact) and update_Q

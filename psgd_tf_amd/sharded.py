@@ -170,6 +170,28 @@ def shard_rows(n_global, rank, world):
     return lo, hi
 
 
+def _host_collectives(group):
+    """gloo groups reduce host tensors (set-up-time scalars only; the per-step exchanges take device tensors on either backend)"""
+    return dist.get_backend(group) == "gloo"
+
+
+def global_rows(n_local, device, group=None):
+    """Rows of the global flat vector = the sum of the ranks' row counts (psgd.py:686 across the group).  Set-up time only:
+    one all-reduce and a host read."""
+    on_host = _host_collectives(group) or device is None or torch.device(device).type == "cpu"
+    t = torch.tensor([int(n_local)], dtype=torch.int64, device="cpu" if on_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
+def global_norm(x, group=None):
+    """2-norm of the global vector whose rows on this rank are x (the clip norm of psgd.py:753): the local sum of squares in fp64,
+    ONE scalar all-reduce (every rank receives the same bits), the root as a device tensor of x's dtype -- no host read."""
+    sq = torch.sum(x.to(torch.float64) ** 2).reshape(1)
+    dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=group)
+    return torch.sqrt(sq[0]).to(x.dtype)
+
+
 class BranchRng:
     """The two coin flips of update_precond_UVd_math_ (psgd.py:562 p = 0.01, :588 p = 0.5), agreed across ranks
     without a per-step exchange: the state of rank 0's generator is broadcast once, when the object is built (the only

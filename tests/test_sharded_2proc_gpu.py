@@ -136,3 +136,127 @@ def test_two_processes_real_kernels_real_collectives(hip_lib, N, r, transport):
     assert rel_err(np.concatenate([sh[0]["u3"], sh[1]["u3"]], 0), new[3]) < 1e-5
     assert rel_err(cat("pre1"), orc.precond_grad_splu(*new, [s64["g"]])[0]) < 1e-5
     assert np.array_equal(sh[0]["L12"][:rr], sh[1]["L12"][:rr]) and np.array_equal(sh[0]["U12"][:, :rr], sh[1]["U12"][:, :rr])
+
+
+# ----------------------------------------------------------------------------- class UVd, row-sharded: UVd(..., group=pg)
+CLS_SHAPES = [(300, 40), (5000,), (64, 64), (1000, 1), (1,)]     # rank 0 owns the first two tensors (17000 rows), rank 1 the rest (5097)
+CLS_SPLIT, CLS_R, CLS_STEPS = 2, 10, 5
+CLS_CLIP = [0.05, float("inf"), 0.05, 0.05, float("inf")]        # psgd.py:675-678 (mutable between steps)
+CLS_EXACT = [True, True, True, False, False]                     # :680; the finite-difference steps come last (see the test)
+CLS_PROB = [1.0, 1.0, 0.0, 1.0, 1.0]                             # :679; step 2 leaves the preconditioner alone (:737-744)
+
+
+def _cls_setup(dev):
+    g = torch.Generator().manual_seed(91)
+    params = [(torch.randn(s, generator=g) * 0.3).to(dev) for s in CLS_SHAPES]
+    n = sum(p.numel() for p in params)
+    sc = (1.0 / (n * CLS_R)) ** 0.5
+    U, V = (torch.randn(n, CLS_R, generator=g) * sc * 6).to(dev), (torch.randn(n, CLS_R, generator=g) * sc * 6).to(dev)
+    d = torch.exp(torch.randn(n, 1, generator=g) * 0.2).to(dev)
+    probes = [[torch.randn(s, generator=g).to(dev) for s in CLS_SHAPES] for _ in range(CLS_STEPS)]
+    return params, U, V, d, probes
+
+
+def _cls_loss(ps, salt):
+    """one rank's loss on ITS parameters; the global loss is the sum over the ranks (block-diagonal Hessian)"""
+    flat = torch.cat([p.reshape(-1) for p in ps])
+    w = torch.cos(torch.arange(flat.numel(), dtype=flat.dtype, device=flat.device) * 0.37 + salt)
+    return 0.5 * torch.sum((1.0 + w * w) * flat * flat) + 0.25 * torch.sum(flat ** 4) + 1e-3 * torch.sum(w * flat) ** 2
+
+
+def _cls_run(opt, prod, own_groups, probes_of, loss_fn, snap):
+    for it in range(CLS_STEPS):
+        queue = {id(p): q for ps, qs in zip(own_groups, probes_of(it)) for p, q in zip(ps, qs)}
+        prod._randn_like = lambda p: queue[id(p)].clone()
+        opt.grad_clip_max_norm.assign(CLS_CLIP[it])
+        opt.exact_hessian_vector_product.assign(CLS_EXACT[it])
+        opt.preconditioner_update_probability.assign(CLS_PROB[it])
+        opt.step(loss_fn)
+        snap(it)
+
+
+def _cls_worker(rank, port, outdir, two_devices):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dev = torch.device("cuda", rank if two_devices else 0)
+    torch.cuda.set_device(dev)
+    if two_devices:
+        dist.init_process_group("nccl", rank=rank, world_size=WORLD, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import preconditioned_stochastic_gradient_descent as psgd
+    from psgd_tf_amd import preconditioned_stochastic_gradient_descent as prod
+    params, U, V, d, probes = _cls_setup(dev)
+    mine = slice(0, CLS_SPLIT) if rank == 0 else slice(CLS_SPLIT, None)
+    own = [p.clone().requires_grad_(True) for p in params[mine]]
+    lo = sum(p.numel() for p in params[:mine.start or 0])
+    hi = lo + sum(p.numel() for p in own)
+    gen = torch.Generator().manual_seed(606 + 13 * rank)                 # different seeds: rank 0's coins must win
+    opt = psgd.UVd(own, rank_of_modification=CLS_R, lr_params=0.004, lr_preconditioner=0.05, generator=gen,
+                   group=dist.group.WORLD)
+    assert opt._num_params_global == sum(p.numel() for p in params) and tuple(opt._U.shape) == (hi - lo, CLS_R)
+    opt._U.copy_(U[lo:hi]); opt._V.copy_(V[lo:hi]); opt._d.copy_(d[lo:hi])
+    calls = {"all_gather_into_tensor": 0, "all_reduce": 0, "broadcast": 0}
+    for name in calls:
+        def wrap(fn, name=name):
+            def counted(*a, **k):
+                calls[name] += 1
+                return fn(*a, **k)
+            return counted
+        setattr(dist, name, wrap(getattr(dist, name)))
+    saved, counts, last = {}, [], dict(calls)
+
+    def snap(it):
+        nonlocal last
+        counts.append([calls[k] - last[k] for k in ("all_gather_into_tensor", "all_reduce", "broadcast")])
+        last = dict(calls)
+        saved["U%d" % it], saved["V%d" % it], saved["d%d" % it] = (x.cpu().numpy().copy() for x in (opt._U, opt._V, opt._d))
+        saved["p%d" % it] = torch.cat([p.detach().reshape(-1) for p in own]).cpu().numpy()
+    _cls_run(opt, prod, [own], lambda it: [probes[it][mine]], lambda: _cls_loss(own, float(rank)), snap)
+    np.savez(os.path.join(outdir, "cls%d.npz" % rank), counts=np.array(counts), **saved)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", [
+    "gloo-one-device",
+    pytest.param("rccl-two-devices", marks=pytest.mark.skipif(not _two_devices(), reason="needs two GPUs (rank k on cuda:k over RCCL)"))])
+def test_sharded_uvd_class_equals_the_unsharded_class(hip_lib, transport):
+    """UVd(..., group=pg) in two processes with the real stage kernels and real collectives against the unsharded class UVd on the
+    concatenated parameters (psgd.py:692-764): clip on and off, a step that leaves the preconditioner alone, exact and
+    finite-difference Hv.  1e-6 through the exact-Hv steps.  The finite-difference steps (:717-727) come last and get 1e-4: h is a
+    difference of two fp32 gradients divided by 2^-11.5, so the last-bit differences between the two runs' states (their
+    reductions are partitioned differently) come back multiplied by ~3e3 in h -- in ANY two runs that are not bit-identical."""
+    import torch.multiprocessing as mp
+    import preconditioned_stochastic_gradient_descent as psgd
+    from psgd_tf_amd import preconditioned_stochastic_gradient_descent as prod
+    outdir = tempfile.mkdtemp()
+    port = 29300 + os.getpid() % 300
+    two = transport == "rccl-two-devices"
+    mp.start_processes(_cls_worker, args=(port, outdir, two), nprocs=WORLD, join=True, start_method="spawn")
+    sh = [np.load(os.path.join(outdir, "cls%d.npz" % k)) for k in range(WORLD)]
+    clip = [c != float("inf") for c in CLS_CLIP]
+    for s in sh:                                                  # collectives per step: 2 exchanges + the clip norm; no broadcast
+        assert s["counts"].tolist() == [[2, int(c), 0] for c in clip], s["counts"]
+    dev = torch.device("cuda:0")
+    params, U, V, d, probes = _cls_setup(dev)
+    allp = [p.clone().requires_grad_(True) for p in params]
+    groups = [allp[:CLS_SPLIT], allp[CLS_SPLIT:]]
+    opt = psgd.UVd(allp, rank_of_modification=CLS_R, lr_params=0.004, lr_preconditioner=0.05,
+                   generator=torch.Generator().manual_seed(606))
+    opt._U.copy_(U); opt._V.copy_(V); opt._d.copy_(d)
+    keep = prod._randn_like
+    try:
+        def snap(it):
+            tol = 1e-6 if all(CLS_EXACT[:it + 1]) else 1e-4
+            got = {k: np.concatenate([s["%s%d" % (k, it)] for s in sh], 0) for k in ("U", "V", "d", "p")}
+            want = {"U": opt._U, "V": opt._V, "d": opt._d, "p": torch.cat([p.detach().reshape(-1) for p in allp])}
+            for k in got:
+                assert rel_err(got[k], want[k].cpu().numpy()) < tol, (it, k, rel_err(got[k], want[k].cpu().numpy()))
+        _cls_run(opt, prod, groups, lambda it: [probes[it][:CLS_SPLIT], probes[it][CLS_SPLIT:]],
+                 lambda: _cls_loss(groups[0], 0.0) + _cls_loss(groups[1], 1.0), snap)
+    finally:
+        prod._randn_like = keep

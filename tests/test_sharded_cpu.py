@@ -193,3 +193,143 @@ def test_sharded_splu_equals_unsharded_oracle(cut):
     for got, want in ((L12, new[0]), (l3, new[1]), (U12, new[2]), (u3, new[3])):
         assert rel_err(got, want) < 1e-7
     assert rel_err(asm_vec("out1"), ref1) < 1e-7
+
+
+# ----------------------------------------------------------------------------- class UVd, row-sharded (UVd(..., group=pg))
+CLS_SHAPES = [(3, 5), (7,), (4, 4), (6, 1), (1,)]          # rank 0 owns the first two tensors (22 rows), rank 1 the rest (23)
+CLS_SPLIT, CLS_R, CLS_STEPS = 2, 3, 5
+
+
+def _cls_setup():
+    """global parameters, initial state and the probe vectors of every step (seeded; the same in every process)"""
+    g = torch.Generator().manual_seed(77)
+    params = [torch.randn(s, generator=g) * 0.7 for s in CLS_SHAPES]
+    n = sum(p.numel() for p in params)
+    sc = (1.0 / (n * CLS_R)) ** 0.5
+    U, V = torch.randn(n, CLS_R, generator=g) * sc * 6, torch.randn(n, CLS_R, generator=g) * sc * 6
+    d = torch.exp(torch.randn(n, 1, generator=g) * 0.2)
+    probes = [[torch.randn(s, generator=g) for s in CLS_SHAPES] for _ in range(CLS_STEPS)]
+    return params, U, V, d, probes
+
+
+def _cls_loss(ps, salt):
+    """a rank's loss on ITS parameters (the global loss is the sum over ranks: block-diagonal Hessian)"""
+    flat = torch.cat([p.reshape(-1) for p in ps])
+    w = torch.cos(torch.arange(flat.numel(), dtype=flat.dtype) * 0.37 + salt)
+    return 0.5 * torch.sum((1.0 + w * w) * flat * flat) + 0.25 * torch.sum(flat ** 4) + torch.sum(w * flat) ** 2
+
+
+def _cls_schedule(opt, it):
+    """hyper-parameters changed between steps (psgd.py:673-680 are mutable): clip on / off, exact / finite-difference Hv,
+    and a step that leaves the preconditioner alone"""
+    opt.grad_clip_max_norm.assign([0.05, float("inf"), 0.05, 0.05, float("inf")][it])
+    opt.exact_hessian_vector_product.assign([True, True, False, True, False][it])
+    opt.preconditioner_update_probability.assign([1.0, 1.0, 1.0, 0.0, 1.0][it])
+
+
+def _cls_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import preconditioned_stochastic_gradient_descent as psgd
+        from psgd_tf_amd import preconditioned_stochastic_gradient_descent as prod
+        from tests.cpu_stages import NumpyStages
+        params, U, V, d, probes = _cls_setup()
+        mine = slice(0, CLS_SPLIT) if rank == 0 else slice(CLS_SPLIT, None)
+        own = [p.clone().requires_grad_(True) for p in params[mine]]
+        lo = sum(p.numel() for p in params[:mine.start or 0])
+        hi = lo + sum(p.numel() for p in own)
+        gen = torch.Generator().manual_seed(4321 + 17 * rank)            # different seeds: rank 0's coins must win
+        opt = psgd.UVd(own, rank_of_modification=CLS_R, lr_params=0.004, lr_preconditioner=0.1, generator=gen,
+                       group=dist.group.WORLD, stage_backend=NumpyStages(CLS_R, dtype=np.float32))
+        assert opt._num_params_global == sum(p.numel() for p in params) and opt._U.shape == (hi - lo, CLS_R)
+        assert abs(float(opt._U.std()) / (1.0 / (opt._num_params_global * CLS_R)) ** 0.5 - 1.0) < 0.4   # :687 on the GLOBAL N
+        opt._U.copy_(U[lo:hi]); opt._V.copy_(V[lo:hi]); opt._d.copy_(d[lo:hi])
+        calls = {"all_gather_into_tensor": 0, "all_reduce": 0, "broadcast": 0}
+        for name in calls:
+            def wrap(fn, name=name):
+                def counted(*a, **k):
+                    calls[name] += 1
+                    return fn(*a, **k)
+                return counted
+            setattr(dist, name, wrap(getattr(dist, name)))
+        per_step = []
+        for it in range(CLS_STEPS):
+            queue = {id(p): q for p, q in zip(own, probes[it][mine])}
+            prod._randn_like = lambda p: queue[id(p)].clone()
+            _cls_schedule(opt, it)
+            before = dict(calls)
+            opt.step(lambda: _cls_loss(own, float(rank)))
+            per_step.append({k: calls[k] - before[k] for k in calls})
+        # collectives per step: 2 exchanges (+1 scalar all-reduce when clipping), nothing else -- no broadcast after set-up
+        clip = [True, False, True, True, False]
+        for it, c in enumerate(per_step):
+            assert c == {"all_gather_into_tensor": 2, "all_reduce": int(clip[it]), "broadcast": 0}, (it, c)
+            assert sum(c.values()) <= 3
+        np.savez(os.path.join(outdir, "cls%d.npz" % rank), U=opt._U.numpy(), V=opt._V.numpy(), d=opt._d.numpy(),
+                 p=torch.cat([p.detach().reshape(-1) for p in own]).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_uvd_class_equals_unsharded_oracle_and_counts_collectives():
+    """UVd(..., group=pg) on two ranks (psgd.py:692-764 row-sharded): parameters and state after five steps -- clip on and off,
+    exact and finite-difference Hv, one step without a preconditioner update -- against oracle.uvd_step on the global vector;
+    at most three collectives per step."""
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_cls_worker, args=(WORLD, _free_port(), outdir), nprocs=WORLD, join=True)
+        sh = [np.load(os.path.join(outdir, "cls%d.npz" % k)) for k in range(WORLD)]
+    got = {k: np.concatenate([s[k] for s in sh], 0) for k in ("U", "V", "d", "p")}
+    params, U, V, d, probes = _cls_setup()
+    U, V, d = (x.numpy().astype(np.float64) for x in (U, V, d))
+    groups = [slice(0, CLS_SPLIT), slice(CLS_SPLIT, None)]
+    gen = torch.Generator().manual_seed(4321)                            # rank 0's generator
+    tiny, delta = float(np.finfo(np.float32).tiny), float(np.finfo(np.float32).eps) ** 0.5
+
+    class Hyp:                                                           # the schedule, replayed on plain attributes
+        def __init__(self): self.value = None
+        def assign(self, v): self.value = v
+    hy = type("H", (), {})()
+    hy.grad_clip_max_norm, hy.exact_hessian_vector_product, hy.preconditioner_update_probability = Hyp(), Hyp(), Hyp()
+
+    def grads_of(ps):                                                    # per rank, exactly as the workers compute them (fp32 autograd)
+        out = []
+        for k, sl in enumerate(groups):
+            own = [p.clone().requires_grad_(True) for p in ps[sl]]
+            out.append((own, torch.autograd.grad(_cls_loss(own, float(k)), own, create_graph=True)))
+        return out
+    for it in range(CLS_STEPS):
+        _cls_schedule(hy, it)
+        exact = hy.exact_hessian_vector_product.value
+        update_Q = bool(torch.rand((), generator=gen).item() < hy.preconditioner_update_probability.value)   # :703
+        bal = upd = False
+        vs = Hvs = None
+        if update_Q:
+            gs = grads_of(params)
+            if exact:
+                vs = probes[it]
+                Hvs = [h for (own, g), sl in zip(gs, groups) for h in torch.autograd.grad(g, own, vs[sl])]
+                stepped_from = params
+            else:
+                vs = [q * np.float32(delta) for q in probes[it]]
+                pert = [p + v for p, v in zip(params, vs)]
+                pg = [x.detach() for own, g in grads_of(pert) for x in g]
+                Hvs = [a - b.detach() for a, b in zip(pg, [x for own, g in gs for x in g])]
+                stepped_from = pert
+            bal = bool(torch.rand((), generator=gen).item() < 0.01)      # :562
+            upd = bool(torch.rand((), generator=gen).item() < 0.5)       # :588
+        else:
+            gs = grads_of(params)
+            stepped_from = params
+        grads = [x.detach() for own, g in gs for x in g]
+        f64 = lambda ts: [t.detach().numpy().astype(np.float64) for t in ts] if ts is not None else None
+        new = orc.uvd_step(f64(stepped_from), f64(grads), f64(Hvs), f64(vs), U, V, d, 0.004, 0.1,
+                           hy.grad_clip_max_norm.value, tiny, balance=bal, update_U=upd, update_Q=update_Q, exact=exact,
+                           delta_param_scale=delta)
+        params = [torch.from_numpy(x.astype(np.float32)) for x in new]
+    want_p = np.concatenate([p.reshape(-1).numpy() for p in params])
+    assert rel_err(got["p"], want_p) < 2e-5
+    for k, ref in (("U", U), ("V", V), ("d", d)):
+        assert rel_err(got[k], ref) < 2e-5, k
