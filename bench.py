@@ -51,15 +51,25 @@ TINY = 1.1754943508222875e-38  # psgd.py:22
 STEP = 0.01                    # psgd.py:664 (lr_preconditioner default)
 
 
-def make_inputs(n_local, n_global, r, dev, seed):
+def make_inputs(n_local, n_global, r, dev, seed, arena=None):
     """SURVEY 8d synthetic inputs: U,V ~ N(0,1)(N r)^-1/2 (psgd.py:687-689), d = 1 (:690),
-    g,v ~ N(0,1) (:713), h = c.*v with c ~ LogUniform[1e-2,1e2]."""
+    g,v ~ N(0,1) (:713), h = c.*v with c ~ LogUniform[1e-2,1e2].
+    arena: a psgd_tf_amd.placement.UVdArena whose regions receive the same values (the state's owner decides where it lives)."""
     g = torch.Generator(device=dev).manual_seed(seed)
     scale = (1.0 / (n_global * r)) ** 0.5
+    g1 = torch.Generator(device=dev).manual_seed(seed + 1)
+    if arena is not None:
+        U, V, d, grad, v, h = arena.U, arena.V, arena.d, arena.g, arena.v, arena.h
+        torch.randn(n_local, r, device=dev, generator=g, out=U).mul_(scale)
+        torch.randn(n_local, r, device=dev, generator=g, out=V).mul_(scale)
+        d.fill_(1.0)
+        torch.randn(n_local, 1, device=dev, generator=g1, out=grad)
+        torch.randn(n_local, 1, device=dev, generator=g1, out=v)
+        h.uniform_(-4.605170186, 4.605170186, generator=g1).exp_().mul_(v)
+        return U, V, d, grad, v, h
     U = torch.randn(n_local, r, device=dev, generator=g) * scale
     V = torch.randn(n_local, r, device=dev, generator=g) * scale
     d = torch.ones(n_local, 1, device=dev)
-    g1 = torch.Generator(device=dev).manual_seed(seed + 1)
     grad = torch.randn(n_local, 1, device=dev, generator=g1)
     v = torch.randn(n_local, 1, device=dev, generator=g1)
     c = torch.exp(torch.empty(n_local, 1, device=dev).uniform_(-4.605170186, 4.605170186, generator=g1))
@@ -568,7 +578,7 @@ def uvd_legs(dev, psgd, lib, state, r, iters):
     }
 
 
-_DROP_KEYS = {"note", "call", "timing", "batched_call", "flop_count", "runs_ms", "mfma_pmc", "sample_detail", "kernels_ms_detail"}
+_DROP_KEYS = {"note", "call", "timing", "batched_call", "flop_count", "runs_ms", "mfma_pmc", "sample_detail", "kernels_ms_detail", "log", "scan"}
 
 
 def _strip(x):
@@ -670,12 +680,23 @@ def launch_ranks(args):
     return proc.returncode if proc.returncode != 0 else (0 if lines else 1)
 
 
-def run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_global, steps, warmup, keep_state=False):
+def run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_global, steps, warmup, keep_state=False,
+            placement_mode=None):
     """Warm-up + timed steps of the UVd update+apply on this rank's rows: `steps` steps between barrier + synchronize
     (MAX over ranks), then a second pass of the same steps with the per-kernel HIP event hooks on."""
     import torch.distributed as dist
     r = args.rank_r
-    U, V, d, grad, v, h = make_inputs(n_local, n_global, r, dev, seed=1000 * rank)
+    # the state's owner places it (psgd_tf_amd/placement.py): one allocation for U, V, d, the workspace and the output, the layout
+    # chosen by a timed probe of both branches (results are bit-identical: only addresses change).  Unsharded path only.
+    arena, placement_log = None, []
+    mode = placement_mode or args.placement
+    if mode != "none" and not use_dist and r <= 32:
+        from psgd_tf_amd import placement
+        arena = (placement.UVdArena.probe(n_local, r, dev, log=placement_log) if mode == "probe"
+                 else placement.UVdArena.packed(n_local, r, dev))
+        arena.install_workspace()
+    U, V, d, grad, v, h = make_inputs(n_local, n_global, r, dev, seed=1000 * rank, arena=arena)
+    out_kw = {"out": arena.out} if arena is not None else {}
     # one step = update then apply on the updated state (psgd.py:732 -> :748).  Default: the fused call
     # (identical results, one pass over V less); --unfused times the two reference-named calls back to back.
     mod = sharded if use_dist else psgd
@@ -686,7 +707,7 @@ def run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_glo
     else:
         def step(i):
             return mod.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, STEP, TINY, balance=False,
-                                                                update_U=(i % 2 == 0))
+                                                                update_U=(i % 2 == 0), **out_kw)
 
     def fence():
         if use_dist:
@@ -717,8 +738,16 @@ def run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_glo
         elapsed = float(tmax.item())
     rec = {"elapsed": elapsed, "slot_ms": slot_ms, "n_local": n_local, "n_global": n_global,
            "ms_per_step": elapsed / steps * 1e3, "value": n_global * steps / elapsed}
+    if arena is not None:
+        inf = arena.info
+        rec["placement"] = {"mode": mode, "layout": inf.get("layout"), "slab_gib": inf.get("slab_bytes", 0) / 2**30,
+                            "boundary_gib": inf.get("boundary_gib"), "note": inf.get("note"),
+                            "probe_packed_step_ms": inf.get("packed_step_ms"),
+                            "probe_step_ms": None if "step_U_ms" not in inf else 0.5 * (inf["step_U_ms"] + inf["step_V_ms"]),
+                            "candidates": inf.get("candidates"), "log": placement_log}
     if keep_state:
         rec["state"] = (U, V, d, grad, v, h)
+        rec["arena"] = arena
     return rec
 
 
@@ -739,7 +768,7 @@ def exchange_overhead(args, psgd, sharded, lib, dev, rows, steps):
         runs = {"unsharded": [], "sharded_1rank": []}
         for rnd in range(3):                                 # interleaved rounds: the two paths see the same clocks and placement
             for name, use_dist in (("unsharded", False), ("sharded_1rank", True)):
-                rec = run_uvd(args, psgd, sharded, lib, dev, 0, 1, use_dist, rows, rows, steps, 10)
+                rec = run_uvd(args, psgd, sharded, lib, dev, 0, 1, use_dist, rows, rows, steps, 10, placement_mode="none")
                 runs[name].append(rec["ms_per_step"])
                 torch.cuda.empty_cache()
         base, shd = statistics.median(runs["unsharded"]), statistics.median(runs["sharded_1rank"])
@@ -781,6 +810,10 @@ def main():
     ap.add_argument("--bpc", type=int, default=0, help="experiment: cap on blocks per CU of the sweeps (psgd_set_tuning key 1)")
     ap.add_argument("--detail-json", default=None, help="also write the full record (every leg, notes) to this file; stdout "
                     "carries the compact line (< 8 KB), stderr a BENCH_DETAIL line with the full record")
+    ap.add_argument("--placement", default="probe", choices=("probe", "packed", "none"),
+                    help="unsharded run: who owns U, V, d, the workspace and the output -- 'probe' (default): one allocation, layout "
+                         "chosen by a timed probe (psgd_tf_amd/placement.py); 'packed': one exact-size allocation; 'none': separate "
+                         "torch allocations (rounds 1-5)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU code path (process group + exchanges) even at world size 1")
     args = ap.parse_args()
@@ -837,6 +870,7 @@ def main():
     main_rec = run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_global, args.steps, args.warmup,
                        keep_state=(world == 1 and not args.no_legs))
     state = main_rec.pop("state", None)
+    arena_keep = main_rec.pop("arena", None)      # (the legs below run on the same placed state)
     weak_rec = None
     if weak_leg_rows:
         torch.cuda.empty_cache()
@@ -886,7 +920,8 @@ def main():
                                        % (world, 4 if args.unfused else 2) if use_dist else "one GPU, no exchange") +
                                       (" [TEST MODE: all ranks on one GPU, gloo -- not a measurement]" if single_dev else ""),
                        "collective_backend": backend, "rccl_ranks": (dist.get_world_size() if use_dist else 0),
-                       "step": STEP, "branches": "balance=0, update_U alternating"},
+                       "step": STEP, "branches": "balance=0, update_U alternating",
+                       "placement": main_rec.get("placement")},
             "roofline": {"bound": "hbm", "kernel": "k_update_s2 (update sweep 2, dominant kernel)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -913,7 +948,7 @@ def main():
                     "wall_ms": two, "params_per_s": n_local / (two * 1e-3),
                     "frac": alg_step * n_local / (two * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "call": "update_precond_UVd_math_ then precond_grad_UVd_math (psgd.py:732, :748), separately timed"}
-            state = None
+            state = arena_keep = None
             torch.cuda.empty_cache()
             if not args.no_legs:
                 c2 = make_inputs(1_000_000, 1_000_000, 10, dev, seed=7)

@@ -228,6 +228,11 @@ class WorkspaceCache:
             total -= int(old.numel())
         return ws
 
+    def put(self, key, ws):
+        """Install a block the caller allocated (placement.UVdArena puts its workspace region where the sweeps want it)."""
+        self._d[key] = ws
+        self._d.move_to_end(key)
+
     def touch(self, key):
         """Mark `key` as just used (callers that keep their own handle to a block call this instead of get())."""
         if key in self._d:

@@ -365,11 +365,12 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
 
 
 def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, balance=None, update_U=None,
-                                             generator=None):
+                                             generator=None, out=None):
     """Extension: update_precond_UVd_math_(U, V, d, v, h, step, tiny) followed by
     precond_grad_UVd_math(U, V, d, g) on the updated state -- the UVd.step pattern (psgd.py:732 -> :748) --
     as one fused call that saves a pass over V.  U or V, and d, are updated in place; returns the
-    preconditioned gradient."""
+    preconditioned gradient.  out (optional): a contiguous fp32 tensor shaped like g to write it to (placement.UVdArena.out:
+    where the output stream lives is worth 4 % of the last sweep); ranks above 32 ignore it."""
     state = _InPlace(U, V, d)
     (U, V, d), v, h, g = state.work, _c(v), _c(h), _c(g)
     dev = _require_hip("update_precond_UVd_math_and_precond_grad", U, V, d, v, h, g)
@@ -382,7 +383,12 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
         out = _wide.update_apply(U, V, d, v, h, g, float(step), float(tiny), bool(balance), bool(update_U), uvd_workspace)
         state.writeback()
         return out
-    out = torch.empty_like(g)
+    if out is None:
+        out = torch.empty_like(g)
+    else:
+        _require_hip("update_precond_UVd_math_and_precond_grad", out, U)
+        if out.shape != g.shape:
+            raise ValueError("update_precond_UVd_math_and_precond_grad: out must be shaped like g")
     ws = uvd_workspace(dev, N, r)
     rc = _lib.load().psgd_uvd_update_apply_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), v.data_ptr(), h.data_ptr(),
                                                 g.data_ptr(), out.data_ptr(), N, r, float(step), float(tiny),
@@ -458,7 +464,7 @@ class UVd:
                  lr_params=0.01, lr_preconditioner=0.01,
                  grad_clip_max_norm=None, preconditioner_update_probability=1.0,
                  exact_hessian_vector_product: bool = True, generator=None, state_dtype=None, group=None,
-                 stage_backend=None):
+                 stage_backend=None, placement=None):
         # group (extension): a torch.distributed process group (dist.group.WORLD for the default one) makes this a
         # ROW-SHARDED optimizer: `params_with_grad` are THIS rank's parameters, the global flat vector of psgd.py:729-730 is the
         # concatenation of the ranks' vectors in rank order, and U, V, d hold this rank's rows only.  A step then costs three
@@ -509,6 +515,24 @@ class UVd:
             self._coins = _sharded.branch_rng_for(generator, group, self._device)
         uv_scale = (1.0 / (self._num_params_global * r)) ** 0.5                              # :687 (the GLOBAL N)
         sd = self._state_dtype
+        # placement (extension; None = plain allocations): "probe" / "packed" carve U, V, d, the workspace, the output and the
+        # flat v / h / g vectors of :729-730, :747 out of ONE allocation owned by this object (placement.UVdArena; "probe" times
+        # candidate layouts once and keeps the fastest: where the WRITTEN streams sit relative to the read ones is worth 5 %)
+        self._arena = None
+        if placement not in (None, "probe", "packed"):
+            raise ValueError("UVd: placement must be None, 'probe' or 'packed', got %r" % (placement,))
+        if placement is not None and self._device.type == "cuda" and self._store_dtype == torch.float32 \
+                and r <= _lib.UVD_MAX_RANK and group is None:
+            from . import placement as _placement
+            self._arena = (_placement.UVdArena.probe if placement == "probe" else _placement.UVdArena.packed)(
+                num_params, r, self._device)
+        if self._arena is not None:
+            self._arena.install_workspace()
+            self._U, self._V, self._d = self._arena.U, self._arena.V, self._arena.d
+            self._U.normal_().mul_(uv_scale)                                                 # :688
+            self._V.normal_().mul_(uv_scale)                                                 # :689
+            self._d.fill_(float(preconditioner_init_scale))                                  # :690
+            return
         self._U = torch.randn(num_params, r, dtype=sd, device=self._device) * uv_scale       # :688
         self._V = torch.randn(num_params, r, dtype=sd, device=self._device) * uv_scale       # :689
         self._d = torch.ones(num_params, 1, dtype=sd, device=self._device) * preconditioner_init_scale  # :690
@@ -526,6 +550,14 @@ class UVd:
             self._U.copy_(U)
             self._V.copy_(V)
             self._d.copy_(d)
+
+    def _flat(self, tensors, name):
+        """psgd.py:729-730, :747: the per-parameter tensors as one flat vector in the state's type -- concatenated straight into
+        the arena's region for it when the state is placed (no second copy, and the vector sits where the sweeps read it)"""
+        parts = [torch.reshape(x, [-1]) for x in tensors]
+        if self._arena is not None and all(x.dtype == self._state_dtype for x in parts):
+            return torch.cat(parts, 0, out=getattr(self._arena, name).view(-1))
+        return torch.cat(parts, 0).to(self._state_dtype)
 
     def _loss_of(self, closure_returns):
         return closure_returns if isinstance(closure_returns, torch.Tensor) else closure_returns[0]
@@ -559,19 +591,19 @@ class UVd:
                 with torch.enable_grad():
                     perturbed_grads = torch.autograd.grad(self._loss_of(closure()), params)
                 Hvs = [pg - g for pg, g in zip(perturbed_grads, grads)]
-            v = torch.cat([torch.reshape(x, [-1]) for x in vs], 0).to(self._state_dtype)      # :729
-            h = torch.cat([torch.reshape(x, [-1]) for x in Hvs], 0).to(self._state_dtype)     # :730
+            v = self._flat(vs, "v")                                                           # :729
+            h = self._flat(Hvs, "h")                                                          # :730
             if not exact:                                                                     # :734-736
                 v = v / self._delta_param_scale
                 h = h / self._delta_param_scale
-            grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0).to(self._state_dtype)    # :747
+            grad = self._flat(grads, "g")                                                     # :747
             # :732-733 then :748 as one fused call (same results, three sweeps instead of six)
             U, V, d = self._state_fp32()
             if self._group is None:
                 pre_grad = update_precond_UVd_math_and_precond_grad(
                     U, V, d, v[:, None].contiguous(), h[:, None].contiguous(),
                     grad[:, None].contiguous(), step=float(self.lr_preconditioner), tiny=self._tiny,
-                    generator=self._generator)
+                    generator=self._generator, out=None if self._arena is None else self._arena.out)
             else:                                  # this rank's rows; 2 exchanges; :562, :588 from the synchronised generator
                 pre_grad = self._sharded.update_precond_UVd_math_and_precond_grad(
                     U, V, d, v[:, None].contiguous(), h[:, None].contiguous(),
@@ -582,7 +614,7 @@ class UVd:
             with torch.enable_grad():
                 closure_returns = closure()
                 grads = torch.autograd.grad(self._loss_of(closure_returns), params)
-            grad = torch.cat([torch.reshape(g, [-1]) for g in grads], 0).to(self._state_dtype)    # :747
+            grad = self._flat(grads, "g")                                                     # :747
             if self._group is None:
                 pre_grad = precond_grad_UVd_math(*self._state_fp32(), grad[:, None].contiguous())     # :748
             else:

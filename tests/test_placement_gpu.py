@@ -1,0 +1,127 @@
+"""GPU: the UVd state's allocator (psgd_tf_amd/placement.py).  Placement changes addresses only -- every result must be the
+same BITS as with plain allocations -- and the probe must come back with a working arena whatever it finds (on a small slab it
+finds no block boundary and keeps the packed layout)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.uvd_cases import TINY32, make_uvd_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _plain(p, dev):
+    return {k: torch.from_numpy(v).to(dev) for k, v in p.items()}
+
+
+def _into(arena, p):
+    for k, name in (("U", "U"), ("V", "V"), ("d", "d"), ("g", "g"), ("v", "v"), ("h", "h")):
+        getattr(arena, name).copy_(torch.from_numpy(p[k]))
+
+
+@pytest.mark.parametrize("N,r", [(300_007, 20), (64_000, 10), (1_000_003, 32)])
+def test_packed_arena_gives_the_same_bits(hip_lib, N, r):
+    import preconditioned_stochastic_gradient_descent as psgd
+    from psgd_tf_amd import placement
+    dev = torch.device("cuda:0")
+    p = make_uvd_problem(N, r, seed=3, uv_gain=2.0, d_spread=0.2)
+    a = _plain(p, dev)
+    arena = placement.UVdArena.packed(N, r, dev)
+    assert all(getattr(arena, k).data_ptr() % 256 == 0 for k in ("U", "V", "d", "out", "ws", "g", "v", "h"))
+    _into(arena, p)
+    arena.install_workspace()
+    for upd in (True, False):
+        want = psgd.update_precond_UVd_math_and_precond_grad(a["U"], a["V"], a["d"], a["v"], a["h"], a["g"], 0.01, TINY32,
+                                                             balance=False, update_U=upd)
+        got = psgd.update_precond_UVd_math_and_precond_grad(arena.U, arena.V, arena.d, arena.v, arena.h, arena.g, 0.01, TINY32,
+                                                            balance=False, update_U=upd, out=arena.out)
+        assert got.data_ptr() == arena.out.data_ptr()
+        assert torch.equal(got, want)
+        for k in ("U", "V", "d"):
+            assert torch.equal(getattr(arena, k), a[k]), k
+    # the two reference-named calls on the placed state, and the workspace the arena installed is the one they use
+    psgd.update_precond_UVd_math_(arena.U, arena.V, arena.d, arena.v, arena.h, 0.01, TINY32, balance=True, update_U=True)
+    psgd.update_precond_UVd_math_(a["U"], a["V"], a["d"], a["v"], a["h"], 0.01, TINY32, balance=True, update_U=True)
+    assert torch.equal(psgd.precond_grad_UVd_math(arena.U, arena.V, arena.d, arena.g),
+                       psgd.precond_grad_UVd_math(a["U"], a["V"], a["d"], a["g"]))
+    assert psgd.uvd_workspace(dev, N, r).data_ptr() == arena.ws.data_ptr()
+    with pytest.raises(ValueError):
+        psgd.update_precond_UVd_math_and_precond_grad(arena.U, arena.V, arena.d, arena.v, arena.h, arena.g, 0.01, TINY32,
+                                                      balance=False, update_U=True, out=arena.out.view(-1)[:-1])
+
+
+def test_probe_on_a_small_slab_falls_back_to_packed_and_works(hip_lib):
+    """A 0.75-GiB 'two-block' slab for a 2M-row problem: the probe runs its boundary scan (13 + bisect points of the last sweep),
+    sees no boundary on one uniform block and returns the packed arena, with the scan in `info`."""
+    import preconditioned_stochastic_gradient_descent as psgd
+    from psgd_tf_amd import placement
+    dev = torch.device("cuda:0")
+    N, r = 2_000_000, 20
+    log = []
+    arena = placement.UVdArena.probe(N, r, dev, two_block_gib=0.75, log=log)
+    assert arena.info["layout"] == "packed" or "two-block" in arena.info["layout"]
+    assert any("scan" in rec for rec in log) and log[0]["layout"] == "packed" and log[0]["step_U_ms"] > 0
+    p = make_uvd_problem(N, r, seed=5)
+    a = _plain(p, dev)
+    _into(arena, p)
+    arena.install_workspace()
+    want = psgd.update_precond_UVd_math_and_precond_grad(a["U"], a["V"], a["d"], a["v"], a["h"], a["g"], 0.01, TINY32,
+                                                         balance=False, update_U=True)
+    got = psgd.update_precond_UVd_math_and_precond_grad(arena.U, arena.V, arena.d, arena.v, arena.h, arena.g, 0.01, TINY32,
+                                                        balance=False, update_U=True, out=arena.out)
+    assert torch.equal(got, want) and torch.equal(arena.U, a["U"]) and torch.equal(arena.d, a["d"])
+
+
+def test_boundary_layout_offsets():
+    """the layout rule around a boundary: U in front, V across it, thin streams behind, nothing overlapping (host logic; the
+    region sizes come from the library)"""
+    from psgd_tf_amd import placement
+    N, r = 100_000_000, 20
+    sz = placement.UVdArena.region_bytes(N, r)
+    slab = 48 << 30
+    for straddle in (0.0, 0.25, 0.4):
+        off = placement.UVdArena.boundary_offsets(N, r, 32 << 30, slab, straddle)
+        spans = sorted((off[k], off[k] + sz[k]) for k in off)
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[0][0] >= 0 and spans[-1][1] <= slab
+        assert all(o % 256 == 0 for o in off.values())
+        behind = (off["V"] + sz["V"] - (32 << 30)) / sz["V"]
+        assert abs(behind - straddle) < 0.01 and off["U"] + sz["U"] <= off["V"] and off["d"] >= (32 << 30)
+    assert placement.UVdArena.boundary_offsets(N, r, 4 << 30, slab) is None           # U would start below the slab
+
+
+def test_uvd_class_with_a_placed_state(hip_lib):
+    """UVd(..., placement='packed'): same parameters and state after three steps as the plain optimizer, bit for bit."""
+    import preconditioned_stochastic_gradient_descent as psgd
+    from psgd_tf_amd import preconditioned_stochastic_gradient_descent as prod
+    dev = torch.device("cuda:0")
+    shapes = [(40, 30), (1000,), (17, 1)]
+    g0 = torch.Generator().manual_seed(11)
+    init = [(torch.randn(s, generator=g0) * 0.3).to(dev) for s in shapes]
+    probes = [[torch.randn(s, generator=g0).to(dev) for s in shapes] for _ in range(3)]
+    n = sum(p.numel() for p in init)
+    U0, V0 = (torch.randn(n, 10, generator=g0) * 0.02).to(dev), (torch.randn(n, 10, generator=g0) * 0.02).to(dev)
+
+    def loss(ps):
+        flat = torch.cat([p.reshape(-1) for p in ps])
+        return 0.5 * torch.sum(flat * flat) + 0.25 * torch.sum(flat ** 4) + 0.01 * torch.sum(flat) ** 2
+    keep = prod._randn_like
+    res = []
+    try:
+        for placement_mode in (None, "packed"):
+            ps = [p.clone().requires_grad_(True) for p in init]
+            opt = psgd.UVd(ps, rank_of_modification=10, lr_params=0.01, lr_preconditioner=0.05, grad_clip_max_norm=0.5,
+                           generator=torch.Generator().manual_seed(3), placement=placement_mode)
+            assert (opt._arena is not None) == (placement_mode is not None)
+            opt._U.copy_(U0); opt._V.copy_(V0)
+            for it in range(3):
+                queue = {id(p): q for p, q in zip(ps, probes[it])}
+                prod._randn_like = lambda p: queue[id(p)].clone()
+                opt.exact_hessian_vector_product.assign(it != 1)
+                opt.step(lambda: loss(ps))
+            res.append([p.detach().clone() for p in ps] + [opt._U.clone(), opt._V.clone(), opt._d.clone()])
+    finally:
+        prod._randn_like = keep
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        psgd.UVd([init[0].clone().requires_grad_(True)], placement="best")
