@@ -77,45 +77,60 @@ def make_inputs(n_local, n_global, r, dev, seed, arena=None):
     return U, V, d, grad, v, h
 
 
-def cpu_baseline(r, sample_rows, budget_s, threads=None):
-    """Reference op sequence on torch-CPU (oracle/psgd_oracle_torch.py), update + apply:
-    a quick thread-count sweep (skinny [N,r] matmuls do not scale to every core), then with the best count
-    2 warm-up + 5 timed steps, median; `sample_rows` bounds the work (stated in `sample`)."""
+def _host_mem_available_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 2**20
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(r, sample_rows, budget_s, threads=None, full_rows=None):
+    """Reference op sequence on torch-CPU (oracle/psgd_oracle_torch.py), update + apply.
+    1. thread-count sweep on the first 1M rows (skinny [N, r] matmuls do not scale to every core), the best three counts timed again
+       on the whole `sample_rows` sample (a bandwidth-bound size can want more threads than a cache-sized one);
+    2. with the best count 2 warm-up + up to 5 timed steps on the sample, median  -> `sample_value`;
+    3. full_rows (the metric's N, given when the host has the memory): 1 warm-up + 2 timed steps on the FULL workload -> `value`
+       (same box, full config); without it `value` is the sample's figure and `full_n_skipped` says why."""
     import statistics
     from oracle import psgd_oracle_torch as ref
     ncpu = os.cpu_count() or 1
-    U, V, d, grad, v, h = make_inputs(sample_rows, sample_rows, r, torch.device("cpu"), 0)
 
-    def one(i):
-        t0 = time.perf_counter()
-        ref.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
-        t1 = time.perf_counter()
-        ref.precond_grad_UVd_math(U, V, d, grad)
-        t2 = time.perf_counter()
-        return t2 - t0, t1 - t0, t2 - t1
+    def stepper(t):
+        U, V, d, grad, v, h = t
 
-    # thread sweep up to every logical CPU (BASELINE.md section 3) on the first `sweep_rows` rows of the sample, so that it fits
-    # the budget; the timed steps then run on the whole sample with the best count
+        def one(i):
+            t0 = time.perf_counter()
+            ref.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+            t1 = time.perf_counter()
+            ref.precond_grad_UVd_math(U, V, d, grad)
+            t2 = time.perf_counter()
+            return t2 - t0, t1 - t0, t2 - t1
+        return one
+
+    data = make_inputs(sample_rows, sample_rows, r, torch.device("cpu"), 0)
+    one = stepper(data)
     sweep_rows = min(sample_rows, 1_000_000)
-    Us, Vs, ds, gs_, vs, hs = (x[:sweep_rows].clone() for x in (U, V, d, grad, v, h))
-
-    def one_small(i):
-        t0 = time.perf_counter()
-        ref.update_precond_UVd_math_(Us, Vs, ds, vs, hs, STEP, TINY, balance=False, update_U=(i % 2 == 0))
-        ref.precond_grad_UVd_math(Us, Vs, ds, gs_)
-        return time.perf_counter() - t0
-
+    one_small = stepper(tuple(x[:sweep_rows].clone() for x in data))
     t_start = time.perf_counter()
     cands = [threads] if threads else sorted({t for t in (4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu})
     sweep = {}
     for t in cands:
         torch.set_num_threads(t)
         one_small(0)
-        sweep[t] = min(one_small(1), one_small(2))
-        if time.perf_counter() - t_start > 0.5 * budget_s:
+        sweep[t] = min(one_small(1)[0], one_small(2)[0])
+        if time.perf_counter() - t_start > 0.4 * budget_s:
             break
-    del Us, Vs, ds, gs_, vs, hs
-    best = min(sweep, key=sweep.get)
+    resweep = {}
+    for t in sorted(sweep, key=sweep.get)[:3]:                 # the best three again, on the timed size
+        torch.set_num_threads(t)
+        one(0)
+        resweep[t] = min(one(1)[0], one(2)[0])
+        if time.perf_counter() - t_start > 0.9 * budget_s and resweep:
+            break
+    best = min(resweep, key=resweep.get)
     torch.set_num_threads(best)
     for i in range(2):
         one(i)
@@ -133,25 +148,40 @@ def cpu_baseline(r, sample_rows, budget_s, threads=None):
                 break
     except OSError:
         pass
-    full = None                                  # the last recorded run of this leg on the metric's full N (--cpu-full)
-    try:
-        fp = os.path.join(ROOT, "profiles", "r03_bench_cpu_full_n100m.json.log")
-        fr = json.loads(open(fp).read().strip().splitlines()[-1])["cpu_baseline"]
-        full = {"value": fr["value"], "cores": fr["cores"], "rows": 100_000_000,
-                "source": "profiles/r03_bench_cpu_full_n100m.json.log (bench.py --cpu-full --cpu-threads 16, an earlier box)"}
-    except Exception:
-        full = None
-    return {"value": sample_rows / med, "unit": "params/s", "cores": best, "kind": "port",
-            "sample": "update+apply on N=%d rows (of the metric's 100M), r=%d fp32: %d timed steps, median %.3f s; %d threads"
-                      % (sample_rows, r, len(runs), med, best),
-            "sample_detail": "torch-CPU restatement of psgd.py:554-627 in the reference's op order (TensorFlow unavailable), "
-                             "2 warm-up steps, min %.3f s; thread sweep on %d rows (s per step): %s; host: %d logical CPUs, %s"
-                             % (min(x[0] for x in runs), sweep_rows, {k: round(v_, 3) for k, v_ in sweep.items()}, ncpu, model),
-            "update_params_per_s": sample_rows / statistics.median(x[1] for x in runs),
-            "apply_params_per_s": sample_rows / statistics.median(x[2] for x in runs),
-            "thread_sweep_max": max(sweep), "logical_cpus": ncpu, "cpu_model": model,
-            "full_n_value": full["value"] if full else None, "full_n_cores": full["cores"] if full else None,
-            "full_n_source": full["source"] if full else None}
+    del data, one, one_small
+    out = {"value": sample_rows / med, "unit": "params/s", "cores": best, "kind": "port",
+           "sample": "update+apply on N=%d rows (of the metric's 100M), r=%d fp32: %d timed steps, median %.3f s; %d threads"
+                     % (sample_rows, r, len(runs), med, best),
+           "sample_detail": "torch-CPU restatement of psgd.py:554-627 in the reference's op order (TensorFlow unavailable), "
+                            "2 warm-up steps, min %.3f s; thread sweep on %d rows (s per step): %s; best three on %d rows: %s; "
+                            "host: %d logical CPUs, %s"
+                            % (min(x[0] for x in runs), sweep_rows, {k: round(v_, 3) for k, v_ in sweep.items()}, sample_rows,
+                               {k: round(v_, 3) for k, v_ in resweep.items()}, ncpu, model),
+           "sample_value": sample_rows / med, "sample_rows": sample_rows,
+           "update_params_per_s": sample_rows / statistics.median(x[1] for x in runs),
+           "apply_params_per_s": sample_rows / statistics.median(x[2] for x in runs),
+           "thread_sweep_max": max(sweep), "logical_cpus": ncpu, "cpu_model": model,
+           "host_mem_available_gib": _host_mem_available_gib(), "full_n_value": None, "full_n_skipped": None}
+    if full_rows and full_rows > sample_rows:
+        need_gib = full_rows * (8 * r + 24 + 3 * 4 * r) * 1.25 / 2**30        # U, V, six vectors, three [N, r] temporaries, slack
+        avail = out["host_mem_available_gib"]
+        if avail is None or avail < need_gib + 8.0:
+            out["full_n_skipped"] = "host MemAvailable %.0f GiB < %.0f GiB needed for N=%d, r=%d" % (avail or 0, need_gib + 8.0,
+                                                                                                  full_rows, r)
+        else:
+            one = stepper(make_inputs(full_rows, full_rows, r, torch.device("cpu"), 0))
+            one(0)
+            fr = [one(1), one(2)]
+            fmed = statistics.median(x[0] for x in fr)
+            out.update(value=full_rows / fmed, full_n_value=full_rows / fmed, full_n_rows=full_rows,
+                       sample="update+apply on the metric's FULL N=%d rows, r=%d fp32, this host: 1 warm-up + 2 timed steps, "
+                              "%.2f / %.2f s; %d threads (chosen on a %d-row sample: %.0f params/s there)"
+                              % (full_rows, r, fr[0][0], fr[1][0], best, sample_rows, sample_rows / med),
+                       update_params_per_s=full_rows / statistics.median(x[1] for x in fr),
+                       apply_params_per_s=full_rows / statistics.median(x[2] for x in fr))
+    elif not full_rows:
+        out["full_n_skipped"] = "--cpu-sample-only"
+    return out
 
 
 LENET5 = [(26, 6), (151, 16), (257, 120), (121, 84), (85, 10)]      # mnist_with_lenet5.py:12-16
@@ -216,6 +246,12 @@ def kron_bench(dev, psgd, iters=20):
         flip[0] ^= 1
         return psgd.precond_grad_kron(pairs[flip[0]][0], pairs[flip[0]][1], G)
     t_f32_cold = timeit(cold32, iters)
+    from psgd_tf_amd import kron as _kron
+    old_route = _kron.set_apply_route("auto")      # the opt-in fast path: new factors take the Gram-free chain
+    try:
+        t_f32_cold_auto = timeit(cold32, iters)
+    finally:
+        _kron.set_apply_route(old_route)
     del Ql2, Qr2, pairs
     # the large updates BEFORE the LeNet5 legs: those create a pool of streams and captured graphs, and a process that holds many streams
     # maps the update's caller stream and its side stream onto shared hardware queues -- the two chains of the update then overlap less
@@ -224,6 +260,17 @@ def kron_bench(dev, psgd, iters=20):
     t_upd = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, G, 0.01), 5)
     dXb, dGb = dX.to(torch.bfloat16), Gb
     t_upd_bf16 = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dXb, dGb, 0.01), 5)
+    # the same fp32 calls on the EXACT fp32 matrix core (v_mfma_f32_16x16x4_f32; tuning key 1 = 0): the default large-layer path
+    # multiplies f16 x 2 planes (about 22-bit operands, fp32 accumulation: 5.7e-7 against fp64 at 4096^2), not IEEE fp32 products
+    t_f32_exact = t_upd_exact = None
+    try:
+        _kron.set_tuning(1, 0)
+        t_f32_exact = timeit(lambda: psgd.precond_grad_kron(Ql, Qr, G), 3)
+        t_upd_exact = timeit(lambda: psgd.update_precond_kron(Ql, Qr, dX, G, 0.01), 3)
+    except Exception as exc:
+        print("exact-fp32 Kron leg failed: %r" % (exc,), file=sys.stderr)
+    finally:
+        _kron.set_tuning(1, 1)
     del dX, dXb
     sts = [state(m, n) for m, n in LENET5]
     Qls, Qrs, Gs = [x[0] for x in sts], [x[1] for x in sts], [x[2] for x in sts]
@@ -270,8 +317,6 @@ def kron_bench(dev, psgd, iters=20):
         t_lenet_loop_graph = t_lenet_upd_loop_graph = float("nan")
     # the same per-layer calls, each on its own forked stream (`with kron.layer_streams():` around the list comprehension: the
     # layers are independent and each call is a chain of 3-5 dependent launches); eager, and as a graph with one branch per layer
-    from psgd_tf_amd import kron as _kron
-
     def forked_apply():                           # (new factors on every call, like cold_loop; inside a capture the Grams are always rebuilt)
         flip[0] ^= 1
         with _kron.layer_streams():
@@ -354,6 +399,8 @@ def kron_bench(dev, psgd, iters=20):
                                             "`ms_unchanged_factors` reuses them",
                                     "mfma_pmc": pmc},
         "4096x4096_fp32": {"ms": t_f32_cold, "gflops": f_big / t_f32_cold / 1e6, "mfma_peak_gflops": 157.3e3,
+                           "arithmetic": "f16x2-plane fp32 emulation (fp32 accumulation)", "route": "reference (default): Gram of psgd.py:192 every call",
+                           "ms_auto_route": t_f32_cold_auto, "ms_exact_fp32_mfma": t_f32_exact,
                            "ms_unchanged_factors": t_f32, "gflops_unchanged_factors": f_big / t_f32 / 1e6,
                            "issued_f16_gflop_per_apply_unchanged_factors": f32_issued / 1e9,
                            "frac_of_f16_peak_issued_unchanged_factors": f32_issued / t_f32 / 1e6 / 2.5e6,
@@ -365,13 +412,14 @@ def kron_bench(dev, psgd, iters=20):
                                    "planes made inside the call; `ms_unchanged_factors` = the prepared form (Gram of psgd.py:192 and factor "
                                    "planes kept from the second call with the same factor tensors on); the "
                                    "fp32 MFMA peak is quoted for reference, it does not bound this kernel"},
-        "lenet5_set_fp32": {"us": t_lb * 1e3, "gflops": f_lenet / t_lb / 1e6, "bound": "launch/latency",
-                            "call": "with kron.layer_batch(): [precond_grad_kron(Ql, Qr, G) for each layer]  (the reference's pattern, "
-                                    "mnist_with_lenet5.py:53, inside the deferred-batching block); `per_layer_calls_us` = the bare pattern",
+        "lenet5_set_fp32": {"us": t_lenet_loop_cold * 1e3, "gflops": f_lenet / t_lenet_loop_cold / 1e6, "bound": "launch/latency",
+                            "call": "[precond_grad_kron(Ql, Qr, G) for each layer]  (the reference's bare pattern, mnist_with_lenet5.py:53, "
+                                    "new factors every call); `layer_batch_us` = the same comprehension inside `with kron.layer_batch():`",
                             "per_layer_calls_us": t_lenet_loop_cold * 1e3,
-                            "layer_batch": {"per_layer_calls_us": t_lb * 1e3, "per_layer_calls_graph_us": t_lb_graph * 1e3,
-                                            "per_layer_update_calls_us": t_lb_upd * 1e3,
-                                            "per_layer_update_calls_graph_us": t_lb_upd_graph * 1e3,
+                            "layer_batch_us": t_lb * 1e3, "layer_batch_update_us": t_lb_upd * 1e3,
+                            "layer_batch": {"apply_us": t_lb * 1e3, "apply_graph_us": t_lb_graph * 1e3,
+                                            "update_us": t_lb_upd * 1e3,
+                                            "update_graph_us": t_lb_upd_graph * 1e3,
                                             "ratio_to_batched": t_lb / t_lenet_cold, "update_ratio_to_batched": t_lb_upd / t_lenet_upd},
                             "per_layer_calls_unchanged_factors_us": t_lenet_loop * 1e3,
                             "per_layer_calls_graph_us": t_lenet_loop_graph * 1e3,
@@ -381,7 +429,7 @@ def kron_bench(dev, psgd, iters=20):
                                     "`*_unchanged_factors*`: the Grams stay prepared (2 launches); `*_graph_us`: the same list "
                                     "comprehension captured once in a CUDA graph and replayed (no host cost; inside a capture the "
                                     "Grams are always rebuilt); `batched_us`: the batched extension, new factors",
-                            "update_us": t_lb_upd * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3,
+                            "update_us": t_lenet_upd_loop * 1e3, "per_layer_update_calls_us": t_lenet_upd_loop * 1e3,
                             "per_layer_update_calls_graph_us": t_lenet_upd_loop_graph * 1e3,
                             "layer_streams": {"per_layer_calls_us": t_lenet_forked * 1e3, "per_layer_calls_graph_us": t_lenet_forked_graph * 1e3,
                                               "per_layer_update_calls_us": t_lenet_upd_forked * 1e3,
@@ -390,7 +438,8 @@ def kron_bench(dev, psgd, iters=20):
                                                       "call on its own forked stream, joined when the block ends; `*_graph_us`: captured once, "
                                                       "the graph has one branch per layer"},
                             "batched_update_us": t_lenet_upd * 1e3},
-        "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6},
+        "4096x4096_fp32_update": {"ms": t_upd, "gflops": f_upd / t_upd / 1e6, "arithmetic": "f16x2-plane fp32 emulation (fp32 accumulation)",
+                                  "ms_exact_fp32_mfma": t_upd_exact},
         "4096x4096_bf16_operands_update": {"ms": t_upd_bf16, "gflops": f_upd / t_upd_bf16 / 1e6,
                                            "note": "products on bf16 operands; balance, triangular solves, norms and "
                                                    "the final subtraction in fp32"},
@@ -581,6 +630,17 @@ def uvd_legs(dev, psgd, lib, state, r, iters):
 _DROP_KEYS = {"note", "call", "timing", "batched_call", "flop_count", "runs_ms", "mfma_pmc", "sample_detail", "kernels_ms_detail", "log", "scan"}
 
 
+def _no_nan(x):
+    """NaN / inf are not JSON: a failed leg's placeholder becomes null"""
+    if isinstance(x, dict):
+        return {k: _no_nan(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_no_nan(v) for v in x]
+    if isinstance(x, float) and (x != x or x in (float("inf"), float("-inf"))):
+        return None
+    return x
+
+
 def _strip(x):
     """The full record without its prose: drops the keys of _DROP_KEYS at any depth and cuts strings to 120 characters (what
     the driver's record keeps of a string)."""
@@ -591,6 +651,8 @@ def _strip(x):
     if isinstance(x, str) and len(x) > 120:
         return x[:117] + "..."
     if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
         return float("%.8g" % x)                 # (value / ms_per_step pairs stay consistent to 1e-7)
     return x
 
@@ -620,9 +682,12 @@ def compact_line(res, limit=7800):
                      kron_bf16_apply_frac_issued=kr["roofline"]["frac"],
                      kron_fp32_apply_ms=kr["4096x4096_fp32"]["ms"], kron_fp32_update_ms=kr["4096x4096_fp32_update"]["ms"],
                      kron_bf16ops_update_ms=kr["4096x4096_bf16_operands_update"]["ms"],
+                     kron_fp32_apply_auto_route_ms=kr["4096x4096_fp32"]["ms_auto_route"],
+                     kron_fp32_exact_apply_ms=kr["4096x4096_fp32"]["ms_exact_fp32_mfma"],
+                     kron_fp32_exact_update_ms=kr["4096x4096_fp32_update"]["ms_exact_fp32_mfma"],
                      lenet5_apply_us=kr["lenet5_set_fp32"]["us"], lenet5_update_us=kr["lenet5_set_fp32"]["update_us"],
-                     lenet5_apply_bare_calls_us=kr["lenet5_set_fp32"]["per_layer_calls_us"],
-                     lenet5_update_bare_calls_us=kr["lenet5_set_fp32"]["per_layer_update_calls_us"],
+                     lenet5_layer_batch_apply_us=kr["lenet5_set_fp32"]["layer_batch_us"],
+                     lenet5_layer_batch_update_us=kr["lenet5_set_fp32"]["layer_batch_update_us"],
                      lenet5_batched_apply_us=kr["lenet5_set_fp32"]["batched_us"],
                      lenet5_batched_update_us=kr["lenet5_set_fp32"]["batched_update_us"])
         pm = kr["4096x4096_bf16_operands"].get("mfma_pmc")
@@ -799,7 +864,10 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="fix the thread count of the CPU baseline (0 = sweep)")
-    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline on the full row count (needs ~45 B/param of host RAM x r/20)")
+    ap.add_argument("--cpu-full", action="store_true", help="(default since round 6; kept for old command lines)")
+    ap.add_argument("--cpu-sample-only", action="store_true",
+                    help="CPU baseline on the bounded sample only (default: the sample, then 1 + 2 steps on the metric's full N when the "
+                         "host has >= 64 GiB available)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kron", action="store_true", help="skip the Kron apply GFLOP/s and sparse-LU legs")
     ap.add_argument("--no-legs", action="store_true", help="skip the apply-alone / update-alone / config-2 legs")
@@ -909,7 +977,8 @@ def main():
         res = {
             "metric": "uvd_update_apply_params_per_sec", "value": value, "unit": "params/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": (scaling if world > 1 else None), "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {"workload": "UVd update+apply (psgd.py:732->:748%s), %s, r=%d" % ("" if args.unfused else ", fused call", what, r),
                        "rows_per_gpu": n_local, "rows_global": n_global, "rank_of_modification": r,
                        "baseline_config": ("configs[3]: UVd N=100M, r=20, flat-vector sharded" if
@@ -919,7 +988,8 @@ def main():
                        "parallelism": ("row-sharded x%d: %d all-gathers/step of r-dim buffers (<= 30 KB) + rank-order fold"
                                        % (world, 4 if args.unfused else 2) if use_dist else "one GPU, no exchange") +
                                       (" [TEST MODE: all ranks on one GPU, gloo -- not a measurement]" if single_dev else ""),
-                       "collective_backend": backend, "rccl_ranks": (dist.get_world_size() if use_dist else 0),
+                       "collective_backend": backend, "rccl_ranks": (dist.get_world_size() if use_dist else None),
+                       "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if (use_dist and backend == "nccl") else None),
                        "step": STEP, "branches": "balance=0, update_U alternating",
                        "placement": main_rec.get("placement")},
             "roofline": {"bound": "hbm", "kernel": "k_update_s2 (update sweep 2, dominant kernel)",
@@ -973,8 +1043,9 @@ def main():
                     res["exchange_overhead"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
             if not args.no_cpu_baseline:
-                rows = n_local if args.cpu_full else args.cpu_sample_rows
-                res["cpu_baseline"] = cpu_baseline(r, rows, args.cpu_budget_s, args.cpu_threads or None)
+                res["cpu_baseline"] = cpu_baseline(r, args.cpu_sample_rows, args.cpu_budget_s, args.cpu_threads or None,
+                                                   full_rows=None if args.cpu_sample_only else n_local)
+        res = _no_nan(res)
         detail = json.dumps(res)
         if args.detail_json:
             with open(args.detail_json, "w") as fh:

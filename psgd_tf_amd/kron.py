@@ -198,19 +198,20 @@ class layer_streams:
 
 
 # --------------------------------------------------------------------------- route of the large fp32 apply
-_apply_route = "auto"
+_apply_route = "reference"
 
 
 def set_apply_route(route):
     """Which chain the fp32 (dense, dense) apply of a LARGE layer runs.  Returns the old value.
 
-    "auto" (default): factors seen for the first time take the Gram-free chain Ql'(Ql((G Qr')Qr)), the same factor tensors a
-        second time make the Gram of psgd.py:190 / :192 and later calls reuse it -- fastest for the reference's update -> apply
-        pattern, but calls 1, 2 and 3 on identical inputs return bits that differ in the last places (3e-6 between the routes,
-        tests/test_kron_gpu.py), and for M >= N the first-sight association order is not the reference's.
-    "reference": always the association order of psgd.py:189-192 -- the Gram of the smaller side, then the products of :190 /
-        :192 -- whatever was seen before: identical inputs give identical bits on every call (the prepared Gram is reused when
-        the factors are unchanged; it is the same Gram, bit for bit, that a fresh call would make)."""
+    "reference" (default since round 6): always the association order of psgd.py:189-192 -- the Gram of the smaller side, then
+        the products of :190 / :192 -- whatever was seen before: identical inputs give identical bits on every call (the prepared
+        Gram is reused when the factors are unchanged; it is the same Gram, bit for bit, that a fresh call would make).
+    "auto" (opt-in fast path): factors seen for the first time take the Gram-free chain Ql'(Ql((G Qr')Qr)), the same factor
+        tensors a second time make the Gram of psgd.py:190 / :192 and later calls reuse it -- fastest for the reference's
+        update -> apply pattern (4096^2: 0.9 ms against 1.03), but calls 1, 2 and 3 on identical inputs return bits that differ
+        in the last places (3e-6 between the routes, tests/test_kron_gpu.py), and for M >= N the first-sight association order
+        is not the reference's."""
     global _apply_route
     if route not in ("auto", "reference"):
         raise ValueError("set_apply_route: 'auto' or 'reference', got %r" % (route,))

@@ -193,6 +193,12 @@ class UVdArena:
                     else:
                         a = m
                 boundary = b
+                # the streams' START was timed: the drop is half done when about half of the 1.2 GiB of written streams is behind the
+                # boundary, so the boundary itself is a little above b.  Blocks are powers of two: take the most aligned multiple of
+                # 64 MiB in [b - 0.25 GiB, b + 0.9 GiB]
+                cands = [m for m in range(((b - GiB // 4) >> 26) << 26, b + (9 * GiB) // 10, 1 << 26) if m > 0]
+                if cands:
+                    boundary = max(cands, key=lambda m: (m & -m, -abs(m - b)))
         say({"layout": "boundary scan (final sweep ms vs offset of d/out/nablaD, GiB)", "scan": scan,
              "boundary_gib": None if boundary is None else boundary / GiB})
         if boundary is None:

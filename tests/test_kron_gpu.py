@@ -1469,17 +1469,16 @@ def test_layer_batch_block_equals_the_batched_entry_points(psgd):
 
 @pytest.mark.parametrize("M,N", [(4096, 4096), (2048, 1536), (1100, 2304), (257, 120)])
 def test_reference_apply_route_is_reproducible(psgd, M, N):
-    """kron.set_apply_route("reference"): always the association order of psgd.py:189-192 (Gram of the smaller side), no
-    first- / second-sight switch: three consecutive calls with identical inputs return identical bits (the default route's three
-    calls take three paths -- direct, prepare + apply, prepared -- whose bits differ in the last places at large shapes)."""
+    """The DEFAULT route (round 6; no route call here): always the association order of psgd.py:189-192 (Gram of the smaller side),
+    no first- / second-sight switch: three consecutive calls with identical inputs return identical bits (the opt-in "auto"
+    route's three calls take three paths -- direct, prepare + apply, prepared -- whose bits differ in the last places)."""
     from psgd_tf_amd import kron
     rng = np.random.default_rng(M + 5 * N)
     Ql, Qr = _dev((_tri_factor(rng, M) * 1.3).astype(np.float32)), _dev(_tri_factor(rng, N).astype(np.float32))
     G = _dev(rng.standard_normal((M, N)).astype(np.float32))
     key = (G.get_device(), M, N, kron._raw_stream(G.get_device()))
-    old = kron.set_apply_route("reference")
+    assert kron._apply_route == "reference"
     try:
-        assert old == "auto"
         kron.invalidate_factor_cache()
         outs, paths = [], []
         for _ in range(3):
@@ -1493,13 +1492,17 @@ def test_reference_apply_route_is_reproducible(psgd, M, N):
             ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
             assert rel_err(outs[0].cpu().numpy(), ref) < TOL
     finally:
-        kron.set_apply_route(old)
+        pass
     with pytest.raises(ValueError):
         kron.set_apply_route("fastest")
-    if kron._apply_slots[key].fn_direct is not None:                       # large layer: the default route starts on the direct chain again
-        kron.invalidate_factor_cache()
-        psgd.precond_grad_kron(Ql, Qr, G)
-        assert kron._apply_slots[key].path == "direct"
+    if kron._apply_slots[key].fn_direct is not None:                       # large layer: the opt-in route starts on the direct chain
+        assert kron.set_apply_route("auto") == "reference"
+        try:
+            kron.invalidate_factor_cache()
+            psgd.precond_grad_kron(Ql, Qr, G)
+            assert kron._apply_slots[key].path == "direct"
+        finally:
+            assert kron.set_apply_route("reference") == "auto"
 
 
 @pytest.mark.parametrize("M,N", [(1024, 1024), (1100, 520), (640, 2304), (2048, 1536)])
@@ -1513,14 +1516,18 @@ def test_large_apply_paths_direct_both_prepared(psgd, M, N):
     Gs = [_dev(rng.standard_normal((M, N)).astype(np.float32)) for _ in range(4)]
     key = (Gs[0].get_device(), M, N, kron._raw_stream(Gs[0].get_device()))
     paths = []
-    for G in Gs:
-        out = psgd.precond_grad_kron(Ql, Qr, G)
-        ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
+    old = kron.set_apply_route("auto")                     # (the opt-in fast path; the default is the reproducible route)
+    try:
+        for G in Gs:
+            out = psgd.precond_grad_kron(Ql, Qr, G)
+            ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
+            assert rel_err(out.cpu().numpy(), ref) < TOL
+            paths.append(kron._apply_slots[key].path)
+        assert paths == ["direct", "both", "prepared", "prepared"], paths
+        Ql.mul_(1.01)                                          # (version counter moves: new factors)
+        out = psgd.precond_grad_kron(Ql, Qr, Gs[0])
+        assert kron._apply_slots[key].path == "direct"
+        ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, Gs[0])))
         assert rel_err(out.cpu().numpy(), ref) < TOL
-        paths.append(kron._apply_slots[key].path)
-    assert paths == ["direct", "both", "prepared", "prepared"], paths
-    Ql.mul_(1.01)                                          # (version counter moves: new factors)
-    out = psgd.precond_grad_kron(Ql, Qr, Gs[0])
-    assert kron._apply_slots[key].path == "direct"
-    ref = orc.precond_grad_kron(*(t.cpu().numpy().astype(np.float64) for t in (Ql, Qr, Gs[0])))
-    assert rel_err(out.cpu().numpy(), ref) < TOL
+    finally:
+        kron.set_apply_route(old)

@@ -7,7 +7,7 @@ import torch
 
 from tests.uvd_cases import TINY32, make_uvd_problem
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 
 
 def _plain(p, dev):
@@ -19,6 +19,7 @@ def _into(arena, p):
         getattr(arena, name).copy_(torch.from_numpy(p[k]))
 
 
+@gpu
 @pytest.mark.parametrize("N,r", [(300_007, 20), (64_000, 10), (1_000_003, 32)])
 def test_packed_arena_gives_the_same_bits(hip_lib, N, r):
     import preconditioned_stochastic_gradient_descent as psgd
@@ -50,6 +51,7 @@ def test_packed_arena_gives_the_same_bits(hip_lib, N, r):
                                                       balance=False, update_U=True, out=arena.out.view(-1)[:-1])
 
 
+@gpu
 def test_probe_on_a_small_slab_falls_back_to_packed_and_works(hip_lib):
     """A 0.75-GiB 'two-block' slab for a 2M-row problem: the probe runs its boundary scan (13 + bisect points of the last sweep),
     sees no boundary on one uniform block and returns the packed arena, with the scan in `info`."""
@@ -89,6 +91,7 @@ def test_boundary_layout_offsets():
     assert placement.UVdArena.boundary_offsets(N, r, 4 << 30, slab) is None           # U would start below the slab
 
 
+@gpu
 def test_uvd_class_with_a_placed_state(hip_lib):
     """UVd(..., placement='packed'): same parameters and state after three steps as the plain optimizer, bit for bit."""
     import preconditioned_stochastic_gradient_descent as psgd
