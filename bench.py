@@ -627,7 +627,7 @@ def uvd_legs(dev, psgd, lib, state, r, iters):
     }
 
 
-_DROP_KEYS = {"note", "call", "timing", "batched_call", "flop_count", "runs_ms", "mfma_pmc", "sample_detail", "kernels_ms_detail", "log", "scan"}
+_DROP_KEYS = {"note", "call", "timing", "batched_call", "flop_count", "runs_ms", "mfma_pmc", "sample_detail", "kernels_ms_detail", "log", "search"}
 
 
 def _no_nan(x):
@@ -805,11 +805,10 @@ def run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_glo
            "ms_per_step": elapsed / steps * 1e3, "value": n_global * steps / elapsed}
     if arena is not None:
         inf = arena.info
-        rec["placement"] = {"mode": mode, "layout": inf.get("layout"), "slab_gib": inf.get("slab_bytes", 0) / 2**30,
-                            "boundary_gib": inf.get("boundary_gib"), "note": inf.get("note"),
-                            "probe_packed_step_ms": inf.get("packed_step_ms"),
+        rec["placement"] = {"mode": mode, "layout": inf.get("layout"), "held_gib": arena.bytes_held / 2**30,
+                            "note": inf.get("note"), "probe_packed_step_ms": inf.get("packed_step_ms"),
                             "probe_step_ms": None if "step_U_ms" not in inf else 0.5 * (inf["step_U_ms"] + inf["step_V_ms"]),
-                            "candidates": inf.get("candidates"), "log": placement_log}
+                            "candidates": inf.get("candidates"), "search": inf.get("search"), "log": placement_log}
     if keep_state:
         rec["state"] = (U, V, d, grad, v, h)
         rec["arena"] = arena

@@ -829,6 +829,8 @@ __device__ __forceinline__ int p3_tile_exps(const P3& X, int x0, int lo, int hi)
 // K tiles [lo, hi) of one operand pair.  LDS image as in k_gemm_x3: [A|B][plane][row * 4 + (chunk ^ swz(row))].  The DMA
 // writes linearly (wave base + 16 B * lane), so the swizzle is applied to the per-lane SOURCE address: the lane that
 // fills slot s = row * 4 + cpos fetches chunk cpos ^ swz(row) of that row.
+// (tile scales) cur_exp: the unit the accumulators of an output tile are in, carried from pass to pass -- the exponent sum of the K
+// tile in hand
 template <int FMT, int ER, bool TS = false>
 __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0, int lo, int hi, P3Lds<FMT>& L,
                                         f32x4 (&acc)[4][4], int* cur_exp = nullptr) {
@@ -866,6 +868,7 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
   }
   // tile scales: the exponents of this row of A tiles / B tiles, one K tile per lane (requested ahead of the DMA: older in vmcnt order)
   int vexpA = 0, vexpB = 0, cur = kTeUnset;
+  bool live = true;                         // (TS) false while a 128-k tile is being dropped (overflow guard below)
   if constexpr (TS) {
     vexpA = p3_tile_exps<FMT>(A, m0, lo, hi);
     vexpB = p3_tile_exps<FMT>(B, n0, lo, hi);
@@ -885,21 +888,48 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
       if ((k0 & 127) == 0 || k0 == lo) {                        // a new 128-k tile: are the accumulators at its scale?
         const int kb = __builtin_amdgcn_readfirstlane((k0 >> 7) - (lo >> 7));
         const int ea = __builtin_amdgcn_readlane(vexpA, kb), eb = __builtin_amdgcn_readlane(vexpB, kb);
+        live = true;
         if (ea != kTeAny && eb != kTeAny) {                     // (an all-zero tile adds zeros at any scale)
           const int c = ea + eb;
-          if (cur != kTeUnset && c != cur) {
-            const int d = c - cur;
+          const int d = (cur == kTeUnset) ? 0 : c - cur;
+          bool drop = false;
+          if (d > 0) {
+            // Moving UP to the unit of a finer tile multiplies what is already there by 2^d: look at what IS there (this wave's
+            // largest |acc|, |cross|; upward moves are rare and the matrix cores are busy meanwhile).  A tile that would push it
+            // past 2^120 is dropped instead: its whole contribution is below 2^-78 of the sum so far, and the matrix-wide
+            // scale of round 4 flushed such a tile to zero before it was ever multiplied.  Per wave: every wave
+            // carries its own accumulators and its own unit.
+            unsigned mx = 0u;
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
               for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  acc[i][j][e] = ldexpf(acc[i][j][e], d);
-                  cross[i][j][e] = ldexpf(cross[i][j][e], d);
+                  mx = max(mx, __float_as_uint(acc[i][j][e]) & 0x7fffffffu);
+                  mx = max(mx, __float_as_uint(cross[i][j][e]) & 0x7fffffffu);
                 }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+            mx = __builtin_amdgcn_readfirstlane(mx);
+            drop = mx != 0u && (int)(mx >> 23) - 127 + d > 120;
           }
-          cur = c;
+          if (drop) {
+            live = false;                                       // (the products of this 128-k tile are not issued)
+          } else {
+            if (d != 0) {
+#pragma unroll
+              for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    acc[i][j][e] = ldexpf(acc[i][j][e], d);
+                    cross[i][j][e] = ldexpf(cross[i][j][e], d);
+                  }
+            }
+            cur = c;
+          }
         }
       }
     }
@@ -945,10 +975,14 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
 #pragma unroll
     for (int j = 1; j < NT; ++j) read_b(j);
     if constexpr (EARLY > 0) {
+      // (TS: a dropped tile skips its products with a wave-uniform branch around each of the two groups -- in the common path one
+      // scalar branch, and the explicit lgkmcnt(0) below is the join, so the counted waits of the fragment reads stay as they were)
+      if (!TS || live) {
 #pragma unroll
-      for (int j = 0; j < EARLY; ++j)
+        for (int j = 0; j < EARLY; ++j)
 #pragma unroll
-        for (int i = 0; i < NT; ++i) mfma6(i, j);
+          for (int i = 0; i < NT; ++i) mfma6(i, j);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // (measured and not kept: ONE barrier per step with the next tile requested right behind it into the other stage --
@@ -958,10 +992,12 @@ __device__ __forceinline__ void p3_pass(const P3& A, const P3& B, int m0, int n0
     if (!(X3_DBG & 16)) __builtin_amdgcn_s_barrier();           // every wave holds its fragments: the buffer is free
     P3_FENCE();
     if (k0 + NS * kX3K < hi && !(X3_DBG & 1)) issue(k0 + NS * kX3K, st);   // the next tile for this stage streams in under the MFMAs
+    if (!TS || live) {
 #pragma unroll
-    for (int j = EARLY; j < NT; ++j)
+      for (int j = EARLY; j < NT; ++j)
 #pragma unroll
-      for (int i = 0; i < NT; ++i) mfma6(i, j);
+        for (int i = 0; i < NT; ++i) mfma6(i, j);
+    }
   }
   if constexpr (FMT == 1) {
 #pragma unroll
@@ -1439,17 +1475,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_gemm_p3_grad(P3Grad p) {
   }
   int r, c;
   const bool patched = p.order == 2 && !(p.T0 & 3) && !(p.T1 & 3);
-  if (id < p.n0) {
-    if (patched) upper_tile_patched(id, p.T0, r, c); else upper_tile(id, p.T0, r, c);
-    p3_body<FMT, ER, TS>(p.g[0], r, c, L);
-  } else if (id < p.n0 + whole1) {
-    if (patched) upper_tile_patched(id - p.n0, p.T1, r, c); else upper_tile(id - p.n0, p.T1, r, c);
-    p3_body<FMT, ER, TS>(p.g[1], r, c, L);
-  } else {
+  // ONE instance of the body for the three kinds of work item (round 6: three inlined copies were past the reach of a short
+  // branch, and the branch relaxation's emergency spill slot gave the kernel a private segment it never touches)
+  const int which = id < p.n0 ? 0 : 1;
+  int tile = id - (which ? p.n0 : 0);
+  P3Split sp{-1, 0, nullptr, nullptr};
+  if (id >= p.n0 + whole1) {
     const int s = id - p.n0 - whole1, t = s / p.nchunk;
-    if (patched) upper_tile_patched(whole1 + t, p.T1, r, c); else upper_tile(whole1 + t, p.T1, r, c);
-    p3_body<FMT, ER, TS>(p.g[1], r, c, L, P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t});
+    tile = whole1 + t;
+    sp = P3Split{s % p.nchunk, p.nchunk, p.scratch + (long)t * p.nchunk * (64 * kThreads), p.cnt + t};
   }
+  const int T = which ? p.T1 : p.T0;
+  if (patched) upper_tile_patched(tile, T, r, c); else upper_tile(tile, T, r, c);
+  p3_body<FMT, ER, TS>(p.g[which], r, c, L, sp);
 }
 
 // One triu product with few output tiles and a long K (the gradient of the dense factor of a sparse Kron format at

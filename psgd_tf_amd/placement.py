@@ -5,17 +5,16 @@ kernel in 4.6 or 5.05 ms depending on where its streams sit in PHYSICAL memory (
 scans found on MI355X:
   * offsets inside one physically uniform allocation do not matter at all (gaps from 256 B to 256 MiB, any order of the eight
     regions: +-0.3 %);
-  * a 48-GiB hipMalloc is backed by a 32-GiB and a 16-GiB block (the VRAM manager hands out powers of two, largest first) that come
-    from two different regions of the address map, and a stream that is WRITTEN (d, out, nablaD, the rewritten factor) runs
-    faster when it lives in the other region than the big read streams: final sweep 3.38 -> 2.91 ms with d / out / nablaD behind
-    the boundary, update sweep 2 5.05 -> 4.88 ms; read-only streams (g, v, h) do not care;
-  * a factor that lies ACROSS the boundary is rewritten fastest of all (4.62 ms), so the best layout found is
-    U in front of the boundary, V across it (about a quarter behind), every thin stream behind: 11.2 -> 10.4-10.6 ms per step;
-  * 16-, 20-, 24- and 28-GiB allocations and separate exact-size allocations all came out of ONE region (flat 11.2 ms).
-Nothing of this can be asked of the driver, so it is MEASURED: `UVdArena.probe` allocates the two-block slab when the device has
-room for it, finds the boundary by sliding the three written thin streams over the slab and timing the last sweep, times the real
-fused step (both branches) on the candidate layouts and on the packed exact-size allocation, and keeps the fastest -- the packed
-one if nothing is gained (the slab is freed again).  Results are bit-identical whatever is chosen: only addresses change.
+  * the address map has (at least) two REGIONS, and a stream that is WRITTEN (d, out, nablaD, the rewritten factor) runs faster when
+    it lives in another region than the big read streams: last sweep 3.38 -> 2.9 ms with d / out / nablaD elsewhere, update sweep 2
+    5.05 -> 4.88 ms; read-only streams (g, v, h) do not care.  11.2 -> 10.5-10.6 ms per step;
+  * where a region ends cannot be asked of the driver and is not where any fixed recipe puts it: a 48-GiB hipMalloc came back as a
+    32-GiB + 16-GiB pair of blocks with the boundary at 32 GiB on three boxes, entirely inside one region on two others (and in two
+    consecutive processes on one box); 16-, 20-, 24-, 28-GiB allocations and separate exact-size ones were always inside one region.
+So it is MEASURED.  `UVdArena.probe` keeps the factors in one power-of-two allocation and walks through the allocator's free memory
+with small thin-stream buffers (each kept while the next is tried) until a small problem's last sweep says "another region", then
+times the real fused step (both branches) on the candidates and on the packed exact-size allocation and keeps the fastest -- the
+packed one if nothing is gained.  Results are bit-identical whatever is chosen: only addresses change.
 
 Who uses it.  `UVd(..., placement="probe")` (the optimizer owns its state: psgd.py:688-690) and bench.py's headline workload.
 Callers of the functional API get the same through `uvd_placed_state`: U, V, d to pass to update_precond_UVd_math_ /
@@ -38,19 +37,33 @@ def _up(x, a=_ALIGN):
 
 
 class UVdArena:
-    """U, V, d, out, the workspace and (optionally used) input staging vectors g, v, h as views of ONE device allocation."""
+    """U, V, d, out, the workspace and (optionally used) input staging vectors g, v, h as views of device allocations this object
+    owns: `where[name] = (uint8 buffer, byte offset)`."""
 
     NAMES = ("U", "V", "d", "out", "ws", "g", "v", "h")
+    THIN = ("d", "out", "ws", "g", "v", "h")
 
-    def __init__(self, N, r, device, slab, offsets, info=None):
-        self.N, self.r, self.device, self.slab, self.offsets = int(N), int(r), torch.device(device), slab, dict(offsets)
+    def __init__(self, N, r, device, where, info=None):
+        self.N, self.r, self.device, self.where = int(N), int(r), torch.device(device), dict(where)
         self.info = info or {}
         sz = self.region_bytes(N, r)
-        view = lambda k: slab[self.offsets[k]:self.offsets[k] + sz[k]]
+
+        def view(k):
+            buf, off = self.where[k]
+            if off % _ALIGN or off < 0 or off + sz[k] > buf.numel():
+                raise ValueError("UVdArena: region %s at offset %d does not fit its buffer" % (k, off))
+            return buf[off:off + sz[k]]
         self.U = view("U").view(torch.float32).view(N, r)
         self.V = view("V").view(torch.float32).view(N, r)
         self.d, self.out, self.g, self.v, self.h = (view(k).view(torch.float32).view(N, 1) for k in ("d", "out", "g", "v", "h"))
         self.ws = view("ws")
+
+    @property
+    def bytes_held(self):
+        seen = {}
+        for buf, _ in self.where.values():
+            seen[buf.data_ptr()] = buf.numel()
+        return sum(seen.values())
 
     @staticmethod
     def region_bytes(N, r):
@@ -61,28 +74,28 @@ class UVdArena:
 
     # ---------------------------------------------------------------- layouts
     @classmethod
-    def packed_offsets(cls, N, r):
-        sz, off, cur = cls.region_bytes(N, r), {}, 0
-        for k in cls.NAMES:
+    def sequential(cls, N, r, names, start=0):
+        """offsets of `names` laid out one after the other from `start`; returns (offsets, end)"""
+        sz, off, cur = cls.region_bytes(N, r), {}, _up(start)
+        for k in names:
             off[k] = cur
             cur = _up(cur + sz[k])
         return off, cur
 
     @classmethod
-    def boundary_offsets(cls, N, r, boundary, slab_bytes, straddle=0.25):
-        """U in front of `boundary` (a byte offset of the slab), V across it with the fraction `straddle` behind (0: V ends at the
-        boundary), every thin stream behind V.  None if it does not fit."""
-        sz = cls.region_bytes(N, r)
-        F = _up(sz["U"])
-        v0 = _up(boundary - int((1.0 - straddle) * F)) if straddle > 0 else (boundary - F) // _ALIGN * _ALIGN
-        off = {"U": v0 - F, "V": v0}
-        cur = max(_up(v0 + F), _up(boundary))
-        for k in ("d", "out", "ws", "g", "v", "h"):
-            off[k] = cur
-            cur = _up(cur + sz[k])
-        if off["U"] < 0 or cur > slab_bytes:
-            return None
-        return off
+    def packed(cls, N, r, device):
+        off, total = cls.sequential(N, r, cls.NAMES)
+        slab = torch.empty(total, dtype=torch.uint8, device=device)
+        return cls(N, r, device, {k: (slab, o) for k, o in off.items()}, {"layout": "packed", "bytes": total})
+
+    @classmethod
+    def two_buffers(cls, N, r, device, fac_buf, thin_buf, info=None):
+        """U, V at the start of `fac_buf`, every thin stream at the start of `thin_buf`"""
+        fo, _ = cls.sequential(N, r, ("U", "V"))
+        to, _ = cls.sequential(N, r, cls.THIN)
+        where = {k: (fac_buf, o) for k, o in fo.items()}
+        where.update({k: (thin_buf, o) for k, o in to.items()})
+        return cls(N, r, device, where, info)
 
     def install_workspace(self, stream=None):
         """make the sweeps of this (device, N, r, stream) use the arena's workspace region (the product module's cache)"""
@@ -135,100 +148,107 @@ class UVdArena:
 
     # ---------------------------------------------------------------- the probe
     @classmethod
-    def packed(cls, N, r, device):
-        off, total = cls.packed_offsets(N, r)
-        slab = torch.empty(total, dtype=torch.uint8, device=device)
-        return cls(N, r, device, slab, off, {"layout": "packed", "slab_bytes": total})
+    def probe(cls, N, r, device, max_tries=10, min_gain=0.01, chunk_bytes=None, log=None):
+        """The faster of the packed exact-size allocation and a TWO-BUFFER arena whose buffers lie in different regions of the
+        address map: U, V in one power-of-two allocation, the thin streams (the written ones matter) in another.
 
-    @classmethod
-    def probe(cls, N, r, device, two_block_gib=None, min_gain=0.01, log=None):
-        """The fastest of: the packed exact-size slab, and layouts around the block boundary of a 2^k + 2^(k-1) slab (measured).
-        Falls back to the packed slab when the device has no room for the larger one, when no boundary shows, or when nothing
-        gains at least `min_gain`.  `log`: a list that receives one dict per timed candidate."""
+        1. the packed slab is timed on the real fused step (both branches) and freed;
+        2. the factor buffer A (2^k >= 2 * 4 N r bytes) is allocated, then thin buffers B1, B2, ... (2^j >= the six thin regions), each
+           kept while the next is tried, so that the allocator walks through its free memory: a small problem (factors of 1/16 of
+           A at its start) times its last sweep with its written thin streams inside A (same region by construction) and in
+           B_i; the first B_i that is >= 5 % faster is in another region;
+        3. (A, that B_i) is timed on the real step; so is the mirror image -- a second factor buffer A2 allocated now (it comes out
+           of the region the walk has reached) with the thin streams in B1 -- when the small problem says A2 and B1 differ;
+        4. the fastest wins -- the packed slab (allocated again) unless a candidate gains at least `min_gain`; everything else is freed.
+        `log`: a list that receives one dict per measurement."""
         device = torch.device(device)
         say = (lambda rec: log.append(rec)) if log is not None else (lambda rec: None)
         sz = cls.region_bytes(N, r)
         need = sum(_up(v) for v in sz.values())
         base = cls.packed(N, r, device)
         tb = base.time_step()
-        best, best_ms = base, 0.5 * (tb[0] + tb[1])
-        say({"layout": "packed", "slab_gib": need / GiB, "step_U_ms": tb[0], "step_V_ms": tb[1]})
+        base_ms = 0.5 * (tb[0] + tb[1])
+        say({"layout": "packed", "gib": need / GiB, "step_U_ms": tb[0], "step_V_ms": tb[1]})
         base.info.update(step_U_ms=tb[0], step_V_ms=tb[1], candidates=1)
-        # the two-block slab: 2^k + 2^(k-1) with 2^k >= what sits in front of the boundary (U and three quarters of V); the VRAM
-        # manager only has to leave its uniform top region for blocks of 32 GiB and more, so k >= 35
-        F = _up(sz["U"])
-        k = max(35, math.ceil(math.log2(max(1.75 * F, 1))))
-        slab_bytes = int(two_block_gib * GiB) if two_block_gib else (1 << k) + (1 << (k - 1))
+        pow2 = lambda x: 1 << max(21, math.ceil(math.log2(max(int(x), 1))))
+        fac_bytes = pow2(2 * _up(sz["U"]))
+        thin_bytes = chunk_bytes or pow2(sum(_up(sz[k]) for k in cls.THIN))
         free, _total = torch.cuda.mem_get_info(device)
-        if need + F > slab_bytes or free < slab_bytes + (2 << 30):
-            base.info["note"] = "no room for the two-block slab (%.0f GiB): packed" % (slab_bytes / GiB)
+        if free + need < 2 * fac_bytes + (max_tries + 1) * thin_bytes + (2 << 30):
+            base.info["note"] = "no room to look for a second region (%.0f GiB free): packed" % (free / GiB)
             return base
-        try:
-            slab = torch.empty(slab_bytes, dtype=torch.uint8, device=device)
-        except RuntimeError:                                   # (out of memory: another tenant holds the device)
-            base.info["note"] = "two-block slab allocation failed: packed"
-            return base
-        # 1. where is the boundary?  The last sweep with d / out / nablaD slid over the slab behind U and V (coarse, then fine)
-        thin3 = _up(sz["d"]) + _up(sz["out"]) + _up(sz["ws"])
-        rest = _up(sz["g"]) + _up(sz["v"]) + _up(sz["h"])
+        info0 = dict(base.info)
+        del base                                               # (the search runs in the memory state the winner will live in)
+        torch.cuda.empty_cache()
 
-        def final_ms(x):
-            off = {"U": 0, "V": F, "g": 2 * F, "v": 2 * F + _up(sz["g"]), "h": 2 * F + _up(sz["g"]) + _up(sz["v"]),
-                   "d": x, "out": x + _up(sz["d"]), "ws": x + _up(sz["d"]) + _up(sz["out"])}
-            return cls(N, r, device, slab, off).time_step(iters=3, final_only=True)[0]
-        lo, hi = 2 * F + rest, slab_bytes - thin3
-        boundary, scan = None, []
-        if hi > lo:
-            n = 13
-            xs = [_up(lo + (hi - lo) * i / (n - 1)) if i < n - 1 else hi // _ALIGN * _ALIGN for i in range(n)]
-            ts = [final_ms(x) for x in xs]
-            scan = [(x / GiB, t) for x, t in zip(xs, ts)]
-            drop = max(range(1, n), key=lambda i: ts[i - 1] - ts[i])
-            if ts[drop - 1] - ts[drop] > 0.03 * ts[drop - 1] and min(ts[drop:]) < 0.97 * max(ts[:drop]):
-                a, b = xs[drop - 1], xs[drop]                          # the streams' START crossed the boundary in (a, b]
-                for _ in range(5):                                     # bisect to ~1/32 of the coarse step
-                    m = _up((a + b) // 2)
-                    if final_ms(m) < 0.5 * (ts[drop - 1] + ts[drop]):
-                        b = m
-                    else:
-                        a = m
-                boundary = b
-                # the streams' START was timed: the drop is half done when about half of the 1.2 GiB of written streams is behind the
-                # boundary, so the boundary itself is a little above b.  Blocks are powers of two: take the most aligned multiple of
-                # 64 MiB in [b - 0.25 GiB, b + 0.9 GiB]
-                cands = [m for m in range(((b - GiB // 4) >> 26) << 26, b + (9 * GiB) // 10, 1 << 26) if m > 0]
-                if cands:
-                    boundary = max(cands, key=lambda m: (m & -m, -abs(m - b)))
-        say({"layout": "boundary scan (final sweep ms vs offset of d/out/nablaD, GiB)", "scan": scan,
-             "boundary_gib": None if boundary is None else boundary / GiB})
-        if boundary is None:
-            del slab
+        def packed_again(note, **more):
             torch.cuda.empty_cache()
-            base.info.update(note="no block boundary with an effect in a %.0f-GiB slab: packed" % (slab_bytes / GiB), scan=scan)
-            return base
-        # 2. the candidate layouts around it, on the real step
-        n_cand = 1
-        for straddle in (0.25, 0.0, 0.4):
-            off = cls.boundary_offsets(N, r, boundary, slab_bytes, straddle)
-            if off is None:
-                continue
-            cand = cls(N, r, device, slab, off, {"layout": "two-block slab, V %d %% behind the boundary" % round(100 * straddle),
-                                                 "slab_bytes": slab_bytes, "boundary_gib": boundary / GiB})
+            a = cls.packed(N, r, device)
+            a.info.update(info0)
+            a.info.update(note=note, **more)
+            return a
+        alloc = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=device)
+        try:
+            A1 = alloc(fac_bytes)
+        except RuntimeError:                                   # (out of memory: another tenant holds the device)
+            return packed_again("the factor buffer could not be allocated: packed")
+        # ---- 2. the small problem: factors of 1/16 of A
+        n = max(64, min(N, (fac_bytes // 16) // (4 * r) // 64 * 64))
+        fo, fend = cls.sequential(n, r, ("U", "V"))
+        ro, rend = cls.sequential(n, r, ("g", "v", "h"), fend)
+        wo, wend = cls.sequential(n, r, ("d", "out", "ws"), rend)          # (inside A: the same region by construction)
+        wo0, _ = cls.sequential(n, r, ("d", "out", "ws"), 0)
+
+        def small_ms(fac, thin):
+            """last sweep of the small problem: factors (and its read-only vectors) in `fac`, d / out / nablaD in `thin` (None: in fac)"""
+            where = {k: (fac, o) for k, o in list(fo.items()) + list(ro.items())}
+            where.update({k: ((fac, o) if thin is None else (thin, wo0[k])) for k, o in wo.items()})
+            return min(cls(n, r, device, where).time_step(iters=4, final_only=True)[0] for _ in range(2))
+        t_same = small_ms(A1, None)
+        Bs, tries, found = [], [], None
+        for i in range(max_tries):
+            try:
+                Bs.append(alloc(thin_bytes))
+            except RuntimeError:
+                break
+            t = small_ms(A1, Bs[-1])
+            tries.append(t)
+            if t < 0.95 * t_same:
+                found = i
+                break
+        say({"layout": "region search: last sweep of a %d-row problem (ms) with its written streams inside the factor buffer, then in "
+                       "thin buffer 1, 2, ..." % n, "same_buffer_ms": t_same, "thin_buffer_ms": tries,
+             "factor_buffer_gib": fac_bytes / GiB, "thin_buffer_gib": thin_bytes / GiB})
+        if found is None:
+            del A1, Bs
+            return packed_again("no second region within %d thin buffers of %.0f GiB: packed" % (len(tries), thin_bytes / GiB),
+                                search={"same_buffer_ms": t_same, "thin_buffer_ms": tries})
+        # ---- 3. the candidates on the real step
+        cands = [("factors in buffer A, thin streams in thin buffer %d" % (found + 1), A1, Bs[found])]
+        if found > 0:                                          # B1 shares A's region: the mirror image needs factors in the other one
+            try:
+                A2 = alloc(fac_bytes)
+                if small_ms(A2, Bs[0]) < 0.95 * small_ms(A2, None):
+                    cands.append(("factors in a second buffer A2, thin streams in thin buffer 1", A2, Bs[0]))
+                del A2
+            except RuntimeError:
+                pass
+        best, best_ms, n_cand = None, base_ms * (1.0 - min_gain), 1
+        for name, fac, thin in cands:
+            cand = cls.two_buffers(N, r, device, fac, thin, {"layout": "two regions: " + name, "bytes": fac.numel() + thin.numel()})
             t = cand.time_step()
             n_cand += 1
-            say({"layout": cand.info["layout"], "slab_gib": slab_bytes / GiB, "boundary_gib": boundary / GiB,
-                 "step_U_ms": t[0], "step_V_ms": t[1], "offsets_gib": {k_: v / GiB for k_, v in off.items()}})
+            say({"layout": cand.info["layout"], "gib": (fac.numel() + thin.numel()) / GiB, "step_U_ms": t[0], "step_V_ms": t[1]})
             cand.info.update(step_U_ms=t[0], step_V_ms=t[1])
-            if 0.5 * (t[0] + t[1]) < best_ms * (1.0 - (min_gain if best is base else 0.0)):
+            if 0.5 * (t[0] + t[1]) < best_ms:
                 best, best_ms = cand, 0.5 * (t[0] + t[1])
-        best.info.update(candidates=n_cand, packed_step_ms=0.5 * (tb[0] + tb[1]), scan=scan)
-        if best is base:
-            del slab
-            torch.cuda.empty_cache()
-            base.info["note"] = "no layout of the two-block slab gained %.0f %%: packed" % (100 * min_gain)
-        else:
-            del base
-            torch.cuda.empty_cache()
+            del cand
+        del cands, A1, Bs, fac, thin
+        if best is None:
+            return packed_again("no two-region layout gained %.0f %%: packed" % (100 * min_gain), candidates=n_cand,
+                                search={"same_buffer_ms": t_same, "thin_buffer_ms": tries})
+        best.info.update(candidates=n_cand, packed_step_ms=base_ms, search={"same_buffer_ms": t_same, "thin_buffer_ms": tries})
+        torch.cuda.empty_cache()                               # (the buffers nothing refers to any more go back to the driver)
         return best
 
 

@@ -188,7 +188,11 @@ def global_norm(x, group=None):
     """2-norm of the global vector whose rows on this rank are x (the clip norm of psgd.py:753): the local sum of squares in fp64,
     ONE scalar all-reduce (every rank receives the same bits), the root as a device tensor of x's dtype -- no host read."""
     sq = torch.sum(x.to(torch.float64) ** 2).reshape(1)
-    dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=group)
+    comm = _direct_comm(group, sq.device) if sq.is_cuda else None
+    if comm is not None:
+        comm.all_reduce_sum_f64(sq, torch.cuda.current_stream(sq.device).cuda_stream)
+    else:
+        dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=group)
     return torch.sqrt(sq[0]).to(x.dtype)
 
 
@@ -241,12 +245,90 @@ def _agree_on_branches(balance, update_U, generator, device, group):
     return b, u
 
 
+class _RcclDirect:
+    """An RCCL communicator of our own for the exchanges, used through ctypes so that the all-gather is enqueued on the CALLER'S
+    stream -- sweep, collective and fold are then one stream-ordered sequence.  torch.distributed runs NCCL / RCCL collectives on a
+    stream of the process group: every exchange is a hop there and back (two cross-stream event waits), which measured 26-64 us per
+    step on a 1.37-ms step.  The unique id travels over the existing torch.distributed group once, at set-up."""
+
+    class _Uid(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_byte * 128)]
+
+    NCCL_FLOAT64 = 8        # ncclDataType_t
+
+    def __init__(self, group, device):
+        import os
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        lib = self.lib
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(self._Uid)]
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._Uid, ctypes.c_int]
+        lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p]
+        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = self._Uid()
+        if self.rank == 0:
+            self._check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        buf = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+        dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), bytes(buf.cpu().numpy().tobytes()), 128)
+        self.comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            self._check(lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise _lib.PsgdHipError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def all_gather_f64(self, send, recv, stream):
+        """recv[rank k] = rank k's send (fp64, contiguous device tensors), enqueued on `stream` (a raw hipStream_t)"""
+        self._check(self.lib.ncclAllGather(send.data_ptr(), recv.data_ptr(), send.numel(), self.NCCL_FLOAT64, self.comm, stream),
+                    "ncclAllGather")
+
+
+    def all_reduce_sum_f64(self, t, stream):
+        """in place SUM over the ranks of a contiguous fp64 device tensor, enqueued on `stream`"""
+        self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), self.NCCL_FLOAT64, 0, self.comm, stream),
+                    "ncclAllReduce")
+
+
+_direct_comms = {}
+EXCHANGES = {"count": 0}    # exchange points passed since import (tests count them per step whatever carries the collective)
+DIRECT_RCCL = True      # exchanges of the HIP backend on RCCL groups go through _RcclDirect (PSGD_DIRECT_RCCL=0 or False: torch.distributed)
+
+
+def _direct_comm(group, device):
+    """the _RcclDirect of (group, device), or None when the exchange should go through torch.distributed (gloo groups, the switch
+    off, or a set-up failure -- reported once)"""
+    import os
+    if not DIRECT_RCCL or os.environ.get("PSGD_DIRECT_RCCL", "1") == "0" or dist.get_backend(group) != "nccl":
+        return None
+    key = (id(group) if group is not None else None, torch.device(device).index)
+    if key not in _direct_comms:
+        try:
+            _direct_comms[key] = (group, _RcclDirect(group, device))       # (the strong reference keeps id() unique)
+        except Exception as exc:                                            # noqa: BLE001 -- any failure means "use torch.distributed"
+            import warnings
+            warnings.warn("psgd_tf_amd.sharded: direct RCCL communicator not available (%s); exchanges use torch.distributed" % (exc,))
+            _direct_comms[key] = (group, None)
+    return _direct_comms[key][1]
+
+
 def _exchange(be, stage, group):
     """One exchange point = one collective: all-gather the send regions, fold them in rank order on every rank."""
+    EXCHANGES["count"] += 1
     world = dist.get_world_size(group)
     send = be.send(stage)
     gathered = be.gather_buf(stage, world)
-    dist.all_gather_into_tensor(gathered, send, group=group)
+    comm = _direct_comm(group, send.device) if send.is_cuda else None
+    if comm is not None:
+        comm.all_gather_f64(send, gathered, torch.cuda.current_stream(send.device).cuda_stream)
+    else:
+        dist.all_gather_into_tensor(gathered, send, group=group)
     be.fold(stage, gathered, world)
 
 

@@ -36,7 +36,7 @@ def test_bench_single_gpu_line(hip_lib):
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["scaling"] is None                                  # one GPU: neither weak nor strong
     pl = d["config"]["placement"]                                # the state's allocator ran its probe and says what it kept
-    assert pl["mode"] == "probe" and pl["layout"] and pl["candidates"] >= 1 and "log" not in pl
+    assert pl["mode"] == "probe" and pl["layout"] and pl["candidates"] >= 1 and pl["held_gib"] > 0 and "log" not in pl
     # the figures the north star names, as scalars of `roofline` (what the driver's record keeps)
     rf = d["roofline"]
     for k in ("apply_ms", "apply_frac", "apply_frac_moved", "update_ms", "update_frac", "step_frac", "step_frac_moved",

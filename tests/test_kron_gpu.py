@@ -948,6 +948,35 @@ def test_tile_scales_with_magnitudes_that_change_along_k(psgd, direction):
         assert torch.isfinite(g).all() and rel_err(g.cpu().numpy(), rr) < TOL
 
 
+@pytest.mark.parametrize("tiny", [1e-20, 1e-30])
+def test_tile_scales_do_not_overflow_behind_a_tiny_tile(psgd, tiny):
+    """moving the accumulators UP to the unit of a much finer K tile multiplied them by 2^(c - cur) with no clamp --
+    blocks of the data scaled by 1e-20 / 1e-30 (2^-66 / 2^-100) behind full-size ones gave accumulators of 2^30 * 2^100 = inf.
+    Now such a tile is dropped (it is below fp32 resolution of the sum, and the matrix-wide scale of round 4 flushed it to zero
+    anyway): finite results at the parity tolerance for the apply and both gradient branches of the update, with the tiny blocks
+    placed so that the contraction of every chained product meets them AFTER large tiles (falling) and before (rising)."""
+    M, N = 2304, 2048
+    rng = np.random.default_rng(33)
+    Ql, Qr = _tri_factor(rng, M, 0.02).astype(np.float32), _tri_factor(rng, N, 0.02).astype(np.float32)
+    for where in ("tail", "head", "middle"):
+        G = rng.standard_normal((M, N))
+        rows = {"tail": slice(M - 640, M), "head": slice(0, 640), "middle": slice(900, 1412)}[where]
+        cols = {"tail": slice(N - 512, N), "head": slice(0, 512), "middle": slice(700, 1212)}[where]
+        G[rows, :] *= tiny
+        G[:, cols] *= tiny
+        G = G.astype(np.float32)
+        ref = orc.precond_grad_kron(Ql.astype(np.float64), Qr.astype(np.float64), G.astype(np.float64))
+        out = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G)).cpu().numpy().astype(np.float64)
+        assert np.isfinite(out).all(), where
+        assert rel_err(out, ref) < TOL and np.max(np.abs(out - ref)) < TOL * np.max(np.abs(ref)), where
+        dX = rng.standard_normal((M, N)).astype(np.float32)
+        for dXv, dGv in ((dX, G), (G, dX)):                  # the tiny blocks in dG (the A chain) and in dX (the solve chain)
+            r = orc.update_precond_kron(*(a.astype(np.float64) for a in (Ql, Qr, dXv, dGv)), 0.01)
+            got = psgd.update_precond_kron(_dev(Ql), _dev(Qr), _dev(dXv), _dev(dGv), 0.01)
+            for g, rr in zip(got, r):
+                assert torch.isfinite(g).all() and rel_err(g.cpu().numpy(), rr) < TOL, where
+
+
 def test_large_update_propagates_nan_through_tile_scales(psgd):
     """A NaN in the data reaches both new factors on the large path too (a tile that holds one gets scale 1; the values carry it)."""
     M, N = 2048, 2176
