@@ -45,9 +45,10 @@ extern "C" {
  * 6 = round 5 (psgd_uvd_apply_cols_f32 added: precond_grad_UVd_math on a matrix g; psgd_uvd_gram_wide_f32 and the psgd_uvd_wide_*
  * entry points of ranks 33 .. 64 added (building blocks, update, fused update -> apply); the sparse-LU entry points take ranks up to PSGD_SPLU_MAX_RANK = 64 and their workspace
  * regions have that capacity -- offsets from psgd_splu_ws_region changed; the fused strip kernels of small Kron layers and their
- * tuning key 21 removed: Kron workspaces of small layers shrink back by that scratch).
+ * tuning key 21 removed: Kron workspaces of small layers shrink back by that scratch);
+ * 7 = round 6 (psgd_kron_bf16_handoff_counter_offset added; bf16 tuning key 7: XCD patch of the fused pair; no layout change).
  * psgd_tf_amd/_lib.py refuses a library whose psgd_abi_version() differs from the one it was written for. */
-#define PSGD_ABI_VERSION 6
+#define PSGD_ABI_VERSION 7
 
 #define PSGD_OK                 0
 #define PSGD_ERR_BAD_ARG       (-1)   /* null pointer, N <= 0, r <= 0 ...            */
@@ -451,7 +452,10 @@ int64_t psgd_kron_dd_workspace_bytes_bf16(int M, int N);
  *        rounds + a stream-K tail finished by a second launch (M = N multiples of 256 with at least one tile per CU: 4096^2
  *        502 -> 262 us); 0 = the 128^2 one-tile-per-workgroup kernel for every shape; 2 / 3 = the stream-K launches for every
  *        shape the kernel can take, with / without whole-tile rounds (tests).
- * key 5: bf16-operand update, the factor updates (:179): 1 (default) tiles in 4 x 4 patches per XCD, 0 = whole tile rows. */
+ * key 5: bf16-operand update, the factor updates (:179): 1 (default) tiles in 4 x 4 patches per XCD, 0 = whole tile rows.
+ * key 7: fused triangular pair of the apply: tile rows of the patch an XCD works on (4: 4 x 8 tiles per XCD at 4096^2, 12 operand panels per
+ *        K step and L2 instead of 18); 0 = whole tile columns per XCD (rounds 1-5); -1 (default) = 8 from 32 tile rows on, 0 below (the
+ *        only shapes where it was measured to gain).  Results are bitwise the same. */
 int psgd_kron_bf16_set_tuning(int key, int value);
 int psgd_kron_dd_apply_bf16(const float *Ql, const float *Qr, const void *G_bf16,
                             void *out_bf16, int M, int N, void *ws,
@@ -484,6 +488,10 @@ int psgd_kron_dd_update_bf16(const float *Ql, const float *Qr, const void *dX_bf
  * caller-owned memory).                                                                                              */
 int psgd_kron_bf16_handoff_timeouts(const void *ws, int M, int N);
 int psgd_kron_bf16_handoff_reset(void *ws, int M, int N, void *stream);
+/* Byte offset of that 32-bit recovery counter inside a workspace of shape (M, N) (round 6): a caller that wants to WATCH it without
+ * synchronising copies the word to pinned host memory asynchronously now and then (psgd_tf_amd/kron.py does, and switches to the
+ * hand-off-free kernels by itself after three recoveries).  < 0 on a bad shape.                                                     */
+int64_t psgd_kron_bf16_handoff_counter_offset(int M, int N);
 #ifdef __cplusplus
 }
 #endif

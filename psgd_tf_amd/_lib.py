@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("PSGD_HIP_LIB", os.path.join(_CSRC, "libpsgd_hip.so"))
 
 PSGD_OK = 0
 PSGD_ERR_BAD_ARG, PSGD_ERR_RANK, PSGD_ERR_WORKSPACE, PSGD_ERR_ALIGN, PSGD_ERR_LAUNCH, PSGD_ERR_SHAPE = -1, -2, -3, -4, -5, -6
-PSGD_ABI_VERSION = 6       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
+PSGD_ABI_VERSION = 7       # must equal include/psgd_hip.h (bumped on every incompatible change of symbols or workspace layout)
 PSGD_WS_SUMS_F64 = 0
 PSGD_WS_MAX_F32 = 1
 PSGD_WS_SEND_F64 = 2
@@ -126,6 +126,7 @@ SIGNATURES = {
     "psgd_kron_dd_workspace_bytes_bf16": (_i64, [_int, _int]),
     "psgd_kron_bf16_handoff_timeouts": (_int, [_c_ws, _int, _int]),
     "psgd_kron_bf16_handoff_reset": (_int, [_c_ws, _int, _int, _strm]),
+    "psgd_kron_bf16_handoff_counter_offset": (_i64, [_int, _int]),
     "psgd_kron_dd_update_workspace_bytes_bf16": (_i64, [_int, _int]),
     "psgd_kron_dd_update_bf16": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, _int, _flt, _flt,
                                         _c_ws, _i64, _strm]),

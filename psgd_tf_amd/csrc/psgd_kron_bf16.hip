@@ -788,6 +788,7 @@ struct HPairArgs {
   unsigned* flags;                 // [M/256][N/256], zeroed before the launch
   unsigned* timeout;               // recoveries so far: +1 whenever a spin gave up and the consumer produced the tile itself
   unsigned spin_limit;             // polls before giving up (2^22 x ~64 cycles ~ 0.5 s; tests shrink it)
+  int patch;                       // > 0: tile rows of an XCD's patch (tri_pair_body); 0: whole tile columns per XCD
 };
 
 template <int DMAPOS>
@@ -798,8 +799,21 @@ __device__ __forceinline__ void tri_pair_body(const HPairArgs& p, const int bid,
   const int tiles_m = p.M / T2, tiles_n = p.N / T2;
   // blocks b, b + 8, ... share an XCD: give each XCD whole tile columns (the hand-offs of a column stay on one L2
   // when the column count allows); rows ascend with the block index inside a column
+  // Round 6 (patch > 0): an XCD gets a PATCH of `patch` tile rows x (tiles per XCD / patch) tile columns instead.  A K step of the
+  // XCD then pulls patch + columns operand panels through its L2 (4 + 8 = 12 at 4096^2, what the dense kernel's 4 x 8 patch pulls)
+  // where whole columns pull 16 + 2 = 18; in phase B every row of a patch reads the SAME T3 chunk at the same time (chunk j is
+  // consumed at time 16 - j by every row >= j).  The hand-offs of a column then cross XCDs: they always were agent-scope (write-through
+  // stores, agent-scope flag, agent-scope acquire) because the non-multiple-of-8 mapping below spreads a column over the XCDs too.
+  // Which CU computes a tile changes; what it computes, and in which order, does not: results are bitwise the same.
   int r, c;
-  if (p.c_count % 8 == 0) {
+  const int total = tiles_m * p.c_count;
+  if (p.patch > 0 && total % 8 == 0 && tiles_m % p.patch == 0 && (total / 8) % p.patch == 0 &&
+      p.c_count % ((total / 8) / p.patch) == 0) {
+    const int xcd = bid % 8, j = bid / 8, pc = (total / 8) / p.patch;      // patch: p.patch rows x pc columns
+    const int pcols = p.c_count / pc;                                       // patches side by side
+    r = (xcd / pcols) * p.patch + j % p.patch;
+    c = p.c_begin + (xcd % pcols) * pc + j / p.patch;
+  } else if (p.c_count % 8 == 0) {
     const int xcd = bid % 8, j = bid / 8, cpx = p.c_count / 8;
     c = p.c_begin + xcd * cpx + j / tiles_m;
     r = j % tiles_m;
@@ -1391,6 +1405,10 @@ static int launch_hgemm_two(const HGemmArgs& g0, const HGemmArgs& g1, hipStream_
 
 static int device_cu_count();
 // ---- stream-K launches (k_hgemm_sk_256) ---------------------------------------------------------------------------------
+static int g_pair_xcd_patch = -1; // psgd_kron_bf16_set_tuning key 7: tile rows of an XCD's patch in the fused pair; 0 = whole tile columns per XCD
+                                  // (rounds 1-5); -1 (default) = by shape: 8 from 32 tile rows on (8192 x 2048: 0.411 -> 0.386 ms), 0 below --
+                                  // at 4096^2 the patch (12 operand panels per K step and L2 instead of 18) changes NOTHING: 0.2575 ms either
+                                  // way, bitwise equal (profiles/r06_bf16_patch_ab.txt): the pair's K loop is not bound by its L2 panels
 static int g_pair_merge_whatif = 0;   // psgd_kron_bf16_set_tuning key 6: 1 = WHAT-IF, wrong results: the apply's two fused pairs as one grid (see k_hgemm_tri_pair2_256)
 static int g_pair_patch = 1;      // psgd_kron_bf16_set_tuning key 5: 1 (default) = the factor updates' tiles in 4 x 4 patches (hgemm_tile_coords,
                                   // sym == 2; from 32 x 32 tiles of 128 on: 4096^2 update 1.716 -> 1.698 ms, equal elsewhere), 0 = tile rows
@@ -1530,7 +1548,8 @@ static int launch_tri_pair(const HWs& k, const uint16_t* Q, const uint16_t* Qt, 
   for (int c0 = 0; c0 < tiles_n; c0 += cpl) {
     const int cc = (tiles_n - c0 < cpl) ? tiles_n - c0 : cpl;
     HPairArgs p = {Q, Mk, B1, Mk, T3, Mk, Qt, Mk, out, ldo, 1, out_trans, Mk, Nk, c0, cc,
-                   k.flags + 4 + flag_set * tiles_m * tiles_n, k.flags, g_spin_limit};
+                   k.flags + 4 + flag_set * tiles_m * tiles_n, k.flags, g_spin_limit,
+                   g_pair_xcd_patch >= 0 ? g_pair_xcd_patch : (tiles_m >= 32 ? 8 : 0)};
     hipLaunchKernelGGL(k_hgemm_tri_pair_256<0>, dim3(tiles_m * cc), dim3(kThreads2), 0, st, p);
     if (hipGetLastError() != hipSuccess) return 1;
   }
@@ -1649,6 +1668,7 @@ int psgd_kron_bf16_set_tuning(int key, int value) {
   if (key == 4) { g_streamk = value; return PSGD_OK; }
   if (key == 5) { g_pair_patch = value; return PSGD_OK; }
   if (key == 6) { g_pair_merge_whatif = value; return PSGD_OK; }
+  if (key == 7) { g_pair_xcd_patch = (value < 0 || value > 16) ? -1 : value; return PSGD_OK; }
   if (key == 2) { g_spin_limit = (value < 0 || value > 30) ? (1u << 22) : (1u << value); return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
@@ -1659,6 +1679,12 @@ int psgd_kron_bf16_handoff_timeouts(const void* ws, int M, int N) {
   unsigned v = 0;
   if (hipMemcpy(&v, k.flags, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return PSGD_ERR_LAUNCH;
   return (int)v;
+}
+
+int64_t psgd_kron_bf16_handoff_counter_offset(int M, int N) {
+  if (M <= 0 || N <= 0) return PSGD_ERR_BAD_ARG;
+  HWs k = hws_layout(static_cast<char*>(nullptr), M, N);
+  return (int64_t)(reinterpret_cast<char*>(k.flags) - static_cast<char*>(nullptr));
 }
 
 int psgd_kron_bf16_handoff_reset(void* ws, int M, int N, void* stream) {

@@ -495,6 +495,57 @@ def check_bf16_handoffs():
     return total
 
 
+# ---- automatic switch to the hand-off-free kernels (round 6).  The fused pair recovers from a hand-off whose producer was not
+# resident in time, but every recovery costs up to its wait bound (~0.5 s): on a device that is persistently shared each call can
+# pay it.  Every HANDOFF_CHECK_EVERY-th bf16 apply on a workspace copies the workspace's recovery counter to pinned host memory
+# WITHOUT synchronising (the copy rides on the stream; its result is read a later call, once its event has completed); after
+# HANDOFF_FALLBACK_AFTER recoveries on one workspace the library switches -- for the process -- to the kernels without in-launch
+# hand-offs (psgd_kron_bf16_set_tuning(0, 4)) and says so once.  bf16_handoff_fallback_active() tells; reset_bf16_handoff_fallback()
+# goes back (e.g. when the other tenant has left).
+HANDOFF_CHECK_EVERY = 16
+HANDOFF_FALLBACK_AFTER = 3
+_handoff_watch = {}       # workspace key -> [calls, counter view, pinned host word, event or None, count at reset]
+_handoff_fallback = [False]
+
+
+def bf16_handoff_fallback_active():
+    return _handoff_fallback[0]
+
+
+def reset_bf16_handoff_fallback():
+    """Back to the fused pairs (the default route) after an automatic fall-back; the recovery counts start from zero."""
+    if _handoff_fallback[0]:
+        _lib.check(_lib.load().psgd_kron_bf16_set_tuning(0, 0), "psgd_kron_bf16_set_tuning")
+        _handoff_fallback[0] = False
+    _handoff_watch.clear()
+
+
+def _watch_handoffs(key, ws, M, N, device):
+    w = _handoff_watch.get(key)
+    if w is None or w[1].data_ptr() < ws.data_ptr() or w[1].data_ptr() >= ws.data_ptr() + ws.numel():
+        off = int(_lib.load().psgd_kron_bf16_handoff_counter_offset(M, N))
+        if off < 0:
+            return
+        w = _handoff_watch[key] = [0, ws[off:off + 4].view(torch.int32), torch.zeros(1, dtype=torch.int32).pin_memory(), None, None]
+    w[0] += 1
+    if w[3] is not None and w[3].query():                  # an earlier copy has landed: look at it
+        seen = int(w[2][0])
+        w[3] = None
+        if w[4] is None:
+            w[4] = seen                                     # (counts from before the watch started do not count)
+        elif seen - w[4] >= HANDOFF_FALLBACK_AFTER and not _handoff_fallback[0]:
+            import warnings
+            _lib.check(_lib.load().psgd_kron_bf16_set_tuning(0, 4), "psgd_kron_bf16_set_tuning")
+            _handoff_fallback[0] = True
+            warnings.warn("psgd_tf_amd.kron: %d hand-offs of the fused bf16 pairs ran into their wait bound on this device (other "
+                          "work holds its CUs): switched to the kernels without in-launch hand-offs "
+                          "(kron.reset_bf16_handoff_fallback() goes back)" % (seen - w[4]))
+    if w[3] is None and (w[0] % HANDOFF_CHECK_EVERY == 1) and not torch.cuda.is_current_stream_capturing():
+        w[2].copy_(w[1], non_blocking=True)
+        w[3] = torch.cuda.Event()
+        w[3].record(torch.cuda.current_stream(device))
+
+
 def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     """psgd.py:182-192 with bf16 MFMA operands (Grad and result in bf16, fp32 master factors)."""
     M, N = Grad.shape
@@ -523,6 +574,8 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
         _bf16_prepared[key] = _FactorTag((Ql, Qr))
     rc = lib.psgd_kron_dd_apply_bf16_prepared(Grad.data_ptr(), out.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "psgd_kron_dd_apply_bf16_prepared")
+    if not _handoff_fallback[0]:
+        _watch_handoffs(key, ws, M, N, Grad.device)
     return out
 
 

@@ -37,7 +37,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.psgd_abi_version() == _lib.PSGD_ABI_VERSION == 6
+    assert lib.psgd_abi_version() == _lib.PSGD_ABI_VERSION == 7
     assert lib.psgd_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -6):
         assert len(lib.psgd_error_string(code)) > 3

@@ -266,6 +266,7 @@ def test_bf16_fused_pair_on_a_shared_device(psgd):
     rng = np.random.default_rng(7)
     Ql, Qr = _dev(_tri_factor(rng, M, 0.01).astype(np.float32)), _dev(_tri_factor(rng, N, 0.01).astype(np.float32))
     G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16)
+    kron.HANDOFF_FALLBACK_AFTER = 1 << 30                  # (this test provokes recoveries on purpose: the automatic switch stays out of it)
     want = psgd.precond_grad_kron(Ql, Qr, G)
     torch.cuda.synchronize()
     assert torch.isfinite(want.float()).all()
@@ -314,6 +315,54 @@ def test_bf16_fused_pair_on_a_shared_device(psgd):
             lib.psgd_kron_bf16_handoff_reset(kron._kron_ws_bf16[key].data_ptr(), m, n, None)
     torch.cuda.synchronize()
     assert kron.check_bf16_handoffs() == 0
+    kron.HANDOFF_FALLBACK_AFTER = 3
+    kron.reset_bf16_handoff_fallback()
+    assert not kron.bf16_handoff_fallback_active()
+
+
+def test_bf16_handoff_fallback_switches_by_itself(psgd):
+    """Round 6: the library watches the recovery counter of a bf16 apply workspace without synchronising (an asynchronous copy of
+    the word every HANDOFF_CHECK_EVERY-th call) and, after HANDOFF_FALLBACK_AFTER recoveries, switches to the kernels without
+    in-launch hand-offs by itself -- a shared device then stops paying the wait bound on every call.  Provoked with a poll bound
+    of 1; the results before and after the switch agree with the fp64 oracle, and reset_bf16_handoff_fallback() goes back."""
+    import warnings
+    from psgd_tf_amd import _lib, kron
+    lib = _lib.load()
+    M, N = 2048, 2304
+    rng = np.random.default_rng(17)
+    Ql, Qr = _dev(_tri_factor(rng, M, 0.01).astype(np.float32)), _dev(_tri_factor(rng, N, 0.01).astype(np.float32))
+    G = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda().to(torch.bfloat16)
+    ref = orc.precond_grad_kron(*(t.float().cpu().numpy().astype(np.float64) for t in (Ql, Qr, G)))
+    kron.reset_bf16_handoff_fallback()
+    want = psgd.precond_grad_kron(Ql, Qr, G)
+    torch.cuda.synchronize()
+    keep = kron.HANDOFF_CHECK_EVERY
+    try:
+        kron.HANDOFF_CHECK_EVERY = 2
+        lib.psgd_kron_bf16_set_tuning(2, 0)                                   # nearly every hand-off gives up and recovers
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for i in range(40):
+                out = psgd.precond_grad_kron(Ql, Qr, G)
+                torch.cuda.synchronize()
+                if kron.bf16_handoff_fallback_active():
+                    break
+        assert kron.bf16_handoff_fallback_active(), "no switch after 40 calls with recoveries"
+        assert any("hand-offs" in str(w_.message) for w_ in caught)
+        assert torch.equal(out, want)                                          # (the call that noticed still ran the fused pair)
+        safe = psgd.precond_grad_kron(Ql, Qr, G)                               # ... this one runs without in-launch hand-offs
+        torch.cuda.synchronize()
+        assert torch.isfinite(safe.float()).all() and rel_err(safe.float().cpu().numpy(), ref) < 2e-2
+    finally:
+        kron.HANDOFF_CHECK_EVERY = keep
+        lib.psgd_kron_bf16_set_tuning(2, 22)
+        kron.reset_bf16_handoff_fallback()
+        for key, (m, n) in kron._bf16_apply_shapes.items():
+            if key in kron._kron_ws_bf16:
+                lib.psgd_kron_bf16_handoff_reset(kron._kron_ws_bf16[key].data_ptr(), m, n, None)
+        torch.cuda.synchronize()
+    assert not kron.bf16_handoff_fallback_active()
+    assert torch.equal(psgd.precond_grad_kron(Ql, Qr, G), want)
     assert torch.equal(psgd.precond_grad_kron(Ql, Qr, G), want)
 
 
