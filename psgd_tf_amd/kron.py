@@ -249,6 +249,13 @@ class layer_batch:
         _batch_ctx = None
         if exc_type is None:
             self.flush()
+        else:
+            # the block is left by an exception: the queued calls are dropped, and the tensors they already returned must not be
+            # readable as results -- NaN, not whatever the allocator left there
+            for it in self.items:
+                for o in (it[-1] if isinstance(it[-1], tuple) else (it[-1],)):
+                    o.fill_(float("nan"))
+            self.items, self.kind = [], None
         return False
 
     def flush(self):
@@ -708,7 +715,12 @@ def precond_grad_kron_batched(Qls, Qrs, Grads, outs=None):
     if not (len(Qls) == len(Qrs) == len(Grads)):
         raise ValueError("precond_grad_kron_batched: the three lists must have one length")
     if not _batched_ok(Qls, Qrs, Grads):
-        return [precond_grad_kron(a, b, g) for a, b, g in zip(Qls, Qrs, Grads)]
+        res = [precond_grad_kron(a, b, g) for a, b, g in zip(Qls, Qrs, Grads)]
+        if outs is not None:                         # (a caller that handed out `outs` already must find the results there)
+            for o, r_ in zip(outs, res):
+                o.copy_(r_)
+            return list(outs)
+        return res
     for a, b, g in zip(Qls, Qrs, Grads):
         _check_rank2_f32("precond_grad_kron_batched", a, b, g)
         _check_kron_shapes("precond_grad_kron_batched", a, b, g)
@@ -739,8 +751,15 @@ def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01, outs=None):
     Qls, Qrs, dXs, dGs = list(Qls), list(Qrs), list(dXs), list(dGs)
     if not (len(Qls) == len(Qrs) == len(dXs) == len(dGs)):
         raise ValueError("update_precond_kron_batched: the four lists must have one length")
+    def _fill(res):                                  # (a caller that handed out `outs` already must find the results there)
+        if outs is None:
+            return res
+        for (ol, orr), (a, b) in zip(outs, res):
+            ol.copy_(a)
+            orr.copy_(b)
+        return [tuple(o) for o in outs]
     if not (_batched_ok(Qls, Qrs, dXs) and _batched_ok(Qls, Qrs, dGs)):
-        return [update_precond_kron(a, b, x, g, step) for a, b, x, g in zip(Qls, Qrs, dXs, dGs)]
+        return _fill([update_precond_kron(a, b, x, g, step) for a, b, x, g in zip(Qls, Qrs, dXs, dGs)])
     small = [i for i, x in enumerate(dXs) if max(x.shape) <= 512]
     if len(small) < len(dXs):
         # a mixed list (the LSTM / NMT drivers mix sizes across 512): the small layers -- launch-bound -- still share their
@@ -753,7 +772,7 @@ def update_precond_kron_batched(Qls, Qrs, dXs, dGs, step=0.01, outs=None):
         for i in range(len(dXs)):
             if out[i] is None:
                 out[i] = update_precond_kron(Qls[i], Qrs[i], dXs[i], dGs[i], step)
-        return out
+        return _fill(out)
     for a, b, x, g in zip(Qls, Qrs, dXs, dGs):
         _check_rank2_f32("update_precond_kron_batched", a, b, x, g)
         _check_kron_shapes("update_precond_kron_batched", a, b, x, g)

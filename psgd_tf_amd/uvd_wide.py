@@ -169,7 +169,7 @@ class _Ctx:
         n = int(self.lib.psgd_uvd_gram_wide_scratch_bytes(self.N, self.r))
         if n < 0:
             _lib.check(n, "psgd_uvd_gram_wide_scratch_bytes")
-        key = (self.dev.index, self.N, self.r)
+        key = (self.dev.index, self.st, self.N, self.r)      # per stream: two streams must not share the fp64 partials
         scr = _gram_scratch.get(key)
         if scr is None or scr.numel() < n:
             scr = _gram_scratch[key] = torch.empty(n, dtype=torch.uint8, device=self.dev)

@@ -1515,8 +1515,10 @@ def test_layer_batch_block_equals_the_batched_entry_points(psgd):
     # an exception inside the block leaves the module usable (nothing is launched for the abandoned queue)
     with pytest.raises(ZeroDivisionError):
         with kron.layer_batch():
-            psgd.precond_grad_kron(Qls[0], Qrs[0], Gs[0])
+            dropped = psgd.precond_grad_kron(Qls[0], Qrs[0], Gs[0])
+            dropped_u = psgd.update_precond_kron(Qls[1], Qrs[1], Gs[1], Gs[1], 0.01) if False else None
             1 / 0
+    assert torch.isnan(dropped).all()                     # (what the abandoned call had handed out is marked, not stale memory)
     assert torch.equal(psgd.precond_grad_kron(Qls[0], Qrs[0], Gs[0]), want_a[0])
     # captured: the graph holds the batched launches
     n5 = 5
