@@ -829,20 +829,34 @@ def exchange_overhead(args, psgd, sharded, lib, dev, rows, steps):
         dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
     try:
         import statistics
+        # ONE set of tensors for both paths (round 6): where d / out / the workspace land relative to the factors is worth +-2 % of a step
+        #  -- more than the exchanges cost -- so two separately allocated problems cannot be compared at this resolution
+        r = args.rank_r
+        U, V, d, grad, v, h = make_inputs(rows, rows, r, dev, seed=0)
+        paths = {"unsharded": psgd, "sharded_1rank": sharded}
+
+        def timed(mod, count):
+            for i in range(10):
+                mod.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(count):
+                out = mod.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, STEP, TINY, balance=False, update_U=(i % 2 == 0))
+            torch.cuda.synchronize(dev)
+            assert torch.isfinite(out).all().item()
+            return (time.perf_counter() - t0) / count * 1e3
         runs = {"unsharded": [], "sharded_1rank": []}
-        for rnd in range(3):                                 # interleaved rounds: the two paths see the same clocks and placement
-            for name, use_dist in (("unsharded", False), ("sharded_1rank", True)):
-                rec = run_uvd(args, psgd, sharded, lib, dev, 0, 1, use_dist, rows, rows, steps, 10, placement_mode="none")
-                runs[name].append(rec["ms_per_step"])
-                torch.cuda.empty_cache()
+        for rnd in range(5):                                 # interleaved rounds: the two paths see the same clocks
+            for name in ("unsharded", "sharded_1rank"):
+                runs[name].append(timed(paths[name], steps))
         base, shd = statistics.median(runs["unsharded"]), statistics.median(runs["sharded_1rank"])
-        return {"rows": rows, "r": args.rank_r, "steps": steps, "rounds": 3, "unsharded_ms": base,
+        return {"rows": rows, "r": r, "steps": steps, "rounds": 5, "unsharded_ms": base,
                 "sharded_1rank_rccl_ms": shd, "added_us_per_step": (shd - base) * 1e3,
                 "added_frac_of_step": (shd - base) / base,
-                "backend": dist.get_backend(), "runs_ms": runs,
-                "note": "one rank's share of BASELINE configs[3] (100M rows / 8); 1-rank RCCL group on this GPU: host "
-                        "issue + 2 all-gather launches (each a hop to the communicator's stream and back) + 2 fold kernels "
-                        "per step, no xGMI hop; medians of 3 interleaved rounds"}
+                "backend": dist.get_backend(), "direct_rccl": sharded._direct_comm(None, dev) is not None, "runs_ms": runs,
+                "note": "one rank's share of BASELINE configs[3] (100M rows / 8) on ONE set of tensors; 1-rank RCCL group on this GPU: host "
+                        "issue + 2 all-gathers on the caller's stream (the library's own RCCL communicator) + 2 fold kernels "
+                        "per step, no xGMI hop; medians of 5 interleaved rounds"}
     finally:
         if own_group:
             dist.destroy_process_group()
@@ -1050,6 +1064,10 @@ def main():
             with open(args.detail_json, "w") as fh:
                 fh.write(detail + "\n")
         print("BENCH_DETAIL " + detail, file=sys.stderr, flush=True)
+        try:                                     # RCCL prints its version banner through C stdio, which a pipe buffers until exit:
+            ctypes.CDLL(None).fflush(None)       # out with it now, so that the JSON line is the LAST line of stdout
+        except Exception:
+            pass
         print(json.dumps(compact_line(res)), flush=True)
 
     if use_dist:

@@ -5,14 +5,18 @@ kernel in 4.6 or 5.05 ms depending on where its streams sit in PHYSICAL memory (
 scans found on MI355X:
   * offsets inside one physically uniform allocation do not matter at all (gaps from 256 B to 256 MiB, any order of the eight
     regions: +-0.3 %);
-  * the address map has (at least) two REGIONS, and a stream that is WRITTEN (d, out, nablaD, the rewritten factor) runs faster when
-    it lives in another region than the big read streams: last sweep 3.38 -> 2.9 ms with d / out / nablaD elsewhere, update sweep 2
-    5.05 -> 4.88 ms; read-only streams (g, v, h) do not care.  11.2 -> 10.5-10.6 ms per step;
-  * where a region ends cannot be asked of the driver and is not where any fixed recipe puts it: a 48-GiB hipMalloc came back as a
-    32-GiB + 16-GiB pair of blocks with the boundary at 32 GiB on three boxes, entirely inside one region on two others (and in two
-    consecutive processes on one box); 16-, 20-, 24-, 28-GiB allocations and separate exact-size ones were always inside one region.
+  * the 288 GiB are THREE REGIONS of 96 GiB -- a walk through all of the device's memory in 4-GiB allocations finds a third of them
+    behaving like the first one and two thirds not, and those two thirds split again in halves (tools/r06_region_walk.py,
+    tools/r06_three_ranks.py): the three ranks of the 12-high HBM3E stacks, each with its own banks.  A stream that is WRITTEN (d,
+    out, nablaD) runs faster when it lives in another region than the big read streams: last sweep 3.39 -> 2.90 ms, update sweep 2
+    5.07 -> 4.89 ms; read-only streams (g, v, h) do not care, and the two factors want to SHARE a region (the Gram sweep reads
+    2.71 ms from one region, 2.85 from two; U / V / thin in three regions is 10.74 ms against 10.58).  11.2 -> 10.55-10.6 ms per step;
+  * where a region ends cannot be asked of the driver and follows no fixed recipe: in allocation order the regions of 8-GiB
+    allocations came as 00001112200222211110; a 48-GiB hipMalloc was a 32-GiB + 16-GiB pair of blocks in two regions on three
+    boxes and inside one region on two others; 16- to 28-GiB allocations and separate exact-size ones were always inside one.
 So it is MEASURED.  `UVdArena.probe` keeps the factors in one power-of-two allocation and walks through the allocator's free memory
-with small thin-stream buffers (each kept while the next is tried) until a small problem's last sweep says "another region", then
+with small thin-stream buffers (each kept while the next is tried; from the third try on 16 GiB apart) until a small problem's last
+sweep says "another region", then
 times the real fused step (both branches) on the candidates and on the packed exact-size allocation and keeps the fastest -- the
 packed one if nothing is gained.  Results are bit-identical whatever is chosen: only addresses change.
 
@@ -148,7 +152,7 @@ class UVdArena:
 
     # ---------------------------------------------------------------- the probe
     @classmethod
-    def probe(cls, N, r, device, max_tries=10, min_gain=0.01, chunk_bytes=None, log=None):
+    def probe(cls, N, r, device, max_tries=8, min_gain=0.01, chunk_bytes=None, log=None):
         """The faster of the packed exact-size allocation and a TWO-BUFFER arena whose buffers lie in different regions of the
         address map: U, V in one power-of-two allocation, the thin streams (the written ones matter) in another.
 
@@ -174,7 +178,7 @@ class UVdArena:
         fac_bytes = pow2(2 * _up(sz["U"]))
         thin_bytes = chunk_bytes or pow2(sum(_up(sz[k]) for k in cls.THIN))
         free, _total = torch.cuda.mem_get_info(device)
-        if free + need < 2 * fac_bytes + (max_tries + 1) * thin_bytes + (2 << 30):
+        if free + need < 2 * fac_bytes + 3 * thin_bytes + (2 << 30):
             base.info["note"] = "no room to look for a second region (%.0f GiB free): packed" % (free / GiB)
             return base
         info0 = dict(base.info)
@@ -205,9 +209,12 @@ class UVdArena:
             where.update({k: ((fac, o) if thin is None else (thin, wo0[k])) for k, o in wo.items()})
             return min(cls(n, r, device, where).time_step(iters=4, final_only=True)[0] for _ in range(2))
         t_same = small_ms(A1, None)
-        Bs, tries, found = [], [], None
+        Bs, tries, found, ballast = [], [], None, []
+        stride = max(thin_bytes, 16 * GiB)                     # from the third try on the walk advances 16 GiB per try (a rank is 96)
         for i in range(max_tries):
             try:
+                if i >= 2 and stride > thin_bytes and torch.cuda.mem_get_info(device)[0] > stride + (4 << 30):
+                    ballast.append(alloc(stride - thin_bytes))
                 Bs.append(alloc(thin_bytes))
             except RuntimeError:
                 break
@@ -216,6 +223,7 @@ class UVdArena:
             if t < 0.95 * t_same:
                 found = i
                 break
+        del ballast
         say({"layout": "region search: last sweep of a %d-row problem (ms) with its written streams inside the factor buffer, then in "
                        "thin buffer 1, 2, ..." % n, "same_buffer_ms": t_same, "thin_buffer_ms": tries,
              "factor_buffer_gib": fac_bytes / GiB, "thin_buffer_gib": thin_bytes / GiB})

@@ -334,8 +334,26 @@ def _exchange(be, stage, group):
 
 def _wide_reduce(group):
     """Exchange of the wide-rank path (r > 32, uvd_wide.py): an all-reduce of one small stacked tensor per exchange point.
-    Every rank receives the same bits (the collective computes each element once and distributes it)."""
+    Every rank receives the same bits (the collective computes each element once and distributes it).  "summax" (the fused step's
+    second exchange: 4r sums and one maximum in one buffer): an all-gather and a fold in rank order on every rank."""
     def reduce(t, op):
+        if op == "summax":
+            world = dist.get_world_size(group)
+            t = t.contiguous()
+            gathered = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+            EXCHANGES["count"] += 1
+            comm = _direct_comm(group, t.device) if (t.is_cuda and t.dtype == torch.float64) else None
+            if comm is not None:
+                comm.all_gather_f64(t, gathered, torch.cuda.current_stream(t.device).cuda_stream)
+            else:
+                dist.all_gather_into_tensor(gathered, t, group=group)
+            g2 = gathered.view(world, -1)
+            out = g2[0].clone()
+            for k in range(1, world):                          # rank order: the same bits on every rank
+                out[:-1] += g2[k][:-1]
+                out[-1] = torch.maximum(out[-1], g2[k][-1])
+            return out
+        EXCHANGES["count"] += 1
         dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=group)
         return t
     return reduce
@@ -406,15 +424,15 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
 def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, balance=None, update_U=None,
                                              generator=None, group=None, backend=None):
     """Sharded fused update -> apply; returns this rank's rows of the preconditioned gradient.
-    2 exchanges: the Gram; the 4r column sums of sweep 2 with max|nablaD| in one buffer.  (r > 32: the update, then the
-    apply, on the wide-rank path: 4 exchanges.)"""
+    2 exchanges: the Gram; the 4r column sums of sweep 2 with max|nablaD| in one buffer (every rank, r > 32 included since
+    round 6)."""
     if backend is None:
         _check_local("sharded update_precond_UVd_math_and_precond_grad", U, V, d, v, h, g)
     if _is_wide(U, backend):
-        # (the branches are agreed HERE, once, so the nested update cannot draw a second pair on some ranks only)
+        # r > 32: the fused sequence on the wide-rank building blocks, 2 exchanges (+ 1 on the balance branch) like the ranks below
         balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
-        update_precond_UVd_math_(U, V, d, v, h, step, tiny, balance=balance, update_U=update_U, group=group)
-        return precond_grad_UVd_math(U, V, d, g, group=group)
+        return _wide.update_apply(U, V, d, v, h, g, float(step), float(tiny), balance, update_U, _psgd.uvd_workspace,
+                                  reduce=_wide_reduce(group))
     be = backend if backend is not None else hip_backend_for(U)
     balance, update_U = _agree_on_branches(balance, update_U, generator, U.device, group)
     if balance:

@@ -304,12 +304,19 @@ def update_apply(U, V, d, v, h, g, step, tiny, balance, update_U, workspace_fn, 
                                                          int(bool(update_U)), scr.data_ptr(), scr.numel(), cx.st),
                    "psgd_uvd_wide_update_apply_f32")
         return out.reshape(g.shape)
+    if reduce is not _no_reduce and not isinstance(g, (list, tuple)) and g.numel() == U.shape[0] and os.environ.get("PSGD_WIDE_STEP") != "0":
+        # row-sharded (round 6): the fused sequence on the building blocks -- TWO exchanges (the Gram; the 4r column sums of the
+        # updated factors with max|nablaD| in one buffer), like the specialised ranks, instead of the four of update + apply
+        return update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce, fused_g=g)
     update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce)
     return precond_grad(U, V, d, g, workspace_fn, reduce)
 
 
-def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce=_no_reduce):
-    """psgd.py:554-617 for r > 32 (in place on U or V, and d)."""
+def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce=_no_reduce, fused_g=None):
+    """psgd.py:554-617 for r > 32 (in place on U or V, and d).
+    fused_g (a column vector g): also precond_grad_UVd_math on the UPDATED state (psgd.py:732 -> :748), returned -- the sums the apply
+    needs, [Unew | Vnew]' [d.*g, d.*g.*nablaD] with the OLD d, travel with max|nablaD| in ONE exchange (reduce(..., "summax"): the last
+    entry is reduced by max), and the two r-vectors of the apply follow from them and the Gram (what k_fused_post does for r <= 64)."""
     cx = _Ctx(U, workspace_fn, full=_full_ok(U, V))
     r, c, rc, dev = cx.r, cx.c, cx.rc, cx.dev
     if balance:                                                                # :562-567
@@ -396,8 +403,9 @@ def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce=_n
     Ph = dv * (a + p)                                                          # :570
     invPv = (b + q) / dv                                                       # :578-579
     nabla = Ph * hv - vv * invPv                                               # :581
-    mud = step / (reduce(torch.max(torch.abs(nabla)).reshape(1), "max")[0] + tiny)    # :582
-    dv.sub_((mud * dv) * nabla)                                                # :584 (d before U / V; a, b keep the old d)
+    if fused_g is None:
+        mud = step / (reduce(torch.max(torch.abs(nabla)).reshape(1), "max")[0] + tiny)    # :582
+        dv.sub_((mud * dv) * nabla)                                            # :584 (d before U / V; a, b keep the old d)
     c1f, c2f = (mu * c1.to(torch.float32)), (mu * c2.to(torch.float32))
     if update_U:                                                               # :600-601
         for k in range(c):
@@ -410,4 +418,28 @@ def update(U, V, d, v, h, step, tiny, balance, update_U, workspace_fn, reduce=_n
         for k in range(c):
             cx.rank2(Vc[k], al, be, c1f[sl(k)], c2f[sl(k)])
         cx.scatter(V, Vc)
-    return None
+    if fused_g is None:
+        return None
+    # ---- the apply on the updated state from ONE more exchange (the factor update above does not need mu_d, so it went first)
+    gv = fused_g.reshape(-1)
+    tg = (dv * gv).contiguous()                                                # d .* g            (old d)
+    tn = (tg * nabla).contiguous()                                             # d .* g .* nablaD
+    sums = torch.stack([torch.stack([cx.colsums(Uc[k], [tg, tn]), cx.colsums(Vc[k], [tg, tn])]) for k in range(c)])   # [c, U|V, tg|tn, rc]
+    packed = reduce(torch.cat([sums.reshape(-1), torch.max(torch.abs(nabla)).to(torch.float64).reshape(1)]), "summax")
+    S = packed[:-1].view(c, 2, 2, rc)
+    pU, pV, qU, qV = (S[:, i, j, :].reshape(-1) for i, j in ((0, 0), (1, 0), (0, 1), (1, 1)))
+    mud = step / (packed[-1].to(torch.float32) + tiny)                         # :582 (the maximum is an fp32 value)
+    Anew = UU
+    if update_U:                                           # Unew = U - a c1f' + b c2f':  Unew'Unew from U'U, U'a = s2, U'b, a'a, a'b, b'b
+        f1, f2 = c1f.to(torch.float64), c2f.to(torch.float64)
+        Ua, Ub = s2, Uw - VU.t() @ x1
+        o = torch.outer
+        Anew = UU - (o(Ua, f1) + o(f1, Ua)) + (o(Ub, f2) + o(f2, Ub)) + aa * o(f1, f1) - ab * (o(f1, f2) + o(f2, f1)) + bb * o(f2, f2)
+    s1n = pV - mud.to(torch.float64) * qV                                      # Vnew'(dnew .* g)
+    s2n = pU - mud.to(torch.float64) * qU + Anew @ s1n                         # Unew'(dnew .* g + Unew s1')
+    dv.sub_((mud * dv) * nabla)                                                # :584
+    acc = (dv * gv).contiguous()
+    for k in range(c):
+        cx.axpy(Uc[k], [acc], s1n[sl(k)].reshape(1, -1))
+        cx.axpy(Vc[k], [acc], s2n[sl(k)].reshape(1, -1))
+    return (dv * acc).reshape(fused_g.shape)                                   # :626

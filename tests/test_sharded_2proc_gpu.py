@@ -49,8 +49,10 @@ def _worker(rank, port, outdir, N, r, two_devices):
     out = sharded.precond_grad_UVd_math(t["U"], t["V"], t["d"], t["g"])
     if be is not None:
         red["apply_s2"] = be.sums(2).cpu().numpy().copy()
+    ex0 = sharded.EXCHANGES["count"]
     outf = sharded.update_precond_UVd_math_and_precond_grad(t["U"], t["V"], t["d"], t["v"], t["h"], t["g"], 0.01, TINY32,
                                                             balance=False, update_U=True)
+    fused_exchanges = sharded.EXCHANGES["count"] - ex0
     if be is not None:
         red["fused_gram"] = be.sums(11).cpu().numpy().copy()
         red["fused_s13"] = be.sums(13).cpu().numpy().copy()
@@ -77,7 +79,8 @@ def _worker(rank, port, outdir, N, r, two_devices):
     np.savez(os.path.join(outdir, "r%d.npz" % rank), U=t["U"].cpu().numpy(), V=t["V"].cpu().numpy(), d=t["d"].cpu().numpy(),
              out=out.cpu().numpy(), outf=outf.cpu().numpy(), pre0=pre0.cpu().numpy(), pre1=pre1.cpu().numpy(),
              L12=new[0].cpu().numpy(), l3=new[1].cpu().numpy(), U12=new[2].cpu().numpy(), u3=new[3].cpu().numpy(),
-             backend=np.array(dist.get_backend()), device=np.array(dev.index), **{"red_" + k: v for k, v in red.items()})
+             backend=np.array(dist.get_backend()), device=np.array(dev.index), fused_exchanges=np.array(fused_exchanges),
+             **{"red_" + k: v for k, v in red.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,6 +103,7 @@ def test_two_processes_real_kernels_real_collectives(hip_lib, N, r, transport):
     sh = [np.load(os.path.join(outdir, "r%d.npz" % k)) for k in range(WORLD)]
     assert str(sh[0]["backend"]) == ("nccl" if two else "gloo")
     assert [int(s["device"]) for s in sh] == ([0, 1] if two else [0, 0])
+    assert [int(s["fused_exchanges"]) for s in sh] == [2, 2]      # the fused step: two exchanges at every rank (r = 40 too, round 6)
     # every reduced region is the same BITS on both ranks (fold of the same copies in the same order)
     reds = [k for k in sh[0].files if k.startswith("red_")]
     assert ("red_fused_s13" in reds) == (r <= 32) and ("red_splu_s3" in reds) == (r <= 32)
