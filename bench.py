@@ -752,10 +752,10 @@ def run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_glo
     import torch.distributed as dist
     r = args.rank_r
     # the state's owner places it (psgd_tf_amd/placement.py): one allocation for U, V, d, the workspace and the output, the layout
-    # chosen by a timed probe of both branches (results are bit-identical: only addresses change).  Unsharded path only.
+    # chosen by a timed probe of both branches (results are bit-identical: only addresses change).
     arena, placement_log = None, []
     mode = placement_mode or args.placement
-    if mode != "none" and not use_dist and r <= 32:
+    if mode != "none" and r <= 32:                          # (per rank: the probe is local, no collective in it)
         from psgd_tf_amd import placement
         arena = (placement.UVdArena.probe(n_local, r, dev, log=placement_log) if mode == "probe"
                  else placement.UVdArena.packed(n_local, r, dev))

@@ -522,7 +522,7 @@ class UVd:
         if placement not in (None, "probe", "packed"):
             raise ValueError("UVd: placement must be None, 'probe' or 'packed', got %r" % (placement,))
         if placement is not None and self._device.type == "cuda" and self._store_dtype == torch.float32 \
-                and r <= _lib.UVD_MAX_RANK and group is None:
+                and r <= _lib.UVD_MAX_RANK and stage_backend is None:
             from . import placement as _placement
             self._arena = (_placement.UVdArena.probe if placement == "probe" else _placement.UVdArena.packed)(
                 num_params, r, self._device)
@@ -608,7 +608,8 @@ class UVd:
                 pre_grad = self._sharded.update_precond_UVd_math_and_precond_grad(
                     U, V, d, v[:, None].contiguous(), h[:, None].contiguous(),
                     grad[:, None].contiguous(), float(self.lr_preconditioner), self._tiny,
-                    generator=self._generator, group=self._group, backend=self._stage_backend)
+                    generator=self._generator, group=self._group, backend=self._stage_backend,
+                    out=None if self._arena is None else self._arena.out)
             self._state_store(U, V, d)
         else:                                                                                 # :737-744
             with torch.enable_grad():

@@ -132,9 +132,10 @@ class HipStages:
         _lib.check(self.lib.psgd_uvd_fused_post_f32(self.N, self.r, float(step), float(tiny), int(bool(update_U)),
                                                     wp, wn, st), "fused_post")
 
-    def fused_final(self, U, V, d, g, step, tiny):
-        """last sweep of the fused step: d update + the whole apply; returns this rank's rows of the result."""
-        out = torch.empty_like(g)
+    def fused_final(self, U, V, d, g, step, tiny, out=None):
+        """last sweep of the fused step: d update + the whole apply; returns this rank's rows of the result (written to `out` when
+        given: placement.UVdArena.out)."""
+        out = torch.empty_like(g) if out is None else out
         wp, wn, st = self._w()
         _lib.check(self.lib.psgd_uvd_fused_final_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), g.data_ptr(),
                                                      out.data_ptr(), self.N, self.r, float(step), float(tiny),
@@ -422,7 +423,7 @@ def update_precond_UVd_math_(U, V, d, v, h, step, tiny, *, balance=None, update_
 
 
 def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, balance=None, update_U=None,
-                                             generator=None, group=None, backend=None):
+                                             generator=None, group=None, backend=None, out=None):
     """Sharded fused update -> apply; returns this rank's rows of the preconditioned gradient.
     2 exchanges: the Gram; the 4r column sums of sweep 2 with max|nablaD| in one buffer (every rank, r > 32 included since
     round 6)."""
@@ -444,6 +445,8 @@ def update_precond_UVd_math_and_precond_grad(U, V, d, v, h, g, step, tiny, *, ba
     be.update_sweep2_fused(U, V, d, v, h, g, step, tiny, update_U)
     _exchange(be, 13, group)
     be.fused_post(step, tiny, update_U)
+    if out is not None and backend is None:                # (the product backend; a placed state passes its arena's output region)
+        return be.fused_final(U, V, d, g, step, tiny, out=out)
     return be.fused_final(U, V, d, g, step, tiny)
 
 

@@ -200,7 +200,8 @@ def _cls_worker(rank, port, outdir, two_devices):
     hi = lo + sum(p.numel() for p in own)
     gen = torch.Generator().manual_seed(606 + 13 * rank)                 # different seeds: rank 0's coins must win
     opt = psgd.UVd(own, rank_of_modification=CLS_R, lr_params=0.004, lr_preconditioner=0.05, generator=gen,
-                   group=dist.group.WORLD)
+                   group=dist.group.WORLD, placement=("packed" if rank == 1 else None))      # (one rank with a placed state: same results)
+    assert (opt._arena is not None) == (rank == 1)
     assert opt._num_params_global == sum(p.numel() for p in params) and tuple(opt._U.shape) == (hi - lo, CLS_R)
     opt._U.copy_(U[lo:hi]); opt._V.copy_(V[lo:hi]); opt._d.copy_(d[lo:hi])
     calls = {"all_gather_into_tensor": 0, "all_reduce": 0, "broadcast": 0}
