@@ -17,9 +17,9 @@ def pick(prefix):
 
 s2, gr = pick("k_update_s2<%d" % r), pick("k_update_gram<%d" % r)
 out = {
-    "_doc": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --steps 3 "
+    "_doc": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --placement packed --steps 3 "
             "--warmup 1 --no-kron --no-exchange-leg`; FETCH_SIZE doubled (gfx950: counts 64 B per 128-B request), WRITE_SIZE exact; see "
-            "MI355X_MICROARCH.md HBM section and tools/pmc_traffic.py. Source: profiles/r0N_bench_pmc_traffic_%s.json "
+            "MI355X_MICROARCH.md HBM section and tools/pmc_traffic.py. Source: profiles/r06_bench_pmc_traffic_%s.json "
             "(the raw per-kernel table of the same passes)" % tag,
     "k_update_s2": {"rows": rows, "r": r, "hbm_bytes_per_launch": s2["hbm_bytes_per_launch"],
                     "fetch_bytes_corrected_x2": s2["fetch_bytes_corrected_x2"], "write_bytes": s2["write_bytes"],

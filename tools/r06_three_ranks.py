@@ -43,8 +43,9 @@ def main():
     print({c: len(v) for c, v in pick.items()})
     st = torch.cuda.current_stream().cuda_stream
 
-    def run(label, bu, bv, bthin, bread=None):
-        """U in buffer bu, V in bv, written thin streams (d, out, ws) in bthin, read-only ones (g, v, h) in bread (default bthin)"""
+    def run(label, bu, bv, bthin, bread=None, bspare=None):
+        """U in buffer bu, V in bv, written thin streams (d, out, ws) in bthin, read-only ones (g, v, h) in bread (default bthin);
+        bspare: the updated factor is written OUT OF PLACE into that buffer (psgd_uvd_update_apply_oop_f32)"""
         bread = bthin if bread is None else bread
         sz = cls.region_bytes(N, r)
         where = {"U": (bufs[bu], 0), "V": (bufs[bv], 0)}
@@ -52,7 +53,7 @@ def main():
         assert bu != bv
         cur = {}
         for k, b in (("d", bthin), ("out", bthin), ("ws", bthin), ("g", bread), ("v", bread), ("h", bread)):
-            assert b not in (bu, bv)
+            assert b not in (bu, bv) and b != bspare
             o = cur.get(b, 0)
             where[k] = (bufs[b], o)
             cur[b] = (o + sz[k] + 255) // 256 * 256
@@ -62,8 +63,13 @@ def main():
         P = lambda t: t.data_ptr()
 
         def call(bu_):
-            rc = lib.psgd_uvd_update_apply_f32(P(a.U), P(a.V), P(a.d), P(a.v), P(a.h), P(a.g), P(a.out), N, r, 0.0, 1.1754943508222875e-38,
-                                               0, bu_, P(a.ws), a.ws.numel(), st)
+            if bspare is not None:
+                assert bspare not in (bu, bv)
+                rc = lib.psgd_uvd_update_apply_oop_f32(P(a.U), P(a.V), P(a.d), P(a.v), P(a.h), P(a.g), P(a.out), bufs[bspare].data_ptr(), N, r,
+                                                       0.0, 1.1754943508222875e-38, 0, bu_, P(a.ws), a.ws.numel(), st)
+            else:
+                rc = lib.psgd_uvd_update_apply_f32(P(a.U), P(a.V), P(a.d), P(a.v), P(a.h), P(a.g), P(a.out), N, r, 0.0, 1.1754943508222875e-38,
+                                                   0, bu_, P(a.ws), a.ws.numel(), st)
             assert rc == 0
         call(1); call(0)
         res = []
@@ -91,6 +97,18 @@ def main():
             label, res[0][0], res[1][0], 0.5 * (res[0][0] + res[1][0]), res[0][1][0], res[1][1][0], res[0][1][1], res[1][1][1],
             res[0][1][2], res[1][1][2]), flush=True)
     c0, c1, c2 = pick[0], pick[1], pick[2]
+    # (the out-of-place variants need a build with psgd_uvd_update_apply_oop_f32 -- an experiment of round 6 that was measured and not
+    #  kept: profiles/r06_placement.txt section 7)
+    if os.environ.get("OOP", "0") == "1" and hasattr(lib, "psgd_uvd_update_apply_oop_f32") and len(c0) >= 3 and len(c1) >= 2 and len(c2) >= 2:
+        run("in place:  U c0, V c0, thin c1", c0[0], c0[1], c1[0])
+        run("OOP -> c0: U c0, V c0, thin c1, spare c0", c0[0], c0[1], c1[0], bspare=c0[2])
+        run("OOP -> c1: U c0, V c0, thin c1, spare c1", c0[0], c0[1], c1[0], bspare=c1[1])
+        run("OOP -> c2: U c0, V c0, thin c1, spare c2", c0[0], c0[1], c1[0], bspare=c2[0])
+        run("OOP -> c1: U c0, V c0, thin c2, spare c1", c0[0], c0[1], c2[0], bspare=c1[0])
+        run("OOP -> c1: U c0, V c1, thin c2, spare c1 (V-branch: same region as V)", c0[0], c1[0], c2[0], bspare=c1[1])
+        run("OOP -> c0: U c0, V c1, thin c2, spare c0", c0[0], c1[0], c2[0], bspare=c0[1])
+        run("in place:  U c0, V c0, thin c1 (again)", c0[0], c0[1], c1[0])
+        return
     if len(c0) >= 4:
         run("U c0, V c0, thin c0 (one class)", c0[0], c0[1], c0[2])
     if len(c0) >= 2 and c1:
