@@ -308,7 +308,7 @@ def _direct_comm(group, device):
     import os
     if not DIRECT_RCCL or os.environ.get("PSGD_DIRECT_RCCL", "1") == "0" or dist.get_backend(group) != "nccl":
         return None
-    key = (id(group) if group is not None else None, torch.device(device).index)
+    key = (id(group) if group is not None else None, torch.device(device).index, dist.get_world_size(group), dist.get_rank(group))
     if key not in _direct_comms:
         try:
             _direct_comms[key] = (group, _RcclDirect(group, device))       # (the strong reference keeps id() unique)
