@@ -882,7 +882,29 @@ def _is_dd_f32(Ql, Qr, X):
             and Ql.device == X.device and Qr.device == X.device)
 
 
+# ---- the triangular contract, checked on request.  psgd.py:173, :179, :190, :192 multiply with the FULL Ql, Qr; the kernels never read
+# the strictly lower triangle of a dense factor.  The two agree for every factor the reference can produce (identity initialisation,
+# updates that preserve triangularity), so the default costs nothing; a caller that builds factors itself can switch the check on and
+# gets a ValueError instead of a silently different result (one reduction and a host read per dense factor per call).
+_check_triangular = [False]
+
+
+def set_triangular_check(on):
+    """True: update_precond_kron / precond_grad_kron verify that square (dense) factors have an all-zero strictly lower triangle."""
+    old, _check_triangular[0] = _check_triangular[0], bool(on)
+    return old
+
+
+def _assert_upper(name, *factors):
+    for q in factors:
+        if q.dim() == 2 and q.shape[0] == q.shape[1] and q.shape[0] > 1 and bool(torch.count_nonzero(torch.tril(q, -1))):
+            raise ValueError("%s: a dense factor has non-zero entries below its diagonal; the kernels treat factors as upper "
+                             "triangular (the reference's own factors always are: psgd.py:40-42, :175-179)" % name)
+
+
 def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
+    if _check_triangular[0]:
+        _assert_upper("update_precond_kron", Ql, Qr)
     if _layer_ctx is not None:
         return _layer_ctx.run(update_precond_kron, (Ql, Qr, dX, dG, step))
     if _is_dd_f32(Ql, Qr, dX) and dG.shape == dX.shape and dG.dtype is _f32 and dG.device == dX.device:
@@ -916,6 +938,8 @@ def update_precond_kron(Ql, Qr, dX, dG, step=0.01):
 
 
 def precond_grad_kron(Ql, Qr, Grad):
+    if _check_triangular[0]:
+        _assert_upper("precond_grad_kron", Ql, Qr)
     if _layer_ctx is not None:
         return _layer_ctx.run(precond_grad_kron, (Ql, Qr, Grad))
     if _is_dd_f32(Ql, Qr, Grad):

@@ -1611,3 +1611,30 @@ def test_large_apply_paths_direct_both_prepared(psgd, M, N):
         assert rel_err(out.cpu().numpy(), ref) < TOL
     finally:
         kron.set_apply_route(old)
+
+
+def test_triangular_contract_check_is_opt_in(psgd):
+    """psgd.py:173, :179, :190, :192 multiply with the full factors; the kernels read the upper triangle only.  By default a factor
+    with entries below its diagonal is treated as its upper triangle (silently, as INTEGRATION.md says); with
+    kron.set_triangular_check(True) the same call raises."""
+    from psgd_tf_amd import kron
+    rng = np.random.default_rng(3)
+    M, N = 40, 24
+    Ql, Qr = _tri_factor(rng, M).astype(np.float32), _tri_factor(rng, N).astype(np.float32)
+    G = rng.standard_normal((M, N)).astype(np.float32)
+    bad = Ql.copy()
+    bad[7, 2] = 0.5
+    want = psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G))
+    assert torch.equal(psgd.precond_grad_kron(_dev(bad), _dev(Qr), _dev(G)), want)       # the lower triangle is not read
+    old = kron.set_triangular_check(True)
+    try:
+        assert old is False
+        assert torch.equal(psgd.precond_grad_kron(_dev(Ql), _dev(Qr), _dev(G)), want)
+        with pytest.raises(ValueError):
+            psgd.precond_grad_kron(_dev(bad), _dev(Qr), _dev(G))
+        with pytest.raises(ValueError):
+            psgd.update_precond_kron(_dev(Ql), _dev(np.tril(Qr) + Qr), _dev(G), _dev(G), 0.01)
+        q1 = _dev(np.ones((1, M), np.float32))                                            # sparse formats are not square factors
+        psgd.precond_grad_kron(q1, _dev(Qr), _dev(rng.standard_normal((M, N)).astype(np.float32)))
+    finally:
+        kron.set_triangular_check(False)
