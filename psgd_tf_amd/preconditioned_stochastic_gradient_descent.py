@@ -464,7 +464,7 @@ class UVd:
                  lr_params=0.01, lr_preconditioner=0.01,
                  grad_clip_max_norm=None, preconditioner_update_probability=1.0,
                  exact_hessian_vector_product: bool = True, generator=None, state_dtype=None, group=None,
-                 stage_backend=None, placement=None):
+                 stage_backend=None, placement="auto"):
         # group (extension): a torch.distributed process group (dist.group.WORLD for the default one) makes this a
         # ROW-SHARDED optimizer: `params_with_grad` are THIS rank's parameters, the global flat vector of psgd.py:729-730 is the
         # concatenation of the ranks' vectors in rank order, and U, V, d hold this rank's rows only.  A step then costs three
@@ -515,12 +515,15 @@ class UVd:
             self._coins = _sharded.branch_rng_for(generator, group, self._device)
         uv_scale = (1.0 / (self._num_params_global * r)) ** 0.5                              # :687 (the GLOBAL N)
         sd = self._state_dtype
-        # placement (extension; None = plain allocations): "probe" / "packed" carve U, V, d, the workspace, the output and the
-        # flat v / h / g vectors of :729-730, :747 out of ONE allocation owned by this object (placement.UVdArena; "probe" times
-        # candidate layouts once and keeps the fastest: where the WRITTEN streams sit relative to the read ones is worth 5 %)
+        # placement (extension): "probe" / "packed" carve U, V, d, the workspace, the output and the flat v / h / g vectors of :729-730,
+        # :747 out of allocations owned by this object (placement.UVdArena; "probe" times candidate layouts once and keeps the
+        # fastest: where the WRITTEN streams sit relative to the read ones is worth 5 %); None = plain allocations; "auto" (default)
+        # = "probe" when a factor is at least 256 MiB (the search costs ~0.6 s and allocates up to ~100 GiB while it runs), None below
         self._arena = None
-        if placement not in (None, "probe", "packed"):
-            raise ValueError("UVd: placement must be None, 'probe' or 'packed', got %r" % (placement,))
+        if placement not in (None, "auto", "probe", "packed"):
+            raise ValueError("UVd: placement must be None, 'auto', 'probe' or 'packed', got %r" % (placement,))
+        if placement == "auto":
+            placement = "probe" if 4 * num_params * r >= (256 << 20) else None
         if placement is not None and self._device.type == "cuda" and self._store_dtype == torch.float32 \
                 and r <= _lib.UVD_MAX_RANK and stage_backend is None:
             from . import placement as _placement
