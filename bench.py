@@ -574,7 +574,7 @@ def uvd_bytes(r, fused):
     return kb
 
 
-def uvd_legs(dev, psgd, lib, state, r, iters):
+def uvd_legs(dev, psgd, lib, state, r, iters, arena=None):
     """precond_grad_UVd_math alone, update_precond_UVd_math_ alone (the two reference-named calls) and the fused
     step on one resident problem: wall time per call from HIP events on the launch stream, per-kernel times from
     the psgd_prof hooks, HBM fractions on SURVEY 8d's algorithmic bytes and on the bytes the sweeps move."""
@@ -610,11 +610,12 @@ def uvd_legs(dev, psgd, lib, state, r, iters):
                 "frac_kernels_only": gbs(alg, ksum) / HBM_PEAK_GBS if ksum else None,
                 "kernels_ms": {x: kms[x] for x in names}}
 
-    wa, ka = timed(lambda i: psgd.precond_grad_UVd_math(U, V, d, grad), iters)
+    okw = {"out": arena.out} if arena is not None else {}          # (the state's owner also owns where the result is written)
+    wa, ka = timed(lambda i: psgd.precond_grad_UVd_math(U, V, d, grad, **okw), iters)
     wu, ku = timed(lambda i: psgd.update_precond_UVd_math_(U, V, d, v, h, STEP, TINY, balance=False,
                                                            update_U=(i % 2 == 0)), iters)
     wf, kf = timed(lambda i: psgd.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, STEP, TINY, balance=False,
-                                                                           update_U=(i % 2 == 0)), iters)
+                                                                           update_U=(i % 2 == 0), **okw), iters)
     return {
         "N": n, "r": r, "timed_calls": iters,
         "apply": dict(leg(wa, ka, ("apply_s1", "apply_s2", "apply_s3"), 4 * (4 * r + 5), 4 * (3 * r + 8)),
@@ -1023,7 +1024,7 @@ def main():
                            "kernels_ms": {k: wk[k] for k in kbytes if wk[k]}}
         if world == 1:
             if state is not None:
-                legs = uvd_legs(dev, psgd, lib, state, r, max(5, min(args.steps, 20)))
+                legs = uvd_legs(dev, psgd, lib, state, r, max(5, min(args.steps, 20)), arena=arena_keep)
                 paths["apply"], paths["update"], paths["step_fused_events"] = legs["apply"], legs["update"], legs["step_fused"]
                 # the two reference-named calls back to back, next to the fused entry point the headline uses
                 two = legs["update"]["wall_ms"] + legs["apply"]["wall_ms"]

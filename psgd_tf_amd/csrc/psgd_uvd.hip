@@ -160,13 +160,34 @@ int policy_grid_blocks(int occ) {
 }
 int device_cus() { return num_cus(); }
 
+static int g_tune_grid[16] = {0};     // psgd_set_tuning key 10 + kind: workgroups of that sweep kind (0 = the rule below)
+
 static int sweep_grid(const UvdOps* ops, int r, int which, int64_t N, int hard_cap) {
-  static int occ_cache[PSGD_UVD_MAX_RANK + 1][8];
+  static int occ_cache[PSGD_UVD_MAX_RANK + 1][16];
+  if (which >= 0 && which < 16 && g_tune_grid[which] > 0) {
+    const int64_t tiles = (N + ops->tile_rows - 1) / ops->tile_rows;
+    int64_t grid = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (grid > g_tune_grid[which]) grid = g_tune_grid[which];
+    if (grid > hard_cap) grid = hard_cap;
+    return (int)(grid < 1 ? 1 : grid);
+  }
   int occ = occ_cache[r][which];
   if (occ == 0) {
     occ = ops->occupancy(which);
     if (occ <= 0) occ = 1;
     occ_cache[r][which] = occ;
+  }
+  // Round 6 (profiles/r06_grid_scan.txt): the sweeps that WRITE a factor or several vectors run faster on FEWER waves -- update sweep 2
+  // on one workgroup per CU instead of the three that fit: 4.87 -> 4.69 ms at N = 100M, r = 20 (placed state), -6 .. -17 % at
+  // r = 10 .. 32 and N = 4M .. 50M; the last sweep of the fused step -1 .. -5 %.  (Fewer concurrent 5-KiB streams keep more DRAM rows
+  // open between a tile's read and its write-back.)  Tiles below 4 KiB per operand (r <= 8) need two workgroups per CU to cover the
+  // latency; the read-only sweeps (Gram, apply) keep every workgroup that fits.  Multiples of the CU count only: 320 or 384
+  // workgroups leave a second, mostly idle round.
+  if (which == kOccUpdS2U || which == kOccUpdS2V || which == kOccUpdS2F) {
+    const int want = ((long)ops->tile_rows * r * 4 >= 4096) ? 1 : 2;
+    if (want < occ) occ = want;
+  } else if (which == kOccFinal) {
+    occ = 1;
   }
   if (g_tune_blocks_per_cu > 0 && g_tune_blocks_per_cu < occ) occ = g_tune_blocks_per_cu;
   if (g_tune_blocks_per_cu < 0) occ = -g_tune_blocks_per_cu;   // experiments: force, even above the occupancy query
@@ -1061,6 +1082,7 @@ int psgd_set_tuning(int key, int value) {
   if (key == 1) { g_tune_blocks_per_cu = value; return PSGD_OK; }
   if (key == 2) { g_tune_coef = value; return PSGD_OK; }
   if (key == 3) { g_tune_tiles_per_wave = value; return PSGD_OK; }
+  if (key >= 10 && key < 26) { g_tune_grid[key - 10] = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 

@@ -297,10 +297,11 @@ def _cols_of(name, x, N):
     return xt if xt.is_contiguous() else xt.contiguous()
 
 
-def precond_grad_UVd_math(U, V, d, g):
+def precond_grad_UVd_math(U, V, d, g, *, out=None):
     """psgd.py:619-627: d .* (I + V U')(I + U V')(d .* g); returns a new tensor shaped like g.
     g is a column vector ([N] or [N, 1]) or, as the reference's docstring allows (:623), a matrix [N, k]: d broadcasts over
-    the columns and U, V are swept once per group of four columns (psgd_uvd_apply_cols_f32)."""
+    the columns and U, V are swept once per group of four columns (psgd_uvd_apply_cols_f32).
+    out (extension; column-vector g, r <= 32): a contiguous fp32 tensor shaped like g to write the result to (placement.UVdArena.out)."""
     U, V, d = _c(U), _c(V), _c(d)
     if isinstance(g, torch.Tensor) and g.dim() == 2 and g.shape[1] > 1:
         dev = _require_hip("precond_grad_UVd_math", U, V, d)
@@ -324,7 +325,12 @@ def precond_grad_UVd_math(U, V, d, g):
     N, r = _uvd_shapes("precond_grad_UVd_math", U, V, d, g)
     if r > _lib.UVD_MAX_RANK:                      # wide rank: column chunks through the same kernels (uvd_wide.py)
         return _wide.precond_grad(U, V, d, g, uvd_workspace)
-    out = torch.empty_like(g)
+    if out is None:
+        out = torch.empty_like(g)
+    else:
+        _require_hip("precond_grad_UVd_math", out, U)
+        if out.shape != g.shape:
+            raise ValueError("precond_grad_UVd_math: out must be shaped like g")
     ws = uvd_workspace(dev, N, r)
     rc = _lib.load().psgd_uvd_apply_f32(U.data_ptr(), V.data_ptr(), d.data_ptr(), g.data_ptr(), out.data_ptr(),
                                          N, r, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
@@ -620,7 +626,8 @@ class UVd:
                 grads = torch.autograd.grad(self._loss_of(closure_returns), params)
             grad = self._flat(grads, "g")                                                     # :747
             if self._group is None:
-                pre_grad = precond_grad_UVd_math(*self._state_fp32(), grad[:, None].contiguous())     # :748
+                pre_grad = precond_grad_UVd_math(*self._state_fp32(), grad[:, None].contiguous(),      # :748
+                                                 out=None if self._arena is None else self._arena.out)
             else:
                 pre_grad = self._sharded.precond_grad_UVd_math(*self._state_fp32(), grad[:, None].contiguous(),
                                                                group=self._group, backend=self._stage_backend)

@@ -42,8 +42,10 @@ def test_packed_arena_gives_the_same_bits(hip_lib, N, r):
     # the two reference-named calls on the placed state, and the workspace the arena installed is the one they use
     psgd.update_precond_UVd_math_(arena.U, arena.V, arena.d, arena.v, arena.h, 0.01, TINY32, balance=True, update_U=True)
     psgd.update_precond_UVd_math_(a["U"], a["V"], a["d"], a["v"], a["h"], 0.01, TINY32, balance=True, update_U=True)
-    assert torch.equal(psgd.precond_grad_UVd_math(arena.U, arena.V, arena.d, arena.g),
-                       psgd.precond_grad_UVd_math(a["U"], a["V"], a["d"], a["g"]))
+    ref = psgd.precond_grad_UVd_math(a["U"], a["V"], a["d"], a["g"])
+    assert torch.equal(psgd.precond_grad_UVd_math(arena.U, arena.V, arena.d, arena.g), ref)
+    placed = psgd.precond_grad_UVd_math(arena.U, arena.V, arena.d, arena.g, out=arena.out)       # the result written into the arena
+    assert placed.data_ptr() == arena.out.data_ptr() and torch.equal(placed, ref)
     assert psgd.uvd_workspace(dev, N, r).data_ptr() == arena.ws.data_ptr()
     with pytest.raises(ValueError):
         psgd.update_precond_UVd_math_and_precond_grad(arena.U, arena.V, arena.d, arena.v, arena.h, arena.g, 0.01, TINY32,
