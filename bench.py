@@ -763,6 +763,11 @@ def run_uvd(args, psgd, sharded, lib, dev, rank, world, use_dist, n_local, n_glo
         arena.install_workspace()
     U, V, d, grad, v, h = make_inputs(n_local, n_global, r, dev, seed=1000 * rank, arena=arena)
     out_kw = {"out": arena.out} if arena is not None else {}
+    if arena is not None and mode == "probe" and args.settle_s > 0:
+        # the probe has just handed tens of GiB back to the driver, which clears released VRAM in the background (on the copy engines, at
+        # the expense of HBM bandwidth): let that finish before anything is timed (untimed set-up, like the probe itself)
+        torch.cuda.synchronize(dev)
+        time.sleep(args.settle_s)
     # one step = update then apply on the updated state (psgd.py:732 -> :748).  Default: the fused call
     # (identical results, one pass over V less); --unfused times the two reference-named calls back to back.
     mod = sharded if use_dist else psgd
@@ -896,6 +901,9 @@ def main():
                     help="unsharded run: who owns U, V, d, the workspace and the output -- 'probe' (default): one allocation, layout "
                          "chosen by a timed probe (psgd_tf_amd/placement.py); 'packed': one exact-size allocation; 'none': separate "
                          "torch allocations (rounds 1-5)")
+    ap.add_argument("--settle-s", type=float, default=1.0,
+                    help="seconds to wait after the placement probe has freed its search buffers (the driver clears released VRAM in the "
+                         "background), before the warm-up steps; untimed set-up")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU code path (process group + exchanges) even at world size 1")
     args = ap.parse_args()

@@ -882,10 +882,11 @@ def _is_dd_f32(Ql, Qr, X):
             and Ql.device == X.device and Qr.device == X.device)
 
 
-# ---- the triangular contract, checked on request.  psgd.py:173, :179, :190, :192 multiply with the FULL Ql, Qr; the kernels never read
-# the strictly lower triangle of a dense factor.  The two agree for every factor the reference can produce (identity initialisation,
-# updates that preserve triangularity), so the default costs nothing; a caller that builds factors itself can switch the check on and
-# gets a ValueError instead of a silently different result (one reduction and a host read per dense factor per call).
+# ---- the triangular contract, checked on request.  psgd.py:173, :179, :190, :192 multiply with the FULL Ql, Qr; the kernels assume
+# upper-triangular factors (large layers skip whole tiles below the diagonal, small layers and diagonal tiles multiply what is stored).
+# All agree for every factor the reference can produce (identity initialisation, updates that preserve triangularity), so the default
+# costs nothing; a caller that builds factors itself can switch the check on and gets a ValueError instead of a silently different
+# result (one reduction and a host read per dense factor per call).
 _check_triangular = [False]
 
 
