@@ -1634,7 +1634,7 @@ def test_triangular_contract_check_is_opt_in(psgd):
         with pytest.raises(ValueError):
             psgd.precond_grad_kron(_dev(bad), _dev(Qr), _dev(G))
         with pytest.raises(ValueError):
-            psgd.update_precond_kron(_dev(Ql), _dev(np.tril(Qr) + Qr), _dev(G), _dev(G), 0.01)
+            psgd.update_precond_kron(_dev(Ql), _dev(Qr + np.tril(Qr.T, -1)), _dev(G), _dev(G), 0.01)
         q1 = _dev(np.ones((1, M), np.float32))                                            # sparse formats are not square factors
         psgd.precond_grad_kron(q1, _dev(Qr), _dev(rng.standard_normal((M, N)).astype(np.float32)))
     finally:
