@@ -159,7 +159,7 @@ class UVdArena:
         1. the packed slab is timed on the real fused step (both branches) and freed;
         2. the factor buffer A (2^k >= 2 * 4 N r bytes) is allocated, then thin buffers B1, B2, ... (2^j >= the six thin regions), each
            kept while the next is tried, so that the allocator walks through its free memory: a small problem (factors of 1/16 of
-           A at its start) times its last sweep with its written thin streams inside A (same region by construction) and in
+           A, at least 512 MiB each, at its start) times its last sweep with its written thin streams inside A (same region by construction) and in
            B_i; the first B_i that is >= 5 % faster is in another region;
         3. (A, that B_i) is timed on the real step; so is the mirror image -- a second factor buffer A2 allocated now (it comes out
            of the region the walk has reached) with the thin streams in B1 -- when the small problem says A2 and B1 differ;
@@ -196,8 +196,9 @@ class UVdArena:
             A1 = alloc(fac_bytes)
         except RuntimeError:                                   # (out of memory: another tenant holds the device)
             return packed_again("the factor buffer could not be allocated: packed")
-        # ---- 2. the small problem: factors of 1/16 of A
-        n = max(64, min(N, (fac_bytes // 16) // (4 * r) // 64 * 64))
+        # ---- 2. the small problem: factors of 1/16 of A, but not below 512 MiB each (a problem that lives in the 256-MiB Infinity Cache
+        #         cannot see where its streams are in HBM) and not above the real problem
+        n = max(64, min(N, max(fac_bytes // 16, 512 << 20) // (4 * r) // 64 * 64))
         fo, fend = cls.sequential(n, r, ("U", "V"))
         ro, rend = cls.sequential(n, r, ("g", "v", "h"), fend)
         wo, wend = cls.sequential(n, r, ("d", "out", "ws"), rend)          # (inside A: the same region by construction)

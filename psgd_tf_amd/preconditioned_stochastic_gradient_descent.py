@@ -524,12 +524,13 @@ class UVd:
         # placement (extension): "probe" / "packed" carve U, V, d, the workspace, the output and the flat v / h / g vectors of :729-730,
         # :747 out of allocations owned by this object (placement.UVdArena; "probe" times candidate layouts once and keeps the
         # fastest: where the WRITTEN streams sit relative to the read ones is worth 5 %); None = plain allocations; "auto" (default)
-        # = "probe" when a factor is at least 256 MiB (the search costs ~0.6 s and allocates up to ~100 GiB while it runs), None below
+        # = "probe" when a factor is at least 1 GiB (the search costs ~0.6 s and allocates up to ~100 GiB while it runs; smaller
+        # states are close to cache-resident and gain little), None below
         self._arena = None
         if placement not in (None, "auto", "probe", "packed"):
             raise ValueError("UVd: placement must be None, 'auto', 'probe' or 'packed', got %r" % (placement,))
         if placement == "auto":
-            placement = "probe" if 4 * num_params * r >= (256 << 20) else None
+            placement = "probe" if 4 * num_params * r >= (1 << 30) else None
         if placement is not None and self._device.type == "cuda" and self._store_dtype == torch.float32 \
                 and r <= _lib.UVD_MAX_RANK and stage_backend is None:
             from . import placement as _placement
