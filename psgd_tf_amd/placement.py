@@ -177,6 +177,9 @@ class UVdArena:
         pow2 = lambda x: 1 << max(21, math.ceil(math.log2(max(int(x), 1))))
         fac_bytes = pow2(2 * _up(sz["U"]))
         thin_bytes = chunk_bytes or pow2(sum(_up(sz[k]) for k in cls.THIN))
+        if fac_bytes < (64 << 20):
+            base.info["note"] = "the state is smaller than the Infinity Cache: packed"
+            return base
         free, _total = torch.cuda.mem_get_info(device)
         if free + need < 2 * fac_bytes + 3 * thin_bytes + (2 << 30):
             base.info["note"] = "no room to look for a second region (%.0f GiB free): packed" % (free / GiB)
@@ -198,7 +201,8 @@ class UVdArena:
             return packed_again("the factor buffer could not be allocated: packed")
         # ---- 2. the small problem: factors of 1/16 of A, but not below 512 MiB each (a problem that lives in the 256-MiB Infinity Cache
         #         cannot see where its streams are in HBM) and not above the real problem
-        n = max(64, min(N, max(fac_bytes // 16, 512 << 20) // (4 * r) // 64 * 64))
+        n = max(64, min(N, max(fac_bytes // 16, 512 << 20) // (4 * r) // 64 * 64,
+                        (fac_bytes - (8 << 20)) // (4 * (2 * r + 8)) // 64 * 64))      # (all of it, thin streams included, must fit A)
         fo, fend = cls.sequential(n, r, ("U", "V"))
         ro, rend = cls.sequential(n, r, ("g", "v", "h"), fend)
         wo, wend = cls.sequential(n, r, ("d", "out", "ws"), rend)          # (inside A: the same region by construction)
