@@ -155,3 +155,13 @@ def test_uvd_class_with_a_placed_state(hip_lib):
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         psgd.UVd([init[0].clone().requires_grad_(True)], placement="best")
+
+
+@gpu
+def test_functional_example_converges(hip_lib):
+    """examples/uvd_functional_step.py: the functional API on a placed state; the preconditioner learns the inverse curvatures of a
+    quadratic whose curvatures span a factor of 100 and the loss falls by more than 1e3 in 200 steps"""
+    from examples.uvd_functional_step import run
+    losses, arena = run(N=300_000, r=10, steps=200, mode="packed")
+    assert all(np.isfinite(losses)) and losses[-1] < 1e-3 * losses[0], (losses[0], losses[-1])
+    assert arena.info["layout"] == "packed"
