@@ -347,7 +347,11 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * 27 [1] the factor updates (:179) of the large update walk their tiles in 4 x 4 patches per XCD (from 32 x 32 tiles on), 0 = whole tile rows
  * 28 [1] chained f16 x 2 plane products write their planes from the epilogue at TILE scales (each 128 x 128 tile at its own maximum; the
  *    consumer's K loop shifts its accumulators when the scale changes), 0 = fp32 out + max|C| + a split launch (one scale per matrix)
- * 29 [1] large fp32 update with both inversions first: dX's planes on the side stream ahead of Ql's inversion, 0 = on the caller's stream */
+ * 29 [1] large fp32 update with both inversions first: dX's planes on the side stream ahead of Ql's inversion, 0 = on the caller's stream
+ * 30 [-1] (round 6) large fp32 update: 1 = the products of psgd.py:173 on a third stream from the fork point on (beside both inversions),
+ *      0 = behind Ql's inversion on the side stream, -1 = 1 when both factors reach 4096
+ * 31 [1] (round 6) large fp32 update on the tile-scale inverse route: the prologue is rho + ONE sweep (balanced upper tiles in fp32, both
+ *      plane forms of both factors at tile scales, the inverted 32-blocks); 0 = the round-5 prologue (two sweeps, one scale per factor) */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

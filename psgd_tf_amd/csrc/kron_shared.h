@@ -56,7 +56,9 @@ int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, v
 // the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for
 // everything already on `main`; the caller puts one chain on it and kron_join makes `main` wait for that chain.
 // Event fork/join only, so it is legal inside a stream capture of `main`.  nullptr = no side stream: stay on `main`.
-struct KronFork { hipStream_t side; hipEvent_t fork, join, mid, aux; };     // mid: a point inside the side chain the caller's stream waits for
+struct KronFork { hipStream_t side; hipEvent_t fork, join, mid, aux; hipStream_t bg; hipEvent_t bg_done; int bg_live; };     // mid: a point inside the side chain the caller's stream waits for
+// bg: a second forked stream (kron_fork_bg makes it wait for the fork point; kron_join waits for it too once it has been used)
+int kron_fork_bg(KronFork* f);                         // 0 on success: f->bg waits for the fork point, f->bg_live = 1
 KronFork* kron_fork(hipStream_t main);
 int kron_join(KronFork* f, hipStream_t main);          // 0 on success
 bool kron_overlap_chains(int M, int N);                // tuning key 9 and the shape rule

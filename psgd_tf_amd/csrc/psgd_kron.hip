@@ -776,6 +776,8 @@ struct P3Args {
   // kTeLd + m0 / 128] receive the tile's exponent (the tables of Crow / Ccol).  Null: the output's scale comes from ometa as before.
   int *te_row, *te_col;
   int neg;               // (tile-scale outputs only) the result is -(A B ...): the inverse levels' -T = -(A^-1 B)
+  int lower_zero;        // C tiles strictly below the diagonal are written as zeros, D is not read there (the factor updates when the
+                         // fused prologue left the balanced factors' lower tiles unwritten: k_kron_balance_planes)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr3_t;
@@ -1142,6 +1144,23 @@ __device__ __forceinline__ void p3_body(const P3Args& g, int by, int bx, P3Lds<F
   const int m0 = by * TM, n0 = bx * TN;
   const bool tri_skip = (g.e.epi == EPI_TRIU_MAX || g.e.sym) && (m0 >= n0 + TN);
   if (g.e.sym && tri_skip) return;      // written by the mirror tile's epilogue
+  if (g.lower_zero && m0 >= n0 + TN) {
+    if (g.e.C) {
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + w * 32 + i * 2 + (lane >> 5), col = n0 + (lane & 31) * 4;
+        if (row < g.e.M) {
+          if (col + 3 < g.e.N && !g.e.c_cs && (g.e.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.e.C) & 15) == 0)
+            *reinterpret_cast<float4*>(g.e.C + (long)row * g.e.ldc + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+          else
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.e.N) g.e.C[(long)row * g.e.ldc + (long)(col + e) * (g.e.c_cs ? g.e.c_cs : 1)] = 0.0f;
+        }
+      }
+    }
+    return;
+  }
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -2739,9 +2758,14 @@ __device__ __forceinline__ void tri_inv32_rows(const float (*Qd)[33], int lane, 
 // the longer of the two and needs nothing but rho, so it shares the launch instead of waiting behind two GEMM stages.
 // The inverted 32 x 32 diagonal blocks of the balanced factors for workgroup `bid` of the inversion part of a balance
 // launch: one block per wave, QrS's first, then QlS's (the layout of dinv the solves read).
+__device__ __forceinline__ void balance_inv_rho(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
+                                                float* dinv, float (*Qd)[32][33], int bid, float rho);
 __device__ __forceinline__ void balance_inv_body(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
                                                  float* dinv, float (*red)[4], float (*Qd)[32][33], int bid) {
-  const float rho = balance_rho(Ql, Qr, M, N, red);
+  balance_inv_rho(Ql, Qr, M, N, dinv, Qd, bid, balance_rho(Ql, Qr, M, N, red));
+}
+__device__ __forceinline__ void balance_inv_rho(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
+                                                float* dinv, float (*Qd)[32][33], int bid, float rho) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nbr = (N + 31) / 32, nbl = (M + 31) / 32;
   const int bi = bid * 4 + w;
@@ -2792,6 +2816,177 @@ __global__ __launch_bounds__(kThreads) void k_kron_balance_inv(const float* __re
     return;
   }
   balance_inv_body(Ql, Qr, M, N, dinv, red, Qd, blockIdx.x);
+}
+
+// ---- round 6: balance + factor planes in ONE pass (the tile-scale route of the large update) -------------------------------------
+// Through round 5 the prologue was two sweeps: k_kron_balance_inv wrote QlS / QrS (every one of its 1024 workgroups first reading the
+// 8192 diagonal elements for rho: more L2 sectors than its share of the matrices) and left partial maxima, k_split3_two read QlS /
+// QrS again for the planes -- 88 + 62 us at 4096^2, and both moved the zero halves below the diagonals.  A plane set only needs a
+// scale per 128 x 128 tile (tile scales), and a tile's maximum is known to the workgroup that holds the tile, so: k_kron_rho (rho's
+// partial maxima, and the zeroing of the later stages' accumulators), then one workgroup per UPPER tile -- read, balance, write the
+// fp32 tile, the tile's exponent, both plane forms.  Tiles below the diagonal are not read; of QlS / QrS only those inside the diagonal
+// 512-blocks are written (zeros: the inversion reads whole diagonal blocks), the factor updates write zeros there (P3Args::lower_zero).
+// (k_kron_rho: the 8192 diagonal elements sit 16 KiB apart, one page each -- ONE workgroup reading them all took 25 us, mostly address
+//  translation; 64 workgroups leave 2 x 64 partial maxima and every consumer wave reduces those: 25 -> ~6 us)
+constexpr int kRhoBlocks = 64;
+__global__ __launch_bounds__(kThreads) void k_kron_rho(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
+                                                       float* __restrict__ part, float* scal, float* zero, int nzero) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x;
+  if (b == 0) {
+    if (threadIdx.x < 64) scal[threadIdx.x] = 0.0f;               // accumulators of the later stages (max|grad|, ...)
+    for (int i = threadIdx.x; i < nzero; i += kThreads) zero[i] = 0.0f;
+  }
+  const int pl = (M + kRhoBlocks - 1) / kRhoBlocks, pr = (N + kRhoBlocks - 1) / kRhoBlocks;
+  float ml = -INFINITY, mr = -INFINITY;
+  for (int i = b * pl + threadIdx.x; i < min(M, (b + 1) * pl); i += kThreads) ml = nmaxf(ml, Ql[(long)i * M + i]);
+  for (int i = b * pr + threadIdx.x; i < min(N, (b + 1) * pr); i += kThreads) mr = nmaxf(mr, Qr[(long)i * N + i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ml = nmaxf(ml, __shfl_down(ml, off, 64));
+    mr = nmaxf(mr, __shfl_down(mr, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ml; red[1][threadIdx.x >> 6] = mr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[b] = nmaxf(nmaxf(red[0][0], red[0][1]), nmaxf(red[0][2], red[0][3]));
+    part[kRhoBlocks + b] = nmaxf(nmaxf(red[1][0], red[1][1]), nmaxf(red[1][2], red[1][3]));
+  }
+}
+__device__ __forceinline__ float rho_of_parts(const float* __restrict__ part) {       // every wave for itself: no LDS, no barrier
+  const int lane = threadIdx.x & 63;
+  float a = part[lane], b = part[kRhoBlocks + lane];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a = nmaxf(a, __shfl_xor(a, off, 64));
+    b = nmaxf(b, __shfl_xor(b, off, 64));
+  }
+  return sqrtf(a / b);                                             // (balance_rho's expression: the same bits)
+}
+
+struct BalSide { const float* Q; int n; float* S; __bf16* Pr; __bf16* Pc; int* te_r; int* te_c; };      // planes: [pad128(n)]^2, row / column form
+// one 128 x 128 upper tile (tr <= tc) of one factor
+__device__ __forceinline__ void balance_planes_tile(const BalSide f, bool left, float rho, int tr, int tc, float (*S)[129], float* red) {
+  const int tid = threadIdx.x, n = f.n, r0 = tr * 128, c0 = tc * 128;
+  const long np = (long)((n + 127) & ~127), ts = np * 32, ps = np * np;
+  const int rl = tid >> 5, cl = (tid & 31) * 4;                    // this lane: rows rl + 8 i, columns cl .. cl + 3
+  const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(f.Q) | reinterpret_cast<uintptr_t>(f.S)) & 15) == 0;
+  float4 v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = r0 + rl + 8 * i, col = c0 + cl;
+    if (vec && row < n && col + 3 < n) v[i] = *reinterpret_cast<const float4*>(f.Q + (long)row * n + col);
+    else {
+      const long rr = min(row, n - 1);
+      v[i].x = f.Q[rr * n + min(col, n - 1)]; v[i].y = f.Q[rr * n + min(col + 1, n - 1)];
+      v[i].z = f.Q[rr * n + min(col + 2, n - 1)]; v[i].w = f.Q[rr * n + min(col + 3, n - 1)];
+    }
+  }
+  float vmax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = r0 + rl + 8 * i, col = c0 + cl;
+    float4 q = left ? make_float4(v[i].x / rho, v[i].y / rho, v[i].z / rho, v[i].w / rho)
+                    : make_float4(rho * v[i].x, rho * v[i].y, rho * v[i].z, rho * v[i].w);
+    if (row < n) {                                                 // the fp32 tile: what was read, balanced (a diagonal tile keeps its lower part)
+      if (vec && col + 3 < n) *reinterpret_cast<float4*>(f.S + (long)row * n + col) = q;
+      else {
+        if (col < n) f.S[(long)row * n + col] = q.x;
+        if (col + 1 < n) f.S[(long)row * n + col + 1] = q.y;
+        if (col + 2 < n) f.S[(long)row * n + col + 2] = q.z;
+        if (col + 3 < n) f.S[(long)row * n + col + 3] = q.w;
+      }
+    }
+    // the planes hold the UPPER part only, zeros in the pads
+    q.x = (row < n && col < n && col >= row) ? q.x : 0.0f;
+    q.y = (row < n && col + 1 < n && col + 1 >= row) ? q.y : 0.0f;
+    q.z = (row < n && col + 2 < n && col + 2 >= row) ? q.z : 0.0f;
+    q.w = (row < n && col + 3 < n && col + 3 >= row) ? q.w : 0.0f;
+    v[i] = q;
+    vmax = amaxf(amaxf(vmax, fabsf(q.x)), amaxf(amaxf(fabsf(q.y), fabsf(q.z)), fabsf(q.w)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = vmax;
+  __syncthreads();
+  vmax = amaxf(amaxf(red[0], red[1]), amaxf(red[2], red[3]));
+  float sc = plane_scale_of_bound(vmax);
+  {
+    const int e0 = p3_exp_of_scale(sc), eq = e0 - (((e0 % kTeQuant) + kTeQuant) % kTeQuant);     // (as the products' epilogue quantises)
+    sc = ldexpf(1.0f, max(eq, -126));
+  }
+  if (tid == 0) {
+    const int ex = (__float_as_uint(vmax) == 0u) ? kTeAny : p3_exp_of_scale(sc);
+    f.te_r[tr * kTeLd + tc] = ex;
+    f.te_c[tc * kTeLd + tr] = ex;
+  }
+  // row form straight from the registers (x = row, k = column: a lane's four columns are four consecutive k)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    unsigned q0[2], q1[2];
+    split2h_pair(v[i].x * sc, v[i].y * sc, q0);
+    split2h_pair(v[i].z * sc, v[i].w * sc, q1);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      *reinterpret_cast<uint2*>(f.Pr + pl * ps + p3_index(ts, r0 + rl + 8 * i, c0 + cl)) = make_uint2(q0[pl], q1[pl]);
+  }
+  // column form (x = column, k = row) through LDS, 64 rows at a time
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float* d = &S[rl + 8 * i][cl];
+      d[0] = v[8 * h + i].x; d[1] = v[8 * h + i].y; d[2] = v[8 * h + i].z; d[3] = v[8 * h + i].w;
+    }
+    __syncthreads();
+    // 16 lanes = the 64 rows (k) of one column (x): 128 contiguous bytes per plane
+    const int g4 = (tid & 15) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = (tid >> 4) + 16 * j;
+      unsigned q0[2], q1[2];
+      split2h_pair(S[g4][col] * sc, S[g4 + 1][col] * sc, q0);
+      split2h_pair(S[g4 + 2][col] * sc, S[g4 + 3][col] * sc, q1);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        *reinterpret_cast<uint2*>(f.Pc + pl * ps + p3_index(ts, c0 + col, r0 + 64 * h + g4)) = make_uint2(q0[pl], q1[pl]);
+    }
+  }
+}
+
+// grid: [inv_blocks: the inverted 32-blocks] [tl: upper tiles of Ql] [tr: of Qr] [zl, zr: the lower tiles inside the diagonal 512-blocks]
+__global__ __launch_bounds__(kThreads) void k_kron_balance_planes(BalSide L, BalSide R, const float* __restrict__ part, float* dinv,
+                                                                  int inv_blocks, int tl, int tr, int zl) {
+  __shared__ float red[2][4];
+  __shared__ __attribute__((aligned(16))) float S[64][129];      // (pitch 129: the transposed reads of 16 rows x 4 columns spread over all banks)
+  int b = blockIdx.x;
+  const float rho = rho_of_parts(part);
+  if (b < inv_blocks) {
+    balance_inv_rho(L.Q, R.Q, L.n, R.n, dinv, reinterpret_cast<float(*)[32][33]>(&S[0][0]), b, rho);      // (4 x 32 x 33 floats fit S)
+    return;
+  }
+  b -= inv_blocks;
+  if (b < tl + tr) {
+    const bool left = b < tl;
+    const BalSide f = left ? L : R;
+    int r, c;
+    upper_tile(left ? b : b - tl, (f.n + 127) / 128, r, c);
+    balance_planes_tile(f, left, rho, r, c, S, red[0]);
+    return;
+  }
+  b -= tl + tr;
+  const bool left = b < zl;
+  const BalSide f = left ? L : R;
+  if (!left) b -= zl;
+  // lower 128-tile number (b % 6) of diagonal 512-block (b / 6): (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
+  const int blk = b / 6, t = b % 6;
+  const int tr_ = t < 1 ? 1 : t < 3 ? 2 : 3, tc_ = t < 1 ? 0 : t < 3 ? t - 1 : t - 3;
+  const int r0 = blk * 512 + tr_ * 128, c0 = blk * 512 + tc_ * 128;
+  for (int e = threadIdx.x; e < 128 * 128; e += kThreads) {
+    const int row = r0 + (e >> 7), col = c0 + (e & 127);
+    if (row < f.n && col < f.n) f.S[(long)row * f.n + col] = 0.0f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2981,7 +3176,8 @@ __global__ __launch_bounds__(kFinThreads) void k_balance_generic(const float* __
 static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 // tile-exponent tables (KronWs::te), one per transient plane buffer
-enum { kTeU0 = 0, kTeU1, kTeU2, kTeU3, kTeY0, kTeY1, kTeY2, kTeG1, kTeG2, kTeIcL, kTeIcR, kTeTpL, kTeTpR, kTeDXp, kTeX1p, kTeSlots = 16 };
+enum { kTeU0 = 0, kTeU1, kTeU2, kTeU3, kTeY0, kTeY1, kTeY2, kTeG1, kTeG2, kTeIcL, kTeIcR, kTeTpL, kTeTpR, kTeDXp, kTeX1p, kTeLr, kTeLc, kTeRr, kTeRc,
+       kTeSlots = 20 };       // (kTeLr .. kTeRc: the balanced factors' planes when the fused prologue made them, k_kron_balance_planes)
 struct KronWs {
   float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv, *Pl, *Pr;
   __bf16 *PP, *F1, *F2, *Y0, *Y1, *Y2;     // operand planes of the large apply (kron_planes): Gram, factor, its transpose; 3 transients
@@ -2997,6 +3193,7 @@ struct KronWs {
   __bf16 *IcL, *IcR, *TpL, *TpR, *DXp, *X1p;
   float *TfL, *TfR;
   int64_t total;
+  bool factor_ts = false;      // (set by the update) the factors' planes carry TILE scales (kTeLr .. kTeRc), made by k_kron_balance_planes
 };
 
 constexpr int kSkMaxTiles = 160, kSkItems = 512;         // split-K of few-tile products: at most 512 partial tiles in flight
@@ -3444,6 +3641,12 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
 // max|C| (into the planes' meta, or wherever `amax` points for an epilogue that has its own: EPI_TRIU_MAX), and a split
 // launch makes the planes.  Tuning key 16 = 0 keeps the epilogue planes with bound scales (A/B runs).
 static int g_planes_exact = 1;
+static int g_bg_front = -1;      // tuning key 30: 1 = (both inversions first) the products of :173 on a THIRD stream from the fork point on, beside both inversions,
+                                 // instead of behind Ql's on the side stream; 0 = the round-5 order; -1 (default) = 1 when both factors reach 4096.
+                                 // Round 6 (profiles/r06_kron_update_order.txt): the full-chip products delay every launch of the two inversion
+                                 // chains (they end at 580 us instead of 405), but X1 and Bt then run alone at their isolated times: 4096^2
+                                 // 2.250 -> 2.215 ms (four alternations), 6144^2 equal, 2048 x 4096 / 3072^2 +1-2 % (hence the rule).
+static inline bool kron_bg_front(int M, int N) { return g_bg_front < 0 ? (M >= 4096 && N >= 4096) : g_bg_front == 1; }
 static int g_x0_side = 1;        // tuning key 29: 1 = (both inversions first) dX's planes on the side stream ahead of Ql's inversion
 static int g_tile_scales = 1;   // tuning key 28: chained f16 x 2 products write their planes with TILE scales from the epilogue (default); 0 = fp32
                                 // out + max|C| + a split launch per chained product (the round-3/4 form, one scale per matrix)
@@ -3821,7 +4024,8 @@ static int planes_update_factors(int M, int N, const KronWs& k, hipStream_t st, 
 static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st, PlaneMeta* pm) {
   const long Mp = pad128(M), Np = pad128(N);
   auto slot = [&](int i) { return pm ? pm + i : pm; };
-  const P3Buf Lr = {k.Lr, Mp, Mp, slot(kPmL)}, Rr = {k.Rr, Np, Np, slot(kPmR)};
+  P3Buf Lr = {k.Lr, Mp, Mp, slot(kPmL)}, Rr = {k.Rr, Np, Np, slot(kPmR)};
+  if (k.factor_ts) { Lr.te = k.te + kTeLr * kTeTable; Rr.te = k.te + kTeRr * kTeTable; }
   P3Buf dGp = {k.U0, Mp, Np, slot(kPmdG)};
   P3Buf Tt = {k.U1, Np, Mp, slot(kPmUT)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
   if (pm && kron_tile_scales(M, N)) { Tt.te = k.te + kTeU1 * kTeTable; Ar.te = k.te + kTeU2 * kTeTable; Ac.te = k.te + kTeU3 * kTeTable; }
@@ -3841,7 +4045,8 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
   const long Mp = pad128(M), Np = pad128(N);
   auto slot = [&](int i) { return pm ? pm + i : pm; };
   const bool ts = pm && kron_tile_scales(M, N);
-  const P3Buf Lc = {k.Lc, Mp, Mp, slot(kPmL)}, Rc = {k.Rc, Np, Np, slot(kPmR)};
+  P3Buf Lc = {k.Lc, Mp, Mp, slot(kPmL)}, Rc = {k.Rc, Np, Np, slot(kPmR)};
+  if (k.factor_ts) { Lc.te = k.te + kTeLc * kTeTable; Rc.te = k.te + kTeRc * kTeTable; }
   P3Buf G1 = {k.G1, Mp, Mp, slot(kPmG1)}, G2 = {k.G2, Np, Np, slot(kPmG2)};
   P3Buf Br = {k.U0, Mp, Np, slot(kPmBt)};
   P3Buf Bc = {k.U1, Np, Mp, slot(kPmBt)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
@@ -3890,6 +4095,7 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
   P3Args s5 = p3_args(G2, Rc, N, N, N, KLO_M | KHI_N | pord);
   s5.e.epi = EPI_D_MINUS; s5.e.C = QrOut; s5.e.ldc = N; s5.e.D = k.QrS; s5.e.ldd = N;
   s5.e.scale_max = k.scal + 1; s5.e.step = step; s5.e.tiny = tiny;
+  s4.lower_zero = s5.lower_zero = k.factor_ts ? 1 : 0;         // (the fused prologue leaves QlS / QrS unwritten below the diagonal)
   return launch_p3_two(s4, s5, st);
 }
 
@@ -4283,6 +4489,21 @@ static int kron_balance_amax(const float* Ql, const float* Qr, int M, int N, flo
                      inv_blocks, part_l, part_r, zero, nzero);
   return (int)hipGetLastError();
 }
+// rho + (balance, fp32 copies of the upper tiles, both plane forms with tile scales, the inverted 32-blocks) -- two launches
+static int g_fused_prologue = 1;    // tuning key 31: 0 = the round-5 prologue (k_kron_balance_inv, k_split3_two: one scale per factor)
+static int kron_balance_planes(const float* Ql, const float* Qr, int M, int N, const KronWs& k, hipStream_t st, float* zero, int nzero) {
+  float* part = k.pm_part + 2 * kPmPartMax;            // (the balance launch's partial maxima on the other route: 2 x kRhoBlocks words here)
+  hipLaunchKernelGGL(k_kron_rho, dim3(kRhoBlocks), dim3(kThreads), 0, st, Ql, Qr, M, N, part, k.scal, zero, nzero);
+  const int TL = (M + 127) / 128, TR = (N + 127) / 128;
+  const int tl = TL * (TL + 1) / 2, tr = TR * (TR + 1) / 2, zl = ((M + 511) / 512) * 6, zr = ((N + 511) / 512) * 6;
+  const int inv_blocks = ((M + 31) / 32 + (N + 31) / 32 + 3) / 4;
+  const BalSide L = {Ql, M, k.QlS, k.Lr, k.Lc, k.te + kTeLr * kTeTable, k.te + kTeLc * kTeTable};
+  const BalSide R = {Qr, N, k.QrS, k.Rr, k.Rc, k.te + kTeRr * kTeTable, k.te + kTeRc * kTeTable};
+  hipLaunchKernelGGL(k_kron_balance_planes, dim3(inv_blocks + tl + tr + zl + zr), dim3(kThreads), 0, st, L, R, part, k.dinv, inv_blocks,
+                     tl, tr, zl);
+  return (int)hipGetLastError();
+}
+
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal,
                  float* dinv, void* inv_ws) {
   const long tot = (long)M * M + (long)N * N;
@@ -4342,7 +4563,9 @@ KronFork* kron_fork(hipStream_t main) {
                       hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&n.join, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&n.mid, hipEventDisableTiming) == hipSuccess &&
-                      hipEventCreateWithFlags(&n.aux, hipEventDisableTiming) == hipSuccess;
+                      hipEventCreateWithFlags(&n.aux, hipEventDisableTiming) == hipSuccess &&
+                      hipStreamCreateWithPriority(&n.bg, hipStreamNonBlocking, prio) == hipSuccess &&
+                      hipEventCreateWithFlags(&n.bg_done, hipEventDisableTiming) == hipSuccess;
       if (dev != cur) (void)hipSetDevice(cur);
       if (!ok) return nullptr;
       it = tab.emplace(std::make_pair(dev, main), n).first;
@@ -4350,7 +4573,14 @@ KronFork* kron_fork(hipStream_t main) {
     f = &it->second;
   }
   if (hipEventRecord(f->fork, main) != hipSuccess || hipStreamWaitEvent(f->side, f->fork, 0) != hipSuccess) return nullptr;
+  f->bg_live = 0;
   return f;
+}
+
+int kron_fork_bg(KronFork* f) {
+  if (!f || !f->bg || hipStreamWaitEvent(f->bg, f->fork, 0) != hipSuccess) return 1;
+  f->bg_live = 1;
+  return 0;
 }
 
 // (Round 4, measured and not kept: CU-masked streams, hipExtStreamCreateWithCUMask -- the two inversion chains on c CUs each, the
@@ -4359,6 +4589,10 @@ KronFork* kron_fork(hipStream_t main) {
 //  are blocking streams, so with the legacy default stream as the caller's they serialise against it: 5.1-5.4 ms.
 //  profiles/r04_cumask_ab.txt)
 int kron_join(KronFork* f, hipStream_t main) {
+  if (f->bg_live) {
+    f->bg_live = 0;
+    if (hipEventRecord(f->bg_done, f->bg) != hipSuccess || hipStreamWaitEvent(main, f->bg_done, 0) != hipSuccess) return 1;
+  }
   if (hipEventRecord(f->join, f->side) != hipSuccess) return 1;
   return hipStreamWaitEvent(main, f->join, 0) != hipSuccess;
 }
@@ -4397,6 +4631,8 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 27) { g_pair_order = value; return PSGD_OK; }
   if (key == 28) { g_tile_scales = value; return PSGD_OK; }
   if (key == 29) { g_x0_side = value; return PSGD_OK; }
+  if (key == 30) { g_bg_front = value; return PSGD_OK; }
+  if (key == 31) { g_fused_prologue = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -4487,18 +4723,23 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
   PlaneMeta* pm = (planes && g_planes_f16 > 1) ? k.pmeta : nullptr;        // f16 x 2 planes of the update
   // K0: balance (:166-170); zeroes k.scal (and the update's plane maxima); the same launch inverts the diagonal blocks the
   // solves of K2 start from
-  KRON_LAUNCH(kron_balance_amax(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal, k.dinv, pm ? k.pm_part + 2 * kPmPartMax : nullptr,
-                                pm ? k.pm_part + 3 * kPmPartMax : nullptr, pm ? &pm[kPmL].scale : nullptr,
-                                pm ? (kPmSlots - kPmL) * 4 : 0));
+  const bool inv_route = pm && g_trsm_inv && kron_inv_route(M, N) && M <= 8192 && N <= 8192;    // (6 levels of meta slots)
+  // (round 6) on the tile-scale route of the inverse solves the whole prologue is rho + ONE sweep (k_kron_balance_planes)
+  k.factor_ts = inv_route && g_fused_prologue && kron_tile_scales(M, N) && inv_blk(M, N) % 128 == 0;
+  if (k.factor_ts)
+    KRON_LAUNCH(kron_balance_planes(Ql, Qr, M, N, k, st, &pm[kPmL].scale, (kPmSlots - kPmL) * 4));
+  else
+    KRON_LAUNCH(kron_balance_amax(Ql, Qr, M, N, k.QlS, k.QrS, st, k.scal, k.dinv, pm ? k.pm_part + 2 * kPmPartMax : nullptr,
+                                  pm ? k.pm_part + 3 * kPmPartMax : nullptr, pm ? &pm[kPmL].scale : nullptr,
+                                  pm ? (kPmSlots - kPmL) * 4 : 0));
   float* dinv_l = k.dinv + (long)((N + 31) / 32) * 1024;
   GemmArgs s[6];
   plan_update(dG, QlOut, QrOut, M, N, step, tiny, k, s);
   // the products (:173) go to the side stream, the solves (:174) stay here; they meet at the gradient products.  The
   // factors' planes belong to the product chain unless the solves read them too (their K = 2048 group products, which
   // exist from 4096 on -- or from 2048 on with tuning key 5): then they are made before the fork.
-  const bool inv_route = pm && g_trsm_inv && kron_inv_route(M, N) && M <= 8192 && N <= 8192;    // (6 levels of meta slots)
   const bool solves_on_planes = planes && (inv_route || M > g_trsm_planes_min_n || N > g_trsm_planes_min_n);
-  if (solves_on_planes) KRON_LAUNCH(planes_update_factors(M, N, k, st, pm));
+  if (solves_on_planes && !k.factor_ts) KRON_LAUNCH(planes_update_factors(M, N, k, st, pm));
   KronFork* fk = kron_overlap_chains(M, N) ? kron_fork(st) : nullptr;
   KronForkScope fork_scope(fk, st);          // joins on every exit path, early error returns included
   hipStream_t sf = fk ? fk->side : st;
@@ -4506,9 +4747,11 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
     // K2 through explicit inverses (tri_inverse): Qr's on this stream, then X1 = dX Ri; Ql's on the side stream ahead of the
     // products of :173; after the join Bt = Li' X1, whose epilogue leaves max|Bt| for the planes of the gradient products.
     const long Mp = pad128(M), Np = pad128(N);
-    InvSide L = {k.QlS, M, dinv_l, k.g1, k.TfL, P3Buf{k.Lc, Mp, Mp, pm + kPmL}, P3Buf{k.G1, Mp, Mp, pm + kPmInvL},
+    P3Buf Lc = {k.Lc, Mp, Mp, pm + kPmL}, Rc = {k.Rc, Np, Np, pm + kPmR};
+    if (k.factor_ts) { Lc.te = k.te + kTeLc * kTeTable; Rc.te = k.te + kTeRc * kTeTable; }
+    InvSide L = {k.QlS, M, dinv_l, k.g1, k.TfL, Lc, P3Buf{k.G1, Mp, Mp, pm + kPmInvL},
                  P3Buf{k.IcL, Mp, Mp, pm + kPmInvL}, P3Buf{k.TpL, Mp, Mp, nullptr}, pm + kPmTL};
-    InvSide R = {k.QrS, N, k.dinv, k.g2, k.TfR, P3Buf{k.Rc, Np, Np, pm + kPmR}, P3Buf{k.G2, Np, Np, pm + kPmInvR},
+    InvSide R = {k.QrS, N, k.dinv, k.g2, k.TfR, Rc, P3Buf{k.G2, Np, Np, pm + kPmInvR},
                  P3Buf{k.IcR, Np, Np, pm + kPmInvR}, P3Buf{k.TpR, Np, Np, nullptr}, pm + kPmTR};
     // Order: the full-chip products of :173 run beside the launch-bound lower levels of Qr's inversion, Ql's inversion beside the
     // products of X1 = dX R^-1 (with the two inversions first and the products colliding afterwards the join came 0.3 ms later).
@@ -4532,7 +4775,12 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
       bs.x1c = P3Buf{k.X1p, Np, Mp, nullptr, nullptr, 0, k.te + kTeX1p * kTeTable};
       bs.bt_fp32 = false;
       if (!inv_first) KRON_LAUNCH(blk_solves_front(bs, st, sf));
-      else {
+      else if (kron_bg_front(M, N) && fk->bg) {
+        KRON_LAUNCH(kron_fork_bg(fk));
+        KRON_LAUNCH(planes_update_front(dG, M, N, k, fk->bg, pm));
+        KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid, g_x0_side ? fk->aux : nullptr));
+        if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
+      } else {
         KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid, g_x0_side ? fk->aux : nullptr));
         KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
         if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;

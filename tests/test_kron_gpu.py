@@ -1026,6 +1026,36 @@ def test_tile_scales_do_not_overflow_behind_a_tiny_tile(psgd, tiny):
                 assert torch.isfinite(g).all() and rel_err(g.cpu().numpy(), rr) < TOL, where
 
 
+@pytest.mark.parametrize("M,N", [(2048, 2048), (2100, 2304), (2560, 2048)])
+def test_fused_prologue_on_a_poisoned_workspace(psgd, hip_lib, M, N):
+    """Round 6: on the inverse route the prologue is rho + ONE sweep (k_kron_balance_planes: balanced upper tiles in fp32, both plane forms
+    at tile scales) that neither reads nor writes the 128-tiles below the diagonals.  With every byte of the workspace set to 0xFF
+    beforehand (NaN in fp32 and in f16) the update still agrees with the fp64 oracle, its results are finite and exactly upper
+    triangular, and the round-5 prologue (tuning key 31 = 0: two sweeps, one scale per factor) gives the same factors to rounding."""
+    from psgd_tf_amd import kron
+    rng = np.random.default_rng(M * 5 + N)
+    Ql, Qr = (_tri_factor(rng, M, 0.02) * 2.5).astype(np.float32), _tri_factor(rng, N, 0.02).astype(np.float32)
+    dX, dG = rng.standard_normal((M, N)).astype(np.float32), rng.standard_normal((M, N)).astype(np.float32)
+    ref = orc.update_precond_kron(*(a.astype(np.float64) for a in (Ql, Qr, dX, dG)), 0.01)
+    dev = [_dev(a) for a in (Ql, Qr, dX, dG)]
+    outs = {}
+    try:
+        for key in (1, 0):
+            assert hip_lib.psgd_kron_set_tuning(31, key) == 0
+            kron._kron_workspace(dev[0].device, M, N).fill_(0xFF)
+            got = psgd.update_precond_kron(*dev, 0.01)
+            torch.cuda.synchronize()
+            for g, r in zip(got, ref):
+                q = g.cpu().numpy()
+                assert np.isfinite(q).all() and np.array_equal(q, np.triu(q)), key
+                assert rel_err(q, r) < TOL, key
+            outs[key] = [g.cpu().numpy() for g in got]
+    finally:
+        hip_lib.psgd_kron_set_tuning(31, 1)
+    for a, b in zip(outs[1], outs[0]):
+        assert rel_err(a, b.astype(np.float64)) < 2e-6
+
+
 def test_large_update_propagates_nan_through_tile_scales(psgd):
     """A NaN in the data reaches both new factors on the large path too (a tile that holds one gets scale 1; the values carry it)."""
     M, N = 2048, 2176

@@ -1,10 +1,11 @@
 """One shape's Kron update in a loop, for `rocprofv3 --kernel-trace --stats`:
     python tools/kron_update_trace.py M N key12 [reps] [bf16]
 """
+import os
 import sys
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import preconditioned_stochastic_gradient_descent as psgd  # noqa: E402
 from psgd_tf_amd import _lib  # noqa: E402
 from tools.kron_bf16_update_timing import tri  # noqa: E402
