@@ -351,7 +351,9 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * 30 [-1] (round 6) large fp32 update: 1 = the products of psgd.py:173 on a third stream from the fork point on (beside both inversions),
  *      0 = behind Ql's inversion on the side stream, -1 = 1 when both factors reach 4096
  * 31 [1] (round 6) large fp32 update on the tile-scale inverse route: the prologue is rho + ONE sweep (balanced upper tiles in fp32, both
- *      plane forms of both factors at tile scales, the inverted 32-blocks); 0 = the round-5 prologue (two sweeps, one scale per factor) */
+ *      plane forms of both factors at tile scales, the inverted 32-blocks) and dX's / dG's planes are one sweep each at tile scales;
+ *      0 = the round-5 prologue (two sweeps, one scale per factor; max|dX|, max|dG| launches ahead of their splits)
+ * 32 [1] (round 6, shapes below key 30's rule) dX's and dG's planes on the third stream, Ql's inversion from the fork point on */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

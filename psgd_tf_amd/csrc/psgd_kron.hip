@@ -2955,6 +2955,57 @@ __device__ __forceinline__ void balance_planes_tile(const BalSide f, bool left, 
   }
 }
 
+// Row-form planes (x = row, k = column) of a row-major fp32 matrix X [R x C] at TILE scales, one workgroup per 128 x 128 tile: the inputs
+// dX and dG of the large update in ONE pass each (they were max|X| over the matrix, then the split: two sweeps).  Pads are written as zeros.
+__global__ __launch_bounds__(kThreads) void k_split_rows_ts(const float* __restrict__ X, int R, int C, __bf16* __restrict__ P, long ts, long ps,
+                                                            int* __restrict__ te) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, r0 = blockIdx.y * 128, c0 = blockIdx.x * 128;
+  const int rl = tid >> 5, cl = (tid & 31) * 4;
+  const bool vec = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  float4 v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = r0 + rl + 8 * i, col = c0 + cl;
+    if (vec && row < R && col + 3 < C) v[i] = *reinterpret_cast<const float4*>(X + (long)row * C + col);
+    else {
+      const long rr = min(row, R - 1);
+      v[i].x = X[rr * C + min(col, C - 1)]; v[i].y = X[rr * C + min(col + 1, C - 1)];
+      v[i].z = X[rr * C + min(col + 2, C - 1)]; v[i].w = X[rr * C + min(col + 3, C - 1)];
+    }
+  }
+  float vmax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = r0 + rl + 8 * i, col = c0 + cl;
+    v[i].x = (row < R && col < C) ? v[i].x : 0.0f;
+    v[i].y = (row < R && col + 1 < C) ? v[i].y : 0.0f;
+    v[i].z = (row < R && col + 2 < C) ? v[i].z : 0.0f;
+    v[i].w = (row < R && col + 3 < C) ? v[i].w : 0.0f;
+    vmax = amaxf(amaxf(vmax, fabsf(v[i].x)), amaxf(amaxf(fabsf(v[i].y), fabsf(v[i].z)), fabsf(v[i].w)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmax = amaxf(vmax, __shfl_down(vmax, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = vmax;
+  __syncthreads();
+  vmax = amaxf(amaxf(red[0], red[1]), amaxf(red[2], red[3]));
+  float sc = plane_scale_of_bound(vmax);
+  {
+    const int e0 = p3_exp_of_scale(sc), eq = e0 - (((e0 % kTeQuant) + kTeQuant) % kTeQuant);
+    sc = ldexpf(1.0f, max(eq, -126));
+  }
+  if (tid == 0) te[blockIdx.y * kTeLd + blockIdx.x] = (__float_as_uint(vmax) == 0u) ? kTeAny : p3_exp_of_scale(sc);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    unsigned q0[2], q1[2];
+    split2h_pair(v[i].x * sc, v[i].y * sc, q0);
+    split2h_pair(v[i].z * sc, v[i].w * sc, q1);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      *reinterpret_cast<uint2*>(P + pl * ps + p3_index(ts, r0 + rl + 8 * i, c0 + cl)) = make_uint2(q0[pl], q1[pl]);
+  }
+}
+
 // grid: [inv_blocks: the inverted 32-blocks] [tl: upper tiles of Ql] [tr: of Qr] [zl, zr: the lower tiles inside the diagonal 512-blocks]
 __global__ __launch_bounds__(kThreads) void k_kron_balance_planes(BalSide L, BalSide R, const float* __restrict__ part, float* dinv,
                                                                   int inv_blocks, int tl, int tr, int zl) {
@@ -3520,6 +3571,13 @@ static int launch_split3(const float* X, long rs, long cs, int R, int C, const P
 // planes of the view (out) and of its transpose (outT: rows/ld swapped) from one read
 // two row-major matrices [Ra x Ca] (row stride Ca) and [Rb x Cb], f16 x 2 row-form planes each (+ the column-form planes when oaT / obT
 // are given), in ONE launch
+// row-form planes of a contiguous row-major X [R x C] at tile scales (out.te), one launch
+static int launch_split_rows_ts(const float* X, int R, int C, const P3Buf& out, hipStream_t st) {
+  const P3 o = p3_of(out);
+  hipLaunchKernelGGL(k_split_rows_ts, dim3((unsigned)(out.ld / 128), (unsigned)(out.rows / 128)), dim3(kThreads), 0, st, X, R, C, out.p, o.ts, o.ps,
+                     out.te);
+  return (int)hipGetLastError();
+}
 static int launch_split3_two(const float* Xa, int Ra, int Ca, const P3Buf& oa, const float* Xb, int Rb, int Cb, const P3Buf& ob,
                              hipStream_t st, SplitOpt opt, const P3Buf* oaT = nullptr, const P3Buf* obT = nullptr) {
   if (!oa.meta || !ob.meta || opt.blk) return 1;
@@ -3647,6 +3705,7 @@ static int g_bg_front = -1;      // tuning key 30: 1 = (both inversions first) t
                                  // chains (they end at 580 us instead of 405), but X1 and Bt then run alone at their isolated times: 4096^2
                                  // 2.250 -> 2.215 ms (four alternations), 6144^2 equal, 2048 x 4096 / 3072^2 +1-2 % (hence the rule).
 static inline bool kron_bg_front(int M, int N) { return g_bg_front < 0 ? (M >= 4096 && N >= 4096) : g_bg_front == 1; }
+static int g_bg_planes = 1;      // tuning key 32: (shapes below key 30's rule) dX's and dG's planes on the third stream, Ql's inversion from the fork point on
 static int g_x0_side = 1;        // tuning key 29: 1 = (both inversions first) dX's planes on the side stream ahead of Ql's inversion
 static int g_tile_scales = 1;   // tuning key 28: chained f16 x 2 products write their planes with TILE scales from the epilogue (default); 0 = fp32
                                 // out + max|C| + a split launch per chained product (the round-3/4 form, one scale per matrix)
@@ -4021,7 +4080,7 @@ static int planes_update_factors(int M, int N, const KronWs& k, hipStream_t st, 
   return launch_split3_both(k.QrS, N, 1, N, N, Rr, Rc, st, SplitOpt{1, 0, 0, 0});
 }
 
-static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st, PlaneMeta* pm) {
+static int planes_update_front(const float* dG, int M, int N, const KronWs& k, hipStream_t st, PlaneMeta* pm, int phase = 3) {     // phase: 1 = dG's planes, 2 = the products
   const long Mp = pad128(M), Np = pad128(N);
   auto slot = [&](int i) { return pm ? pm + i : pm; };
   P3Buf Lr = {k.Lr, Mp, Mp, slot(kPmL)}, Rr = {k.Rr, Np, Np, slot(kPmR)};
@@ -4030,8 +4089,14 @@ static int planes_update_front(const float* dG, int M, int N, const KronWs& k, h
   P3Buf Tt = {k.U1, Np, Mp, slot(kPmUT)}, Ar = {k.U2, Mp, Np, slot(kPmUA)}, Ac = {k.U3, Np, Mp, slot(kPmUA)};
   if (pm && kron_tile_scales(M, N)) { Tt.te = k.te + kTeU1 * kTeTable; Ar.te = k.te + kTeU2 * kTeTable; Ac.te = k.te + kTeU3 * kTeTable; }
   int e;
-  if (pm && (e = launch_absmax(dG, (long)M * N, dGp, k.pm_part + kPmPartMax, st))) return e;     // (the side stream's array)
-  if ((e = launch_split3(dG, N, 1, M, N, dGp, st))) return e;
+  if (k.factor_ts) {                                            // (round 6, the tile-scale inverse route: dG's planes in one sweep)
+    dGp.te = k.te + kTeU0 * kTeTable;
+    if ((phase & 1) && (e = launch_split_rows_ts(dG, M, N, dGp, st))) return e;
+  } else if (phase & 1) {
+    if (pm && (e = launch_absmax(dG, (long)M * N, dGp, k.pm_part + kPmPartMax, st))) return e;     // (the side stream's array)
+    if ((e = launch_split3(dG, N, 1, M, N, dGp, st))) return e;
+  }
+  if (!(phase & 2)) return 0;
   P3Args s0 = p3_args(dGp, Rr, M, N, N, KLO_N);                 // T = dG QrS'  (:173); (n, k) view of QrS' = QrS
   if ((e = p3_chain(s0, k.T, nullptr, &Tt, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args s1 = p3_args(Lr, Tt, M, N, M, KLO_M);                  // A = QlS T
@@ -4267,14 +4332,20 @@ enum { kPmPieceX = kPmStrip, kPmPieceW = kPmStrip + 8, kPmPieceV = kPmStrip + 16
 // (l_ready: recorded on `side` behind L's inversion, for callers that put more work on `side` before the join)
 // (x0_ready: an event of the caller's.  Given one, dX's planes are made on `side` AHEAD of L's inversion -- which is not needed before
 //  the left solve -- so that R's inversion, the head of the critical path, starts ~75 us earlier; `main` waits for the event before X1.)
-static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hipEvent_t l_ready = nullptr, hipEvent_t x0_ready = nullptr) {
+// (x0_stream: a third stream for dX's planes instead of `side` -- L's inversion then starts at the fork point too)
+static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hipEvent_t l_ready = nullptr, hipEvent_t x0_ready = nullptr,
+                            hipStream_t x0_stream = nullptr) {
   const int M = s.M, N = s.N, h = s.h;
   int e;
   const bool x0_side = x0_ready && side != main;
-  hipStream_t sx = x0_side ? side : main;
-  if (!s.X0p.part && (e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, sx))) return e;      // (unless the caller has the maxima)
-  if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, sx))) return e;
-  if (x0_side && hipEventRecord(x0_ready, side) != hipSuccess) return 1;
+  hipStream_t sx = x0_side ? (x0_stream ? x0_stream : side) : main;
+  if (s.X0p.te) {                                               // (tile scales: one sweep)
+    if ((e = launch_split_rows_ts(s.X0, M, N, s.X0p, sx))) return e;
+  } else {
+    if (!s.X0p.part && (e = launch_absmax(s.X0, (long)M * N, s.X0p, s.part, sx))) return e;      // (unless the caller has the maxima)
+    if ((e = launch_split3(s.X0, N, 1, M, N, s.X0p, sx))) return e;
+  }
+  if (x0_side && hipEventRecord(x0_ready, sx) != hipSuccess) return 1;
   if ((e = tri_inverse_pair(s.R, main, s.L, side, h))) return e;
   if (l_ready && hipEventRecord(l_ready, side) != hipSuccess) return 1;
   if (x0_side && hipStreamWaitEvent(main, x0_ready, 0) != hipSuccess) return 1;
@@ -4633,6 +4704,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 29) { g_x0_side = value; return PSGD_OK; }
   if (key == 30) { g_bg_front = value; return PSGD_OK; }
   if (key == 31) { g_fused_prologue = value; return PSGD_OK; }
+  if (key == 32) { g_bg_planes = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -4773,13 +4845,24 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
       // whichever stream order -- U0 / U1 stay with the products of :173
       bs.pa.te = k.te + kTeY0 * kTeTable; bs.pb.te = k.te + kTeY1 * kTeTable;
       bs.x1c = P3Buf{k.X1p, Np, Mp, nullptr, nullptr, 0, k.te + kTeX1p * kTeTable};
+      if (k.factor_ts) bs.X0p.te = k.te + kTeDXp * kTeTable;
       bs.bt_fp32 = false;
       if (!inv_first) KRON_LAUNCH(blk_solves_front(bs, st, sf));
       else if (kron_bg_front(M, N) && fk->bg) {
+        // third stream: dX's planes, dG's planes, the two products; the side stream has Ql's inversion alone, from the fork point on (behind
+        // dX's planes its first launch -- 256 workgroups -- met the first product and took 449 us instead of 63: Bt then waited for it)
         KRON_LAUNCH(kron_fork_bg(fk));
+        KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid, g_x0_side ? fk->aux : nullptr, fk->bg));
         KRON_LAUNCH(planes_update_front(dG, M, N, k, fk->bg, pm));
-        KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid, g_x0_side ? fk->aux : nullptr));
         if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
+      } else if (g_bg_planes && k.factor_ts && g_x0_side && fk->bg) {
+        // the input planes (one sweep each) on the third stream; the side stream: Ql's inversion from the fork point on, then the products
+        KRON_LAUNCH(kron_fork_bg(fk));
+        KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid, fk->aux, fk->bg));
+        KRON_LAUNCH(planes_update_front(dG, M, N, k, fk->bg, pm, 1));
+        if (hipEventRecord(fk->bg_done, fk->bg) != hipSuccess || hipStreamWaitEvent(sf, fk->bg_done, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
+        KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm, 2));
+        if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;      // (Ql's inverse, for Bt)
       } else {
         KRON_LAUNCH(blk_solves_front(bs, st, sf, fk->mid, g_x0_side ? fk->aux : nullptr));
         KRON_LAUNCH(planes_update_front(dG, M, N, k, sf, pm));
