@@ -31,7 +31,7 @@ def main():
                 assert lib.psgd_kron_set_tuning(key, v) == 0
                 out = psgd.update_precond_kron(Ql, Qr, a, b, 0.01)
                 torch.cuda.synchronize()
-                if v == 0 and ref is None:
+                if ref is None:
                     ref = [o.clone() for o in out]
                 err = max(float((o - r).abs().max()) for o, r in zip(out, ref)) if not bf else float("nan")
                 t = min(timeit(lambda: psgd.update_precond_kron(Ql, Qr, a, b, 0.01), 5) for _ in range(3))
