@@ -18,6 +18,9 @@
 
 namespace psgd {
 
+#ifndef GW_ACC64_LDS
+#define GW_ACC64_LDS 0  // round 6, review item 9 (one bounded experiment): 1 = the fp64 sums of a multiplying wave live in LDS, not in 40 registers
+#endif
 #ifndef GW_DBG
 #define GW_DBG 0        // what-if builds (wrong results): 2 = no MFMA phase, 4 = no split / plane writes (loads stay), 8 = no t / w columns
 #endif
@@ -36,6 +39,8 @@ struct GwPlan {
   int owner[15];       // multiplying wave of super pair sp = gw_pair_index(NS, si, sj)
   int slot0[15];       // its first accumulator slot
   int max_load;        // accumulator slots a wave needs
+  int base[kGwMulWaves];   // first GLOBAL slot of a wave (prefix sums of the loads): GW_ACC64_LDS
+  int load[kGwMulWaves];
 };
 template <int NB>
 constexpr GwPlan gw_make_plan() {
@@ -63,6 +68,7 @@ constexpr GwPlan gw_make_plan() {
   }
   for (int k = 0; k < kGwMulWaves; ++k)
     if (load[k] > p.max_load) p.max_load = load[k];
+  for (int k = 0, b = 0; k < kGwMulWaves; ++k) { p.base[k] = b; p.load[k] = load[k]; b += load[k]; }
   return p;
 }
 template <int NB> struct GwPlanOf { static constexpr GwPlan value = gw_make_plan<NB>(); };
@@ -106,6 +112,9 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
   constexpr int NP = NB * (NB + 1) / 2;
   typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) u32x4g PL[2][3][NC * 4 + 16];     // (+ 16 units: the scratch of the t / w wave)
+#if GW_ACC64_LDS
+  __shared__ double A64[NP][4][64];                                         // [global slot][e][lane]: 2 KiB per block pair
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long G = gridDim.x;
   const long tfirst = TAIL ? tile0 : (long)blockIdx.x;       // this workgroup's first tile; TAIL: its only one
@@ -267,6 +276,29 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
   // ---- mfma role: waves 5 .. 15
   const int mw = wave - 5;
   f32x4 acc[NPW];
+#if GW_ACC64_LDS
+  int my_base = 0, my_load = 0;
+  gw_static_for<0, kGwMulWaves>([&](auto kc) {
+    if (mw == decltype(kc)::value) { my_base = GwPlanOf<NB>::value.base[decltype(kc)::value]; my_load = GwPlanOf<NB>::value.load[decltype(kc)::value]; }
+  });
+  double (*my64)[4][64] = A64 + my_base;
+#pragma unroll
+  for (int p = 0; p < NPW; ++p) {
+    acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p < my_load)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) my64[p][e][lane] = 0.0;
+  }
+  auto fold = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) {
+      if (p < my_load)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) my64[p][e][lane] += (double)acc[p][e];
+      acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+#else
   double acc64[NPW][4];
 #pragma unroll
   for (int p = 0; p < NPW; ++p) {
@@ -274,6 +306,15 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc64[p][e] = 0.0;
   }
+  auto fold = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
+      acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+#endif
   int since = 0;
   tile_loop([]() {}, [&](auto ic, long t) {
     if (t >= ntiles) return;                         // (padding iteration of the last round)
@@ -315,19 +356,11 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
       });
     });
     if (++since == 256 / kGwRows) {
-#pragma unroll
-      for (int p = 0; p < NPW; ++p) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
-        acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      fold();
       since = 0;
     }
   });
-#pragma unroll
-  for (int p = 0; p < NPW; ++p)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc64[p][e] += (double)acc[p][e];
+  fold();
   // every pair is owned by one wave: its partial goes straight out, [block][pair][e * 64 + lane]
   double* dst = part + (long)blockIdx.x * NP * 256;
   {
@@ -347,7 +380,11 @@ __global__ __launch_bounds__(kGwThreads) void k_gram_wide(const float* __restric
               constexpr int slot = s0 + (si == sj ? (a == 0 ? b : nb + (b - 1)) : a * nb + b);
               constexpr int pi = gw_pair_index(NB, 2 * si + a, 2 * sj + b);
 #pragma unroll
+#if GW_ACC64_LDS
+              for (int e = 0; e < 4; ++e) dst[pi * 256 + e * 64 + lane] = my64[slot][e][lane];
+#else
               for (int e = 0; e < 4; ++e) dst[pi * 256 + e * 64 + lane] = acc64[slot][e];
+#endif
             });
           });
         }
