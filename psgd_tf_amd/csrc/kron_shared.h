@@ -24,6 +24,14 @@ int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, flo
                  void* inv_ws = nullptr);  // the workspace of kron_inv_solves_*: the launch also does kron_inv_prepare's zeroing and leaves
                                            // the partial maxima of QlS / QrS there (then kron_inv_solves_front(..., maxima_ready = true))
 
+// (round 6) The same on the tile-scale inverse route as rho + ONE sweep: QlS / QrS (upper 128-tiles, and zeros in the lower tiles inside
+// the diagonal 512-blocks: NOTHING else below the diagonals is written -- the caller's last product must write zeros there itself), the
+// inverted 32-blocks, and the factors' column-form planes at tile scales straight into the workspace of kron_inv_solves_* (then
+// kron_inv_solves_front(..., maxima_ready = true, planes_ready = true)).  kron_fused_prologue_on: shape rule and tuning key 31.
+bool kron_fused_prologue_on(int M, int N);
+int kron_balance_planes(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* dinv, void* inv_ws,
+                        float* scal = nullptr);      // scal: 64 scratch words to zero in the first launch (or null)
+
 // Solve y Q = x for nvec vectors (vector i at stride si, element j at stride sj; Q upper triangular [n][n]);
 // dinv: scratch of ceil(n/32) * 1024 floats.  0 on success.
 // lite: the trailing products of the blocked solve keep only the three leading terms of the bf16 x 3 split (2^-16 relative)
@@ -46,11 +54,15 @@ int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_
                           hipEvent_t l_ready = nullptr,      // l_ready: recorded on `side` behind Ql's inversion (for callers that queue
                                                              // more work on `side` and let `main` wait for this point only)
                           bool maxima_ready = false,         // kron_balance(..., inv_ws) left the factors' partial maxima: no k_absmax launches
-                          int x0_parts = 0);                 // > 0: kron_inv_part(ws)[0 .. x0_parts) hold the partial maxima of |X0| already
+                          int x0_parts = 0,                  // > 0: kron_inv_part(ws)[0 .. x0_parts) hold the partial maxima of |X0| already
+                          bool planes_ready = false,         // kron_balance_planes made the factors' planes (tile scales): no split launches;
+                                                             // X0's planes are then one sweep at tile scales too (x0_parts is not used)
+                          hipEvent_t x0_ready = nullptr,     // with x0_stream: X0's planes are made THERE (the caller has put whatever makes X0
+                          hipStream_t x0_stream = nullptr);  // on that stream), x0_ready is recorded behind them and `main` waits for it before X1
 float* kron_inv_part(void* ws, int M, int N);                // the array for X0's partial maxima (kron_inv_part_max() floats)
 int kron_inv_part_max();
 bool kron_inv_first(int M, int N);                           // the order rule (tuning key 25): both inversions ahead of the products of :173
-int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main);
+int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main, bool planes_ready = false);
 
 // The update has two chains that meet only at the gradient products: the products dG QrS' -> QlS (.) (psgd.py:173) and
 // the solves (:174).  kron_fork makes `side` (a default-priority stream kept per device and caller stream; tuning key 10) wait for

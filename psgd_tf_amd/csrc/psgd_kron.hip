@@ -2830,12 +2830,14 @@ __global__ __launch_bounds__(kThreads) void k_kron_balance_inv(const float* __re
 //  translation; 64 workgroups leave 2 x 64 partial maxima and every consumer wave reduces those: 25 -> ~6 us)
 constexpr int kRhoBlocks = 64;
 __global__ __launch_bounds__(kThreads) void k_kron_rho(const float* __restrict__ Ql, const float* __restrict__ Qr, int M, int N,
-                                                       float* __restrict__ part, float* scal, float* zero, int nzero) {
+                                                       float* __restrict__ part, float* scal, float* zero, int nzero,
+                                                       unsigned* zero2, int nzero2) {      // (zero2: the gradient grid's arrival counters)
   __shared__ float red[2][4];
   const int b = blockIdx.x;
   if (b == 0) {
-    if (threadIdx.x < 64) scal[threadIdx.x] = 0.0f;               // accumulators of the later stages (max|grad|, ...)
+    if (scal && threadIdx.x < 64) scal[threadIdx.x] = 0.0f;       // accumulators of the later stages (max|grad|, ...)
     for (int i = threadIdx.x; i < nzero; i += kThreads) zero[i] = 0.0f;
+    for (int i = threadIdx.x; i < nzero2; i += kThreads) zero2[i] = 0u;
   }
   const int pl = (M + kRhoBlocks - 1) / kRhoBlocks, pr = (N + kRhoBlocks - 1) / kRhoBlocks;
   float ml = -INFINITY, mr = -INFINITY;
@@ -2917,12 +2919,12 @@ __device__ __forceinline__ void balance_planes_tile(const BalSide f, bool left, 
   }
   if (tid == 0) {
     const int ex = (__float_as_uint(vmax) == 0u) ? kTeAny : p3_exp_of_scale(sc);
-    f.te_r[tr * kTeLd + tc] = ex;
+    if (f.te_r) f.te_r[tr * kTeLd + tc] = ex;
     f.te_c[tc * kTeLd + tr] = ex;
   }
   // row form straight from the registers (x = row, k = column: a lane's four columns are four consecutive k)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 16 && f.Pr; ++i) {
     unsigned q0[2], q1[2];
     split2h_pair(v[i].x * sc, v[i].y * sc, q0);
     split2h_pair(v[i].z * sc, v[i].w * sc, q1);
@@ -3908,7 +3910,7 @@ static int g_grad_split = 1;    // tuning key 6: 0 = no K split of the gradient 
 constexpr int g_grad_order = 1;    // (frozen in round 4, was tuning key 17) tile order of the gradient grid for M = N (see k_gemm_p3_grad; tools/grad_order_ab.py:
                                 // 4096^2 update 2.95-2.98 -> 2.87-2.88 ms, 6144^2 8.5 -> 8.3; patches of 4 x 4 tiles (2) are no better:
                                 // L2 locality is not what bounds this grid; 2048 x 4096 loses 9 % with either)
-static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsigned* cnt, hipStream_t st) {
+static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsigned* cnt, hipStream_t st, bool cnt_zeroed = false) {
   static int slots = 0;
   if (!slots) {
     int dev = 0, cus = 0;
@@ -3934,7 +3936,7 @@ static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsi
     const int steps = (b.e.K + 31) / 32;               // per pair; every chunk needs at least one K step
     if (steps < kGradChunks / 2) p.nsplit = 0;
   }
-  if (p.nsplit && hipMemsetAsync(cnt, 0, (size_t)p.nsplit * 4, st) != hipSuccess) return 1;
+  if (p.nsplit && !cnt_zeroed && hipMemsetAsync(cnt, 0, (size_t)p.nsplit * 4, st) != hipSuccess) return 1;
   const dim3 grid(p.n0 + p.n1 - p.nsplit + p.nsplit * p.nchunk);
   const bool none = p3_no_early(p.n0 + p.n1 >= slots / 2);
   if (!a.fmt) hipLaunchKernelGGL((k_gemm_p3_grad<0, 2>), grid, dim3(kThreads), 0, st, p);
@@ -4136,7 +4138,7 @@ static int planes_update_back(float* QlOut, float* QrOut, int M, int N, float st
     // of every upper tile at that tile's own maximum -- no fp32 gradients, no split launch
     p3_out_row(s2, G1);
     p3_out_row(s3, G2);
-    if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st))) return e;
+    if ((e = launch_p3_grad(s2, s3, k.split_scratch, k.split_cnt, st, k.factor_ts))) return e;      // (factor_ts: the prologue zeroed the counters)
   } else if (pm && g_planes_exact) {
     // f16 x 2 (see p3_chain): the gradients in fp32 (the epilogue's triu and max|.| as on the fp32 route), then their planes
     // with the scale of that very maximum.  Tiles below the diagonal are not written and not read (K ranges of s4 / s5).
@@ -4522,11 +4524,16 @@ static BlkSolve inv_solve_problem(const InvSolveWs& k, const float* QlS, const f
 
 int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_r, const float* dinv_l, const float* X0, float* X1,
                           float* Bt, int M, int N, void* ws, hipStream_t main, hipStream_t side, hipEvent_t l_ready, bool maxima_ready,
-                          int x0_parts) {
+                          int x0_parts, bool planes_ready, hipEvent_t x0_ready, hipStream_t x0_stream) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
   int e;
   // column-form planes of the balanced factors (the B operand of T = A^-1 B, and of the blocked solves' trailing updates)
   BlkSolve s = inv_solve_problem(k, QlS, QrS, dinv_r, dinv_l, X0, X1, Bt, M, N);
+  if (planes_ready) {                                  // (kron_balance_planes: the planes are there, at tile scales)
+    s.R.Qc.te = k.te + kTeRc * kTeTable; s.L.Qc.te = k.te + kTeLc * kTeTable;
+    s.X0p.te = k.te + kTeDXp * kTeTable;
+    return blk_solves_front(s, main, side, l_ready, x0_stream ? x0_ready : nullptr, x0_stream);
+  }
   if (maxima_ready) {                                  // (the balance launch left one partial maximum per workgroup of its grid)
     s.R.Qc.part = k.part + 2 * kPmPartMax; s.L.Qc.part = k.part + kPmPartMax;
     s.R.Qc.npart = s.L.Qc.npart = balance_grid(M, N);
@@ -4544,9 +4551,10 @@ int kron_inv_solves_front(const float* QlS, const float* QrS, const float* dinv_
 float* kron_inv_part(void* ws, int M, int N) { return inv_solve_layout(static_cast<char*>(ws), M, N).part; }
 int kron_inv_part_max() { return kPmPartMax; }
 
-int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main) {
+int kron_inv_solves_back(const float* QlS, float* X1, float* Bt, int M, int N, void* ws, hipStream_t main, bool planes_ready) {
   const InvSolveWs k = inv_solve_layout(static_cast<char*>(ws), M, N);
   BlkSolve s = inv_solve_problem(k, QlS, nullptr, nullptr, nullptr, nullptr, X1, Bt, M, N);
+  if (planes_ready) { s.R.Qc.te = k.te + kTeRc * kTeTable; s.L.Qc.te = k.te + kTeLc * kTeTable; }
   return blk_solves_back(s, main);
 }
 
@@ -4562,17 +4570,24 @@ static int kron_balance_amax(const float* Ql, const float* Qr, int M, int N, flo
 }
 // rho + (balance, fp32 copies of the upper tiles, both plane forms with tile scales, the inverted 32-blocks) -- two launches
 static int g_fused_prologue = 1;    // tuning key 31: 0 = the round-5 prologue (k_kron_balance_inv, k_split3_two: one scale per factor)
-static int kron_balance_planes(const float* Ql, const float* Qr, int M, int N, const KronWs& k, hipStream_t st, float* zero, int nzero) {
-  float* part = k.pm_part + 2 * kPmPartMax;            // (the balance launch's partial maxima on the other route: 2 x kRhoBlocks words here)
-  hipLaunchKernelGGL(k_kron_rho, dim3(kRhoBlocks), dim3(kThreads), 0, st, Ql, Qr, M, N, part, k.scal, zero, nzero);
+static int launch_balance_planes(const BalSide& L, const BalSide& R, float* part, float* scal, float* dinv, float* zero, int nzero,
+                                 hipStream_t st, unsigned* zero2 = nullptr, int nzero2 = 0) {
+  const int M = L.n, N = R.n;
+  hipLaunchKernelGGL(k_kron_rho, dim3(kRhoBlocks), dim3(kThreads), 0, st, L.Q, R.Q, M, N, part, scal, zero, nzero, zero2, nzero2);
   const int TL = (M + 127) / 128, TR = (N + 127) / 128;
   const int tl = TL * (TL + 1) / 2, tr = TR * (TR + 1) / 2, zl = ((M + 511) / 512) * 6, zr = ((N + 511) / 512) * 6;
   const int inv_blocks = ((M + 31) / 32 + (N + 31) / 32 + 3) / 4;
-  const BalSide L = {Ql, M, k.QlS, k.Lr, k.Lc, k.te + kTeLr * kTeTable, k.te + kTeLc * kTeTable};
-  const BalSide R = {Qr, N, k.QrS, k.Rr, k.Rc, k.te + kTeRr * kTeTable, k.te + kTeRc * kTeTable};
-  hipLaunchKernelGGL(k_kron_balance_planes, dim3(inv_blocks + tl + tr + zl + zr), dim3(kThreads), 0, st, L, R, part, k.dinv, inv_blocks,
+  hipLaunchKernelGGL(k_kron_balance_planes, dim3(inv_blocks + tl + tr + zl + zr), dim3(kThreads), 0, st, L, R, part, dinv, inv_blocks,
                      tl, tr, zl);
   return (int)hipGetLastError();
+}
+static int kron_balance_planes(const float* Ql, const float* Qr, int M, int N, const KronWs& k, hipStream_t st, float* zero, int nzero) {
+  float* part = k.pm_part + 2 * kPmPartMax;            // (the balance launch's partial maxima on the other route: 2 x kRhoBlocks words here)
+  const BalSide L = {Ql, M, k.QlS, k.Lr, k.Lc, k.te + kTeLr * kTeTable, k.te + kTeLc * kTeTable};
+  const BalSide R = {Qr, N, k.QrS, k.Rr, k.Rc, k.te + kTeRr * kTeTable, k.te + kTeRc * kTeTable};
+  // (the arrival counters of the gradient grid's K-split tail: zeroed here instead of by a memset launch in front of that grid --
+  //  9 us of fill kernel and a launch gap on the critical path)
+  return launch_balance_planes(L, R, part, k.scal, k.dinv, zero, nzero, st, k.split_cnt, k.split_cnt ? kGradSplitMax : 0);
 }
 
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal,
@@ -4591,6 +4606,18 @@ int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, flo
     hipLaunchKernelGGL(k_kron_balance, dim3(grid), dim3(kThreads), 0, st, Ql, Qr, M, N, QlS, QrS, scal);
   }
   return (int)hipGetLastError();
+}
+
+bool kron_fused_prologue_on(int M, int N) {
+  return g_fused_prologue && kron_inv_solves_on(M, N) && kron_tile_scales(M, N) && inv_blk(M, N) % 128 == 0;
+}
+int kron_balance_planes(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* dinv, void* inv_ws,
+                        float* scal) {
+  const InvSolveWs k = inv_solve_layout(static_cast<char*>(inv_ws), M, N);
+  const BalSide L = {Ql, M, QlS, nullptr, k.Lc, nullptr, k.te + kTeLc * kTeTable};
+  const BalSide R = {Qr, N, QrS, nullptr, k.Rc, nullptr, k.te + kTeRc * kTeTable};
+  return launch_balance_planes(L, R, k.part + 2 * kPmPartMax, scal, dinv, reinterpret_cast<float*>(k.pm),
+                               kPmSlots * (int)(sizeof(PlaneMeta) / sizeof(float)), st);
 }
 
 int kron_trsm_ut(const float* Q, int n, const float* X, float* Y, int nvec, long si, long sj, float* dinv, hipStream_t st,

@@ -62,6 +62,8 @@ struct HGemmArgs {
   const float* D; long ldd;
   const float* scale_max; float step, tiny;
   int patch_order;                  // sym == 2: the tiles in 4 x 4 patches (tuning key 5)
+  int lower_zero;                   // sym == 2, HEPI_D_MINUS: zeros below the diagonal instead of copies of D (D is not read there:
+                                    // kron_balance_planes leaves it unwritten)
 };
 enum { HEPI_STORE = 0, HEPI_TRIU_MAX = 1, HEPI_D_MINUS = 2 };
 __device__ __forceinline__ bool g_pair_patch_dev(const HGemmArgs& g) { return g.patch_order != 0; }
@@ -342,7 +344,9 @@ __device__ __forceinline__ void hgemm_nt_body(const HGemmArgs& g, int bid, u32x4
 #pragma unroll 4
     for (int k = 0; k < TM * TN / 4 / kThreads; ++k) {
       const int idx = tid + kThreads * k, row = n0 + (idx >> 5), col = m0 + 4 * (idx & 31);
-      if (row < g.M && col < g.N) *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) = *reinterpret_cast<const f32x4*>(D + (long)row * g.ldd + col);
+      if (row < g.M && col < g.N)
+        *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) =
+            g.lower_zero ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(D + (long)row * g.ldd + col);
     }
   }
 }
@@ -1819,13 +1823,17 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   HUpdWs k = hupd_layout(static_cast<char*>(ws), M, N);
   const uint16_t* dGb = static_cast<const uint16_t*>(dG);
   const int ld1 = k.ld1, ld2 = k.ld2;
-  if (hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   // the zero columns between the two halves of the concatenated K axis (only when N or M is not a K-tile multiple)
   if (k.n64 != N && hipMemsetAsync(k.W1, 0, (size_t)k.w1_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   if (k.m64 != M && hipMemsetAsync(k.W2, 0, (size_t)k.w2_bytes, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   const bool inv_route = k.inv_ws && psgdk::kron_inv_solves_on(M, N);
+  const bool fused = inv_route && psgdk::kron_fused_prologue_on(M, N);
+  // (the two max words: zeroed by the fused prologue's first launch, else by a memset -- a 12-us launch of its own on this stream)
+  if (!fused && hipMemsetAsync(k.scal, 0, 256, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   // :166-170 (+ the solves' inverted diagonal blocks; on the inverse route also the zeroed plane metas and the factors' partial maxima)
-  HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, nullptr, k.dinv, inv_route ? k.inv_ws : nullptr));
+  // (round 6) on the tile-scale inverse route: rho + ONE sweep that also writes the factors' column-form planes for the solves
+  if (fused) HK(psgdk::kron_balance_planes(Ql, Qr, M, N, k.QlS, k.QrS, st, k.dinv, k.inv_ws, k.scal));
+  else HK(psgdk::kron_balance(Ql, Qr, M, N, k.QlS, k.QrS, st, nullptr, k.dinv, inv_route ? k.inv_ws : nullptr));
   // the bf16 products of :173 go to the side stream (kron_shared.h), the fp32 solves of :174 stay on the caller's
   psgdk::KronFork* fk = psgdk::kron_overlap_chains(M, N) ? psgdk::kron_fork(st) : nullptr;
   psgdk::KronForkScope fork_scope(fk, st);   // joins on every exit path, early error returns included
@@ -1855,12 +1863,16 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
   if (!inv_first) { const int rc = products(); if (rc) return rc; }
   // Bt = QlS^-T dX QrS^-1 in fp32                                                                   (:174)
   int x0_parts = 0;
+  // (round 6, fused prologue) dX's conversion and planes on the third stream: X1 needs them only behind Qr's inversion
+  const bool x0_bg = fused && fk && fk->bg && inv_first;
+  hipStream_t sx = st;
+  if (x0_bg) { HK(psgdk::kron_fork_bg(fk)); sx = fk->bg; }
   {
     const long n8 = (long)M * N / 8;
     int grid = (int)((n8 + kThreads - 1) / kThreads);
-    x0_parts = inv_route ? psgdk::kron_inv_part_max() : 0;            // (the inverse route: dX's partial maxima from this launch)
+    x0_parts = (inv_route && !fused) ? psgdk::kron_inv_part_max() : 0;   // (the inverse route: dX's partial maxima from this launch)
     if (grid > (x0_parts ? x0_parts : 4096)) grid = x0_parts ? x0_parts : 4096;
-    hipLaunchKernelGGL(k_bf16_to_f32, dim3(grid), dim3(kThreads), 0, st, static_cast<const uint16_t*>(dX), k.X0, n8,
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(grid), dim3(kThreads), 0, sx, static_cast<const uint16_t*>(dX), k.X0, n8,
                        x0_parts ? psgdk::kron_inv_part(k.inv_ws, M, N) : static_cast<float*>(nullptr));
     HK((int)hipGetLastError());
     if (x0_parts) x0_parts = grid;
@@ -1871,15 +1883,16 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     // from 4096 on -- ahead of them (kron_inv_first), the products then running beside X1 and Bt.
     const float* dinv_l = k.dinv + (long)((N + 31) / 32) * 1024;
     if (inv_first) {
-      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, fk->mid, true, x0_parts));
+      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, fk->mid, true, x0_parts, fused, x0_bg ? fk->aux : nullptr,
+                                      x0_bg ? fk->bg : nullptr));
       { const int rc = products(); if (rc) return rc; }
       if (hipStreamWaitEvent(st, fk->mid, 0) != hipSuccess) return PSGD_ERR_LAUNCH;
-      HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
+      HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st, fused));
       HK(fork_scope.join());
     } else {
-      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, nullptr, true, x0_parts));
+      HK(psgdk::kron_inv_solves_front(k.QlS, k.QrS, k.dinv, dinv_l, k.X0, k.X1, k.Bt, M, N, k.inv_ws, st, sf, nullptr, true, x0_parts, fused));
       HK(fork_scope.join());
-      HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st));
+      HK(psgdk::kron_inv_solves_back(k.QlS, k.X1, k.Bt, M, N, k.inv_ws, st, fused));
     }
   } else {
     HK(psgdk::kron_trsm_ut(k.QrS, N, k.X0, k.X1, M, (long)N, 1L, k.dinv, st, g_trsm_lite, true));
@@ -1904,6 +1917,7 @@ int psgd_kron_dd_update_bf16(const float* Ql, const float* Qr, const void* dX, c
     HGemmArgs h = {k.g2, N, k.QrTb, N, QrOut, N, 0, 0, N, N, N, KLO_M | KHI_N, 2};
     h.epi = HEPI_D_MINUS; h.D = k.QrS; h.ldd = N; h.scale_max = k.scal + 1; h.step = step; h.tiny = tiny;
     g.patch_order = h.patch_order = g_pair_patch;
+    g.lower_zero = h.lower_zero = fused ? 1 : 0;
     // (as a stream-K launch, twice: 136 + 70 and, with the final fix-up launch, 136 + 53 us against 137 -- short K ranges, ~5 pieces per
     //  workgroup, nearly every tile cut, a D tile read per epilogue)
     HK(launch_hgemm_two(g, h, st));
