@@ -2872,7 +2872,7 @@ __device__ __forceinline__ void balance_planes_tile(const BalSide f, bool left, 
   const int tid = threadIdx.x, n = f.n, r0 = tr * 128, c0 = tc * 128;
   const long np = (long)((n + 127) & ~127), ts = np * 32, ps = np * np;
   const int rl = tid >> 5, cl = (tid & 31) * 4;                    // this lane: rows rl + 8 i, columns cl .. cl + 3
-  const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(f.Q) | reinterpret_cast<uintptr_t>(f.S)) & 15) == 0;
+  const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(f.Q) | reinterpret_cast<uintptr_t>(f.S)) & 15) == 0;      // (S may be null)
   float4 v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -2890,7 +2890,7 @@ __device__ __forceinline__ void balance_planes_tile(const BalSide f, bool left, 
     const int row = r0 + rl + 8 * i, col = c0 + cl;
     float4 q = left ? make_float4(v[i].x / rho, v[i].y / rho, v[i].z / rho, v[i].w / rho)
                     : make_float4(rho * v[i].x, rho * v[i].y, rho * v[i].z, rho * v[i].w);
-    if (row < n) {                                                 // the fp32 tile: what was read, balanced (a diagonal tile keeps its lower part)
+    if (row < n && f.S) {                                          // the fp32 tile: what was read, balanced (a diagonal tile keeps its lower part)
       if (vec && col + 3 < n) *reinterpret_cast<float4*>(f.S + (long)row * n + col) = q;
       else {
         if (col < n) f.S[(long)row * n + col] = q.x;
@@ -2920,7 +2920,7 @@ __device__ __forceinline__ void balance_planes_tile(const BalSide f, bool left, 
   if (tid == 0) {
     const int ex = (__float_as_uint(vmax) == 0u) ? kTeAny : p3_exp_of_scale(sc);
     if (f.te_r) f.te_r[tr * kTeLd + tc] = ex;
-    f.te_c[tc * kTeLd + tr] = ex;
+    if (f.te_c) f.te_c[tc * kTeLd + tr] = ex;
   }
   // row form straight from the registers (x = row, k = column: a lane's four columns are four consecutive k)
 #pragma unroll
@@ -2933,6 +2933,7 @@ __device__ __forceinline__ void balance_planes_tile(const BalSide f, bool left, 
       *reinterpret_cast<uint2*>(f.Pr + pl * ps + p3_index(ts, r0 + rl + 8 * i, c0 + cl)) = make_uint2(q0[pl], q1[pl]);
   }
   // column form (x = column, k = row) through LDS, 64 rows at a time
+  if (!f.Pc) return;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     __syncthreads();
@@ -2957,11 +2958,14 @@ __device__ __forceinline__ void balance_planes_tile(const BalSide f, bool left, 
   }
 }
 
-// Row-form planes (x = row, k = column) of a row-major fp32 matrix X [R x C] at TILE scales, one workgroup per 128 x 128 tile: the inputs
-// dX and dG of the large update in ONE pass each (they were max|X| over the matrix, then the split: two sweeps).  Pads are written as zeros.
+// Planes of a row-major fp32 matrix X [R x C] at TILE scales, one workgroup per 128 x 128 tile, ONE sweep: row form (x = row, k = column)
+// and / or column form (x = column, k = row) -- the inputs dX, dG, G of the large update and apply (they were max|X| over the matrix, then
+// the split: two sweeps).  Pads are written as zeros.  Pr: [pad128(R) x pad128(C)], Pc: [pad128(C) x pad128(R)] (either may be null).
 __global__ __launch_bounds__(kThreads) void k_split_rows_ts(const float* __restrict__ X, int R, int C, __bf16* __restrict__ P, long ts, long ps,
-                                                            int* __restrict__ te) {
+                                                            int* __restrict__ te, __bf16* __restrict__ Pc, long tsc, long psc,
+                                                            int* __restrict__ tec) {
   __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) float S[64][129];
   const int tid = threadIdx.x, r0 = blockIdx.y * 128, c0 = blockIdx.x * 128;
   const int rl = tid >> 5, cl = (tid & 31) * 4;
   const bool vec = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
@@ -2996,15 +3000,41 @@ __global__ __launch_bounds__(kThreads) void k_split_rows_ts(const float* __restr
     const int e0 = p3_exp_of_scale(sc), eq = e0 - (((e0 % kTeQuant) + kTeQuant) % kTeQuant);
     sc = ldexpf(1.0f, max(eq, -126));
   }
-  if (tid == 0) te[blockIdx.y * kTeLd + blockIdx.x] = (__float_as_uint(vmax) == 0u) ? kTeAny : p3_exp_of_scale(sc);
+  if (tid == 0) {
+    const int ex = (__float_as_uint(vmax) == 0u) ? kTeAny : p3_exp_of_scale(sc);
+    if (te) te[blockIdx.y * kTeLd + blockIdx.x] = ex;
+    if (tec) tec[blockIdx.x * kTeLd + blockIdx.y] = ex;
+  }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 16 && P; ++i) {
     unsigned q0[2], q1[2];
     split2h_pair(v[i].x * sc, v[i].y * sc, q0);
     split2h_pair(v[i].z * sc, v[i].w * sc, q1);
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
       *reinterpret_cast<uint2*>(P + pl * ps + p3_index(ts, r0 + rl + 8 * i, c0 + cl)) = make_uint2(q0[pl], q1[pl]);
+  }
+  if (!Pc) return;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                                    // (as balance_planes_tile: 64 rows at a time through LDS)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float* d = &S[rl + 8 * i][cl];
+      d[0] = v[8 * h + i].x; d[1] = v[8 * h + i].y; d[2] = v[8 * h + i].z; d[3] = v[8 * h + i].w;
+    }
+    __syncthreads();
+    const int g4 = (tid & 15) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = (tid >> 4) + 16 * j;
+      unsigned q0[2], q1[2];
+      split2h_pair(S[g4][col] * sc, S[g4 + 1][col] * sc, q0);
+      split2h_pair(S[g4 + 2][col] * sc, S[g4 + 3][col] * sc, q1);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        *reinterpret_cast<uint2*>(Pc + pl * psc + p3_index(tsc, c0 + col, r0 + 64 * h + g4)) = make_uint2(q0[pl], q1[pl]);
+    }
   }
 }
 
@@ -3014,7 +3044,7 @@ __global__ __launch_bounds__(kThreads) void k_kron_balance_planes(BalSide L, Bal
   __shared__ float red[2][4];
   __shared__ __attribute__((aligned(16))) float S[64][129];      // (pitch 129: the transposed reads of 16 rows x 4 columns spread over all banks)
   int b = blockIdx.x;
-  const float rho = rho_of_parts(part);
+  const float rho = part ? rho_of_parts(part) : 1.0f;             // (no partial maxima: planes of the factors as they are -- the apply)
   if (b < inv_blocks) {
     balance_inv_rho(L.Q, R.Q, L.n, R.n, dinv, reinterpret_cast<float(*)[32][33]>(&S[0][0]), b, rho);      // (4 x 32 x 33 floats fit S)
     return;
@@ -3230,7 +3260,8 @@ static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 // tile-exponent tables (KronWs::te), one per transient plane buffer
 enum { kTeU0 = 0, kTeU1, kTeU2, kTeU3, kTeY0, kTeY1, kTeY2, kTeG1, kTeG2, kTeIcL, kTeIcR, kTeTpL, kTeTpR, kTeDXp, kTeX1p, kTeLr, kTeLc, kTeRr, kTeRc,
-       kTeSlots = 20 };       // (kTeLr .. kTeRc: the balanced factors' planes when the fused prologue made them, k_kron_balance_planes)
+       kTePP, kTeF1, kTeF2,   // (the PREPARED state of the apply: survive update calls like the planes they describe)
+       kTeSlots = 24 };       // (kTeLr .. kTeRc: the factors' planes when one sweep made them, k_kron_balance_planes)
 struct KronWs {
   float *scal, *QlS, *QrS, *T, *A, *X1, *Bt, *g1, *g2, *dinv, *Pl, *Pr;
   __bf16 *PP, *F1, *F2, *Y0, *Y1, *Y2;     // operand planes of the large apply (kron_planes): Gram, factor, its transpose; 3 transients
@@ -3577,7 +3608,23 @@ static int launch_split3(const float* X, long rs, long cs, int R, int C, const P
 static int launch_split_rows_ts(const float* X, int R, int C, const P3Buf& out, hipStream_t st) {
   const P3 o = p3_of(out);
   hipLaunchKernelGGL(k_split_rows_ts, dim3((unsigned)(out.ld / 128), (unsigned)(out.rows / 128)), dim3(kThreads), 0, st, X, R, C, out.p, o.ts, o.ps,
-                     out.te);
+                     out.te, static_cast<__bf16*>(nullptr), 0L, 0L, static_cast<int*>(nullptr));
+  return (int)hipGetLastError();
+}
+// planes of two upper-triangular matrices as they are (no balance), upper tiles only, tile scales: one launch (k_kron_balance_planes)
+static int g_fused_prologue = 1;    // tuning key 31: 0 = the round-5 prologues (max|X| launches ahead of the splits, one scale per matrix)
+static int launch_factor_planes_ts(const BalSide& L, const BalSide& R, hipStream_t st) {
+  const int TL = (L.n + 127) / 128, TR = (R.n + 127) / 128;
+  const int tl = TL * (TL + 1) / 2, tr = TR * (TR + 1) / 2;
+  hipLaunchKernelGGL(k_kron_balance_planes, dim3(tl + tr), dim3(kThreads), 0, st, L, R, static_cast<const float*>(nullptr),
+                     static_cast<float*>(nullptr), 0, tl, tr, 0);
+  return (int)hipGetLastError();
+}
+// ... the column form (x = column, k = row): outT [pad128(C) x pad128(R)]
+static int launch_split_cols_ts(const float* X, int R, int C, const P3Buf& outT, hipStream_t st) {
+  const P3 o = p3_of(outT);
+  hipLaunchKernelGGL(k_split_rows_ts, dim3((unsigned)(outT.rows / 128), (unsigned)(outT.ld / 128)), dim3(kThreads), 0, st, X, R, C,
+                     static_cast<__bf16*>(nullptr), 0L, 0L, static_cast<int*>(nullptr), outT.p, o.ts, o.ps, outT.te);
   return (int)hipGetLastError();
 }
 static int launch_split3_two(const float* Xa, int Ra, int Ca, const P3Buf& oa, const float* Xb, int Rb, int Cb, const P3Buf& ob,
@@ -3962,8 +4009,20 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
   const long nsp = pad128(ns), nbp = pad128(nb);
   PlaneMeta* pm = g_planes_f16 ? k.pmeta : nullptr;
   P3Buf QsT = {k.Y0, nsp, nsp, pm ? pm + kPmQs : pm}, F1 = {k.F1, nbp, nbp, pm ? pm + kPmF : pm};
-  const P3Buf PP = {k.PP, nsp, nsp, pm ? pm + kPmPP : pm};
+  P3Buf PP = {k.PP, nsp, nsp, pm ? pm + kPmPP : pm};
   int e;
+  if (pm && g_fused_prologue && kron_tile_scales(M, N)) {
+    // (round 6) tile scales: both factors' planes from ONE sweep over their upper tiles (no max|.| launch, nothing below the diagonals
+    // read or written), the Gram's planes straight from its epilogue (no fp32 Gram, no split launch)
+    QsT.te = k.te + kTeY0 * kTeTable; PP.te = k.te + kTePP * kTeTable;
+    const BalSide a = {Qs, ns, nullptr, nullptr, k.Y0, nullptr, QsT.te};
+    const BalSide b = {Qb, nb, nullptr, k.F1, k.F2, k.te + kTeF1 * kTeTable, k.te + kTeF2 * kTeTable};
+    if ((e = launch_factor_planes_ts(a, b, st))) return e;
+    P3Args g = p3_args(QsT, QsT, ns, ns, ns, KHI_M | KHI_N);                            // Qs'Qs, symmetric
+    g.e.sym = 1;
+    p3_out_row(g, PP); p3_out_col(g, PP);
+    return launch_p3(g, st);
+  }
   // the maxima of both factors from one launch over their upper triangles (second array of the partial maxima for the bigger factor)
   const bool both = pm && ((reinterpret_cast<uintptr_t>(Qs) | reinterpret_cast<uintptr_t>(Qb)) & 15) == 0 && ns % 4 == 0 && nb % 4 == 0;
   if (both) {
@@ -3996,12 +4055,19 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
   PlaneMeta *mPP = pm ? pm + kPmPP : pm, *mF = pm ? pm + kPmF : pm, *mG = pm ? pm + kPmG : pm, *mT = pm ? pm + kPmT : pm,
             *mA = pm ? pm + kPmA : pm;
   P3Buf Gin = {k.Y0, M < N ? Np : Mp, M < N ? Mp : Np, mG};                              // planes of G' (M < N) or G
+  const bool ts = pm && g_fused_prologue && kron_tile_scales(M, N);                      // (as planes_prepare: the prepared state has tile scales)
+  int* const te = k.te;
+  if (ts) Gin.te = te + kTeY0 * kTeTable;
   // (the maxima of the two intermediates, slots kPmT and kPmA, start from zero: consecutive PlaneMeta, 8 floats)
-  if (pm && (e = launch_absmax(G, (long)M * N, Gin, k.pm_part, st, &mT->scale, 8))) return e;
+  if (pm && !ts && (e = launch_absmax(G, (long)M * N, Gin, k.pm_part, st, &mT->scale, 8))) return e;
   if (M < N) {
-    const P3Buf PP = {k.PP, Mp, Mp, mPP}, F1 = {k.F1, Np, Np, mF}, F2 = {k.F2, Np, Np, mF};
-    const P3Buf Gt = Gin, T = {k.Y1, Mp, Np, mT}, A = {k.Y2, Mp, Np, mA};
-    if ((e = launch_split3(G, 1, N, N, M, Gt, st))) return e;                            // (n, k = m) = G[m][n]
+    P3Buf PP = {k.PP, Mp, Mp, mPP}, F1 = {k.F1, Np, Np, mF}, F2 = {k.F2, Np, Np, mF};
+    P3Buf Gt = Gin, T = {k.Y1, Mp, Np, mT}, A = {k.Y2, Mp, Np, mA};
+    if (ts) {
+      PP.te = te + kTePP * kTeTable; F1.te = te + kTeF1 * kTeTable; F2.te = te + kTeF2 * kTeTable;
+      T.te = te + kTeY1 * kTeTable; A.te = te + kTeY2 * kTeTable;
+      if ((e = launch_split_cols_ts(G, M, N, Gt, st))) return e;                         // one sweep, tile scales
+    } else if ((e = launch_split3(G, 1, N, N, M, Gt, st))) return e;                     // (n, k = m) = G[m][n]
     P3Args g0 = p3_args(PP, Gt, M, N, M, 0);                                             // (Ql'Ql) G
     if ((e = p3_chain(g0, k.T, &T, nullptr, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
     P3Args g1 = p3_args(T, F1, M, N, N, KLO_N);                                          // (.) Qr'
@@ -4010,9 +4076,13 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
     g2.e.C = out; g2.e.ldc = N;
     return launch_p3_auto(g2, k.sk_scratch, k.sk_cnt, st);
   }
-  const P3Buf PP = {k.PP, Np, Np, mPP}, F1 = {k.F1, Mp, Mp, mF}, F2 = {k.F2, Mp, Mp, mF};
-  const P3Buf Gp = Gin, Tt = {k.Y1, Np, Mp, mT}, At = {k.Y2, Np, Mp, mA};
-  if ((e = launch_split3(G, N, 1, M, N, Gp, st))) return e;
+  P3Buf PP = {k.PP, Np, Np, mPP}, F1 = {k.F1, Mp, Mp, mF}, F2 = {k.F2, Mp, Mp, mF};
+  P3Buf Gp = Gin, Tt = {k.Y1, Np, Mp, mT}, At = {k.Y2, Np, Mp, mA};
+  if (ts) {
+    PP.te = te + kTePP * kTeTable; F1.te = te + kTeF1 * kTeTable; F2.te = te + kTeF2 * kTeTable;
+    Tt.te = te + kTeY1 * kTeTable; At.te = te + kTeY2 * kTeTable;
+    if ((e = launch_split_rows_ts(G, M, N, Gp, st))) return e;
+  } else if ((e = launch_split3(G, N, 1, M, N, Gp, st))) return e;
   P3Args g0 = p3_args(Gp, PP, M, N, N, 0);                                               // G (Qr'Qr)
   if ((e = p3_chain(g0, k.T, nullptr, &Tt, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
   P3Args g1 = p3_args(F1, Tt, M, N, M, KLO_M);                                           // Ql (.)
@@ -4033,6 +4103,29 @@ static int planes_apply_direct(const float* Ql, const float* Qr, const float* G,
   const P3Buf Lc = {k.Lc, Mp, Mp, pm + kPmL}, Rc = {k.Rc, Np, Np, pm + kPmR};
   float* zero = &pm[kPmT].scale;                       // the maxima of the three intermediates (slots 5, 6, 7) start from zero
   int e;
+  if (g_fused_prologue && kron_tile_scales(M, N)) {
+    // (round 6) every plane set of the chain at tile scales: the factors (both forms of both) from one sweep over their upper tiles, G
+    // from one sweep -- no max|.| launches
+    int* const te = k.te;
+    P3Buf Lr2 = Lr, Lc2 = Lc, Rr2 = Rr, Rc2 = Rc;
+    Lr2.te = te + kTeLr * kTeTable; Lc2.te = te + kTeLc * kTeTable; Rr2.te = te + kTeRr * kTeTable; Rc2.te = te + kTeRc * kTeTable;
+    const BalSide a = {Ql, M, nullptr, k.Lr, k.Lc, Lr2.te, Lc2.te}, b = {Qr, N, nullptr, k.Rr, k.Rc, Rr2.te, Rc2.te};
+    if ((e = launch_factor_planes_ts(a, b, st))) return e;
+    P3Buf Gp = {k.U0, Mp, Np, pm + kPmG};
+    Gp.te = te + kTeU0 * kTeTable;
+    if ((e = launch_split_rows_ts(G, M, N, Gp, st))) return e;
+    P3Buf T1r = {k.U2, Mp, Np, pm + kPmT}, T2c = {k.U1, Np, Mp, pm + kPmA}, T3c = {k.U3, Np, Mp, pm + kPmA + 1};
+    T1r.te = te + kTeU2 * kTeTable; T2c.te = te + kTeU1 * kTeTable; T3c.te = te + kTeU3 * kTeTable;
+    P3Args s0 = p3_args(Gp, Rr2, M, N, N, KLO_N);                 // T1 = G Qr'
+    if ((e = p3_chain(s0, k.T, &T1r, nullptr, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
+    P3Args s1 = p3_args(T1r, Rc2, M, N, N, KHI_N);                // T2 = T1 Qr
+    if ((e = p3_chain(s1, k.A, nullptr, &T2c, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
+    P3Args s2 = p3_args(Lr2, T2c, M, N, M, KLO_M);                // T3 = Ql T2
+    if ((e = p3_chain(s2, k.T, nullptr, &T3c, nullptr, k.sk_scratch, k.sk_cnt, st))) return e;
+    P3Args s3 = p3_args(Lc2, T3c, M, N, M, KHI_M);                // out = Ql' T3
+    s3.e.C = out; s3.e.ldc = N;
+    return launch_p3_auto(s3, k.sk_scratch, k.sk_cnt, st);
+  }
   if (((reinterpret_cast<uintptr_t>(Ql) | reinterpret_cast<uintptr_t>(Qr)) & 15) == 0 && M % 4 == 0 && N % 4 == 0) {
     const int ba = M < 1024 ? M : 1024, bb = N < 1024 ? N : 1024;
     hipLaunchKernelGGL(k_absmax_tri2, dim3(ba + bb), dim3(kThreads), 0, st, Ql, M, k.pm_part, ba, Qr, N, k.pm_part + kPmPartMax, zero, 12);
@@ -4569,7 +4662,6 @@ static int kron_balance_amax(const float* Ql, const float* Qr, int M, int N, flo
   return (int)hipGetLastError();
 }
 // rho + (balance, fp32 copies of the upper tiles, both plane forms with tile scales, the inverted 32-blocks) -- two launches
-static int g_fused_prologue = 1;    // tuning key 31: 0 = the round-5 prologue (k_kron_balance_inv, k_split3_two: one scale per factor)
 static int launch_balance_planes(const BalSide& L, const BalSide& R, float* part, float* scal, float* dinv, float* zero, int nzero,
                                  hipStream_t st, unsigned* zero2 = nullptr, int nzero2 = 0) {
   const int M = L.n, N = R.n;

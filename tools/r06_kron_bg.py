@@ -23,6 +23,28 @@ def main():
         Ql = torch.triu(torch.randn(M, M, device=dev, generator=g) * 0.02, 1) + torch.eye(M, device=dev)
         Qr = torch.triu(torch.randn(N, N, device=dev, generator=g) * 0.02, 1) + torch.eye(N, device=dev)
         G, dX = torch.randn(M, N, device=dev, generator=g), torch.randn(M, N, device=dev, generator=g)
+        if os.environ.get("APPLY"):                  # the apply with NEW factors on every call: default ("reference") and "auto" routes
+            from psgd_tf_amd import kron
+            Ql2, Qr2 = Ql.clone(), Qr.clone()
+            pairs, flip = [(Ql, Qr), (Ql2, Qr2)], [0]
+
+            def cold():
+                flip[0] ^= 1
+                return psgd.precond_grad_kron(pairs[flip[0]][0], pairs[flip[0]][1], G)
+            line, ref_out = [], None
+            for v in settings:
+                assert lib.psgd_kron_set_tuning(key, v) == 0
+                kron.invalidate_factor_cache()
+                out = cold().clone()
+                if ref_out is None:
+                    ref_out = out
+                tr = min(timeit(cold, 10) for _ in range(3))
+                old = kron.set_apply_route("auto")
+                ta = min(timeit(cold, 10) for _ in range(3))
+                kron.set_apply_route(old)
+                line.append("%d: ref %.3f auto %.3f ms (%.1e)" % (v, tr, ta, float((out - ref_out).abs().max() / ref_out.abs().max())))
+            print("%dx%d apply  " % (M, N) + " | ".join(line), flush=True)
+            continue
         ref = None
         for bf in (False, True):
             a, b = (dX.to(torch.bfloat16), G.to(torch.bfloat16)) if bf else (dX, G)
