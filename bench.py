@@ -203,19 +203,26 @@ def kron_bench(dev, psgd, iters=20):
         # ten warm-up updates' worth of structure is not needed for timing: factors are dense upper-triangular
         return Ql, Qr, torch.randn(M, N, device=dev, generator=g)
 
-    def timeit(fn, n, warm_ms=30.0, min_ms=20.0):
-        # Steady-state clocks: the same call runs for >= 30 ms before the timed region, which covers >= 20 ms.  After an
+    def timeit(fn, n, warm_ms=60.0, min_ms=20.0):
+        # Steady-state clocks: the same call runs for >= 60 ms before the timed region, which covers >= 20 ms.  After an
         # idle gap (tensor set-up, a host sync) the device takes tens of ms to settle its clock: the same 0.5-ms GEMM
         # measures 0.52 or 0.65 ms depending on what ran in the milliseconds before it (profiles/r02_kron_x3_whatif.txt).
+        # (round 6: the warm-up is counted in MEASURED device time, in chunks of ~10 ms, and the call's duration is re-estimated from the
+        #  last chunk -- the first three calls after a gap run at 0.4-1 ms where the settled call takes 0.26, so a warm-up sized from them
+        #  was 10-20 ms and the timed region still sat on the clock ramp: the first leg of this function read 0.29-0.33 ms for a call that
+        #  every stand-alone run of the same protocol measures at 0.262)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        per = max(e0.elapsed_time(e1) / 3, 1e-3)
-        for _ in range(min(2000, int(warm_ms / per))):
-            fn()
+        spent, per, chunk = 0.0, 1.0, 3
+        while spent < warm_ms:
+            e0.record()
+            for _ in range(chunk):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            dt = e0.elapsed_time(e1)
+            spent += dt
+            per = max(dt / chunk, 1e-3)
+            chunk = min(2000, max(3, int(10.0 / per)))
         n = max(n, min(2000, int(min_ms / per) + 1))
         e0.record()
         for _ in range(n):
