@@ -310,12 +310,26 @@ def _direct_comm(group, device):
         return None
     key = (id(group) if group is not None else None, torch.device(device).index, dist.get_world_size(group), dist.get_rank(group))
     if key not in _direct_comms:
+        comm, why = None, None
         try:
-            _direct_comms[key] = (group, _RcclDirect(group, device))       # (the strong reference keeps id() unique)
+            comm = _RcclDirect(group, device)
         except Exception as exc:                                            # noqa: BLE001 -- any failure means "use torch.distributed"
+            why = exc
+        # Every rank must take the SAME route from here on (a rank on torch.distributed and a rank on its own communicator would wait for
+        # each other forever): one MIN over "my set-up worked" through the existing group; a single failure anywhere switches all ranks.
+        ok = torch.tensor([1.0 if comm is not None else 0.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if float(ok.item()) < 1.0:
+            if comm is not None:
+                why = "another rank's set-up failed"
+                try:
+                    comm.lib.ncclCommDestroy(comm.comm)
+                except Exception:                                            # noqa: BLE001
+                    pass
+                comm = None
             import warnings
-            warnings.warn("psgd_tf_amd.sharded: direct RCCL communicator not available (%s); exchanges use torch.distributed" % (exc,))
-            _direct_comms[key] = (group, None)
+            warnings.warn("psgd_tf_amd.sharded: direct RCCL communicator not available (%s); exchanges use torch.distributed" % (why,))
+        _direct_comms[key] = (group, comm)                                  # (the strong reference keeps id() unique)
     return _direct_comms[key][1]
 
 
