@@ -1647,10 +1647,12 @@ static HUpdWs hupd_layout(char* base, int M, int N) {
   return k;
 }
 
-static int launch_factors_cvt(const HWs& k, FactorJob j0, FactorJob j1, hipStream_t st) {
+// zero_flags: the launch also zeroes the hand-off flags of the fused pairs (the apply behind it then needs no memset launch)
+static int launch_factors_cvt(const HWs& k, FactorJob j0, FactorJob j1, hipStream_t st, bool zero_flags = false) {
   const int n = j0.n > j1.n ? j0.n : j1.n;
   dim3 grid((n + 63) / 64, (n + 63) / 64, 2);
-  hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, j0, j1, static_cast<unsigned*>(nullptr), 0);
+  hipLaunchKernelGGL(k_factors_to_bf16, grid, dim3(kThreads), 0, st, j0, j1, zero_flags ? k.flags + 4 : static_cast<unsigned*>(nullptr),
+                     zero_flags ? (int)((k.flag_bytes - 16) / 4) : 0);
   return (int)hipGetLastError();
 }
 
@@ -1723,7 +1725,11 @@ int psgd_kron_bf16_prepare_factors(const float* Ql, const float* Qr, int M, int 
   return PSGD_OK;
 }
 
+static int apply_prepared_impl(const void* G, void* out, int M, int N, void* ws, int64_t ws_bytes, void* stream, bool flags_zeroed);
 int psgd_kron_dd_apply_bf16_prepared(const void* G, void* out, int M, int N, void* ws, int64_t ws_bytes, void* stream) {
+  return apply_prepared_impl(G, out, M, N, ws, ws_bytes, stream, false);
+}
+static int apply_prepared_impl(const void* G, void* out, int M, int N, void* ws, int64_t ws_bytes, void* stream, bool flags_zeroed) {
   if (!G || !out) return PSGD_ERR_BAD_ARG;
   const int rc = bf16_apply_check(M, N, ws, ws_bytes);
   if (rc) return rc;
@@ -1732,7 +1738,8 @@ int psgd_kron_dd_apply_bf16_prepared(const void* G, void* out, int M, int N, voi
   HWs k = hws_layout(static_cast<char*>(ws), M, N);
   const uint16_t* Gb = static_cast<const uint16_t*>(G);
   // hand-off flags of the fused pairs: zero before every call (the sticky word in front of them stays)
-  if (hipMemsetAsync(k.flags + 4, 0, (size_t)k.flag_bytes - 16, st) != hipSuccess) return PSGD_ERR_LAUNCH;
+  // (flags_zeroed: the conversion launch of psgd_kron_dd_apply_bf16 did it)
+  if (!flags_zeroed && hipMemsetAsync(k.flags + 4, 0, (size_t)k.flag_bytes - 16, st) != hipSuccess) return PSGD_ERR_LAUNCH;
   if (pair_legal(M, N) && g_two_pairs) {
     // Two fused triangular pairs and no Gram:  out = Ql' (Ql ((G Qr') Qr)).  Same product as psgd.py:189-192 with the
     // Gram Qr'Qr (resp. Ql'Ql) re-associated into the chain: (G Qr') Qr costs the flops of the dense G (Qr'Qr) alone,
@@ -1792,9 +1799,12 @@ int psgd_kron_dd_apply_bf16_prepared(const void* G, void* out, int M, int N, voi
 int psgd_kron_dd_apply_bf16(const float* Ql, const float* Qr, const void* G, void* out, int M, int N, void* ws,
                             int64_t ws_bytes, void* stream) {
   if (!Ql || !Qr || !G || !out) return PSGD_ERR_BAD_ARG;
-  const int rc = psgd_kron_bf16_prepare_factors(Ql, Qr, M, N, ws, ws_bytes, stream);
+  // new factors on every call (what BASELINE's second metric times): the conversion launch also zeroes the pairs' hand-off flags
+  const int rc = bf16_apply_check(M, N, ws, ws_bytes);
   if (rc) return rc;
-  return psgd_kron_dd_apply_bf16_prepared(G, out, M, N, ws, ws_bytes, stream);
+  HWs k = hws_layout(static_cast<char*>(ws), M, N);
+  HK(launch_factors_cvt(k, FactorJob{Qr, k.Qr, k.QrT, N}, FactorJob{Ql, k.Ql, k.QlT, M}, static_cast<hipStream_t>(stream), true));
+  return apply_prepared_impl(G, out, M, N, ws, ws_bytes, stream, true);
 }
 
 int64_t psgd_kron_dd_update_workspace_bytes_bf16(int M, int N) {

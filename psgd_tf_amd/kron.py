@@ -576,11 +576,13 @@ def _precond_grad_dense_dense_bf16(Ql, Qr, Grad):
     # these are not the very tensor objects (same storage, same version counter) the copies were made from.
     tag = _bf16_prepared.get(key)
     if not (tag is not None and tag.matches((Ql, Qr)) and _cache_usable()):
-        _lib.check(lib.psgd_kron_bf16_prepare_factors(Ql.data_ptr(), Qr.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st),
-                   "psgd_kron_bf16_prepare_factors")
+        # new factors: ONE call converts them and applies (the conversion launch zeroes the pairs' hand-off flags: no memset launch)
+        rc = lib.psgd_kron_dd_apply_bf16(Ql.data_ptr(), Qr.data_ptr(), Grad.data_ptr(), out.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "psgd_kron_dd_apply_bf16")
         _bf16_prepared[key] = _FactorTag((Ql, Qr))
-    rc = lib.psgd_kron_dd_apply_bf16_prepared(Grad.data_ptr(), out.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st)
-    _lib.check(rc, "psgd_kron_dd_apply_bf16_prepared")
+    else:
+        rc = lib.psgd_kron_dd_apply_bf16_prepared(Grad.data_ptr(), out.data_ptr(), M, N, ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "psgd_kron_dd_apply_bf16_prepared")
     if not _handoff_fallback[0]:
         _watch_handoffs(key, ws, M, N, Grad.device)
     return out
