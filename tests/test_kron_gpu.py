@@ -746,7 +746,7 @@ def test_bf16_update_rejects_mixed_dtypes(psgd):
                                  torch.ones(8, 16, device="cuda"), torch.ones(8, 16, device="cuda"))
 
 
-@pytest.mark.parametrize("M,N", [(257, 120), (85, 10), (16, 40), (640, 1024), (1100, 1030), (2049, 1024)])
+@pytest.mark.parametrize("M,N", [(257, 120), (85, 10), (16, 40), (640, 1024), (1100, 1030), (2049, 1024), (2304, 2048)])
 def test_prepared_grams_follow_the_factors(psgd, hip_lib, M, N):
     """fp32 apply: the Grams of the factors are kept in the workspace and recomputed only when the factors change (same
     rules as the bf16 copies below); single and batched calls; small (both Grams), large (reference-order Gram) and
