@@ -46,8 +46,9 @@ class _Poison:
         from psgd_tf_amd import preconditioned_stochastic_gradient_descent as core
         for cache in (kron._kron_ws, kron._kron_ws_bf16, kron._batch_ws, kron._sparse_ws, core._ws_cache):
             cache._d.clear()
+        from psgd_tf_amd import sharded
         for d in (uvd_wide._gram_scratch, uvd_wide._update_scratch, uvd_wide._wide_scratch, kron._prepared, kron._apply_slots,
-                  kron._padded_factors, kron._handoff_watch):
+                  kron._padded_factors, kron._handoff_watch, sharded._backends, sharded._splu_backends):
             d.clear()
         kron.invalidate_factor_cache()
         self.made = 0
@@ -168,3 +169,35 @@ def test_sparse_lu(psgd, poisoned, N, r):
     L12, l3, U12, u3, dx, dg = q["L12"], q["l3"], q["U12"], q["u3"], q["dx"], q["dg"]
     _twice(lambda: psgd.precond_grad_splu(L12, l3, U12, u3, [dg]), poisoned, expect_ws=False)
     _twice(lambda: psgd.update_precond_splu(L12, l3, U12, u3, [dx], [dg], 0.01), poisoned, expect_ws=False)
+
+
+@pytest.fixture(scope="module")
+def pg():
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29546")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,r", [(1_000_000, 10), (300_000, 40)])
+def test_sharded_stages_on_a_one_rank_group(psgd, poisoned, pg, N, r):
+    """the row-sharded driver (stage entry points + exchanges on the library's own RCCL communicator): its stage workspaces and gather
+    buffers start poisoned too"""
+    from psgd_tf_amd import sharded
+    g = torch.Generator(device="cuda").manual_seed(N + r)
+    scale = (1.0 / (N * r)) ** 0.5
+    U0, V0 = torch.randn(N, r, device="cuda", generator=g) * scale, torch.randn(N, r, device="cuda", generator=g) * scale
+    d0 = torch.ones(N, 1, device="cuda")
+    v, grad = torch.randn(N, 1, device="cuda", generator=g), torch.randn(N, 1, device="cuda", generator=g)
+    h = v * 1.5
+    _twice(lambda: sharded.precond_grad_UVd_math(U0, V0, d0, grad), poisoned, expect_ws=False)
+    for update_u in (True, False):
+        def fused():
+            U, V, d = U0.clone(), V0.clone(), d0.clone()
+            out = sharded.update_precond_UVd_math_and_precond_grad(U, V, d, v, h, grad, 0.01, psgd._tiny, balance=True, update_U=update_u)
+            return U, V, d, out
+        _twice(fused, poisoned, expect_ws=False)
