@@ -3310,12 +3310,20 @@ static inline bool kron_planes(int M, int N) {          // the update, and the w
   return kron_planes_apply(M, N) || ((M > N ? M : N) >= 384 && kron_t128(M, N) >= 9);
 }
 static inline int pad128(int x) { return (x + 127) & ~127; }
-// The two triangular solves of the large fp32 update through explicit inverses (tri_inverse): both factors at least 2048 -- below,
+// The two triangular solves of the large fp32 update through explicit inverses (tri_inverse): (rounds 3-5) both factors at least 2048 -- below,
 // a solve is a few strips and the inversion's chain of launches costs more than it saves (tools/trsm_inv_ab.py: 4096^2 3.35 -> 2.94
 // ms, 2944^2 1.89 -> 1.70, 2048 x 4096 1.83 -> 1.70, 6144^2 9.35 -> 8.33; at the end of the round, `mid`: 2048^2 0.895 -> 0.866,
 // 1792^2 0.789 -> 0.789, 1536^2 0.60 -> 0.71, 1024^2 0.35 -> 0.51, 2048 x 1024 0.62 -> 0.76).  A pure function of the shape (workspace).
-constexpr int kInvMinN = 2048;
-static inline bool kron_inv_route(int M, int N) { return M >= kInvMinN && N >= kInvMinN; }
+// Round 6: the LARGER factor decides -- a 1024 x 4096 layer (an MLP weight of a transformer) solved its 4096-side in eight strips with
+// seven trailing products between them, 744 of the update's 1244 us on one launch-bound chain; through the inverses (the small side's is
+// one level) 1024 x 4096 1.142 -> 0.908 ms, 4096 x 1024 1.253 -> 0.983, 1536 x 3072 1.086 -> 0.810, 1280 x 5120 1.757 -> 1.301,
+// 1024 x 8192 3.11 -> 2.35, 1024 x 2048 0.561 -> 0.526; with a smaller side below 1024 it stops paying (768 x 3072 0.790 -> 0.729 but
+// 512 x 2048 0.497 -> 0.519): the larger side from 2048, the smaller from kInvMinSmall (tools/r06_kron_shapes.py).
+constexpr int kInvMinN = 2048, kInvMinSmall = 1024;
+static inline bool kron_inv_route(int M, int N) {
+  const int lo = M < N ? M : N, hi = M < N ? N : M;
+  return lo >= kInvMinSmall && hi >= kInvMinN;
+}
 
 static KronWs kron_layout(char* base, int M, int N) {
   KronWs k;
