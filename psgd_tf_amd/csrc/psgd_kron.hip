@@ -3280,7 +3280,7 @@ struct KronWs {
   bool factor_ts = false;      // (set by the update) the factors' planes carry TILE scales (kTeLr .. kTeRc), made by k_kron_balance_planes
 };
 
-constexpr int kSkMaxTiles = 160, kSkItems = 512;         // split-K of few-tile products: at most 512 partial tiles in flight
+constexpr int kSkMaxTiles = 256, kSkItems = 512;         // split-K of few-tile products: at most 512 partial tiles in flight
 constexpr int kGradSplitMax = 256, kGradChunks = 8;      // K-split tail of the gradient grid: at most 256 tiles in 8 chunks each
 // Large applies run on pre-split operand planes (k_gemm_p3).  A pure function of the shape: the workspace layout follows it.
 // Which shapes run on operand planes (pure functions of the shape: the workspace layout follows them).  Measured
@@ -3363,7 +3363,7 @@ static KronWs kron_layout(char* base, int M, int N) {
       k.IcR = planes(Np * Np); k.TpR = planes(Np * Np); k.TfR = take(nn);
       k.DXp = planes(Mp * Np); k.X1p = planes(Mp * Np);
     }
-    if (kron_t128(M, N) <= 80) {                           // few output tiles: room for tiles x chunks <= 512 partial tiles
+    if (kron_t128(M, N) <= kSkMaxTiles) {                  // few output tiles: room for tiles x chunks <= 512 partial tiles
       k.sk_scratch = take((int64_t)kSkItems * 64 * kThreads * 4);
       k.sk_cnt = reinterpret_cast<unsigned*>(take(kSkMaxTiles * 4));
     }
@@ -3722,6 +3722,8 @@ static int launch_p3(const P3Args& g, hipStream_t st) {
 // launch_p3, or the K range of every tile dealt to several blocks when the product has few output tiles and a K worth
 // splitting (scratch, cnt: KronWs::sk_*; null = never split)
 constexpr int g_splitk = 1;        // (frozen in round 4, was tuning key 8) 0 = no split-K of few-tile products
+static thread_local bool t_p3_alone = false;      // set by the callers whose products run alone on the device (planes_apply*)
+struct P3AloneScope { bool old; P3AloneScope() : old(t_p3_alone) { t_p3_alone = true; } ~P3AloneScope() { t_p3_alone = old; } };
 static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStream_t st) {
   const int tx = (g.e.N + 127) / 128, ty = (g.e.M + 127) / 128, tiles = tx * ty, steps = (g.e.K + 31) / 32;
   // Measured (tools/kron_splitk_ab.py): the partial tiles cost 64 KiB of traffic each way per item, so the split only pays for
@@ -3739,6 +3741,13 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
   int nchunk = (!g_splitk || !scratch || g.e.A2 || g.e.sym || tiles > 80 || steps < min_steps) ? 1 : kSkItems / tiles;
   if (nchunk > 8) nchunk = 8;
   while (nchunk > 1 && steps / nchunk < min_chunk) --nchunk;
+  // Round 6: 81 .. 256 tiles with a long K -- the products of a 1024 x 4096 layer with its 4096-factor are 256 tiles of up to 128 K
+  // steps: half the block slots stay empty and the launch takes its longest tile's time (117 us).  Two chunks per tile fill the chip.
+  // Only where the product has the chip to itself (the apply: t_p3_alone): in the update the products of :173 run beside the solves' chain,
+  // and twice the workgroups there are twice the slots the other chain waits for (1024 x 4096 update 0.904 -> 0.936 ms with it, the apply
+  // 0.339 -> 0.301; 512 x 4096 apply 0.306 -> 0.235, 768 x 3072 0.263 -> 0.222, 1024 x 2048 0.226 -> 0.202).
+  static const int env_mid = getenv("PSGD_SPLITK_MID") ? atoi(getenv("PSGD_SPLITK_MID")) : 1;      // (env: A/B runs)
+  if (env_mid && t_p3_alone && scratch && !g.e.A2 && !g.e.sym && tiles > 80 && tiles <= kSkMaxTiles && steps >= 64) nchunk = 2;
   if (nchunk <= 1) return launch_p3(g, st);
   if (hipMemsetAsync(cnt, 0, (size_t)tiles * 4, st) != hipSuccess) return 1;
   if (g.fmt && p3_uses_te(g)) hipLaunchKernelGGL((k_gemm_p3_splitk_rect<1, true>), dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
@@ -4059,6 +4068,7 @@ static int planes_prepare(const float* Ql, const float* Qr, int M, int N, const 
 static int planes_apply(const float* G, float* out, int M, int N, const KronWs& k, hipStream_t st) {
   const long Mp = pad128(M), Np = pad128(N);
   int e;
+  P3AloneScope alone;
   PlaneMeta* pm = g_planes_f16 ? k.pmeta : nullptr;
   PlaneMeta *mPP = pm ? pm + kPmPP : pm, *mF = pm ? pm + kPmF : pm, *mG = pm ? pm + kPmG : pm, *mT = pm ? pm + kPmT : pm,
             *mA = pm ? pm + kPmA : pm;
@@ -4106,6 +4116,7 @@ static int planes_apply(const float* G, float* out, int M, int N, const KronWs& 
 // triangular product (4096^2: 1.01 -> 0.93 ms).  Uses the update's plane buffers; the prepared state (PP, F1, F2) is left alone.
 static int planes_apply_direct(const float* Ql, const float* Qr, const float* G, float* out, int M, int N, const KronWs& k, hipStream_t st) {
   const long Mp = pad128(M), Np = pad128(N);
+  P3AloneScope alone;
   PlaneMeta* pm = k.pmeta;
   P3Buf Lr = {k.Lr, Mp, Mp, pm + kPmL}, Rr = {k.Rr, Np, Np, pm + kPmR};
   const P3Buf Lc = {k.Lc, Mp, Mp, pm + kPmL}, Rc = {k.Rc, Np, Np, pm + kPmR};
