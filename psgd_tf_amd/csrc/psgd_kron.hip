@@ -3319,10 +3319,13 @@ static inline int pad128(int x) { return (x + 127) & ~127; }
 // one level) 1024 x 4096 1.142 -> 0.908 ms, 4096 x 1024 1.253 -> 0.983, 1536 x 3072 1.086 -> 0.810, 1280 x 5120 1.757 -> 1.301,
 // 1024 x 8192 3.11 -> 2.35, 1024 x 2048 0.561 -> 0.526; with a smaller side below 1024 it stops paying (768 x 3072 0.790 -> 0.729 but
 // 512 x 2048 0.497 -> 0.519): the larger side from 2048, the smaller from kInvMinSmall (tools/r06_kron_shapes.py).
+// The longer the larger side -- the more strips its solve would take --, the smaller the other side may be: from 2560 on a 512-side joins
+// (896 x 3584 1.037 -> 0.833, 768 x 4096 1.145 -> 0.898, 512 x 4096 1.035 -> 0.881, 512 x 8192 2.63 -> 2.02, 768 x 3072 0.841 -> 0.738;
+// 640 x 2560 and 512 x 3072 -1..-2 %), from 4096 on a 256-side (256 x 4096 0.983 -> 0.850, 384 x 4096 1.003 -> 0.870).
 constexpr int kInvMinN = 2048, kInvMinSmall = 1024;
 static inline bool kron_inv_route(int M, int N) {
   const int lo = M < N ? M : N, hi = M < N ? N : M;
-  return lo >= kInvMinSmall && hi >= kInvMinN;
+  return (lo >= kInvMinSmall && hi >= kInvMinN) || (lo >= 512 && hi >= 2560) || (lo >= 256 && hi >= 4096);
 }
 
 static KronWs kron_layout(char* base, int M, int N) {

@@ -95,7 +95,7 @@ def test_kron_fp32_apply(psgd, poisoned, M, N):
     _twice(lambda: psgd.precond_grad_kron(Ql, Qr, G), poisoned)
 
 
-@pytest.mark.parametrize("M,N", KRON_SHAPES + [(2304, 2048), (3072, 2560), (4096, 2048), (1024, 4096), (4096, 1024), (1152, 2048)])
+@pytest.mark.parametrize("M,N", KRON_SHAPES + [(2304, 2048), (3072, 2560), (4096, 2048), (1024, 4096), (4096, 1024), (1152, 2048), (512, 4096), (4096, 256), (640, 2560), (384, 4100)])
 def test_kron_fp32_update(psgd, poisoned, M, N):
     rng = np.random.default_rng(M + 11 * N)
     Ql, Qr, dX, dG = _tri(rng, M, scale=1.5), _tri(rng, N), _randn(rng, M, N), _randn(rng, M, N, scale=2.0)
