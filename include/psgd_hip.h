@@ -353,7 +353,9 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  * 31 [1] (round 6) large fp32 update on the tile-scale inverse route: the prologue is rho + ONE sweep (balanced upper tiles in fp32, both
  *      plane forms of both factors at tile scales, the inverted 32-blocks) and dX's / dG's planes are one sweep each at tile scales;
  *      0 = the round-5 prologue (two sweeps, one scale per factor; max|dX|, max|dG| launches ahead of their splits)
- * 32 [1] (round 6, shapes below key 30's rule) dX's and dG's planes on the third stream, Ql's inversion from the fork point on */
+ * 32 [1] (round 6, shapes below key 30's rule) dX's and dG's planes on the third stream, Ql's inversion from the fork point on
+ * 33 [1] (round 6) M != N: every tile of the smaller factor's gradient is split along its K (the longer side) into chunks as long as the
+ *      other gradient's tiles; 0 = whole tiles */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

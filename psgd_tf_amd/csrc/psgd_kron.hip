@@ -3352,8 +3352,10 @@ static KronWs kron_layout(char* base, int M, int N) {
     k.Lr = planes(Mp * Mp); k.Lc = planes(Mp * Mp); k.G1 = planes(Mp * Mp);
     k.Rr = planes(Np * Np); k.Rc = planes(Np * Np); k.G2 = planes(Np * Np);
     k.U0 = planes(Mp * Np); k.U1 = planes(Mp * Np); k.U2 = planes(Mp * Np); k.U3 = planes(Mp * Np);
-    if (M == N) {                                          // (the K-split tail applies to M = N only; never more tiles than exist)
-      const int64_t T1 = Np / 128, nsp = T1 * (T1 + 1) / 2 < kGradSplitMax ? T1 * (T1 + 1) / 2 : kGradSplitMax;
+    {
+      // M = N: the K-split tail of the gradient grid; M != N (round 6): EVERY tile of the smaller gradient is split -- its K is the longer
+      // side (launch_p3_grad).  Never more tiles than the smaller triangle has.
+      const int64_t T1 = small / 128, nsp = T1 * (T1 + 1) / 2 < kGradSplitMax ? T1 * (T1 + 1) / 2 : kGradSplitMax;
       k.split_scratch = take(nsp * kGradChunks * 64 * kThreads * 4);
       k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
     }
@@ -3970,6 +3972,7 @@ static int launch_p3_two(const P3Args& a, const P3Args& b, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+static int g_grad_rect = 1;     // tuning key 33: M != N, every tile of the smaller gradient split along its (long) K; 0 = whole tiles (rounds 1-5)
 static int g_grad_split = 1;    // tuning key 6: 0 = no K split of the gradient grid's tail.  (While the split's hand-off was a __threadfence() per
                                 // block -- a release of the whole L2 -- it cost more than it saved on the f16 x 2 planes and was off for a
                                 // while: profiles/r03_grad_grid_isolated.txt.  With the write-through hand-off: 4096^2 0.762 -> 0.665 ms,
@@ -3985,18 +3988,32 @@ static int launch_p3_grad(const P3Args& a, const P3Args& b, float* scratch, unsi
     slots = 2 * cus;                                   // two resident blocks per CU
   }
   P3Grad p;
-  p.g[0] = a; p.g[1] = b;
-  p.T0 = (a.e.M + 127) / 128; p.T1 = (b.e.M + 127) / 128;
+  // M != N (round 6): the gradient of the SMALLER factor has few tiles with the longer side as its K -- a 1024 x 4096 layer: 36 tiles of 2 x 128
+  // K steps beside 528 tiles of 2 x 32, and the launch took the long tiles' 246 us where the work is ~95 us of the chip.  That product goes
+  // second and ALL its tiles are split into K chunks as long as the other product's tiles (the chunk count = the ratio of the sides, even, <= 8).
+  const bool rect_split = g_grad_split && g_grad_rect && scratch && a.e.K != b.e.K;
+  const P3Args& lng = a.e.K > b.e.K ? a : b;          // (the longer K: the smaller output)
+  const P3Args& sht = a.e.K > b.e.K ? b : a;
+  const int Tl = (lng.e.M + 127) / 128, nl = Tl * (Tl + 1) / 2;
+  const int ratio = (lng.e.K + sht.e.K / 2) / sht.e.K;
+  const bool rect = rect_split && ratio >= 2 && nl <= kGradSplitMax;
+  if (rect) { p.g[0] = sht; p.g[1] = lng; } else { p.g[0] = a; p.g[1] = b; }
+  p.T0 = (p.g[0].e.M + 127) / 128; p.T1 = (p.g[1].e.M + 127) / 128;
   p.n0 = p.T0 * (p.T0 + 1) / 2; p.n1 = p.T1 * (p.T1 + 1) / 2;
   p.nchunk = kGradChunks; p.scratch = scratch; p.cnt = cnt;
   p.order = a.e.K == b.e.K ? g_grad_order : 0;       // (M != N: the two products' tiles cost differently, contiguous runs unbalance the XCDs)
   const int rem = (p.n0 + p.n1) % slots;
   p.nsplit = 0;
+  if (rect) {
+    p.nsplit = p.n1;
+    p.nchunk = ratio >= 7 ? 8 : ratio >= 5 ? 6 : ratio >= 3 ? 4 : 2;
+    if (p.nchunk > kGradChunks) p.nchunk = kGradChunks;
+  }
   // a short last round (at most an eighth of the slots): twice that many tiles become eighth-size items, which the idle
   // slots of the last full round and one short extra round absorb
   // (only when the tiles of both products cost the same, M = N: measured -0.11 ms of 1.55 at 4096^2 -- blocks of a thin last
   // round run faster than the model's, each has its SIMDs to itself -- and +0.3 ms at 3000 x 5000, where they do not)
-  if (g_grad_split && scratch && a.e.K == b.e.K && rem > 0 && rem <= slots / 8 && p.n0 + p.n1 > slots) {
+  if (!rect && g_grad_split && scratch && a.e.K == b.e.K && rem > 0 && rem <= slots / 8 && p.n0 + p.n1 > slots) {
     p.nsplit = 2 * rem;
     if (p.nsplit > p.n1) p.nsplit = p.n1;
     if (p.nsplit > kGradSplitMax) p.nsplit = kGradSplitMax;
@@ -4846,6 +4863,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 30) { g_bg_front = value; return PSGD_OK; }
   if (key == 31) { g_fused_prologue = value; return PSGD_OK; }
   if (key == 32) { g_bg_planes = value; return PSGD_OK; }
+  if (key == 33) { g_grad_rect = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
