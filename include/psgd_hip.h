@@ -355,7 +355,8 @@ int64_t psgd_kron_dd_workspace_bytes(int M, int N);
  *      0 = the round-5 prologue (two sweeps, one scale per factor; max|dX|, max|dG| launches ahead of their splits)
  * 32 [1] (round 6, shapes below key 30's rule) dX's and dG's planes on the third stream, Ql's inversion from the fork point on
  * 33 [1] (round 6) M != N: every tile of the smaller factor's gradient is split along its K (the longer side) into chunks as long as the
- *      other gradient's tiles; 0 = whole tiles */
+ *      other gradient's tiles; 0 = whole tiles
+ * 34 [1] (round 6) products of the blocked solves with at most 256 output tiles and >= 64 K steps: two workgroups per tile; 0 = one */
 int psgd_kron_set_tuning(int key, int value);
 
 /* _precond_grad_dense_dense(Ql, Qr, Grad)  psgd.py:182-192.

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -3357,7 +3358,7 @@ static KronWs kron_layout(char* base, int M, int N) {
       // side (launch_p3_grad).  Never more tiles than the smaller triangle has.
       const int64_t T1 = small / 128, nsp = T1 * (T1 + 1) / 2 < kGradSplitMax ? T1 * (T1 + 1) / 2 : kGradSplitMax;
       k.split_scratch = take(nsp * kGradChunks * 64 * kThreads * 4);
-      k.split_cnt = reinterpret_cast<unsigned*>(take(kGradSplitMax * 4));
+      k.split_cnt = reinterpret_cast<unsigned*>(take(2 * kGradSplitMax * 4));      // (second half: the solves' split products, launch_p3_solve)
     }
     k.S0 = planes(big * 2048);
     k.pmeta = reinterpret_cast<PlaneMeta*>(take(1024));      // kPmSlots x 16 B
@@ -3758,6 +3759,17 @@ static int launch_p3_auto(const P3Args& g, float* scratch, unsigned* cnt, hipStr
   if (g.fmt && p3_uses_te(g)) hipLaunchKernelGGL((k_gemm_p3_splitk_rect<1, true>), dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
   else if (g.fmt) hipLaunchKernelGGL(k_gemm_p3_splitk_rect<1>, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
   else hipLaunchKernelGGL(k_gemm_p3_splitk_rect<0>, dim3(tiles * nchunk), dim3(kThreads), 0, st, g, ty, tx, nchunk, scratch, cnt);
+  return (int)hipGetLastError();
+}
+
+// The products of the blocked solves of a layer with one long side (1024 x 4096: X1_j = W_j Ri_jj is 128 tiles of up to 64 K steps --
+// a quarter of the block slots): two workgroups per tile.  Counters: zeroed by the prologue's first launch, left at zero by every use.
+static int g_solve_split = 1;      // tuning key 34
+static int launch_p3_solve(const P3Args& g, float* scratch, int slots, unsigned* cnt, hipStream_t st) {
+  const int tx = (g.e.N + 127) / 128, ty = (g.e.M + 127) / 128, tiles = tx * ty, steps = (g.e.K + 31) / 32;
+  if (!g_solve_split || !scratch || !cnt || !g.fmt || !p3_uses_te(g) || g.e.A2 || g.e.sym || tiles > kGradSplitMax || 2 * tiles > slots || steps < 64)
+    return launch_p3(g, st);
+  hipLaunchKernelGGL((k_gemm_p3_splitk_rect<1, true>), dim3(tiles * 2), dim3(kThreads), 0, st, g, ty, tx, 2, scratch, cnt);
   return (int)hipGetLastError();
 }
 
@@ -4442,6 +4454,7 @@ struct BlkSolve {
   // tile scales (pa.te, pb.te, x1c.te, Br.te, Bc.te all set): every piece's planes come out of the epilogue of the product that makes it
   P3Buf x1c;                     // column-form planes of X1 / V: (x = n, k = m), [pad128(N) x pad128(M)]
   bool bt_fp32 = true;           // the caller reads Bt in fp32 as well
+  float* sk_scratch = nullptr; int sk_slots = 0; unsigned* sk_cnt = nullptr;      // (launch_p3_solve; null: whole tiles)
 };
 static inline bool blk_tile_scales(const BlkSolve& s) { return s.pa.te && s.pb.te && s.x1c.te && s.h % 128 == 0; }
 static P3 p3_sub(const P3Buf& b, long x0, long k0) {              // the (x >= x0, k >= k0) corner of a plane set (k0 a multiple of 32;
@@ -4497,13 +4510,13 @@ static int blk_solves_front(BlkSolve& s, hipStream_t main, hipStream_t side, hip
     Xj.ld = pad128(hj);
     if (j < nb - 1) p3_out_row(d, Xj);
     p3_out_col_at(d, s.x1c, c0, 0);
-    if ((e = launch_p3(d, main))) return e;
+    if ((e = launch_p3_solve(d, s.sk_scratch, s.sk_slots, s.sk_cnt, main))) return e;
     if (j == nb - 1) break;
     const int c1 = c0 + hj;
     P3Args t = blk_product(p3_of(Xj), p3_sub(s.R.Qc, c1, c0), M, N - c1, hj, 0, s.Bt + c1, N, (j == 0 ? s.X0 : s.Bt) + c1, N, nullptr);
     s.pb.ld = pad128(N - c1);                                         // W_{>j}: the next block column is its first h columns
     p3_out_row(t, s.pb);
-    if ((e = launch_p3(t, main))) return e;
+    if ((e = launch_p3_solve(t, s.sk_scratch, s.sk_slots, s.sk_cnt, main))) return e;
   }
   for (int j = 0; j < nb && !ts; ++j) {
     const int c0 = j * h, hj = N - c0 < h ? N - c0 : h;
@@ -4545,13 +4558,13 @@ static int blk_solves_back(BlkSolve& s, hipStream_t main) {
                              s.bt_fp32 ? s.Bt + (long)r0 * N : nullptr, N, nullptr, 0, nullptr);             // Bt_i = Li_ii' V_i
       if (s.Br.p) p3_out_row_at(d, s.Br, r0, 0);
       p3_out_col_at(d, s.Bc, 0, r0);
-      if ((e = launch_p3(d, main))) return e;
+      if ((e = launch_p3_solve(d, s.sk_scratch, s.sk_slots, s.sk_cnt, main))) return e;
       if (i == mb - 1) break;
       const int r1 = r0 + hi;
       P3Args t = blk_product(p3_sub(s.L.Qc, r1, r0), p3_sub(s.Bc, 0, r0), M - r1, N, hi, 0, s.X1 + (long)r1 * N, N,
                              s.X1 + (long)r1 * N, N, nullptr);                                                // V_{>i} -= L[i, >i]' Bt_i
       p3_out_col_at(t, s.x1c, 0, r1);
-      if ((e = launch_p3(t, main))) return e;
+      if ((e = launch_p3_solve(t, s.sk_scratch, s.sk_slots, s.sk_cnt, main))) return e;
     }
     return 0;
   }
@@ -4718,7 +4731,7 @@ static int kron_balance_planes(const float* Ql, const float* Qr, int M, int N, c
   const BalSide R = {Qr, N, k.QrS, k.Rr, k.Rc, k.te + kTeRr * kTeTable, k.te + kTeRc * kTeTable};
   // (the arrival counters of the gradient grid's K-split tail: zeroed here instead of by a memset launch in front of that grid --
   //  9 us of fill kernel and a launch gap on the critical path)
-  return launch_balance_planes(L, R, part, k.scal, k.dinv, zero, nzero, st, k.split_cnt, k.split_cnt ? kGradSplitMax : 0);
+  return launch_balance_planes(L, R, part, k.scal, k.dinv, zero, nzero, st, k.split_cnt, k.split_cnt ? 2 * kGradSplitMax : 0);
 }
 
 int kron_balance(const float* Ql, const float* Qr, int M, int N, float* QlS, float* QrS, hipStream_t st, float* scal,
@@ -4864,6 +4877,7 @@ int psgd_kron_set_tuning(int key, int value) {
   if (key == 31) { g_fused_prologue = value; return PSGD_OK; }
   if (key == 32) { g_bg_planes = value; return PSGD_OK; }
   if (key == 33) { g_grad_rect = value; return PSGD_OK; }
+  if (key == 34) { g_solve_split = value; return PSGD_OK; }
   return PSGD_ERR_BAD_ARG;
 }
 
@@ -5005,6 +5019,10 @@ int psgd_kron_dd_update_f32(const float* Ql, const float* Qr, const float* dX, c
       bs.pa.te = k.te + kTeY0 * kTeTable; bs.pb.te = k.te + kTeY1 * kTeTable;
       bs.x1c = P3Buf{k.X1p, Np, Mp, nullptr, nullptr, 0, k.te + kTeX1p * kTeTable};
       if (k.factor_ts) bs.X0p.te = k.te + kTeDXp * kTeTable;
+      if (k.factor_ts && k.split_cnt) {          // (nothing writes k.T on this route: partial tiles of the solves' split products)
+        bs.sk_scratch = k.T; bs.sk_slots = (int)std::min<int64_t>((int64_t)M * N / (64 * kThreads), 1 << 20);
+        bs.sk_cnt = k.split_cnt + kGradSplitMax;
+      }
       bs.bt_fp32 = false;
       if (!inv_first) KRON_LAUNCH(blk_solves_front(bs, st, sf));
       else if (kron_bg_front(M, N) && fk->bg) {
